@@ -1,0 +1,313 @@
+// oracle/ref_harness/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Thin extern "C" shim over the REAL reference (Grok 8.0.2 compiled by oracle/Makefile into
+// oracle/_ref/libgrokj2k_ref.so).  It lets the Python tests / bench.py's cpu_baseline leg call
+//   * the reference's stage kernels directly (mct::compress_rev/irrev, dwt53/dwt97 row+column
+//     kernels in the level loop of WaveletFwd.cpp:491-602, ojph_encode_codeblock, ojph_decode_codeblock)
+//   * the reference's whole encoder/decoder through its public API, with the call sequence of
+//     tests/test_tile_encoder.cpp:68-253 (+ HT flags), writing to a memory stream
+//   * grk_compress_with_plugin(codec, tile) with a grk_plugin_tile tree built by OUR plugin
+//     (the drop-in boundary).
+// Nothing here is product code and nothing in grok_amd/ may link it.
+#include <cstdint>
+#include <cstring>
+#include <cstdlib>
+#include <chrono>
+#include <vector>
+#include <algorithm>
+#include <cstdio>
+
+// ojph headers first: grk_includes.h poisons malloc/free (util/MemManager.h:73)
+#include "ojph_block_encoder.h"
+#include "ojph_block_decoder.h"
+#include "ojph_mem.h"
+#include "grk_includes.h"
+
+using namespace grk;
+
+static bool g_inited = false;
+static int g_verbose = 0;
+
+static void msg_quiet(const char*, void*) {}
+static void msg_err(const char* m, void*) { if (g_verbose) fprintf(stderr, "[grok] %s\n", m); }
+
+extern "C" {
+
+int ref_init(int threads, int verbose)
+{
+	g_verbose = verbose;
+	if (!g_inited) {
+		grk_initialize(nullptr, (uint32_t)threads);
+		grk_set_info_handler(msg_quiet, nullptr);
+		grk_set_warning_handler(msg_quiet, nullptr);
+		grk_set_error_handler(msg_err, nullptr);
+		g_inited = true;
+	}
+	return (int)ThreadPool::get()->num_threads();
+}
+
+// ---------------------------------------------------------------- stage kernels
+void ref_rct(int32_t* c0, int32_t* c1, int32_t* c2, uint64_t n) { mct::compress_rev(c0, c1, c2, n); }
+void ref_ict(int32_t* c0, int32_t* c1, int32_t* c2, uint64_t n) { mct::compress_irrev(c0, c1, c2, n); }
+
+} // extern "C"
+template <typename T, typename DWT>
+static void fwd_levels(T* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{
+	// resolution sizes for an origin-0 tile component: ceil(w / 2^l)
+	std::vector<uint32_t> rw(levels + 1), rh(levels + 1);
+	for (uint32_t l = 0; l <= levels; ++l) {
+		rw[l] = (uint32_t)(((uint64_t)w + (1ull << l) - 1) >> l);
+		rh[l] = (uint32_t)(((uint64_t)h + (1ull << l) - 1) >> l);
+	}
+	size_t tmpn = (size_t)std::max(w, h) * 8 + 64;
+	T* tmp = (T*)grkAlignedMalloc(tmpn * sizeof(T));
+	DWT dwt;
+	for (uint32_t l = 0; l < levels; ++l) {
+		uint32_t cw = rw[l], ch = rh[l];
+		// vertical pass, 8 columns at a time (WaveletFwd.cpp:491-507)
+		uint32_t j = 0;
+		for (; j + 8 - 1 < cw; j += 8)
+			dwt.encode_and_deinterleave_v(plane + j, tmp, ch, true, stride, 8);
+		if (j < cw)
+			dwt.encode_and_deinterleave_v(plane + j, tmp, ch, true, stride, cw - j);
+		// horizontal pass (WaveletFwd.cpp:553-561)
+		for (uint32_t r = 0; r < ch; ++r)
+			dwt.encode_and_deinterleave_h_one_row(plane + (size_t)r * stride, tmp, cw, true);
+	}
+	grkAlignedFree(tmp);
+}
+
+extern "C" {
+void ref_dwt53_fwd(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{ fwd_levels<int32_t, dwt53>(plane, w, h, stride, levels); }
+void ref_dwt97_fwd(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{ fwd_levels<float, dwt97>(plane, w, h, stride, levels); }
+
+void ref_dwt53_row(int32_t* row, uint32_t n, int even)
+{
+	std::vector<int32_t> tmp(n + 16);
+	dwt53 d; d.encode_and_deinterleave_h_one_row(row, tmp.data(), n, even != 0);
+}
+void ref_dwt97_row(float* row, uint32_t n, int even)
+{
+	float* tmp = (float*)grkAlignedMalloc((n + 16) * sizeof(float));
+	dwt97 d; d.encode_and_deinterleave_h_one_row(row, tmp, n, even != 0);
+	grkAlignedFree(tmp);
+}
+
+// HT cleanup encode of one block. `sm` = sign-magnitude words as produced by T1HT::preCompress.
+int32_t ref_ht_encode_block(uint32_t* sm, uint32_t kmax, uint32_t w, uint32_t h, uint32_t stride,
+							uint8_t* out, uint32_t cap)
+{
+	static thread_local ojph::mem_elastic_allocator* elastic = nullptr;
+	if (elastic) { delete elastic; elastic = nullptr; }
+	elastic = new ojph::mem_elastic_allocator(1048576);
+	ojph::coded_lists* coded = nullptr;
+	uint32_t lengths[2] = {0, 0};
+	ojph::local::ojph_encode_codeblock(sm, kmax, 1, w, h, stride, lengths, elastic, coded);
+	if (lengths[0] > cap) return -1;
+	memcpy(out, coded->buf, lengths[0]);
+	return (int32_t)lengths[0];
+}
+
+// HT cleanup decode; `missing_msbs` as Grok passes it (Kmax-1, T1DecompressScheduler.cpp:59).
+int32_t ref_ht_decode_block(const uint8_t* coded, uint32_t len, uint32_t missing_msbs,
+							uint32_t w, uint32_t h, uint32_t* out)
+{
+	std::vector<uint8_t> buf(len + 32, 0);
+	memcpy(buf.data() + 8, coded, len);
+	bool ok = ojph::local::ojph_decode_codeblock(buf.data() + 8, out, missing_msbs, 1, len, 0, w, h, w);
+	return ok ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- whole codec
+struct EncCfg {
+	int32_t C, W, H, TW, TH, prec, irrev, numres, ht, mode; // mode 0: grk_compress_tile, 1: grk_compress(image data)
+	int32_t rate_algo;                                        // parameters.rateControlAlgorithm
+	int32_t cblk_w, cblk_h;                                   // 0 = default 64
+};
+
+static void fill_params(grk_cparameters& p, const EncCfg& c)
+{
+	grk_compress_set_default_params(&p);
+	p.tile_size_on = true;
+	p.tx0 = 0; p.ty0 = 0;
+	p.t_width = (uint32_t)c.TW; p.t_height = (uint32_t)c.TH;
+	p.irreversible = c.irrev != 0;
+	p.numresolution = (uint32_t)c.numres;
+	p.prog_order = GRK_LRCP;
+	p.tcp_mct = (c.C >= 3) ? 1 : 0;
+	if (c.ht) { p.isHT = true; p.cblk_sty = GRK_CBLKSTY_HT; }
+	p.rateControlAlgorithm = (uint32_t)c.rate_algo;
+	if (c.cblk_w) p.cblockw_init = (uint32_t)c.cblk_w;
+	if (c.cblk_h) p.cblockh_init = (uint32_t)c.cblk_h;
+}
+
+static grk_image* make_image(const EncCfg& c, bool alloc)
+{
+	std::vector<grk_image_cmptparm> cp((size_t)c.C);
+	memset(cp.data(), 0, sizeof(grk_image_cmptparm) * cp.size());
+	for (auto& q : cp) {
+		q.dx = 1; q.dy = 1; q.w = (uint32_t)c.W; q.h = (uint32_t)c.H;
+		q.x0 = 0; q.y0 = 0; q.prec = (uint8_t)c.prec; q.sgnd = false;
+	}
+	auto img = grk_image_new((uint16_t)c.C, cp.data(), c.C >= 3 ? GRK_CLRSPC_SRGB : GRK_CLRSPC_GRAY, alloc);
+	if (!img) return nullptr;
+	img->x0 = 0; img->y0 = 0; img->x1 = (uint32_t)c.W; img->y1 = (uint32_t)c.H;
+	return img;
+}
+
+// Encode `pixels` (component-major planar, tightly packed, ceil(prec/8) bytes per sample, whole
+// image) with the reference CPU encoder. Returns coded length or <0. `secs` = wall time of the
+// compress calls only (steady_clock), the figure BASELINE.md §3 asks for.
+int64_t ref_encode(const EncCfg* cfg, const uint8_t* pixels, uint8_t* out, uint64_t cap, double* secs,
+				   void* plugin_tile /* grk_plugin_tile* or null */)
+{
+	const EncCfg& c = *cfg;
+	grk_cparameters param;
+	fill_params(param, c);
+	const int bps = (c.prec + 7) / 8;
+	bool use_image_data = (c.mode == 1) || plugin_tile;
+	grk_image* image = make_image(c, use_image_data);
+	if (!image) return -2;
+	if (use_image_data) {
+		for (int k = 0; k < c.C; ++k) {
+			auto comp = image->comps + k;
+			const uint8_t* src = pixels + (size_t)k * c.W * c.H * bps;
+			for (int y = 0; y < c.H; ++y)
+				for (int x = 0; x < c.W; ++x) {
+					size_t i = (size_t)y * c.W + x;
+					comp->data[(size_t)y * comp->stride + x] =
+						bps == 1 ? (int32_t)src[i] : (int32_t)((const uint16_t*)src)[i];
+				}
+		}
+	}
+	grk_stream* stream = grk_stream_create_mem_stream(out, cap, false, false);
+	grk_codec* codec = grk_compress_create(GRK_CODEC_J2K, stream);
+	int64_t rc = -3;
+	double t = 0;
+	do {
+		if (!codec) break;
+		if (!grk_compress_init(codec, &param, image)) { rc = -4; break; }
+		auto t0 = std::chrono::steady_clock::now();
+		if (!grk_compress_start(codec)) { rc = -5; break; }
+		if (plugin_tile) {
+			if (!grk_compress_with_plugin(codec, (grk_plugin_tile*)plugin_tile)) { rc = -6; break; }
+		} else if (c.mode == 1) {
+			if (!grk_compress(codec)) { rc = -6; break; }
+		} else {
+			int tcols = (c.W + c.TW - 1) / c.TW, trows = (c.H + c.TH - 1) / c.TH;
+			std::vector<uint8_t> tilebuf;
+			bool ok = true;
+			for (int ty = 0; ty < trows && ok; ++ty)
+				for (int tx = 0; tx < tcols && ok; ++tx) {
+					int x0 = tx * c.TW, y0 = ty * c.TH;
+					int tw = std::min(c.TW, c.W - x0), th = std::min(c.TH, c.H - y0);
+					const uint8_t* src = pixels;
+					uint64_t tsize = (uint64_t)tw * th * c.C * bps;
+					if (tcols * trows > 1) {
+						tilebuf.resize(tsize);
+						for (int k = 0; k < c.C; ++k)
+							for (int y = 0; y < th; ++y)
+								memcpy(tilebuf.data() + ((size_t)k * th + y) * tw * bps,
+									   pixels + (((size_t)k * c.H + y0 + y) * c.W + x0) * bps, (size_t)tw * bps);
+						src = tilebuf.data();
+					}
+					ok = grk_compress_tile(codec, (uint16_t)(ty * tcols + tx), (uint8_t*)src, tsize);
+				}
+			if (!ok) { rc = -6; break; }
+		}
+		if (!grk_compress_end(codec)) { rc = -7; break; }
+		t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		rc = (int64_t)grk_stream_get_write_mem_stream_length(stream);
+	} while (0);
+	if (secs) *secs = t;
+	grk_object_unref(stream);
+	grk_object_unref(codec);
+	grk_object_unref(&image->obj);
+	return rc;
+}
+
+// Decode a whole codestream with the reference decoder into int32 planes (C x H x W, tight).
+int32_t ref_decode(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, int32_t W, int32_t H)
+{
+	grk_dparameters dp;
+	grk_decompress_set_default_params(&dp);
+	grk_stream* stream = grk_stream_create_mem_stream((uint8_t*)j2k, len, false, true);
+	grk_codec* codec = grk_decompress_create(GRK_CODEC_J2K, stream);
+	int32_t rc = -1;
+	do {
+		if (!codec) break;
+		if (!grk_decompress_init(codec, &dp)) { rc = -2; break; }
+		grk_header_info hi; memset(&hi, 0, sizeof(hi));
+		if (!grk_decompress_read_header(codec, &hi)) { rc = -3; break; }
+		if (!grk_decompress(codec, nullptr)) { rc = -4; break; }
+		grk_image* img = grk_decompress_get_composited_image(codec);
+		if (!img || img->numcomps != C) { rc = -5; break; }
+		for (int k = 0; k < C; ++k) {
+			auto comp = img->comps + k;
+			if ((int)comp->w != W || (int)comp->h != H || !comp->data) { rc = -6; break; }
+			for (int y = 0; y < H; ++y)
+				memcpy(out + ((size_t)k * H + y) * W, comp->data + (size_t)y * comp->stride, (size_t)W * 4);
+		}
+		if (rc == -6) break;
+		grk_decompress_end(codec);
+		rc = 0;
+	} while (0);
+	grk_object_unref(stream);
+	grk_object_unref(codec);
+	return rc;
+}
+
+// Load a real plugin .so through the reference's own minpf loader (grk_initialize(pluginPath)),
+// then report what the host sees. Used by the boundary test.
+int ref_plugin_load(const char* dir, int threads)
+{
+	bool ok = grk_initialize(dir, (uint32_t)threads);
+	g_inited = true;
+	grk_set_info_handler(msg_quiet, nullptr);
+	grk_set_warning_handler(msg_quiet, nullptr);
+	grk_set_error_handler(msg_err, nullptr);
+	return ok ? 1 : 0;
+}
+int ref_plugin_init(int device, int verbose)
+{
+	grk_plugin_init_info info; info.deviceId = device; info.verbose = verbose != 0;
+	return grk_plugin_init(info) ? 1 : 0;
+}
+uint32_t ref_plugin_debug_state(void) { return grk_plugin_get_debug_state(); }
+
+// sizes/offsets of the ABI structs, for the mirror check in tests/test_abi.py
+uint64_t ref_abi_sizeof(int which)
+{
+	switch (which) {
+	case 0: return sizeof(grk_plugin_pass);
+	case 1: return sizeof(grk_plugin_code_block);
+	case 2: return sizeof(grk_plugin_precinct);
+	case 3: return sizeof(grk_plugin_band);
+	case 4: return sizeof(grk_plugin_resolution);
+	case 5: return sizeof(grk_plugin_tile_component);
+	case 6: return sizeof(grk_plugin_tile);
+	case 7: return sizeof(grk_cparameters);
+	case 8: return offsetof(grk_plugin_code_block, compressedData);
+	case 9: return offsetof(grk_plugin_code_block, passes);
+	case 10: return offsetof(grk_plugin_band, stepsize);
+	case 11: return sizeof(grk_plugin_init_info);
+	case 12: return sizeof(grk_plugin_compress_user_callback_info);
+	case 13: return offsetof(grk_cparameters, isHT);
+	case 14: return offsetof(grk_cparameters, tcp_mct);
+	case 15: return offsetof(grk_cparameters, numresolution);
+	case 16: return offsetof(grk_cparameters, irreversible);
+	case 17: return offsetof(grk_cparameters, infile);
+	case 18: return offsetof(grk_cparameters, outfile);
+	case 19: return offsetof(grk_cparameters, t_width);
+	case 20: return offsetof(grk_cparameters, cblockw_init);
+	case 21: return offsetof(grk_cparameters, deviceId);
+	case 22: return offsetof(grk_cparameters, rateControlAlgorithm);
+	case 23: return offsetof(grk_cparameters, cblk_sty);
+	default: return 0;
+	}
+}
+
+} // extern "C"

@@ -1,0 +1,102 @@
+"""ctypes loader for oracle/_ref/libref_harness.so (the REAL reference, test infrastructure only).
+
+Available only where oracle/_ref was built (this container, or the prebuilt files shipped to the
+GPU box).  Tests that need it call `have_ref()` and skip otherwise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REFDIR = os.path.join(_HERE, "..", "oracle", "_ref")
+_lib = None
+
+
+class EncCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("C", "W", "H", "TW", "TH", "prec", "irrev", "numres", "ht", "mode",
+                 "rate_algo", "cblk_w", "cblk_h")]
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_REFDIR, "libref_harness.so"))
+
+
+def lib(threads=0):
+    global _lib
+    if _lib is None:
+        C.CDLL(os.path.join(_REFDIR, "libgrokj2k_ref.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(os.path.join(_REFDIR, "libref_harness.so"))
+        L.ref_init.restype = C.c_int
+        L.ref_encode.restype = C.c_int64
+        L.ref_encode.argtypes = [C.POINTER(EncCfg), C.c_void_p, C.c_void_p, C.c_uint64,
+                                 C.POINTER(C.c_double), C.c_void_p]
+        L.ref_decode.restype = C.c_int32
+        L.ref_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.ref_ht_encode_block.restype = C.c_int32
+        L.ref_ht_encode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_uint32]
+        L.ref_ht_decode_block.restype = C.c_int32
+        L.ref_ht_decode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        for f in ("ref_rct", "ref_ict"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+            getattr(L, f).restype = None
+        for f in ("ref_dwt53_fwd", "ref_dwt97_fwd"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+            getattr(L, f).restype = None
+        for f in ("ref_dwt53_row", "ref_dwt97_row"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+            getattr(L, f).restype = None
+        L.ref_abi_sizeof.restype = C.c_uint64
+        L.ref_abi_sizeof.argtypes = [C.c_int]
+        L.ref_init(threads, int(os.environ.get("REF_VERBOSE", "0")))
+        _lib = L
+    return _lib
+
+
+def encode(pixels, prec, TW=None, TH=None, irrev=0, numres=6, ht=1, mode=0, rate_algo=0,
+           plugin_tile=None, cblk=(0, 0)):
+    """pixels: (C,H,W) uint8/uint16 array. Returns (bytes, seconds)."""
+    L = lib()
+    px = np.ascontiguousarray(pixels)
+    Cn, H, W = px.shape
+    cfg = EncCfg(Cn, W, H, TW or W, TH or H, prec, irrev, numres, ht, mode, rate_algo, cblk[0], cblk[1])
+    cap = px.size * 4 + (1 << 20)
+    out = np.zeros(cap, np.uint8)
+    secs = C.c_double(0)
+    n = L.ref_encode(C.byref(cfg), px.ctypes.data, out.ctypes.data, cap, C.byref(secs),
+                     plugin_tile)
+    if n < 0:
+        raise RuntimeError("ref_encode failed rc=%d" % n)
+    return out[:n].tobytes(), secs.value
+
+
+def decode(j2k, Cn, H, W):
+    L = lib()
+    buf = np.frombuffer(j2k, np.uint8).copy()
+    out = np.zeros((Cn, H, W), np.int32)
+    rc = L.ref_decode(buf.ctypes.data, buf.size, out.ctypes.data, Cn, W, H)
+    if rc != 0:
+        raise RuntimeError("ref_decode failed rc=%d" % rc)
+    return out
+
+
+def ht_encode_block(sm, kmax):
+    """sm: (h,w) uint32 sign-magnitude MSB-aligned words."""
+    L = lib()
+    a = np.ascontiguousarray(sm, np.uint32)
+    h, w = a.shape
+    out = np.zeros(w * h * 4 + 4096, np.uint8)
+    n = L.ref_ht_encode_block(a.ctypes.data, kmax, w, h, w, out.ctypes.data, out.size)
+    assert n >= 0
+    return out[:n].tobytes()
+
+
+def ht_decode_block(coded, missing_msbs, w, h):
+    L = lib()
+    buf = np.frombuffer(coded, np.uint8).copy()
+    out = np.zeros((h, w), np.uint32)
+    rc = L.ref_ht_decode_block(buf.ctypes.data, buf.size, missing_msbs, w, h, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("ref_ht_decode_block failed")
+    return out
