@@ -1,0 +1,574 @@
+/* oracle/j2k_oracle.c -- TEST INFRASTRUCTURE ONLY (see j2k_oracle.h).
+ *
+ * CPU restatement of the reference hot path.  Written from the behavioural description in
+ * SURVEY.md Appendix A and checked against the real reference (oracle/_ref) and the Appendix C
+ * known answers; it is deliberately organised differently from the reference (per-quad analysis
+ * followed by stream emission, mirror-indexed lifting) because it doubles as the specification
+ * the HIP kernels are written against.
+ */
+#include "j2k_oracle.h"
+#include "ht_vlc_tables.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+/* ------------------------------------------------------------------ a1/a2 ingest + DC shift */
+void orc_ingest(const void* src, int bps, int32_t* dst, uint32_t w, uint32_t h, uint32_t stride,
+                int32_t dc)
+{
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            size_t i = (size_t)y * w + x;
+            int32_t v = bps == 1 ? (int32_t)((const uint8_t*)src)[i] : (int32_t)((const uint16_t*)src)[i];
+            dst[(size_t)y * stride + x] = v - dc;
+        }
+}
+
+/* ------------------------------------------------------------------ a3 RCT (mct.cpp:94-104) */
+void orc_rct_fwd(int32_t* c0, int32_t* c1, int32_t* c2, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        int32_t r = c0[i], g = c1[i], b = c2[i];
+        c0[i] = (r + 2 * g + b) >> 2;
+        c1[i] = b - g;
+        c2[i] = r - g;
+    }
+}
+void orc_rct_inv(int32_t* c0, int32_t* c1, int32_t* c2, size_t n)
+{   /* mct.cpp:454-464 */
+    for (size_t i = 0; i < n; ++i) {
+        int32_t y = c0[i], u = c1[i], v = c2[i];
+        int32_t g = y - ((u + v) >> 2);
+        c0[i] = v + g; c1[i] = g; c2[i] = u + g;
+    }
+}
+
+/* ------------------------------------------------------------------ a4 ICT (mct.cpp:469-554)
+ * y = .299 r + .587 g + .114 b (left-to-right), u = cb*(b-y), v = cr*(r-y); every product and
+ * sum individually rounded to fp32 (the file is built with -ffp-contract=off). */
+void orc_ict_fwd(int32_t* c0, int32_t* c1, int32_t* c2, size_t n)
+{
+    const float a_r = 0.299f, a_g = 0.587f, a_b = 0.114f;
+    const float cb = 0.5f / (1.0f - a_b), cr = 0.5f / (1.0f - a_r);
+    for (size_t i = 0; i < n; ++i) {
+        float r = (float)c0[i], g = (float)c1[i], b = (float)c2[i];
+        float y = a_r * r;
+        y = y + a_g * g;
+        y = y + a_b * b;
+        float u = cb * (b - y);
+        float v = cr * (r - y);
+        memcpy(&c0[i], &y, 4); memcpy(&c1[i], &u, 4); memcpy(&c2[i], &v, 4);
+    }
+}
+
+/* ------------------------------------------------------------------ a6 5/3 lifting
+ * One line, first sample on an even coordinate. Whole-sample symmetric extension is expressed by
+ * mirroring indices (x[-1]=x[1], x[n]=x[n-2]); this reproduces the reference's edge formulas
+ * (WaveletFwd.cpp:866-883) bit for bit because the mirrored operands are the same values. */
+static inline uint32_t mirror(int32_t i, uint32_t n)
+{
+    if (n == 1) return 0;
+    int32_t p = 2 * ((int32_t)n - 1);
+    i %= p; if (i < 0) i += p;
+    return (uint32_t)(i < (int32_t)n ? i : p - i);
+}
+
+static void dwt53_line(const int32_t* in, size_t istride, int32_t* out, size_t ostride, uint32_t n,
+                       int32_t* tmp)
+{
+    if (n == 1) { out[0] = in[0]; return; }
+    uint32_t sn = (n + 1) >> 1, dn = n - sn;
+    for (uint32_t k = 0; k < n; ++k) tmp[k] = in[k * istride];
+    /* predict: odd samples */
+    for (uint32_t k = 1; k < n; k += 2)
+        tmp[k] -= (tmp[k - 1] + tmp[mirror((int32_t)k + 1, n)]) >> 1;
+    /* update: even samples */
+    for (uint32_t k = 0; k < n; k += 2)
+        tmp[k] += (tmp[mirror((int32_t)k - 1, n)] + tmp[mirror((int32_t)k + 1, n)] + 2) >> 2;
+    for (uint32_t i = 0; i < sn; ++i) out[i * ostride] = tmp[2 * i];
+    for (uint32_t i = 0; i < dn; ++i) out[(sn + i) * ostride] = tmp[2 * i + 1];
+}
+
+void orc_dwt53_fwd_1d(int32_t* x, uint32_t n)
+{
+    int32_t* tmp = (int32_t*)malloc((n + 1) * sizeof(int32_t));
+    dwt53_line(x, 1, x, 1, n, tmp);
+    free(tmp);
+}
+
+/* a7 9/7 lifting: four sweeps + scaling; (a+b)*c with three separate fp32 roundings
+ * (WaveletFwd.cpp:134-214). */
+static void dwt97_line(const float* in, size_t istride, float* out, size_t ostride, uint32_t n,
+                       float* w)
+{
+    static const float alpha = -1.586134342f, beta = -0.052980118f;
+    static const float gamma_ = 0.882911075f, delta = 0.443506852f;
+    static const float K = 1.230174105f;
+    const float invK = (float)(1.0 / 1.230174105);
+    if (n == 1) { out[0] = in[0]; return; }
+    uint32_t sn = (n + 1) >> 1, dn = n - sn;
+    for (uint32_t k = 0; k < n; ++k) w[k] = in[k * istride];
+    const float c[4] = {alpha, beta, gamma_, delta};
+    for (int s = 0; s < 4; ++s) {
+        uint32_t first = (s & 1) ? 0u : 1u;      /* alpha,gamma: odd ; beta,delta: even */
+        for (uint32_t k = first; k < n; k += 2) {
+            float l = w[mirror((int32_t)k - 1, n)], r = w[mirror((int32_t)k + 1, n)];
+            float sum = l + r;
+            float prod = sum * c[s];
+            w[k] = w[k] + prod;
+        }
+    }
+    for (uint32_t i = 0; i < sn; ++i) out[i * ostride] = w[2 * i] * invK;
+    for (uint32_t i = 0; i < dn; ++i) out[(sn + i) * ostride] = w[2 * i + 1] * K;
+}
+
+void orc_dwt97_fwd_1d(float* x, uint32_t n)
+{
+    float* tmp = (float*)malloc((n + 1) * sizeof(float));
+    dwt97_line(x, 1, x, 1, n, tmp);
+    free(tmp);
+}
+
+static uint32_t cdivp2(uint32_t v, uint32_t n) { return (uint32_t)(((uint64_t)v + (1ull << n) - 1) >> n); }
+
+/* a5: level loop -- vertical pass over every column, then horizontal over every row
+ * (WaveletFwd.cpp:491-602). */
+void orc_dwt53_fwd(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{
+    uint32_t m = (w > h ? w : h) + 2;
+    int32_t* tmp = (int32_t*)malloc(m * sizeof(int32_t));
+    for (uint32_t l = 0; l < levels; ++l) {
+        uint32_t cw = cdivp2(w, l), ch = cdivp2(h, l);
+        for (uint32_t x = 0; x < cw; ++x) dwt53_line(plane + x, stride, plane + x, stride, ch, tmp);
+        for (uint32_t y = 0; y < ch; ++y) dwt53_line(plane + (size_t)y * stride, 1, plane + (size_t)y * stride, 1, cw, tmp);
+    }
+    free(tmp);
+}
+void orc_dwt97_fwd(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{
+    uint32_t m = (w > h ? w : h) + 2;
+    float* tmp = (float*)malloc(m * sizeof(float));
+    for (uint32_t l = 0; l < levels; ++l) {
+        uint32_t cw = cdivp2(w, l), ch = cdivp2(h, l);
+        for (uint32_t x = 0; x < cw; ++x) dwt97_line(plane + x, stride, plane + x, stride, ch, tmp);
+        for (uint32_t y = 0; y < ch; ++y) dwt97_line(plane + (size_t)y * stride, 1, plane + (size_t)y * stride, 1, cw, tmp);
+    }
+    free(tmp);
+}
+
+/* inverse 5/3 (for round-trip property tests): horizontal then vertical per level, low->high */
+static void idwt53_line(int32_t* io, size_t st, uint32_t n, int32_t* tmp)
+{
+    if (n == 1) return;
+    uint32_t sn = (n + 1) >> 1, dn = n - sn;
+    for (uint32_t i = 0; i < sn; ++i) tmp[2 * i] = io[i * st];
+    for (uint32_t i = 0; i < dn; ++i) tmp[2 * i + 1] = io[(sn + i) * st];
+    for (uint32_t k = 0; k < n; k += 2)
+        tmp[k] -= (tmp[mirror((int32_t)k - 1, n)] + tmp[mirror((int32_t)k + 1, n)] + 2) >> 2;
+    for (uint32_t k = 1; k < n; k += 2)
+        tmp[k] += (tmp[k - 1] + tmp[mirror((int32_t)k + 1, n)]) >> 1;
+    for (uint32_t k = 0; k < n; ++k) io[k * st] = tmp[k];
+}
+void orc_dwt53_inv(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{
+    uint32_t m = (w > h ? w : h) + 2;
+    int32_t* tmp = (int32_t*)malloc(m * sizeof(int32_t));
+    for (int32_t l = (int32_t)levels - 1; l >= 0; --l) {
+        uint32_t cw = cdivp2(w, (uint32_t)l), ch = cdivp2(h, (uint32_t)l);
+        for (uint32_t y = 0; y < ch; ++y) idwt53_line(plane + (size_t)y * stride, 1, cw, tmp);
+        for (uint32_t x = 0; x < cw; ++x) idwt53_line(plane + x, stride, ch, tmp);
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ a8 exponents / step sizes */
+/* BIBO gains of the 5/3 analysis bank per decomposition count (codestream/HTParams.cpp:139-154);
+ * values converge after ~15 levels. */
+static const float bibo53_l[34] = {1.0000e+00f, 1.5000e+00f, 1.6250e+00f, 1.6875e+00f, 1.6963e+00f,
+    1.7067e+00f, 1.7116e+00f, 1.7129e+00f, 1.7141e+00f, 1.7145e+00f, 1.7151e+00f, 1.7152e+00f,
+    1.7155e+00f, 1.7155e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f,
+    1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f,
+    1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f, 1.7156e+00f,
+    1.7156e+00f};
+static const float bibo53_h[34] = {2.0000e+00f, 2.5000e+00f, 2.7500e+00f, 2.8047e+00f, 2.8198e+00f,
+    2.8410e+00f, 2.8558e+00f, 2.8601e+00f, 2.8628e+00f, 2.8656e+00f, 2.8662e+00f, 2.8667e+00f,
+    2.8669e+00f, 2.8670e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f,
+    2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f,
+    2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f, 2.8671e+00f,
+    2.8671e+00f};
+/* sqrt energy gains of the 9/7 synthesis bank (HTParams.cpp:72-87), first 12 levels */
+static const float gain97_l[13] = {1.0000e+00f, 1.4021e+00f, 2.0304e+00f, 2.9012e+00f, 4.1153e+00f,
+    5.8245e+00f, 8.2388e+00f, 1.1652e+01f, 1.6479e+01f, 2.3304e+01f, 3.2957e+01f, 4.6609e+01f, 6.5915e+01f};
+static const float gain97_h[13] = {1.4425e+00f, 1.9669e+00f, 2.8839e+00f, 4.1475e+00f, 5.8946e+00f,
+    8.3472e+00f, 1.1809e+01f, 1.6701e+01f, 2.3620e+01f, 3.3403e+01f, 4.7240e+01f, 6.6807e+01f, 9.4479e+01f};
+
+static int rev_X(float g) { return (int)ceil(log(g * 1.1f) / M_LN2); }
+
+void orc_ht_rev_exponents(uint32_t prec, uint32_t levels, uint8_t* expn)
+{
+    int B = (int)prec;                               /* D4: no +1 for RCT */
+    uint32_t s = 0;
+    float bl = bibo53_l[levels];
+    expn[s++] = (uint8_t)(B + rev_X(bl * bl));
+    for (int d = (int)levels - 1; d >= 0; --d) {
+        float l = bibo53_l[d + 1], hh = bibo53_h[d];
+        int X = rev_X(hh * l);
+        expn[s++] = (uint8_t)(B + X);
+        expn[s++] = (uint8_t)(B + X);
+        expn[s++] = (uint8_t)(B + rev_X(hh * hh));
+    }
+}
+
+static uint16_t irrev_code(float delta_b)
+{
+    uint32_t e = 0;
+    while (delta_b < 1.0f) { e++; delta_b *= 2.0f; }
+    uint32_t mant = (uint32_t)round(delta_b * (float)(1 << 11)) - (1 << 11);
+    if (mant >= (1u << 11)) mant = 0x7FF;
+    return (uint16_t)((e << 11) | mant);
+}
+
+void orc_ht_irrev_stepsizes(uint32_t prec, uint32_t levels, uint16_t* spqcd, float* delta)
+{
+    float base = 1.0f / (float)(1u << prec);        /* unsigned components */
+    uint32_t s = 0;
+    float gl = gain97_l[levels];
+    spqcd[s++] = irrev_code(base / (gl * gl));
+    for (int d = (int)levels - 1; d >= 0; --d) {
+        float l = gain97_l[d + 1], hh = gain97_h[d];
+        uint16_t c = irrev_code(base / (l * hh));
+        spqcd[s++] = c; spqcd[s++] = c;
+        spqcd[s++] = irrev_code(base / (hh * hh));
+    }
+    /* Quantizer.cpp:41-45, encoder side: numbps = prec + log2gain(0,1,1,2) */
+    for (uint32_t b = 0; b < s; ++b) {
+        uint32_t orient = b == 0 ? 0 : ((b - 1) % 3) + 1;
+        uint32_t gain = orient == 0 ? 0 : (orient == 3 ? 2 : 1);
+        int ex = spqcd[b] >> 11, mant = spqcd[b] & 0x7FF;
+        delta[b] = (float)((1.0 + mant / 2048.0) * pow(2.0, (int32_t)(prec + gain) - ex));
+    }
+}
+
+/* ------------------------------------------------------------------ a9 block enumeration */
+uint32_t orc_enumerate_blocks(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp,
+                              const uint8_t* expn, orc_block* out, uint32_t cap)
+{
+    uint32_t n = 0;
+    const uint32_t cb = 1u << cblk_exp;
+    for (uint32_t r = 0; r <= levels; ++r) {
+        uint32_t rw = cdivp2(w, levels - r), rh = cdivp2(h, levels - r);
+        uint32_t lw = r ? cdivp2(w, levels - r + 1) : 0, lh = r ? cdivp2(h, levels - r + 1) : 0;
+        uint32_t nb = r ? 3 : 1;
+        for (uint32_t bi = 0; bi < nb; ++bi) {
+            uint32_t orient = r ? bi + 1 : 0;
+            uint32_t bw = r ? ((orient & 1) ? rw - lw : lw) : rw;
+            uint32_t bh = r ? ((orient & 2) ? rh - lh : lh) : rh;
+            uint32_t ox = (orient & 1) ? lw : 0, oy = (orient & 2) ? lh : 0;
+            uint32_t qcd_idx = r ? 3 * (r - 1) + 1 + bi : 0;
+            if (bw == 0 || bh == 0) continue;
+            uint32_t gx = (bw + cb - 1) >> cblk_exp, gy = (bh + cb - 1) >> cblk_exp;
+            for (uint32_t by = 0; by < gy; ++by)
+                for (uint32_t bx = 0; bx < gx; ++bx) {
+                    if (n < cap) {
+                        orc_block* b = &out[n];
+                        b->x = ox + bx * cb; b->y = oy + by * cb;
+                        b->w = (bx + 1) * cb <= bw ? cb : bw - bx * cb;
+                        b->h = (by + 1) * cb <= bh ? cb : bh - by * cb;
+                        b->res = (uint8_t)r; b->band = (uint8_t)orient;
+                        b->kmax = expn ? expn[qcd_idx] : 0; b->pad = 0;
+                        b->bx = bx; b->by = by;
+                    }
+                    ++n;
+                }
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ a10 sign-magnitude */
+void orc_ht_signmag_rev(const int32_t* src, uint32_t stride, uint32_t w, uint32_t h, uint32_t kmax,
+                        uint32_t* dst)
+{
+    uint32_t shift = 30 - kmax;
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            int32_t v = src[(size_t)y * stride + x];
+            uint32_t mag = (uint32_t)(v < 0 ? -(int64_t)v : v);
+            dst[y * w + x] = (v < 0 ? 0x80000000u : 0u) | (mag << shift);
+        }
+}
+void orc_ht_signmag_irrev(const float* src, uint32_t stride, uint32_t w, uint32_t h, uint32_t kmax,
+                          float inv_delta, uint32_t* dst)
+{
+    uint32_t shift = 30 - kmax;
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            float c = src[(size_t)y * stride + x];
+            float a = fabsf(c) * inv_delta;
+            uint32_t q = (uint32_t)a;               /* truncation = dead-zone quantiser */
+            uint32_t lim = (1u << kmax) - 1; if (q > lim) q = lim;
+            dst[y * w + x] = ((c < 0 && q) ? 0x80000000u : 0u) | (q << shift);
+        }
+}
+
+/* ------------------------------------------------------------------ a11 HT cleanup encoder */
+/* forward LSB-first packer with 0xFF -> next-byte-7-bits stuffing (MagSgn; :415-454) */
+typedef struct { uint8_t* buf; uint32_t pos, cap; uint32_t acc; int used, limit; } fwd_bits;
+static void fb_init(fwd_bits* b, uint8_t* buf, uint32_t cap) { b->buf = buf; b->pos = 0; b->cap = cap; b->acc = 0; b->used = 0; b->limit = 8; }
+static int fb_put(fwd_bits* b, uint32_t v, int n)
+{
+    while (n > 0) {
+        int t = b->limit - b->used; if (t > n) t = n;
+        b->acc |= (v & ((1u << t) - 1)) << b->used;
+        b->used += t; v >>= t; n -= t;
+        if (b->used == b->limit) {
+            if (b->pos >= b->cap) return -1;
+            b->buf[b->pos++] = (uint8_t)b->acc;
+            b->limit = (b->acc == 0xFF) ? 7 : 8;
+            b->acc = 0; b->used = 0;
+        }
+    }
+    return 0;
+}
+static void fb_finish(fwd_bits* b)
+{
+    if (b->used) {
+        int t = b->limit - b->used;
+        b->acc |= (0xFFu & ((1u << t) - 1)) << b->used;     /* pad with ones */
+        if (b->acc != 0xFF) b->buf[b->pos++] = (uint8_t)b->acc;
+    } else if (b->limit == 7) {
+        b->pos--;                                           /* drop a trailing 0xFF */
+    }
+}
+
+/* MEL: 13-state adaptive run-length coder, bits MSB-first, same 0xFF stuffing (:217-291) */
+typedef struct { uint8_t* buf; uint32_t pos, cap; int left, acc, run, k; } mel_enc;
+static const int MEL_E[13] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 4, 5};
+static void mel_init_(mel_enc* m, uint8_t* buf, uint32_t cap) { m->buf = buf; m->pos = 0; m->cap = cap; m->left = 8; m->acc = 0; m->run = 0; m->k = 0; }
+static void mel_bit(mel_enc* m, int v)
+{
+    m->acc = (m->acc << 1) | v;
+    if (--m->left == 0) {
+        m->buf[m->pos++] = (uint8_t)m->acc;
+        m->left = (m->acc == 0xFF) ? 7 : 8;
+        m->acc = 0;
+    }
+}
+static void mel_event(mel_enc* m, int one)
+{
+    if (!one) {
+        if (++m->run >= (1 << MEL_E[m->k])) { mel_bit(m, 1); m->run = 0; if (m->k < 12) m->k++; }
+    } else {
+        mel_bit(m, 0);
+        for (int t = MEL_E[m->k]; t > 0;) mel_bit(m, (m->run >> --t) & 1);
+        m->run = 0; if (m->k > 0) m->k--;
+    }
+}
+
+/* VLC: grows downwards from the end of its buffer; a byte following one that is > 0x8F holds
+ * 7 bits when those 7 bits are all ones (:296-351) */
+typedef struct { uint8_t* end; uint32_t pos, cap; int used, acc, prev_gt8f; } vlc_enc;
+static void vlc_init_(vlc_enc* v, uint8_t* buf, uint32_t cap)
+{ v->end = buf + cap - 1; v->pos = 1; v->cap = cap; v->end[0] = 0xFF; v->used = 4; v->acc = 0xF; v->prev_gt8f = 1; }
+static void vlc_put(vlc_enc* v, int cw, int n)
+{
+    while (n > 0) {
+        int room = 8 - v->prev_gt8f - v->used;
+        int t = room < n ? room : n;
+        v->acc |= (cw & ((1 << t) - 1)) << v->used;
+        v->used += t; room -= t; n -= t; cw >>= t;
+        if (room == 0) {
+            if (v->prev_gt8f && v->acc != 0x7F) { v->prev_gt8f = 0; continue; }  /* 8th bit allowed after all */
+            *(v->end - v->pos) = (uint8_t)v->acc; v->pos++;
+            v->prev_gt8f = v->acc > 0x8F;
+            v->acc = 0; v->used = 0;
+        }
+    }
+}
+
+static void uvlc_code(int u, int* pre, int* pre_len, int* suf, int* suf_len)
+{   /* :189-210 */
+    if (u == 0)      { *pre = 0; *pre_len = 0; *suf = 0; *suf_len = 0; }
+    else if (u == 1) { *pre = 1; *pre_len = 1; *suf = 0; *suf_len = 0; }
+    else if (u == 2) { *pre = 2; *pre_len = 2; *suf = 0; *suf_len = 0; }
+    else if (u <= 4) { *pre = 4; *pre_len = 3; *suf = u - 3; *suf_len = 1; }
+    else             { *pre = 0; *pre_len = 3; *suf = u - 5; *suf_len = 5; }
+}
+
+typedef struct { uint8_t rho, emax, e[4]; uint32_t v[4]; } quad_info;
+
+int32_t orc_ht_encode_sm(const uint32_t* sm, uint32_t kmax, uint32_t w, uint32_t h, uint8_t* out,
+                         uint32_t cap)
+{
+    const uint32_t p = 30 - kmax;
+    const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
+    const uint32_t MS_CAP = 4 * w * h + 64, MEL_CAP = 192 + (QW * QH) / 4, VLC_CAP = 3072 + 2 * QW * QH;
+    uint8_t* ms_buf = (uint8_t*)malloc(MS_CAP);
+    uint8_t* mel_buf = (uint8_t*)malloc(MEL_CAP);
+    uint8_t* vlc_buf = (uint8_t*)malloc(VLC_CAP);
+    quad_info* row = (quad_info*)calloc(QW + 2, sizeof(quad_info));    /* current quad row  */
+    uint8_t* eb = (uint8_t*)calloc(2 * QW + 4, 1);     /* exponents of the sample row just above */
+    uint8_t* sb = (uint8_t*)calloc(2 * QW + 4, 1);     /* significance of that row               */
+    /* eb/sb are indexed by x+1 so that x=-1 is addressable */
+    fwd_bits ms; mel_enc mel; vlc_enc vlc;
+    fb_init(&ms, ms_buf, MS_CAP); mel_init_(&mel, mel_buf, MEL_CAP); vlc_init_(&vlc, vlc_buf, VLC_CAP);
+
+    for (uint32_t qy = 0; qy < QH; ++qy) {
+        /* ---- stage 1: per-quad sample analysis (:513-563) */
+        for (uint32_t qx = 0; qx < QW; ++qx) {
+            quad_info* q = &row[qx];
+            memset(q, 0, sizeof(*q));
+            for (int i = 0; i < 4; ++i) {
+                uint32_t x = 2 * qx + (uint32_t)(i >> 1), y = 2 * qy + (uint32_t)(i & 1);
+                uint32_t t = (x < w && y < h) ? sm[(size_t)y * w + x] : 0;
+                uint32_t val = ((t + t) >> p) & ~1u;             /* 2*mu */
+                if (val) {
+                    q->rho |= (uint8_t)(1 << i);
+                    q->e[i] = (uint8_t)(32 - __builtin_clz(val - 1));
+                    if (q->e[i] > q->emax) q->emax = q->e[i];
+                    q->v[i] = val - 2 + (t >> 31);               /* 2(mu-1) + sign */
+                }
+            }
+        }
+        /* ---- stage 2+3: per quad-pair context, VLC/UVLC/MEL/MagSgn emission */
+        for (uint32_t qx0 = 0; qx0 < QW; qx0 += 2) {
+            int u[2] = {0, 0};
+            for (uint32_t j = 0; j < 2 && qx0 + j < QW; ++j) {
+                uint32_t qx = qx0 + j;
+                const quad_info* q = &row[qx];
+                int rho_left = qx ? row[qx - 1].rho : 0;
+                int c_q, kappa, U;
+                uint16_t tuple;
+                if (qy == 0) {
+                    c_q = (rho_left >> 1) | (rho_left & 1);                     /* :652, :709 */
+                    kappa = 1;
+                } else {
+                    /* neighbourhood in the sample row above: columns 2qx-1 .. 2qx+2 (index +1) */
+                    const uint8_t* E = eb + 2 * qx, *S = sb + 2 * qx;
+                    int emx = E[0]; if (E[1] > emx) emx = E[1]; if (E[2] > emx) emx = E[2]; if (E[3] > emx) emx = E[3];
+                    int max_e = emx - 1;
+                    c_q = (S[0] | S[1]) | (((rho_left >> 2) | (rho_left >> 3)) & 1) << 1 | (S[2] | S[3]) << 2;   /* :723,:799,:872,:912 */
+                    kappa = (q->rho & (q->rho - 1)) ? (max_e > 1 ? max_e : 1) : 1;                          /* :783 */
+                }
+                U = q->emax > kappa ? q->emax : kappa;
+                u[j] = U - kappa;
+                int eps = 0;
+                if (u[j] > 0)
+                    for (int i = 0; i < 4; ++i) eps |= (q->e[i] == q->emax) << i;
+                tuple = (qy == 0 ? HT_VLC_ENC0 : HT_VLC_ENC1)[(c_q << 8) | (q->rho << 4) | eps];
+                vlc_put(&vlc, tuple >> 8, (tuple >> 4) & 7);
+                if (c_q == 0) mel_event(&mel, q->rho != 0);
+                for (int i = 0; i < 4; ++i) {
+                    int m = (q->rho >> i & 1) ? U - ((tuple >> i) & 1) : 0;
+                    if (m && fb_put(&ms, q->v[i] & ((m >= 32) ? 0xFFFFFFFFu : ((1u << m) - 1)), m)) goto overflow;
+                }
+            }
+            int pre0, pl0, s0, sl0, pre1, pl1, s1, sl1;
+            if (qy == 0) {
+                if (u[0] > 0 && u[1] > 0) mel_event(&mel, (u[0] < u[1] ? u[0] : u[1]) > 2);       /* :684 */
+                if (u[0] > 2 && u[1] > 2) {
+                    uvlc_code(u[0] - 2, &pre0, &pl0, &s0, &sl0); uvlc_code(u[1] - 2, &pre1, &pl1, &s1, &sl1);
+                    vlc_put(&vlc, pre0, pl0); vlc_put(&vlc, pre1, pl1); vlc_put(&vlc, s0, sl0); vlc_put(&vlc, s1, sl1);
+                } else if (u[0] > 2 && u[1] > 0) {
+                    uvlc_code(u[0], &pre0, &pl0, &s0, &sl0);
+                    vlc_put(&vlc, pre0, pl0); vlc_put(&vlc, u[1] - 1, 1); vlc_put(&vlc, s0, sl0);
+                } else {
+                    uvlc_code(u[0], &pre0, &pl0, &s0, &sl0); uvlc_code(u[1], &pre1, &pl1, &s1, &sl1);
+                    vlc_put(&vlc, pre0, pl0); vlc_put(&vlc, pre1, pl1); vlc_put(&vlc, s0, sl0); vlc_put(&vlc, s1, sl1);
+                }
+            } else {
+                uvlc_code(u[0], &pre0, &pl0, &s0, &sl0); uvlc_code(u[1], &pre1, &pl1, &s1, &sl1);
+                vlc_put(&vlc, pre0, pl0); vlc_put(&vlc, pre1, pl1); vlc_put(&vlc, s0, sl0); vlc_put(&vlc, s1, sl1);
+            }
+        }
+        /* ---- line state for the next quad row: bottom samples (1 and 3) of this row */
+        memset(eb, 0, 2 * QW + 4); memset(sb, 0, 2 * QW + 4);
+        for (uint32_t qx = 0; qx < QW; ++qx) {
+            eb[2 * qx + 1] = row[qx].e[1]; eb[2 * qx + 2] = row[qx].e[3];
+            sb[2 * qx + 1] = (row[qx].rho >> 1) & 1; sb[2 * qx + 2] = (row[qx].rho >> 3) & 1;
+        }
+    }
+
+    /* ---- termination (:357-385, :438-454) */
+    if (mel.run > 0) mel_bit(&mel, 1);
+    {
+        int mel_acc = mel.acc << mel.left;
+        int mel_mask = (0xFF << mel.left) & 0xFF;
+        int vlc_mask = 0xFF >> (8 - vlc.used);
+        if ((mel_mask | vlc_mask) != 0) {
+            int fuse = mel_acc | vlc.acc;
+            if ((((fuse ^ mel_acc) & mel_mask) | ((fuse ^ vlc.acc) & vlc_mask)) == 0 && fuse != 0xFF && vlc.pos > 1) {
+                mel.buf[mel.pos++] = (uint8_t)fuse;
+            } else {
+                mel.buf[mel.pos++] = (uint8_t)mel_acc;
+                *(vlc.end - vlc.pos) = (uint8_t)vlc.acc; vlc.pos++;
+            }
+        }
+    }
+    fb_finish(&ms);
+
+    int32_t total = (int32_t)(ms.pos + mel.pos + vlc.pos);
+    if ((uint32_t)total > cap) goto overflow;
+    memcpy(out, ms.buf, ms.pos);
+    memcpy(out + ms.pos, mel.buf, mel.pos);
+    memcpy(out + ms.pos + mel.pos, vlc.end - vlc.pos + 1, vlc.pos);
+    {
+        uint32_t scup = mel.pos + vlc.pos;                      /* :930-935 */
+        out[total - 1] = (uint8_t)(scup >> 4);
+        out[total - 2] = (uint8_t)((out[total - 2] & 0xF0) | (scup & 0xF));
+    }
+    free(ms_buf); free(mel_buf); free(vlc_buf); free(row); free(eb); free(sb);
+    return total;
+overflow:
+    free(ms_buf); free(mel_buf); free(vlc_buf); free(row); free(eb); free(sb);
+    return -1;
+}
+
+int32_t orc_ht_encode_block_rev(const int32_t* src, uint32_t stride, uint32_t w, uint32_t h,
+                                uint32_t kmax, uint8_t* out, uint32_t cap)
+{
+    uint32_t* sm = (uint32_t*)malloc((size_t)w * h * 4);
+    orc_ht_signmag_rev(src, stride, w, h, kmax, sm);
+    int32_t n = orc_ht_encode_sm(sm, kmax, w, h, out, cap);
+    free(sm);
+    return n;
+}
+
+/* ------------------------------------------------------------------ whole tile, reversible */
+static uint32_t stride_for(uint32_t w) { return (w + 31) & ~31u; }     /* util/MemManager.cpp:38-43 */
+
+int32_t orc_encode_tile_rev(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
+                            uint32_t prec, uint32_t levels, int mct, orc_block* blocks_out,
+                            uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
+                            uint64_t* total_bytes)
+{
+    uint32_t stride = stride_for(w);
+    size_t plane_n = (size_t)stride * h;
+    int32_t* planes = (int32_t*)calloc(plane_n * ncomp, sizeof(int32_t));
+    uint8_t expn[3 * 32 + 1];
+    if (!planes) return -1;
+    for (uint32_t c = 0; c < ncomp; ++c)
+        orc_ingest((const uint8_t*)pixels + (size_t)c * w * h * bps, bps, planes + c * plane_n, w, h, stride,
+                   1 << (prec - 1));
+    if (mct && ncomp >= 3) orc_rct_fwd(planes, planes + plane_n, planes + 2 * plane_n, plane_n);
+    for (uint32_t c = 0; c < ncomp; ++c) orc_dwt53_fwd(planes + c * plane_n, w, h, stride, levels);
+    orc_ht_rev_exponents(prec, levels, expn);
+    uint32_t nb = orc_enumerate_blocks(w, h, levels, 6, expn, NULL, 0);
+    if (nb * ncomp > max_blocks) { free(planes); return -2; }
+    uint64_t off = 0; uint32_t k = 0;
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        orc_enumerate_blocks(w, h, levels, 6, expn, blocks_out + k, nb);
+        for (uint32_t i = 0; i < nb; ++i, ++k) {
+            orc_block* b = &blocks_out[k];
+            b->pad = (uint8_t)c;
+            if (cap - off < 20000) { free(planes); return -3; }
+            int32_t n = orc_ht_encode_block_rev(planes + c * plane_n + (size_t)b->y * stride + b->x, stride,
+                                                b->w, b->h, b->kmax, coded + off, (uint32_t)(cap - off > 0x7fffffff ? 0x7fffffff : cap - off));
+            if (n < 0) { free(planes); return -4; }
+            lens[k] = (uint32_t)n; off += (uint32_t)n;
+        }
+    }
+    *total_bytes = off;
+    free(planes);
+    return (int32_t)k;
+}

@@ -1,0 +1,81 @@
+/* oracle/j2k_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's per-tile hot path, used exclusively
+ * as the parity checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * The product (grok_amd/) never links, imports or calls anything declared here.
+ *
+ * Parity status: PINNED.  Every function below is checked (tests/test_oracle_*.py) against
+ *   - the known-answer vectors of SURVEY.md Appendix C.1/C.2 (committed under tests/golden/), and
+ *   - the real reference built from its own sources by oracle/Makefile (oracle/_ref), call by call.
+ */
+#ifndef J2K_ORACLE_H
+#define J2K_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- a1/a2: widen + DC level shift  (tile/TileProcessor.cpp:1166-1216, :922-944) */
+void orc_ingest(const void* src, int bytes_per_sample, int32_t* dst,
+                uint32_t w, uint32_t h, uint32_t stride, int32_t dc_shift);
+
+/* ---- a3/a4: forward colour transforms, in place (point_transform/mct.cpp:48-105, :469-554) */
+void orc_rct_fwd(int32_t* c0, int32_t* c1, int32_t* c2, size_t n);
+void orc_ict_fwd(int32_t* c0, int32_t* c1, int32_t* c2, size_t n); /* writes float bit patterns */
+
+/* ---- a5-a7: forward DWT over `levels` decompositions, in place, Mallat layout
+ *            (transform/WaveletFwd.cpp:434-609; 5/3 :625-906; 9/7 :134-214, :911-994) */
+void orc_dwt53_fwd(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels);
+void orc_dwt97_fwd(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels);
+void orc_dwt53_fwd_1d(int32_t* x, uint32_t n);           /* [s | d] out, even start */
+void orc_dwt97_fwd_1d(float* x, uint32_t n);
+/* inverse transforms (transform/WaveletReverse.cpp:852-936, :1360-1439) for round-trip checks */
+void orc_dwt53_inv(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels);
+void orc_rct_inv(int32_t* c0, int32_t* c1, int32_t* c2, size_t n);
+
+/* ---- a8: quantiser exponents.  Reversible HT: codestream/HTParams.cpp:248-268 (RCT bit NOT
+ *          added: defect D4).  Fills 3*levels+1 exponents in QCD order; Kmax(band)=expn (a8). */
+void orc_ht_rev_exponents(uint32_t prec, uint32_t levels, uint8_t* expn /* [3*levels+1] */);
+/* irreversible HT: HTParams.cpp:269-312 -> (expn<<11)|mant per band, and the float step of
+ * Quantizer.cpp:41-45 */
+void orc_ht_irrev_stepsizes(uint32_t prec, uint32_t levels, uint16_t* spqcd, float* delta);
+
+/* ---- a9: code-block enumeration (comp-local; order res -> band -> precinct(1) -> raster) */
+typedef struct {
+    uint32_t x, y;        /* origin inside the component's Mallat plane (samples) */
+    uint32_t w, h;        /* block size */
+    uint8_t  res, band;   /* resolution 0..levels ; orientation 0=LL 1=HL 2=LH 3=HH */
+    uint8_t  kmax;        /* band->numbps for HT = QCD exponent */
+    uint8_t  pad;
+    uint32_t bx, by;      /* block coordinates inside the band's code-block grid */
+} orc_block;
+/* returns number of blocks (writes at most cap of them). cblk_exp = log2 nominal size (6). */
+uint32_t orc_enumerate_blocks(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp,
+                              const uint8_t* expn, orc_block* out, uint32_t cap);
+
+/* ---- a10: sign-magnitude conversion (t1/t1_ht/T1HT.cpp:58-84), a11: HT cleanup encoder
+ *           (t1/t1_ht/coding/ojph_block_encoder.cpp:463-938). Returns coded length. */
+void     orc_ht_signmag_rev(const int32_t* src, uint32_t stride, uint32_t w, uint32_t h,
+                            uint32_t kmax, uint32_t* dst /* w*h */);
+int32_t  orc_ht_encode_sm(const uint32_t* sm, uint32_t kmax, uint32_t w, uint32_t h,
+                          uint8_t* out, uint32_t cap);
+int32_t  orc_ht_encode_block_rev(const int32_t* src, uint32_t stride, uint32_t w, uint32_t h,
+                                 uint32_t kmax, uint8_t* out, uint32_t cap);
+/* irreversible ("intended" dead-zone quantiser of SURVEY.md A.5, NOT the reference's D1 bug) */
+void     orc_ht_signmag_irrev(const float* src, uint32_t stride, uint32_t w, uint32_t h,
+                              uint32_t kmax, float inv_delta, uint32_t* dst);
+
+/* ---- whole tile, reversible: pixels (C planes, tight) -> per-block coded bytes.
+ * blocks_out[i] describes block i (enumeration order comp -> res -> band -> raster), lens[i] its
+ * coded length, bytes are appended to `coded` (capacity cap). Returns total number of blocks or <0. */
+int32_t orc_encode_tile_rev(const void* pixels, int bytes_per_sample, uint32_t ncomp,
+                            uint32_t w, uint32_t h, uint32_t prec, uint32_t levels, int mct,
+                            orc_block* blocks_out, uint32_t* lens, uint32_t max_blocks,
+                            uint8_t* coded, uint64_t cap, uint64_t* total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -47,13 +47,25 @@ int ref_init(int threads, int verbose)
 }
 
 // ---------------------------------------------------------------- stage kernels
-void ref_rct(int32_t* c0, int32_t* c1, int32_t* c2, uint64_t n) { mct::compress_rev(c0, c1, c2, n); }
-void ref_ict(int32_t* c0, int32_t* c1, int32_t* c2, uint64_t n) { mct::compress_irrev(c0, c1, c2, n); }
+// the reference kernels use aligned SIMD loads: stage the caller's arrays in grkAlignedMalloc memory
+static void mct_staged(int32_t* c0, int32_t* c1, int32_t* c2, uint64_t n, bool irrev)
+{
+	int32_t* p[3]; int32_t* u[3] = {c0, c1, c2};
+	for (int i = 0; i < 3; ++i) { p[i] = (int32_t*)grkAlignedMalloc((n + 64) * 4); memcpy(p[i], u[i], n * 4); }
+	if (irrev) mct::compress_irrev(p[0], p[1], p[2], n); else mct::compress_rev(p[0], p[1], p[2], n);
+	for (int i = 0; i < 3; ++i) { memcpy(u[i], p[i], n * 4); grkAlignedFree(p[i]); }
+}
+void ref_rct(int32_t* c0, int32_t* c1, int32_t* c2, uint64_t n) { mct_staged(c0, c1, c2, n, false); }
+void ref_ict(int32_t* c0, int32_t* c1, int32_t* c2, uint64_t n) { mct_staged(c0, c1, c2, n, true); }
 
 } // extern "C"
 template <typename T, typename DWT>
-static void fwd_levels(T* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+static void fwd_levels(T* user, uint32_t w, uint32_t h, uint32_t ustride, uint32_t levels)
 {
+	// aligned staging plane with the reference's own stride rule (util/MemManager.cpp:38-43)
+	uint32_t stride = (w + 31u) & ~31u;
+	T* plane = (T*)grkAlignedMalloc(((size_t)stride * h + 64) * sizeof(T));
+	for (uint32_t y = 0; y < h; ++y) memcpy(plane + (size_t)y * stride, user + (size_t)y * ustride, w * sizeof(T));
 	// resolution sizes for an origin-0 tile component: ceil(w / 2^l)
 	std::vector<uint32_t> rw(levels + 1), rh(levels + 1);
 	for (uint32_t l = 0; l <= levels; ++l) {
@@ -76,6 +88,8 @@ static void fwd_levels(T* plane, uint32_t w, uint32_t h, uint32_t stride, uint32
 			dwt.encode_and_deinterleave_h_one_row(plane + (size_t)r * stride, tmp, cw, true);
 	}
 	grkAlignedFree(tmp);
+	for (uint32_t y = 0; y < h; ++y) memcpy(user + (size_t)y * ustride, plane + (size_t)y * stride, w * sizeof(T));
+	grkAlignedFree(plane);
 }
 
 extern "C" {
@@ -86,14 +100,17 @@ void ref_dwt97_fwd(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32
 
 void ref_dwt53_row(int32_t* row, uint32_t n, int even)
 {
-	std::vector<int32_t> tmp(n + 16);
-	dwt53 d; d.encode_and_deinterleave_h_one_row(row, tmp.data(), n, even != 0);
+	int32_t* a = (int32_t*)grkAlignedMalloc((n + 16) * 4); memcpy(a, row, n * 4);
+	int32_t* tmp = (int32_t*)grkAlignedMalloc((n + 16) * 4);
+	dwt53 d; d.encode_and_deinterleave_h_one_row(a, tmp, n, even != 0);
+	memcpy(row, a, n * 4); grkAlignedFree(a); grkAlignedFree(tmp);
 }
 void ref_dwt97_row(float* row, uint32_t n, int even)
 {
+	float* a = (float*)grkAlignedMalloc((n + 16) * 4); memcpy(a, row, n * 4);
 	float* tmp = (float*)grkAlignedMalloc((n + 16) * sizeof(float));
-	dwt97 d; d.encode_and_deinterleave_h_one_row(row, tmp, n, even != 0);
-	grkAlignedFree(tmp);
+	dwt97 d; d.encode_and_deinterleave_h_one_row(a, tmp, n, even != 0);
+	memcpy(row, a, n * 4); grkAlignedFree(a); grkAlignedFree(tmp);
 }
 
 // HT cleanup encode of one block. `sm` = sign-magnitude words as produced by T1HT::preCompress.

@@ -1,0 +1,143 @@
+"""ctypes wrapper around oracle/liboracle_j2k.so (the plain-C CPU restatement; test infra only)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ODIR = os.path.join(_HERE, "..", "oracle")
+_lib = None
+
+
+class Block(C.Structure):
+    _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32),
+                ("res", C.c_uint8), ("band", C.c_uint8), ("kmax", C.c_uint8), ("comp", C.c_uint8),
+                ("bx", C.c_uint32), ("by", C.c_uint32)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(_ODIR, "liboracle_j2k.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", _ODIR, "oracle"])
+        L = C.CDLL(so)
+        L.orc_ht_encode_sm.restype = C.c_int32
+        L.orc_ht_encode_sm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_ht_encode_block_rev.restype = C.c_int32
+        L.orc_ht_encode_block_rev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_enumerate_blocks.restype = C.c_uint32
+        L.orc_enumerate_blocks.argtypes = [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_encode_tile_rev.restype = C.c_int32
+        L.orc_encode_tile_rev.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32,
+                                          C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        for f in ("orc_rct_fwd", "orc_ict_fwd", "orc_rct_inv"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+            getattr(L, f).restype = None
+        for f in ("orc_dwt53_fwd", "orc_dwt97_fwd", "orc_dwt53_inv"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+            getattr(L, f).restype = None
+        for f in ("orc_dwt53_fwd_1d", "orc_dwt97_fwd_1d"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_uint32]
+            getattr(L, f).restype = None
+        L.orc_ht_rev_exponents.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_ht_rev_exponents.restype = None
+        L.orc_ht_irrev_stepsizes.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_ht_irrev_stepsizes.restype = None
+        L.orc_ingest.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32]
+        L.orc_ingest.restype = None
+        L.orc_ht_signmag_rev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_ht_signmag_rev.restype = None
+        L.orc_ht_signmag_irrev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        L.orc_ht_signmag_irrev.restype = None
+        _lib = L
+    return _lib
+
+
+def signmag(coeffs, kmax):
+    c = np.asarray(coeffs, np.int64)
+    return (np.where(c < 0, 0x80000000, 0) | (np.abs(c) << (30 - kmax))).astype(np.uint32)
+
+
+def ht_encode_sm(sm, kmax):
+    a = np.ascontiguousarray(sm, np.uint32)
+    h, w = a.shape
+    out = np.zeros(w * h * 4 + 8192, np.uint8)
+    n = lib().orc_ht_encode_sm(a.ctypes.data, kmax, w, h, out.ctypes.data, out.size)
+    assert n >= 0
+    return out[:n].tobytes()
+
+
+def rev_exponents(prec, levels):
+    e = np.zeros(3 * levels + 1, np.uint8)
+    lib().orc_ht_rev_exponents(prec, levels, e.ctypes.data)
+    return e
+
+
+def irrev_stepsizes(prec, levels):
+    q = np.zeros(3 * levels + 1, np.uint16)
+    d = np.zeros(3 * levels + 1, np.float32)
+    lib().orc_ht_irrev_stepsizes(prec, levels, q.ctypes.data, d.ctypes.data)
+    return q, d
+
+
+def enumerate_blocks(w, h, levels, expn=None, cblk_exp=6):
+    L = lib()
+    e = None if expn is None else np.ascontiguousarray(expn, np.uint8)
+    n = L.orc_enumerate_blocks(w, h, levels, cblk_exp, e.ctypes.data if e is not None else None, None, 0)
+    arr = (Block * n)()
+    L.orc_enumerate_blocks(w, h, levels, cblk_exp, e.ctypes.data if e is not None else None, arr, n)
+    return list(arr)
+
+
+def dwt53_fwd(plane, levels):
+    p = np.ascontiguousarray(plane, np.int32).copy()
+    h, w = p.shape
+    lib().orc_dwt53_fwd(p.ctypes.data, w, h, w, levels)
+    return p
+
+
+def dwt97_fwd(plane, levels):
+    p = np.ascontiguousarray(plane, np.float32).copy()
+    h, w = p.shape
+    lib().orc_dwt97_fwd(p.ctypes.data, w, h, w, levels)
+    return p
+
+
+def dwt53_inv(plane, levels):
+    p = np.ascontiguousarray(plane, np.int32).copy()
+    h, w = p.shape
+    lib().orc_dwt53_inv(p.ctypes.data, w, h, w, levels)
+    return p
+
+
+def rct_fwd(r, g, b):
+    a = [np.ascontiguousarray(v, np.int32).copy() for v in (r, g, b)]
+    lib().orc_rct_fwd(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[0].size)
+    return a
+
+
+def ict_fwd(r, g, b):
+    a = [np.ascontiguousarray(v, np.int32).copy() for v in (r, g, b)]
+    lib().orc_ict_fwd(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[0].size)
+    return [v.view(np.float32) for v in a]
+
+
+def encode_tile_rev(pixels, prec, levels, mct=None):
+    """pixels (C,H,W) u8/u16 -> (blocks, lens, coded bytes) in reference enumeration order."""
+    px = np.ascontiguousarray(pixels)
+    Cn, H, W = px.shape
+    if mct is None:
+        mct = Cn >= 3
+    L = lib()
+    nb = L.orc_enumerate_blocks(W, H, levels, 6, None, None, 0) * Cn
+    blocks = (Block * nb)()
+    lens = np.zeros(nb, np.uint32)
+    cap = px.size * 4 + nb * 64 + (1 << 16)
+    coded = np.zeros(cap, np.uint8)
+    tot = C.c_uint64(0)
+    n = L.orc_encode_tile_rev(px.ctypes.data, px.dtype.itemsize, Cn, W, H, prec, levels, int(mct),
+                              blocks, lens.ctypes.data, nb, coded.ctypes.data, cap, C.byref(tot))
+    assert n == nb, n
+    return list(blocks), lens, coded[:tot.value]
