@@ -1,0 +1,208 @@
+"""ctypes binding of include/grok_amd.h (no compute in Python; fails loudly without the .so)."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_LEVELS = 10
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libgrok_amd.so")
+
+
+class TileParams(C.Structure):
+    _fields_ = [("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("num_comps", C.c_uint16),
+                ("prec", C.c_uint8), ("sgnd", C.c_uint8), ("irreversible", C.c_uint8),
+                ("mct", C.c_uint8), ("num_levels", C.c_uint8), ("cblk_w_exp", C.c_uint8),
+                ("cblk_h_exp", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+    @classmethod
+    def make(cls, w, h, comps, prec, levels, irreversible=False, mct=None, sgnd=False, cblk=(6, 6)):
+        if mct is None:
+            mct = comps >= 3
+        return cls(w, h, comps, prec, int(sgnd), int(irreversible), int(mct), levels, cblk[0], cblk[1])
+
+
+class Block(C.Structure):
+    _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
+                ("px", C.c_uint32), ("py", C.c_uint32), ("comp", C.c_uint16), ("res", C.c_uint8),
+                ("band", C.c_uint8), ("kmax", C.c_uint8), ("reserved", C.c_uint8 * 3),
+                ("stepsize", C.c_float)]
+
+
+class CodedBlock(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("length", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise NativeLibraryMissing(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % p)
+        L = C.CDLL(p)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        PP = C.POINTER(TileParams)
+        L.grk_amd_version.restype = C.c_char_p
+        L.grk_amd_last_error.restype = C.c_char_p
+        L.grk_amd_last_error.argtypes = [vp]
+        L.grk_amd_create.argtypes = [i32, i32, C.POINTER(vp)]
+        L.grk_amd_destroy.argtypes = [vp]
+        L.grk_amd_destroy.restype = None
+        L.grk_amd_set_stream.argtypes = [vp, vp]
+        L.grk_amd_tile_num_blocks.restype = C.c_int64
+        L.grk_amd_tile_num_blocks.argtypes = [PP]
+        L.grk_amd_tile_layout.restype = C.c_int64
+        L.grk_amd_tile_layout.argtypes = [PP, vp, u64, vp]
+        L.grk_amd_plane_stride.restype = u32
+        L.grk_amd_plane_stride.argtypes = [PP]
+        L.grk_amd_plane_elems.restype = u64
+        L.grk_amd_plane_elems.argtypes = [PP]
+        L.grk_amd_encode_tiles.argtypes = [vp, PP, u32, vp, i32, vp, C.POINTER(u64)]
+        L.grk_amd_fetch_table.argtypes = [vp, vp, C.POINTER(u64)]
+        L.grk_amd_fetch_coded.argtypes = [vp, vp, u64]
+        L.grk_amd_coded_device_ptr.restype = vp
+        L.grk_amd_coded_device_ptr.argtypes = [vp]
+        L.grk_amd_plane_device_ptr.restype = vp
+        L.grk_amd_plane_device_ptr.argtypes = [vp, i32]
+        L.grk_amd_synchronize.argtypes = [vp]
+        L.grk_amd_stage_ingest_mct.argtypes = [vp, PP, u32, vp, vp]
+        L.grk_amd_stage_dwt_fwd.argtypes = [vp, PP, u32, vp, vp]
+        L.grk_amd_stage_ht_encode.argtypes = [vp, PP, u32, vp]
+        L.grk_amd_enable_timing.argtypes = [vp, i32]
+        L.grk_amd_kernel_ms.restype = C.c_double
+        L.grk_amd_kernel_ms.argtypes = [vp, i32, C.POINTER(u32)]
+        L.grk_amd_write_codestream.restype = C.c_int64
+        L.grk_amd_write_codestream.argtypes = [PP, u32, u32, vp, vp, vp, u64]
+        _lib = L
+    return _lib
+
+
+def tile_layout(params):
+    """Host-only geometry: (list of Block, qcd words)."""
+    L = lib()
+    n = L.grk_amd_tile_num_blocks(C.byref(params))
+    if n < 0:
+        raise ValueError("grk_amd_tile_num_blocks failed: %d" % n)
+    blocks = (Block * n)()
+    qcd = (C.c_uint16 * (3 * MAX_LEVELS + 1))()
+    rc = L.grk_amd_tile_layout(C.byref(params), blocks, n, qcd)
+    if rc < 0:
+        raise ValueError("grk_amd_tile_layout failed: %d" % rc)
+    return list(blocks), list(qcd)[:3 * params.num_levels + 1]
+
+
+def write_codestream(params, img_w, img_h, table, coded):
+    """table: ctypes array / numpy structured array of CodedBlock rows; coded: bytes-like."""
+    L = lib()
+    cbuf = np.frombuffer(coded, np.uint8) if not isinstance(coded, np.ndarray) else coded
+    cap = int(cbuf.size) + len(table) * 8 + (1 << 20)
+    out = np.empty(cap, np.uint8)
+    tptr = table.ctypes.data if isinstance(table, np.ndarray) else C.addressof(table)
+    n = L.grk_amd_write_codestream(C.byref(params), img_w, img_h, tptr, cbuf.ctypes.data, out.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError("grk_amd_write_codestream failed: %d" % n)
+    return out[:n].tobytes()
+
+
+CODED_DTYPE = np.dtype([("offset", np.uint64), ("length", np.uint32), ("reserved", np.uint32)])
+
+
+class Context:
+    """One GPU context (grk_amd_ctx)."""
+
+    def __init__(self, device=0, verbose=False):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.grk_amd_create(device, int(verbose), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("grk_amd_create(device=%d) failed: %d (no usable HIP device?)" % (device, rc))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._L.grk_amd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %d (%s)" % (what, rc, self._L.grk_amd_last_error(self._h).decode()))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._L.grk_amd_set_stream(self._h, stream_ptr), "set_stream")
+
+    def synchronize(self):
+        self._check(self._L.grk_amd_synchronize(self._h), "synchronize")
+
+    def encode_tiles(self, params, ntiles, pixels_ptr, on_device, fetch=True):
+        """Runs the hot path. Returns (table ndarray, total_bytes) when fetch else None."""
+        if fetch:
+            n = self._L.grk_amd_tile_num_blocks(C.byref(params)) * ntiles
+            table = np.zeros(n, CODED_DTYPE)
+            tot = C.c_uint64(0)
+            self._check(self._L.grk_amd_encode_tiles(self._h, C.byref(params), ntiles, pixels_ptr, int(on_device),
+                                                     table.ctypes.data, C.byref(tot)), "encode_tiles")
+            return table, tot.value
+        self._check(self._L.grk_amd_encode_tiles(self._h, C.byref(params), ntiles, pixels_ptr, int(on_device),
+                                                 None, None), "encode_tiles")
+        return None
+
+    def encode_host(self, params, pixels, ntiles=1):
+        """pixels: numpy array holding the tiles back to back (host memory)."""
+        px = np.ascontiguousarray(pixels)
+        table, tot = self.encode_tiles(params, ntiles, px.ctypes.data, False)
+        coded = np.empty(tot, np.uint8)
+        if tot:
+            self._check(self._L.grk_amd_fetch_coded(self._h, coded.ctypes.data, tot), "fetch_coded")
+        return table, coded
+
+    def fetch_table(self, nblocks):
+        table = np.zeros(nblocks, CODED_DTYPE)
+        tot = C.c_uint64(0)
+        self._check(self._L.grk_amd_fetch_table(self._h, table.ctypes.data, C.byref(tot)), "fetch_table")
+        return table, tot.value
+
+    def fetch_coded(self, nbytes):
+        coded = np.empty(nbytes, np.uint8)
+        if nbytes:
+            self._check(self._L.grk_amd_fetch_coded(self._h, coded.ctypes.data, nbytes), "fetch_coded")
+        return coded
+
+    def coded_device_ptr(self):
+        return self._L.grk_amd_coded_device_ptr(self._h)
+
+    def plane_device_ptr(self, which):
+        return self._L.grk_amd_plane_device_ptr(self._h, which)
+
+    def stage_ingest_mct(self, params, ntiles, d_pixels, d_planes):
+        self._check(self._L.grk_amd_stage_ingest_mct(self._h, C.byref(params), ntiles, d_pixels, d_planes), "stage_ingest_mct")
+
+    def stage_dwt_fwd(self, params, nplanes, d_in, d_out):
+        self._check(self._L.grk_amd_stage_dwt_fwd(self._h, C.byref(params), nplanes, d_in, d_out), "stage_dwt_fwd")
+
+    def stage_ht_encode(self, params, ntiles, d_mallat):
+        self._check(self._L.grk_amd_stage_ht_encode(self._h, C.byref(params), ntiles, d_mallat), "stage_ht_encode")
+
+    def enable_timing(self, on=True):
+        self._check(self._L.grk_amd_enable_timing(self._h, int(on)), "enable_timing")
+
+    def kernel_ms(self, which):
+        n = C.c_uint32(0)
+        ms = self._L.grk_amd_kernel_ms(self._h, which, C.byref(n))
+        return ms, n.value

@@ -1,0 +1,430 @@
+// grok_amd/csrc/context.hip -- implementation of the C-ABI in include/grok_amd.h.
+//
+// One grk_amd_ctx per process per GPU.  All device memory is owned by the context and grows
+// monotonically (288 GB of HBM3E: an 8K x 8K x 3 tile needs ~3.6 GB of working planes, a batch of
+// 256 1024^2 tiles ~12 GB), so steady-state encode calls perform no allocation and enqueue
+// nothing but kernels on one HIP stream.
+#include "../../include/grok_amd.h"
+#include "geometry.h"
+#include "kernels.h"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+using namespace grk_amd;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = n + (n >> 3) + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Timer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double total_ms = 0; uint32_t launches = 0;
+};
+
+} // namespace
+
+struct grk_amd_ctx {
+    int device = 0;
+    int verbose = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // working set
+    DevBuf pixels, p0, p1, llA, llB, blockdesc, slots, lengths, offsets, arena, flag;
+    // geometry cache
+    grk_amd_tile_params gp{};
+    bool have_geom = false;
+    TileGeom geom;
+    std::vector<HtBlockDesc> h_desc;
+    uint32_t last_ntiles = 0;
+    uint64_t last_nblocks = 0;
+    // timing
+    bool timing = false;
+    Timer timers[4];
+};
+
+namespace {
+
+int fail(grk_amd_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+        if (c->verbose) fprintf(stderr, "[grok_amd] %s\n", c->err.c_str());
+    }
+    return code;
+}
+
+#define HIP_TRY(c, call, what)                                                      \
+    do { hipError_t _e = (call); if (_e != hipSuccess) return fail(c, GRK_AMD_ERR_NO_DEVICE, what, _e); } while (0)
+
+bool same_params(const grk_amd_tile_params& a, const grk_amd_tile_params& b)
+{
+    return a.tile_w == b.tile_w && a.tile_h == b.tile_h && a.num_comps == b.num_comps && a.prec == b.prec &&
+           a.sgnd == b.sgnd && a.irreversible == b.irreversible && a.mct == b.mct &&
+           a.num_levels == b.num_levels && a.cblk_w_exp == b.cblk_w_exp && a.cblk_h_exp == b.cblk_h_exp;
+}
+
+int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
+{
+    if (c->have_geom && same_params(c->gp, *p)) return GRK_AMD_OK;
+    int rc = build_tile_geom(*p, c->geom);
+    if (rc != GRK_AMD_OK) return fail(c, rc, "unsupported tile parameters");
+    c->gp = *p;
+    c->have_geom = true;
+    const TileGeom& g = c->geom;
+    c->h_desc.clear();
+    for (uint32_t k = 0; k < p->num_comps; ++k)
+        for (const auto& b : g.blocks_comp0) {
+            HtBlockDesc d;
+            d.px = b.px; d.py = b.py;
+            d.w = (uint16_t)(b.x1 - b.x0); d.h = (uint16_t)(b.y1 - b.y0);
+            d.comp = (uint16_t)k; d.kmax = b.kmax; d.pad = 0;
+            d.inv_step = 1.0f / b.stepsize;
+            c->h_desc.push_back(d);
+        }
+    HIP_TRY(c, c->blockdesc.ensure(c->h_desc.size() * sizeof(HtBlockDesc)), "alloc block table");
+    HIP_TRY(c, hipMemcpyAsync(c->blockdesc.p, c->h_desc.data(), c->h_desc.size() * sizeof(HtBlockDesc),
+                              hipMemcpyHostToDevice, c->stream), "upload block table");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync block table");
+    return GRK_AMD_OK;
+}
+
+struct ScopedTimer {
+    grk_amd_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(grk_amd_ctx* c_, int w) : c(c_), which(w)
+    {
+        if (!c->timing) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ScopedTimer()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->timers[which].ev.emplace_back(a, b);
+    }
+};
+
+void drain_timers(grk_amd_ctx* c)
+{
+    for (auto& t : c->timers) {
+        for (auto& pr : t.ev) {
+            float ms = 0;
+            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                t.total_ms += ms; t.launches++;
+            }
+            (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+        }
+        t.ev.clear();
+    }
+}
+
+uint32_t ll_stride_for(uint32_t w) { return (((w + 1) >> 1) + 31u) & ~31u; }
+
+int run_ingest(grk_amd_ctx* c, uint32_t ntiles, const void* d_pixels, void* d_planes)
+{
+    const TileGeom& g = c->geom;
+    IngestArgs a{};
+    a.pixels = d_pixels; a.planes = (int32_t*)d_planes;
+    a.w = g.p.tile_w; a.h = g.p.tile_h; a.stride = g.stride; a.pitch = g.plane_elems;
+    a.ncomp = g.p.num_comps; a.ntiles = ntiles;
+    a.bytes_per_sample = (g.p.prec + 7) / 8;
+    a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
+    a.mct = g.p.mct; a.irreversible = g.p.irreversible;
+    ScopedTimer t(c, 0);
+    HIP_TRY(c, launch_ingest(a, c->stream), "launch ingest");
+    return GRK_AMD_OK;
+}
+
+int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out)
+{
+    const TileGeom& g = c->geom;
+    const uint32_t L = g.p.num_levels;
+    const uint32_t W = g.p.tile_w, H = g.p.tile_h;
+    if (L == 0) {
+        HIP_TRY(c, hipMemcpyAsync(d_out, d_in, (size_t)nplanes * g.plane_elems * 4, hipMemcpyDeviceToDevice, c->stream), "copy planes");
+        return GRK_AMD_OK;
+    }
+    // LL ping-pong storage: A holds LL1, LL3, ...; B holds LL2, LL4, ...
+    const uint32_t sA = ll_stride_for(W), hA = (H + 1) >> 1;
+    const uint32_t sB = ll_stride_for((W + 1) >> 1), hB = (hA + 1) >> 1;
+    const uint64_t pitchA = (uint64_t)sA * hA, pitchB = (uint64_t)sB * hB;
+    HIP_TRY(c, c->llA.ensure((size_t)nplanes * pitchA * 4 + 256), "alloc LL ping");
+    HIP_TRY(c, c->llB.ensure((size_t)nplanes * pitchB * 4 + 256), "alloc LL pong");
+    ScopedTimer t(c, 1);
+    for (uint32_t l = 0; l < L; ++l) {
+        DwtLevelArgs a{};
+        a.cw = ceil_div_pow2(W, l); a.ch = ceil_div_pow2(H, l);
+        if (l == 0) { a.in = (const int32_t*)d_in; a.in_stride = g.stride; a.in_pitch = g.plane_elems; }
+        else if (l & 1) { a.in = (const int32_t*)c->llA.p; a.in_stride = sA; a.in_pitch = pitchA; }
+        else { a.in = (const int32_t*)c->llB.p; a.in_stride = sB; a.in_pitch = pitchB; }
+        a.mallat = (int32_t*)d_out; a.m_stride = g.stride; a.m_pitch = g.plane_elems;
+        if (l + 1 == L) { a.ll = (int32_t*)d_out; a.ll_stride = g.stride; a.ll_pitch = g.plane_elems; }
+        else if ((l + 1) & 1) { a.ll = (int32_t*)c->llA.p; a.ll_stride = sA; a.ll_pitch = pitchA; }
+        else { a.ll = (int32_t*)c->llB.p; a.ll_stride = sB; a.ll_pitch = pitchB; }
+        a.nplanes = nplanes;
+        a.irreversible = g.p.irreversible;
+        // enough workgroups to cover the chip several times, few enough to amortise warm-up rows
+        const uint32_t sh = (a.ch + 1) >> 1;
+        uint32_t seg = 64;
+        const uint64_t strips = (a.cw + 503) / 504;
+        while (seg > 8 && strips * ((sh + seg - 1) / seg) * nplanes < 4096) seg >>= 1;
+        a.seg_pairs = seg;
+        HIP_TRY(c, launch_dwt_level(a, c->stream), "launch dwt level");
+    }
+    return GRK_AMD_OK;
+}
+
+uint32_t slot_bytes_for(const TileGeom& g, uint32_t& max_kmax, uint32_t& max_samples)
+{
+    max_kmax = 0; max_samples = 0;
+    for (const auto& b : g.blocks_comp0) {
+        max_kmax = std::max<uint32_t>(max_kmax, b.kmax);
+        max_samples = std::max<uint32_t>(max_samples, (b.x1 - b.x0) * (b.y1 - b.y0));
+    }
+    // MagSgn: <= (kmax+1) bits/sample, 8/7 stuffing worst case; MEL <= 192 B; VLC <= 4 KiB
+    uint64_t ms = ((uint64_t)max_samples * (max_kmax + 2) + 7) / 8;
+    ms = ms * 8 / 7 + 64;
+    return (uint32_t)((ms + 192 + 4096 + 255) & ~255ull);
+}
+
+int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
+{
+    const TileGeom& g = c->geom;
+    const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
+    const uint64_t nblocks = (uint64_t)bpt * ntiles;
+    uint32_t max_kmax, max_samples;
+    const uint32_t slot = slot_bytes_for(g, max_kmax, max_samples);
+    HIP_TRY(c, c->slots.ensure(nblocks * slot), "alloc block slots");
+    HIP_TRY(c, c->lengths.ensure(nblocks * 4), "alloc lengths");
+    HIP_TRY(c, c->offsets.ensure((nblocks + 1) * 8), "alloc offsets");
+    HIP_TRY(c, c->flag.ensure(64), "alloc flag");
+    // arena: generous bound = half of the slot space (typical lossless output is ~50% of 1 B/sample)
+    const uint64_t raw = (uint64_t)ntiles * g.p.num_comps * g.p.tile_w * g.p.tile_h * ((g.p.prec + 7) / 8);
+    HIP_TRY(c, c->arena.ensure(raw * 2 + nblocks * 32 + (1u << 20)), "alloc coded arena");
+    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, 64, c->stream), "clear flag");
+    HtArgs a{};
+    a.mallat = (const int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
+    a.blocks = (const HtBlockDesc*)c->blockdesc.p; a.blocks_per_tile = bpt; a.ncomp = g.p.num_comps; a.ntiles = ntiles;
+    a.slots = (uint8_t*)c->slots.p; a.slot_bytes = slot; a.lengths = (uint32_t*)c->lengths.p;
+    a.irreversible = g.p.irreversible; a.max_kmax = max_kmax; a.max_block_samples = max_samples;
+    CompactArgs k{};
+    k.slots = a.slots; k.slot_bytes = slot; k.lengths = a.lengths; k.nblocks = (uint32_t)nblocks;
+    k.offsets = (uint64_t*)c->offsets.p; k.arena = (uint8_t*)c->arena.p; k.arena_bytes = c->arena.cap;
+    k.overflow_flag = (uint32_t*)c->flag.p;
+    ScopedTimer t(c, 2);
+    HIP_TRY(c, launch_ht_encode(a, c->stream), "launch ht encode");
+    HIP_TRY(c, launch_compact(k, c->stream), "launch compaction");
+    c->last_ntiles = ntiles;
+    c->last_nblocks = nblocks;
+    return GRK_AMD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* grk_amd_version(void) { return "grok_amd 0.1 (gfx950)"; }
+
+int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
+{
+    if (!out) return GRK_AMD_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GRK_AMD_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return GRK_AMD_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return GRK_AMD_ERR_NO_DEVICE;
+    auto* c = new grk_amd_ctx();
+    c->device = device_id; c->verbose = verbose;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GRK_AMD_ERR_NO_DEVICE; }
+    c->own_stream = true;
+    *out = c;
+    return GRK_AMD_OK;
+}
+
+void grk_amd_destroy(grk_amd_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->slots, &c->lengths,
+                      &c->offsets, &c->arena, &c->flag})
+        b->release();
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* grk_amd_last_error(grk_amd_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int grk_amd_set_stream(grk_amd_ctx* c, void* s)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (s) c->stream = (hipStream_t)s;
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return GRK_AMD_ERR_NO_DEVICE;
+        c->own_stream = true;
+    }
+    return GRK_AMD_OK;
+}
+
+int64_t grk_amd_tile_num_blocks(const grk_amd_tile_params* p)
+{
+    if (!p) return GRK_AMD_ERR_INVALID;
+    TileGeom g;
+    int rc = build_tile_geom(*p, g);
+    if (rc != GRK_AMD_OK) return rc;
+    return (int64_t)g.blocks_per_comp * p->num_comps;
+}
+
+int64_t grk_amd_tile_layout(const grk_amd_tile_params* p, grk_amd_block* blocks, uint64_t cap, uint16_t* qcd)
+{
+    if (!p) return GRK_AMD_ERR_INVALID;
+    TileGeom g;
+    int rc = build_tile_geom(*p, g);
+    if (rc != GRK_AMD_OK) return rc;
+    const uint64_t n = (uint64_t)g.blocks_per_comp * p->num_comps;
+    if (blocks) {
+        if (cap < n) return GRK_AMD_ERR_INVALID;
+        uint64_t i = 0;
+        for (uint32_t k = 0; k < p->num_comps; ++k)
+            for (auto b : g.blocks_comp0) { b.comp = (uint16_t)k; blocks[i++] = b; }
+    }
+    if (qcd) std::memcpy(qcd, g.qcd_words, sizeof(uint16_t) * g.num_bands_total);
+    return (int64_t)n;
+}
+
+uint32_t grk_amd_plane_stride(const grk_amd_tile_params* p) { return p ? ((p->tile_w + 31u) & ~31u) : 0; }
+uint64_t grk_amd_plane_elems(const grk_amd_tile_params* p) { return p ? (uint64_t)grk_amd_plane_stride(p) * p->tile_h : 0; }
+
+int grk_amd_stage_ingest_mct(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const void* d_pixels, void* d_planes)
+{
+    if (!c || !p || !d_pixels || !d_planes) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    int rc = ensure_geom(c, p); if (rc) return rc;
+    return run_ingest(c, ntiles, d_pixels, d_planes);
+}
+
+int grk_amd_stage_dwt_fwd(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nplanes, void* d_in, void* d_out)
+{
+    if (!c || !p || !d_in || !d_out) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    int rc = ensure_geom(c, p); if (rc) return rc;
+    return run_dwt(c, nplanes, d_in, d_out);
+}
+
+int grk_amd_stage_ht_encode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const void* d_mallat)
+{
+    if (!c || !p || !d_mallat) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    int rc = ensure_geom(c, p); if (rc) return rc;
+    return run_ht(c, ntiles, d_mallat);
+}
+
+int grk_amd_fetch_table(grk_amd_ctx* c, grk_amd_coded_block* table, uint64_t* total)
+{
+    if (!c || !c->last_nblocks) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    const uint64_t n = c->last_nblocks;
+    std::vector<uint64_t> off(n + 1);
+    std::vector<uint32_t> len(n);
+    uint32_t flag = 0;
+    HIP_TRY(c, hipMemcpyAsync(off.data(), c->offsets.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream), "fetch offsets");
+    HIP_TRY(c, hipMemcpyAsync(len.data(), c->lengths.p, n * 4, hipMemcpyDeviceToHost, c->stream), "fetch lengths");
+    HIP_TRY(c, hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream), "fetch flag");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    if (flag) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
+    if (table)
+        for (uint64_t i = 0; i < n; ++i) { table[i].offset = off[i]; table[i].length = len[i]; table[i].reserved = 0; }
+    if (total) *total = off[n];
+    return GRK_AMD_OK;
+}
+
+int grk_amd_fetch_coded(grk_amd_ctx* c, uint8_t* dst, uint64_t nbytes)
+{
+    if (!c || !dst) return GRK_AMD_ERR_INVALID;
+    if (nbytes > c->arena.cap) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    HIP_TRY(c, hipMemcpyAsync(dst, c->arena.p, nbytes, hipMemcpyDeviceToHost, c->stream), "fetch coded");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    return GRK_AMD_OK;
+}
+
+void* grk_amd_coded_device_ptr(grk_amd_ctx* c) { return c ? c->arena.p : nullptr; }
+void* grk_amd_plane_device_ptr(grk_amd_ctx* c, int which) { return c ? (which ? c->p1.p : c->p0.p) : nullptr; }
+
+int grk_amd_synchronize(grk_amd_ctx* c)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    return GRK_AMD_OK;
+}
+
+int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const void* pixels,
+                         int on_device, grk_amd_coded_block* table, uint64_t* total)
+{
+    if (!c || !p || !pixels || ntiles == 0) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    int rc = ensure_geom(c, p); if (rc) return rc;
+    const TileGeom& g = c->geom;
+    const size_t tile_bytes = (size_t)g.p.num_comps * g.p.tile_w * g.p.tile_h * ((g.p.prec + 7) / 8);
+    const void* d_px = pixels;
+    if (!on_device) {
+        HIP_TRY(c, c->pixels.ensure(tile_bytes * ntiles), "alloc pixel staging");
+        HIP_TRY(c, hipMemcpyAsync(c->pixels.p, pixels, tile_bytes * ntiles, hipMemcpyHostToDevice, c->stream), "upload pixels");
+        d_px = c->pixels.p;
+    }
+    const uint32_t nplanes = ntiles * g.p.num_comps;
+    HIP_TRY(c, c->p0.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc planes");
+    HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
+    {
+        ScopedTimer t(c, 3);
+        rc = run_ingest(c, ntiles, d_px, c->p0.p); if (rc) return rc;
+        rc = run_dwt(c, nplanes, c->p0.p, c->p1.p); if (rc) return rc;
+        rc = run_ht(c, ntiles, c->p1.p); if (rc) return rc;
+    }
+    if (table || total) return grk_amd_fetch_table(c, table, total);
+    return GRK_AMD_OK;
+}
+
+int grk_amd_enable_timing(grk_amd_ctx* c, int on)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    for (auto& t : c->timers) { t.total_ms = 0; t.launches = 0; }
+    c->timing = on != 0;
+    return GRK_AMD_OK;
+}
+
+double grk_amd_kernel_ms(grk_amd_ctx* c, int which, uint32_t* launches)
+{
+    if (!c || which < 0 || which > 3) return -1.0;
+    (void)hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    if (launches) *launches = c->timers[which].launches;
+    return c->timers[which].launches ? c->timers[which].total_ms / c->timers[which].launches : 0.0;
+}
+
+} // extern "C"

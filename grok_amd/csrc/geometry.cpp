@@ -1,0 +1,133 @@
+// grok_amd/csrc/geometry.cpp -- see geometry.h for the reference citations.
+#include "geometry.h"
+#include <cmath>
+#include <cstring>
+
+namespace grk_amd {
+
+// BIBO gains of the 5/3 analysis filter bank indexed by decomposition count; these are the
+// constants OpenJPH/Grok use to size the reversible HT exponents (codestream/HTParams.cpp:139-154).
+static const float kBibo53L[] = {1.0000e+00f, 1.5000e+00f, 1.6250e+00f, 1.6875e+00f, 1.6963e+00f,
+                                 1.7067e+00f, 1.7116e+00f, 1.7129e+00f, 1.7141e+00f, 1.7145e+00f,
+                                 1.7151e+00f, 1.7152e+00f};
+static const float kBibo53H[] = {2.0000e+00f, 2.5000e+00f, 2.7500e+00f, 2.8047e+00f, 2.8198e+00f,
+                                 2.8410e+00f, 2.8558e+00f, 2.8601e+00f, 2.8628e+00f, 2.8656e+00f,
+                                 2.8662e+00f, 2.8667e+00f};
+// sqrt of the 9/7 synthesis energy gains (HTParams.cpp:72-87)
+static const float kGain97L[] = {1.0000e+00f, 1.4021e+00f, 2.0304e+00f, 2.9012e+00f, 4.1153e+00f,
+                                 5.8245e+00f, 8.2388e+00f, 1.1652e+01f, 1.6479e+01f, 2.3304e+01f,
+                                 3.2957e+01f, 4.6609e+01f};
+static const float kGain97H[] = {1.4425e+00f, 1.9669e+00f, 2.8839e+00f, 4.1475e+00f, 5.8946e+00f,
+                                 8.3472e+00f, 1.1809e+01f, 1.6701e+01f, 2.3620e+01f, 3.3403e+01f,
+                                 4.7240e+01f, 6.6807e+01f};
+
+static int guard_log2(float g) { return (int)std::ceil(std::log(g * 1.1f) / M_LN2); }
+
+static uint16_t irrev_word(float delta)
+{
+    uint32_t e = 0;
+    while (delta < 1.0f) { ++e; delta *= 2.0f; }
+    uint32_t mant = (uint32_t)std::round(delta * (float)(1 << 11)) - (1u << 11);
+    if (mant >= (1u << 11)) mant = 0x7FF;
+    return (uint16_t)((e << 11) | mant);
+}
+
+// QCD words in marker order [LL, then per resolution HL LH HH].
+// Reversible: Grok calls qcd.generate() before tcp->mct is set, so the RCT guard bit is never
+// added -- reproduced here on purpose.
+static void make_qcd(const grk_amd_tile_params& p, uint16_t* w)
+{
+    const uint32_t L = p.num_levels;
+    uint32_t s = 0;
+    if (!p.irreversible) {
+        int B = p.prec;
+        w[s++] = (uint16_t)((B + guard_log2(kBibo53L[L] * kBibo53L[L])) << 3);
+        for (int d = (int)L - 1; d >= 0; --d) {
+            float l = kBibo53L[d + 1], h = kBibo53H[d];
+            uint16_t x = (uint16_t)((B + guard_log2(h * l)) << 3);
+            w[s++] = x; w[s++] = x;
+            w[s++] = (uint16_t)((B + guard_log2(h * h)) << 3);
+        }
+    } else {
+        float base = 1.0f / (float)(1u << (p.prec + (p.sgnd ? 1 : 0)));
+        w[s++] = irrev_word(base / (kGain97L[L] * kGain97L[L]));
+        for (int d = (int)L - 1; d >= 0; --d) {
+            float l = kGain97L[d + 1], h = kGain97H[d];
+            uint16_t x = irrev_word(base / (l * h));
+            w[s++] = x; w[s++] = x;
+            w[s++] = irrev_word(base / (h * h));
+        }
+    }
+}
+
+int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
+{
+    if (p.tile_w == 0 || p.tile_h == 0 || p.num_comps == 0 || p.num_comps > 4) return GRK_AMD_ERR_INVALID;
+    if (p.prec == 0 || p.prec > 16) return GRK_AMD_ERR_UNSUPPORTED;
+    if (p.num_levels > GRK_AMD_MAX_LEVELS) return GRK_AMD_ERR_UNSUPPORTED;
+    if (p.cblk_w_exp < 2 || p.cblk_w_exp > 6 || p.cblk_h_exp < 2 || p.cblk_h_exp > 6) return GRK_AMD_ERR_UNSUPPORTED;
+    if (p.mct && p.num_comps < 3) return GRK_AMD_ERR_INVALID;
+    // one precinct per resolution (default exponent 15, CodeStreamCompress.cpp:514-518)
+    if (p.tile_w > 32768 || p.tile_h > 32768) return GRK_AMD_ERR_UNSUPPORTED;
+
+    g.p = p;
+    g.stride = (p.tile_w + 31u) & ~31u;                       // util/MemManager.cpp:38-43
+    g.plane_elems = (uint64_t)g.stride * p.tile_h;
+    const uint32_t L = p.num_levels;
+    make_qcd(p, g.qcd_words);
+    g.num_bands_total = 3 * L + 1;
+    g.res.assign(L + 1, ResGeom{});
+    g.blocks_comp0.clear();
+    const uint32_t cbw = 1u << p.cblk_w_exp, cbh = 1u << p.cblk_h_exp;
+    uint32_t nblk = 0;
+    for (uint32_t r = 0; r <= L; ++r) {
+        ResGeom& R = g.res[r];
+        R.w = ceil_div_pow2(p.tile_w, L - r);
+        R.h = ceil_div_pow2(p.tile_h, L - r);
+        uint32_t lw = r ? ceil_div_pow2(p.tile_w, L - r + 1) : 0;
+        uint32_t lh = r ? ceil_div_pow2(p.tile_h, L - r + 1) : 0;
+        R.num_bands = r ? 3 : 1;
+        for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
+            BandGeom& B = R.band[bi];
+            B.orient = (uint8_t)(r ? bi + 1 : 0);
+            B.w = r ? ((B.orient & 1) ? R.w - lw : lw) : R.w;
+            B.h = r ? ((B.orient & 2) ? R.h - lh : lh) : R.h;
+            B.ox = (B.orient & 1) ? lw : 0;
+            B.oy = (B.orient & 2) ? lh : 0;
+            uint32_t qi = r ? 3 * (r - 1) + 1 + bi : 0;
+            B.qcd = g.qcd_words[qi];
+            uint32_t gain = B.orient == 0 ? 0 : (B.orient == 3 ? 2 : 1);
+            if (!p.irreversible) {
+                uint32_t expn = B.qcd >> 3;
+                B.kmax = (uint8_t)expn;                       // numbps = expn + numgbits(1) - 1
+                B.stepsize = (float)std::pow(2.0, (int)(p.prec + gain) - (int)expn);
+            } else {
+                uint32_t expn = B.qcd >> 11, mant = B.qcd & 0x7FF;
+                B.kmax = (uint8_t)expn;
+                B.stepsize = (float)((1.0 + mant / 2048.0) * std::pow(2.0, (int)(p.prec + gain) - (int)expn));
+            }
+            if (B.kmax > 30) return GRK_AMD_ERR_UNSUPPORTED;
+            B.first_block = nblk;
+            if (B.w == 0 || B.h == 0) { B.gw = B.gh = 0; continue; }
+            B.gw = (B.w + cbw - 1) >> p.cblk_w_exp;
+            B.gh = (B.h + cbh - 1) >> p.cblk_h_exp;
+            for (uint32_t by = 0; by < B.gh; ++by)
+                for (uint32_t bx = 0; bx < B.gw; ++bx) {
+                    grk_amd_block b;
+                    std::memset(&b, 0, sizeof(b));
+                    b.x0 = bx * cbw; b.y0 = by * cbh;
+                    b.x1 = (bx + 1) * cbw < B.w ? (bx + 1) * cbw : B.w;
+                    b.y1 = (by + 1) * cbh < B.h ? (by + 1) * cbh : B.h;
+                    b.px = B.ox + b.x0; b.py = B.oy + b.y0;
+                    b.comp = 0; b.res = (uint8_t)r; b.band = B.orient; b.kmax = B.kmax;
+                    b.stepsize = B.stepsize;
+                    g.blocks_comp0.push_back(b);
+                    ++nblk;
+                }
+        }
+    }
+    g.blocks_per_comp = nblk;
+    return GRK_AMD_OK;
+}
+
+} // namespace grk_amd

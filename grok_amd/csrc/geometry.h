@@ -1,0 +1,47 @@
+// grok_amd/csrc/geometry.h -- host-side tile geometry and quantiser parameters.
+//
+// Restates, for the hot path's restricted case (dx=dy=1, tile origin on a 2^levels grid, one
+// precinct per resolution), what the reference derives in
+//   tile/TileComponent.cpp:69-170 (resolutions / bands),  util/util.cpp:34-59 (band windows),
+//   t1/T1Structs.cpp:109-136, :449-493 (precinct + code-block grid),
+//   tile/TileComponentWindowBuffer.h:287-313 (block origin in the Mallat plane),
+//   codestream/HTParams.cpp:248-312 + codestream/Quantizer.cpp:26-66 (exponents, Kmax, step).
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "../../include/grok_amd.h"
+
+namespace grk_amd {
+
+struct BandGeom {
+    uint8_t  orient;        // 0 LL 1 HL 2 LH 3 HH
+    uint32_t w, h;          // band size
+    uint32_t ox, oy;        // origin in the Mallat plane
+    uint32_t gw, gh;        // code-block grid of the (single) precinct
+    uint8_t  kmax;          // numbps
+    uint16_t qcd;           // SPqcd word (expn<<3 | or expn<<11|mant)
+    float    stepsize;      // band->stepsize on the encoder side
+    uint32_t first_block;   // index (within the component) of the band's first block
+};
+struct ResGeom {
+    uint32_t w, h;
+    uint32_t num_bands;
+    BandGeom band[3];
+};
+struct TileGeom {
+    grk_amd_tile_params p;
+    uint32_t stride;                 // plane row stride in elements
+    uint64_t plane_elems;            // elements per plane
+    std::vector<ResGeom> res;        // levels+1, coarsest first
+    std::vector<grk_amd_block> blocks_comp0;   // blocks of one component
+    uint32_t blocks_per_comp;
+    uint16_t qcd_words[3 * GRK_AMD_MAX_LEVELS + 1];
+    uint32_t num_bands_total;
+};
+
+// returns GRK_AMD_OK or an error code
+int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g);
+
+inline uint32_t ceil_div_pow2(uint32_t v, uint32_t n) { return (uint32_t)(((uint64_t)v + (1ull << n) - 1) >> n); }
+
+} // namespace grk_amd

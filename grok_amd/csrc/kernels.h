@@ -1,0 +1,64 @@
+// grok_amd/csrc/kernels.h -- host-callable launchers of the gfx950 kernels.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace grk_amd {
+
+// ---- K1: ingest + DC shift + forward colour transform (kernels_ingest.hip) -------------------
+struct IngestArgs {
+    const void* pixels;      // tiles back to back, component-major planar, tight
+    int32_t*    planes;      // [tile][comp] planes, `stride` elements per row, `pitch` per plane
+    uint32_t w, h, stride;
+    uint64_t pitch;
+    uint32_t ncomp, ntiles;
+    uint32_t bytes_per_sample;   // 1 or 2
+    int32_t  dc;                 // 2^(prec-1) or 0
+    int      mct;                // apply RCT/ICT to components 0..2
+    int      irreversible;
+};
+hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
+
+// ---- K2: one forward DWT level, vertical + horizontal fused (kernels_dwt.hip) ----------------
+struct DwtLevelArgs {
+    const int32_t* in;  uint32_t in_stride;  uint64_t in_pitch;    // current LL, cw x ch
+    int32_t* ll;        uint32_t ll_stride;  uint64_t ll_pitch;    // next LL (sw x sh)
+    int32_t* mallat;    uint32_t m_stride;   uint64_t m_pitch;     // HL/LH/HH go to their Mallat slots
+    uint32_t cw, ch;      // size of the level being transformed
+    uint32_t nplanes;
+    uint32_t seg_pairs;   // row pairs per workgroup
+    int      irreversible;
+};
+hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s);
+
+// ---- K3: HT cleanup encoder, one wavefront per code-block (kernels_ht.hip) -------------------
+struct HtBlockDesc {        // one per code-block of a tile-component set (all comps of one tile)
+    uint32_t px, py;        // origin in the plane
+    uint16_t w, h;
+    uint16_t comp;
+    uint8_t  kmax;
+    uint8_t  pad;
+    float    inv_step;      // 1/stepsize (irreversible)
+};
+struct HtArgs {
+    const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp]
+    const HtBlockDesc* blocks; uint32_t blocks_per_tile; uint32_t ncomp; uint32_t ntiles;
+    uint8_t*  slots;  uint32_t slot_bytes;      // per-block scratch slots
+    uint32_t* lengths;                          // [ntiles*blocks_per_tile]
+    int irreversible;
+    uint32_t max_kmax;            // largest kmax among the blocks (sizes the raw MagSgn LDS buffer)
+    uint32_t max_block_samples;   // largest w*h among the blocks
+};
+hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);
+
+// ---- K4: offsets (exclusive scan of lengths, 16-byte aligned) + compaction -------------------
+struct CompactArgs {
+    const uint8_t* slots; uint32_t slot_bytes;
+    const uint32_t* lengths; uint32_t nblocks;
+    uint64_t* offsets;          // [nblocks+1]; offsets[nblocks] = total
+    uint8_t* arena; uint64_t arena_bytes;
+    uint32_t* overflow_flag;
+};
+hipError_t launch_compact(const CompactArgs& a, hipStream_t s);
+
+} // namespace grk_amd

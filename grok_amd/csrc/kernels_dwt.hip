@@ -1,0 +1,225 @@
+// grok_amd/csrc/kernels_dwt.hip -- K2: one forward DWT level (5/3 int32 or 9/7 fp32), gfx950.
+//
+// Replaces one iteration of WaveletFwdImpl::encode_procedure (transform/WaveletFwd.cpp:478-604):
+// the reference runs a vertical pass over all columns and then a horizontal pass over all rows,
+// in place, with a de-interleave copy each (>= 4 full sweeps of the level through memory).
+// Here both passes are fused so every sample of the level is read once and written once
+// (8 bytes / sample / level = the algorithmic figure of SURVEY.md §8d):
+//
+//  * a workgroup (256 threads) owns a column strip of 504 output columns (+4 halo columns each
+//    side) and a segment of `seg_pairs` output row pairs; it streams down the rows;
+//  * vertical lifting runs in registers as a recurrence per column (two columns per lane ->
+//    8-byte coalesced loads, 512 B per wave per row); state is 2 (5/3) or 4 (9/7) values, so
+//    there is no vertical halo re-read except the 2..5 warm-up rows at a segment start;
+//  * each finished pair of rows (one low, one high) is exchanged through a double-buffered LDS
+//    line (4 KiB) and every lane produces one (low,high) output pair per line with the local
+//    lifting stencil; outputs go straight to the LL ping-pong plane and to the HL/LH/HH slots of
+//    the Mallat plane, 256 B contiguous per wave.
+//
+// Image borders use whole-sample symmetric extension by index mirroring, which reproduces the
+// reference's edge formulas exactly (the mirrored operands are the same numbers; A.3/A.4).
+// fp32 9/7: (l + r) * c and the accumulate are separately rounded (__fadd_rn/__fmul_rn, no FMA),
+// the order of WaveletFwd.cpp:143-160; scaling low*invK, high*K as in :46, :203-213.
+#include "kernels.h"
+#include <type_traits>
+
+namespace grk_amd {
+
+namespace {
+
+constexpr int   kThreads  = 256;
+constexpr int   kCols     = 2 * kThreads;      // columns staged per line
+constexpr int   kHalo     = 4;                 // columns each side
+constexpr int   kOutCols  = kCols - 2 * kHalo; // 504
+
+__device__ __forceinline__ uint32_t mirror_idx(int32_t i, uint32_t n)
+{
+    if (n == 1) return 0;
+    const int32_t p = 2 * ((int32_t)n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    return (uint32_t)(i < (int32_t)n ? i : p - i);
+}
+
+constexpr float kAlpha = -1.586134342f;
+constexpr float kBeta  = -0.052980118f;
+constexpr float kGamma = 0.882911075f;
+constexpr float kDelta = 0.443506852f;
+constexpr float kK     = 1.230174105f;
+
+__device__ __forceinline__ float lift(float x, float l, float r, float c)
+{
+    return __fadd_rn(x, __fmul_rn(__fadd_rn(l, r), c));
+}
+
+// ---- per-column vertical recurrences ---------------------------------------------------------
+struct V53 {
+    int32_t xe, dp;
+    __device__ __forceinline__ void init(int32_t x_even) { xe = x_even; dp = 0; }
+    // consumes x[2i+1], x[2i+2]; yields pair i
+    __device__ __forceinline__ void step(int32_t x1, int32_t x2, int32_t& s, int32_t& d)
+    {
+        d = x1 - ((xe + x2) >> 1);
+        s = xe + ((dp + d + 2) >> 2);
+        xe = x2; dp = d;
+    }
+};
+struct V97 {
+    float xe, a1, b2, c3;
+    __device__ __forceinline__ void init(float x_even) { xe = x_even; a1 = b2 = c3 = 0.f; }
+    // consumes x[2i+1], x[2i+2]; yields pair i-1
+    __device__ __forceinline__ void step(float x1, float x2, float& s, float& d, float inv_k)
+    {
+        float a = lift(x1, xe, x2, kAlpha);
+        float b = lift(xe, a1, a, kBeta);
+        float c = lift(a1, b2, b, kGamma);
+        float e = lift(b2, c3, c, kDelta);
+        s = __fmul_rn(e, inv_k);
+        d = __fmul_rn(c, kK);
+        xe = x2; a1 = a; b2 = b; c3 = c;
+    }
+};
+
+// ---- horizontal local stencils on an LDS line; w points at local column 2t ------------------
+__device__ __forceinline__ void h53(const int32_t* w, int32_t& s, int32_t& d)
+{
+    int2 m = *reinterpret_cast<const int2*>(w - 2);   // w[-2], w[-1]
+    int2 c = *reinterpret_cast<const int2*>(w);       // w[0],  w[1]
+    int32_t p2 = w[2];
+    int32_t dm = m.y - ((m.x + c.x) >> 1);
+    d = c.y - ((c.x + p2) >> 1);
+    s = c.x + ((dm + d + 2) >> 2);
+}
+__device__ __forceinline__ void h97(const float* w, float& s, float& d, float inv_k)
+{
+    float2 q0 = *reinterpret_cast<const float2*>(w - 4);  // -4 -3
+    float2 q1 = *reinterpret_cast<const float2*>(w - 2);  // -2 -1
+    float2 q2 = *reinterpret_cast<const float2*>(w);      //  0  1
+    float2 q3 = *reinterpret_cast<const float2*>(w + 2);  //  2  3
+    float  p4 = w[4];
+    float am3 = lift(q0.y, q0.x, q1.x, kAlpha);
+    float am1 = lift(q1.y, q1.x, q2.x, kAlpha);
+    float ap1 = lift(q2.y, q2.x, q3.x, kAlpha);
+    float ap3 = lift(q3.y, q3.x, p4, kAlpha);
+    float bm2 = lift(q1.x, am3, am1, kBeta);
+    float b0  = lift(q2.x, am1, ap1, kBeta);
+    float bp2 = lift(q3.x, ap1, ap3, kBeta);
+    float cm1 = lift(am1, bm2, b0, kGamma);
+    float cp1 = lift(ap1, b0, bp2, kGamma);
+    float e0  = lift(b0, cm1, cp1, kDelta);
+    s = __fmul_rn(e0, inv_k);
+    d = __fmul_rn(cp1, kK);
+}
+
+template <bool F97>
+__global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
+{
+    using T  = typename std::conditional<F97, float, int32_t>::type;
+    using T2 = typename std::conditional<F97, float2, int2>::type;
+    __shared__ __attribute__((aligned(16))) T line[2][2][kCols];   // [parity][low/high][column]
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t cw = a.cw, ch = a.ch;
+    const uint32_t sw = (cw + 1) >> 1, dw = cw - sw;
+    const uint32_t sh = (ch + 1) >> 1, dh = ch - sh;
+    const float inv_k = (float)(1.0 / 1.230174105);
+
+    const int32_t c_first = (int32_t)(blockIdx.x * kOutCols) - kHalo;    // global column of local 0
+    const int32_t cA = c_first + 2 * (int32_t)t;
+    const uint32_t mA = mirror_idx(cA, cw), mB = mirror_idx(cA + 1, cw);
+    const bool vec = (cA >= 0) && ((uint32_t)cA + 1 < cw);
+
+    const T* in = reinterpret_cast<const T*>(a.in) + (size_t)blockIdx.z * a.in_pitch;
+    T* ll = reinterpret_cast<T*>(a.ll) + (size_t)blockIdx.z * a.ll_pitch;
+    T* mp = reinterpret_cast<T*>(a.mallat) + (size_t)blockIdx.z * a.m_pitch;
+
+    const int32_t J0 = (int32_t)(blockIdx.y * a.seg_pairs);
+    const int32_t J1 = min((int32_t)sh, J0 + (int32_t)a.seg_pairs);
+    constexpr int lag  = F97 ? 1 : 0;
+    constexpr int warm = F97 ? 2 : 1;
+
+    auto load_row = [&](int32_t r, T& va, T& vb) {
+        const T* row = in + (size_t)mirror_idx(r, ch) * a.in_stride;
+        if (vec) { T2 q = *reinterpret_cast<const T2*>(row + cA); va = q.x; vb = q.y; }
+        else     { va = row[mA]; vb = row[mB]; }
+    };
+
+    typename std::conditional<F97, V97, V53>::type colA, colB;
+    int32_t i = J0 - warm;
+    {
+        T xa, xb;
+        load_row(2 * i, xa, xb);
+        colA.init(xa); colB.init(xb);
+    }
+    T n1a, n1b, n2a, n2b;                 // prefetched rows of the next step
+    load_row(2 * i + 1, n1a, n1b);
+    load_row(2 * i + 2, n2a, n2b);
+
+    // the output pair this lane produces in the horizontal phase
+    const bool h_lane = (t >= kHalo / 2) && (t < kThreads - kHalo / 2);
+    const uint32_t Jc = (uint32_t)((c_first >> 1) + (int32_t)t);         // global pair column (valid when h_lane)
+    const bool st_s = h_lane && Jc < sw, st_d = h_lane && Jc < dw;
+
+    const int32_t i_end = J1 - 1 + lag;
+    for (int par = 0; i <= i_end; ++i, par ^= 1) {
+        T x1a = n1a, x1b = n1b, x2a = n2a, x2b = n2b;
+        if (i < i_end) {                 // prefetch rows of step i+1 while this one computes
+            load_row(2 * i + 3, n1a, n1b);
+            load_row(2 * i + 4, n2a, n2b);
+        }
+        T sA, dA, sB, dB;
+        if constexpr (F97) {
+            colA.step(x1a, x2a, sA, dA, inv_k);
+            colB.step(x1b, x2b, sB, dB, inv_k);
+        } else {
+            colA.step(x1a, x2a, sA, dA);
+            colB.step(x1b, x2b, sB, dB);
+        }
+        const int32_t j = i - lag;       // row pair just completed (uniform over the workgroup)
+        if (j < J0) continue;
+        if (ch == 1) {                   // single-row level: vertical pass is the identity
+            load_row(0, sA, sB);
+        }
+        T2 ql, qh;
+        ql.x = sA; ql.y = sB; qh.x = dA; qh.y = dB;
+        *reinterpret_cast<T2*>(&line[par][0][2 * t]) = ql;
+        *reinterpret_cast<T2*>(&line[par][1][2 * t]) = qh;
+        __syncthreads();
+        if (h_lane) {
+            const bool has_h = (uint32_t)j < dh;
+            T ls, ld, hs = 0, hd = 0;
+            if constexpr (F97) {
+                if (cw == 1) { ls = line[par][0][2 * t]; ld = 0; if (has_h) hs = line[par][1][2 * t]; }
+                else {
+                    h97(&line[par][0][2 * t], ls, ld, inv_k);
+                    if (has_h) h97(&line[par][1][2 * t], hs, hd, inv_k);
+                }
+            } else {
+                h53(&line[par][0][2 * t], ls, ld);
+                if (has_h) h53(&line[par][1][2 * t], hs, hd);
+            }
+            if (st_s) ll[(size_t)j * a.ll_stride + Jc] = ls;
+            if (st_d) mp[(size_t)j * a.m_stride + sw + Jc] = ld;
+            if (has_h) {
+                if (st_s) mp[(size_t)(sh + j) * a.m_stride + Jc] = hs;
+                if (st_d) mp[(size_t)(sh + j) * a.m_stride + sw + Jc] = hd;
+            }
+        }
+    }
+}
+
+} // namespace
+
+hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
+{
+    const uint32_t sh = (a.ch + 1) >> 1;
+    dim3 grid((a.cw + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
+    dim3 block(kThreads);
+    if (a.irreversible)
+        hipLaunchKernelGGL(dwt_level_kernel<true>, grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL(dwt_level_kernel<false>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace grk_amd

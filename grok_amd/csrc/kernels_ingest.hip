@@ -1,0 +1,100 @@
+// grok_amd/csrc/kernels_ingest.hip -- K1: widen + DC level shift + RCT/ICT, gfx950.
+//
+// Replaces TileProcessor::copy_uncompressed_data_to_tile (tile/TileProcessor.cpp:1166-1216),
+// dc_level_shift_encode (:922-944) and mct::compress_rev / compress_irrev
+// (point_transform/mct.cpp:48-105, :469-554) with one HBM-bound pass:
+// reads b_in bytes/sample, writes 4 bytes/sample (S*(b_in+4) algorithmic bytes).
+// Each lane handles 4 consecutive samples of a row: one 4/8-byte load per component and one
+// 16-byte store per component, so a wave moves 256..512 B in and 1 KiB out per instruction.
+#include "kernels.h"
+
+namespace grk_amd {
+
+__device__ __forceinline__ void color_fwd(int32_t& c0, int32_t& c1, int32_t& c2, bool irrev)
+{
+    if (!irrev) {
+        // RCT (mct.cpp:94-104)
+        int32_t r = c0, g = c1, b = c2;
+        c0 = (r + 2 * g + b) >> 2;
+        c1 = b - g;
+        c2 = r - g;
+    } else {
+        // ICT (mct.cpp:541-553): every product/sum rounded separately, left-to-right adds.
+        const float a_r = 0.299f, a_g = 0.587f, a_b = 0.114f;
+        const float cb = 0.5f / (1.0f - a_b), cr = 0.5f / (1.0f - a_r);
+        float r = (float)c0, g = (float)c1, b = (float)c2;
+        float y = __fmul_rn(a_r, r);
+        y = __fadd_rn(y, __fmul_rn(a_g, g));
+        y = __fadd_rn(y, __fmul_rn(a_b, b));
+        float u = __fmul_rn(cb, __fsub_rn(b, y));
+        float v = __fmul_rn(cr, __fsub_rn(r, y));
+        c0 = __float_as_int(y); c1 = __float_as_int(u); c2 = __float_as_int(v);
+    }
+}
+
+template <typename PIX>
+__device__ __forceinline__ void load4(const PIX* p, bool vec, uint32_t n, int32_t v[4])
+{
+    if (vec) {
+        if constexpr (sizeof(PIX) == 1) {
+            uchar4 q = *reinterpret_cast<const uchar4*>(p);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            ushort4 q = *reinterpret_cast<const ushort4*>(p);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        }
+    } else {
+        for (uint32_t i = 0; i < 4; ++i) v[i] = i < n ? (int32_t)p[i] : 0;
+    }
+}
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a)
+{
+    const uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    const uint32_t y = blockIdx.y;
+    const uint32_t tile = blockIdx.z;
+    if (x >= a.w) return;
+    const uint32_t n = a.w - x < 4 ? a.w - x : 4;
+    const size_t comp_px = (size_t)a.w * a.h;
+    const PIX* src = reinterpret_cast<const PIX*>(a.pixels) + (size_t)tile * a.ncomp * comp_px + (size_t)y * a.w + x;
+    int32_t* dst = a.planes + (size_t)tile * a.ncomp * a.pitch + (size_t)y * a.stride + x;
+    // rows are tightly packed: 4-sample vectors are aligned only when w % 4 == 0
+    const bool vec = (n == 4) && ((a.w & 3u) == 0);
+    const bool irrev = a.irreversible != 0;
+
+    int32_t c[4][4];
+    for (uint32_t k = 0; k < a.ncomp; ++k) {
+        load4<PIX>(src + k * comp_px, vec, n, c[k]);
+        for (int i = 0; i < 4; ++i) c[k][i] -= a.dc;
+    }
+    if (a.mct) {
+        for (int i = 0; i < 4; ++i) color_fwd(c[0][i], c[1][i], c[2][i], irrev);
+    } else if (irrev) {
+        // 9/7 without MCT: the transform works on floats
+        for (uint32_t k = 0; k < a.ncomp; ++k)
+            for (int i = 0; i < 4; ++i) c[k][i] = __float_as_int((float)c[k][i]);
+    }
+    if (a.mct && irrev && a.ncomp > 3)
+        for (int i = 0; i < 4; ++i) c[3][i] = __float_as_int((float)c[3][i]);
+    for (uint32_t k = 0; k < a.ncomp; ++k) {
+        int32_t* d = dst + (size_t)k * a.pitch;
+        if (n == 4) {
+            *reinterpret_cast<int4*>(d) = make_int4(c[k][0], c[k][1], c[k][2], c[k][3]);   // stride % 32 == 0, x % 4 == 0
+        } else {
+            for (uint32_t i = 0; i < n; ++i) d[i] = c[k][i];
+        }
+    }
+}
+
+hipError_t launch_ingest(const IngestArgs& a, hipStream_t s)
+{
+    dim3 grid((a.w + 1023) / 1024, a.h, a.ntiles), block(256);
+    if (a.bytes_per_sample == 1)
+        hipLaunchKernelGGL(ingest_kernel<uint8_t>, grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL(ingest_kernel<uint16_t>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace grk_amd

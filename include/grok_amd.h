@@ -1,0 +1,154 @@
+/* include/grok_amd.h -- the C-ABI of the MI355X tile processor (libgrok_amd.so).
+ *
+ * This is the thin C layer SURVEY.md §8(b) asks for underneath the Grok plugin entry points:
+ * plain pointers and sizes only (no torch / C++ types), one opaque context per GPU.
+ * The plugin shim (libgrokj2k_plugin.so, include/grk_plugin_abi.h) wraps these calls into the
+ * grk_plugin_* protocol; bench.py and the parity tests call them through ctypes.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the Grok
+ * 8.0.2 tree, src/lib/jp2/...):
+ *
+ *   grk_amd_encode_tiles        TileProcessor::do_compress()  tile/TileProcessor.cpp:665-699
+ *                               = dc_level_shift_encode :922, mct_encode :945, dwt_encode :977,
+ *                                 t1_encode :992 (T1HT::compress, t1/t1_ht/T1HT.cpp:102-128)
+ *   grk_amd_stage_ingest_mct    TileProcessor.cpp:1166-1216 + :922-944 + mct::compress_rev/irrev
+ *                               (point_transform/mct.cpp:48-105, :469-554)
+ *   grk_amd_stage_dwt_fwd       WaveletFwdImpl::compress (transform/WaveletFwd.cpp:612-620)
+ *   grk_amd_stage_ht_encode     T1CompressScheduler::scheduleCompress (t1/T1CompressScheduler.cpp:33-90)
+ *                               + ojph_encode_codeblock (t1/t1_ht/coding/ojph_block_encoder.cpp:463)
+ *   grk_amd_tile_layout         TileComponent::init geometry (tile/TileComponent.cpp:69-170),
+ *                               Quantizer::setBandStepSizeAndBps (codestream/Quantizer.cpp:26-66),
+ *                               param_qcd::set_rev_quant/set_irrev_quant (codestream/HTParams.cpp:248-312)
+ *   grk_amd_write_codestream    CodeStreamCompress main header + tile parts + T2 packets, restricted
+ *                               to 1 layer / LRCP / 1 precinct per resolution
+ *                               (codestream/CodeStreamCompress.cpp:722-753, t2/T2Compress.cpp:123-333)
+ *
+ * Error convention (mirrors the plugin boundary, grok.h:1781): 0 = success, negative = failure /
+ * "not handled" so that the host can fall back to its CPU path.  No exceptions cross this ABI.
+ */
+#ifndef GROK_AMD_H
+#define GROK_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRK_AMD_OK                0
+#define GRK_AMD_ERR_NO_DEVICE    -1   /* no HIP device / HIP runtime failure           */
+#define GRK_AMD_ERR_UNSUPPORTED  -2   /* parameter combination outside the hot path     */
+#define GRK_AMD_ERR_INVALID      -3   /* bad argument                                   */
+#define GRK_AMD_ERR_NOMEM        -4
+#define GRK_AMD_ERR_OVERFLOW     -5   /* coded data did not fit the arena               */
+
+#define GRK_AMD_MAX_LEVELS 10
+
+typedef struct grk_amd_ctx grk_amd_ctx;      /* one per process per GPU */
+
+/* What the hot path needs out of grk_cparameters / grk_image (grok.h:451-573, :866-929). */
+typedef struct grk_amd_tile_params {
+    uint32_t tile_w, tile_h;     /* tile-component size (dx=dy=1, tile origin on an even grid) */
+    uint16_t num_comps;          /* 1..4 ; MCT needs >=3                                        */
+    uint8_t  prec;               /* bits per sample, 1..16                                      */
+    uint8_t  sgnd;               /* signed samples (DC shift 0)                                 */
+    uint8_t  irreversible;       /* 0: RCT + 5/3 (lossless)   1: ICT + 9/7 + dead-zone quantiser*/
+    uint8_t  mct;                /* tcp_mct: component transform on components 0..2             */
+    uint8_t  num_levels;         /* numresolution - 1                                           */
+    uint8_t  cblk_w_exp;         /* log2 code-block width  (6)                                  */
+    uint8_t  cblk_h_exp;         /* log2 code-block height (6)                                  */
+    uint8_t  reserved[3];
+} grk_amd_tile_params;
+
+/* One code-block of the tile, in the reference's enumeration order
+ * comp -> resolution -> band -> precinct(1) -> raster (T1CompressScheduler.cpp:44-85). */
+typedef struct grk_amd_block {
+    uint32_t x0, y0, x1, y1;     /* band coordinates (what grk_plugin_code_block.x0.. carries) */
+    uint32_t px, py;             /* origin inside the component's Mallat plane                 */
+    uint16_t comp;
+    uint8_t  res;                /* 0 = coarsest                                               */
+    uint8_t  band;               /* orientation 0 LL, 1 HL, 2 LH, 3 HH                         */
+    uint8_t  kmax;               /* band->numbps (= QCD exponent for HT, numgbits 1)           */
+    uint8_t  reserved[3];
+    float    stepsize;           /* band->stepsize (1.0 reversible)                            */
+} grk_amd_block;
+
+/* Result row per coded block. `offset` is relative to the start of the coded arena. */
+typedef struct grk_amd_coded_block {
+    uint64_t offset;
+    uint32_t length;             /* MagSgn | MEL | VLC bytes of the single HT cleanup pass      */
+    uint32_t reserved;
+} grk_amd_coded_block;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* plugin_init(grk_plugin_init_info{deviceId,verbose}) -> grk_amd_create (grok.h:1749-1757) */
+int  grk_amd_create(int device_id, int verbose, grk_amd_ctx** out);
+void grk_amd_destroy(grk_amd_ctx* ctx);
+const char* grk_amd_version(void);
+const char* grk_amd_last_error(grk_amd_ctx* ctx);
+/* use an externally owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own */
+int  grk_amd_set_stream(grk_amd_ctx* ctx, void* hip_stream);
+
+/* ---- geometry (host only, no GPU needed) ---------------------------------------------------- */
+/* Number of code-blocks in one tile (all components). */
+int64_t grk_amd_tile_num_blocks(const grk_amd_tile_params* p);
+/* Fill `blocks` (capacity cap) in enumeration order; returns count or negative error.
+ * Also returns per-band QCD words: reversible -> expn<<3 (u8), irreversible -> (expn<<11)|mant. */
+int64_t grk_amd_tile_layout(const grk_amd_tile_params* p, grk_amd_block* blocks, uint64_t cap,
+                            uint16_t* qcd_words /* [3*levels+1] or NULL */);
+/* int32 elements between consecutive rows / planes of the device working planes */
+uint32_t grk_amd_plane_stride(const grk_amd_tile_params* p);
+uint64_t grk_amd_plane_elems(const grk_amd_tile_params* p);
+
+/* ---- whole hot path -------------------------------------------------------------------------
+ * Encode `num_tiles` equally sized tiles in one batch.  `pixels` holds the tiles back to back,
+ * each tile component-major planar, row-major, tightly packed, ceil(prec/8) bytes per sample,
+ * host endian -- the layout grk_compress_tile() takes (TileProcessor.cpp:1177-1213).
+ * pixels_on_device != 0: `pixels` is a device pointer (HBM-resident input, what bench.py times).
+ *
+ * On return the coded bytes of all blocks live in the context's device arena; `table` (host,
+ * num_tiles * blocks_per_tile rows, tile-major) describes them.  Pass table == NULL to leave the
+ * table on the device as well (fully asynchronous; fetch later with grk_amd_fetch_table). */
+int grk_amd_encode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
+                         const void* pixels, int pixels_on_device,
+                         grk_amd_coded_block* table, uint64_t* total_bytes);
+int grk_amd_fetch_table(grk_amd_ctx* ctx, grk_amd_coded_block* table, uint64_t* total_bytes);
+/* copy coded bytes [0,total) of the arena to host memory */
+int grk_amd_fetch_coded(grk_amd_ctx* ctx, uint8_t* dst, uint64_t nbytes);
+/* device pointers for zero-copy consumers (RCCL gather of tile parts, tests) */
+void* grk_amd_coded_device_ptr(grk_amd_ctx* ctx);
+void* grk_amd_plane_device_ptr(grk_amd_ctx* ctx, int which /*0: ingest planes, 1: Mallat planes*/);
+int  grk_amd_synchronize(grk_amd_ctx* ctx);
+
+/* ---- stage entry points (parity tests and per-kernel benchmarks call these) ------------------
+ * All pointers are DEVICE pointers; planes are int32 (or float32 bit patterns for 9/7) with
+ * row stride grk_amd_plane_stride() and plane pitch grk_amd_plane_elems(). */
+int grk_amd_stage_ingest_mct(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
+                             const void* d_pixels, void* d_planes);
+/* forward DWT of num_planes planes: d_in (ingest planes) -> d_out (Mallat layout); d_in is
+ * clobbered (its top-left quadrant is reused as LL ping-pong storage). */
+int grk_amd_stage_dwt_fwd(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_planes,
+                          void* d_in, void* d_out);
+/* HT cleanup-encode every block of num_tiles tiles from Mallat planes into the context arena. */
+int grk_amd_stage_ht_encode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
+                            const void* d_mallat);
+
+/* average duration (ms) of the named kernel family over the launches since the last reset,
+ * measured with HIP events on the context's stream when timing is enabled.
+ * which: 0 ingest+mct, 1 dwt (all levels), 2 ht encode, 3 whole encode_tiles call */
+int    grk_amd_enable_timing(grk_amd_ctx* ctx, int on);
+double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
+
+/* ---- codestream assembly (host) ----------------------------------
+ * Writes a complete Part-15 codestream (SOC SIZ CAP COD QCD COM, then per tile SOT SOD + LRCP
+ * packets, EOC) for an image of img_w x img_h cut into tiles of p->tile_w x p->tile_h, given the
+ * per-tile block tables + coded bytes produced above (tiles in raster order).
+ * Byte-identical to the reference's output for the same parameters. Returns length or <0. */
+int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
+                                 const grk_amd_coded_block* table, const uint8_t* coded,
+                                 uint8_t* out, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GROK_AMD_H */

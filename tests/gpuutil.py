@@ -1,0 +1,44 @@
+"""Helpers for the -m gpu parity tests: device buffers via torch, calls through the C-ABI."""
+import numpy as np
+import torch
+
+import grok_amd as G
+
+_ctx = None
+
+
+def ctx():
+    global _ctx
+    if _ctx is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("GPU test invoked without a GPU")
+        _ctx = G.Context(0)
+    return _ctx
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def dev_planes(params, nplanes):
+    n = G.lib().grk_amd_plane_elems(params) * nplanes
+    return torch.zeros(int(n), dtype=torch.int32, device="cuda")
+
+
+def planes_to_numpy(t, params, nplanes):
+    stride = G.lib().grk_amd_plane_stride(params)
+    a = t.cpu().numpy().reshape(nplanes, params.tile_h, stride)
+    return a[:, :, :params.tile_w]
+
+
+def upload_planes(planes, params):
+    """planes: (n, H, W) int32 -> device tensor in the padded plane layout."""
+    stride = G.lib().grk_amd_plane_stride(params)
+    n, H, W = planes.shape
+    buf = np.zeros((n, H, stride), np.int32)
+    buf[:, :, :W] = planes
+    return to_dev(buf.reshape(-1))
+
+
+def split_blocks(table, coded):
+    return [bytes(coded[int(o):int(o) + int(l)]) for o, l in zip(table["offset"], table["length"])]
