@@ -1,3 +1,208 @@
-// placeholder, replaced below
+// grok_amd/csrc/t2_writer.cpp -- host-side Tier-2 + codestream assembly.
+//
+// The Grok plugin protocol hands ONE grk_plugin_tile to every tile of an image (defect D3), so
+// multi-tile images -- the tile-sharded multi-GPU configuration -- cannot go through
+// grk_compress_with_plugin.  This writer produces the same bytes the reference would:
+//   main header : CodeStreamCompress.cpp:722-753 (SOC, SIZ markers/SIZMarker.cpp, CAP :936-981,
+//                 COD :1060-1105, QCD Quantizer.cpp:87-121, COM :296-309)
+//   tile part   : SOT markers/SOTMarker.cpp:41-72, SOD, then one packet per (resolution, component)
+//                 in LRCP order (t2/PacketIter.cpp:805-829) -- 1 layer, 1 precinct per resolution,
+//                 no SOP/EPH, every code-block included with its single HT cleanup pass
+//   packet      : T2Compress::compressPacket t2/T2Compress.cpp:123-333; tag trees t1/TagTree.cpp:170-218;
+//                 bit stuffing t1/BitIO.cpp:46-175
+// It is O(#code-blocks) host work plus one memcpy of the coded bytes.
 #include "../../include/grok_amd.h"
-extern "C" int64_t grk_amd_write_codestream(const grk_amd_tile_params*, uint32_t, uint32_t, const grk_amd_coded_block*, const uint8_t*, uint8_t*, uint64_t) { return GRK_AMD_ERR_UNSUPPORTED; }
+#include "geometry.h"
+#include <cstring>
+#include <vector>
+
+namespace {
+
+using namespace grk_amd;
+
+struct Out {
+    uint8_t* p; uint64_t cap; uint64_t n = 0; bool ovf = false;
+    void u8(uint32_t v) { if (n < cap) p[n] = (uint8_t)v; else ovf = true; ++n; }
+    void u16(uint32_t v) { u8(v >> 8); u8(v & 0xFF); }
+    void u32(uint32_t v) { u16(v >> 16); u16(v & 0xFFFF); }
+    void bytes(const uint8_t* s, uint64_t len)
+    {
+        if (n + len <= cap) std::memcpy(p + n, s, len); else ovf = true;
+        n += len;
+    }
+    void patch32(uint64_t at, uint32_t v)
+    {
+        if (at + 4 <= cap) { p[at] = (uint8_t)(v >> 24); p[at + 1] = (uint8_t)(v >> 16); p[at + 2] = (uint8_t)(v >> 8); p[at + 3] = (uint8_t)v; }
+    }
+};
+
+// MSB-first packet-header bit writer: a byte following 0xFF carries 7 bits (BitIO.cpp:46-175)
+struct HeaderBits {
+    Out& o; uint8_t buf = 0; int ct = 8;
+    explicit HeaderBits(Out& out) : o(out) {}
+    void byteout() { o.u8(buf); ct = (buf == 0xFF) ? 7 : 8; buf = 0; }
+    void bit(uint32_t b) { if (ct == 0) byteout(); --ct; buf = (uint8_t)(buf | (b << ct)); }
+    void put(uint32_t v, int n) { for (int i = n - 1; i >= 0; --i) bit((v >> i) & 1); }
+    void comma(int n) { while (--n >= 0) bit(1); bit(0); }
+    void flush() { byteout(); if (ct == 7) byteout(); }
+};
+
+// Tag tree over a gw x gh leaf grid (ISO 15444-1 B.10.2), quad-tree reduced level by level.
+struct TagTree {
+    struct Node { int32_t value, low; bool known; };
+    std::vector<std::vector<Node>> lvl;
+    std::vector<uint32_t> lw, lh;
+    void init(uint32_t gw, uint32_t gh)
+    {
+        lvl.clear(); lw.clear(); lh.clear();
+        uint32_t w = gw, h = gh;
+        for (;;) {
+            lw.push_back(w); lh.push_back(h);
+            lvl.emplace_back((size_t)w * h, Node{0x7FFFFFFF, 0, false});
+            if (w * h <= 1) break;
+            w = (w + 1) >> 1; h = (h + 1) >> 1;
+        }
+    }
+    void set(uint32_t x, uint32_t y, int32_t v)
+    {
+        for (size_t l = 0; l < lvl.size(); ++l) {
+            Node& nd = lvl[l][(size_t)(y >> l) * lw[l] + (x >> l)];
+            if (nd.value <= v) break;
+            nd.value = v;
+        }
+    }
+    void encode(HeaderBits& hb, uint32_t x, uint32_t y, int32_t threshold)
+    {
+        int32_t low = 0;
+        for (int l = (int)lvl.size() - 1; l >= 0; --l) {
+            Node& nd = lvl[l][(size_t)(y >> l) * lw[l] + (x >> l)];
+            if (low > nd.low) nd.low = low; else low = nd.low;
+            while (low < threshold) {
+                if (low >= nd.value) {
+                    if (!nd.known) { hb.bit(1); nd.known = true; }
+                    break;
+                }
+                hb.bit(0);
+                ++low;
+            }
+            nd.low = low;
+        }
+    }
+};
+
+int floor_log2(uint32_t v) { int r = 0; while (v >>= 1) ++r; return r; }
+
+void write_main_header(Out& o, const TileGeom& g, uint32_t img_w, uint32_t img_h)
+{
+    const grk_amd_tile_params& p = g.p;
+    o.u16(0xFF4F);                                                     // SOC
+    o.u16(0xFF51); o.u16(38 + 3 * p.num_comps); o.u16(0x4000);         // SIZ, Rsiz: HTJ2K (Part 15)
+    o.u32(img_w); o.u32(img_h); o.u32(0); o.u32(0);
+    o.u32(p.tile_w); o.u32(p.tile_h); o.u32(0); o.u32(0);
+    o.u16(p.num_comps);
+    for (uint32_t c = 0; c < p.num_comps; ++c) { o.u8((p.prec - 1) | (p.sgnd ? 0x80 : 0)); o.u8(1); o.u8(1); }
+    // CAP (CodeStreamCompress.cpp:936-981; MAGBp HTParams.cpp:313-329)
+    uint32_t B = 0;
+    const uint32_t nb = 3 * p.num_levels + 1;
+    for (uint32_t i = 0; i < nb; ++i) {
+        if (!p.irreversible) B = std::max<uint32_t>(B, (uint32_t)(g.qcd_words[i] >> 3) + 1 - 1);
+        else {
+            uint32_t lev = p.num_levels - (i ? (i - 1) / 3 : 0);
+            B = std::max<uint32_t>(B, (uint32_t)(g.qcd_words[i] >> 11) + 1 - lev);
+        }
+    }
+    uint32_t Bp = B <= 8 ? 0 : (B < 28 ? B - 8 : (B < 48 ? 13 + (B >> 2) : 31));
+    o.u16(0xFF50); o.u16(8); o.u32(0x00020000); o.u16((p.irreversible ? 0x0020 : 0) | Bp);
+    // COD
+    o.u16(0xFF52); o.u16(12); o.u8(0); o.u8(0); o.u16(1); o.u8(p.mct ? 1 : 0);
+    o.u8(p.num_levels); o.u8(p.cblk_w_exp - 2); o.u8(p.cblk_h_exp - 2); o.u8(0x40); o.u8(p.irreversible ? 0 : 1);
+    // QCD: one guard bit
+    if (!p.irreversible) {
+        o.u16(0xFF5C); o.u16(3 + nb); o.u8(0x20);
+        for (uint32_t i = 0; i < nb; ++i) o.u8(g.qcd_words[i] & 0xFF);
+    } else {
+        o.u16(0xFF5C); o.u16(3 + 2 * nb); o.u8(0x22);
+        for (uint32_t i = 0; i < nb; ++i) o.u16(g.qcd_words[i]);
+    }
+    // COM (the reference's default comment, so that whole files compare byte for byte)
+    static const char kCom[] = "Created by Grok     version 8.0.2";
+    const uint32_t cl = (uint32_t)std::strlen(kCom);
+    o.u16(0xFF64); o.u16(4 + cl); o.u16(1);
+    o.bytes(reinterpret_cast<const uint8_t*>(kCom), cl);
+}
+
+void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_block* comp_table, const uint8_t* coded)
+{
+    const ResGeom& R = g.res[r];
+    HeaderBits hb(o);
+    hb.bit(1);
+    TagTree incl, zbp;
+    for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
+        const BandGeom& B = R.band[bi];
+        if (!B.gw || !B.gh) continue;
+        incl.init(B.gw, B.gh); zbp.init(B.gw, B.gh);
+        for (uint32_t y = 0; y < B.gh; ++y)
+            for (uint32_t x = 0; x < B.gw; ++x) { incl.set(x, y, 0); zbp.set(x, y, (int32_t)B.kmax - 1); }
+        for (uint32_t y = 0; y < B.gh; ++y)
+            for (uint32_t x = 0; x < B.gw; ++x) {
+                const grk_amd_coded_block& cb = comp_table[B.first_block + y * B.gw + x];
+                incl.encode(hb, x, y, 1);
+                zbp.encode(hb, x, y, 0x7FFFFFFF);
+                hb.bit(0);                                            // one coding pass
+                const uint32_t len = cb.length;
+                int inc = floor_log2(len) + 1 - 3;
+                if (inc < 0) inc = 0;
+                hb.comma(inc);
+                hb.put(len, 3 + inc);
+            }
+    }
+    hb.flush();
+    for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
+        const BandGeom& B = R.band[bi];
+        for (uint32_t k = 0; k < B.gw * B.gh; ++k) {
+            const grk_amd_coded_block& cb = comp_table[B.first_block + k];
+            o.bytes(coded + cb.offset, cb.length);
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
+                                            const grk_amd_coded_block* table, const uint8_t* coded,
+                                            uint8_t* out, uint64_t cap)
+{
+    if (!p || !table || !coded || !out) return GRK_AMD_ERR_INVALID;
+    TileGeom g;
+    int rc = build_tile_geom(*p, g);
+    if (rc != GRK_AMD_OK) return rc;
+    // equally sized tiles on a grid whose pitch keeps every band aligned (see geometry.h)
+    if (img_w % p->tile_w || img_h % p->tile_h) return GRK_AMD_ERR_UNSUPPORTED;
+    const uint32_t tcols = img_w / p->tile_w, trows = img_h / p->tile_h;
+    if ((uint64_t)tcols * trows > 65535) return GRK_AMD_ERR_UNSUPPORTED;
+    if (tcols * trows > 1 && ((p->tile_w | p->tile_h) & ((1u << p->num_levels) - 1))) return GRK_AMD_ERR_UNSUPPORTED;
+    for (uint32_t r = 0; r <= p->num_levels && tcols * trows > 1; ++r)
+        for (uint32_t b = 0; b < g.res[r].num_bands; ++b) {
+            // a band narrower than a code-block must not straddle a global code-block grid line
+            const BandGeom& B = g.res[r].band[b];
+            const uint32_t cw = 1u << p->cblk_w_exp, chh = 1u << p->cblk_h_exp;
+            if ((B.w % cw) && (cw % B.w)) return GRK_AMD_ERR_UNSUPPORTED;
+            if ((B.h % chh) && (chh % B.h)) return GRK_AMD_ERR_UNSUPPORTED;
+        }
+    Out o{out, cap};
+    write_main_header(o, g, img_w, img_h);
+    const uint64_t bpt = (uint64_t)g.blocks_per_comp * p->num_comps;
+    for (uint32_t t = 0; t < tcols * trows; ++t) {
+        const uint64_t sot = o.n;
+        o.u16(0xFF90); o.u16(10); o.u16(t); o.u32(0); o.u8(0); o.u8(1);
+        o.u16(0xFF93);
+        const grk_amd_coded_block* tt = table + t * bpt;
+        for (uint32_t r = 0; r <= p->num_levels; ++r)
+            for (uint32_t c = 0; c < p->num_comps; ++c)
+                write_packet(o, g, r, tt + (uint64_t)c * g.blocks_per_comp, coded);
+        o.patch32(sot + 6, (uint32_t)(o.n - sot));
+    }
+    o.u16(0xFFD9);
+    if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
+    return (int64_t)o.n;
+}

@@ -186,7 +186,7 @@ int64_t ref_encode(const EncCfg* cfg, const uint8_t* pixels, uint8_t* out, uint6
 	fill_params(param, c);
 	const int bps = (c.prec + 7) / 8;
 	bool use_image_data = (c.mode == 1) || plugin_tile;
-	grk_image* image = make_image(c, use_image_data);
+	grk_image* image = make_image(c, true);   // multi-tile paths dereference comp->data (TileProcessor.cpp:1137-1147)
 	if (!image) return -2;
 	if (use_image_data) {
 		for (int k = 0; k < c.C; ++k) {

@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads, exports every symbol include/grok_amd.h declares, and its
+host-only entry points (geometry, Tier-2 writer) behave; no GPU compute is attempted."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import grok_amd as G
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(grk_amd_[a-z0-9_]+|plugin_[a-z0-9_]+|minpf_post_load_plugin)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = G.lib()
+    syms = declared_symbols("grok_amd.h")
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), "libgrok_amd.so does not export %s" % s
+
+
+def test_missing_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        G.Context(0)
+
+
+@pytest.mark.parametrize("w,h,c,levels,nblocks", [(512, 512, 1, 3, 64), (4096, 4096, 3, 5, 12288),
+                                                   (8192, 8192, 3, 5, 49152), (1024, 1024, 3, 5, 777)])
+def test_block_counts_match_survey(w, h, c, levels, nblocks):
+    p = G.TileParams.make(w, h, c, 8, levels)
+    assert G.lib().grk_amd_tile_num_blocks(C.byref(p)) == nblocks
+
+
+@pytest.mark.parametrize("w,h,levels", [(512, 512, 3), (1024, 1024, 5), (200, 120, 2), (130, 67, 5), (37, 3, 1), (1, 1, 0)])
+def test_layout_matches_oracle_enumeration(w, h, levels):
+    p = G.TileParams.make(w, h, 1, 8, levels)
+    blocks, qcd = G.tile_layout(p)
+    expn = O.rev_exponents(8, levels)
+    assert [q >> 3 for q in qcd] == expn.tolist()
+    ob = O.enumerate_blocks(w, h, levels, expn)
+    assert len(ob) == len(blocks)
+    for a, b in zip(blocks, ob):
+        assert (a.px, a.py, a.x1 - a.x0, a.y1 - a.y0, a.res, a.band, a.kmax) == (b.x, b.y, b.w, b.h, b.res, b.band, b.kmax)
+
+
+def test_irreversible_qcd_matches_oracle():
+    p = G.TileParams.make(8192, 8192, 3, 16, 5, irreversible=True)
+    blocks, qcd = G.tile_layout(p)
+    oq, od = O.irrev_stepsizes(16, 5)
+    assert qcd == oq.tolist()
+    steps = {}
+    for b in blocks:
+        steps[(b.res, b.band)] = b.stepsize
+    idx = 0
+    for r in range(6):
+        for band in ([0] if r == 0 else [1, 2, 3]):
+            assert steps[(r, band)] == pytest.approx(float(od[idx]), rel=0, abs=0)
+            idx += 1
+
+
+def test_unsupported_parameters_are_rejected():
+    L = G.lib()
+    bad = G.TileParams.make(64, 64, 1, 8, 11)
+    assert L.grk_amd_tile_num_blocks(C.byref(bad)) == -2
+    bad = G.TileParams.make(0, 64, 1, 8, 1)
+    assert L.grk_amd_tile_num_blocks(C.byref(bad)) == -3
+    bad = G.TileParams.make(64, 64, 2, 8, 1, mct=True)
+    assert L.grk_amd_tile_num_blocks(C.byref(bad)) == -3
