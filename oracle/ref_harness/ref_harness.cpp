@@ -132,9 +132,13 @@ int32_t ref_ht_encode_block(uint32_t* sm, uint32_t kmax, uint32_t w, uint32_t h,
 int32_t ref_ht_decode_block(const uint8_t* coded, uint32_t len, uint32_t missing_msbs,
 							uint32_t w, uint32_t h, uint32_t* out)
 {
+	// the decoder works on whole quad pairs: give it a padded scratch plane and copy the block out
 	std::vector<uint8_t> buf(len + 32, 0);
 	memcpy(buf.data() + 8, coded, len);
-	bool ok = ojph::local::ojph_decode_codeblock(buf.data() + 8, out, missing_msbs, 1, len, 0, w, h, w);
+	const uint32_t stride = ((w + 7u) & ~7u) + 8u;
+	std::vector<uint32_t> tmp((size_t)stride * (h + 4), 0);
+	bool ok = ojph::local::ojph_decode_codeblock(buf.data() + 8, tmp.data(), missing_msbs, 1, len, 0, w, h, stride);
+	for (uint32_t y = 0; y < h; ++y) memcpy(out + (size_t)y * w, tmp.data() + (size_t)y * stride, w * 4);
 	return ok ? 0 : -1;
 }
 
