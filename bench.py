@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: encode Mpixels/s (whole job) for 8K RGB HTJ2K
+lossless, with the dominant kernel's HBM roofline and the reference CPU encoder beside it.
+
+One "step" = one pass of the hot path (ingest+DC+RCT -> 5-level 5/3 DWT -> HT cleanup coding of
+64x64 code-blocks -> compaction) over one 8192x8192x3 8-bit tile whose pixels are already
+resident in HBM.  With N ranks (torchrun, one process per GPU) the job is an (N*8192)x8192 image
+cut into N tiles of 8192x8192: tile t is encoded on rank t (tiles are independent, SURVEY.md
+§8e) and every step ends with the path's one real exchange: the coded tile-parts are gathered on
+rank 0 over RCCL/xGMI.  Per-GPU work is fixed => weak scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 8k|cfg2|cfg1|cfg4tile]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import grok_amd as G  # noqa: E402
+import synth  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+WORKLOADS = {
+    # name: (C, W, H, prec, levels, ntiles per rank, description)
+    "8k": (3, 8192, 8192, 8, 5, 1,
+           "8192x8192x3 8-bit RGB, 1 tile, RCT+5/3 lossless HTJ2K, 5 levels, 64x64 blocks (BASELINE metric shape)"),
+    "cfg2": (3, 4096, 4096, 8, 5, 1,
+             "4096x4096x3 8-bit RGB, 1 tile, RCT+5/3 lossless HTJ2K, 5 levels (BASELINE configs[1])"),
+    "cfg1": (1, 512, 512, 8, 3, 1, "512x512 8-bit mono, 1 tile, 5/3 lossless, 3 levels, HTJ2K (configs[0])"),
+    "cfg4tile": (3, 1024, 1024, 8, 5, 64,
+                 "64 tiles of 1024x1024x3 8-bit per rank, RCT+5/3 lossless HTJ2K, 5 levels (configs[3] tiling)"),
+}
+
+
+def sigma(levels):
+    return sum(4.0 ** -l for l in range(levels))
+
+
+def cpu_baseline(rank_threads):
+    """Grok's own CPU encode (oracle/_ref = the real reference built from its sources) on this
+    box's host cores, on a bounded sample of the same workload."""
+    try:
+        import refharness as R
+        if not R.have_ref():
+            raise RuntimeError("oracle/_ref missing")
+        R.lib(threads=rank_threads)
+        W = H = 4096
+        px = synth.g2(3, H, W, 8)
+        R.encode(synth.g2(3, 1024, 1024, 8), 8, numres=6)          # warm the thread pool
+        times, t_start = [], time.time()
+        while len(times) < 5 and (time.time() - t_start < 20.0 or len(times) < 2):
+            _, secs = R.encode(px, 8, numres=6)
+            times.append(secs)
+        med = sorted(times)[len(times) // 2]
+        return {"value": round(W * H / med / 1e6, 2), "unit": "Mpixels/s", "cores": rank_threads,
+                "kind": "reference",
+                "sample": "Grok 8.0.2 CPU encoder (oracle/_ref), %d x 4096x4096x3 8-bit G2 RCT+5/3 HTJ2K 5 levels, "
+                          "median of compress-call wall times, %d threads" % (len(times), rank_threads)}
+    except Exception as e:  # fall back to the scalar port of the oracle
+        import oracle as O
+        px = synth.g2(3, 1024, 1024, 8)
+        t0 = time.time()
+        O.encode_tile_rev(px, 8, 5)
+        dt = time.time() - t0
+        return {"value": round(1024 * 1024 / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                "sample": "oracle/j2k_oracle.c scalar port, 1 x 1024x1024x3 (reference harness unavailable: %s)" % e}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    Cn, W, H, prec, levels, ntiles, desc = WORKLOADS[args.workload]
+    params = G.TileParams.make(W, H, Cn, prec, levels)
+    ctx = G.Context(local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    # synthetic tile(s): generator G2 (bounded gradient + LCG noise), same buffer for every tile
+    tile = synth.g2(Cn, H, W, prec)
+    host = np.ascontiguousarray(np.broadcast_to(tile.reshape(1, -1), (ntiles, tile.size))).reshape(-1)
+    d_px = torch.from_numpy(host.view(np.uint8)).to(dev)
+    nblocks = G.lib().grk_amd_tile_num_blocks(C.byref(params)) * ntiles
+    pixels_per_step = W * H * ntiles
+    samples = pixels_per_step * Cn
+
+    # rank 0 owns the header blob; everybody gets it by broadcast (tiny, outside the timed region)
+    if world > 1:
+        hdr = torch.tensor(list(bytes(params)), dtype=torch.uint8, device=dev)
+        dist.broadcast(hdr, 0)
+
+    gather_bufs = None
+
+    def step():
+        with torch.cuda.stream(stream):
+            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+        if world > 1:
+            # exchange step: coded bytes of this rank's tile-part(s) -> rank 0
+            _, total = ctx.fetch_table(nblocks)
+            n = torch.tensor([total], dtype=torch.int64, device=dev)
+            sizes = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(sizes, n)
+            mx = int(max(int(s.item()) for s in sizes))
+            mx = (mx + 4095) & ~4095
+            ptr = ctx.coded_device_ptr()
+            # wrap the context arena without copying
+            src = _as_tensor(ptr, mx, dev)
+            nonlocal gather_bufs
+            if rank == 0:
+                if gather_bufs is None or gather_bufs[0].numel() < mx:
+                    gather_bufs = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
+                dist.gather(src, [b[:mx] for b in gather_bufs], dst=0)
+            else:
+                dist.gather(src, None, dst=0)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel-family average durations (HIP events on the context's stream)
+    fam = {}
+    for idx, name in ((0, "ingest_mct"), (1, "dwt53_5levels"), (2, "ht_cleanup_encode"), (4, "compact")):
+        ms, n = ctx.kernel_ms(idx)
+        fam[name] = (ms, n)
+    ctx.enable_timing(False)
+    table, total = ctx.fetch_table(nblocks)
+    b_in = (prec + 7) // 8
+    algo = {"ingest_mct": samples * (b_in + 4), "dwt53_5levels": 8.0 * samples * sigma(levels),
+            "ht_cleanup_encode": 4.0 * samples + float(total), "compact": 2.0 * float(total)}
+    dom = max(("ingest_mct", "dwt53_5levels", "ht_cleanup_encode"), key=lambda k: fam[k][0])
+    ach = algo[dom] / (fam[dom][0] * 1e-3) / 1e9 if fam[dom][0] > 0 else 0.0
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": round(fam[dom][0], 4),
+                "launches": fam[dom][1]}
+    kernels = {k: {"avg_ms": round(v[0], 4), "launches": v[1],
+                   "algorithmic_GBps": round(algo[k] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+               for k, v in fam.items()}
+    pipeline_bytes = algo["ingest_mct"] + algo["dwt53_5levels"] + algo["ht_cleanup_encode"]
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = pixels_per_step * world * args.steps / dt / 1e6
+        out = {
+            "metric": "encode Mpixels/s (whole node), 8K RGB HTJ2K lossless",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": desc, "tiles_per_gpu": ntiles, "code_blocks_per_gpu": int(nblocks),
+                       "coded_bytes_per_gpu": int(total), "generator": "G2 (SURVEY.md §8d)",
+                       "parallelism": "tile-sharded x%d, coded tile-parts gathered on rank 0 (RCCL)" % world
+                       if world > 1 else "1 GPU"},
+            "roofline": roofline,
+            "pipeline": {"algorithmic_bytes_per_step": int(pipeline_bytes),
+                         "achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _as_tensor(ptr, nbytes, dev):
+    """Zero-copy uint8 view of a raw device pointer (context-owned arena)."""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device=dev)
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,7 @@ struct grk_amd_ctx {
     uint64_t last_nblocks = 0;
     // timing
     bool timing = false;
-    Timer timers[4];
+    Timer timers[5];
 };
 
 namespace {
@@ -231,9 +231,14 @@ int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
     k.slots = a.slots; k.slot_bytes = slot; k.lengths = a.lengths; k.nblocks = (uint32_t)nblocks;
     k.offsets = (uint64_t*)c->offsets.p; k.arena = (uint8_t*)c->arena.p; k.arena_bytes = c->arena.cap;
     k.overflow_flag = (uint32_t*)c->flag.p;
-    ScopedTimer t(c, 2);
-    HIP_TRY(c, launch_ht_encode(a, c->stream), "launch ht encode");
-    HIP_TRY(c, launch_compact(k, c->stream), "launch compaction");
+    {
+        ScopedTimer t(c, 2);
+        HIP_TRY(c, launch_ht_encode(a, c->stream), "launch ht encode");
+    }
+    {
+        ScopedTimer t(c, 4);
+        HIP_TRY(c, launch_compact(k, c->stream), "launch compaction");
+    }
     c->last_ntiles = ntiles;
     c->last_nblocks = nblocks;
     return GRK_AMD_OK;
@@ -420,7 +425,7 @@ int grk_amd_enable_timing(grk_amd_ctx* c, int on)
 
 double grk_amd_kernel_ms(grk_amd_ctx* c, int which, uint32_t* launches)
 {
-    if (!c || which < 0 || which > 3) return -1.0;
+    if (!c || which < 0 || which > 4) return -1.0;
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
     if (launches) *launches = c->timers[which].launches;

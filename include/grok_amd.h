@@ -126,7 +126,7 @@ int  grk_amd_synchronize(grk_amd_ctx* ctx);
 int grk_amd_stage_ingest_mct(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
                              const void* d_pixels, void* d_planes);
 /* forward DWT of num_planes planes: d_in (ingest planes) -> d_out (Mallat layout); d_in is
- * clobbered (its top-left quadrant is reused as LL ping-pong storage). */
+ * left untouched (intermediate LL planes live in context-owned ping-pong buffers). */
 int grk_amd_stage_dwt_fwd(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_planes,
                           void* d_in, void* d_out);
 /* HT cleanup-encode every block of num_tiles tiles from Mallat planes into the context arena. */
@@ -135,7 +135,8 @@ int grk_amd_stage_ht_encode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint
 
 /* average duration (ms) of the named kernel family over the launches since the last reset,
  * measured with HIP events on the context's stream when timing is enabled.
- * which: 0 ingest+mct, 1 dwt (all levels), 2 ht encode, 3 whole encode_tiles call */
+ * which: 0 ingest+mct, 1 dwt (all levels), 2 ht encode kernel, 3 whole encode_tiles call,
+ *        4 offset scan + compaction */
 int    grk_amd_enable_timing(grk_amd_ctx* ctx, int on);
 double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
 
