@@ -162,7 +162,8 @@ def gpu_codestream(px, prec, L, TW=None, TH=None):
     ("g0", 1, 64, 64, 0, "4afbe3defe07e7ca0e8d4c1d5433b84d"),
     ("g0", 1, 128, 128, 1, "8ae843154d7f6f1283e796a9bd029758"),
     ("g2", 3, 1024, 1024, 5, "2ec6724e8acd2796841140b37cf5ca72"),
-    ("g2", 3, 4096, 4096, 5, "9acbfe328b6611cfec34020db95f3c5b")])     # BASELINE configs[1]
+    ("g2", 3, 4096, 4096, 5, "9acbfe328b6611cfec34020db95f3c5b"),      # BASELINE configs[1]
+    ("g2", 3, 8192, 8192, 5, "7e5275ef3d61edd7b95332bef74a986c")])     # BASELINE metric shape (md5 of oracle/_ref run)
 def test_gpu_codestream_md5_vs_grok(gen, C, W, H, L, md5):
     cs = gpu_codestream(getattr(synth, gen)(C, H, W), 8, L)
     assert hashlib.md5(cs).hexdigest() == md5
