@@ -312,11 +312,23 @@ void orc_ht_signmag_irrev(const float* src, uint32_t stride, uint32_t w, uint32_
 }
 
 /* ------------------------------------------------------------------ a11 HT cleanup encoder */
+/* Optional taps that record the RAW (un-stuffed) MagSgn / VLC bit streams and the MEL state just
+ * before termination; used by ht_wave_model.c to validate the wave-parallel phase-B formulation. */
+typedef struct { uint32_t* bits; uint32_t n, cap_words; } raw_tap;
+static __thread raw_tap* g_tap_ms = NULL;
+static __thread raw_tap* g_tap_vlc = NULL;
+static __thread int* g_tap_mel = NULL;      /* [pos, acc, left, run] */
+static void tap_put(raw_tap* t, uint32_t v, int n)
+{
+    for (int i = 0; i < n; ++i, ++t->n)
+        if (((v >> i) & 1) && (t->n >> 5) < t->cap_words) t->bits[t->n >> 5] |= 1u << (t->n & 31);
+}
 /* forward LSB-first packer with 0xFF -> next-byte-7-bits stuffing (MagSgn; :415-454) */
 typedef struct { uint8_t* buf; uint32_t pos, cap; uint32_t acc; int used, limit; } fwd_bits;
 static void fb_init(fwd_bits* b, uint8_t* buf, uint32_t cap) { b->buf = buf; b->pos = 0; b->cap = cap; b->acc = 0; b->used = 0; b->limit = 8; }
 static int fb_put(fwd_bits* b, uint32_t v, int n)
 {
+    if (g_tap_ms) tap_put(g_tap_ms, v, n);
     while (n > 0) {
         int t = b->limit - b->used; if (t > n) t = n;
         b->acc |= (v & ((1u << t) - 1)) << b->used;
@@ -372,6 +384,7 @@ static void vlc_init_(vlc_enc* v, uint8_t* buf, uint32_t cap)
 { v->end = buf + cap - 1; v->pos = 1; v->cap = cap; v->end[0] = 0xFF; v->used = 4; v->acc = 0xF; v->prev_gt8f = 1; }
 static void vlc_put(vlc_enc* v, int cw, int n)
 {
+    if (g_tap_vlc) tap_put(g_tap_vlc, (uint32_t)cw, n);
     while (n > 0) {
         int room = 8 - v->prev_gt8f - v->used;
         int t = room < n ? room : n;
@@ -490,6 +503,7 @@ int32_t orc_ht_encode_sm(const uint32_t* sm, uint32_t kmax, uint32_t w, uint32_t
     }
 
     /* ---- termination (:357-385, :438-454) */
+    if (g_tap_mel) { g_tap_mel[0] = (int)mel.pos; g_tap_mel[1] = mel.acc; g_tap_mel[2] = mel.left; g_tap_mel[3] = mel.run; }
     if (mel.run > 0) mel_bit(&mel, 1);
     {
         int mel_acc = mel.acc << mel.left;
@@ -522,6 +536,32 @@ int32_t orc_ht_encode_sm(const uint32_t* sm, uint32_t kmax, uint32_t w, uint32_t
 overflow:
     free(ms_buf); free(mel_buf); free(vlc_buf); free(row); free(eb); free(sb);
     return -1;
+}
+
+/* raw streams of one block (test support for the wave model): MagSgn bits, VLC bits (starting
+ * with the four initial 1 bits of vlc_init), MEL bytes produced so far + coder state */
+int32_t orc_ht_raw_streams(const uint32_t* sm, uint32_t kmax, uint32_t w, uint32_t h,
+                           uint32_t* ms_raw, uint32_t ms_words, uint32_t* ms_bits,
+                           uint32_t* vlc_raw, uint32_t vlc_words, uint32_t* vlc_bits,
+                           uint8_t* mel_bytes, int* mel_state /* [pos,acc,left,run] */)
+{
+    raw_tap tm = {ms_raw, 0, ms_words}, tv = {vlc_raw, 0, vlc_words};
+    memset(ms_raw, 0, ms_words * 4); memset(vlc_raw, 0, vlc_words * 4);
+    tap_put(&tv, 0xF, 4);
+    uint32_t cap = 4 * w * h + 8192;
+    uint8_t* tmp = (uint8_t*)malloc(cap);
+    g_tap_ms = &tm; g_tap_vlc = &tv; g_tap_mel = mel_state;
+    int32_t n = orc_ht_encode_sm(sm, kmax, w, h, tmp, cap);
+    g_tap_ms = NULL; g_tap_vlc = NULL; g_tap_mel = NULL;
+    /* MEL bytes are a prefix of the MEL segment of the output: [ms_len, ms_len + pos) -- recover
+     * them by re-encoding is unnecessary: Scup tells where MEL starts */
+    if (n > 0) {
+        uint32_t scup = ((uint32_t)tmp[n - 1] << 4) | (tmp[n - 2] & 0xF);
+        memcpy(mel_bytes, tmp + (n - (int32_t)scup), (size_t)mel_state[0]);
+    }
+    *ms_bits = tm.n; *vlc_bits = tv.n;
+    free(tmp);
+    return n;
 }
 
 int32_t orc_ht_encode_block_rev(const int32_t* src, uint32_t stride, uint32_t w, uint32_t h,

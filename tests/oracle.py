@@ -141,3 +141,32 @@ def encode_tile_rev(pixels, prec, levels, mct=None):
                               blocks, lens.ctypes.data, nb, coded.ctypes.data, cap, C.byref(tot))
     assert n == nb, n
     return list(blocks), lens, coded[:tot.value]
+
+
+def _bind_model():
+    L = lib()
+    vp, u32 = C.c_void_p, C.c_uint32
+    L.orc_ht_raw_streams.restype = C.c_int32
+    L.orc_ht_raw_streams.argtypes = [vp, u32, u32, u32, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), vp, vp]
+    L.orc_ht_model_phase_b.restype = C.c_int32
+    L.orc_ht_model_phase_b.argtypes = [vp, u32, vp, u32, vp, vp, vp]
+    return L
+
+
+def ht_wave_model(sm, kmax):
+    """raw streams of the oracle encoder -> wave-parallel phase-B model -> bytes"""
+    L = _bind_model()
+    a = np.ascontiguousarray(sm, np.uint32)
+    h, w = a.shape
+    msw = w * h * (kmax + 2) // 32 + 8
+    vw = 1024
+    ms = np.zeros(msw, np.uint32)
+    vl = np.zeros(vw, np.uint32)
+    mel = np.zeros(512, np.uint8)
+    st = (C.c_int * 4)()
+    mb, vb = C.c_uint32(0), C.c_uint32(0)
+    nref = L.orc_ht_raw_streams(a.ctypes.data, kmax, w, h, ms.ctypes.data, msw, C.byref(mb),
+                                vl.ctypes.data, vw, C.byref(vb), mel.ctypes.data, st)
+    out = np.zeros(nref + 64, np.uint8)
+    nm = L.orc_ht_model_phase_b(ms.ctypes.data, mb.value, vl.ctypes.data, vb.value, mel.ctypes.data, st, out.ctypes.data)
+    return out[:nm].tobytes()

@@ -1,0 +1,23 @@
+"""CPU: the wave-parallel phase-B formulation (oracle/ht_wave_model.c, which the HIP kernel
+transliterates) equals the serial stuffing writers of the oracle on adversarial inputs."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+
+@pytest.mark.parametrize("mode", range(6))
+def test_wave_model_matches_oracle(mode):
+    rng = np.random.default_rng(100 + mode)
+    for trial in range(60):
+        w, h, kmax = int(rng.integers(1, 65)), int(rng.integers(1, 65)), int(rng.integers(2, 20))
+        if trial % 3 == 0:
+            w = h = 64
+        mag = rng.integers(0, 1 << kmax, size=(h, w))
+        if mode == 1: mag = mag >> rng.integers(0, kmax, size=(h, w))
+        if mode == 2: mag = np.where(rng.random((h, w)) < 0.9, 0, mag)
+        if mode == 3: mag = mag & 3
+        if mode == 4: mag = np.full((h, w), (1 << kmax) - 1)              # every MagSgn byte is 0xFF
+        if mode == 5: mag = np.where(rng.random((h, w)) < 0.5, (1 << kmax) - 1, mag)
+        sm = O.signmag(mag * np.where(rng.random((h, w)) < 0.5, -1, 1), kmax)
+        assert O.ht_wave_model(sm, kmax) == O.ht_encode_sm(sm, kmax), (w, h, kmax, mode)
