@@ -48,12 +48,14 @@ struct grk_amd_ctx {
     bool own_stream = false;
     std::string err;
     // working set
-    DevBuf pixels, p0, p1, llA, llB, blockdesc, slots, lengths, offsets, arena, flag;
+    DevBuf pixels, p0, p1, llA, llB, blockdesc, lengths, offsets, arena, flag;
     // geometry cache
     grk_amd_tile_params gp{};
     bool have_geom = false;
     TileGeom geom;
     std::vector<HtBlockDesc> h_desc;
+    std::vector<uint64_t> h_off;
+    std::vector<uint32_t> h_len;
     uint32_t last_ntiles = 0;
     uint64_t last_nblocks = 0;
     // timing
@@ -194,17 +196,13 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out)
     return GRK_AMD_OK;
 }
 
-uint32_t slot_bytes_for(const TileGeom& g, uint32_t& max_kmax, uint32_t& max_samples)
+void block_extents(const TileGeom& g, uint32_t& max_kmax, uint32_t& max_samples)
 {
     max_kmax = 0; max_samples = 0;
     for (const auto& b : g.blocks_comp0) {
         max_kmax = std::max<uint32_t>(max_kmax, b.kmax);
         max_samples = std::max<uint32_t>(max_samples, (b.x1 - b.x0) * (b.y1 - b.y0));
     }
-    // MagSgn: <= (kmax+1) bits/sample, 8/7 stuffing worst case; MEL <= 192 B; VLC <= 4 KiB
-    uint64_t ms = ((uint64_t)max_samples * (max_kmax + 2) + 7) / 8;
-    ms = ms * 8 / 7 + 64;
-    return (uint32_t)((ms + 192 + 4096 + 255) & ~255ull);
 }
 
 int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
@@ -213,31 +211,27 @@ int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
     uint32_t max_kmax, max_samples;
-    const uint32_t slot = slot_bytes_for(g, max_kmax, max_samples);
-    HIP_TRY(c, c->slots.ensure(nblocks * slot), "alloc block slots");
+    block_extents(g, max_kmax, max_samples);
     HIP_TRY(c, c->lengths.ensure(nblocks * 4), "alloc lengths");
     HIP_TRY(c, c->offsets.ensure((nblocks + 1) * 8), "alloc offsets");
     HIP_TRY(c, c->flag.ensure(64), "alloc flag");
-    // arena: generous bound = half of the slot space (typical lossless output is ~50% of 1 B/sample)
+    // arena: worst case of the HT cleanup pass is ~ (kmax+1)/8 * 8/7 bytes per sample + VLC/MEL;
+    // twice the raw input size plus per-block slack covers every lossless case we accept
     const uint64_t raw = (uint64_t)ntiles * g.p.num_comps * g.p.tile_w * g.p.tile_h * ((g.p.prec + 7) / 8);
-    HIP_TRY(c, c->arena.ensure(raw * 2 + nblocks * 32 + (1u << 20)), "alloc coded arena");
+    HIP_TRY(c, c->arena.ensure(raw * 2 + nblocks * 64 + (1u << 20)), "alloc coded arena");
+    // flag[0] = overflow flag, flag[2..3] = 64-bit arena cursor
     HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, 64, c->stream), "clear flag");
     HtArgs a{};
     a.mallat = (const int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.blocks = (const HtBlockDesc*)c->blockdesc.p; a.blocks_per_tile = bpt; a.ncomp = g.p.num_comps; a.ntiles = ntiles;
-    a.slots = (uint8_t*)c->slots.p; a.slot_bytes = slot; a.lengths = (uint32_t*)c->lengths.p;
+    a.arena = (uint8_t*)c->arena.p; a.arena_bytes = c->arena.cap;
+    a.cursor = (unsigned long long*)((uint8_t*)c->flag.p + 8);
+    a.lengths = (uint32_t*)c->lengths.p; a.offsets = (unsigned long long*)c->offsets.p;
+    a.overflow_flag = (uint32_t*)c->flag.p;
     a.irreversible = g.p.irreversible; a.max_kmax = max_kmax; a.max_block_samples = max_samples;
-    CompactArgs k{};
-    k.slots = a.slots; k.slot_bytes = slot; k.lengths = a.lengths; k.nblocks = (uint32_t)nblocks;
-    k.offsets = (uint64_t*)c->offsets.p; k.arena = (uint8_t*)c->arena.p; k.arena_bytes = c->arena.cap;
-    k.overflow_flag = (uint32_t*)c->flag.p;
     {
         ScopedTimer t(c, 2);
         HIP_TRY(c, launch_ht_encode(a, c->stream), "launch ht encode");
-    }
-    {
-        ScopedTimer t(c, 4);
-        HIP_TRY(c, launch_compact(k, c->stream), "launch compaction");
     }
     c->last_ntiles = ntiles;
     c->last_nblocks = nblocks;
@@ -272,7 +266,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
-    for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->slots, &c->lengths,
+    for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
                       &c->offsets, &c->arena, &c->flag})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -352,17 +346,18 @@ int grk_amd_fetch_table(grk_amd_ctx* c, grk_amd_coded_block* table, uint64_t* to
     if (!c || !c->last_nblocks) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     const uint64_t n = c->last_nblocks;
-    std::vector<uint64_t> off(n + 1);
-    std::vector<uint32_t> len(n);
-    uint32_t flag = 0;
-    HIP_TRY(c, hipMemcpyAsync(off.data(), c->offsets.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream), "fetch offsets");
-    HIP_TRY(c, hipMemcpyAsync(len.data(), c->lengths.p, n * 4, hipMemcpyDeviceToHost, c->stream), "fetch lengths");
-    HIP_TRY(c, hipMemcpyAsync(&flag, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream), "fetch flag");
+    uint64_t flagwords[2] = {0, 0};       // [0] low 32 bits: overflow flag, [1]: arena cursor
+    HIP_TRY(c, hipMemcpyAsync(flagwords, c->flag.p, 16, hipMemcpyDeviceToHost, c->stream), "fetch flag");
+    if (table) {
+        c->h_off.resize(n); c->h_len.resize(n);
+        HIP_TRY(c, hipMemcpyAsync(c->h_off.data(), c->offsets.p, n * 8, hipMemcpyDeviceToHost, c->stream), "fetch offsets");
+        HIP_TRY(c, hipMemcpyAsync(c->h_len.data(), c->lengths.p, n * 4, hipMemcpyDeviceToHost, c->stream), "fetch lengths");
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
-    if (flag) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
+    if (flagwords[0] & 0xFFFFFFFFu) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
     if (table)
-        for (uint64_t i = 0; i < n; ++i) { table[i].offset = off[i]; table[i].length = len[i]; table[i].reserved = 0; }
-    if (total) *total = off[n];
+        for (uint64_t i = 0; i < n; ++i) { table[i].offset = c->h_off[i]; table[i].length = c->h_len[i]; table[i].reserved = 0; }
+    if (total) *total = flagwords[1];
     return GRK_AMD_OK;
 }
 

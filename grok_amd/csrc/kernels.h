@@ -43,22 +43,15 @@ struct HtBlockDesc {        // one per code-block of a tile-component set (all c
 struct HtArgs {
     const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp]
     const HtBlockDesc* blocks; uint32_t blocks_per_tile; uint32_t ncomp; uint32_t ntiles;
-    uint8_t*  slots;  uint32_t slot_bytes;      // per-block scratch slots
+    uint8_t*  arena; uint64_t arena_bytes;      // coded bytes of all blocks, allocated by atomic cursor
+    unsigned long long* cursor;                 // bytes used in the arena (zeroed per call)
     uint32_t* lengths;                          // [ntiles*blocks_per_tile]
+    unsigned long long* offsets;                // [ntiles*blocks_per_tile]
+    uint32_t* overflow_flag;
     int irreversible;
     uint32_t max_kmax;            // largest kmax among the blocks (sizes the raw MagSgn LDS buffer)
     uint32_t max_block_samples;   // largest w*h among the blocks
 };
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);
-
-// ---- K4: offsets (exclusive scan of lengths, 16-byte aligned) + compaction -------------------
-struct CompactArgs {
-    const uint8_t* slots; uint32_t slot_bytes;
-    const uint32_t* lengths; uint32_t nblocks;
-    uint64_t* offsets;          // [nblocks+1]; offsets[nblocks] = total
-    uint8_t* arena; uint64_t arena_bytes;
-    uint32_t* overflow_flag;
-};
-hipError_t launch_compact(const CompactArgs& a, hipStream_t s);
 
 } // namespace grk_amd

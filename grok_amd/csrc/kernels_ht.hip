@@ -37,7 +37,7 @@ __device__ __forceinline__ void mel_put_bit(MelState& m, uint8_t* buf, int v, bo
 {
     m.acc = (m.acc << 1) | v;
     if (--m.left == 0) {
-        if (writer) buf[m.pos] = (uint8_t)m.acc;
+        if (writer && m.pos < 250) buf[m.pos] = (uint8_t)m.acc;   // valid streams stay < 128 bytes (:475)
         m.pos++;
         m.left = (m.acc == 0xFF) ? 7 : 8;
         m.acc = 0;
@@ -103,13 +103,63 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
-template <bool IRREV>
-__global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_words, uint32_t vlc_words)
+// Event walker shared by the MagSgn and VLC streams (oracle/ht_wave_model.c: walk()).
+// 64 lanes test 64 raw words per round for positions of the current byte phase where a stuffing
+// event can happen; every event marks one OUTPUT byte index as "7 bits wide".
+template <bool VLC>
+__device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nwords, uint32_t nbits,
+                                                uint32_t* marks, uint32_t& last_p, int lane)
 {
+    uint32_t K = 0, s = 0;
+    constexpr uint32_t need = VLC ? 7 : 8;
+    while (s + need <= nbits) {
+        const uint32_t B = s >> 5, phase = s & 7;
+        const uint32_t i = B + lane;
+        const uint32_t w0 = i < nwords ? raw[i] : 0u;
+        const uint32_t w1 = i + 1 < nwords ? raw[i + 1] : 0u;
+        const uint64_t hi = w0 | ((uint64_t)w1 << 32);
+        uint64_t c = hi & (hi >> 1);
+        c &= c >> 2;
+        uint32_t cand;
+        if constexpr (!VLC) {
+            c &= c >> 4;
+            cand = (uint32_t)c;
+        } else {
+            c &= c >> 3;
+            const uint32_t wm = i == 0 ? 0xFFFFFFFFu : (i - 1 < nwords ? raw[i - 1] : 0u);
+            const uint64_t lo = wm | ((uint64_t)w0 << 32);
+            const uint64_t pv = (lo >> 31) & ((lo >> 30) | (lo >> 29) | (lo >> 28));
+            cand = (uint32_t)c & (uint32_t)pv;
+        }
+        uint32_t m = 0x01010101u << phase;
+        if (lane == 0) m &= 0xFFFFFFFFu << (s & 31);
+        const uint32_t hit = cand & m;
+        const uint64_t ballot = __ballot(hit != 0);
+        if (!ballot) { s = 32 * (B + 64) + phase; continue; }
+        const int L = __ffsll((long long)ballot) - 1;
+        const uint32_t hl = __shfl(hit, L);
+        const uint32_t p = 32 * (B + (uint32_t)L) + (uint32_t)(__ffs((int)hl) - 1);
+        const uint32_t j = (p + K) >> 3;
+        const uint32_t mj = VLC ? j : j + 1;
+        if (lane == 0) marks[mj >> 5] |= 1u << (mj & 31);
+        ++K; last_p = p;
+        s = p + 15;
+    }
+    return K;
+}
+
+template <bool IRREV>
+__global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_words, uint32_t vlc_words, uint32_t mark_words, uint32_t vmark_words)
+{
+    // LDS: raw MagSgn bits | raw VLC bits | 64 zero words | 7-bit-byte bitmaps | their prefix counts | MEL bytes
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* ms_raw  = smem;
     uint32_t* vlc_raw = smem + ms_words;
-    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(smem + ms_words + vlc_words);
+    uint32_t* marks   = vlc_raw + vlc_words;
+    uint32_t* vmarks  = marks + mark_words;
+    uint16_t* pref    = reinterpret_cast<uint16_t*>(vmarks + vmark_words);
+    uint16_t* vpref   = pref + mark_words;
+    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(vpref + vmark_words);     // 256 bytes
 
     const int lane = threadIdx.x;
     const uint32_t gid = blockIdx.x;
@@ -119,8 +169,9 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
     const int32_t* src = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
     const uint32_t p = 30u - bd.kmax;
+    const bool vec2 = ((bd.px | a.stride) & 1u) == 0;      // 8-byte row-pair loads are aligned
 
-    for (uint32_t i = lane; i < ms_words + vlc_words + 64; i += 64) smem[i] = 0;
+    for (uint32_t i = lane; i < ms_words + vlc_words; i += 64) smem[i] = 0;
     __syncthreads();
     if (lane == 0) vlc_raw[0] = 0xF;             // vlc_init: four 1 bits pending (:315-318)
     __syncthreads();
@@ -135,24 +186,36 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
         const uint32_t qy = 2 * it + half;
         const bool active = qx < QW && qy < QH;
         // ---- samples -> sign-magnitude words (T1HT.cpp:71-84 / dead-zone quantiser) ----------
+        int32_t rawv[4] = {0, 0, 0, 0};          // [0]=(x0,y0) [1]=(x0,y0+1) [2]=(x0+1,y0) [3]=(x0+1,y0+1)
+        {
+            const uint32_t x0 = 2 * qx, y0 = 2 * qy;
+            if (x0 < w && y0 < h) {
+                const int32_t* row0 = src + (size_t)y0 * a.stride + x0;
+                const bool pair = x0 + 1 < w;
+                if (vec2 && pair) { const int2 q = *reinterpret_cast<const int2*>(row0); rawv[0] = q.x; rawv[2] = q.y; }
+                else { rawv[0] = row0[0]; if (pair) rawv[2] = row0[1]; }
+                if (y0 + 1 < h) {
+                    const int32_t* row1 = row0 + a.stride;
+                    if (vec2 && pair) { const int2 q = *reinterpret_cast<const int2*>(row1); rawv[1] = q.x; rawv[3] = q.y; }
+                    else { rawv[1] = row1[0]; if (pair) rawv[3] = row1[1]; }
+                }
+            }
+        }
         uint32_t tw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t x = 2 * qx + (i >> 1), y = 2 * qy + (i & 1);
-            uint32_t t = 0;
-            if (x < w && y < h) {
-                const int32_t raw = src[(size_t)y * a.stride + x];
-                if constexpr (IRREV) {
-                    const float c = __int_as_float(raw);
-                    float q = __fmul_rn(fabsf(c), bd.inv_step);
-                    uint32_t mag = (uint32_t)q;
-                    const uint32_t lim = (1u << bd.kmax) - 1u;
-                    mag = mag > lim ? lim : mag;
-                    t = ((c < 0.f && mag) ? 0x80000000u : 0u) | (mag << p);
-                } else {
-                    const uint32_t mag = (uint32_t)(raw < 0 ? -raw : raw);
-                    t = (raw < 0 ? 0x80000000u : 0u) | (mag << p);
-                }
+            const int32_t raw = rawv[i];
+            uint32_t t;
+            if constexpr (IRREV) {
+                const float c = __int_as_float(raw);
+                float q = __fmul_rn(fabsf(c), bd.inv_step);
+                uint32_t mag = (uint32_t)q;
+                const uint32_t lim = (1u << bd.kmax) - 1u;
+                mag = mag > lim ? lim : mag;
+                t = ((c < 0.f && mag) ? 0x80000000u : 0u) | (mag << p);
+            } else {
+                const uint32_t mag = (uint32_t)(raw < 0 ? -raw : raw);
+                t = (raw < 0 ? 0x80000000u : 0u) | (mag << p);
             }
             tw[i] = t;
         }
@@ -264,103 +327,124 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     }
     __syncthreads();
 
-    // ================= phase B (v1: serial in lane 0) ============================================
-    uint8_t* out = a.slots + (size_t)gid * a.slot_bytes;
-    if (lane == 0) {
-        // MagSgn: forward, 0xFF -> next byte carries 7 bits (:415-454)
-        uint32_t pos = 0, nb = 0, limit = 8;
-        while (ms_bits - pos >= limit) {
-            const uint32_t b = get_bits(ms_raw, pos, limit);
-            out[nb++] = (uint8_t)b;
-            pos += limit;
-            limit = (b == 0xFF) ? 7 : 8;
-        }
-        const uint32_t rem = ms_bits - pos;
-        if (rem > 0) {
-            const uint32_t b = get_bits(ms_raw, pos, rem) | ((((1u << (limit - rem)) - 1u) << rem) & 0xFF);
-            if (b != 0xFF) out[nb++] = (uint8_t)b;
-        } else if (limit == 7) {
-            nb--;
-        }
-        const uint32_t ms_len = nb;
-        // VLC: bytes grow downwards from the end of the slot (:296-351)
-        uint8_t* vend = out + a.slot_bytes - 1;
-        vend[0] = 0xFF;
-        uint32_t vpos = 1, vp = 0;
-        int prev_gt = 1;
-        uint32_t vacc = 0, vused = 0;
-        for (;;) {
-            const uint32_t avail = vlc_bits - vp;
-            if (prev_gt && avail >= 7 && get_bits(vlc_raw, vp, 7) == 0x7F) {
-                *(vend - vpos) = 0x7F; vpos++; vp += 7; prev_gt = 0;
-                continue;
-            }
-            if (avail < 8) { vused = avail; vacc = avail ? get_bits(vlc_raw, vp, avail) : 0; break; }
-            const uint32_t b = get_bits(vlc_raw, vp, 8);
-            *(vend - vpos) = (uint8_t)b; vpos++; vp += 8; prev_gt = b > 0x8F;
-        }
-        // termination of MEL and VLC (:357-385)
-        if (mel.run > 0) mel_put_bit(mel, mel_buf, 1, true);
-        {
-            const int mel_acc = mel.acc << mel.left;
-            const int mel_mask = (0xFF << mel.left) & 0xFF;
-            const int vlc_mask = 0xFF >> (8 - vused);
-            if ((mel_mask | vlc_mask) != 0) {
-                const int fuse = mel_acc | (int)vacc;
-                if ((((fuse ^ mel_acc) & mel_mask) | ((fuse ^ (int)vacc) & vlc_mask)) == 0 && fuse != 0xFF && vpos > 1) {
-                    mel_buf[mel.pos++] = (uint8_t)fuse;
-                } else {
-                    mel_buf[mel.pos++] = (uint8_t)mel_acc;
-                    *(vend - vpos) = (uint8_t)vacc; vpos++;
-                }
-            }
-        }
-        // concatenate MagSgn | MEL | VLC and patch Scup (:924-935)
-        for (uint32_t i = 0; i < mel.pos; ++i) out[ms_len + i] = mel_buf[i];
-        const uint32_t total = ms_len + mel.pos + vpos;
-        uint8_t* vdst = out + ms_len + mel.pos;
-        const uint8_t* vsrc = vend - vpos + 1;
-        for (uint32_t i = 0; i < vpos; ++i) vdst[i] = vsrc[i];       // vdst < vsrc: ascending copy is safe
-        const uint32_t scup = mel.pos + vpos;
-        out[total - 1] = (uint8_t)(scup >> 4);
-        out[total - 2] = (uint8_t)((out[total - 2] & 0xF0) | (scup & 0xF));
-        a.lengths[gid] = total;
-    }
-}
-
-// ---- K4: exclusive scan of lengths (16-byte aligned slots in the arena) + gather ---------------
-__global__ __launch_bounds__(1024) void scan_offsets_kernel(CompactArgs a)
-{
-    __shared__ uint64_t part[1024];
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (a.nblocks + 1023) / 1024;
-    const uint32_t b0 = t * per, b1 = min(a.nblocks, b0 + per);
-    uint64_t sum = 0;
-    for (uint32_t i = b0; i < b1; ++i) sum += (a.lengths[i] + 15u) & ~15u;
-    part[t] = sum;
+    // ================= phase B: stuffing, termination, emission (see oracle/ht_wave_model.c) =====
+    const uint32_t msw = ms_words, vw = vlc_words;          // raw buffers are followed by zeroed words
+    for (uint32_t i = lane; i < mark_words + vmark_words; i += 64) marks[i] = 0;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint64_t o = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += o;
-        __syncthreads();
+
+    // ---- B1: MagSgn events
+    uint32_t last_p = 0;
+    const uint32_t K = walk_events<false>(ms_raw, msw, ms_bits, marks, last_p, lane);
+    uint32_t pos, limit, nfull;
+    if (K && last_p + 15 > ms_bits) { pos = last_p + 8; limit = 7; nfull = (pos + K - 1) >> 3; }
+    else { const uint32_t s0 = K ? last_p + 15 : 0; pos = s0 + 8 * ((ms_bits - s0) >> 3); limit = 8; nfull = (pos + K) >> 3; }
+    const uint32_t rem = ms_bits - pos;
+    uint32_t ms_len, final_byte = 0, has_final = 0;
+    if (rem > 0) {
+        final_byte = get_bits(ms_raw, pos, rem) | ((((1u << (limit - rem)) - 1u) << rem) & 0xFF);
+        has_final = final_byte != 0xFF;
+        ms_len = nfull + has_final;
+    } else {
+        ms_len = (limit == 7) ? nfull - 1 : nfull;
     }
-    uint64_t off = part[t] - sum;
-    for (uint32_t i = b0; i < b1; ++i) { a.offsets[i] = off; off += (a.lengths[i] + 15u) & ~15u; }
-    if (t == 1023) {
-        a.offsets[a.nblocks] = part[1023];
-        if (part[1023] > a.arena_bytes) *a.overflow_flag = 1;
+    const uint32_t ms_emit = min(nfull, ms_len);
+
+    // ---- B2: VLC events + tail
+    uint32_t vlast = 0;
+    const uint32_t Kv = walk_events<true>(vlc_raw, vw, vlc_bits, vmarks, vlast, lane);
+    const uint32_t vs0 = Kv ? vlast + 7 : 0;
+    const uint32_t vposr = vs0 + 8 * ((vlc_bits - vs0) >> 3);
+    const uint32_t vused = vlc_bits - vposr;
+    const uint32_t vacc = vused ? get_bits(vlc_raw, vposr, vused) : 0;
+    const uint32_t nv = (vposr + Kv) >> 3;
+
+    // ---- B3: MEL / VLC termination (terminate_mel_vlc :357-385), wave-uniform
+    if (mel.run > 0) mel_put_bit(mel, mel_buf, 1, lane == 0);
+    uint32_t vextra = 0;
+    {
+        const int macc = mel.acc << mel.left;
+        const int mel_mask = (0xFF << mel.left) & 0xFF;
+        const int vlc_mask = 0xFF >> (8 - (int)vused);
+        if ((mel_mask | vlc_mask) != 0) {
+            const int fuse = macc | (int)vacc;
+            if ((((fuse ^ macc) & mel_mask) | ((fuse ^ (int)vacc) & vlc_mask)) == 0 && fuse != 0xFF && nv >= 1) {
+                if (lane == 0 && mel.pos < 250) mel_buf[mel.pos] = (uint8_t)fuse;
+            } else {
+                if (lane == 0 && mel.pos < 250) mel_buf[mel.pos] = (uint8_t)macc;
+                vextra = 1;
+            }
+            mel.pos++;
+        }
     }
-}
-__global__ __launch_bounds__(64) void gather_kernel(CompactArgs a)
-{
-    const uint32_t b = blockIdx.x;
-    const uint64_t off = a.offsets[b];
-    const uint32_t len = a.lengths[b];
-    if (off + len > a.arena_bytes) return;
-    const uint4* s = reinterpret_cast<const uint4*>(a.slots + (size_t)b * a.slot_bytes);
-    uint4* d = reinterpret_cast<uint4*>(a.arena + off);
-    for (uint32_t i = threadIdx.x; i < (len + 15) / 16; i += 64) d[i] = s[i];
+    const uint32_t mel_len = mel.pos;
+    const uint32_t vcount = nv + vextra;
+    const uint32_t total = ms_len + mel_len + vcount + 1;
+    const uint32_t scup = mel_len + vcount + 1;
+
+    // ---- B4: prefix popcounts of the mark bitmaps (one pass covers both bitmaps back to back)
+    {
+        uint32_t base = 0;
+        for (uint32_t w0 = 0; w0 < mark_words; w0 += 64) {
+            const uint32_t i = w0 + lane;
+            const uint32_t c = i < mark_words ? __popc(marks[i]) : 0;
+            const uint32_t incl = wave_incl_scan(c, lane);
+            if (i < mark_words) pref[i] = (uint16_t)(base + incl - c);
+            base += __shfl(incl, 63);
+        }
+        base = 0;
+        for (uint32_t w0 = 0; w0 < vmark_words; w0 += 64) {
+            const uint32_t i = w0 + lane;
+            const uint32_t c = i < vmark_words ? __popc(vmarks[i]) : 0;
+            const uint32_t incl = wave_incl_scan(c, lane);
+            if (i < vmark_words) vpref[i] = (uint16_t)(base + incl - c);
+            base += __shfl(incl, 63);
+        }
+    }
+
+    // ---- allocate the block's bytes in the arena (16-byte aligned, order of arrival)
+    unsigned long long base_off = 0;
+    if (lane == 0) base_off = atomicAdd(a.cursor, (unsigned long long)((total + 15u) & ~15u));
+    base_off = ((unsigned long long)__shfl((uint32_t)(base_off >> 32), 0) << 32) | __shfl((uint32_t)base_off, 0);
+    if (lane == 0) { a.lengths[gid] = total; a.offsets[gid] = base_off; }
+    if (base_off + total > a.arena_bytes) {
+        if (lane == 0) *a.overflow_flag = 1;
+        return;
+    }
+    uint8_t* out = a.arena + base_off;
+    __syncthreads();
+
+    // ---- B5: emission. MagSgn: one dword (4 bytes) per lane and iteration, coalesced stores
+    for (uint32_t j = 4 * lane; j < ms_emit; j += 256) {
+        const uint32_t wd = j >> 5, bit = j & 31;
+        const uint32_t mw = marks[wd];
+        const uint32_t k = pref[wd] + __popc(mw & ((1u << bit) - 1u));
+        const uint32_t flags = (mw >> bit) & 0xF;
+        uint32_t start = 8 * j - k;
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t n = ((flags >> b) & 1) ? 7u : 8u;
+            word |= get_bits(ms_raw, start, n) << (8 * b);
+            start += n;
+        }
+        if (j + 4 <= ms_emit) *reinterpret_cast<uint32_t*>(out + j) = word;
+        else for (uint32_t b = 0; j + b < ms_emit; ++b) out[j + b] = (uint8_t)(word >> (8 * b));
+    }
+    if (has_final && lane == 0) out[ms_len - 1] = (uint8_t)final_byte;
+    for (uint32_t i = lane; i < mel_len; i += 64) out[ms_len + i] = mel_buf[i < 250 ? i : 249];
+    // VLC bytes are stored in reverse order of generation; the first one carries Scup's low nibble
+    for (uint32_t j = lane; j < nv; j += 64) {
+        const uint32_t wd = j >> 5, bit = j & 31;
+        const uint32_t mw = vmarks[wd];
+        const uint32_t k = vpref[wd] + __popc(mw & ((1u << bit) - 1u));
+        uint32_t byte = get_bits(vlc_raw, 8 * j - k, ((mw >> bit) & 1) ? 7u : 8u);
+        if (j == 0) byte = (byte & 0xF0) | (scup & 0xF);
+        out[total - 2 - j] = (uint8_t)byte;
+    }
+    if (lane == 0) {
+        if (vextra) out[total - 2 - nv] = (uint8_t)(nv == 0 ? ((vacc & 0xF0) | (scup & 0xF)) : vacc);
+        out[total - 1] = (uint8_t)(scup >> 4);
+    }
 }
 
 } // namespace
@@ -379,23 +463,20 @@ hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s)
         if (e != hipSuccess) return e;
         g_tables_ready[dev] = true;
     }
-    // raw MagSgn stream: at most (kmax+1) bits per sample; VLC: <= 24 bits per quad + slack
+    // raw MagSgn stream: at most (kmax+1) bits per sample; VLC: < 32 bits per quad pair.
     const uint32_t max_bits = a.max_block_samples * (a.max_kmax + 2u);
     const uint32_t ms_words = max_bits / 32 + 8;
-    const uint32_t vlc_words = 1024;
-    const size_t shmem = (size_t)(ms_words + vlc_words + 64) * 4;
+    const uint32_t vlc_bits_max = 16u * ((a.max_block_samples + 3) / 4 + 64) + 64;
+    const uint32_t vlc_words = vlc_bits_max / 32 + 8;
+    const uint32_t mark_words = (max_bits / 7 + 64) / 32 + 2;
+    const uint32_t vmark_words = (vlc_bits_max / 7 + 64) / 32 + 2;
+    const size_t shmem = (size_t)(ms_words + vlc_words + mark_words + vmark_words) * 4 +
+                         (size_t)(mark_words + vmark_words + 2) * 2 + 256;
     const uint32_t nblocks = a.blocks_per_tile * a.ntiles;
     if (a.irreversible)
-        hipLaunchKernelGGL(ht_encode_kernel<true>, dim3(nblocks), dim3(64), shmem, s, a, ms_words, vlc_words);
+        hipLaunchKernelGGL(ht_encode_kernel<true>, dim3(nblocks), dim3(64), shmem, s, a, ms_words, vlc_words, mark_words, vmark_words);
     else
-        hipLaunchKernelGGL(ht_encode_kernel<false>, dim3(nblocks), dim3(64), shmem, s, a, ms_words, vlc_words);
-    return hipGetLastError();
-}
-
-hipError_t launch_compact(const CompactArgs& a, hipStream_t s)
-{
-    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(gather_kernel, dim3(a.nblocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(ht_encode_kernel<false>, dim3(nblocks), dim3(64), shmem, s, a, ms_words, vlc_words, mark_words, vmark_words);
     return hipGetLastError();
 }
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ void load4(const PIX* p, bool vec, uint32_t n, int32_
     }
 }
 
-template <typename PIX>
+template <typename PIX, int NC>
 __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a)
 {
     const uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 4u;
@@ -63,21 +63,25 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a)
     const bool vec = (n == 4) && ((a.w & 3u) == 0);
     const bool irrev = a.irreversible != 0;
 
-    int32_t c[4][4];
-    for (uint32_t k = 0; k < a.ncomp; ++k) {
-        load4<PIX>(src + k * comp_px, vec, n, c[k]);
+    // NC is a compile-time constant so that c[][] lives in registers (a runtime bound spills to scratch)
+    int32_t c[NC][4];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        load4<PIX>(src + (size_t)k * comp_px, vec, n, c[k]);
         for (int i = 0; i < 4; ++i) c[k][i] -= a.dc;
     }
-    if (a.mct) {
-        for (int i = 0; i < 4; ++i) color_fwd(c[0][i], c[1][i], c[2][i], irrev);
+    if (NC >= 3 && a.mct) {
+        for (int i = 0; i < 4; ++i) color_fwd(c[0][i], c[NC >= 3 ? 1 : 0][i], c[NC >= 3 ? 2 : 0][i], irrev);
     } else if (irrev) {
         // 9/7 without MCT: the transform works on floats
-        for (uint32_t k = 0; k < a.ncomp; ++k)
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
             for (int i = 0; i < 4; ++i) c[k][i] = __float_as_int((float)c[k][i]);
     }
-    if (a.mct && irrev && a.ncomp > 3)
-        for (int i = 0; i < 4; ++i) c[3][i] = __float_as_int((float)c[3][i]);
-    for (uint32_t k = 0; k < a.ncomp; ++k) {
+    if (NC > 3 && a.mct && irrev)
+        for (int i = 0; i < 4; ++i) c[NC > 3 ? 3 : 0][i] = __float_as_int((float)c[NC > 3 ? 3 : 0][i]);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
         int32_t* d = dst + (size_t)k * a.pitch;
         if (n == 4) {
             *reinterpret_cast<int4*>(d) = make_int4(c[k][0], c[k][1], c[k][2], c[k][3]);   // stride % 32 == 0, x % 4 == 0
@@ -90,10 +94,15 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a)
 hipError_t launch_ingest(const IngestArgs& a, hipStream_t s)
 {
     dim3 grid((a.w + 1023) / 1024, a.h, a.ntiles), block(256);
-    if (a.bytes_per_sample == 1)
-        hipLaunchKernelGGL(ingest_kernel<uint8_t>, grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL(ingest_kernel<uint16_t>, grid, block, 0, s, a);
+#define GRK_INGEST(PIX)                                                                          \
+    switch (a.ncomp) {                                                                          \
+    case 1: hipLaunchKernelGGL((ingest_kernel<PIX, 1>), grid, block, 0, s, a); break;           \
+    case 2: hipLaunchKernelGGL((ingest_kernel<PIX, 2>), grid, block, 0, s, a); break;           \
+    case 3: hipLaunchKernelGGL((ingest_kernel<PIX, 3>), grid, block, 0, s, a); break;           \
+    default: hipLaunchKernelGGL((ingest_kernel<PIX, 4>), grid, block, 0, s, a); break;          \
+    }
+    if (a.bytes_per_sample == 1) { GRK_INGEST(uint8_t) } else { GRK_INGEST(uint16_t) }
+#undef GRK_INGEST
     return hipGetLastError();
 }
 
