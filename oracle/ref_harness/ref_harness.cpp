@@ -281,6 +281,56 @@ int32_t ref_decode(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, in
 	return rc;
 }
 
+// ---- the file-oriented plugin protocol: grk_plugin_compress(params, callback) (grok.cpp:628) ----
+// The callback below is what src/bin/jp2/grk_compress.cpp:1604-1987 does in essence: build the
+// image, create codec + stream, grk_compress_init/start, grk_compress_with_plugin(codec, tile), end.
+static const EncCfg* g_cb_cfg = nullptr;
+static const uint8_t* g_cb_pixels = nullptr;
+static uint8_t* g_cb_out = nullptr;
+static uint64_t g_cb_cap = 0;
+static int64_t g_cb_len = -100;
+
+static bool host_compress_callback(grk_plugin_compress_user_callback_info* info)
+{
+	const EncCfg& c = *g_cb_cfg;
+	g_cb_len = -101;
+	if (!info || !info->tile) { if (info) info->error_code = 1; return false; }
+	const int bps = (c.prec + 7) / 8;
+	grk_image* image = make_image(c, true);
+	for (int k = 0; k < c.C; ++k) {
+		auto comp = image->comps + k;
+		const uint8_t* src = g_cb_pixels + (size_t)k * c.W * c.H * bps;
+		for (int y = 0; y < c.H; ++y)
+			for (int x = 0; x < c.W; ++x) {
+				size_t i = (size_t)y * c.W + x;
+				comp->data[(size_t)y * comp->stride + x] = bps == 1 ? (int32_t)src[i] : (int32_t)((const uint16_t*)src)[i];
+			}
+	}
+	grk_stream* stream = grk_stream_create_mem_stream(g_cb_out, g_cb_cap, false, false);
+	grk_codec* codec = grk_compress_create(GRK_CODEC_J2K, stream);
+	bool ok = codec && grk_compress_init(codec, info->compressor_parameters, image) && grk_compress_start(codec) &&
+			  grk_compress_with_plugin(codec, info->tile) && grk_compress_end(codec);
+	g_cb_len = ok ? (int64_t)grk_stream_get_write_mem_stream_length(stream) : -102;
+	info->error_code = ok ? 0 : 1;
+	grk_object_unref(stream);
+	grk_object_unref(codec);
+	grk_object_unref(&image->obj);
+	return ok;
+}
+
+// returns coded length (>=0), or the plugin's refusal code (<0)
+int64_t ref_plugin_compress_file(const EncCfg* cfg, const uint8_t* pixels, const char* infile, uint8_t* out, uint64_t cap)
+{
+	grk_cparameters param;
+	fill_params(param, *cfg);
+	strncpy(param.infile, infile, GRK_PATH_LEN - 1);
+	strncpy(param.outfile, "mem.j2k", GRK_PATH_LEN - 1);
+	g_cb_cfg = cfg; g_cb_pixels = pixels; g_cb_out = out; g_cb_cap = cap; g_cb_len = -100;
+	int32_t rc = grk_plugin_compress(&param, host_compress_callback);
+	if (rc != 0) return rc < 0 ? rc : -rc;
+	return g_cb_len;
+}
+
 // Load a real plugin .so through the reference's own minpf loader (grk_initialize(pluginPath)),
 // then report what the host sees. Used by the boundary test.
 int ref_plugin_load(const char* dir, int threads)

@@ -100,3 +100,45 @@ def ht_decode_block(coded, missing_msbs, w, h):
     if rc != 0:
         raise RuntimeError("ref_ht_decode_block failed")
     return out
+
+
+def plugin_dir():
+    return os.path.abspath(os.path.join(_HERE, "..", "grok_amd", "lib"))
+
+
+def plugin_load(threads=0):
+    """Load OUR libgrokj2k_plugin.so through Grok's own minpf loader (grk_initialize(pluginPath))."""
+    L = lib(threads)
+    L.ref_plugin_load.restype = C.c_int
+    L.ref_plugin_load.argtypes = [C.c_char_p, C.c_int]
+    return L.ref_plugin_load(plugin_dir().encode(), threads)
+
+
+def plugin_init(device=0, verbose=0):
+    L = lib()
+    L.ref_plugin_init.restype = C.c_int
+    L.ref_plugin_init.argtypes = [C.c_int, C.c_int]
+    return L.ref_plugin_init(device, verbose)
+
+
+def plugin_compress_file(pixels, prec, infile, numres=6, irrev=0):
+    """grk_plugin_compress(params{infile}, host callback) -> bytes, or a negative refusal code."""
+    L = lib()
+    L.ref_plugin_compress_file.restype = C.c_int64
+    L.ref_plugin_compress_file.argtypes = [C.POINTER(EncCfg), C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+    px = np.ascontiguousarray(pixels)
+    Cn, H, W = px.shape
+    cfg = EncCfg(Cn, W, H, W, H, prec, irrev, numres, 1, 1, 1, 0, 0)
+    cap = px.size * 4 + (1 << 20)
+    out = np.zeros(cap, np.uint8)
+    n = L.ref_plugin_compress_file(C.byref(cfg), px.ctypes.data, infile.encode(), out.ctypes.data, cap)
+    return out[:n].tobytes() if n >= 0 else int(n)
+
+
+def write_pnm(path, px, prec):
+    Cn, H, W = px.shape
+    assert Cn in (1, 3)
+    with open(path, "wb") as f:
+        f.write(b"P%d\n%d %d\n%d\n" % (5 if Cn == 1 else 6, W, H, (1 << prec) - 1))
+        inter = np.ascontiguousarray(np.moveaxis(px, 0, -1))
+        f.write(inter.astype(">u2").tobytes() if prec > 8 else inter.astype(np.uint8).tobytes())

@@ -1,0 +1,58 @@
+"""-m gpu: the drop-in boundary, end to end through the REAL Grok library (oracle/_ref):
+our plugin's tile tree -> grk_compress_with_plugin() -> file identical to Grok's pure-CPU encode."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import grok_amd as G
+import gpuutil as U
+import refharness as R
+import synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not shipped")]
+
+PLUGIN = os.path.join(os.path.dirname(G.lib_path()), "libgrokj2k_plugin.so")
+
+
+def _plugin():
+    L = C.CDLL(PLUGIN)
+    L.grk_amd_plugin_tile_create.restype = C.c_void_p
+    L.grk_amd_plugin_tile_create.argtypes = [C.c_void_p, C.POINTER(G.TileParams), C.c_void_p, C.c_int]
+    L.grk_amd_plugin_tile_destroy.argtypes = [C.c_void_p]
+    return L
+
+
+@pytest.mark.parametrize("Cn,H,W,prec,numres,gen", [(1, 512, 512, 8, 4, "g2"), (3, 256, 320, 8, 6, "g2"),
+                                                    (3, 512, 512, 8, 6, "g0"), (1, 128, 128, 12, 5, "g2")])
+def test_compress_with_plugin_tile_equals_cpu(Cn, H, W, prec, numres, gen):
+    px = getattr(synth, gen)(Cn, H, W, prec)
+    cpu, _ = R.encode(px, prec, numres=numres, mode=1)
+    p = G.TileParams.make(W, H, Cn, prec, numres - 1)
+    L = _plugin()
+    tile = L.grk_amd_plugin_tile_create(U.ctx()._h, C.byref(p), px.ctypes.data, 0)
+    assert tile
+    try:
+        # rateControlAlgorithm = 1: defect D2 of the reference's plugin path
+        via_plugin, _ = R.encode(px, prec, numres=numres, mode=1, rate_algo=1, plugin_tile=tile)
+    finally:
+        L.grk_amd_plugin_tile_destroy(tile)
+    assert via_plugin == cpu
+
+
+def test_file_protocol_through_grok_loader(tmp_path):
+    """grk_initialize(plugin dir) -> grk_plugin_init -> grk_plugin_compress(params{infile}, cb):
+    Grok dlsym()s plugin_encode in our .so, we read the PNM, encode on the GPU and call back."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    for Cn, prec in ((1, 8), (3, 8), (1, 12)):
+        px = synth.g2(Cn, 192, 256, prec)
+        path = str(tmp_path / ("in_%d_%d.%s" % (Cn, prec, "pgm" if Cn == 1 else "ppm")))
+        R.write_pnm(path, px, prec)
+        got = R.plugin_compress_file(px, prec, path, numres=5)
+        assert not isinstance(got, int), "plugin refused: %s" % got
+        cpu, _ = R.encode(px, prec, numres=5, mode=1)
+        assert got == cpu
+    # a request outside the hot path is declined (non-zero) so that the host falls back to its CPU path
+    assert isinstance(R.plugin_compress_file(synth.g2(1, 64, 64, 8), 8, "/nonexistent.pgm", numres=3), int)
