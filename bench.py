@@ -89,8 +89,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # GROK_AMD_FORCE_DIST=1 exercises the exchange step on a 1-GPU box (world_size 1 over RCCL)
+    use_dist = world > 1 or os.environ.get("GROK_AMD_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
@@ -111,37 +114,27 @@ def main():
     samples = pixels_per_step * Cn
 
     # rank 0 owns the header blob; everybody gets it by broadcast (tiny, outside the timed region)
-    if world > 1:
-        hdr = torch.tensor(list(bytes(params)), dtype=torch.uint8, device=dev)
-        dist.broadcast(hdr, 0)
+    if use_dist:
+        import grok_amd.dist as D
+        got = D.broadcast_params(params, dev)
+        assert bytes(got) == bytes(params)
 
-    gather_bufs = None
+    scratch = None
+    last_parts = None
 
     def step():
+        nonlocal scratch, last_parts
         with torch.cuda.stream(stream):
             ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
-        if world > 1:
-            # exchange step: coded bytes of this rank's tile-part(s) -> rank 0
-            _, total = ctx.fetch_table(nblocks)
-            n = torch.tensor([total], dtype=torch.int64, device=dev)
-            sizes = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(sizes, n)
-            mx = int(max(int(s.item()) for s in sizes))
-            mx = (mx + 4095) & ~4095
-            ptr = ctx.coded_device_ptr()
-            # wrap the context arena without copying
-            src = _as_tensor(ptr, mx, dev)
-            nonlocal gather_bufs
-            if rank == 0:
-                if gather_bufs is None or gather_bufs[0].numel() < mx:
-                    gather_bufs = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
-                dist.gather(src, [b[:mx] for b in gather_bufs], dst=0)
-            else:
-                dist.gather(src, None, dst=0)
+        if use_dist:
+            # the path's one real exchange: coded tile-parts of every rank -> rank 0 (RCCL over xGMI)
+            table, total = ctx.fetch_table(nblocks)
+            arena = _as_tensor(ctx.coded_device_ptr(), (total + 4095) & ~4095, dev)
+            last_parts, scratch = D.gather_tile_parts(table, arena, dev, dst=0, scratch=scratch)
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -154,10 +147,17 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if rank == 0:
+            # the gathered tile-parts really are a codestream: assemble the (N*W) x H image once
+            ft, fc = D.merge_tile_parts(last_parts, world * ntiles, nblocks // ntiles)
+            if ntiles == 1:
+                cs_len = len(G.write_codestream(params, W * world, H, ft, fc))
+            else:
+                cs_len = int(ft["length"].sum())
 
     # per-kernel-family average durations (HIP events on the context's stream)
     fam = {}
@@ -191,19 +191,21 @@ def main():
             "config": {"workload": desc, "tiles_per_gpu": ntiles, "code_blocks_per_gpu": int(nblocks),
                        "coded_bytes_per_gpu": int(total), "generator": "G2 (SURVEY.md §8d)",
                        "parallelism": "tile-sharded x%d, coded tile-parts gathered on rank 0 (RCCL)" % world
-                       if world > 1 else "1 GPU"},
+                       if use_dist else "1 GPU"},
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_step": int(pipeline_bytes),
                          "achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                          "frac_of_hbm_peak": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "kernels": kernels,
         }
+        if use_dist:
+            out["config"]["assembled_codestream_bytes"] = cs_len
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
