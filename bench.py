@@ -170,9 +170,24 @@ def main():
     algo = {"ingest_mct": samples * (b_in + 4), "dwt53_5levels": 8.0 * samples * sigma(levels),
             "ht_cleanup_encode": 4.0 * samples + float(total), "compact": 2.0 * float(total)}
     dom = max(("ingest_mct", "dwt53_5levels", "ht_cleanup_encode"), key=lambda k: fam[k][0])
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this
+    # process; they come from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/summarize_pmc.py: FETCH_SIZE x1024 x2 [gfx950 half-count] + WRITE_SIZE x1024).
+    traffic = None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)))
+        if cands:
+            pm = json.load(open(cands[-1]))
+            key = {"ingest_mct": "ingest_kernel", "dwt53_5levels": "dwt_level_kernel",
+                   "ht_cleanup_encode": "ht_encode_kernel"}[dom]
+            mult = levels if dom == "dwt53_5levels" else 1      # dwt: per-level average x launches per step
+            traffic = int(pm[key]["hbm_bytes_per_launch"] * mult)
+    except Exception:
+        traffic = None
     ach = algo[dom] / (fam[dom][0] * 1e-3) / 1e9 if fam[dom][0] > 0 else 0.0
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": round(fam[dom][0], 4),
                 "launches": fam[dom][1]}
     kernels = {k: {"avg_ms": round(v[0], 4), "launches": v[1],
