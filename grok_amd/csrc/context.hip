@@ -354,7 +354,8 @@ int grk_amd_fetch_table(grk_amd_ctx* c, grk_amd_coded_block* table, uint64_t* to
         HIP_TRY(c, hipMemcpyAsync(c->h_len.data(), c->lengths.p, n * 4, hipMemcpyDeviceToHost, c->stream), "fetch lengths");
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
-    if (flagwords[0] & 0xFFFFFFFFu) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
+    if (flagwords[0] & 1u) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
+    if (flagwords[0] & 2u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "coefficient magnitude exceeds Kmax+1 bits");
     if (table)
         for (uint64_t i = 0; i < n; ++i) { table[i].offset = c->h_off[i]; table[i].length = c->h_len[i]; table[i].reserved = 0; }
     if (total) *total = flagwords[1];

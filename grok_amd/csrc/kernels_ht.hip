@@ -4,18 +4,25 @@
 // t1/t1_ht/coding/ojph_block_encoder.cpp:463-938), which the reference runs one block per CPU
 // thread and strictly serially inside the block.
 //
-// Wave64 decomposition (lane <-> quad, two quad rows of 32 quads per iteration):
-//   phase A (all 64 lanes): sample -> (rho, exponents, MagSgn values) per quad; the context of a
-//       quad only needs its left neighbour's rho and the exponent/significance of the sample row
-//       above, both fetched with __shfl; VLC tuple lookup; per-quad MagSgn bit count and
-//       per-quad-pair VLC+UVLC bit count; wave prefix sums give every codeword its bit offset in
-//       the raw (un-stuffed) MagSgn / VLC streams, which are assembled in LDS with ds_or;
-//       MEL events are gathered with __ballot and run through the 13-state MEL coder in
-//       wave-uniform (scalar) code.
-//   phase B: byte-stuffing + termination + concatenation MagSgn | MEL | VLC(reversed) + Scup.
+// The kernel is bound by VALU issue (a wave64 instruction occupies a SIMD for 4 cycles), so the
+// whole of phase A is written branch-free and counted in instructions:
+//   * lane <-> quad, two quad rows of 32 quads per iteration; samples of the next iteration are
+//     prefetched while the current one is analysed;
+//   * exponents are kept in "leading-zero" form (v_ffbh), the 4-neighbour maximum of the row
+//     above is one v_pk_min_u16, the VLC table is indexed directly by (eps, rho, neighbour
+//     insignificance flags) -- the table is permuted on the host so no context value is built;
+//   * one packed DPP prefix sum per iteration yields the bit offsets of both the MagSgn and the
+//     VLC stream; a quad's four MagSgn values are concatenated in registers and OR-ed into the
+//     raw (un-stuffed) stream in LDS with three ds_or; the VLC/UVLC bits of a quad pair are
+//     placed by each lane for its own quad (<= 30 bits per pair);
+//   * MEL events are gathered with v_cmp (ballot) and run through the 13-state MEL coder on the
+//     scalar unit.
+//   phase B: byte-stuffing + termination + concatenation MagSgn | MEL | VLC(reversed) + Scup
+//     (event walker modelled in oracle/ht_wave_model.c).
 //
-// Bit-exactness contract: the byte string per block equals ojph_encode_codeblock's (tests compare
-// against oracle/ and the reference build).
+// Bit-exactness contract: the byte string per block equals ojph_encode_codeblock's for every
+// input with |coefficient| < 2^(Kmax+1) (guaranteed by the BIBO-derived exponents for in-range
+// pixels); larger magnitudes raise GRK_AMD_ERR_UNSUPPORTED instead of producing other bytes.
 #include "kernels.h"
 #include "ht_vlc_tables.h"
 
@@ -23,10 +30,20 @@ namespace grk_amd {
 
 namespace {
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __constant__ uint8_t kMelE[13] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 4, 5};
 
-// device copies of the generated encoder tables: [0..2047] first quad row, [2048..4095] others
+// device tables (filled by launch_ht_encode on first use per device)
+//   g_vlc_enc[0..2047]    first quad row : index (c_q<<8)|(rho<<4)|eps
+//   g_vlc_enc[2048..4095] other rows     : index (ctx<<8)|(rho<<4)|eps with ctx = n_w | rl<<1 | n_e<<2,
+//                                          n_w/n_e = "both upper neighbours insignificant" flags
+//   entry = (cwd<<8)|(len<<4)|e_k
 __device__ uint16_t g_vlc_enc[4096];
+//   g_uvlc[u] : x = pre<<8 | suf<<16, y = pre_len<<8 | suf_len<<16 (ojph_block_encoder.cpp:189-210);
+//   entries 33,34: the 1-bit code (u-1) of the second quad in the first-row "u0>2, u1 in 1..2" mode
+__device__ uint2 g_uvlc[64];
 
 struct MelState {
     int run, k, acc, left;
@@ -60,23 +77,28 @@ __device__ __forceinline__ void mel_event(MelState& m, uint8_t* buf, int one, bo
     }
 }
 
-__device__ __forceinline__ void or_bits(uint32_t* raw, uint32_t pos, uint32_t val, uint32_t n)
+__device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
-    if (n == 0) return;
-    const uint32_t w = pos >> 5, sh = pos & 31;
-    atomicOr(&raw[w], val << sh);
-    if (sh + n > 32) atomicOr(&raw[w + 1], val >> (32 - sh));
+    (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void or_bits64(uint32_t* raw, uint32_t pos, uint64_t val, uint32_t n)
+// OR val (no bits at or above 64) into the little-endian bit array at bit `pos`
+__device__ __forceinline__ void or_bits64(uint32_t* raw, uint32_t pos, uint64_t val)
 {
-    if (n == 0) return;
-    const uint32_t w = pos >> 5, sh = pos & 31;
-    atomicOr(&raw[w], (uint32_t)(val << sh));
-    if (sh + n > 32) {
-        const uint64_t hi = val >> (32 - sh);
-        atomicOr(&raw[w + 1], (uint32_t)hi);
-        if (sh + n > 64) atomicOr(&raw[w + 2], (uint32_t)(hi >> 32));
-    }
+    const uint32_t sh = pos & 31;
+    uint32_t* w = raw + (pos >> 5);
+    const uint64_t lo = val << sh;
+    const uint32_t top = ((uint32_t)(val >> 32) >> 1) >> (31 - sh);
+    lds_or(w, (uint32_t)lo);
+    lds_or(w + 1, (uint32_t)(lo >> 32));
+    lds_or(w + 2, top);
+}
+__device__ __forceinline__ void or_bits32(uint32_t* raw, uint32_t pos, uint32_t val)
+{
+    const uint32_t sh = pos & 31;
+    uint32_t* w = raw + (pos >> 5);
+    const uint64_t lo = (uint64_t)val << sh;
+    lds_or(w, (uint32_t)lo);
+    lds_or(w + 1, (uint32_t)(lo >> 32));
 }
 // n <= 25 bits starting at bit `pos` of a little-endian bit array
 __device__ __forceinline__ uint32_t get_bits(const uint32_t* raw, uint32_t pos, uint32_t n)
@@ -86,26 +108,44 @@ __device__ __forceinline__ uint32_t get_bits(const uint32_t* raw, uint32_t pos, 
     return (uint32_t)(v >> sh) & ((1u << n) - 1);
 }
 
-__device__ __forceinline__ void uvlc(int u, uint32_t& pre, uint32_t& pl, uint32_t& suf, uint32_t& sl)
-{   // ojph_block_encoder.cpp:189-210
-    if (u <= 2)      { pre = (uint32_t)u; pl = (uint32_t)u; suf = 0; sl = 0; }
-    else if (u <= 4) { pre = 4; pl = 3; suf = (uint32_t)(u - 3); sl = 1; }
-    else             { pre = 0; pl = 3; suf = (uint32_t)(u - 5); sl = 5; }
+// v_ffbh_i32: leading bits equal to the sign bit (= clz for positive input), 0xFFFFFFFF for 0 and -1
+__device__ __forceinline__ uint32_t ffbh_i32(uint32_t t)
+{
+    uint32_t r;
+    asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(t));
+    return r;
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, true);
+}
+// inclusive prefix sum over the 64 lanes: 4 row_shr steps inside each row of 16, then row_bcast
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += dpp0<0x111, 0xF>(v);      // row_shr:1
+    v += dpp0<0x112, 0xF>(v);      // row_shr:2
+    v += dpp0<0x114, 0xF>(v);      // row_shr:4
+    v += dpp0<0x118, 0xF>(v);      // row_shr:8
+    v += dpp0<0x142, 0xA>(v);      // row_bcast:15 -> rows 1,3
+    v += dpp0<0x143, 0xC>(v);      // row_bcast:31 -> rows 2,3
     return v;
+}
+__device__ __forceinline__ uint32_t quad_swap(uint32_t v)          // value of lane ^ 1
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t bperm(int addr, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v);
 }
 
 // Event walker shared by the MagSgn and VLC streams (oracle/ht_wave_model.c: walk()).
-// 64 lanes test 64 raw words per round for positions of the current byte phase where a stuffing
-// event can happen; every event marks one OUTPUT byte index as "7 bits wide".
+// A window of 64 raw words is tested at once for positions where a stuffing event can happen
+// (8 resp. 7 consecutive ones; VLC additionally needs the previous byte > 0x8F); the candidates do
+// not depend on the byte phase, so all events inside one window are resolved without reloading.
+// Every event marks one OUTPUT byte index as "7 bits wide".
 template <bool VLC>
 __device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nwords, uint32_t nbits,
                                                 uint32_t* marks, uint32_t& last_p, int lane)
@@ -113,7 +153,7 @@ __device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nw
     uint32_t K = 0, s = 0;
     constexpr uint32_t need = VLC ? 7 : 8;
     while (s + need <= nbits) {
-        const uint32_t B = s >> 5, phase = s & 7;
+        const uint32_t B = s >> 5;
         const uint32_t i = B + lane;
         const uint32_t w0 = i < nwords ? raw[i] : 0u;
         const uint32_t w1 = i + 1 < nwords ? raw[i + 1] : 0u;
@@ -131,19 +171,26 @@ __device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nw
             const uint64_t pv = (lo >> 31) & ((lo >> 30) | (lo >> 29) | (lo >> 28));
             cand = (uint32_t)c & (uint32_t)pv;
         }
-        uint32_t m = 0x01010101u << phase;
-        if (lane == 0) m &= 0xFFFFFFFFu << (s & 31);
-        const uint32_t hit = cand & m;
-        const uint64_t ballot = __ballot(hit != 0);
-        if (!ballot) { s = 32 * (B + 64) + phase; continue; }
-        const int L = __ffsll((long long)ballot) - 1;
-        const uint32_t hl = __shfl(hit, L);
-        const uint32_t p = 32 * (B + (uint32_t)L) + (uint32_t)(__ffs((int)hl) - 1);
-        const uint32_t j = (p + K) >> 3;
-        const uint32_t mj = VLC ? j : j + 1;
-        if (lane == 0) marks[mj >> 5] |= 1u << (mj & 31);
-        ++K; last_p = p;
-        s = p + 15;
+        const uint32_t wend = 32 * (B + 64);
+        // resolve every event of this window; `s` (wave-uniform) is the next byte start
+        while (true) {
+            const uint32_t phase = s & 7, sw = s >> 5;
+            uint32_t m = 0x01010101u << phase;
+            if (i < sw) m = 0;                                   // positions before s are no byte starts
+            else if (i == sw) m &= 0xFFFFFFFFu << (s & 31);
+            const uint32_t hit = cand & m;
+            const uint64_t ballot = __ballot(hit != 0);
+            if (!ballot) { s = wend + phase; break; }
+            const int L = __ffsll((long long)ballot) - 1;
+            const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)hit, L);
+            const uint32_t p = 32 * (B + (uint32_t)L) + (uint32_t)(__ffs((int)hl) - 1);
+            const uint32_t j = (p + K) >> 3;
+            const uint32_t mj = VLC ? j : j + 1;
+            if (lane == 0) marks[mj >> 5] |= 1u << (mj & 31);
+            ++K; last_p = p;
+            s = p + 15;
+            if (s >= wend) break;
+        }
     }
     return K;
 }
@@ -151,15 +198,16 @@ __device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nw
 template <bool IRREV>
 __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_words, uint32_t vlc_words, uint32_t mark_words, uint32_t vmark_words)
 {
-    // LDS: raw MagSgn bits | raw VLC bits | 64 zero words | 7-bit-byte bitmaps | their prefix counts | MEL bytes
+    // LDS: UVLC table | raw MagSgn bits | raw VLC bits | 7-bit-byte bitmaps | their prefix counts | MEL bytes
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* ms_raw  = smem;
-    uint32_t* vlc_raw = smem + ms_words;
+    uint2*    uvlc_l  = reinterpret_cast<uint2*>(smem);                          // 64 entries
+    uint32_t* ms_raw  = smem + 128;
+    uint32_t* vlc_raw = ms_raw + ms_words;
     uint32_t* marks   = vlc_raw + vlc_words;
     uint32_t* vmarks  = marks + mark_words;
     uint16_t* pref    = reinterpret_cast<uint16_t*>(vmarks + vmark_words);
     uint16_t* vpref   = pref + mark_words;
-    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(vpref + vmark_words);     // 256 bytes
+    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(vpref + vmark_words);         // 256 bytes
 
     const int lane = threadIdx.x;
     const uint32_t gid = blockIdx.x;
@@ -168,148 +216,180 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
     const int32_t* src = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
-    const uint32_t p = 30u - bd.kmax;
-    const bool vec2 = ((bd.px | a.stride) & 1u) == 0;      // 8-byte row-pair loads are aligned
+    const bool full = w == 64 && h == 64 && ((bd.px | a.stride) & 1u) == 0;   // 8-byte row-pair loads, no edges
+    const uint32_t kmax = bd.kmax;
+    const bool narrow = kmax + 2 <= 16;           // a quad's four MagSgn values fit 64 bits
 
-    for (uint32_t i = lane; i < ms_words + vlc_words; i += 64) smem[i] = 0;
+    uvlc_l[lane] = g_uvlc[lane];
+    for (uint32_t i = lane; i < ms_words + vlc_words + mark_words + vmark_words; i += 64) ms_raw[i] = 0;
     __syncthreads();
     if (lane == 0) vlc_raw[0] = 0xF;             // vlc_init: four 1 bits pending (:315-318)
     __syncthreads();
 
     MelState mel{0, 0, 0, 8, 0};
     uint32_t ms_bits = 0, vlc_bits = 4;
-    uint32_t Bprev = 0;
+    uint32_t Bprev = 0xFFFFFFFFu;                // "all insignificant" row above the block
+    uint32_t ovf = 0;
     const uint32_t qx = lane & 31, half = lane >> 5;
+    const bool odd = lane & 1;
+    const bool isq0 = qx == 0, isq31 = qx == 31;
+    const int a_x32 = (lane ^ 32) << 2, a_up = ((lane - 1) & 63) << 2, a_dn = ((lane + 1) & 63) << 2;
     const uint32_t iters = (QH + 1) >> 1;
+    const uint32_t stride_b = a.stride * 4u;
+    const char* srcb = reinterpret_cast<const char*>(src);
+    const float inv_step = bd.inv_step;
+    const uint32_t lim = (1u << kmax) - 1u;
+
+    // ---- sample fetch: r[0]=(x0,y0) [1]=(x0,y0+1) [2]=(x0+1,y0) [3]=(x0+1,y0+1) -------------------
+    auto fetch = [&](uint32_t it, int32_t (&r)[4]) {
+        const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
+        if (full) {
+            const uint32_t off = y0 * stride_b + x0 * 4u;
+            const i32x2 q0 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off));
+            const i32x2 q1 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off + stride_b));
+            r[0] = q0.x; r[2] = q0.y; r[1] = q1.x; r[3] = q1.y;
+        } else {
+            // clamp addresses into the block, zero what lies outside
+            const uint32_t xa = min(x0, w - 1), xb = min(x0 + 1, w - 1);
+            const uint32_t ya = min(y0, h - 1), yb = min(y0 + 1, h - 1);
+            const int32_t v0 = *reinterpret_cast<const int32_t*>(srcb + ya * stride_b + xa * 4u);
+            const int32_t v2 = *reinterpret_cast<const int32_t*>(srcb + ya * stride_b + xb * 4u);
+            const int32_t v1 = *reinterpret_cast<const int32_t*>(srcb + yb * stride_b + xa * 4u);
+            const int32_t v3 = *reinterpret_cast<const int32_t*>(srcb + yb * stride_b + xb * 4u);
+            const bool ox0 = x0 < w, ox1 = x0 + 1 < w, oy0 = y0 < h, oy1 = y0 + 1 < h;
+            r[0] = (ox0 && oy0) ? v0 : 0; r[2] = (ox1 && oy0) ? v2 : 0;
+            r[1] = (ox0 && oy1) ? v1 : 0; r[3] = (ox1 && oy1) ? v3 : 0;
+        }
+    };
+
+    int32_t nxt[4];
+    fetch(0, nxt);
 
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t qy = 2 * it + half;
-        const bool active = qx < QW && qy < QH;
-        // ---- samples -> sign-magnitude words (T1HT.cpp:71-84 / dead-zone quantiser) ----------
-        int32_t rawv[4] = {0, 0, 0, 0};          // [0]=(x0,y0) [1]=(x0,y0+1) [2]=(x0+1,y0) [3]=(x0+1,y0+1)
-        {
-            const uint32_t x0 = 2 * qx, y0 = 2 * qy;
-            if (x0 < w && y0 < h) {
-                const int32_t* row0 = src + (size_t)y0 * a.stride + x0;
-                const bool pair = x0 + 1 < w;
-                if (vec2 && pair) { const int2 q = *reinterpret_cast<const int2*>(row0); rawv[0] = q.x; rawv[2] = q.y; }
-                else { rawv[0] = row0[0]; if (pair) rawv[2] = row0[1]; }
-                if (y0 + 1 < h) {
-                    const int32_t* row1 = row0 + a.stride;
-                    if (vec2 && pair) { const int2 q = *reinterpret_cast<const int2*>(row1); rawv[1] = q.x; rawv[3] = q.y; }
-                    else { rawv[1] = row1[0]; if (pair) rawv[3] = row1[1]; }
-                }
-            }
-        }
-        uint32_t tw[4];
+        const bool active = full || (qx < QW && qy < QH);
+        const int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+
+        // ---- per-sample analysis (:513-563): magnitude, MagSgn value, exponent as leading-zero count
+        uint32_t mag[4], vv[4], c[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int32_t raw = rawv[i];
-            uint32_t t;
             if constexpr (IRREV) {
-                const float c = __int_as_float(raw);
-                float q = __fmul_rn(fabsf(c), bd.inv_step);
-                uint32_t mag = (uint32_t)q;
-                const uint32_t lim = (1u << bd.kmax) - 1u;
-                mag = mag > lim ? lim : mag;
-                t = ((c < 0.f && mag) ? 0x80000000u : 0u) | (mag << p);
+                const float cf = __int_as_float(r[i]);
+                const float q = __fmul_rn(fabsf(cf), inv_step);
+                mag[i] = min((uint32_t)q, lim);
             } else {
-                const uint32_t mag = (uint32_t)(raw < 0 ? -raw : raw);
-                t = (raw < 0 ? 0x80000000u : 0u) | (mag << p);
+                mag[i] = (uint32_t)max(r[i], -r[i]);
             }
-            tw[i] = t;
+            const uint32_t sb = (uint32_t)r[i] >> 31;
+            const uint32_t t = (mag[i] << 1) - 1u;                 // val - 1  (val = 2*mag)
+            vv[i] = t + sb - 1u;                                   // val - 2 + sign
+            c[i] = ffbh_i32(t);                                          // clz(val-1); 0xFFFFFFFF when insignificant
+            b[i] = min(mag[i], 1u);
         }
-        // ---- per-sample analysis (:513-563) ---------------------------------------------------
-        uint32_t rho = 0, emax = 0, e[4], v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t val = ((tw[i] + tw[i]) >> p) & ~1u;
-            e[i] = 0; v[i] = 0;
-            if (val) {
-                rho |= 1u << i;
-                e[i] = 32u - (uint32_t)__clz((int)(val - 1));
-                emax = max(emax, e[i]);
-                v[i] = val - 2 + (tw[i] >> 31);
-            }
-        }
-        // ---- neighbourhood ---------------------------------------------------------------------
-        const uint32_t Bcur = e[1] | (e[3] << 8) | (((rho >> 1) & 1) << 16) | (((rho >> 3) & 1) << 17);
+        ovf |= mag[0] | mag[1];
+        ovf |= mag[2] | mag[3];
+        const uint32_t rho = b[0] | (b[1] << 1) | (b[2] << 2) | (b[3] << 3);
+        const uint32_t cm = min(min(c[0], c[1]), min(c[2], c[3]));
+        const uint32_t emax = 32u - min(cm, 32u);
+
+        // ---- neighbourhood: exponents / significance of the sample row above, left quad's rho ----
+        const uint32_t Bcur = __builtin_amdgcn_perm(c[3], c[1], 0x05040100u);   // lo16 = c[1], hi16 = c[3]
         const uint32_t sel = half ? Bprev : Bcur;
-        const uint32_t above = __shfl_xor(sel, 32);
-        uint32_t above_l = __shfl_up(above, 1);   if (qx == 0)  above_l = 0;
-        uint32_t above_r = __shfl_down(above, 1); if (qx == 31) above_r = 0;
-        uint32_t rho_left = __shfl_up(rho, 1);    if (qx == 0)  rho_left = 0;
-        uint32_t c_q, kappa;
-        if (qy == 0) {
-            c_q = (rho_left >> 1) | (rho_left & 1);
-            kappa = 1;
-        } else {
-            const uint32_t e_w = (above_l >> 8) & 0xFF, e_n0 = above & 0xFF, e_n1 = (above >> 8) & 0xFF, e_e = above_r & 0xFF;
-            const int max_e = (int)max(max(e_w, e_n0), max(e_n1, e_e)) - 1;
-            const uint32_t s_w = ((above_l >> 17) | (above >> 16)) & 1, s_e = ((above >> 17) | (above_r >> 16)) & 1;
-            c_q = s_w | ((((rho_left >> 2) | (rho_left >> 3)) & 1) << 1) | (s_e << 2);
-            kappa = (rho & (rho - 1)) ? (uint32_t)max(1, max_e) : 1u;
+        const uint32_t above = bperm(a_x32, sel);
+        uint32_t above_l = bperm(a_up, above);  above_l = isq0 ? 0xFFFFFFFFu : above_l;
+        uint32_t above_r = bperm(a_dn, above);  above_r = isq31 ? 0xFFFFFFFFu : above_r;
+        uint32_t rho_l = bperm(a_up, rho);      rho_l = isq0 ? 0u : rho_l;
+        // max exponent of {w, n0, n1, e} = 32 - min of their leading-zero counts
+        const uint32_t Y = __builtin_amdgcn_perm(above_l, above_r, 0x07060100u);   // lo16 = e, hi16 = w
+        const u16x2 pm = __builtin_elementwise_min(__builtin_bit_cast(u16x2, above), __builtin_bit_cast(u16x2, Y));
+        const uint32_t m4 = min((uint32_t)pm.x, (uint32_t)pm.y);
+        const int kap_e = 31 - (int)m4;                             // max_e - 1 (negative when all insignificant)
+        const uint32_t kappa = (rho & (rho - 1)) ? (uint32_t)max(1, kap_e) : 1u;
+        const uint32_t n_w = (((above_l >> 16) & above) >> 15) & 1u;    // w and n0 both insignificant
+        const uint32_t n_e = (((above >> 16) & above_r) >> 15) & 1u;    // n1 and e both insignificant
+        const uint32_t rlb = min(rho_l & 0xCu, 1u);
+        uint32_t ctx = n_w | (rlb << 1) | (n_e << 2);
+        uint32_t tbase = 2048u;
+        bool cq0 = ctx == 5u;                                           // c_q == 0
+        if (it == 0) {                                                  // first quad row (:652, :709)
+            const uint32_t cq_first = (rho_l >> 1) | (rho_l & 1u);
+            ctx = half ? ctx : cq_first;
+            tbase = half ? 2048u : 0u;
+            cq0 = half ? cq0 : cq_first == 0u;
         }
+
         const uint32_t U = max(emax, kappa);
         const uint32_t u = U - kappa;
-        uint32_t eps = 0;
-        if (u > 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) eps |= (uint32_t)(e[i] == emax) << i;
-        }
-        uint32_t tuple = 0;
-        if (active) tuple = g_vlc_enc[(qy == 0 ? 0u : 2048u) + ((c_q << 8) | (rho << 4) | eps)];
-        // ---- MagSgn: bit counts, offsets, emission --------------------------------------------
-        uint32_t m[4], ms_len = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            m[i] = ((rho >> i) & 1) ? U - ((tuple >> i) & 1) : 0;
-            ms_len += m[i];
-        }
-        const uint32_t ms_incl = wave_incl_scan(ms_len, lane);
-        uint32_t mpos = ms_bits + ms_incl - ms_len;
-        ms_bits += __shfl(ms_incl, 63);
+        uint32_t eps = (uint32_t)(c[0] == cm) | ((uint32_t)(c[1] == cm) << 1) | ((uint32_t)(c[2] == cm) << 2) | ((uint32_t)(c[3] == cm) << 3);
+        eps = u ? eps : 0u;
+        uint32_t tuple = g_vlc_enc[tbase + ((ctx << 8) | (rho << 4) | eps)];
+        if (!full) tuple = active ? tuple : 0u;
+
+        // next iteration's samples: issued here so that the wait for `tuple` does not cover them
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < iters) fetch(it + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- MagSgn: bit counts, in-register concatenation of the quad --------------------------
+        uint32_t m[4], vm[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (m[i]) {
-                const uint32_t mask = m[i] >= 32 ? 0xFFFFFFFFu : ((1u << m[i]) - 1u);
-                or_bits(ms_raw, mpos, v[i] & mask, m[i]);
-                mpos += m[i];
-            }
+            m[i] = __umul24(U - ((tuple >> i) & 1u), b[i]);
+            vm[i] = __builtin_amdgcn_ubfe(vv[i], 0u, m[i]);
         }
-        // ---- VLC + UVLC per quad pair (even lane assembles) ------------------------------------
-        const uint32_t tuple_p = __shfl_xor(tuple, 1);
-        const uint32_t u_p = __shfl_xor(u, 1);
-        uint64_t cw = 0; uint32_t cl = 0;
-        if ((qx & 1) == 0 && active) {
-            const uint32_t u0 = u, u1 = u_p;                  // partner inactive -> tuple_p = 0, u1 = 0
-            cw = tuple >> 8; cl = (tuple >> 4) & 7;
-            cw |= (uint64_t)(tuple_p >> 8) << cl; cl += (tuple_p >> 4) & 7;
-            uint32_t p0, l0, s0, sl0, p1, l1, s1, sl1;
-            if (qy == 0 && u0 > 2 && u1 > 2) {
-                uvlc((int)u0 - 2, p0, l0, s0, sl0); uvlc((int)u1 - 2, p1, l1, s1, sl1);
-                cw |= (uint64_t)p0 << cl; cl += l0; cw |= (uint64_t)p1 << cl; cl += l1;
-                cw |= (uint64_t)s0 << cl; cl += sl0; cw |= (uint64_t)s1 << cl; cl += sl1;
-            } else if (qy == 0 && u0 > 2 && u1 > 0) {
-                uvlc((int)u0, p0, l0, s0, sl0);
-                cw |= (uint64_t)p0 << cl; cl += l0; cw |= (uint64_t)(u1 - 1) << cl; cl += 1;
-                cw |= (uint64_t)s0 << cl; cl += sl0;
-            } else {
-                uvlc((int)u0, p0, l0, s0, sl0); uvlc((int)u1, p1, l1, s1, sl1);
-                cw |= (uint64_t)p0 << cl; cl += l0; cw |= (uint64_t)p1 << cl; cl += l1;
-                cw |= (uint64_t)s0 << cl; cl += sl0; cw |= (uint64_t)s1 << cl; cl += sl1;
-            }
-        }
-        const uint32_t v_incl = wave_incl_scan(cl, lane);
-        or_bits64(vlc_raw, vlc_bits + v_incl - cl, cw, cl);
-        vlc_bits += __shfl(v_incl, 63);
-        // ---- MEL events (wave-uniform) ----------------------------------------------------------
-        const bool ev = active && c_q == 0;
-        const bool xev = (qy == 0) && (qx & 1) && u > 0 && u_p > 0;
-        const uint64_t H = __ballot(ev), V = __ballot(ev && rho != 0);
-        const uint64_t XH = __ballot(xev), XV = __ballot(xev && min(u, u_p) > 2);
-        uint64_t Hm = H, Vm = V;
+        const uint32_t m01 = m[0] + m[1], m23 = m[2] + m[3];
+        const uint32_t ms_len = m01 + m23;
+
+        // ---- VLC + UVLC: every lane places the bits of its own quad inside the pair's window ----
+        uint32_t ui = u;
+        bool xev = false, xv = false;
         if (it == 0) {
+            const uint32_t up = quad_swap(u);
+            const bool first = half == 0;
+            const bool both = first && u > 2 && up > 2;
+            ui = both ? u - 2 : u;
+            ui = (first && odd && up > 2 && u > 0 && u <= 2) ? 32u + u : ui;
+            xev = first && odd && u > 0 && up > 0;
+            xv = xev && min(u, up) > 2;
+        }
+        const uint2 ue = uvlc_l[ui];
+        const uint32_t A = (tuple >> 8) | ue.x;                       // cwd | pre<<8 | suf<<16
+        const uint32_t Lw = ((tuple >> 4) & 7u) | ue.y;               // len | pl<<8 | sl<<16
+        const uint32_t Lp = quad_swap(Lw);
+        const uint32_t S = Lw + Lp;
+        const uint32_t Lq = odd ? Lp : 0u;
+        const uint32_t slen = S & 0xFFu, spl = (S >> 8) & 0xFFu;
+        const uint32_t off_pre = slen + ((Lq >> 8) & 0xFFu);
+        const uint32_t off_suf = slen + spl + (Lq >> 16);
+        const uint32_t cl = slen + spl + (S >> 16);                   // bits of the whole pair
+        const uint32_t wv = ((A & 0xFFu) << (Lq & 0xFFu)) | (((A >> 8) & 0xFFu) << off_pre) | ((A >> 16) << off_suf);
+
+        // ---- one packed prefix sum: low 16 bits MagSgn, high 16 bits VLC (pair total on even lanes)
+        const uint32_t packed = ms_len | ((odd ? 0u : cl) << 16);
+        const uint32_t incl = wave_incl_scan(packed);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t mpos = ms_bits + ((incl - packed) & 0xFFFFu);
+        const uint32_t vpos = vlc_bits + (incl >> 16) - cl;
+        ms_bits += tot & 0xFFFFu;
+        vlc_bits += tot >> 16;
+
+        if (narrow) {
+            const uint32_t v01 = vm[0] | (vm[1] << m[0]);
+            const uint32_t v23 = vm[2] | (vm[3] << m[2]);
+            or_bits64(ms_raw, mpos, (uint64_t)v01 | ((uint64_t)v23 << m01));
+        } else {
+            or_bits64(ms_raw, mpos, (uint64_t)vm[0] | ((uint64_t)vm[1] << m[0]));
+            or_bits64(ms_raw, mpos + m01, (uint64_t)vm[2] | ((uint64_t)vm[3] << m[2]));
+        }
+        or_bits32(vlc_raw, vpos, wv);
+
+        // ---- MEL events (wave-uniform, scalar unit) ------------------------------------------------
+        const bool ev = active && cq0;
+        const uint64_t H = __ballot(ev), V = __ballot(ev && rho != 0);
+        uint64_t Hm = H;
+        if (it == 0) {
+            const uint64_t XH = __ballot(xev), XV = __ballot(xv);
             for (int pr = 0; pr < 16; ++pr) {
                 const int l0 = 2 * pr, l1 = l0 + 1;
                 if ((H >> l0) & 1) mel_event(mel, mel_buf, (int)((V >> l0) & 1), lane == 0);
@@ -320,17 +400,19 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
         }
         while (Hm) {
             const int i = __ffsll((long long)Hm) - 1;
-            mel_event(mel, mel_buf, (int)((Vm >> i) & 1), lane == 0);
+            mel_event(mel, mel_buf, (int)((V >> i) & 1), lane == 0);
             Hm &= Hm - 1;
         }
         Bprev = Bcur;
     }
+    // magnitudes beyond Kmax+1 bits: outside the contract (see header) -> flag, host reports it
+    if (!IRREV && __ballot((ovf >> (kmax + 1)) != 0)) {
+        if (lane == 0) atomicOr(a.overflow_flag, 2u);
+    }
     __syncthreads();
 
     // ================= phase B: stuffing, termination, emission (see oracle/ht_wave_model.c) =====
-    const uint32_t msw = ms_words, vw = vlc_words;          // raw buffers are followed by zeroed words
-    for (uint32_t i = lane; i < mark_words + vmark_words; i += 64) marks[i] = 0;
-    __syncthreads();
+    const uint32_t msw = ms_words, vw = vlc_words;
 
     // ---- B1: MagSgn events
     uint32_t last_p = 0;
@@ -381,23 +463,25 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const uint32_t total = ms_len + mel_len + vcount + 1;
     const uint32_t scup = mel_len + vcount + 1;
 
-    // ---- B4: prefix popcounts of the mark bitmaps (one pass covers both bitmaps back to back)
+    // ---- B4: prefix popcounts of the mark bitmaps (only the words emission will look at)
     {
         uint32_t base = 0;
-        for (uint32_t w0 = 0; w0 < mark_words; w0 += 64) {
+        const uint32_t mw_used = min(mark_words, (ms_emit >> 5) + 2);
+        for (uint32_t w0 = 0; w0 < mw_used; w0 += 64) {
             const uint32_t i = w0 + lane;
-            const uint32_t c = i < mark_words ? __popc(marks[i]) : 0;
-            const uint32_t incl = wave_incl_scan(c, lane);
-            if (i < mark_words) pref[i] = (uint16_t)(base + incl - c);
-            base += __shfl(incl, 63);
+            const uint32_t cnt = i < mark_words ? __popc(marks[i]) : 0;
+            const uint32_t incl = wave_incl_scan(cnt);
+            if (i < mark_words) pref[i] = (uint16_t)(base + incl - cnt);
+            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         base = 0;
-        for (uint32_t w0 = 0; w0 < vmark_words; w0 += 64) {
+        const uint32_t vw_used = min(vmark_words, (nv >> 5) + 2);
+        for (uint32_t w0 = 0; w0 < vw_used; w0 += 64) {
             const uint32_t i = w0 + lane;
-            const uint32_t c = i < vmark_words ? __popc(vmarks[i]) : 0;
-            const uint32_t incl = wave_incl_scan(c, lane);
-            if (i < vmark_words) vpref[i] = (uint16_t)(base + incl - c);
-            base += __shfl(incl, 63);
+            const uint32_t cnt = i < vmark_words ? __popc(vmarks[i]) : 0;
+            const uint32_t incl = wave_incl_scan(cnt);
+            if (i < vmark_words) vpref[i] = (uint16_t)(base + incl - cnt);
+            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
     }
 
@@ -407,7 +491,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     base_off = ((unsigned long long)__shfl((uint32_t)(base_off >> 32), 0) << 32) | __shfl((uint32_t)base_off, 0);
     if (lane == 0) { a.lengths[gid] = total; a.offsets[gid] = base_off; }
     if (base_off + total > a.arena_bytes) {
-        if (lane == 0) *a.overflow_flag = 1;
+        if (lane == 0) atomicOr(a.overflow_flag, 1u);
         return;
     }
     uint8_t* out = a.arena + base_off;
@@ -419,16 +503,18 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
         const uint32_t mw = marks[wd];
         const uint32_t k = pref[wd] + __popc(mw & ((1u << bit) - 1u));
         const uint32_t flags = (mw >> bit) & 0xF;
-        uint32_t start = 8 * j - k;
+        const uint32_t start = 8 * j - k;
+        const uint32_t sw = start >> 5;
+        uint64_t win = (ms_raw[sw] | ((uint64_t)ms_raw[sw + 1] << 32)) >> (start & 31);   // >= 32 valid bits
         uint32_t word = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t n = ((flags >> b) & 1) ? 7u : 8u;
-            word |= get_bits(ms_raw, start, n) << (8 * b);
-            start += n;
+        for (int bb = 0; bb < 4; ++bb) {
+            const uint32_t seven = (flags >> bb) & 1u;
+            word |= ((uint32_t)win & (0xFFu >> seven)) << (8 * bb);
+            win >>= 8u - seven;
         }
         if (j + 4 <= ms_emit) *reinterpret_cast<uint32_t*>(out + j) = word;
-        else for (uint32_t b = 0; j + b < ms_emit; ++b) out[j + b] = (uint8_t)(word >> (8 * b));
+        else for (uint32_t bb = 0; j + bb < ms_emit; ++bb) out[j + bb] = (uint8_t)(word >> (8 * bb));
     }
     if (has_final && lane == 0) out[ms_len - 1] = (uint8_t)final_byte;
     for (uint32_t i = lane; i < mel_len; i += 64) out[ms_len + i] = mel_buf[i < 250 ? i : 249];
@@ -451,26 +537,50 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
 
 static bool g_tables_ready[16] = {false};
 
+static hipError_t upload_tables()
+{
+    // first-row table as generated; other rows re-indexed by the neighbour flags the kernel computes
+    static uint16_t enc[4096];
+    for (uint32_t i = 0; i < 2048; ++i) {
+        enc[i] = HT_VLC_ENC0[i];
+        const uint32_t ctx = i >> 8, n_w = ctx & 1u, rl = (ctx >> 1) & 1u, n_e = (ctx >> 2) & 1u;
+        const uint32_t c_q = (n_w ? 0u : 1u) | (rl << 1) | ((n_e ? 0u : 1u) << 2);
+        enc[2048 + i] = HT_VLC_ENC1[(c_q << 8) | (i & 0xFFu)];
+    }
+    static uint2 uv[64];
+    for (uint32_t u = 0; u < 64; ++u) {
+        uint32_t pre = 0, pl = 0, suf = 0, sl = 0;
+        if (u < 32) {                                   // ojph_block_encoder.cpp:189-210
+            if (u <= 2)      { pre = u; pl = u; }
+            else if (u <= 4) { pre = 4; pl = 3; suf = u - 3; sl = 1; }
+            else             { pre = 0; pl = 3; suf = u - 5; sl = 5; }
+        } else if (u == 33 || u == 34) { pre = u - 33; pl = 1; }
+        uv[u].x = (pre << 8) | (suf << 16);
+        uv[u].y = (pl << 8) | (sl << 16);
+    }
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_enc), enc, sizeof(enc), 0, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_uvlc), uv, sizeof(uv), 0, hipMemcpyHostToDevice);
+}
+
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 16 && !g_tables_ready[dev]) {
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_enc), HT_VLC_ENC0, sizeof(HT_VLC_ENC0), 0, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return e;
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_enc), HT_VLC_ENC1, sizeof(HT_VLC_ENC1), sizeof(HT_VLC_ENC0), hipMemcpyHostToDevice);
+        e = upload_tables();
         if (e != hipSuccess) return e;
         g_tables_ready[dev] = true;
     }
-    // raw MagSgn stream: at most (kmax+1) bits per sample; VLC: < 32 bits per quad pair.
+    // raw MagSgn stream: at most (kmax+2) bits per sample; VLC: < 32 bits per quad pair.
     const uint32_t max_bits = a.max_block_samples * (a.max_kmax + 2u);
     const uint32_t ms_words = max_bits / 32 + 8;
     const uint32_t vlc_bits_max = 16u * ((a.max_block_samples + 3) / 4 + 64) + 64;
     const uint32_t vlc_words = vlc_bits_max / 32 + 8;
     const uint32_t mark_words = (max_bits / 7 + 64) / 32 + 2;
     const uint32_t vmark_words = (vlc_bits_max / 7 + 64) / 32 + 2;
-    const size_t shmem = (size_t)(ms_words + vlc_words + mark_words + vmark_words) * 4 +
+    const size_t shmem = 512 + (size_t)(ms_words + vlc_words + mark_words + vmark_words) * 4 +
                          (size_t)(mark_words + vmark_words + 2) * 2 + 256;
     const uint32_t nblocks = a.blocks_per_tile * a.ntiles;
     if (a.irreversible)
