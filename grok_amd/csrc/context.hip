@@ -214,20 +214,22 @@ int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
     block_extents(g, max_kmax, max_samples);
     HIP_TRY(c, c->lengths.ensure(nblocks * 4), "alloc lengths");
     HIP_TRY(c, c->offsets.ensure((nblocks + 1) * 8), "alloc offsets");
-    HIP_TRY(c, c->flag.ensure(64), "alloc flag");
+    HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc allocator state");
     // arena: worst case of the HT cleanup pass is ~ (kmax+1)/8 * 8/7 bytes per sample + VLC/MEL;
     // twice the raw input size plus per-block slack covers every lossless case we accept
     const uint64_t raw = (uint64_t)ntiles * g.p.num_comps * g.p.tile_w * g.p.tile_h * ((g.p.prec + 7) / 8);
-    HIP_TRY(c, c->arena.ensure(raw * 2 + nblocks * 64 + (1u << 20)), "alloc coded arena");
-    // flag[0] = overflow flag, flag[2..3] = 64-bit arena cursor
-    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, 64, c->stream), "clear flag");
+    // allocation regions: enough to keep the per-address atomic rate off the critical path, few enough
+    // that small jobs do not spread over many mostly empty chunks
+    uint32_t regions = 1;
+    while (regions < kHtAllocRegions && nblocks / (regions * 2) >= 256) regions *= 2;
+    HIP_TRY(c, c->arena.ensure(raw * 2 + nblocks * 64 + (size_t)(regions + 1) * kHtAllocChunk + (1u << 20)), "alloc coded arena");
     HtArgs a{};
     a.mallat = (const int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.blocks = (const HtBlockDesc*)c->blockdesc.p; a.blocks_per_tile = bpt; a.ncomp = g.p.num_comps; a.ntiles = ntiles;
     a.arena = (uint8_t*)c->arena.p; a.arena_bytes = c->arena.cap;
-    a.cursor = (unsigned long long*)((uint8_t*)c->flag.p + 8);
+    a.alloc = (unsigned long long*)c->flag.p;        // [0] status flags, [1] bytes used (launch_ht_encode resets them)
     a.lengths = (uint32_t*)c->lengths.p; a.offsets = (unsigned long long*)c->offsets.p;
-    a.overflow_flag = (uint32_t*)c->flag.p;
+    a.region_mask = regions - 1;
     a.irreversible = g.p.irreversible; a.max_kmax = max_kmax; a.max_block_samples = max_samples;
     {
         ScopedTimer t(c, 2);

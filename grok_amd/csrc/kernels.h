@@ -43,15 +43,19 @@ struct HtBlockDesc {        // one per code-block of a tile-component set (all c
 struct HtArgs {
     const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp]
     const HtBlockDesc* blocks; uint32_t blocks_per_tile; uint32_t ncomp; uint32_t ntiles;
-    uint8_t*  arena; uint64_t arena_bytes;      // coded bytes of all blocks, allocated by atomic cursor
-    unsigned long long* cursor;                 // bytes used in the arena (zeroed per call)
+    uint8_t*  arena; uint64_t arena_bytes;      // coded bytes of all blocks (chunked region allocator, kernels_ht.hip)
+    unsigned long long* alloc;                  // kHtAllocBytes of allocator state: [0] status flags (bit 0 arena
+                                                // overflow, bit 1 magnitude out of contract), [1] bytes used, region words
     uint32_t* lengths;                          // [ntiles*blocks_per_tile]
     unsigned long long* offsets;                // [ntiles*blocks_per_tile]
-    uint32_t* overflow_flag;
+    uint32_t region_mask;         // (power of two <= kHtAllocRegions) - 1: block i allocates from region i & mask
     int irreversible;
     uint32_t max_kmax;            // largest kmax among the blocks (sizes the raw MagSgn LDS buffer)
     uint32_t max_block_samples;   // largest w*h among the blocks
 };
+constexpr size_t   kHtAllocBytes = 8192;
+constexpr uint32_t kHtAllocRegions = 16;           // region words available; a launch uses region_mask + 1 of them
+constexpr uint32_t kHtAllocChunk = 256u << 10;     // bytes a region takes from the shared cursor at a time
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);
 
 } // namespace grk_amd
