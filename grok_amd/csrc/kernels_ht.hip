@@ -25,6 +25,7 @@
 // pixels); larger magnitudes raise GRK_AMD_ERR_UNSUPPORTED instead of producing other bytes.
 #include "kernels.h"
 #include "ht_vlc_tables.h"
+#include <type_traits>
 
 namespace grk_amd {
 
@@ -279,38 +280,58 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const float inv_step = bd.inv_step;
     const uint32_t lim = (1u << kmax) - 1u;
 
+    // Phase A exists twice: FULL for 64x64 blocks whose row pairs can be loaded as aligned 8-byte
+    // words (all but the lowest resolutions), and the general edge-handling version.  The choice is
+    // made once per block: a branch inside the fetch would make the loads land in merged registers
+    // and be waited for on the spot, which defeats the prefetch.
+    auto phase_a = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+
     // ---- sample fetch: r[0]=(x0,y0) [1]=(x0,y0+1) [2]=(x0+1,y0) [3]=(x0+1,y0+1) -------------------
     auto fetch = [&](uint32_t it, int32_t (&r)[4]) {
         const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
-        if (full) {
+        if constexpr (FULL) {
             const uint32_t off = y0 * stride_b + x0 * 4u;
             const i32x2 q0 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off));
             const i32x2 q1 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off + stride_b));
             r[0] = q0.x; r[2] = q0.y; r[1] = q1.x; r[3] = q1.y;
         } else {
-            // clamp addresses into the block, zero what lies outside
+            // addresses clamped into the block; what lies outside is zeroed when the values are used
             const uint32_t xa = min(x0, w - 1), xb = min(x0 + 1, w - 1);
             const uint32_t ya = min(y0, h - 1), yb = min(y0 + 1, h - 1);
-            const int32_t v0 = *reinterpret_cast<const int32_t*>(srcb + ya * stride_b + xa * 4u);
-            const int32_t v2 = *reinterpret_cast<const int32_t*>(srcb + ya * stride_b + xb * 4u);
-            const int32_t v1 = *reinterpret_cast<const int32_t*>(srcb + yb * stride_b + xa * 4u);
-            const int32_t v3 = *reinterpret_cast<const int32_t*>(srcb + yb * stride_b + xb * 4u);
-            const bool ox0 = x0 < w, ox1 = x0 + 1 < w, oy0 = y0 < h, oy1 = y0 + 1 < h;
-            r[0] = (ox0 && oy0) ? v0 : 0; r[2] = (ox1 && oy0) ? v2 : 0;
-            r[1] = (ox0 && oy1) ? v1 : 0; r[3] = (ox1 && oy1) ? v3 : 0;
+            r[0] = *reinterpret_cast<const int32_t*>(srcb + ya * stride_b + xa * 4u);
+            r[2] = *reinterpret_cast<const int32_t*>(srcb + ya * stride_b + xb * 4u);
+            r[1] = *reinterpret_cast<const int32_t*>(srcb + yb * stride_b + xa * 4u);
+            r[3] = *reinterpret_cast<const int32_t*>(srcb + yb * stride_b + xb * 4u);
         }
     };
 
-    int32_t nxt[4];
-    fetch(0, nxt);
+    // samples are fetched two iterations ahead, even and odd iterations into their own registers
+    int32_t nE[4], nO[4] = {0, 0, 0, 0};
+    fetch(0, nE);
+    if (iters > 1) fetch(1, nO);
 
-    for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t qy = 2 * it + half;
-        const bool active = full || (qx < QW && qy < QH);
-        const int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+    // The loop is software-pipelined: stage 1 of iteration it+1 (sample analysis, neighbourhood,
+    // VLC table index -> table load issued) runs before stage 2 of iteration it (everything that
+    // needs the table entry), so the table latency hides behind a stage of arithmetic.
+    struct Stage1 {
+        uint32_t vv[4], b[4];
+        uint32_t rho, U, u, tuple;
+        bool cq0;
+    };
+
+    auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) {
+        int32_t r[4] = {nbuf[0], nbuf[1], nbuf[2], nbuf[3]};
+        if constexpr (!FULL) {
+            const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
+            const bool ox0 = x0 < w, ox1 = x0 + 1 < w, oy0 = y0 < h, oy1 = y0 + 1 < h;
+            r[0] = (ox0 && oy0) ? r[0] : 0; r[2] = (ox1 && oy0) ? r[2] : 0;
+            r[1] = (ox0 && oy1) ? r[1] : 0; r[3] = (ox1 && oy1) ? r[3] : 0;
+        }
+        if (it + 2 < iters) fetch(it + 2, nbuf);
 
         // ---- per-sample analysis (:513-563): magnitude, MagSgn value, exponent as leading-zero count
-        uint32_t mag[4], vv[4], c[4], b[4];
+        uint32_t mag[4], c[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if constexpr (IRREV) {
@@ -322,13 +343,13 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
             }
             const uint32_t sb = (uint32_t)r[i] >> 31;
             const uint32_t t = (mag[i] << 1) - 1u;                 // val - 1  (val = 2*mag)
-            vv[i] = t + sb - 1u;                                   // val - 2 + sign
-            c[i] = ffbh_i32(t);                                          // clz(val-1); 0xFFFFFFFF when insignificant
-            b[i] = min(mag[i], 1u);
+            o.vv[i] = t + sb - 1u;                                 // val - 2 + sign
+            c[i] = ffbh_i32(t);                                    // clz(val-1); 0xFFFFFFFF when insignificant
+            o.b[i] = min(mag[i], 1u);
         }
         ovf |= mag[0] | mag[1];
         ovf |= mag[2] | mag[3];
-        const uint32_t rho = b[0] | (b[1] << 1) | (b[2] << 2) | (b[3] << 3);
+        const uint32_t rho = o.b[0] | (o.b[1] << 1) | (o.b[2] << 2) | (o.b[3] << 3);
         const uint32_t cm = min(min(c[0], c[1]), min(c[2], c[3]));
         const uint32_t emax = 32u - min(cm, 32u);
 
@@ -357,25 +378,28 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
             tbase = half ? 2048u : 0u;
             cq0 = half ? cq0 : cq_first == 0u;
         }
-
         const uint32_t U = max(emax, kappa);
         const uint32_t u = U - kappa;
         uint32_t eps = (uint32_t)(c[0] == cm) | ((uint32_t)(c[1] == cm) << 1) | ((uint32_t)(c[2] == cm) << 2) | ((uint32_t)(c[3] == cm) << 3);
         eps = u ? eps : 0u;
-        uint32_t tuple = g_vlc_enc[tbase + ((ctx << 8) | (rho << 4) | eps)];
-        if (!full) tuple = active ? tuple : 0u;
+        o.tuple = g_vlc_enc[tbase + ((ctx << 8) | (rho << 4) | eps)];
+        o.rho = rho; o.U = U; o.u = u; o.cq0 = cq0;
+        Bprev = Bcur;
+    };
 
-        // next iteration's samples: issued here so that the wait for `tuple` does not cover them
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < iters) fetch(it + 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
+    auto stage2 = [&](uint32_t it, const Stage1& s) {
+        const uint32_t qy = 2 * it + half;
+        const bool active = FULL || (qx < QW && qy < QH);
+        const uint32_t U = s.U, u = s.u, rho = s.rho;
+        uint32_t tuple = s.tuple;
+        if constexpr (!FULL) tuple = active ? tuple : 0u;
 
         // ---- MagSgn: bit counts, in-register concatenation of the quad --------------------------
         uint32_t m[4], vm[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            m[i] = __umul24(U - ((tuple >> i) & 1u), b[i]);
-            vm[i] = __builtin_amdgcn_ubfe(vv[i], 0u, m[i]);
+            m[i] = __umul24(U - ((tuple >> i) & 1u), s.b[i]);
+            vm[i] = __builtin_amdgcn_ubfe(s.vv[i], 0u, m[i]);
         }
         const uint32_t m01 = m[0] + m[1], m23 = m[2] + m[3];
         const uint32_t ms_len = m01 + m23;
@@ -424,7 +448,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
         or_bits32(vlc_raw, vpos, wv);
 
         // ---- MEL events (wave-uniform, scalar unit) ------------------------------------------------
-        const bool ev = active && cq0;
+        const bool ev = active && s.cq0;
         const uint64_t H = __ballot(ev), V = __ballot(ev && rho != 0);
         uint64_t Hm = H;
         if (it == 0) {
@@ -442,8 +466,20 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
             mel_event(mel, mel_buf, (int)((V >> i) & 1), lane == 0);
             Hm &= Hm - 1;
         }
-        Bprev = Bcur;
+    };
+
+    Stage1 sE, sO;                       // unrolled by two so that no pipeline register is ever copied
+    stage1(0, sE, nE);
+    for (uint32_t it = 0; it < iters; it += 2) {
+        if (it + 1 < iters) stage1(it + 1, sO, nO);
+        stage2(it, sE);
+        if (it + 1 < iters) {
+            if (it + 2 < iters) stage1(it + 2, sE, nE);
+            stage2(it + 1, sO);
+        }
     }
+    };   // phase_a
+    if (full) phase_a(std::true_type{}); else phase_a(std::false_type{});
     // magnitudes beyond Kmax+1 bits: outside the contract (see header) -> flag, host reports it
     if (!IRREV && __ballot((ovf >> (kmax + 1)) != 0)) {
         if (lane == 0) atomicOr(reinterpret_cast<unsigned int*>(a.alloc), 2u);
