@@ -169,6 +169,10 @@ def main():
     b_in = (prec + 7) // 8
     algo = {"ingest_mct": samples * (b_in + 4), "dwt53_5levels": 8.0 * samples * sigma(levels),
             "ht_cleanup_encode": 4.0 * samples + float(total), "compact": 2.0 * float(total)}
+    if fam["ingest_mct"][1] == 0:
+        # K1 is fused into DWT level 0: that launch reads the pixels (b_in B/sample) instead of an
+        # int32 plane, so the family's algorithmic bytes are S*b_in + 4*S + 8*S*(sigma_L - 1)
+        algo["dwt53_5levels"] = samples * (b_in + 4.0) + 8.0 * samples * (sigma(levels) - 1.0)
     dom = max(("ingest_mct", "dwt53_5levels", "ht_cleanup_encode"), key=lambda k: fam[k][0])
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this
     # process; they come from the committed rocprofv3 --pmc passes of this same command
@@ -193,7 +197,8 @@ def main():
     kernels = {k: {"avg_ms": round(v[0], 4), "launches": v[1],
                    "algorithmic_GBps": round(algo[k] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
                for k, v in fam.items()}
-    pipeline_bytes = algo["ingest_mct"] + algo["dwt53_5levels"] + algo["ht_cleanup_encode"]
+    # whole-pipeline figure of SURVEY.md §8(d) (unfused definition, kept so that rounds compare)
+    pipeline_bytes = samples * (b_in + 4) + 8.0 * samples * sigma(levels) + algo["ht_cleanup_encode"]
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

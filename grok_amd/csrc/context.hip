@@ -157,7 +157,8 @@ int run_ingest(grk_amd_ctx* c, uint32_t ntiles, const void* d_pixels, void* d_pl
     return GRK_AMD_OK;
 }
 
-int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out)
+// d_pixels != nullptr: level 0 reads the caller's pixels directly (K1 fused into K2), d_in is unused
+int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const void* d_pixels = nullptr, uint32_t ntiles = 0)
 {
     const TileGeom& g = c->geom;
     const uint32_t L = g.p.num_levels;
@@ -191,7 +192,13 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out)
         const uint64_t strips = (a.cw + 503) / 504;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * nplanes < 4096) seg >>= 1;
         a.seg_pairs = seg;
-        HIP_TRY(c, launch_dwt_level(a, c->stream), "launch dwt level");
+        if (l == 0 && d_pixels) {
+            a.pixels = d_pixels; a.px_bytes = (g.p.prec + 7) / 8;
+            a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
+            HIP_TRY(c, launch_dwt_level0_fused(a, ntiles, g.p.num_comps, g.p.mct, c->stream), "launch fused dwt level 0");
+        } else {
+            HIP_TRY(c, launch_dwt_level(a, c->stream), "launch dwt level");
+        }
     }
     return GRK_AMD_OK;
 }
@@ -399,12 +406,19 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         d_px = c->pixels.p;
     }
     const uint32_t nplanes = ntiles * g.p.num_comps;
-    HIP_TRY(c, c->p0.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc planes");
+    // with at least one DWT level, level 0 consumes the pixels itself and the int32 ingest planes
+    // (4 bytes per sample written and read back) never exist
+    const bool fused = g.p.num_levels >= 1 && ((uintptr_t)d_px & 3u) == 0;
+    if (!fused) HIP_TRY(c, c->p0.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc planes");
     HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
     {
         ScopedTimer t(c, 3);
-        rc = run_ingest(c, ntiles, d_px, c->p0.p); if (rc) return rc;
-        rc = run_dwt(c, nplanes, c->p0.p, c->p1.p); if (rc) return rc;
+        if (fused) {
+            rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles); if (rc) return rc;
+        } else {
+            rc = run_ingest(c, ntiles, d_px, c->p0.p); if (rc) return rc;
+            rc = run_dwt(c, nplanes, c->p0.p, c->p1.p); if (rc) return rc;
+        }
         rc = run_ht(c, ntiles, c->p1.p); if (rc) return rc;
     }
     if (table || total) return grk_amd_fetch_table(c, table, total);

@@ -28,8 +28,15 @@ struct DwtLevelArgs {
     uint32_t nplanes;
     uint32_t seg_pairs;   // row pairs per workgroup
     int      irreversible;
+    // level 0 fused with K1 (launch_dwt_level0_fused): rows come from the caller's pixel planes
+    const void* pixels;   // tiles back to back, component-major planar, tight (as IngestArgs::pixels)
+    uint32_t px_bytes;    // 1 or 2 bytes per sample
+    int32_t  dc;          // 2^(prec-1) or 0
+    uint32_t ncomp;       // components per tile
+    uint32_t comp0, zdiv; // set by the launcher: first component of a z slot, z slots per tile
 };
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s);
+hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, int mct, hipStream_t s);
 
 // ---- K3: HT cleanup encoder, one wavefront per code-block (kernels_ht.hip) -------------------
 struct HtBlockDesc {        // one per code-block of a tile-component set (all comps of one tile)

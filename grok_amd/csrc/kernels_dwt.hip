@@ -111,12 +111,40 @@ __device__ __forceinline__ void h97(const float* w, float& s, float& d, float in
     d = __fmul_rn(cp1, kK);
 }
 
-template <bool F97>
+// forward colour transform of one pixel (same arithmetic as kernels_ingest.hip: mct.cpp:94-104, :541-553)
+__device__ __forceinline__ void color_fwd_px(int32_t& c0, int32_t& c1, int32_t& c2, bool irrev)
+{
+    if (!irrev) {
+        const int32_t r = c0, g = c1, b = c2;
+        c0 = (r + 2 * g + b) >> 2;
+        c1 = b - g;
+        c2 = r - g;
+    } else {
+        const float a_r = 0.299f, a_g = 0.587f, a_b = 0.114f;
+        const float cb = 0.5f / (1.0f - a_b), cr = 0.5f / (1.0f - a_r);
+        const float r = (float)c0, g = (float)c1, b = (float)c2;
+        float y = __fmul_rn(a_r, r);
+        y = __fadd_rn(y, __fmul_rn(a_g, g));
+        y = __fadd_rn(y, __fmul_rn(a_b, b));
+        c0 = __float_as_int(y);
+        c1 = __float_as_int(__fmul_rn(cb, __fsub_rn(b, y)));
+        c2 = __float_as_int(__fmul_rn(cr, __fsub_rn(r, y)));
+    }
+}
+
+// PX = 0: the level reads an int32/float plane (levels >= 1, and level 0 of the stage entry point).
+// PX = 1 / 2: level 0 fused with K1 -- the rows come straight from the caller's 8- / 16-bit pixel
+//   planes, DC shift and RCT/ICT are applied in registers and NC (= 3 with MCT) components run
+//   through the transform side by side, so the int32 ingest planes are never written or read
+//   (saves 8 of the 8 + b_in + 4 bytes per sample that K1 + level 0 move separately).
+template <bool F97, int NC, int PX>
 __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 {
     using T  = typename std::conditional<F97, float, int32_t>::type;
     using T2 = typename std::conditional<F97, float2, int2>::type;
-    __shared__ __attribute__((aligned(16))) T line[2][2][kCols];   // [parity][low/high][column]
+    using PIX = typename std::conditional<PX == 2, uint16_t, uint8_t>::type;
+    static_assert(PX != 0 || NC == 1, "plane input is one component per workgroup");
+    __shared__ __attribute__((aligned(16))) T line[2][NC][2][kCols];   // [parity][comp][low/high][column]
 
     const uint32_t t = threadIdx.x;
     const uint32_t cw = a.cw, ch = a.ch;
@@ -129,31 +157,75 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     const uint32_t mA = mirror_idx(cA, cw), mB = mirror_idx(cA + 1, cw);
     const bool vec = (cA >= 0) && ((uint32_t)cA + 1 < cw);
 
-    const T* in = reinterpret_cast<const T*>(a.in) + (size_t)blockIdx.z * a.in_pitch;
-    T* ll = reinterpret_cast<T*>(a.ll) + (size_t)blockIdx.z * a.ll_pitch;
-    T* mp = reinterpret_cast<T*>(a.mallat) + (size_t)blockIdx.z * a.m_pitch;
+    // first plane this workgroup produces
+    uint32_t plane0 = blockIdx.z;
+    if constexpr (PX != 0) plane0 = (blockIdx.z / a.zdiv) * a.ncomp + a.comp0 + (blockIdx.z % a.zdiv);
+    const T* in = reinterpret_cast<const T*>(a.in) + (size_t)plane0 * a.in_pitch;
+    T* ll = reinterpret_cast<T*>(a.ll) + (size_t)plane0 * a.ll_pitch;
+    T* mp = reinterpret_cast<T*>(a.mallat) + (size_t)plane0 * a.m_pitch;
+    const size_t comp_px = (size_t)cw * ch;
+    const PIX* pix = reinterpret_cast<const PIX*>(a.pixels) + (size_t)plane0 * comp_px;
+    const bool pvec = vec && (cw & 1u) == 0;          // tightly packed rows: pairs aligned only for even widths
 
     const int32_t J0 = (int32_t)(blockIdx.y * a.seg_pairs);
     const int32_t J1 = min((int32_t)sh, J0 + (int32_t)a.seg_pairs);
     constexpr int lag  = F97 ? 1 : 0;
     constexpr int warm = F97 ? 2 : 1;
 
-    auto load_row = [&](int32_t r, T& va, T& vb) {
-        const T* row = in + (size_t)mirror_idx(r, ch) * a.in_stride;
-        if (vec) { T2 q = *reinterpret_cast<const T2*>(row + cA); va = q.x; vb = q.y; }
-        else     { va = row[mA]; vb = row[mB]; }
+    // raw row fetch (no arithmetic, so that prefetched rows stay in flight) and its conversion
+    struct Raw { int32_t a[NC], b[NC]; };
+    auto fetch_row = [&](int32_t r, Raw& q) {
+        const uint32_t rr = mirror_idx(r, ch);
+        if constexpr (PX == 0) {
+            const int32_t* row = reinterpret_cast<const int32_t*>(in) + (size_t)rr * a.in_stride;
+            if (vec) { const int2 v = *reinterpret_cast<const int2*>(row + cA); q.a[0] = v.x; q.b[0] = v.y; }
+            else     { q.a[0] = row[mA]; q.b[0] = row[mB]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const PIX* row = pix + (size_t)k * comp_px + (size_t)rr * cw;
+                if (pvec) {
+                    if constexpr (PX == 1) { const uchar2 v = *reinterpret_cast<const uchar2*>(row + cA); q.a[k] = v.x; q.b[k] = v.y; }
+                    else                   { const ushort2 v = *reinterpret_cast<const ushort2*>(row + cA); q.a[k] = v.x; q.b[k] = v.y; }
+                } else { q.a[k] = row[mA]; q.b[k] = row[mB]; }
+            }
+        }
+    };
+    auto convert = [&](const Raw& q, T (&va)[NC], T (&vb)[NC]) {
+        if constexpr (PX == 0) {
+            if constexpr (F97) { va[0] = __int_as_float(q.a[0]); vb[0] = __int_as_float(q.b[0]); }
+            else               { va[0] = q.a[0]; vb[0] = q.b[0]; }
+        } else {
+            int32_t xa[NC], xb[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) { xa[k] = q.a[k] - a.dc; xb[k] = q.b[k] - a.dc; }
+            if constexpr (NC == 3) {            // launched with NC = 3 only for the MCT components
+                color_fwd_px(xa[0], xa[1], xa[2], F97);
+                color_fwd_px(xb[0], xb[1], xb[2], F97);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    if constexpr (F97) { va[k] = __int_as_float(xa[k]); vb[k] = __int_as_float(xb[k]); }
+                    else               { va[k] = xa[k]; vb[k] = xb[k]; }
+                }
+            } else {
+                if constexpr (F97) { va[0] = (float)xa[0]; vb[0] = (float)xb[0]; }
+                else               { va[0] = xa[0]; vb[0] = xb[0]; }
+            }
+        }
     };
 
-    typename std::conditional<F97, V97, V53>::type colA, colB;
+    typename std::conditional<F97, V97, V53>::type colA[NC], colB[NC];
     int32_t i = J0 - warm;
     {
-        T xa, xb;
-        load_row(2 * i, xa, xb);
-        colA.init(xa); colB.init(xb);
+        Raw q; T xa[NC], xb[NC];
+        fetch_row(2 * i, q);
+        convert(q, xa, xb);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { colA[k].init(xa[k]); colB[k].init(xb[k]); }
     }
-    T n1a, n1b, n2a, n2b;                 // prefetched rows of the next step
-    load_row(2 * i + 1, n1a, n1b);
-    load_row(2 * i + 2, n2a, n2b);
+    Raw n1, n2;                           // prefetched rows of the next step
+    fetch_row(2 * i + 1, n1);
+    fetch_row(2 * i + 2, n2);
 
     // the output pair this lane produces in the horizontal phase
     const bool h_lane = (t >= kHalo / 2) && (t < kThreads - kHalo / 2);
@@ -162,47 +234,62 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 
     const int32_t i_end = J1 - 1 + lag;
     for (int par = 0; i <= i_end; ++i, par ^= 1) {
-        T x1a = n1a, x1b = n1b, x2a = n2a, x2b = n2b;
+        T x1a[NC], x1b[NC], x2a[NC], x2b[NC];
+        convert(n1, x1a, x1b);
+        convert(n2, x2a, x2b);
         if (i < i_end) {                 // prefetch rows of step i+1 while this one computes
-            load_row(2 * i + 3, n1a, n1b);
-            load_row(2 * i + 4, n2a, n2b);
+            fetch_row(2 * i + 3, n1);
+            fetch_row(2 * i + 4, n2);
         }
-        T sA, dA, sB, dB;
-        if constexpr (F97) {
-            colA.step(x1a, x2a, sA, dA, inv_k);
-            colB.step(x1b, x2b, sB, dB, inv_k);
-        } else {
-            colA.step(x1a, x2a, sA, dA);
-            colB.step(x1b, x2b, sB, dB);
+        T sA[NC], dA[NC], sB[NC], dB[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            if constexpr (F97) {
+                colA[k].step(x1a[k], x2a[k], sA[k], dA[k], inv_k);
+                colB[k].step(x1b[k], x2b[k], sB[k], dB[k], inv_k);
+            } else {
+                colA[k].step(x1a[k], x2a[k], sA[k], dA[k]);
+                colB[k].step(x1b[k], x2b[k], sB[k], dB[k]);
+            }
         }
         const int32_t j = i - lag;       // row pair just completed (uniform over the workgroup)
         if (j < J0) continue;
         if (ch == 1) {                   // single-row level: vertical pass is the identity
-            load_row(0, sA, sB);
+            Raw q;
+            fetch_row(0, q);
+            convert(q, sA, sB);
         }
-        T2 ql, qh;
-        ql.x = sA; ql.y = sB; qh.x = dA; qh.y = dB;
-        *reinterpret_cast<T2*>(&line[par][0][2 * t]) = ql;
-        *reinterpret_cast<T2*>(&line[par][1][2 * t]) = qh;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            T2 ql, qh;
+            ql.x = sA[k]; ql.y = sB[k]; qh.x = dA[k]; qh.y = dB[k];
+            *reinterpret_cast<T2*>(&line[par][k][0][2 * t]) = ql;
+            *reinterpret_cast<T2*>(&line[par][k][1][2 * t]) = qh;
+        }
         __syncthreads();
         if (h_lane) {
             const bool has_h = (uint32_t)j < dh;
-            T ls, ld, hs = 0, hd = 0;
-            if constexpr (F97) {
-                if (cw == 1) { ls = line[par][0][2 * t]; ld = 0; if (has_h) hs = line[par][1][2 * t]; }
-                else {
-                    h97(&line[par][0][2 * t], ls, ld, inv_k);
-                    if (has_h) h97(&line[par][1][2 * t], hs, hd, inv_k);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                T ls, ld, hs = 0, hd = 0;
+                if constexpr (F97) {
+                    if (cw == 1) { ls = line[par][k][0][2 * t]; ld = 0; if (has_h) hs = line[par][k][1][2 * t]; }
+                    else {
+                        h97(&line[par][k][0][2 * t], ls, ld, inv_k);
+                        if (has_h) h97(&line[par][k][1][2 * t], hs, hd, inv_k);
+                    }
+                } else {
+                    h53(&line[par][k][0][2 * t], ls, ld);
+                    if (has_h) h53(&line[par][k][1][2 * t], hs, hd);
                 }
-            } else {
-                h53(&line[par][0][2 * t], ls, ld);
-                if (has_h) h53(&line[par][1][2 * t], hs, hd);
-            }
-            if (st_s) ll[(size_t)j * a.ll_stride + Jc] = ls;
-            if (st_d) mp[(size_t)j * a.m_stride + sw + Jc] = ld;
-            if (has_h) {
-                if (st_s) mp[(size_t)(sh + j) * a.m_stride + Jc] = hs;
-                if (st_d) mp[(size_t)(sh + j) * a.m_stride + sw + Jc] = hd;
+                T* llk = ll + (size_t)k * a.ll_pitch;
+                T* mpk = mp + (size_t)k * a.m_pitch;
+                if (st_s) llk[(size_t)j * a.ll_stride + Jc] = ls;
+                if (st_d) mpk[(size_t)j * a.m_stride + sw + Jc] = ld;
+                if (has_h) {
+                    if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Jc] = hs;
+                    if (st_d) mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = hd;
+                }
             }
         }
     }
@@ -216,9 +303,39 @@ hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
     dim3 grid((a.cw + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
     dim3 block(kThreads);
     if (a.irreversible)
-        hipLaunchKernelGGL(dwt_level_kernel<true>, grid, block, 0, s, a);
+        hipLaunchKernelGGL((dwt_level_kernel<true, 1, 0>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL(dwt_level_kernel<false>, grid, block, 0, s, a);
+        hipLaunchKernelGGL((dwt_level_kernel<false, 1, 0>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// Level 0 straight from the pixels. `a` describes level 0 (cw x ch = tile size, in/in_stride unused);
+// a.nplanes is ignored: the grid covers ntiles x (MCT triple | every component on its own).
+hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, int mct, hipStream_t s)
+{
+    const uint32_t sh = (a0.ch + 1) >> 1;
+    dim3 block(kThreads);
+    auto go = [&](uint32_t comp0, uint32_t zdiv, int nc) {
+        DwtLevelArgs a = a0;
+        a.comp0 = comp0; a.zdiv = zdiv; a.ncomp = ncomp;
+        dim3 grid((a.cw + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, ntiles * zdiv);
+#define GRK_L0(F97, NC, PX) hipLaunchKernelGGL((dwt_level_kernel<F97, NC, PX>), grid, block, 0, s, a)
+        const int px = a.px_bytes == 1 ? 1 : 2;
+        if (a.irreversible) {
+            if (nc == 3) { if (px == 1) GRK_L0(true, 3, 1); else GRK_L0(true, 3, 2); }
+            else         { if (px == 1) GRK_L0(true, 1, 1); else GRK_L0(true, 1, 2); }
+        } else {
+            if (nc == 3) { if (px == 1) GRK_L0(false, 3, 1); else GRK_L0(false, 3, 2); }
+            else         { if (px == 1) GRK_L0(false, 1, 1); else GRK_L0(false, 1, 2); }
+        }
+#undef GRK_L0
+    };
+    if (mct && ncomp >= 3) {
+        go(0, 1, 3);
+        for (uint32_t k = 3; k < ncomp; ++k) go(k, 1, 1);
+    } else {
+        go(0, ncomp, 1);
+    }
     return hipGetLastError();
 }
 
