@@ -75,6 +75,27 @@ int32_t orc_encode_tile_rev(const void* pixels, int bytes_per_sample, uint32_t n
                             orc_block* blocks_out, uint32_t* lens, uint32_t max_blocks,
                             uint8_t* coded, uint64_t cap, uint64_t* total_bytes);
 
+/* ======================= decode half (oracle/j2k_decode_oracle.c) ================================ */
+/* ---- a14: HT cleanup-pass block decoder (t1/t1_ht/coding/ojph_block_decoder.cpp:989-1625, cleanup
+ *           only).  `missing_msbs` = band numbps - block numbps as Grok passes it
+ *           (T1DecompressScheduler.cpp:59; Kmax-1 for streams of the encoder above).  out: w x h
+ *           words `sign<<31 | (2*mu+1) << (29-missing_msbs)`, row stride `stride`.  0 ok, -1 bad stream. */
+int32_t orc_ht_decode_block(const uint8_t* coded, uint32_t len, uint32_t missing_msbs,
+                            uint32_t w, uint32_t h, uint32_t* out, uint32_t stride);
+/* ---- a15: dequantisation (filters/PostDecompressFilters.h:94-106 ShiftHTFilter, :128-140 ScaleHTFilter) */
+void orc_ht_dequant_rev(const uint32_t* sm, uint32_t n, uint32_t k_msbs, int32_t* out);
+void orc_ht_dequant_irrev(const uint32_t* sm, uint32_t n, float scale, float* out);
+/* ---- a16: inverse 9/7 over `levels` decompositions, in place, Mallat layout in, image out
+ *           (transform/WaveletReverse.cpp:938-1074, :1360-1439); 5/3: orc_dwt53_inv above */
+void orc_dwt97_inv(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels);
+/* ---- a17: inverse colour transform + DC level shift + clamp to [lo,hi], in place
+ *           (point_transform/mct.cpp:369-465 rev, :186-294 irrev (float bit patterns in), :297-364,
+ *           :109-177 single component) */
+void orc_rct_inv_store(int32_t* c0, int32_t* c1, int32_t* c2, size_t n, int32_t shift, int32_t lo, int32_t hi);
+void orc_ict_inv_store(int32_t* c0, int32_t* c1, int32_t* c2, size_t n, int32_t shift, int32_t lo, int32_t hi);
+void orc_dc_store_rev(int32_t* c, size_t n, int32_t shift, int32_t lo, int32_t hi);
+void orc_dc_store_irrev(int32_t* c, size_t n, int32_t shift, int32_t lo, int32_t hi);
+
 #ifdef __cplusplus
 }
 #endif

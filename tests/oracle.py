@@ -51,8 +51,67 @@ def lib():
         L.orc_ht_signmag_rev.restype = None
         L.orc_ht_signmag_irrev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
         L.orc_ht_signmag_irrev.restype = None
+        L.orc_ht_decode_block.restype = C.c_int32
+        L.orc_ht_decode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_ht_dequant_rev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_ht_dequant_rev.restype = None
+        L.orc_ht_dequant_irrev.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
+        L.orc_ht_dequant_irrev.restype = None
+        L.orc_dwt97_inv.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_dwt97_inv.restype = None
+        for f in ("orc_rct_inv_store", "orc_ict_inv_store"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32]
+            getattr(L, f).restype = None
+        for f in ("orc_dc_store_rev", "orc_dc_store_irrev"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32]
+            getattr(L, f).restype = None
         _lib = L
     return _lib
+
+
+def ht_decode_block(coded, missing_msbs, w, h):
+    """-> (h, w) uint32 sign-magnitude words, or None for a stream the decoder rejects."""
+    buf = np.frombuffer(bytes(coded), np.uint8).copy()
+    out = np.zeros((h, w), np.uint32)
+    rc = lib().orc_ht_decode_block(buf.ctypes.data, buf.size, missing_msbs, w, h, out.ctypes.data, w)
+    return out if rc == 0 else None
+
+
+def ht_dequant_rev(sm, k_msbs):
+    a = np.ascontiguousarray(sm, np.uint32)
+    out = np.zeros(a.shape, np.int32)
+    lib().orc_ht_dequant_rev(a.ctypes.data, a.size, k_msbs, out.ctypes.data)
+    return out
+
+
+def ht_dequant_irrev(sm, scale):
+    a = np.ascontiguousarray(sm, np.uint32)
+    out = np.zeros(a.shape, np.float32)
+    lib().orc_ht_dequant_irrev(a.ctypes.data, a.size, float(scale), out.ctypes.data)
+    return out
+
+
+def dwt97_inv(plane, levels):
+    p = np.ascontiguousarray(plane, np.float32).copy()
+    h, w = p.shape
+    lib().orc_dwt97_inv(p.ctypes.data, w, h, w, levels)
+    return p
+
+
+def color_inv_store(planes, prec, irrev, mct, sgnd=False):
+    """planes: list of (H,W) int32 arrays (float bit patterns when irrev). Returns clamped int32 pixels."""
+    shift = 0 if sgnd else 1 << (prec - 1)
+    lo, hi = (-(1 << (prec - 1)), (1 << (prec - 1)) - 1) if sgnd else (0, (1 << prec) - 1)
+    a = [np.ascontiguousarray(p, np.int32).copy() for p in planes]
+    L = lib()
+    k0 = 0
+    if mct and len(a) >= 3:
+        f = L.orc_ict_inv_store if irrev else L.orc_rct_inv_store
+        f(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[0].size, shift, lo, hi)
+        k0 = 3
+    for k in range(k0, len(a)):
+        (L.orc_dc_store_irrev if irrev else L.orc_dc_store_rev)(a[k].ctypes.data, a[k].size, shift, lo, hi)
+    return a
 
 
 def signmag(coeffs, kmax):
