@@ -36,7 +36,7 @@ class Block(C.Structure):
 
 
 class CodedBlock(C.Structure):
-    _fields_ = [("offset", C.c_uint64), ("length", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("offset", C.c_uint64), ("length", C.c_uint32), ("missing_msbs", C.c_uint32)]
 
 
 _lib = None
@@ -79,6 +79,11 @@ def lib():
         L.grk_amd_stage_ingest_mct.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_stage_dwt_fwd.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_stage_ht_encode.argtypes = [vp, PP, u32, vp]
+        L.grk_amd_stage_dwt_inv.argtypes = [vp, PP, u32, vp, vp]
+        L.grk_amd_stage_ht_decode.argtypes = [vp, PP, u32, vp, vp, vp]
+        L.grk_amd_decode_tiles.argtypes = [vp, PP, u32, vp, vp, u64, i32, vp, i32]
+        L.grk_amd_decode_status.argtypes = [vp]
+        L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
         L.grk_amd_kernel_ms.restype = C.c_double
         L.grk_amd_kernel_ms.argtypes = [vp, i32, C.POINTER(u32)]
@@ -115,7 +120,7 @@ def write_codestream(params, img_w, img_h, table, coded):
     return out[:n].tobytes()
 
 
-CODED_DTYPE = np.dtype([("offset", np.uint64), ("length", np.uint32), ("reserved", np.uint32)])
+CODED_DTYPE = np.dtype([("offset", np.uint64), ("length", np.uint32), ("missing_msbs", np.uint32)])
 
 
 class Context:
@@ -198,6 +203,35 @@ class Context:
 
     def stage_ht_encode(self, params, ntiles, d_mallat):
         self._check(self._L.grk_amd_stage_ht_encode(self._h, C.byref(params), ntiles, d_mallat), "stage_ht_encode")
+
+    def stage_ht_decode(self, params, ntiles, table, d_coded, d_mallat):
+        t = np.ascontiguousarray(table)
+        self._check(self._L.grk_amd_stage_ht_decode(self._h, C.byref(params), ntiles, t.ctypes.data, d_coded, d_mallat),
+                    "stage_ht_decode")
+
+    def decode_host(self, params, table, coded, ntiles=1):
+        """table: CODED_DTYPE rows, coded: bytes-like (host). Returns pixels (ntiles, C, H, W)."""
+        t = np.ascontiguousarray(table)
+        cb = np.frombuffer(coded, np.uint8) if not isinstance(coded, np.ndarray) else np.ascontiguousarray(coded)
+        dt = np.uint8 if params.prec <= 8 else np.uint16
+        out = np.zeros((ntiles, params.num_comps, params.tile_h, params.tile_w), dt)
+        self._check(self._L.grk_amd_decode_tiles(self._h, C.byref(params), ntiles, t.ctypes.data, cb.ctypes.data, cb.size, 0,
+                                                 out.ctypes.data, 0), "decode_tiles")
+        return out
+
+    def decode_device(self, params, ntiles, table, d_coded, coded_bytes, d_pixels):
+        t = np.ascontiguousarray(table)
+        self._check(self._L.grk_amd_decode_tiles(self._h, C.byref(params), ntiles, t.ctypes.data, d_coded, coded_bytes, 1,
+                                                 d_pixels, 1), "decode_tiles")
+
+    def decode_status(self):
+        self._check(self._L.grk_amd_decode_status(self._h), "decode_status")
+
+    def stage_dwt_inv(self, params, nplanes, d_mallat, d_out):
+        self._check(self._L.grk_amd_stage_dwt_inv(self._h, C.byref(params), nplanes, d_mallat, d_out), "stage_dwt_inv")
+
+    def stage_egress(self, params, ntiles, d_planes, d_pixels):
+        self._check(self._L.grk_amd_stage_egress(self._h, C.byref(params), ntiles, d_planes, d_pixels), "stage_egress")
 
     def enable_timing(self, on=True):
         self._check(self._L.grk_amd_enable_timing(self._h, int(on)), "enable_timing")

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <cmath>
 
 using namespace grk_amd;
 
@@ -49,18 +50,19 @@ struct grk_amd_ctx {
     std::string err;
     // working set
     DevBuf pixels, p0, p1, llA, llB, blockdesc, lengths, offsets, arena, flag;
+    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels;
     // geometry cache
     grk_amd_tile_params gp{};
     bool have_geom = false;
     TileGeom geom;
-    std::vector<HtBlockDesc> h_desc;
+    std::vector<HtBlockDesc> h_desc, h_desc_dec;
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
     uint32_t last_ntiles = 0;
     uint64_t last_nblocks = 0;
     // timing
     bool timing = false;
-    Timer timers[5];
+    Timer timers[8];
 };
 
 namespace {
@@ -103,6 +105,27 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
             d.inv_step = 1.0f / b.stepsize;
             c->h_desc.push_back(d);
         }
+    // decode-side descriptors: inv_step carries the dequantisation scale of the band
+    // (codestream/Quantizer.cpp:41-63 with compress = false: log2_gain 0, then / 2^(31 - numbps))
+    c->h_desc_dec = c->h_desc;
+    {
+        size_t i = 0;
+        for (uint32_t k = 0; k < p->num_comps; ++k)
+            for (const auto& b : g.blocks_comp0) {
+                float scale = 1.0f;
+                if (p->irreversible) {
+                    const uint32_t bi = b.res == 0 ? 0u : 3u * b.res - 2u + (b.band - 1u);
+                    const uint16_t wq = g.qcd_words[bi];
+                    const double step = (1.0 + (wq & 0x7FF) / 2048.0) * std::pow(2.0, (int)p->prec - (int)(wq >> 11));
+                    scale = (float)step;
+                    scale /= (float)(1u << (31 - b.kmax));
+                }
+                c->h_desc_dec[i++].inv_step = scale;
+            }
+    }
+    HIP_TRY(c, c->dec_desc.ensure(c->h_desc_dec.size() * sizeof(HtBlockDesc)), "alloc decode block table");
+    HIP_TRY(c, hipMemcpyAsync(c->dec_desc.p, c->h_desc_dec.data(), c->h_desc_dec.size() * sizeof(HtBlockDesc),
+                              hipMemcpyHostToDevice, c->stream), "upload decode block table");
     HIP_TRY(c, c->blockdesc.ensure(c->h_desc.size() * sizeof(HtBlockDesc)), "alloc block table");
     HIP_TRY(c, hipMemcpyAsync(c->blockdesc.p, c->h_desc.data(), c->h_desc.size() * sizeof(HtBlockDesc),
                               hipMemcpyHostToDevice, c->stream), "upload block table");
@@ -203,6 +226,97 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
     return GRK_AMD_OK;
 }
 
+int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out)
+{
+    const TileGeom& g = c->geom;
+    const uint32_t L = g.p.num_levels;
+    const uint32_t W = g.p.tile_w, H = g.p.tile_h;
+    if (L == 0) {
+        HIP_TRY(c, hipMemcpyAsync(d_out, d_mallat, (size_t)nplanes * g.plane_elems * 4, hipMemcpyDeviceToDevice, c->stream), "copy planes");
+        return GRK_AMD_OK;
+    }
+    // same ping-pong storage as the forward transform: A holds LL1, LL3, ...; B holds LL2, LL4, ...
+    const uint32_t sA = ll_stride_for(W), hA = (H + 1) >> 1;
+    const uint32_t sB = ll_stride_for((W + 1) >> 1), hB = (hA + 1) >> 1;
+    const uint64_t pitchA = (uint64_t)sA * hA, pitchB = (uint64_t)sB * hB;
+    HIP_TRY(c, c->llA.ensure((size_t)nplanes * pitchA * 4 + 256), "alloc LL ping");
+    HIP_TRY(c, c->llB.ensure((size_t)nplanes * pitchB * 4 + 256), "alloc LL pong");
+    ScopedTimer t(c, 6);
+    for (int32_t l = (int32_t)L - 1; l >= 0; --l) {
+        IdwtLevelArgs a{};
+        a.cw = ceil_div_pow2(W, (uint32_t)l); a.ch = ceil_div_pow2(H, (uint32_t)l);
+        if ((uint32_t)l + 1 == L) { a.ll = (const int32_t*)d_mallat; a.ll_stride = g.stride; a.ll_pitch = g.plane_elems; }
+        else if ((l + 1) & 1) { a.ll = (const int32_t*)c->llA.p; a.ll_stride = sA; a.ll_pitch = pitchA; }
+        else { a.ll = (const int32_t*)c->llB.p; a.ll_stride = sB; a.ll_pitch = pitchB; }
+        a.mallat = (const int32_t*)d_mallat; a.m_stride = g.stride; a.m_pitch = g.plane_elems;
+        if (l == 0) { a.out = (int32_t*)d_out; a.out_stride = g.stride; a.out_pitch = g.plane_elems; }
+        else if (l & 1) { a.out = (int32_t*)c->llA.p; a.out_stride = sA; a.out_pitch = pitchA; }
+        else { a.out = (int32_t*)c->llB.p; a.out_stride = sB; a.out_pitch = pitchB; }
+        a.nplanes = nplanes;
+        a.irreversible = g.p.irreversible;
+        const uint32_t sh = (a.ch + 1) >> 1;
+        uint32_t seg = 64;
+        const uint64_t strips = (((a.cw + 1) >> 1) + 251) / 252;
+        while (seg > 8 && strips * ((sh + seg - 1) / seg) * nplanes < 4096) seg >>= 1;
+        a.seg_pairs = seg;
+        HIP_TRY(c, launch_idwt_level(a, c->stream), "launch idwt level");
+    }
+    return GRK_AMD_OK;
+}
+
+int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* table, const void* d_coded, void* d_mallat)
+{
+    const TileGeom& g = c->geom;
+    const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
+    const uint64_t nblocks = (uint64_t)bpt * ntiles;
+    uint32_t max_len = 0;
+    for (uint64_t i = 0; i < nblocks; ++i) max_len = std::max(max_len, table[i].length);
+    if (max_len > (48u << 10)) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "code-block longer than 48 KiB");
+    static_assert(sizeof(HtDecBlock) == sizeof(grk_amd_coded_block), "decode table rows are grk_amd_coded_block");
+    HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
+    HIP_TRY(c, c->dec_quads.ensure(nblocks * 1024 * 4), "alloc quad info");
+    HIP_TRY(c, c->dec_mslen.ensure(nblocks * 4), "alloc ms lengths");
+    HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc status");
+    HIP_TRY(c, hipMemcpyAsync(c->dec_table.p, table, nblocks * sizeof(HtDecBlock), hipMemcpyHostToDevice, c->stream), "upload decode table");
+    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, 16, c->stream), "clear status");
+    HtDecArgs a{};
+    a.table = (const HtDecBlock*)c->dec_table.p;
+    a.blocks = (const HtBlockDesc*)c->dec_desc.p; a.blocks_per_tile = bpt; a.nblocks = (uint32_t)nblocks; a.ncomp = g.p.num_comps;
+    a.coded = (const uint8_t*)d_coded;
+    a.quads = (uint32_t*)c->dec_quads.p; a.ms_len = (uint32_t*)c->dec_mslen.p; a.status = (unsigned int*)c->flag.p;
+    a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
+    a.irreversible = g.p.irreversible;
+    ScopedTimer t(c, 5);
+    HIP_TRY(c, launch_ht_decode(a, max_len, c->stream), "launch ht decode");
+    return GRK_AMD_OK;
+}
+
+int check_decode_status(grk_amd_ctx* c)
+{
+    uint32_t st = 0;
+    HIP_TRY(c, hipMemcpyAsync(&st, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream), "fetch status");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    if (st & 4u) return fail(c, GRK_AMD_ERR_INVALID, "corrupt HT code-block (bad Scup or U_q > missing_msbs)");
+    return GRK_AMD_OK;
+}
+
+int run_egress(grk_amd_ctx* c, uint32_t ntiles, const void* d_planes, void* d_pixels, uint32_t out_bytes)
+{
+    const TileGeom& g = c->geom;
+    EgressArgs a{};
+    a.planes = (const int32_t*)d_planes; a.pixels = d_pixels;
+    a.w = g.p.tile_w; a.h = g.p.tile_h; a.stride = g.stride; a.pitch = g.plane_elems;
+    a.ncomp = g.p.num_comps; a.ntiles = ntiles;
+    a.bytes_per_sample = out_bytes;
+    a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
+    a.lo = g.p.sgnd ? -(1 << (g.p.prec - 1)) : 0;
+    a.hi = g.p.sgnd ? (1 << (g.p.prec - 1)) - 1 : (1 << g.p.prec) - 1;
+    a.mct = g.p.mct; a.irreversible = g.p.irreversible;
+    ScopedTimer t(c, 7);
+    HIP_TRY(c, launch_egress(a, c->stream), "launch egress");
+    return GRK_AMD_OK;
+}
+
 void block_extents(const TileGeom& g, uint32_t& max_kmax, uint32_t& max_samples)
 {
     max_kmax = 0; max_samples = 0;
@@ -276,7 +390,8 @@ void grk_amd_destroy(grk_amd_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
     for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
-                      &c->offsets, &c->arena, &c->flag})
+                      &c->offsets, &c->arena, &c->flag, &c->dec_desc, &c->dec_table, &c->dec_quads, &c->dec_mslen,
+                      &c->dec_coded, &c->dec_pixels})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -350,6 +465,76 @@ int grk_amd_stage_ht_encode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32
     return run_ht(c, ntiles, d_mallat);
 }
 
+int grk_amd_stage_dwt_inv(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nplanes, const void* d_mallat, void* d_out)
+{
+    if (!c || !p || !d_mallat || !d_out) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    int rc = ensure_geom(c, p); if (rc) return rc;
+    return run_idwt(c, nplanes, d_mallat, d_out);
+}
+
+int grk_amd_stage_ht_decode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
+                            const grk_amd_coded_block* table, const void* d_coded, void* d_mallat)
+{
+    if (!c || !p || !table || !d_coded || !d_mallat || ntiles == 0) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    int rc = ensure_geom(c, p); if (rc) return rc;
+    rc = run_ht_decode(c, ntiles, table, d_coded, d_mallat); if (rc) return rc;
+    return check_decode_status(c);
+}
+
+int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
+                         const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
+                         void* pixels, int pixels_on_device)
+{
+    if (!c || !p || !table || !coded || !pixels || ntiles == 0) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    int rc = ensure_geom(c, p); if (rc) return rc;
+    const TileGeom& g = c->geom;
+    const void* d_coded = coded;
+    if (!coded_on_device) {
+        HIP_TRY(c, c->dec_coded.ensure(coded_bytes + 64), "alloc coded staging");
+        HIP_TRY(c, hipMemcpyAsync(c->dec_coded.p, coded, coded_bytes, hipMemcpyHostToDevice, c->stream), "upload coded");
+        d_coded = c->dec_coded.p;
+    }
+    const uint32_t nplanes = ntiles * g.p.num_comps;
+    const uint32_t bps = (g.p.prec + 7u) / 8u;
+    const size_t px_bytes = (size_t)nplanes * g.p.tile_w * g.p.tile_h * bps;
+    void* d_px = pixels;
+    if (!pixels_on_device) {
+        HIP_TRY(c, c->dec_pixels.ensure(px_bytes), "alloc pixel staging");
+        d_px = c->dec_pixels.p;
+    }
+    HIP_TRY(c, c->p0.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc planes");
+    HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
+    {
+        ScopedTimer t(c, 3);
+        rc = run_ht_decode(c, ntiles, table, d_coded, c->p1.p); if (rc) return rc;
+        rc = run_idwt(c, nplanes, c->p1.p, c->p0.p); if (rc) return rc;
+        rc = run_egress(c, ntiles, c->p0.p, d_px, bps); if (rc) return rc;
+    }
+    if (!pixels_on_device) {
+        HIP_TRY(c, hipMemcpyAsync(pixels, d_px, px_bytes, hipMemcpyDeviceToHost, c->stream), "download pixels");
+        return check_decode_status(c);
+    }
+    return GRK_AMD_OK;
+}
+
+int grk_amd_decode_status(grk_amd_ctx* c)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    return check_decode_status(c);
+}
+
+int grk_amd_stage_egress(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const void* d_planes, void* d_pixels)
+{
+    if (!c || !p || !d_planes || !d_pixels) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    int rc = ensure_geom(c, p); if (rc) return rc;
+    return run_egress(c, ntiles, d_planes, d_pixels, (p->prec + 7u) / 8u);
+}
+
 int grk_amd_fetch_table(grk_amd_ctx* c, grk_amd_coded_block* table, uint64_t* total)
 {
     if (!c || !c->last_nblocks) return GRK_AMD_ERR_INVALID;
@@ -365,8 +550,13 @@ int grk_amd_fetch_table(grk_amd_ctx* c, grk_amd_coded_block* table, uint64_t* to
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     if (flagwords[0] & 1u) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
     if (flagwords[0] & 2u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "coefficient magnitude exceeds Kmax+1 bits");
-    if (table)
-        for (uint64_t i = 0; i < n; ++i) { table[i].offset = c->h_off[i]; table[i].length = c->h_len[i]; table[i].reserved = 0; }
+    if (table) {
+        const uint32_t bpt = (uint32_t)c->h_desc.size();
+        for (uint64_t i = 0; i < n; ++i) {
+            table[i].offset = c->h_off[i]; table[i].length = c->h_len[i];
+            table[i].missing_msbs = c->h_desc[i % bpt].kmax - 1u;      // numbps = 1 is signalled (T1HT.cpp:123)
+        }
+    }
     if (total) *total = flagwords[1];
     return GRK_AMD_OK;
 }
@@ -437,7 +627,7 @@ int grk_amd_enable_timing(grk_amd_ctx* c, int on)
 
 double grk_amd_kernel_ms(grk_amd_ctx* c, int which, uint32_t* launches)
 {
-    if (!c || which < 0 || which > 4) return -1.0;
+    if (!c || which < 0 || which > 7) return -1.0;
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
     if (launches) *launches = c->timers[which].launches;

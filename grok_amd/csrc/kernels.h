@@ -65,4 +65,48 @@ constexpr uint32_t kHtAllocRegions = 16;           // region words available; a 
 constexpr uint32_t kHtAllocChunk = 256u << 10;     // bytes a region takes from the shared cursor at a time
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);
 
+// ---- K5: HT cleanup decoder + dequantisation (kernels_htdec.hip) --------------------------------
+struct HtDecBlock {          // one per code-block, same layout as grk_amd_coded_block
+    uint64_t offset;         // first byte of the block's cleanup pass inside `coded`
+    uint32_t length;         // Lcup (0: block has no data -> all samples zero)
+    uint32_t missing_msbs;   // band numbps - block numbps (T1DecompressScheduler.cpp:59)
+};
+struct HtDecArgs {
+    const HtDecBlock* table;                   // [ntiles * blocks_per_tile], device
+    const HtBlockDesc* blocks;                 // geometry per block of one tile; inv_step = decode scale (irreversible)
+    uint32_t blocks_per_tile, nblocks, ncomp;
+    const uint8_t* coded;                      // device
+    uint32_t* quads;                           // [nblocks][32*32] K5a -> K5b: CxtVLC entry | (u_q + 1) << 16 per quad
+    uint32_t* ms_len;                          // [nblocks] MagSgn bytes (0xFFFFFFFF: block rejected)
+    unsigned int* status;                      // bit 2: a block was rejected
+    int32_t* mallat; uint32_t stride; uint64_t pitch;
+    int irreversible;
+};
+hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s);
+
+// ---- K6: one inverse DWT level, horizontal + vertical fused (kernels_idwt.hip) ------------------
+struct IdwtLevelArgs {
+    const int32_t* ll;     uint32_t ll_stride;  uint64_t ll_pitch;   // LL of the level (sw x sh)
+    const int32_t* mallat; uint32_t m_stride;   uint64_t m_pitch;    // HL/LH/HH read from their Mallat slots
+    int32_t* out;          uint32_t out_stride; uint64_t out_pitch;  // synthesised level, cw x ch
+    uint32_t cw, ch;
+    uint32_t nplanes;
+    uint32_t seg_pairs;
+    int      irreversible;
+};
+hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s);
+
+// ---- K7: inverse colour transform + DC shift + clamp + store as pixels (kernels_idwt.hip) --------
+struct EgressArgs {
+    const int32_t* planes;   // [tile][comp] planes (float bit patterns when irreversible)
+    void*    pixels;         // tiles back to back, component-major planar, tight
+    uint32_t w, h, stride;
+    uint64_t pitch;
+    uint32_t ncomp, ntiles;
+    uint32_t bytes_per_sample;   // 1, 2 or 4 (int32 out)
+    int32_t  dc, lo, hi;
+    int      mct, irreversible;
+};
+hipError_t launch_egress(const EgressArgs& a, hipStream_t s);
+
 } // namespace grk_amd

@@ -1,0 +1,360 @@
+// grok_amd/csrc/kernels_htdec.hip -- K5: HTJ2K cleanup-pass decoder + dequantisation, gfx950.
+//
+// Replaces T1HT::decompress -> ojph_decode_codeblock (t1/t1_ht/T1HT.cpp:129-179,
+// t1/t1_ht/coding/ojph_block_decoder.cpp:989-1625, cleanup pass only -- Grok passes lengths2 = 0)
+// and the ShiftHTFilter / ScaleHTFilter post-processing (filters/PostDecompressFilters.h:94-140).
+//
+// The reference decodes a block strictly serially.  The dependences are of two kinds and the
+// work is split along them:
+//
+//  K5a ht_dec_vlc_kernel -- ONE LANE PER CODE-BLOCK.  MEL and VLC/UVLC decoding is a chain through
+//      the whole block (every codeword's position depends on the previous one, every context on the
+//      previous quad), so a wavefront gives it no parallelism; instead each lane walks the VLC and
+//      MEL segments of its own block and emits one word per quad: the CxtVLC table entry
+//      (rho, u_off, e_k, e_1) and u_q + 1.  Few lanes per wave are used on purpose when there are
+//      few blocks, so that several waves per SIMD hide each other's latency.
+//  K5b ht_dec_ms_kernel  -- ONE WAVEFRONT PER CODE-BLOCK.  The MagSgn segment is un-stuffed in
+//      parallel into LDS (byte widths 8/7 -> prefix sum -> ds_or); then, one quad row per
+//      iteration with lane <-> sample column, the exponent bound of the row above gives kappa,
+//      a wave prefix sum of the bit counts m_n gives every sample its bit offset, and the
+//      magnitudes are extracted, dequantised and stored to the component's Mallat plane as
+//      coalesced rows.  Only the exponents of a row feed the next row.
+//
+// Results equal the reference's on every stream a conforming encoder produces; streams the
+// reference rejects (bad Scup, U_q > missing_msbs) are rejected here as well.
+#include "kernels.h"
+#include "ht_vlc_tables.h"
+
+namespace grk_amd {
+
+namespace {
+
+__device__ uint16_t g_vlc_dec[2048];         // [0..1023] first quad row, [1024..2047] others; index (c_q<<7)|7 bits
+
+constexpr uint32_t kQuadStride = 32;         // quads per row in the per-block quad-info array (blocks <= 64 wide)
+constexpr uint32_t kQuadWords  = 32 * 32;
+
+// ---- K5a --------------------------------------------------------------------------------------------
+struct RevReader {          // VLC: backward, LSB first; after a byte > 0x8F a byte whose 7 LSBs are ones carries 7 bits
+    const uint8_t* d; int pos, left; uint64_t acc; int n; uint32_t unstuff;
+    __device__ __forceinline__ void fill()
+    {
+        while (n <= 32) {
+            const uint32_t b = (left > 0 && pos >= 0) ? d[pos] : 0u;
+            --pos; --left;
+            const uint32_t w = 8u - ((unstuff && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
+            acc |= (uint64_t)b << n;
+            n += (int)w;
+            unstuff = b > 0x8Fu;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek() { fill(); return (uint32_t)acc; }
+    __device__ __forceinline__ void skip(uint32_t nb) { acc >>= nb; n -= (int)nb; }
+};
+
+struct MelReader {          // MEL: forward, MSB first; byte after 0xFF carries 7 bits; last byte |= 0x0F
+    const uint8_t* d; int pos, left; uint32_t cur; int nb; uint32_t unstuff;
+    int k, zeros; bool one_pending;
+    __device__ __forceinline__ int bit()
+    {
+        if (nb == 0) {
+            uint32_t b = 0xFFu;
+            if (left > 0) { b = d[pos]; if (left == 1) b |= 0x0Fu; ++pos; }
+            --left;
+            nb = 8 - (int)unstuff;
+            cur = b & (unstuff ? 0x7Fu : 0xFFu);
+            unstuff = b == 0xFFu;
+        }
+        --nb;
+        return (int)((cur >> nb) & 1u);
+    }
+    __device__ __forceinline__ int event()
+    {
+        if (zeros == 0 && !one_pending) {
+            const int e = (int)((0x5433222111000ull >> (4 * k)) & 0xF);     // MEL exponents (:196)
+            if (bit()) { zeros = 1 << e; if (k < 12) ++k; }
+            else {
+                int r = 0;
+                for (int i = 0; i < e; ++i) r = (r << 1) | bit();
+                zeros = r; one_pending = true; if (k > 0) --k;
+            }
+        }
+        if (zeros > 0) { --zeros; return 0; }
+        one_pending = false;
+        return 1;
+    }
+};
+
+// UVLC prefix: '1' -> 1, '01' -> 2, '001' -> 3 + 1-bit suffix, '000' -> 5 + 5-bit suffix (:706-716)
+__device__ __forceinline__ void uvlc_prefix(uint32_t bits, uint32_t& pl, uint32_t& sl, uint32_t& base)
+{
+    if (bits & 1u)      { pl = 1; sl = 0; base = 1; }
+    else if (bits & 2u) { pl = 2; sl = 0; base = 2; }
+    else if (bits & 4u) { pl = 3; sl = 1; base = 3; }
+    else                { pl = 3; sl = 5; base = 5; }
+}
+
+__global__ void ht_dec_vlc_kernel(HtDecArgs a)
+{
+    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= a.nblocks) return;
+    const HtDecBlock in = a.table[blk];
+    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
+    uint32_t* qi = a.quads + (size_t)blk * kQuadWords;
+    const uint32_t w = bd.w, h = bd.h;
+    const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
+    const uint32_t mm = in.missing_msbs;
+    const uint8_t* D = a.coded + in.offset;
+    const int lcup = (int)in.length;
+
+    if (in.length == 0) {                                  // block absent from the codestream: all zero
+        for (uint32_t qy = 0; qy < QH; ++qy)
+            for (uint32_t q = 0; q < QW; ++q) qi[qy * kQuadStride + q] = 0;
+        return;
+    }
+    bool bad = mm > 29 || lcup < 2;
+    int scup = 0;
+    if (!bad) {
+        scup = ((int)D[lcup - 1] << 4) + (D[lcup - 2] & 0xF);
+        bad = scup < 2 || scup > lcup || scup > 4079;
+    }
+    if (bad) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; return; }
+    a.ms_len[blk] = (uint32_t)(lcup - scup);
+
+    MelReader mel{D, lcup - scup, scup - 1, 0u, 0, 0u, 0, 0, false};
+    RevReader vlc;
+    {
+        const uint32_t d0 = D[lcup - 2];
+        vlc.d = D; vlc.pos = lcup - 3; vlc.left = scup - 2;
+        vlc.acc = d0 >> 4; vlc.n = 4 - (((d0 >> 4) & 7u) == 7u ? 1 : 0);
+        vlc.unstuff = (d0 | 0xFu) > 0x8Fu;
+    }
+    uint64_t sa = 0;                     // significance of the bottom sample row of the quad row above: bit x
+    for (uint32_t qy = 0; qy < QH; ++qy) {
+        uint64_t sn = 0;
+        uint32_t chain = 0;
+        const uint16_t* tbl = g_vlc_dec + (qy == 0 ? 0 : 1024);
+        for (uint32_t q0 = 0; q0 < QW; q0 += 2) {
+            uint32_t qinf[2] = {0u, 0u}, U[2] = {1u, 1u};
+#pragma unroll
+            for (uint32_t j = 0; j < 2; ++j) {
+                const uint32_t q = q0 + j;
+                if (q < QW) {
+                    uint32_t c = chain;
+                    if (qy > 0) {
+                        const uint32_t nw_n = q == 0 ? (uint32_t)(sa & 1u) : (uint32_t)((sa >> (2 * q - 1)) & 3u);
+                        const uint32_t ne_nf = (uint32_t)((sa >> (2 * q + 1)) & 3u);
+                        c |= (nw_n ? 1u : 0u) | (ne_nf ? 4u : 0u);
+                    }
+                    uint32_t t = tbl[(c << 7) | (vlc.peek() & 0x7Fu)];
+                    if (c == 0 && !mel.event()) t = 0;
+                    vlc.skip(t & 7u);
+                    qinf[j] = t;
+                    const uint32_t rho = (t >> 4) & 0xFu;
+                    chain = qy == 0 ? ((rho & 1u) | (rho >> 1)) : ((((rho >> 2) | (rho >> 3)) & 1u) << 1);
+                    sn |= (uint64_t)(((rho >> 1) & 1u) | (((rho >> 3) & 1u) << 1)) << (2 * q);
+                }
+            }
+            uint32_t mode = ((qinf[0] >> 3) & 1u) | (((qinf[1] >> 3) & 1u) << 1);
+            uint32_t add = 1;
+            if (qy == 0 && mode == 3 && mel.event()) { mode = 4; add = 3; }
+            if (mode) {
+                uint32_t v = vlc.peek(), used, pl, sl, base;
+                uvlc_prefix(v, pl, sl, base); v >>= pl;
+                if (mode <= 2) {
+                    used = pl + sl;
+                    U[mode - 1] = base + (v & ((1u << sl) - 1u)) + 1;
+                } else if (mode == 3 && qy == 0 && pl > 2) {        // second quad: one bit
+                    U[1] = (v & 1u) + 2; v >>= 1; used = pl + 1 + sl;
+                    U[0] = base + (v & ((1u << sl) - 1u)) + 1;
+                } else {
+                    uint32_t pl2, sl2, base2;
+                    uvlc_prefix(v, pl2, sl2, base2); v >>= pl2;
+                    used = pl + pl2 + sl + sl2;
+                    U[0] = base + (v & ((1u << sl) - 1u)) + add; v >>= sl;
+                    U[1] = base2 + (v & ((1u << sl2) - 1u)) + add;
+                }
+                vlc.skip(used);
+            }
+            if (U[0] > mm || U[1] > mm) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; return; }   // :1194
+            qi[qy * kQuadStride + q0] = qinf[0] | (U[0] << 16);
+            if (q0 + 1 < QW) qi[qy * kQuadStride + q0 + 1] = qinf[1] | (U[1] << 16);
+        }
+        sa = sn;
+    }
+}
+
+// ---- K5b --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
+{
+    (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += dpp0<0x111, 0xF>(v);
+    v += dpp0<0x112, 0xF>(v);
+    v += dpp0<0x114, 0xF>(v);
+    v += dpp0<0x118, 0xF>(v);
+    v += dpp0<0x142, 0xA>(v);
+    v += dpp0<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t bperm(int addr, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v);
+}
+
+template <bool IRREV>
+__global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t raw[];       // un-stuffed MagSgn bits + 4 words of ones
+    const int lane = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const HtDecBlock in = a.table[blk];
+    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
+    const uint32_t tile = blk / a.blocks_per_tile;
+    const uint32_t w = bd.w, h = bd.h;
+    const uint32_t QH = (h + 1) >> 1;
+    int32_t* dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
+    const uint32_t ms_len = a.ms_len[blk];
+    const uint32_t x = lane;                              // sample column of this lane
+    const bool col_ok = x < w;
+
+    if (in.length == 0 || ms_len == 0xFFFFFFFFu) {        // absent or rejected block: zeros
+        for (uint32_t y = 0; y < h; ++y) if (col_ok) dst[(size_t)y * a.stride + x] = 0;
+        return;
+    }
+    // ---- un-stuff the MagSgn segment: byte i contributes 8 bits, or 7 if byte i-1 is 0xFF ----------
+    const uint8_t* D = a.coded + in.offset;
+    for (uint32_t i = lane; i < raw_words; i += 64) raw[i] = 0;
+    __syncthreads();
+    uint32_t base_bits = 0;
+    for (uint32_t i0 = 0; i0 < ms_len; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t b = 0, wd = 0;
+        if (i < ms_len) {
+            b = D[i];
+            const bool st = i > 0 && D[i - 1] == 0xFFu;
+            wd = st ? 7u : 8u;
+            b &= st ? 0x7Fu : 0xFFu;
+        }
+        const uint32_t incl = wave_incl_scan(wd);
+        const uint32_t pos = base_bits + incl - wd;
+        if (wd) {
+            const uint64_t v = (uint64_t)b << (pos & 31);
+            lds_or(&raw[pos >> 5], (uint32_t)v);
+            lds_or(&raw[(pos >> 5) + 1], (uint32_t)(v >> 32));
+        }
+        base_bits += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    __syncthreads();
+    // an exhausted MagSgn segment reads as ones (frwd_read<0xFF>, :823-850)
+    if (lane < 4) {
+        const uint32_t wi = (base_bits >> 5) + lane;
+        const uint32_t ones = lane == 0 ? (0xFFFFFFFFu << (base_bits & 31)) : 0xFFFFFFFFu;
+        if (wi < raw_words) lds_or(&raw[wi], ones);
+    }
+    __syncthreads();
+
+    // ---- quad rows ---------------------------------------------------------------------------------
+    const uint32_t mm = in.missing_msbs;
+    const uint32_t p = 30u - mm;
+    const uint32_t* qi = a.quads + (size_t)blk * kQuadWords;
+    const uint32_t q = x >> 1, right = x & 1u;
+    const int a_l1 = ((lane - 1) & 63) << 2, a_l2 = ((lane - 2) & 63) << 2;
+    const int a_r1 = ((lane + 1) & 63) << 2, a_r2 = ((lane + 2) & 63) << 2;
+    uint32_t Eprev = 0;                                   // exponent of this column's bottom sample, row above
+    uint32_t bitpos = 0;
+    uint32_t info = col_ok ? qi[q] : 0u;
+    for (uint32_t qy = 0; qy < QH; ++qy) {
+        const uint32_t cur = info;
+        if (qy + 1 < QH) info = col_ok ? qi[(qy + 1) * kQuadStride + q] : 0u;     // prefetch next row's quad info
+        const uint32_t rho = (cur >> 4) & 0xFu, e1 = (cur >> 8) & 0xFu, ek = (cur >> 12) & 0xFu;
+        uint32_t U = cur >> 16;
+        // kappa: max exponent over columns 2q-1 .. 2q+2 of the row above, when more than one sample is significant
+        {
+            const uint32_t El1 = bperm(a_l1, Eprev), El2 = bperm(a_l2, Eprev);
+            const uint32_t Er1 = bperm(a_r1, Eprev), Er2 = bperm(a_r2, Eprev);
+            // left lane (x = 2q):  2q-1 = x-1, 2q+1 = x+1, 2q+2 = x+2 ; right lane (x = 2q+1): 2q-1 = x-2, 2q = x-1, 2q+2 = x+1
+            uint32_t far_l = right ? El2 : El1;           // column 2q-1
+            uint32_t far_r = right ? Er1 : Er2;           // column 2q+2
+            const uint32_t mate = right ? El1 : Er1;      // the other column of this quad
+            if (x < (right ? 2u : 1u)) far_l = 0;         // outside the block
+            if (x + (right ? 1u : 2u) > 63u) far_r = 0;
+            const uint32_t E = max(max(Eprev, mate), max(far_l, far_r));
+            if (qy > 0 && (rho & (rho - 1))) U += E > 2 ? E - 2 : 0;
+        }
+        // this lane's two samples: i = 2*right (top) and 2*right + 1 (bottom)
+        const uint32_t it = 2 * right, ib = it + 1;
+        const uint32_t st = (rho >> it) & 1u, sb = (rho >> ib) & 1u;
+        const uint32_t mt = st ? U - ((ek >> it) & 1u) : 0u;
+        const uint32_t mb = sb ? U - ((ek >> ib) & 1u) : 0u;
+        const uint32_t incl = wave_incl_scan(mt + mb);
+        const uint32_t pos = bitpos + incl - (mt + mb);
+        bitpos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        // up to 62 bits from the raw stream
+        const uint32_t wi = pos >> 5, sh = pos & 31;
+        const uint64_t lo = raw[wi] | ((uint64_t)raw[wi + 1] << 32);
+        const uint32_t hi = raw[wi + 2];
+        const uint64_t win = (lo >> sh) | (sh ? ((uint64_t)hi << (64 - sh)) : 0ull);
+        const uint32_t bt = (uint32_t)win & ((1u << mt) - 1u);
+        const uint32_t bb = (uint32_t)(win >> mt) & ((1u << mb) - 1u);
+        const uint32_t vt = bt | (((e1 >> it) & 1u) << mt) | 1u;
+        const uint32_t vb = bb | (((e1 >> ib) & 1u) << mb) | 1u;
+        const uint32_t wt = st ? ((bt << 31) | ((vt + 2u) << (p - 1u))) : 0u;
+        const uint32_t wb = sb ? ((bb << 31) | ((vb + 2u) << (p - 1u))) : 0u;
+        Eprev = sb ? 32u - (uint32_t)__clz((int)vb) : 0u;
+        // dequantise and store (PostDecompressFilters.h: ShiftHTFilter shift = 31 - (k_msbs + 1) = p)
+        int32_t ot, ob;
+        if constexpr (IRREV) {
+            const float ft = (float)(int32_t)(wt & 0x7FFFFFFFu) * bd.inv_step;       // inv_step holds the decode scale here
+            const float fb = (float)(int32_t)(wb & 0x7FFFFFFFu) * bd.inv_step;
+            ot = __float_as_int((wt & 0x80000000u) ? -ft : ft);
+            ob = __float_as_int((wb & 0x80000000u) ? -fb : fb);
+        } else {
+            const int32_t mgt = (int32_t)((wt & 0x7FFFFFFFu) >> p), mgb = (int32_t)((wb & 0x7FFFFFFFu) >> p);
+            ot = (wt & 0x80000000u) ? -mgt : mgt;
+            ob = (wb & 0x80000000u) ? -mgb : mgb;
+        }
+        if (col_ok) {
+            const uint32_t y0 = 2 * qy;
+            dst[(size_t)y0 * a.stride + x] = ot;
+            if (y0 + 1 < h) dst[(size_t)(y0 + 1) * a.stride + x] = ob;
+        }
+    }
+}
+
+} // namespace
+
+static bool g_dec_tables_ready[16] = {false};
+
+hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 16 && !g_dec_tables_ready[dev]) {
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_dec), HT_VLC_DEC0, sizeof(HT_VLC_DEC0), 0, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_dec), HT_VLC_DEC1, sizeof(HT_VLC_DEC1), sizeof(HT_VLC_DEC0), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        g_dec_tables_ready[dev] = true;
+    }
+    // K5a: few lanes per wave when blocks are few, so that >= ~4 waves per SIMD overlap their latencies
+    uint32_t lanes = 64;
+    while (lanes > 8 && (a.nblocks + lanes - 1) / lanes < 4096) lanes >>= 1;
+    hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nblocks + lanes - 1) / lanes), dim3(lanes), 0, s, a);
+    const uint32_t raw_words = (max_ms_bytes * 8u) / 32u + 8u;
+    if (a.irreversible)
+        hipLaunchKernelGGL(ht_dec_ms_kernel<true>, dim3(a.nblocks), dim3(64), raw_words * 4, s, a, raw_words);
+    else
+        hipLaunchKernelGGL(ht_dec_ms_kernel<false>, dim3(a.nblocks), dim3(64), raw_words * 4, s, a, raw_words);
+    return hipGetLastError();
+}
+
+} // namespace grk_amd

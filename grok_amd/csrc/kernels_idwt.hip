@@ -1,0 +1,285 @@
+// grok_amd/csrc/kernels_idwt.hip -- K6: one inverse DWT level (5/3 int32 or 9/7 fp32) and K7: egress
+// (inverse RCT/ICT + DC level shift + clamp + narrowing store), gfx950.
+//
+// K6 replaces one resolution step of decompress_tile_53 / decompress_tile_97
+// (transform/WaveletReverse.cpp:852-936, :1360-1439), which synthesises all rows horizontally
+// (LL|HL and LH|HH), then all columns vertically, through split windows in memory.  Here both
+// passes are fused, mirroring K2:
+//  * a workgroup (256 threads) owns 504 output columns (252 coefficient pairs + 2 halo pairs each
+//    side) and a segment of `seg_pairs` output row pairs and streams down the rows;
+//  * per row pair it loads one LL, HL, LH and HH row segment (one coefficient per lane and band),
+//    exchanges them through a double-buffered LDS line, and every lane synthesises two adjacent
+//    output columns of the low row and of the high row with the local inverse lifting stencil;
+//  * vertical synthesis runs in registers as a recurrence per column (state 2 values for 5/3,
+//    4 for 9/7) and the finished rows are stored 8 bytes per lane (512 B per wave and row).
+// Every coefficient is read once and every sample written once: 8 bytes/sample/level.
+//
+// Borders: whole-sample symmetric extension by mirroring the interleaved index (lifting preserves
+// the symmetry, so the extended synthesis equals the reference's edge formulas, :104-184, :990-1060).
+// 9/7: low*K, high*(2/K) first, then the four lifting sweeps with coefficients -delta, -gamma,
+// -beta, -alpha, each `x + ((l + r) * c)` separately rounded (:1068-1073, :1005-1008).
+#include "kernels.h"
+#include <type_traits>
+
+namespace grk_amd {
+
+namespace {
+
+constexpr int kThreads   = 256;
+constexpr int kHaloPairs = 2;
+constexpr int kOutPairs  = kThreads - 2 * kHaloPairs;     // 252 pairs = 504 columns
+
+__device__ __forceinline__ uint32_t mirror_idx(int32_t i, uint32_t n)
+{
+    if (n == 1) return 0;
+    const int32_t p = 2 * ((int32_t)n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    return (uint32_t)(i < (int32_t)n ? i : p - i);
+}
+
+constexpr float kK        = 1.230174105f;
+constexpr float kTwoInvK  = 1.625732422f;
+constexpr float kIDelta   = -0.443506852f;
+constexpr float kIGamma   = -0.882911075f;
+constexpr float kIBeta    = 0.052980118f;
+constexpr float kIAlpha   = 1.586134342f;
+
+__device__ __forceinline__ float lift(float x, float l, float r, float c)
+{
+    return __fadd_rn(x, __fmul_rn(__fadd_rn(l, r), c));
+}
+
+// ---- horizontal synthesis of one row: s = low half (LL or LH), d = high half (HL or HH) in LDS,
+//      lane produces the samples at columns 2j and 2j+1 (j = its local pair index) -----------------
+__device__ __forceinline__ void hs53(const int32_t* s, const int32_t* d, int32_t& xe, int32_t& xo)
+{
+    const int32_t dm = d[-1], d0 = d[0], dp = d[1];
+    xe = s[0] - ((dm + d0 + 2) >> 2);
+    const int32_t xe2 = s[1] - ((d0 + dp + 2) >> 2);
+    xo = d0 + ((xe + xe2) >> 1);
+}
+__device__ __forceinline__ void hs97(const float* s, const float* d, float& xe, float& xo)
+{
+    float sk[4], dk[5], e1[4], o1[3], e2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sk[i] = __fmul_rn(s[i - 1], kK);             // pairs j-1 .. j+2
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dk[i] = __fmul_rn(d[i - 2], kTwoInvK);       // pairs j-2 .. j+2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e1[i] = lift(sk[i], dk[i], dk[i + 1], kIDelta);      // evens j-1 .. j+2
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o1[i] = lift(dk[i + 1], e1[i], e1[i + 1], kIGamma);  // odds  j-1 .. j+1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) e2[i] = lift(e1[i + 1], o1[i], o1[i + 1], kIBeta);   // evens j, j+1
+    xe = e2[0];
+    xo = lift(o1[1], e2[0], e2[1], kIAlpha);
+}
+
+// ---- per-column vertical synthesis recurrences; step i consumes (s_i, d_i) ---------------------------
+struct IV53 {       // yields rows 2i-1 and 2i
+    int32_t dprev, xprev;
+    __device__ __forceinline__ void init() { dprev = 0; xprev = 0; }
+    __device__ __forceinline__ void step(int32_t s, int32_t d, int32_t& r_odd, int32_t& r_even)
+    {
+        r_even = s - ((dprev + d + 2) >> 2);
+        r_odd = dprev + ((xprev + r_even) >> 1);
+        dprev = d; xprev = r_even;
+    }
+};
+struct IV97 {       // yields rows 2(i-1) and 2(i-2)+1
+    float dk1, e1p, o1p, e2p;       // dK[i-1], e1[i-1], o1[i-2], e2[i-2]
+    __device__ __forceinline__ void init() { dk1 = e1p = o1p = e2p = 0.f; }
+    __device__ __forceinline__ void step(float s, float d, float& r_odd, float& r_even)
+    {
+        const float dk = __fmul_rn(d, kTwoInvK);
+        const float e1 = lift(__fmul_rn(s, kK), dk1, dk, kIDelta);     // e1[i]
+        const float o1 = lift(dk1, e1p, e1, kIGamma);                  // o1[i-1]
+        const float e2 = lift(e1p, o1p, o1, kIBeta);                   // e2[i-1]
+        r_odd = lift(o1p, e2p, e2, kIAlpha);                           // row 2(i-2)+1
+        r_even = e2;                                                   // row 2(i-1)
+        dk1 = dk; e1p = e1; o1p = o1; e2p = e2;
+    }
+};
+
+template <bool F97>
+__global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
+{
+    using T  = typename std::conditional<F97, float, int32_t>::type;
+    using T2 = typename std::conditional<F97, float2, int2>::type;
+    // [parity][row: low/high][half: s/d][local pair index]
+    __shared__ __attribute__((aligned(16))) T line[2][2][2][kThreads];
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t cw = a.cw, ch = a.ch;
+    const uint32_t sw = (cw + 1) >> 1, sh = (ch + 1) >> 1;
+
+    const T* ll = reinterpret_cast<const T*>(a.ll) + (size_t)blockIdx.z * a.ll_pitch;
+    const T* mp = reinterpret_cast<const T*>(a.mallat) + (size_t)blockIdx.z * a.m_pitch;
+    T* out = reinterpret_cast<T*>(a.out) + (size_t)blockIdx.z * a.out_pitch;
+
+    // the pair this lane loads and (if not a halo lane) synthesises
+    const int32_t J = (int32_t)(blockIdx.x * kOutPairs) - kHaloPairs + (int32_t)t;
+    // horizontal mirror in the interleaved domain: low sample 2J, high sample 2J+1
+    const uint32_t js = mirror_idx(2 * J, cw) >> 1;
+    const uint32_t jd = cw > 1 ? (mirror_idx(2 * J + 1, cw) - 1) >> 1 : 0;
+    const bool h_lane = (t >= (uint32_t)kHaloPairs) && (t < (uint32_t)(kThreads - kHaloPairs)) && J >= 0;
+    const bool st_e = h_lane && (uint32_t)(2 * J) < cw, st_o = h_lane && (uint32_t)(2 * J + 1) < cw;
+
+    const int32_t I0 = (int32_t)(blockIdx.y * a.seg_pairs);
+    const int32_t I1 = min((int32_t)sh, I0 + (int32_t)a.seg_pairs);
+    // rows [2*I0, 2*I1) are this workgroup's; the recurrences lag behind the input by `lag` pairs
+    constexpr int lag  = F97 ? 2 : 1;       // rows 2i and 2i+1 are complete after step i + lag
+    constexpr int warm = F97 ? 2 : 1;       // steps before I0 whose outputs are discarded
+
+    struct Raw { T ls, ld, hs, hd; };
+    auto fetch = [&](int32_t i, Raw& q) {
+        // vertical mirror in the interleaved domain: low row 2i, high row 2i+1
+        const uint32_t is = mirror_idx(2 * i, ch) >> 1;
+        const uint32_t id = ch > 1 ? (mirror_idx(2 * i + 1, ch) - 1) >> 1 : 0;
+        q.ls = ll[(size_t)is * a.ll_stride + js];
+        q.ld = cw > 1 ? mp[(size_t)is * a.m_stride + sw + jd] : T(0);
+        q.hs = ch > 1 ? mp[(size_t)(sh + id) * a.m_stride + js] : T(0);
+        q.hd = (ch > 1 && cw > 1) ? mp[(size_t)(sh + id) * a.m_stride + sw + jd] : T(0);
+    };
+
+    typename std::conditional<F97, IV97, IV53>::type colA, colB;
+    colA.init(); colB.init();
+    Raw cur, nxt;
+    int32_t i = I0 - warm;
+    fetch(i, cur);
+    const int32_t i_end = I1 - 1 + lag;
+    for (int par = 0; i <= i_end; ++i, par ^= 1) {
+        if (i < i_end) fetch(i + 1, nxt);
+        line[par][0][0][t] = cur.ls; line[par][0][1][t] = cur.ld;
+        line[par][1][0][t] = cur.hs; line[par][1][1][t] = cur.hd;
+        __syncthreads();
+        if (h_lane) {
+            T se, so, de, dodd;                           // low row / high row, even / odd column
+            if (cw == 1) { se = line[par][0][0][t]; so = 0; de = line[par][1][0][t]; dodd = 0; }
+            else if constexpr (F97) {
+                hs97(&line[par][0][0][t], &line[par][0][1][t], se, so);
+                hs97(&line[par][1][0][t], &line[par][1][1][t], de, dodd);
+            } else {
+                hs53(&line[par][0][0][t], &line[par][0][1][t], se, so);
+                hs53(&line[par][1][0][t], &line[par][1][1][t], de, dodd);
+            }
+            T oA, eA, oB, eB;                             // finished rows (odd, even) of columns 2J and 2J+1
+            if (ch == 1) { eA = se; eB = so; oA = oB = 0; }
+            else { colA.step(se, de, oA, eA); colB.step(so, dodd, oB, eB); }
+            // which output rows these are
+            const int32_t r_even = ch == 1 ? 0 : 2 * (i - (lag - 1));
+            const int32_t r_odd = r_even - 1;              // 5/3: 2i-1 ; 9/7: 2(i-2)+1
+            const bool ok_e = ch == 1 ? (i == 0) : (r_even >= 2 * I0 && r_even < 2 * I1 && (uint32_t)r_even < ch);
+            const bool ok_o = ch > 1 && r_odd >= 2 * I0 && r_odd < 2 * I1 && (uint32_t)r_odd < ch;
+            if (ok_e) {
+                T* row = out + (size_t)r_even * a.out_stride + 2 * J;
+                if (st_o) { T2 v; v.x = eA; v.y = eB; *reinterpret_cast<T2*>(row) = v; }
+                else if (st_e) row[0] = eA;
+            }
+            if (ok_o) {
+                T* row = out + (size_t)r_odd * a.out_stride + 2 * J;
+                if (st_o) { T2 v; v.x = oA; v.y = oB; *reinterpret_cast<T2*>(row) = v; }
+                else if (st_e) row[0] = oA;
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// ---- K7 egress -----------------------------------------------------------------------------------
+// float -> int32 as the reference's bulk path (_mm256_cvtps_epi32, mct.cpp:248-250): round to nearest
+// even, out of range / NaN -> 0x80000000 (v_cvt would saturate instead)
+__device__ __forceinline__ int32_t cvt_rn(float f)
+{
+    return fabsf(f) < 2147483648.0f ? __float2int_rn(f) : (int32_t)0x80000000;
+}
+template <typename PIX, int NC>
+__global__ __launch_bounds__(256) void egress_kernel(EgressArgs a)
+{
+    const uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    const uint32_t y = blockIdx.y;
+    const uint32_t tile = blockIdx.z;
+    if (x >= a.w) return;
+    const uint32_t n = a.w - x < 4 ? a.w - x : 4;
+    const size_t comp_px = (size_t)a.w * a.h;
+    const int32_t* src = a.planes + (size_t)tile * a.ncomp * a.pitch + (size_t)y * a.stride + x;
+    PIX* dst = reinterpret_cast<PIX*>(a.pixels) + (size_t)tile * a.ncomp * comp_px + (size_t)y * a.w + x;
+    const bool irrev = a.irreversible != 0;
+
+    int32_t c[NC][4];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int4 v = *reinterpret_cast<const int4*>(src + (size_t)k * a.pitch);     // stride % 32 == 0: in-row padding is readable
+        c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
+    }
+    constexpr int K1 = NC >= 3 ? 1 : 0, K2 = NC >= 3 ? 2 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (NC >= 3 && a.mct) {
+            if (!irrev) {                                   // inverse RCT (mct.cpp:454-464)
+                const int32_t yy = c[0][i], u = c[K1][i], v = c[K2][i];
+                const int32_t g = yy - ((u + v) >> 2);
+                c[0][i] = v + g; c[K1][i] = g; c[K2][i] = u + g;
+            } else {                                        // inverse ICT (mct.cpp:278-289), round to nearest even
+                const float yy = __int_as_float(c[0][i]), u = __int_as_float(c[K1][i]), v = __int_as_float(c[K2][i]);
+                const float r = __fadd_rn(yy, __fmul_rn(v, 1.402f));
+                const float g = __fsub_rn(__fsub_rn(yy, __fmul_rn(u, 0.34413f)), __fmul_rn(v, 0.71414f));
+                const float b = __fadd_rn(yy, __fmul_rn(u, 1.772f));
+                c[0][i] = cvt_rn(r); c[K1][i] = cvt_rn(g); c[K2][i] = cvt_rn(b);
+            }
+#pragma unroll
+            for (int k = 3; k < NC; ++k) if (irrev) c[k][i] = cvt_rn(__int_as_float(c[k][i]));
+        } else if (irrev) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) c[k][i] = cvt_rn(__int_as_float(c[k][i]));
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) c[k][i] = min(max(c[k][i] + a.dc, a.lo), a.hi);
+    }
+    const bool vec = (n == 4) && ((a.w & 3u) == 0);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        PIX* d = dst + (size_t)k * comp_px;
+        if (vec) {
+            if constexpr (sizeof(PIX) == 1) *reinterpret_cast<uchar4*>(d) = make_uchar4((uint8_t)c[k][0], (uint8_t)c[k][1], (uint8_t)c[k][2], (uint8_t)c[k][3]);
+            else if constexpr (sizeof(PIX) == 2) *reinterpret_cast<ushort4*>(d) = make_ushort4((uint16_t)c[k][0], (uint16_t)c[k][1], (uint16_t)c[k][2], (uint16_t)c[k][3]);
+            else *reinterpret_cast<int4*>(d) = make_int4(c[k][0], c[k][1], c[k][2], c[k][3]);
+        } else {
+            for (uint32_t i = 0; i < n; ++i) d[i] = (PIX)c[k][i];
+        }
+    }
+}
+
+} // namespace
+
+hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s)
+{
+    const uint32_t sw = (a.cw + 1) >> 1, sh = (a.ch + 1) >> 1;
+    dim3 grid((sw + kOutPairs - 1) / kOutPairs, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
+    dim3 block(kThreads);
+    if (a.irreversible)
+        hipLaunchKernelGGL(idwt_level_kernel<true>, grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL(idwt_level_kernel<false>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_egress(const EgressArgs& a, hipStream_t s)
+{
+    dim3 grid((a.w + 1023) / 1024, a.h, a.ntiles), block(256);
+#define GRK_EGRESS(PIX)                                                                          \
+    switch (a.ncomp) {                                                                          \
+    case 1: hipLaunchKernelGGL((egress_kernel<PIX, 1>), grid, block, 0, s, a); break;           \
+    case 2: hipLaunchKernelGGL((egress_kernel<PIX, 2>), grid, block, 0, s, a); break;           \
+    case 3: hipLaunchKernelGGL((egress_kernel<PIX, 3>), grid, block, 0, s, a); break;           \
+    default: hipLaunchKernelGGL((egress_kernel<PIX, 4>), grid, block, 0, s, a); break;          \
+    }
+    if (a.bytes_per_sample == 1) { GRK_EGRESS(uint8_t) }
+    else if (a.bytes_per_sample == 2) { GRK_EGRESS(uint16_t) }
+    else { GRK_EGRESS(int32_t) }
+#undef GRK_EGRESS
+    return hipGetLastError();
+}
+
+} // namespace grk_amd

@@ -77,7 +77,8 @@ typedef struct grk_amd_block {
 typedef struct grk_amd_coded_block {
     uint64_t offset;
     uint32_t length;             /* MagSgn | MEL | VLC bytes of the single HT cleanup pass      */
-    uint32_t reserved;
+    uint32_t missing_msbs;       /* band numbps - block numbps: what the decoder needs besides the
+                                    bytes (Kmax - 1 for blocks of this encoder, T1HT.cpp:123)    */
 } grk_amd_coded_block;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
@@ -133,10 +134,39 @@ int grk_amd_stage_dwt_fwd(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32
 int grk_amd_stage_ht_encode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
                             const void* d_mallat);
 
+/* ---- decode: the inverse hot path --------------------------------
+ * TileProcessor::decompress T1 + post-T1 for HT blocks: T1HT::decompress (t1/t1_ht/T1HT.cpp:129-179,
+ * ojph_decode_codeblock t1/t1_ht/coding/ojph_block_decoder.cpp:989), dequantisation
+ * (filters/PostDecompressFilters.h:94-140), inverse DWT (transform/WaveletReverse.cpp:852-936,
+ * :1360-1439), inverse MCT + DC shift + clamp (point_transform/mct.cpp:109-465).
+ * `table` (host) has one row per code-block in the encoder's enumeration order with the block's
+ * byte range inside `coded` and its missing_msbs -- exactly what the host's Tier-2 parser knows
+ * after decompress_synch_plugin_with_host (plugin/plugin_bridge.cpp:63-76); length 0 = no data.
+ * `pixels` receives the tiles back to back, component-major planar, tight, ceil(prec/8) bytes per
+ * sample.  With pixels_on_device != 0 the call is asynchronous: query grk_amd_decode_status().
+ * Returns GRK_AMD_ERR_INVALID for a block the reference decoder would reject. */
+int grk_amd_decode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
+                         const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes,
+                         int coded_on_device, void* pixels, int pixels_on_device);
+int grk_amd_decode_status(grk_amd_ctx* ctx);
+/* HT cleanup decode + dequantisation of every block into Mallat planes (device pointers) */
+int grk_amd_stage_ht_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
+                            const grk_amd_coded_block* table, const void* d_coded, void* d_mallat);
+
+/* ---- decode-side stages ------------------------------------------
+ * inverse DWT of num_planes Mallat planes -> image-domain planes
+ *   (transform/WaveletReverse.cpp:852-936 decompress_tile_53, :1360-1439 decompress_tile_97) */
+int grk_amd_stage_dwt_inv(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_planes,
+                          const void* d_mallat, void* d_out);
+/* inverse RCT/ICT + DC level shift + clamp, planes -> tightly packed pixels (ceil(prec/8) bytes)
+ *   (point_transform/mct.cpp:109-177, :186-294, :297-364, :369-465) */
+int grk_amd_stage_egress(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
+                         const void* d_planes, void* d_pixels);
+
 /* average duration (ms) of the named kernel family over the launches since the last reset,
  * measured with HIP events on the context's stream when timing is enabled.
  * which: 0 ingest+mct, 1 dwt (all levels), 2 ht encode kernel, 3 whole encode_tiles call,
- *        4 offset scan + compaction */
+ *        4 (unused), 5 ht decode, 6 inverse dwt (all levels), 7 egress */
 int    grk_amd_enable_timing(grk_amd_ctx* ctx, int on);
 double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
 

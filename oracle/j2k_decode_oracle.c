@@ -273,6 +273,13 @@ void orc_dwt97_inv(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32
 
 /* ---- a17: inverse colour transforms + DC shift + clamp ------------------------------------------- */
 static int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* float -> int32 as the reference's bulk path does it (_mm256_cvtps_epi32, mct.cpp:248-250): round to
+ * nearest even; out of range or NaN gives the "integer indefinite" value 0x80000000 */
+static int32_t cvt_rn(float f)
+{
+    if (!(fabsf(f) < 2147483648.0f)) return INT32_MIN;
+    return (int32_t)lrintf(f);
+}
 void orc_rct_inv_store(int32_t* c0, int32_t* c1, int32_t* c2, size_t n, int32_t shift, int32_t lo, int32_t hi)
 {   /* mct.cpp:369-465 */
     for (size_t i = 0; i < n; ++i) {
@@ -289,9 +296,9 @@ void orc_ict_inv_store(int32_t* c0, int32_t* c1, int32_t* c2, size_t n, int32_t 
         const float r = y + (v * 1.402f);
         const float g = y - (u * 0.34413f) - (v * 0.71414f);
         const float b = y + (u * 1.772f);
-        c0[i] = clampi((int32_t)lrintf(r) + shift, lo, hi);
-        c1[i] = clampi((int32_t)lrintf(g) + shift, lo, hi);
-        c2[i] = clampi((int32_t)lrintf(b) + shift, lo, hi);
+        c0[i] = clampi(cvt_rn(r) + shift, lo, hi);
+        c1[i] = clampi(cvt_rn(g) + shift, lo, hi);
+        c2[i] = clampi(cvt_rn(b) + shift, lo, hi);
     }
 }
 void orc_dc_store_rev(int32_t* c, size_t n, int32_t shift, int32_t lo, int32_t hi)
@@ -302,6 +309,6 @@ void orc_dc_store_irrev(int32_t* c, size_t n, int32_t shift, int32_t lo, int32_t
 {   /* mct.cpp:109-177 */
     for (size_t i = 0; i < n; ++i) {
         float f; memcpy(&f, &c[i], 4);
-        c[i] = clampi((int32_t)lrintf(f) + shift, lo, hi);
+        c[i] = clampi(cvt_rn(f) + shift, lo, hi);
     }
 }

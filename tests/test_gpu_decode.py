@@ -1,0 +1,205 @@
+"""-m gpu: the decode-side HIP kernels against the CPU oracle, through the C-ABI, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import grok_amd as G
+import oracle as O
+import chain
+import synth
+import gpuutil as U
+
+pytestmark = pytest.mark.gpu
+
+IDWT_CASES = [(8, 8, 1), (64, 64, 3), (65, 33, 3), (100, 77, 5), (17, 1, 2), (1, 9, 2), (3, 3, 1), (2, 2, 1),
+              (255, 257, 5), (512, 512, 5), (1024, 1024, 5), (1500, 700, 4), (4, 600, 3), (1009, 64, 2)]
+
+
+@pytest.mark.parametrize("W,H,L", IDWT_CASES)
+def test_idwt53(W, H, L):
+    rng = np.random.default_rng(W * 13 + H)
+    a = rng.integers(-3000, 3000, size=(2, H, W)).astype(np.int32)         # arbitrary Mallat content
+    p = G.TileParams.make(W, H, 1, 8, L, mct=False)
+    d_in = U.upload_planes(a, p)
+    d_out = U.dev_planes(p, 2)
+    U.ctx().stage_dwt_inv(p, 2, d_in.data_ptr(), d_out.data_ptr())
+    U.ctx().synchronize()
+    got = U.planes_to_numpy(d_out, p, 2)
+    for k in range(2):
+        assert np.array_equal(got[k], O.dwt53_inv(a[k], L)), "plane %d" % k
+
+
+@pytest.mark.parametrize("W,H,L", IDWT_CASES)
+def test_idwt97_bit_exact(W, H, L):
+    rng = np.random.default_rng(W * 17 + H)
+    a = (rng.standard_normal((2, H, W)) * 200).astype(np.float32)
+    p = G.TileParams.make(W, H, 1, 8, L, irreversible=True, mct=False)
+    d_in = U.upload_planes(a.view(np.int32), p)
+    d_out = U.dev_planes(p, 2)
+    U.ctx().stage_dwt_inv(p, 2, d_in.data_ptr(), d_out.data_ptr())
+    U.ctx().synchronize()
+    got = U.planes_to_numpy(d_out, p, 2)
+    for k in range(2):
+        want = O.dwt97_inv(a[k], L).view(np.int32)
+        assert np.array_equal(got[k], want), "plane %d: max int diff %d" % (
+            k, np.abs(got[k].astype(np.int64) - want).max())
+
+
+def test_fwd_then_inv_53_is_identity_8k():
+    """Full-size property (one 8192^2 plane): the GPU inverse undoes the GPU forward transform."""
+    rng = np.random.default_rng(5)
+    W = H = 8192
+    a = rng.integers(-128, 128, size=(1, H, W)).astype(np.int32)
+    p = G.TileParams.make(W, H, 1, 8, 5, mct=False)
+    d_in = U.upload_planes(a, p)
+    d_m = U.dev_planes(p, 1)
+    d_out = U.dev_planes(p, 1)
+    U.ctx().stage_dwt_fwd(p, 1, d_in.data_ptr(), d_m.data_ptr())
+    U.ctx().stage_dwt_inv(p, 1, d_m.data_ptr(), d_out.data_ptr())
+    U.ctx().synchronize()
+    assert np.array_equal(U.planes_to_numpy(d_out, p, 1)[0], a[0])
+
+
+@pytest.mark.parametrize("C,H,W,prec,irrev", [(3, 64, 64, 8, 0), (3, 33, 70, 8, 0), (1, 17, 5, 8, 0), (3, 128, 256, 16, 0),
+                                              (3, 64, 64, 8, 1), (3, 50, 101, 12, 1), (1, 64, 64, 8, 1), (4, 32, 36, 8, 0),
+                                              (4, 32, 36, 10, 1)])
+def test_egress(C, H, W, prec, irrev):
+    rng = np.random.default_rng(C * 100 + W + prec)
+    span = 1 << prec
+    if irrev:
+        planes = (rng.standard_normal((2, C, H, W)) * span / 3).astype(np.float32)
+        planes[0, :, 0, :8] = np.array([0.5, 1.5, 2.5, -0.5, -1.5, 1e9, -1e9, 0.49999997], np.float32)[:min(8, W)] \
+            if W >= 8 else planes[0, :, 0, :8]
+        raw = planes.view(np.int32)
+    else:
+        raw = rng.integers(-span, span, size=(2, C, H, W)).astype(np.int32)
+    p = G.TileParams.make(W, H, C, prec, 0, irreversible=bool(irrev))
+    d_pl = U.upload_planes(raw.reshape(2 * C, H, W), p)
+    bps = (prec + 7) // 8
+    d_px = torch.zeros(2 * C * H * W * bps, dtype=torch.uint8, device="cuda")
+    U.ctx().stage_egress(p, 2, d_pl.data_ptr(), d_px.data_ptr())
+    U.ctx().synchronize()
+    got = d_px.cpu().numpy().view(np.uint8 if bps == 1 else np.uint16).reshape(2, C, H, W)
+    for t in range(2):
+        want = np.stack(O.color_inv_store([raw[t, k] for k in range(C)], prec, bool(irrev), C >= 3))
+        assert np.array_equal(got[t].astype(np.int32), want)
+
+
+# ---- K5: HT cleanup decoder + dequantisation ------------------------------------------------------
+def _ht_dec_case(W, H, L, C, prec, mode, seed, irrev=False):
+    """Random in-range Mallat planes -> oracle block encoder -> HIP decoder == the planes (rev) /
+    == oracle decode (irrev)."""
+    rng = np.random.default_rng(seed)
+    p = G.TileParams.make(W, H, C, prec, L, irreversible=irrev)
+    blocks, qcd = G.tile_layout(p)
+    planes = np.zeros((C, H, W), np.int32)
+    table = np.zeros(len(blocks), G.capi.CODED_DTYPE)
+    chunks, off = [], 0
+    for i, b in enumerate(blocks):
+        bw, bh = b.x1 - b.x0, b.y1 - b.y0
+        kb = b.kmax - 2                                   # decodable range (defect D5)
+        mag = rng.integers(0, (1 << kb) + 1, size=(bh, bw))
+        if mode == 1:
+            mag = mag >> rng.integers(0, kb + 1, size=(bh, bw))
+        elif mode == 2:
+            mag = np.where(rng.random((bh, bw)) < 0.93, 0, mag & 7)
+        elif mode == 3:
+            mag = np.zeros((bh, bw), np.int64)
+        elif mode == 4:
+            mag = np.full((bh, bw), 1 << kb)
+        sign = np.where(rng.random((bh, bw)) < 0.5, -1, 1)
+        coef = (mag * sign).astype(np.int32)
+        planes[b.comp, b.py:b.py + bh, b.px:b.px + bw] = coef
+        cb = O.ht_encode_sm(O.signmag(coef, b.kmax), b.kmax)
+        if mode == 3 and i % 3 == 0:
+            cb = b""                                      # block without data
+        table["offset"][i] = off; table["length"][i] = len(cb); table["missing_msbs"][i] = b.kmax - 1
+        chunks.append(cb + b"\0" * (-len(cb) % 16)); off += len(chunks[-1])
+    coded = b"".join(chunks) or b"\0" * 16
+    d_c = U.to_dev(np.frombuffer(coded, np.uint8))
+    d_m = U.dev_planes(p, C)
+    U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_m.data_ptr())
+    U.ctx().synchronize()
+    got = U.planes_to_numpy(d_m, p, C)
+    if not irrev:
+        assert np.array_equal(got, planes)
+    else:
+        for i, b in enumerate(blocks):
+            bw, bh = b.x1 - b.x0, b.y1 - b.y0
+            sm = O.ht_decode_block(chunks[i][:int(table["length"][i])], b.kmax - 1, bw, bh) if table["length"][i] else np.zeros((bh, bw), np.uint32)
+            want = O.ht_dequant_irrev(sm, chain.band_scale_dec(prec, qcd[chain.band_index(b)], b.kmax))
+            assert np.array_equal(got[b.comp, b.py:b.py + bh, b.px:b.px + bw], want.view(np.int32)), "block %d" % i
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_ht_decode_blocks_512(mode):
+    _ht_dec_case(512, 512, 3, 1, 8, mode, 300 + mode)
+
+
+@pytest.mark.parametrize("W,H,L,C,prec", [(200, 120, 2, 3, 8), (130, 67, 5, 1, 12), (1024, 1024, 5, 3, 8),
+                                           (64, 64, 0, 1, 16), (37, 3, 1, 1, 8), (1, 1, 0, 1, 8)])
+def test_ht_decode_blocks_ragged(W, H, L, C, prec):
+    _ht_dec_case(W, H, L, C, prec, 1, W + H)
+
+
+def test_ht_decode_irreversible_scale():
+    _ht_dec_case(256, 192, 3, 3, 10, 1, 77, irrev=True)
+
+
+def test_ht_decode_rejects_corrupt_block():
+    p = G.TileParams.make(64, 64, 1, 8, 0)
+    blocks, _ = G.tile_layout(p)
+    cb = bytearray(O.ht_encode_sm(O.signmag(np.ones((64, 64), np.int32), blocks[0].kmax), blocks[0].kmax))
+    cb[-1] = 0xFF; cb[-2] |= 0x0F
+    table = np.zeros(1, G.capi.CODED_DTYPE)
+    table["length"][0] = len(cb); table["missing_msbs"][0] = blocks[0].kmax - 1
+    d_c = U.to_dev(np.frombuffer(bytes(cb) + b"\0" * 16, np.uint8))
+    d_m = U.dev_planes(p, 1)
+    with pytest.raises(RuntimeError):
+        U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_m.data_ptr())
+
+
+# ---- whole decode path ------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,H,W,prec,L,gen", [(1, 512, 512, 8, 3, "g2"), (3, 256, 384, 8, 5, "g2"), (3, 128, 128, 16, 4, "g2"),
+                                               (3, 100, 77, 8, 3, "g2"), (1, 64, 64, 12, 0, "g2"), (3, 1024, 1024, 8, 5, "g2")])
+def test_lossless_round_trip(C, H, W, prec, L, gen):
+    """GPU encode -> GPU decode == source pixels (RCT + 5/3 + HT, both directions on the device)."""
+    px = getattr(synth, gen)(C, H, W, prec)
+    p = G.TileParams.make(W, H, C, prec, L)
+    table, coded = U.ctx().encode_host(p, px)
+    back = U.ctx().decode_host(p, table, coded)
+    assert np.array_equal(back[0], px)
+
+
+@pytest.mark.parametrize("C,H,W,prec,L", [(1, 128, 128, 8, 3), (3, 96, 160, 8, 4), (3, 128, 192, 12, 5), (1, 67, 45, 8, 2)])
+def test_decode_irreversible_equals_oracle_chain(C, H, W, prec, L):
+    """ICT + 9/7 + quantiser: blocks from the oracle encoder, decoded on the GPU == the oracle decode
+    chain, which tests/test_oracle_decode.py pins to grk_decompress pixel for pixel."""
+    px = synth.g2(C, H, W, prec)
+    p, blocks, qcd, table, coded = chain.encode_tile_oracle(px, prec, L, irrev=True)
+    table["missing_msbs"] = [b.kmax - 1 for b in blocks]
+    want = chain.decode_tile_oracle(p, blocks, qcd, table, coded)
+    got = U.ctx().decode_host(p, table, coded + b"\0" * 16)
+    assert np.array_equal(got[0].astype(np.int32), want)
+
+
+def test_decode_multi_tile_batch():
+    tile = synth.g2(3, 256, 256, 8)
+    batch = np.ascontiguousarray(np.stack([tile, tile[:, ::-1].copy(), np.roll(tile, 5, axis=2)]))
+    p = G.TileParams.make(256, 256, 3, 8, 4)
+    table, coded = U.ctx().encode_host(p, batch, ntiles=3)
+    back = U.ctx().decode_host(p, table, coded, ntiles=3)
+    assert np.array_equal(back, batch)
+
+
+def test_round_trip_8k_property():
+    """BASELINE full size: 8192^2 x 3 encode -> decode on the device returns the source (lossless)."""
+    px = synth.g2(3, 8192, 8192, 8)
+    p = G.TileParams.make(8192, 8192, 3, 8, 5)
+    c = U.ctx()
+    d_px = U.to_dev(px.reshape(-1))
+    table, tot = c.encode_tiles(p, 1, d_px.data_ptr(), True)
+    d_out = torch.zeros(px.size, dtype=torch.uint8, device="cuda")
+    c.decode_device(p, 1, table, c.coded_device_ptr(), tot, d_out.data_ptr())
+    c.decode_status()
+    assert torch.equal(d_out, d_px)
