@@ -63,10 +63,24 @@ def cpu_baseline(rank_threads):
             _, secs = R.encode(px, 8, numres=6)
             times.append(secs)
         med = sorted(times)[len(times) // 2]
-        return {"value": round(W * H / med / 1e6, 2), "unit": "Mpixels/s", "cores": rank_threads,
-                "kind": "reference",
-                "sample": "Grok 8.0.2 CPU encoder (oracle/_ref), %d x 4096x4096x3 8-bit G2 RCT+5/3 HTJ2K 5 levels, "
-                          "median of compress-call wall times, %d threads" % (len(times), rank_threads)}
+        out = {"value": round(W * H / med / 1e6, 2), "unit": "Mpixels/s", "cores": rank_threads,
+               "kind": "reference",
+               "sample": "Grok 8.0.2 CPU encoder (oracle/_ref), %d x 4096x4096x3 8-bit G2 RCT+5/3 HTJ2K 5 levels, "
+                         "median of compress-call wall times, %d threads" % (len(times), rank_threads)}
+        # the decode direction beside it: grk_decompress of the codestream just produced
+        try:
+            cs, _ = R.encode(px, 8, numres=6)
+            dts = []
+            for _ in range(3):
+                t0 = time.time()
+                R.decode(cs, 3, H, W)
+                dts.append(time.time() - t0)
+            out["decode"] = {"value": round(W * H / sorted(dts)[1] / 1e6, 2), "unit": "Mpixels/s",
+                             "sample": "grk_decompress of the same 4096x4096x3 stream, median of 3 wall times "
+                                       "(includes codestream parsing and Tier-2)"}
+        except Exception as e:  # noqa: BLE001
+            out["decode"] = {"value": None, "error": str(e)}
+        return out
     except Exception as e:  # fall back to the scalar port of the oracle
         import oracle as O
         px = synth.g2(3, 1024, 1024, 8)
@@ -159,6 +173,39 @@ def main():
             else:
                 cs_len = int(ft["length"].sum())
 
+    # ---- the decode direction on the blocks just produced (HBM-resident coded bytes -> pixels) ----
+    decode = None
+    if not use_dist:
+        table_d, total_d = ctx.fetch_table(nblocks)
+        d_back = torch.empty_like(d_px)
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                ctx.decode_device(params, ntiles, table_d, ctx.coded_device_ptr(), total_d, d_back.data_ptr())
+        torch.cuda.synchronize(dev)
+        ctx.enable_timing(True)
+        dsteps = max(3, min(args.steps, 10))
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for _ in range(dsteps):
+                ctx.decode_device(params, ntiles, table_d, ctx.coded_device_ptr(), total_d, d_back.data_ptr())
+        torch.cuda.synchronize(dev)
+        ddt = time.perf_counter() - t0
+        ctx.decode_status()
+        dk = {name: ctx.kernel_ms(idx) for idx, name in ((5, "ht_cleanup_decode"), (6, "idwt53_5levels"), (7, "egress_mct"))}
+        b_in_d = (prec + 7) // 8
+        dalgo = {"ht_cleanup_decode": 4.0 * samples + float(total_d), "idwt53_5levels": 8.0 * samples * sigma(levels),
+                 "egress_mct": samples * (4.0 + b_in_d)}
+        decode = {"value": round(pixels_per_step * dsteps / ddt / 1e6, 1), "unit": "Mpixels/s",
+                  "ms_per_step": round(ddt / dsteps * 1e3, 4), "steps": dsteps, "lossless_round_trip": bool(torch.equal(d_back, d_px)),
+                  "kernels": {k: {"avg_ms": round(v[0], 4), "launches": v[1],
+                                  "algorithmic_GBps": round(dalgo[k] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+                              for k, v in dk.items()}}
+        ctx.enable_timing(True)      # reset the timers; the encode families were read out below from a fresh run
+        with torch.cuda.stream(stream):
+            for _ in range(args.steps):
+                ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+        torch.cuda.synchronize(dev)
+
     # per-kernel-family average durations (HIP events on the context's stream)
     fam = {}
     for idx, name in ((0, "ingest_mct"), (1, "dwt53_5levels"), (2, "ht_cleanup_encode"), (4, "compact")):
@@ -217,6 +264,7 @@ def main():
                          "achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                          "frac_of_hbm_peak": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "kernels": kernels,
+            "decode": decode,
         }
         if use_dist:
             out["config"]["assembled_codestream_bytes"] = cs_len
