@@ -80,7 +80,7 @@ def lib():
         L.grk_amd_stage_dwt_fwd.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_stage_ht_encode.argtypes = [vp, PP, u32, vp]
         L.grk_amd_stage_dwt_inv.argtypes = [vp, PP, u32, vp, vp]
-        L.grk_amd_stage_ht_decode.argtypes = [vp, PP, u32, vp, vp, vp]
+        L.grk_amd_stage_ht_decode.argtypes = [vp, PP, u32, vp, vp, u64, vp]
         L.grk_amd_decode_tiles.argtypes = [vp, PP, u32, vp, vp, u64, i32, vp, i32]
         L.grk_amd_decode_status.argtypes = [vp]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
@@ -204,9 +204,10 @@ class Context:
     def stage_ht_encode(self, params, ntiles, d_mallat):
         self._check(self._L.grk_amd_stage_ht_encode(self._h, C.byref(params), ntiles, d_mallat), "stage_ht_encode")
 
-    def stage_ht_decode(self, params, ntiles, table, d_coded, d_mallat):
+    def stage_ht_decode(self, params, ntiles, table, d_coded, coded_bytes, d_mallat):
         t = np.ascontiguousarray(table)
-        self._check(self._L.grk_amd_stage_ht_decode(self._h, C.byref(params), ntiles, t.ctypes.data, d_coded, d_mallat),
+        self._check(self._L.grk_amd_stage_ht_decode(self._h, C.byref(params), ntiles, t.ctypes.data, d_coded, coded_bytes,
+                                                    d_mallat),
                     "stage_ht_decode")
 
     def decode_host(self, params, table, coded, ntiles=1):

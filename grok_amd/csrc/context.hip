@@ -264,7 +264,7 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
     return GRK_AMD_OK;
 }
 
-int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* table, const void* d_coded, void* d_mallat)
+int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes, void* d_mallat)
 {
     const TileGeom& g = c->geom;
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
@@ -282,7 +282,7 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     HtDecArgs a{};
     a.table = (const HtDecBlock*)c->dec_table.p;
     a.blocks = (const HtBlockDesc*)c->dec_desc.p; a.blocks_per_tile = bpt; a.nblocks = (uint32_t)nblocks; a.ncomp = g.p.num_comps;
-    a.coded = (const uint8_t*)d_coded;
+    a.coded = (const uint8_t*)d_coded; a.coded_bytes = coded_bytes;
     a.quads = (uint32_t*)c->dec_quads.p; a.ms_len = (uint32_t*)c->dec_mslen.p; a.status = (unsigned int*)c->flag.p;
     a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.irreversible = g.p.irreversible;
@@ -474,12 +474,12 @@ int grk_amd_stage_dwt_inv(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t
 }
 
 int grk_amd_stage_ht_decode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
-                            const grk_amd_coded_block* table, const void* d_coded, void* d_mallat)
+                            const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes, void* d_mallat)
 {
     if (!c || !p || !table || !d_coded || !d_mallat || ntiles == 0) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = ensure_geom(c, p); if (rc) return rc;
-    rc = run_ht_decode(c, ntiles, table, d_coded, d_mallat); if (rc) return rc;
+    rc = run_ht_decode(c, ntiles, table, d_coded, coded_bytes, d_mallat); if (rc) return rc;
     return check_decode_status(c);
 }
 
@@ -509,7 +509,7 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
     {
         ScopedTimer t(c, 3);
-        rc = run_ht_decode(c, ntiles, table, d_coded, c->p1.p); if (rc) return rc;
+        rc = run_ht_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p); if (rc) return rc;
         rc = run_idwt(c, nplanes, c->p1.p, c->p0.p); if (rc) return rc;
         rc = run_egress(c, ntiles, c->p0.p, d_px, bps); if (rc) return rc;
     }

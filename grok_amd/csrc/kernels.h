@@ -75,7 +75,7 @@ struct HtDecArgs {
     const HtDecBlock* table;                   // [ntiles * blocks_per_tile], device
     const HtBlockDesc* blocks;                 // geometry per block of one tile; inv_step = decode scale (irreversible)
     uint32_t blocks_per_tile, nblocks, ncomp;
-    const uint8_t* coded;                      // device
+    const uint8_t* coded; uint64_t coded_bytes; // device buffer holding every block's bytes
     uint32_t* quads;                           // [nblocks][32*32] K5a -> K5b: CxtVLC entry | (u_q + 1) << 16 per quad
     uint32_t* ms_len;                          // [nblocks] MagSgn bytes (0xFFFFFFFF: block rejected)
     unsigned int* status;                      // bit 2: a block was rejected

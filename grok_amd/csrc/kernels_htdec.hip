@@ -35,12 +35,47 @@ constexpr uint32_t kQuadStride = 32;         // quads per row in the per-block q
 constexpr uint32_t kQuadWords  = 32 * 32;
 
 // ---- K5a --------------------------------------------------------------------------------------------
+// Byte cursor over the coded buffer that fetches aligned 8-byte words one word ahead of use, so the
+// serial decoder never waits for memory (a byte-at-a-time reader costs one full HBM/L2 latency per
+// byte on the critical path).  DIR = +1 walks forward (MEL), -1 backward (VLC).
+template <int DIR>
+struct ByteCursor {
+    const uint8_t* lo; const uint8_t* hi;      // readable range [lo, hi)
+    const uint8_t* wp;                         // aligned address of the current word
+    uint64_t cur, nxt; int idx;
+    __device__ __forceinline__ uint64_t load(const uint8_t* p) const
+    {
+        // an aligned word that overlaps the buffer lies in a mapped page (words do not straddle pages);
+        // its bytes outside [lo, hi) are never consumed (the readers count the bytes they may use)
+        return (p + 8 > lo && p < hi) ? *reinterpret_cast<const uint64_t*>(p) : 0ull;
+    }
+    __device__ __forceinline__ void init(const uint8_t* p, const uint8_t* lo_, const uint8_t* hi_)
+    {
+        lo = lo_; hi = hi_;
+        idx = (int)((uintptr_t)p & 7u);
+        wp = p - idx;
+        cur = load(wp);
+        nxt = load(wp + 8 * DIR);
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        const uint32_t b = (uint32_t)(cur >> (8 * idx)) & 0xFFu;
+        idx += DIR;
+        if (idx < 0 || idx > 7) {
+            cur = nxt; wp += 8 * DIR; idx = DIR > 0 ? 0 : 7;
+            nxt = load(wp + 8 * DIR);
+        }
+        return b;
+    }
+};
+
 struct RevReader {          // VLC: backward, LSB first; after a byte > 0x8F a byte whose 7 LSBs are ones carries 7 bits
-    const uint8_t* d; int pos, left; uint64_t acc; int n; uint32_t unstuff;
+    ByteCursor<-1> bc; int pos, left; uint64_t acc; int n; uint32_t unstuff;
     __device__ __forceinline__ void fill()
     {
         while (n <= 32) {
-            const uint32_t b = (left > 0 && pos >= 0) ? d[pos] : 0u;
+            const uint32_t raw = bc.next();
+            const uint32_t b = (left > 0 && pos >= 0) ? raw : 0u;
             --pos; --left;
             const uint32_t w = 8u - ((unstuff && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
             acc |= (uint64_t)b << n;
@@ -48,40 +83,48 @@ struct RevReader {          // VLC: backward, LSB first; after a byte > 0x8F a b
             unstuff = b > 0x8Fu;
         }
     }
-    __device__ __forceinline__ uint32_t peek() { fill(); return (uint32_t)acc; }
+    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)acc; }      // valid after fill(): > 32 bits
     __device__ __forceinline__ void skip(uint32_t nb) { acc >>= nb; n -= (int)nb; }
 };
 
 struct MelReader {          // MEL: forward, MSB first; byte after 0xFF carries 7 bits; last byte |= 0x0F
-    const uint8_t* d; int pos, left; uint32_t cur; int nb; uint32_t unstuff;
-    int k, zeros; bool one_pending;
-    __device__ __forceinline__ int bit()
+    ByteCursor<1> bc; int left; uint32_t unstuff;
+    uint64_t tmp; int bits;             // un-stuffed bits, next bit at the MSB
+    int k;
+    int run;                            // what is left of the current run, in the reference's coding (:196-235, :1101-1111):
+                                        // 2 * (zero events) + 1 if it ends with a one, 2 * (zero events - 1) otherwise
+    __device__ __forceinline__ void init(const uint8_t* p, int size, const uint8_t* lo, const uint8_t* hi)
     {
-        if (nb == 0) {
+        bc.init(p, lo, hi);
+        left = size; unstuff = 0; tmp = 0; bits = 0; k = 0;
+        run = get_run();
+    }
+    __device__ __forceinline__ int get_run()
+    {
+        while (bits < 6) {                                 // longest codeword: 1 + 5 bits
             uint32_t b = 0xFFu;
-            if (left > 0) { b = d[pos]; if (left == 1) b |= 0x0Fu; ++pos; }
+            if (left > 0) { b = bc.next(); if (left == 1) b |= 0x0Fu; }
             --left;
-            nb = 8 - (int)unstuff;
-            cur = b & (unstuff ? 0x7Fu : 0xFFu);
+            const int nb = 8 - (int)unstuff;
+            tmp |= (uint64_t)(b & (unstuff ? 0x7Fu : 0xFFu)) << (64 - nb - bits);
+            bits += nb;
             unstuff = b == 0xFFu;
         }
-        --nb;
-        return (int)((cur >> nb) & 1u);
+        const int e = (int)((0x5433222111000ull >> (4 * k)) & 0xF);     // MEL exponents (:196)
+        const bool one = (tmp >> 63) != 0;                 // '1': 2^e zero events; '0' + e bits: that many, then a one
+        const int r = one ? ((1 << e) - 1) << 1 : ((int)((tmp >> (63 - e)) & ((1u << e) - 1u)) << 1) + 1;
+        k = one ? (k < 12 ? k + 1 : 12) : (k > 0 ? k - 1 : 0);
+        const int used = one ? 1 : e + 1;
+        tmp <<= used; bits -= used;
+        return r;
     }
+    // one MEL event (:1101-1111): 1 if the run ends here with a one
     __device__ __forceinline__ int event()
     {
-        if (zeros == 0 && !one_pending) {
-            const int e = (int)((0x5433222111000ull >> (4 * k)) & 0xF);     // MEL exponents (:196)
-            if (bit()) { zeros = 1 << e; if (k < 12) ++k; }
-            else {
-                int r = 0;
-                for (int i = 0; i < e; ++i) r = (r << 1) | bit();
-                zeros = r; one_pending = true; if (k > 0) --k;
-            }
-        }
-        if (zeros > 0) { --zeros; return 0; }
-        one_pending = false;
-        return 1;
+        run -= 2;
+        const int ev = run == -1;
+        if (run < 0) run = get_run();
+        return ev;
     }
 };
 
@@ -96,6 +139,11 @@ __device__ __forceinline__ void uvlc_prefix(uint32_t bits, uint32_t& pl, uint32_
 
 __global__ void ht_dec_vlc_kernel(HtDecArgs a)
 {
+    // CxtVLC decode tables in LDS: one dependent lookup per quad sits on the serial chain
+    __shared__ uint16_t tbl_l[2048];
+    for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(tbl_l)[i] = reinterpret_cast<const uint32_t*>(g_vlc_dec)[i];
+    __syncthreads();
     const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
     if (blk >= a.nblocks) return;
     const HtDecBlock in = a.table[blk];
@@ -121,11 +169,14 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
     if (bad) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; return; }
     a.ms_len[blk] = (uint32_t)(lcup - scup);
 
-    MelReader mel{D, lcup - scup, scup - 1, 0u, 0, 0u, 0, 0, false};
+    const uint8_t* buf_hi = a.coded + a.coded_bytes;
+    MelReader mel;
+    mel.init(D + (lcup - scup), scup - 1, a.coded, buf_hi);
     RevReader vlc;
     {
         const uint32_t d0 = D[lcup - 2];
-        vlc.d = D; vlc.pos = lcup - 3; vlc.left = scup - 2;
+        vlc.bc.init(D + (lcup - 3), a.coded, buf_hi);
+        vlc.pos = lcup - 3; vlc.left = scup - 2;
         vlc.acc = d0 >> 4; vlc.n = 4 - (((d0 >> 4) & 7u) == 7u ? 1 : 0);
         vlc.unstuff = (d0 | 0xFu) > 0x8Fu;
     }
@@ -133,9 +184,10 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
     for (uint32_t qy = 0; qy < QH; ++qy) {
         uint64_t sn = 0;
         uint32_t chain = 0;
-        const uint16_t* tbl = g_vlc_dec + (qy == 0 ? 0 : 1024);
+        const uint16_t* tbl = tbl_l + (qy == 0 ? 0 : 1024);
         for (uint32_t q0 = 0; q0 < QW; q0 += 2) {
             uint32_t qinf[2] = {0u, 0u}, U[2] = {1u, 1u};
+            vlc.fill();                                   // > 32 bits: a quad pair consumes at most 7 + 7 + 17
 #pragma unroll
             for (uint32_t j = 0; j < 2; ++j) {
                 const uint32_t q = q0 + j;
@@ -155,30 +207,29 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
                     sn |= (uint64_t)(((rho >> 1) & 1u) | (((rho >> 3) & 1u) << 1)) << (2 * q);
                 }
             }
-            uint32_t mode = ((qinf[0] >> 3) & 1u) | (((qinf[1] >> 3) & 1u) << 1);
-            uint32_t add = 1;
-            if (qy == 0 && mode == 3 && mel.event()) { mode = 4; add = 3; }
-            if (mode) {
-                uint32_t v = vlc.peek(), used, pl, sl, base;
-                uvlc_prefix(v, pl, sl, base); v >>= pl;
-                if (mode <= 2) {
-                    used = pl + sl;
-                    U[mode - 1] = base + (v & ((1u << sl) - 1u)) + 1;
-                } else if (mode == 3 && qy == 0 && pl > 2) {        // second quad: one bit
-                    U[1] = (v & 1u) + 2; v >>= 1; used = pl + 1 + sl;
-                    U[0] = base + (v & ((1u << sl) - 1u)) + 1;
-                } else {
-                    uint32_t pl2, sl2, base2;
-                    uvlc_prefix(v, pl2, sl2, base2); v >>= pl2;
-                    used = pl + pl2 + sl + sl2;
-                    U[0] = base + (v & ((1u << sl) - 1u)) + add; v >>= sl;
-                    U[1] = base2 + (v & ((1u << sl2) - 1u)) + add;
-                }
-                vlc.skip(used);
+            // u values of the pair (:668-777), written without branches: prefix0, prefix1, suffix0, suffix1,
+            // each present only if its quad has u_off set
+            const uint32_t uo0 = (qinf[0] >> 3) & 1u, uo1 = (qinf[1] >> 3) & 1u;
+            uint32_t add = 1, onebit = 0;
+            uint32_t v = vlc.peek();
+            uint32_t pl, sl, base, pl2, sl2, base2;
+            uvlc_prefix(v, pl, sl, base);
+            pl = uo0 ? pl : 0; sl = uo0 ? sl : 0; base = uo0 ? base : 0;
+            v >>= pl;
+            if (qy == 0 && (uo0 & uo1)) {                          // first row, both: a MEL event picks the variant
+                if (mel.event()) add = 3;
+                else if (pl > 2) onebit = 1;                       // second quad is a single bit
             }
+            uvlc_prefix(v, pl2, sl2, base2);
+            pl2 = uo1 ? pl2 : 0; sl2 = uo1 ? sl2 : 0; base2 = uo1 ? base2 : 0;
+            if (onebit) { pl2 = 1; sl2 = 0; base2 = (v & 1u) + 1u; }
+            v >>= pl2;
+            U[0] = base + (v & ((1u << sl) - 1u)) + (uo0 ? add : 1u);
+            v >>= sl;
+            U[1] = base2 + (v & ((1u << sl2) - 1u)) + (uo1 ? add : 1u);
+            vlc.skip(pl + pl2 + sl + sl2);
             if (U[0] > mm || U[1] > mm) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; return; }   // :1194
-            qi[qy * kQuadStride + q0] = qinf[0] | (U[0] << 16);
-            if (q0 + 1 < QW) qi[qy * kQuadStride + q0 + 1] = qinf[1] | (U[1] << 16);
+            *reinterpret_cast<uint2*>(&qi[qy * kQuadStride + q0]) = make_uint2(qinf[0] | (U[0] << 16), qinf[1] | (U[1] << 16));
         }
         sa = sn;
     }
@@ -346,8 +397,11 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
         g_dec_tables_ready[dev] = true;
     }
     // K5a: few lanes per wave when blocks are few, so that >= ~4 waves per SIMD overlap their latencies
+    // K5a is one serial chain per lane.  A wave costs the same issue slots however many lanes are
+    // live, so few lanes per wave multiply the instruction count, while few waves per SIMD leave the
+    // chain's own latency exposed: aim for ~1.5-2 waves per SIMD (1024 SIMDs), measured optimum.
     uint32_t lanes = 64;
-    while (lanes > 8 && (a.nblocks + lanes - 1) / lanes < 4096) lanes >>= 1;
+    while (lanes > 16 && (a.nblocks + lanes - 1) / lanes < 1280) lanes >>= 1;
     hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nblocks + lanes - 1) / lanes), dim3(lanes), 0, s, a);
     const uint32_t raw_words = (max_ms_bytes * 8u) / 32u + 8u;
     if (a.irreversible)

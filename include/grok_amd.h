@@ -151,7 +151,8 @@ int grk_amd_decode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
 int grk_amd_decode_status(grk_amd_ctx* ctx);
 /* HT cleanup decode + dequantisation of every block into Mallat planes (device pointers) */
 int grk_amd_stage_ht_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
-                            const grk_amd_coded_block* table, const void* d_coded, void* d_mallat);
+                            const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes,
+                            void* d_mallat);
 
 /* ---- decode-side stages ------------------------------------------
  * inverse DWT of num_planes Mallat planes -> image-domain planes

@@ -27,7 +27,8 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    for k in ("ht_encode_kernel", "dwt_level_kernel", "ingest_kernel"):
+    for k in ("ht_encode_kernel", "idwt_level_kernel", "dwt_level_kernel", "ingest_kernel", "ht_dec_vlc_kernel",
+              "ht_dec_ms_kernel", "egress_kernel"):
         if k in name:
             return k
     return None

@@ -118,7 +118,7 @@ def _ht_dec_case(W, H, L, C, prec, mode, seed, irrev=False):
     coded = b"".join(chunks) or b"\0" * 16
     d_c = U.to_dev(np.frombuffer(coded, np.uint8))
     d_m = U.dev_planes(p, C)
-    U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_m.data_ptr())
+    U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
     U.ctx().synchronize()
     got = U.planes_to_numpy(d_m, p, C)
     if not irrev:
@@ -156,7 +156,7 @@ def test_ht_decode_rejects_corrupt_block():
     d_c = U.to_dev(np.frombuffer(bytes(cb) + b"\0" * 16, np.uint8))
     d_m = U.dev_planes(p, 1)
     with pytest.raises(RuntimeError):
-        U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_m.data_ptr())
+        U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
 
 
 # ---- whole decode path ------------------------------------------------------------------------------

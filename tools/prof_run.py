@@ -12,4 +12,12 @@ d = torch.from_numpy(px.reshape(-1)).cuda()
 for _ in range(n):
     ctx.encode_tiles(p, 1, d.data_ptr(), True, fetch=False)
 ctx.synchronize()
+if os.environ.get("PROF_DECODE", "1") == "1":
+    nb = G.lib().grk_amd_tile_num_blocks(p)
+    table, tot = ctx.fetch_table(nb)
+    back = torch.empty_like(d)
+    for _ in range(n):
+        ctx.decode_device(p, 1, table, ctx.coded_device_ptr(), tot, back.data_ptr())
+    ctx.decode_status()
+    assert torch.equal(back, d)
 print("done")
