@@ -56,6 +56,8 @@ struct grk_amd_ctx {
     bool have_geom = false;
     TileGeom geom;
     std::vector<HtBlockDesc> h_desc, h_desc_dec;
+    HtClass ht_classes[2]; uint32_t ht_num_classes = 0;     // block classes of K3 (by LDS need)
+    DevBuf ht_sel;
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
     uint32_t last_ntiles = 0;
@@ -105,6 +107,43 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
             d.inv_step = 1.0f / b.stepsize;
             c->h_desc.push_back(d);
         }
+    // K3 block classes: LDS per wave decides the occupancy (16 waves per CU need <= 10 KiB each).  If
+    // the blocks whose Kmax makes them fit are the majority, they get their own launch and the rest
+    // (the few high-Kmax blocks of the low resolutions) a second one.
+    {
+        auto extents = [&](uint32_t kmax_lo, uint32_t kmax_hi, HtClass& cl, std::vector<uint32_t>* idx) {
+            cl = HtClass{nullptr, 0, 0, 0, 0};
+            for (uint32_t i = 0; i < c->h_desc.size(); ++i) {
+                const HtBlockDesc& d = c->h_desc[i];
+                if (d.kmax < kmax_lo || d.kmax > kmax_hi) continue;
+                cl.count++;
+                cl.max_kmax = std::max<uint32_t>(cl.max_kmax, d.kmax);
+                cl.max_samples = std::max<uint32_t>(cl.max_samples, (uint32_t)d.w * d.h);
+                cl.max_quads = std::max<uint32_t>(cl.max_quads, ((d.w + 1u) / 2u) * ((d.h + 1u) / 2u));
+                if (idx) idx->push_back(i);
+            }
+        };
+        constexpr size_t kLdsFor16Waves = 10240;
+        HtClass all; extents(0, 255, all, nullptr);
+        c->ht_num_classes = 1; c->ht_classes[0] = all;
+        if (ht_lds_bytes(all.max_samples, all.max_quads, all.max_kmax) > kLdsFor16Waves) {
+            uint32_t T = all.max_kmax;                  // largest threshold whose class fits
+            HtClass lo;
+            while (T > 0) { extents(0, T, lo, nullptr); if (lo.count == 0 || ht_lds_bytes(lo.max_samples, lo.max_quads, lo.max_kmax) <= kLdsFor16Waves) break; --T; }
+            if (T > 0 && lo.count * 2 > all.count && lo.count < all.count) {
+                std::vector<uint32_t> sel_lo, sel_hi;
+                HtClass hi;
+                extents(0, T, lo, &sel_lo); extents(T + 1, 255, hi, &sel_hi);
+                std::vector<uint32_t> sel(sel_lo);
+                sel.insert(sel.end(), sel_hi.begin(), sel_hi.end());
+                HIP_TRY(c, c->ht_sel.ensure(sel.size() * 4), "alloc class index");
+                HIP_TRY(c, hipMemcpyAsync(c->ht_sel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, c->stream), "upload class index");
+                HIP_TRY(c, hipStreamSynchronize(c->stream), "sync class index");
+                lo.sel = (const uint32_t*)c->ht_sel.p; hi.sel = lo.sel + sel_lo.size();
+                c->ht_classes[0] = lo; c->ht_classes[1] = hi; c->ht_num_classes = 2;
+            }
+        }
+    }
     // decode-side descriptors: inv_step carries the dequantisation scale of the band
     // (codestream/Quantizer.cpp:41-63 with compress = false: log2_gain 0, then / 2^(31 - numbps))
     c->h_desc_dec = c->h_desc;
@@ -317,22 +356,11 @@ int run_egress(grk_amd_ctx* c, uint32_t ntiles, const void* d_planes, void* d_pi
     return GRK_AMD_OK;
 }
 
-void block_extents(const TileGeom& g, uint32_t& max_kmax, uint32_t& max_samples)
-{
-    max_kmax = 0; max_samples = 0;
-    for (const auto& b : g.blocks_comp0) {
-        max_kmax = std::max<uint32_t>(max_kmax, b.kmax);
-        max_samples = std::max<uint32_t>(max_samples, (b.x1 - b.x0) * (b.y1 - b.y0));
-    }
-}
-
 int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
 {
     const TileGeom& g = c->geom;
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
-    uint32_t max_kmax, max_samples;
-    block_extents(g, max_kmax, max_samples);
     HIP_TRY(c, c->lengths.ensure(nblocks * 4), "alloc lengths");
     HIP_TRY(c, c->offsets.ensure((nblocks + 1) * 8), "alloc offsets");
     HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc allocator state");
@@ -351,7 +379,9 @@ int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
     a.alloc = (unsigned long long*)c->flag.p;        // [0] status flags, [1] bytes used (launch_ht_encode resets them)
     a.lengths = (uint32_t*)c->lengths.p; a.offsets = (unsigned long long*)c->offsets.p;
     a.region_mask = regions - 1;
-    a.irreversible = g.p.irreversible; a.max_kmax = max_kmax; a.max_block_samples = max_samples;
+    a.irreversible = g.p.irreversible;
+    a.num_classes = c->ht_num_classes;
+    for (uint32_t k = 0; k < c->ht_num_classes; ++k) a.classes[k] = c->ht_classes[k];
     {
         ScopedTimer t(c, 2);
         HIP_TRY(c, launch_ht_encode(a, c->stream), "launch ht encode");
@@ -391,7 +421,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     drain_timers(c);
     for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
                       &c->offsets, &c->arena, &c->flag, &c->dec_desc, &c->dec_table, &c->dec_quads, &c->dec_mslen,
-                      &c->dec_coded, &c->dec_pixels})
+                      &c->dec_coded, &c->dec_pixels, &c->ht_sel})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -47,6 +47,11 @@ struct HtBlockDesc {        // one per code-block of a tile-component set (all c
     uint8_t  pad;
     float    inv_step;      // 1/stepsize (irreversible)
 };
+struct HtClass {
+    const uint32_t* sel;      // device: indices (within a tile) of the blocks of this class; nullptr = all blocks in order
+    uint32_t count;
+    uint32_t max_kmax, max_samples, max_quads;   // extents that size the class's LDS buffers
+};
 struct HtArgs {
     const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp]
     const HtBlockDesc* blocks; uint32_t blocks_per_tile; uint32_t ncomp; uint32_t ntiles;
@@ -55,11 +60,12 @@ struct HtArgs {
                                                 // overflow, bit 1 magnitude out of contract), [1] bytes used, region words
     uint32_t* lengths;                          // [ntiles*blocks_per_tile]
     unsigned long long* offsets;                // [ntiles*blocks_per_tile]
+    const uint32_t* sel; uint32_t sel_count;    // set per launch by launch_ht_encode from `classes`
+    HtClass classes[2]; uint32_t num_classes;   // block classes of a tile (by LDS need), each launched on its own
     uint32_t region_mask;         // (power of two <= kHtAllocRegions) - 1: block i allocates from region i & mask
     int irreversible;
-    uint32_t max_kmax;            // largest kmax among the blocks (sizes the raw MagSgn LDS buffer)
-    uint32_t max_block_samples;   // largest w*h among the blocks
 };
+size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax);
 constexpr size_t   kHtAllocBytes = 8192;
 constexpr uint32_t kHtAllocRegions = 16;           // region words available; a launch uses region_mask + 1 of them
 constexpr uint32_t kHtAllocChunk = 256u << 10;     // bytes a region takes from the shared cursor at a time

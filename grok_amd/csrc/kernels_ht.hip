@@ -238,21 +238,23 @@ __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* fl
 template <bool IRREV>
 __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_words, uint32_t vlc_words, uint32_t mark_words, uint32_t vmark_words)
 {
-    // LDS: UVLC table | raw MagSgn bits | raw VLC bits | 7-bit-byte bitmaps | their prefix counts | MEL bytes
+    // LDS (kept under 10 KiB for 8-bit content so that 16 waves fit a CU): raw MagSgn bits | raw VLC bits |
+    // 7-bit-byte bitmaps (phase B) aliased with the UVLC table (phase A) | MEL bytes
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint2*    uvlc_l  = reinterpret_cast<uint2*>(smem);                          // 64 entries
-    uint32_t* ms_raw  = smem + 128;
+    uint32_t* ms_raw  = smem;
     uint32_t* vlc_raw = ms_raw + ms_words;
     uint32_t* marks   = vlc_raw + vlc_words;
     uint32_t* vmarks  = marks + mark_words;
-    uint16_t* pref    = reinterpret_cast<uint16_t*>(vmarks + vmark_words);
-    uint16_t* vpref   = pref + mark_words;
-    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(vpref + vmark_words);         // 256 bytes
+    uint2*    uvlc_l  = reinterpret_cast<uint2*>(marks);                         // 64 entries, phase A only
+    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(marks + max(mark_words + vmark_words, 128u));   // 256 bytes
 
     const int lane = threadIdx.x;
-    const uint32_t gid = blockIdx.x;
-    const uint32_t tile = gid / a.blocks_per_tile;
-    const HtBlockDesc bd = a.blocks[gid % a.blocks_per_tile];
+    // this launch covers the blocks sel[0..sel_count) of every tile (all blocks when sel == nullptr)
+    const uint32_t li = blockIdx.x % a.sel_count;
+    const uint32_t tile = blockIdx.x / a.sel_count;
+    const uint32_t lb = a.sel ? a.sel[li] : li;
+    const uint32_t gid = tile * a.blocks_per_tile + lb;
+    const HtBlockDesc bd = a.blocks[lb];
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
     const int32_t* src = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const bool narrow = kmax + 2 <= 16;           // a quad's four MagSgn values fit 64 bits
 
     uvlc_l[lane] = g_uvlc[lane];
-    for (uint32_t i = lane; i < ms_words + vlc_words + mark_words + vmark_words; i += 64) ms_raw[i] = 0;
+    for (uint32_t i = lane; i < ms_words + vlc_words; i += 64) ms_raw[i] = 0;
     __syncthreads();
     if (lane == 0) vlc_raw[0] = 0xF;             // vlc_init: four 1 bits pending (:315-318)
     __syncthreads();
@@ -495,6 +497,8 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
 
     // ================= phase B: stuffing, termination, emission (see oracle/ht_wave_model.c) =====
     const uint32_t msw = ms_words, vw = vlc_words;
+    for (uint32_t i = lane; i < mark_words + vmark_words; i += 64) marks[i] = 0;      // the UVLC table is dead now
+    __syncthreads();
 
     // ---- B1: MagSgn events
     uint32_t last_p = 0;
@@ -545,28 +549,6 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const uint32_t total = ms_len + mel_len + vcount + 1;
     const uint32_t scup = mel_len + vcount + 1;
 
-    // ---- B4: prefix popcounts of the mark bitmaps (only the words emission will look at)
-    {
-        uint32_t base = 0;
-        const uint32_t mw_used = min(mark_words, (ms_emit >> 5) + 2);
-        for (uint32_t w0 = 0; w0 < mw_used; w0 += 64) {
-            const uint32_t i = w0 + lane;
-            const uint32_t cnt = i < mark_words ? __popc(marks[i]) : 0;
-            const uint32_t incl = wave_incl_scan(cnt);
-            if (i < mark_words) pref[i] = (uint16_t)(base + incl - cnt);
-            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        base = 0;
-        const uint32_t vw_used = min(vmark_words, (nv >> 5) + 2);
-        for (uint32_t w0 = 0; w0 < vw_used; w0 += 64) {
-            const uint32_t i = w0 + lane;
-            const uint32_t cnt = i < vmark_words ? __popc(vmarks[i]) : 0;
-            const uint32_t incl = wave_incl_scan(cnt);
-            if (i < vmark_words) vpref[i] = (uint16_t)(base + incl - cnt);
-            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-    }
-
     // ---- the reserved bytes (16-byte aligned, order of arrival)
     base_off = ((unsigned long long)__shfl((uint32_t)(base_off >> 32), 0) << 32) | __shfl((uint32_t)base_off, 0);
     if (lane == 0) { a.lengths[gid] = total; a.offsets[gid] = base_off; }
@@ -577,12 +559,17 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     uint8_t* out = a.arena + base_off;
     __syncthreads();
 
-    // ---- B5: emission. MagSgn: one dword (4 bytes) per lane and iteration, coalesced stores
-    for (uint32_t j = 4 * lane; j < ms_emit; j += 256) {
-        const uint32_t wd = j >> 5, bit = j & 31;
-        const uint32_t mw = marks[wd];
-        const uint32_t k = pref[wd] + __popc(mw & ((1u << bit) - 1u));
-        const uint32_t flags = (mw >> bit) & 0xF;
+    // ---- B5: emission. MagSgn: one dword (4 bytes) per lane and iteration, coalesced stores; the number
+    //      of 7-bit bytes before a lane's first byte is a running count plus a wave prefix sum
+    uint32_t kbase = 0;
+    for (uint32_t j0 = 0; j0 < ms_emit; j0 += 256) {
+        const uint32_t j = j0 + 4 * lane;
+        const uint32_t flags = j < ms_emit ? (marks[j >> 5] >> (j & 31)) & 0xFu : 0u;
+        const uint32_t cnt = __popc(flags);
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t k = kbase + incl - cnt;
+        kbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (j >= ms_emit) continue;
         const uint32_t start = 8 * j - k;
         const uint32_t sw = start >> 5;
         uint64_t win = (ms_raw[sw] | ((uint64_t)ms_raw[sw + 1] << 32)) >> (start & 31);   // >= 32 valid bits
@@ -599,11 +586,15 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     if (has_final && lane == 0) out[ms_len - 1] = (uint8_t)final_byte;
     for (uint32_t i = lane; i < mel_len; i += 64) out[ms_len + i] = mel_buf[i < 250 ? i : 249];
     // VLC bytes are stored in reverse order of generation; the first one carries Scup's low nibble
-    for (uint32_t j = lane; j < nv; j += 64) {
-        const uint32_t wd = j >> 5, bit = j & 31;
-        const uint32_t mw = vmarks[wd];
-        const uint32_t k = vpref[wd] + __popc(mw & ((1u << bit) - 1u));
-        uint32_t byte = get_bits(vlc_raw, 8 * j - k, ((mw >> bit) & 1) ? 7u : 8u);
+    uint32_t vkbase = 0;
+    for (uint32_t j0 = 0; j0 < nv; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool seven = j < nv && ((vmarks[j >> 5] >> (j & 31)) & 1u);
+        const uint64_t bal = __ballot(seven);
+        const uint32_t k = vkbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        vkbase += (uint32_t)__popcll(bal);
+        if (j >= nv) continue;
+        uint32_t byte = get_bits(vlc_raw, 8 * j - k, seven ? 7u : 8u);
         if (j == 0) byte = (byte & 0xF0) | (scup & 0xF);
         out[total - 2 - j] = (uint8_t)byte;
     }
@@ -643,6 +634,28 @@ static hipError_t upload_tables()
     return hipMemcpyToSymbol(HIP_SYMBOL(g_uvlc), uv, sizeof(uv), 0, hipMemcpyHostToDevice);
 }
 
+// LDS words of a launch whose largest block has `samples` samples in `quads` quads and exponent kmax
+static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, uint32_t& ms_words, uint32_t& vlc_words,
+                          uint32_t& mark_words, uint32_t& vmark_words, size_t& bytes)
+{
+    const uint32_t ms_bits = samples * (kmax + 2u);                 // m_n <= U_q <= Kmax + 2 inside the contract
+    const uint32_t vlc_bits = quads * 15u + 4u;                     // cwd <= 7, UVLC prefix <= 3, suffix <= 5 bits per quad
+    ms_words = ((ms_bits + 31u) / 32u + 4u + 1u) & ~1u;             // slack: or_bits64 / window reads touch two words beyond
+    vlc_words = ((vlc_bits + 31u) / 32u + 4u + 1u) & ~1u;
+    mark_words = ((ms_bits + ms_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;   // one bit per stuffed output byte
+    vmark_words = ((vlc_bits + vlc_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;
+    uint32_t mk = mark_words + vmark_words;
+    if (mk < 128u) mk = 128u;                                       // the UVLC table lives there during phase A
+    bytes = (size_t)(ms_words + vlc_words + mk) * 4u + 256u;
+}
+
+size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax)
+{
+    uint32_t a, b, c, d; size_t n;
+    ht_lds_layout(samples, quads, kmax, a, b, c, d, n);
+    return n;
+}
+
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s)
 {
     int dev = 0;
@@ -653,21 +666,22 @@ hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s)
         if (e != hipSuccess) return e;
         g_tables_ready[dev] = true;
     }
-    // raw MagSgn stream: at most (kmax+2) bits per sample; VLC: < 32 bits per quad pair.
-    const uint32_t max_bits = a.max_block_samples * (a.max_kmax + 2u);
-    const uint32_t ms_words = max_bits / 32 + 8;
-    const uint32_t vlc_bits_max = 16u * ((a.max_block_samples + 3) / 4 + 64) + 64;
-    const uint32_t vlc_words = vlc_bits_max / 32 + 8;
-    const uint32_t mark_words = (max_bits / 7 + 64) / 32 + 2;
-    const uint32_t vmark_words = (vlc_bits_max / 7 + 64) / 32 + 2;
-    const size_t shmem = 512 + (size_t)(ms_words + vlc_words + mark_words + vmark_words) * 4 +
-                         (size_t)(mark_words + vmark_words + 2) * 2 + 256;
-    const uint32_t nblocks = a.blocks_per_tile * a.ntiles;
     hipLaunchKernelGGL(ht_alloc_init_kernel, dim3(1), dim3(64), 0, s, a.alloc);
-    if (a.irreversible)
-        hipLaunchKernelGGL(ht_encode_kernel<true>, dim3(nblocks), dim3(64), shmem, s, a, ms_words, vlc_words, mark_words, vmark_words);
-    else
-        hipLaunchKernelGGL(ht_encode_kernel<false>, dim3(nblocks), dim3(64), shmem, s, a, ms_words, vlc_words, mark_words, vmark_words);
+    // one launch per block class (HtClass): the dynamic LDS size is what fixes the occupancy, and the
+    // few high-Kmax blocks of the low resolutions would otherwise cost every block a wave per SIMD
+    for (uint32_t k = 0; k < a.num_classes; ++k) {
+        const HtClass& c = a.classes[k];
+        if (c.count == 0) continue;
+        uint32_t ms_words, vlc_words, mark_words, vmark_words; size_t shmem;
+        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, ms_words, vlc_words, mark_words, vmark_words, shmem);
+        HtArgs b = a;
+        b.sel = c.sel; b.sel_count = c.count;
+        const uint32_t grid = c.count * a.ntiles;
+        if (a.irreversible)
+            hipLaunchKernelGGL(ht_encode_kernel<true>, dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
+        else
+            hipLaunchKernelGGL(ht_encode_kernel<false>, dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
+    }
     return hipGetLastError();
 }
 
