@@ -252,7 +252,9 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         const uint32_t sh = (a.ch + 1) >> 1;
         uint32_t seg = 64;
         const uint64_t strips = (a.cw + 503) / 504;
-        while (seg > 8 && strips * ((sh + seg - 1) / seg) * nplanes < 4096) seg >>= 1;
+        // workgroups along z: planes, or for the fused level 0 tiles (x components when there is no MCT triple)
+        const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
+        while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
         a.seg_pairs = seg;
         if (l == 0 && d_pixels) {
             a.pixels = d_pixels; a.px_bytes = (g.p.prec + 7) / 8;

@@ -40,6 +40,13 @@ __device__ __forceinline__ uint32_t mirror_idx(int32_t i, uint32_t n)
     if (i < 0) i += p;
     return (uint32_t)(i < (int32_t)n ? i : p - i);
 }
+// same for indices that leave [0, n) by fewer than 16 samples (the row loop): one reflection, no division
+__device__ __forceinline__ uint32_t mirror_row(int32_t i, uint32_t n)
+{
+    if (n < 16) return mirror_idx(i, n);
+    i = i < 0 ? -i : i;
+    return (uint32_t)(i < (int32_t)n ? i : 2 * ((int32_t)n - 1) - i);
+}
 
 constexpr float kAlpha = -1.586134342f;
 constexpr float kBeta  = -0.052980118f;
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     // raw row fetch (no arithmetic, so that prefetched rows stay in flight) and its conversion
     struct Raw { int32_t a[NC], b[NC]; };
     auto fetch_row = [&](int32_t r, Raw& q) {
-        const uint32_t rr = mirror_idx(r, ch);
+        const uint32_t rr = mirror_row(r, ch);
         if constexpr (PX == 0) {
             const int32_t* row = reinterpret_cast<const int32_t*>(in) + (size_t)rr * a.in_stride;
             if (vec) { const int2 v = *reinterpret_cast<const int2*>(row + cA); q.a[0] = v.x; q.b[0] = v.y; }

@@ -37,6 +37,13 @@ __device__ __forceinline__ uint32_t mirror_idx(int32_t i, uint32_t n)
     if (i < 0) i += p;
     return (uint32_t)(i < (int32_t)n ? i : p - i);
 }
+// same for indices that leave [0, n) by fewer than 16 samples (the row loop): one reflection, no division
+__device__ __forceinline__ uint32_t mirror_row(int32_t i, uint32_t n)
+{
+    if (n < 16) return mirror_idx(i, n);
+    i = i < 0 ? -i : i;
+    return (uint32_t)(i < (int32_t)n ? i : 2 * ((int32_t)n - 1) - i);
+}
 
 constexpr float kK        = 1.230174105f;
 constexpr float kTwoInvK  = 1.625732422f;
@@ -135,8 +142,8 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     struct Raw { T ls, ld, hs, hd; };
     auto fetch = [&](int32_t i, Raw& q) {
         // vertical mirror in the interleaved domain: low row 2i, high row 2i+1
-        const uint32_t is = mirror_idx(2 * i, ch) >> 1;
-        const uint32_t id = ch > 1 ? (mirror_idx(2 * i + 1, ch) - 1) >> 1 : 0;
+        const uint32_t is = mirror_row(2 * i, ch) >> 1;
+        const uint32_t id = ch > 1 ? (mirror_row(2 * i + 1, ch) - 1) >> 1 : 0;
         q.ls = ll[(size_t)is * a.ll_stride + js];
         q.ld = cw > 1 ? mp[(size_t)is * a.m_stride + sw + jd] : T(0);
         q.hs = ch > 1 ? mp[(size_t)(sh + id) * a.m_stride + js] : T(0);
