@@ -96,6 +96,15 @@ void orc_ict_inv_store(int32_t* c0, int32_t* c1, int32_t* c2, size_t n, int32_t 
 void orc_dc_store_rev(int32_t* c, size_t n, int32_t shift, int32_t lo, int32_t hi);
 void orc_dc_store_irrev(int32_t* c, size_t n, int32_t shift, int32_t lo, int32_t hi);
 
+/* ---- a13: Part-1 (EBCOT) Tier-1 block decoder (oracle/ebcot_oracle.c; t1/t1_part1/T1.cpp:1262-1337,
+ *           code-block style 0).  numbps = magnitude bit-planes coded for the block (band numbps minus
+ *           the zero bit-planes Tier-2 signals), orient 0 LL / 1 HL / 2 LH / 3 HH.  out: w*h int32 in
+ *           the decoder's representation (one extra fractional bit).  Then ShiftFilter / ScaleFilter. */
+int32_t orc_t1_decode_block(const uint8_t* coded, uint32_t len, uint32_t numpasses, uint32_t numbps,
+                            uint32_t orient, uint32_t w, uint32_t h, int32_t* out);
+void orc_t1_dequant_rev(const int32_t* v, uint32_t n, int32_t* out);
+void orc_t1_dequant_irrev(const int32_t* v, uint32_t n, float stepsize, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -382,3 +382,61 @@ uint64_t ref_abi_sizeof(int which)
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------- Part-1 (EBCOT/MQ) block coder
+// Drives the reference's own T1 (t1/t1_part1/T1.cpp) on one code-block, the way T1Part1::compress /
+// ::decompress do (t1/t1_part1/T1Part1.cpp:33-151): reversible path, cblk_sty = 0, no rate control.
+#include "t1_common.h"
+extern "C" {
+
+// coef: w x h int32 (row stride `stride`).  Returns coded length; *numpasses / *numbps as the encoder
+// reports them (numbps = magnitude bit-planes actually coded).
+int32_t ref_t1_encode_block(const int32_t* coef, uint32_t w, uint32_t h, uint32_t stride, uint32_t orient,
+							uint8_t* out, uint32_t cap, uint32_t* numpasses, uint32_t* numbps)
+{
+	grk::T1 t1(true, w, h);
+	if (!t1.alloc(w, h)) return -1;
+	auto d = t1.getUncompressedData();
+	uint32_t maxv = 0;
+	for (uint32_t y = 0; y < h; ++y)
+		for (uint32_t x = 0; x < w; ++x) {
+			int32_t temp = coef[(size_t)y * stride + x] * (1 << T1_NMSEDEC_FRACBITS);
+			temp = (int32_t)to_smr(temp);
+			maxv = std::max<uint32_t>(maxv, smr_abs(temp));
+			d[(size_t)y * w + x] = temp;
+		}
+	std::vector<uint8_t> buf((size_t)w * h * 8 + 4096, 0);
+	grk::cblk_enc c;
+	memset(&c, 0, sizeof(c));
+	c.x0 = 0; c.y0 = 0; c.x1 = w; c.y1 = h;
+	c.data = buf.data() + 2;           // the coder writes one byte before the start (mqc_init_enc)
+	t1.compress_cblk(&c, maxv, (uint8_t)orient, 0, 0, 1, 1.0, 0, nullptr, 0, false);
+	uint32_t len = c.numPassesTotal ? c.passes[c.numPassesTotal - 1].rate : 0;
+	*numpasses = c.numPassesTotal; *numbps = c.numbps;
+	int32_t rc = -1;
+	if (len <= cap) { memcpy(out, c.data, len); rc = (int32_t)len; }
+	t1.code_block_enc_deallocate(&c);
+	return rc;
+}
+
+// out: w x h int32 in the decoder's own representation (one extra fractional bit: value*2 +- 1)
+int32_t ref_t1_decode_block(const uint8_t* coded, uint32_t len, uint32_t numpasses, uint32_t numbps,
+							uint32_t orient, uint32_t w, uint32_t h, int32_t* out)
+{
+	grk::T1 t1(false, w, h);
+	DecompressCodeblock cblk;
+	cblk.setRect(grkRectU32(0, 0, w, h));
+	if (!cblk.alloc()) return -1;
+	cblk.numbps = numbps;
+	auto seg = cblk.nextSegment();
+	seg->numpasses = numpasses; seg->len = len; seg->maxpasses = numpasses;
+	std::vector<int32_t> data((size_t)w * h, 0);
+	t1.attachUncompressedData(data.data(), w, h);
+	t1.allocCompressedData(len + 8);
+	memcpy(t1.getCompressedDataBuffer(), coded, len);
+	bool ok = t1.decompress_cblk(&cblk, t1.getCompressedDataBuffer(), (uint8_t)orient, 0);
+	memcpy(out, data.data(), data.size() * 4);
+	return ok ? 0 : -1;
+}
+
+} // extern "C"

@@ -65,8 +65,30 @@ def lib():
         for f in ("orc_dc_store_rev", "orc_dc_store_irrev"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32]
             getattr(L, f).restype = None
+        L.orc_t1_decode_block.restype = C.c_int32
+        L.orc_t1_decode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_void_p]
+        L.orc_t1_dequant_rev.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_t1_dequant_rev.restype = None
+        L.orc_t1_dequant_irrev.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
+        L.orc_t1_dequant_irrev.restype = None
         _lib = L
     return _lib
+
+
+def t1_decode_block(coded, numpasses, numbps, orient, w, h):
+    """Part-1 block decode -> (h, w) int32 in the decoder's representation, or None if rejected."""
+    buf = np.frombuffer(bytes(coded) + b"\0\0", np.uint8).copy()
+    out = np.zeros((h, w), np.int32)
+    rc = lib().orc_t1_decode_block(buf.ctypes.data, len(coded), numpasses, numbps, orient, w, h, out.ctypes.data)
+    return out if rc == 0 else None
+
+
+def t1_dequant_rev(v):
+    a = np.ascontiguousarray(v, np.int32)
+    out = np.zeros(a.shape, np.int32)
+    lib().orc_t1_dequant_rev(a.ctypes.data, a.size, out.ctypes.data)
+    return out
 
 
 def ht_decode_block(coded, missing_msbs, w, h):

@@ -102,6 +102,34 @@ def ht_decode_block(coded, missing_msbs, w, h):
     return out
 
 
+def t1_encode_block(coef, orient):
+    """Reference Part-1 (EBCOT) block encoder -> (bytes, numpasses, numbps)."""
+    L = lib()
+    L.ref_t1_encode_block.restype = C.c_int32
+    L.ref_t1_encode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    a = np.ascontiguousarray(coef, np.int32)
+    h, w = a.shape
+    out = np.zeros(w * h * 8 + 4096, np.uint8)
+    npass, nbps = C.c_uint32(0), C.c_uint32(0)
+    n = L.ref_t1_encode_block(a.ctypes.data, w, h, w, orient, out.ctypes.data, out.size, C.byref(npass), C.byref(nbps))
+    assert n >= 0
+    return out[:n].tobytes(), npass.value, nbps.value
+
+
+def t1_decode_block(coded, numpasses, numbps, orient, w, h):
+    L = lib()
+    L.ref_t1_decode_block.restype = C.c_int32
+    L.ref_t1_decode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_void_p]
+    buf = np.frombuffer(bytes(coded) + b"\0" * 8, np.uint8).copy()
+    out = np.zeros((h, w), np.int32)
+    rc = L.ref_t1_decode_block(buf.ctypes.data, len(coded), numpasses, numbps, orient, w, h, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("ref_t1_decode_block failed")
+    return out
+
+
 def plugin_dir():
     return os.path.abspath(os.path.join(_HERE, "..", "grok_amd", "lib"))
 
