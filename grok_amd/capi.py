@@ -22,10 +22,12 @@ class TileParams(C.Structure):
                 ("cblk_h_exp", C.c_uint8), ("reserved", C.c_uint8 * 3)]
 
     @classmethod
-    def make(cls, w, h, comps, prec, levels, irreversible=False, mct=None, sgnd=False, cblk=(6, 6)):
+    def make(cls, w, h, comps, prec, levels, irreversible=False, mct=None, sgnd=False, cblk=(6, 6), part1=False):
         if mct is None:
             mct = comps >= 3
-        return cls(w, h, comps, prec, int(sgnd), int(irreversible), int(mct), levels, cblk[0], cblk[1])
+        p = cls(w, h, comps, prec, int(sgnd), int(irreversible), int(mct), levels, cblk[0], cblk[1])
+        p.reserved[0] = int(part1)
+        return p
 
 
 class Block(C.Structure):

@@ -50,7 +50,7 @@ struct grk_amd_ctx {
     std::string err;
     // working set
     DevBuf pixels, p0, p1, llA, llB, blockdesc, lengths, offsets, arena, flag;
-    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels;
+    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels, dec_work;
     // geometry cache
     grk_amd_tile_params gp{};
     bool have_geom = false;
@@ -86,7 +86,8 @@ bool same_params(const grk_amd_tile_params& a, const grk_amd_tile_params& b)
 {
     return a.tile_w == b.tile_w && a.tile_h == b.tile_h && a.num_comps == b.num_comps && a.prec == b.prec &&
            a.sgnd == b.sgnd && a.irreversible == b.irreversible && a.mct == b.mct &&
-           a.num_levels == b.num_levels && a.cblk_w_exp == b.cblk_w_exp && a.cblk_h_exp == b.cblk_h_exp;
+           a.num_levels == b.num_levels && a.cblk_w_exp == b.cblk_w_exp && a.cblk_h_exp == b.cblk_h_exp &&
+           a.reserved[0] == b.reserved[0];
 }
 
 int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
@@ -103,7 +104,7 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
             HtBlockDesc d;
             d.px = b.px; d.py = b.py;
             d.w = (uint16_t)(b.x1 - b.x0); d.h = (uint16_t)(b.y1 - b.y0);
-            d.comp = (uint16_t)k; d.kmax = b.kmax; d.pad = 0;
+            d.comp = (uint16_t)k; d.kmax = b.kmax; d.pad = b.band;
             d.inv_step = 1.0f / b.stepsize;
             c->h_desc.push_back(d);
         }
@@ -157,7 +158,7 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
                     const uint16_t wq = g.qcd_words[bi];
                     const double step = (1.0 + (wq & 0x7FF) / 2048.0) * std::pow(2.0, (int)p->prec - (int)(wq >> 11));
                     scale = (float)step;
-                    scale /= (float)(1u << (31 - b.kmax));
+                    if (!p->reserved[0]) scale /= (float)(1u << (31 - b.kmax));     // HT only (Quantizer.cpp:54-63)
                 }
                 c->h_desc_dec[i++].inv_step = scale;
             }
@@ -332,6 +333,30 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     return GRK_AMD_OK;
 }
 
+int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes, void* d_mallat)
+{
+    const TileGeom& g = c->geom;
+    const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
+    const uint64_t nblocks = (uint64_t)bpt * ntiles;
+    const uint32_t L = t1_lanes_per_group((uint32_t)nblocks);
+    const uint64_t groups = (nblocks + L - 1) / L;
+    HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
+    HIP_TRY(c, c->dec_work.ensure(groups * L * 4096 * 4), "alloc Part-1 workspace");
+    HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc status");
+    HIP_TRY(c, hipMemcpyAsync(c->dec_table.p, table, nblocks * sizeof(HtDecBlock), hipMemcpyHostToDevice, c->stream), "upload decode table");
+    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, 16, c->stream), "clear status");
+    T1DecArgs a{};
+    a.table = (const HtDecBlock*)c->dec_table.p;
+    a.blocks = (const HtBlockDesc*)c->dec_desc.p; a.blocks_per_tile = bpt; a.nblocks = (uint32_t)nblocks; a.ncomp = g.p.num_comps;
+    a.coded = (const uint8_t*)d_coded; a.coded_bytes = coded_bytes;
+    a.work = (int32_t*)c->dec_work.p; a.status = (unsigned int*)c->flag.p;
+    a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
+    a.irreversible = g.p.irreversible;
+    ScopedTimer t(c, 5);
+    HIP_TRY(c, launch_t1_decode(a, c->stream), "launch Part-1 decode");
+    return GRK_AMD_OK;
+}
+
 int check_decode_status(grk_amd_ctx* c)
 {
     uint32_t st = 0;
@@ -423,7 +448,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     drain_timers(c);
     for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
                       &c->offsets, &c->arena, &c->flag, &c->dec_desc, &c->dec_table, &c->dec_quads, &c->dec_mslen,
-                      &c->dec_coded, &c->dec_pixels, &c->ht_sel})
+                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->ht_sel})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -511,7 +536,9 @@ int grk_amd_stage_ht_decode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32
     if (!c || !p || !table || !d_coded || !d_mallat || ntiles == 0) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = ensure_geom(c, p); if (rc) return rc;
-    rc = run_ht_decode(c, ntiles, table, d_coded, coded_bytes, d_mallat); if (rc) return rc;
+    rc = p->reserved[0] ? run_t1_decode(c, ntiles, table, d_coded, coded_bytes, d_mallat)
+                        : run_ht_decode(c, ntiles, table, d_coded, coded_bytes, d_mallat);
+    if (rc) return rc;
     return check_decode_status(c);
 }
 
@@ -541,7 +568,9 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
     {
         ScopedTimer t(c, 3);
-        rc = run_ht_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p); if (rc) return rc;
+        rc = p->reserved[0] ? run_t1_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p)
+                            : run_ht_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p);
+        if (rc) return rc;
         rc = run_idwt(c, nplanes, c->p1.p, c->p0.p); if (rc) return rc;
         rc = run_egress(c, ntiles, c->p0.p, d_px, bps); if (rc) return rc;
     }

@@ -90,6 +90,20 @@ struct HtDecArgs {
 };
 hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s);
 
+// ---- K8: Part-1 (EBCOT) block decoder + dequantisation (kernels_t1dec.hip) -----------------------
+struct T1DecArgs {
+    const HtDecBlock* table;                   // missing_msbs field carries numbps | numpasses << 8
+    const HtBlockDesc* blocks;                 // pad = band orientation, inv_step = band step size (irreversible)
+    uint32_t blocks_per_tile, nblocks, ncomp;
+    const uint8_t* coded; uint64_t coded_bytes;
+    int32_t* work;                             // [groups][64*64][lanes per group] decoded values
+    unsigned int* status;
+    int32_t* mallat; uint32_t stride; uint64_t pitch;
+    int irreversible;
+};
+uint32_t   t1_lanes_per_group(uint32_t nblocks);
+hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s);
+
 // ---- K6: one inverse DWT level, horizontal + vertical fused (kernels_idwt.hip) ------------------
 struct IdwtLevelArgs {
     const int32_t* ll;     uint32_t ll_stride;  uint64_t ll_pitch;   // LL of the level (sw x sh)

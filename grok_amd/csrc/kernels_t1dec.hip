@@ -1,0 +1,272 @@
+// grok_amd/csrc/kernels_t1dec.hip -- K8: Part-1 (EBCOT) Tier-1 block decoder + dequantisation, gfx950.
+//
+// Replaces T1Part1::decompress -> T1::decompress_cblk (t1/t1_part1/T1Part1.cpp:124-151,
+// t1/t1_part1/T1.cpp:1262-1337: code-block style 0, one arithmetic-coded segment) with its MQ decoder
+// (mqc_dec.cpp:107-177, mqc_dec_inl.h) and ShiftFilter / ScaleFilter
+// (filters/PostDecompressFilters.h:26-35, :60-71).
+//
+// EBCOT decoding is one dependent chain per code-block: every MQ decision renormalises the
+// interval the next one uses and every context depends on the samples decoded so far.  As in K5a the
+// parallelism is therefore ACROSS blocks:
+//  K8a t1_dec_kernel  -- one lane per code-block.  Significance / sign / visited / refined state is
+//      kept as one 64-bit row bitmap each (code-blocks are at most 64 wide), so a sample's whole
+//      8-neighbourhood is three 3-bit windows; all lanes of a wave walk (stripe, column, row) in
+//      lockstep, which makes the per-lane bitmap arrays (scratch) and the transposed value workspace
+//      coalesced across lanes; the 19 context states and the MQ table live in LDS; coded bytes come
+//      through the word-ahead cursor.
+//  K8b t1_store_kernel -- one wavefront per code-block: workspace -> dequantise -> Mallat plane rows.
+#include "kernels.h"
+
+namespace grk_amd {
+
+namespace {
+
+// T.800 Table C.2: Qe | NMPS << 16 | NLPS << 22 | SWITCH << 28
+#define MQROW(qe, nm, nl, sw) ((uint32_t)(qe) | ((uint32_t)(nm) << 16) | ((uint32_t)(nl) << 22) | ((uint32_t)(sw) << 28))
+__device__ const uint32_t g_mq_table[47] = {
+    MQROW(0x5601, 1, 1, 1),  MQROW(0x3401, 2, 6, 0),  MQROW(0x1801, 3, 9, 0),  MQROW(0x0AC1, 4, 12, 0), MQROW(0x0521, 5, 29, 0),
+    MQROW(0x0221, 38, 33, 0), MQROW(0x5601, 7, 6, 1),  MQROW(0x5401, 8, 14, 0), MQROW(0x4801, 9, 14, 0), MQROW(0x3801, 10, 14, 0),
+    MQROW(0x3001, 11, 17, 0), MQROW(0x2401, 12, 18, 0), MQROW(0x1C01, 13, 20, 0), MQROW(0x1601, 29, 21, 0), MQROW(0x5601, 15, 14, 1),
+    MQROW(0x5401, 16, 14, 0), MQROW(0x5101, 17, 15, 0), MQROW(0x4801, 18, 16, 0), MQROW(0x3801, 19, 17, 0), MQROW(0x3401, 20, 18, 0),
+    MQROW(0x3001, 21, 19, 0), MQROW(0x2801, 22, 19, 0), MQROW(0x2401, 23, 20, 0), MQROW(0x2201, 24, 21, 0), MQROW(0x1C01, 25, 22, 0),
+    MQROW(0x1801, 26, 23, 0), MQROW(0x1601, 27, 24, 0), MQROW(0x1401, 28, 25, 0), MQROW(0x1201, 29, 26, 0), MQROW(0x1101, 30, 27, 0),
+    MQROW(0x0AC1, 31, 28, 0), MQROW(0x09C1, 32, 29, 0), MQROW(0x08A1, 33, 30, 0), MQROW(0x0521, 34, 31, 0), MQROW(0x0441, 35, 32, 0),
+    MQROW(0x02A1, 36, 33, 0), MQROW(0x0221, 37, 34, 0), MQROW(0x0141, 38, 35, 0), MQROW(0x0111, 39, 36, 0), MQROW(0x0085, 40, 37, 0),
+    MQROW(0x0049, 41, 38, 0), MQROW(0x0025, 42, 39, 0), MQROW(0x0015, 43, 40, 0), MQROW(0x0009, 44, 41, 0), MQROW(0x0005, 45, 42, 0),
+    MQROW(0x0001, 45, 43, 0), MQROW(0x5601, 46, 46, 0)};
+#undef MQROW
+
+constexpr int kCtxZC = 0, kCtxAgg = 17, kCtxUni = 18, kNumCtx = 19;
+constexpr uint32_t kMaxLanes = 64;
+
+struct MqDec {
+    const uint8_t* d; uint32_t len, pos;        // pos = index of the byte the reference's `bp` points at
+    uint32_t a, c, ct;
+    uint8_t* cx;                                 // this lane's 19 context bytes in LDS: state | mps << 7
+    const uint32_t* tab;                         // MQ table in LDS
+    const uint8_t* lo; const uint8_t* hi;        // readable range of the coded buffer
+    __device__ __forceinline__ uint32_t byte_at(uint32_t i) const
+    {   // block bytes followed by the artificial 0xFF 0xFF terminator (mqc_dec.cpp:113-118)
+        const uint8_t* p = d + i;
+        return (i < len && p >= lo && p < hi) ? *p : 0xFFu;
+    }
+    __device__ __forceinline__ void bytein()
+    {
+        const uint32_t cur = byte_at(pos), nxt = byte_at(pos + 1);
+        if (cur == 0xFFu) {
+            if (nxt > 0x8Fu) { c += 0xFF00u; ct = 8; }
+            else { ++pos; c += nxt << 9; ct = 7; }
+        } else { ++pos; c += nxt << 8; ct = 8; }
+    }
+    __device__ __forceinline__ void init()
+    {
+        pos = 0;
+        for (int i = 0; i < kNumCtx; ++i) cx[i] = 0;
+        cx[kCtxUni] = 46; cx[kCtxAgg] = 3; cx[kCtxZC] = 4;
+        c = (len == 0 ? 0xFFu : byte_at(0)) << 16;
+        bytein();
+        c <<= 7; ct -= 7; a = 0x8000u;
+    }
+    __device__ __forceinline__ uint32_t decode(int ctx)
+    {
+        const uint32_t st = cx[ctx];
+        const uint32_t row = tab[st & 0x7Fu];
+        const uint32_t qe = row & 0xFFFFu, mps = st >> 7;
+        uint32_t dbit;
+        a -= qe;
+        if ((c >> 16) < qe) {                              // LPS exchange (C.3.2)
+            const bool toM = a < qe;
+            dbit = toM ? mps : mps ^ 1u;
+            const uint32_t nst = toM ? ((row >> 16) & 0x3Fu) : ((row >> 22) & 0x3Fu);
+            const uint32_t nm = toM ? mps : mps ^ (row >> 28);
+            cx[ctx] = (uint8_t)(nst | (nm << 7));
+            a = qe;
+        } else {
+            c -= qe << 16;
+            if (a & 0x8000u) return mps;
+            const bool toL = a < qe;
+            dbit = toL ? mps ^ 1u : mps;
+            const uint32_t nst = toL ? ((row >> 22) & 0x3Fu) : ((row >> 16) & 0x3Fu);
+            const uint32_t nm = toL ? mps ^ (row >> 28) : mps;
+            cx[ctx] = (uint8_t)(nst | (nm << 7));
+        }
+        do {                                               // RENORMD
+            if (ct == 0) bytein();
+            a <<= 1; c <<= 1; --ct;
+        } while (a < 0x8000u);
+        return dbit;
+    }
+};
+
+// bits (x-1, x, x+1) of a row bitmap at positions 0, 1, 2
+__device__ __forceinline__ uint32_t win3(uint64_t s, uint32_t x)
+{
+    return (uint32_t)(x ? (s >> (x - 1)) : (s << 1)) & 7u;
+}
+
+__global__ void t1_dec_kernel(T1DecArgs a)
+{
+    __shared__ uint32_t mq_l[47];
+    __shared__ uint8_t ctx_l[kMaxLanes][20];
+    for (uint32_t i = threadIdx.x; i < 47; i += blockDim.x) mq_l[i] = g_mq_table[i];
+    __syncthreads();
+    const uint32_t L = blockDim.x;
+    const uint32_t blk = blockIdx.x * L + threadIdx.x;
+    if (blk >= a.nblocks) return;
+    const HtDecBlock in = a.table[blk];
+    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
+    const uint32_t w = bd.w, h = bd.h;
+    const uint32_t orient = bd.pad;                        // 0 LL, 1 HL, 2 LH, 3 HH
+    const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
+    // value workspace, transposed so that the lanes of a wave touch consecutive words: [group][y*64+x][lane]
+    int32_t* ws = a.work + (size_t)blockIdx.x * 4096u * L + threadIdx.x;
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) ws[(size_t)(y * 64u + x) * L] = 0;
+    if (in.length == 0 || numpasses == 0 || numbps == 0) return;
+    if (numbps >= 25u) { atomicOr(a.status, 4u); return; }         // k_max_bit_planes (t1_common.h:70)
+
+    // row bitmaps with one border row above and below: index y + 1
+    uint64_t sig[66], neg[66], pi[66], mu[66];
+    for (int i = 0; i < 66; ++i) { sig[i] = 0; neg[i] = 0; pi[i] = 0; mu[i] = 0; }
+
+    MqDec mq;
+    mq.d = a.coded + in.offset; mq.len = in.length;
+    mq.lo = a.coded; mq.hi = a.coded + a.coded_bytes;
+    mq.cx = ctx_l[threadIdx.x]; mq.tab = mq_l;
+    mq.init();
+
+    // sign of a newly significant sample (Tables D.2, D.3) and state update
+    auto make_significant = [&](uint32_t x, uint32_t y, int32_t oneplushalf) {
+        const uint64_t s1 = sig[y + 1], n1 = neg[y + 1];
+        // horizontal: left/right neighbours; vertical: above/below
+        auto contrib = [](uint32_t sa, uint32_t na, uint32_t sb, uint32_t nb) {
+            int s = (sa ? (na ? -1 : 1) : 0) + (sb ? (nb ? -1 : 1) : 0);
+            return s > 1 ? 1 : (s < -1 ? -1 : s);
+        };
+        const uint32_t ws1 = win3(s1, x), wn1 = win3(n1, x);
+        const int hc = contrib(ws1 & 1u, wn1 & 1u, (ws1 >> 2) & 1u, (wn1 >> 2) & 1u);
+        const int vc = contrib((uint32_t)(sig[y] >> x) & 1u, (uint32_t)(neg[y] >> x) & 1u,
+                               (uint32_t)(sig[y + 2] >> x) & 1u, (uint32_t)(neg[y + 2] >> x) & 1u);
+        int cxn, xr;
+        if (hc == 1)      { cxn = vc == 1 ? 13 : (vc == 0 ? 12 : 11); xr = 0; }
+        else if (hc == 0) { cxn = vc == 0 ? 9 : 10; xr = vc == -1; }
+        else              { cxn = vc == 1 ? 11 : (vc == 0 ? 12 : 13); xr = 1; }
+        const uint32_t ng = mq.decode(cxn) ^ (uint32_t)xr;
+        ws[(size_t)(y * 64u + x) * L] = ng ? -oneplushalf : oneplushalf;
+        sig[y + 1] |= 1ull << x;
+        if (ng) neg[y + 1] |= 1ull << x;
+    };
+    // zero-coding context (Table D.1) from the three row windows
+    auto zc_ctx = [&](uint32_t x, uint32_t y) -> int {
+        const uint32_t w0 = win3(sig[y], x), w1 = win3(sig[y + 1], x), w2 = win3(sig[y + 2], x);
+        int hh = (int)(w1 & 1u) + (int)((w1 >> 2) & 1u);
+        int vv = (int)((w0 >> 1) & 1u) + (int)((w2 >> 1) & 1u);
+        const int dd = (int)(w0 & 1u) + (int)((w0 >> 2) & 1u) + (int)(w2 & 1u) + (int)((w2 >> 2) & 1u);
+        if (orient == 1) { const int s = hh; hh = vv; vv = s; }
+        if (orient == 3) {
+            const int hv = hh + vv;
+            if (dd >= 3) return 8;
+            if (dd == 2) return hv >= 1 ? 7 : 6;
+            if (dd == 1) return hv >= 2 ? 5 : (hv == 1 ? 4 : 3);
+            return hv >= 2 ? 2 : hv;
+        }
+        if (hh == 2) return 8;
+        if (hh == 1) return vv >= 1 ? 7 : (dd >= 1 ? 6 : 5);
+        if (vv == 2) return 4;
+        if (vv == 1) return 3;
+        return dd >= 2 ? 2 : dd;
+    };
+    auto has_sig_nb = [&](uint32_t x, uint32_t y) -> bool {
+        return ((win3(sig[y], x) | win3(sig[y + 2], x)) | (win3(sig[y + 1], x) & 5u)) != 0;
+    };
+
+    int bp = (int)numbps, type = 2;
+    for (uint32_t p = 0; p < numpasses && bp >= 1; ++p) {
+        const int32_t one = 1 << bp, oph = one | (one >> 1), poshalf = one >> 1;
+        for (uint32_t k = 0; k < h; k += 4) {
+            const uint32_t ye = min(k + 4, h);
+            for (uint32_t x = 0; x < w; ++x) {
+                if (type == 0) {                                       // significance propagation (T1.cpp:1024-1152)
+                    for (uint32_t y = k; y < ye; ++y) {
+                        if (((sig[y + 1] | pi[y + 1]) >> x) & 1ull) continue;
+                        if (!has_sig_nb(x, y)) continue;
+                        if (mq.decode(kCtxZC + zc_ctx(x, y))) make_significant(x, y, oph);
+                        pi[y + 1] |= 1ull << x;
+                    }
+                } else if (type == 1) {                                // magnitude refinement (T1.cpp:1160-1255)
+                    for (uint32_t y = k; y < ye; ++y) {
+                        if (!((sig[y + 1] >> x) & 1ull) || ((pi[y + 1] >> x) & 1ull)) continue;
+                        const int cxn = ((mu[y + 1] >> x) & 1ull) ? 16 : (has_sig_nb(x, y) ? 15 : 14);
+                        const uint32_t b = mq.decode(cxn);
+                        int32_t* v = &ws[(size_t)(y * 64u + x) * L];
+                        const int32_t cur = *v;
+                        *v = cur + ((b ^ (uint32_t)(cur < 0)) ? poshalf : -poshalf);
+                        mu[y + 1] |= 1ull << x;
+                    }
+                } else {                                               // cleanup (T1.cpp:854-1007)
+                    uint32_t y = k;
+                    if (k + 4 <= h) {
+                        bool quiet = true;
+                        for (uint32_t j = 0; j < 4; ++j)
+                            quiet = quiet && !(((sig[k + j + 1] | pi[k + j + 1]) >> x) & 1ull) && !has_sig_nb(x, k + j);
+                        if (quiet) {
+                            if (!mq.decode(kCtxAgg)) continue;
+                            uint32_t r = mq.decode(kCtxUni);
+                            r = (r << 1) | mq.decode(kCtxUni);
+                            make_significant(x, k + r, oph);
+                            y = k + r + 1;
+                        }
+                    }
+                    for (; y < ye; ++y) {
+                        if (((sig[y + 1] | pi[y + 1]) >> x) & 1ull) continue;
+                        if (mq.decode(kCtxZC + zc_ctx(x, y))) make_significant(x, y, oph);
+                    }
+                }
+            }
+        }
+        if (type == 2) for (int i = 0; i < 66; ++i) pi[i] = 0;
+        if (++type == 3) { type = 0; --bp; }
+    }
+}
+
+// K8b: workspace -> dequantise -> Mallat plane (one wavefront per code-block, lane <-> column)
+template <bool IRREV>
+__global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a, uint32_t L)
+{
+    const uint32_t blk = blockIdx.x, x = threadIdx.x;
+    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
+    const uint32_t tile = blk / a.blocks_per_tile;
+    if (x >= bd.w) return;
+    const int32_t* ws = a.work + (size_t)(blk / L) * 4096u * L + (blk % L);
+    int32_t* dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
+    const float scale = bd.inv_step / 2;                            // ScaleFilter: stepsize / 2
+    for (uint32_t y = 0; y < bd.h; ++y) {
+        const int32_t v = ws[(size_t)(y * 64u + x) * L];
+        int32_t o;
+        if constexpr (IRREV) o = __float_as_int(__fmul_rn((float)v, scale));
+        else o = v / 2;                                             // ShiftFilter: truncation toward zero
+        dst[(size_t)y * a.stride + x] = o;
+    }
+}
+
+} // namespace
+
+uint32_t t1_lanes_per_group(uint32_t nblocks)
+{
+    uint32_t lanes = 64;
+    while (lanes > 16 && (nblocks + lanes - 1) / lanes < 1280) lanes >>= 1;
+    return lanes;
+}
+
+hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s)
+{
+    const uint32_t L = t1_lanes_per_group(a.nblocks);
+    hipLaunchKernelGGL(t1_dec_kernel, dim3((a.nblocks + L - 1) / L), dim3(L), 0, s, a);
+    if (a.irreversible)
+        hipLaunchKernelGGL(t1_store_kernel<true>, dim3(a.nblocks), dim3(64), 0, s, a, L);
+    else
+        hipLaunchKernelGGL(t1_store_kernel<false>, dim3(a.nblocks), dim3(64), 0, s, a, L);
+    return hipGetLastError();
+}
+
+} // namespace grk_amd

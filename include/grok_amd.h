@@ -57,7 +57,9 @@ typedef struct grk_amd_tile_params {
     uint8_t  num_levels;         /* numresolution - 1                                           */
     uint8_t  cblk_w_exp;         /* log2 code-block width  (6)                                  */
     uint8_t  cblk_h_exp;         /* log2 code-block height (6)                                  */
-    uint8_t  reserved[3];
+    uint8_t  reserved[3];        /* [0]: decode only -- 1 = the blocks are Part-1 (EBCOT/MQ, code-block
+                                    style 0) instead of HT; then missing_msbs of a table row carries
+                                    numbps | numpasses << 8 (block bit-planes coded, coding passes)   */
 } grk_amd_tile_params;
 
 /* One code-block of the tile, in the reference's enumeration order

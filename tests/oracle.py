@@ -91,6 +91,13 @@ def t1_dequant_rev(v):
     return out
 
 
+def t1_dequant_irrev(v, stepsize):
+    a = np.ascontiguousarray(v, np.int32)
+    out = np.zeros(a.shape, np.float32)
+    lib().orc_t1_dequant_irrev(a.ctypes.data, a.size, float(stepsize), out.ctypes.data)
+    return out
+
+
 def ht_decode_block(coded, missing_msbs, w, h):
     """-> (h, w) uint32 sign-magnitude words, or None for a stream the decoder rejects."""
     buf = np.frombuffer(bytes(coded), np.uint8).copy()

@@ -203,3 +203,96 @@ def test_round_trip_8k_property():
     c.decode_device(p, 1, table, c.coded_device_ptr(), tot, d_out.data_ptr())
     c.decode_status()
     assert torch.equal(d_out, d_px)
+
+
+# ---- K8: Part-1 (EBCOT/MQ) block decoder ------------------------------------
+import refharness as R
+
+needs_ref = pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not shipped")
+
+
+def _part1_tile(px, prec, L):
+    """Forward chain on the CPU (oracle RCT + 5/3), every block coded by Grok's own Part-1 T1."""
+    C, H, W = px.shape
+    p = G.TileParams.make(W, H, C, prec, L, part1=True)
+    blocks, _ = G.tile_layout(p)
+    planes = [px[c].astype(np.int32) - (1 << (prec - 1)) for c in range(C)]
+    if C >= 3:
+        planes[:3] = O.rct_fwd(*planes[:3])
+    mall = [O.dwt53_fwd(v, L) for v in planes]
+    table = np.zeros(len(blocks), G.capi.CODED_DTYPE)
+    chunks, off = [], 0
+    for i, b in enumerate(blocks):
+        bw, bh = b.x1 - b.x0, b.y1 - b.y0
+        cb, npass, nbps = R.t1_encode_block(mall[b.comp][b.py:b.py + bh, b.px:b.px + bw], b.band)
+        table["offset"][i] = off; table["length"][i] = len(cb); table["missing_msbs"][i] = nbps | (npass << 8)
+        chunks.append(cb + b"\0" * (-len(cb) % 16 + 16)); off += len(chunks[-1])
+    return p, blocks, mall, table, b"".join(chunks)
+
+
+@needs_ref
+@pytest.mark.parametrize("C,H,W,prec,L,gen", [(1, 128, 128, 8, 3, "g2"), (3, 96, 160, 8, 4, "g2"), (3, 100, 77, 12, 3, "g2"),
+                                               (1, 64, 64, 8, 0, "g0"), (3, 256, 256, 8, 5, "g0")])
+def test_part1_decode_round_trip(C, H, W, prec, L, gen):
+    """Blocks from the reference's EBCOT encoder -> GPU (MQ decode, dequantise, inverse 5/3, inverse RCT)
+    == source pixels; the Mallat planes after K8 equal the coefficients that were coded."""
+    px = getattr(synth, gen)(C, H, W, prec)
+    p, blocks, mall, table, coded = _part1_tile(px, prec, L)
+    d_c = U.to_dev(np.frombuffer(coded, np.uint8))
+    d_m = U.dev_planes(p, C)
+    U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
+    U.ctx().synchronize()
+    got = U.planes_to_numpy(d_m, p, C)
+    for c in range(C):
+        assert np.array_equal(got[c], mall[c]), "component %d" % c
+    back = U.ctx().decode_host(p, table, coded)
+    assert np.array_equal(back[0], px)
+
+
+@needs_ref
+def test_part1_decode_truncated_passes_equal_oracle():
+    """Fewer passes than coded (quality-layer truncation): GPU == oracle == reference T1, block by block."""
+    rng = np.random.default_rng(11)
+    p = G.TileParams.make(256, 192, 1, 10, 2, part1=True)
+    blocks, _ = G.tile_layout(p)
+    table = np.zeros(len(blocks), G.capi.CODED_DTYPE)
+    chunks, off, want = [], 0, np.zeros((192, 256), np.int32)
+    for i, b in enumerate(blocks):
+        bw, bh = b.x1 - b.x0, b.y1 - b.y0
+        coef = (rng.integers(-400, 400, size=(bh, bw)) >> rng.integers(0, 9, size=(bh, bw))).astype(np.int32)
+        cb, npass, nbps = R.t1_encode_block(coef, b.band)
+        keep = max(1, npass - int(rng.integers(0, 6)))
+        table["offset"][i] = off; table["length"][i] = len(cb); table["missing_msbs"][i] = nbps | (keep << 8)
+        chunks.append(cb + b"\0" * (-len(cb) % 16 + 16)); off += len(chunks[-1])
+        want[b.py:b.py + bh, b.px:b.px + bw] = O.t1_dequant_rev(O.t1_decode_block(cb, keep, nbps, b.band, bw, bh))
+    d_c = U.to_dev(np.frombuffer(b"".join(chunks), np.uint8))
+    d_m = U.dev_planes(p, 1)
+    U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
+    U.ctx().synchronize()
+    assert np.array_equal(U.planes_to_numpy(d_m, p, 1)[0], want)
+
+
+@needs_ref
+def test_part1_decode_irreversible_dequant():
+    """ScaleFilter path: (float)v * stepsize/2 with the band's step from the QCD words (Quantizer.cpp:41-45,
+    decode side: log2_gain 0); the entropy-decoded integers are the same as in the reversible case."""
+    rng = np.random.default_rng(21)
+    prec, L = 10, 3
+    p = G.TileParams.make(192, 128, 1, prec, L, irreversible=True, mct=False, part1=True)
+    blocks, qcd = G.tile_layout(p)
+    table = np.zeros(len(blocks), G.capi.CODED_DTYPE)
+    chunks, off, want = [], 0, np.zeros((128, 192), np.float32)
+    for i, b in enumerate(blocks):
+        bw, bh = b.x1 - b.x0, b.y1 - b.y0
+        coef = (rng.integers(-300, 300, size=(bh, bw)) >> rng.integers(0, 8, size=(bh, bw))).astype(np.int32)
+        cb, npass, nbps = R.t1_encode_block(coef, b.band)
+        table["offset"][i] = off; table["length"][i] = len(cb); table["missing_msbs"][i] = nbps | (npass << 8)
+        chunks.append(cb + b"\0" * (-len(cb) % 16 + 16)); off += len(chunks[-1])
+        wq = qcd[chain.band_index(b)]
+        step = np.float32((1.0 + (wq & 0x7FF) / 2048.0) * 2.0 ** (prec - (wq >> 11)))
+        want[b.py:b.py + bh, b.px:b.px + bw] = O.t1_dequant_irrev(O.t1_decode_block(cb, npass, nbps, b.band, bw, bh), step)
+    d_c = U.to_dev(np.frombuffer(b"".join(chunks), np.uint8))
+    d_m = U.dev_planes(p, 1)
+    U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
+    U.ctx().synchronize()
+    assert np.array_equal(U.planes_to_numpy(d_m, p, 1)[0], want.view(np.int32))
