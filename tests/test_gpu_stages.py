@@ -212,3 +212,21 @@ def test_gpu_8k_properties():
         b = blocks[i]
         sm = O.signmag(mall[b.comp][b.py:b.py + (b.y1 - b.y0), b.px:b.px + (b.x1 - b.x0)], b.kmax)
         assert b1[i] == O.ht_encode_sm(sm, b.kmax), "block %d" % i
+
+
+# ---- irreversible path (ICT + 9/7 + dead-zone quantiser + HT): BASELINE configs[2] shape -----------
+import chain
+
+
+@pytest.mark.parametrize("C,H,W,prec,L", [(3, 128, 192, 8, 3), (3, 256, 256, 16, 5), (1, 100, 77, 12, 2), (4, 64, 96, 10, 3)])
+def test_encode_irreversible_blocks_vs_oracle(C, H, W, prec, L):
+    """Whole irreversible encode on the GPU (fused ingest + 9/7, quantiser inside K3) == the oracle chain,
+    block for block; the oracle chain's codestreams are pinned to grk_decompress in test_oracle_decode.py
+    (the reference's own HT 9/7 *encoder* is unusable as an oracle: defect D1)."""
+    px = synth.g2(C, H, W, prec)
+    p, blocks, qcd, otable, ocoded = chain.encode_tile_oracle(px, prec, L, irrev=True)
+    table, coded = U.ctx().encode_host(p, px)
+    got = U.split_blocks(table, coded)
+    want = [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
+    bad = [i for i in range(len(blocks)) if got[i] != want[i]]
+    assert not bad, "blocks differing from the oracle: %s" % bad[:10]
