@@ -85,6 +85,7 @@ def lib():
         L.grk_amd_stage_ht_decode.argtypes = [vp, PP, u32, vp, vp, u64, vp]
         L.grk_amd_decode_tiles.argtypes = [vp, PP, u32, vp, vp, u64, i32, vp, i32]
         L.grk_amd_decode_status.argtypes = [vp]
+        L.grk_amd_set_decode_qcd.argtypes = [vp, vp, u32]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
         L.grk_amd_kernel_ms.restype = C.c_double
@@ -226,6 +227,10 @@ class Context:
         t = np.ascontiguousarray(table)
         self._check(self._L.grk_amd_decode_tiles(self._h, C.byref(params), ntiles, t.ctypes.data, d_coded, coded_bytes, 1,
                                                  d_pixels, 1), "decode_tiles")
+
+    def set_decode_qcd(self, words):
+        w = np.ascontiguousarray(words, np.uint16)
+        self._check(self._L.grk_amd_set_decode_qcd(self._h, w.ctypes.data if w.size else None, w.size), "set_decode_qcd")
 
     def decode_status(self):
         self._check(self._L.grk_amd_decode_status(self._h), "decode_status")

@@ -56,6 +56,7 @@ struct grk_amd_ctx {
     bool have_geom = false;
     TileGeom geom;
     std::vector<HtBlockDesc> h_desc, h_desc_dec;
+    std::vector<uint16_t> dec_qcd;                          // decode: QCD words of a foreign stream (optional)
     HtClass ht_classes[2]; uint32_t ht_num_classes = 0;     // block classes of K3 (by LDS need)
     DevBuf ht_sel;
     std::vector<uint64_t> h_off;
@@ -155,7 +156,7 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
                 float scale = 1.0f;
                 if (p->irreversible) {
                     const uint32_t bi = b.res == 0 ? 0u : 3u * b.res - 2u + (b.band - 1u);
-                    const uint16_t wq = g.qcd_words[bi];
+                    const uint16_t wq = (c->dec_qcd.size() == g.num_bands_total) ? c->dec_qcd[bi] : g.qcd_words[bi];
                     const double step = (1.0 + (wq & 0x7FF) / 2048.0) * std::pow(2.0, (int)p->prec - (int)(wq >> 11));
                     scale = (float)step;
                     if (!p->reserved[0]) scale /= (float)(1u << (31 - b.kmax));     // HT only (Quantizer.cpp:54-63)
@@ -578,6 +579,14 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         HIP_TRY(c, hipMemcpyAsync(pixels, d_px, px_bytes, hipMemcpyDeviceToHost, c->stream), "download pixels");
         return check_decode_status(c);
     }
+    return GRK_AMD_OK;
+}
+
+int grk_amd_set_decode_qcd(grk_amd_ctx* c, const uint16_t* words, uint32_t count)
+{
+    if (!c || (count && !words)) return GRK_AMD_ERR_INVALID;
+    c->dec_qcd.assign(words, words + count);
+    c->have_geom = false;                  // the per-block dequantisation scales are rebuilt on the next call
     return GRK_AMD_OK;
 }
 

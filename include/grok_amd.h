@@ -151,6 +151,10 @@ int grk_amd_decode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes,
                          int coded_on_device, void* pixels, int pixels_on_device);
 int grk_amd_decode_status(grk_amd_ctx* ctx);
+/* Irreversible streams of another encoder: the SPqcd words (expn << 11 | mant, one per sub-band in QCD
+ * order) its QCD marker carries, from which the decode-side step sizes are derived
+ * (codestream/Quantizer.cpp:41-63).  count = 0 returns to the exponents this library's encoder writes. */
+int grk_amd_set_decode_qcd(grk_amd_ctx* ctx, const uint16_t* words, uint32_t count);
 /* HT cleanup decode + dequantisation of every block into Mallat planes (device pointers) */
 int grk_amd_stage_ht_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
                             const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes,

@@ -296,3 +296,48 @@ def test_part1_decode_irreversible_dequant():
     U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
     U.ctx().synchronize()
     assert np.array_equal(U.planes_to_numpy(d_m, p, 1)[0], want.view(np.int32))
+
+
+# ---- streams of the reference's OWN encoders, through the test-side Tier-2 reader ------------------------
+import j2kparse as J
+
+
+def _gpu_decode_reference_stream(cs, part1):
+    info = J.parse(cs)
+    p = G.TileParams.make(info["W"], info["H"], info["C"], info["prec"], info["levels"],
+                          irreversible=bool(info["irreversible"]), mct=bool(info["mct"]), part1=part1)
+    blocks, _ = G.tile_layout(p)
+    rows, data = J.decode_table(info, blocks, part1)
+    table = np.array(rows, dtype=G.capi.CODED_DTYPE)
+    c = U.ctx()
+    c.set_decode_qcd([(e << 11) | m for e, m in info["qcd"]] if info["irreversible"] else [])
+    try:
+        return c.decode_host(p, table, data)[0]
+    finally:
+        c.set_decode_qcd([])
+
+
+@needs_ref
+@pytest.mark.parametrize("C,H,W,prec,numres", [(3, 96, 160, 8, 5), (1, 128, 128, 8, 4), (3, 256, 256, 12, 6), (3, 100, 77, 8, 3)])
+@pytest.mark.parametrize("ht", [1, 0])
+def test_decode_reference_lossless_stream(C, H, W, prec, numres, ht):
+    """grk_compress output (HT and Part-1, RCT + 5/3) decoded on the GPU == the source == grk_decompress."""
+    px = synth.g2(C, H, W, prec)
+    cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=ht)
+    got = _gpu_decode_reference_stream(cs, part1=not ht)
+    assert np.array_equal(got, px)
+    assert np.array_equal(got.astype(np.int32), R.decode(cs, C, H, W))
+
+
+@needs_ref
+@pytest.mark.parametrize("C,H,W,prec,numres", [(3, 96, 160, 8, 5), (1, 128, 128, 8, 4), (3, 256, 256, 12, 6), (3, 100, 77, 8, 3)])
+def test_decode_reference_part1_irreversible_stream(C, H, W, prec, numres):
+    """BASELINE configs[4] shape: Part-1 EBCOT + ICT + 9/7 coded by the reference, decoded on the GPU (MQ decode,
+    ScaleFilter, inverse 9/7, inverse ICT) == grk_decompress pixel for pixel; and close to the source."""
+    px = synth.g2(C, H, W, prec)
+    cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=0, irrev=1)
+    got = _gpu_decode_reference_stream(cs, part1=True).astype(np.int32)
+    ref = R.decode(cs, C, H, W)
+    if C == 3:      # (without MCT the reference's irreversible encoder scales by 2048, TileProcessor.cpp:928-931: not a usable source)
+        assert np.abs(ref - px.astype(np.int32)).max() <= max(2, (1 << prec) // 64)
+    assert np.array_equal(got, ref)

@@ -46,3 +46,54 @@ def test_t1_decode_truncated_pass_sequence(keep):
     cb, npass, nbps = R.t1_encode_block(coef, 3)
     k = min(keep, npass)
     assert np.array_equal(O.t1_decode_block(cb, k, nbps, 3, 64, 64), R.t1_decode_block(cb, k, nbps, 3, 64, 64))
+
+
+# ---- whole Part-1 streams of the reference encoder through the test-side Tier-2 reader ------------------
+import grok_amd as G
+import chain
+import j2kparse as J
+import synth
+
+
+def _oracle_decode_stream(cs, part1):
+    info = J.parse(cs)
+    W, H, Cn, prec, L, irrev = info["W"], info["H"], info["C"], info["prec"], info["levels"], bool(info["irreversible"])
+    p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev, mct=bool(info["mct"]), part1=part1)
+    blocks, _ = G.tile_layout(p)
+    rows, data = J.decode_table(info, blocks, part1)
+    mall = [np.zeros((H, W), np.float32 if irrev else np.int32) for _ in range(Cn)]
+    for (off, ln, extra), b in zip(rows, blocks):
+        bw, bh = b.x1 - b.x0, b.y1 - b.y0
+        if not ln:
+            continue
+        expn, mant = info["qcd"][chain.band_index(b)]
+        if part1:
+            v = O.t1_decode_block(data[off:off + ln], extra >> 8, extra & 0xFF, b.band, bw, bh)
+            if irrev:
+                v = O.t1_dequant_irrev(v, np.float32((1.0 + mant / 2048.0) * 2.0 ** (prec - expn)))
+            else:
+                v = O.t1_dequant_rev(v)
+        else:
+            sm = O.ht_decode_block(data[off:off + ln], extra, bw, bh)
+            v = O.ht_dequant_rev(sm, extra)
+        mall[b.comp][b.py:b.py + bh, b.px:b.px + bw] = v
+    planes = [O.dwt97_inv(m, L) if irrev else O.dwt53_inv(m, L) for m in mall]
+    planes = [pl.view(np.int32) if irrev else pl for pl in planes]
+    return np.stack(O.color_inv_store(planes, prec, irrev, bool(info["mct"])))
+
+
+@pytest.mark.parametrize("C,H,W,prec,numres", [(3, 96, 160, 8, 5), (1, 128, 128, 8, 4), (3, 128, 128, 12, 6)])
+@pytest.mark.parametrize("irrev", [0, 1])
+def test_reference_part1_stream_oracle_chain_equals_grk_decompress(C, H, W, prec, numres, irrev):
+    """BASELINE configs[4] shape on the CPU: a Part-1 stream written by grk_compress, its blocks recovered by the
+    test-side T2 reader, decoded by the oracle chain (MQ decode -> ShiftFilter/ScaleFilter -> inverse 5/3 | 9/7
+    -> inverse RCT/ICT) == grk_decompress, pixel for pixel."""
+    px = synth.g2(C, H, W, prec)
+    cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=0, irrev=irrev)
+    assert np.array_equal(_oracle_decode_stream(cs, True), R.decode(cs, C, H, W))
+
+
+def test_reference_ht_stream_through_t2_reader():
+    px = synth.g2(3, 96, 160, 8)
+    cs, _ = R.encode(px, 8, numres=5, mode=1)
+    assert np.array_equal(_oracle_decode_stream(cs, False), px.astype(np.int32))
