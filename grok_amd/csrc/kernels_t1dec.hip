@@ -8,12 +8,14 @@
 // EBCOT decoding is one dependent chain per code-block: every MQ decision renormalises the
 // interval the next one uses and every context depends on the samples decoded so far.  As in K5a the
 // parallelism is therefore ACROSS blocks:
-//  K8a t1_dec_kernel  -- one lane per code-block.  Significance / sign / visited / refined state is
-//      kept as one 64-bit row bitmap each (code-blocks are at most 64 wide), so a sample's whole
-//      8-neighbourhood is three 3-bit windows; all lanes of a wave walk (stripe, column, row) in
-//      lockstep, which makes the per-lane bitmap arrays (scratch) and the transposed value workspace
-//      coalesced across lanes; the 19 context states and the MQ table live in LDS; coded bytes come
-//      through the word-ahead cursor.
+//  K8a t1_dec_kernel  -- one lane per code-block, 16 lanes per workgroup.  Significance / sign / visited /
+//      refined state is kept as one 64-bit row bitmap each (code-blocks are at most 64 wide), so a
+//      sample's whole 8-neighbourhood is three 3-bit windows.  The bitmaps (2 KiB per block), the 19
+//      context states and the MQ table live in LDS -- every decision reads them on the serial chain, and
+//      in scratch (= global memory) each access cost a full memory latency: 129 ms for 12 288 blocks.
+//      Decoded values go to a transposed global workspace with fire-and-forget stores/atomics, so that
+//      they never stall the chain; all lanes walk (stripe, column, row) in lockstep, which makes those
+//      accesses and the LDS rows conflict-free.
 //  K8b t1_store_kernel -- one wavefront per code-block: workspace -> dequantise -> Mallat plane rows.
 #include "kernels.h"
 
@@ -37,7 +39,7 @@ __device__ const uint32_t g_mq_table[47] = {
 #undef MQROW
 
 constexpr int kCtxZC = 0, kCtxAgg = 17, kCtxUni = 18, kNumCtx = 19;
-constexpr uint32_t kMaxLanes = 64;
+constexpr uint32_t kMaxLanes = 16;            // lanes (= code-blocks) per workgroup: 16 x 2 KiB of bitmaps
 
 struct MqDec {
     const uint8_t* d; uint32_t len, pos;        // pos = index of the byte the reference's `bp` points at
@@ -108,6 +110,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
 {
     __shared__ uint32_t mq_l[47];
     __shared__ uint8_t ctx_l[kMaxLanes][20];
+    __shared__ uint64_t bm_l[4][66][kMaxLanes];
     for (uint32_t i = threadIdx.x; i < 47; i += blockDim.x) mq_l[i] = g_mq_table[i];
     __syncthreads();
     const uint32_t L = blockDim.x;
@@ -125,8 +128,13 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     if (in.length == 0 || numpasses == 0 || numbps == 0) return;
     if (numbps >= 25u) { atomicOr(a.status, 4u); return; }         // k_max_bit_planes (t1_common.h:70)
 
-    // row bitmaps with one border row above and below: index y + 1
-    uint64_t sig[66], neg[66], pi[66], mu[66];
+    // row bitmaps with one border row above and below (index y + 1), [row][lane] so that lanes never share a bank
+    struct Rows {
+        uint64_t* p;
+        __device__ __forceinline__ uint64_t& operator[](uint32_t i) const { return p[i * kMaxLanes]; }
+    };
+    const Rows sig{&bm_l[0][0][threadIdx.x]}, neg{&bm_l[1][0][threadIdx.x]}, pi{&bm_l[2][0][threadIdx.x]},
+               mu{&bm_l[3][0][threadIdx.x]};
     for (int i = 0; i < 66; ++i) { sig[i] = 0; neg[i] = 0; pi[i] = 0; mu[i] = 0; }
 
     MqDec mq;
@@ -198,9 +206,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                         if (!((sig[y + 1] >> x) & 1ull) || ((pi[y + 1] >> x) & 1ull)) continue;
                         const int cxn = ((mu[y + 1] >> x) & 1ull) ? 16 : (has_sig_nb(x, y) ? 15 : 14);
                         const uint32_t b = mq.decode(cxn);
-                        int32_t* v = &ws[(size_t)(y * 64u + x) * L];
-                        const int32_t cur = *v;
-                        *v = cur + ((b ^ (uint32_t)(cur < 0)) ? poshalf : -poshalf);
+                        const uint32_t isneg = (uint32_t)(neg[y + 1] >> x) & 1u;        // sign of the value, without reading it back
+                        atomicAdd(&ws[(size_t)(y * 64u + x) * L], (b ^ isneg) ? poshalf : -poshalf);
                         mu[y + 1] |= 1ull << x;
                     }
                 } else {                                               // cleanup (T1.cpp:854-1007)
@@ -253,9 +260,8 @@ __global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a, uint32_t L)
 
 uint32_t t1_lanes_per_group(uint32_t nblocks)
 {
-    uint32_t lanes = 64;
-    while (lanes > 16 && (nblocks + lanes - 1) / lanes < 1280) lanes >>= 1;
-    return lanes;
+    (void)nblocks;
+    return kMaxLanes;
 }
 
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s)
