@@ -143,95 +143,140 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     mq.cx = ctx_l[threadIdx.x]; mq.tab = mq_l;
     mq.init();
 
-    // sign of a newly significant sample (Tables D.2, D.3) and state update
-    auto make_significant = [&](uint32_t x, uint32_t y, int32_t oneplushalf) {
-        const uint64_t s1 = sig[y + 1], n1 = neg[y + 1];
-        // horizontal: left/right neighbours; vertical: above/below
-        auto contrib = [](uint32_t sa, uint32_t na, uint32_t sb, uint32_t nb) {
-            int s = (sa ? (na ? -1 : 1) : 0) + (sb ? (nb ? -1 : 1) : 0);
-            return s > 1 ? 1 : (s < -1 ? -1 : s);
-        };
-        const uint32_t ws1 = win3(s1, x), wn1 = win3(n1, x);
-        const int hc = contrib(ws1 & 1u, wn1 & 1u, (ws1 >> 2) & 1u, (wn1 >> 2) & 1u);
-        const int vc = contrib((uint32_t)(sig[y] >> x) & 1u, (uint32_t)(neg[y] >> x) & 1u,
-                               (uint32_t)(sig[y + 2] >> x) & 1u, (uint32_t)(neg[y + 2] >> x) & 1u);
-        int cxn, xr;
-        if (hc == 1)      { cxn = vc == 1 ? 13 : (vc == 0 ? 12 : 11); xr = 0; }
-        else if (hc == 0) { cxn = vc == 0 ? 9 : 10; xr = vc == -1; }
-        else              { cxn = vc == 1 ? 11 : (vc == 0 ? 12 : 13); xr = 1; }
-        const uint32_t ng = mq.decode(cxn) ^ (uint32_t)xr;
-        ws[(size_t)(y * 64u + x) * L] = ng ? -oneplushalf : oneplushalf;
-        sig[y + 1] |= 1ull << x;
-        if (ng) neg[y + 1] |= 1ull << x;
-    };
-    // zero-coding context (Table D.1) from the three row windows
-    auto zc_ctx = [&](uint32_t x, uint32_t y) -> int {
-        const uint32_t w0 = win3(sig[y], x), w1 = win3(sig[y + 1], x), w2 = win3(sig[y + 2], x);
-        int hh = (int)(w1 & 1u) + (int)((w1 >> 2) & 1u);
-        int vv = (int)((w0 >> 1) & 1u) + (int)((w2 >> 1) & 1u);
-        const int dd = (int)(w0 & 1u) + (int)((w0 >> 2) & 1u) + (int)(w2 & 1u) + (int)((w2 >> 2) & 1u);
-        if (orient == 1) { const int s = hh; hh = vv; vv = s; }
-        if (orient == 3) {
-            const int hv = hh + vv;
-            if (dd >= 3) return 8;
-            if (dd == 2) return hv >= 1 ? 7 : 6;
-            if (dd == 1) return hv >= 2 ? 5 : (hv == 1 ? 4 : 3);
-            return hv >= 2 ? 2 : hv;
-        }
-        if (hh == 2) return 8;
-        if (hh == 1) return vv >= 1 ? 7 : (dd >= 1 ? 6 : 5);
-        if (vv == 2) return 4;
-        if (vv == 1) return 3;
-        return dd >= 2 ? 2 : dd;
-    };
-    auto has_sig_nb = [&](uint32_t x, uint32_t y) -> bool {
-        return ((win3(sig[y], x) | win3(sig[y + 2], x)) | (win3(sig[y + 1], x) & 5u)) != 0;
-    };
+    // ---- the passes work stripe by stripe with the stripe's rows in REGISTERS: S[j+1] / N[j+1] are the
+    //      significance / sign rows of stripe row j (S[0], S[5]: the rows above and below), P[j] / M[j] its
+    //      visited / refined rows.  Columns that cannot code anything are skipped with a candidate mask.
+    const uint64_t wmask = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+    auto dil = [](uint64_t v) { return v | (v << 1) | (v >> 1); };
 
     int bp = (int)numbps, type = 2;
     for (uint32_t p = 0; p < numpasses && bp >= 1; ++p) {
         const int32_t one = 1 << bp, oph = one | (one >> 1), poshalf = one >> 1;
         for (uint32_t k = 0; k < h; k += 4) {
-            const uint32_t ye = min(k + 4, h);
-            for (uint32_t x = 0; x < w; ++x) {
-                if (type == 0) {                                       // significance propagation (T1.cpp:1024-1152)
-                    for (uint32_t y = k; y < ye; ++y) {
-                        if (((sig[y + 1] | pi[y + 1]) >> x) & 1ull) continue;
-                        if (!has_sig_nb(x, y)) continue;
-                        if (mq.decode(kCtxZC + zc_ctx(x, y))) make_significant(x, y, oph);
-                        pi[y + 1] |= 1ull << x;
+            uint64_t S[6], N[6], P[4], M[4];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { S[j] = sig[k + j]; N[j] = neg[k + j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { P[j] = pi[k + 1 + j]; M[j] = mu[k + 1 + j]; }
+            const uint32_t nr = min(4u, h - k);
+            // rows of the stripe that do not exist behave as "already coded"
+            uint64_t rowok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rowok[j] = (uint32_t)j < nr ? wmask : 0ull;
+
+            // per-sample pieces (j is a compile-time constant after unrolling)
+#define T1_SIGN_AND_SET(j, x)                                                                                     \
+            {                                                                                                     \
+                const uint32_t ws1 = win3(S[(j) + 1], x), wn1 = win3(N[(j) + 1], x);                              \
+                const uint32_t su = (uint32_t)(S[(j)] >> (x)) & 1u, nu = (uint32_t)(N[(j)] >> (x)) & 1u;          \
+                const uint32_t sd = (uint32_t)(S[(j) + 2] >> (x)) & 1u, nd = (uint32_t)(N[(j) + 2] >> (x)) & 1u;  \
+                int hc = (int)((ws1 & 1u) ? ((wn1 & 1u) ? -1 : 1) : 0) + (int)((ws1 & 4u) ? ((wn1 & 4u) ? -1 : 1) : 0); \
+                int vc = (int)(su ? (nu ? -1 : 1) : 0) + (int)(sd ? (nd ? -1 : 1) : 0);                           \
+                hc = max(-1, min(1, hc)); vc = max(-1, min(1, vc));                                               \
+                int cxn, xr;                                                                                      \
+                if (hc == 1)      { cxn = vc == 1 ? 13 : (vc == 0 ? 12 : 11); xr = 0; }                            \
+                else if (hc == 0) { cxn = vc == 0 ? 9 : 10; xr = vc == -1; }                                      \
+                else              { cxn = vc == 1 ? 11 : (vc == 0 ? 12 : 13); xr = 1; }                            \
+                const uint32_t ng = mq.decode(cxn) ^ (uint32_t)xr;                                                \
+                ws[(size_t)((k + (j)) * 64u + (x)) * L] = ng ? -oph : oph;                                        \
+                S[(j) + 1] |= 1ull << (x);                                                                        \
+                if (ng) N[(j) + 1] |= 1ull << (x);                                                                \
+            }
+            auto zc_ctx = [&](uint32_t w0, uint32_t w1, uint32_t w2) -> int {       // Table D.1
+                int hh = (int)(w1 & 1u) + (int)((w1 >> 2) & 1u);
+                int vv = (int)((w0 >> 1) & 1u) + (int)((w2 >> 1) & 1u);
+                const int dd = (int)(w0 & 1u) + (int)((w0 >> 2) & 1u) + (int)(w2 & 1u) + (int)((w2 >> 2) & 1u);
+                if (orient == 1) { const int t = hh; hh = vv; vv = t; }
+                if (orient == 3) {
+                    const int hv = hh + vv;
+                    if (dd >= 3) return 8;
+                    if (dd == 2) return hv >= 1 ? 7 : 6;
+                    if (dd == 1) return hv >= 2 ? 5 : (hv == 1 ? 4 : 3);
+                    return hv >= 2 ? 2 : hv;
+                }
+                if (hh == 2) return 8;
+                if (hh == 1) return vv >= 1 ? 7 : (dd >= 1 ? 6 : 5);
+                if (vv == 2) return 4;
+                if (vv == 1) return 3;
+                return dd >= 2 ? 2 : dd;
+            };
+
+            if (type == 0) {                                           // significance propagation (T1.cpp:1024-1152)
+                uint32_t x = 0;
+                while (x < w) {
+                    uint64_t cm = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cm |= ~(S[j + 1] | P[j]) & (dil(S[j]) | dil(S[j + 2]) | (S[j + 1] << 1) | (S[j + 1] >> 1)) & rowok[j];
+                    cm &= ~0ull << x;
+                    if (!cm) break;
+                    x = (uint32_t)__ffsll((long long)cm) - 1u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!((rowok[j] >> x) & 1ull) || (((S[j + 1] | P[j]) >> x) & 1ull)) continue;
+                        const uint32_t w0 = win3(S[j], x), w1 = win3(S[j + 1], x), w2 = win3(S[j + 2], x);
+                        if (!((w0 | w2) | (w1 & 5u))) continue;
+                        if (mq.decode(kCtxZC + zc_ctx(w0, w1, w2))) T1_SIGN_AND_SET(j, x)
+                        P[j] |= 1ull << x;
                     }
-                } else if (type == 1) {                                // magnitude refinement (T1.cpp:1160-1255)
-                    for (uint32_t y = k; y < ye; ++y) {
-                        if (!((sig[y + 1] >> x) & 1ull) || ((pi[y + 1] >> x) & 1ull)) continue;
-                        const int cxn = ((mu[y + 1] >> x) & 1ull) ? 16 : (has_sig_nb(x, y) ? 15 : 14);
+                    ++x;
+                }
+            } else if (type == 1) {                                    // magnitude refinement (T1.cpp:1160-1255)
+                uint64_t cm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cm |= S[j + 1] & ~P[j] & rowok[j];
+                while (cm) {
+                    const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
+                    cm &= cm - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!((S[j + 1] & ~P[j] & rowok[j]) >> x & 1ull)) continue;
+                        const uint32_t w0 = win3(S[j], x), w1 = win3(S[j + 1], x), w2 = win3(S[j + 2], x);
+                        const int cxn = ((M[j] >> x) & 1ull) ? 16 : (((w0 | w2) | (w1 & 5u)) ? 15 : 14);    // Table D.4
                         const uint32_t b = mq.decode(cxn);
-                        const uint32_t isneg = (uint32_t)(neg[y + 1] >> x) & 1u;        // sign of the value, without reading it back
-                        atomicAdd(&ws[(size_t)(y * 64u + x) * L], (b ^ isneg) ? poshalf : -poshalf);
-                        mu[y + 1] |= 1ull << x;
+                        const uint32_t isneg = (uint32_t)(N[j + 1] >> x) & 1u;   // the value's sign, without reading it back
+                        atomicAdd(&ws[(size_t)((k + j) * 64u + x) * L], (b ^ isneg) ? poshalf : -poshalf);
+                        M[j] |= 1ull << x;
                     }
-                } else {                                               // cleanup (T1.cpp:854-1007)
-                    uint32_t y = k;
-                    if (k + 4 <= h) {
-                        bool quiet = true;
-                        for (uint32_t j = 0; j < 4; ++j)
-                            quiet = quiet && !(((sig[k + j + 1] | pi[k + j + 1]) >> x) & 1ull) && !has_sig_nb(x, k + j);
-                        if (quiet) {
+                }
+            } else {                                                   // cleanup (T1.cpp:854-1007)
+                uint64_t cm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cm |= ~(S[j + 1] | P[j]) & rowok[j];
+                while (cm) {
+                    const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
+                    cm &= cm - 1;
+                    uint32_t first = 0;                                // first row still to be coded normally
+                    if (nr == 4) {                                     // run-length mode: whole column quiet (D.3.4)
+                        uint64_t busy = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            busy |= S[j + 1] | P[j] | dil(S[j]) | dil(S[j + 2]) | (S[j + 1] << 1) | (S[j + 1] >> 1);
+                        if (!((busy >> x) & 1ull)) {
                             if (!mq.decode(kCtxAgg)) continue;
                             uint32_t r = mq.decode(kCtxUni);
                             r = (r << 1) | mq.decode(kCtxUni);
-                            make_significant(x, k + r, oph);
-                            y = k + r + 1;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) if ((uint32_t)j == r) T1_SIGN_AND_SET(j, x)
+                            first = r + 1;
                         }
                     }
-                    for (; y < ye; ++y) {
-                        if (((sig[y + 1] | pi[y + 1]) >> x) & 1ull) continue;
-                        if (mq.decode(kCtxZC + zc_ctx(x, y))) make_significant(x, y, oph);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if ((uint32_t)j < first || !((rowok[j] >> x) & 1ull) || (((S[j + 1] | P[j]) >> x) & 1ull)) continue;
+                        const uint32_t w0 = win3(S[j], x), w1 = win3(S[j + 1], x), w2 = win3(S[j + 2], x);
+                        if (mq.decode(kCtxZC + zc_ctx(w0, w1, w2))) T1_SIGN_AND_SET(j, x)
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P[j] = 0;                  // the plane is complete
+            }
+#undef T1_SIGN_AND_SET
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sig[k + 1 + j] = S[j + 1]; neg[k + 1 + j] = N[j + 1]; pi[k + 1 + j] = P[j]; mu[k + 1 + j] = M[j];
             }
         }
-        if (type == 2) for (int i = 0; i < 66; ++i) pi[i] = 0;
         if (++type == 3) { type = 0; --bp; }
     }
 }
