@@ -8,11 +8,12 @@
 // EBCOT decoding is one dependent chain per code-block: every MQ decision renormalises the
 // interval the next one uses and every context depends on the samples decoded so far.  As in K5a the
 // parallelism is therefore ACROSS blocks:
-//  K8a t1_dec_kernel  -- one lane per code-block, 16 lanes per workgroup.  Significance / sign / visited /
+//  K8a t1_dec_kernel  -- one lane per code-block, kMaxLanes lanes per workgroup.  Significance / sign / visited /
 //      refined state is kept as one 64-bit row bitmap each (code-blocks are at most 64 wide), so a
 //      sample's whole 8-neighbourhood is three 3-bit windows.  The bitmaps (2 KiB per block), the 19
 //      context states and the MQ table live in LDS -- every decision reads them on the serial chain, and
-//      in scratch (= global memory) each access cost a full memory latency: 129 ms for 12 288 blocks.
+//      in scratch (= global memory) each access costs a full memory latency.  A stripe's rows are held in
+//      registers while it is processed and columns that cannot code anything are skipped by a mask.
 //      Decoded values go to a transposed global workspace with fire-and-forget stores/atomics, so that
 //      they never stall the chain; all lanes walk (stripe, column, row) in lockstep, which makes those
 //      accesses and the LDS rows conflict-free.
@@ -39,7 +40,12 @@ __device__ const uint32_t g_mq_table[47] = {
 #undef MQROW
 
 constexpr int kCtxZC = 0, kCtxAgg = 17, kCtxUni = 18, kNumCtx = 19;
-constexpr uint32_t kMaxLanes = 16;            // lanes (= code-blocks) per workgroup: 16 x 2 KiB of bitmaps
+// Lanes (= code-blocks) per workgroup.  The passes are branchy (which sample codes what differs per block), so
+// the lanes of a wave mostly take turns: measured on 12 288 blocks 16 lanes 80 ms, 4 lanes 38.6 ms, 2 lanes
+// 32.5 ms (issue-bound: a wave instruction costs the same however few lanes are live, but the instruction
+// stream per wave shrinks faster than the number of waves grows).  A single-decode-site formulation that
+// keeps 64 lanes busy is the next step.
+constexpr uint32_t kMaxLanes = 2;
 
 struct MqDec {
     const uint8_t* d; uint32_t len, pos;        // pos = index of the byte the reference's `bp` points at
