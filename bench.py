@@ -243,10 +243,9 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)))
         if cands:
             pm = json.load(open(cands[-1]))
-            key = {"ingest_mct": "ingest_kernel", "dwt53_5levels": "dwt_level_kernel",
-                   "ht_cleanup_encode": "ht_encode_kernel"}[dom]
-            mult = levels if dom == "dwt53_5levels" else 1      # dwt: per-level average x launches per step
-            traffic = int(pm[key]["hbm_bytes_per_launch"] * mult)
+            fams = {"ingest_mct": ("ingest_kernel",), "dwt53_5levels": ("dwt_level0_fused", "dwt_levels_1plus"),
+                    "ht_cleanup_encode": ("ht_encode_kernel",)}[dom]
+            traffic = int(sum(pm[k]["hbm_bytes_per_step"] for k in fams if k in pm)) or None
     except Exception:
         traffic = None
     ach = algo[dom] / (fam[dom][0] * 1e-3) / 1e9 if fam[dom][0] > 0 else 0.0

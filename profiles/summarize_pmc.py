@@ -10,6 +10,10 @@ Units and corrections (same guide):
     (8 B/lane) and reports 398,769 KiB (x2 = 816.7 MB, +1.4 % over the algorithmic bytes).
   * WRITE_SIZE needs no correction: ingest_kernel writes 805,306,368 B and reports 786,432.0 KiB exactly.
 
+Kernel families are reported PER STEP (one encode_tiles / decode_tiles call): a family may be several
+launches (DWT levels, the two Kmax classes of the HT encoder); steps are counted by the one-per-step
+kernels ht_alloc_init_kernel (encode) and ht_dec_vlc_kernel / t1_dec_kernel (decode).
+
 usage: summarize_pmc.py fetch_counter_collection.csv write_counter_collection.csv out.json
 """
 import collections
@@ -17,37 +21,58 @@ import csv
 import json
 import sys
 
+FAMILIES = [  # (family, substring(s) of the kernel name)
+    ("dwt_level0_fused", ("dwt_level_kernel<false, 3, 1>", "dwt_level_kernel<true, 3, 1>", "dwt_level_kernel<false, 3, 2>",
+                          "dwt_level_kernel<true, 3, 2>", "dwt_level_kernel<false, 1, 1>", "dwt_level_kernel<true, 1, 1>",
+                          "dwt_level_kernel<false, 1, 2>", "dwt_level_kernel<true, 1, 2>")),
+    ("dwt_levels_1plus", ("dwt_level_kernel<false, 1, 0>", "dwt_level_kernel<true, 1, 0>")),
+    ("ht_encode_kernel", ("ht_encode_kernel",)),
+    ("ht_dec_vlc_kernel", ("ht_dec_vlc_kernel",)),
+    ("ht_dec_ms_kernel", ("ht_dec_ms_kernel",)),
+    ("t1_dec_kernel", ("t1_dec_kernel",)),
+    ("idwt_level_kernel", ("idwt_level_kernel",)),
+    ("egress_kernel", ("egress_kernel",)),
+    ("ingest_kernel", ("ingest_kernel",)),
+]
 
-def per_kernel(path, counter):
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return acc
 
-
-def short(name):
-    for k in ("ht_encode_kernel", "idwt_level_kernel", "dwt_level_kernel", "ingest_kernel", "ht_dec_vlc_kernel",
-              "ht_dec_ms_kernel", "egress_kernel"):
-        if k in name:
-            return k
+def family(name):
+    for fam, subs in FAMILIES:
+        if any(s in name for s in subs):
+            return fam
     return None
 
 
-def main(fetch_csv, write_csv, out_json):
-    f = per_kernel(fetch_csv, "FETCH_SIZE")
-    w = per_kernel(write_csv, "WRITE_SIZE")
-    out = {}
-    for name in f:
-        k = short(name)
-        if not k or name not in w:
+def totals(path, counter):
+    tot, cnt = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
             continue
-        fr = sum(f[name]) / len(f[name]) * 1024 * 2       # KiB -> B, gfx950 half-count correction
-        wr = sum(w[name]) / len(w[name]) * 1024
-        out[k] = {"launches_sampled": len(f[name]), "hbm_read_bytes_per_launch": int(fr),
-                  "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(fr + wr),
-                  "fetch_size_kib_raw_mean": sum(f[name]) / len(f[name]),
-                  "write_size_kib_raw_mean": sum(w[name]) / len(w[name])}
+        name = r["Kernel_Name"]
+        cnt[name] += 1
+        f = family(name)
+        if f:
+            tot[f] += float(r["Counter_Value"])
+    return tot, cnt
+
+
+def main(fetch_csv, write_csv, out_json):
+    f, fc = totals(fetch_csv, "FETCH_SIZE")
+    w, wc = totals(write_csv, "WRITE_SIZE")
+
+    def steps(cnt, enc):
+        keys = ("ht_alloc_init_kernel",) if enc else ("ht_dec_vlc_kernel", "t1_dec_kernel")
+        return max(1, sum(v for k, v in cnt.items() if any(s in k for s in keys)))
+    out = {}
+    for fam, _ in FAMILIES:
+        if fam not in f and fam not in w:
+            continue
+        enc = fam in ("dwt_level0_fused", "dwt_levels_1plus", "ht_encode_kernel", "ingest_kernel")
+        nf, nw = steps(fc, enc), steps(wc, enc)
+        rd = f.get(fam, 0.0) * 1024 * 2 / nf          # KiB -> B, gfx950 half-count correction
+        wr = w.get(fam, 0.0) * 1024 / nw
+        out[fam] = {"steps_sampled": nf, "hbm_read_bytes_per_step": int(rd), "hbm_write_bytes_per_step": int(wr),
+                    "hbm_bytes_per_step": int(rd + wr)}
     json.dump(out, open(out_json, "w"), indent=1)
     for k, v in out.items():
         print(k, v)
