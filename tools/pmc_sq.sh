@@ -20,7 +20,8 @@ for f in sorted(glob.glob(R+"/gpurun_out/pmc_sq_*.csv")):
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        s="ht" if "ht_encode" in k else "dwt" if "dwt_level" in k else "ingest" if "ingest" in k else None
+        s=("ht" if "ht_encode" in k else "dwt0" if "dwt_level_kernel<false, 3, 1>" in k else "dwtN" if "dwt_level" in k and "idwt" not in k
+           else "idwt" if "idwt_level" in k else "vlc" if "ht_dec_vlc" in k else "ms" if "ht_dec_ms" in k else None)
         if s: acc[(s,r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (s,c),v in sorted(acc.items()):
         print(s,c,sum(v)/len(v),len(v))
