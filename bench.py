@@ -138,16 +138,25 @@ def main():
 
     scratch = None
     last_parts = None
+    # one encode up front: buffers exist, and the arena capacity the exchange may slice from is known
+    ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+    _, total0 = ctx.fetch_table(nblocks)
+    raw_bytes = samples * ((prec + 7) // 8)
+    arena_cap = int(raw_bytes * 2)          # grk_amd allocates >= 2 x raw (context.hip: run_ht)
 
     def step():
         nonlocal scratch, last_parts
         with torch.cuda.stream(stream):
             ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
-        if use_dist:
-            # the path's one real exchange: coded tile-parts of every rank -> rank 0 (RCCL over xGMI)
-            table, total = ctx.fetch_table(nblocks)
-            arena = _as_tensor(ctx.coded_device_ptr(), (total + 4095) & ~4095, dev)
-            last_parts, scratch = D.gather_tile_parts(table, arena, dev, dst=0, scratch=scratch)
+            if use_dist:
+                # the path's one real exchange: coded tile-parts of every rank -> rank 0 (RCCL over xGMI), straight
+                # from the encoder's device-resident table and arena (the collectives are enqueued behind the encode
+                # on this stream; the only host synchronisation is the exchange of the byte counts)
+                used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
+                offs = _as_tensor(ctx.table_device_ptr(0), nblocks, dev, "<i8")
+                lens = _as_tensor(ctx.table_device_ptr(1), nblocks, dev, "<i4")
+                arena = _as_tensor(ctx.coded_device_ptr(), arena_cap, dev)
+                last_parts, scratch = D.gather_tile_parts_device(used, offs, lens, arena, dst=0, scratch=scratch)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -170,7 +179,7 @@ def main():
         dt = float(t.item())
         if rank == 0:
             # the gathered tile-parts really are a codestream: assemble the (N*W) x H image once
-            ft, fc = D.merge_tile_parts(last_parts, world * ntiles, nblocks // ntiles)
+            ft, fc = D.merge_tile_parts(D.parts_to_numpy(last_parts), world * ntiles, nblocks // ntiles)
             if ntiles == 1:
                 cs_len = len(G.write_codestream(params, W * world, H, ft, fc))
             else:
@@ -284,18 +293,28 @@ def main():
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
         elif world == 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes a version banner to stdout through C stdio: flush that first so that the JSON line is the
+    # LAST line on stdout
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if line is not None:
+        print(line, flush=True)
 
 
-def _as_tensor(ptr, nbytes, dev):
-    """Zero-copy uint8 view of a raw device pointer (context-owned arena)."""
+def _as_tensor(ptr, n, dev, typestr="|u1"):
+    """Zero-copy view of a raw device pointer (context-owned memory): n elements of `typestr`."""
     class _Holder:
         pass
     h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    h.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(h, device=dev)
 
 

@@ -75,6 +75,8 @@ def lib():
         L.grk_amd_fetch_coded.argtypes = [vp, vp, u64]
         L.grk_amd_coded_device_ptr.restype = vp
         L.grk_amd_coded_device_ptr.argtypes = [vp]
+        L.grk_amd_table_device_ptr.restype = vp
+        L.grk_amd_table_device_ptr.argtypes = [vp, i32]
         L.grk_amd_plane_device_ptr.restype = vp
         L.grk_amd_plane_device_ptr.argtypes = [vp, i32]
         L.grk_amd_synchronize.argtypes = [vp]
@@ -194,6 +196,9 @@ class Context:
 
     def coded_device_ptr(self):
         return self._L.grk_amd_coded_device_ptr(self._h)
+
+    def table_device_ptr(self, which):
+        return self._L.grk_amd_table_device_ptr(self._h, which)
 
     def plane_device_ptr(self, which):
         return self._L.grk_amd_plane_device_ptr(self._h, which)

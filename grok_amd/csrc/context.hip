@@ -642,6 +642,16 @@ int grk_amd_fetch_coded(grk_amd_ctx* c, uint8_t* dst, uint64_t nbytes)
 }
 
 void* grk_amd_coded_device_ptr(grk_amd_ctx* c) { return c ? c->arena.p : nullptr; }
+void* grk_amd_table_device_ptr(grk_amd_ctx* c, int which)
+{
+    if (!c) return nullptr;
+    switch (which) {
+    case 0: return c->offsets.p;                                    // uint64[nblocks]
+    case 1: return c->lengths.p;                                    // uint32[nblocks]
+    case 2: return c->flag.p ? (uint8_t*)c->flag.p + 8 : nullptr;   // uint64: bytes used in the arena
+    default: return nullptr;
+    }
+}
 void* grk_amd_plane_device_ptr(grk_amd_ctx* c, int which) { return c ? (which ? c->p1.p : c->p0.p) : nullptr; }
 
 int grk_amd_synchronize(grk_amd_ctx* c)

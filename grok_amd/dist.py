@@ -78,6 +78,55 @@ def gather_tile_parts(table, coded, device, dst=0, scratch=None):
     return None, scratch
 
 
+def gather_tile_parts_device(used, offsets, lengths, arena, dst=0, scratch=None):
+    """The same exchange with everything already on the device and ONE host synchronisation (the byte counts,
+    which size the transfer): `used` int64[1] bytes used in `arena` (uint8[>= used]), `offsets` int64[n],
+    `lengths` int32[n] -- views of the encoder's own device table (grk_amd_table_device_ptr).
+    Returns on dst ([(offsets, lengths, coded uint8 tensor) per rank], scratch), elsewhere (None, scratch);
+    parts_to_numpy() turns them into what merge_tile_parts() takes."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = arena.device
+    meta = torch.cat([used.reshape(1).to(torch.int64), torch.tensor([offsets.numel()], dtype=torch.int64, device=device)])
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    m = torch.stack(metas).cpu()                       # the one synchronisation
+    sizes, nrows = [int(v) for v in m[:, 0]], [int(v) for v in m[:, 1]]
+    pad = (max(sizes) + 4095) & ~4095
+    maxrows = max(nrows)
+    if arena.numel() < pad:
+        buf = torch.zeros(pad, dtype=torch.uint8, device=device)
+        buf[:arena.numel()] = arena
+    else:
+        buf = arena[:pad]
+    if offsets.numel() < maxrows:
+        offsets = torch.cat([offsets, offsets.new_zeros(maxrows - offsets.numel())])
+        lengths = torch.cat([lengths, lengths.new_zeros(maxrows - lengths.numel())])
+    if rank == dst:
+        if scratch is None or scratch[0][0].numel() < pad or scratch[1][0].numel() != maxrows:
+            scratch = ([torch.empty(pad, dtype=torch.uint8, device=device) for _ in range(world)],
+                       [torch.empty(maxrows, dtype=torch.int64, device=device) for _ in range(world)],
+                       [torch.empty(maxrows, dtype=torch.int32, device=device) for _ in range(world)])
+        bufs = [s[:pad] for s in scratch[0]]
+        dist.gather(buf, bufs, dst=dst)
+        dist.gather(offsets, scratch[1], dst=dst)
+        dist.gather(lengths, scratch[2], dst=dst)
+        return [(scratch[1][r][:nrows[r]], scratch[2][r][:nrows[r]], bufs[r][:sizes[r]]) for r in range(world)], scratch
+    dist.gather(buf, None, dst=dst)
+    dist.gather(offsets, None, dst=dst)
+    dist.gather(lengths, None, dst=dst)
+    return None, scratch
+
+
+def parts_to_numpy(parts):
+    out = []
+    for offs, lens, coded in parts:
+        t = np.zeros(offs.numel(), CODED_DTYPE)
+        t["offset"] = offs.cpu().numpy().astype(np.uint64)
+        t["length"] = lens.cpu().numpy().astype(np.uint32)
+        out.append((t, coded))
+    return out
+
+
 def merge_tile_parts(parts, ntiles, blocks_per_tile):
     """Rank-major parts (round-robin tile ownership) -> one tile-ordered table + one byte buffer."""
     world = len(parts)

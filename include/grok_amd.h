@@ -121,6 +121,9 @@ int grk_amd_fetch_coded(grk_amd_ctx* ctx, uint8_t* dst, uint64_t nbytes);
 /* device pointers for zero-copy consumers (RCCL gather of tile parts, tests) */
 void* grk_amd_coded_device_ptr(grk_amd_ctx* ctx);
 void* grk_amd_plane_device_ptr(grk_amd_ctx* ctx, int which /*0: ingest planes, 1: Mallat planes*/);
+/* the block table of the last encode where it was produced, for exchanges that never touch the host:
+ * which 0: uint64 offsets[nblocks], 1: uint32 lengths[nblocks], 2: uint64 bytes used in the arena */
+void* grk_amd_table_device_ptr(grk_amd_ctx* ctx, int which);
 int  grk_amd_synchronize(grk_amd_ctx* ctx);
 
 /* ---- stage entry points (parity tests and per-kernel benchmarks call these) ------------------

@@ -54,9 +54,14 @@ def _worker(rank, world, port, q):
     table = np.concatenate(tabs)
     coded = torch.from_numpy(np.concatenate(chunks))
     parts, _ = D.gather_tile_parts(table, coded, dev, dst=0)
+    # the device-resident variant bench.py uses (tables as tensors, one host synchronisation)
+    parts2, _ = D.gather_tile_parts_device(torch.tensor([coded.numel()]), torch.from_numpy(table["offset"].astype(np.int64)),
+                                           torch.from_numpy(table["length"].astype(np.int32)), coded, dst=0)
     if rank == 0:
         full_table, full_coded = D.merge_tile_parts(parts, ntiles, bpt)
         cs = G.write_codestream(p, 256, 256, full_table, full_coded)
+        t2, c2 = D.merge_tile_parts(D.parts_to_numpy(parts2), ntiles, bpt)
+        assert G.write_codestream(p, 256, 256, t2, c2) == cs
         q.put(cs)
     dist.barrier()
     dist.destroy_process_group()
