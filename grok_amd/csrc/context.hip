@@ -215,6 +215,7 @@ int run_ingest(grk_amd_ctx* c, uint32_t ntiles, const void* d_pixels, void* d_pl
     a.ncomp = g.p.num_comps; a.ntiles = ntiles;
     a.bytes_per_sample = (g.p.prec + 7) / 8;
     a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
+    a.sext = g.p.sgnd ? (1 << (8 * a.bytes_per_sample - 1)) : 0;
     a.mct = g.p.mct; a.irreversible = g.p.irreversible;
     ScopedTimer t(c, 0);
     HIP_TRY(c, launch_ingest(a, c->stream), "launch ingest");
@@ -261,6 +262,7 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         if (l == 0 && d_pixels) {
             a.pixels = d_pixels; a.px_bytes = (g.p.prec + 7) / 8;
             a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
+            a.sext = g.p.sgnd ? (1 << (8 * a.px_bytes - 1)) : 0;
             HIP_TRY(c, launch_dwt_level0_fused(a, ntiles, g.p.num_comps, g.p.mct, c->stream), "launch fused dwt level 0");
         } else {
             HIP_TRY(c, launch_dwt_level(a, c->stream), "launch dwt level");

@@ -14,6 +14,7 @@ struct IngestArgs {
     uint32_t ncomp, ntiles;
     uint32_t bytes_per_sample;   // 1 or 2
     int32_t  dc;                 // 2^(prec-1) or 0
+    int32_t  sext;               // signed samples: 1 << (8*bytes_per_sample - 1) (stored as int8/int16), else 0
     int      mct;                // apply RCT/ICT to components 0..2
     int      irreversible;
 };
@@ -32,6 +33,7 @@ struct DwtLevelArgs {
     const void* pixels;   // tiles back to back, component-major planar, tight (as IngestArgs::pixels)
     uint32_t px_bytes;    // 1 or 2 bytes per sample
     int32_t  dc;          // 2^(prec-1) or 0
+    int32_t  sext;        // signed samples: sign bit of the stored word (see IngestArgs), else 0
     uint32_t ncomp;       // components per tile
     uint32_t comp0, zdiv; // set by the launcher: first component of a z slot, z slots per tile
 };

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         } else {
             int32_t xa[NC], xb[NC];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) { xa[k] = q.a[k] - a.dc; xb[k] = q.b[k] - a.dc; }
+            for (int k = 0; k < NC; ++k) {          // sign-extend int8/int16 samples, DC shift
+                xa[k] = ((q.a[k] ^ a.sext) - a.sext) - a.dc; xb[k] = ((q.b[k] ^ a.sext) - a.sext) - a.dc;
+            }
             if constexpr (NC == 3) {            // launched with NC = 3 only for the MCT components
                 color_fwd_px(xa[0], xa[1], xa[2], F97);
                 color_fwd_px(xb[0], xb[1], xb[2], F97);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a)
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         load4<PIX>(src + (size_t)k * comp_px, vec, n, c[k]);
-        for (int i = 0; i < 4; ++i) c[k][i] -= a.dc;
+        for (int i = 0; i < 4; ++i) c[k][i] = ((c[k][i] ^ a.sext) - a.sext) - a.dc;     // sign-extend int8/int16, DC shift
     }
     if (NC >= 3 && a.mct) {
         for (int i = 0; i < 4; ++i) color_fwd(c[0][i], c[NC >= 3 ? 1 : 0][i], c[NC >= 3 ? 2 : 0][i], irrev);

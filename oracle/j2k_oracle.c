@@ -19,7 +19,11 @@ void orc_ingest(const void* src, int bps, int32_t* dst, uint32_t w, uint32_t h, 
     for (uint32_t y = 0; y < h; ++y)
         for (uint32_t x = 0; x < w; ++x) {
             size_t i = (size_t)y * w + x;
-            int32_t v = bps == 1 ? (int32_t)((const uint8_t*)src)[i] : (int32_t)((const uint16_t*)src)[i];
+            int32_t v;                 /* bps < 0: signed samples, read as int8 / int16 (TileProcessor.cpp:1188-1212) */
+            if (bps == 1) v = ((const uint8_t*)src)[i];
+            else if (bps == 2) v = ((const uint16_t*)src)[i];
+            else if (bps == -1) v = ((const int8_t*)src)[i];
+            else v = ((const int16_t*)src)[i];
             dst[(size_t)y * stride + x] = v - dc;
         }
 }

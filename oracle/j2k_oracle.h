@@ -18,6 +18,7 @@ extern "C" {
 #endif
 
 /* ---- a1/a2: widen + DC level shift  (tile/TileProcessor.cpp:1166-1216, :922-944) */
+/*     bytes_per_sample < 0: signed samples (int8 / int16), dc_shift is then 0 */
 void orc_ingest(const void* src, int bytes_per_sample, int32_t* dst,
                 uint32_t w, uint32_t h, uint32_t stride, int32_t dc_shift);
 

@@ -20,14 +20,14 @@ def band_index(b):
     return 0 if b.res == 0 else 3 * b.res - 2 + (b.band - 1)
 
 
-def encode_tile_oracle(px, prec, levels, irrev=False, mct=None):
-    """px: (C,H,W) unsigned pixels. Returns (params, blocks, qcd, table, coded bytes)."""
+def encode_tile_oracle(px, prec, levels, irrev=False, mct=None, sgnd=False):
+    """px: (C,H,W) pixels (int8/int16 when sgnd). Returns (params, blocks, qcd, table, coded bytes)."""
     Cn, H, W = px.shape
     if mct is None:
         mct = Cn >= 3
-    p = G.TileParams.make(W, H, Cn, prec, levels, irreversible=irrev, mct=mct)
+    p = G.TileParams.make(W, H, Cn, prec, levels, irreversible=irrev, mct=mct, sgnd=sgnd)
     blocks, qcd = G.tile_layout(p)
-    planes = [px[c].astype(np.int32) - (1 << (prec - 1)) for c in range(Cn)]
+    planes = [px[c].astype(np.int32) - (0 if sgnd else 1 << (prec - 1)) for c in range(Cn)]
     if irrev:
         if mct:
             planes[:3] = [v.view(np.float32) for v in O.ict_fwd(*planes[:3])]
@@ -82,4 +82,4 @@ def decode_tile_oracle(p, blocks, qcd, table, coded, stop_after=None):
     if stop_after == "idwt":
         return planes
     planes = [pl.view(np.int32) if irrev else pl for pl in planes]
-    return np.stack(O.color_inv_store(planes, prec, irrev, bool(p.mct)))
+    return np.stack(O.color_inv_store(planes, prec, irrev, bool(p.mct), sgnd=bool(p.sgnd)))

@@ -341,3 +341,17 @@ def test_decode_reference_part1_irreversible_stream(C, H, W, prec, numres):
     if C == 3:      # (without MCT the reference's irreversible encoder scales by 2048, TileProcessor.cpp:928-931: not a usable source)
         assert np.abs(ref - px.astype(np.int32)).max() <= max(2, (1 << prec) // 64)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("C,H,W,prec,L", [(1, 96, 128, 8, 3), (3, 128, 160, 8, 4), (3, 64, 96, 12, 2)])
+def test_signed_samples_round_trip_and_blocks(C, H, W, prec, L):
+    """Signed input (int8/int16 samples, DC shift 0): GPU blocks == oracle chain's, GPU decode returns the source."""
+    u = synth.g2(C, H, W, prec).astype(np.int32)
+    px = (u - (1 << (prec - 1))).astype(np.int8 if prec <= 8 else np.int16)
+    p, blocks, qcd, otable, ocoded = chain.encode_tile_oracle(px, prec, L, sgnd=True)
+    table, coded = U.ctx().encode_host(p, px)
+    got = U.split_blocks(table, coded)
+    want = [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
+    assert got == want
+    back = U.ctx().decode_host(p, table, coded)[0]
+    assert np.array_equal(back.view(px.dtype), px)

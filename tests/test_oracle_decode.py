@@ -90,3 +90,18 @@ def test_irreversible_chain_vs_reference_decoder(Cn, H, W, prec, L):
     err = np.abs(ref.astype(np.int64) - px.astype(np.int64))
     assert err.max() <= max(2, (1 << prec) // 64), "reference decode of our lossy stream is far from the source"
     assert np.array_equal(ours, ref)
+
+
+@needs_ref
+@pytest.mark.parametrize("Cn,prec", [(1, 8), (3, 8), (3, 12)])
+def test_signed_samples_lossless_vs_reference_decoder(Cn, prec):
+    """Signed components (SIZ Ssiz bit 7, DC shift 0, samples read as int8/int16, TileProcessor.cpp:1188-1212):
+    our stream through grk_decompress returns the signed source; the oracle decode chain agrees."""
+    H, W, L = 96, 128, 3
+    u = synth.g2(Cn, H, W, prec).astype(np.int32)
+    px = (u - (1 << (prec - 1))).astype(np.int8 if prec <= 8 else np.int16)
+    p, blocks, qcd, table, coded = chain.encode_tile_oracle(px, prec, L, sgnd=True)
+    cs = G.write_codestream(p, W, H, table, coded)
+    ref = R.decode(cs, Cn, H, W)
+    assert np.array_equal(ref, px.astype(np.int32))
+    assert np.array_equal(chain.decode_tile_oracle(p, blocks, qcd, table, coded), ref)
