@@ -145,10 +145,10 @@ import os
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def gpu_codestream(px, prec, L, TW=None, TH=None):
+def gpu_codestream(px, prec, L, TW=None, TH=None, cblk=(6, 6)):
     C, H, W = px.shape
     TW, TH = TW or W, TH or H
-    p = G.TileParams.make(TW, TH, C, prec, L)
+    p = G.TileParams.make(TW, TH, C, prec, L, cblk=cblk)
     tiles = [px[:, ty * TH:(ty + 1) * TH, tx * TW:(tx + 1) * TW] for ty in range(H // TH) for tx in range(W // TW)]
     batch = np.ascontiguousarray(np.stack(tiles))
     table, coded = U.ctx().encode_host(p, batch, ntiles=len(tiles))
@@ -230,3 +230,14 @@ def test_encode_irreversible_blocks_vs_oracle(C, H, W, prec, L):
     want = [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
     bad = [i for i in range(len(blocks)) if got[i] != want[i]]
     assert not bad, "blocks differing from the oracle: %s" % bad[:10]
+
+
+@pytest.mark.parametrize("cblk", [(5, 5), (6, 5), (4, 4), (5, 6), (2, 2)])
+def test_gpu_codestream_other_block_sizes_vs_grok(cblk):
+    """Code-block sizes other than 64x64 (COD SPcod): the GPU file equals Grok's CPU encode byte for byte."""
+    import refharness as R
+    if not R.have_ref():
+        pytest.skip("oracle/_ref not shipped")
+    px = synth.g2(3, 128, 192, 8)
+    want, _ = R.encode(px, 8, numres=4, mode=1, cblk=(1 << cblk[0], 1 << cblk[1]))
+    assert gpu_codestream(px, 8, 3, cblk=cblk) == want
