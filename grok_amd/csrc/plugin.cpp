@@ -229,6 +229,49 @@ GRA_EXPORT void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile)
     delete reinterpret_cast<TileOwner*>(tile);
 }
 
+GRA_EXPORT int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
+                                          void* pixels, int pixels_on_device)
+{
+    if (!ctx || !p || !tile || !pixels) return GRK_AMD_ERR_INVALID;
+    const int64_t nb = grk_amd_tile_num_blocks(p);
+    if (nb <= 0) return (int)(nb ? nb : GRK_AMD_ERR_UNSUPPORTED);
+    std::vector<grk_amd_block> layout((size_t)nb);
+    if (grk_amd_tile_layout(p, layout.data(), (uint64_t)nb, nullptr) != nb) return GRK_AMD_ERR_INVALID;
+    if (tile->numComponents != p->num_comps) return GRK_AMD_ERR_INVALID;
+    // walk the tree in the enumeration order both sides share: comp -> resolution -> band -> precinct -> block
+    std::vector<grk_amd_coded_block> table((size_t)nb);
+    std::vector<uint8_t> coded;
+    size_t i = 0;
+    for (uint32_t c = 0; c < tile->numComponents; ++c) {
+        const gra_plugin_tile_component* tc = tile->tileComponents[c];
+        for (uint32_t r = 0; r < tc->numResolutions; ++r) {
+            const gra_plugin_resolution* res = tc->resolutions[r];
+            for (uint32_t b = 0; b < res->numBands; ++b) {
+                const gra_plugin_band* band = res->band[b];
+                for (uint64_t pr = 0; pr < band->numPrecincts; ++pr) {
+                    const gra_plugin_precinct* prec = band->precincts[pr];
+                    for (uint64_t k = 0; k < prec->numBlocks; ++k) {
+                        if (i >= (size_t)nb) return GRK_AMD_ERR_INVALID;
+                        const gra_plugin_code_block* cb = prec->blocks[k];
+                        grk_amd_coded_block& row = table[i];
+                        row.offset = coded.size();
+                        row.length = cb->compressedData ? cb->compressedDataLength : 0;
+                        const uint32_t nbp = (uint32_t)cb->numBitPlanes;
+                        if (p->reserved[0]) row.missing_msbs = row.length ? (nbp | ((uint32_t)cb->numPasses << 8)) : 0;
+                        else row.missing_msbs = layout[i].kmax >= nbp ? layout[i].kmax - nbp : 0;   // band numbps - block numbps
+                        if (row.length) coded.insert(coded.end(), cb->compressedData, cb->compressedData + row.length);
+                        coded.resize((coded.size() + 15u) & ~(size_t)15u);
+                        ++i;
+                    }
+                }
+            }
+        }
+    }
+    if (i != (size_t)nb) return GRK_AMD_ERR_INVALID;
+    coded.resize(coded.size() + 16);
+    return grk_amd_decode_tiles(ctx, p, 1, table.data(), coded.data(), coded.size(), 0, pixels, pixels_on_device);
+}
+
 GRA_EXPORT gra_minpf_exit_func minpf_post_load_plugin(const char*, const gra_minpf_platform_services* services)
 {
     if (!services || !services->registerObject) return nullptr;

@@ -211,6 +211,14 @@ gra_plugin_tile* grk_amd_plugin_tile_create(grk_amd_ctx* ctx, const grk_amd_tile
                                             const void* pixels, int pixels_on_device);
 void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile);
 
+/* ---- the decode counterpart: a tile tree as the HOST fills it after its Tier-2 parse in
+ * decompress_synch_plugin_with_host (plugin/plugin_bridge.cpp:63-76: per block compressedData,
+ * compressedDataLength, numBitPlanes = block numbps, numPasses) is decoded on the GPU into `pixels`
+ * (layout of grk_amd_decode_tiles).  p->reserved[0] = 1 for Part-1 (EBCOT) blocks, 0 for HT.
+ * Returns 0, or a negative GRK_AMD_ERR_* so that the host keeps its CPU decoder. */
+int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
+                               void* pixels, int pixels_on_device);
+
 #ifdef __cplusplus
 }
 #endif

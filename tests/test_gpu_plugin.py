@@ -11,7 +11,8 @@ import gpuutil as U
 import refharness as R
 import synth
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not shipped")]
+pytestmark = [pytest.mark.gpu]
+needs_ref = pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not shipped")
 
 PLUGIN = os.path.join(os.path.dirname(G.lib_path()), "libgrokj2k_plugin.so")
 
@@ -24,6 +25,7 @@ def _plugin():
     return L
 
 
+@needs_ref
 @pytest.mark.parametrize("Cn,H,W,prec,numres,gen", [(1, 512, 512, 8, 4, "g2"), (3, 256, 320, 8, 6, "g2"),
                                                     (3, 512, 512, 8, 6, "g0"), (1, 128, 128, 12, 5, "g2")])
 def test_compress_with_plugin_tile_equals_cpu(Cn, H, W, prec, numres, gen):
@@ -41,6 +43,7 @@ def test_compress_with_plugin_tile_equals_cpu(Cn, H, W, prec, numres, gen):
     assert via_plugin == cpu
 
 
+@needs_ref
 def test_file_protocol_through_grok_loader(tmp_path):
     """grk_initialize(plugin dir) -> grk_plugin_init -> grk_plugin_compress(params{infile}, cb):
     Grok dlsym()s plugin_encode in our .so, we read the PNM, encode on the GPU and call back."""
@@ -56,3 +59,24 @@ def test_file_protocol_through_grok_loader(tmp_path):
         assert got == cpu
     # a request outside the hot path is declined (non-zero) so that the host falls back to its CPU path
     assert isinstance(R.plugin_compress_file(synth.g2(1, 64, 64, 8), 8, "/nonexistent.pgm", numres=3), int)
+
+
+@pytest.mark.parametrize("Cn,H,W,prec,L", [(1, 256, 256, 8, 3), (3, 128, 192, 8, 4), (3, 64, 96, 12, 2)])
+def test_plugin_tile_decode_round_trip(Cn, H, W, prec, L):
+    """The decode counterpart at the plugin-tile level: a grk_plugin_tile tree carrying what the host's Tier-2
+    puts there (compressedData, compressedDataLength, numBitPlanes, numPasses; plugin_bridge.cpp:63-76) ->
+    grk_amd_plugin_tile_decode -> the source pixels.  (No oracle/_ref needed: the tree comes from our encoder.)"""
+    px = synth.g2(Cn, H, W, prec)
+    p = G.TileParams.make(W, H, Cn, prec, L)
+    Lp = _plugin()
+    Lp.grk_amd_plugin_tile_decode.restype = C.c_int
+    Lp.grk_amd_plugin_tile_decode.argtypes = [C.c_void_p, C.POINTER(G.TileParams), C.c_void_p, C.c_void_p, C.c_int]
+    tile = Lp.grk_amd_plugin_tile_create(U.ctx()._h, C.byref(p), px.ctypes.data, 0)
+    assert tile
+    try:
+        out = np.zeros_like(px)
+        rc = Lp.grk_amd_plugin_tile_decode(U.ctx()._h, C.byref(p), tile, out.ctypes.data, 0)
+        assert rc == 0
+        assert np.array_equal(out, px)
+    finally:
+        Lp.grk_amd_plugin_tile_destroy(tile)
