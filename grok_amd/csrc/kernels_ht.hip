@@ -263,7 +263,10 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const bool narrow = kmax + 2 <= 16;           // a quad's four MagSgn values fit 64 bits
 
     uvlc_l[lane] = g_uvlc[lane];
-    for (uint32_t i = lane; i < ms_words + vlc_words; i += 64) ms_raw[i] = 0;
+    {   // clear the raw streams 16 bytes per lane and instruction (ms_words + vlc_words is a multiple of 4)
+        uint4* z = reinterpret_cast<uint4*>(ms_raw);
+        for (uint32_t i = lane; i < (ms_words + vlc_words) / 4; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
     if (lane == 0) vlc_raw[0] = 0xF;             // vlc_init: four 1 bits pending (:315-318)
     __syncthreads();
@@ -640,8 +643,8 @@ static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, uint3
 {
     const uint32_t ms_bits = samples * (kmax + 2u);                 // m_n <= U_q <= Kmax + 2 inside the contract
     const uint32_t vlc_bits = quads * 15u + 4u;                     // cwd <= 7, UVLC prefix <= 3, suffix <= 5 bits per quad
-    ms_words = ((ms_bits + 31u) / 32u + 4u + 1u) & ~1u;             // slack: or_bits64 / window reads touch two words beyond
-    vlc_words = ((vlc_bits + 31u) / 32u + 4u + 1u) & ~1u;
+    ms_words = ((ms_bits + 31u) / 32u + 4u + 3u) & ~3u;             // slack: or_bits64 / window reads touch two words beyond;
+    vlc_words = ((vlc_bits + 31u) / 32u + 4u + 3u) & ~3u;           // multiples of 4 words: cleared as uint4
     mark_words = ((ms_bits + ms_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;   // one bit per stuffed output byte
     vmark_words = ((vlc_bits + vlc_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;
     uint32_t mk = mark_words + vmark_words;
