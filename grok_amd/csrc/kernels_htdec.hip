@@ -24,6 +24,7 @@
 // reference rejects (bad Scup, U_q > missing_msbs) are rejected here as well.
 #include "kernels.h"
 #include "ht_vlc_tables.h"
+#include <cstdlib>
 
 namespace grk_amd {
 
@@ -70,17 +71,43 @@ struct ByteCursor {
 };
 
 struct RevReader {          // VLC: backward, LSB first; after a byte > 0x8F a byte whose 7 LSBs are ones carries 7 bits
-    ByteCursor<-1> bc; int pos, left; uint64_t acc; int n; uint32_t unstuff;
+    const uint8_t* lo; const uint8_t* hi;      // readable range of the coded buffer
+    const uint8_t* bp;                         // next byte to read (addresses go down)
+    uint64_t cur, prv;                         // the aligned word holding *bp and the word below it (fetched ahead)
+    int left;                                  // bytes of the segment still unread; beyond it zeros are fed
+    uint64_t acc; int n; uint32_t unstuff;
+    __device__ __forceinline__ uint64_t load(const uint8_t* p) const
+    {
+        return (p + 8 > lo && p < hi) ? *reinterpret_cast<const uint64_t*>(p) : 0ull;
+    }
+    __device__ __forceinline__ void init(const uint8_t* first, int count, const uint8_t* lo_, const uint8_t* hi_)
+    {
+        lo = lo_; hi = hi_; bp = first; left = count;
+        const uint8_t* wp = first - ((uintptr_t)first & 7u);
+        cur = load(wp); prv = load(wp - 8);
+    }
+    // four bytes at once, straight-line (the refill is on the serial chain of every quad pair)
     __device__ __forceinline__ void fill()
     {
-        while (n <= 32) {
-            const uint32_t raw = bc.next();
-            const uint32_t b = (left > 0 && pos >= 0) ? raw : 0u;
-            --pos; --left;
-            const uint32_t w = 8u - ((unstuff && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
+        if (n > 32) return;
+        const uint32_t o = (uint32_t)((uintptr_t)bp & 7u);
+        // bytes bp-3 .. bp as a little-endian word (byte 3 = *bp is read first)
+        const uint32_t w = o >= 3 ? (uint32_t)(cur >> (8 * (o - 3))) : (uint32_t)((cur << (8 * (3 - o))) | (prv >> (8 * (o + 5))));
+        const int v = left < 0 ? 0 : (left > 4 ? 4 : left);
+        uint32_t us = unstuff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = i < v ? (w >> (24 - 8 * i)) & 0xFFu : 0u;
+            const uint32_t wd = 8u - ((us && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
             acc |= (uint64_t)b << n;
-            n += (int)w;
-            unstuff = b > 0x8Fu;
+            n += (int)wd;
+            us = b > 0x8Fu;
+        }
+        unstuff = us;
+        bp -= 4; left -= 4;
+        if (o < 4) {                                       // moved into the word below: fetch the next one ahead
+            cur = prv;
+            prv = load(bp - ((uintptr_t)bp & 7u) - 8);
         }
     }
     __device__ __forceinline__ uint32_t peek() const { return (uint32_t)acc; }      // valid after fill(): > 32 bits
@@ -128,13 +155,12 @@ struct MelReader {          // MEL: forward, MSB first; byte after 0xFF carries 
     }
 };
 
-// UVLC prefix: '1' -> 1, '01' -> 2, '001' -> 3 + 1-bit suffix, '000' -> 5 + 5-bit suffix (:706-716)
+// UVLC prefix: '1' -> 1, '01' -> 2, '001' -> 3 + 1-bit suffix, '000' -> 5 + 5-bit suffix (:706-716), looked up by
+// the three next bits in a table packed into one 64-bit constant: entry = prefix_len | suffix_len << 2 | base << 5
 __device__ __forceinline__ void uvlc_prefix(uint32_t bits, uint32_t& pl, uint32_t& sl, uint32_t& base)
 {
-    if (bits & 1u)      { pl = 1; sl = 0; base = 1; }
-    else if (bits & 2u) { pl = 2; sl = 0; base = 2; }
-    else if (bits & 4u) { pl = 3; sl = 1; base = 3; }
-    else                { pl = 3; sl = 5; base = 5; }
+    const uint32_t d = (uint32_t)(0x21422167214221B7ull >> (8 * (bits & 7u))) & 0xFFu;
+    pl = d & 3u; sl = (d >> 2) & 7u; base = d >> 5;
 }
 
 __global__ void ht_dec_vlc_kernel(HtDecArgs a)
@@ -175,8 +201,7 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
     RevReader vlc;
     {
         const uint32_t d0 = D[lcup - 2];
-        vlc.bc.init(D + (lcup - 3), a.coded, buf_hi);
-        vlc.pos = lcup - 3; vlc.left = scup - 2;
+        vlc.init(D + (lcup - 3), scup - 2, a.coded, buf_hi);
         vlc.acc = d0 >> 4; vlc.n = 4 - (((d0 >> 4) & 7u) == 7u ? 1 : 0);
         vlc.unstuff = (d0 | 0xFu) > 0x8Fu;
     }
@@ -402,6 +427,7 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
     // chain's own latency exposed: aim for ~1.5-2 waves per SIMD (1024 SIMDs), measured optimum.
     uint32_t lanes = 64;
     while (lanes > 16 && (a.nblocks + lanes - 1) / lanes < 1280) lanes >>= 1;
+    if (const char* e = getenv("GRK_AMD_VLC_LANES")) lanes = (uint32_t)atoi(e);
     hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nblocks + lanes - 1) / lanes), dim3(lanes), 0, s, a);
     const uint32_t raw_words = (max_ms_bytes * 8u) / 32u + 8u;
     if (a.irreversible)
