@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include "ht_vlc_tables.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace grk_amd {
 
@@ -36,74 +37,50 @@ constexpr uint32_t kQuadStride = 32;         // quads per row in the per-block q
 constexpr uint32_t kQuadWords  = 32 * 32;
 
 // ---- K5a --------------------------------------------------------------------------------------------
-// Byte cursor over the coded buffer that fetches aligned 8-byte words one word ahead of use, so the
-// serial decoder never waits for memory (a byte-at-a-time reader costs one full HBM/L2 latency per
-// byte on the critical path).  DIR = +1 walks forward (MEL), -1 backward (VLC).
-template <int DIR>
-struct ByteCursor {
-    const uint8_t* lo; const uint8_t* hi;      // readable range [lo, hi)
-    const uint8_t* wp;                         // aligned address of the current word
-    uint64_t cur, nxt; int idx;
+// Both readers keep the aligned 8-byte word under the cursor and the next one in registers (fetched one
+// word ahead of use, so the serial decoder never waits for memory) and refill FOUR bytes at a time with
+// straight-line SWAR code: which bytes are bit-stuffed depends only on the byte read just before, so the
+// four widths are computed at once and the bytes packed with three shifts.  One refill check per quad
+// pair is enough for both (a pair consumes <= 31 VLC bits and <= 18 MEL bits).
+struct WordWindow {
+    const uint8_t* lo; const uint8_t* hi;      // readable range [lo, hi) of the coded buffer
     __device__ __forceinline__ uint64_t load(const uint8_t* p) const
     {
         // an aligned word that overlaps the buffer lies in a mapped page (words do not straddle pages);
         // its bytes outside [lo, hi) are never consumed (the readers count the bytes they may use)
         return (p + 8 > lo && p < hi) ? *reinterpret_cast<const uint64_t*>(p) : 0ull;
     }
-    __device__ __forceinline__ void init(const uint8_t* p, const uint8_t* lo_, const uint8_t* hi_)
-    {
-        lo = lo_; hi = hi_;
-        idx = (int)((uintptr_t)p & 7u);
-        wp = p - idx;
-        cur = load(wp);
-        nxt = load(wp + 8 * DIR);
-    }
-    __device__ __forceinline__ uint32_t next()
-    {
-        const uint32_t b = (uint32_t)(cur >> (8 * idx)) & 0xFFu;
-        idx += DIR;
-        if (idx < 0 || idx > 7) {
-            cur = nxt; wp += 8 * DIR; idx = DIR > 0 ? 0 : 7;
-            nxt = load(wp + 8 * DIR);
-        }
-        return b;
-    }
 };
 
-struct RevReader {          // VLC: backward, LSB first; after a byte > 0x8F a byte whose 7 LSBs are ones carries 7 bits
-    const uint8_t* lo; const uint8_t* hi;      // readable range of the coded buffer
+struct RevReader : WordWindow {   // VLC: backward, LSB first; after a byte > 0x8F a byte whose 7 LSBs are ones carries 7 bits
     const uint8_t* bp;                         // next byte to read (addresses go down)
-    uint64_t cur, prv;                         // the aligned word holding *bp and the word below it (fetched ahead)
+    uint64_t cur, prv;                         // the aligned word holding *bp and the word below it
     int left;                                  // bytes of the segment still unread; beyond it zeros are fed
     uint64_t acc; int n; uint32_t unstuff;
-    __device__ __forceinline__ uint64_t load(const uint8_t* p) const
-    {
-        return (p + 8 > lo && p < hi) ? *reinterpret_cast<const uint64_t*>(p) : 0ull;
-    }
     __device__ __forceinline__ void init(const uint8_t* first, int count, const uint8_t* lo_, const uint8_t* hi_)
     {
         lo = lo_; hi = hi_; bp = first; left = count;
         const uint8_t* wp = first - ((uintptr_t)first & 7u);
         cur = load(wp); prv = load(wp - 8);
     }
-    // four bytes at once, straight-line (the refill is on the serial chain of every quad pair)
     __device__ __forceinline__ void fill()
     {
         if (n > 32) return;
         const uint32_t o = (uint32_t)((uintptr_t)bp & 7u);
-        // bytes bp-3 .. bp as a little-endian word (byte 3 = *bp is read first)
-        const uint32_t w = o >= 3 ? (uint32_t)(cur >> (8 * (o - 3))) : (uint32_t)((cur << (8 * (3 - o))) | (prv >> (8 * (o + 5))));
+        // bytes bp-3 .. bp as a little-endian word: byte 3 (= *bp) is read first, so byte i follows byte i+1
+        uint32_t w = o >= 3 ? (uint32_t)(cur >> (8 * (o - 3))) : (uint32_t)((cur << (8 * (3 - o))) | (prv >> (8 * (o + 5))));
         const int v = left < 0 ? 0 : (left > 4 ? 4 : left);
-        uint32_t us = unstuff;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t b = i < v ? (w >> (24 - 8 * i)) & 0xFFu : 0u;
-            const uint32_t wd = 8u - ((us && (b & 0x7Fu) == 0x7Fu) ? 1u : 0u);
-            acc |= (uint64_t)b << n;
-            n += (int)wd;
-            us = b > 0x8Fu;
-        }
-        unstuff = us;
+        w &= (uint32_t)(0xFFFFFFFF00000000ull >> (8 * v));                          // bytes past the segment read as 0
+        const uint32_t l7 = w & 0x7F7F7F7Fu;
+        const uint32_t g = (l7 + 0x70707070u) & w & 0x80808080u;                    // byte > 0x8F
+        const uint32_t e = (l7 + 0x01010101u) & 0x80808080u;                        // 7 LSBs all ones
+        const uint32_t st = e & ((g >> 8) | (unstuff << 31));                       // byte carries 7 bits
+        unstuff = (g >> 7) & 1u;
+        const uint32_t s3 = st >> 31, s2 = (st >> 23) & 1u, s1 = (st >> 15) & 1u;
+        const uint32_t sh2 = 8u - s3, sh1 = sh2 + 8u - s2, sh0 = sh1 + 8u - s1;
+        const uint32_t val = (w >> 24) | (((w >> 16) & 0xFFu) << sh2) | (((w >> 8) & 0xFFu) << sh1) | ((w & 0xFFu) << sh0);
+        acc |= (uint64_t)val << n;
+        n += 32 - (int)__builtin_popcount(st);
         bp -= 4; left -= 4;
         if (o < 4) {                                       // moved into the word below: fetch the next one ahead
             cur = prv;
@@ -114,43 +91,61 @@ struct RevReader {          // VLC: backward, LSB first; after a byte > 0x8F a b
     __device__ __forceinline__ void skip(uint32_t nb) { acc >>= nb; n -= (int)nb; }
 };
 
-struct MelReader {          // MEL: forward, MSB first; byte after 0xFF carries 7 bits; last byte |= 0x0F
-    ByteCursor<1> bc; int left; uint32_t unstuff;
+struct MelReader : WordWindow {   // MEL: forward, MSB first; byte after 0xFF carries 7 bits; last byte |= 0x0F; then 0xFF
+    const uint8_t* bp; uint64_t cur, nxt; int left; uint32_t unstuff;
     uint64_t tmp; int bits;             // un-stuffed bits, next bit at the MSB
     int k;
     int run;                            // what is left of the current run, in the reference's coding (:196-235, :1101-1111):
                                         // 2 * (zero events) + 1 if it ends with a one, 2 * (zero events - 1) otherwise
-    __device__ __forceinline__ void init(const uint8_t* p, int size, const uint8_t* lo, const uint8_t* hi)
+    __device__ __forceinline__ void init(const uint8_t* p, int size, const uint8_t* lo_, const uint8_t* hi_)
     {
-        bc.init(p, lo, hi);
-        left = size; unstuff = 0; tmp = 0; bits = 0; k = 0;
-        run = get_run();
+        lo = lo_; hi = hi_; bp = p; left = size;
+        const uint8_t* wp = p - ((uintptr_t)p & 7u);
+        cur = load(wp); nxt = load(wp + 8);
+        unstuff = 0; tmp = 0; bits = 0; k = 0; run = -1;
+        fill();
+        (void)event(false);                                // run < 0: decodes the first run
     }
-    __device__ __forceinline__ int get_run()
+    __device__ __forceinline__ void fill()
     {
-        while (bits < 6) {                                 // longest codeword: 1 + 5 bits
-            uint32_t b = 0xFFu;
-            if (left > 0) { b = bc.next(); if (left == 1) b |= 0x0Fu; }
-            --left;
-            const int nb = 8 - (int)unstuff;
-            tmp |= (uint64_t)(b & (unstuff ? 0x7Fu : 0xFFu)) << (64 - nb - bits);
-            bits += nb;
-            unstuff = b == 0xFFu;
+        if (bits > 32) return;
+        const uint32_t o = (uint32_t)((uintptr_t)bp & 7u);
+        uint32_t w = o <= 4 ? (uint32_t)(cur >> (8 * o)) : (uint32_t)((cur >> (8 * o)) | (nxt << (64 - 8 * o)));   // byte 0 first
+        const int v = left < 0 ? 0 : (left > 4 ? 4 : left);
+        const uint32_t valid = (uint32_t)((1ull << (8 * v)) - 1ull);
+        w = (w & valid) | ~valid;                                                   // past the segment: 0xFF
+        w |= (left >= 1 && left <= 4) ? 0x0Fu << (8 * (left - 1)) : 0u;             // the segment's last byte
+        const uint32_t ff = ((w & 0x7F7F7F7Fu) + 0x01010101u) & w & 0x80808080u;    // byte == 0xFF
+        const uint32_t st = (ff << 8) | (unstuff << 7);                             // byte follows a 0xFF: 7 bits, MSB dropped
+        unstuff = ff >> 31;
+        w &= ~st;
+        const uint32_t f0 = (st >> 7) & 1u, f1 = (st >> 15) & 1u, f2 = (st >> 23) & 1u, f3 = st >> 31;
+        const uint32_t h0 = 24u + f0, h1 = h0 - 8u + f1, h2 = h1 - 8u + f2, h3 = h2 - 8u + f3;
+        const uint32_t val = ((w & 0xFFu) << h0) | (((w >> 8) & 0xFFu) << h1) | (((w >> 16) & 0xFFu) << h2) | ((w >> 24) << h3);
+        tmp |= (uint64_t)val << (32 - bits);
+        bits += 32 - (int)h3;
+        bp += 4; left -= 4;
+        if (o >= 4) {
+            cur = nxt;
+            nxt = load(bp - ((uintptr_t)bp & 7u) + 8);
         }
-        const int e = (int)((0x5433222111000ull >> (4 * k)) & 0xF);     // MEL exponents (:196)
-        const bool one = (tmp >> 63) != 0;                 // '1': 2^e zero events; '0' + e bits: that many, then a one
-        const int r = one ? ((1 << e) - 1) << 1 : ((int)((tmp >> (63 - e)) & ((1u << e) - 1u)) << 1) + 1;
-        k = one ? (k < 12 ? k + 1 : 12) : (k > 0 ? k - 1 : 0);
-        const int used = one ? 1 : e + 1;
-        tmp <<= used; bits -= used;
-        return r;
     }
-    // one MEL event (:1101-1111): 1 if the run ends here with a one
-    __device__ __forceinline__ int event()
+    // One MEL event if `need` (:1101-1111): returns 1 if the run ends here with a one.  Written without branches:
+    // lanes of a wave disagree about needing an event / a new run almost every time.
+    __device__ __forceinline__ uint32_t event(bool need)
     {
-        run -= 2;
-        const int ev = run == -1;
-        if (run < 0) run = get_run();
+        run -= need ? 2 : 0;
+        const uint32_t ev = run == -1;
+        const bool take = run < 0;                                                  // decode the next run (:196-235)
+        const uint32_t e = (uint32_t)(0x5433222111000ull >> (4 * k)) & 0xFu;        // MEL exponents (:196)
+        const uint32_t top = (uint32_t)(tmp >> 32);
+        const bool one = (top >> 31) != 0;                 // '1': 2^e zero events; '0' + e bits: that many, then a one
+        const int r = one ? (int)((2u << e) - 2u) : (int)((((top >> (31u - e)) & ((1u << e) - 1u)) << 1) | 1u);
+        const int kn = one ? (k < 12 ? k + 1 : 12) : (k > 0 ? k - 1 : 0);
+        const uint32_t used = take ? (one ? 1u : e + 1u) : 0u;
+        run = take ? r : run;
+        k = take ? kn : k;
+        tmp <<= used; bits -= (int)used;
         return ev;
     }
 };
@@ -205,59 +200,74 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
         vlc.acc = d0 >> 4; vlc.n = 4 - (((d0 >> 4) & 7u) == 7u ? 1 : 0);
         vlc.unstuff = (d0 | 0xFu) > 0x8Fu;
     }
+    const uint32_t NP = (QW + 1) >> 1;  // quad pairs per row
     uint64_t sa = 0;                     // significance of the bottom sample row of the quad row above: bit x
-    for (uint32_t qy = 0; qy < QH; ++qy) {
-        uint64_t sn = 0;
-        uint32_t chain = 0;
-        const uint16_t* tbl = tbl_l + (qy == 0 ? 0 : 1024);
+    // One quad row; the first row has its own contexts, table and u-value rules, so it gets its own instance.
+    auto quad_row = [&](auto first_tag, uint32_t qy) -> bool {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint16_t* tbl = tbl_l + (FIRST ? 0 : 1024);
+        uint32_t* qrow = qi + qy * kQuadStride;
+        uint64_t sw = sa, sn = 0;
+        uint32_t west = 0, chain = 0;    // sample 2 * q0 - 1 of the row above; the west quad's contribution to c_q
         for (uint32_t q0 = 0; q0 < QW; q0 += 2) {
-            uint32_t qinf[2] = {0u, 0u}, U[2] = {1u, 1u};
-            vlc.fill();                                   // > 32 bits: a quad pair consumes at most 7 + 7 + 17
-#pragma unroll
-            for (uint32_t j = 0; j < 2; ++j) {
-                const uint32_t q = q0 + j;
-                if (q < QW) {
-                    uint32_t c = chain;
-                    if (qy > 0) {
-                        const uint32_t nw_n = q == 0 ? (uint32_t)(sa & 1u) : (uint32_t)((sa >> (2 * q - 1)) & 3u);
-                        const uint32_t ne_nf = (uint32_t)((sa >> (2 * q + 1)) & 3u);
-                        c |= (nw_n ? 1u : 0u) | (ne_nf ? 4u : 0u);
-                    }
-                    uint32_t t = tbl[(c << 7) | (vlc.peek() & 0x7Fu)];
-                    if (c == 0 && !mel.event()) t = 0;
-                    vlc.skip(t & 7u);
-                    qinf[j] = t;
-                    const uint32_t rho = (t >> 4) & 0xFu;
-                    chain = qy == 0 ? ((rho & 1u) | (rho >> 1)) : ((((rho >> 2) | (rho >> 3)) & 1u) << 1);
-                    sn |= (uint64_t)(((rho >> 1) & 1u) | (((rho >> 3) & 1u) << 1)) << (2 * q);
-                }
-            }
-            // u values of the pair (:668-777), written without branches: prefix0, prefix1, suffix0, suffix1,
+            vlc.fill();                  // > 32 bits: a quad pair consumes at most 7 + 7 + 17
+            mel.fill();                  // > 18 bits: at most three runs of 6 bits
+            const bool has1 = q0 + 1 < QW;
+            const uint32_t up = (uint32_t)sw;            // samples 2 * q0 ... of the row above
+            const uint32_t nb0 = ((up << 1) | west) & 0xFu, nb1 = (up >> 1) & 0xFu;   // nw, n, ne, nf of each quad
+            west = (up >> 3) & 1u; sw >>= 4;
+            // ---- quad q0
+            uint32_t c = chain;
+            if (!FIRST) c |= ((nb0 & 3u) ? 1u : 0u) | ((nb0 & 12u) ? 4u : 0u);
+            uint32_t t0 = tbl[(c << 7) | (vlc.peek() & 0x7Fu)];
+            uint32_t ev = mel.event(c == 0);
+            t0 = (c == 0 && !ev) ? 0u : t0;
+            vlc.skip(t0 & 7u);
+            const uint32_t rho0 = (t0 >> 4) & 0xFu;
+            chain = FIRST ? ((rho0 & 1u) | (rho0 >> 1)) : ((((rho0 >> 2) | (rho0 >> 3)) & 1u) << 1);
+            // ---- quad q0 + 1 (absent when the row has an odd number of quads)
+            c = chain;
+            if (!FIRST) c |= ((nb1 & 3u) ? 1u : 0u) | ((nb1 & 12u) ? 4u : 0u);
+            uint32_t t1 = tbl[(c << 7) | (vlc.peek() & 0x7Fu)];
+            ev = mel.event(has1 && c == 0);
+            t1 = (!has1 || (c == 0 && !ev)) ? 0u : t1;
+            vlc.skip(t1 & 7u);
+            const uint32_t rho1 = (t1 >> 4) & 0xFu;
+            chain = FIRST ? ((rho1 & 1u) | (rho1 >> 1)) : ((((rho1 >> 2) | (rho1 >> 3)) & 1u) << 1);
+            const uint32_t sb = ((rho0 >> 1) & 1u) | (((rho0 >> 3) & 1u) << 1) | (((rho1 >> 1) & 1u) << 2) | (((rho1 >> 3) & 1u) << 3);
+            sn = (sn >> 4) | ((uint64_t)sb << 60);
+            // ---- u values of the pair (:668-777), written without branches: prefix0, prefix1, suffix0, suffix1,
             // each present only if its quad has u_off set
-            const uint32_t uo0 = (qinf[0] >> 3) & 1u, uo1 = (qinf[1] >> 3) & 1u;
+            const uint32_t uo0 = (t0 >> 3) & 1u, uo1 = (t1 >> 3) & 1u;
             uint32_t add = 1, onebit = 0;
             uint32_t v = vlc.peek();
             uint32_t pl, sl, base, pl2, sl2, base2;
             uvlc_prefix(v, pl, sl, base);
             pl = uo0 ? pl : 0; sl = uo0 ? sl : 0; base = uo0 ? base : 0;
             v >>= pl;
-            if (qy == 0 && (uo0 & uo1)) {                          // first row, both: a MEL event picks the variant
-                if (mel.event()) add = 3;
-                else if (pl > 2) onebit = 1;                       // second quad is a single bit
+            if (FIRST) {                                           // both quads: a MEL event picks the variant
+                const uint32_t both = uo0 & uo1;
+                const uint32_t e2 = mel.event(both != 0);
+                add = (both & e2) ? 3u : 1u;
+                onebit = both & (e2 ^ 1u) & (pl > 2 ? 1u : 0u);    // second quad is a single bit
             }
             uvlc_prefix(v, pl2, sl2, base2);
             pl2 = uo1 ? pl2 : 0; sl2 = uo1 ? sl2 : 0; base2 = uo1 ? base2 : 0;
-            if (onebit) { pl2 = 1; sl2 = 0; base2 = (v & 1u) + 1u; }
+            if (FIRST) { pl2 = onebit ? 1u : pl2; sl2 = onebit ? 0u : sl2; base2 = onebit ? (v & 1u) + 1u : base2; }
             v >>= pl2;
-            U[0] = base + (v & ((1u << sl) - 1u)) + (uo0 ? add : 1u);
+            const uint32_t U0 = base + (v & ((1u << sl) - 1u)) + (uo0 ? add : 1u);
             v >>= sl;
-            U[1] = base2 + (v & ((1u << sl2) - 1u)) + (uo1 ? add : 1u);
+            const uint32_t U1 = base2 + (v & ((1u << sl2) - 1u)) + (uo1 ? add : 1u);
             vlc.skip(pl + pl2 + sl + sl2);
-            if (U[0] > mm || U[1] > mm) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; return; }   // :1194
-            *reinterpret_cast<uint2*>(&qi[qy * kQuadStride + q0]) = make_uint2(qinf[0] | (U[0] << 16), qinf[1] | (U[1] << 16));
+            if (U0 > mm || U1 > mm) return false;                  // :1194
+            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(t0 | (U0 << 16), t1 | (U1 << 16));
         }
-        sa = sn;
-    }
+        sa = sn >> (64u - 4u * NP);
+        return true;
+    };
+    bool ok = quad_row(std::true_type{}, 0);
+    for (uint32_t qy = 1; ok && qy < QH; ++qy) ok = quad_row(std::false_type{}, qy);
+    if (!ok) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; }
 }
 
 // ---- K5b --------------------------------------------------------------------------------------------
