@@ -22,11 +22,12 @@ class TileParams(C.Structure):
                 ("cblk_h_exp", C.c_uint8), ("reserved", C.c_uint8 * 3)]
 
     @classmethod
-    def make(cls, w, h, comps, prec, levels, irreversible=False, mct=None, sgnd=False, cblk=(6, 6), part1=False):
+    def make(cls, w, h, comps, prec, levels, irreversible=False, mct=None, sgnd=False, cblk=(6, 6), part1=False, cblksty=0):
         if mct is None:
             mct = comps >= 3
         p = cls(w, h, comps, prec, int(sgnd), int(irreversible), int(mct), levels, cblk[0], cblk[1])
         p.reserved[0] = int(part1)
+        p.reserved[1] = int(cblksty)       # Part-1 decode: LAZY 1, RESET 2, TERMALL 4, VSC 8, PTERM 16, SEGSYM 32
         return p
 
 
@@ -88,6 +89,7 @@ def lib():
         L.grk_amd_decode_tiles.argtypes = [vp, PP, u32, vp, vp, u64, i32, vp, i32]
         L.grk_amd_decode_status.argtypes = [vp]
         L.grk_amd_set_decode_qcd.argtypes = [vp, vp, u32]
+        L.grk_amd_set_decode_segments.argtypes = [vp, vp, vp, u32]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
         L.grk_amd_kernel_ms.restype = C.c_double
@@ -232,6 +234,18 @@ class Context:
         t = np.ascontiguousarray(table)
         self._check(self._L.grk_amd_decode_tiles(self._h, C.byref(params), ntiles, t.ctypes.data, d_coded, coded_bytes, 1,
                                                  d_pixels, 1), "decode_tiles")
+
+    def set_decode_segments(self, per_block):
+        """Part-1 blocks with several codeword segments (LAZY / TERMALL): per_block = [[(bytes, passes), ...], ...] in
+        table order; None or [] returns to one segment per block."""
+        if not per_block:
+            self._check(self._L.grk_amd_set_decode_segments(self._h, None, None, 0), "set_decode_segments")
+            return
+        first = np.zeros(len(per_block) + 1, np.uint32)
+        first[1:] = np.cumsum([len(b) for b in per_block])
+        segs = np.array([v for b in per_block for s in b for v in s], np.uint32).reshape(-1, 2)
+        self._check(self._L.grk_amd_set_decode_segments(self._h, first.ctypes.data, segs.ctypes.data if segs.size else None,
+                                                        len(per_block)), "set_decode_segments")
 
     def set_decode_qcd(self, words):
         w = np.ascontiguousarray(words, np.uint16)

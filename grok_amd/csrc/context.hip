@@ -57,6 +57,9 @@ struct grk_amd_ctx {
     TileGeom geom;
     std::vector<HtBlockDesc> h_desc, h_desc_dec;
     std::vector<uint16_t> dec_qcd;                          // decode: QCD words of a foreign stream (optional)
+    std::vector<uint32_t> dec_seg_first;                    // Part-1 decode: codeword segments (optional), [nblocks + 1]
+    std::vector<grk_amd_segment> dec_segs;
+    DevBuf dec_seg_dev;
     HtClass ht_classes[2]; uint32_t ht_num_classes = 0;     // block classes of K3 (by LDS need)
     DevBuf ht_sel;
     std::vector<uint64_t> h_off;
@@ -88,7 +91,7 @@ bool same_params(const grk_amd_tile_params& a, const grk_amd_tile_params& b)
     return a.tile_w == b.tile_w && a.tile_h == b.tile_h && a.num_comps == b.num_comps && a.prec == b.prec &&
            a.sgnd == b.sgnd && a.irreversible == b.irreversible && a.mct == b.mct &&
            a.num_levels == b.num_levels && a.cblk_w_exp == b.cblk_w_exp && a.cblk_h_exp == b.cblk_h_exp &&
-           a.reserved[0] == b.reserved[0];
+           a.reserved[0] == b.reserved[0] && a.reserved[1] == b.reserved[1];
 }
 
 int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
@@ -355,6 +358,19 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     a.work = (int32_t*)c->dec_work.p; a.status = (unsigned int*)c->flag.p;
     a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.irreversible = g.p.irreversible;
+    a.cblksty = g.p.reserved[1];
+    if (!c->dec_seg_first.empty()) {
+        if (c->dec_seg_first.size() != nblocks + 1 || c->dec_seg_first.back() != c->dec_segs.size())
+            return fail(c, GRK_AMD_ERR_INVALID, "segment list does not match the number of blocks");
+        static_assert(sizeof(grk_amd_segment) == sizeof(uint2), "segments are {bytes, passes}");
+        const size_t nf = c->dec_seg_first.size() * 4, ns = c->dec_segs.size() * sizeof(grk_amd_segment);
+        const size_t ns_off = (nf + 15) & ~(size_t)15;
+        HIP_TRY(c, c->dec_seg_dev.ensure(ns_off + ns + 16), "alloc segment list");
+        HIP_TRY(c, hipMemcpyAsync(c->dec_seg_dev.p, c->dec_seg_first.data(), nf, hipMemcpyHostToDevice, c->stream), "upload segment index");
+        if (ns) HIP_TRY(c, hipMemcpyAsync((char*)c->dec_seg_dev.p + ns_off, c->dec_segs.data(), ns, hipMemcpyHostToDevice, c->stream), "upload segments");
+        a.seg_first = (const uint32_t*)c->dec_seg_dev.p;
+        a.segs = (const uint2*)((const char*)c->dec_seg_dev.p + ns_off);
+    }
     ScopedTimer t(c, 5);
     HIP_TRY(c, launch_t1_decode(a, c->stream), "launch Part-1 decode");
     return GRK_AMD_OK;
@@ -589,6 +605,17 @@ int grk_amd_set_decode_qcd(grk_amd_ctx* c, const uint16_t* words, uint32_t count
     if (!c || (count && !words)) return GRK_AMD_ERR_INVALID;
     c->dec_qcd.assign(words, words + count);
     c->have_geom = false;                  // the per-block dequantisation scales are rebuilt on the next call
+    return GRK_AMD_OK;
+}
+
+int grk_amd_set_decode_segments(grk_amd_ctx* c, const uint32_t* first_segment, const grk_amd_segment* segments, uint32_t nblocks)
+{
+    if (!c || (nblocks && (!first_segment || (first_segment[nblocks] && !segments)))) return GRK_AMD_ERR_INVALID;
+    c->dec_seg_first.clear(); c->dec_segs.clear();
+    if (nblocks) {
+        c->dec_seg_first.assign(first_segment, first_segment + nblocks + 1);
+        c->dec_segs.assign(segments, segments + first_segment[nblocks]);
+    }
     return GRK_AMD_OK;
 }
 

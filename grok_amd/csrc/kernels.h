@@ -102,6 +102,9 @@ struct T1DecArgs {
     unsigned int* status;
     int32_t* mallat; uint32_t stride; uint64_t pitch;
     int irreversible;
+    uint32_t cblksty;                          // COD code-block style bits (LAZY 1, RESET 2, TERMALL 4, VSC 8, PTERM 16, SEGSYM 32)
+    const uint32_t* seg_first;                 // [nblocks + 1] first codeword segment of each block, or null: one segment
+    const uint2* segs;                         // {bytes, passes} per segment
 };
 uint32_t   t1_lanes_per_group(uint32_t nblocks);
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s);

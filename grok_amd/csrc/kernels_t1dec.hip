@@ -1,9 +1,11 @@
 // grok_amd/csrc/kernels_t1dec.hip -- K8: Part-1 (EBCOT) Tier-1 block decoder + dequantisation, gfx950.
 //
 // Replaces T1Part1::decompress -> T1::decompress_cblk (t1/t1_part1/T1Part1.cpp:124-151,
-// t1/t1_part1/T1.cpp:1262-1337: code-block style 0, one arithmetic-coded segment) with its MQ decoder
-// (mqc_dec.cpp:107-177, mqc_dec_inl.h) and ShiftFilter / ScaleFilter
-// (filters/PostDecompressFilters.h:26-35, :60-71).
+// t1/t1_part1/T1.cpp:1262-1337) with its MQ decoder (mqc_dec.cpp:107-177, mqc_dec_inl.h), the raw (bypass)
+// decoder (mqc_dec.cpp:156-160, mqc_dec_inl.h:55-76) and ShiftFilter / ScaleFilter
+// (filters/PostDecompressFilters.h:26-35, :60-71).  Code-block styles as the reference decodes them: LAZY (raw
+// sig-prop / mag-ref passes from the fifth plane on), RESET, TERMALL (both through the codeword-segment list),
+// VSC, SEGSYM (decoded, a bad symbol is only a warning there) and PTERM (a check that does not change the result).
 //
 // EBCOT decoding is one dependent chain per code-block: every MQ decision renormalises the
 // interval the next one uses and every context depends on the samples decoded so far.  As in K5a the
@@ -66,14 +68,30 @@ struct MqDec {
             else { ++pos; c += nxt << 9; ct = 7; }
         } else { ++pos; c += nxt << 8; ct = 8; }
     }
-    __device__ __forceinline__ void init()
+    __device__ __forceinline__ void reset_states()                 // mqc_resetstates (mqc_dec.cpp:168-175)
     {
-        pos = 0;
         for (int i = 0; i < kNumCtx; ++i) cx[i] = 0;
         cx[kCtxUni] = 46; cx[kCtxAgg] = 3; cx[kCtxZC] = 4;
+    }
+    __device__ __forceinline__ void init_segment()                 // mqc_init_dec (:140-154): the states are kept
+    {
+        pos = 0;
         c = (len == 0 ? 0xFFu : byte_at(0)) << 16;
         bytein();
         c <<= 7; ct -= 7; a = 0x8000u;
+    }
+    __device__ __forceinline__ void init_raw_segment() { pos = 0; c = 0; ct = 0; }     // mqc_raw_init_dec (:156-160)
+    __device__ __forceinline__ uint32_t raw_decode()               // mqc_raw_decode (mqc_dec_inl.h:55-76)
+    {
+        if (ct == 0) {
+            const uint32_t b = byte_at(pos);
+            if (c == 0xFFu) {
+                if (b > 0x8Fu) { c = 0xFFu; ct = 8; }              // the terminating marker: ones for ever
+                else { c = b; ++pos; ct = 7; }
+            } else { c = b; ++pos; ct = 8; }
+        }
+        --ct;
+        return (c >> ct) & 1u;
     }
     __device__ __forceinline__ uint32_t decode(int ctx)
     {
@@ -144,10 +162,15 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     for (int i = 0; i < 66; ++i) { sig[i] = 0; neg[i] = 0; pi[i] = 0; mu[i] = 0; }
 
     MqDec mq;
-    mq.d = a.coded + in.offset; mq.len = in.length;
     mq.lo = a.coded; mq.hi = a.coded + a.coded_bytes;
     mq.cx = ctx_l[threadIdx.x]; mq.tab = mq_l;
-    mq.init();
+    mq.reset_states();
+    const bool lazy = (a.cblksty & 0x01u) != 0, reset = (a.cblksty & 0x02u) != 0, vsc = (a.cblksty & 0x08u) != 0,
+               segsym = (a.cblksty & 0x20u) != 0;
+    // codeword segments: the caller's list, or the whole block as one segment (T1.cpp:1280-1292)
+    uint32_t sg = a.seg_first ? a.seg_first[blk] : 0u;
+    const uint32_t sg_end = a.seg_first ? a.seg_first[blk + 1] : 1u;
+    uint32_t seg_off = 0;
 
     // ---- the passes work stripe by stripe with the stripe's rows in REGISTERS: S[j+1] / N[j+1] are the
     //      significance / sign rows of stripe row j (S[0], S[5]: the rows above and below), P[j] / M[j] its
@@ -156,7 +179,14 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     auto dil = [](uint64_t v) { return v | (v << 1) | (v >> 1); };
 
     int bp = (int)numbps, type = 2;
-    for (uint32_t p = 0; p < numpasses && bp >= 1; ++p) {
+    for (; sg < sg_end; ++sg) {
+    const uint32_t seg_len = a.seg_first ? a.segs[sg].x : in.length, seg_passes = a.seg_first ? a.segs[sg].y : numpasses;
+    const bool raw_seg = lazy && bp <= (int)numbps - 4 && type < 2;           // decided where the segment starts
+    mq.d = a.coded + in.offset + seg_off; mq.len = seg_len;
+    seg_off += seg_len;
+    if (raw_seg) mq.init_raw_segment(); else mq.init_segment();
+    for (uint32_t p = 0; p < seg_passes && bp >= 1; ++p) {
+        const bool raw = raw_seg && type < 2;
         const int32_t one = 1 << bp, oph = one | (one >> 1), poshalf = one >> 1;
         for (uint32_t k = 0; k < h; k += 4) {
             uint64_t S[6], N[6], P[4], M[4];
@@ -164,6 +194,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             for (int j = 0; j < 6; ++j) { S[j] = sig[k + j]; N[j] = neg[k + j]; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { P[j] = pi[k + 1 + j]; M[j] = mu[k + 1 + j]; }
+            if (vsc) { S[5] = 0; N[5] = 0; }       // vertically causal: a stripe never sees the one below (T1.cpp:198-221)
             const uint32_t nr = min(4u, h - k);
             // rows of the stripe that do not exist behave as "already coded"
             uint64_t rowok[4];
@@ -183,7 +214,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 if (hc == 1)      { cxn = vc == 1 ? 13 : (vc == 0 ? 12 : 11); xr = 0; }                            \
                 else if (hc == 0) { cxn = vc == 0 ? 9 : 10; xr = vc == -1; }                                      \
                 else              { cxn = vc == 1 ? 11 : (vc == 0 ? 12 : 13); xr = 1; }                            \
-                const uint32_t ng = mq.decode(cxn) ^ (uint32_t)xr;                                                \
+                const uint32_t ng = raw ? mq.raw_decode() : (mq.decode(cxn) ^ (uint32_t)xr);                      \
                 ws[(size_t)((k + (j)) * 64u + (x)) * L] = ng ? -oph : oph;                                        \
                 S[(j) + 1] |= 1ull << (x);                                                                        \
                 if (ng) N[(j) + 1] |= 1ull << (x);                                                                \
@@ -222,7 +253,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                         if (!((rowok[j] >> x) & 1ull) || (((S[j + 1] | P[j]) >> x) & 1ull)) continue;
                         const uint32_t w0 = win3(S[j], x), w1 = win3(S[j + 1], x), w2 = win3(S[j + 2], x);
                         if (!((w0 | w2) | (w1 & 5u))) continue;
-                        if (mq.decode(kCtxZC + zc_ctx(w0, w1, w2))) T1_SIGN_AND_SET(j, x)
+                        if (raw ? mq.raw_decode() : mq.decode(kCtxZC + zc_ctx(w0, w1, w2))) T1_SIGN_AND_SET(j, x)
                         P[j] |= 1ull << x;
                     }
                     ++x;
@@ -239,7 +270,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                         if (!((S[j + 1] & ~P[j] & rowok[j]) >> x & 1ull)) continue;
                         const uint32_t w0 = win3(S[j], x), w1 = win3(S[j + 1], x), w2 = win3(S[j + 2], x);
                         const int cxn = ((M[j] >> x) & 1ull) ? 16 : (((w0 | w2) | (w1 & 5u)) ? 15 : 14);    // Table D.4
-                        const uint32_t b = mq.decode(cxn);
+                        const uint32_t b = raw ? mq.raw_decode() : mq.decode(cxn);
                         const uint32_t isneg = (uint32_t)(N[j + 1] >> x) & 1u;   // the value's sign, without reading it back
                         atomicAdd(&ws[(size_t)((k + j) * 64u + x) * L], (b ^ isneg) ? poshalf : -poshalf);
                         M[j] |= 1ull << x;
@@ -283,7 +314,11 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 sig[k + 1 + j] = S[j + 1]; neg[k + 1 + j] = N[j + 1]; pi[k + 1 + j] = P[j]; mu[k + 1 + j] = M[j];
             }
         }
+        if (type == 2 && segsym)                               // dec_clnpass_check_segsym (:977-993): 0xA expected, only warned about
+            for (int i = 0; i < 4; ++i) (void)mq.decode(kCtxUni);
+        if (reset && !raw_seg) mq.reset_states();
         if (++type == 3) { type = 0; --bp; }
+    }
     }
 }
 

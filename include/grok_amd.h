@@ -57,9 +57,12 @@ typedef struct grk_amd_tile_params {
     uint8_t  num_levels;         /* numresolution - 1                                           */
     uint8_t  cblk_w_exp;         /* log2 code-block width  (6)                                  */
     uint8_t  cblk_h_exp;         /* log2 code-block height (6)                                  */
-    uint8_t  reserved[3];        /* [0]: decode only -- 1 = the blocks are Part-1 (EBCOT/MQ, code-block
-                                    style 0) instead of HT; then missing_msbs of a table row carries
-                                    numbps | numpasses << 8 (block bit-planes coded, coding passes)   */
+    uint8_t  reserved[3];        /* [0]: decode only -- 1 = the blocks are Part-1 (EBCOT/MQ) instead of HT;
+                                    then missing_msbs of a table row carries numbps | numpasses << 8
+                                    (block bit-planes coded, coding passes in total)
+                                    [1]: Part-1 decode -- the COD code-block style bits as the reference
+                                    names them (grok.h GRK_CBLKSTY_*): LAZY 0x01, RESET 0x02, TERMALL 0x04,
+                                    VSC 0x08, PTERM 0x10, SEGSYM 0x20                                 */
 } grk_amd_tile_params;
 
 /* One code-block of the tile, in the reference's enumeration order
@@ -158,6 +161,14 @@ int grk_amd_decode_status(grk_amd_ctx* ctx);
  * order) its QCD marker carries, from which the decode-side step sizes are derived
  * (codestream/Quantizer.cpp:41-63).  count = 0 returns to the exponents this library's encoder writes. */
 int grk_amd_set_decode_qcd(grk_amd_ctx* ctx, const uint16_t* words, uint32_t count);
+/* Part-1 blocks with more than one codeword segment (LAZY, TERMALL -- T1::decompress_cblk's segment loop,
+ * t1/t1_part1/T1.cpp:1280-1318; Grok's own plugin bridge refuses those, plugin_bridge.cpp:50-61, so this is
+ * reachable through this C ABI only).  Segments of block i are first_segment[i] .. first_segment[i+1]-1, their
+ * bytes lie end to end at the block's offset.  Applies to the following decode calls; nblocks = 0 returns to
+ * one segment per block (length and pass count of the table row). */
+typedef struct grk_amd_segment { uint32_t length; uint32_t numpasses; } grk_amd_segment;
+int grk_amd_set_decode_segments(grk_amd_ctx* ctx, const uint32_t* first_segment, const grk_amd_segment* segments,
+                                uint32_t nblocks);
 /* HT cleanup decode + dequantisation of every block into Mallat planes (device pointers) */
 int grk_amd_stage_ht_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
                             const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes,

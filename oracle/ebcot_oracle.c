@@ -1,8 +1,10 @@
 /* oracle/ebcot_oracle.c -- TEST INFRASTRUCTURE ONLY (see j2k_oracle.h).
  *
  * CPU restatement of row a13 of SURVEY.md §8: the Part-1 (EBCOT) Tier-1 block DEcoder
- *   T1::decompress_cblk                 t1/t1_part1/T1.cpp:1262-1337   (default code-block style 0:
- *                                        one segment, all passes arithmetic-coded)
+ *   T1::decompress_cblk                 t1/t1_part1/T1.cpp:1262-1337   (segments; code-block styles LAZY = raw
+ *                                        sig-prop/mag-ref passes after four planes, RESET, TERMALL, VSC,
+ *                                        PTERM [a check only], SEGSYM)
+ *   raw (bypass) decoder                 mqc_dec.cpp:156-160, mqc_dec_inl.h:55-76; raw passes T1.cpp:1009-1021, :1155-1165
  *   cleanup / sig-prop / mag-ref passes  T1.cpp:854-1007, :1024-1152, :1160-1255
  *   MQ decoder                           t1/t1_part1/mqc_dec.cpp:107-177, mqc_dec_inl.h:26-150
  *   dequantisation                       filters/PostDecompressFilters.h:26-35 (ShiftFilter: v/2),
@@ -48,14 +50,39 @@ static void mq_bytein(mq_t* m)
         else { m->pos++; m->c += nxt << 9; m->ct = 7; }
     } else { m->pos++; m->c += nxt << 8; m->ct = 8; }
 }
-static void mq_init(mq_t* m, const uint8_t* d, uint32_t len)
-{
-    m->d = d; m->len = len; m->pos = 0;
+static void mq_resetstates(mq_t* m)
+{   /* mqc_resetstates (mqc_dec.cpp:168-175) */
     memset(m->idx, 0, sizeof m->idx); memset(m->mps, 0, sizeof m->mps);
-    m->idx[CTX_UNI] = 46; m->idx[CTX_AGG] = 3; m->idx[CTX_ZC] = 4;   /* mqc_resetstates */
+    m->idx[CTX_UNI] = 46; m->idx[CTX_AGG] = 3; m->idx[CTX_ZC] = 4;
+}
+static void mq_init_dec(mq_t* m, const uint8_t* d, uint32_t len)
+{   /* mqc_init_dec (mqc_dec.cpp:140-154): a segment start; the context states are NOT touched */
+    m->d = d; m->len = len; m->pos = 0;
     m->c = (len == 0 ? 0xFFu : d[0]) << 16;
     mq_bytein(m);
     m->c <<= 7; m->ct -= 7; m->a = 0x8000;
+}
+static void mq_init(mq_t* m, const uint8_t* d, uint32_t len)
+{
+    mq_resetstates(m);
+    mq_init_dec(m, d, len);
+}
+/* raw (bypass) segments: mqc_raw_init_dec (mqc_dec.cpp:156-160), mqc_raw_decode (mqc_dec_inl.h:55-76) */
+static void raw_init_dec(mq_t* m, const uint8_t* d, uint32_t len)
+{
+    m->d = d; m->len = len; m->pos = 0; m->c = 0; m->ct = 0;
+}
+static uint32_t raw_decode(mq_t* m)
+{
+    if (m->ct == 0) {
+        const uint32_t b = mq_byte(m, m->pos);
+        if (m->c == 0xFF) {
+            if (b > 0x8F) { m->c = 0xFF; m->ct = 8; }                /* the terminating marker: ones for ever */
+            else { m->c = b; m->pos++; m->ct = 7; }
+        } else { m->c = b; m->pos++; m->ct = 8; }
+    }
+    m->ct--;
+    return (m->c >> m->ct) & 1u;
 }
 static uint32_t mq_decode(mq_t* m, int cx)
 {
@@ -82,15 +109,23 @@ static uint32_t mq_decode(mq_t* m, int cx)
 /* ---- coding passes --------------------------------------------------------------------------------- */
 enum { F_SIG = 1, F_NEG = 2, F_PI = 4, F_MU = 8 };          /* significant, negative, visited this plane, refined */
 
-typedef struct { uint8_t* f; int32_t* v; uint32_t w, h, fs; int orient; mq_t mq; } t1_t;
+typedef struct { uint8_t* f; int32_t* v; uint32_t w, h, fs; int orient; int vsc, raw; mq_t mq; } t1_t;
 #define FL(t, x, y) ((t)->f[((y) + 1) * (t)->fs + (x) + 1])
+/* Neighbour (x + dx, y + dy) as sample (x, y) sees it.  Vertically causal contexts (VSC): the last row of a
+ * stripe never learns about the stripe below -- update_flags skips the northward update for ci == 0
+ * (T1.cpp:198-221) -- so those three neighbours read as insignificant. */
+static uint8_t NB(const t1_t* t, uint32_t x, uint32_t y, int dx, int dy)
+{
+    if (t->vsc && dy == 1 && (y & 3u) == 3u) return 0;
+    return FL(t, x + dx, y + dy);
+}
 
 static int zc_ctx(const t1_t* t, uint32_t x, uint32_t y)
 {   /* Table D.1 */
-    int hh = (FL(t, x - 1, y) & F_SIG) + (FL(t, x + 1, y) & F_SIG);
-    int vv = (FL(t, x, y - 1) & F_SIG) + (FL(t, x, y + 1) & F_SIG);
-    int dd = (FL(t, x - 1, y - 1) & F_SIG) + (FL(t, x + 1, y - 1) & F_SIG) +
-             (FL(t, x - 1, y + 1) & F_SIG) + (FL(t, x + 1, y + 1) & F_SIG);
+    int hh = (NB(t, x, y, -1, 0) & F_SIG) + (NB(t, x, y, 1, 0) & F_SIG);
+    int vv = (NB(t, x, y, 0, -1) & F_SIG) + (NB(t, x, y, 0, 1) & F_SIG);
+    int dd = (NB(t, x, y, -1, -1) & F_SIG) + (NB(t, x, y, 1, -1) & F_SIG) +
+             (NB(t, x, y, -1, 1) & F_SIG) + (NB(t, x, y, 1, 1) & F_SIG);
     if (t->orient == 1) { int s = hh; hh = vv; vv = s; }            /* HL: horizontal and vertical swap roles */
     if (t->orient == 3) {                                            /* HH */
         int hv = hh + vv;
@@ -107,8 +142,8 @@ static int zc_ctx(const t1_t* t, uint32_t x, uint32_t y)
 }
 static int any_sig_neighbour(const t1_t* t, uint32_t x, uint32_t y)
 {
-    return (FL(t, x - 1, y) | FL(t, x + 1, y) | FL(t, x, y - 1) | FL(t, x, y + 1) | FL(t, x - 1, y - 1) |
-            FL(t, x + 1, y - 1) | FL(t, x - 1, y + 1) | FL(t, x + 1, y + 1)) & F_SIG;
+    return (NB(t, x, y, -1, 0) | NB(t, x, y, 1, 0) | NB(t, x, y, 0, -1) | NB(t, x, y, 0, 1) | NB(t, x, y, -1, -1) |
+            NB(t, x, y, 1, -1) | NB(t, x, y, -1, 1) | NB(t, x, y, 1, 1)) & F_SIG;
 }
 static int contrib(uint8_t a, uint8_t b)
 {   /* Table D.2: sign contribution of two opposite neighbours */
@@ -119,7 +154,7 @@ static int contrib(uint8_t a, uint8_t b)
 }
 static uint32_t decode_sign(t1_t* t, uint32_t x, uint32_t y)
 {   /* Table D.3 */
-    const int hc = contrib(FL(t, x - 1, y), FL(t, x + 1, y)), vc = contrib(FL(t, x, y - 1), FL(t, x, y + 1));
+    const int hc = contrib(NB(t, x, y, -1, 0), NB(t, x, y, 1, 0)), vc = contrib(NB(t, x, y, 0, -1), NB(t, x, y, 0, 1));
     int cx, xr;
     if (hc == 1)      { cx = vc == 1 ? 13 : (vc == 0 ? 12 : 11); xr = 0; }
     else if (hc == 0) { cx = vc == 0 ? 9 : 10; xr = vc == -1; }
@@ -128,7 +163,7 @@ static uint32_t decode_sign(t1_t* t, uint32_t x, uint32_t y)
 }
 static void become_significant(t1_t* t, uint32_t x, uint32_t y, int32_t oneplushalf)
 {
-    const uint32_t neg = decode_sign(t, x, y);
+    const uint32_t neg = t->raw ? raw_decode(&t->mq) : decode_sign(t, x, y);       /* raw: the sign bit itself (T1.cpp:1016-1018) */
     t->v[y * t->w + x] = neg ? -oneplushalf : oneplushalf;
     FL(t, x, y) |= (uint8_t)(F_SIG | (neg ? F_NEG : 0));
 }
@@ -140,7 +175,7 @@ static void sigpass(t1_t* t, int bp)
         for (uint32_t x = 0; x < t->w; ++x)
             for (uint32_t y = k; y < k + 4 && y < t->h; ++y) {
                 if ((FL(t, x, y) & (F_SIG | F_PI)) || !any_sig_neighbour(t, x, y)) continue;
-                if (mq_decode(&t->mq, CTX_ZC + zc_ctx(t, x, y))) become_significant(t, x, y, oph);
+                if (t->raw ? raw_decode(&t->mq) : mq_decode(&t->mq, CTX_ZC + zc_ctx(t, x, y))) become_significant(t, x, y, oph);
                 FL(t, x, y) |= F_PI;
             }
 }
@@ -152,7 +187,7 @@ static void refpass(t1_t* t, int bp)
             for (uint32_t y = k; y < k + 4 && y < t->h; ++y) {
                 if ((FL(t, x, y) & (F_SIG | F_PI)) != F_SIG) continue;
                 const int cx = (FL(t, x, y) & F_MU) ? 16 : (any_sig_neighbour(t, x, y) ? 15 : 14);   /* Table D.4 */
-                const uint32_t b = mq_decode(&t->mq, cx);
+                const uint32_t b = t->raw ? raw_decode(&t->mq) : mq_decode(&t->mq, cx);
                 int32_t* p = &t->v[y * t->w + x];
                 *p += (b ^ (uint32_t)(*p < 0)) ? poshalf : -poshalf;
                 FL(t, x, y) |= F_MU;
@@ -190,7 +225,7 @@ int32_t orc_t1_decode_block(const uint8_t* coded, uint32_t len, uint32_t numpass
 {
     if (numbps >= 31 - 6) return -1;                                 /* k_max_bit_planes (t1_common.h:70) */
     t1_t t;
-    t.w = w; t.h = h; t.fs = w + 2; t.orient = (int)orient;
+    t.w = w; t.h = h; t.fs = w + 2; t.orient = (int)orient; t.vsc = 0; t.raw = 0;
     t.f = (uint8_t*)calloc((size_t)(w + 2) * (h + 2), 1);
     t.v = out;
     memset(out, 0, (size_t)w * h * sizeof(int32_t));
@@ -204,6 +239,49 @@ int32_t orc_t1_decode_block(const uint8_t* coded, uint32_t len, uint32_t numpass
     }
     free(t.f);
     return 0;
+}
+
+/* The general form (T1.cpp:1262-1337): `nsegs` codeword segments of seg_len[i] bytes holding seg_passes[i] passes
+ * each, laid end to end in `coded`; cblksty = the COD code-block style bits (LAZY 1, RESET 2, TERMALL 4, VSC 8,
+ * PTERM 16, SEGSYM 32).  Returns the number of segmentation symbols that were not 0xA (the reference only warns),
+ * or -1 if the block is rejected. */
+int32_t orc_t1_decode_block_sty(const uint8_t* coded, uint32_t nsegs, const uint32_t* seg_len, const uint32_t* seg_passes,
+                                uint32_t numbps, uint32_t orient, uint32_t cblksty, uint32_t w, uint32_t h, int32_t* out)
+{
+    if (numbps >= 31 - 6) return -1;
+    t1_t t;
+    t.w = w; t.h = h; t.fs = w + 2; t.orient = (int)orient; t.vsc = (cblksty & 8u) != 0; t.raw = 0;
+    t.f = (uint8_t*)calloc((size_t)(w + 2) * (h + 2), 1);
+    t.v = out;
+    memset(out, 0, (size_t)w * h * sizeof(int32_t));
+    int bp = (int)numbps, type = 2, bad_segsym = 0;
+    uint32_t off = 0;
+    mq_resetstates(&t.mq);
+    for (uint32_t sg = 0; sg < nsegs; ++sg) {
+        t.raw = (bp <= (int)numbps - 4) && type < 2 && (cblksty & 1u);            /* decided at the segment start */
+        if (t.raw) raw_init_dec(&t.mq, coded + off, seg_len[sg]);
+        else mq_init_dec(&t.mq, coded + off, seg_len[sg]);
+        off += seg_len[sg];
+        for (uint32_t p = 0; p < seg_passes[sg] && bp >= 1; ++p) {
+            if (type == 0) sigpass(&t, bp);
+            else if (type == 1) refpass(&t, bp);
+            else {
+                const int was_raw = t.raw;
+                t.raw = 0;                                                          /* the cleanup pass is never raw */
+                clnpass(&t, bp);
+                if (cblksty & 32u) {                                                /* dec_clnpass_check_segsym (:977-993) */
+                    uint32_t v = 0;
+                    for (int i = 0; i < 4; ++i) v = (v << 1) | mq_decode(&t.mq, CTX_UNI);
+                    if (v != 0xA) ++bad_segsym;
+                }
+                t.raw = was_raw;
+            }
+            if ((cblksty & 2u) && !t.raw) mq_resetstates(&t.mq);
+            if (++type == 3) { type = 0; --bp; }
+        }
+    }
+    free(t.f);
+    return bad_segsym;
 }
 
 /* ---- dequantisation ------------------------------------------------------------------------------------ */

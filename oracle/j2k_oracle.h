@@ -103,6 +103,10 @@ void orc_dc_store_irrev(int32_t* c, size_t n, int32_t shift, int32_t lo, int32_t
  *           the decoder's representation (one extra fractional bit).  Then ShiftFilter / ScaleFilter. */
 int32_t orc_t1_decode_block(const uint8_t* coded, uint32_t len, uint32_t numpasses, uint32_t numbps,
                             uint32_t orient, uint32_t w, uint32_t h, int32_t* out);
+/* general form: codeword segments + code-block styles (LAZY 1, RESET 2, TERMALL 4, VSC 8, PTERM 16, SEGSYM 32);
+ * returns the number of bad segmentation symbols (the reference only warns) or -1 */
+int32_t orc_t1_decode_block_sty(const uint8_t* coded, uint32_t nsegs, const uint32_t* seg_len, const uint32_t* seg_passes,
+                                uint32_t numbps, uint32_t orient, uint32_t cblksty, uint32_t w, uint32_t h, int32_t* out);
 void orc_t1_dequant_rev(const int32_t* v, uint32_t n, int32_t* out);
 void orc_t1_dequant_irrev(const int32_t* v, uint32_t n, float stepsize, float* out);
 

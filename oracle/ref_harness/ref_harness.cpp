@@ -147,6 +147,7 @@ struct EncCfg {
 	int32_t C, W, H, TW, TH, prec, irrev, numres, ht, mode; // mode 0: grk_compress_tile, 1: grk_compress(image data)
 	int32_t rate_algo;                                        // parameters.rateControlAlgorithm
 	int32_t cblk_w, cblk_h;                                   // 0 = default 64
+	int32_t cblk_sty;                                         // Part-1 code-block style bits (grk_compress -M)
 };
 
 static void fill_params(grk_cparameters& p, const EncCfg& c)
@@ -160,6 +161,7 @@ static void fill_params(grk_cparameters& p, const EncCfg& c)
 	p.prog_order = GRK_LRCP;
 	p.tcp_mct = (c.C >= 3) ? 1 : 0;
 	if (c.ht) { p.isHT = true; p.cblk_sty = GRK_CBLKSTY_HT; }
+	else if (c.cblk_sty) p.cblk_sty = (uint8_t)c.cblk_sty;
 	p.rateControlAlgorithm = (uint32_t)c.rate_algo;
 	if (c.cblk_w) p.cblockw_init = (uint32_t)c.cblk_w;
 	if (c.cblk_h) p.cblockh_init = (uint32_t)c.cblk_h;
@@ -435,6 +437,63 @@ int32_t ref_t1_decode_block(const uint8_t* coded, uint32_t len, uint32_t numpass
 	t1.allocCompressedData(len + 8);
 	memcpy(t1.getCompressedDataBuffer(), coded, len);
 	bool ok = t1.decompress_cblk(&cblk, t1.getCompressedDataBuffer(), (uint8_t)orient, 0);
+	memcpy(out, data.data(), data.size() * 4);
+	return ok ? 0 : -1;
+}
+
+// Part-1 encoder with a code-block style: also returns each pass's cumulative rate and termination flag, from which
+// the codeword segments follow (a segment ends at every terminated pass and at the last pass).
+int32_t ref_t1_encode_block_sty(const int32_t* coef, uint32_t w, uint32_t h, uint32_t stride, uint32_t orient, uint32_t cblksty,
+								uint8_t* out, uint32_t cap, uint32_t* numpasses, uint32_t* numbps, uint32_t* pass_rate,
+								uint8_t* pass_term, uint32_t pass_cap)
+{
+	grk::T1 t1(true, w, h);
+	if (!t1.alloc(w, h)) return -1;
+	auto d = t1.getUncompressedData();
+	uint32_t maxv = 0;
+	for (uint32_t y = 0; y < h; ++y)
+		for (uint32_t x = 0; x < w; ++x) {
+			int32_t temp = coef[(size_t)y * stride + x] * (1 << T1_NMSEDEC_FRACBITS);
+			temp = (int32_t)to_smr(temp);
+			maxv = std::max<uint32_t>(maxv, smr_abs(temp));
+			d[(size_t)y * w + x] = temp;
+		}
+	std::vector<uint8_t> buf((size_t)w * h * 8 + 4096, 0);
+	grk::cblk_enc c;
+	memset(&c, 0, sizeof(c));
+	c.x0 = 0; c.y0 = 0; c.x1 = w; c.y1 = h;
+	c.data = buf.data() + 2;
+	t1.compress_cblk(&c, maxv, (uint8_t)orient, 0, 0, 1, 1.0, cblksty, nullptr, 0, false);
+	uint32_t len = c.numPassesTotal ? c.passes[c.numPassesTotal - 1].rate : 0;
+	*numpasses = c.numPassesTotal; *numbps = c.numbps;
+	int32_t rc = -1;
+	if (len <= cap && c.numPassesTotal <= pass_cap) {
+		memcpy(out, c.data, len); rc = (int32_t)len;
+		for (uint32_t i = 0; i < c.numPassesTotal; ++i) { pass_rate[i] = c.passes[i].rate; pass_term[i] = c.passes[i].term ? 1 : 0; }
+	}
+	t1.code_block_enc_deallocate(&c);
+	return rc;
+}
+
+int32_t ref_t1_decode_block_sty(const uint8_t* coded, uint32_t nsegs, const uint32_t* seg_len, const uint32_t* seg_passes,
+								uint32_t numbps, uint32_t orient, uint32_t cblksty, uint32_t w, uint32_t h, int32_t* out)
+{
+	grk::T1 t1(false, w, h);
+	DecompressCodeblock cblk;
+	cblk.setRect(grkRectU32(0, 0, w, h));
+	if (!cblk.alloc()) return -1;
+	cblk.numbps = numbps;
+	uint32_t len = 0;
+	for (uint32_t i = 0; i < nsegs; ++i) {
+		auto seg = cblk.nextSegment();
+		seg->numpasses = seg_passes[i]; seg->len = seg_len[i]; seg->maxpasses = seg_passes[i];
+		len += seg_len[i];
+	}
+	std::vector<int32_t> data((size_t)w * h, 0);
+	t1.attachUncompressedData(data.data(), w, h);
+	t1.allocCompressedData(len + 8);
+	memcpy(t1.getCompressedDataBuffer(), coded, len);
+	bool ok = t1.decompress_cblk(&cblk, t1.getCompressedDataBuffer(), (uint8_t)orient, cblksty);
 	memcpy(out, data.data(), data.size() * 4);
 	return ok ? 0 : -1;
 }

@@ -113,6 +113,19 @@ def parse(cs):
     cexp = min(info["cbw"], 15), min(info["cbh"], 15)
     state = {}
     blocks = {}
+    segments = {}                 # key -> [(bytes, passes), ...] codeword segments (B.10.7.2: TERMALL / LAZY split them)
+    sty = info["cblk_sty"]
+
+    def split_passes(npass):
+        if sty & 0x04:            # TERMALL: every pass terminated (T2Decompress.cpp:169-186)
+            return [1] * npass
+        if sty & 0x01:            # LAZY: 10 passes, then raw pair / cleanup alternately
+            out, cap = [], 10
+            while npass > 0:
+                out.append(min(cap, npass)); npass -= out[-1]
+                cap = 2 if cap in (10, 1) else 1
+            return out
+        return [npass]
 
     def band_rect(r, b):
         n = L - r + (1 if r > 0 else 0)
@@ -171,20 +184,18 @@ def parse(cs):
                     while br.bit():
                         lb += 1
                     lblock[idx] = lb
-                    if info["ht"]:
-                        # HT: the cleanup pass is one segment; placeholder passes multiply by 3 (T.814 B.?), the
-                        # reference's encoder emits a single pass
-                        nbits = lb + int(np.floor(np.log2(npass)))
-                    else:
-                        nbits = lb + int(np.floor(np.log2(npass)))
-                    ln = br.bits(nbits)
-                    todo.append(((c, r, b, idx), npass, zero_bp, ln))
+                    # one length per codeword segment, lblock + floor(log2(passes in the segment)) bits each; HT: the
+                    # reference's encoder emits the single cleanup pass as one segment
+                    segs = [(br.bits(lb + int(np.floor(np.log2(k)))), k) for k in ([npass] if info["ht"] else split_passes(npass))]
+                    segments[(c, r, b, idx)] = segs
+                    todo.append(((c, r, b, idx), npass, zero_bp, sum(a for a, _ in segs)))
             pos = br.align()
             for key, npass, zero_bp, ln in todo:
                 blocks[key] = (cs[pos:pos + ln], npass, zero_bp)
                 pos += ln
     assert pos <= end + 2, "packet parsing ran past the tile-part"
     info["blocks"] = blocks
+    info["segments"] = segments
     return info
 
 
@@ -210,3 +221,14 @@ def decode_table(info, layout_blocks, part1):
         chunks.append(pad)
         off += len(pad)
     return rows, b"".join(chunks)
+
+
+def segment_list(info, layout_blocks):
+    """Codeword segments per block, [[(bytes, passes), ...], ...], in the order of grk_amd_tile_layout."""
+    out, counters = [], {}
+    for b in layout_blocks:
+        key3 = (b.comp, b.res, b.band)
+        idx = counters.get(key3, 0)
+        counters[key3] = idx + 1
+        out.append([sg for sg in info["segments"].get((b.comp, b.res, b.band, idx), []) if sg[1]])
+    return out

@@ -68,12 +68,26 @@ def lib():
         L.orc_t1_decode_block.restype = C.c_int32
         L.orc_t1_decode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_uint32, C.c_void_p]
+        L.orc_t1_decode_block_sty.restype = C.c_int32
+        L.orc_t1_decode_block_sty.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_t1_dequant_rev.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_t1_dequant_rev.restype = None
         L.orc_t1_dequant_irrev.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
         L.orc_t1_dequant_irrev.restype = None
         _lib = L
     return _lib
+
+
+def t1_decode_block_sty(coded, segs, numbps, orient, cblksty, w, h):
+    """Part-1 block decode, general form: segs = [(length, passes), ...] -> ((h, w) int32, bad segmentation symbols)."""
+    buf = np.frombuffer(bytes(coded) + b"\0" * 8, np.uint8).copy()
+    sl = np.array([a for a, _ in segs], np.uint32)
+    sp = np.array([b for _, b in segs], np.uint32)
+    out = np.zeros((h, w), np.int32)
+    rc = lib().orc_t1_decode_block_sty(buf.ctypes.data, len(segs), sl.ctypes.data, sp.ctypes.data, numbps, orient, cblksty, w, h,
+                                       out.ctypes.data)
+    return (out, rc) if rc >= 0 else (None, rc)
 
 
 def t1_decode_block(coded, numpasses, numbps, orient, w, h):

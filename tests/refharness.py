@@ -15,7 +15,7 @@ _lib = None
 class EncCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("C", "W", "H", "TW", "TH", "prec", "irrev", "numres", "ht", "mode",
-                 "rate_algo", "cblk_w", "cblk_h")]
+                 "rate_algo", "cblk_w", "cblk_h", "cblk_sty")]
 
 
 def have_ref():
@@ -55,12 +55,12 @@ def lib(threads=0):
 
 
 def encode(pixels, prec, TW=None, TH=None, irrev=0, numres=6, ht=1, mode=0, rate_algo=0,
-           plugin_tile=None, cblk=(0, 0)):
+           plugin_tile=None, cblk=(0, 0), cblksty=0):
     """pixels: (C,H,W) uint8/uint16 array. Returns (bytes, seconds)."""
     L = lib()
     px = np.ascontiguousarray(pixels)
     Cn, H, W = px.shape
-    cfg = EncCfg(Cn, W, H, TW or W, TH or H, prec, irrev, numres, ht, mode, rate_algo, cblk[0], cblk[1])
+    cfg = EncCfg(Cn, W, H, TW or W, TH or H, prec, irrev, numres, ht, mode, rate_algo, cblk[0], cblk[1], cblksty)
     cap = px.size * 4 + (1 << 20)
     out = np.zeros(cap, np.uint8)
     secs = C.c_double(0)
@@ -170,3 +170,43 @@ def write_pnm(path, px, prec):
         f.write(b"P%d\n%d %d\n%d\n" % (5 if Cn == 1 else 6, W, H, (1 << prec) - 1))
         inter = np.ascontiguousarray(np.moveaxis(px, 0, -1))
         f.write(inter.astype(">u2").tobytes() if prec > 8 else inter.astype(np.uint8).tobytes())
+
+
+def t1_encode_block_sty(coef, orient, cblksty):
+    """Reference Part-1 block encoder with a code-block style -> (bytes, [(segment length, passes)...], numbps)."""
+    L = lib()
+    L.ref_t1_encode_block_sty.restype = C.c_int32
+    L.ref_t1_encode_block_sty.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
+                                          C.c_uint32]
+    a = np.ascontiguousarray(coef, np.int32)
+    h, w = a.shape
+    out = np.zeros(w * h * 8 + 4096, np.uint8)
+    rate = np.zeros(128, np.uint32)
+    term = np.zeros(128, np.uint8)
+    npass, nbps = C.c_uint32(0), C.c_uint32(0)
+    n = L.ref_t1_encode_block_sty(a.ctypes.data, w, h, w, orient, cblksty, out.ctypes.data, out.size, C.byref(npass),
+                                  C.byref(nbps), rate.ctypes.data, term.ctypes.data, rate.size)
+    assert n >= 0
+    segs, start, first = [], 0, 0
+    for i in range(npass.value):
+        if term[i] or i == npass.value - 1:
+            segs.append((int(rate[i]) - start, i + 1 - first))
+            start, first = int(rate[i]), i + 1
+    return out[:n].tobytes(), segs, nbps.value
+
+
+def t1_decode_block_sty(coded, segs, numbps, orient, cblksty, w, h):
+    L = lib()
+    L.ref_t1_decode_block_sty.restype = C.c_int32
+    L.ref_t1_decode_block_sty.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_uint32, C.c_void_p]
+    buf = np.frombuffer(bytes(coded) + b"\0" * 8, np.uint8).copy()
+    sl = np.array([a for a, _ in segs], np.uint32)
+    sp = np.array([b for _, b in segs], np.uint32)
+    out = np.zeros((h, w), np.int32)
+    rc = L.ref_t1_decode_block_sty(buf.ctypes.data, len(segs), sl.ctypes.data, sp.ctypes.data, numbps, orient, cblksty, w, h,
+                                   out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("ref_t1_decode_block_sty failed")
+    return out

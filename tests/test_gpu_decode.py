@@ -272,6 +272,74 @@ def test_part1_decode_truncated_passes_equal_oracle():
     assert np.array_equal(U.planes_to_numpy(d_m, p, 1)[0], want)
 
 
+STYLES = [0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x01 | 0x04, 0x02 | 0x08 | 0x20, 0x3F, 0x04 | 0x10]
+
+
+@needs_ref
+@pytest.mark.parametrize("sty", STYLES)
+def test_part1_decode_code_block_styles(sty):
+    """Row a13's code-block styles: blocks coded by the reference's T1 with LAZY / RESET / TERMALL / VSC / PTERM /
+    SEGSYM (and mixes), handed over with their codeword segments, decode on the GPU to what the reference's T1
+    and the oracle make of them -- also with trailing segments dropped."""
+    rng = np.random.default_rng(100 + sty)
+    p = G.TileParams.make(200, 136, 1, 12, 2, part1=True, cblksty=sty)
+    blocks, _ = G.tile_layout(p)
+    for drop in (0, 1):
+        table = np.zeros(len(blocks), G.capi.CODED_DTYPE)
+        chunks, off, want, seglist = [], 0, np.zeros((136, 200), np.int32), []
+        for i, b in enumerate(blocks):
+            bw, bh = b.x1 - b.x0, b.y1 - b.y0
+            coef = (rng.integers(-2000, 2000, size=(bh, bw)) >> rng.integers(0, 11, size=(bh, bw))).astype(np.int32)
+            cb, segs, nbps = R.t1_encode_block_sty(coef, b.band, sty)
+            if drop and len(segs) > 1:
+                segs = segs[:max(1, len(segs) - int(rng.integers(1, 4)))]
+            n = sum(a for a, _ in segs)
+            table["offset"][i] = off; table["length"][i] = n
+            table["missing_msbs"][i] = nbps | (sum(k for _, k in segs) << 8)
+            seglist.append(segs)
+            chunks.append(cb[:n] + b"\0" * (-n % 16 + 16)); off += len(chunks[-1])
+            ref = R.t1_decode_block_sty(cb[:n], segs, nbps, b.band, sty, bw, bh) if segs else np.zeros((bh, bw), np.int32)
+            if segs:
+                assert np.array_equal(O.t1_decode_block_sty(cb[:n], segs, nbps, b.band, sty, bw, bh)[0], ref)
+            want[b.py:b.py + bh, b.px:b.px + bw] = O.t1_dequant_rev(ref)
+            if not drop:
+                assert np.array_equal(want[b.py:b.py + bh, b.px:b.px + bw], coef)
+        d_c = U.to_dev(np.frombuffer(b"".join(chunks), np.uint8))
+        d_m = U.dev_planes(p, 1)
+        U.ctx().set_decode_segments(seglist)
+        try:
+            U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
+            U.ctx().synchronize()
+        finally:
+            U.ctx().set_decode_segments(None)
+        assert np.array_equal(U.planes_to_numpy(d_m, p, 1)[0], want)
+
+
+@needs_ref
+def test_part1_single_segment_styles_without_segment_list():
+    """RESET / VSC / SEGSYM / PTERM keep one codeword segment: the table row alone describes the block (what the
+    reference's plugin bridge hands over, plugin_bridge.cpp:63-76)."""
+    rng = np.random.default_rng(5)
+    sty = 0x02 | 0x08 | 0x10 | 0x20
+    p = G.TileParams.make(128, 128, 1, 10, 1, part1=True, cblksty=sty)
+    blocks, _ = G.tile_layout(p)
+    table = np.zeros(len(blocks), G.capi.CODED_DTYPE)
+    chunks, off, want = [], 0, np.zeros((128, 128), np.int32)
+    for i, b in enumerate(blocks):
+        bw, bh = b.x1 - b.x0, b.y1 - b.y0
+        coef = (rng.integers(-500, 500, size=(bh, bw)) >> rng.integers(0, 9, size=(bh, bw))).astype(np.int32)
+        cb, segs, nbps = R.t1_encode_block_sty(coef, b.band, sty)
+        assert len(segs) == 1
+        table["offset"][i] = off; table["length"][i] = len(cb); table["missing_msbs"][i] = nbps | (segs[0][1] << 8)
+        chunks.append(cb + b"\0" * (-len(cb) % 16 + 16)); off += len(chunks[-1])
+        want[b.py:b.py + bh, b.px:b.px + bw] = coef
+    d_c = U.to_dev(np.frombuffer(b"".join(chunks), np.uint8))
+    d_m = U.dev_planes(p, 1)
+    U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
+    U.ctx().synchronize()
+    assert np.array_equal(U.planes_to_numpy(d_m, p, 1)[0], want)
+
+
 @needs_ref
 def test_part1_decode_irreversible_dequant():
     """ScaleFilter path: (float)v * stepsize/2 with the band's step from the QCD words (Quantizer.cpp:41-45,
@@ -305,16 +373,20 @@ import j2kparse as J
 def _gpu_decode_reference_stream(cs, part1):
     info = J.parse(cs)
     p = G.TileParams.make(info["W"], info["H"], info["C"], info["prec"], info["levels"],
-                          irreversible=bool(info["irreversible"]), mct=bool(info["mct"]), part1=part1)
+                          irreversible=bool(info["irreversible"]), mct=bool(info["mct"]), part1=part1,
+                          cblksty=info["cblk_sty"] & 0x3F if part1 else 0)
     blocks, _ = G.tile_layout(p)
     rows, data = J.decode_table(info, blocks, part1)
     table = np.array(rows, dtype=G.capi.CODED_DTYPE)
     c = U.ctx()
     c.set_decode_qcd([(e << 11) | m for e, m in info["qcd"]] if info["irreversible"] else [])
+    if part1 and info["cblk_sty"] & 0x05:                      # LAZY / TERMALL: several codeword segments per block
+        c.set_decode_segments(J.segment_list(info, blocks))
     try:
         return c.decode_host(p, table, data)[0]
     finally:
         c.set_decode_qcd([])
+        c.set_decode_segments(None)
 
 
 @needs_ref
@@ -341,6 +413,20 @@ def test_decode_reference_part1_irreversible_stream(C, H, W, prec, numres):
     if C == 3:      # (without MCT the reference's irreversible encoder scales by 2048, TileProcessor.cpp:928-931: not a usable source)
         assert np.abs(ref - px.astype(np.int32)).max() <= max(2, (1 << prec) // 64)
     assert np.array_equal(got, ref)
+
+
+@needs_ref
+@pytest.mark.parametrize("sty", [0x01, 0x02, 0x04, 0x08, 0x20, 0x01 | 0x04, 0x3F])
+@pytest.mark.parametrize("irrev", [0, 1])
+def test_decode_reference_part1_styled_stream(sty, irrev):
+    """`grk_compress -M sty` streams (code-block styles, codeword segments through Tier-2) decoded on the GPU ==
+    grk_decompress pixel for pixel."""
+    px = synth.g2(3, 128, 192, 10)
+    cs, _ = R.encode(px, 10, numres=4, mode=1, ht=0, irrev=irrev, cblksty=sty)
+    got = _gpu_decode_reference_stream(cs, part1=True).astype(np.int32)
+    assert np.array_equal(got, R.decode(cs, 3, 128, 192))
+    if not irrev:
+        assert np.array_equal(got, px.astype(np.int32))
 
 
 @pytest.mark.parametrize("C,H,W,prec,L", [(1, 96, 128, 8, 3), (3, 128, 160, 8, 4), (3, 64, 96, 12, 2)])

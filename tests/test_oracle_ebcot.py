@@ -48,6 +48,40 @@ def test_t1_decode_truncated_pass_sequence(keep):
     assert np.array_equal(O.t1_decode_block(cb, k, nbps, 3, 64, 64), R.t1_decode_block(cb, k, nbps, 3, 64, 64))
 
 
+# ---- code-block styles and codeword segments (row a13: LAZY / RESET / TERMALL / VSC / PTERM / SEGSYM) ----------
+STYLES = [0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x01 | 0x04, 0x02 | 0x08 | 0x20, 0x01 | 0x02 | 0x04 | 0x08 | 0x10 | 0x20, 0x04 | 0x10]
+
+
+@pytest.mark.parametrize("sty", STYLES)
+@pytest.mark.parametrize("w,h,bits,mode", [(64, 64, 11, 0), (64, 64, 9, 1), (32, 32, 8, 2), (37, 13, 10, 1), (64, 6, 7, 0),
+                                           (5, 64, 12, 1), (1, 1, 6, 0), (64, 64, 3, 0)])
+def test_t1_decode_styles_equal_reference(w, h, bits, mode, sty):
+    rng = np.random.default_rng(w * 13 + h * 7 + bits + sty * 101 + mode)
+    for orient in (0, 1, 3):
+        coef = _block(rng, w, h, bits, mode)
+        cb, segs, nbps = R.t1_encode_block_sty(coef, orient, sty)
+        if sty & 0x04:
+            assert all(n == 1 for _, n in segs)                     # TERMALL: one segment per pass
+        ref = R.t1_decode_block_sty(cb, segs, nbps, orient, sty, w, h)
+        got, bad = O.t1_decode_block_sty(cb, segs, nbps, orient, sty, w, h)
+        assert bad == 0
+        assert np.array_equal(got, ref)
+        assert np.array_equal(O.t1_dequant_rev(got), coef)
+
+
+def test_t1_decode_styles_truncated_segments():
+    """Dropping trailing segments (a layer truncation at a terminated pass) decodes like the reference."""
+    rng = np.random.default_rng(77)
+    coef = _block(rng, 64, 64, 10, 1)
+    for sty in (0x04, 0x01 | 0x04, 0x01):
+        cb, segs, nbps = R.t1_encode_block_sty(coef, 2, sty)
+        for keep in (1, 2, len(segs) // 2, len(segs) - 1):
+            part = segs[:max(keep, 1)]
+            n = sum(a for a, _ in part)
+            assert np.array_equal(O.t1_decode_block_sty(cb[:n], part, nbps, 2, sty, 64, 64)[0],
+                                  R.t1_decode_block_sty(cb[:n], part, nbps, 2, sty, 64, 64))
+
+
 # ---- whole Part-1 streams of the reference encoder through the test-side Tier-2 reader ------------------
 import grok_amd as G
 import chain
@@ -61,14 +95,19 @@ def _oracle_decode_stream(cs, part1):
     p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev, mct=bool(info["mct"]), part1=part1)
     blocks, _ = G.tile_layout(p)
     rows, data = J.decode_table(info, blocks, part1)
+    seglist = J.segment_list(info, blocks)
     mall = [np.zeros((H, W), np.float32 if irrev else np.int32) for _ in range(Cn)]
-    for (off, ln, extra), b in zip(rows, blocks):
+    for (off, ln, extra), b, segs in zip(rows, blocks, seglist):
         bw, bh = b.x1 - b.x0, b.y1 - b.y0
         if not ln:
             continue
         expn, mant = info["qcd"][chain.band_index(b)]
         if part1:
-            v = O.t1_decode_block(data[off:off + ln], extra >> 8, extra & 0xFF, b.band, bw, bh)
+            if info["cblk_sty"]:
+                v, bad = O.t1_decode_block_sty(data[off:off + ln], segs, extra & 0xFF, b.band, info["cblk_sty"], bw, bh)
+                assert bad == 0
+            else:
+                v = O.t1_decode_block(data[off:off + ln], extra >> 8, extra & 0xFF, b.band, bw, bh)
             if irrev:
                 v = O.t1_dequant_irrev(v, np.float32((1.0 + mant / 2048.0) * 2.0 ** (prec - expn)))
             else:
@@ -91,6 +130,17 @@ def test_reference_part1_stream_oracle_chain_equals_grk_decompress(C, H, W, prec
     px = synth.g2(C, H, W, prec)
     cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=0, irrev=irrev)
     assert np.array_equal(_oracle_decode_stream(cs, True), R.decode(cs, C, H, W))
+
+
+@pytest.mark.parametrize("sty", [0x01, 0x02, 0x04, 0x08, 0x20, 0x01 | 0x04, 0x3F])
+@pytest.mark.parametrize("irrev", [0, 1])
+def test_reference_part1_styled_stream_oracle_chain_equals_grk_decompress(sty, irrev):
+    """The same with `grk_compress -M`: code-block styles and their codeword segments through Tier-2."""
+    px = synth.g2(3, 128, 192, 10)
+    cs, _ = R.encode(px, 10, numres=4, mode=1, ht=0, irrev=irrev, cblksty=sty)
+    info = J.parse(cs)
+    assert info["cblk_sty"] == sty
+    assert np.array_equal(_oracle_decode_stream(cs, True), R.decode(cs, 3, 128, 192))
 
 
 def test_reference_ht_stream_through_t2_reader():
