@@ -41,9 +41,11 @@ __device__ __forceinline__ uint32_t mirror_idx(int32_t i, uint32_t n)
     return (uint32_t)(i < (int32_t)n ? i : p - i);
 }
 // same for indices that leave [0, n) by fewer than 16 samples (the row loop): one reflection, no division
+// (TALL: the caller knows n >= 16)
+template <bool TALL>
 __device__ __forceinline__ uint32_t mirror_row(int32_t i, uint32_t n)
 {
-    if (n < 16) return mirror_idx(i, n);
+    if (!TALL && n < 16) return mirror_idx(i, n);
     i = i < 0 ? -i : i;
     return (uint32_t)(i < (int32_t)n ? i : 2 * ((int32_t)n - 1) - i);
 }
@@ -179,129 +181,151 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     constexpr int lag  = F97 ? 1 : 0;
     constexpr int warm = F97 ? 2 : 1;
 
-    // raw row fetch (no arithmetic, so that prefetched rows stay in flight) and its conversion
-    struct Raw { int32_t a[NC], b[NC]; };
-    auto fetch_row = [&](int32_t r, Raw& q) {
-        const uint32_t rr = mirror_row(r, ch);
-        if constexpr (PX == 0) {
-            const int32_t* row = reinterpret_cast<const int32_t*>(in) + (size_t)rr * a.in_stride;
-            if (vec) { const int2 v = *reinterpret_cast<const int2*>(row + cA); q.a[0] = v.x; q.b[0] = v.y; }
-            else     { q.a[0] = row[mA]; q.b[0] = row[mB]; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                const PIX* row = pix + (size_t)k * comp_px + (size_t)rr * cw;
-                if (pvec) {
-                    if constexpr (PX == 1) { const uchar2 v = *reinterpret_cast<const uchar2*>(row + cA); q.a[k] = v.x; q.b[k] = v.y; }
-                    else                   { const ushort2 v = *reinterpret_cast<const ushort2*>(row + cA); q.a[k] = v.x; q.b[k] = v.y; }
-                } else { q.a[k] = row[mA]; q.b[k] = row[mB]; }
-            }
-        }
-    };
-    auto convert = [&](const Raw& q, T (&va)[NC], T (&vb)[NC]) {
-        if constexpr (PX == 0) {
-            if constexpr (F97) { va[0] = __int_as_float(q.a[0]); vb[0] = __int_as_float(q.b[0]); }
-            else               { va[0] = q.a[0]; vb[0] = q.b[0]; }
-        } else {
-            int32_t xa[NC], xb[NC];
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {          // sign-extend int8/int16 samples, DC shift
-                xa[k] = ((q.a[k] ^ a.sext) - a.sext) - a.dc; xb[k] = ((q.b[k] ^ a.sext) - a.sext) - a.dc;
-            }
-            if constexpr (NC == 3) {            // launched with NC = 3 only for the MCT components
-                color_fwd_px(xa[0], xa[1], xa[2], F97);
-                color_fwd_px(xb[0], xb[1], xb[2], F97);
-#pragma unroll
+    // Interior strips of a tall level take the FAST instance: no column mirroring, aligned pair loads from a uniform
+    // row pointer, unpredicated stores (the generic instance spends more instructions on addresses and predicates
+    // than on the transform; this kernel is instruction-issue bound, not bandwidth bound).
+    const uint32_t lane_col = (uint32_t)cA;
+    auto strip = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        // raw row fetch (no arithmetic, so that prefetched rows stay in flight) and its conversion
+        struct Raw { int32_t a[NC], b[NC]; };
+        auto fetch_row = [&](int32_t r, Raw& q) {
+            const uint32_t rr = mirror_row<FAST>(r, ch);
+            if constexpr (PX == 0) {
+                const int32_t* row = reinterpret_cast<const int32_t*>(in) + (size_t)rr * a.in_stride;
+                if (FAST || vec) { const int2 v = *reinterpret_cast<const int2*>(row + lane_col); q.a[0] = v.x; q.b[0] = v.y; }
+                else     { q.a[0] = row[mA]; q.b[0] = row[mB]; }
+            } else {
+    #pragma unroll
                 for (int k = 0; k < NC; ++k) {
-                    if constexpr (F97) { va[k] = __int_as_float(xa[k]); vb[k] = __int_as_float(xb[k]); }
-                    else               { va[k] = xa[k]; vb[k] = xb[k]; }
+                    const PIX* row = pix + (size_t)k * comp_px + (size_t)rr * cw;
+                    if (FAST) {       // uniform row pointer + a 32-bit lane offset: one load, no per-lane 64-bit address arithmetic
+                        if constexpr (PX == 1) { const uchar2 v = *reinterpret_cast<const uchar2*>(row + lane_col); q.a[k] = v.x; q.b[k] = v.y; }
+                        else                   { const ushort2 v = *reinterpret_cast<const ushort2*>(row + lane_col); q.a[k] = v.x; q.b[k] = v.y; }
+                    } else if (pvec) {
+                        if constexpr (PX == 1) { const uchar2 v = *reinterpret_cast<const uchar2*>(row + cA); q.a[k] = v.x; q.b[k] = v.y; }
+                        else                   { const ushort2 v = *reinterpret_cast<const ushort2*>(row + cA); q.a[k] = v.x; q.b[k] = v.y; }
+                    } else { q.a[k] = row[mA]; q.b[k] = row[mB]; }
                 }
-            } else {
-                if constexpr (F97) { va[0] = (float)xa[0]; vb[0] = (float)xb[0]; }
-                else               { va[0] = xa[0]; vb[0] = xb[0]; }
             }
-        }
-    };
-
-    typename std::conditional<F97, V97, V53>::type colA[NC], colB[NC];
-    int32_t i = J0 - warm;
-    {
-        Raw q; T xa[NC], xb[NC];
-        fetch_row(2 * i, q);
-        convert(q, xa, xb);
-#pragma unroll
-        for (int k = 0; k < NC; ++k) { colA[k].init(xa[k]); colB[k].init(xb[k]); }
-    }
-    Raw n1, n2;                           // prefetched rows of the next step
-    fetch_row(2 * i + 1, n1);
-    fetch_row(2 * i + 2, n2);
-
-    // the output pair this lane produces in the horizontal phase
-    const bool h_lane = (t >= kHalo / 2) && (t < kThreads - kHalo / 2);
-    const uint32_t Jc = (uint32_t)((c_first >> 1) + (int32_t)t);         // global pair column (valid when h_lane)
-    const bool st_s = h_lane && Jc < sw, st_d = h_lane && Jc < dw;
-
-    const int32_t i_end = J1 - 1 + lag;
-    for (int par = 0; i <= i_end; ++i, par ^= 1) {
-        T x1a[NC], x1b[NC], x2a[NC], x2b[NC];
-        convert(n1, x1a, x1b);
-        convert(n2, x2a, x2b);
-        if (i < i_end) {                 // prefetch rows of step i+1 while this one computes
-            fetch_row(2 * i + 3, n1);
-            fetch_row(2 * i + 4, n2);
-        }
-        T sA[NC], dA[NC], sB[NC], dB[NC];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            if constexpr (F97) {
-                colA[k].step(x1a[k], x2a[k], sA[k], dA[k], inv_k);
-                colB[k].step(x1b[k], x2b[k], sB[k], dB[k], inv_k);
+        };
+        auto convert = [&](const Raw& q, T (&va)[NC], T (&vb)[NC]) {
+            if constexpr (PX == 0) {
+                if constexpr (F97) { va[0] = __int_as_float(q.a[0]); vb[0] = __int_as_float(q.b[0]); }
+                else               { va[0] = q.a[0]; vb[0] = q.b[0]; }
             } else {
-                colA[k].step(x1a[k], x2a[k], sA[k], dA[k]);
-                colB[k].step(x1b[k], x2b[k], sB[k], dB[k]);
-            }
-        }
-        const int32_t j = i - lag;       // row pair just completed (uniform over the workgroup)
-        if (j < J0) continue;
-        if (ch == 1) {                   // single-row level: vertical pass is the identity
-            Raw q;
-            fetch_row(0, q);
-            convert(q, sA, sB);
-        }
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            T2 ql, qh;
-            ql.x = sA[k]; ql.y = sB[k]; qh.x = dA[k]; qh.y = dB[k];
-            *reinterpret_cast<T2*>(&line[par][k][0][2 * t]) = ql;
-            *reinterpret_cast<T2*>(&line[par][k][1][2 * t]) = qh;
-        }
-        __syncthreads();
-        if (h_lane) {
-            const bool has_h = (uint32_t)j < dh;
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                T ls, ld, hs = 0, hd = 0;
-                if constexpr (F97) {
-                    if (cw == 1) { ls = line[par][k][0][2 * t]; ld = 0; if (has_h) hs = line[par][k][1][2 * t]; }
-                    else {
-                        h97(&line[par][k][0][2 * t], ls, ld, inv_k);
-                        if (has_h) h97(&line[par][k][1][2 * t], hs, hd, inv_k);
+                int32_t xa[NC], xb[NC];
+    #pragma unroll
+                for (int k = 0; k < NC; ++k) {          // sign-extend int8/int16 samples, DC shift
+                    xa[k] = ((q.a[k] ^ a.sext) - a.sext) - a.dc; xb[k] = ((q.b[k] ^ a.sext) - a.sext) - a.dc;
+                }
+                if constexpr (NC == 3) {            // launched with NC = 3 only for the MCT components
+                    color_fwd_px(xa[0], xa[1], xa[2], F97);
+                    color_fwd_px(xb[0], xb[1], xb[2], F97);
+    #pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        if constexpr (F97) { va[k] = __int_as_float(xa[k]); vb[k] = __int_as_float(xb[k]); }
+                        else               { va[k] = xa[k]; vb[k] = xb[k]; }
                     }
                 } else {
-                    h53(&line[par][k][0][2 * t], ls, ld);
-                    if (has_h) h53(&line[par][k][1][2 * t], hs, hd);
+                    if constexpr (F97) { va[0] = (float)xa[0]; vb[0] = (float)xb[0]; }
+                    else               { va[0] = xa[0]; vb[0] = xb[0]; }
                 }
-                T* llk = ll + (size_t)k * a.ll_pitch;
-                T* mpk = mp + (size_t)k * a.m_pitch;
-                if (st_s) llk[(size_t)j * a.ll_stride + Jc] = ls;
-                if (st_d) mpk[(size_t)j * a.m_stride + sw + Jc] = ld;
-                if (has_h) {
-                    if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Jc] = hs;
-                    if (st_d) mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = hd;
+            }
+        };
+
+        typename std::conditional<F97, V97, V53>::type colA[NC], colB[NC];
+        int32_t i = J0 - warm;
+        {
+            Raw q; T xa[NC], xb[NC];
+            fetch_row(2 * i, q);
+            convert(q, xa, xb);
+    #pragma unroll
+            for (int k = 0; k < NC; ++k) { colA[k].init(xa[k]); colB[k].init(xb[k]); }
+        }
+        Raw n1, n2;                           // prefetched rows of the next step
+        fetch_row(2 * i + 1, n1);
+        fetch_row(2 * i + 2, n2);
+
+        // the output pair this lane produces in the horizontal phase
+        const bool h_lane = (t >= kHalo / 2) && (t < kThreads - kHalo / 2);
+        const uint32_t Jc = (uint32_t)((c_first >> 1) + (int32_t)t);         // global pair column (valid when h_lane)
+        const bool st_s = h_lane && (FAST || Jc < sw), st_d = h_lane && (FAST || Jc < dw);
+
+        const int32_t i_end = J1 - 1 + lag;
+        for (int par = 0; i <= i_end; ++i, par ^= 1) {
+            T x1a[NC], x1b[NC], x2a[NC], x2b[NC];
+            convert(n1, x1a, x1b);
+            convert(n2, x2a, x2b);
+            if (i < i_end) {                 // prefetch rows of step i+1 while this one computes
+                fetch_row(2 * i + 3, n1);
+                fetch_row(2 * i + 4, n2);
+            }
+            T sA[NC], dA[NC], sB[NC], dB[NC];
+    #pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if constexpr (F97) {
+                    colA[k].step(x1a[k], x2a[k], sA[k], dA[k], inv_k);
+                    colB[k].step(x1b[k], x2b[k], sB[k], dB[k], inv_k);
+                } else {
+                    colA[k].step(x1a[k], x2a[k], sA[k], dA[k]);
+                    colB[k].step(x1b[k], x2b[k], sB[k], dB[k]);
+                }
+            }
+            const int32_t j = i - lag;       // row pair just completed (uniform over the workgroup)
+            if (j < J0) continue;
+            if (ch == 1) {                   // single-row level: vertical pass is the identity
+                Raw q;
+                fetch_row(0, q);
+                convert(q, sA, sB);
+            }
+    #pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                T2 ql, qh;
+                ql.x = sA[k]; ql.y = sB[k]; qh.x = dA[k]; qh.y = dB[k];
+                *reinterpret_cast<T2*>(&line[par][k][0][2 * t]) = ql;
+                *reinterpret_cast<T2*>(&line[par][k][1][2 * t]) = qh;
+            }
+            __syncthreads();
+            if (h_lane) {
+                const bool has_h = (uint32_t)j < dh;
+    #pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    T ls, ld, hs = 0, hd = 0;
+                    if constexpr (F97) {
+                        if (cw == 1) { ls = line[par][k][0][2 * t]; ld = 0; if (has_h) hs = line[par][k][1][2 * t]; }
+                        else {
+                            h97(&line[par][k][0][2 * t], ls, ld, inv_k);
+                            if (has_h) h97(&line[par][k][1][2 * t], hs, hd, inv_k);
+                        }
+                    } else {
+                        h53(&line[par][k][0][2 * t], ls, ld);
+                        if (has_h) h53(&line[par][k][1][2 * t], hs, hd);
+                    }
+                    T* llk = ll + (size_t)k * a.ll_pitch;
+                    T* mpk = mp + (size_t)k * a.m_pitch;
+                    if (FAST) {          // interior strip: every horizontal lane owns a column of all four sub-bands
+                        llk[(size_t)j * a.ll_stride + Jc] = ls;
+                        mpk[(size_t)j * a.m_stride + sw + Jc] = ld;
+                        if (has_h) {
+                            mpk[(size_t)(sh + j) * a.m_stride + Jc] = hs;
+                            mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = hd;
+                        }
+                    } else {
+                        if (st_s) llk[(size_t)j * a.ll_stride + Jc] = ls;
+                        if (st_d) mpk[(size_t)j * a.m_stride + sw + Jc] = ld;
+                        if (has_h) {
+                            if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Jc] = hs;
+                            if (st_d) mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = hd;
+                        }
+                    }
                 }
             }
         }
-    }
+    };
+    const bool fast = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (cw & 1u) == 0 && ch >= 16 &&
+                      (uint32_t)(c_first >> 1) + kThreads - kHalo / 2 <= dw;
+    if (fast) strip(std::true_type{}); else strip(std::false_type{});
 }
 
 } // namespace
