@@ -30,7 +30,14 @@ namespace {
 constexpr int   kThreads  = 256;
 constexpr int   kCols     = 2 * kThreads;      // columns staged per line
 constexpr int   kHalo     = 4;                 // columns each side
-constexpr int   kOutCols  = kCols - 2 * kHalo; // 504
+#ifndef DWT_OUTCOLS
+#define DWT_OUTCOLS 448
+#endif
+// Output columns per strip.  At most kCols - 2 * kHalo = 504; 448 makes a strip 224 output pairs = 7 x 128 bytes of
+// every sub-band row, so each wave's stores cover whole, aligned cache lines.
+constexpr int   kOutCols  = DWT_OUTCOLS;
+constexpr int   kOutPairs = kOutCols / 2;
+static_assert(kOutCols <= kCols - 2 * kHalo && kOutCols % 2 == 0, "strip does not fit the staged line");
 
 __device__ __forceinline__ uint32_t mirror_idx(int32_t i, uint32_t n)
 {
@@ -199,9 +206,10 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     #pragma unroll
                 for (int k = 0; k < NC; ++k) {
                     const PIX* row = pix + (size_t)k * comp_px + (size_t)rr * cw;
-                    if (FAST) {       // uniform row pointer + a 32-bit lane offset: one load, no per-lane 64-bit address arithmetic
-                        if constexpr (PX == 1) { const uchar2 v = *reinterpret_cast<const uchar2*>(row + lane_col); q.a[k] = v.x; q.b[k] = v.y; }
-                        else                   { const ushort2 v = *reinterpret_cast<const ushort2*>(row + lane_col); q.a[k] = v.x; q.b[k] = v.y; }
+                    if (FAST) {       // the pair stays packed in one register until convert(): a load whose result is
+                                      // unpacked at once is waited for at once, and the prefetch buys nothing
+                        if constexpr (PX == 1) q.a[k] = *reinterpret_cast<const uint16_t*>(row + lane_col);
+                        else                   q.a[k] = (int32_t)*reinterpret_cast<const uint32_t*>(row + lane_col);
                     } else if (pvec) {
                         if constexpr (PX == 1) { const uchar2 v = *reinterpret_cast<const uchar2*>(row + cA); q.a[k] = v.x; q.b[k] = v.y; }
                         else                   { const ushort2 v = *reinterpret_cast<const ushort2*>(row + cA); q.a[k] = v.x; q.b[k] = v.y; }
@@ -217,7 +225,12 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
                 int32_t xa[NC], xb[NC];
     #pragma unroll
                 for (int k = 0; k < NC; ++k) {          // sign-extend int8/int16 samples, DC shift
-                    xa[k] = ((q.a[k] ^ a.sext) - a.sext) - a.dc; xb[k] = ((q.b[k] ^ a.sext) - a.sext) - a.dc;
+                    int32_t pa = q.a[k], pb = q.b[k];
+                    if constexpr (FAST) {               // unpack the pair fetch_row left in q.a
+                        constexpr int B = PX == 1 ? 8 : 16;
+                        pb = (int32_t)((uint32_t)pa >> B); pa &= (1 << B) - 1;
+                    }
+                    xa[k] = ((pa ^ a.sext) - a.sext) - a.dc; xb[k] = ((pb ^ a.sext) - a.sext) - a.dc;
                 }
                 if constexpr (NC == 3) {            // launched with NC = 3 only for the MCT components
                     color_fwd_px(xa[0], xa[1], xa[2], F97);
@@ -248,20 +261,27 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         fetch_row(2 * i + 2, n2);
 
         // the output pair this lane produces in the horizontal phase
-        const bool h_lane = (t >= kHalo / 2) && (t < kThreads - kHalo / 2);
-        const uint32_t Jc = (uint32_t)((c_first >> 1) + (int32_t)t);         // global pair column (valid when h_lane)
+        // FAST: the halo lanes repeat the work of the nearest owning lane (same LDS reads, same value to the same address),
+        // so that the horizontal phase has no branch at all: with one path through the loop body the compiler's wait for
+        // the prefetched rows does not also wait for the stores issued after them
+        // lane t owns output pair t of the strip (local columns kHalo + 2t, + 1); lanes past the strip's last pair idle
+        const uint32_t tp = FAST ? min(t, (uint32_t)(kOutPairs - 1)) : t;
+        const uint32_t th = tp + kHalo / 2;                                  // its pair index inside the staged line
+        const bool h_lane = FAST || t < (uint32_t)kOutPairs;
+        const uint32_t Jc = blockIdx.x * kOutPairs + tp;                     // global pair column
         const bool st_s = h_lane && (FAST || Jc < sw), st_d = h_lane && (FAST || Jc < dw);
 
         const int32_t i_end = J1 - 1 + lag;
-        for (int par = 0; i <= i_end; ++i, par ^= 1) {
+        T sA[NC], dA[NC], sB[NC], dB[NC];
+        // one vertical step: consumes the prefetched rows and fetches those of the next step (always, rows past the
+        // end mirror back into the plane: the steady-state loop then has a single path, so the wait for a prefetched
+        // row never has to cover the stores issued after it)
+        auto vstep = [&]() {
             T x1a[NC], x1b[NC], x2a[NC], x2b[NC];
             convert(n1, x1a, x1b);
             convert(n2, x2a, x2b);
-            if (i < i_end) {                 // prefetch rows of step i+1 while this one computes
-                fetch_row(2 * i + 3, n1);
-                fetch_row(2 * i + 4, n2);
-            }
-            T sA[NC], dA[NC], sB[NC], dB[NC];
+            fetch_row(2 * i + 3, n1);
+            fetch_row(2 * i + 4, n2);
     #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 if constexpr (F97) {
@@ -272,9 +292,11 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
                     colB[k].step(x1b[k], x2b[k], sB[k], dB[k]);
                 }
             }
-            const int32_t j = i - lag;       // row pair just completed (uniform over the workgroup)
-            if (j < J0) continue;
-            if (ch == 1) {                   // single-row level: vertical pass is the identity
+        };
+        for (; i - lag < J0; ++i) vstep();   // warm-up steps produce no output
+        // horizontal phase of the row pair the vertical step just finished: exchange through the LDS line, local stencil
+        auto hphase = [&](int par, int32_t j, T (&o)[NC][4]) {
+            if (!FAST && ch == 1) {          // single-row level: vertical pass is the identity
                 Raw q;
                 fetch_row(0, q);
                 convert(q, sA, sB);
@@ -288,43 +310,76 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
             }
             __syncthreads();
             if (h_lane) {
-                const bool has_h = (uint32_t)j < dh;
+                const bool has_h = FAST || (uint32_t)j < dh;      // FAST levels have an even height
     #pragma unroll
                 for (int k = 0; k < NC; ++k) {
                     T ls, ld, hs = 0, hd = 0;
                     if constexpr (F97) {
-                        if (cw == 1) { ls = line[par][k][0][2 * t]; ld = 0; if (has_h) hs = line[par][k][1][2 * t]; }
+                        if (!FAST && cw == 1) { ls = line[par][k][0][2 * th]; ld = 0; if (has_h) hs = line[par][k][1][2 * th]; }
                         else {
-                            h97(&line[par][k][0][2 * t], ls, ld, inv_k);
-                            if (has_h) h97(&line[par][k][1][2 * t], hs, hd, inv_k);
+                            h97(&line[par][k][0][2 * th], ls, ld, inv_k);
+                            if (has_h) h97(&line[par][k][1][2 * th], hs, hd, inv_k);
                         }
                     } else {
-                        h53(&line[par][k][0][2 * t], ls, ld);
-                        if (has_h) h53(&line[par][k][1][2 * t], hs, hd);
+                        h53(&line[par][k][0][2 * th], ls, ld);
+                        if (has_h) h53(&line[par][k][1][2 * th], hs, hd);
                     }
+                    o[k][0] = ls; o[k][1] = ld; o[k][2] = hs; o[k][3] = hd;
+                }
+            }
+        };
+        auto store_out = [&](int32_t j, const T (&o)[NC][4]) {
+            if (h_lane) {
+                const bool has_h = FAST || (uint32_t)j < dh;
+    #pragma unroll
+                for (int k = 0; k < NC; ++k) {
                     T* llk = ll + (size_t)k * a.ll_pitch;
                     T* mpk = mp + (size_t)k * a.m_pitch;
                     if (FAST) {          // interior strip: every horizontal lane owns a column of all four sub-bands
-                        llk[(size_t)j * a.ll_stride + Jc] = ls;
-                        mpk[(size_t)j * a.m_stride + sw + Jc] = ld;
-                        if (has_h) {
-                            mpk[(size_t)(sh + j) * a.m_stride + Jc] = hs;
-                            mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = hd;
-                        }
+                        llk[(size_t)j * a.ll_stride + Jc] = o[k][0];
+                        mpk[(size_t)j * a.m_stride + sw + Jc] = o[k][1];
+                        mpk[(size_t)(sh + j) * a.m_stride + Jc] = o[k][2];
+                        mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = o[k][3];
                     } else {
-                        if (st_s) llk[(size_t)j * a.ll_stride + Jc] = ls;
-                        if (st_d) mpk[(size_t)j * a.m_stride + sw + Jc] = ld;
+                        if (st_s) llk[(size_t)j * a.ll_stride + Jc] = o[k][0];
+                        if (st_d) mpk[(size_t)j * a.m_stride + sw + Jc] = o[k][1];
                         if (has_h) {
-                            if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Jc] = hs;
-                            if (st_d) mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = hd;
+                            if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Jc] = o[k][2];
+                            if (st_d) mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = o[k][3];
                         }
                     }
                 }
             }
+        };
+        T o[NC][4];
+        if constexpr (FAST) {
+            // The compiler's wait for a prefetched row drains every vector memory operation in flight (gfx9 has one
+            // counter for loads and stores, and the wait is merged conservatively over the loop's edges).  So all of them
+            // are issued in one place, right after that wait -- the next rows AND the previous pair's results, which stay
+            // in registers for one iteration -- and each has a whole iteration to complete before the next wait.
+            if (i <= i_end) {
+                vstep();
+                hphase(0, i - lag, o);
+                int32_t jp = i - lag;
+                ++i;
+                for (int par = 1; i <= i_end; ++i, par ^= 1) {
+                    vstep();
+                    store_out(jp, o);
+                    hphase(par, i - lag, o);
+                    jp = i - lag;
+                }
+                store_out(jp, o);
+            }
+        } else {
+            for (int par = 0; i <= i_end; ++i, par ^= 1) {
+                vstep();
+                hphase(par, i - lag, o);
+                store_out(i - lag, o);
+            }
         }
     };
-    const bool fast = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (cw & 1u) == 0 && ch >= 16 &&
-                      (uint32_t)(c_first >> 1) + kThreads - kHalo / 2 <= dw;
+    const bool fast = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (cw & 1u) == 0 && ch >= 16 && (ch & 1u) == 0 &&
+                      (blockIdx.x + 1) * kOutPairs <= dw;
     if (fast) strip(std::true_type{}); else strip(std::false_type{});
 }
 
