@@ -257,7 +257,7 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         // enough workgroups to cover the chip several times, few enough to amortise warm-up rows
         const uint32_t sh = (a.ch + 1) >> 1;
         uint32_t seg = 64;
-        const uint64_t strips = (a.cw + 503) / 504;
+        const uint64_t strips = (a.cw + dwt_strip_cols() - 1) / dwt_strip_cols();
         // workgroups along z: planes, or for the fused level 0 tiles (x components when there is no MCT triple)
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
@@ -304,7 +304,7 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
         a.irreversible = g.p.irreversible;
         const uint32_t sh = (a.ch + 1) >> 1;
         uint32_t seg = 64;
-        const uint64_t strips = (((a.cw + 1) >> 1) + 251) / 252;
+        const uint64_t strips = (((a.cw + 1) >> 1) + idwt_strip_pairs() - 1) / idwt_strip_pairs();
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * nplanes < 4096) seg >>= 1;
         a.seg_pairs = seg;
         HIP_TRY(c, launch_idwt_level(a, c->stream), "launch idwt level");

@@ -72,6 +72,8 @@ constexpr size_t   kHtAllocBytes = 8192;
 constexpr uint32_t kHtAllocRegions = 16;           // region words available; a launch uses region_mask + 1 of them
 constexpr uint32_t kHtAllocChunk = 256u << 10;     // bytes a region takes from the shared cursor at a time
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);
+uint32_t   dwt_strip_cols();      // output columns a K2 workgroup owns
+uint32_t   idwt_strip_pairs();    // coefficient pairs a K6 workgroup owns
 
 // ---- K5: HT cleanup decoder + dequantisation (kernels_htdec.hip) --------------------------------
 struct HtDecBlock {          // one per code-block, same layout as grk_amd_coded_block

@@ -169,7 +169,12 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     const float inv_k = (float)(1.0 / 1.230174105);
 
     const int32_t c_first = (int32_t)(blockIdx.x * kOutCols) - kHalo;    // global column of local 0
-    const int32_t cA = c_first + 2 * (int32_t)t;
+    // Which pair of the staged line this lane carries through the vertical pass: lanes [0, kOutPairs) take the strip's
+    // own pairs IN ORDER (their row loads start on a cache-line boundary), the next kHalo lanes the halo pairs left and
+    // right of it; whatever lanes remain ride along on columns nobody reads.
+    constexpr uint32_t HP = kHalo / 2;
+    const uint32_t lp = t < (uint32_t)kOutPairs ? t + HP : (t < kOutPairs + HP ? t - kOutPairs : t);
+    const int32_t cA = c_first + 2 * (int32_t)lp;
     const uint32_t mA = mirror_idx(cA, cw), mB = mirror_idx(cA + 1, cw);
     const bool vec = (cA >= 0) && ((uint32_t)cA + 1 < cw);
 
@@ -305,8 +310,8 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
             for (int k = 0; k < NC; ++k) {
                 T2 ql, qh;
                 ql.x = sA[k]; ql.y = sB[k]; qh.x = dA[k]; qh.y = dB[k];
-                *reinterpret_cast<T2*>(&line[par][k][0][2 * t]) = ql;
-                *reinterpret_cast<T2*>(&line[par][k][1][2 * t]) = qh;
+                *reinterpret_cast<T2*>(&line[par][k][0][2 * lp]) = ql;
+                *reinterpret_cast<T2*>(&line[par][k][1][2 * lp]) = qh;
             }
             __syncthreads();
             if (h_lane) {
@@ -384,6 +389,8 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 }
 
 } // namespace
+
+uint32_t dwt_strip_cols() { return kOutCols; }
 
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
 {

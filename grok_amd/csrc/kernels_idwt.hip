@@ -27,7 +27,10 @@ namespace {
 
 constexpr int kThreads   = 256;
 constexpr int kHaloPairs = 2;
-constexpr int kOutPairs  = kThreads - 2 * kHaloPairs;     // 252 pairs = 504 columns
+// Coefficient pairs per strip.  At most kThreads - 2 * kHaloPairs = 252; 224 pairs = 7 cache lines of each sub-band row
+// and 14 of each output row, so loads and stores cover whole, aligned lines.
+constexpr int kOutPairs  = 224;
+static_assert(kOutPairs <= kThreads - 2 * kHaloPairs, "strip does not fit the staged line");
 
 __device__ __forceinline__ uint32_t mirror_idx(int32_t i, uint32_t n)
 {
@@ -125,12 +128,15 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     const T* mp = reinterpret_cast<const T*>(a.mallat) + (size_t)blockIdx.z * a.m_pitch;
     T* out = reinterpret_cast<T*>(a.out) + (size_t)blockIdx.z * a.out_pitch;
 
-    // the pair this lane loads and (if not a halo lane) synthesises
-    const int32_t J = (int32_t)(blockIdx.x * kOutPairs) - kHaloPairs + (int32_t)t;
+    // The pair this lane loads and (lanes [0, kOutPairs)) synthesises: the strip's own pairs in lane order, so that a
+    // wave's loads and stores start on cache-line boundaries; the next 2 * kHaloPairs lanes fetch the halo pairs left
+    // and right of the strip.  lp = position in the staged line.
+    const uint32_t lp = t < (uint32_t)kOutPairs ? t + kHaloPairs : (t < (uint32_t)(kOutPairs + kHaloPairs) ? t - kOutPairs : t);
+    const int32_t J = (int32_t)(blockIdx.x * kOutPairs) - kHaloPairs + (int32_t)lp;
     // horizontal mirror in the interleaved domain: low sample 2J, high sample 2J+1
     const uint32_t js = mirror_idx(2 * J, cw) >> 1;
     const uint32_t jd = cw > 1 ? (mirror_idx(2 * J + 1, cw) - 1) >> 1 : 0;
-    const bool h_lane = (t >= (uint32_t)kHaloPairs) && (t < (uint32_t)(kThreads - kHaloPairs)) && J >= 0;
+    const bool h_lane = t < (uint32_t)kOutPairs;
     const bool st_e = h_lane && (uint32_t)(2 * J) < cw, st_o = h_lane && (uint32_t)(2 * J + 1) < cw;
 
     const int32_t I0 = (int32_t)(blockIdx.y * a.seg_pairs);
@@ -158,18 +164,18 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     const int32_t i_end = I1 - 1 + lag;
     for (int par = 0; i <= i_end; ++i, par ^= 1) {
         if (i < i_end) fetch(i + 1, nxt);
-        line[par][0][0][t] = cur.ls; line[par][0][1][t] = cur.ld;
-        line[par][1][0][t] = cur.hs; line[par][1][1][t] = cur.hd;
+        line[par][0][0][lp] = cur.ls; line[par][0][1][lp] = cur.ld;
+        line[par][1][0][lp] = cur.hs; line[par][1][1][lp] = cur.hd;
         __syncthreads();
         if (h_lane) {
             T se, so, de, dodd;                           // low row / high row, even / odd column
-            if (cw == 1) { se = line[par][0][0][t]; so = 0; de = line[par][1][0][t]; dodd = 0; }
+            if (cw == 1) { se = line[par][0][0][lp]; so = 0; de = line[par][1][0][lp]; dodd = 0; }
             else if constexpr (F97) {
-                hs97(&line[par][0][0][t], &line[par][0][1][t], se, so);
-                hs97(&line[par][1][0][t], &line[par][1][1][t], de, dodd);
+                hs97(&line[par][0][0][lp], &line[par][0][1][lp], se, so);
+                hs97(&line[par][1][0][lp], &line[par][1][1][lp], de, dodd);
             } else {
-                hs53(&line[par][0][0][t], &line[par][0][1][t], se, so);
-                hs53(&line[par][1][0][t], &line[par][1][1][t], de, dodd);
+                hs53(&line[par][0][0][lp], &line[par][0][1][lp], se, so);
+                hs53(&line[par][1][0][lp], &line[par][1][1][lp], de, dodd);
             }
             T oA, eA, oB, eB;                             // finished rows (odd, even) of columns 2J and 2J+1
             if (ch == 1) { eA = se; eB = so; oA = oB = 0; }
@@ -259,6 +265,8 @@ __global__ __launch_bounds__(256) void egress_kernel(EgressArgs a)
 }
 
 } // namespace
+
+uint32_t idwt_strip_pairs() { return kOutPairs; }
 
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s)
 {
