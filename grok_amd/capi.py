@@ -90,6 +90,7 @@ def lib():
         L.grk_amd_decode_status.argtypes = [vp]
         L.grk_amd_set_decode_qcd.argtypes = [vp, vp, u32]
         L.grk_amd_set_decode_segments.argtypes = [vp, vp, vp, u32]
+        L.grk_amd_set_overlap.argtypes = [vp, i32]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
         L.grk_amd_kernel_ms.restype = C.c_double
@@ -234,6 +235,9 @@ class Context:
         t = np.ascontiguousarray(table)
         self._check(self._L.grk_amd_decode_tiles(self._h, C.byref(params), ntiles, t.ctypes.data, d_coded, coded_bytes, 1,
                                                  d_pixels, 1), "decode_tiles")
+
+    def set_overlap(self, on):
+        self._check(self._L.grk_amd_set_overlap(self._h, int(bool(on))), "set_overlap")
 
     def set_decode_segments(self, per_block):
         """Part-1 blocks with several codeword segments (LAZY / TERMALL): per_block = [[(bytes, passes), ...], ...] in

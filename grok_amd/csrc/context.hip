@@ -9,6 +9,7 @@
 #include "kernels.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,7 +61,12 @@ struct grk_amd_ctx {
     std::vector<uint32_t> dec_seg_first;                    // Part-1 decode: codeword segments (optional), [nblocks + 1]
     std::vector<grk_amd_segment> dec_segs;
     DevBuf dec_seg_dev;
-    HtClass ht_classes[2]; uint32_t ht_num_classes = 0;     // block classes of K3 (by LDS need)
+    HtClass ht_classes[kHtMaxClasses]; uint32_t ht_num_classes = 0;   // block classes of K3: {top resolution, rest} x {LDS small, large}
+    uint8_t ht_class_top[kHtMaxClasses] = {}, ht_class_big[kHtMaxClasses] = {};
+    hipStream_t side2 = nullptr; hipEvent_t ev_side2 = nullptr;      // the large-LDS classes run beside the small-LDS ones
+    hipStream_t side = nullptr;                             // K3 of the top resolution runs here beside DWT levels >= 1
+    hipEvent_t ev_level0 = nullptr, ev_side = nullptr;
+    bool overlap = false;
     DevBuf ht_sel;
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
@@ -68,7 +74,7 @@ struct grk_amd_ctx {
     uint64_t last_nblocks = 0;
     // timing
     bool timing = false;
-    Timer timers[8];
+    Timer timers[10];
 };
 
 namespace {
@@ -85,6 +91,10 @@ int fail(grk_amd_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
 
 #define HIP_TRY(c, call, what)                                                      \
     do { hipError_t _e = (call); if (_e != hipSuccess) return fail(c, GRK_AMD_ERR_NO_DEVICE, what, _e); } while (0)
+
+#ifndef GRK_AMD_OVERLAP_DEFAULT
+#define GRK_AMD_OVERLAP_DEFAULT 1
+#endif
 
 bool same_params(const grk_amd_tile_params& a, const grk_amd_tile_params& b)
 {
@@ -103,8 +113,10 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
     c->have_geom = true;
     const TileGeom& g = c->geom;
     c->h_desc.clear();
+    std::vector<uint8_t> h_res;                 // resolution of each block (0 = coarsest)
     for (uint32_t k = 0; k < p->num_comps; ++k)
         for (const auto& b : g.blocks_comp0) {
+            h_res.push_back(b.res);
             HtBlockDesc d;
             d.px = b.px; d.py = b.py;
             d.w = (uint16_t)(b.x1 - b.x0); d.h = (uint16_t)(b.y1 - b.y0);
@@ -112,42 +124,44 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
             d.inv_step = 1.0f / b.stepsize;
             c->h_desc.push_back(d);
         }
-    // K3 block classes: LDS per wave decides the occupancy (16 waves per CU need <= 10 KiB each).  If
-    // the blocks whose Kmax makes them fit are the majority, they get their own launch and the rest
-    // (the few high-Kmax blocks of the low resolutions) a second one.
+    // K3 block classes = {top resolution, the rest} x {LDS need small, large}, each its own launch: (1) a launch's
+    // LDS buffers are sized for its largest Kmax, and the LDS per wave is what fixes the occupancy (16 waves per CU
+    // need <= 10 KiB each; the few high-Kmax blocks would otherwise cost every block a wave per SIMD); (2) the top
+    // resolution's sub-bands (3/4 of all blocks) are final after DWT level 0, so they are coded beside the remaining
+    // levels (run_dwt, overlap).  Few classes on purpose: a launch ends with a tail of long-running waves, and
+    // launches on one stream do not overlap (measured: one class per resolution costs 0.15 ms at 8K).
     {
-        auto extents = [&](uint32_t kmax_lo, uint32_t kmax_hi, HtClass& cl, std::vector<uint32_t>* idx) {
-            cl = HtClass{nullptr, 0, 0, 0, 0};
-            for (uint32_t i = 0; i < c->h_desc.size(); ++i) {
-                const HtBlockDesc& d = c->h_desc[i];
-                if (d.kmax < kmax_lo || d.kmax > kmax_hi) continue;
-                cl.count++;
-                cl.max_kmax = std::max<uint32_t>(cl.max_kmax, d.kmax);
-                cl.max_samples = std::max<uint32_t>(cl.max_samples, (uint32_t)d.w * d.h);
-                cl.max_quads = std::max<uint32_t>(cl.max_quads, ((d.w + 1u) / 2u) * ((d.h + 1u) / 2u));
-                if (idx) idx->push_back(i);
-            }
-        };
         constexpr size_t kLdsFor16Waves = 10240;
-        HtClass all; extents(0, 255, all, nullptr);
-        c->ht_num_classes = 1; c->ht_classes[0] = all;
-        if (ht_lds_bytes(all.max_samples, all.max_quads, all.max_kmax) > kLdsFor16Waves) {
-            uint32_t T = all.max_kmax;                  // largest threshold whose class fits
-            HtClass lo;
-            while (T > 0) { extents(0, T, lo, nullptr); if (lo.count == 0 || ht_lds_bytes(lo.max_samples, lo.max_quads, lo.max_kmax) <= kLdsFor16Waves) break; --T; }
-            if (T > 0 && lo.count * 2 > all.count && lo.count < all.count) {
-                std::vector<uint32_t> sel_lo, sel_hi;
-                HtClass hi;
-                extents(0, T, lo, &sel_lo); extents(T + 1, 255, hi, &sel_hi);
-                std::vector<uint32_t> sel(sel_lo);
-                sel.insert(sel.end(), sel_hi.begin(), sel_hi.end());
-                HIP_TRY(c, c->ht_sel.ensure(sel.size() * 4), "alloc class index");
-                HIP_TRY(c, hipMemcpyAsync(c->ht_sel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, c->stream), "upload class index");
-                HIP_TRY(c, hipStreamSynchronize(c->stream), "sync class index");
-                lo.sel = (const uint32_t*)c->ht_sel.p; hi.sel = lo.sel + sel_lo.size();
-                c->ht_classes[0] = lo; c->ht_classes[1] = hi; c->ht_num_classes = 2;
+        std::vector<uint32_t> sel;
+        std::vector<HtClass> cls;
+        std::vector<size_t> first;
+        std::vector<uint8_t> ctop, cbig;
+        for (int top = 1; top >= 0; --top)
+            for (int big = 0; big < 2; ++big) {
+                HtClass cl{nullptr, 0, 0, 0, 0};
+                const size_t at = sel.size();
+                for (uint32_t i = 0; i < c->h_desc.size(); ++i) {
+                    if ((int)(h_res[i] == g.p.num_levels && g.p.num_levels >= 1) != top) continue;
+                    const HtBlockDesc& d = c->h_desc[i];
+                    const uint32_t samples = (uint32_t)d.w * d.h, quads = ((d.w + 1u) / 2u) * ((d.h + 1u) / 2u);
+                    if ((int)(ht_lds_bytes(samples, quads, d.kmax) > kLdsFor16Waves) != big) continue;
+                    cl.count++;
+                    cl.max_kmax = std::max<uint32_t>(cl.max_kmax, d.kmax);
+                    cl.max_samples = std::max<uint32_t>(cl.max_samples, samples);
+                    cl.max_quads = std::max<uint32_t>(cl.max_quads, quads);
+                    sel.push_back(i);
+                }
+                if (cl.count) { cls.push_back(cl); first.push_back(at); ctop.push_back((uint8_t)top); cbig.push_back((uint8_t)big); }
             }
+        HIP_TRY(c, c->ht_sel.ensure(sel.size() * 4 + 16), "alloc class index");
+        HIP_TRY(c, hipMemcpyAsync(c->ht_sel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, c->stream), "upload class index");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync class index");
+        for (size_t k = 0; k < cls.size(); ++k) {
+            cls[k].sel = (const uint32_t*)c->ht_sel.p + first[k];
+            c->ht_classes[k] = cls[k];
+            c->ht_class_top[k] = ctop[k]; c->ht_class_big[k] = cbig[k];
         }
+        c->ht_num_classes = (uint32_t)cls.size();
     }
     // decode-side descriptors: inv_step carries the dequantisation scale of the band
     // (codestream/Quantizer.cpp:41-63 with compress = false: log2_gain 0, then / 2^(31 - numbps))
@@ -179,16 +193,17 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
 
 struct ScopedTimer {
     grk_amd_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(grk_amd_ctx* c_, int w) : c(c_), which(w)
+    hipStream_t st;
+    ScopedTimer(grk_amd_ctx* c_, int w, hipStream_t s = nullptr) : c(c_), which(w), st(s ? s : c_->stream)
     {
         if (!c->timing) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, st);
     }
     ~ScopedTimer()
     {
         if (!a) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         c->timers[which].ev.emplace_back(a, b);
     }
 };
@@ -226,7 +241,10 @@ int run_ingest(grk_amd_ctx* c, uint32_t ntiles, const void* d_pixels, void* d_pl
 }
 
 // d_pixels != nullptr: level 0 reads the caller's pixels directly (K1 fused into K2), d_in is unused
-int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const void* d_pixels = nullptr, uint32_t ntiles = 0)
+HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* rc);
+
+int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const void* d_pixels = nullptr, uint32_t ntiles = 0,
+            bool overlap_ht = false)
 {
     const TileGeom& g = c->geom;
     const uint32_t L = g.p.num_levels;
@@ -269,6 +287,31 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
             HIP_TRY(c, launch_dwt_level0_fused(a, ntiles, g.p.num_comps, g.p.mct, c->stream), "launch fused dwt level 0");
         } else {
             HIP_TRY(c, launch_dwt_level(a, c->stream), "launch dwt level");
+        }
+        if (overlap_ht && (l == 0 || l + 1 == L)) {
+            // After level 0 the top resolution's sub-bands are final: its code-blocks (3/4 of all) are coded on
+            // low-priority side streams while the remaining levels -- short, latency-bound launches that are the
+            // critical path -- run here.  After the last level the rest follows: small-LDS class on this stream (run_ht),
+            // large-LDS class on the second side stream, so that the launches' tails overlap.
+            int rc = GRK_AMD_OK;
+            const HtArgs h = make_ht_args(c, ntiles, d_out, &rc);
+            if (rc) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_level0, c->stream), "record level");
+            for (uint32_t k = 0; k < h.num_classes; ++k) {
+                const bool top = c->ht_class_top[k] != 0, big = c->ht_class_big[k] != 0;
+                hipStream_t st = nullptr;
+                if (l == 0 && top) st = big ? c->side2 : c->side;
+                if (l + 1 == L && !top && big) st = c->side2;
+                if (L == 1 && !top && !big) st = nullptr;          // (run_ht launches it on the main stream)
+                if (!st) continue;
+                HIP_TRY(c, hipStreamWaitEvent(st, c->ev_level0, 0), "side stream waits for the level");
+                ScopedTimer tt(c, st == c->side ? 4 : 8, st);
+                HIP_TRY(c, launch_ht_classes(h, k, k + 1, st), "launch ht encode (side stream)");
+            }
+            if (l + 1 == L) {
+                HIP_TRY(c, hipEventRecord(c->ev_side, c->side), "record side stream");
+                HIP_TRY(c, hipEventRecord(c->ev_side2, c->side2), "record side stream 2");
+            }
         }
     }
     return GRK_AMD_OK;
@@ -402,14 +445,17 @@ int run_egress(grk_amd_ctx* c, uint32_t ntiles, const void* d_planes, void* d_pi
     return GRK_AMD_OK;
 }
 
-int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
+HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* rc)
 {
+    HtArgs a{};
+    *rc = GRK_AMD_OK;
+    auto try_ = [&](hipError_t e, const char* what) { if (e != hipSuccess && *rc == GRK_AMD_OK) *rc = fail(c, GRK_AMD_ERR_NO_DEVICE, what, e); };
     const TileGeom& g = c->geom;
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
-    HIP_TRY(c, c->lengths.ensure(nblocks * 4), "alloc lengths");
-    HIP_TRY(c, c->offsets.ensure((nblocks + 1) * 8), "alloc offsets");
-    HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc allocator state");
+    try_(c->lengths.ensure(nblocks * 4), "alloc lengths");
+    try_(c->offsets.ensure((nblocks + 1) * 8), "alloc offsets");
+    try_(c->flag.ensure(kHtAllocBytes), "alloc allocator state");
     // arena: worst case of the HT cleanup pass is ~ (kmax+1)/8 * 8/7 bytes per sample + VLC/MEL;
     // twice the raw input size plus per-block slack covers every lossless case we accept
     const uint64_t raw = (uint64_t)ntiles * g.p.num_comps * g.p.tile_w * g.p.tile_h * ((g.p.prec + 7) / 8);
@@ -417,23 +463,41 @@ int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat)
     // that small jobs do not spread over many mostly empty chunks
     uint32_t regions = 1;
     while (regions < kHtAllocRegions && nblocks / (regions * 2) >= 256) regions *= 2;
-    HIP_TRY(c, c->arena.ensure(raw * 2 + nblocks * 64 + (size_t)(regions + 1) * kHtAllocChunk + (1u << 20)), "alloc coded arena");
-    HtArgs a{};
+    try_(c->arena.ensure(raw * 2 + nblocks * 64 + (size_t)(regions + 1) * kHtAllocChunk + (1u << 20)), "alloc coded arena");
     a.mallat = (const int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.blocks = (const HtBlockDesc*)c->blockdesc.p; a.blocks_per_tile = bpt; a.ncomp = g.p.num_comps; a.ntiles = ntiles;
     a.arena = (uint8_t*)c->arena.p; a.arena_bytes = c->arena.cap;
-    a.alloc = (unsigned long long*)c->flag.p;        // [0] status flags, [1] bytes used (launch_ht_encode resets them)
+    a.alloc = (unsigned long long*)c->flag.p;        // [0] status flags, [1] bytes used (launch_ht_alloc_init resets them)
     a.lengths = (uint32_t*)c->lengths.p; a.offsets = (unsigned long long*)c->offsets.p;
     a.region_mask = regions - 1;
     a.irreversible = g.p.irreversible;
     a.num_classes = c->ht_num_classes;
     for (uint32_t k = 0; k < c->ht_num_classes; ++k) a.classes[k] = c->ht_classes[k];
+    return a;
+}
+
+// overlapped: the top resolution and the large-LDS classes are already running on the side streams (run_dwt)
+int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, bool overlapped = false)
+{
+    int rc = GRK_AMD_OK;
+    const HtArgs a = make_ht_args(c, ntiles, d_mallat, &rc);
+    if (rc) return rc;
     {
         ScopedTimer t(c, 2);
-        HIP_TRY(c, launch_ht_encode(a, c->stream), "launch ht encode");
+        if (!overlapped) {
+            HIP_TRY(c, launch_ht_alloc_init(a, c->stream), "reset arena allocator");
+            HIP_TRY(c, launch_ht_classes(a, 0, a.num_classes, c->stream), "launch ht encode");
+        } else {
+            for (uint32_t k = 0; k < a.num_classes; ++k)
+                if (!c->ht_class_top[k] && !c->ht_class_big[k]) HIP_TRY(c, launch_ht_classes(a, k, k + 1, c->stream), "launch ht encode");
+        }
+    }
+    if (overlapped) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0), "join side stream");
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side2, 0), "join side stream 2");
     }
     c->last_ntiles = ntiles;
-    c->last_nblocks = nblocks;
+    c->last_nblocks = (uint64_t)c->geom.blocks_per_comp * c->geom.p.num_comps * ntiles;
     return GRK_AMD_OK;
 }
 
@@ -455,6 +519,19 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
     c->device = device_id; c->verbose = verbose;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GRK_AMD_ERR_NO_DEVICE; }
     c->own_stream = true;
+    {   // side stream for K3 of the top resolution (lowest priority: the DWT chain on the main stream is the critical path)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const char* e = getenv("GRK_AMD_OVERLAP");
+        c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
+        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_level0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) {
+            c->side = nullptr; c->overlap = false;
+        }
+    }
     *out = c;
     return GRK_AMD_OK;
 }
@@ -470,6 +547,12 @@ void grk_amd_destroy(grk_amd_ctx* c)
                       &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->ht_sel})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
+    if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
+    if (c->ev_level0) (void)hipEventDestroy(c->ev_level0);
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    for (DevBuf* b : {&c->dec_seg_dev}) b->release();
     delete c;
 }
 
@@ -712,15 +795,30 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
     {
         ScopedTimer t(c, 3);
+        const bool ov = c->overlap && g.p.num_levels >= 1 && c->side != nullptr;
+        if (ov) {       // the allocator must be reset before the first K3 launch of either stream
+            int rc2 = GRK_AMD_OK;
+            const HtArgs h = make_ht_args(c, ntiles, c->p1.p, &rc2);
+            if (rc2) return rc2;
+            HIP_TRY(c, launch_ht_alloc_init(h, c->stream), "reset arena allocator");
+        }
         if (fused) {
-            rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles); if (rc) return rc;
+            rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, ov); if (rc) return rc;
         } else {
             rc = run_ingest(c, ntiles, d_px, c->p0.p); if (rc) return rc;
-            rc = run_dwt(c, nplanes, c->p0.p, c->p1.p); if (rc) return rc;
+            rc = run_dwt(c, nplanes, c->p0.p, c->p1.p, nullptr, ntiles, ov); if (rc) return rc;
         }
-        rc = run_ht(c, ntiles, c->p1.p); if (rc) return rc;
+        rc = run_ht(c, ntiles, c->p1.p, ov); if (rc) return rc;
     }
     if (table || total) return grk_amd_fetch_table(c, table, total);
+    return GRK_AMD_OK;
+}
+
+int grk_amd_set_overlap(grk_amd_ctx* c, int on)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    c->overlap = on != 0 && c->side != nullptr && c->side2 != nullptr;
     return GRK_AMD_OK;
 }
 
@@ -736,7 +834,7 @@ int grk_amd_enable_timing(grk_amd_ctx* c, int on)
 
 double grk_amd_kernel_ms(grk_amd_ctx* c, int which, uint32_t* launches)
 {
-    if (!c || which < 0 || which > 7) return -1.0;
+    if (!c || which < 0 || which > 9) return -1.0;
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
     if (launches) *launches = c->timers[which].launches;

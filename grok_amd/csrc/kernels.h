@@ -49,6 +49,7 @@ struct HtBlockDesc {        // one per code-block of a tile-component set (all c
     uint8_t  pad;
     float    inv_step;      // 1/stepsize (irreversible)
 };
+constexpr uint32_t kHtMaxClasses = 24;      // (resolution, LDS need): up to 10 levels + 1, two each
 struct HtClass {
     const uint32_t* sel;      // device: indices (within a tile) of the blocks of this class; nullptr = all blocks in order
     uint32_t count;
@@ -63,7 +64,7 @@ struct HtArgs {
     uint32_t* lengths;                          // [ntiles*blocks_per_tile]
     unsigned long long* offsets;                // [ntiles*blocks_per_tile]
     const uint32_t* sel; uint32_t sel_count;    // set per launch by launch_ht_encode from `classes`
-    HtClass classes[2]; uint32_t num_classes;   // block classes of a tile (by LDS need), each launched on its own
+    HtClass classes[kHtMaxClasses]; uint32_t num_classes;   // block classes of a tile (= resolutions, finest first), each launched on its own
     uint32_t region_mask;         // (power of two <= kHtAllocRegions) - 1: block i allocates from region i & mask
     int irreversible;
 };
@@ -71,7 +72,9 @@ size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax);
 constexpr size_t   kHtAllocBytes = 8192;
 constexpr uint32_t kHtAllocRegions = 16;           // region words available; a launch uses region_mask + 1 of them
 constexpr uint32_t kHtAllocChunk = 256u << 10;     // bytes a region takes from the shared cursor at a time
-hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);
+hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);          // allocator reset + every class
+hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s);
+hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hipStream_t s);   // classes [first, last)
 uint32_t   dwt_strip_cols();      // output columns a K2 workgroup owns
 uint32_t   idwt_strip_pairs();    // coefficient pairs a K6 workgroup owns
 

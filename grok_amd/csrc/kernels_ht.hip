@@ -659,7 +659,7 @@ size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax)
     return n;
 }
 
-hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s)
+static hipError_t ensure_tables()
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -669,10 +669,24 @@ hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s)
         if (e != hipSuccess) return e;
         g_tables_ready[dev] = true;
     }
+    return hipSuccess;
+}
+
+hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s)
+{
+    hipError_t e = ensure_tables();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ht_alloc_init_kernel, dim3(1), dim3(64), 0, s, a.alloc);
+    return hipGetLastError();
+}
+
+hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hipStream_t s)
+{
+    hipError_t e = ensure_tables();
+    if (e != hipSuccess) return e;
     // one launch per block class (HtClass): the dynamic LDS size is what fixes the occupancy, and the
     // few high-Kmax blocks of the low resolutions would otherwise cost every block a wave per SIMD
-    for (uint32_t k = 0; k < a.num_classes; ++k) {
+    for (uint32_t k = first; k < last && k < a.num_classes; ++k) {
         const HtClass& c = a.classes[k];
         if (c.count == 0) continue;
         uint32_t ms_words, vlc_words, mark_words, vmark_words; size_t shmem;
@@ -686,6 +700,13 @@ hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s)
             hipLaunchKernelGGL(ht_encode_kernel<false>, dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s)
+{
+    hipError_t e = launch_ht_alloc_init(a, s);
+    if (e != hipSuccess) return e;
+    return launch_ht_classes(a, 0, a.num_classes, s);
 }
 
 } // namespace grk_amd

@@ -186,9 +186,15 @@ int grk_amd_stage_egress(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
 
 /* average duration (ms) of the named kernel family over the launches since the last reset,
  * measured with HIP events on the context's stream when timing is enabled.
- * which: 0 ingest+mct, 1 dwt (all levels), 2 ht encode kernel, 3 whole encode_tiles call,
- *        4 (unused), 5 ht decode, 6 inverse dwt (all levels), 7 egress */
+ * which: 0 ingest+mct, 1 dwt (all levels), 2 ht encode kernel (launches on the context's stream), 3 whole
+ *        encode_tiles call, 4 ht encode kernel, top resolution (side stream, beside DWT levels >= 1),
+ *        5 ht decode, 6 inverse dwt (all levels), 7 egress, 8 ht encode kernel, large-LDS classes (second side stream).
+ * One encode runs the ht encode kernel up to three times (2, 4, 8): its time per step is their sum. */
 int    grk_amd_enable_timing(grk_amd_ctx* ctx, int on);
+/* K3 of the top resolution beside DWT levels >= 1 on side streams (default on; environment GRK_AMD_OVERLAP=0/1
+ * sets the default).  Off = every kernel alone on the GPU, one after the other: what per-kernel durations
+ * (roofline figures, rocprofv3 summaries) should be measured with, since co-running kernels stretch each other. */
+int    grk_amd_set_overlap(grk_amd_ctx* ctx, int on);
 double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
 
 /* ---- codestream assembly (host) ----------------------------------

@@ -1,0 +1,32 @@
+"""A/B of GRK_AMD_OVERLAP (K3 of the top resolution beside DWT levels >= 1): ms per 8K encode step (dev tool)."""
+import os, sys, subprocess, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "--one":
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import grok_amd.capi as capi
+    if os.environ.get("AB_LIB"):
+        capi.lib_path = lambda: os.environ["AB_LIB"]
+    import numpy as np, torch, grok_amd as G, synth
+    W = H = int(os.environ.get("ABL_SIZE", "8192"))
+    px = synth.g2(3, H, W, 8)
+    p = G.TileParams.make(W, H, 3, 8, 5)
+    ctx = G.Context(0)
+    d = torch.from_numpy(px.reshape(-1)).cuda()
+    for _ in range(5): ctx.encode_tiles(p, 1, d.data_ptr(), True, fetch=False)
+    ctx.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 40
+    for _ in range(n): ctx.encode_tiles(p, 1, d.data_ptr(), True, fetch=False)
+    ctx.synchronize()
+    print(os.path.basename(os.path.dirname(os.environ.get("AB_LIB", "x/current/l"))), "overlap", os.environ.get("GRK_AMD_OVERLAP"), "ms/step %.4f" % ((time.perf_counter() - t0) / n * 1e3))
+else:
+    variants = [("", "0"), ("", "1")]
+    d = os.path.join(ROOT, "build", "abl")
+    if os.path.isdir(d):
+        variants = [(os.path.join(d, n, "libgrok_amd.so"), "0") for n in sorted(os.listdir(d))] + variants
+    for rep in range(2):
+        for lib, ov in variants:
+            env = dict(os.environ, GRK_AMD_OVERLAP=ov)
+            if lib: env["AB_LIB"] = lib
+            r = subprocess.run([sys.executable, __file__, "--one"], capture_output=True, text=True, env=env)
+            print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:])
