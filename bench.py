@@ -6,8 +6,12 @@ One "step" = one pass of the hot path (ingest+DC+RCT -> 5-level 5/3 DWT -> HT cl
 64x64 code-blocks -> compaction) over one 8192x8192x3 8-bit tile whose pixels are already
 resident in HBM.  With N ranks (torchrun, one process per GPU) the job is an (N*8192)x8192 image
 cut into N tiles of 8192x8192: tile t is encoded on rank t (tiles are independent, SURVEY.md
-§8e) and every step ends with the path's one real exchange: the coded tile-parts are gathered on
-rank 0 over RCCL/xGMI.  Per-GPU work is fixed => weak scaling.
+§8e) and every step ends with the path's one real exchange over RCCL/xGMI: an all_gather of the
+ranks' coded byte counts, from which each rank knows where its tile-parts go in the codestream
+(parallel writer; the coded bytes stay on their GPU -- funnelling N x ~100 MB per step into rank 0
+would bound the job by one GPU's xGMI ingress; `--exchange gather` times that design).  After the
+timed region the tile-parts are gathered once and assembled into the codestream as a check.
+Per-GPU work is fixed => weak scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 8k|cfg2|cfg1|cfg4tile]
 """
@@ -100,6 +104,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="offsets", choices=("offsets", "gather"),
+                    help="N > 1, per step: 'offsets' = all_gather of the coded byte counts (parallel writer: every rank "
+                         "learns where its tile-parts go, the bytes stay put); 'gather' = all coded tile-parts to rank 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,19 +151,29 @@ def main():
     raw_bytes = samples * ((prec + 7) // 8)
     arena_cap = int(raw_bytes * 2)          # grk_amd allocates >= 2 x raw (context.hip: run_ht)
 
-    def step():
+    counts = my_off = None
+
+    def gather_parts():
         nonlocal scratch, last_parts
+        used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
+        offs = _as_tensor(ctx.table_device_ptr(0), nblocks, dev, "<i8")
+        lens = _as_tensor(ctx.table_device_ptr(1), nblocks, dev, "<i4")
+        arena = _as_tensor(ctx.coded_device_ptr(), arena_cap, dev)
+        last_parts, scratch = D.gather_tile_parts_device(used, offs, lens, arena, dst=0, scratch=scratch)
+
+    def step():
+        nonlocal counts, my_off
         with torch.cuda.stream(stream):
             ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
             if use_dist:
-                # the path's one real exchange: coded tile-parts of every rank -> rank 0 (RCCL over xGMI), straight
-                # from the encoder's device-resident table and arena (the collectives are enqueued behind the encode
-                # on this stream; the only host synchronisation is the exchange of the byte counts)
+                # the path's one real exchange, enqueued behind the encode on this stream (RCCL over xGMI)
                 used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
-                offs = _as_tensor(ctx.table_device_ptr(0), nblocks, dev, "<i8")
-                lens = _as_tensor(ctx.table_device_ptr(1), nblocks, dev, "<i4")
-                arena = _as_tensor(ctx.coded_device_ptr(), arena_cap, dev)
-                last_parts, scratch = D.gather_tile_parts_device(used, offs, lens, arena, dst=0, scratch=scratch)
+                if args.exchange == "offsets":
+                    # parallel writer: byte counts only; every rank learns its tile-parts' place in the codestream
+                    counts, my_off = D.exchange_tile_part_offsets(used, counts)
+                else:
+                    # funnel: every coded tile-part to rank 0, straight from the encoder's device table and arena
+                    gather_parts()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -177,6 +194,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if args.exchange == "offsets":
+            # outside the timed region: collect the tile-parts once and check them against the exchanged counts
+            with torch.cuda.stream(stream):
+                gather_parts()
+            torch.cuda.synchronize(dev)
+            if rank == 0:
+                assert [int(v) for v in counts.cpu()] == [int(c.numel()) for _, _, c in last_parts], "byte counts disagree"
         if rank == 0:
             # the gathered tile-parts really are a codestream: assemble the (N*W) x H image once
             ft, fc = D.merge_tile_parts(D.parts_to_numpy(last_parts), world * ntiles, nblocks // ntiles)
@@ -293,7 +317,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if irrev else "int32", "data": "synthetic",
             "config": {"workload": desc, "tiles_per_gpu": ntiles, "code_blocks_per_gpu": int(nblocks),
                        "coded_bytes_per_gpu": int(total), "generator": "G2 (SURVEY.md §8d)",
-                       "parallelism": "tile-sharded x%d, coded tile-parts gathered on rank 0 (RCCL)" % world
+                       "parallelism": ("tile-sharded x%d, per step all_gather of the coded byte counts (RCCL): every rank "
+                                       "learns its tile-parts' offsets in the codestream, the bytes stay on their GPU" % world)
+                       if args.exchange == "offsets" else
+                       "tile-sharded x%d, coded tile-parts gathered on rank 0 every step (RCCL)" % world
                        if use_dist else "1 GPU"},
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_step": int(pipeline_bytes),

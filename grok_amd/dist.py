@@ -117,6 +117,21 @@ def gather_tile_parts_device(used, offsets, lengths, arena, dst=0, scratch=None)
     return None, scratch
 
 
+def exchange_tile_part_offsets(used, counts=None):
+    """What a parallel codestream writer needs per step, and all it needs: every rank's coded byte count, from which
+    each rank knows where its tile-parts start in the file (exclusive prefix sum; headers are a host-side constant).
+    One all_gather of 8 bytes per rank over RCCL, enqueued on the current stream behind the encode -- no host
+    synchronisation, no coded byte leaves its GPU (each rank writes its own tile-parts at its offset; funnelling
+    N x ~100 MB per step into one GPU would bound the job by that GPU's xGMI ingress instead).
+    used: int64[1] device tensor (grk_amd_table_device_ptr(ctx, 2)).  Returns (counts int64[world], my offset int64[1])."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if counts is None:
+        counts = torch.zeros(world, dtype=torch.int64, device=used.device)
+    dist.all_gather_into_tensor(counts, used.reshape(1).to(torch.int64))
+    starts = torch.cumsum(counts, 0) - counts
+    return counts, starts[rank:rank + 1]
+
+
 def parts_to_numpy(parts):
     out = []
     for offs, lens, coded in parts:

@@ -57,6 +57,12 @@ def _worker(rank, world, port, q):
     # the device-resident variant bench.py uses (tables as tensors, one host synchronisation)
     parts2, _ = D.gather_tile_parts_device(torch.tensor([coded.numel()]), torch.from_numpy(table["offset"].astype(np.int64)),
                                            torch.from_numpy(table["length"].astype(np.int32)), coded, dst=0)
+    # the per-step exchange of the parallel-writer design: byte counts only; every rank learns its offset
+    counts, my_off = D.exchange_tile_part_offsets(torch.tensor([coded.numel()]))
+    all_sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(all_sizes, torch.tensor([coded.numel()], dtype=torch.int64))
+    assert [int(v) for v in counts] == [int(v) for v in all_sizes]
+    assert int(my_off) == sum(int(v) for v in all_sizes[:rank])
     if rank == 0:
         full_table, full_coded = D.merge_tile_parts(parts, ntiles, bpt)
         cs = G.write_codestream(p, 256, 256, full_table, full_coded)
