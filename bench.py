@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="every kernel alone on the GPU, also in the timed region (what the rocprofv3 kernel-trace summary "
+                         "that the roofline durations are checked against is taken with)")
     ap.add_argument("--exchange", default="offsets", choices=("offsets", "gather"),
                     help="N > 1, per step: 'offsets' = all_gather of the coded byte counts (parallel writer: every rank "
                          "learns where its tile-parts go, the bytes stay put); 'gather' = all coded tile-parts to rank 0")
@@ -126,6 +129,8 @@ def main():
     irrev = args.workload == "cfg3"
     params = G.TileParams.make(W, H, Cn, prec, levels, irreversible=irrev)
     ctx = G.Context(local_rank)
+    if args.no_overlap:
+        ctx.set_overlap(False)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -266,10 +271,10 @@ def main():
         ctx.enable_timing(False)
         return out
     # as the timed region ran (kernels of the two directions of the pipeline share the GPU and stretch each other) ...
-    fam_overlapped = family_pass(True)
+    fam_overlapped = family_pass(not args.no_overlap)
     # ... and one kernel at a time: the durations a kernel's roofline figure is about
     fam = family_pass(False)
-    ctx.set_overlap(True)
+    ctx.set_overlap(not args.no_overlap)
     table, total = ctx.fetch_table(nblocks)
     b_in = (prec + 7) // 8
     algo = {"ingest_mct": samples * (b_in + 4), "dwt53_5levels": 8.0 * samples * sigma(levels),
