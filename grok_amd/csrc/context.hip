@@ -67,6 +67,7 @@ struct grk_amd_ctx {
     hipStream_t side = nullptr;                             // K3 of the top resolution runs here beside DWT levels >= 1
     hipEvent_t ev_level0 = nullptr, ev_side = nullptr;
     bool overlap = false;
+    bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
     DevBuf ht_sel;
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
@@ -241,10 +242,21 @@ int run_ingest(grk_amd_ctx* c, uint32_t ntiles, const void* d_pixels, void* d_pl
 }
 
 // d_pixels != nullptr: level 0 reads the caller's pixels directly (K1 fused into K2), d_in is unused
-HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* rc);
+HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* rc, bool h16 = false);
+
+// 16-bit planes are safe when no coefficient of any level can leave int16.  Bound (5/3, L1 norms of the analysis
+// filters: low-pass 1.5, high-pass 2 per dimension; RCT chroma is one bit wider than the pixels): the LL of level l is
+// below M * 2.25^l, a detail band of level l below 4 * M * 2.25^(l-1), with M = 2^prec the largest input magnitude.
+bool planes16_ok(const grk_amd_tile_params& p)
+{
+    if (p.irreversible || p.prec > 8 || p.num_levels == 0) return false;
+    double bound = (double)(1u << p.prec) * 4.0;
+    for (uint32_t l = 1; l < p.num_levels; ++l) bound *= 2.25;
+    return bound + 8.0 * p.num_levels < 32767.0;
+}
 
 int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const void* d_pixels = nullptr, uint32_t ntiles = 0,
-            bool overlap_ht = false)
+            bool overlap_ht = false, bool h16 = false)
 {
     const TileGeom& g = c->geom;
     const uint32_t L = g.p.num_levels;
@@ -272,6 +284,7 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         else { a.ll = (int32_t*)c->llB.p; a.ll_stride = sB; a.ll_pitch = pitchB; }
         a.nplanes = nplanes;
         a.irreversible = g.p.irreversible;
+        a.h16 = h16 ? 1 : 0;
         // enough workgroups to cover the chip several times, few enough to amortise warm-up rows
         const uint32_t sh = (a.ch + 1) >> 1;
         uint32_t seg = 64;
@@ -294,7 +307,7 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
             // critical path -- run here.  After the last level the rest follows: small-LDS class on this stream (run_ht),
             // large-LDS class on the second side stream, so that the launches' tails overlap.
             int rc = GRK_AMD_OK;
-            const HtArgs h = make_ht_args(c, ntiles, d_out, &rc);
+            const HtArgs h = make_ht_args(c, ntiles, d_out, &rc, h16);
             if (rc) return rc;
             HIP_TRY(c, hipEventRecord(c->ev_level0, c->stream), "record level");
             for (uint32_t k = 0; k < h.num_classes; ++k) {
@@ -445,7 +458,7 @@ int run_egress(grk_amd_ctx* c, uint32_t ntiles, const void* d_planes, void* d_pi
     return GRK_AMD_OK;
 }
 
-HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* rc)
+HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* rc, bool h16)
 {
     HtArgs a{};
     *rc = GRK_AMD_OK;
@@ -464,7 +477,7 @@ HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* 
     uint32_t regions = 1;
     while (regions < kHtAllocRegions && nblocks / (regions * 2) >= 256) regions *= 2;
     try_(c->arena.ensure(raw * 2 + nblocks * 64 + (size_t)(regions + 1) * kHtAllocChunk + (1u << 20)), "alloc coded arena");
-    a.mallat = (const int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
+    a.mallat = (const int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems; a.h16 = h16 ? 1 : 0;
     a.blocks = (const HtBlockDesc*)c->blockdesc.p; a.blocks_per_tile = bpt; a.ncomp = g.p.num_comps; a.ntiles = ntiles;
     a.arena = (uint8_t*)c->arena.p; a.arena_bytes = c->arena.cap;
     a.alloc = (unsigned long long*)c->flag.p;        // [0] status flags, [1] bytes used (launch_ht_alloc_init resets them)
@@ -477,10 +490,10 @@ HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* 
 }
 
 // overlapped: the top resolution and the large-LDS classes are already running on the side streams (run_dwt)
-int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, bool overlapped = false)
+int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, bool overlapped = false, bool h16 = false)
 {
     int rc = GRK_AMD_OK;
-    const HtArgs a = make_ht_args(c, ntiles, d_mallat, &rc);
+    const HtArgs a = make_ht_args(c, ntiles, d_mallat, &rc, h16);
     if (rc) return rc;
     {
         ScopedTimer t(c, 2);
@@ -522,6 +535,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
     {   // side stream for K3 of the top resolution (lowest priority: the DWT chain on the main stream is the critical path)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (const char* e16 = getenv("GRK_AMD_PLANES16")) c->planes16 = atoi(e16) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
@@ -796,19 +810,22 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     {
         ScopedTimer t(c, 3);
         const bool ov = c->overlap && g.p.num_levels >= 1 && c->side != nullptr;
+        // 8-bit reversible content: int16 LL / Mallat planes between K2 and K3 (half the bytes written and read back);
+        // needs the fused level 0 (the stand-alone ingest kernel writes int32 planes)
+        const bool h16 = c->planes16 && fused && planes16_ok(g.p);
         if (ov) {       // the allocator must be reset before the first K3 launch of either stream
             int rc2 = GRK_AMD_OK;
-            const HtArgs h = make_ht_args(c, ntiles, c->p1.p, &rc2);
+            const HtArgs h = make_ht_args(c, ntiles, c->p1.p, &rc2, h16);
             if (rc2) return rc2;
             HIP_TRY(c, launch_ht_alloc_init(h, c->stream), "reset arena allocator");
         }
         if (fused) {
-            rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, ov); if (rc) return rc;
+            rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, ov, h16); if (rc) return rc;
         } else {
             rc = run_ingest(c, ntiles, d_px, c->p0.p); if (rc) return rc;
             rc = run_dwt(c, nplanes, c->p0.p, c->p1.p, nullptr, ntiles, ov); if (rc) return rc;
         }
-        rc = run_ht(c, ntiles, c->p1.p, ov); if (rc) return rc;
+        rc = run_ht(c, ntiles, c->p1.p, ov, h16); if (rc) return rc;
     }
     if (table || total) return grk_amd_fetch_table(c, table, total);
     return GRK_AMD_OK;

@@ -36,6 +36,7 @@ struct DwtLevelArgs {
     int32_t  sext;        // signed samples: sign bit of the stored word (see IngestArgs), else 0
     uint32_t ncomp;       // components per tile
     uint32_t comp0, zdiv; // set by the launcher: first component of a z slot, z slots per tile
+    int      h16;         // reversible, 8-bit pixels: every plane (in, ll, mallat) holds int16 instead of int32
 };
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s);
 hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, int mct, hipStream_t s);
@@ -56,7 +57,8 @@ struct HtClass {
     uint32_t max_kmax, max_samples, max_quads;   // extents that size the class's LDS buffers
 };
 struct HtArgs {
-    const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp]
+    const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp] (stride, pitch in elements)
+    int h16;                                                  // the planes hold int16 coefficients (reversible only)
     const HtBlockDesc* blocks; uint32_t blocks_per_tile; uint32_t ncomp; uint32_t ntiles;
     uint8_t*  arena; uint64_t arena_bytes;      // coded bytes of all blocks (chunked region allocator, kernels_ht.hip)
     unsigned long long* alloc;                  // kHtAllocBytes of allocator state: [0] status flags (bit 0 arena

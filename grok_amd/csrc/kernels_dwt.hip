@@ -153,9 +153,12 @@ __device__ __forceinline__ void color_fwd_px(int32_t& c0, int32_t& c1, int32_t& 
 //   planes, DC shift and RCT/ICT are applied in registers and NC (= 3 with MCT) components run
 //   through the transform side by side, so the int32 ingest planes are never written or read
 //   (saves 8 of the 8 + b_in + 4 bytes per sample that K1 + level 0 move separately).
-template <bool F97, int NC, int PX>
+// H16 (reversible only): the planes this level reads (PX = 0) and writes hold int16 coefficients -- half the bytes
+//   of the int32 working type; the caller guarantees the range (context.hip: planes16_ok).
+template <bool F97, int NC, int PX, bool H16 = false>
 __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 {
+    static_assert(!(F97 && H16), "16-bit planes are for the reversible transform");
     using T  = typename std::conditional<F97, float, int32_t>::type;
     using T2 = typename std::conditional<F97, float2, int2>::type;
     using PIX = typename std::conditional<PX == 2, uint16_t, uint8_t>::type;
@@ -181,9 +184,10 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     // first plane this workgroup produces
     uint32_t plane0 = blockIdx.z;
     if constexpr (PX != 0) plane0 = (blockIdx.z / a.zdiv) * a.ncomp + a.comp0 + (blockIdx.z % a.zdiv);
-    const T* in = reinterpret_cast<const T*>(a.in) + (size_t)plane0 * a.in_pitch;
-    T* ll = reinterpret_cast<T*>(a.ll) + (size_t)plane0 * a.ll_pitch;
-    T* mp = reinterpret_cast<T*>(a.mallat) + (size_t)plane0 * a.m_pitch;
+    using PT = typename std::conditional<H16, int16_t, T>::type;             // element type of the planes in memory
+    const PT* in = reinterpret_cast<const PT*>(a.in) + (size_t)plane0 * a.in_pitch;
+    PT* ll = reinterpret_cast<PT*>(a.ll) + (size_t)plane0 * a.ll_pitch;
+    PT* mp = reinterpret_cast<PT*>(a.mallat) + (size_t)plane0 * a.m_pitch;
     const size_t comp_px = (size_t)cw * ch;
     const PIX* pix = reinterpret_cast<const PIX*>(a.pixels) + (size_t)plane0 * comp_px;
     const bool pvec = vec && (cw & 1u) == 0;          // tightly packed rows: pairs aligned only for even widths
@@ -204,9 +208,15 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         auto fetch_row = [&](int32_t r, Raw& q) {
             const uint32_t rr = mirror_row<FAST>(r, ch);
             if constexpr (PX == 0) {
-                const int32_t* row = reinterpret_cast<const int32_t*>(in) + (size_t)rr * a.in_stride;
-                if (FAST || vec) { const int2 v = *reinterpret_cast<const int2*>(row + lane_col); q.a[0] = v.x; q.b[0] = v.y; }
-                else     { q.a[0] = row[mA]; q.b[0] = row[mB]; }
+                if constexpr (H16) {
+                    const int16_t* row = reinterpret_cast<const int16_t*>(in) + (size_t)rr * a.in_stride;
+                    if (FAST) q.a[0] = (int32_t)*reinterpret_cast<const uint32_t*>(row + lane_col);   // pair stays packed
+                    else { q.a[0] = row[mA]; q.b[0] = row[mB]; }
+                } else {
+                    const int32_t* row = reinterpret_cast<const int32_t*>(in) + (size_t)rr * a.in_stride;
+                    if (FAST || vec) { const int2 v = *reinterpret_cast<const int2*>(row + lane_col); q.a[0] = v.x; q.b[0] = v.y; }
+                    else     { q.a[0] = row[mA]; q.b[0] = row[mB]; }
+                }
             } else {
     #pragma unroll
                 for (int k = 0; k < NC; ++k) {
@@ -225,6 +235,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         auto convert = [&](const Raw& q, T (&va)[NC], T (&vb)[NC]) {
             if constexpr (PX == 0) {
                 if constexpr (F97) { va[0] = __int_as_float(q.a[0]); vb[0] = __int_as_float(q.b[0]); }
+                else if constexpr (H16 && FAST) { va[0] = (int32_t)(int16_t)q.a[0]; vb[0] = q.a[0] >> 16; }
                 else               { va[0] = q.a[0]; vb[0] = q.b[0]; }
             } else {
                 int32_t xa[NC], xb[NC];
@@ -338,19 +349,19 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
                 const bool has_h = FAST || (uint32_t)j < dh;
     #pragma unroll
                 for (int k = 0; k < NC; ++k) {
-                    T* llk = ll + (size_t)k * a.ll_pitch;
-                    T* mpk = mp + (size_t)k * a.m_pitch;
+                    PT* llk = ll + (size_t)k * a.ll_pitch;
+                    PT* mpk = mp + (size_t)k * a.m_pitch;
                     if (FAST) {          // interior strip: every horizontal lane owns a column of all four sub-bands
-                        llk[(size_t)j * a.ll_stride + Jc] = o[k][0];
-                        mpk[(size_t)j * a.m_stride + sw + Jc] = o[k][1];
-                        mpk[(size_t)(sh + j) * a.m_stride + Jc] = o[k][2];
-                        mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = o[k][3];
+                        llk[(size_t)j * a.ll_stride + Jc] = (PT)o[k][0];
+                        mpk[(size_t)j * a.m_stride + sw + Jc] = (PT)o[k][1];
+                        mpk[(size_t)(sh + j) * a.m_stride + Jc] = (PT)o[k][2];
+                        mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = (PT)o[k][3];
                     } else {
-                        if (st_s) llk[(size_t)j * a.ll_stride + Jc] = o[k][0];
-                        if (st_d) mpk[(size_t)j * a.m_stride + sw + Jc] = o[k][1];
+                        if (st_s) llk[(size_t)j * a.ll_stride + Jc] = (PT)o[k][0];
+                        if (st_d) mpk[(size_t)j * a.m_stride + sw + Jc] = (PT)o[k][1];
                         if (has_h) {
-                            if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Jc] = o[k][2];
-                            if (st_d) mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = o[k][3];
+                            if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Jc] = (PT)o[k][2];
+                            if (st_d) mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = (PT)o[k][3];
                         }
                     }
                 }
@@ -399,6 +410,8 @@ hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
     dim3 block(kThreads);
     if (a.irreversible)
         hipLaunchKernelGGL((dwt_level_kernel<true, 1, 0>), grid, block, 0, s, a);
+    else if (a.h16)
+        hipLaunchKernelGGL((dwt_level_kernel<false, 1, 0, true>), grid, block, 0, s, a);
     else
         hipLaunchKernelGGL((dwt_level_kernel<false, 1, 0>), grid, block, 0, s, a);
     return hipGetLastError();
@@ -419,6 +432,9 @@ hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint
         if (a.irreversible) {
             if (nc == 3) { if (px == 1) GRK_L0(true, 3, 1); else GRK_L0(true, 3, 2); }
             else         { if (px == 1) GRK_L0(true, 1, 1); else GRK_L0(true, 1, 2); }
+        } else if (a.h16 && px == 1) {       // 16-bit planes exist for 8-bit pixels only (context.hip: planes16_ok)
+            if (nc == 3) hipLaunchKernelGGL((dwt_level_kernel<false, 3, 1, true>), grid, block, 0, s, a);
+            else         hipLaunchKernelGGL((dwt_level_kernel<false, 1, 1, true>), grid, block, 0, s, a);
         } else {
             if (nc == 3) { if (px == 1) GRK_L0(false, 3, 1); else GRK_L0(false, 3, 2); }
             else         { if (px == 1) GRK_L0(false, 1, 1); else GRK_L0(false, 1, 2); }

@@ -235,7 +235,8 @@ __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* fl
     }
 }
 
-template <bool IRREV>
+// H16: the Mallat planes hold int16 coefficients (reversible, 8-bit pixels; kernels_dwt.hip H16)
+template <bool IRREV, bool H16 = false>
 __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_words, uint32_t vlc_words, uint32_t mark_words, uint32_t vmark_words)
 {
     // LDS (kept under 10 KiB for 8-bit content so that 16 waves fit a CU): raw MagSgn bits | raw VLC bits |
@@ -257,8 +258,10 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const HtBlockDesc bd = a.blocks[lb];
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
-    const int32_t* src = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
-    const bool full = w == 64 && h == 64 && ((bd.px | a.stride) & 1u) == 0;   // 8-byte row-pair loads, no edges
+    constexpr uint32_t EB = H16 ? 2u : 4u;         // bytes per coefficient
+    const char* src = reinterpret_cast<const char*>(a.mallat) +
+                      (((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px) * EB;
+    const bool full = w == 64 && h == 64 && ((bd.px | a.stride) & 1u) == 0;   // aligned row-pair loads, no edges
     const uint32_t kmax = bd.kmax;
     const bool narrow = kmax + 2 <= 16;           // a quad's four MagSgn values fit 64 bits
 
@@ -280,8 +283,8 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     const bool isq0 = qx == 0, isq31 = qx == 31;
     const int a_x32 = (lane ^ 32) << 2, a_up = ((lane - 1) & 63) << 2, a_dn = ((lane + 1) & 63) << 2;
     const uint32_t iters = (QH + 1) >> 1;
-    const uint32_t stride_b = a.stride * 4u;
-    const char* srcb = reinterpret_cast<const char*>(src);
+    const uint32_t stride_b = a.stride * EB;
+    const char* srcb = src;
     const float inv_step = bd.inv_step;
     const uint32_t lim = (1u << kmax) - 1u;
 
@@ -296,18 +299,24 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     auto fetch = [&](uint32_t it, int32_t (&r)[4]) {
         const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
         if constexpr (FULL) {
-            const uint32_t off = y0 * stride_b + x0 * 4u;
-            const i32x2 q0 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off));
-            const i32x2 q1 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off + stride_b));
-            r[0] = q0.x; r[2] = q0.y; r[1] = q1.x; r[3] = q1.y;
+            const uint32_t off = y0 * stride_b + x0 * EB;
+            if constexpr (H16) {     // one word = the row's two samples; unpacked in stage 1 so that the load stays in flight
+                r[0] = __builtin_nontemporal_load(reinterpret_cast<const int32_t*>(srcb + off));
+                r[1] = __builtin_nontemporal_load(reinterpret_cast<const int32_t*>(srcb + off + stride_b));
+            } else {
+                const i32x2 q0 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off));
+                const i32x2 q1 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off + stride_b));
+                r[0] = q0.x; r[2] = q0.y; r[1] = q1.x; r[3] = q1.y;
+            }
         } else {
             // addresses clamped into the block; what lies outside is zeroed when the values are used
             const uint32_t xa = min(x0, w - 1), xb = min(x0 + 1, w - 1);
             const uint32_t ya = min(y0, h - 1), yb = min(y0 + 1, h - 1);
-            r[0] = *reinterpret_cast<const int32_t*>(srcb + ya * stride_b + xa * 4u);
-            r[2] = *reinterpret_cast<const int32_t*>(srcb + ya * stride_b + xb * 4u);
-            r[1] = *reinterpret_cast<const int32_t*>(srcb + yb * stride_b + xa * 4u);
-            r[3] = *reinterpret_cast<const int32_t*>(srcb + yb * stride_b + xb * 4u);
+            using ET = typename std::conditional<H16, int16_t, int32_t>::type;
+            r[0] = *reinterpret_cast<const ET*>(srcb + ya * stride_b + xa * EB);
+            r[2] = *reinterpret_cast<const ET*>(srcb + ya * stride_b + xb * EB);
+            r[1] = *reinterpret_cast<const ET*>(srcb + yb * stride_b + xa * EB);
+            r[3] = *reinterpret_cast<const ET*>(srcb + yb * stride_b + xb * EB);
         }
     };
 
@@ -327,6 +336,10 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
 
     auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) {
         int32_t r[4] = {nbuf[0], nbuf[1], nbuf[2], nbuf[3]};
+        if constexpr (FULL && H16) {
+            r[0] = (int32_t)(int16_t)nbuf[0]; r[2] = nbuf[0] >> 16;
+            r[1] = (int32_t)(int16_t)nbuf[1]; r[3] = nbuf[1] >> 16;
+        }
         if constexpr (!FULL) {
             const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
             const bool ox0 = x0 < w, ox1 = x0 + 1 < w, oy0 = y0 < h, oy1 = y0 + 1 < h;
@@ -696,6 +709,8 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
         const uint32_t grid = c.count * a.ntiles;
         if (a.irreversible)
             hipLaunchKernelGGL(ht_encode_kernel<true>, dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
+        else if (a.h16)
+            hipLaunchKernelGGL((ht_encode_kernel<false, true>), dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
         else
             hipLaunchKernelGGL(ht_encode_kernel<false>, dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
     }

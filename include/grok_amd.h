@@ -124,6 +124,8 @@ int grk_amd_fetch_coded(grk_amd_ctx* ctx, uint8_t* dst, uint64_t nbytes);
 /* device pointers for zero-copy consumers (RCCL gather of tile parts, tests) */
 void* grk_amd_coded_device_ptr(grk_amd_ctx* ctx);
 void* grk_amd_plane_device_ptr(grk_amd_ctx* ctx, int which /*0: ingest planes, 1: Mallat planes*/);
+/* (after grk_amd_encode_tiles of 8-bit reversible content the Mallat planes hold int16 coefficients -- same strides
+ *  and pitches in elements -- unless the environment says GRK_AMD_PLANES16=0; the stage entry points are int32) */
 /* the block table of the last encode where it was produced, for exchanges that never touch the host:
  * which 0: uint64 offsets[nblocks], 1: uint32 lengths[nblocks], 2: uint64 bytes used in the arena */
 void* grk_amd_table_device_ptr(grk_amd_ctx* ctx, int which);

@@ -241,3 +241,33 @@ def test_gpu_codestream_other_block_sizes_vs_grok(cblk):
     px = synth.g2(3, 128, 192, 8)
     want, _ = R.encode(px, 8, numres=4, mode=1, cblk=(1 << cblk[0], 1 << cblk[1]))
     assert gpu_codestream(px, 8, 3, cblk=cblk) == want
+
+
+@pytest.mark.parametrize("C,H,W,L,sgnd,mct", [(3, 512, 640, 5, False, True), (1, 300, 517, 3, False, False), (3, 257, 129, 2, False, True),
+                                              (3, 256, 256, 5, True, True), (4, 192, 320, 4, False, True), (3, 1024, 1024, 1, False, False)])
+def test_int16_planes_equal_int32_planes(C, H, W, L, sgnd, mct, monkeypatch):
+    """8-bit reversible encodes keep int16 LL / Mallat planes between K2 and K3 (half the bytes; context.hip
+    planes16_ok).  The same tile through a context with GRK_AMD_PLANES16=0 (int32 planes), with and without the
+    K3/DWT overlap, and through the oracle chain: identical blocks.  Extreme pixels (0 / 255 checkerboards)
+    push the coefficients to the bound the 16-bit planes are sized for."""
+    rng = np.random.default_rng(H * 7 + W)
+    px = synth.g2(C, H, W, 8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    px[:, :H // 2] = np.where(((yy[:H // 2] // 3 + xx[:H // 2] // 5 + rng.integers(0, 2)) & 1) == 0, 0, 255).astype(np.uint8)
+    if sgnd:
+        px = (px.astype(np.int32) - 128).astype(np.int8)
+    p = G.TileParams.make(W, H, C, 8, L, sgnd=sgnd, mct=mct)
+    got = {}
+    for planes16, overlap in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("GRK_AMD_PLANES16", planes16)
+        monkeypatch.setenv("GRK_AMD_OVERLAP", overlap)
+        c = G.Context(0)
+        try:
+            t, coded = c.encode_host(p, px)
+            got[(planes16, overlap)] = U.split_blocks(t, coded)
+        finally:
+            c.close() if hasattr(c, "close") else None
+    assert got[("1", "1")] == got[("0", "1")] == got[("1", "0")]
+    _, _, _, otable, ocoded = chain.encode_tile_oracle(px, 8, L, mct=mct, sgnd=sgnd)
+    want = [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
+    assert got[("1", "1")] == want
