@@ -240,6 +240,10 @@ def main():
         b_in_d = (prec + 7) // 8
         dalgo = {"ht_cleanup_decode": 4.0 * samples + float(total_d), "idwt53_5levels": 8.0 * samples * sigma(levels),
                  "egress_mct": samples * (4.0 + b_in_d)}
+        if dk["egress_mct"][1] == 0:
+            # K7 is fused into the last inverse DWT level: that launch writes the pixels (b_in B/sample) instead of an
+            # int32 plane, so the family's algorithmic bytes are 8*S*(sigma_L - 1) + 4*S + S*b_in
+            dalgo["idwt53_5levels"] = 8.0 * samples * (sigma(levels) - 1.0) + samples * (4.0 + b_in_d)
         decode = {"value": round(pixels_per_step * dsteps / ddt / 1e6, 1), "unit": "Mpixels/s",
                   "ms_per_step": round(ddt / dsteps * 1e3, 4), "steps": dsteps, "lossless_round_trip": (bool(torch.equal(d_back, d_px)) if not irrev else None),
                   "max_abs_error": (int((d_back.view(torch.int16 if prec > 8 else torch.uint8).to(torch.int32) -

@@ -67,6 +67,7 @@ struct grk_amd_ctx {
     hipStream_t side = nullptr;                             // K3 of the top resolution runs here beside DWT levels >= 1
     hipEvent_t ev_level0 = nullptr, ev_side = nullptr;
     bool overlap = false;
+    bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
     bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
     DevBuf ht_sel;
     std::vector<uint64_t> h_off;
@@ -330,7 +331,9 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
     return GRK_AMD_OK;
 }
 
-int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out)
+// d_pixels != nullptr: the last level writes the pixels itself (K7 fused, out_bytes 1 or 2) and d_out is not touched
+int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out, void* d_pixels = nullptr,
+             uint32_t ntiles = 0, uint32_t out_bytes = 0)
 {
     const TileGeom& g = c->geom;
     const uint32_t L = g.p.num_levels;
@@ -361,9 +364,19 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
         const uint32_t sh = (a.ch + 1) >> 1;
         uint32_t seg = 64;
         const uint64_t strips = (((a.cw + 1) >> 1) + idwt_strip_pairs() - 1) / idwt_strip_pairs();
-        while (seg > 8 && strips * ((sh + seg - 1) / seg) * nplanes < 4096) seg >>= 1;
+        const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
+        while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
         a.seg_pairs = seg;
-        HIP_TRY(c, launch_idwt_level(a, c->stream), "launch idwt level");
+        if (l == 0 && d_pixels) {
+            a.pixels = d_pixels; a.px_bytes = out_bytes;
+            a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
+            a.lo = g.p.sgnd ? -(1 << (g.p.prec - 1)) : 0;
+            a.hi = g.p.sgnd ? (1 << (g.p.prec - 1)) - 1 : (1 << g.p.prec) - 1;
+            a.mct = g.p.mct;
+            HIP_TRY(c, launch_idwt_level0_fused(a, ntiles, g.p.num_comps, c->stream), "launch fused idwt level 0");
+        } else {
+            HIP_TRY(c, launch_idwt_level(a, c->stream), "launch idwt level");
+        }
     }
     return GRK_AMD_OK;
 }
@@ -536,6 +549,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (const char* e16 = getenv("GRK_AMD_PLANES16")) c->planes16 = atoi(e16) != 0;
+        if (const char* ef = getenv("GRK_AMD_FUSE_EGRESS")) c->fuse_egress = atoi(ef) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
@@ -680,15 +694,22 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         HIP_TRY(c, c->dec_pixels.ensure(px_bytes), "alloc pixel staging");
         d_px = c->dec_pixels.p;
     }
-    HIP_TRY(c, c->p0.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc planes");
+    const bool fuse_out = g.p.num_levels >= 1 && bps <= 2 && c->fuse_egress;
+    if (!fuse_out) HIP_TRY(c, c->p0.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc planes");
     HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
     {
         ScopedTimer t(c, 3);
         rc = p->reserved[0] ? run_t1_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p)
                             : run_ht_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p);
         if (rc) return rc;
-        rc = run_idwt(c, nplanes, c->p1.p, c->p0.p); if (rc) return rc;
-        rc = run_egress(c, ntiles, c->p0.p, d_px, bps); if (rc) return rc;
+        // with at least one DWT level and 8-/16-bit pixels the last level writes the pixels itself (K7 fused): the
+        // int32 image planes (4 bytes per sample written and read back) never exist
+        if (fuse_out) {
+            rc = run_idwt(c, nplanes, c->p1.p, nullptr, d_px, ntiles, bps); if (rc) return rc;
+        } else {
+            rc = run_idwt(c, nplanes, c->p1.p, c->p0.p); if (rc) return rc;
+            rc = run_egress(c, ntiles, c->p0.p, d_px, bps); if (rc) return rc;
+        }
     }
     if (!pixels_on_device) {
         HIP_TRY(c, hipMemcpyAsync(pixels, d_px, px_bytes, hipMemcpyDeviceToHost, c->stream), "download pixels");

@@ -125,8 +125,16 @@ struct IdwtLevelArgs {
     uint32_t nplanes;
     uint32_t seg_pairs;
     int      irreversible;
+    // last level fused with K7 (launch_idwt_level0_fused): the rows leave as the caller's pixels
+    void*    pixels;      // tiles back to back, component-major planar, tight (as EgressArgs::pixels)
+    uint32_t px_bytes;    // 1 or 2 bytes per sample
+    int32_t  dc, lo, hi;  // DC shift and clamp range (EgressArgs)
+    int      mct;
+    uint32_t ncomp;       // components per tile
+    uint32_t comp0, zdiv; // set by the launcher: first component of a z slot, z slots per tile
 };
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s);
+hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, hipStream_t s);
 
 // ---- K7: inverse colour transform + DC shift + clamp + store as pixels (kernels_idwt.hip) --------
 struct EgressArgs {

@@ -112,21 +112,65 @@ struct IV97 {       // yields rows 2(i-1) and 2(i-2)+1
     }
 };
 
-template <bool F97>
+// float -> int32 as the reference's bulk path (_mm256_cvtps_epi32, mct.cpp:248-250): round to nearest
+// even, out of range / NaN -> 0x80000000 (v_cvt would saturate instead)
+__device__ __forceinline__ int32_t cvt_rn(float f)
+{
+    return fabsf(f) < 2147483648.0f ? __float2int_rn(f) : (int32_t)0x80000000;
+}
+// K7 for one pixel: inverse RCT/ICT on the MCT triple (mct.cpp:454-464, :278-289), float -> int, DC shift, clamp.
+// c[] holds int32 values or float bit patterns (irreversible).
+template <int NC>
+__device__ __forceinline__ void egress_px(int32_t (&c)[NC], bool irrev, bool mct, int32_t dc, int32_t lo, int32_t hi)
+{
+    constexpr int K1 = NC >= 3 ? 1 : 0, K2 = NC >= 3 ? 2 : 0;
+    if (NC >= 3 && mct) {
+        if (!irrev) {
+            const int32_t yy = c[0], u = c[K1], v = c[K2];
+            const int32_t g = yy - ((u + v) >> 2);
+            c[0] = v + g; c[K1] = g; c[K2] = u + g;
+        } else {
+            const float yy = __int_as_float(c[0]), u = __int_as_float(c[K1]), v = __int_as_float(c[K2]);
+            const float r = __fadd_rn(yy, __fmul_rn(v, 1.402f));
+            const float g = __fsub_rn(__fsub_rn(yy, __fmul_rn(u, 0.34413f)), __fmul_rn(v, 0.71414f));
+            const float b = __fadd_rn(yy, __fmul_rn(u, 1.772f));
+            c[0] = cvt_rn(r); c[K1] = cvt_rn(g); c[K2] = cvt_rn(b);
+        }
+#pragma unroll
+        for (int k = 3; k < NC; ++k) if (irrev) c[k] = cvt_rn(__int_as_float(c[k]));
+    } else if (irrev) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) c[k] = cvt_rn(__int_as_float(c[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c[k] = min(max(c[k] + dc, lo), hi);
+}
+
+// PXO = 0: the level writes an int32/float plane (every level but the last, and the stage entry point).
+// PXO = 1 / 2: the LAST level fused with K7 -- NC (= 3 with MCT) components are synthesised side by side and the
+//   finished rows leave as 8- / 16-bit pixels after the inverse colour transform, DC shift and clamp, so the
+//   int32 image planes (4 B/sample written + read back by K7) never exist.
+template <bool F97, int NC, int PXO>
 __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
 {
     using T  = typename std::conditional<F97, float, int32_t>::type;
     using T2 = typename std::conditional<F97, float2, int2>::type;
-    // [parity][row: low/high][half: s/d][local pair index]
-    __shared__ __attribute__((aligned(16))) T line[2][2][2][kThreads];
+    using PIX = typename std::conditional<PXO == 2, uint16_t, uint8_t>::type;
+    static_assert(PXO != 0 || NC == 1, "plane output is one component per workgroup");
+    // [parity][comp][row: low/high][half: s/d][local pair index]
+    __shared__ __attribute__((aligned(16))) T line[2][NC][2][2][kThreads];
 
     const uint32_t t = threadIdx.x;
     const uint32_t cw = a.cw, ch = a.ch;
     const uint32_t sw = (cw + 1) >> 1, sh = (ch + 1) >> 1;
 
-    const T* ll = reinterpret_cast<const T*>(a.ll) + (size_t)blockIdx.z * a.ll_pitch;
-    const T* mp = reinterpret_cast<const T*>(a.mallat) + (size_t)blockIdx.z * a.m_pitch;
-    T* out = reinterpret_cast<T*>(a.out) + (size_t)blockIdx.z * a.out_pitch;
+    uint32_t plane0 = blockIdx.z;
+    if constexpr (PXO != 0) plane0 = (blockIdx.z / a.zdiv) * a.ncomp + a.comp0 + (blockIdx.z % a.zdiv);
+    const T* ll = reinterpret_cast<const T*>(a.ll) + (size_t)plane0 * a.ll_pitch;
+    const T* mp = reinterpret_cast<const T*>(a.mallat) + (size_t)plane0 * a.m_pitch;
+    T* out = reinterpret_cast<T*>(a.out) + (size_t)plane0 * a.out_pitch;
+    const size_t comp_px = (size_t)cw * ch;
+    PIX* pix = reinterpret_cast<PIX*>(a.pixels) + (size_t)plane0 * comp_px;
 
     // The pair this lane loads and (lanes [0, kOutPairs)) synthesises: the strip's own pairs in lane order, so that a
     // wave's loads and stores start on cache-line boundaries; the next 2 * kHaloPairs lanes fetch the halo pairs left
@@ -145,68 +189,95 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     constexpr int lag  = F97 ? 2 : 1;       // rows 2i and 2i+1 are complete after step i + lag
     constexpr int warm = F97 ? 2 : 1;       // steps before I0 whose outputs are discarded
 
-    struct Raw { T ls, ld, hs, hd; };
+    struct Raw { T ls[NC], ld[NC], hs[NC], hd[NC]; };
     auto fetch = [&](int32_t i, Raw& q) {
         // vertical mirror in the interleaved domain: low row 2i, high row 2i+1
         const uint32_t is = mirror_row(2 * i, ch) >> 1;
         const uint32_t id = ch > 1 ? (mirror_row(2 * i + 1, ch) - 1) >> 1 : 0;
-        q.ls = ll[(size_t)is * a.ll_stride + js];
-        q.ld = cw > 1 ? mp[(size_t)is * a.m_stride + sw + jd] : T(0);
-        q.hs = ch > 1 ? mp[(size_t)(sh + id) * a.m_stride + js] : T(0);
-        q.hd = (ch > 1 && cw > 1) ? mp[(size_t)(sh + id) * a.m_stride + sw + jd] : T(0);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const T* llk = ll + (size_t)k * a.ll_pitch;
+            const T* mpk = mp + (size_t)k * a.m_pitch;
+            q.ls[k] = llk[(size_t)is * a.ll_stride + js];
+            q.ld[k] = cw > 1 ? mpk[(size_t)is * a.m_stride + sw + jd] : T(0);
+            q.hs[k] = ch > 1 ? mpk[(size_t)(sh + id) * a.m_stride + js] : T(0);
+            q.hd[k] = (ch > 1 && cw > 1) ? mpk[(size_t)(sh + id) * a.m_stride + sw + jd] : T(0);
+        }
+    };
+    // one finished row of this lane's two columns leaves the kernel: as a plane row, or as pixels
+    const bool px_vec = (cw & 1u) == 0;          // tightly packed pixel rows: pairs are aligned only for even widths
+    auto emit = [&](int32_t r, const T (&vA)[NC], const T (&vB)[NC]) {
+        if constexpr (PXO == 0) {
+            T* row = out + (size_t)r * a.out_stride + 2 * J;
+            if (st_o) { T2 v; v.x = vA[0]; v.y = vB[0]; *reinterpret_cast<T2*>(row) = v; }
+            else if (st_e) row[0] = vA[0];
+        } else {
+            int32_t cA[NC], cB[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if constexpr (F97) { cA[k] = __float_as_int(vA[k]); cB[k] = __float_as_int(vB[k]); }
+                else               { cA[k] = vA[k]; cB[k] = vB[k]; }
+            }
+            egress_px<NC>(cA, F97, a.mct != 0, a.dc, a.lo, a.hi);
+            egress_px<NC>(cB, F97, a.mct != 0, a.dc, a.lo, a.hi);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                PIX* row = pix + (size_t)k * comp_px + (size_t)r * cw + 2 * J;
+                if (st_o && px_vec) {
+                    if constexpr (PXO == 1) *reinterpret_cast<uchar2*>(row) = make_uchar2((uint8_t)cA[k], (uint8_t)cB[k]);
+                    else                    *reinterpret_cast<ushort2*>(row) = make_ushort2((uint16_t)cA[k], (uint16_t)cB[k]);
+                } else {
+                    if (st_e) row[0] = (PIX)cA[k];
+                    if (st_o) row[1] = (PIX)cB[k];
+                }
+            }
+        }
     };
 
-    typename std::conditional<F97, IV97, IV53>::type colA, colB;
-    colA.init(); colB.init();
+    typename std::conditional<F97, IV97, IV53>::type colA[NC], colB[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { colA[k].init(); colB[k].init(); }
     Raw cur, nxt;
     int32_t i = I0 - warm;
     fetch(i, cur);
     const int32_t i_end = I1 - 1 + lag;
     for (int par = 0; i <= i_end; ++i, par ^= 1) {
         if (i < i_end) fetch(i + 1, nxt);
-        line[par][0][0][lp] = cur.ls; line[par][0][1][lp] = cur.ld;
-        line[par][1][0][lp] = cur.hs; line[par][1][1][lp] = cur.hd;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            line[par][k][0][0][lp] = cur.ls[k]; line[par][k][0][1][lp] = cur.ld[k];
+            line[par][k][1][0][lp] = cur.hs[k]; line[par][k][1][1][lp] = cur.hd[k];
+        }
         __syncthreads();
         if (h_lane) {
-            T se, so, de, dodd;                           // low row / high row, even / odd column
-            if (cw == 1) { se = line[par][0][0][lp]; so = 0; de = line[par][1][0][lp]; dodd = 0; }
-            else if constexpr (F97) {
-                hs97(&line[par][0][0][lp], &line[par][0][1][lp], se, so);
-                hs97(&line[par][1][0][lp], &line[par][1][1][lp], de, dodd);
-            } else {
-                hs53(&line[par][0][0][lp], &line[par][0][1][lp], se, so);
-                hs53(&line[par][1][0][lp], &line[par][1][1][lp], de, dodd);
+            T oA[NC], eA[NC], oB[NC], eB[NC];                 // finished rows (odd, even) of columns 2J and 2J+1
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                T se, so, de, dodd;                           // low row / high row, even / odd column
+                if (cw == 1) { se = line[par][k][0][0][lp]; so = 0; de = line[par][k][1][0][lp]; dodd = 0; }
+                else if constexpr (F97) {
+                    hs97(&line[par][k][0][0][lp], &line[par][k][0][1][lp], se, so);
+                    hs97(&line[par][k][1][0][lp], &line[par][k][1][1][lp], de, dodd);
+                } else {
+                    hs53(&line[par][k][0][0][lp], &line[par][k][0][1][lp], se, so);
+                    hs53(&line[par][k][1][0][lp], &line[par][k][1][1][lp], de, dodd);
+                }
+                if (ch == 1) { eA[k] = se; eB[k] = so; oA[k] = oB[k] = 0; }
+                else { colA[k].step(se, de, oA[k], eA[k]); colB[k].step(so, dodd, oB[k], eB[k]); }
             }
-            T oA, eA, oB, eB;                             // finished rows (odd, even) of columns 2J and 2J+1
-            if (ch == 1) { eA = se; eB = so; oA = oB = 0; }
-            else { colA.step(se, de, oA, eA); colB.step(so, dodd, oB, eB); }
             // which output rows these are
             const int32_t r_even = ch == 1 ? 0 : 2 * (i - (lag - 1));
             const int32_t r_odd = r_even - 1;              // 5/3: 2i-1 ; 9/7: 2(i-2)+1
             const bool ok_e = ch == 1 ? (i == 0) : (r_even >= 2 * I0 && r_even < 2 * I1 && (uint32_t)r_even < ch);
             const bool ok_o = ch > 1 && r_odd >= 2 * I0 && r_odd < 2 * I1 && (uint32_t)r_odd < ch;
-            if (ok_e) {
-                T* row = out + (size_t)r_even * a.out_stride + 2 * J;
-                if (st_o) { T2 v; v.x = eA; v.y = eB; *reinterpret_cast<T2*>(row) = v; }
-                else if (st_e) row[0] = eA;
-            }
-            if (ok_o) {
-                T* row = out + (size_t)r_odd * a.out_stride + 2 * J;
-                if (st_o) { T2 v; v.x = oA; v.y = oB; *reinterpret_cast<T2*>(row) = v; }
-                else if (st_e) row[0] = oA;
-            }
+            if (ok_e) emit(r_even, eA, eB);
+            if (ok_o) emit(r_odd, oA, oB);
         }
         cur = nxt;
     }
 }
 
-// ---- K7 egress -----------------------------------------------------------------------------------
-// float -> int32 as the reference's bulk path (_mm256_cvtps_epi32, mct.cpp:248-250): round to nearest
-// even, out of range / NaN -> 0x80000000 (v_cvt would saturate instead)
-__device__ __forceinline__ int32_t cvt_rn(float f)
-{
-    return fabsf(f) < 2147483648.0f ? __float2int_rn(f) : (int32_t)0x80000000;
-}
+// ---- K7 egress, stand-alone (stage entry point; pixel sizes the fused last level does not cover) ----------
 template <typename PIX, int NC>
 __global__ __launch_bounds__(256) void egress_kernel(EgressArgs a)
 {
@@ -274,9 +345,39 @@ hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s)
     dim3 grid((sw + kOutPairs - 1) / kOutPairs, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
     dim3 block(kThreads);
     if (a.irreversible)
-        hipLaunchKernelGGL(idwt_level_kernel<true>, grid, block, 0, s, a);
+        hipLaunchKernelGGL((idwt_level_kernel<true, 1, 0>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL(idwt_level_kernel<false>, grid, block, 0, s, a);
+        hipLaunchKernelGGL((idwt_level_kernel<false, 1, 0>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// The last level (cw x ch = tile size) straight to pixels (a0.pixels, px_bytes 1 or 2, dc/lo/hi, mct set by the caller);
+// a0.nplanes is ignored: the grid covers ntiles x (MCT triple | every component on its own).
+hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, hipStream_t s)
+{
+    const uint32_t sw = (a0.cw + 1) >> 1, sh = (a0.ch + 1) >> 1;
+    dim3 block(kThreads);
+    auto go = [&](uint32_t comp0, uint32_t zdiv, int nc) {
+        IdwtLevelArgs a = a0;
+        a.comp0 = comp0; a.zdiv = zdiv; a.ncomp = ncomp;
+        dim3 grid((sw + kOutPairs - 1) / kOutPairs, (sh + a.seg_pairs - 1) / a.seg_pairs, ntiles * zdiv);
+#define GRK_I0(F97, NC, PX) hipLaunchKernelGGL((idwt_level_kernel<F97, NC, PX>), grid, block, 0, s, a)
+        const int px = a.px_bytes == 1 ? 1 : 2;
+        if (a.irreversible) {
+            if (nc == 3) { if (px == 1) GRK_I0(true, 3, 1); else GRK_I0(true, 3, 2); }
+            else         { if (px == 1) GRK_I0(true, 1, 1); else GRK_I0(true, 1, 2); }
+        } else {
+            if (nc == 3) { if (px == 1) GRK_I0(false, 3, 1); else GRK_I0(false, 3, 2); }
+            else         { if (px == 1) GRK_I0(false, 1, 1); else GRK_I0(false, 1, 2); }
+        }
+#undef GRK_I0
+    };
+    if (a0.mct && ncomp >= 3) {
+        go(0, 1, 3);
+        for (uint32_t k = 3; k < ncomp; ++k) go(k, 1, 1);    // components beyond the triple: no colour transform (NC = 1)
+    } else {
+        go(0, ncomp, 1);
+    }
     return hipGetLastError();
 }
 
