@@ -196,6 +196,135 @@ int32_t encode_file(gra_cparameters* cp, const char* in, const char* out, gra_en
 std::thread g_batch;
 std::atomic<bool> g_batch_done{true}, g_batch_stop{false};
 
+// ---- decode: the callback record of plugin_decompress (plugin/plugin_interface.h:86-130).  C++ on purpose -- it
+//      carries two std::string members, so it is no C ABI; plugin and host must share one libstdc++.  Its layout is
+//      checked against the reference's own struct in oracle/ref_harness/abi_check.cpp.
+struct DecodeCallbackInfo {
+    size_t deviceId = 0;
+    gra_init_decompressors_func init_decompressors_func = nullptr;
+    std::string inputFile, outputFile;
+    int32_t decod_format = 0, cod_format = 0;             // GRK_UNK_FMT: the host takes them from its own parameters
+    void* stream = nullptr; void* codec = nullptr;
+    void* decompressor_parameters = nullptr;
+    gra_header_info header_info;
+    gra_image* image = nullptr;
+    bool plugin_owns_image = false;
+    gra_plugin_tile* tile = nullptr;
+    int32_t error_code = 0;
+    uint32_t decompress_flags = 0;
+    void* user_data = nullptr;
+};
+typedef int32_t (*DecodeUserCallback)(DecodeCallbackInfo*);
+
+gra_header_info g_dec_header;           // what the host's header parser told init_decompressors_func
+gra_image* g_dec_image = nullptr;
+int dec_init_decompressors(gra_header_info* h, gra_image* img)
+{
+    if (!h || !img) return 1;
+    g_dec_header = *h;
+    g_dec_image = img;
+    return 0;
+}
+
+// The plugin side of Grok's decode protocol (grk_decompress.cpp:792-1008 is the host side):
+//   1. GRK_DECODE_HEADER: the host opens the stream, reads the main header and calls init_decompressors_func
+//   2. GRK_DECODE_T2 with our tile tree attached: the host runs Tier-2 and decompress_synch_plugin_with_host copies
+//      every code-block's bytes, numbps and pass count into the tree (plugin_bridge.cpp:24-80); T1 and everything
+//      after it are skipped on the host (TileProcessor.cpp:786-789, CodeStreamDecompress.cpp:935-936)
+//   3. block decode, inverse DWT, inverse MCT on the GPU; the pixels go into the host's grk_image
+//   4. GRK_DECODE_POST_T1: the host stores the image;  5. GRK_PLUGIN_DECODE_CLEAN
+// Anything outside the hot path's scope is declined (non-zero) and the host decodes on its CPU.
+int32_t decompress_file(void* params, DecodeUserCallback cb)
+{
+    if (!g_ctx || !cb) return -1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DecodeCallbackInfo info;
+    std::memset(&info.header_info, 0, sizeof(info.header_info));
+    info.decompressor_parameters = params;
+    info.init_decompressors_func = dec_init_decompressors;
+    info.decompress_flags = GRA_DECODE_HEADER;
+    g_dec_image = nullptr;
+    auto clean = [&](int32_t rc) {
+        info.decompress_flags = GRA_PLUGIN_DECODE_CLEAN;
+        (void)cb(&info);
+        return rc;
+    };
+    if (cb(&info) != 0 || !g_dec_image) return clean(-1);
+    const gra_header_info& h = g_dec_header;
+    gra_image* img = g_dec_image;
+    // the scope of the hot path: one tile at the origin, equal full-resolution components, default
+    // precincts, one codeword segment per block (the host's bridge throws on more), reversible transform
+    if (h.t_grid_width * h.t_grid_height != 1 || img->numcomps == 0 || img->x0 || img->y0 || (h.csty & 1u) ||
+        h.irreversible || (h.cblk_sty & 0x05u) || h.numresolutions == 0)
+        return clean(-1);
+    const gra_image_comp& c0 = img->comps[0];
+    for (uint16_t k = 0; k < img->numcomps; ++k) {
+        const gra_image_comp& ck = img->comps[k];
+        if (ck.dx != 1 || ck.dy != 1 || ck.w != c0.w || ck.h != c0.h || ck.prec != c0.prec || ck.sgnd != c0.sgnd || ck.prec > 16)
+            return clean(-1);
+    }
+    grk_amd_tile_params tp{};
+    tp.tile_w = img->x1 - img->x0; tp.tile_h = img->y1 - img->y0; tp.num_comps = img->numcomps;
+    tp.prec = c0.prec; tp.sgnd = c0.sgnd; tp.irreversible = 0; tp.mct = h.mct ? 1 : 0;
+    tp.num_levels = (uint8_t)(h.numresolutions - 1);
+    uint32_t ew = 0, eh = 0;
+    while ((1u << ew) < h.cblockw_init) ++ew;
+    while ((1u << eh) < h.cblockh_init) ++eh;
+    tp.cblk_w_exp = (uint8_t)ew; tp.cblk_h_exp = (uint8_t)eh;
+    tp.reserved[0] = (h.cblk_sty & 0x40u) ? 0 : 1;         // HT bit clear: classic Part-1 blocks
+    tp.reserved[1] = h.cblk_sty & 0x3Fu;
+    const int64_t nb = grk_amd_tile_num_blocks(&tp);
+    if (nb <= 0) return clean(-1);
+    std::vector<grk_amd_block> layout((size_t)nb);
+    if (grk_amd_tile_layout(&tp, layout.data(), (uint64_t)nb, nullptr) != nb) return clean(-1);
+    // a tree whose blocks own buffers the host can copy into: nominal block area x 4 bytes, as the host allocates
+    // for its own code-blocks (t1/T1Structs.cpp:292-307)
+    std::vector<grk_amd_coded_block> slots((size_t)nb);
+    uint64_t cap = 0;
+    for (size_t i = 0; i < (size_t)nb; ++i) {
+        slots[i].offset = cap; slots[i].length = 0; slots[i].missing_msbs = 0;
+        cap += (uint64_t)(layout[i].x1 - layout[i].x0) * (layout[i].y1 - layout[i].y0) * 4u + 16u;
+    }
+    gra_plugin_tile* tree = build_tree(tp, layout, slots, std::vector<uint8_t>(cap, 0));
+    for (auto* b : reinterpret_cast<TileOwner*>(tree)->block_ptr) { b->numBitPlanes = 0; b->numPasses = 0; }
+    auto done = [&](int32_t rc) { grk_amd_plugin_tile_destroy(tree); return clean(rc); };
+    info.tile = tree;
+    // T2 alone cannot be asked for: without GRK_DECODE_POST_T1 the host never advances to the next tile-part
+    // (CodeStreamDecompress.cpp:968-973 skips findNextTile) and its tile loop then fails with "no SOT marker found"
+    // (:452-461, :2076) AFTER Tier-2 and the synch have run -- reference defect D11.  With POST_T1 set the host also
+    // runs its inverse MCT + DC shift over the (empty) tile buffers and hands them to the image (cheap next to T1 and
+    // the DWT, which stay skipped: TileProcessor.cpp:786-818); the pixels are overwritten below.
+    info.decompress_flags = GRA_DECODE_T2 | GRA_DECODE_POST_T1;
+    tree->decompress_flags = GRA_DECODE_T2 | GRA_DECODE_POST_T1;
+    if (cb(&info) != 0) return done(-1);
+    const size_t bps = (tp.prec + 7u) / 8u, npx = (size_t)tp.tile_w * tp.tile_h;
+    std::vector<uint8_t> px(npx * tp.num_comps * bps);
+    if (grk_amd_plugin_tile_decode(g_ctx, &tp, tree, px.data(), 0) != GRK_AMD_OK) return done(-1);
+    img = info.image ? info.image : img;
+    for (uint16_t k = 0; k < img->numcomps; ++k) {
+        gra_image_comp& ck = img->comps[k];
+        if (!ck.data) {                                   // the host skipped post-T1, so nothing was allocated
+            ck.stride = (ck.w + 31u) & ~31u;
+            void* mem = nullptr;
+            if (posix_memalign(&mem, 64, (size_t)ck.stride * ck.h * sizeof(int32_t)) != 0) return done(-1);
+            ck.data = static_cast<int32_t*>(mem);         // freed by the host with the image (grk_aligned_free = free)
+        }
+        for (uint32_t y = 0; y < ck.h; ++y) {
+            int32_t* dst = ck.data + (size_t)y * ck.stride;
+            const uint8_t* src = px.data() + ((size_t)k * npx + (size_t)y * tp.tile_w) * bps;
+            for (uint32_t x = 0; x < ck.w; ++x) {
+                if (bps == 1) dst[x] = tp.sgnd ? (int32_t)(int8_t)src[x] : (int32_t)src[x];
+                else { uint16_t v; std::memcpy(&v, src + 2 * x, 2); dst[x] = tp.sgnd ? (int32_t)(int16_t)v : (int32_t)v; }
+            }
+        }
+    }
+    info.decompress_flags = GRA_DECODE_POST_T1;
+    tree->decompress_flags = GRA_DECODE_POST_T1;
+    const int32_t rc = cb(&info);
+    info.tile = nullptr;
+    return done(rc == 0 ? 0 : -1);
+}
+
 int32_t plugin_exit() { return 0; }
 void* plugin_create(gra_minpf_object_params*) { return nullptr; }
 int32_t plugin_destroy(void*) { return 0; }
@@ -341,9 +470,35 @@ GRA_EXPORT void plugin_stop_batch_encode(void)
     g_batch_done = true;
 }
 
-// Decode side is not on the device yet (SURVEY.md §8a rows a13-a17 are "next"): decline, the host
-// keeps its CPU decoder (grk_decompress.cpp falls back when the plugin returns non-zero).
-GRA_EXPORT int32_t plugin_decompress(void*, gra_decode_callback) { return -1; }
+// Decode: Grok's plugin protocol end to end (decompress_file above); what is outside the hot path's scope is declined
+// and the host keeps its CPU decoder (grk_decompress.cpp falls back when the plugin returns non-zero).  The batch
+// variants stay declined.
+GRA_EXPORT int32_t plugin_decompress(void* decompress_parameters, gra_decode_callback callback)
+{
+    return decompress_file(decompress_parameters, reinterpret_cast<DecodeUserCallback>(callback));
+}
+// layout facts of the C++ callback record for the ABI check (oracle/ref_harness/abi_check.cpp, tests)
+GRA_EXPORT size_t grk_amd_plugin_decode_info_layout(int which)
+{
+    switch (which) {
+    case 0: return sizeof(DecodeCallbackInfo);
+    case 1: return offsetof(DecodeCallbackInfo, init_decompressors_func);
+    case 2: return offsetof(DecodeCallbackInfo, inputFile);
+    case 3: return offsetof(DecodeCallbackInfo, outputFile);
+    case 4: return offsetof(DecodeCallbackInfo, decod_format);
+    case 5: return offsetof(DecodeCallbackInfo, stream);
+    case 6: return offsetof(DecodeCallbackInfo, codec);
+    case 7: return offsetof(DecodeCallbackInfo, decompressor_parameters);
+    case 8: return offsetof(DecodeCallbackInfo, header_info);
+    case 9: return offsetof(DecodeCallbackInfo, image);
+    case 10: return offsetof(DecodeCallbackInfo, plugin_owns_image);
+    case 11: return offsetof(DecodeCallbackInfo, tile);
+    case 12: return offsetof(DecodeCallbackInfo, error_code);
+    case 13: return offsetof(DecodeCallbackInfo, decompress_flags);
+    case 14: return offsetof(DecodeCallbackInfo, user_data);
+    default: return 0;
+    }
+}
 GRA_EXPORT int32_t plugin_init_batch_decompress(const char*, const char*, void*, gra_decode_callback) { return -1; }
 GRA_EXPORT int32_t plugin_batch_decompress(void) { return -1; }
 GRA_EXPORT void plugin_stop_batch_decompress(void) {}

@@ -170,6 +170,53 @@ typedef struct gra_encode_callback_info {
 typedef void (*gra_encode_callback)(gra_encode_callback_info* info);
 typedef int32_t (*gra_decode_callback)(void* info /* PluginDecodeCallbackInfo*, C++ only */);
 
+/* ---- decode side: what the host hands the plugin's init_decompressors_func (grok.h:1814-1815) ---------------
+ *   gra_header_info   grk_header_info  grok.h:634-687   (leading fields spelled out, the rest opaque; same size)
+ *   gra_image_comp    grk_image_comp   grok.h:866-891
+ *   gra_image         grk_image        grok.h:907-929
+ * PluginDecodeCallbackInfo itself (plugin/plugin_interface.h:86-130) has std::string members: it is mirrored in
+ * C++ inside plugin.cpp, and its layout is checked by oracle/ref_harness/abi_check.cpp like everything here. */
+#define GRA_DECODE_HEADER        (1u << 0)      /* grok.h:1249-1254 */
+#define GRA_DECODE_T2            (1u << 1)
+#define GRA_DECODE_T1            (1u << 2)
+#define GRA_DECODE_POST_T1       (1u << 3)
+#define GRA_PLUGIN_DECODE_CLEAN  (1u << 4)
+#define GRA_HEADER_INFO_SIZE     11360
+typedef struct gra_header_info {
+    uint32_t cblockw_init, cblockh_init;
+    bool     irreversible;
+    uint32_t mct;
+    uint16_t rsiz;
+    uint32_t numresolutions;
+    uint8_t  csty, cblk_sty;
+    uint32_t prcw_init[GRA_J2K_MAXRLVLS], prch_init[GRA_J2K_MAXRLVLS];
+    uint32_t tx0, ty0, t_width, t_height, t_grid_width, t_grid_height;
+    uint16_t tcp_numlayers;
+    uint64_t opaque[(GRA_HEADER_INFO_SIZE - 320) / 8];   /* xml, comments, asoc boxes: not touched */
+} gra_header_info;
+typedef struct gra_image_comp {
+    void*    obj;                 /* grk_object */
+    uint32_t dx, dy, w, stride, h, x0, y0;
+    uint16_t Xcrg, Ycrg;
+    uint8_t  prec;
+    bool     sgnd;
+    int32_t* data;
+    int32_t  type, association;   /* GRK_COMPONENT_TYPE, GRK_COMPONENT_ASSOC */
+} gra_image_comp;
+typedef struct gra_image {
+    void*    obj;
+    uint32_t x0, y0, x1, y1;
+    uint16_t numcomps;
+    int32_t  color_space;         /* GRK_COLOR_SPACE */
+    bool     color_applied, has_capture_resolution;
+    double   capture_resolution[2];
+    bool     has_display_resolution;
+    double   display_resolution[2];
+    void*    meta;
+    gra_image_comp* comps;
+} gra_image;
+typedef int (*gra_init_decompressors_func)(gra_header_info* header_info, gra_image* image);
+
 /* ---- minimal plugin framework registration (plugin/minpf_plugin.h:25-60) --------------------- */
 typedef struct gra_minpf_api_version { int32_t major, minor; } gra_minpf_api_version;
 typedef struct gra_minpf_object_params { const char* id; const struct gra_minpf_platform_services* platformServices; } gra_minpf_object_params;

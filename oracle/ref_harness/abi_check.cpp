@@ -79,4 +79,50 @@ SAME_OFF(gra_minpf_platform_services, grk::minpf_platform_services, invokeServic
 static_assert(GRA_PATH_LEN == GRK_PATH_LEN && GRA_J2K_MAXRLVLS == GRK_J2K_MAXRLVLS &&
               GRA_NUM_COMMENTS_SUPPORTED == GRK_NUM_COMMENTS_SUPPORTED && GRA_CBLKSTY_HT == GRK_CBLKSTY_HT, "constants");
 
+// decode side
+SAME_SIZE(gra_header_info, grk_header_info);
+static_assert(sizeof(grk_header_info) == GRA_HEADER_INFO_SIZE, "GRA_HEADER_INFO_SIZE");
+SAME_OFF(gra_header_info, grk_header_info, cblockw_init); SAME_OFF(gra_header_info, grk_header_info, cblockh_init);
+SAME_OFF(gra_header_info, grk_header_info, irreversible); SAME_OFF(gra_header_info, grk_header_info, mct);
+SAME_OFF(gra_header_info, grk_header_info, rsiz); SAME_OFF(gra_header_info, grk_header_info, numresolutions);
+SAME_OFF(gra_header_info, grk_header_info, csty); SAME_OFF(gra_header_info, grk_header_info, cblk_sty);
+SAME_OFF(gra_header_info, grk_header_info, prcw_init); SAME_OFF(gra_header_info, grk_header_info, prch_init);
+SAME_OFF(gra_header_info, grk_header_info, tx0); SAME_OFF(gra_header_info, grk_header_info, t_width);
+SAME_OFF(gra_header_info, grk_header_info, t_grid_width); SAME_OFF(gra_header_info, grk_header_info, t_grid_height);
+SAME_OFF(gra_header_info, grk_header_info, tcp_numlayers);
+SAME_SIZE(gra_image_comp, grk_image_comp);
+SAME_OFF(gra_image_comp, grk_image_comp, dx); SAME_OFF(gra_image_comp, grk_image_comp, w); SAME_OFF(gra_image_comp, grk_image_comp, stride);
+SAME_OFF(gra_image_comp, grk_image_comp, h); SAME_OFF(gra_image_comp, grk_image_comp, x0); SAME_OFF(gra_image_comp, grk_image_comp, y0);
+SAME_OFF(gra_image_comp, grk_image_comp, prec); SAME_OFF(gra_image_comp, grk_image_comp, sgnd); SAME_OFF(gra_image_comp, grk_image_comp, data);
+SAME_SIZE(gra_image, grk_image);
+SAME_OFF(gra_image, grk_image, x0); SAME_OFF(gra_image, grk_image, y1); SAME_OFF(gra_image, grk_image, numcomps);
+SAME_OFF(gra_image, grk_image, comps);
+static_assert(GRA_DECODE_HEADER == GRK_DECODE_HEADER && GRA_DECODE_T2 == GRK_DECODE_T2 && GRA_DECODE_T1 == GRK_DECODE_T1 &&
+              GRA_DECODE_POST_T1 == GRK_DECODE_POST_T1 && GRA_PLUGIN_DECODE_CLEAN == GRK_PLUGIN_DECODE_CLEAN, "decode flags");
+
+// layout of the reference's C++ decode callback record, for comparison with the plugin's own mirror
+// (grk_amd_plugin_decode_info_layout in libgrokj2k_plugin.so; tests/test_plugin_host.py)
+extern "C" size_t ref_decode_info_layout(int which)
+{
+    using I = grk::PluginDecodeCallbackInfo;
+    switch (which) {
+    case 0: return sizeof(I);
+    case 1: return offsetof(I, init_decompressors_func);
+    case 2: return offsetof(I, inputFile);
+    case 3: return offsetof(I, outputFile);
+    case 4: return offsetof(I, decod_format);
+    case 5: return offsetof(I, stream);
+    case 6: return offsetof(I, codec);
+    case 7: return offsetof(I, decompressor_parameters);
+    case 8: return offsetof(I, header_info);
+    case 9: return offsetof(I, image);
+    case 10: return offsetof(I, plugin_owns_image);
+    case 11: return offsetof(I, tile);
+    case 12: return offsetof(I, error_code);
+    case 13: return offsetof(I, decompress_flags);
+    case 14: return offsetof(I, user_data);
+    default: return 0;
+    }
+}
+
 extern "C" int ref_abi_mirror_checked(void) { return 1; }

@@ -333,6 +333,80 @@ int64_t ref_plugin_compress_file(const EncCfg* cfg, const uint8_t* pixels, const
 	return g_cb_len;
 }
 
+// ---- the decode protocol: grk_plugin_decompress(params, callback) (grok.cpp:727-743) ------------------------
+// The callback below is what src/bin/jp2/grk_decompress.cpp:971-1008 (decompress_callback -> preProcess /
+// postProcess) does in essence, with a memory stream instead of a file and a buffer instead of an image writer.
+static const uint8_t* g_dcb_j2k = nullptr;
+static uint64_t g_dcb_len = 0;
+static int32_t* g_dcb_out = nullptr;
+static int32_t g_dcb_C = 0, g_dcb_W = 0, g_dcb_H = 0;
+static int g_dcb_stage[4] = {0, 0, 0, 0};     // header, t2, post-t1, clean calls seen
+
+static int32_t host_decompress_callback(grk_plugin_decompress_callback_info* info)
+{
+	if (!info) return -1;
+	if (info->decompress_flags & GRK_PLUGIN_DECODE_CLEAN) {
+		g_dcb_stage[3]++;
+		if (info->stream) grk_object_unref(info->stream);
+		info->stream = nullptr;
+		if (info->codec) grk_object_unref(info->codec);
+		info->codec = nullptr;
+		info->image = nullptr;
+		return 0;
+	}
+	if (info->decompress_flags & GRK_DECODE_HEADER) {
+		g_dcb_stage[0]++;
+		if (!info->stream) info->stream = grk_stream_create_mem_stream((uint8_t*)g_dcb_j2k, g_dcb_len, false, true);
+		if (!info->stream) return 1;
+		if (!info->codec) {
+			info->codec = grk_decompress_create(GRK_CODEC_J2K, info->stream);
+			if (!info->codec) return 1;
+			if (!grk_decompress_init(info->codec, &info->decompressor_parameters->core)) return 1;
+		}
+		if (!grk_decompress_read_header(info->codec, &info->header_info)) return 1;
+		info->image = grk_decompress_get_composited_image(info->codec);
+		if (info->init_decompressors_func) return info->init_decompressors_func(&info->header_info, info->image);
+		return 0;
+	}
+	if (info->decompress_flags & (GRK_DECODE_T2 | GRK_DECODE_T1)) {
+		g_dcb_stage[1]++;
+		if (!info->codec || !info->tile) return 1;
+		info->tile->decompress_flags = info->decompress_flags;
+		if (getenv("REF_HARNESS_DEBUG")) grk_set_error_handler([](const char* m, void*) { fprintf(stderr, "[grk error] %s\n", m); }, nullptr);
+		if (!grk_decompress_set_window(info->codec, 0, 0, 0, 0)) { if (getenv("REF_HARNESS_DEBUG")) fprintf(stderr, "set_window failed\n"); return 1; }
+		if (!grk_decompress(info->codec, info->tile)) { if (getenv("REF_HARNESS_DEBUG")) fprintf(stderr, "grk_decompress failed\n"); return 1; }
+		if (!grk_decompress_end(info->codec)) { if (getenv("REF_HARNESS_DEBUG")) fprintf(stderr, "decompress_end failed\n"); return 1; }
+		return 0;
+	}
+	if (info->decompress_flags & GRK_DECODE_POST_T1) {
+		g_dcb_stage[2]++;
+		auto img = info->image;
+		if (!img || img->numcomps != g_dcb_C) return 1;
+		for (int k = 0; k < g_dcb_C; ++k) {
+			auto comp = img->comps + k;
+			if ((int)comp->w != g_dcb_W || (int)comp->h != g_dcb_H || !comp->data) return 1;
+			for (int y = 0; y < g_dcb_H; ++y)
+				memcpy(g_dcb_out + ((size_t)k * g_dcb_H + y) * g_dcb_W, comp->data + (size_t)y * comp->stride, (size_t)g_dcb_W * 4);
+		}
+		return 0;
+	}
+	return -1;
+}
+
+// returns the plugin's answer (0 = decoded by the plugin), stages[] = how often each protocol stage was called
+int32_t ref_plugin_decompress(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, int32_t W, int32_t H, int32_t* stages)
+{
+	grk_decompress_parameters param;
+	memset(&param, 0, sizeof(param));
+	grk_decompress_set_default_params(&param.core);
+	param.decod_format = GRK_J2K_FMT;
+	g_dcb_j2k = j2k; g_dcb_len = len; g_dcb_out = out; g_dcb_C = C; g_dcb_W = W; g_dcb_H = H;
+	memset(g_dcb_stage, 0, sizeof(g_dcb_stage));
+	int32_t rc = grk_plugin_decompress(&param, host_decompress_callback);
+	if (stages) memcpy(stages, g_dcb_stage, sizeof(g_dcb_stage));
+	return rc;
+}
+
 // Load a real plugin .so through the reference's own minpf loader (grk_initialize(pluginPath)),
 // then report what the host sees. Used by the boundary test.
 int ref_plugin_load(const char* dir, int threads)

@@ -163,6 +163,20 @@ def plugin_compress_file(pixels, prec, infile, numres=6, irrev=0):
     return out[:n].tobytes() if n >= 0 else int(n)
 
 
+def plugin_decompress(j2k, Cn, H, W):
+    """grk_plugin_decompress(params, host callback): Grok dlsym()s plugin_decompress in our .so and the two sides run the
+    decode protocol (header -> T2 into the plugin's tile tree -> plugin decodes -> post-T1 -> clean).
+    -> ((C,H,W) int32 pixels, stage call counts) or (refusal code, stage call counts)."""
+    L = lib()
+    L.ref_plugin_decompress.restype = C.c_int32
+    L.ref_plugin_decompress.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    buf = np.frombuffer(j2k, np.uint8).copy()
+    out = np.zeros((Cn, H, W), np.int32)
+    stages = np.zeros(4, np.int32)
+    rc = L.ref_plugin_decompress(buf.ctypes.data, buf.size, out.ctypes.data, Cn, W, H, stages.ctypes.data)
+    return (out if rc == 0 else int(rc)), [int(v) for v in stages]
+
+
 def write_pnm(path, px, prec):
     Cn, H, W = px.shape
     assert Cn in (1, 3)

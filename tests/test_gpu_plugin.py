@@ -61,6 +61,40 @@ def test_file_protocol_through_grok_loader(tmp_path):
     assert isinstance(R.plugin_compress_file(synth.g2(1, 64, 64, 8), 8, "/nonexistent.pgm", numres=3), int)
 
 
+@needs_ref
+@pytest.mark.parametrize("Cn,H,W,prec,numres,ht,sty", [(3, 192, 256, 8, 5, 1, 0), (1, 128, 128, 8, 4, 1, 0), (3, 100, 77, 12, 3, 1, 0),
+                                                        (3, 128, 192, 8, 4, 0, 0), (1, 96, 160, 10, 3, 0, 0x02 | 0x08 | 0x20)])
+def test_decode_protocol_through_grok_loader(Cn, H, W, prec, numres, ht, sty):
+    """grk_initialize(plugin dir) -> grk_plugin_init -> grk_plugin_decompress(params, cb): Grok dlsym()s
+    plugin_decompress in our .so; the host parses the header and runs Tier-2 INTO OUR TILE TREE
+    (decompress_synch_plugin_with_host), skips its own T1 / inverse DWT / inverse MCT, and gets the pixels of the
+    GPU decode back in its grk_image.  HT and classic (Part-1, also with single-segment code-block styles) streams
+    written by grk_compress; result == grk_decompress on the CPU == the source."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    px = synth.g2(Cn, H, W, prec)
+    cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=ht, cblksty=sty)
+    got, stages = R.plugin_decompress(cs, Cn, H, W)
+    assert not isinstance(got, int), "plugin refused: %s (stages %s)" % (got, stages)
+    assert stages == [1, 1, 1, 1]
+    assert np.array_equal(got, R.decode(cs, Cn, H, W))
+    assert np.array_equal(got, px.astype(np.int32))
+
+
+@needs_ref
+def test_decode_protocol_declines_outside_the_hot_path():
+    """Irreversible streams, multi-segment code-block styles and multi-tile images are answered with non-zero:
+    the host keeps its CPU decoder (grk_decompress.cpp:953-955)."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    px = synth.g2(3, 128, 128, 8)
+    for kw in (dict(irrev=1, ht=0), dict(ht=0, cblksty=0x04), dict(TW=64, TH=64)):
+        cs, _ = R.encode(px, 8, numres=3, mode=1, **kw)
+        got, stages = R.plugin_decompress(cs, 3, 128, 128)
+        assert isinstance(got, int) and got != 0
+        assert stages[3] == 1                       # the host was told to clean up
+
+
 @pytest.mark.parametrize("Cn,H,W,prec,L", [(1, 256, 256, 8, 3), (3, 128, 192, 8, 4), (3, 64, 96, 12, 2)])
 def test_plugin_tile_decode_round_trip(Cn, H, W, prec, L):
     """The decode counterpart at the plugin-tile level: a grk_plugin_tile tree carrying what the host's Tier-2

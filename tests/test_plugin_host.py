@@ -62,6 +62,22 @@ def test_abi_mirror_compiled_against_grok_headers():
 
 @needs_ref
 @pytest.mark.ref
+def test_decode_callback_record_layout_matches_reference():
+    """plugin_decompress's callback record (PluginDecodeCallbackInfo, plugin/plugin_interface.h:86-130) has std::string
+    members, so it is mirrored in C++ inside plugin.cpp: every offset and the size equal the reference's own."""
+    P = C.CDLL(os.path.join(R.plugin_dir(), "libgrokj2k_plugin.so"))
+    P.grk_amd_plugin_decode_info_layout.restype = C.c_size_t
+    P.grk_amd_plugin_decode_info_layout.argtypes = [C.c_int]
+    L = R.lib()
+    L.ref_decode_info_layout.restype = C.c_size_t
+    L.ref_decode_info_layout.argtypes = [C.c_int]
+    for which in range(15):
+        assert P.grk_amd_plugin_decode_info_layout(which) == L.ref_decode_info_layout(which), which
+    assert L.ref_decode_info_layout(0) > 11000
+
+
+@needs_ref
+@pytest.mark.ref
 def test_grok_loader_accepts_our_plugin():
     """grk_initialize(<dir with libgrokj2k_plugin.so>) -> minpf dlopen + registration succeed."""
     assert R.plugin_load() == 1
