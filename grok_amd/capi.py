@@ -90,6 +90,7 @@ def lib():
         L.grk_amd_decode_status.argtypes = [vp]
         L.grk_amd_set_decode_qcd.argtypes = [vp, vp, u32]
         L.grk_amd_set_decode_segments.argtypes = [vp, vp, vp, u32]
+        L.grk_amd_set_decode_steps.argtypes = [vp, vp, u32]
         L.grk_amd_set_overlap.argtypes = [vp, i32]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
@@ -235,6 +236,11 @@ class Context:
         t = np.ascontiguousarray(table)
         self._check(self._L.grk_amd_decode_tiles(self._h, C.byref(params), ntiles, t.ctypes.data, d_coded, coded_bytes, 1,
                                                  d_pixels, 1), "decode_tiles")
+
+    def set_decode_steps(self, steps):
+        """Band step sizes as the host's decoder holds them, [comp][band] (None / empty: back to the QCD words)."""
+        a = np.ascontiguousarray(steps if steps is not None else [], np.float32).reshape(-1)
+        self._check(self._L.grk_amd_set_decode_steps(self._h, a.ctypes.data if a.size else None, a.size), "set_decode_steps")
 
     def set_overlap(self, on):
         self._check(self._L.grk_amd_set_overlap(self._h, int(bool(on))), "set_overlap")

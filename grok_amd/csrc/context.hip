@@ -58,6 +58,7 @@ struct grk_amd_ctx {
     TileGeom geom;
     std::vector<HtBlockDesc> h_desc, h_desc_dec;
     std::vector<uint16_t> dec_qcd;                          // decode: QCD words of a foreign stream (optional)
+    std::vector<float> dec_steps;                           // decode: band step sizes as the host holds them (optional), [comp][band]
     std::vector<uint32_t> dec_seg_first;                    // Part-1 decode: codeword segments (optional), [nblocks + 1]
     std::vector<grk_amd_segment> dec_segs;
     DevBuf dec_seg_dev;
@@ -173,8 +174,10 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
         for (uint32_t k = 0; k < p->num_comps; ++k)
             for (const auto& b : g.blocks_comp0) {
                 float scale = 1.0f;
-                if (p->irreversible) {
-                    const uint32_t bi = b.res == 0 ? 0u : 3u * b.res - 2u + (b.band - 1u);
+                const uint32_t bi = b.res == 0 ? 0u : 3u * b.res - 2u + (b.band - 1u);
+                if (p->irreversible && c->dec_steps.size() == (size_t)p->num_comps * g.num_bands_total) {
+                    scale = c->dec_steps[(size_t)k * g.num_bands_total + bi];      // the host's TileBand::stepsize, fix-ups included
+                } else if (p->irreversible) {
                     const uint16_t wq = (c->dec_qcd.size() == g.num_bands_total) ? c->dec_qcd[bi] : g.qcd_words[bi];
                     const double step = (1.0 + (wq & 0x7FF) / 2048.0) * std::pow(2.0, (int)p->prec - (int)(wq >> 11));
                     scale = (float)step;
@@ -722,6 +725,14 @@ int grk_amd_set_decode_qcd(grk_amd_ctx* c, const uint16_t* words, uint32_t count
 {
     if (!c || (count && !words)) return GRK_AMD_ERR_INVALID;
     c->dec_qcd.assign(words, words + count);
+    c->have_geom = false;                  // the per-block dequantisation scales are rebuilt on the next call
+    return GRK_AMD_OK;
+}
+
+int grk_amd_set_decode_steps(grk_amd_ctx* c, const float* steps, uint32_t count)
+{
+    if (!c || (count && !steps)) return GRK_AMD_ERR_INVALID;
+    c->dec_steps.assign(steps, steps + count);
     c->have_geom = false;                  // the per-block dequantisation scales are rebuilt on the next call
     return GRK_AMD_OK;
 }

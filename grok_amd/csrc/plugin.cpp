@@ -253,9 +253,10 @@ int32_t decompress_file(void* params, DecodeUserCallback cb)
     const gra_header_info& h = g_dec_header;
     gra_image* img = g_dec_image;
     // the scope of the hot path: one tile at the origin, equal full-resolution components, default
-    // precincts, one codeword segment per block (the host's bridge throws on more), reversible transform
+    // precincts, one codeword segment per block (the host's bridge throws on more); irreversible only for classic
+    // blocks (the reference's own HT + 9/7 encoder is broken, D1: there is no stream to be compatible with)
     if (h.t_grid_width * h.t_grid_height != 1 || img->numcomps == 0 || img->x0 || img->y0 || (h.csty & 1u) ||
-        h.irreversible || (h.cblk_sty & 0x05u) || h.numresolutions == 0)
+        (h.irreversible && (h.cblk_sty & 0x40u)) || (h.cblk_sty & 0x05u) || h.numresolutions == 0)
         return clean(-1);
     const gra_image_comp& c0 = img->comps[0];
     for (uint16_t k = 0; k < img->numcomps; ++k) {
@@ -265,7 +266,7 @@ int32_t decompress_file(void* params, DecodeUserCallback cb)
     }
     grk_amd_tile_params tp{};
     tp.tile_w = img->x1 - img->x0; tp.tile_h = img->y1 - img->y0; tp.num_comps = img->numcomps;
-    tp.prec = c0.prec; tp.sgnd = c0.sgnd; tp.irreversible = 0; tp.mct = h.mct ? 1 : 0;
+    tp.prec = c0.prec; tp.sgnd = c0.sgnd; tp.irreversible = h.irreversible ? 1 : 0; tp.mct = h.mct ? 1 : 0;
     tp.num_levels = (uint8_t)(h.numresolutions - 1);
     uint32_t ew = 0, eh = 0;
     while ((1u << ew) < h.cblockw_init) ++ew;
@@ -370,6 +371,7 @@ GRA_EXPORT int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_p
     // walk the tree in the enumeration order both sides share: comp -> resolution -> band -> precinct -> block
     std::vector<grk_amd_coded_block> table((size_t)nb);
     std::vector<uint8_t> coded;
+    std::vector<float> steps;            // irreversible: the bands' step sizes; the host's synch stores half (plugin_bridge.cpp:40)
     size_t i = 0;
     for (uint32_t c = 0; c < tile->numComponents; ++c) {
         const gra_plugin_tile_component* tc = tile->tileComponents[c];
@@ -377,6 +379,7 @@ GRA_EXPORT int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_p
             const gra_plugin_resolution* res = tc->resolutions[r];
             for (uint32_t b = 0; b < res->numBands; ++b) {
                 const gra_plugin_band* band = res->band[b];
+                steps.push_back(band->stepsize * 2.0f);
                 for (uint64_t pr = 0; pr < band->numPrecincts; ++pr) {
                     const gra_plugin_precinct* prec = band->precincts[pr];
                     for (uint64_t k = 0; k < prec->numBlocks; ++k) {
@@ -398,7 +401,10 @@ GRA_EXPORT int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_p
     }
     if (i != (size_t)nb) return GRK_AMD_ERR_INVALID;
     coded.resize(coded.size() + 16);
-    return grk_amd_decode_tiles(ctx, p, 1, table.data(), coded.data(), coded.size(), 0, pixels, pixels_on_device);
+    if (p->irreversible && grk_amd_set_decode_steps(ctx, steps.data(), (uint32_t)steps.size()) != GRK_AMD_OK) return GRK_AMD_ERR_INVALID;
+    const int rc = grk_amd_decode_tiles(ctx, p, 1, table.data(), coded.data(), coded.size(), 0, pixels, pixels_on_device);
+    if (p->irreversible) (void)grk_amd_set_decode_steps(ctx, nullptr, 0);
+    return rc;
 }
 
 GRA_EXPORT gra_minpf_exit_func minpf_post_load_plugin(const char*, const gra_minpf_platform_services* services)

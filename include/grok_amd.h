@@ -163,6 +163,11 @@ int grk_amd_decode_status(grk_amd_ctx* ctx);
  * order) its QCD marker carries, from which the decode-side step sizes are derived
  * (codestream/Quantizer.cpp:41-63).  count = 0 returns to the exponents this library's encoder writes. */
 int grk_amd_set_decode_qcd(grk_amd_ctx* ctx, const uint16_t* words, uint32_t count);
+/* The same for a host that already holds the band step sizes: steps[comp * (3 * levels + 1) + band] = the
+ * TileBand::stepsize Grok's decoder computed (codestream/Quantizer.cpp:26-66, HT fix-up :54-63 included; note that
+ * decompress_synch_plugin_with_host stores HALF of it in the plugin tree, plugin_bridge.cpp:40).  Takes precedence
+ * over the QCD words; count = 0 drops it. */
+int grk_amd_set_decode_steps(grk_amd_ctx* ctx, const float* steps, uint32_t count);
 /* Part-1 blocks with more than one codeword segment (LAZY, TERMALL -- T1::decompress_cblk's segment loop,
  * t1/t1_part1/T1.cpp:1280-1318; Grok's own plugin bridge refuses those, plugin_bridge.cpp:50-61, so this is
  * reachable through this C ABI only).  Segments of block i are first_segment[i] .. first_segment[i+1]-1, their

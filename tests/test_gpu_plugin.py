@@ -62,33 +62,36 @@ def test_file_protocol_through_grok_loader(tmp_path):
 
 
 @needs_ref
-@pytest.mark.parametrize("Cn,H,W,prec,numres,ht,sty", [(3, 192, 256, 8, 5, 1, 0), (1, 128, 128, 8, 4, 1, 0), (3, 100, 77, 12, 3, 1, 0),
-                                                        (3, 128, 192, 8, 4, 0, 0), (1, 96, 160, 10, 3, 0, 0x02 | 0x08 | 0x20)])
-def test_decode_protocol_through_grok_loader(Cn, H, W, prec, numres, ht, sty):
+@pytest.mark.parametrize("Cn,H,W,prec,numres,ht,sty,irrev", [(3, 192, 256, 8, 5, 1, 0, 0), (1, 128, 128, 8, 4, 1, 0, 0), (3, 100, 77, 12, 3, 1, 0, 0),
+                                                              (3, 128, 192, 8, 4, 0, 0, 0), (1, 96, 160, 10, 3, 0, 0x02 | 0x08 | 0x20, 0),
+                                                              (3, 128, 192, 12, 5, 0, 0, 1), (3, 96, 160, 8, 4, 0, 0x20, 1)])
+def test_decode_protocol_through_grok_loader(Cn, H, W, prec, numres, ht, sty, irrev):
     """grk_initialize(plugin dir) -> grk_plugin_init -> grk_plugin_decompress(params, cb): Grok dlsym()s
     plugin_decompress in our .so; the host parses the header and runs Tier-2 INTO OUR TILE TREE
     (decompress_synch_plugin_with_host), skips its own T1 / inverse DWT / inverse MCT, and gets the pixels of the
     GPU decode back in its grk_image.  HT and classic (Part-1, also with single-segment code-block styles) streams
-    written by grk_compress; result == grk_decompress on the CPU == the source."""
+    written by grk_compress, lossless and (classic blocks: BASELINE configs[4]'s shape) ICT + 9/7 with the band step
+    sizes taken from the tree; result == grk_decompress on the CPU (== the source when lossless)."""
     assert R.plugin_load() == 1
     assert R.plugin_init(0) == 1
     px = synth.g2(Cn, H, W, prec)
-    cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=ht, cblksty=sty)
+    cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=ht, cblksty=sty, irrev=irrev)
     got, stages = R.plugin_decompress(cs, Cn, H, W)
     assert not isinstance(got, int), "plugin refused: %s (stages %s)" % (got, stages)
     assert stages == [1, 1, 1, 1]
     assert np.array_equal(got, R.decode(cs, Cn, H, W))
-    assert np.array_equal(got, px.astype(np.int32))
+    if not irrev:
+        assert np.array_equal(got, px.astype(np.int32))
 
 
 @needs_ref
 def test_decode_protocol_declines_outside_the_hot_path():
-    """Irreversible streams, multi-segment code-block styles and multi-tile images are answered with non-zero:
+    """HT + 9/7 streams (D1), multi-segment code-block styles and multi-tile images are answered with non-zero:
     the host keeps its CPU decoder (grk_decompress.cpp:953-955)."""
     assert R.plugin_load() == 1
     assert R.plugin_init(0) == 1
     px = synth.g2(3, 128, 128, 8)
-    for kw in (dict(irrev=1, ht=0), dict(ht=0, cblksty=0x04), dict(TW=64, TH=64)):
+    for kw in (dict(irrev=1, ht=1), dict(ht=0, cblksty=0x04), dict(TW=64, TH=64)):
         cs, _ = R.encode(px, 8, numres=3, mode=1, **kw)
         got, stages = R.plugin_decompress(cs, 3, 128, 128)
         assert isinstance(got, int) and got != 0
