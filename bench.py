@@ -255,6 +255,31 @@ def main():
         if decode_err:
             decode["rejected"] = decode_err
             decode["lossless_round_trip"] = None
+        elif ntiles == 1 and levels >= 1 and prec <= 16:
+            # region (windowed) decode of the same tile: a centred window of 1/64 of the area -- only the code-blocks and
+            # the parts of each DWT level the window depends on are computed (grk_amd_decode_region)
+            wx0, wy0 = (W // 2 - W // 16) & ~1, (H // 2 - H // 16) & ~1
+            wx1, wy1 = wx0 + W // 8, wy0 + H // 8
+            d_win = torch.empty((wx1 - wx0) * (wy1 - wy0) * Cn * ((prec + 7) // 8), dtype=torch.uint8, device=dev)
+            try:
+                with torch.cuda.stream(stream):
+                    for _ in range(2):
+                        ctx.decode_region_device(params, table_d, ctx.coded_device_ptr(), total_d, wx0, wy0, wx1, wy1, d_win.data_ptr())
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                with torch.cuda.stream(stream):
+                    for _ in range(dsteps):
+                        ctx.decode_region_device(params, table_d, ctx.coded_device_ptr(), total_d, wx0, wy0, wx1, wy1, d_win.data_ptr())
+                torch.cuda.synchronize(dev)
+                rdt = (time.perf_counter() - t0) / dsteps
+                full = d_back.view(Cn, H, W * ((prec + 7) // 8)) if prec <= 8 else None
+                ok = None
+                if prec <= 8 and not irrev:
+                    ok = bool(torch.equal(d_win.view(Cn, wy1 - wy0, wx1 - wx0), full[:, wy0:wy1, wx0:wx1]))
+                decode["region"] = {"window": [wx0, wy0, wx1, wy1], "ms_per_step": round(rdt * 1e3, 4),
+                                    "equals_crop_of_full_decode": ok}
+            except Exception as e:        # noqa: BLE001
+                decode["region"] = {"error": str(e)}
 
     # ---- per-kernel-family durations: HIP events on the stream each kernel is launched on, `steps` more encodes.
     # K3 runs up to three times per step -- top resolution on a side stream beside DWT levels >= 1 (timer 4), the rest

@@ -91,6 +91,7 @@ def lib():
         L.grk_amd_set_decode_qcd.argtypes = [vp, vp, u32]
         L.grk_amd_set_decode_segments.argtypes = [vp, vp, vp, u32]
         L.grk_amd_set_decode_steps.argtypes = [vp, vp, u32]
+        L.grk_amd_decode_region.argtypes = [vp, PP, vp, vp, u64, i32, u32, u32, u32, u32, vp, i32]
         L.grk_amd_set_overlap.argtypes = [vp, i32]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
@@ -231,6 +232,21 @@ class Context:
         self._check(self._L.grk_amd_decode_tiles(self._h, C.byref(params), ntiles, t.ctypes.data, cb.ctypes.data, cb.size, 0,
                                                  out.ctypes.data, 0), "decode_tiles")
         return out
+
+    def decode_region_host(self, params, table, coded, x0, y0, x1, y1):
+        """Windowed decode of one tile -> pixels (C, y1 - y0, x1 - x0)."""
+        t = np.ascontiguousarray(table)
+        cb = np.frombuffer(coded, np.uint8) if not isinstance(coded, np.ndarray) else np.ascontiguousarray(coded)
+        dt = np.uint8 if params.prec <= 8 else np.uint16
+        out = np.zeros((params.num_comps, y1 - y0, x1 - x0), dt)
+        self._check(self._L.grk_amd_decode_region(self._h, C.byref(params), t.ctypes.data, cb.ctypes.data, cb.size, 0,
+                                                  x0, y0, x1, y1, out.ctypes.data, 0), "decode_region")
+        return out
+
+    def decode_region_device(self, params, table, d_coded, coded_bytes, x0, y0, x1, y1, d_pixels):
+        t = np.ascontiguousarray(table)
+        self._check(self._L.grk_amd_decode_region(self._h, C.byref(params), t.ctypes.data, d_coded, coded_bytes, 1,
+                                                  x0, y0, x1, y1, d_pixels, 1), "decode_region")
 
     def decode_device(self, params, ntiles, table, d_coded, coded_bytes, d_pixels):
         t = np.ascontiguousarray(table)

@@ -334,9 +334,36 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
     return GRK_AMD_OK;
 }
 
-// d_pixels != nullptr: the last level writes the pixels itself (K7 fused, out_bytes 1 or 2) and d_out is not touched
+// Region decode (the reference: grk_decompress_set_window -> WaveletReverse.cpp:1466-2213 partial
+// synthesis over a sparse buffer).  need[l] = the part of LL_l (l = 0: the image) that has to be right so that the
+// window is; level l is synthesised from the coefficient pairs pairs[l] of LL_{l+1} and of resolution L - l's bands.
+// A synthesised sample depends on the pairs within 1 (5/3) or 2 (9/7) of its own, the kernel's strip halo and the
+// recurrence warm-up reach 2 pairs further: the margins below are conservative on purpose.
+struct Rect { uint32_t x0, y0, x1, y1; };
+struct RegionPlan { std::vector<Rect> need, pairs; };
+RegionPlan plan_region(const grk_amd_tile_params& p, Rect win)
+{
+    RegionPlan r;
+    const uint32_t L = p.num_levels, M = p.irreversible ? 4u : 2u;
+    r.need.resize(L + 1); r.pairs.resize(L);
+    r.need[0] = win;
+    for (uint32_t l = 0; l < L; ++l) {
+        const uint32_t cw = ceil_div_pow2(p.tile_w, l), ch = ceil_div_pow2(p.tile_h, l);
+        const uint32_t sw = (cw + 1) >> 1, sh = (ch + 1) >> 1;
+        const Rect n = r.need[l];
+        Rect q;
+        q.x0 = n.x0 / 2 > M ? n.x0 / 2 - M : 0; q.y0 = n.y0 / 2 > M ? n.y0 / 2 - M : 0;
+        q.x1 = std::min(sw, (n.x1 - 1) / 2 + M + 1); q.y1 = std::min(sh, (n.y1 - 1) / 2 + M + 1);
+        r.pairs[l] = q;
+        r.need[l + 1] = q;
+    }
+    return r;
+}
+
+// d_pixels != nullptr: the last level writes the pixels itself (K7 fused, out_bytes 1 or 2) and d_out is not touched;
+// plan != nullptr: only what the window needs is synthesised, and d_pixels is the window (K7 fused required)
 int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out, void* d_pixels = nullptr,
-             uint32_t ntiles = 0, uint32_t out_bytes = 0)
+             uint32_t ntiles = 0, uint32_t out_bytes = 0, const RegionPlan* plan = nullptr)
 {
     const TileGeom& g = c->geom;
     const uint32_t L = g.p.num_levels;
@@ -370,6 +397,16 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
         a.seg_pairs = seg;
+        a.wx0 = 0; a.wy0 = 0; a.wx1 = a.cw; a.wy1 = a.ch;
+        if (plan) {       // the strips and row segments that produce need[l]
+            const Rect n = plan->need[(uint32_t)l];
+            const uint32_t op = idwt_strip_pairs();
+            seg = 16;
+            a.seg_pairs = seg;
+            a.strip0 = (n.x0 / 2) / op; a.nstrips = ((n.x1 - 1) / 2) / op - a.strip0 + 1;
+            a.seg0 = (n.y0 / 2) / seg; a.nsegs = ((n.y1 - 1) / 2) / seg - a.seg0 + 1;
+            if (l == 0) { a.wx0 = n.x0; a.wy0 = n.y0; a.wx1 = n.x1; a.wy1 = n.y1; }
+        }
         if (l == 0 && d_pixels) {
             a.pixels = d_pixels; a.px_bytes = out_bytes;
             a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
@@ -675,29 +712,51 @@ int grk_amd_stage_ht_decode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32
     return check_decode_status(c);
 }
 
-int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
-                         const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
-                         void* pixels, int pixels_on_device)
+static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
+                       const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
+                       void* pixels, int pixels_on_device, const Rect* win)
 {
     if (!c || !p || !table || !coded || !pixels || ntiles == 0) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = ensure_geom(c, p); if (rc) return rc;
     const TileGeom& g = c->geom;
+    const uint32_t nplanes = ntiles * g.p.num_comps;
+    const uint32_t bps = (g.p.prec + 7u) / 8u;
+    const bool fuse_out = g.p.num_levels >= 1 && bps <= 2 && c->fuse_egress;
+    // region decode: the blocks no sample of the window depends on are not decoded, the synthesis covers what is needed
+    RegionPlan plan;
+    std::vector<grk_amd_coded_block> wtable;
+    if (win) {
+        if (ntiles != 1 || win->x0 >= win->x1 || win->y0 >= win->y1 || win->x1 > g.p.tile_w || win->y1 > g.p.tile_h)
+            return fail(c, GRK_AMD_ERR_INVALID, "window outside the tile");
+        if (!fuse_out) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "region decode needs at least one DWT level and 8-/16-bit pixels");
+        plan = plan_region(g.p, *win);
+        const uint32_t L = g.p.num_levels;
+        wtable.assign(table, table + (size_t)g.blocks_per_comp * g.p.num_comps);
+        size_t i = 0;
+        for (uint32_t k = 0; k < g.p.num_comps; ++k)
+            for (const auto& b : g.blocks_comp0) {
+                const Rect& need = b.res == 0 ? plan.need[L] : plan.pairs[L - b.res];
+                if (b.x0 >= need.x1 || b.x1 <= need.x0 || b.y0 >= need.y1 || b.y1 <= need.y0) {
+                    wtable[i].offset = 0; wtable[i].length = 0; wtable[i].missing_msbs = kSkipBlock;
+                }
+                ++i;
+            }
+        table = wtable.data();
+    }
     const void* d_coded = coded;
     if (!coded_on_device) {
         HIP_TRY(c, c->dec_coded.ensure(coded_bytes + 64), "alloc coded staging");
         HIP_TRY(c, hipMemcpyAsync(c->dec_coded.p, coded, coded_bytes, hipMemcpyHostToDevice, c->stream), "upload coded");
         d_coded = c->dec_coded.p;
     }
-    const uint32_t nplanes = ntiles * g.p.num_comps;
-    const uint32_t bps = (g.p.prec + 7u) / 8u;
-    const size_t px_bytes = (size_t)nplanes * g.p.tile_w * g.p.tile_h * bps;
+    const size_t px_bytes = win ? (size_t)g.p.num_comps * (win->x1 - win->x0) * (win->y1 - win->y0) * bps
+                                : (size_t)nplanes * g.p.tile_w * g.p.tile_h * bps;
     void* d_px = pixels;
     if (!pixels_on_device) {
         HIP_TRY(c, c->dec_pixels.ensure(px_bytes), "alloc pixel staging");
         d_px = c->dec_pixels.p;
     }
-    const bool fuse_out = g.p.num_levels >= 1 && bps <= 2 && c->fuse_egress;
     if (!fuse_out) HIP_TRY(c, c->p0.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc planes");
     HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
     {
@@ -708,7 +767,7 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         // with at least one DWT level and 8-/16-bit pixels the last level writes the pixels itself (K7 fused): the
         // int32 image planes (4 bytes per sample written and read back) never exist
         if (fuse_out) {
-            rc = run_idwt(c, nplanes, c->p1.p, nullptr, d_px, ntiles, bps); if (rc) return rc;
+            rc = run_idwt(c, nplanes, c->p1.p, nullptr, d_px, ntiles, bps, win ? &plan : nullptr); if (rc) return rc;
         } else {
             rc = run_idwt(c, nplanes, c->p1.p, c->p0.p); if (rc) return rc;
             rc = run_egress(c, ntiles, c->p0.p, d_px, bps); if (rc) return rc;
@@ -718,7 +777,23 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         HIP_TRY(c, hipMemcpyAsync(pixels, d_px, px_bytes, hipMemcpyDeviceToHost, c->stream), "download pixels");
         return check_decode_status(c);
     }
+    if (win) HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");      // the adapted table was uploaded from a local
     return GRK_AMD_OK;
+}
+
+int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
+                         const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
+                         void* pixels, int pixels_on_device)
+{
+    return decode_impl(c, p, ntiles, table, coded, coded_bytes, coded_on_device, pixels, pixels_on_device, nullptr);
+}
+
+int grk_amd_decode_region(grk_amd_ctx* c, const grk_amd_tile_params* p,
+                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
+                          uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* pixels, int pixels_on_device)
+{
+    const Rect win{x0, y0, x1, y1};
+    return decode_impl(c, p, 1, table, coded, coded_bytes, coded_on_device, pixels, pixels_on_device, &win);
 }
 
 int grk_amd_set_decode_qcd(grk_amd_ctx* c, const uint16_t* words, uint32_t count)

@@ -81,6 +81,7 @@ uint32_t   dwt_strip_cols();      // output columns a K2 workgroup owns
 uint32_t   idwt_strip_pairs();    // coefficient pairs a K6 workgroup owns
 
 // ---- K5: HT cleanup decoder + dequantisation (kernels_htdec.hip) --------------------------------
+constexpr uint32_t kSkipBlock = 0xFFFFFFFFu;   // missing_msbs of a zero-length row: the block lies outside the decoded region
 struct HtDecBlock {          // one per code-block, same layout as grk_amd_coded_block
     uint64_t offset;         // first byte of the block's cleanup pass inside `coded`
     uint32_t length;         // Lcup (0: block has no data -> all samples zero)
@@ -132,6 +133,9 @@ struct IdwtLevelArgs {
     int      mct;
     uint32_t ncomp;       // components per tile
     uint32_t comp0, zdiv; // set by the launcher: first component of a z slot, z slots per tile
+    uint32_t wx0, wy0, wx1, wy1;   // window of the tile the pixels are for (the whole tile: 0, 0, cw, ch)
+    // region decode: only the strips [strip0, strip0 + nstrips) x row segments [seg0, seg0 + nsegs) (0 = all)
+    uint32_t strip0, nstrips, seg0, nsegs;
 };
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s);
 hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, hipStream_t s);

@@ -176,11 +176,7 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
     const uint8_t* D = a.coded + in.offset;
     const int lcup = (int)in.length;
 
-    if (in.length == 0) {                                  // block absent from the codestream: all zero
-        for (uint32_t qy = 0; qy < QH; ++qy)
-            for (uint32_t q = 0; q < QW; ++q) qi[qy * kQuadStride + q] = 0;
-        return;
-    }
+    if (in.length == 0) return;                            // absent (K5b writes the zeros) or outside the decoded region
     bool bad = mm > 29 || lcup < 2;
     int scup = 0;
     if (!bad) {
@@ -311,6 +307,7 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
     const uint32_t x = lane;                              // sample column of this lane
     const bool col_ok = x < w;
 
+    if (in.length == 0 && in.missing_msbs == kSkipBlock) return;   // region decode: nobody reads this block's samples
     if (in.length == 0 || ms_len == 0xFFFFFFFFu) {        // absent or rejected block: zeros
         for (uint32_t y = 0; y < h; ++y) if (col_ok) dst[(size_t)y * a.stride + x] = 0;
         return;

@@ -169,21 +169,23 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     const T* ll = reinterpret_cast<const T*>(a.ll) + (size_t)plane0 * a.ll_pitch;
     const T* mp = reinterpret_cast<const T*>(a.mallat) + (size_t)plane0 * a.m_pitch;
     T* out = reinterpret_cast<T*>(a.out) + (size_t)plane0 * a.out_pitch;
-    const size_t comp_px = (size_t)cw * ch;
+    // pixel output: the window [wx0, wx1) x [wy0, wy1) of the tile (the whole tile unless a region is decoded), tight
+    const uint32_t win_w = a.wx1 - a.wx0;
+    const size_t comp_px = (size_t)win_w * (a.wy1 - a.wy0);
     PIX* pix = reinterpret_cast<PIX*>(a.pixels) + (size_t)plane0 * comp_px;
 
     // The pair this lane loads and (lanes [0, kOutPairs)) synthesises: the strip's own pairs in lane order, so that a
     // wave's loads and stores start on cache-line boundaries; the next 2 * kHaloPairs lanes fetch the halo pairs left
     // and right of the strip.  lp = position in the staged line.
     const uint32_t lp = t < (uint32_t)kOutPairs ? t + kHaloPairs : (t < (uint32_t)(kOutPairs + kHaloPairs) ? t - kOutPairs : t);
-    const int32_t J = (int32_t)(blockIdx.x * kOutPairs) - kHaloPairs + (int32_t)lp;
+    const int32_t J = (int32_t)((blockIdx.x + a.strip0) * kOutPairs) - kHaloPairs + (int32_t)lp;
     // horizontal mirror in the interleaved domain: low sample 2J, high sample 2J+1
     const uint32_t js = mirror_idx(2 * J, cw) >> 1;
     const uint32_t jd = cw > 1 ? (mirror_idx(2 * J + 1, cw) - 1) >> 1 : 0;
     const bool h_lane = t < (uint32_t)kOutPairs;
     const bool st_e = h_lane && (uint32_t)(2 * J) < cw, st_o = h_lane && (uint32_t)(2 * J + 1) < cw;
 
-    const int32_t I0 = (int32_t)(blockIdx.y * a.seg_pairs);
+    const int32_t I0 = (int32_t)((blockIdx.y + a.seg0) * a.seg_pairs);
     const int32_t I1 = min((int32_t)sh, I0 + (int32_t)a.seg_pairs);
     // rows [2*I0, 2*I1) are this workgroup's; the recurrences lag behind the input by `lag` pairs
     constexpr int lag  = F97 ? 2 : 1;       // rows 2i and 2i+1 are complete after step i + lag
@@ -205,7 +207,9 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
         }
     };
     // one finished row of this lane's two columns leaves the kernel: as a plane row, or as pixels
-    const bool px_vec = (cw & 1u) == 0;          // tightly packed pixel rows: pairs are aligned only for even widths
+    const bool px_vec = ((win_w | a.wx0) & 1u) == 0;   // tightly packed pixel rows: pairs are aligned only for even widths / origins
+    const bool in_e = (uint32_t)(2 * J) >= a.wx0 && (uint32_t)(2 * J) < a.wx1;
+    const bool in_o = (uint32_t)(2 * J + 1) >= a.wx0 && (uint32_t)(2 * J + 1) < a.wx1;
     auto emit = [&](int32_t r, const T (&vA)[NC], const T (&vB)[NC]) {
         if constexpr (PXO == 0) {
             T* row = out + (size_t)r * a.out_stride + 2 * J;
@@ -222,13 +226,14 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
             egress_px<NC>(cB, F97, a.mct != 0, a.dc, a.lo, a.hi);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                PIX* row = pix + (size_t)k * comp_px + (size_t)r * cw + 2 * J;
-                if (st_o && px_vec) {
+                if ((uint32_t)r < a.wy0 || (uint32_t)r >= a.wy1) continue;
+                PIX* row = pix + (size_t)k * comp_px + (size_t)((uint32_t)r - a.wy0) * win_w + (2 * J - (int32_t)a.wx0);
+                if (st_o && px_vec && in_e && in_o) {
                     if constexpr (PXO == 1) *reinterpret_cast<uchar2*>(row) = make_uchar2((uint8_t)cA[k], (uint8_t)cB[k]);
                     else                    *reinterpret_cast<ushort2*>(row) = make_ushort2((uint16_t)cA[k], (uint16_t)cB[k]);
                 } else {
-                    if (st_e) row[0] = (PIX)cA[k];
-                    if (st_o) row[1] = (PIX)cB[k];
+                    if (st_e && in_e) row[0] = (PIX)cA[k];
+                    if (st_o && in_o) row[1] = (PIX)cB[k];
                 }
             }
         }
@@ -342,7 +347,8 @@ uint32_t idwt_strip_pairs() { return kOutPairs; }
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s)
 {
     const uint32_t sw = (a.cw + 1) >> 1, sh = (a.ch + 1) >> 1;
-    dim3 grid((sw + kOutPairs - 1) / kOutPairs, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
+    // strips x row segments: all of them, or the caller's sub-grid (region decode)
+    dim3 grid(a.nstrips ? a.nstrips : (sw + kOutPairs - 1) / kOutPairs, a.nsegs ? a.nsegs : (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
     dim3 block(kThreads);
     if (a.irreversible)
         hipLaunchKernelGGL((idwt_level_kernel<true, 1, 0>), grid, block, 0, s, a);
@@ -360,7 +366,7 @@ hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, ui
     auto go = [&](uint32_t comp0, uint32_t zdiv, int nc) {
         IdwtLevelArgs a = a0;
         a.comp0 = comp0; a.zdiv = zdiv; a.ncomp = ncomp;
-        dim3 grid((sw + kOutPairs - 1) / kOutPairs, (sh + a.seg_pairs - 1) / a.seg_pairs, ntiles * zdiv);
+        dim3 grid(a.nstrips ? a.nstrips : (sw + kOutPairs - 1) / kOutPairs, a.nsegs ? a.nsegs : (sh + a.seg_pairs - 1) / a.seg_pairs, ntiles * zdiv);
 #define GRK_I0(F97, NC, PX) hipLaunchKernelGGL((idwt_level_kernel<F97, NC, PX>), grid, block, 0, s, a)
         const int px = a.px_bytes == 1 ? 1 : 2;
         if (a.irreversible) {

@@ -147,6 +147,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
     // value workspace, transposed so that the lanes of a wave touch consecutive words: [group][y*64+x][lane]
     int32_t* ws = a.work + (size_t)blockIdx.x * 4096u * L + threadIdx.x;
+    if (in.length == 0 && in.missing_msbs == kSkipBlock) return;       // region decode: outside the decoded region
     for (uint32_t y = 0; y < h; ++y)
         for (uint32_t x = 0; x < w; ++x) ws[(size_t)(y * 64u + x) * L] = 0;
     if (in.length == 0 || numpasses == 0 || numbps == 0) return;
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a, uint32_t L)
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
     const uint32_t tile = blk / a.blocks_per_tile;
     if (x >= bd.w) return;
+    { const HtDecBlock in = a.table[blk]; if (in.length == 0 && in.missing_msbs == kSkipBlock) return; }
     const int32_t* ws = a.work + (size_t)(blk / L) * 4096u * L + (blk % L);
     int32_t* dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
     const float scale = bd.inv_step / 2;                            // ScaleFilter: stepsize / 2

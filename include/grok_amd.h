@@ -159,6 +159,16 @@ int grk_amd_decode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes,
                          int coded_on_device, void* pixels, int pixels_on_device);
 int grk_amd_decode_status(grk_amd_ctx* ctx);
+/* Region (windowed) decode of ONE tile -- what grk_decompress_set_window() + grk_decompress() do on the host
+ * (grok.h; partial synthesis: transform/WaveletReverse.cpp:1466-2213, tile/SparseBuffer.h): the pixels of the window
+ * [x0, x1) x [y0, y1) of the tile, component-major planar, tight, (x1 - x0) * (y1 - y0) samples per component --
+ * bit-identical to the same crop of grk_amd_decode_tiles' output.  Only the code-blocks a sample of the window depends
+ * on are entropy-decoded and only the strips / row segments of each DWT level that lead to it are synthesised, so
+ * the cost follows the window, not the image.  table / coded describe the whole tile, as for grk_amd_decode_tiles.
+ * Needs at least one DWT level and <= 16-bit pixels (GRK_AMD_ERR_UNSUPPORTED otherwise). */
+int grk_amd_decode_region(grk_amd_ctx* ctx, const grk_amd_tile_params* p,
+                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
+                          uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* pixels, int pixels_on_device);
 /* Irreversible streams of another encoder: the SPqcd words (expn << 11 | mant, one per sub-band in QCD
  * order) its QCD marker carries, from which the decode-side step sizes are derived
  * (codestream/Quantizer.cpp:41-63).  count = 0 returns to the exponents this library's encoder writes. */

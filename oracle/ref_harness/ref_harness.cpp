@@ -283,6 +283,40 @@ int32_t ref_decode(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, in
 	return rc;
 }
 
+// Windowed decode (grk_decompress_set_window, grok.h; WaveletReverse.cpp:1466-2213 does the partial synthesis):
+// out = C planes of (x1 - x0) x (y1 - y0) samples.
+int32_t ref_decode_window(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+	grk_dparameters dp;
+	grk_decompress_set_default_params(&dp);
+	grk_stream* stream = grk_stream_create_mem_stream((uint8_t*)j2k, len, false, true);
+	grk_codec* codec = grk_decompress_create(GRK_CODEC_J2K, stream);
+	int32_t rc = -1;
+	const int W = (int)(x1 - x0), H = (int)(y1 - y0);
+	do {
+		if (!codec) break;
+		if (!grk_decompress_init(codec, &dp)) { rc = -2; break; }
+		grk_header_info hi; memset(&hi, 0, sizeof(hi));
+		if (!grk_decompress_read_header(codec, &hi)) { rc = -3; break; }
+		if (!grk_decompress_set_window(codec, x0, y0, x1, y1)) { rc = -7; break; }
+		if (!grk_decompress(codec, nullptr)) { rc = -4; break; }
+		grk_image* img = grk_decompress_get_composited_image(codec);
+		if (!img || img->numcomps != C) { rc = -5; break; }
+		for (int k = 0; k < C; ++k) {
+			auto comp = img->comps + k;
+			if ((int)comp->w != W || (int)comp->h != H || !comp->data) { rc = -6; break; }
+			for (int y = 0; y < H; ++y)
+				memcpy(out + ((size_t)k * H + y) * W, comp->data + (size_t)y * comp->stride, (size_t)W * 4);
+		}
+		if (rc == -6) break;
+		grk_decompress_end(codec);
+		rc = 0;
+	} while (0);
+	grk_object_unref(stream);
+	grk_object_unref(codec);
+	return rc;
+}
+
 // ---- the file-oriented plugin protocol: grk_plugin_compress(params, callback) (grok.cpp:628) ----
 // The callback below is what src/bin/jp2/grk_compress.cpp:1604-1987 does in essence: build the
 // image, create codec + stream, grk_compress_init/start, grk_compress_with_plugin(codec, tile), end.

@@ -81,6 +81,19 @@ def decode(j2k, Cn, H, W):
     return out
 
 
+def decode_window(j2k, Cn, x0, y0, x1, y1):
+    """grk_decompress with grk_decompress_set_window(x0, y0, x1, y1) -> (C, y1 - y0, x1 - x0) int32."""
+    L = lib()
+    L.ref_decode_window.restype = C.c_int32
+    L.ref_decode_window.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    buf = np.frombuffer(j2k, np.uint8).copy()
+    out = np.zeros((Cn, y1 - y0, x1 - x0), np.int32)
+    rc = L.ref_decode_window(buf.ctypes.data, buf.size, out.ctypes.data, Cn, x0, y0, x1, y1)
+    if rc != 0:
+        raise RuntimeError("ref_decode_window failed rc=%d" % rc)
+    return out
+
+
 def ht_encode_block(sm, kmax):
     """sm: (h,w) uint32 sign-magnitude MSB-aligned words."""
     L = lib()

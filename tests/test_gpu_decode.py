@@ -441,3 +441,65 @@ def test_signed_samples_round_trip_and_blocks(C, H, W, prec, L):
     assert got == want
     back = U.ctx().decode_host(p, table, coded)[0]
     assert np.array_equal(back.view(px.dtype), px)
+
+
+# ---- region (windowed) decode: SURVEY.md §8f N4 ---------------------------------------------------------------
+WINDOWS = [(0, 0, 64, 64), (100, 37, 227, 201), (1, 1, 2, 2), (0, 0, None, None), (333, 250, None, None), (65, 130, 66, 400),
+           (2, 0, 700, 9), (511, 301, 513, 303)]
+
+
+@pytest.mark.parametrize("C,H,W,prec,L,irrev", [(3, 512, 768, 8, 5, False), (1, 517, 700, 12, 3, False), (3, 512, 768, 10, 4, True),
+                                                (3, 600, 1100, 8, 1, False)])
+def test_region_decode_equals_crop_of_full_decode(C, H, W, prec, L, irrev):
+    """grk_amd_decode_region == the same crop of grk_amd_decode_tiles, bit for bit (5/3 and 9/7), for windows at the
+    corners, across strip / segment / code-block boundaries, one pixel wide, and the whole tile -- although only the
+    blocks and the parts of each DWT level the window depends on are computed (what grk_decompress_set_window does
+    on the host, whose windowed output equals the crop of its full output as well: tests/test_oracle_decode.py)."""
+    px = synth.g2(C, H, W, prec)
+    p = G.TileParams.make(W, H, C, prec, L, irreversible=irrev)
+    table, coded = U.ctx().encode_host(p, px)
+    full = U.ctx().decode_host(p, table, coded)[0]
+    if not irrev:
+        assert np.array_equal(full, px)
+    for (x0, y0, x1, y1) in WINDOWS:
+        x1 = W if x1 is None else min(x1, W); y1 = H if y1 is None else min(y1, H)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        # poison the planes the previous call left behind: whatever the window does not depend on must not leak in
+        try:
+            U.ctx().decode_host(p, table, _scrambled(table, coded))
+        except Exception:
+            pass                                  # (a scrambled block may be rejected; the planes are dirty either way)
+        got = U.ctx().decode_region_host(p, table, coded, x0, y0, x1, y1)
+        assert np.array_equal(got, full[:, y0:y1, x0:x1]), (x0, y0, x1, y1)
+
+
+def _scrambled(table, coded):
+    """The same blocks with their payload bit-flipped in the middle: decodes to different (garbage) coefficients."""
+    c = np.frombuffer(coded, np.uint8).copy()
+    for o, l in zip(table["offset"], table["length"]):
+        if l > 8:
+            c[int(o) + 1:int(o) + int(l) // 2] ^= 0x55
+    return c
+
+
+@needs_ref
+@pytest.mark.parametrize("ht,irrev", [(1, 0), (0, 0), (0, 1)])
+def test_region_decode_of_reference_stream_equals_reference_window(ht, irrev):
+    """A grk_compress stream (HT, classic, classic ICT + 9/7): our windowed decode == grk_decompress with
+    grk_decompress_set_window on the same window."""
+    px = synth.g2(3, 384, 512, 8)
+    cs, _ = R.encode(px, 8, numres=5, mode=1, ht=ht, irrev=irrev)
+    info = J.parse(cs)
+    p = G.TileParams.make(512, 384, 3, 8, 4, irreversible=bool(irrev), mct=True, part1=not ht)
+    blocks, _ = G.tile_layout(p)
+    rows, data = J.decode_table(info, blocks, not ht)
+    table = np.array(rows, dtype=G.capi.CODED_DTYPE)
+    c = U.ctx()
+    c.set_decode_qcd([(e << 11) | m for e, m in info["qcd"]] if irrev else [])
+    try:
+        for (x0, y0, x1, y1) in ((0, 0, 100, 100), (131, 77, 390, 300), (500, 380, 512, 384)):
+            got = c.decode_region_host(p, table, data, x0, y0, x1, y1).astype(np.int32)
+            assert np.array_equal(got, R.decode_window(cs, 3, x0, y0, x1, y1)), (x0, y0, x1, y1)
+    finally:
+        c.set_decode_qcd([])
