@@ -11,7 +11,7 @@ Units and corrections (same guide):
   * WRITE_SIZE needs no correction: ingest_kernel writes 805,306,368 B and reports 786,432.0 KiB exactly.
 
 Kernel families are reported PER STEP (one encode_tiles / decode_tiles call): a family may be several
-launches (DWT levels, the two Kmax classes of the HT encoder); steps are counted by the one-per-step
+launches (DWT levels, the classes of the HT encoder; the last inverse DWT level carries K7 when fused); steps are counted by the one-per-step
 kernels ht_alloc_init_kernel (encode) and ht_dec_vlc_kernel / t1_dec_kernel (decode).
 
 usage: summarize_pmc.py fetch_counter_collection.csv write_counter_collection.csv out.json
@@ -21,24 +21,23 @@ import csv
 import json
 import sys
 
-FAMILIES = [  # (family, substring(s) of the kernel name)
-    ("dwt_level0_fused", ("dwt_level_kernel<false, 3, 1>", "dwt_level_kernel<true, 3, 1>", "dwt_level_kernel<false, 3, 2>",
-                          "dwt_level_kernel<true, 3, 2>", "dwt_level_kernel<false, 1, 1>", "dwt_level_kernel<true, 1, 1>",
-                          "dwt_level_kernel<false, 1, 2>", "dwt_level_kernel<true, 1, 2>")),
-    ("dwt_levels_1plus", ("dwt_level_kernel<false, 1, 0>", "dwt_level_kernel<true, 1, 0>")),
-    ("ht_encode_kernel", ("ht_encode_kernel",)),
-    ("ht_dec_vlc_kernel", ("ht_dec_vlc_kernel",)),
-    ("ht_dec_ms_kernel", ("ht_dec_ms_kernel",)),
-    ("t1_dec_kernel", ("t1_dec_kernel",)),
-    ("idwt_level_kernel", ("idwt_level_kernel",)),
-    ("egress_kernel", ("egress_kernel",)),
-    ("ingest_kernel", ("ingest_kernel",)),
+FAMILIES = [  # (family, test on the kernel name); the inverse kernels first: "idwt_level_kernel" contains "dwt_level_kernel"
+    ("idwt_last_level_fused", lambda n: "idwt_level_kernel<" in n and not n.split("idwt_level_kernel<")[1].startswith(("false, 1, 0", "true, 1, 0"))),
+    ("idwt_level_kernel", lambda n: "idwt_level_kernel<" in n),
+    ("dwt_levels_1plus", lambda n: "dwt_level_kernel<false, 1, 0" in n or "dwt_level_kernel<true, 1, 0" in n),
+    ("dwt_level0_fused", lambda n: "dwt_level_kernel<" in n),
+    ("ht_encode_kernel", lambda n: "ht_encode_kernel" in n),
+    ("ht_dec_vlc_kernel", lambda n: "ht_dec_vlc_kernel" in n),
+    ("ht_dec_ms_kernel", lambda n: "ht_dec_ms_kernel" in n),
+    ("t1_dec_kernel", lambda n: "t1_dec_kernel" in n),
+    ("egress_kernel", lambda n: "egress_kernel" in n),
+    ("ingest_kernel", lambda n: "ingest_kernel" in n),
 ]
 
 
 def family(name):
-    for fam, subs in FAMILIES:
-        if any(s in name for s in subs):
+    for fam, test in FAMILIES:
+        if test(name):
             return fam
     return None
 
