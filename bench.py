@@ -186,6 +186,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # a sequence of frames: consecutive encodes are pipelined (the next frame's DWT runs while this one's blocks are still
+    # being coded; each encode works in its own buffer set and is complete when the timed region ends).  Not with N > 1:
+    # there every step ends with an exchange that reads this step's results.
+    pipelined = not use_dist and not args.no_overlap
+    ctx.set_pipelining(pipelined)
     for _ in range(args.warmup):
         step()
     sync()
@@ -195,6 +200,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
+    ctx.set_pipelining(False)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -337,6 +343,13 @@ def main():
     kernels = {k: {"avg_ms": round(v[0], 4), "launches": v[1],
                    "algorithmic_GBps": round(algo[k] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
                for k, v in fam.items()}
+    if not use_dist:
+        parallelism = "1 GPU, consecutive encodes pipelined (grk_amd_set_pipelining)" if pipelined else "1 GPU"
+    elif args.exchange == "offsets":
+        parallelism = ("tile-sharded x%d, per step all_gather of the coded byte counts (RCCL): every rank learns its "
+                       "tile-parts' offsets in the codestream, the bytes stay on their GPU" % world)
+    else:
+        parallelism = "tile-sharded x%d, coded tile-parts gathered on rank 0 every step (RCCL)" % world
     kernels_overlapped = {k: {"avg_ms": round(v[0], 4), "launches": v[1]} for k, v in fam_overlapped.items()}
     # whole-pipeline figure of SURVEY.md §8(d) (unfused definition, kept so that rounds compare)
     pipeline_bytes = samples * (b_in + 4) + 8.0 * samples * sigma(levels) + algo["ht_cleanup_encode"]
@@ -351,11 +364,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if irrev else "int32", "data": "synthetic",
             "config": {"workload": desc, "tiles_per_gpu": ntiles, "code_blocks_per_gpu": int(nblocks),
                        "coded_bytes_per_gpu": int(total), "generator": "G2 (SURVEY.md §8d)",
-                       "parallelism": ("tile-sharded x%d, per step all_gather of the coded byte counts (RCCL): every rank "
-                                       "learns its tile-parts' offsets in the codestream, the bytes stay on their GPU" % world)
-                       if args.exchange == "offsets" else
-                       "tile-sharded x%d, coded tile-parts gathered on rank 0 every step (RCCL)" % world
-                       if use_dist else "1 GPU"},
+                       "parallelism": parallelism},
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_step": int(pipeline_bytes),
                          "achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),

@@ -93,6 +93,7 @@ def lib():
         L.grk_amd_set_decode_steps.argtypes = [vp, vp, u32]
         L.grk_amd_decode_region.argtypes = [vp, PP, vp, vp, u64, i32, u32, u32, u32, u32, vp, i32]
         L.grk_amd_set_overlap.argtypes = [vp, i32]
+        L.grk_amd_set_pipelining.argtypes = [vp, i32]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
         L.grk_amd_kernel_ms.restype = C.c_double
@@ -257,6 +258,9 @@ class Context:
         """Band step sizes as the host's decoder holds them, [comp][band] (None / empty: back to the QCD words)."""
         a = np.ascontiguousarray(steps if steps is not None else [], np.float32).reshape(-1)
         self._check(self._L.grk_amd_set_decode_steps(self._h, a.ctypes.data if a.size else None, a.size), "set_decode_steps")
+
+    def set_pipelining(self, on):
+        self._check(self._L.grk_amd_set_pipelining(self._h, int(bool(on))), "set_pipelining")
 
     def set_overlap(self, on):
         self._check(self._L.grk_amd_set_overlap(self._h, int(bool(on))), "set_overlap")

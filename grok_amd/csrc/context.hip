@@ -68,6 +68,11 @@ struct grk_amd_ctx {
     hipStream_t side = nullptr;                             // K3 of the top resolution runs here beside DWT levels >= 1
     hipEvent_t ev_level0 = nullptr, ev_side = nullptr;
     bool overlap = false;
+    // Pipelining of consecutive encodes (grk_amd_set_pipelining): a second set of per-encode buffers, so that the next
+    // encode's DWT can start while the side streams still code the blocks of this one
+    struct AltSet { DevBuf p1, arena, lengths, offsets, flag; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alt;
+    bool pipelining = false;
+    bool side_pending = false;       // side-stream work of the latest encode has not been joined on the main stream yet
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
     bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
     DevBuf ht_sel;
@@ -248,6 +253,16 @@ int run_ingest(grk_amd_ctx* c, uint32_t ntiles, const void* d_pixels, void* d_pl
 // d_pixels != nullptr: level 0 reads the caller's pixels directly (K1 fused into K2), d_in is unused
 HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* rc, bool h16 = false);
 
+// everything that reads or overwrites the results of the latest encode on the main stream comes after its side streams
+int join_side(grk_amd_ctx* c)
+{
+    if (!c->side_pending) return GRK_AMD_OK;
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0), "join side stream");
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side2, 0), "join side stream 2");
+    c->side_pending = false;
+    return GRK_AMD_OK;
+}
+
 // 16-bit planes are safe when no coefficient of any level can leave int16.  Bound (5/3, L1 norms of the analysis
 // filters: low-pass 1.5, high-pass 2 per dimension; RCT chroma is one bit wider than the pixels): the LL of level l is
 // below M * 2.25^l, a detail band of level l below 4 * M * 2.25^(l-1), with M = 2^prec the largest input magnitude.
@@ -319,7 +334,10 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
                 hipStream_t st = nullptr;
                 if (l == 0 && top) st = big ? c->side2 : c->side;
                 if (l + 1 == L && !top && big) st = c->side2;
-                if (L == 1 && !top && !big) st = nullptr;          // (run_ht launches it on the main stream)
+                // the rest: on the main stream (run_ht) beside the tail of the top resolution -- unless consecutive encodes
+                // are pipelined: then the main stream carries nothing but the DWT chain, so that the next encode's level 0
+                // starts as early as possible, and every K3 launch queues on the side streams
+                if (l + 1 == L && !top && !big && c->pipelining) st = c->side;
                 if (!st) continue;
                 HIP_TRY(c, hipStreamWaitEvent(st, c->ev_level0, 0), "side stream waits for the level");
                 ScopedTimer tt(c, st == c->side ? 4 : 8, st);
@@ -554,13 +572,13 @@ int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, bool overlappe
             HIP_TRY(c, launch_ht_alloc_init(a, c->stream), "reset arena allocator");
             HIP_TRY(c, launch_ht_classes(a, 0, a.num_classes, c->stream), "launch ht encode");
         } else {
-            for (uint32_t k = 0; k < a.num_classes; ++k)
+            for (uint32_t k = 0; k < a.num_classes && !c->pipelining; ++k)
                 if (!c->ht_class_top[k] && !c->ht_class_big[k]) HIP_TRY(c, launch_ht_classes(a, k, k + 1, c->stream), "launch ht encode");
         }
     }
     if (overlapped) {
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0), "join side stream");
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side2, 0), "join side stream 2");
+        c->side_pending = true;
+        if (!c->pipelining) { const int jr = join_side(c); if (jr) return jr; }    // pipelining: the next consumer joins
     }
     c->last_ntiles = ntiles;
     c->last_nblocks = (uint64_t)c->geom.blocks_per_comp * c->geom.p.num_comps * ntiles;
@@ -595,6 +613,8 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
             hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->alt.ev_side, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->alt.ev_side2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_level0, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) {
             c->side = nullptr; c->overlap = false;
@@ -618,6 +638,9 @@ void grk_amd_destroy(grk_amd_ctx* c)
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
+    if (c->alt.ev_side) (void)hipEventDestroy(c->alt.ev_side);
+    if (c->alt.ev_side2) (void)hipEventDestroy(c->alt.ev_side2);
+    for (DevBuf* b : {&c->alt.p1, &c->alt.arena, &c->alt.lengths, &c->alt.offsets, &c->alt.flag}) b->release();
     if (c->ev_level0) (void)hipEventDestroy(c->ev_level0);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     for (DevBuf* b : {&c->dec_seg_dev}) b->release();
@@ -678,6 +701,7 @@ int grk_amd_stage_ingest_mct(grk_amd_ctx* c, const grk_amd_tile_params* p, uint3
 
 int grk_amd_stage_dwt_fwd(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nplanes, void* d_in, void* d_out)
 {
+    if (c) { const int jr = join_side(c); if (jr) return jr; }
     if (!c || !p || !d_in || !d_out) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = ensure_geom(c, p); if (rc) return rc;
@@ -686,6 +710,7 @@ int grk_amd_stage_dwt_fwd(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t
 
 int grk_amd_stage_ht_encode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const void* d_mallat)
 {
+    if (c) { const int jr = join_side(c); if (jr) return jr; }
     if (!c || !p || !d_mallat) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = ensure_geom(c, p); if (rc) return rc;
@@ -694,6 +719,7 @@ int grk_amd_stage_ht_encode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32
 
 int grk_amd_stage_dwt_inv(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nplanes, const void* d_mallat, void* d_out)
 {
+    if (c) { const int jr = join_side(c); if (jr) return jr; }
     if (!c || !p || !d_mallat || !d_out) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = ensure_geom(c, p); if (rc) return rc;
@@ -703,6 +729,7 @@ int grk_amd_stage_dwt_inv(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t
 int grk_amd_stage_ht_decode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
                             const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes, void* d_mallat)
 {
+    if (c) { const int jr = join_side(c); if (jr) return jr; }
     if (!c || !p || !table || !d_coded || !d_mallat || ntiles == 0) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = ensure_geom(c, p); if (rc) return rc;
@@ -718,7 +745,8 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
 {
     if (!c || !p || !table || !coded || !pixels || ntiles == 0) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
-    int rc = ensure_geom(c, p); if (rc) return rc;
+    int rc = join_side(c); if (rc) return rc;        // (the Mallat planes and the status word are shared with the encoder)
+    rc = ensure_geom(c, p); if (rc) return rc;
     const TileGeom& g = c->geom;
     const uint32_t nplanes = ntiles * g.p.num_comps;
     const uint32_t bps = (g.p.prec + 7u) / 8u;
@@ -842,6 +870,7 @@ int grk_amd_fetch_table(grk_amd_ctx* c, grk_amd_coded_block* table, uint64_t* to
 {
     if (!c || !c->last_nblocks) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
+    { const int jr = join_side(c); if (jr) return jr; }
     const uint64_t n = c->last_nblocks;
     uint64_t flagwords[2] = {0, 0};       // [0] low 32 bits: overflow flag, [1]: arena cursor
     HIP_TRY(c, hipMemcpyAsync(flagwords, c->flag.p, 16, hipMemcpyDeviceToHost, c->stream), "fetch flag");
@@ -869,6 +898,7 @@ int grk_amd_fetch_coded(grk_amd_ctx* c, uint8_t* dst, uint64_t nbytes)
     if (!c || !dst) return GRK_AMD_ERR_INVALID;
     if (nbytes > c->arena.cap) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
+    { const int jr = join_side(c); if (jr) return jr; }
     HIP_TRY(c, hipMemcpyAsync(dst, c->arena.p, nbytes, hipMemcpyDeviceToHost, c->stream), "fetch coded");
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     return GRK_AMD_OK;
@@ -890,7 +920,10 @@ void* grk_amd_plane_device_ptr(grk_amd_ctx* c, int which) { return c ? (which ? 
 int grk_amd_synchronize(grk_amd_ctx* c)
 {
     if (!c) return GRK_AMD_ERR_INVALID;
+    { const int jr = join_side(c); if (jr) return jr; }
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    if (c->side) HIP_TRY(c, hipStreamSynchronize(c->side), "sync side stream");        // (a pipelined predecessor)
+    if (c->side2) HIP_TRY(c, hipStreamSynchronize(c->side2), "sync side stream 2");
     return GRK_AMD_OK;
 }
 
@@ -917,6 +950,20 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     {
         ScopedTimer t(c, 3);
         const bool ov = c->overlap && g.p.num_levels >= 1 && c->side != nullptr;
+        if (ov && c->pipelining) {
+            // take the other buffer set: the blocks of the previous encode may still be being coded from the set used
+            // last; the set taken now was last used two encodes ago, and its side-stream work is waited for here
+            // (hipStreamWaitEvent on an event never recorded is a no-op)
+            std::swap(c->p1, c->alt.p1); std::swap(c->arena, c->alt.arena); std::swap(c->lengths, c->alt.lengths);
+            std::swap(c->offsets, c->alt.offsets); std::swap(c->flag, c->alt.flag);
+            std::swap(c->ev_side, c->alt.ev_side); std::swap(c->ev_side2, c->alt.ev_side2);
+            c->side_pending = false;
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0), "wait for the buffer set");
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side2, 0), "wait for the buffer set");
+            HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
+        } else {
+            rc = join_side(c); if (rc) return rc;
+        }
         // 8-bit reversible content: int16 LL / Mallat planes between K2 and K3 (half the bytes written and read back);
         // needs the fused level 0 (the stand-alone ingest kernel writes int32 planes)
         const bool h16 = c->planes16 && fused && planes16_ok(g.p);
@@ -938,10 +985,18 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     return GRK_AMD_OK;
 }
 
+int grk_amd_set_pipelining(grk_amd_ctx* c, int on)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    const int rc = grk_amd_synchronize(c);
+    c->pipelining = on != 0 && c->side != nullptr && c->side2 != nullptr;
+    return rc;
+}
+
 int grk_amd_set_overlap(grk_amd_ctx* c, int on)
 {
     if (!c) return GRK_AMD_ERR_INVALID;
-    (void)hipStreamSynchronize(c->stream);
+    (void)grk_amd_synchronize(c);
     c->overlap = on != 0 && c->side != nullptr && c->side2 != nullptr;
     return GRK_AMD_OK;
 }

@@ -212,6 +212,13 @@ int    grk_amd_enable_timing(grk_amd_ctx* ctx, int on);
  * sets the default).  Off = every kernel alone on the GPU, one after the other: what per-kernel durations
  * (roofline figures, rocprofv3 summaries) should be measured with, since co-running kernels stretch each other. */
 int    grk_amd_set_overlap(grk_amd_ctx* ctx, int on);
+/* Pipelining of consecutive grk_amd_encode_tiles calls (a sequence of frames; default off): the per-encode buffers
+ * (Mallat planes, coded arena, block table, allocator state) exist twice and the call returns without joining its side
+ * streams, so the next call's DWT runs while the blocks of this one are still being coded.  The results of a call stay
+ * valid until the second next call.  Every grk_amd_* function that reads them (fetch_table, fetch_coded, synchronize,
+ * decode, the stage entry points) joins first; a caller that consumes grk_amd_coded_device_ptr / _table_device_ptr on
+ * its own stream must call grk_amd_synchronize before.  Needs the overlap (above) to be on. */
+int    grk_amd_set_pipelining(grk_amd_ctx* ctx, int on);
 double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
 
 /* ---- codestream assembly (host) ----------------------------------

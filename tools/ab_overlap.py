@@ -11,6 +11,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     px = synth.g2(3, H, W, 8)
     p = G.TileParams.make(W, H, 3, 8, 5)
     ctx = G.Context(0)
+    ctx.set_pipelining(os.environ.get("AB_PIPE") == "1")
     d = torch.from_numpy(px.reshape(-1)).cuda()
     for _ in range(5): ctx.encode_tiles(p, 1, d.data_ptr(), True, fetch=False)
     ctx.synchronize(); torch.cuda.synchronize()
@@ -18,15 +19,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     n = 40
     for _ in range(n): ctx.encode_tiles(p, 1, d.data_ptr(), True, fetch=False)
     ctx.synchronize()
-    print(os.path.basename(os.path.dirname(os.environ.get("AB_LIB", "x/current/l"))), "overlap", os.environ.get("GRK_AMD_OVERLAP"), "ms/step %.4f" % ((time.perf_counter() - t0) / n * 1e3))
+    print(os.path.basename(os.path.dirname(os.environ.get("AB_LIB", "x/current/l"))), "pipe", os.environ.get("AB_PIPE"), "overlap", os.environ.get("GRK_AMD_OVERLAP"), "ms/step %.4f" % ((time.perf_counter() - t0) / n * 1e3))
 else:
-    variants = [("", "0"), ("", "1")]
+    variants = [("", "0", "0"), ("", "1", "0"), ("", "1", "1")]
     d = os.path.join(ROOT, "build", "abl")
     if os.path.isdir(d):
-        variants = [(os.path.join(d, n, "libgrok_amd.so"), "0") for n in sorted(os.listdir(d))] + variants
+        variants = [(os.path.join(d, n, "libgrok_amd.so"), "0", "0") for n in sorted(os.listdir(d))] + variants
     for rep in range(2):
-        for lib, ov in variants:
-            env = dict(os.environ, GRK_AMD_OVERLAP=ov)
+        for lib, ov, pipe in variants:
+            env = dict(os.environ, GRK_AMD_OVERLAP=ov, AB_PIPE=pipe)
             if lib: env["AB_LIB"] = lib
             r = subprocess.run([sys.executable, __file__, "--one"], capture_output=True, text=True, env=env)
             print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:])
