@@ -336,8 +336,8 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
                 if (l + 1 == L && !top && big) st = c->side2;
                 // the rest: on the main stream (run_ht) beside the tail of the top resolution -- unless consecutive encodes
                 // are pipelined: then the main stream carries nothing but the DWT chain, so that the next encode's level 0
-                // starts as early as possible, and every K3 launch queues on the side streams
-                if (l + 1 == L && !top && !big && c->pipelining) st = c->side;
+                // starts as early as possible, and every K3 launch queues on a side stream
+                if (l + 1 == L && !top && !big && c->pipelining) st = c->side2;    // (its tail then overlaps the top class's)
                 if (!st) continue;
                 HIP_TRY(c, hipStreamWaitEvent(st, c->ev_level0, 0), "side stream waits for the level");
                 ScopedTimer tt(c, st == c->side ? 4 : 8, st);

@@ -19,15 +19,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     n = 40
     for _ in range(n): ctx.encode_tiles(p, 1, d.data_ptr(), True, fetch=False)
     ctx.synchronize()
-    print(os.path.basename(os.path.dirname(os.environ.get("AB_LIB", "x/current/l"))), "pipe", os.environ.get("AB_PIPE"), "overlap", os.environ.get("GRK_AMD_OVERLAP"), "ms/step %.4f" % ((time.perf_counter() - t0) / n * 1e3))
+    print(os.path.basename(os.path.dirname(os.environ.get("AB_LIB", "x/current/l"))), "pipe", os.environ.get("AB_PIPE"), "rest2", os.environ.get("GRK_AMD_REST_SIDE2"), "overlap", os.environ.get("GRK_AMD_OVERLAP"), "ms/step %.4f" % ((time.perf_counter() - t0) / n * 1e3))
 else:
-    variants = [("", "0", "0"), ("", "1", "0"), ("", "1", "1")]
+    variants = [("", "1", "1"), ("", "1", "2")]
     d = os.path.join(ROOT, "build", "abl")
     if os.path.isdir(d):
         variants = [(os.path.join(d, n, "libgrok_amd.so"), "0", "0") for n in sorted(os.listdir(d))] + variants
     for rep in range(2):
         for lib, ov, pipe in variants:
-            env = dict(os.environ, GRK_AMD_OVERLAP=ov, AB_PIPE=pipe)
+            env = dict(os.environ, GRK_AMD_OVERLAP=ov, AB_PIPE="1" if pipe != "0" else "0")
+            if pipe == "2": env["GRK_AMD_REST_SIDE2"] = "1"
             if lib: env["AB_LIB"] = lib
             r = subprocess.run([sys.executable, __file__, "--one"], capture_output=True, text=True, env=env)
             print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:])
