@@ -70,7 +70,9 @@ struct grk_amd_ctx {
     bool overlap = false;
     // Pipelining of consecutive encodes (grk_amd_set_pipelining): a second set of per-encode buffers, so that the next
     // encode's DWT can start while the side streams still code the blocks of this one
-    struct AltSet { DevBuf p1, arena, lengths, offsets, flag; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alt;
+    struct AltSet { DevBuf p1, arena, lengths, offsets, flag, ovf; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alt;
+    DevBuf ovf;                      // K3: blocks handed to the fallback launch (kernels.h: HtArgs::ovf_list)
+    bool lds_cap = true;             // K3 with capped LDS buffers + fallback launch (GRK_AMD_LDS_CAP=0: worst-case buffers)
     bool pipelining = false;
     bool side_pending = false;       // side-stream work of the latest encode has not been joined on the main stream yet
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
@@ -146,7 +148,7 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
         std::vector<uint8_t> ctop, cbig;
         for (int top = 1; top >= 0; --top)
             for (int big = 0; big < 2; ++big) {
-                HtClass cl{nullptr, 0, 0, 0, 0};
+                HtClass cl{nullptr, 0, 0, 0, 0, 0};
                 const size_t at = sel.size();
                 for (uint32_t i = 0; i < c->h_desc.size(); ++i) {
                     if ((int)(h_res[i] == g.p.num_levels && g.p.num_levels >= 1) != top) continue;
@@ -553,10 +555,17 @@ HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* 
     a.arena = (uint8_t*)c->arena.p; a.arena_bytes = c->arena.cap;
     a.alloc = (unsigned long long*)c->flag.p;        // [0] status flags, [1] bytes used (launch_ht_alloc_init resets them)
     a.lengths = (uint32_t*)c->lengths.p; a.offsets = (unsigned long long*)c->offsets.p;
+    try_(c->ovf.ensure(nblocks * 4 + 16), "alloc fallback list");
+    a.ovf_list = c->lds_cap ? (uint32_t*)c->ovf.p : nullptr;
     a.region_mask = regions - 1;
     a.irreversible = g.p.irreversible;
     a.num_classes = c->ht_num_classes;
-    for (uint32_t k = 0; k < c->ht_num_classes; ++k) a.classes[k] = c->ht_classes[k];
+    uint32_t ovf_base = 0;
+    for (uint32_t k = 0; k < c->ht_num_classes; ++k) {
+        a.classes[k] = c->ht_classes[k];
+        a.classes[k].ovf_base = ovf_base;
+        ovf_base += c->ht_classes[k].count * ntiles;
+    }
     return a;
 }
 
@@ -608,6 +617,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (const char* e16 = getenv("GRK_AMD_PLANES16")) c->planes16 = atoi(e16) != 0;
         if (const char* ef = getenv("GRK_AMD_FUSE_EGRESS")) c->fuse_egress = atoi(ef) != 0;
+        if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
@@ -640,7 +650,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
     if (c->alt.ev_side) (void)hipEventDestroy(c->alt.ev_side);
     if (c->alt.ev_side2) (void)hipEventDestroy(c->alt.ev_side2);
-    for (DevBuf* b : {&c->alt.p1, &c->alt.arena, &c->alt.lengths, &c->alt.offsets, &c->alt.flag}) b->release();
+    for (DevBuf* b : {&c->alt.p1, &c->alt.arena, &c->alt.lengths, &c->alt.offsets, &c->alt.flag, &c->alt.ovf, &c->ovf}) b->release();
     if (c->ev_level0) (void)hipEventDestroy(c->ev_level0);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     for (DevBuf* b : {&c->dec_seg_dev}) b->release();
@@ -912,6 +922,7 @@ void* grk_amd_table_device_ptr(grk_amd_ctx* c, int which)
     case 0: return c->offsets.p;                                    // uint64[nblocks]
     case 1: return c->lengths.p;                                    // uint32[nblocks]
     case 2: return c->flag.p ? (uint8_t*)c->flag.p + 8 : nullptr;   // uint64: bytes used in the arena
+    case 3: return c->flag.p ? (uint8_t*)c->flag.p + 16 : nullptr;  // uint64[24]: blocks each K3 class handed to its fallback launch
     default: return nullptr;
     }
 }
@@ -955,7 +966,7 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             // last; the set taken now was last used two encodes ago, and its side-stream work is waited for here
             // (hipStreamWaitEvent on an event never recorded is a no-op)
             std::swap(c->p1, c->alt.p1); std::swap(c->arena, c->alt.arena); std::swap(c->lengths, c->alt.lengths);
-            std::swap(c->offsets, c->alt.offsets); std::swap(c->flag, c->alt.flag);
+            std::swap(c->offsets, c->alt.offsets); std::swap(c->flag, c->alt.flag); std::swap(c->ovf, c->alt.ovf);
             std::swap(c->ev_side, c->alt.ev_side); std::swap(c->ev_side2, c->alt.ev_side2);
             c->side_pending = false;
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0), "wait for the buffer set");

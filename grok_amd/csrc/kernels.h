@@ -55,6 +55,7 @@ struct HtClass {
     const uint32_t* sel;      // device: indices (within a tile) of the blocks of this class; nullptr = all blocks in order
     uint32_t count;
     uint32_t max_kmax, max_samples, max_quads;   // extents that size the class's LDS buffers
+    uint32_t ovf_base;        // first entry of the class's part of HtArgs::ovf_list
 };
 struct HtArgs {
     const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp] (stride, pitch in elements)
@@ -66,6 +67,9 @@ struct HtArgs {
     uint32_t* lengths;                          // [ntiles*blocks_per_tile]
     unsigned long long* offsets;                // [ntiles*blocks_per_tile]
     const uint32_t* sel; uint32_t sel_count;    // set per launch by launch_ht_encode from `classes`
+    uint32_t* ovf_list; uint32_t ovf_base;      // [ntiles * blocks_per_tile] blocks whose raw streams outgrew the capped LDS
+                                                // buffers (per class from ovf_base; count in alloc[2 + class]): coded again
+                                                // by the fallback launch.  nullptr: worst-case buffers, no fallback
     HtClass classes[kHtMaxClasses]; uint32_t num_classes;   // block classes of a tile (= resolutions, finest first), each launched on its own
     uint32_t region_mask;         // (power of two <= kHtAllocRegions) - 1: block i allocates from region i & mask
     int irreversible;

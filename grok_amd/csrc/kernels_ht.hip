@@ -210,7 +210,7 @@ constexpr uint32_t kChunkUnits = kHtAllocChunk / 16u;
 __global__ void ht_alloc_init_kernel(unsigned long long* flagbuf)
 {
     const uint32_t t = threadIdx.x;
-    if (t < 2) flagbuf[t] = 0;                                  // [0] status flags, [1] cursor (bytes)
+    if (t < 32) flagbuf[t] = 0;                                 // [0] status flags, [1] cursor (bytes), [2 + class] blocks handed to the fallback launch
     // "chunk full" so that the first allocation refills; the start field holds a value no real chunk
     // has, otherwise waves waiting for the refill could not tell the first chunk (start 0) from this state
     if (t < kAllocRegions) flagbuf[32 * (1 + t)] = (0xFFFFFFFFFFull << 24) | kChunkUnits;
@@ -235,10 +235,16 @@ __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* fl
     }
 }
 
+// LDS words of the two raw streams, the two bitmaps, and what the raw streams may hold (bits) before the block is
+// handed to the fallback launch
+struct HtLds { uint32_t ms_words, vlc_words, mark_words, vmark_words, ms_cap_bits, vlc_cap_bits; };
+
+// One code-block, by one wavefront.  li = index of the block in the launch's class list, tile = tile index.
 // H16: the Mallat planes hold int16 coefficients (reversible, 8-bit pixels; kernels_dwt.hip H16)
-template <bool IRREV, bool H16 = false>
-__global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_words, uint32_t vlc_words, uint32_t mark_words, uint32_t vmark_words)
+template <bool IRREV, bool H16>
+__device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, uint32_t tile, const HtLds& L, uint32_t class_id)
 {
+    const uint32_t ms_words = L.ms_words, vlc_words = L.vlc_words, mark_words = L.mark_words, vmark_words = L.vmark_words;
     // LDS (kept under 10 KiB for 8-bit content so that 16 waves fit a CU): raw MagSgn bits | raw VLC bits |
     // 7-bit-byte bitmaps (phase B) aliased with the UVLC table (phase A) | MEL bytes
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -251,8 +257,6 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
 
     const int lane = threadIdx.x;
     // this launch covers the blocks sel[0..sel_count) of every tile (all blocks when sel == nullptr)
-    const uint32_t li = blockIdx.x % a.sel_count;
-    const uint32_t tile = blockIdx.x / a.sel_count;
     const uint32_t lb = a.sel ? a.sel[li] : li;
     const uint32_t gid = tile * a.blocks_per_tile + lb;
     const HtBlockDesc bd = a.blocks[lb];
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
 
     MelState mel{0, 0, 0, 8, 0};
     uint32_t ms_bits = 0, vlc_bits = 4;
+    bool lds_full = false;
     uint32_t Bprev = 0xFFFFFFFFu;                // "all insignificant" row above the block
     uint32_t ovf = 0;
     const uint32_t qx = lane & 31, half = lane >> 5;
@@ -455,6 +460,11 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
         ms_bits += tot & 0xFFFFu;
         vlc_bits += tot >> 16;
 
+        // The raw streams have room for what real content needs, not for the worst case (the LDS per wave is what limits
+        // the occupancy: 16 -> 24 waves per CU is 15-18 % of this kernel): a block that outgrows them stops writing and is
+        // coded again by the fallback launch with worst-case buffers (wave-uniform test, never taken on natural images).
+        lds_full = lds_full || ms_bits > L.ms_cap_bits || vlc_bits > L.vlc_cap_bits;
+        if (lds_full) return;
         if (narrow) {
             const uint32_t v01 = vm[0] | (vm[1] << m[0]);
             const uint32_t v23 = vm[2] | (vm[3] << m[2]);
@@ -498,6 +508,13 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     }
     };   // phase_a
     if (full) phase_a(std::true_type{}); else phase_a(std::false_type{});
+    if (lds_full) {                       // hand the block to the fallback launch (kernels.h: HtArgs::ovf_list)
+        if (lane == 0) {
+            const unsigned long long at = __hip_atomic_fetch_add(a.alloc + 2 + class_id, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.ovf_list[a.ovf_base + at] = tile * a.sel_count + li;
+        }
+        return;
+    }
     // magnitudes beyond Kmax+1 bits: outside the contract (see header) -> flag, host reports it
     if (!IRREV && __ballot((ovf >> (kmax + 1)) != 0)) {
         if (lane == 0) atomicOr(reinterpret_cast<unsigned int*>(a.alloc), 2u);
@@ -620,6 +637,25 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, uint32_t ms_wor
     }
 }
 
+template <bool IRREV, bool H16>
+__global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, HtLds L, uint32_t class_id)
+{
+    ht_encode_block<IRREV, H16>(a, blockIdx.x % a.sel_count, blockIdx.x / a.sel_count, L, class_id);
+}
+
+// The blocks the launch above handed over (raw streams outgrew their LDS): worst-case buffers, a fixed grid that walks
+// the list.  With nothing on the list -- the normal case -- every workgroup leaves at once.
+template <bool IRREV, bool H16>
+__global__ __launch_bounds__(64) void ht_encode_fallback_kernel(HtArgs a, HtLds L, uint32_t class_id)
+{
+    const uint32_t count = (uint32_t)a.alloc[2 + class_id];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t id = a.ovf_list[a.ovf_base + i];
+        ht_encode_block<IRREV, H16>(a, id % a.sel_count, id / a.sel_count, L, class_id);
+        __syncthreads();
+    }
+}
+
 } // namespace
 
 static bool g_tables_ready[16] = {false};
@@ -651,11 +687,17 @@ static hipError_t upload_tables()
 }
 
 // LDS words of a launch whose largest block has `samples` samples in `quads` quads and exponent kmax
-static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, uint32_t& ms_words, uint32_t& vlc_words,
-                          uint32_t& mark_words, uint32_t& vmark_words, size_t& bytes)
+// capped = false: the worst case (m_n <= U_q <= Kmax + 2 inside the contract; cwd <= 7, UVLC prefix <= 3, suffix <= 5
+// bits per quad).  capped = true: what real content needs with room to spare -- 8 bits per sample on average for
+// 8-bit content (Kmax <= 11), Kmax - 3 beyond; 10 VLC bits per quad.
+static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool capped, uint32_t& ms_words, uint32_t& vlc_words,
+                          uint32_t& mark_words, uint32_t& vmark_words, size_t& bytes, uint32_t* ms_cap = nullptr, uint32_t* vlc_cap = nullptr)
 {
-    const uint32_t ms_bits = samples * (kmax + 2u);                 // m_n <= U_q <= Kmax + 2 inside the contract
-    const uint32_t vlc_bits = quads * 15u + 4u;                     // cwd <= 7, UVLC prefix <= 3, suffix <= 5 bits per quad
+    const uint32_t per_sample = capped ? std::min(kmax + 2u, kmax <= 11u ? 8u : kmax - 3u) : kmax + 2u;
+    const uint32_t ms_bits = samples * per_sample;
+    const uint32_t vlc_bits = quads * (capped ? 10u : 15u) + 4u;
+    if (ms_cap) *ms_cap = ms_bits;
+    if (vlc_cap) *vlc_cap = vlc_bits;
     ms_words = ((ms_bits + 31u) / 32u + 4u + 3u) & ~3u;             // slack: or_bits64 / window reads touch two words beyond;
     vlc_words = ((vlc_bits + 31u) / 32u + 4u + 3u) & ~3u;           // multiples of 4 words: cleared as uint4
     mark_words = ((ms_bits + ms_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;   // one bit per stuffed output byte
@@ -668,7 +710,7 @@ static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, uint3
 size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax)
 {
     uint32_t a, b, c, d; size_t n;
-    ht_lds_layout(samples, quads, kmax, a, b, c, d, n);
+    ht_lds_layout(samples, quads, kmax, false, a, b, c, d, n);
     return n;
 }
 
@@ -702,17 +744,30 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
     for (uint32_t k = first; k < last && k < a.num_classes; ++k) {
         const HtClass& c = a.classes[k];
         if (c.count == 0) continue;
-        uint32_t ms_words, vlc_words, mark_words, vmark_words; size_t shmem;
-        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, ms_words, vlc_words, mark_words, vmark_words, shmem);
+        // capped LDS when that buys occupancy (waves per CU = 160 KiB / LDS per wave, at most 32), else worst-case buffers
+        HtLds full{}, cap{};
+        size_t shmem_full, shmem_cap;
+        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, false, full.ms_words, full.vlc_words, full.mark_words, full.vmark_words,
+                      shmem_full, &full.ms_cap_bits, &full.vlc_cap_bits);
+        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, true, cap.ms_words, cap.vlc_words, cap.mark_words, cap.vmark_words,
+                      shmem_cap, &cap.ms_cap_bits, &cap.vlc_cap_bits);
+        auto waves = [](size_t lds) { return std::min<size_t>(32, (160u << 10) / std::max<size_t>(lds, 1)); };
+        const bool use_cap = a.ovf_list && waves(shmem_cap) > waves(shmem_full);
+        const HtLds& L = use_cap ? cap : full;
+        const size_t shmem = use_cap ? shmem_cap : shmem_full;
         HtArgs b = a;
         b.sel = c.sel; b.sel_count = c.count;
+        b.ovf_base = c.ovf_base;
         const uint32_t grid = c.count * a.ntiles;
-        if (a.irreversible)
-            hipLaunchKernelGGL(ht_encode_kernel<true>, dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
-        else if (a.h16)
-            hipLaunchKernelGGL((ht_encode_kernel<false, true>), dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
-        else
-            hipLaunchKernelGGL(ht_encode_kernel<false>, dim3(grid), dim3(64), shmem, s, b, ms_words, vlc_words, mark_words, vmark_words);
+#define GRK_HT(KERNEL, G, SH, LL)                                                                                                   \
+        do {                                                                                                                        \
+            if (a.irreversible) hipLaunchKernelGGL((KERNEL<true, false>), dim3(G), dim3(64), SH, s, b, LL, k);                   \
+            else if (a.h16)     hipLaunchKernelGGL((KERNEL<false, true>), dim3(G), dim3(64), SH, s, b, LL, k);                    \
+            else                hipLaunchKernelGGL((KERNEL<false, false>), dim3(G), dim3(64), SH, s, b, LL, k);                   \
+        } while (0)
+        GRK_HT(ht_encode_kernel, grid, shmem, L);
+        if (use_cap) GRK_HT(ht_encode_fallback_kernel, std::min<uint32_t>(grid, 4096u), shmem_full, full);
+#undef GRK_HT
     }
     return hipGetLastError();
 }

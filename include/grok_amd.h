@@ -127,7 +127,10 @@ void* grk_amd_plane_device_ptr(grk_amd_ctx* ctx, int which /*0: ingest planes, 1
 /* (after grk_amd_encode_tiles of 8-bit reversible content the Mallat planes hold int16 coefficients -- same strides
  *  and pitches in elements -- unless the environment says GRK_AMD_PLANES16=0; the stage entry points are int32) */
 /* the block table of the last encode where it was produced, for exchanges that never touch the host:
- * which 0: uint64 offsets[nblocks], 1: uint32 lengths[nblocks], 2: uint64 bytes used in the arena */
+ * which 0: uint64 offsets[nblocks], 1: uint32 lengths[nblocks], 2: uint64 bytes used in the arena,
+ * 3: uint64[24] diagnostics -- per block class, how many blocks outgrew the capped LDS buffers of the HT encoder and
+ *    were coded by its fallback launch (0 on natural images; environment GRK_AMD_LDS_CAP=0 gives every block
+ *    worst-case buffers instead) */
 void* grk_amd_table_device_ptr(grk_amd_ctx* ctx, int which);
 int  grk_amd_synchronize(grk_amd_ctx* ctx);
 

@@ -313,3 +313,35 @@ def test_pipelined_encodes_keep_their_results_until_the_second_next_call():
     assert U.split_blocks(t, coded) == want[2]
     c.set_pipelining(False)
     c.close()
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth", "mixed"])
+def test_ht_encoder_lds_cap_and_fallback(kind, monkeypatch):
+    """K3 sizes its LDS streams for what real content needs (occupancy); a block that outgrows them is coded again by
+    the fallback launch with worst-case buffers.  White noise overflows the blocks of the fine sub-bands, a smooth image none, a
+    mixture some: the blocks always equal the oracle's and those of a context with GRK_AMD_LDS_CAP=0."""
+    rng = np.random.default_rng(3)
+    H, W = 512, 768
+    noise = rng.integers(0, 256, size=(3, H, W), dtype=np.uint8)
+    smooth = synth.g2(3, H, W, 8)
+    px = {"noise": noise, "smooth": smooth, "mixed": np.where((np.arange(W) // 128 % 2 == 0)[None, None, :], noise, smooth)}[kind]
+    px = np.ascontiguousarray(px)
+    p = G.TileParams.make(W, H, 3, 8, 5)
+    nb = G.lib().grk_amd_tile_num_blocks(p)
+    got = {}
+    for cap in ("1", "0"):
+        monkeypatch.setenv("GRK_AMD_LDS_CAP", cap)
+        c = G.Context(0)
+        t, coded = c.encode_host(p, px)
+        got[cap] = U.split_blocks(t, coded)
+        handed = int(_dev_view(c.table_device_ptr(3), 24, "<i8").cpu().sum())
+        if cap == "0" or kind == "smooth":
+            assert handed == 0
+        elif kind == "noise":
+            assert handed > nb // 8
+        else:
+            assert 0 < handed < nb
+        c.close()
+    assert got["1"] == got["0"]
+    _, _, _, otable, ocoded = chain.encode_tile_oracle(px, 8, 5)
+    assert got["1"] == [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
