@@ -157,6 +157,9 @@ def main():
     arena_cap = int(raw_bytes * 2)          # grk_amd allocates >= 2 x raw (context.hip: run_ht)
 
     counts = my_off = None
+    counts_buf = [None, None]
+    nstep = [0]
+    comm = torch.cuda.Stream(device=dev)
 
     def gather_parts():
         nonlocal scratch, last_parts
@@ -170,15 +173,20 @@ def main():
         nonlocal counts, my_off
         with torch.cuda.stream(stream):
             ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
-            if use_dist:
-                # the path's one real exchange, enqueued behind the encode on this stream (RCCL over xGMI)
+            if use_dist and args.exchange == "offsets":
+                # the path's one real exchange (RCCL over xGMI), parallel-writer design: byte counts only; every rank
+                # learns its tile-parts' place in the codestream.  It runs on its own stream, which waits for this
+                # encode's results, so that the context's stream is free for the next frame (pipelining)
                 used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
-                if args.exchange == "offsets":
-                    # parallel writer: byte counts only; every rank learns its tile-parts' place in the codestream
-                    counts, my_off = D.exchange_tile_part_offsets(used, counts)
-                else:
-                    # funnel: every coded tile-part to rank 0, straight from the encoder's device table and arena
-                    gather_parts()
+                ctx.stream_wait_results(comm.cuda_stream)
+                with torch.cuda.stream(comm):
+                    slot = nstep[0] & 1
+                    counts_buf[slot], my_off = D.exchange_tile_part_offsets(used, counts_buf[slot])
+                    counts = counts_buf[slot]
+                nstep[0] += 1
+            elif use_dist:
+                # funnel: every coded tile-part to rank 0, straight from the encoder's device table and arena
+                gather_parts()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -189,7 +197,7 @@ def main():
     # a sequence of frames: consecutive encodes are pipelined (the next frame's DWT runs while this one's blocks are still
     # being coded; each encode works in its own buffer set and is complete when the timed region ends).  Not with N > 1:
     # there every step ends with an exchange that reads this step's results.
-    pipelined = not use_dist and not args.no_overlap
+    pipelined = not args.no_overlap and (not use_dist or args.exchange == "offsets")
     ctx.set_pipelining(pipelined)
     for _ in range(args.warmup):
         step()

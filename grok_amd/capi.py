@@ -94,6 +94,7 @@ def lib():
         L.grk_amd_decode_region.argtypes = [vp, PP, vp, vp, u64, i32, u32, u32, u32, u32, vp, i32]
         L.grk_amd_set_overlap.argtypes = [vp, i32]
         L.grk_amd_set_pipelining.argtypes = [vp, i32]
+        L.grk_amd_stream_wait_results.argtypes = [vp, vp]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
         L.grk_amd_kernel_ms.restype = C.c_double
@@ -258,6 +259,9 @@ class Context:
         """Band step sizes as the host's decoder holds them, [comp][band] (None / empty: back to the QCD words)."""
         a = np.ascontiguousarray(steps if steps is not None else [], np.float32).reshape(-1)
         self._check(self._L.grk_amd_set_decode_steps(self._h, a.ctypes.data if a.size else None, a.size), "set_decode_steps")
+
+    def stream_wait_results(self, hip_stream):
+        self._check(self._L.grk_amd_stream_wait_results(self._h, C.c_void_p(hip_stream)), "stream_wait_results")
 
     def set_pipelining(self, on):
         self._check(self._L.grk_amd_set_pipelining(self._h, int(bool(on))), "set_pipelining")

@@ -74,6 +74,7 @@ struct grk_amd_ctx {
     DevBuf ovf;                      // K3: blocks handed to the fallback launch (kernels.h: HtArgs::ovf_list)
     bool lds_cap = true;             // K3 with capped LDS buffers + fallback launch (GRK_AMD_LDS_CAP=0: worst-case buffers)
     bool pipelining = false;
+    hipEvent_t ev_main = nullptr;
     bool side_pending = false;       // side-stream work of the latest encode has not been joined on the main stream yet
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
     bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
@@ -648,6 +649,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     if (c->alt.ev_side) (void)hipEventDestroy(c->alt.ev_side);
     if (c->alt.ev_side2) (void)hipEventDestroy(c->alt.ev_side2);
     for (DevBuf* b : {&c->alt.p1, &c->alt.arena, &c->alt.lengths, &c->alt.offsets, &c->alt.flag, &c->alt.ovf, &c->ovf}) b->release();
@@ -993,6 +995,20 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         rc = run_ht(c, ntiles, c->p1.p, ov, h16); if (rc) return rc;
     }
     if (table || total) return grk_amd_fetch_table(c, table, total);
+    return GRK_AMD_OK;
+}
+
+int grk_amd_stream_wait_results(grk_amd_ctx* c, void* hip_stream)
+{
+    if (!c || !hip_stream) return GRK_AMD_ERR_INVALID;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (!c->ev_main) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming), "create event");
+    HIP_TRY(c, hipEventRecord(c->ev_main, c->stream), "record main stream");
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_main, 0), "wait for the main stream");
+    if (c->side_pending) {
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_side, 0), "wait for the side stream");
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_side2, 0), "wait for the side stream 2");
+    }
     return GRK_AMD_OK;
 }
 

@@ -222,6 +222,10 @@ int    grk_amd_set_overlap(grk_amd_ctx* ctx, int on);
  * decode, the stage entry points) joins first; a caller that consumes grk_amd_coded_device_ptr / _table_device_ptr on
  * its own stream must call grk_amd_synchronize before.  Needs the overlap (above) to be on. */
 int    grk_amd_set_pipelining(grk_amd_ctx* ctx, int on);
+/* Makes `hip_stream` (the caller's, e.g. the one its RCCL collectives run on) wait for the results of the latest encode
+ * -- the context's stream and, when pipelined, its side streams -- without blocking the context's own stream: the
+ * consumer of grk_amd_coded_device_ptr / grk_amd_table_device_ptr in a pipelined sequence. */
+int    grk_amd_stream_wait_results(grk_amd_ctx* ctx, void* hip_stream);
 double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
 
 /* ---- codestream assembly (host) ----------------------------------
