@@ -6,15 +6,21 @@
 // Here both passes are fused so every sample of the level is read once and written once
 // (8 bytes / sample / level = the algorithmic figure of SURVEY.md §8d):
 //
-//  * a workgroup (256 threads) owns a column strip of 504 output columns (+4 halo columns each
-//    side) and a segment of `seg_pairs` output row pairs; it streams down the rows;
-//  * vertical lifting runs in registers as a recurrence per column (two columns per lane ->
-//    8-byte coalesced loads, 512 B per wave per row); state is 2 (5/3) or 4 (9/7) values, so
-//    there is no vertical halo re-read except the 2..5 warm-up rows at a segment start;
+//  * a workgroup (256 threads) owns a column strip of 448 output columns (224 pairs = 7 cache
+//    lines of every sub-band row, +4 halo columns each side) and a segment of `seg_pairs` output row
+//    pairs; it streams down the rows;
+//  * vertical lifting runs in registers as a recurrence per column (two columns per lane, the
+//    strip's own pairs on lanes 0..223 in order so that row loads start on line boundaries); state
+//    is 2 (5/3) or 4 (9/7) values, so there is no vertical halo re-read except the 2..5 warm-up rows
+//    at a segment start;
 //  * each finished pair of rows (one low, one high) is exchanged through a double-buffered LDS
 //    line (4 KiB) and every lane produces one (low,high) output pair per line with the local
 //    lifting stencil; outputs go straight to the LL ping-pong plane and to the HL/LH/HH slots of
-//    the Mallat plane, 256 B contiguous per wave.
+//    the Mallat plane, whole aligned cache lines per wave;
+//  * level 0 can read the caller's pixels itself (K1 fused: DC shift + RCT/ICT in registers, three
+//    components side by side) and, for 8-bit reversible content, all planes hold int16 (H16);
+//  * interior strips take a single-basic-block FAST instance whose memory operations are all issued
+//    in one place per iteration (see the kernel).
 //
 // Image borders use whole-sample symmetric extension by index mirroring, which reproduces the
 // reference's edge formulas exactly (the mirrored operands are the same numbers; A.3/A.4).

@@ -245,7 +245,7 @@ template <bool IRREV, bool H16>
 __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, uint32_t tile, const HtLds& L, uint32_t class_id)
 {
     const uint32_t ms_words = L.ms_words, vlc_words = L.vlc_words, mark_words = L.mark_words, vmark_words = L.vmark_words;
-    // LDS (kept under 10 KiB for 8-bit content so that 16 waves fit a CU): raw MagSgn bits | raw VLC bits |
+    // LDS (sized by the launch, HtLds: for real content rather than the worst case, so that 24 waves fit a CU): raw MagSgn bits | raw VLC bits |
     // 7-bit-byte bitmaps (phase B) aliased with the UVLC table (phase A) | MEL bytes
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* ms_raw  = smem;

@@ -5,14 +5,18 @@
 // (transform/WaveletReverse.cpp:852-936, :1360-1439), which synthesises all rows horizontally
 // (LL|HL and LH|HH), then all columns vertically, through split windows in memory.  Here both
 // passes are fused, mirroring K2:
-//  * a workgroup (256 threads) owns 504 output columns (252 coefficient pairs + 2 halo pairs each
-//    side) and a segment of `seg_pairs` output row pairs and streams down the rows;
+//  * a workgroup (256 threads) owns 448 output columns (224 coefficient pairs = 7 cache lines of
+//    each sub-band row, + 2 halo pairs each side) and a segment of `seg_pairs` output row pairs and
+//    streams down the rows;
 //  * per row pair it loads one LL, HL, LH and HH row segment (one coefficient per lane and band),
 //    exchanges them through a double-buffered LDS line, and every lane synthesises two adjacent
 //    output columns of the low row and of the high row with the local inverse lifting stencil;
 //  * vertical synthesis runs in registers as a recurrence per column (state 2 values for 5/3,
 //    4 for 9/7) and the finished rows are stored 8 bytes per lane (512 B per wave and row).
 // Every coefficient is read once and every sample written once: 8 bytes/sample/level.
+// The LAST level can write the caller's pixels itself (K7 fused: three MCT components side by side,
+// inverse RCT/ICT + DC shift + clamp in registers), for the whole tile or for a window of it; a
+// region decode launches only the strips x row segments the window depends on.
 //
 // Borders: whole-sample symmetric extension by mirroring the interleaved index (lifting preserves
 // the symmetry, so the extended synthesis equals the reference's edge formulas, :104-184, :990-1060).
