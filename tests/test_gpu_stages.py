@@ -345,3 +345,52 @@ def test_ht_encoder_lds_cap_and_fallback(kind, monkeypatch):
     assert got["1"] == got["0"]
     _, _, _, otable, ocoded = chain.encode_tile_oracle(px, 8, 5)
     assert got["1"] == [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        C = int(rng.choice([1, 3, 3, 4]))
+        W, H = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+        prec = int(rng.choice([8, 8, 10, 12, 16]))
+        L = int(rng.integers(0, 7))
+        irrev = bool(rng.integers(0, 3) == 0)
+        sgnd = bool(rng.integers(0, 4) == 0)
+        mct = C >= 3 and bool(rng.integers(0, 4) != 0)
+        if irrev and not mct and C >= 3:
+            continue                                  # (the reference's irreversible path without MCT scales by 2048: D1)
+        out.append((C, H, W, prec, L, irrev, sgnd, mct))
+    return out
+
+
+@pytest.mark.parametrize("C,H,W,prec,L,irrev,sgnd,mct", _random_cases(24, 20260926) + _random_cases(24, 7))
+def test_random_geometries_encode_and_decode(C, H, W, prec, L, irrev, sgnd, mct):
+    """A seeded sweep over odd sizes, 0..6 levels, 1/3/4 components, 8..16 bits, signed, with and without MCT, 5/3 and
+    9/7: the encoder's blocks == the oracle chain's, and the decoder returns the source (lossless) or what the oracle's
+    decode chain makes of the same blocks (9/7).  Every fast path and its fallback gets exercised by some case:
+    FAST / edge DWT strips, 16-bit planes, fused level 0 / last level, capped LDS, K3 / DWT overlap."""
+    rng = np.random.default_rng(C * 1000003 + H * 1009 + W)
+    u = synth.g2(C, H, W, prec).astype(np.int64)
+    u += rng.integers(-3, 4, size=u.shape)                          # a little texture on top of the ramp
+    u = np.clip(u, 0, (1 << prec) - 1)
+    if sgnd:
+        px = (u - (1 << (prec - 1))).astype(np.int8 if prec <= 8 else np.int16)
+    else:
+        px = u.astype(np.uint8 if prec <= 8 else np.uint16)
+    p, blocks, qcd, otable, ocoded = chain.encode_tile_oracle(px, prec, L, irrev=irrev, mct=mct, sgnd=sgnd)
+    table, coded = U.ctx().encode_host(p, px)
+    got = U.split_blocks(table, coded)
+    want = [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
+    bad = [i for i in range(len(want)) if got[i] != want[i]]
+    assert not bad, "blocks differing from the oracle chain: %s" % bad[:10]
+    try:
+        ref = chain.decode_tile_oracle(p, blocks, qcd, otable, ocoded)
+    except AssertionError:                # near-full-scale content: the reference's decoder rejects U_q > missing_msbs (D5)
+        with pytest.raises(RuntimeError):
+            U.ctx().decode_host(p, table, coded)
+        return
+    back = U.ctx().decode_host(p, table, coded)[0]
+    assert np.array_equal(back.view(px.dtype).astype(np.int32), ref.astype(np.int32))
+    if not irrev:
+        assert np.array_equal(back.view(px.dtype), px)
