@@ -448,7 +448,11 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
     uint32_t max_len = 0;
-    for (uint64_t i = 0; i < nblocks; ++i) max_len = std::max(max_len, table[i].length);
+    for (uint64_t i = 0; i < nblocks; ++i) {
+        max_len = std::max(max_len, table[i].length);
+        if (table[i].offset > coded_bytes || table[i].length > coded_bytes - table[i].offset)
+            return fail(c, GRK_AMD_ERR_INVALID, "block table row points outside the coded buffer");
+    }
     if (max_len > (48u << 10)) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "code-block longer than 48 KiB");
     static_assert(sizeof(HtDecBlock) == sizeof(grk_amd_coded_block), "decode table rows are grk_amd_coded_block");
     HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
@@ -476,6 +480,9 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
     const uint32_t L = t1_lanes_per_group((uint32_t)nblocks);
     const uint64_t groups = (nblocks + L - 1) / L;
+    for (uint64_t i = 0; i < nblocks; ++i)
+        if (table[i].offset > coded_bytes || table[i].length > coded_bytes - table[i].offset)
+            return fail(c, GRK_AMD_ERR_INVALID, "block table row points outside the coded buffer");
     HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
     HIP_TRY(c, c->dec_work.ensure(groups * L * 4096 * 4), "alloc Part-1 workspace");
     HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc status");

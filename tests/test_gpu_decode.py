@@ -560,3 +560,52 @@ def test_random_reference_streams_full_and_windowed(C, H, W, prec, numres, ht, i
     finally:
         c.set_decode_qcd([])
         c.set_decode_segments(None)
+
+
+# ---- corrupt input (the reference fuzzes its decoder, tests/fuzzers/grk_decompress_fuzzer.cpp; one corrupt-HT case in
+#      its regression suite): garbage must be rejected or decoded to garbage, never fault, hang or poison later calls
+@pytest.mark.parametrize("part1", [False, True])
+def test_corrupt_streams_do_not_fault(part1):
+    rng = np.random.default_rng(99 + part1)
+    px = synth.g2(3, 192, 256, 8)
+    if part1:
+        if not R.have_ref():
+            pytest.skip("oracle/_ref not shipped")
+        p, blocks, mall, table, coded = _part1_tile(px, 8, 3)
+    else:
+        p = G.TileParams.make(256, 192, 3, 8, 3)
+        table, coded = U.ctx().encode_host(p, px)
+    good = np.frombuffer(coded, np.uint8).copy()
+    c = U.ctx()
+    for trial in range(12):
+        bad = good.copy()
+        t = table.copy()
+        kind = trial % 4
+        if kind == 0:                                    # random bytes everywhere
+            bad[:] = rng.integers(0, 256, size=bad.size, dtype=np.uint8)
+        elif kind == 1:                                  # a few flipped bits per block
+            for o, l in zip(t["offset"], t["length"]):
+                for _ in range(3):
+                    if l:
+                        bad[int(o) + int(rng.integers(0, l))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:                                  # truncated blocks
+            t["length"] = (t["length"] * rng.random(len(t))).astype(np.uint32)
+        else:                                            # wrong side information
+            if part1:
+                t["missing_msbs"] = (rng.integers(0, 30, size=len(t)) | (rng.integers(0, 60, size=len(t)) << 8)).astype(np.uint32)
+            else:
+                t["missing_msbs"] = rng.integers(0, 40, size=len(t)).astype(np.uint32)
+        try:
+            c.decode_host(p, t, bad)
+        except RuntimeError:
+            pass
+    # rows pointing outside the buffer are refused on the host
+    t = table.copy(); t["offset"][len(t) // 2] = good.size + 5
+    with pytest.raises(RuntimeError):
+        c.decode_host(p, t, good)
+    t = table.copy(); t["length"][0] = good.size + 1
+    with pytest.raises(RuntimeError):
+        c.decode_host(p, t, good)
+    # and the context still decodes the intact stream
+    back = c.decode_host(p, table, good)[0]
+    assert np.array_equal(back, px)
