@@ -33,6 +33,9 @@ namespace grk_amd {
 
 namespace {
 
+#ifndef DWT_FAST_EDGE
+#define DWT_FAST_EDGE 1
+#endif
 constexpr int   kThreads  = 256;
 constexpr int   kCols     = 2 * kThreads;      // columns staged per line
 constexpr int   kHalo     = 4;                 // columns each side
@@ -206,9 +209,15 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     // Interior strips of a tall level take the FAST instance: no column mirroring, aligned pair loads from a uniform
     // row pointer, unpredicated stores (the generic instance spends more instructions on addresses and predicates
     // than on the transform; this kernel is instruction-issue bound, not bandwidth bound).
-    const uint32_t lane_col = (uint32_t)cA;
-    auto strip = [&](auto fast_tag) {
+    // FAST on an edge strip (EDGE): a mirrored column pair is a real pair read backwards -- (-2, -1) is (x[2], x[1]), and
+    // (cw, cw + 1) is (x[cw-2], x[cw-3]) for an even width -- so every lane still does ONE pair load, from the smaller of
+    // its two mirrored columns, and swaps the halves if they are mirrored
+    const uint32_t ld_edge = min(mA, mB);
+    const bool swp_edge = mA > mB;
+    auto strip = [&](auto fast_tag, auto edge_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const uint32_t lane_col = EDGE ? ld_edge : (uint32_t)cA;
         // raw row fetch (no arithmetic, so that prefetched rows stay in flight) and its conversion
         struct Raw { int32_t a[NC], b[NC]; };
         auto fetch_row = [&](int32_t r, Raw& q) {
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
                 if constexpr (F97) { va[0] = __int_as_float(q.a[0]); vb[0] = __int_as_float(q.b[0]); }
                 else if constexpr (H16 && FAST) { va[0] = (int32_t)(int16_t)q.a[0]; vb[0] = q.a[0] >> 16; }
                 else               { va[0] = q.a[0]; vb[0] = q.b[0]; }
+                if constexpr (EDGE) { const T ta = va[0]; va[0] = swp_edge ? vb[0] : ta; vb[0] = swp_edge ? ta : vb[0]; }
             } else {
                 int32_t xa[NC], xb[NC];
     #pragma unroll
@@ -251,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
                     if constexpr (FAST) {               // unpack the pair fetch_row left in q.a
                         constexpr int B = PX == 1 ? 8 : 16;
                         pb = (int32_t)((uint32_t)pa >> B); pa &= (1 << B) - 1;
+                        if constexpr (EDGE) { const int32_t ta = pa; pa = swp_edge ? pb : ta; pb = swp_edge ? ta : pb; }
                     }
                     xa[k] = ((pa ^ a.sext) - a.sext) - a.dc; xb[k] = ((pb ^ a.sext) - a.sext) - a.dc;
                 }
@@ -287,7 +298,9 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         // so that the horizontal phase has no branch at all: with one path through the loop body the compiler's wait for
         // the prefetched rows does not also wait for the stores issued after them
         // lane t owns output pair t of the strip (local columns kHalo + 2t, + 1); lanes past the strip's last pair idle
-        const uint32_t tp = FAST ? min(t, (uint32_t)(kOutPairs - 1)) : t;
+        // (EDGE: the strip may end before its 224th pair; the lanes past the last real pair repeat it as well)
+        const uint32_t nvalid = EDGE ? min((uint32_t)kOutPairs, sw - blockIdx.x * kOutPairs) : (uint32_t)kOutPairs;
+        const uint32_t tp = FAST ? min(t, nvalid - 1u) : t;
         const uint32_t th = tp + kHalo / 2;                                  // its pair index inside the staged line
         const bool h_lane = FAST || t < (uint32_t)kOutPairs;
         const uint32_t Jc = blockIdx.x * kOutPairs + tp;                     // global pair column
@@ -400,9 +413,11 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
             }
         }
     };
-    const bool fast = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (cw & 1u) == 0 && ch >= 16 && (ch & 1u) == 0 &&
-                      (blockIdx.x + 1) * kOutPairs <= dw;
-    if (fast) strip(std::true_type{}); else strip(std::false_type{});
+    const bool even = (cw & 1u) == 0 && cw >= 4 && ch >= 16 && (ch & 1u) == 0;
+    const bool interior = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (blockIdx.x + 1) * kOutPairs <= dw;
+    if (even && interior) strip(std::true_type{}, std::false_type{});
+    else if (even && DWT_FAST_EDGE) strip(std::true_type{}, std::true_type{});
+    else strip(std::false_type{}, std::false_type{});
 }
 
 } // namespace
