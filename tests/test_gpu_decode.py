@@ -609,3 +609,22 @@ def test_corrupt_streams_do_not_fault(part1):
     # and the context still decodes the intact stream
     back = c.decode_host(p, table, good)[0]
     assert np.array_equal(back, px)
+
+
+@pytest.mark.parametrize("C,H,W,prec,L,irrev", [(3, 200, 333, 8, 3, False), (3, 256, 256, 12, 5, True), (1, 129, 65, 10, 2, False),
+                                                (4, 128, 192, 8, 2, False)])
+def test_fused_last_level_equals_separate_egress(C, H, W, prec, L, irrev, monkeypatch):
+    """K7 inside the last inverse DWT level (default) == inverse DWT to int32 planes + the stand-alone egress kernel
+    (GRK_AMD_FUSE_EGRESS=0), for the MCT triple, extra components, odd sizes, 5/3 and 9/7."""
+    px = synth.g2(C, H, W, prec)
+    p = G.TileParams.make(W, H, C, prec, L, irreversible=irrev)
+    table, coded = U.ctx().encode_host(p, px)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("GRK_AMD_FUSE_EGRESS", fuse)
+        c = G.Context(0)
+        out[fuse] = c.decode_host(p, table, coded)[0]
+        c.close()
+    assert np.array_equal(out["1"], out["0"])
+    if not irrev:
+        assert np.array_equal(out["1"], px)
