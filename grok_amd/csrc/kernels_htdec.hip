@@ -24,7 +24,6 @@
 // reference rejects (bad Scup, U_q > missing_msbs) are rejected here as well.
 #include "kernels.h"
 #include "ht_vlc_tables.h"
-#include <cstdlib>
 #include <type_traits>
 
 namespace grk_amd {
@@ -434,7 +433,6 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
     // chain's own latency exposed: aim for ~1.5-2 waves per SIMD (1024 SIMDs), measured optimum.
     uint32_t lanes = 64;
     while (lanes > 16 && (a.nblocks + lanes - 1) / lanes < 1280) lanes >>= 1;
-    if (const char* e = getenv("GRK_AMD_VLC_LANES")) lanes = (uint32_t)atoi(e);
     hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nblocks + lanes - 1) / lanes), dim3(lanes), 0, s, a);
     const uint32_t raw_words = (max_ms_bytes * 8u) / 32u + 8u;
     if (a.irreversible)
