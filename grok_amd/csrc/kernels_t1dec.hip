@@ -47,18 +47,75 @@ constexpr int kCtxZC = 0, kCtxAgg = 17, kCtxUni = 18, kNumCtx = 19;
 // 32.5 ms (issue-bound: a wave instruction costs the same however few lanes are live, but the instruction
 // stream per wave shrinks faster than the number of waves grows).  A single-decode-site formulation that
 // keeps 64 lanes busy is the next step.
-constexpr uint32_t kMaxLanes = 2;
+#ifndef T1_LANES
+#define T1_LANES 1
+#endif
+constexpr uint32_t kMaxLanes = T1_LANES;
+
+// One block per wave (kUniform): everything the decoder touches is wave-uniform, so the compiler keeps it on the scalar
+// unit, and the two lookups on every decision's dependency chain -- context state and Table C.2 -- come out of VGPRs
+// whose LANE i holds entry i (v_readlane / v_writelane with a scalar index: a few cycles) instead of LDS (> 100).
+constexpr bool kUniform = kMaxLanes == 1;
+#ifndef T1_WIN
+#define T1_WIN 1
+#endif
+#ifndef T1_VREG
+#define T1_VREG 1
+#endif
+constexpr bool kWin = kUniform && T1_WIN, kVreg = kUniform && T1_VREG;
 
 struct MqDec {
     const uint8_t* d; uint32_t len, pos;        // pos = index of the byte the reference's `bp` points at
     uint32_t a, c, ct;
     uint8_t* cx;                                 // this lane's 19 context bytes in LDS: state | mps << 7
     const uint32_t* tab;                         // MQ table in LDS
+    uint32_t cxv, tabv;                          // kUniform: lane i holds context byte i / table entry i
     const uint8_t* lo; const uint8_t* hi;        // readable range of the coded buffer
-    __device__ __forceinline__ uint32_t byte_at(uint32_t i) const
-    {   // block bytes followed by the artificial 0xFF 0xFF terminator (mqc_dec.cpp:113-118)
+    uint32_t win[4], wbase;                      // kUniform: the 16 coded bytes [wbase, wbase + 16) of the segment
+    __device__ __forceinline__ uint32_t ctx_get(int i) const
+    {
+        if constexpr (kUniform) return (uint32_t)__builtin_amdgcn_readlane((int)cxv, i); else return cx[i];
+    }
+    __device__ __forceinline__ void ctx_set(int i, uint32_t v)
+    {
+        if constexpr (kUniform) cxv = threadIdx.x == (uint32_t)i ? v : cxv;        // (every lane is active)
+        else cx[i] = (uint8_t)v;
+    }
+    __device__ __forceinline__ uint32_t tab_get(uint32_t i) const
+    {
+        if constexpr (kUniform) return (uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)i); else return tab[i];
+    }
+    __device__ __forceinline__ void refill(uint32_t i)
+    {   // 16 bytes from the dword-aligned address at or below d + i: one load per ~100 decisions instead of two
+        // dependent byte loads per BYTEIN (each of which would also wait for every value store still in flight)
         const uint8_t* p = d + i;
-        return (i < len && p >= lo && p < hi) ? *p : 0xFFu;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+        const uint8_t* q = p - mis;
+        wbase = i - mis;
+        if (q >= lo && q + 16 <= hi) {
+            const uint32_t* q4 = reinterpret_cast<const uint32_t*>(q);
+            win[0] = q4[0]; win[1] = q4[1]; win[2] = q4[2]; win[3] = q4[3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t v = 0;
+                for (int b = 0; b < 4; ++b) { const uint8_t* r = q + k * 4 + b; v |= (uint32_t)((r >= lo && r < hi) ? *r : 0xFFu) << (8 * b); }
+                win[k] = v;
+            }
+        }
+    }
+    __device__ __forceinline__ uint32_t byte_at(uint32_t i)
+    {   // block bytes followed by the artificial 0xFF 0xFF terminator (mqc_dec.cpp:113-118)
+        if constexpr (kWin) {
+            if (i >= len) return 0xFFu;
+            if (i - wbase >= 16u) refill(i);
+            const uint32_t o = i - wbase;
+            const uint32_t lo2 = (o & 8u) ? win[2] : win[0], hi2 = (o & 8u) ? win[3] : win[1];
+            return (((o & 4u) ? hi2 : lo2) >> ((o & 3u) * 8u)) & 0xFFu;
+        } else {
+            const uint8_t* p = d + i;
+            return (i < len && p >= lo && p < hi) ? *p : 0xFFu;
+        }
     }
     __device__ __forceinline__ void bytein()
     {
@@ -70,17 +127,17 @@ struct MqDec {
     }
     __device__ __forceinline__ void reset_states()                 // mqc_resetstates (mqc_dec.cpp:168-175)
     {
-        for (int i = 0; i < kNumCtx; ++i) cx[i] = 0;
-        cx[kCtxUni] = 46; cx[kCtxAgg] = 3; cx[kCtxZC] = 4;
+        for (int i = 0; i < kNumCtx; ++i) ctx_set(i, 0);
+        ctx_set(kCtxUni, 46); ctx_set(kCtxAgg, 3); ctx_set(kCtxZC, 4);
     }
     __device__ __forceinline__ void init_segment()                 // mqc_init_dec (:140-154): the states are kept
     {
-        pos = 0;
+        pos = 0; wbase = 0x80000000u;
         c = (len == 0 ? 0xFFu : byte_at(0)) << 16;
         bytein();
         c <<= 7; ct -= 7; a = 0x8000u;
     }
-    __device__ __forceinline__ void init_raw_segment() { pos = 0; c = 0; ct = 0; }     // mqc_raw_init_dec (:156-160)
+    __device__ __forceinline__ void init_raw_segment() { pos = 0; c = 0; ct = 0; wbase = 0x80000000u; }     // mqc_raw_init_dec (:156-160)
     __device__ __forceinline__ uint32_t raw_decode()               // mqc_raw_decode (mqc_dec_inl.h:55-76)
     {
         if (ct == 0) {
@@ -95,8 +152,8 @@ struct MqDec {
     }
     __device__ __forceinline__ uint32_t decode(int ctx)
     {
-        const uint32_t st = cx[ctx];
-        const uint32_t row = tab[st & 0x7Fu];
+        const uint32_t st = ctx_get(ctx);
+        const uint32_t row = tab_get(st & 0x7Fu);
         const uint32_t qe = row & 0xFFFFu, mps = st >> 7;
         uint32_t dbit;
         a -= qe;
@@ -105,7 +162,7 @@ struct MqDec {
             dbit = toM ? mps : mps ^ 1u;
             const uint32_t nst = toM ? ((row >> 16) & 0x3Fu) : ((row >> 22) & 0x3Fu);
             const uint32_t nm = toM ? mps : mps ^ (row >> 28);
-            cx[ctx] = (uint8_t)(nst | (nm << 7));
+            ctx_set(ctx, nst | (nm << 7));
             a = qe;
         } else {
             c -= qe << 16;
@@ -114,7 +171,7 @@ struct MqDec {
             dbit = toL ? mps ^ 1u : mps;
             const uint32_t nst = toL ? ((row >> 22) & 0x3Fu) : ((row >> 16) & 0x3Fu);
             const uint32_t nm = toL ? mps ^ (row >> 28) : mps;
-            cx[ctx] = (uint8_t)(nst | (nm << 7));
+            ctx_set(ctx, nst | (nm << 7));
         }
         do {                                               // RENORMD
             if (ct == 0) bytein();
@@ -137,8 +194,13 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     __shared__ uint64_t bm_l[4][66][kMaxLanes];
     for (uint32_t i = threadIdx.x; i < 47; i += blockDim.x) mq_l[i] = g_mq_table[i];
     __syncthreads();
-    const uint32_t L = blockDim.x;
-    const uint32_t blk = blockIdx.x * L + threadIdx.x;
+    const uint32_t tabv0 = threadIdx.x < 47 ? g_mq_table[threadIdx.x] : 0u;       // kUniform: Table C.2 across the lanes
+    // kUniform: all 64 lanes run the same (uniform) program -- lane-resident tables need every lane's registers to
+    // stay live through the compiler's copies -- and only lane 0 performs the side effects
+    const bool writer = !kUniform || threadIdx.x == 0;
+    const uint32_t L = kMaxLanes == 1 ? 1u : blockDim.x;
+    const uint32_t lane_i = kMaxLanes == 1 ? 0u : threadIdx.x;      // (one lane per workgroup: everything below is wave-uniform)
+    const uint32_t blk = blockIdx.x * L + lane_i;
     if (blk >= a.nblocks) return;
     const HtDecBlock in = a.table[blk];
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
@@ -146,25 +208,28 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     const uint32_t orient = bd.pad;                        // 0 LL, 1 HL, 2 LH, 3 HH
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
     // value workspace, transposed so that the lanes of a wave touch consecutive words: [group][y*64+x][lane]
-    int32_t* ws = a.work + (size_t)blockIdx.x * 4096u * L + threadIdx.x;
+    int32_t* ws = a.work + (size_t)blockIdx.x * 4096u * L + lane_i;
     if (in.length == 0 && in.missing_msbs == kSkipBlock) return;       // region decode: outside the decoded region
-    for (uint32_t y = 0; y < h; ++y)
-        for (uint32_t x = 0; x < w; ++x) ws[(size_t)(y * 64u + x) * L] = 0;
+    if constexpr (!kVreg)                                // (kUniform: the first pass writes every row, K8b zeroes absent blocks)
+        for (uint32_t y = 0; y < h; ++y)
+            for (uint32_t x = kUniform ? threadIdx.x : 0u; x < w; x += kUniform ? 64u : 1u) ws[(size_t)(y * 64u + x) * L] = 0;
     if (in.length == 0 || numpasses == 0 || numbps == 0) return;
-    if (numbps >= 25u) { atomicOr(a.status, 4u); return; }         // k_max_bit_planes (t1_common.h:70)
+    if (numbps >= 25u) { if (writer) atomicOr(a.status, 4u); return; }         // k_max_bit_planes (t1_common.h:70)
 
     // row bitmaps with one border row above and below (index y + 1), [row][lane] so that lanes never share a bank
     struct Rows {
         uint64_t* p;
         __device__ __forceinline__ uint64_t& operator[](uint32_t i) const { return p[i * kMaxLanes]; }
     };
-    const Rows sig{&bm_l[0][0][threadIdx.x]}, neg{&bm_l[1][0][threadIdx.x]}, pi{&bm_l[2][0][threadIdx.x]},
-               mu{&bm_l[3][0][threadIdx.x]};
-    for (int i = 0; i < 66; ++i) { sig[i] = 0; neg[i] = 0; pi[i] = 0; mu[i] = 0; }
+    const Rows sig{&bm_l[0][0][lane_i]}, neg{&bm_l[1][0][lane_i]}, pi{&bm_l[2][0][lane_i]},
+               mu{&bm_l[3][0][lane_i]};
+    for (int i = kUniform ? (int)threadIdx.x : 0; i < 66; i += kUniform ? 64 : 1) { sig[i] = 0; neg[i] = 0; pi[i] = 0; mu[i] = 0; }
+    if (kUniform) __syncthreads();
 
     MqDec mq;
     mq.lo = a.coded; mq.hi = a.coded + a.coded_bytes;
-    mq.cx = ctx_l[threadIdx.x]; mq.tab = mq_l;
+    mq.cx = ctx_l[lane_i]; mq.tab = mq_l;
+    mq.tabv = tabv0; mq.cxv = 0;
     mq.reset_states();
     const bool lazy = (a.cblksty & 0x01u) != 0, reset = (a.cblksty & 0x02u) != 0, vsc = (a.cblksty & 0x08u) != 0,
                segsym = (a.cblksty & 0x20u) != 0;
@@ -180,6 +245,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     auto dil = [](uint64_t v) { return v | (v << 1) | (v >> 1); };
 
     int bp = (int)numbps, type = 2;
+    bool first_pass = true;                                 // kUniform: nothing in the workspace yet
+    const uint32_t tl = threadIdx.x;
     for (; sg < sg_end; ++sg) {
     const uint32_t seg_len = a.seg_first ? a.segs[sg].x : in.length, seg_passes = a.seg_first ? a.segs[sg].y : numpasses;
     const bool raw_seg = lazy && bp <= (int)numbps - 4 && type < 2;           // decided where the segment starts
@@ -197,6 +264,15 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             for (int j = 0; j < 4; ++j) { P[j] = pi[k + 1 + j]; M[j] = mu[k + 1 + j]; }
             if (vsc) { S[5] = 0; N[5] = 0; }       // vertically causal: a stripe never sees the one below (T1.cpp:198-221)
             const uint32_t nr = min(4u, h - k);
+            // kUniform: the stripe's decoded values live in registers, lane <-> column: one coalesced row load at the
+            // start (not in the first pass) and one coalesced row store at the end instead of a store / an atomic per sample
+            int32_t V[4] = {0, 0, 0, 0};
+            if constexpr (kVreg) {
+                if (!first_pass) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) V[j] = ws[(k + j) * 64u + tl];
+                }
+            }
             // rows of the stripe that do not exist behave as "already coded"
             uint64_t rowok[4];
 #pragma unroll
@@ -216,7 +292,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 else if (hc == 0) { cxn = vc == 0 ? 9 : 10; xr = vc == -1; }                                      \
                 else              { cxn = vc == 1 ? 11 : (vc == 0 ? 12 : 13); xr = 1; }                            \
                 const uint32_t ng = raw ? mq.raw_decode() : (mq.decode(cxn) ^ (uint32_t)xr);                      \
-                ws[(size_t)((k + (j)) * 64u + (x)) * L] = ng ? -oph : oph;                                        \
+                if constexpr (kVreg) { const int32_t sm = -(int32_t)ng; V[(j)] = tl == (x) ? (oph ^ sm) - sm : V[(j)]; } \
+                else if (writer) ws[(size_t)((k + (j)) * 64u + (x)) * L] = ng ? -oph : oph;                       \
                 S[(j) + 1] |= 1ull << (x);                                                                        \
                 if (ng) N[(j) + 1] |= 1ull << (x);                                                                \
             }
@@ -273,7 +350,9 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                         const int cxn = ((M[j] >> x) & 1ull) ? 16 : (((w0 | w2) | (w1 & 5u)) ? 15 : 14);    // Table D.4
                         const uint32_t b = raw ? mq.raw_decode() : mq.decode(cxn);
                         const uint32_t isneg = (uint32_t)(N[j + 1] >> x) & 1u;   // the value's sign, without reading it back
-                        atomicAdd(&ws[(size_t)((k + j) * 64u + x) * L], (b ^ isneg) ? poshalf : -poshalf);
+                        const int32_t dm = (int32_t)(b ^ isneg) - 1, dv = (poshalf ^ dm) - dm;     // +half | -half
+                        if constexpr (kVreg) V[j] += tl == x ? dv : 0;
+                        else if (writer) atomicAdd(&ws[(size_t)((k + j) * 64u + x) * L], dv);
                         M[j] |= 1ull << x;
                     }
                 }
@@ -310,14 +389,19 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 for (int j = 0; j < 4; ++j) P[j] = 0;                  // the plane is complete
             }
 #undef T1_SIGN_AND_SET
+            if constexpr (kVreg) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws[(k + j) * 64u + tl] = V[j];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                sig[k + 1 + j] = S[j + 1]; neg[k + 1 + j] = N[j + 1]; pi[k + 1 + j] = P[j]; mu[k + 1 + j] = M[j];
+                if (writer) { sig[k + 1 + j] = S[j + 1]; neg[k + 1 + j] = N[j + 1]; pi[k + 1 + j] = P[j]; mu[k + 1 + j] = M[j]; }
             }
         }
         if (type == 2 && segsym)                               // dec_clnpass_check_segsym (:977-993): 0xA expected, only warned about
             for (int i = 0; i < 4; ++i) (void)mq.decode(kCtxUni);
         if (reset && !raw_seg) mq.reset_states();
+        first_pass = false;
         if (++type == 3) { type = 0; --bp; }
     }
     }
@@ -331,12 +415,15 @@ __global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a, uint32_t L)
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
     const uint32_t tile = blk / a.blocks_per_tile;
     if (x >= bd.w) return;
-    { const HtDecBlock in = a.table[blk]; if (in.length == 0 && in.missing_msbs == kSkipBlock) return; }
+    const HtDecBlock in = a.table[blk];
+    if (in.length == 0 && in.missing_msbs == kSkipBlock) return;
+    const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
+    const bool absent = kVreg && (in.length == 0 || numpasses == 0 || numbps == 0 || numbps >= 25u);    // K8a wrote nothing
     const int32_t* ws = a.work + (size_t)(blk / L) * 4096u * L + (blk % L);
     int32_t* dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
     const float scale = bd.inv_step / 2;                            // ScaleFilter: stepsize / 2
     for (uint32_t y = 0; y < bd.h; ++y) {
-        const int32_t v = ws[(size_t)(y * 64u + x) * L];
+        const int32_t v = absent ? 0 : ws[(size_t)(y * 64u + x) * L];
         int32_t o;
         if constexpr (IRREV) o = __float_as_int(__fmul_rn((float)v, scale));
         else o = v / 2;                                             // ShiftFilter: truncation toward zero
@@ -355,7 +442,7 @@ uint32_t t1_lanes_per_group(uint32_t nblocks)
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s)
 {
     const uint32_t L = t1_lanes_per_group(a.nblocks);
-    hipLaunchKernelGGL(t1_dec_kernel, dim3((a.nblocks + L - 1) / L), dim3(L), 0, s, a);
+    hipLaunchKernelGGL(t1_dec_kernel, dim3((a.nblocks + L - 1) / L), dim3(kUniform ? 64u : L), 0, s, a);
     if (a.irreversible)
         hipLaunchKernelGGL(t1_store_kernel<true>, dim3(a.nblocks), dim3(64), 0, s, a, L);
     else

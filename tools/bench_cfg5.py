@@ -6,6 +6,9 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
+import grok_amd.capi as _capi
+if os.environ.get("AB_LIB"):
+    _capi.lib_path = lambda: os.environ["AB_LIB"]
 import grok_amd as G, synth, refharness as R, j2kparse as J
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
