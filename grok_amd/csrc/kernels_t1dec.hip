@@ -10,15 +10,19 @@
 // EBCOT decoding is one dependent chain per code-block: every MQ decision renormalises the
 // interval the next one uses and every context depends on the samples decoded so far.  As in K5a the
 // parallelism is therefore ACROSS blocks:
-//  K8a t1_dec_kernel  -- one lane per code-block, kMaxLanes lanes per workgroup.  Significance / sign / visited /
-//      refined state is kept as one 64-bit row bitmap each (code-blocks are at most 64 wide), so a
-//      sample's whole 8-neighbourhood is three 3-bit windows.  The bitmaps (2 KiB per block), the 19
-//      context states and the MQ table live in LDS -- every decision reads them on the serial chain, and
-//      in scratch (= global memory) each access costs a full memory latency.  A stripe's rows are held in
-//      registers while it is processed and columns that cannot code anything are skipped by a mask.
-//      Decoded values go to a transposed global workspace with fire-and-forget stores/atomics, so that
-//      they never stall the chain; all lanes walk (stripe, column, row) in lockstep, which makes those
-//      accesses and the LDS rows conflict-free.
+//  K8a t1_dec_kernel  -- ONE code-block per wavefront, all 64 lanes running the same (uniform) program.  The lanes
+//      are used as register-resident tables and storage: lane i of `cxv` / `tabv` holds MQ context state i / row i
+//      of Table C.2 (v_readlane: both are on every decision's dependency chain, LDS would cost > 100 cycles each),
+//      lane x of V[0..3] holds the decoded values of column x of the current stripe (one coalesced row load / store
+//      per stripe and pass instead of a store / an atomic per sample), and the coded bytes come through a 16-byte
+//      register window.  Significance / sign / visited / refined state is one 64-bit row bitmap each (code-blocks
+//      are at most 64 wide) in LDS, a stripe's rows in registers while it is processed; columns that cannot code
+//      anything in a pass are skipped by a mask.  Measured: ~110 executed instructions and ~800
+//      cycles per MQ decision with one wave alone on a SIMD; with many blocks resident the CU's single scalar unit
+//      and its four vector units are about equally loaded, which is why this mixed scalar / vector form beats an
+//      all-scalar one (a hand-scheduled 45-instruction scalar decoder was 1.5x slower on whole images).
+//      (T1_LANES > 1 keeps the earlier several-blocks-per-wave form for comparison: branch divergence makes the
+//      lanes take turns -- 16 lanes 80 ms, 4 lanes 38.6 ms, 2 lanes 41 ms, this form 23 ms on 12 288 blocks.)
 //  K8b t1_store_kernel -- one wavefront per code-block: workspace -> dequantise -> Mallat plane rows.
 #include "kernels.h"
 
@@ -42,11 +46,7 @@ __device__ const uint32_t g_mq_table[47] = {
 #undef MQROW
 
 constexpr int kCtxZC = 0, kCtxAgg = 17, kCtxUni = 18, kNumCtx = 19;
-// Lanes (= code-blocks) per workgroup.  The passes are branchy (which sample codes what differs per block), so
-// the lanes of a wave mostly take turns: measured on 12 288 blocks 16 lanes 80 ms, 4 lanes 38.6 ms, 2 lanes
-// 32.5 ms (issue-bound: a wave instruction costs the same however few lanes are live, but the instruction
-// stream per wave shrinks faster than the number of waves grows).  A single-decode-site formulation that
-// keeps 64 lanes busy is the next step.
+// Lanes (= code-blocks) per workgroup; 1 = the wave-uniform form described above.
 #ifndef T1_LANES
 #define T1_LANES 1
 #endif
