@@ -77,3 +77,26 @@ def test_unsupported_parameters_are_rejected():
     assert L.grk_amd_tile_num_blocks(C.byref(bad)) == -3
     bad = G.TileParams.make(64, 64, 2, 8, 1, mct=True)
     assert L.grk_amd_tile_num_blocks(C.byref(bad)) == -3
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under grok_amd/ or include/ imports, links, dlopens or executes it
+    (comments that cite it are fine), and the product libraries carry no dependency on it."""
+    import re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = re.compile(r"^\s*(import|from)\s+oracle\b|liboracle|oracle/_ref|dlopen\([^)]*oracle|CDLL\([^)]*oracle", re.M)
+    for sub in ("grok_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(root, sub)):
+            for f in fs:
+                if not f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                    continue
+                text = open(os.path.join(dp, f), errors="replace").read()
+                # drop comments before looking for uses
+                text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+                text = re.sub(r"//[^\n]*|#[^\n]*", "", text)
+                assert not code.search(text), "%s refers to the oracle" % os.path.join(dp, f)
+    for lib in ("libgrok_amd.so", "libgrokj2k_plugin.so"):
+        path = os.path.join(root, "grok_amd", "lib", lib)
+        if os.path.exists(path):
+            needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+            assert "oracle" not in needed
