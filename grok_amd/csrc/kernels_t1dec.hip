@@ -56,13 +56,7 @@ constexpr uint32_t kMaxLanes = T1_LANES;
 // unit, and the two lookups on every decision's dependency chain -- context state and Table C.2 -- come out of VGPRs
 // whose LANE i holds entry i (v_readlane / v_writelane with a scalar index: a few cycles) instead of LDS (> 100).
 constexpr bool kUniform = kMaxLanes == 1;
-#ifndef T1_WIN
-#define T1_WIN 1
-#endif
-#ifndef T1_VREG
-#define T1_VREG 1
-#endif
-constexpr bool kWin = kUniform && T1_WIN, kVreg = kUniform && T1_VREG;
+constexpr bool kWin = kUniform, kVreg = kUniform;         // the coded-byte window / the stripe values in registers
 
 struct MqDec {
     const uint8_t* d; uint32_t len, pos;        // pos = index of the byte the reference's `bp` points at
