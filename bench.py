@@ -53,40 +53,66 @@ def sigma(levels):
     return sum(4.0 ** -l for l in range(levels))
 
 
-def cpu_baseline(rank_threads):
-    """Grok's own CPU encode (oracle/_ref = the real reference built from its sources) on this
-    box's host cores, on a bounded sample of the same workload."""
+def cpu_baseline(rank_threads, want_cfg5=True):
+    """Grok's own CPU encoder / decoder (oracle/_ref = the real reference built from its sources) on this box's host
+    cores, on bounded samples of the same workloads.  Returns (json object, cfg5 stream or None): the classic
+    (Part-1) codestream the reference's encoder writes for the configs[4] image is also what the GPU decodes in
+    extra_workloads() -- the product has no Part-1 encoder, so the reference is the only source of such a stream."""
+    cfg5 = None
     try:
         import refharness as R
         if not R.have_ref():
             raise RuntimeError("oracle/_ref missing")
         R.lib(threads=rank_threads)
-        W = H = 4096
-        px = synth.g2(3, H, W, 8)
         R.encode(synth.g2(3, 1024, 1024, 8), 8, numres=6)          # warm the thread pool
-        times, t_start = [], time.time()
-        while len(times) < 5 and (time.time() - t_start < 20.0 or len(times) < 2):
-            _, secs = R.encode(px, 8, numres=6)
-            times.append(secs)
-        med = sorted(times)[len(times) // 2]
-        out = {"value": round(W * H / med / 1e6, 2), "unit": "Mpixels/s", "cores": rank_threads,
+
+        def enc_sample(S, max_runs, budget_s):
+            px = synth.g2(3, S, S, 8)
+            times, t_start = [], time.time()
+            while len(times) < max_runs and (time.time() - t_start < budget_s or len(times) < 2):
+                cs, secs = R.encode(px, 8, numres=6)
+                times.append(secs)
+            return px, cs, sorted(times)[len(times) // 2], len(times)
+
+        _, _, med8, n8 = enc_sample(8192, 3, 12.0)
+        px, cs, med4, n4 = enc_sample(4096, 5, 8.0)
+        out = {"value": round(8192 * 8192 / med8 / 1e6, 2), "unit": "Mpixels/s", "cores": rank_threads,
                "kind": "reference",
-               "sample": "Grok 8.0.2 CPU encoder (oracle/_ref), %d x 4096x4096x3 8-bit G2 RCT+5/3 HTJ2K 5 levels, "
-                         "median of compress-call wall times, %d threads" % (len(times), rank_threads)}
+               "sample": "Grok 8.0.2 CPU encoder (oracle/_ref), %d x 8192x8192x3 8-bit G2 RCT+5/3 HTJ2K 5 levels (the GPU line's "
+                         "workload), median of compress-call wall times, %d threads" % (n8, rank_threads),
+               "cfg2": {"value": round(4096 * 4096 / med4 / 1e6, 2), "unit": "Mpixels/s",
+                        "sample": "%d x 4096x4096x3 8-bit, same settings" % n4}}
         # the decode direction beside it: grk_decompress of the codestream just produced
         try:
-            cs, _ = R.encode(px, 8, numres=6)
             dts = []
             for _ in range(3):
                 t0 = time.time()
-                R.decode(cs, 3, H, W)
+                R.decode(cs, 3, 4096, 4096)
                 dts.append(time.time() - t0)
-            out["decode"] = {"value": round(W * H / sorted(dts)[1] / 1e6, 2), "unit": "Mpixels/s",
-                             "sample": "grk_decompress of the same 4096x4096x3 stream, median of 3 wall times "
+            out["decode"] = {"value": round(4096 * 4096 / sorted(dts)[1] / 1e6, 2), "unit": "Mpixels/s",
+                             "sample": "grk_decompress of the 4096x4096x3 HT stream, median of 3 wall times "
                                        "(includes codestream parsing and Tier-2)"}
         except Exception as e:  # noqa: BLE001
             out["decode"] = {"value": None, "error": str(e)}
-        return out
+        if want_cfg5:
+            try:      # BASELINE configs[4]: 8192^2 x 3 12-bit, Part-1 EBCOT + ICT + 9/7
+                S = 8192
+                px5 = synth.g2(3, S, S, 12)
+                t0 = time.time()
+                cs5, _ = R.encode(px5, 12, numres=6, mode=1, ht=0, irrev=1)
+                t_enc = time.time() - t0
+                dts = []
+                for _ in range(2):
+                    t0 = time.time()
+                    ref5 = R.decode(cs5, 3, S, S)
+                    dts.append(time.time() - t0)
+                out["cfg5_decode"] = {"value": round(S * S / min(dts) / 1e6, 2), "unit": "Mpixels/s",
+                                      "sample": "grk_decompress of an 8192x8192x3 12-bit Part-1 + ICT + 9/7 stream (%d bytes, written "
+                                                "by grk_compress in %.1f s), best of 2 wall times" % (len(cs5), t_enc)}
+                cfg5 = (cs5, ref5, S)
+            except Exception as e:  # noqa: BLE001
+                out["cfg5_decode"] = {"value": None, "error": str(e)}
+        return out, cfg5
     except Exception as e:  # fall back to the scalar port of the oracle
         import oracle as O
         px = synth.g2(3, 1024, 1024, 8)
@@ -94,7 +120,125 @@ def cpu_baseline(rank_threads):
         O.encode_tile_rev(px, 8, 5)
         dt = time.time() - t0
         return {"value": round(1024 * 1024 / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-                "sample": "oracle/j2k_oracle.c scalar port, 1 x 1024x1024x3 (reference harness unavailable: %s)" % e}
+                "sample": "oracle/j2k_oracle.c scalar port, 1 x 1024x1024x3 (reference harness unavailable: %s)" % e}, None
+
+
+def _pmc_traffic(workload, fams):
+    """HBM bytes per step of the kernel families `fams` from the committed rocprofv3 --pmc passes of the same workload
+    (profiles/summarize_pmc.py: FETCH_SIZE x1024 x2 [gfx950 half-count] + WRITE_SIZE x1024); None without a summary."""
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % workload)))
+        if not cands:
+            return None
+        pm = json.load(open(cands[-1]))
+        return int(sum(pm[k]["hbm_bytes_per_step"] for k in fams if k in pm)) or None
+    except Exception:
+        return None
+
+
+def extra_workloads(ctx, dev, stream, steps, cfg5):
+    """The other BASELINE configurations on the same GPU, a few steps each: cfg2, cfg3 with its
+    9/7 DWT family against the HBM roofline (north_star's >= 40 % target), the cfg4 tiling, and the cfg5 decode."""
+    out = {}
+    for name in ("cfg2", "cfg3", "cfg4tile"):
+        Cn, W, H, prec, levels, ntiles, desc = WORKLOADS[name]
+        irrev = name == "cfg3"
+        params = G.TileParams.make(W, H, Cn, prec, levels, irreversible=irrev)
+        tile = synth.g2(Cn, H, W, prec)
+        host = np.ascontiguousarray(np.broadcast_to(tile.reshape(1, -1), (ntiles, tile.size))).reshape(-1)
+        d_px = torch.from_numpy(host.view(np.uint8)).to(dev)
+        samples = W * H * ntiles * Cn
+        b_in = (prec + 7) // 8
+        nblocks = G.lib().grk_amd_tile_num_blocks(C.byref(params)) * ntiles
+        ctx.set_overlap(True)
+        ctx.set_pipelining(True)
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for _ in range(steps):
+                ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        ctx.set_pipelining(False)
+        # kernel families one at a time (HIP events on the stream each kernel is launched on)
+        ctx.set_overlap(False)
+        ctx.enable_timing(True)
+        with torch.cuda.stream(stream):
+            for _ in range(steps):
+                ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+        torch.cuda.synchronize(dev)
+        dwt_ms = ctx.kernel_ms(1)[0]
+        parts = [ctx.kernel_ms(i) for i in (2, 4, 8)]
+        n_ht = max([n for _, n in parts] + [1])
+        ht_ms = sum(m * n for m, n in parts) / n_ht
+        ctx.enable_timing(False)
+        ctx.set_overlap(True)
+        _, total = ctx.fetch_table(nblocks)
+        dwt_bytes = samples * (b_in + 4.0) + 8.0 * samples * (sigma(levels) - 1.0)       # level 0 reads the pixels (K1 fused)
+        w = {"workload": desc, "ms_per_step": round(ms, 4), "value": round(W * H * ntiles / ms / 1e3, 1), "unit": "Mpixels/s",
+             "dtype": "f32" if irrev else "int32", "coded_bytes": int(total),
+             "kernels": {
+                 ("dwt97_5levels" if irrev else "dwt53_5levels"): {
+                     "avg_ms": round(dwt_ms, 4), "algorithmic_bytes": int(dwt_bytes),
+                     "algorithmic_GBps": round(dwt_bytes / dwt_ms / 1e6, 1) if dwt_ms > 0 else None,
+                     "frac": round(dwt_bytes / dwt_ms / 1e6 / HBM_PEAK_GBPS, 4) if dwt_ms > 0 else None,
+                     # SURVEY.md §8(d)'s unfused DWT-only figure 8*S*sigma_L (4 B read + 4 B written per sample and level),
+                     # the one north_star's ">= 40 % of the HBM roofline on the 5-level 9/7 DWT" is stated on
+                     "frac_on_8S_sigma": round(8.0 * samples * sigma(levels) / dwt_ms / 1e6 / HBM_PEAK_GBPS, 4) if dwt_ms > 0 else None,
+                     "traffic": _pmc_traffic(name, ("dwt_level0_fused", "dwt_levels_1plus"))},
+                 "ht_cleanup_encode": {
+                     "avg_ms": round(ht_ms, 4), "algorithmic_bytes": int(4.0 * samples + total),
+                     "algorithmic_GBps": round((4.0 * samples + total) / ht_ms / 1e6, 1) if ht_ms > 0 else None,
+                     "frac": round((4.0 * samples + total) / ht_ms / 1e6 / HBM_PEAK_GBPS, 4) if ht_ms > 0 else None,
+                     "traffic": _pmc_traffic(name, ("ht_encode_kernel",))}}}
+        out[name] = w
+        del d_px
+    if cfg5 is not None:
+        try:
+            import j2kparse as J
+            cs5, ref5, S = cfg5
+            info = J.parse(cs5)
+            p5 = G.TileParams.make(S, S, 3, 12, info["levels"], irreversible=True, mct=True, part1=True)
+            blocks, _ = G.tile_layout(p5)
+            rows, data = J.decode_table(info, blocks, True)
+            table = np.array(rows, dtype=G.capi.CODED_DTYPE)
+            ctx.set_decode_qcd([(e << 11) | m for e, m in info["qcd"]])
+            d_c = torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(dev)
+            d_out = torch.zeros(3 * S * S, dtype=torch.int16, device=dev)
+            with torch.cuda.stream(stream):
+                ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), d_out.data_ptr())
+            torch.cuda.synchronize(dev)
+            ctx.decode_status()
+            ctx.enable_timing(True)
+            n5 = 3
+            t0 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                for _ in range(n5):
+                    ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), d_out.data_ptr())
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / n5 * 1e3
+            got = d_out.cpu().numpy().view(np.uint16).reshape(3, S, S)
+            k8, k6 = ctx.kernel_ms(5)[0], ctx.kernel_ms(6)[0]
+            ctx.enable_timing(False)
+            samples = 3.0 * S * S
+            out["cfg5"] = {"workload": "8192x8192x3 12-bit decode, Part-1 EBCOT + ICT + 9/7 stream written by grk_compress (BASELINE configs[4])",
+                           "ms_per_step": round(ms, 3), "value": round(S * S / ms / 1e3, 1), "unit": "Mpixels/s", "dtype": "f32",
+                           "coded_bytes": int(len(data)), "pixels_equal_grk_decompress": bool(np.array_equal(got.astype(np.int32), ref5)),
+                           "kernels": {"t1_ebcot_decode": {"avg_ms": round(k8, 3), "algorithmic_bytes": int(4 * samples + len(data)),
+                                                           "algorithmic_GBps": round((4 * samples + len(data)) / k8 / 1e6, 1) if k8 > 0 else None,
+                                                           "traffic": _pmc_traffic("cfg5", ("t1_dec_kernel",))},
+                                       "idwt97_5levels": {"avg_ms": round(k6, 3),
+                                                          "algorithmic_bytes": int(8 * samples * (sigma(5) - 1) + samples * 6),
+                                                          "algorithmic_GBps": round((8 * samples * (sigma(5) - 1) + samples * 6) / k6 / 1e6, 1) if k6 > 0 else None,
+                                                          "traffic": _pmc_traffic("cfg5", ("idwt_last_level_fused", "idwt_level_kernel"))}}}
+            ctx.set_decode_qcd([])
+        except Exception as e:  # noqa: BLE001
+            out["cfg5"] = {"error": str(e)}
+    return out
 
 
 def main():
@@ -104,6 +248,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` object (cfg2, cfg3, cfg4tile, cfg5 decode)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="every kernel alone on the GPU, also in the timed region (what the rocprofv3 kernel-trace summary "
                          "that the roofline durations are checked against is taken with)")
@@ -330,17 +475,8 @@ def main():
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this
     # process; they come from the committed rocprofv3 --pmc passes of this same command
     # (profiles/summarize_pmc.py: FETCH_SIZE x1024 x2 [gfx950 half-count] + WRITE_SIZE x1024).
-    traffic = None
-    try:
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)))
-        if cands:
-            pm = json.load(open(cands[-1]))
-            fams = {"ingest_mct": ("ingest_kernel",), "dwt53_5levels": ("dwt_level0_fused", "dwt_levels_1plus"),
-                    "ht_cleanup_encode": ("ht_encode_kernel",)}[dom]
-            traffic = int(sum(pm[k]["hbm_bytes_per_step"] for k in fams if k in pm)) or None
-    except Exception:
-        traffic = None
+    traffic = _pmc_traffic(args.workload, {"ingest_mct": ("ingest_kernel",), "dwt53_5levels": ("dwt_level0_fused", "dwt_levels_1plus"),
+                                            "ht_cleanup_encode": ("ht_encode_kernel",)}[dom])
     ach = algo[dom] / (fam[dom][0] * 1e-3) / 1e9 if fam[dom][0] > 0 else 0.0
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -362,6 +498,7 @@ def main():
     # whole-pipeline figure of SURVEY.md §8(d) (unfused definition, kept so that rounds compare)
     pipeline_bytes = samples * (b_in + 4) + 8.0 * samples * sigma(levels) + algo["ht_cleanup_encode"]
 
+    pipe_traffic = _pmc_traffic(args.workload, ("ingest_kernel", "dwt_level0_fused", "dwt_levels_1plus", "ht_encode_kernel"))
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = pixels_per_step * world * args.steps / dt / 1e6
@@ -374,19 +511,26 @@ def main():
                        "coded_bytes_per_gpu": int(total), "generator": "G2 (SURVEY.md §8d)",
                        "parallelism": parallelism},
             "roofline": roofline,
-            "pipeline": {"algorithmic_bytes_per_step": int(pipeline_bytes),
-                         "achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                         "frac_of_hbm_peak": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            # equivalent-work figure (SURVEY.md §8d's UNFUSED definition: int32 planes between every stage), kept so that
+            # rounds compare; the fused pipeline moves far fewer bytes -- `dram_*` is what the PMC counters saw per step
+            "pipeline": {"unfused_equivalent_bytes_per_step": int(pipeline_bytes),
+                         "unfused_equivalent_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                         "dram_traffic_bytes_per_step": pipe_traffic,
+                         "dram_GBps": round(pipe_traffic / (ms_per_step * 1e-3) / 1e9, 1) if pipe_traffic else None,
+                         "dram_frac_of_hbm_peak": round(pipe_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if pipe_traffic else None},
             "kernels": kernels,
             "kernels_overlapped": kernels_overlapped,
             "decode": decode,
         }
         if use_dist:
             out["config"]["assembled_codestream_bytes"] = cs_len
+        cfg5 = None
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            out["cpu_baseline"], cfg5 = cpu_baseline(os.cpu_count() or 1, want_cfg5=not args.no_workloads and args.workload == "8k")
         elif world == 1:
             out["cpu_baseline"] = None
+        if world == 1 and not use_dist and not args.no_workloads and args.workload == "8k":
+            out["workloads"] = extra_workloads(ctx, dev, stream, max(3, min(args.steps, 10)), cfg5)
         line = json.dumps(out)
     else:
         line = None

@@ -16,27 +16,37 @@ def g0(C, H, W, prec=8):
 
 
 def _lcg_all(n, seed=12345):
-    """s_{i+1} = s_i*1664525 + 1013904223 mod 2^32, returns s_1..s_n (vectorised by doubling)."""
-    a = np.uint64(1664525)
-    c = np.uint64(1013904223)
-    m = np.uint64(0xFFFFFFFF)
-    out = np.empty(n, np.uint64)
-    out[0] = (np.uint64(seed) * a + c) & m
-    filled = 1
-    ak, ck = a, c          # composition of `filled` steps: s -> ak*s + ck
-    while filled < n:
-        k = min(filled, n - filled)
-        out[filled:filled + k] = (out[:k] * ak + ck) & m
-        # square the step map
-        ck = (ak * ck + ck) & m
-        ak = (ak * ak) & m
-        filled += k
+    """s_{i+1} = s_i*1664525 + 1013904223 mod 2^32, returns s_1..s_n as uint32 (vectorised by doubling;
+    uint32 arithmetic wraps, which IS the mod 2^32)."""
+    a = np.uint32(1664525)
+    c = np.uint32(1013904223)
+    out = np.empty(n, np.uint32)
+    with np.errstate(over="ignore"):
+        out[0] = np.uint32(seed & 0xFFFFFFFF) * a + c
+        filled = 1
+        ak, ck = a, c          # composition of `filled` steps: s -> ak*s + ck
+        while filled < n:
+            k = min(filled, n - filled)
+            np.multiply(out[:k], ak, out=out[filled:filled + k])
+            out[filled:filled + k] += ck
+            # square the step map
+            ck = ak * ck + ck
+            ak = ak * ak
+            filled += k
     return out
 
 
 def g2(C, H, W, prec=8, seed=12345):
     s = _lcg_all(C * H * W, seed).reshape(C, H, W)
-    y, x = np.meshgrid(np.arange(H, dtype=np.uint64), np.arange(W, dtype=np.uint64), indexing="ij")
-    c = np.arange(C, dtype=np.uint64).reshape(C, 1, 1)
-    v = ((x + y + np.uint64(37) * c) * np.uint64((1 << prec) - 16)) // np.uint64(W + H + 74) + ((s >> np.uint64(24)) & np.uint64(7))
-    return v.astype(np.uint8 if prec <= 8 else np.uint16)
+    s >>= np.uint32(24)
+    s &= np.uint32(7)
+    k, d = (1 << prec) - 16, W + H + 74
+    wide = (W + H + 37 * C) * k >= 1 << 32       # (never for the sizes in use: 16384^2 x 16 bit is 2.2e9)
+    t = np.uint64 if wide else np.uint32
+    xy = np.arange(H, dtype=t)[:, None] + np.arange(W, dtype=t)[None, :]
+    out = np.empty((C, H, W), np.uint8 if prec <= 8 else np.uint16)
+    for c in range(C):
+        v = (xy + t(37 * c)) * t(k) // t(d)
+        v += s[c]
+        out[c] = v
+    return out

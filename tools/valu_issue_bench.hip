@@ -1,0 +1,149 @@
+// tools/valu_issue_bench.hip -- how many cycles does one wave64 integer VALU instruction hold a gfx950 SIMD?
+//
+// K3 (HT cleanup encoder) is VALU-issue bound; whether it sits at 40 % or 80 % of the issue roof depends on
+// whether the integer / bit-manipulation ops it is made of issue at 2 cycles per wave64 instruction (SIMD-32,
+// what MI355X_MICROARCH.md lists for v_fma_f32) or at 4 (SIMD-16, GCN).  This measures it: per op, a loop of
+// independent (ILP 8) or dependent (ILP 1) instructions, timed with s_memtime inside the wave, at 1, 2, 4 waves
+// per SIMD on ONE CU (a single workgroup of 256 / 512 / 1024 threads: a workgroup's waves are dealt to the four
+// SIMDs in turn), and over the whole chip at 8 waves per SIMD (wall time).
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/valu_issue_bench tools/valu_issue_bench.hip && tools/valu_issue_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int kIters = 512;       // loop trips
+constexpr int kPerIter = 32;      // instructions of the measured kind per trip
+
+enum Op { AND, LSHL, FFBH, PKMIN, ADD, BFE, MUL24, PERM, DPP_ADD, CNDMASK, MIN, LSHL_OR, FMA, AND_OR, MBCNT, READLANE, BPERM, LDS_OR, NUM_OPS };
+static const char* kNames[NUM_OPS] = {"v_and_b32", "v_lshlrev_b32", "v_ffbh_i32", "v_pk_min_u16", "v_add_u32", "v_bfe_u32",
+                                      "v_mul_u32_u24", "v_perm_b32", "v_add_u32 dpp row_shr:1", "v_cndmask_b32", "v_min_u32",
+                                      "v_lshl_or_b32", "v_fma_f32", "v_and_or_b32", "v_mbcnt_lo_u32_b32", "v_readlane_b32 (->sgpr)",
+                                      "ds_bpermute_b32", "ds_or_b32 (atomic)"};
+
+template <int OP, int ILP>
+__device__ __forceinline__ void one(uint32_t& a, uint32_t b, uint32_t* lds)
+{
+    if constexpr (OP == AND)      asm volatile("v_and_b32 %0, %1, %0" : "+v"(a) : "v"(b));
+    if constexpr (OP == LSHL)     asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a));
+    if constexpr (OP == FFBH)     asm volatile("v_ffbh_i32 %0, %0" : "+v"(a));
+    if constexpr (OP == PKMIN)    asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a) : "v"(b));
+    if constexpr (OP == ADD)      asm volatile("v_add_u32 %0, %1, %0" : "+v"(a) : "v"(b));
+    if constexpr (OP == BFE)      asm volatile("v_bfe_u32 %0, %0, 1, 31" : "+v"(a));
+    if constexpr (OP == MUL24)    asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(a) : "v"(b));
+    if constexpr (OP == PERM)     asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
+    if constexpr (OP == DPP_ADD && ILP > 1)  asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a));
+    // (a VALU write followed by a DPP read of the same register needs two wait states: the dependent chain pays them)
+    if constexpr (OP == DPP_ADD && ILP == 1) asm volatile("s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a));
+    if constexpr (OP == CNDMASK)  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b));
+    if constexpr (OP == MIN)      asm volatile("v_min_u32 %0, %1, %0" : "+v"(a) : "v"(b));
+    if constexpr (OP == LSHL_OR)  asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a) : "v"(b));
+    if constexpr (OP == FMA)      asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
+    if constexpr (OP == AND_OR)   asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
+    if constexpr (OP == MBCNT)    asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a) : "v"(b));
+    if constexpr (OP == READLANE) { uint32_t s; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s) : "v"(a)); asm volatile("" :: "s"(s)); }
+    if constexpr (OP == BPERM)    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(8)" : "+v"(a) : "v"(b));
+    if constexpr (OP == LDS_OR)   asm volatile("ds_or_b32 %0, %1\n s_waitcnt lgkmcnt(8)" :: "v"(b), "v"(a) : "memory");
+}
+
+// ILP = number of independent accumulators the kPerIter instructions of a trip are spread over
+template <int OP, int ILP>
+__global__ __launch_bounds__(1024) void bench(uint64_t* cycles, uint32_t* sink, uint32_t seed)
+{
+    __shared__ uint32_t lds[2048];
+    lds[threadIdx.x] = seed; lds[threadIdx.x + 1024] = seed;
+    uint32_t acc[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc[i] = seed * (threadIdx.x + 3) + i;
+    uint32_t b = (threadIdx.x * 4u) & 0xFCu;          // a valid LDS byte address / bpermute lane address / operand
+    if (OP == LDS_OR) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) acc[i] = 1u << i;
+    }
+    __syncthreads();
+    const uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+        for (int j = 0; j < kPerIter; ++j) one<OP, ILP>(acc[j % ILP], b, lds);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint64_t t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s ^= acc[i];
+    if (s == 0x12345678u) sink[0] = s + lds[b >> 2];
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int OP, int ILP>
+static int run(uint64_t* d_cycles, uint32_t* d_sink, double clock_ghz, bool& header)
+{
+    if (!header) {
+        printf("%-26s %4s | %9s %9s %9s | %s\n", "op", "ILP", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD",
+               "chip, 8 w/SIMD: cycles per wave-instruction and SIMD (from wall time)");
+        header = true;
+    }
+    const double n = (double)kIters * kPerIter;
+    double cpi[3];
+    for (int k = 0; k < 3; ++k) {
+        const int threads = 256 << k;
+        hipLaunchKernelGGL((bench<OP, ILP>), dim3(1), dim3(threads), 0, 0, d_cycles, d_sink, 7u);     // warm
+        hipLaunchKernelGGL((bench<OP, ILP>), dim3(1), dim3(threads), 0, 0, d_cycles, d_sink, 7u);
+        CHECK(hipDeviceSynchronize());
+        std::vector<uint64_t> h(threads / 64);
+        CHECK(hipMemcpy(h.data(), d_cycles, h.size() * 8, hipMemcpyDeviceToHost));
+        // SIMD-side interval between two instructions of the kind: the slowest wave's cycles / (instructions x waves on the SIMD)
+        const uint64_t worst = *std::max_element(h.begin(), h.end());
+        cpi[k] = (double)worst / n / (double)(1 << k);
+    }
+    // whole chip: 256 CUs x 2 workgroups of 1024 threads resident = 8 waves per SIMD, 8 rounds
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int grid = 256 * 2 * 8;
+    hipLaunchKernelGGL((bench<OP, ILP>), dim3(grid), dim3(1024), 0, 0, d_cycles, d_sink, 7u);
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((bench<OP, ILP>), dim3(grid), dim3(1024), 0, 0, d_cycles, d_sink, 7u);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double wave_instr_per_simd = n * (double)grid * 16.0 / (256.0 * 4.0);
+    const double chip = ms * 1e-3 * clock_ghz * 1e9 / wave_instr_per_simd;
+    printf("%-26s %4d | %9.2f %9.2f %9.2f | %6.2f   (%.3f ms)\n", kNames[OP], ILP, cpi[0], cpi[1], cpi[2], chip, ms);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
+__global__ void clock_probe(uint64_t* out)
+{
+    const uint64_t c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    while (wall_clock64() - r0 < 1000000) { }          // 10 ms of the 100 MHz constant clock
+    out[0] = __builtin_readcyclecounter() - c0; out[1] = wall_clock64() - r0;
+}
+
+int main()
+{
+    uint64_t* d_cycles; uint32_t* d_sink;
+    CHECK(hipMalloc(&d_cycles, 8 * 65536 * 16)); CHECK(hipMalloc(&d_sink, 64));
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    hipLaunchKernelGGL(clock_probe, dim3(1), dim3(1), 0, 0, d_cycles);
+    CHECK(hipDeviceSynchronize());
+    uint64_t pr[2]; CHECK(hipMemcpy(pr, d_cycles, 16, hipMemcpyDeviceToHost));
+    int wc_khz = 0; (void)hipDeviceGetAttribute(&wc_khz, hipDeviceAttributeWallClockRate, 0);
+    const double wall_hz = wc_khz ? wc_khz * 1e3 : 1e8;
+    const double smem_ghz = (double)pr[0] / ((double)pr[1] / wall_hz) / 1e9;
+    printf("device %s, %d CUs, clockRate %.0f MHz; s_memtime advances at %.3f GHz (vs wall clock %.0f MHz)\n",
+           prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1e3, smem_ghz, wall_hz / 1e6);
+    printf("columns: SIMD-side cycles (s_memtime ticks) between two wave64 instructions of the kind = slowest wave's ticks / (instructions x waves per SIMD)\n");
+    // the chip column needs the shader clock under load; the in-wave columns are in s_memtime ticks whatever the clock is
+    const double ghz = prop.clockRate / 1e6;
+    if (smem_ghz < 0.5 * ghz) printf("NOTE: s_memtime is a constant clock here: multiply the in-wave columns by %.2f for shader cycles at %.0f MHz\n", ghz / smem_ghz, ghz * 1e3);
+    bool header = false;
+#define RUN(OP) do { if (run<OP, 8>(d_cycles, d_sink, ghz, header)) return 1; if (run<OP, 1>(d_cycles, d_sink, ghz, header)) return 1; } while (0)
+    RUN(FMA); RUN(AND); RUN(ADD); RUN(LSHL); RUN(MIN); RUN(FFBH); RUN(PKMIN); RUN(BFE); RUN(MUL24); RUN(PERM);
+    RUN(LSHL_OR); RUN(AND_OR); RUN(CNDMASK); RUN(MBCNT); RUN(DPP_ADD); RUN(READLANE); RUN(BPERM); RUN(LDS_OR);
+    return 0;
+}
