@@ -118,10 +118,15 @@ bool same_params(const grk_amd_tile_params& a, const grk_amd_tile_params& b)
 int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
 {
     if (c->have_geom && same_params(c->gp, *p)) return GRK_AMD_OK;
+    // the tables rebuilt below may still be read by K3 launches of a pipelined predecessor on the side streams
+    if (c->side) HIP_TRY(c, hipStreamSynchronize(c->side), "sync side stream");
+    if (c->side2) HIP_TRY(c, hipStreamSynchronize(c->side2), "sync side stream 2");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    c->side_pending = false;
+    c->have_geom = false;                      // valid again only once every table below is on the device
     int rc = build_tile_geom(*p, c->geom);
     if (rc != GRK_AMD_OK) return fail(c, rc, "unsupported tile parameters");
     c->gp = *p;
-    c->have_geom = true;
     const TileGeom& g = c->geom;
     c->h_desc.clear();
     std::vector<uint8_t> h_res;                 // resolution of each block (0 = coarsest)
@@ -201,6 +206,7 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
     HIP_TRY(c, hipMemcpyAsync(c->blockdesc.p, c->h_desc.data(), c->h_desc.size() * sizeof(HtBlockDesc),
                               hipMemcpyHostToDevice, c->stream), "upload block table");
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync block table");
+    c->have_geom = true;
     return GRK_AMD_OK;
 }
 
@@ -478,13 +484,11 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     const TileGeom& g = c->geom;
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
-    const uint32_t L = t1_lanes_per_group((uint32_t)nblocks);
-    const uint64_t groups = (nblocks + L - 1) / L;
     for (uint64_t i = 0; i < nblocks; ++i)
         if (table[i].offset > coded_bytes || table[i].length > coded_bytes - table[i].offset)
             return fail(c, GRK_AMD_ERR_INVALID, "block table row points outside the coded buffer");
     HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
-    HIP_TRY(c, c->dec_work.ensure(groups * L * 4096 * 4), "alloc Part-1 workspace");
+    HIP_TRY(c, c->dec_work.ensure(nblocks * 4096 * 4), "alloc Part-1 workspace");
     HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc status");
     HIP_TRY(c, hipMemcpyAsync(c->dec_table.p, table, nblocks * sizeof(HtDecBlock), hipMemcpyHostToDevice, c->stream), "upload decode table");
     HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, 16, c->stream), "clear status");

@@ -110,7 +110,7 @@ struct T1DecArgs {
     const HtBlockDesc* blocks;                 // pad = band orientation, inv_step = band step size (irreversible)
     uint32_t blocks_per_tile, nblocks, ncomp;
     const uint8_t* coded; uint64_t coded_bytes;
-    int32_t* work;                             // [groups][64*64][lanes per group] decoded values
+    int32_t* work;                             // [nblocks][64*64] decoded values
     unsigned int* status;
     int32_t* mallat; uint32_t stride; uint64_t pitch;
     int irreversible;
@@ -118,7 +118,6 @@ struct T1DecArgs {
     const uint32_t* seg_first;                 // [nblocks + 1] first codeword segment of each block, or null: one segment
     const uint2* segs;                         // {bytes, passes} per segment
 };
-uint32_t   t1_lanes_per_group(uint32_t nblocks);
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s);
 
 // ---- K6: one inverse DWT level, horizontal + vertical fused (kernels_idwt.hip) ------------------

@@ -33,18 +33,12 @@ namespace grk_amd {
 
 namespace {
 
-#ifndef DWT_FAST_EDGE
-#define DWT_FAST_EDGE 1
-#endif
 constexpr int   kThreads  = 256;
 constexpr int   kCols     = 2 * kThreads;      // columns staged per line
 constexpr int   kHalo     = 4;                 // columns each side
-#ifndef DWT_OUTCOLS
-#define DWT_OUTCOLS 448
-#endif
 // Output columns per strip.  At most kCols - 2 * kHalo = 504; 448 makes a strip 224 output pairs = 7 x 128 bytes of
 // every sub-band row, so each wave's stores cover whole, aligned cache lines.
-constexpr int   kOutCols  = DWT_OUTCOLS;
+constexpr int   kOutCols  = 448;
 constexpr int   kOutPairs = kOutCols / 2;
 static_assert(kOutCols <= kCols - 2 * kHalo && kOutCols % 2 == 0, "strip does not fit the staged line");
 
@@ -419,7 +413,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     const bool even = (cw & 1u) == 0 && cw >= 4 && ch >= 16 && (ch & 1u) == 0;
     const bool interior = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (blockIdx.x + 1) * kOutPairs <= dw;
     if (even && interior) strip(std::true_type{}, std::false_type{});
-    else if (even && DWT_FAST_EDGE) strip(std::true_type{}, std::true_type{});
+    else if (even) strip(std::true_type{}, std::true_type{});
     else strip(std::false_type{}, std::false_type{});
 }
 

@@ -21,8 +21,8 @@
 //      cycles per MQ decision with one wave alone on a SIMD; with many blocks resident the CU's single scalar unit
 //      and its four vector units are about equally loaded, which is why this mixed scalar / vector form beats an
 //      all-scalar one (a hand-scheduled 45-instruction scalar decoder was 1.5x slower on whole images).
-//      (T1_LANES > 1 keeps the earlier several-blocks-per-wave form for comparison: branch divergence makes the
-//      lanes take turns -- 16 lanes 80 ms, 4 lanes 38.6 ms, 2 lanes 41 ms, this form 23 ms on 12 288 blocks.)
+//      (An earlier several-blocks-per-wave form -- branch divergence makes the lanes take turns -- measured 80 ms
+//      with 16 lanes, 38.6 ms with 4 and 41 ms with 2 where this form takes 23 ms, on 12 288 blocks.)
 //  K8b t1_store_kernel -- one wavefront per code-block: workspace -> dequantise -> Mallat plane rows.
 #include "kernels.h"
 
@@ -46,39 +46,19 @@ __device__ const uint32_t g_mq_table[47] = {
 #undef MQROW
 
 constexpr int kCtxZC = 0, kCtxAgg = 17, kCtxUni = 18, kNumCtx = 19;
-// Lanes (= code-blocks) per workgroup; 1 = the wave-uniform form described above.
-#ifndef T1_LANES
-#define T1_LANES 1
-#endif
-constexpr uint32_t kMaxLanes = T1_LANES;
 
-// One block per wave (kUniform): everything the decoder touches is wave-uniform, so the compiler keeps it on the scalar
-// unit, and the two lookups on every decision's dependency chain -- context state and Table C.2 -- come out of VGPRs
-// whose LANE i holds entry i (v_readlane / v_writelane with a scalar index: a few cycles) instead of LDS (> 100).
-constexpr bool kUniform = kMaxLanes == 1;
-constexpr bool kWin = kUniform, kVreg = kUniform;         // the coded-byte window / the stripe values in registers
-
+// One block per wave: everything the decoder touches is wave-uniform, so the compiler keeps it on the scalar unit, and
+// the two lookups on every decision's dependency chain -- context state and Table C.2 -- come out of VGPRs whose LANE i
+// holds entry i (v_readlane / v_writelane with a scalar index: a few cycles) instead of LDS (> 100).
 struct MqDec {
     const uint8_t* d; uint32_t len, pos;        // pos = index of the byte the reference's `bp` points at
     uint32_t a, c, ct;
-    uint8_t* cx;                                 // this lane's 19 context bytes in LDS: state | mps << 7
-    const uint32_t* tab;                         // MQ table in LDS
-    uint32_t cxv, tabv;                          // kUniform: lane i holds context byte i / table entry i
+    uint32_t cxv, tabv;                          // lane i holds context byte i (state | mps << 7) / table entry i
     const uint8_t* lo; const uint8_t* hi;        // readable range of the coded buffer
-    uint32_t win[4], wbase;                      // kUniform: the 16 coded bytes [wbase, wbase + 16) of the segment
-    __device__ __forceinline__ uint32_t ctx_get(int i) const
-    {
-        if constexpr (kUniform) return (uint32_t)__builtin_amdgcn_readlane((int)cxv, i); else return cx[i];
-    }
-    __device__ __forceinline__ void ctx_set(int i, uint32_t v)
-    {
-        if constexpr (kUniform) cxv = threadIdx.x == (uint32_t)i ? v : cxv;        // (every lane is active)
-        else cx[i] = (uint8_t)v;
-    }
-    __device__ __forceinline__ uint32_t tab_get(uint32_t i) const
-    {
-        if constexpr (kUniform) return (uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)i); else return tab[i];
-    }
+    uint32_t win[4], wbase;                      // the 16 coded bytes [wbase, wbase + 16) of the segment
+    __device__ __forceinline__ uint32_t ctx_get(int i) const { return (uint32_t)__builtin_amdgcn_readlane((int)cxv, i); }
+    __device__ __forceinline__ void ctx_set(int i, uint32_t v) { cxv = threadIdx.x == (uint32_t)i ? v : cxv; }   // (every lane is active)
+    __device__ __forceinline__ uint32_t tab_get(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)i); }
     __device__ __forceinline__ void refill(uint32_t i)
     {   // 16 bytes from the dword-aligned address at or below d + i: one load per ~100 decisions instead of two
         // dependent byte loads per BYTEIN (each of which would also wait for every value store still in flight)
@@ -100,16 +80,11 @@ struct MqDec {
     }
     __device__ __forceinline__ uint32_t byte_at(uint32_t i)
     {   // block bytes followed by the artificial 0xFF 0xFF terminator (mqc_dec.cpp:113-118)
-        if constexpr (kWin) {
-            if (i >= len) return 0xFFu;
-            if (i - wbase >= 16u) refill(i);
-            const uint32_t o = i - wbase;
-            const uint32_t lo2 = (o & 8u) ? win[2] : win[0], hi2 = (o & 8u) ? win[3] : win[1];
-            return (((o & 4u) ? hi2 : lo2) >> ((o & 3u) * 8u)) & 0xFFu;
-        } else {
-            const uint8_t* p = d + i;
-            return (i < len && p >= lo && p < hi) ? *p : 0xFFu;
-        }
+        if (i >= len) return 0xFFu;
+        if (i - wbase >= 16u) refill(i);
+        const uint32_t o = i - wbase;
+        const uint32_t lo2 = (o & 8u) ? win[2] : win[0], hi2 = (o & 8u) ? win[3] : win[1];
+        return (((o & 4u) ? hi2 : lo2) >> ((o & 3u) * 8u)) & 0xFFu;
     }
     __device__ __forceinline__ void bytein()
     {
@@ -183,46 +158,31 @@ __device__ __forceinline__ uint32_t win3(uint64_t s, uint32_t x)
 
 __global__ void t1_dec_kernel(T1DecArgs a)
 {
-    __shared__ uint32_t mq_l[47];
-    __shared__ uint8_t ctx_l[kMaxLanes][20];
-    __shared__ uint64_t bm_l[4][66][kMaxLanes];
-    for (uint32_t i = threadIdx.x; i < 47; i += blockDim.x) mq_l[i] = g_mq_table[i];
-    __syncthreads();
-    const uint32_t tabv0 = threadIdx.x < 47 ? g_mq_table[threadIdx.x] : 0u;       // kUniform: Table C.2 across the lanes
-    // kUniform: all 64 lanes run the same (uniform) program -- lane-resident tables need every lane's registers to
-    // stay live through the compiler's copies -- and only lane 0 performs the side effects
-    const bool writer = !kUniform || threadIdx.x == 0;
-    const uint32_t L = kMaxLanes == 1 ? 1u : blockDim.x;
-    const uint32_t lane_i = kMaxLanes == 1 ? 0u : threadIdx.x;      // (one lane per workgroup: everything below is wave-uniform)
-    const uint32_t blk = blockIdx.x * L + lane_i;
+    __shared__ uint64_t bm_l[4][66];
+    const uint32_t tabv0 = threadIdx.x < 47 ? g_mq_table[threadIdx.x] : 0u;       // Table C.2 across the lanes
+    // all 64 lanes run the same (uniform) program -- lane-resident tables need every lane's registers to stay live
+    // through the compiler's copies -- and only lane 0 performs the side effects
+    const bool writer = threadIdx.x == 0;
+    const uint32_t blk = blockIdx.x;
     if (blk >= a.nblocks) return;
     const HtDecBlock in = a.table[blk];
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t orient = bd.pad;                        // 0 LL, 1 HL, 2 LH, 3 HH
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
-    // value workspace, transposed so that the lanes of a wave touch consecutive words: [group][y*64+x][lane]
-    int32_t* ws = a.work + (size_t)blockIdx.x * 4096u * L + lane_i;
+    // value workspace of the block, [y * 64 + x] (the first pass writes every row, K8b zeroes absent blocks)
+    int32_t* ws = a.work + (size_t)blockIdx.x * 4096u;
     if (in.length == 0 && in.missing_msbs == kSkipBlock) return;       // region decode: outside the decoded region
-    if constexpr (!kVreg)                                // (kUniform: the first pass writes every row, K8b zeroes absent blocks)
-        for (uint32_t y = 0; y < h; ++y)
-            for (uint32_t x = kUniform ? threadIdx.x : 0u; x < w; x += kUniform ? 64u : 1u) ws[(size_t)(y * 64u + x) * L] = 0;
     if (in.length == 0 || numpasses == 0 || numbps == 0) return;
     if (numbps >= 25u) { if (writer) atomicOr(a.status, 4u); return; }         // k_max_bit_planes (t1_common.h:70)
 
-    // row bitmaps with one border row above and below (index y + 1), [row][lane] so that lanes never share a bank
-    struct Rows {
-        uint64_t* p;
-        __device__ __forceinline__ uint64_t& operator[](uint32_t i) const { return p[i * kMaxLanes]; }
-    };
-    const Rows sig{&bm_l[0][0][lane_i]}, neg{&bm_l[1][0][lane_i]}, pi{&bm_l[2][0][lane_i]},
-               mu{&bm_l[3][0][lane_i]};
-    for (int i = kUniform ? (int)threadIdx.x : 0; i < 66; i += kUniform ? 64 : 1) { sig[i] = 0; neg[i] = 0; pi[i] = 0; mu[i] = 0; }
-    if (kUniform) __syncthreads();
+    // row bitmaps with one border row above and below (index y + 1)
+    uint64_t* const sig = bm_l[0]; uint64_t* const neg = bm_l[1]; uint64_t* const pi = bm_l[2]; uint64_t* const mu = bm_l[3];
+    for (int i = (int)threadIdx.x; i < 66; i += 64) { sig[i] = 0; neg[i] = 0; pi[i] = 0; mu[i] = 0; }
+    __syncthreads();
 
     MqDec mq;
     mq.lo = a.coded; mq.hi = a.coded + a.coded_bytes;
-    mq.cx = ctx_l[lane_i]; mq.tab = mq_l;
     mq.tabv = tabv0; mq.cxv = 0;
     mq.reset_states();
     const bool lazy = (a.cblksty & 0x01u) != 0, reset = (a.cblksty & 0x02u) != 0, vsc = (a.cblksty & 0x08u) != 0,
@@ -239,7 +199,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     auto dil = [](uint64_t v) { return v | (v << 1) | (v >> 1); };
 
     int bp = (int)numbps, type = 2;
-    bool first_pass = true;                                 // kUniform: nothing in the workspace yet
+    bool first_pass = true;                                 // nothing in the workspace yet
     const uint32_t tl = threadIdx.x;
     for (; sg < sg_end; ++sg) {
     const uint32_t seg_len = a.seg_first ? a.segs[sg].x : in.length, seg_passes = a.seg_first ? a.segs[sg].y : numpasses;
@@ -258,14 +218,12 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             for (int j = 0; j < 4; ++j) { P[j] = pi[k + 1 + j]; M[j] = mu[k + 1 + j]; }
             if (vsc) { S[5] = 0; N[5] = 0; }       // vertically causal: a stripe never sees the one below (T1.cpp:198-221)
             const uint32_t nr = min(4u, h - k);
-            // kUniform: the stripe's decoded values live in registers, lane <-> column: one coalesced row load at the
-            // start (not in the first pass) and one coalesced row store at the end instead of a store / an atomic per sample
+            // the stripe's decoded values live in registers, lane <-> column: one coalesced row load at the start (not
+            // in the first pass) and one coalesced row store at the end instead of a store / an atomic per sample
             int32_t V[4] = {0, 0, 0, 0};
-            if constexpr (kVreg) {
-                if (!first_pass) {
+            if (!first_pass) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) V[j] = ws[(k + j) * 64u + tl];
-                }
+                for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) V[j] = ws[(k + j) * 64u + tl];
             }
             // rows of the stripe that do not exist behave as "already coded"
             uint64_t rowok[4];
@@ -286,8 +244,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 else if (hc == 0) { cxn = vc == 0 ? 9 : 10; xr = vc == -1; }                                      \
                 else              { cxn = vc == 1 ? 11 : (vc == 0 ? 12 : 13); xr = 1; }                            \
                 const uint32_t ng = raw ? mq.raw_decode() : (mq.decode(cxn) ^ (uint32_t)xr);                      \
-                if constexpr (kVreg) { const int32_t sm = -(int32_t)ng; V[(j)] = tl == (x) ? (oph ^ sm) - sm : V[(j)]; } \
-                else if (writer) ws[(size_t)((k + (j)) * 64u + (x)) * L] = ng ? -oph : oph;                       \
+                { const int32_t sm = -(int32_t)ng; V[(j)] = tl == (x) ? (oph ^ sm) - sm : V[(j)]; }                \
                 S[(j) + 1] |= 1ull << (x);                                                                        \
                 if (ng) N[(j) + 1] |= 1ull << (x);                                                                \
             }
@@ -345,8 +302,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                         const uint32_t b = raw ? mq.raw_decode() : mq.decode(cxn);
                         const uint32_t isneg = (uint32_t)(N[j + 1] >> x) & 1u;   // the value's sign, without reading it back
                         const int32_t dm = (int32_t)(b ^ isneg) - 1, dv = (poshalf ^ dm) - dm;     // +half | -half
-                        if constexpr (kVreg) V[j] += tl == x ? dv : 0;
-                        else if (writer) atomicAdd(&ws[(size_t)((k + j) * 64u + x) * L], dv);
+                        V[j] += tl == x ? dv : 0;
                         M[j] |= 1ull << x;
                     }
                 }
@@ -383,10 +339,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 for (int j = 0; j < 4; ++j) P[j] = 0;                  // the plane is complete
             }
 #undef T1_SIGN_AND_SET
-            if constexpr (kVreg) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws[(k + j) * 64u + tl] = V[j];
-            }
+            for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws[(k + j) * 64u + tl] = V[j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (writer) { sig[k + 1 + j] = S[j + 1]; neg[k + 1 + j] = N[j + 1]; pi[k + 1 + j] = P[j]; mu[k + 1 + j] = M[j]; }
@@ -403,7 +357,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
 
 // K8b: workspace -> dequantise -> Mallat plane (one wavefront per code-block, lane <-> column)
 template <bool IRREV>
-__global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a, uint32_t L)
+__global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a)
 {
     const uint32_t blk = blockIdx.x, x = threadIdx.x;
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
@@ -412,12 +366,12 @@ __global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a, uint32_t L)
     const HtDecBlock in = a.table[blk];
     if (in.length == 0 && in.missing_msbs == kSkipBlock) return;
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
-    const bool absent = kVreg && (in.length == 0 || numpasses == 0 || numbps == 0 || numbps >= 25u);    // K8a wrote nothing
-    const int32_t* ws = a.work + (size_t)(blk / L) * 4096u * L + (blk % L);
+    const bool absent = in.length == 0 || numpasses == 0 || numbps == 0 || numbps >= 25u;    // K8a wrote nothing
+    const int32_t* ws = a.work + (size_t)blk * 4096u;
     int32_t* dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
     const float scale = bd.inv_step / 2;                            // ScaleFilter: stepsize / 2
     for (uint32_t y = 0; y < bd.h; ++y) {
-        const int32_t v = absent ? 0 : ws[(size_t)(y * 64u + x) * L];
+        const int32_t v = absent ? 0 : ws[y * 64u + x];
         int32_t o;
         if constexpr (IRREV) o = __float_as_int(__fmul_rn((float)v, scale));
         else o = v / 2;                                             // ShiftFilter: truncation toward zero
@@ -427,20 +381,13 @@ __global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a, uint32_t L)
 
 } // namespace
 
-uint32_t t1_lanes_per_group(uint32_t nblocks)
-{
-    (void)nblocks;
-    return kMaxLanes;
-}
-
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s)
 {
-    const uint32_t L = t1_lanes_per_group(a.nblocks);
-    hipLaunchKernelGGL(t1_dec_kernel, dim3((a.nblocks + L - 1) / L), dim3(kUniform ? 64u : L), 0, s, a);
+    hipLaunchKernelGGL(t1_dec_kernel, dim3(a.nblocks), dim3(64), 0, s, a);
     if (a.irreversible)
-        hipLaunchKernelGGL(t1_store_kernel<true>, dim3(a.nblocks), dim3(64), 0, s, a, L);
+        hipLaunchKernelGGL(t1_store_kernel<true>, dim3(a.nblocks), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL(t1_store_kernel<false>, dim3(a.nblocks), dim3(64), 0, s, a, L);
+        hipLaunchKernelGGL(t1_store_kernel<false>, dim3(a.nblocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -161,7 +161,10 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
     std::memset(&p, 0, sizeof p);
     p.tile_w = w; p.tile_h = h; p.num_comps = (uint16_t)comps; p.prec = (uint8_t)prec; p.sgnd = 0;
     p.irreversible = cp->irreversible ? 1 : 0;
-    p.mct = cp->tcp_mct ? 1 : 0;
+    // tcp_mct as grk_compress leaves it: 255 = "not set" (the library then applies RCT/ICT to >= 3 components,
+    // CodeStreamCompress.cpp:345-352), 0 / 1 as given, 2 = custom array MCT (mct_data) -- outside the hot path
+    if (cp->tcp_mct == 2 || cp->mct_data) return false;
+    p.mct = cp->tcp_mct == 255 ? (comps >= 3 ? 1 : 0) : (cp->tcp_mct ? 1 : 0);
     p.num_levels = (uint8_t)(cp->numresolution - 1);
     p.cblk_w_exp = (uint8_t)lg(cp->cblockw_init ? cp->cblockw_init : 64);
     p.cblk_h_exp = (uint8_t)lg(cp->cblockh_init ? cp->cblockh_init : 64);
@@ -195,6 +198,65 @@ int32_t encode_file(gra_cparameters* cp, const char* in, const char* out, gra_en
 // ---- batch mode: a worker thread walks the input directory ----------------------------------------
 std::thread g_batch;
 std::atomic<bool> g_batch_done{true}, g_batch_stop{false};
+
+// ---- the stream's own main header: QCD (guard bits, exponents) and the file size ---------------------------------
+// The host hands a plugin every block's numbps but not the band's (plugin_bridge.cpp:63-76), and the HT decoder needs
+// their difference (missing_msbs).  Grok's own HT streams carry the exponents of HTParams.cpp:248-312 with one guard bit
+// (D4 included), which is what grk_amd_tile_layout models; another encoder's stream need not.  So the band numbps come
+// from the codestream itself: the file `grk_decompress -i` names in parameters->infile.
+struct StreamHeader {
+    uint64_t file_size = 0;
+    uint32_t guard_bits = 0, qstyle = 0;
+    std::vector<uint16_t> words;          // SPqcd values in band order (8-bit expn << 3 for style 0)
+    bool overrides = false;               // QCC / COC / RGN / POC in the main header: per-component deviations
+};
+bool read_stream_header(const char* path, StreamHeader& h)
+{
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::vector<uint8_t> b(1u << 20);
+    b.resize(std::fread(b.data(), 1, b.size(), f));
+    bool ok = std::fseek(f, 0, SEEK_END) == 0;
+    const long sz = std::ftell(f);
+    std::fclose(f);
+    if (!ok || sz <= 0) return false;
+    h.file_size = (uint64_t)sz;
+    size_t at = 0;
+    auto be16 = [&](size_t i) { return (uint32_t)(b[i] << 8 | b[i + 1]); };
+    auto be32 = [&](size_t i) { return (uint32_t)b[i] << 24 | (uint32_t)b[i + 1] << 16 | (uint32_t)b[i + 2] << 8 | b[i + 3]; };
+    if (b.size() >= 12 && be32(0) == 12 && be32(4) == 0x6A502020u) {          // JP2: walk the boxes to the codestream
+        for (;;) {
+            if (at + 8 > b.size()) return false;
+            uint64_t len = be32(at);
+            const uint32_t type = be32(at + 4);
+            size_t hdr = 8;
+            if (len == 1) { if (at + 16 > b.size()) return false; len = (uint64_t)be32(at + 8) << 32 | be32(at + 12); hdr = 16; }
+            if (type == 0x6A703263u) { at += hdr; break; }                    // 'jp2c'
+            if (len < hdr) return false;                                      // (0 = to the end of the file: no codestream box follows)
+            at += len;
+        }
+    }
+    if (at + 4 > b.size() || be16(at) != 0xFF4F) return false;
+    at += 2;
+    bool have_qcd = false;
+    while (at + 4 <= b.size()) {
+        const uint32_t m = be16(at), len = be16(at + 2);
+        if (m == 0xFF90 || m == 0xFF93) break;                                // SOT / SOD: end of the main header
+        if (m < 0xFF00 || len < 2 || at + 2 + len > b.size()) return false;
+        const size_t d = at + 4, n = len - 2;
+        if (m == 0xFF5C && n >= 1) {                                          // QCD
+            h.guard_bits = b[d] >> 5; h.qstyle = b[d] & 0x1Fu;
+            h.words.clear();
+            if (h.qstyle == 0) for (size_t i = 1; i < n; ++i) h.words.push_back(b[d + i]);
+            else for (size_t i = 1; i + 1 < n; i += 2) h.words.push_back((uint16_t)be16(d + i));
+            have_qcd = true;
+        } else if (m == 0xFF5D || m == 0xFF53 || m == 0xFF5E || m == 0xFF5F) {
+            h.overrides = true;
+        }
+        at += 2 + len;
+    }
+    return have_qcd;
+}
 
 // ---- decode: the callback record of plugin_decompress (plugin/plugin_interface.h:86-130).  C++ on purpose -- it
 //      carries two std::string members, so it is no C ABI; plugin and host must share one libstdc++.  Its layout is
@@ -252,6 +314,14 @@ int32_t decompress_file(void* params, DecodeUserCallback cb)
     if (cb(&info) != 0 || !g_dec_image) return clean(-1);
     const gra_header_info& h = g_dec_header;
     gra_image* img = g_dec_image;
+    // the stream's main header, from the file the host was pointed at (grk_decompress -i: parameters->infile,
+    // grk_decompress.cpp:552).  A host that decodes from memory gives us nothing to read it from: declined.
+    StreamHeader sh;
+    {
+        const gra_decompress_parameters_head* dp = static_cast<const gra_decompress_parameters_head*>(params);
+        const char* path = !dp ? nullptr : dp->infile[0] ? dp->infile : dp->core.infile[0] ? dp->core.infile : nullptr;
+        if (!path || !read_stream_header(path, sh) || sh.overrides) return clean(-1);
+    }
     // the scope of the hot path: one tile at the origin, equal full-resolution components, default
     // precincts, one codeword segment per block (the host's bridge throws on more); irreversible only for classic
     // blocks (the reference's own HT + 9/7 encoder is broken, D1: there is no stream to be compatible with)
@@ -280,13 +350,30 @@ int32_t decompress_file(void* params, DecodeUserCallback cb)
     if (grk_amd_tile_layout(&tp, layout.data(), (uint64_t)nb, nullptr) != nb) return clean(-1);
     // a tree whose blocks own buffers the host can copy into: nominal block area x 4 bytes, as the host allocates
     // for its own code-blocks (t1/T1Structs.cpp:292-307)
+    // The host copies getSegBuffersLen() bytes into a block's buffer without asking how large it is
+    // (plugin_bridge.cpp:69-71 copy_to_contiguous_buffer), so a crafted stream that signals a longer block writes past
+    // its slot.  No block is longer than the file it comes from: a tail of that size behind the last slot keeps every
+    // such write inside the allocation, and the lengths are checked against the slots after the Tier-2 callback.
     std::vector<grk_amd_coded_block> slots((size_t)nb);
+    std::vector<uint64_t> slot_cap((size_t)nb);
     uint64_t cap = 0;
     for (size_t i = 0; i < (size_t)nb; ++i) {
         slots[i].offset = cap; slots[i].length = 0; slots[i].missing_msbs = 0;
-        cap += (uint64_t)(layout[i].x1 - layout[i].x0) * (layout[i].y1 - layout[i].y0) * 4u + 16u;
+        slot_cap[i] = (uint64_t)(layout[i].x1 - layout[i].x0) * (layout[i].y1 - layout[i].y0) * 4u + 16u;
+        cap += slot_cap[i];
     }
-    gra_plugin_tile* tree = build_tree(tp, layout, slots, std::vector<uint8_t>(cap, 0));
+    // band numbps of an HT stream from ITS quantisation marker (reversible: 8-bit exponents; Quantizer.cpp:49-51)
+    std::vector<uint8_t> band_numbps;
+    if (!tp.reserved[0]) {
+        const size_t nbands = 3u * tp.num_levels + 1u;
+        if (sh.qstyle != 0 || sh.words.size() < nbands) return clean(-1);
+        for (size_t b = 0; b < nbands; ++b) {
+            const int v = (int)(sh.words[b] >> 3) + (int)sh.guard_bits - 1;
+            if (v < 1 || v > 31) return clean(-1);
+            band_numbps.push_back((uint8_t)v);
+        }
+    }
+    gra_plugin_tile* tree = build_tree(tp, layout, slots, std::vector<uint8_t>(cap + sh.file_size + 64, 0));
     for (auto* b : reinterpret_cast<TileOwner*>(tree)->block_ptr) { b->numBitPlanes = 0; b->numPasses = 0; }
     auto done = [&](int32_t rc) { grk_amd_plugin_tile_destroy(tree); return clean(rc); };
     info.tile = tree;
@@ -298,9 +385,15 @@ int32_t decompress_file(void* params, DecodeUserCallback cb)
     info.decompress_flags = GRA_DECODE_T2 | GRA_DECODE_POST_T1;
     tree->decompress_flags = GRA_DECODE_T2 | GRA_DECODE_POST_T1;
     if (cb(&info) != 0) return done(-1);
+    {
+        const auto& bl = reinterpret_cast<TileOwner*>(tree)->blocks;
+        for (size_t i = 0; i < (size_t)nb; ++i)
+            if (bl[i].compressedDataLength > slot_cap[i]) return done(-1);       // overran its slot: the CPU decoder takes it
+    }
     const size_t bps = (tp.prec + 7u) / 8u, npx = (size_t)tp.tile_w * tp.tile_h;
     std::vector<uint8_t> px(npx * tp.num_comps * bps);
-    if (grk_amd_plugin_tile_decode(g_ctx, &tp, tree, px.data(), 0) != GRK_AMD_OK) return done(-1);
+    if (grk_amd_plugin_tile_decode_qcd(g_ctx, &tp, tree, band_numbps.empty() ? nullptr : band_numbps.data(),
+                                       (uint32_t)band_numbps.size(), px.data(), 0) != GRK_AMD_OK) return done(-1);
     img = info.image ? info.image : img;
     for (uint16_t k = 0; k < img->numcomps; ++k) {
         gra_image_comp& ck = img->comps[k];
@@ -362,7 +455,14 @@ GRA_EXPORT void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile)
 GRA_EXPORT int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
                                           void* pixels, int pixels_on_device)
 {
+    return grk_amd_plugin_tile_decode_qcd(ctx, p, tile, nullptr, 0, pixels, pixels_on_device);
+}
+
+GRA_EXPORT int grk_amd_plugin_tile_decode_qcd(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
+                                              const uint8_t* band_numbps, uint32_t nbands, void* pixels, int pixels_on_device)
+{
     if (!ctx || !p || !tile || !pixels) return GRK_AMD_ERR_INVALID;
+    if (band_numbps && nbands != 3u * p->num_levels + 1u) return GRK_AMD_ERR_INVALID;
     const int64_t nb = grk_amd_tile_num_blocks(p);
     if (nb <= 0) return (int)(nb ? nb : GRK_AMD_ERR_UNSUPPORTED);
     std::vector<grk_amd_block> layout((size_t)nb);
@@ -390,7 +490,12 @@ GRA_EXPORT int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_p
                         row.length = cb->compressedData ? cb->compressedDataLength : 0;
                         const uint32_t nbp = (uint32_t)cb->numBitPlanes;
                         if (p->reserved[0]) row.missing_msbs = row.length ? (nbp | ((uint32_t)cb->numPasses << 8)) : 0;
-                        else row.missing_msbs = layout[i].kmax >= nbp ? layout[i].kmax - nbp : 0;   // band numbps - block numbps
+                        else {                                                // band numbps - block numbps
+                            const uint32_t bn = band_numbps ? band_numbps[layout[i].res ? 3u * layout[i].res - 2u + (layout[i].band - 1u) : 0u]
+                                                            : layout[i].kmax;
+                            if (row.length && nbp > bn) return GRK_AMD_ERR_INVALID;
+                            row.missing_msbs = row.length ? bn - nbp : 0;
+                        }
                         if (row.length) coded.insert(coded.end(), cb->compressedData, cb->compressedData + row.length);
                         coded.resize((coded.size() + 15u) & ~(size_t)15u);
                         ++i;

@@ -216,6 +216,23 @@ typedef struct gra_image {
     gra_image_comp* comps;
 } gra_image;
 typedef int (*gra_init_decompressors_func)(gra_header_info* header_info, gra_image* image);
+/* head of grk_decompress_parameters (grok.h:692-732 grk_dparameters, :754-760): the input path is all the plugin
+ * reads out of it -- plugin_decompress takes the stream's QCD and the file size from the file (see plugin.cpp) */
+typedef struct gra_dparameters {
+    uint8_t  cp_reduce;
+    uint16_t cp_layer;
+    char     infile[GRA_PATH_LEN], outfile[GRA_PATH_LEN];
+    int32_t  decod_format, cod_format;      /* GRK_SUPPORTED_FILE_FMT */
+    uint32_t DA_x0, DA_x1, DA_y0, DA_y1;
+    bool     m_verbose;
+    uint16_t tile_index;
+    uint32_t nb_tile_to_decompress, flags;
+    int32_t  tileCacheStrategy;             /* GRK_TILE_CACHE_STRATEGY */
+} gra_dparameters;
+typedef struct gra_decompress_parameters_head {
+    gra_dparameters core;
+    char infile[GRA_PATH_LEN], outfile[GRA_PATH_LEN];
+} gra_decompress_parameters_head;
 
 /* ---- minimal plugin framework registration (plugin/minpf_plugin.h:25-60) --------------------- */
 typedef struct gra_minpf_api_version { int32_t major, minor; } gra_minpf_api_version;
@@ -265,6 +282,12 @@ void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile);
  * Returns 0, or a negative GRK_AMD_ERR_* so that the host keeps its CPU decoder. */
 int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
                                void* pixels, int pixels_on_device);
+/* The same for an HT stream whose QCD is not the one this library's encoder writes (another encoder's guard bits or
+ * exponents): band_numbps[band] = expn_b + guard bits - 1 in QCD order (codestream/Quantizer.cpp:49-51), nbands =
+ * 3 * levels + 1 -- the HT decoder's missing_msbs is band numbps - block numbps (T1DecompressScheduler.cpp:59) and
+ * the host hands over block numbps only.  NULL / 0: the exponents of grk_amd_tile_layout (Grok's own HT streams). */
+int grk_amd_plugin_tile_decode_qcd(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
+                                   const uint8_t* band_numbps, uint32_t nbands, void* pixels, int pixels_on_device);
 
 #ifdef __cplusplus
 }

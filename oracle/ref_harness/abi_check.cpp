@@ -126,3 +126,11 @@ extern "C" size_t ref_decode_info_layout(int which)
 }
 
 extern "C" int ref_abi_mirror_checked(void) { return 1; }
+
+// decode parameters: the plugin reads the input path only (plugin.cpp: decompress_file)
+SAME_SIZE(gra_dparameters, grk_dparameters);
+SAME_OFF(gra_dparameters, grk_dparameters, infile); SAME_OFF(gra_dparameters, grk_dparameters, outfile);
+SAME_OFF(gra_dparameters, grk_dparameters, tileCacheStrategy);
+static_assert(offsetof(gra_decompress_parameters_head, core) == offsetof(grk_decompress_parameters, core), "core");
+static_assert(offsetof(gra_decompress_parameters_head, infile) == offsetof(grk_decompress_parameters, infile), "infile");
+static_assert(offsetof(gra_decompress_parameters_head, outfile) == offsetof(grk_decompress_parameters, outfile), "outfile");

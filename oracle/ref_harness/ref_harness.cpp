@@ -342,6 +342,8 @@ static bool host_compress_callback(grk_plugin_compress_user_callback_info* info)
 				comp->data[(size_t)y * comp->stride + x] = bps == 1 ? (int32_t)src[i] : (int32_t)((const uint16_t*)src)[i];
 			}
 	}
+	// "Decide if MCT should be used" (grk_compress.cpp:1817-1820): 255 = not set on the command line
+	if (info->compressor_parameters->tcp_mct == 255) info->compressor_parameters->tcp_mct = (image->numcomps >= 3) ? 1 : 0;
 	grk_stream* stream = grk_stream_create_mem_stream(g_cb_out, g_cb_cap, false, false);
 	grk_codec* codec = grk_compress_create(GRK_CODEC_J2K, stream);
 	bool ok = codec && grk_compress_init(codec, info->compressor_parameters, image) && grk_compress_start(codec) &&
@@ -361,6 +363,9 @@ int64_t ref_plugin_compress_file(const EncCfg* cfg, const uint8_t* pixels, const
 	fill_params(param, *cfg);
 	strncpy(param.infile, infile, GRK_PATH_LEN - 1);
 	strncpy(param.outfile, "mem.j2k", GRK_PATH_LEN - 1);
+	// grk_compress leaves tcp_mct at 255 ("not set") until its callback has loaded the image (grk_compress.cpp:1836,
+	// :1708-1720): REF_TCP_MCT=255 hands the plugin that sentinel, the callback below resolves it as the CLI does
+	if (const char* e = getenv("REF_TCP_MCT")) param.tcp_mct = (uint8_t)atoi(e);
 	g_cb_cfg = cfg; g_cb_pixels = pixels; g_cb_out = out; g_cb_cap = cap; g_cb_len = -100;
 	int32_t rc = grk_plugin_compress(&param, host_compress_callback);
 	if (rc != 0) return rc < 0 ? rc : -rc;
@@ -428,12 +433,16 @@ static int32_t host_decompress_callback(grk_plugin_decompress_callback_info* inf
 }
 
 // returns the plugin's answer (0 = decoded by the plugin), stages[] = how often each protocol stage was called
-int32_t ref_plugin_decompress(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, int32_t W, int32_t H, int32_t* stages)
+// infile: where the same bytes lie as a file (grk_decompress -i sets parameters->infile, grk_decompress.cpp:552; a plugin
+// may read the main header from it), or null
+int32_t ref_plugin_decompress(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, int32_t W, int32_t H, int32_t* stages,
+							  const char* infile)
 {
 	grk_decompress_parameters param;
 	memset(&param, 0, sizeof(param));
 	grk_decompress_set_default_params(&param.core);
 	param.decod_format = GRK_J2K_FMT;
+	if (infile) strncpy(param.infile, infile, GRK_PATH_LEN - 1);
 	g_dcb_j2k = j2k; g_dcb_len = len; g_dcb_out = out; g_dcb_C = C; g_dcb_W = W; g_dcb_H = H;
 	memset(g_dcb_stage, 0, sizeof(g_dcb_stage));
 	int32_t rc = grk_plugin_decompress(&param, host_decompress_callback);

@@ -176,17 +176,30 @@ def plugin_compress_file(pixels, prec, infile, numres=6, irrev=0):
     return out[:n].tobytes() if n >= 0 else int(n)
 
 
-def plugin_decompress(j2k, Cn, H, W):
+def plugin_decompress(j2k, Cn, H, W, as_file=True):
     """grk_plugin_decompress(params, host callback): Grok dlsym()s plugin_decompress in our .so and the two sides run the
-    decode protocol (header -> T2 into the plugin's tile tree -> plugin decodes -> post-T1 -> clean).
+    decode protocol (header -> T2 into the plugin's tile tree -> plugin decodes -> post-T1 -> clean).  as_file: the stream
+    also lies in a file named by parameters->infile, as with `grk_decompress -i` (the plugin reads the main header's QCD
+    and the file size from it; without a file it declines).
     -> ((C,H,W) int32 pixels, stage call counts) or (refusal code, stage call counts)."""
+    import tempfile
     L = lib()
     L.ref_plugin_decompress.restype = C.c_int32
-    L.ref_plugin_decompress.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.ref_plugin_decompress.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_char_p]
     buf = np.frombuffer(j2k, np.uint8).copy()
     out = np.zeros((Cn, H, W), np.int32)
     stages = np.zeros(4, np.int32)
-    rc = L.ref_plugin_decompress(buf.ctypes.data, buf.size, out.ctypes.data, Cn, W, H, stages.ctypes.data)
+    path = None
+    if as_file:
+        fd, path = tempfile.mkstemp(suffix=".j2k")
+        with os.fdopen(fd, "wb") as f:
+            f.write(bytes(j2k))
+    try:
+        rc = L.ref_plugin_decompress(buf.ctypes.data, buf.size, out.ctypes.data, Cn, W, H, stages.ctypes.data,
+                                     path.encode() if path else None)
+    finally:
+        if path:
+            os.unlink(path)
     return (out if rc == 0 else int(rc)), [int(v) for v in stages]
 
 

@@ -85,6 +85,68 @@ def test_decode_protocol_through_grok_loader(Cn, H, W, prec, numres, ht, sty, ir
 
 
 @needs_ref
+def test_file_protocol_with_mct_not_set_on_the_command_line(tmp_path, monkeypatch):
+    """grk_compress hands the plugin tcp_mct = 255 ("not set") unless -Y was given (grk_compress.cpp:1836; resolved
+    only inside its callback, :1817-1820): the plugin resolves it the same way -- grayscale is coded without MCT, RGB
+    with -- instead of declining every grayscale image.  tcp_mct = 2 (custom array MCT) is declined."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    monkeypatch.setenv("REF_TCP_MCT", "255")
+    for Cn in (1, 3):
+        px = synth.g2(Cn, 128, 192, 8)
+        path = str(tmp_path / ("m%d.%s" % (Cn, "pgm" if Cn == 1 else "ppm")))
+        R.write_pnm(path, px, 8)
+        got = R.plugin_compress_file(px, 8, path, numres=4)
+        assert not isinstance(got, int), "plugin refused: %s" % got
+        cpu, _ = R.encode(px, 8, numres=4, mode=1)
+        assert got == cpu
+    monkeypatch.setenv("REF_TCP_MCT", "2")
+    assert isinstance(R.plugin_compress_file(px, 8, path, numres=4), int)
+
+
+def _patch_guard_bits(cs, guard):
+    """The same codestream with another number of guard bits in QCD: band numbps = expn + G - 1 moves, the blocks'
+    zero-bit-plane counts in the packet headers stay, so every block's numbps moves with it and missing_msbs (their
+    difference, all the HT decoder uses) does not -- a legal stream with the same pixels, but not Grok's QCD."""
+    b = bytearray(cs)
+    i = b.index(b"\xff\x5c")
+    assert b[i + 4] >> 5 == 1
+    b[i + 4] = (b[i + 4] & 0x1F) | (guard << 5)
+    return bytes(b)
+
+
+@needs_ref
+@pytest.mark.parametrize("Cn,H,W,prec,numres", [(3, 192, 256, 8, 5), (1, 128, 128, 12, 4)])
+def test_decode_protocol_takes_band_numbps_from_the_stream(Cn, H, W, prec, numres):
+    """an HT stream whose QCD is not the one this library's encoder models (here: 2 and 3 guard bits) must
+    decode through the plugin to what grk_decompress makes of it -- the host hands over block numbps only, the band's
+    comes from the stream's own QCD marker, read from the file the host was pointed at."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    px = synth.g2(Cn, H, W, prec)
+    cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=1)
+    for guard in (2, 3):
+        alt = _patch_guard_bits(cs, guard)
+        ref = R.decode(alt, Cn, H, W)
+        assert np.array_equal(ref, px.astype(np.int32))
+        got, stages = R.plugin_decompress(alt, Cn, H, W)
+        assert not isinstance(got, int), "plugin refused: %s (stages %s)" % (got, stages)
+        assert np.array_equal(got, ref)
+
+
+@needs_ref
+def test_decode_protocol_declines_without_a_file_to_read_the_qcd_from():
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    px = synth.g2(1, 128, 128, 8)
+    cs, _ = R.encode(px, 8, numres=3, mode=1, ht=1)
+    got, stages = R.plugin_decompress(cs, 1, 128, 128, as_file=False)
+    assert isinstance(got, int) and got != 0 and stages[3] == 1
+    got, _ = R.plugin_decompress(cs, 1, 128, 128)
+    assert np.array_equal(got, px.astype(np.int32))
+
+
+@needs_ref
 def test_decode_protocol_declines_outside_the_hot_path():
     """HT + 9/7 streams (D1), multi-segment code-block styles and multi-tile images are answered with non-zero:
     the host keeps its CPU decoder (grk_decompress.cpp:953-955)."""

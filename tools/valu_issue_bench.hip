@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -19,35 +20,148 @@
 constexpr int kIters = 512;       // loop trips
 constexpr int kPerIter = 32;      // instructions of the measured kind per trip
 
-enum Op { AND, LSHL, FFBH, PKMIN, ADD, BFE, MUL24, PERM, DPP_ADD, CNDMASK, MIN, LSHL_OR, FMA, AND_OR, MBCNT, READLANE, BPERM, LDS_OR, NUM_OPS };
-static const char* kNames[NUM_OPS] = {"v_and_b32", "v_lshlrev_b32", "v_ffbh_i32", "v_pk_min_u16", "v_add_u32", "v_bfe_u32",
-                                      "v_mul_u32_u24", "v_perm_b32", "v_add_u32 dpp row_shr:1", "v_cndmask_b32", "v_min_u32",
-                                      "v_lshl_or_b32", "v_fma_f32", "v_and_or_b32", "v_mbcnt_lo_u32_b32", "v_readlane_b32 (->sgpr)",
-                                      "ds_bpermute_b32", "ds_or_b32 (atomic)"};
+enum Op { FMA, FMA3, MULF, ADDF, CVT, MOV, AND, ANDLIT, OR, XOR, NOT, ADD, SUB, ADDCO, LSHL, LSHLV, LSHR, ASHR, MIN, MAXI, FFBH, BFE, BFEI, BFEV, MUL24, MAD24, MULLO, PERM, ALIGNBIT, ADD3, OR3, MIN3, LSHL_ADD, LSHL_OR, AND_OR, BITOP3, LSHL64, LSHLADD64, PKMIN, PKADD, PKMAXI, PKLSHL, PKSUB, SDWA_ADD, SDWA_MIN16, CMP_VCC, CMP_SGPR, CND_VCC, CND_SGPR, CND_IMM, CMP_CND, MBCNT, DPP_ADD, DPP_QP, DPP_WSHR, DPP_WSHL, PERMLANE32, READLANE, READFIRST, SWIZZLE, BPERM, LDS_OR, LDS_RD32, LDS_RD64, LDS_WR32, LDS_WR64, NUM_OPS };
+static const char* kNames[NUM_OPS] = {
+    "v_fma_f32",
+    "v_fma_f32 (3 distinct srcs)",
+    "v_mul_f32",
+    "v_add_f32",
+    "v_cvt_f32_u32",
+    "v_mov_b32",
+    "v_and_b32",
+    "v_and_b32 (32-bit literal)",
+    "v_or_b32",
+    "v_xor_b32",
+    "v_not_b32",
+    "v_add_u32",
+    "v_sub_u32",
+    "v_add_co_u32 (writes vcc)",
+    "v_lshlrev_b32",
+    "v_lshlrev_b32 (vgpr amount)",
+    "v_lshrrev_b32",
+    "v_ashrrev_i32",
+    "v_min_u32",
+    "v_max_i32",
+    "v_ffbh_i32",
+    "v_bfe_u32",
+    "v_bfe_i32",
+    "v_bfe_u32 (vgpr width)",
+    "v_mul_u32_u24",
+    "v_mad_u32_u24",
+    "v_mul_lo_u32",
+    "v_perm_b32",
+    "v_alignbit_b32",
+    "v_add3_u32",
+    "v_or3_b32",
+    "v_min3_u32",
+    "v_lshl_add_u32",
+    "v_lshl_or_b32",
+    "v_and_or_b32",
+    "v_bitop3_b32",
+    "v_lshlrev_b64",
+    "v_lshl_add_u64",
+    "v_pk_min_u16",
+    "v_pk_add_u16",
+    "v_pk_max_i16",
+    "v_pk_lshlrev_b16",
+    "v_pk_sub_i16",
+    "v_add_u32_sdwa (BYTE_1 + WORD_1)",
+    "v_min_u16_sdwa",
+    "v_cmp_ne_u32 -> vcc",
+    "v_cmp_ne_u32_e64 -> sgpr pair",
+    "v_cndmask_b32 (vcc, set before the loop)",
+    "v_cndmask_b32_e64 (sgpr pair)",
+    "v_cndmask_b32_e64 0, 1 (sgpr pair)",
+    "v_cmp_ne_u32 vcc + v_cndmask (2 instr)",
+    "v_mbcnt_lo_u32_b32",
+    "v_add_u32 dpp row_shr:1",
+    "v_mov_b32 dpp quad_perm:[1,0,3,2]",
+    "v_mov_b32 dpp wave_shr:1",
+    "v_mov_b32 dpp wave_shl:1",
+    "v_permlane32_swap_b32",
+    "v_readlane_b32 (-> sgpr)",
+    "v_readfirstlane_b32",
+    "ds_swizzle_b32 (swap halves of 32? no: qdmode)",
+    "ds_bpermute_b32",
+    "ds_or_b32 (atomic)",
+    "ds_read_b32",
+    "ds_read_b64",
+    "ds_write_b32",
+    "ds_write_b64"};
 
+// operands of the templates: the accumulator (chain register), a loop-invariant VGPR (also a valid LDS byte address /
+// lane address), an SGPR pair (written by the -> sgpr forms), a 64-bit accumulator pair
 template <int OP, int ILP>
-__device__ __forceinline__ void one(uint32_t& a, uint32_t b, uint32_t* lds)
+__device__ __forceinline__ void one(uint32_t& a, uint32_t b, uint64_t& m, uint64_t& w, uint32_t& sc)
 {
-    if constexpr (OP == AND)      asm volatile("v_and_b32 %0, %1, %0" : "+v"(a) : "v"(b));
-    if constexpr (OP == LSHL)     asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a));
-    if constexpr (OP == FFBH)     asm volatile("v_ffbh_i32 %0, %0" : "+v"(a));
-    if constexpr (OP == PKMIN)    asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a) : "v"(b));
-    if constexpr (OP == ADD)      asm volatile("v_add_u32 %0, %1, %0" : "+v"(a) : "v"(b));
-    if constexpr (OP == BFE)      asm volatile("v_bfe_u32 %0, %0, 1, 31" : "+v"(a));
-    if constexpr (OP == MUL24)    asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(a) : "v"(b));
-    if constexpr (OP == PERM)     asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
-    if constexpr (OP == DPP_ADD && ILP > 1)  asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a));
     // (a VALU write followed by a DPP read of the same register needs two wait states: the dependent chain pays them)
-    if constexpr (OP == DPP_ADD && ILP == 1) asm volatile("s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a));
-    if constexpr (OP == CNDMASK)  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b));
-    if constexpr (OP == MIN)      asm volatile("v_min_u32 %0, %1, %0" : "+v"(a) : "v"(b));
-    if constexpr (OP == LSHL_OR)  asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a) : "v"(b));
-    if constexpr (OP == FMA)      asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
-    if constexpr (OP == AND_OR)   asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
-    if constexpr (OP == MBCNT)    asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a) : "v"(b));
-    if constexpr (OP == READLANE) { uint32_t s; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s) : "v"(a)); asm volatile("" :: "s"(s)); }
-    if constexpr (OP == BPERM)    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(8)" : "+v"(a) : "v"(b));
-    if constexpr (OP == LDS_OR)   asm volatile("ds_or_b32 %0, %1\n s_waitcnt lgkmcnt(8)" :: "v"(b), "v"(a) : "memory");
+    if constexpr (ILP == 1 && (OP == DPP_ADD || OP == DPP_QP || OP == DPP_WSHR || OP == DPP_WSHL || OP == PERMLANE32)) asm volatile("s_nop 1");
+    if constexpr (OP == FMA) asm volatile("v_fma_f32 %0, %0, %4, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == FMA3) asm volatile("v_fma_f32 %0, %0, %4, 2.0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MULF) asm volatile("v_mul_f32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == ADDF) asm volatile("v_add_f32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == CVT) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MOV) asm volatile("v_mov_b32 %0, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == AND) asm volatile("v_and_b32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == ANDLIT) asm volatile("v_and_b32 %0, 0x1ffffffc, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == OR) asm volatile("v_or_b32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == XOR) asm volatile("v_xor_b32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == NOT) asm volatile("v_not_b32 %0, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == ADD) asm volatile("v_add_u32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == SUB) asm volatile("v_sub_u32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == ADDCO) asm volatile("v_add_co_u32 %0, vcc, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LSHLV) asm volatile("v_lshlrev_b32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LSHR) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == ASHR) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MIN) asm volatile("v_min_u32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MAXI) asm volatile("v_max_i32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == FFBH) asm volatile("v_ffbh_i32 %0, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == BFE) asm volatile("v_bfe_u32 %0, %0, 1, 31" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == BFEI) asm volatile("v_bfe_i32 %0, %0, 1, 31" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == BFEV) asm volatile("v_bfe_u32 %0, %0, 0, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MUL24) asm volatile("v_mul_u32_u24 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MAD24) asm volatile("v_mad_u32_u24 %0, %0, %4, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MULLO) asm volatile("v_mul_lo_u32 %0, %0, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == PERM) asm volatile("v_perm_b32 %0, %0, %4, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %4, 7" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == ADD3) asm volatile("v_add3_u32 %0, %0, %4, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == OR3) asm volatile("v_or3_b32 %0, %0, %4, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MIN3) asm volatile("v_min3_u32 %0, %0, %4, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == AND_OR) asm volatile("v_and_or_b32 %0, %0, %4, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %4, %4 bitop3:0xc8" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LSHL64) asm volatile("v_lshlrev_b64 %2, 1, %2" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LSHLADD64) asm volatile("v_lshl_add_u64 %2, %2, 0, %2" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == PKMIN) asm volatile("v_pk_min_u16 %0, %0, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == PKADD) asm volatile("v_pk_add_u16 %0, %0, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == PKMAXI) asm volatile("v_pk_max_i16 %0, %0, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == PKLSHL) asm volatile("v_pk_lshlrev_b16 %0, 1, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == PKSUB) asm volatile("v_pk_sub_i16 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == SDWA_ADD) asm volatile("v_add_u32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:WORD_1" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == SDWA_MIN16) asm volatile("v_min_u16_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == CMP_VCC) asm volatile("v_cmp_ne_u32 vcc, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == CMP_SGPR) asm volatile("v_cmp_ne_u32_e64 %1, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == CND_VCC) asm volatile("v_cndmask_b32 %0, %0, %4, vcc" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == CND_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %4, %1" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == CND_IMM) asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == CMP_CND) asm volatile("v_cmp_ne_u32 vcc, %4, %0\n v_cndmask_b32 %0, %0, %4, vcc" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MBCNT) asm volatile("v_mbcnt_lo_u32_b32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == DPP_ADD) asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == DPP_QP) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == DPP_WSHR) asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == DPP_WSHL) asm volatile("v_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == PERMLANE32) asm volatile("v_permlane32_swap_b32 %0, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == READLANE) asm volatile("v_readlane_b32 %3, %0, 3" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == READFIRST) asm volatile("v_readfirstlane_b32 %3, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == SWIZZLE) asm volatile("ds_swizzle_b32 %0, %0 offset:0x8055\n s_waitcnt lgkmcnt(8)" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == BPERM) asm volatile("ds_bpermute_b32 %0, %4, %0\n s_waitcnt lgkmcnt(8)" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LDS_OR) asm volatile("ds_or_b32 %4, %0\n s_waitcnt lgkmcnt(8)" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LDS_RD32) asm volatile("ds_read_b32 %0, %4\n s_waitcnt lgkmcnt(8)" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LDS_RD64) asm volatile("ds_read_b64 %2, %4\n s_waitcnt lgkmcnt(8)" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LDS_WR32) asm volatile("ds_write_b32 %4, %0\n s_waitcnt lgkmcnt(8)" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == LDS_WR64) asm volatile("ds_write_b64 %4, %2\n s_waitcnt lgkmcnt(8)" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
 }
 
 // ILP = number of independent accumulators the kPerIter instructions of a trip are spread over
@@ -59,22 +173,28 @@ __global__ __launch_bounds__(1024) void bench(uint64_t* cycles, uint32_t* sink, 
     uint32_t acc[ILP];
 #pragma unroll
     for (int i = 0; i < ILP; ++i) acc[i] = seed * (threadIdx.x + 3) + i;
-    uint32_t b = (threadIdx.x * 4u) & 0xFCu;          // a valid LDS byte address / bpermute lane address / operand
+    uint32_t b = (threadIdx.x * 8u) & 0x1F8u;         // a valid LDS byte address / bpermute lane address / operand
+    uint64_t m = 0x5555555555555555ull, w[ILP];
+    uint32_t sc = seed;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) w[i] = acc[i];
     if (OP == LDS_OR) {
 #pragma unroll
         for (int i = 0; i < ILP; ++i) acc[i] = 1u << i;
     }
+    asm volatile("v_cmp_gt_u32 vcc, 40, %0" :: "v"(b) : "vcc");
     __syncthreads();
     const uint64_t t0 = __builtin_readcyclecounter();
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
-        for (int j = 0; j < kPerIter; ++j) one<OP, ILP>(acc[j % ILP], b, lds);
+        for (int j = 0; j < kPerIter; ++j) one<OP, ILP>(acc[j % ILP], b, m, w[j % ILP], sc);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const uint64_t t1 = __builtin_readcyclecounter();
     uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < ILP; ++i) s ^= acc[i];
+    for (int i = 0; i < ILP; ++i) s ^= acc[i] ^ (uint32_t)w[i] ^ (uint32_t)(w[i] >> 32);
+    s ^= (uint32_t)m ^ sc;
     if (s == 0x12345678u) sink[0] = s + lds[b >> 2];
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
@@ -124,7 +244,7 @@ __global__ void clock_probe(uint64_t* out)
     out[0] = __builtin_readcyclecounter() - c0; out[1] = wall_clock64() - r0;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     uint64_t* d_cycles; uint32_t* d_sink;
     CHECK(hipMalloc(&d_cycles, 8 * 65536 * 16)); CHECK(hipMalloc(&d_sink, 64));
@@ -142,8 +262,73 @@ int main()
     const double ghz = prop.clockRate / 1e6;
     if (smem_ghz < 0.5 * ghz) printf("NOTE: s_memtime is a constant clock here: multiply the in-wave columns by %.2f for shader cycles at %.0f MHz\n", ghz / smem_ghz, ghz * 1e3);
     bool header = false;
-#define RUN(OP) do { if (run<OP, 8>(d_cycles, d_sink, ghz, header)) return 1; if (run<OP, 1>(d_cycles, d_sink, ghz, header)) return 1; } while (0)
-    RUN(FMA); RUN(AND); RUN(ADD); RUN(LSHL); RUN(MIN); RUN(FFBH); RUN(PKMIN); RUN(BFE); RUN(MUL24); RUN(PERM);
-    RUN(LSHL_OR); RUN(AND_OR); RUN(CNDMASK); RUN(MBCNT); RUN(DPP_ADD); RUN(READLANE); RUN(BPERM); RUN(LDS_OR);
+    const char* only = argc > 1 ? argv[1] : nullptr;
+#define RUN(OP) do { if (!only || strstr(kNames[OP], only)) { if (run<OP, 8>(d_cycles, d_sink, ghz, header)) return 1; if (run<OP, 1>(d_cycles, d_sink, ghz, header)) return 1; } } while (0)
+    RUN(FMA);
+    RUN(FMA3);
+    RUN(MULF);
+    RUN(ADDF);
+    RUN(CVT);
+    RUN(MOV);
+    RUN(AND);
+    RUN(ANDLIT);
+    RUN(OR);
+    RUN(XOR);
+    RUN(NOT);
+    RUN(ADD);
+    RUN(SUB);
+    RUN(ADDCO);
+    RUN(LSHL);
+    RUN(LSHLV);
+    RUN(LSHR);
+    RUN(ASHR);
+    RUN(MIN);
+    RUN(MAXI);
+    RUN(FFBH);
+    RUN(BFE);
+    RUN(BFEI);
+    RUN(BFEV);
+    RUN(MUL24);
+    RUN(MAD24);
+    RUN(MULLO);
+    RUN(PERM);
+    RUN(ALIGNBIT);
+    RUN(ADD3);
+    RUN(OR3);
+    RUN(MIN3);
+    RUN(LSHL_ADD);
+    RUN(LSHL_OR);
+    RUN(AND_OR);
+    RUN(BITOP3);
+    RUN(LSHL64);
+    RUN(LSHLADD64);
+    RUN(PKMIN);
+    RUN(PKADD);
+    RUN(PKMAXI);
+    RUN(PKLSHL);
+    RUN(PKSUB);
+    RUN(SDWA_ADD);
+    RUN(SDWA_MIN16);
+    RUN(CMP_VCC);
+    RUN(CMP_SGPR);
+    RUN(CND_VCC);
+    RUN(CND_SGPR);
+    RUN(CND_IMM);
+    RUN(CMP_CND);
+    RUN(MBCNT);
+    RUN(DPP_ADD);
+    RUN(DPP_QP);
+    RUN(DPP_WSHR);
+    RUN(DPP_WSHL);
+    RUN(PERMLANE32);
+    RUN(READLANE);
+    RUN(READFIRST);
+    RUN(SWIZZLE);
+    RUN(BPERM);
+    RUN(LDS_OR);
+    RUN(LDS_RD32);
+    RUN(LDS_RD64);
+    RUN(LDS_WR32);
+    RUN(LDS_WR64);
     return 0;
 }
