@@ -140,35 +140,41 @@ int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
             d.inv_step = 1.0f / b.stepsize;
             c->h_desc.push_back(d);
         }
-    // K3 block classes = {top resolution, the rest} x {LDS need small, large}, each its own launch: (1) a launch's
-    // LDS buffers are sized for its largest Kmax, and the LDS per wave is what fixes the occupancy (16 waves per CU
-    // need <= 10 KiB each; the few high-Kmax blocks would otherwise cost every block a wave per SIMD); (2) the top
-    // resolution's sub-bands (3/4 of all blocks) are final after DWT level 0, so they are coded beside the remaining
-    // levels (run_dwt, overlap).  Few classes on purpose: a launch ends with a tail of long-running waves, and
-    // launches on one stream do not overlap (measured: one class per resolution costs 0.15 ms at 8K).
+    // K3 block classes, each its own launch: the top resolution's sub-bands (3/4 of all blocks) are final after DWT
+    // level 0, so they are coded beside the remaining levels (run_dwt, overlap), the rest after the last level; a third
+    // class holds ALL blocks, for when nothing overlaps (one launch, one tail).  The LDS buffers of a launch are sized
+    // for what the class's typical block needs (capped, kernels_ht.hip) -- the LDS per wave is what fixes the occupancy
+    // -- and the blocks that outgrow them, e.g. the few high-Kmax blocks of the low resolutions, go through the fallback
+    // launch.  Only with GRK_AMD_LDS_CAP=0 (worst-case buffers, no fallback) are the large-LDS blocks classes of their
+    // own, so that they do not cost every block a wave per SIMD.  Few classes on purpose: a launch ends with a tail of
+    // long-running waves, and launches on one stream do not overlap (measured: one class per resolution costs 0.15 ms at 8K).
     {
         constexpr size_t kLdsFor16Waves = 10240;
         std::vector<uint32_t> sel;
         std::vector<HtClass> cls;
         std::vector<size_t> first;
         std::vector<uint8_t> ctop, cbig;
-        for (int top = 1; top >= 0; --top)
-            for (int big = 0; big < 2; ++big) {
-                HtClass cl{nullptr, 0, 0, 0, 0, 0};
-                const size_t at = sel.size();
-                for (uint32_t i = 0; i < c->h_desc.size(); ++i) {
-                    if ((int)(h_res[i] == g.p.num_levels && g.p.num_levels >= 1) != top) continue;
-                    const HtBlockDesc& d = c->h_desc[i];
-                    const uint32_t samples = (uint32_t)d.w * d.h, quads = ((d.w + 1u) / 2u) * ((d.h + 1u) / 2u);
-                    if ((int)(ht_lds_bytes(samples, quads, d.kmax) > kLdsFor16Waves) != big) continue;
-                    cl.count++;
-                    cl.max_kmax = std::max<uint32_t>(cl.max_kmax, d.kmax);
-                    cl.max_samples = std::max<uint32_t>(cl.max_samples, samples);
-                    cl.max_quads = std::max<uint32_t>(cl.max_quads, quads);
-                    sel.push_back(i);
-                }
-                if (cl.count) { cls.push_back(cl); first.push_back(at); ctop.push_back((uint8_t)top); cbig.push_back((uint8_t)big); }
+        auto add_class = [&](int top, int big) {       // top: 1 top resolution, 0 the rest, 2 every block;  big: -1 any, 0 / 1 by LDS need
+            HtClass cl{nullptr, 0, 0, 0, 0, 0, 0};
+            const size_t at = sel.size();
+            uint32_t hist[64] = {0};
+            for (uint32_t i = 0; i < c->h_desc.size(); ++i) {
+                if (top != 2 && (int)(h_res[i] == g.p.num_levels && g.p.num_levels >= 1) != top) continue;
+                const HtBlockDesc& d = c->h_desc[i];
+                const uint32_t samples = (uint32_t)d.w * d.h, quads = ((d.w + 1u) / 2u) * ((d.h + 1u) / 2u);
+                if (big >= 0 && (int)(ht_lds_bytes(samples, quads, d.kmax) > kLdsFor16Waves) != big) continue;
+                cl.count++;
+                cl.max_kmax = std::max<uint32_t>(cl.max_kmax, d.kmax);
+                cl.max_samples = std::max<uint32_t>(cl.max_samples, samples);
+                cl.max_quads = std::max<uint32_t>(cl.max_quads, quads);
+                hist[d.kmax & 63u] += samples;
+                sel.push_back(i);
             }
+            for (uint32_t k = 0; k < 64; ++k) if (hist[k] > hist[cl.cap_kmax]) cl.cap_kmax = k;     // where most of the samples are
+            if (cl.count) { cls.push_back(cl); first.push_back(at); ctop.push_back((uint8_t)top); cbig.push_back((uint8_t)(big > 0)); }
+        };
+        if (c->lds_cap) { add_class(1, -1); add_class(0, -1); add_class(2, -1); }
+        else { add_class(1, 0); add_class(1, 1); add_class(0, 0); add_class(0, 1); }
         HIP_TRY(c, c->ht_sel.ensure(sel.size() * 4 + 16), "alloc class index");
         HIP_TRY(c, hipMemcpyAsync(c->ht_sel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, c->stream), "upload class index");
         HIP_TRY(c, hipStreamSynchronize(c->stream), "sync class index");
@@ -339,6 +345,7 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
             if (rc) return rc;
             HIP_TRY(c, hipEventRecord(c->ev_level0, c->stream), "record level");
             for (uint32_t k = 0; k < h.num_classes; ++k) {
+                if (c->ht_class_top[k] == 2) continue;               // (the all-blocks class is for the non-overlapped path)
                 const bool top = c->ht_class_top[k] != 0, big = c->ht_class_big[k] != 0;
                 hipStream_t st = nullptr;
                 if (l == 0 && top) st = big ? c->side2 : c->side;
@@ -567,7 +574,7 @@ HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* 
     a.arena = (uint8_t*)c->arena.p; a.arena_bytes = c->arena.cap;
     a.alloc = (unsigned long long*)c->flag.p;        // [0] status flags, [1] bytes used (launch_ht_alloc_init resets them)
     a.lengths = (uint32_t*)c->lengths.p; a.offsets = (unsigned long long*)c->offsets.p;
-    try_(c->ovf.ensure(nblocks * 4 + 16), "alloc fallback list");
+    try_(c->ovf.ensure(2 * nblocks * 4 + 16), "alloc fallback list");      // (every block is in two classes)
     a.ovf_list = c->lds_cap ? (uint32_t*)c->ovf.p : nullptr;
     a.region_mask = regions - 1;
     a.irreversible = g.p.irreversible;
@@ -589,9 +596,12 @@ int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, bool overlappe
     if (rc) return rc;
     {
         ScopedTimer t(c, 2);
-        if (!overlapped) {
+        if (!overlapped) {         // one launch of every block where there is such a class, else class by class
             HIP_TRY(c, launch_ht_alloc_init(a, c->stream), "reset arena allocator");
-            HIP_TRY(c, launch_ht_classes(a, 0, a.num_classes, c->stream), "launch ht encode");
+            bool all = false;
+            for (uint32_t k = 0; k < a.num_classes; ++k) all = all || c->ht_class_top[k] == 2;
+            for (uint32_t k = 0; k < a.num_classes; ++k)
+                if ((c->ht_class_top[k] == 2) == all) HIP_TRY(c, launch_ht_classes(a, k, k + 1, c->stream), "launch ht encode");
         } else {
             for (uint32_t k = 0; k < a.num_classes && !c->pipelining; ++k)
                 if (!c->ht_class_top[k] && !c->ht_class_big[k]) HIP_TRY(c, launch_ht_classes(a, k, k + 1, c->stream), "launch ht encode");

@@ -54,8 +54,9 @@ constexpr uint32_t kHtMaxClasses = 24;      // (resolution, LDS need): up to 10 
 struct HtClass {
     const uint32_t* sel;      // device: indices (within a tile) of the blocks of this class; nullptr = all blocks in order
     uint32_t count;
-    uint32_t max_kmax, max_samples, max_quads;   // extents that size the class's LDS buffers
+    uint32_t max_kmax, max_samples, max_quads;   // extents that size the class's worst-case LDS buffers
     uint32_t ovf_base;        // first entry of the class's part of HtArgs::ovf_list
+    uint32_t cap_kmax;        // the exponent most of the class's samples have: sizes the capped LDS buffers
 };
 struct HtArgs {
     const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp] (stride, pitch in elements)
@@ -72,6 +73,7 @@ struct HtArgs {
                                                 // by the fallback launch.  nullptr: worst-case buffers, no fallback
     HtClass classes[kHtMaxClasses]; uint32_t num_classes;   // block classes of a tile (= resolutions, finest first), each launched on its own
     uint32_t region_mask;         // (power of two <= kHtAllocRegions) - 1: block i allocates from region i & mask
+    const uint32_t* vlc_tab;      // the CxtVLC encode table on the device (set by launch_ht_classes)
     int irreversible;
 };
 size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax);

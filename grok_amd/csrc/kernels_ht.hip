@@ -33,6 +33,7 @@ namespace {
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 // MEL exponents E[k], k = 0..12 = {0,0,0,1,1,1,2,2,2,3,3,4,5} (ojph_block_encoder.cpp:226), one nibble each
 constexpr uint64_t kMelE = 0x5433222111000ull;
@@ -41,8 +42,9 @@ constexpr uint64_t kMelE = 0x5433222111000ull;
 //   g_vlc_enc[0..2047]    first quad row : index (c_q<<8)|(rho<<4)|eps
 //   g_vlc_enc[2048..4095] other rows     : index (ctx<<8)|(rho<<4)|eps with ctx = n_w | rl<<1 | n_e<<2,
 //                                          n_w/n_e = "both upper neighbours insignificant" flags
-//   entry = (cwd<<8)|(len<<4)|e_k
-__device__ uint16_t g_vlc_enc[4096];
+//   entry = cwd << 20 | len << 4 | e_k spread as the kernel's packed arithmetic wants it: bit 0 sample 0, bit 1 sample 1,
+//           bit 16 sample 2, bit 17 sample 3
+__device__ uint32_t g_vlc_enc[4096];
 //   g_uvlc[u] : x = pre<<8 | suf<<16, y = pre_len<<8 | suf_len<<16 (ojph_block_encoder.cpp:189-210);
 //   entries 33,34: the 1-bit code (u-1) of the second quad in the first-row "u0>2, u1 in 1..2" mode
 __device__ uint2 g_uvlc[64];
@@ -115,6 +117,52 @@ __device__ __forceinline__ uint32_t ffbh_i32(uint32_t t)
 {
     uint32_t r;
     asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(t));
+    return r;
+}
+
+// v_ffbh_u32: leading zeros, 0xFFFFFFFF for 0
+__device__ __forceinline__ uint32_t ffbh_u32(uint32_t t)
+{
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(t));
+    return r;
+}
+// any function of three bit vectors in one 2-cycle instruction; bit (a << 2 | b << 1 | c) of TT is the result for inputs a, b, c:
+// 0xEA (a & b) | c   0xA8 (a | b) & c   0xE4 c ? a : b   0x80 a & b & c
+template <int TT>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return (uint32_t)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)c, TT);
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+// (written as instructions: the compiler rewrites the C++ forms of these three into compare + select sequences)
+__device__ __forceinline__ uint32_t pk_lshr15_u16(uint32_t a)          // bit 15 of each half -> bit 0 of that half
+{
+    uint32_t r;
+    asm("v_pk_lshrrev_b16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t sign_mask(uint32_t a)               // 0xFFFFFFFF when bit 31 is set, else 0
+{
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mul_lo_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
@@ -297,24 +345,35 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     // words (all but the lowest resolutions), and the general edge-handling version.  The choice is
     // made once per block: a branch inside the fetch would make the loads land in merged registers
     // and be waited for on the spot, which defeats the prefetch.
+    //
+    // Instruction selection follows the issue rates measured on gfx950 (profiles/r02_valu_issue_rates.txt): a wave64
+    // and / or / xor / not / add / sub / right shift / v_bitop3 holds the SIMD for 2 cycles, everything else (left
+    // shifts, min / max, ffbh, bfe, every compare and select, SDWA, DPP, v_pk_*) for 4 -- so flags are gathered with
+    // right shifts + v_bitop3 instead of compare + select, and 16-bit samples are analysed two at a time (v_pk_*).
+    const uint32_t q0m = isq0 ? 0xFFFFFFFFu : 0u, q31m = isq31 ? 0xFFFFFFFFu : 0u;   // lanes without a left / right neighbour
+    const uint32_t hmask = half ? 0xFFFFFFFFu : 0u;
+    const uint32_t lane_off = 2u * half * stride_b + 2u * qx * EB;                  // FULL: the lane's samples inside an iteration's rows
+    const char* const vtab = reinterpret_cast<const char*>(a.vlc_tab);
     auto phase_a = [&](auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
+    constexpr bool PK = FULL && H16;         // samples stay packed: word 0 = (x0, y0) | (x0+1, y0) << 16, word 1 = the row below
 
     // ---- sample fetch: r[0]=(x0,y0) [1]=(x0,y0+1) [2]=(x0+1,y0) [3]=(x0+1,y0+1) -------------------
     auto fetch = [&](uint32_t it, int32_t (&r)[4]) {
-        const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
         if constexpr (FULL) {
-            const uint32_t off = y0 * stride_b + x0 * EB;
-            if constexpr (H16) {     // one word = the row's two samples; unpacked in stage 1 so that the load stays in flight
-                r[0] = __builtin_nontemporal_load(reinterpret_cast<const int32_t*>(srcb + off));
-                r[1] = __builtin_nontemporal_load(reinterpret_cast<const int32_t*>(srcb + off + stride_b));
+            // 32-bit offsets from the block's (wave-uniform) origin: scalar base + vector offset addressing, one add per row
+            const uint32_t o0 = lane_off + it * (4u * stride_b), o1 = o0 + stride_b;
+            if constexpr (H16) {     // one word = the row's two samples
+                r[0] = __builtin_nontemporal_load(reinterpret_cast<const int32_t*>(srcb + o0));
+                r[1] = __builtin_nontemporal_load(reinterpret_cast<const int32_t*>(srcb + o1));
             } else {
-                const i32x2 q0 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off));
-                const i32x2 q1 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + off + stride_b));
+                const i32x2 q0 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + o0));
+                const i32x2 q1 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + o1));
                 r[0] = q0.x; r[2] = q0.y; r[1] = q1.x; r[3] = q1.y;
             }
         } else {
             // addresses clamped into the block; what lies outside is zeroed when the values are used
+            const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
             const uint32_t xa = min(x0, w - 1), xb = min(x0 + 1, w - 1);
             const uint32_t ya = min(y0, h - 1), yb = min(y0 + 1, h - 1);
             using ET = typename std::conditional<H16, int16_t, int32_t>::type;
@@ -334,98 +393,141 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     // VLC table index -> table load issued) runs before stage 2 of iteration it (everything that
     // needs the table entry), so the table latency hides behind a stage of arithmetic.
     struct Stage1 {
-        uint32_t vv[4], b[4];
-        uint32_t rho, U, u, tuple;
-        bool cq0;
+        uint32_t vv[4];          // MagSgn values 2 mag - 2 + sign; PK: [0] = samples 0 | 2 << 16, [1] = samples 1 | 3 << 16
+        uint32_t R;              // significance, spread: bit 0 sample 0, bit 1 sample 1, bit 16 sample 2, bit 17 sample 3
+        uint32_t U, u, tuple;
+        uint64_t H, V;           // MEL: quads coded with context 0, and which of them are significant (ballots: scalar registers)
     };
 
     auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) {
-        int32_t r[4] = {nbuf[0], nbuf[1], nbuf[2], nbuf[3]};
-        if constexpr (FULL && H16) {
-            r[0] = (int32_t)(int16_t)nbuf[0]; r[2] = nbuf[0] >> 16;
-            r[1] = (int32_t)(int16_t)nbuf[1]; r[3] = nbuf[1] >> 16;
-        }
-        if constexpr (!FULL) {
-            const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
-            const bool ox0 = x0 < w, ox1 = x0 + 1 < w, oy0 = y0 < h, oy1 = y0 + 1 < h;
-            r[0] = (ox0 && oy0) ? r[0] : 0; r[2] = (ox1 && oy0) ? r[2] : 0;
-            r[1] = (ox0 && oy1) ? r[1] : 0; r[3] = (ox1 && oy1) ? r[3] : 0;
-        }
-        if (it + 2 < iters) fetch(it + 2, nbuf);
-
-        // ---- per-sample analysis (:513-563): magnitude, MagSgn value, exponent as leading-zero count
-        uint32_t mag[4], c[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (IRREV) {
-                const float cf = __int_as_float(r[i]);
-                const float q = __fmul_rn(fabsf(cf), inv_step);
-                mag[i] = min((uint32_t)q, lim);
-            } else {
-                mag[i] = (uint32_t)max(r[i], -r[i]);
+        uint32_t c[4], R;        // c: exponents as leading-zero counts of 2 mag - 1 (0xFFFFFFFF: insignificant)
+        if constexpr (PK) {
+            const int32_t nw0 = nbuf[0], nw1 = nbuf[1];
+            const i16x2 w0 = __builtin_bit_cast(i16x2, nw0), w1 = __builtin_bit_cast(i16x2, nw1);
+            if (it + 2 < iters) fetch(it + 2, nbuf);
+            const u16x2 p0 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w0, -w0));      // magnitudes
+            const u16x2 p1 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w1, -w1));
+            const uint32_t P0 = __builtin_bit_cast(uint32_t, p0), P1 = __builtin_bit_cast(uint32_t, p1);
+            ovf |= P0 | P1;
+            const u16x2 one2 = {1, 1};
+            const u16x2 T0 = __builtin_elementwise_sub_sat(p0 + p0, one2);                        // 2 mag - 1, 0: insignificant
+            const u16x2 T1 = __builtin_elementwise_sub_sat(p1 + p1, one2);
+            const uint32_t t0 = __builtin_bit_cast(uint32_t, T0), t1 = __builtin_bit_cast(uint32_t, T1);
+            c[0] = ffbh_u32(t0 & 0xFFFFu); c[2] = ffbh_u32(t0 >> 16);
+            c[1] = ffbh_u32(t1 & 0xFFFFu); c[3] = ffbh_u32(t1 >> 16);
+            // 2 mag - 2 + sign = (2 mag - 1) - (1 - sign); 1 - sign = bit 15 of ~w per half
+            o.vv[0] = pk_sub_u16(t0, pk_lshr15_u16(~(uint32_t)nw0));
+            o.vv[1] = pk_sub_u16(t1, pk_lshr15_u16(~(uint32_t)nw1));
+            R = pk_min_u16(P1, 0x00010001u);
+            R = (R << 1) | pk_min_u16(P0, 0x00010001u);
+        } else {
+            int32_t r[4] = {nbuf[0], nbuf[1], nbuf[2], nbuf[3]};
+            if constexpr (!FULL) {
+                const uint32_t x0 = 2 * qx, y0 = 4 * it + 2 * half;
+                const bool ox0 = x0 < w, ox1 = x0 + 1 < w, oy0 = y0 < h, oy1 = y0 + 1 < h;
+                r[0] = (ox0 && oy0) ? r[0] : 0; r[2] = (ox1 && oy0) ? r[2] : 0;
+                r[1] = (ox0 && oy1) ? r[1] : 0; r[3] = (ox1 && oy1) ? r[3] : 0;
             }
-            const uint32_t sb = (uint32_t)r[i] >> 31;
-            const uint32_t t = (mag[i] << 1) - 1u;                 // val - 1  (val = 2*mag)
-            o.vv[i] = t + sb - 1u;                                 // val - 2 + sign
-            c[i] = ffbh_i32(t);                                    // clz(val-1); 0xFFFFFFFF when insignificant
-            o.b[i] = min(mag[i], 1u);
+            if (it + 2 < iters) fetch(it + 2, nbuf);
+            // ---- per-sample analysis (:513-563): magnitude, MagSgn value, exponent as leading-zero count
+            uint32_t t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t mag;
+                if constexpr (IRREV) {
+                    const float cf = __int_as_float(r[i]);
+                    const float q = __fmul_rn(fabsf(cf), inv_step);
+                    mag = min((uint32_t)q, lim);
+                } else {
+                    mag = (uint32_t)max(r[i], -r[i]);
+                }
+                ovf |= mag;
+                t[i] = (mag << 1) - 1u;                                // val - 1  (val = 2*mag); -1: insignificant
+                o.vv[i] = t[i] - 1u + ((uint32_t)r[i] >> 31);          // val - 2 + sign
+                c[i] = ffbh_i32(t[i]);                                 // clz(val-1); 0xFFFFFFFF when insignificant
+            }
+            // the sign bits of t are the insignificance flags
+            uint32_t nR = t[0] >> 31;
+            nR = bitop3<0xEA>(t[1] >> 30, 2u, nR);
+            nR = bitop3<0xEA>(t[2] >> 15, 0x10000u, nR);
+            nR = bitop3<0xEA>(t[3] >> 14, 0x20000u, nR);
+            R = nR ^ 0x30003u;
         }
-        ovf |= mag[0] | mag[1];
-        ovf |= mag[2] | mag[3];
-        const uint32_t rho = o.b[0] | (o.b[1] << 1) | (o.b[2] << 2) | (o.b[3] << 3);
+        const uint32_t rho = bitop3<0xA8>(R, R >> 14, 15u);           // (R | R >> 14) & 15
         const uint32_t cm = min(min(c[0], c[1]), min(c[2], c[3]));
         const uint32_t emax = 32u - min(cm, 32u);
 
         // ---- neighbourhood: exponents / significance of the sample row above, left quad's rho ----
         const uint32_t Bcur = __builtin_amdgcn_perm(c[3], c[1], 0x05040100u);   // lo16 = c[1], hi16 = c[3]
-        const uint32_t sel = half ? Bprev : Bcur;
+        const uint32_t sel = bitop3<0xE4>(Bprev, Bcur, hmask);                  // half ? Bprev : Bcur
         const uint32_t above = bperm(a_x32, sel);
-        uint32_t above_l = bperm(a_up, above);  above_l = isq0 ? 0xFFFFFFFFu : above_l;
-        uint32_t above_r = bperm(a_dn, above);  above_r = isq31 ? 0xFFFFFFFFu : above_r;
-        uint32_t rho_l = bperm(a_up, rho);      rho_l = isq0 ? 0u : rho_l;
+        const uint32_t above_l = bperm(a_up, above) | q0m;
+        const uint32_t above_r = bperm(a_dn, above) | q31m;
+        const uint32_t rho_l = bperm(a_up, rho) & ~q0m;
         // max exponent of {w, n0, n1, e} = 32 - min of their leading-zero counts
         const uint32_t Y = __builtin_amdgcn_perm(above_l, above_r, 0x07060100u);   // lo16 = e, hi16 = w
         const u16x2 pm = __builtin_elementwise_min(__builtin_bit_cast(u16x2, above), __builtin_bit_cast(u16x2, Y));
         const uint32_t m4 = min((uint32_t)pm.x, (uint32_t)pm.y);
         const int kap_e = 31 - (int)m4;                             // max_e - 1 (negative when all insignificant)
-        const uint32_t kappa = (rho & (rho - 1)) ? (uint32_t)max(1, kap_e) : 1u;
-        const uint32_t n_w = (((above_l >> 16) & above) >> 15) & 1u;    // w and n0 both insignificant
-        const uint32_t n_e = (((above >> 16) & above_r) >> 15) & 1u;    // n1 and e both insignificant
-        const uint32_t rlb = min(rho_l & 0xCu, 1u);
-        uint32_t ctx = n_w | (rlb << 1) | (n_e << 2);
-        uint32_t tbase = 2048u;
-        bool cq0 = ctx == 5u;                                           // c_q == 0
+        // kappa = max(1, max_e - 1) when the quad has two or more significant samples, else 1: bit rho of 0xFEE8 = popcount(rho) >= 2
+        const uint32_t gmask = sign_mask(0xFEE80000u << (15u - rho));
+        const uint32_t kappa = (uint32_t)max(1, kap_e & (int)gmask);
+        // byte offset of the quad's entry in the VLC table (4-byte entries): eps << 2 | rho << 6 | ctx << 10 | other rows << 13,
+        // ctx = n_w | rl << 1 | n_e << 2 with n_w / n_e = "both upper neighbours insignificant" (bit 15 of the packed counts)
+        uint32_t coff = bitop3<0xEA>(((above_l >> 16) & above) >> 5, 0x400u, 0x2000u);
+        coff = bitop3<0xEA>(((above >> 16) & above_r) >> 3, 0x1000u, coff);
+        coff = bitop3<0xEA>((rho_l & 0xCu) + 0x7FCu, 0x800u, coff);
+        bool cq0 = (coff & 0x1C00u) == 0x1400u;                         // c_q == 0
         if (it == 0) {                                                  // first quad row (:652, :709)
             const uint32_t cq_first = (rho_l >> 1) | (rho_l & 1u);
-            ctx = half ? ctx : cq_first;
-            tbase = half ? 2048u : 0u;
+            coff = half ? coff : cq_first << 10;
             cq0 = half ? cq0 : cq_first == 0u;
         }
         const uint32_t U = max(emax, kappa);
         const uint32_t u = U - kappa;
-        uint32_t eps = (uint32_t)(c[0] == cm) | ((uint32_t)(c[1] == cm) << 1) | ((uint32_t)(c[2] == cm) << 2) | ((uint32_t)(c[3] == cm) << 3);
-        eps = u ? eps : 0u;
-        o.tuple = g_vlc_enc[tbase + ((ctx << 8) | (rho << 4) | eps)];
-        o.rho = rho; o.U = U; o.u = u; o.cq0 = cq0;
+        // eps: the samples that attain the maximum exponent (c == cm), only if u > 0.  c - cm - 1 is negative exactly there
+        // (and for insignificant samples, which rho masks out)
+        const uint32_t ncm = ~cm;
+        uint32_t e4 = ((c[0] + ncm) >> 29) & 4u;
+        e4 = bitop3<0xEA>((c[1] + ncm) >> 28, 8u, e4);
+        e4 = bitop3<0xEA>((c[2] + ncm) >> 27, 16u, e4);
+        e4 = bitop3<0xEA>((c[3] + ncm) >> 26, 32u, e4);
+        const uint32_t um = sign_mask(0u - u);
+        e4 = bitop3<0x80>(e4, rho << 2, um);
+        const uint32_t off = ((rho << 6) | coff) | e4;
+        o.tuple = *reinterpret_cast<const uint32_t*>(vtab + off);
+        const uint32_t qy = 2 * it + half;
+        const bool active = FULL || (qx < QW && qy < QH);
+        o.H = __ballot(active && cq0);
+        o.V = o.H & __ballot(rho != 0);
+        o.R = R; o.U = U; o.u = u;
         Bprev = Bcur;
     };
 
     auto stage2 = [&](uint32_t it, const Stage1& s) {
         const uint32_t qy = 2 * it + half;
         const bool active = FULL || (qx < QW && qy < QH);
-        const uint32_t U = s.U, u = s.u, rho = s.rho;
+        const uint32_t U = s.U, u = s.u;
         uint32_t tuple = s.tuple;
         if constexpr (!FULL) tuple = active ? tuple : 0u;
 
-        // ---- MagSgn: bit counts, in-register concatenation of the quad --------------------------
-        uint32_t m[4], vm[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            m[i] = __umul24(U - ((tuple >> i) & 1u), s.b[i]);
-            vm[i] = __builtin_amdgcn_ubfe(s.vv[i], 0u, m[i]);
-        }
-        const uint32_t m01 = m[0] + m[1], m23 = m[2] + m[3];
+        // ---- MagSgn: bit counts m = U - e_k for significant samples, two at a time: M02 = m0 | m2 << 16, M13 = m1 | m3 << 16
+        //      (the table entry carries e_k spread the same way)
+        const uint32_t U2 = __builtin_amdgcn_perm(U, U, 0x05040100u);
+        const uint32_t M02 = pk_mul_lo_u16(s.R & 0x00010001u, U2) - (tuple & 0x00010001u);
+        const uint32_t M13 = pk_mul_lo_u16((s.R >> 1) & 0x00010001u, U2) - ((tuple >> 1) & 0x00010001u);
+        const uint32_t Msum = M02 + M13;
+        const uint32_t m01 = Msum & 0xFFFFu, m23 = Msum >> 16;
         const uint32_t ms_len = m01 + m23;
+        const uint32_t m2 = M02 >> 16, m3 = M13 >> 16;                  // (v_bfe / shifts take m0, m1 from the low 5 bits of M02, M13)
+        uint32_t vm[4];
+        if constexpr (PK) {
+            vm[0] = __builtin_amdgcn_ubfe(s.vv[0], 0u, M02); vm[2] = __builtin_amdgcn_ubfe(s.vv[0], 16u, m2);
+            vm[1] = __builtin_amdgcn_ubfe(s.vv[1], 0u, M13); vm[3] = __builtin_amdgcn_ubfe(s.vv[1], 16u, m3);
+        } else {
+            vm[0] = __builtin_amdgcn_ubfe(s.vv[0], 0u, M02); vm[2] = __builtin_amdgcn_ubfe(s.vv[2], 0u, m2);
+            vm[1] = __builtin_amdgcn_ubfe(s.vv[1], 0u, M13); vm[3] = __builtin_amdgcn_ubfe(s.vv[3], 0u, m3);
+        }
 
         // ---- VLC + UVLC: every lane places the bits of its own quad inside the pair's window ----
         uint32_t ui = u;
@@ -440,7 +542,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             xv = xev && min(u, up) > 2;
         }
         const uint2 ue = uvlc_l[ui];
-        const uint32_t A = (tuple >> 8) | ue.x;                       // cwd | pre<<8 | suf<<16
+        const uint32_t A = (tuple >> 20) | ue.x;                      // cwd | pre<<8 | suf<<16
         const uint32_t Lw = ((tuple >> 4) & 7u) | ue.y;               // len | pl<<8 | sl<<16
         const uint32_t Lp = quad_swap(Lw);
         const uint32_t S = Lw + Lp;
@@ -466,18 +568,17 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         lds_full = lds_full || ms_bits > L.ms_cap_bits || vlc_bits > L.vlc_cap_bits;
         if (lds_full) return;
         if (narrow) {
-            const uint32_t v01 = vm[0] | (vm[1] << m[0]);
-            const uint32_t v23 = vm[2] | (vm[3] << m[2]);
+            const uint32_t v01 = vm[0] | (vm[1] << (M02 & 31u));
+            const uint32_t v23 = vm[2] | (vm[3] << m2);
             or_bits64(ms_raw, mpos, (uint64_t)v01 | ((uint64_t)v23 << m01));
         } else {
-            or_bits64(ms_raw, mpos, (uint64_t)vm[0] | ((uint64_t)vm[1] << m[0]));
-            or_bits64(ms_raw, mpos + m01, (uint64_t)vm[2] | ((uint64_t)vm[3] << m[2]));
+            or_bits64(ms_raw, mpos, (uint64_t)vm[0] | ((uint64_t)vm[1] << (M02 & 0xFFFFu)));
+            or_bits64(ms_raw, mpos + m01, (uint64_t)vm[2] | ((uint64_t)vm[3] << m2));
         }
         or_bits32(vlc_raw, vpos, wv);
 
         // ---- MEL events (wave-uniform, scalar unit) ------------------------------------------------
-        const bool ev = active && s.cq0;
-        const uint64_t H = __ballot(ev), V = __ballot(ev && rho != 0);
+        const uint64_t H = s.H, V = s.V;
         uint64_t Hm = H;
         if (it == 0) {
             const uint64_t XH = __ballot(xev), XV = __ballot(xv);
@@ -516,6 +617,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         return;
     }
     // magnitudes beyond Kmax+1 bits: outside the contract (see header) -> flag, host reports it
+    if constexpr (H16) ovf = (ovf & 0xFFFFu) | (ovf >> 16);          // FULL blocks accumulate two magnitudes per word
     if (!IRREV && __ballot((ovf >> (kmax + 1)) != 0)) {
         if (lane == 0) atomicOr(reinterpret_cast<unsigned int*>(a.alloc), 2u);
     }
@@ -659,16 +761,21 @@ __global__ __launch_bounds__(64) void ht_encode_fallback_kernel(HtArgs a, HtLds 
 } // namespace
 
 static bool g_tables_ready[16] = {false};
+static const uint32_t* g_vlc_tab_dev[16] = {nullptr};     // device address of g_vlc_enc per device (a kernel argument: a scalar base register)
 
 static hipError_t upload_tables()
 {
     // first-row table as generated; other rows re-indexed by the neighbour flags the kernel computes
-    static uint16_t enc[4096];
+    static uint32_t enc[4096];
+    auto entry = [](uint32_t t) {          // generated (cwd << 8 | len << 4 | e_k) -> the kernel's layout
+        const uint32_t ek = t & 15u;
+        return ((t >> 8) << 20) | (((t >> 4) & 7u) << 4) | (ek & 3u) | ((ek >> 2) << 16);
+    };
     for (uint32_t i = 0; i < 2048; ++i) {
-        enc[i] = HT_VLC_ENC0[i];
+        enc[i] = entry(HT_VLC_ENC0[i]);
         const uint32_t ctx = i >> 8, n_w = ctx & 1u, rl = (ctx >> 1) & 1u, n_e = (ctx >> 2) & 1u;
         const uint32_t c_q = (n_w ? 0u : 1u) | (rl << 1) | ((n_e ? 0u : 1u) << 2);
-        enc[2048 + i] = HT_VLC_ENC1[(c_q << 8) | (i & 0xFFu)];
+        enc[2048 + i] = entry(HT_VLC_ENC1[(c_q << 8) | (i & 0xFFu)]);
     }
     static uint2 uv[64];
     for (uint32_t u = 0; u < 64; ++u) {
@@ -688,12 +795,13 @@ static hipError_t upload_tables()
 
 // LDS words of a launch whose largest block has `samples` samples in `quads` quads and exponent kmax
 // capped = false: the worst case (m_n <= U_q <= Kmax + 2 inside the contract; cwd <= 7, UVLC prefix <= 3, suffix <= 5
-// bits per quad).  capped = true: what real content needs with room to spare -- 8 bits per sample on average for
-// 8-bit content (Kmax <= 11), Kmax - 3 beyond; 10 VLC bits per quad.
-static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool capped, uint32_t& ms_words, uint32_t& vlc_words,
+// bits per quad).  capped = true: what real content needs with room to spare -- reversible: 8 bits per sample on
+// average for 8-bit content (Kmax <= 11), Kmax - 3 beyond; quantised (irreversible) coefficients: 8 bits whatever the
+// exponent (the default step sizes leave ~3 bits per sample of a 16-bit image); 10 VLC bits per quad.
+static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool capped, bool irrev, uint32_t& ms_words, uint32_t& vlc_words,
                           uint32_t& mark_words, uint32_t& vmark_words, size_t& bytes, uint32_t* ms_cap = nullptr, uint32_t* vlc_cap = nullptr)
 {
-    const uint32_t per_sample = capped ? std::min(kmax + 2u, kmax <= 11u ? 8u : kmax - 3u) : kmax + 2u;
+    const uint32_t per_sample = !capped ? kmax + 2u : irrev ? std::min(kmax + 2u, 8u) : std::min(kmax + 2u, kmax <= 11u ? 8u : kmax - 3u);
     const uint32_t ms_bits = samples * per_sample;
     const uint32_t vlc_bits = quads * (capped ? 10u : 15u) + 4u;
     if (ms_cap) *ms_cap = ms_bits;
@@ -710,20 +818,26 @@ static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool 
 size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax)
 {
     uint32_t a, b, c, d; size_t n;
-    ht_lds_layout(samples, quads, kmax, false, a, b, c, d, n);
+    ht_lds_layout(samples, quads, kmax, false, false, a, b, c, d, n);
     return n;
 }
 
-static hipError_t ensure_tables()
+static hipError_t ensure_tables(const uint32_t** tab = nullptr)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 16 && !g_tables_ready[dev]) {
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!g_tables_ready[dev]) {
         e = upload_tables();
         if (e != hipSuccess) return e;
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_vlc_enc));
+        if (e != hipSuccess) return e;
+        g_vlc_tab_dev[dev] = static_cast<const uint32_t*>(p);
         g_tables_ready[dev] = true;
     }
+    if (tab) *tab = g_vlc_tab_dev[dev];
     return hipSuccess;
 }
 
@@ -737,7 +851,8 @@ hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s)
 
 hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hipStream_t s)
 {
-    hipError_t e = ensure_tables();
+    const uint32_t* vlc_tab = nullptr;
+    hipError_t e = ensure_tables(&vlc_tab);
     if (e != hipSuccess) return e;
     // one launch per block class (HtClass): the dynamic LDS size is what fixes the occupancy, and the
     // few high-Kmax blocks of the low resolutions would otherwise cost every block a wave per SIMD
@@ -747,10 +862,10 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
         // capped LDS when that buys occupancy (waves per CU = 160 KiB / LDS per wave, at most 32), else worst-case buffers
         HtLds full{}, cap{};
         size_t shmem_full, shmem_cap;
-        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, false, full.ms_words, full.vlc_words, full.mark_words, full.vmark_words,
+        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, false, false, full.ms_words, full.vlc_words, full.mark_words, full.vmark_words,
                       shmem_full, &full.ms_cap_bits, &full.vlc_cap_bits);
-        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, true, cap.ms_words, cap.vlc_words, cap.mark_words, cap.vmark_words,
-                      shmem_cap, &cap.ms_cap_bits, &cap.vlc_cap_bits);
+        ht_lds_layout(c.max_samples, c.max_quads, c.cap_kmax, true, a.irreversible != 0, cap.ms_words, cap.vlc_words, cap.mark_words,
+                      cap.vmark_words, shmem_cap, &cap.ms_cap_bits, &cap.vlc_cap_bits);
         auto waves = [](size_t lds) { return std::min<size_t>(32, (160u << 10) / std::max<size_t>(lds, 1)); };
         const bool use_cap = a.ovf_list && waves(shmem_cap) > waves(shmem_full);
         const HtLds& L = use_cap ? cap : full;
@@ -758,6 +873,7 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
         HtArgs b = a;
         b.sel = c.sel; b.sel_count = c.count;
         b.ovf_base = c.ovf_base;
+        b.vlc_tab = vlc_tab;
         const uint32_t grid = c.count * a.ntiles;
 #define GRK_HT(KERNEL, G, SH, LL)                                                                                                   \
         do {                                                                                                                        \
@@ -766,7 +882,9 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
             else                hipLaunchKernelGGL((KERNEL<false, false>), dim3(G), dim3(64), SH, s, b, LL, k);                   \
         } while (0)
         GRK_HT(ht_encode_kernel, grid, shmem, L);
-        if (use_cap) GRK_HT(ht_encode_fallback_kernel, std::min<uint32_t>(grid, 4096u), shmem_full, full);
+        // the blocks that outgrew the capped buffers: a small fixed grid walks the list (with nothing on it -- natural
+        // images at the top resolution -- its workgroups leave at once)
+        if (use_cap) GRK_HT(ht_encode_fallback_kernel, std::min<uint32_t>(grid, 1024u), shmem_full, full);
 #undef GRK_HT
     }
     return hipGetLastError();

@@ -335,8 +335,10 @@ def test_ht_encoder_lds_cap_and_fallback(kind, monkeypatch):
         t, coded = c.encode_host(p, px)
         got[cap] = U.split_blocks(t, coded)
         handed = int(_dev_view(c.table_device_ptr(3), 24, "<i8").cpu().sum())
-        if cap == "0" or kind == "smooth":
+        if cap == "0":
             assert handed == 0
+        elif kind == "smooth":       # at most the few high-Kmax blocks of the lowest resolutions (the buffers are sized for the typical block)
+            assert handed <= sum(1 for b in G.tile_layout(p)[0] if b.res <= 2)
         elif kind == "noise":
             assert handed > nb // 8
         else:

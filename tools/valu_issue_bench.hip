@@ -20,8 +20,14 @@
 constexpr int kIters = 512;       // loop trips
 constexpr int kPerIter = 32;      // instructions of the measured kind per trip
 
-enum Op { FMA, FMA3, MULF, ADDF, CVT, MOV, AND, ANDLIT, OR, XOR, NOT, ADD, SUB, ADDCO, LSHL, LSHLV, LSHR, ASHR, MIN, MAXI, FFBH, BFE, BFEI, BFEV, MUL24, MAD24, MULLO, PERM, ALIGNBIT, ADD3, OR3, MIN3, LSHL_ADD, LSHL_OR, AND_OR, BITOP3, LSHL64, LSHLADD64, PKMIN, PKADD, PKMAXI, PKLSHL, PKSUB, SDWA_ADD, SDWA_MIN16, CMP_VCC, CMP_SGPR, CND_VCC, CND_SGPR, CND_IMM, CMP_CND, MBCNT, DPP_ADD, DPP_QP, DPP_WSHR, DPP_WSHL, PERMLANE32, READLANE, READFIRST, SWIZZLE, BPERM, LDS_OR, LDS_RD32, LDS_RD64, LDS_WR32, LDS_WR64, NUM_OPS };
+enum Op { MIX_AND_LSHL, MIX_AND_AND_LSHL, MIX_ADD_BFE_OR, MIX_AND_SALU, MIX_LSHL_SALU, AND_SGPR, FMA, FMA3, MULF, ADDF, CVT, MOV, AND, ANDLIT, OR, XOR, NOT, ADD, SUB, ADDCO, LSHL, LSHLV, LSHR, ASHR, MIN, MAXI, FFBH, BFE, BFEI, BFEV, MUL24, MAD24, MULLO, PERM, ALIGNBIT, ADD3, OR3, MIN3, LSHL_ADD, LSHL_OR, AND_OR, BITOP3, LSHL64, LSHLADD64, PKMIN, PKADD, PKMAXI, PKLSHL, PKSUB, SDWA_ADD, SDWA_MIN16, CMP_VCC, CMP_SGPR, CND_VCC, CND_SGPR, CND_IMM, CMP_CND, MBCNT, DPP_ADD, DPP_QP, DPP_WSHR, DPP_WSHL, PERMLANE32, READLANE, READFIRST, SWIZZLE, BPERM, LDS_OR, LDS_RD32, LDS_RD64, LDS_WR32, LDS_WR64, NUM_OPS };
 static const char* kNames[NUM_OPS] = {
+    "mix: v_and + v_lshlrev (2 instr)",
+    "mix: v_and + v_and + v_lshlrev (3 instr)",
+    "mix: v_add + v_bfe + v_or (3 instr)",
+    "mix: v_and + s_add (2 instr)",
+    "mix: v_lshlrev + s_add (2 instr)",
+    "v_and_b32 (sgpr operand)",
     "v_fma_f32",
     "v_fma_f32 (3 distinct srcs)",
     "v_mul_f32",
@@ -96,6 +102,12 @@ __device__ __forceinline__ void one(uint32_t& a, uint32_t b, uint64_t& m, uint64
 {
     // (a VALU write followed by a DPP read of the same register needs two wait states: the dependent chain pays them)
     if constexpr (ILP == 1 && (OP == DPP_ADD || OP == DPP_QP || OP == DPP_WSHR || OP == DPP_WSHL || OP == PERMLANE32)) asm volatile("s_nop 1");
+    if constexpr (OP == MIX_AND_LSHL) asm volatile("v_and_b32 %0, %4, %0\n v_lshlrev_b32 %0, 1, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MIX_AND_AND_LSHL) asm volatile("v_and_b32 %0, %4, %0\n v_lshlrev_b32 %0, 1, %0\n v_or_b32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MIX_ADD_BFE_OR) asm volatile("v_add_u32 %0, %4, %0\n v_bfe_u32 %0, %0, 1, 31\n v_or_b32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
+    if constexpr (OP == MIX_AND_SALU) asm volatile("v_and_b32 %0, %4, %0\n s_add_u32 %3, %3, 3" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory", "scc");
+    if constexpr (OP == MIX_LSHL_SALU) asm volatile("v_lshlrev_b32 %0, 1, %0\n s_add_u32 %3, %3, 3" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory", "scc");
+    if constexpr (OP == AND_SGPR) asm volatile("v_and_b32 %0, %3, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
     if constexpr (OP == FMA) asm volatile("v_fma_f32 %0, %0, %4, %4" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
     if constexpr (OP == FMA3) asm volatile("v_fma_f32 %0, %0, %4, 2.0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
     if constexpr (OP == MULF) asm volatile("v_mul_f32 %0, %4, %0" : "+v"(a), "+s"(m), "+v"(w), "+s"(sc) : "v"(b) : "vcc", "memory");
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(1024) void bench(uint64_t* cycles, uint32_t* sink, 
 #pragma unroll
     for (int i = 0; i < ILP; ++i) acc[i] = seed * (threadIdx.x + 3) + i;
     uint32_t b = (threadIdx.x * 8u) & 0x1F8u;         // a valid LDS byte address / bpermute lane address / operand
-    uint64_t m = 0x5555555555555555ull, w[ILP];
+    uint64_t m = 0x5555555555555555ull, w[ILP];   // (the mix rows use the low word of w as a second, independent chain)
     uint32_t sc = seed;
 #pragma unroll
     for (int i = 0; i < ILP; ++i) w[i] = acc[i];
@@ -264,6 +276,7 @@ int main(int argc, char** argv)
     bool header = false;
     const char* only = argc > 1 ? argv[1] : nullptr;
 #define RUN(OP) do { if (!only || strstr(kNames[OP], only)) { if (run<OP, 8>(d_cycles, d_sink, ghz, header)) return 1; if (run<OP, 1>(d_cycles, d_sink, ghz, header)) return 1; } } while (0)
+    RUN(MIX_AND_LSHL); RUN(MIX_AND_AND_LSHL); RUN(MIX_ADD_BFE_OR); RUN(MIX_AND_SALU); RUN(MIX_LSHL_SALU); RUN(AND_SGPR);
     RUN(FMA);
     RUN(FMA3);
     RUN(MULF);
