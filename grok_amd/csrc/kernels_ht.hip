@@ -127,8 +127,42 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t t)
     asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(t));
     return r;
 }
+// leading-zero count (v_ffbh_u32 of a 16-bit half, or v_ffbh_i32 of a word) written into byte B of `acc`, the other
+// bytes kept: four of them leave a quad's exponents packed in one register without a single unpack / pack instruction
+template <int B, int HALF>
+__device__ __forceinline__ void ffbh_u16_to_byte(uint32_t& acc, uint32_t packed)
+{
+    if constexpr (B == 0) {
+        if constexpr (HALF == 0) asm("v_ffbh_u32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(acc) : "v"(packed));
+        else asm("v_ffbh_u32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(acc) : "v"(packed));
+    } else if constexpr (B == 1) {
+        if constexpr (HALF == 0) asm("v_ffbh_u32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(acc) : "v"(packed));
+        else asm("v_ffbh_u32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(acc) : "v"(packed));
+    } else if constexpr (B == 2) {
+        if constexpr (HALF == 0) asm("v_ffbh_u32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(acc) : "v"(packed));
+        else asm("v_ffbh_u32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(acc) : "v"(packed));
+    } else {
+        if constexpr (HALF == 0) asm("v_ffbh_u32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(acc) : "v"(packed));
+        else asm("v_ffbh_u32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(acc) : "v"(packed));
+    }
+}
+template <int B>
+__device__ __forceinline__ void ffbh_i32_to_byte(uint32_t& acc, uint32_t t)
+{
+    if constexpr (B == 0) asm("v_ffbh_i32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(acc) : "v"(t));
+    else if constexpr (B == 1) asm("v_ffbh_i32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(acc) : "v"(t));
+    else if constexpr (B == 2) asm("v_ffbh_i32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(acc) : "v"(t));
+    else asm("v_ffbh_i32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(acc) : "v"(t));
+}
+__device__ __forceinline__ uint32_t min_of_bytes(uint32_t c)
+{
+    uint32_t m1, m2;
+    asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(m1) : "v"(c));
+    asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(m2) : "v"(c));
+    return min(m1, m2);
+}
 // any function of three bit vectors in one 2-cycle instruction; bit (a << 2 | b << 1 | c) of TT is the result for inputs a, b, c:
-// 0xEA (a & b) | c   0xA8 (a | b) & c   0xE4 c ? a : b   0x80 a & b & c
+// 0xEA (a & b) | c   0xA8 (a | b) & c   0xE4 c ? a : b   0x80 a & b & c   0x30 a & ~b
 template <int TT>
 __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -283,6 +317,28 @@ __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* fl
     }
 }
 
+// Output bytes j .. j + 3 (first byte in bits 0-7) of a raw bit stream whose 7-bit bytes are marked in the bitmap `mk`;
+// pre[w] = marks in the bitmap words before w, lsh = j & 31, lowm = (1 << lsh) - 1
+__device__ __forceinline__ uint32_t stuffed_dword(const uint32_t* raw, const uint32_t* mk, const uint16_t* pre, uint32_t j,
+                                                  uint32_t lsh, uint32_t lowm)
+{
+    const uint32_t mw = mk[j >> 5];
+    const uint32_t flags = (mw >> lsh) & 0xFu;
+    const uint32_t k = pre[j >> 5] + __popc(mw & lowm);
+    const uint32_t start = 8 * j - k;
+    const uint32_t sw = start >> 5;
+    const uint32_t win = __builtin_amdgcn_alignbit(raw[sw + 1], raw[sw], start & 31u);    // the 32 raw bits from `start`
+    if (flags == 0) return win;
+    uint32_t word = 0, o = 0;                     // a 7-bit byte among them: byte by byte (they take fewer than 32 bits)
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+        const uint32_t seven = (flags >> bb) & 1u;
+        word |= ((win >> o) & (0xFFu >> seven)) << (8 * bb);
+        o += 8u - seven;
+    }
+    return word;
+}
+
 // LDS words of the two raw streams, the two bitmaps, and what the raw streams may hold (bits) before the block is
 // handed to the fallback launch
 struct HtLds { uint32_t ms_words, vlc_words, mark_words, vmark_words, ms_cap_bits, vlc_cap_bits; };
@@ -301,7 +357,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     uint32_t* marks   = vlc_raw + vlc_words;
     uint32_t* vmarks  = marks + mark_words;
     uint2*    uvlc_l  = reinterpret_cast<uint2*>(marks);                         // 64 entries, phase A only
-    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(marks + max(mark_words + vmark_words, 128u));   // 256 bytes
+    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(marks + max(mark_words + vmark_words + (mark_words + vmark_words + 1u) / 2u, 128u));   // 256 bytes
 
     const int lane = threadIdx.x;
     // this launch covers the blocks sel[0..sel_count) of every tile (all blocks when sel == nullptr)
@@ -394,32 +450,29 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     // needs the table entry), so the table latency hides behind a stage of arithmetic.
     struct Stage1 {
         uint32_t vv[4];          // MagSgn values 2 mag - 2 + sign; PK: [0] = samples 0 | 2 << 16, [1] = samples 1 | 3 << 16
-        uint32_t R;              // significance, spread: bit 0 sample 0, bit 1 sample 1, bit 16 sample 2, bit 17 sample 3
+        uint32_t R;              // significance, one flag per byte: bit 0 sample 0, bit 8 sample 1, bit 16 sample 2, bit 24 sample 3
         uint32_t U, u, tuple;
         uint64_t H, V;           // MEL: quads coded with context 0, and which of them are significant (ballots: scalar registers)
     };
 
     auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) {
-        uint32_t c[4], R;        // c: exponents as leading-zero counts of 2 mag - 1 (0xFFFFFFFF: insignificant)
+        // C: the four exponents as leading-zero counts of 2 mag - 1, one per byte (sample i in byte i; 0xFF: insignificant)
+        uint32_t C;
         if constexpr (PK) {
             const int32_t nw0 = nbuf[0], nw1 = nbuf[1];
             const i16x2 w0 = __builtin_bit_cast(i16x2, nw0), w1 = __builtin_bit_cast(i16x2, nw1);
             if (it + 2 < iters) fetch(it + 2, nbuf);
             const u16x2 p0 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w0, -w0));      // magnitudes
             const u16x2 p1 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w1, -w1));
-            const uint32_t P0 = __builtin_bit_cast(uint32_t, p0), P1 = __builtin_bit_cast(uint32_t, p1);
-            ovf |= P0 | P1;
+            ovf |= __builtin_bit_cast(uint32_t, p0) | __builtin_bit_cast(uint32_t, p1);
             const u16x2 one2 = {1, 1};
-            const u16x2 T0 = __builtin_elementwise_sub_sat(p0 + p0, one2);                        // 2 mag - 1, 0: insignificant
-            const u16x2 T1 = __builtin_elementwise_sub_sat(p1 + p1, one2);
-            const uint32_t t0 = __builtin_bit_cast(uint32_t, T0), t1 = __builtin_bit_cast(uint32_t, T1);
-            c[0] = ffbh_u32(t0 & 0xFFFFu); c[2] = ffbh_u32(t0 >> 16);
-            c[1] = ffbh_u32(t1 & 0xFFFFu); c[3] = ffbh_u32(t1 >> 16);
+            const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(p0 + p0, one2));   // 2 mag - 1, 0: insignificant
+            const uint32_t t1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(p1 + p1, one2));
+            ffbh_u16_to_byte<0, 0>(C, t0); ffbh_u16_to_byte<1, 0>(C, t1);
+            ffbh_u16_to_byte<2, 1>(C, t0); ffbh_u16_to_byte<3, 1>(C, t1);
             // 2 mag - 2 + sign = (2 mag - 1) - (1 - sign); 1 - sign = bit 15 of ~w per half
             o.vv[0] = pk_sub_u16(t0, pk_lshr15_u16(~(uint32_t)nw0));
             o.vv[1] = pk_sub_u16(t1, pk_lshr15_u16(~(uint32_t)nw1));
-            R = pk_min_u16(P1, 0x00010001u);
-            R = (R << 1) | pk_min_u16(P0, 0x00010001u);
         } else {
             int32_t r[4] = {nbuf[0], nbuf[1], nbuf[2], nbuf[3]};
             if constexpr (!FULL) {
@@ -444,21 +497,18 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 ovf |= mag;
                 t[i] = (mag << 1) - 1u;                                // val - 1  (val = 2*mag); -1: insignificant
                 o.vv[i] = t[i] - 1u + ((uint32_t)r[i] >> 31);          // val - 2 + sign
-                c[i] = ffbh_i32(t[i]);                                 // clz(val-1); 0xFFFFFFFF when insignificant
             }
-            // the sign bits of t are the insignificance flags
-            uint32_t nR = t[0] >> 31;
-            nR = bitop3<0xEA>(t[1] >> 30, 2u, nR);
-            nR = bitop3<0xEA>(t[2] >> 15, 0x10000u, nR);
-            nR = bitop3<0xEA>(t[3] >> 14, 0x20000u, nR);
-            R = nR ^ 0x30003u;
+            ffbh_i32_to_byte<0>(C, t[0]); ffbh_i32_to_byte<1>(C, t[1]);     // clz(val-1); 0xFF when insignificant
+            ffbh_i32_to_byte<2>(C, t[2]); ffbh_i32_to_byte<3>(C, t[3]);
         }
-        const uint32_t rho = bitop3<0xA8>(R, R >> 14, 15u);           // (R | R >> 14) & 15
-        const uint32_t cm = min(min(c[0], c[1]), min(c[2], c[3]));
+        const uint32_t N = bitop3<0x30>(0x01010101u, C >> 7, 0u);      // significance, one flag per byte (a & ~b)
+        const uint32_t rho = __builtin_amdgcn_udot4(N, 0x08040201u, 0u, false);
+        const uint32_t rho2 = __builtin_amdgcn_udot4(N, 0x20100804u, 0u, false);       // rho << 2
+        const uint32_t cm = min_of_bytes(C);
         const uint32_t emax = 32u - min(cm, 32u);
 
         // ---- neighbourhood: exponents / significance of the sample row above, left quad's rho ----
-        const uint32_t Bcur = __builtin_amdgcn_perm(c[3], c[1], 0x05040100u);   // lo16 = c[1], hi16 = c[3]
+        const uint32_t Bcur = __builtin_amdgcn_perm(C, C, 0x0C030C01u);         // lo16 = byte 1 (sample 1), hi16 = byte 3 (sample 3)
         const uint32_t sel = bitop3<0xE4>(Bprev, Bcur, hmask);                  // half ? Bprev : Bcur
         const uint32_t above = bperm(a_x32, sel);
         const uint32_t above_l = bperm(a_up, above) | q0m;
@@ -473,9 +523,9 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         const uint32_t gmask = sign_mask(0xFEE80000u << (15u - rho));
         const uint32_t kappa = (uint32_t)max(1, kap_e & (int)gmask);
         // byte offset of the quad's entry in the VLC table (4-byte entries): eps << 2 | rho << 6 | ctx << 10 | other rows << 13,
-        // ctx = n_w | rl << 1 | n_e << 2 with n_w / n_e = "both upper neighbours insignificant" (bit 15 of the packed counts)
-        uint32_t coff = bitop3<0xEA>(((above_l >> 16) & above) >> 5, 0x400u, 0x2000u);
-        coff = bitop3<0xEA>(((above >> 16) & above_r) >> 3, 0x1000u, coff);
+        // ctx = n_w | rl << 1 | n_e << 2 with n_w / n_e = "both upper neighbours insignificant" (bit 7 of the packed counts)
+        uint32_t coff = bitop3<0xEA>(((above_l >> 16) & above) << 3, 0x400u, 0x2000u);
+        coff = bitop3<0xEA>(((above >> 16) & above_r) << 5, 0x1000u, coff);
         coff = bitop3<0xEA>((rho_l & 0xCu) + 0x7FCu, 0x800u, coff);
         bool cq0 = (coff & 0x1C00u) == 0x1400u;                         // c_q == 0
         if (it == 0) {                                                  // first quad row (:652, :709)
@@ -485,22 +535,20 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         }
         const uint32_t U = max(emax, kappa);
         const uint32_t u = U - kappa;
-        // eps: the samples that attain the maximum exponent (c == cm), only if u > 0.  c - cm - 1 is negative exactly there
-        // (and for insignificant samples, which rho masks out)
-        const uint32_t ncm = ~cm;
-        uint32_t e4 = ((c[0] + ncm) >> 29) & 4u;
-        e4 = bitop3<0xEA>((c[1] + ncm) >> 28, 8u, e4);
-        e4 = bitop3<0xEA>((c[2] + ncm) >> 27, 16u, e4);
-        e4 = bitop3<0xEA>((c[3] + ncm) >> 26, 32u, e4);
+        // eps: the samples that attain the maximum exponent (byte of C == cm), only if u > 0.  Byte-wise C - cm is 0 exactly
+        // there (no borrows: every byte >= cm); (x & 0x1F) + 0x7F keeps bit 7 clear for a zero byte only.  (Insignificant
+        // samples may pass as well: rho masks them out.)
+        const uint32_t X = C - __builtin_amdgcn_perm(cm, cm, 0u);             // cm in every byte
+        const uint32_t Yz = (X & 0x1F1F1F1Fu) + 0x7F7F7F7Fu;
+        const uint32_t e4 = __builtin_amdgcn_udot4(bitop3<0x30>(0x01010101u, Yz >> 7, 0u), 0x20100804u, 0u, false);      // eps << 2
         const uint32_t um = sign_mask(0u - u);
-        e4 = bitop3<0x80>(e4, rho << 2, um);
-        const uint32_t off = ((rho << 6) | coff) | e4;
+        const uint32_t off = ((rho2 << 4) | coff) | bitop3<0x80>(e4, rho2, um);
         o.tuple = *reinterpret_cast<const uint32_t*>(vtab + off);
         const uint32_t qy = 2 * it + half;
         const bool active = FULL || (qx < QW && qy < QH);
         o.H = __ballot(active && cq0);
         o.V = o.H & __ballot(rho != 0);
-        o.R = R; o.U = U; o.u = u;
+        o.R = N; o.U = U; o.u = u;
         Bprev = Bcur;
     };
 
@@ -515,7 +563,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         //      (the table entry carries e_k spread the same way)
         const uint32_t U2 = __builtin_amdgcn_perm(U, U, 0x05040100u);
         const uint32_t M02 = pk_mul_lo_u16(s.R & 0x00010001u, U2) - (tuple & 0x00010001u);
-        const uint32_t M13 = pk_mul_lo_u16((s.R >> 1) & 0x00010001u, U2) - ((tuple >> 1) & 0x00010001u);
+        const uint32_t M13 = pk_mul_lo_u16((s.R >> 8) & 0x00010001u, U2) - ((tuple >> 1) & 0x00010001u);
         const uint32_t Msum = M02 + M13;
         const uint32_t m01 = Msum & 0xFFFFu, m23 = Msum >> 16;
         const uint32_t ms_len = m01 + m23;
@@ -632,6 +680,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
 
     // ================= phase B: stuffing, termination, emission (see oracle/ht_wave_model.c) =====
     const uint32_t msw = ms_words, vw = vlc_words;
+#pragma unroll 1
     for (uint32_t i = lane; i < mark_words + vmark_words; i += 64) marks[i] = 0;      // the UVLC table is dead now
     __syncthreads();
 
@@ -694,44 +743,62 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     uint8_t* out = a.arena + base_off;
     __syncthreads();
 
-    // ---- B5: emission. MagSgn: one dword (4 bytes) per lane and iteration, coalesced stores; the number
-    //      of 7-bit bytes before a lane's first byte is a running count plus a wave prefix sum
-    uint32_t kbase = 0;
+    // ---- B4: how many 7-bit bytes lie before each word of the two bitmaps (one wave scan per 64 words)
+    uint16_t* const pre16 = reinterpret_cast<uint16_t*>(vmarks + vmark_words);      // [mark_words | vmark_words]
+    {
+        const uint32_t nmw = (ms_emit + 31u) >> 5, nvw = (nv + 31u) >> 5;
+        uint32_t kb = 0;
+#pragma unroll 1
+        for (uint32_t w0 = 0; w0 < nmw; w0 += 64) {
+            const uint32_t wi = w0 + lane;
+            const uint32_t cnt = wi < nmw ? __popc(marks[wi]) : 0u;
+            const uint32_t incl = wave_incl_scan(cnt);
+            if (wi < nmw) pre16[wi] = (uint16_t)(kb + incl - cnt);
+            kb += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        kb = 0;
+#pragma unroll 1
+        for (uint32_t w0 = 0; w0 < nvw; w0 += 64) {
+            const uint32_t wi = w0 + lane;
+            const uint32_t cnt = wi < nvw ? __popc(vmarks[wi]) : 0u;
+            const uint32_t incl = wave_incl_scan(cnt);
+            if (wi < nvw) pre16[mark_words + wi] = (uint16_t)(kb + incl - cnt);
+            kb += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    __syncthreads();
+
+    // ---- B5: emission, one dword (4 output bytes) per lane and iteration.  Byte j starts at raw bit 8 j - (7-bit bytes
+    //      before it); with no 7-bit byte among the four -- all but ~1 dword in 64 -- the dword is 32 raw bits as they lie
+    const uint32_t lsh = (4u * lane) & 31u, lowm = (1u << lsh) - 1u;         // the lane's place in its bitmap word
+#pragma unroll 1
     for (uint32_t j0 = 0; j0 < ms_emit; j0 += 256) {
         const uint32_t j = j0 + 4 * lane;
-        const uint32_t flags = j < ms_emit ? (marks[j >> 5] >> (j & 31)) & 0xFu : 0u;
-        const uint32_t cnt = __popc(flags);
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t k = kbase + incl - cnt;
-        kbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (j >= ms_emit) continue;
-        const uint32_t start = 8 * j - k;
-        const uint32_t sw = start >> 5;
-        uint64_t win = (ms_raw[sw] | ((uint64_t)ms_raw[sw + 1] << 32)) >> (start & 31);   // >= 32 valid bits
-        uint32_t word = 0;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            const uint32_t seven = (flags >> bb) & 1u;
-            word |= ((uint32_t)win & (0xFFu >> seven)) << (8 * bb);
-            win >>= 8u - seven;
+        const uint32_t word = stuffed_dword(ms_raw, marks, pre16, j, lsh, lowm);
+        if (j + 4 <= ms_emit) *reinterpret_cast<uint32_t*>(out + j) = word;      // coalesced, aligned
+        else {
+#pragma unroll 1
+            for (uint32_t bb = 0; j + bb < ms_emit; ++bb) out[j + bb] = (uint8_t)(word >> (8 * bb));
         }
-        if (j + 4 <= ms_emit) *reinterpret_cast<uint32_t*>(out + j) = word;
-        else for (uint32_t bb = 0; j + bb < ms_emit; ++bb) out[j + bb] = (uint8_t)(word >> (8 * bb));
     }
     if (has_final && lane == 0) out[ms_len - 1] = (uint8_t)final_byte;
+#pragma unroll 1
     for (uint32_t i = lane; i < mel_len; i += 64) out[ms_len + i] = mel_buf[i < 250 ? i : 249];
-    // VLC bytes are stored in reverse order of generation; the first one carries Scup's low nibble
-    uint32_t vkbase = 0;
-    for (uint32_t j0 = 0; j0 < nv; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool seven = j < nv && ((vmarks[j >> 5] >> (j & 31)) & 1u);
-        const uint64_t bal = __ballot(seven);
-        const uint32_t k = vkbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        vkbase += (uint32_t)__popcll(bal);
+    // VLC bytes are stored in reverse order of generation (byte j at total - 2 - j); the first one carries Scup's low nibble
+#pragma unroll 1
+    for (uint32_t j0 = 0; j0 < nv; j0 += 256) {
+        const uint32_t j = j0 + 4 * lane;
         if (j >= nv) continue;
-        uint32_t byte = get_bits(vlc_raw, 8 * j - k, seven ? 7u : 8u);
-        if (j == 0) byte = (byte & 0xF0) | (scup & 0xF);
-        out[total - 2 - j] = (uint8_t)byte;
+        uint32_t word = stuffed_dword(vlc_raw, vmarks, pre16 + mark_words, j, lsh, lowm);
+        if (j == 0) word = (word & ~0xFu) | (scup & 0xFu);
+        if (j + 4 <= nv) {
+            typedef uint32_t u32_any __attribute__((aligned(1)));
+            *reinterpret_cast<u32_any*>(out + total - 5 - j) = __builtin_bswap32(word);
+        } else {
+#pragma unroll 1
+            for (uint32_t bb = 0; j + bb < nv; ++bb) out[total - 2 - j - bb] = (uint8_t)(word >> (8 * bb));
+        }
     }
     if (lane == 0) {
         if (vextra) out[total - 2 - nv] = (uint8_t)(nv == 0 ? ((vacc & 0xF0) | (scup & 0xF)) : vacc);
@@ -810,7 +877,7 @@ static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool 
     vlc_words = ((vlc_bits + 31u) / 32u + 4u + 3u) & ~3u;           // multiples of 4 words: cleared as uint4
     mark_words = ((ms_bits + ms_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;   // one bit per stuffed output byte
     vmark_words = ((vlc_bits + vlc_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;
-    uint32_t mk = mark_words + vmark_words;
+    uint32_t mk = mark_words + vmark_words + (mark_words + vmark_words + 1u) / 2u;    // + 16-bit prefix counts per bitmap word
     if (mk < 128u) mk = 128u;                                       // the UVLC table lives there during phase A
     bytes = (size_t)(ms_words + vlc_words + mk) * 4u + 256u;
 }

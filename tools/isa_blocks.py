@@ -3,7 +3,7 @@ import sys
 s = open(sys.argv[1]).read()
 i = s.index(sys.argv[2] + "E") if sys.argv[2] + "E" in s else s.index(sys.argv[2])
 i = s.index(":\n", i)
-k = s[i:]; k = k[:k.index("s_endpgm") + 10]
+k = s[i:]; k = k[:k.index(".Lfunc_end")]
 cur = "entry"; cnt = {cur: [0, 0, 0, []]}; order = [cur]
 for l in k.split("\n"):
     t = l.split(";")[0].strip()

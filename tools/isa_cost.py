@@ -26,7 +26,7 @@ def main():
     i = s.index(key)
     i = s.index(":\n", i)
     k = s[i:]
-    k = k[:k.index("s_endpgm") + 10]
+    k = k[:k.index(".Lfunc_end")]
     lines = k.split("\n")
     first = sys.argv[3] if len(sys.argv) > 3 else None
     last = sys.argv[4] if len(sys.argv) > 4 else None
