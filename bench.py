@@ -4,16 +4,16 @@ lossless, with the dominant kernel's HBM roofline and the reference CPU encoder 
 
 One "step" = one pass of the hot path (ingest+DC+RCT -> 5-level 5/3 DWT -> HT cleanup coding of
 64x64 code-blocks -> compaction) over one 8192x8192x3 8-bit tile whose pixels are already
-resident in HBM.  With N ranks (torchrun, one process per GPU) the job is an (N*8192)x8192 image
-cut into N tiles of 8192x8192: tile t is encoded on rank t (tiles are independent, SURVEY.md
-§8e) and every step ends with the path's one real exchange over RCCL/xGMI: an all_gather of the
-ranks' coded byte counts, from which each rank knows where its tile-parts go in the codestream
-(parallel writer; the coded bytes stay on their GPU -- funnelling N x ~100 MB per step into rank 0
-would bound the job by one GPU's xGMI ingress; `--exchange gather` times that design).  After the
-timed region the tile-parts are gathered once and assembled into the codestream as a check.
-Per-GPU work is fixed => weak scaling.
+resident in HBM.  With N ranks (torchrun, one process per GPU) the job is a sequence of (N*8192)x8192
+frames cut into N tiles of 8192x8192: tile t is encoded on rank t (tiles are independent, SURVEY.md
+§8e: no data-path collective) and every frame ends with the path's one real exchange over RCCL/xGMI,
+the gather of the ranks' coded tile-parts (exact sizes) on the frame's writer rank, which rotates with
+the frame number (grok_amd.dist: funnelling every frame into rank 0 would bound the job by one GPU's
+xGMI ingress).  Per-GPU work is fixed => weak scaling.  The same line reports, under "multi_gpu", the
+counts-only exchange (parallel-writer design: the bytes stay on their GPU) and the BASELINE configs[3]
+shape -- 16384x16384 as 256 tiles of 1024x1024 split over the ranks, strong scaling.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 8k|cfg2|cfg1|cfg4tile]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 8k|cfg2|cfg1|cfg3|cfg4tile]
 """
 import argparse
 import ctypes as C
@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import grok_amd as G  # noqa: E402
+import grok_amd.dist as D  # noqa: E402
 import synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
@@ -252,9 +253,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="every kernel alone on the GPU, also in the timed region (what the rocprofv3 kernel-trace summary "
                          "that the roofline durations are checked against is taken with)")
-    ap.add_argument("--exchange", default="offsets", choices=("offsets", "gather"),
-                    help="N > 1, per step: 'offsets' = all_gather of the coded byte counts (parallel writer: every rank "
-                         "learns where its tile-parts go, the bytes stay put); 'gather' = all coded tile-parts to rank 0")
+    ap.add_argument("--exchange", default="gather", choices=("gather", "counts"),
+                    help="N > 1, per frame, what the headline number is timed with: 'gather' = every rank's coded tile-parts "
+                         "(exact sizes) to the frame's writer rank, which rotates with the frame number; 'counts' = all_gather of "
+                         "the coded byte counts only (parallel writers: the bytes stay on their GPU).  The other one is reported "
+                         "under multi_gpu as well")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -289,49 +292,13 @@ def main():
 
     # rank 0 owns the header blob; everybody gets it by broadcast (tiny, outside the timed region)
     if use_dist:
-        import grok_amd.dist as D
         got = D.broadcast_params(params, dev)
         assert bytes(got) == bytes(params)
 
-    scratch = None
-    last_parts = None
-    # one encode up front: buffers exist, and the arena capacity the exchange may slice from is known
+    # one encode up front: buffers exist
     ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
     _, total0 = ctx.fetch_table(nblocks)
-    raw_bytes = samples * ((prec + 7) // 8)
-    arena_cap = int(raw_bytes * 2)          # grk_amd allocates >= 2 x raw (context.hip: run_ht)
-
-    counts = my_off = None
-    counts_buf = [None, None]
-    nstep = [0]
-    comm = torch.cuda.Stream(device=dev)
-
-    def gather_parts():
-        nonlocal scratch, last_parts
-        used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
-        offs = _as_tensor(ctx.table_device_ptr(0), nblocks, dev, "<i8")
-        lens = _as_tensor(ctx.table_device_ptr(1), nblocks, dev, "<i4")
-        arena = _as_tensor(ctx.coded_device_ptr(), arena_cap, dev)
-        last_parts, scratch = D.gather_tile_parts_device(used, offs, lens, arena, dst=0, scratch=scratch)
-
-    def step():
-        nonlocal counts, my_off
-        with torch.cuda.stream(stream):
-            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
-            if use_dist and args.exchange == "offsets":
-                # the path's one real exchange (RCCL over xGMI), parallel-writer design: byte counts only; every rank
-                # learns its tile-parts' place in the codestream.  It runs on its own stream, which waits for this
-                # encode's results, so that the context's stream is free for the next frame (pipelining)
-                used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
-                ctx.stream_wait_results(comm.cuda_stream)
-                with torch.cuda.stream(comm):
-                    slot = nstep[0] & 1
-                    counts_buf[slot], my_off = D.exchange_tile_part_offsets(used, counts_buf[slot])
-                    counts = counts_buf[slot]
-                nstep[0] += 1
-            elif use_dist:
-                # funnel: every coded tile-part to rank 0, straight from the encoder's device table and arena
-                gather_parts()
+    comm = torch.cuda.Stream(device=dev) if use_dist else None
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -339,39 +306,124 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # a sequence of frames: consecutive encodes are pipelined (the next frame's DWT runs while this one's blocks are still
-    # being coded; each encode works in its own buffer set and is complete when the timed region ends).  Not with N > 1:
-    # there every step ends with an exchange that reads this step's results.
-    pipelined = not args.no_overlap and (not use_dist or args.exchange == "offsets")
-    ctx.set_pipelining(pipelined)
-    for _ in range(args.warmup):
-        step()
-    sync()
-    ctx.enable_timing(False)         # nothing but the hot path inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    ctx.set_pipelining(False)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        if args.exchange == "offsets":
-            # outside the timed region: collect the tile-parts once and check them against the exchanged counts
+    def run_frames(prm, nt, d_pixels, nblk, exchange, steps, warmup):
+        """`warmup` + `steps` frames of `nt` tiles on this rank, each followed by `exchange` (None / "counts" / "gather");
+        consecutive frames are pipelined (the next frame's DWT runs while this one's blocks are still being coded and its
+        tile-parts travel).  Returns (seconds for `steps` frames, MAX over ranks; the gathered parts of the last frame on its
+        writer; that writer's rank)."""
+        raw = nt * prm.num_comps * prm.tile_w * prm.tile_h * ((prm.prec + 7) // 8)
+        arena_cap = int(raw * 2)                # grk_amd allocates >= 2 x raw (context.hip: make_ht_args)
+        pipe = [None]
+        cbuf = [None, None]
+
+        def one(f):
             with torch.cuda.stream(stream):
-                gather_parts()
-            torch.cuda.synchronize(dev)
-            if rank == 0:
-                assert [int(v) for v in counts.cpu()] == [int(c.numel()) for _, _, c in last_parts], "byte counts disagree"
-        if rank == 0:
-            # the gathered tile-parts really are a codestream: assemble the (N*W) x H image once
-            ft, fc = D.merge_tile_parts(D.parts_to_numpy(last_parts), world * ntiles, nblocks // ntiles)
-            if ntiles == 1:
-                cs_len = len(G.write_codestream(params, W * world, H, ft, fc))
-            else:
-                cs_len = int(ft["length"].sum())
+                if pipe[0] is not None:                        # three buffer sets in rotation: this frame reuses frame f - 3's
+                    ev = pipe[0].done_event(f - 3)
+                    if ev is not None:
+                        stream.wait_event(ev)                  # ... once its gather has read them
+                ctx.encode_tiles(prm, nt, d_pixels.data_ptr(), True, fetch=False)
+                if exchange is None:
+                    return
+                used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
+                if exchange == "counts":
+                    if cbuf[f & 1] is None:
+                        cbuf[f & 1] = torch.empty(world, dtype=torch.int64, device=dev)
+                    ctx.stream_wait_results(comm.cuda_stream)
+                    with torch.cuda.stream(comm):
+                        dist.all_gather_into_tensor(cbuf[f & 1], used)      # 8 bytes per rank, out of the encoder's own word
+                else:
+                    offs = _as_tensor(ctx.table_device_ptr(0), nblk, dev, "<i8")
+                    lens = _as_tensor(ctx.table_device_ptr(1), nblk, dev, "<i4")
+                    arena = _as_tensor(ctx.coded_device_ptr(), arena_cap, dev)
+                    pipe[0].submit(f, used, offs, lens, arena, wait_results=ctx.stream_wait_results)
+                    if args.no_overlap:
+                        pipe[0].flush()                         # one buffer set: the gather cannot lag behind the encoder
+
+        def flush():
+            if pipe[0] is not None:
+                return pipe[0].flush()
+            return None, None
+
+        ctx.set_pipelining(False if args.no_overlap else (2 if exchange == "gather" else True))
+        if exchange == "gather":
+            pipe[0] = D.FramePipeline(dev, (stream, comm))
+        for f in range(warmup):
+            one(f)
+        flush()
+        sync()
+        ctx.enable_timing(False)         # nothing but the hot path inside the timed region
+        t0 = time.perf_counter()
+        for f in range(steps):
+            one(warmup + f)
+        parts, root = flush()
+        sync()
+        secs = time.perf_counter() - t0
+        ctx.set_pipelining(False)
+        if use_dist:
+            t = torch.tensor([secs], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            secs = float(t.item())
+        return secs, parts, root
+
+    def assembled_bytes(prm, nt, nblk, img_w, img_h, parts, root):
+        """The frame the last gather delivered really is a codestream: Tier-2 + headers over it on its writer."""
+        n = torch.zeros(1, dtype=torch.int64, device=dev)
+        if parts is not None and rank == root:
+            ft, fc = D.merge_tile_parts(D.parts_to_numpy(parts), world * nt, nblk // nt)
+            n[0] = len(G.write_codestream(prm, img_w, img_h, ft, fc)) if nt == 1 or img_w else int(ft["length"].sum())
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        return int(n.item())
+
+    pipelined = not args.no_overlap
+    exchange = (args.exchange if use_dist else None)
+    dt, last_parts, last_root = run_frames(params, ntiles, d_px, nblocks, exchange, args.steps, args.warmup)
+    multi_gpu = None
+    if use_dist:
+        multi_gpu = {"world_size": world, "backend": "nccl (RCCL %s)" % ".".join(str(v) for v in torch.cuda.nccl.version()),
+                     "headline_exchange": args.exchange}
+        per = {}
+        per[args.exchange] = {"ms_per_step": round(dt / args.steps * 1e3, 4),
+                              "Mpixels_s": round(pixels_per_step * world * args.steps / dt / 1e6, 1)}
+        if args.exchange == "gather":
+            cs_len = assembled_bytes(params, ntiles, nblocks, W * world if ntiles == 1 else 0, H, last_parts, last_root)
+        other = "counts" if args.exchange == "gather" else "gather"
+        if not args.no_workloads:
+            dt2, parts2, root2 = run_frames(params, ntiles, d_px, nblocks, other, args.steps, args.warmup)
+            per[other] = {"ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                          "Mpixels_s": round(pixels_per_step * world * args.steps / dt2 / 1e6, 1)}
+            if other == "gather":
+                cs_len = assembled_bytes(params, ntiles, nblocks, W * world if ntiles == 1 else 0, H, parts2, root2)
+        elif args.exchange != "gather":
+            cs_len = 0
+        multi_gpu["replica_%s" % args.workload] = {
+            "shape": "one %dx%d tile per rank and frame (a %dx%d frame), weak scaling" % (W, H, W * world, H) if ntiles == 1 else desc,
+            "gather": per.get("gather"), "counts": per.get("counts"),
+            "note": "gather = coded tile-parts + block tables to the frame's writer (rank f mod N), exact sizes, issued one frame "
+                    "behind the encoder; counts = all_gather of 16 bytes per rank (parallel writers)"}
+        # BASELINE configs[3]: 16384x16384 as 256 tiles of 1024x1024, the tiles split over the ranks (strong scaling)
+        if not args.no_workloads and args.workload == "8k" and 256 % world == 0:
+            p4 = G.TileParams.make(1024, 1024, 3, 8, 5)
+            nt4 = 256 // world
+            t4 = synth.g2(3, 1024, 1024, 8)
+            h4 = np.ascontiguousarray(np.broadcast_to(t4.reshape(1, -1), (nt4, t4.size))).reshape(-1)
+            d4 = torch.from_numpy(h4.view(np.uint8)).to(dev)
+            nb4 = G.lib().grk_amd_tile_num_blocks(C.byref(p4)) * nt4
+            ctx.encode_tiles(p4, nt4, d4.data_ptr(), True, fetch=False)
+            ctx.synchronize()
+            res4 = {}
+            for ex in ("gather", "counts"):
+                st4 = max(3, args.steps // 2)
+                d_t, parts4, root4 = run_frames(p4, nt4, d4, nb4, ex, st4, 2)
+                res4[ex] = {"ms_per_step": round(d_t / st4 * 1e3, 4), "Mpixels_s": round(16384.0 * 16384.0 * st4 / d_t / 1e6, 1)}
+                if ex == "gather":
+                    res4["assembled_block_bytes"] = assembled_bytes(p4, nt4, nb4, 0, 0, parts4, root4)
+            multi_gpu["cfg4_strong"] = {"shape": "16384x16384x3 8-bit as 256 tiles of 1024x1024, %d tiles per rank and frame, "
+                                                 "strong scaling (BASELINE configs[3])" % nt4, **res4}
+            del d4
+            # back to the headline shape for the per-kernel passes below
+            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+            ctx.synchronize()
 
     # ---- the decode direction on the blocks just produced (HBM-resident coded bytes -> pixels) ----
     decode = None
@@ -489,11 +541,12 @@ def main():
                for k, v in fam.items()}
     if not use_dist:
         parallelism = "1 GPU, consecutive encodes pipelined (grk_amd_set_pipelining)" if pipelined else "1 GPU"
-    elif args.exchange == "offsets":
-        parallelism = ("tile-sharded x%d, per step all_gather of the coded byte counts (RCCL): every rank learns its "
-                       "tile-parts' offsets in the codestream, the bytes stay on their GPU" % world)
+    elif args.exchange == "counts":
+        parallelism = ("tile-sharded x%d, per frame all_gather of the coded byte counts (RCCL): parallel writers, the bytes "
+                       "stay on their GPU" % world)
     else:
-        parallelism = "tile-sharded x%d, coded tile-parts gathered on rank 0 every step (RCCL)" % world
+        parallelism = ("tile-sharded x%d, per frame the coded tile-parts (exact sizes) gathered over RCCL on the frame's writer "
+                       "rank, which rotates with the frame number; the gather runs one frame behind the encoder" % world)
     kernels_overlapped = {k: {"avg_ms": round(v[0], 4), "launches": v[1]} for k, v in fam_overlapped.items()}
     # whole-pipeline figure of SURVEY.md §8(d) (unfused definition, kept so that rounds compare)
     pipeline_bytes = samples * (b_in + 4) + 8.0 * samples * sigma(levels) + algo["ht_cleanup_encode"]
@@ -524,6 +577,7 @@ def main():
         }
         if use_dist:
             out["config"]["assembled_codestream_bytes"] = cs_len
+            out["multi_gpu"] = multi_gpu
         cfg5 = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], cfg5 = cpu_baseline(os.cpu_count() or 1, want_cfg5=not args.no_workloads and args.workload == "8k")
@@ -547,13 +601,21 @@ def main():
         print(line, flush=True)
 
 
+_views = {}
+
+
 def _as_tensor(ptr, n, dev, typestr="|u1"):
-    """Zero-copy view of a raw device pointer (context-owned memory): n elements of `typestr`."""
-    class _Holder:
-        pass
-    h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(h, device=dev)
+    """Zero-copy view of a raw device pointer (context-owned memory): n elements of `typestr` (cached: the encoder's
+    buffer sets alternate between a handful of addresses)."""
+    key = (int(ptr), int(n), typestr)
+    t = _views.get(key)
+    if t is None:
+        class _Holder:
+            pass
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        t = _views[key] = torch.as_tensor(h, device=dev)
+    return t
 
 
 if __name__ == "__main__":

@@ -6,7 +6,8 @@ package is only the ctypes binding used by bench.py and the tests; it never comp
 itself and raises loudly when the native library is missing.
 """
 from .capi import (TileParams, Block, CodedBlock, Context, lib, lib_path, NativeLibraryMissing,
-                   tile_layout, write_codestream)
+                   tile_layout, write_codestream, write_tile_part, write_main_header, locate_tile_parts,
+                   CS_TLM, CS_PLT)
 
 __all__ = ["TileParams", "Block", "CodedBlock", "Context", "lib", "lib_path", "NativeLibraryMissing",
-           "tile_layout", "write_codestream"]
+           "tile_layout", "write_codestream", "write_tile_part", "write_main_header", "locate_tile_parts", "CS_TLM", "CS_PLT"]

@@ -101,6 +101,14 @@ def lib():
         L.grk_amd_kernel_ms.argtypes = [vp, i32, C.POINTER(u32)]
         L.grk_amd_write_codestream.restype = C.c_int64
         L.grk_amd_write_codestream.argtypes = [PP, u32, u32, vp, vp, vp, u64]
+        L.grk_amd_write_codestream_ex.restype = C.c_int64
+        L.grk_amd_write_codestream_ex.argtypes = [PP, u32, u32, vp, vp, u32, vp, u64]
+        L.grk_amd_write_main_header.restype = C.c_int64
+        L.grk_amd_write_main_header.argtypes = [PP, u32, u32, u32, vp, vp, u64]
+        L.grk_amd_write_tile_part.restype = C.c_int64
+        L.grk_amd_write_tile_part.argtypes = [PP, u32, u32, vp, vp, vp, u64]
+        L.grk_amd_locate_tile_parts.restype = C.c_int64
+        L.grk_amd_locate_tile_parts.argtypes = [vp, u64, vp, vp, vp, u64, C.POINTER(i32)]
         _lib = L
     return _lib
 
@@ -119,17 +127,62 @@ def tile_layout(params):
     return list(blocks), list(qcd)[:3 * params.num_levels + 1]
 
 
-def write_codestream(params, img_w, img_h, table, coded):
-    """table: ctypes array / numpy structured array of CodedBlock rows; coded: bytes-like."""
+CS_TLM, CS_PLT = 1, 2
+
+
+def write_codestream(params, img_w, img_h, table, coded, flags=0):
+    """table: ctypes array / numpy structured array of CodedBlock rows; coded: bytes-like; flags: CS_TLM | CS_PLT."""
     L = lib()
     cbuf = np.frombuffer(coded, np.uint8) if not isinstance(coded, np.ndarray) else coded
     cap = int(cbuf.size) + len(table) * 8 + (1 << 20)
     out = np.empty(cap, np.uint8)
     tptr = table.ctypes.data if isinstance(table, np.ndarray) else C.addressof(table)
-    n = L.grk_amd_write_codestream(C.byref(params), img_w, img_h, tptr, cbuf.ctypes.data, out.ctypes.data, cap)
+    n = L.grk_amd_write_codestream_ex(C.byref(params), img_w, img_h, tptr, cbuf.ctypes.data, flags, out.ctypes.data, cap)
     if n < 0:
         raise RuntimeError("grk_amd_write_codestream failed: %d" % n)
     return out[:n].tobytes()
+
+
+def write_tile_part(params, tile_index, tile_table, coded, flags=0, size_only=False):
+    """One tile-part (SOT [PLT] SOD packets) as bytes, or only its length (no coded bytes needed)."""
+    L = lib()
+    t = np.ascontiguousarray(tile_table)
+    if size_only:
+        n = L.grk_amd_write_tile_part(C.byref(params), tile_index, flags, t.ctypes.data, None, None, 0)
+        if n < 0:
+            raise RuntimeError("grk_amd_write_tile_part failed: %d" % n)
+        return int(n)
+    cbuf = np.frombuffer(coded, np.uint8) if not isinstance(coded, np.ndarray) else coded
+    cap = int(t["length"].sum()) + len(t) * 8 + 4096
+    out = np.empty(cap, np.uint8)
+    n = L.grk_amd_write_tile_part(C.byref(params), tile_index, flags, t.ctypes.data, cbuf.ctypes.data, out.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError("grk_amd_write_tile_part failed: %d" % n)
+    return out[:n].tobytes()
+
+
+def write_main_header(params, img_w, img_h, flags=0, tile_part_bytes=None):
+    L = lib()
+    out = np.empty(4096 + (5 * len(tile_part_bytes) if tile_part_bytes is not None else 0), np.uint8)
+    tp = np.ascontiguousarray(tile_part_bytes, np.uint32) if tile_part_bytes is not None else None
+    n = L.grk_amd_write_main_header(C.byref(params), img_w, img_h, flags, tp.ctypes.data if tp is not None else None,
+                                    out.ctypes.data, out.size)
+    if n < 0:
+        raise RuntimeError("grk_amd_write_main_header failed: %d" % n)
+    return out[:n].tobytes()
+
+
+def locate_tile_parts(cs):
+    """-> ([(offset, length, tile index)], used_tlm)"""
+    L = lib()
+    buf = np.frombuffer(cs, np.uint8)
+    n = L.grk_amd_locate_tile_parts(buf.ctypes.data, buf.size, None, None, None, 0, None)
+    if n < 0:
+        raise RuntimeError("grk_amd_locate_tile_parts failed: %d" % n)
+    off = np.zeros(n, np.uint64); ln = np.zeros(n, np.uint32); ti = np.zeros(n, np.uint16)
+    used = C.c_int(0)
+    L.grk_amd_locate_tile_parts(buf.ctypes.data, buf.size, off.ctypes.data, ln.ctypes.data, ti.ctypes.data, n, C.byref(used))
+    return [(int(a), int(b), int(c)) for a, b, c in zip(off, ln, ti)], bool(used.value)
 
 
 CODED_DTYPE = np.dtype([("offset", np.uint64), ("length", np.uint32), ("missing_msbs", np.uint32)])
@@ -264,7 +317,8 @@ class Context:
         self._check(self._L.grk_amd_stream_wait_results(self._h, C.c_void_p(hip_stream)), "stream_wait_results")
 
     def set_pipelining(self, on):
-        self._check(self._L.grk_amd_set_pipelining(self._h, int(bool(on))), "set_pipelining")
+        """False / True (two buffer sets) / 2 (three: results valid until the third next call)."""
+        self._check(self._L.grk_amd_set_pipelining(self._h, int(on)), "set_pipelining")
 
     def set_overlap(self, on):
         self._check(self._L.grk_amd_set_overlap(self._h, int(bool(on))), "set_overlap")

@@ -70,7 +70,9 @@ struct grk_amd_ctx {
     bool overlap = false;
     // Pipelining of consecutive encodes (grk_amd_set_pipelining): a second set of per-encode buffers, so that the next
     // encode's DWT can start while the side streams still code the blocks of this one
-    struct AltSet { DevBuf p1, arena, lengths, offsets, flag, ovf; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alt;
+    struct AltSet { DevBuf p1, arena, lengths, offsets, flag, ovf; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alt, alt2;
+    int pipe_depth = 2;              // buffer sets in rotation when pipelining: 2, or 3 (grk_amd_set_pipelining(ctx, 2): the
+                                     // results of a call then stay valid until the THIRD next call)
     DevBuf ovf;                      // K3: blocks handed to the fallback launch (kernels.h: HtArgs::ovf_list)
     bool lds_cap = true;             // K3 with capped LDS buffers + fallback launch (GRK_AMD_LDS_CAP=0: worst-case buffers)
     bool pipelining = false;
@@ -647,6 +649,8 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
             hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->alt.ev_side, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->alt.ev_side2, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->alt2.ev_side, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->alt2.ev_side2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_level0, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) {
             c->side = nullptr; c->overlap = false;
@@ -671,9 +675,12 @@ void grk_amd_destroy(grk_amd_ctx* c)
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
-    if (c->alt.ev_side) (void)hipEventDestroy(c->alt.ev_side);
-    if (c->alt.ev_side2) (void)hipEventDestroy(c->alt.ev_side2);
-    for (DevBuf* b : {&c->alt.p1, &c->alt.arena, &c->alt.lengths, &c->alt.offsets, &c->alt.flag, &c->alt.ovf, &c->ovf}) b->release();
+    for (auto* as : {&c->alt, &c->alt2}) {
+        if (as->ev_side) (void)hipEventDestroy(as->ev_side);
+        if (as->ev_side2) (void)hipEventDestroy(as->ev_side2);
+        for (DevBuf* b : {&as->p1, &as->arena, &as->lengths, &as->offsets, &as->flag, &as->ovf}) b->release();
+    }
+    c->ovf.release();
     if (c->ev_level0) (void)hipEventDestroy(c->ev_level0);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     for (DevBuf* b : {&c->dec_seg_dev}) b->release();
@@ -988,9 +995,19 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             // take the other buffer set: the blocks of the previous encode may still be being coded from the set used
             // last; the set taken now was last used two encodes ago, and its side-stream work is waited for here
             // (hipStreamWaitEvent on an event never recorded is a no-op)
-            std::swap(c->p1, c->alt.p1); std::swap(c->arena, c->alt.arena); std::swap(c->lengths, c->alt.lengths);
-            std::swap(c->offsets, c->alt.offsets); std::swap(c->flag, c->alt.flag); std::swap(c->ovf, c->alt.ovf);
-            std::swap(c->ev_side, c->alt.ev_side); std::swap(c->ev_side2, c->alt.ev_side2);
+            auto swap_with = [&](grk_amd_ctx::AltSet& as) {
+                std::swap(c->p1, as.p1); std::swap(c->arena, as.arena); std::swap(c->lengths, as.lengths);
+                std::swap(c->offsets, as.offsets); std::swap(c->flag, as.flag); std::swap(c->ovf, as.ovf);
+                std::swap(c->ev_side, as.ev_side); std::swap(c->ev_side2, as.ev_side2);
+            };
+            if (c->pipe_depth == 3) {       // (current, alt = last call's, alt2 = the call before) -> the oldest becomes current
+                swap_with(c->alt2);
+                std::swap(c->alt.p1, c->alt2.p1); std::swap(c->alt.arena, c->alt2.arena); std::swap(c->alt.lengths, c->alt2.lengths);
+                std::swap(c->alt.offsets, c->alt2.offsets); std::swap(c->alt.flag, c->alt2.flag); std::swap(c->alt.ovf, c->alt2.ovf);
+                std::swap(c->alt.ev_side, c->alt2.ev_side); std::swap(c->alt.ev_side2, c->alt2.ev_side2);
+            } else {
+                swap_with(c->alt);
+            }
             c->side_pending = false;
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0), "wait for the buffer set");
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side2, 0), "wait for the buffer set");
@@ -1038,6 +1055,7 @@ int grk_amd_set_pipelining(grk_amd_ctx* c, int on)
     if (!c) return GRK_AMD_ERR_INVALID;
     const int rc = grk_amd_synchronize(c);
     c->pipelining = on != 0 && c->side != nullptr && c->side2 != nullptr;
+    c->pipe_depth = on >= 2 ? 3 : 2;
     return rc;
 }
 

@@ -20,19 +20,19 @@ namespace {
 
 using namespace grk_amd;
 
-struct Out {
+struct Out {          // p == nullptr: only counts (ovf stays false)
     uint8_t* p; uint64_t cap; uint64_t n = 0; bool ovf = false;
-    void u8(uint32_t v) { if (n < cap) p[n] = (uint8_t)v; else ovf = true; ++n; }
+    void u8(uint32_t v) { if (p) { if (n < cap) p[n] = (uint8_t)v; else ovf = true; } ++n; }
     void u16(uint32_t v) { u8(v >> 8); u8(v & 0xFF); }
     void u32(uint32_t v) { u16(v >> 16); u16(v & 0xFFFF); }
     void bytes(const uint8_t* s, uint64_t len)
     {
-        if (n + len <= cap) std::memcpy(p + n, s, len); else ovf = true;
+        if (p) { if (n + len <= cap) std::memcpy(p + n, s, len); else ovf = true; }
         n += len;
     }
     void patch32(uint64_t at, uint32_t v)
     {
-        if (at + 4 <= cap) { p[at] = (uint8_t)(v >> 24); p[at + 1] = (uint8_t)(v >> 16); p[at + 2] = (uint8_t)(v >> 8); p[at + 3] = (uint8_t)v; }
+        if (p && at + 4 <= cap) { p[at] = (uint8_t)(v >> 24); p[at + 1] = (uint8_t)(v >> 16); p[at + 2] = (uint8_t)(v >> 8); p[at + 3] = (uint8_t)v; }
     }
 };
 
@@ -92,8 +92,10 @@ struct TagTree {
 
 int floor_log2(uint32_t v) { int r = 0; while (v >>= 1) ++r; return r; }
 
-void write_main_header(Out& o, const TileGeom& g, uint32_t img_w, uint32_t img_h)
+// tlm_at: where the Ptlm fields of the TLM marker segment start (0: none written)
+void write_main_header(Out& o, const TileGeom& g, uint32_t img_w, uint32_t img_h, uint32_t flags, uint32_t ntiles, uint64_t* tlm_at)
 {
+    if (tlm_at) *tlm_at = 0;
     const grk_amd_tile_params& p = g.p;
     o.u16(0xFF4F);                                                     // SOC
     o.u16(0xFF51); o.u16(38 + 3 * p.num_comps); o.u16(0x4000);         // SIZ, Rsiz: HTJ2K (Part 15)
@@ -123,6 +125,13 @@ void write_main_header(Out& o, const TileGeom& g, uint32_t img_w, uint32_t img_h
     } else {
         o.u16(0xFF5C); o.u16(3 + 2 * nb); o.u8(0x22);
         for (uint32_t i = 0; i < nb; ++i) o.u16(g.qcd_words[i]);
+    }
+    // TLM (markers/LengthMarkers.cpp:166-189, written between QCD and COM: CodeStreamCompress.cpp:734): Ztlm 0, Stlm 0x50 =
+    // one-byte tile index + four-byte tile-part length per tile-part; the lengths are patched in once they are known
+    if (flags & GRK_AMD_CS_TLM) {
+        o.u16(0xFF55); o.u16(4 + 5 * ntiles); o.u8(0); o.u8(0x50);
+        if (tlm_at) *tlm_at = o.n;
+        for (uint32_t t = 0; t < ntiles; ++t) { o.u8(t); o.u32(0); }
     }
     // COM (the reference's default comment, so that whole files compare byte for byte)
     static const char kCom[] = "Created by Grok     version 8.0.2";
@@ -166,19 +175,14 @@ void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_blo
     }
 }
 
-} // namespace
-
-extern "C" int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
-                                            const grk_amd_coded_block* table, const uint8_t* coded,
-                                            uint8_t* out, uint64_t cap)
+// checks shared by the entry points below; fills g
+int check_layout(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h, TileGeom& g, uint32_t& tcols, uint32_t& trows)
 {
-    if (!p || !table || !coded || !out) return GRK_AMD_ERR_INVALID;
-    TileGeom g;
     int rc = build_tile_geom(*p, g);
     if (rc != GRK_AMD_OK) return rc;
     // equally sized tiles on a grid whose pitch keeps every band aligned (see geometry.h)
     if (img_w % p->tile_w || img_h % p->tile_h) return GRK_AMD_ERR_UNSUPPORTED;
-    const uint32_t tcols = img_w / p->tile_w, trows = img_h / p->tile_h;
+    tcols = img_w / p->tile_w; trows = img_h / p->tile_h;
     if ((uint64_t)tcols * trows > 65535) return GRK_AMD_ERR_UNSUPPORTED;
     if (tcols * trows > 1 && ((p->tile_w | p->tile_h) & ((1u << p->num_levels) - 1))) return GRK_AMD_ERR_UNSUPPORTED;
     for (uint32_t r = 0; r <= p->num_levels && tcols * trows > 1; ++r)
@@ -189,20 +193,154 @@ extern "C" int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32
             if ((B.w % cw) && (cw % B.w)) return GRK_AMD_ERR_UNSUPPORTED;
             if ((B.h % chh) && (chh % B.h)) return GRK_AMD_ERR_UNSUPPORTED;
         }
+    return GRK_AMD_OK;
+}
+
+// SOT, (PLT,) SOD and the LRCP packets of one tile; returns the tile-part's length
+uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, const grk_amd_coded_block* tt, const uint8_t* coded)
+{
+    const grk_amd_tile_params& p = g.p;
+    const uint64_t sot = o.n;
+    o.u16(0xFF90); o.u16(10); o.u16(t); o.u32(0); o.u8(0); o.u8(1);
+    if (flags & GRK_AMD_CS_PLT) {
+        // PLT (markers/LengthMarkers.cpp:313-374, written in front of SOD: TileProcessor.cpp:719-726): Zplt 0, then every
+        // packet's length as a big-endian base-128 number (continuation bit 0x80).  The packets are sized with a counting pass.
+        std::vector<uint8_t> body;
+        for (uint32_t r = 0; r <= p.num_levels; ++r)
+            for (uint32_t c = 0; c < p.num_comps; ++c) {
+                Out cnt{nullptr, 0};
+                write_packet(cnt, g, r, tt + (uint64_t)c * g.blocks_per_comp, coded);
+                uint8_t tmp[5]; int k = 0;
+                uint64_t v = cnt.n;
+                tmp[k++] = (uint8_t)(v & 0x7F);
+                while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
+                while (k) body.push_back(tmp[--k]);
+            }
+        // (one marker segment: 18 packets of a 6-resolution RGB tile need < 100 bytes; the reference starts another
+        //  segment near 64 KiB, LengthMarkers.cpp:315-316)
+        o.u16(0xFF58); o.u16((uint32_t)(3 + body.size())); o.u8(0);
+        o.bytes(body.data(), body.size());
+    }
+    o.u16(0xFF93);
+    for (uint32_t r = 0; r <= p.num_levels; ++r)
+        for (uint32_t c = 0; c < p.num_comps; ++c)
+            write_packet(o, g, r, tt + (uint64_t)c * g.blocks_per_comp, coded);
+    o.patch32(sot + 6, (uint32_t)(o.n - sot));
+    return o.n - sot;
+}
+
+} // namespace
+
+extern "C" int64_t grk_amd_write_codestream_ex(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
+                                               const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
+                                               uint8_t* out, uint64_t cap)
+{
+    if (!p || !table || !coded || !out) return GRK_AMD_ERR_INVALID;
+    TileGeom g;
+    uint32_t tcols = 0, trows = 0;
+    int rc = check_layout(p, img_w, img_h, g, tcols, trows);
+    if (rc != GRK_AMD_OK) return rc;
+    const uint32_t ntiles = tcols * trows;
+    if ((flags & GRK_AMD_CS_TLM) && ntiles > 255) return GRK_AMD_ERR_UNSUPPORTED;     // (one-byte Ttlm, as the reference writes it)
     Out o{out, cap};
-    write_main_header(o, g, img_w, img_h);
+    uint64_t tlm_at = 0;
+    write_main_header(o, g, img_w, img_h, flags, ntiles, &tlm_at);
     const uint64_t bpt = (uint64_t)g.blocks_per_comp * p->num_comps;
-    for (uint32_t t = 0; t < tcols * trows; ++t) {
-        const uint64_t sot = o.n;
-        o.u16(0xFF90); o.u16(10); o.u16(t); o.u32(0); o.u8(0); o.u8(1);
-        o.u16(0xFF93);
-        const grk_amd_coded_block* tt = table + t * bpt;
-        for (uint32_t r = 0; r <= p->num_levels; ++r)
-            for (uint32_t c = 0; c < p->num_comps; ++c)
-                write_packet(o, g, r, tt + (uint64_t)c * g.blocks_per_comp, coded);
-        o.patch32(sot + 6, (uint32_t)(o.n - sot));
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const uint64_t len = write_tile_part(o, g, t, flags, table + t * bpt, coded);
+        if (tlm_at) o.patch32(tlm_at + 5ull * t + 1, (uint32_t)len);
     }
     o.u16(0xFFD9);
     if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
     return (int64_t)o.n;
+}
+
+extern "C" int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
+                                            const grk_amd_coded_block* table, const uint8_t* coded,
+                                            uint8_t* out, uint64_t cap)
+{
+    return grk_amd_write_codestream_ex(p, img_w, img_h, table, coded, 0, out, cap);
+}
+
+extern "C" int64_t grk_amd_write_main_header(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h, uint32_t flags,
+                                             const uint32_t* tile_part_bytes, uint8_t* out, uint64_t cap)
+{
+    if (!p) return GRK_AMD_ERR_INVALID;
+    TileGeom g;
+    uint32_t tcols = 0, trows = 0;
+    int rc = check_layout(p, img_w, img_h, g, tcols, trows);
+    if (rc != GRK_AMD_OK) return rc;
+    const uint32_t ntiles = tcols * trows;
+    if (flags & GRK_AMD_CS_TLM) { if (ntiles > 255) return GRK_AMD_ERR_UNSUPPORTED; if (!tile_part_bytes) return GRK_AMD_ERR_INVALID; }
+    Out o{out, cap};
+    uint64_t tlm_at = 0;
+    write_main_header(o, g, img_w, img_h, flags, ntiles, &tlm_at);
+    for (uint32_t t = 0; tlm_at && t < ntiles; ++t) o.patch32(tlm_at + 5ull * t + 1, tile_part_bytes[t]);
+    if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
+    return (int64_t)o.n;
+}
+
+extern "C" int64_t grk_amd_write_tile_part(const grk_amd_tile_params* p, uint32_t tile_index, uint32_t flags,
+                                           const grk_amd_coded_block* tile_table, const uint8_t* coded, uint8_t* out, uint64_t cap)
+{
+    if (!p || !tile_table || (out && !coded)) return GRK_AMD_ERR_INVALID;
+    TileGeom g;
+    int rc = build_tile_geom(*p, g);
+    if (rc != GRK_AMD_OK) return rc;
+    Out o{out, cap};
+    write_tile_part(o, g, tile_index, flags, tile_table, coded);
+    if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
+    return (int64_t)o.n;
+}
+
+// Random access into a codestream (the reader's side of markers/LengthMarkers.cpp:91-164): where every tile-part starts
+// and how long it is -- from the TLM marker segments when the main header carries them (no byte of a tile-part is
+// touched), else by hopping from SOT to SOT over Psot.
+extern "C" int64_t grk_amd_locate_tile_parts(const uint8_t* cs, uint64_t len, uint64_t* offsets, uint32_t* lengths,
+                                             uint16_t* tile_index, uint64_t cap, int* used_tlm)
+{
+    if (!cs || len < 4 || cs[0] != 0xFF || cs[1] != 0x4F) return GRK_AMD_ERR_INVALID;
+    auto be16 = [&](uint64_t i) { return (uint32_t)(cs[i] << 8 | cs[i + 1]); };
+    auto be32 = [&](uint64_t i) { return (uint32_t)cs[i] << 24 | (uint32_t)cs[i + 1] << 16 | (uint32_t)cs[i + 2] << 8 | cs[i + 3]; };
+    std::vector<std::pair<uint32_t, uint32_t>> tlm;       // (tile index or 0xFFFFFFFF = "next", length), in marker order
+    uint64_t at = 2;
+    bool have_tlm = false;
+    while (at + 4 <= len) {
+        const uint32_t m = be16(at);
+        if (m == 0xFF90) break;
+        const uint32_t l = be16(at + 2);
+        if (m < 0xFF00 || l < 2 || at + 2 + l > len) return GRK_AMD_ERR_INVALID;
+        if (m == 0xFF55 && l >= 4) {
+            have_tlm = true;
+            const uint32_t stlm = cs[at + 5], st = (stlm >> 4) & 3u, sp = (stlm >> 6) & 1u;
+            const uint32_t rec = st + (sp ? 4u : 2u);
+            if (st == 3) return GRK_AMD_ERR_INVALID;
+            for (uint64_t q = at + 6; q + rec <= at + 2 + l; q += rec) {
+                const uint32_t ti = st == 0 ? 0xFFFFFFFFu : st == 1 ? cs[q] : be16(q);
+                tlm.emplace_back(ti, sp ? be32(q + st) : be16(q + st));
+            }
+        }
+        at += 2 + l;
+    }
+    if (at + 12 > len || be16(at) != 0xFF90) return GRK_AMD_ERR_INVALID;
+    if (used_tlm) *used_tlm = have_tlm ? 1 : 0;
+    uint64_t n = 0;
+    if (have_tlm) {
+        uint32_t next = 0;
+        for (const auto& e : tlm) {
+            const uint32_t ti = e.first == 0xFFFFFFFFu ? next : e.first;
+            if (at + e.second > len) return GRK_AMD_ERR_INVALID;
+            if (n < cap) { if (offsets) offsets[n] = at; if (lengths) lengths[n] = e.second; if (tile_index) tile_index[n] = (uint16_t)ti; }
+            ++n; at += e.second; next = ti + 1;
+        }
+        return (int64_t)n;
+    }
+    while (at + 12 <= len && be16(at) == 0xFF90) {
+        const uint32_t psot = be32(at + 6);
+        const uint64_t l = psot ? psot : len - 2 - at;            // Psot 0: the last tile-part runs to EOC
+        if (l < 14 || at + l > len) return GRK_AMD_ERR_INVALID;
+        if (n < cap) { if (offsets) offsets[n] = at; if (lengths) lengths[n] = (uint32_t)l; if (tile_index) tile_index[n] = (uint16_t)be16(at + 4); }
+        ++n; at += l;
+    }
+    return (int64_t)n;
 }

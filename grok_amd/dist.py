@@ -1,11 +1,22 @@
 """Tile sharding across the GPUs of a node (one process per GPU, torch.distributed; backend "nccl"
 is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
 
-Tiles of a JPEG 2000 image are independent, so the data path needs no collective:
-rank r encodes tiles {t : t mod R == r}.  The only exchanges are
+Tiles of a JPEG 2000 image are independent (the reference runs them as independent tasks and
+writes their tile-parts in index order, codestream/CodeStreamCompress.cpp:535-603), so the data path needs no
+collective: rank r encodes tiles {t : t mod R == r}.  The exchanges are
   * broadcast of the coding-parameter blob from rank 0 (a few bytes, once), and
-  * the gather of the coded tile-parts to the rank that writes the codestream:
-    all_gather of byte counts, then gather of the (padded) coded arenas.
+  * per frame, what it takes to make ONE codestream of the ranks' tile-parts:
+      exchange_counts   -- all_gather of (bytes used in the coded arena, rows of the block table) per rank.  These are
+                           ARENA EXTENTS (they include the allocator's 16-byte alignment of every block and exclude packet
+                           headers): they size the transfer below; a tile-part's place in the FILE is known once the
+                           writer has run Tier-2 over the gathered block lengths (grk_amd_tile_part_bytes / merge_tile_parts).
+      gather_frame      -- every rank's coded bytes and block table to the frame's writer rank, EXACT sizes (grouped
+                           send / recv, no padding to the largest rank).  The writer rotates with the frame number
+                           (frame f -> rank f mod R): funnelling every frame into one GPU would bound the job by that
+                           GPU's xGMI ingress (7 links), rotating spreads the same traffic over all of them.
+    The receive sizes have to be known on the host, so a frame's gather is issued one frame late (FramePipeline): the
+    counts travel device -> pinned host memory asynchronously behind the encode, and are read when the next frame has
+    already been queued -- the GPU never waits for the host.
 """
 import ctypes as C
 
@@ -32,104 +43,162 @@ def broadcast_params(params, device, src=0):
     return TileParams.from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
 
 
-def gather_tile_parts(table, coded, device, dst=0, scratch=None):
-    """Gather this rank's coded blocks on rank `dst`.
+def exchange_counts(used, nrows, out=None):
+    """all_gather of this rank's (arena bytes used, block-table rows): int64[world, 2] on the device, no host
+    synchronisation.  `used`: int64[1] device tensor (grk_amd_table_device_ptr(ctx, 2)) or an int; `nrows`: int."""
+    world = dist.get_world_size()
+    dev = used.device if isinstance(used, torch.Tensor) else torch.device("cpu")
+    mine = torch.empty(2, dtype=torch.int64, device=dev)
+    mine[0:1] = used.reshape(1).to(torch.int64) if isinstance(used, torch.Tensor) else int(used)
+    mine[1] = int(nrows)
+    if out is None:
+        out = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    return out.view(world, 2)
 
-    table : numpy CODED_DTYPE rows of this rank's blocks (offsets relative to `coded`)
-    coded : 1-D uint8 torch tensor on `device` holding the coded bytes (may be longer than needed)
-    returns on dst: list over ranks of (table, coded uint8 tensor); elsewhere None.
-    """
+
+def gather_frame(counts_host, offsets, lengths, arena, root, bufs=None):
+    """Every rank's coded bytes + block table to `root`, exact sizes.
+
+    counts_host : [[bytes used, table rows]] per rank, ON THE HOST (what exchange_counts() gathered)
+    offsets     : int64[rows] / lengths: int32[rows] / arena: uint8[>= used] -- this rank's (device) tensors, e.g. views of
+                  the encoder's own table and arena (grk_amd_table_device_ptr, grk_amd_coded_device_ptr)
+    bufs        : root's receive storage from an earlier call (grown as needed) or None
+    Returns on root ([(offsets, lengths, coded) per rank], bufs) -- the root's own part is referenced, not copied --,
+    elsewhere (None, None)."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    used = int((table["offset"] + table["length"]).max()) if len(table) else 0
-    meta = torch.tensor([used, len(table)], dtype=torch.int64, device=device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    sizes = [int(m[0].item()) for m in metas]
-    nrows = [int(m[1].item()) for m in metas]
-    pad = (max(sizes) + 4095) & ~4095
-    maxrows = max(nrows)
-    # block tables travel as int64 triples (offset, length, 0)
-    tab = torch.zeros(maxrows * 2, dtype=torch.int64, device=device)
-    if len(table):
-        tab[0:2 * len(table):2] = torch.from_numpy(table["offset"].astype(np.int64)).to(device)
-        tab[1:2 * len(table):2] = torch.from_numpy(table["length"].astype(np.int64)).to(device)
-    if coded.numel() < pad:
-        buf = torch.zeros(pad, dtype=torch.uint8, device=device)
-        buf[:coded.numel()] = coded
-    else:
-        buf = coded[:pad]
-    if rank == dst:
-        if scratch is None or scratch[0].numel() < pad:
-            scratch = [torch.empty(pad, dtype=torch.uint8, device=device) for _ in range(world)]
-        bufs = [s[:pad] for s in scratch]
-        tabs = [torch.empty_like(tab) for _ in range(world)]
-        dist.gather(buf, bufs, dst=dst)
-        dist.gather(tab, tabs, dst=dst)
-        out = []
-        for r in range(world):
-            t = np.zeros(nrows[r], CODED_DTYPE)
-            tt = tabs[r].cpu().numpy()
-            t["offset"] = tt[0:2 * nrows[r]:2]
-            t["length"] = tt[1:2 * nrows[r]:2]
-            out.append((t, bufs[r][:sizes[r]]))
-        return out, scratch
-    dist.gather(buf, None, dst=dst)
-    dist.gather(tab, None, dst=dst)
-    return None, scratch
+    sizes = [int(c[0]) for c in counts_host]
+    rows = [int(c[1]) for c in counts_host]
+    dev = arena.device
+    if rank != root:
+        ops = [dist.P2POp(dist.isend, arena[:sizes[rank]], root),
+               dist.P2POp(dist.isend, offsets[:rows[rank]], root),
+               dist.P2POp(dist.isend, lengths[:rows[rank]], root)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return None, None
+    need_b = sum(s for r, s in enumerate(sizes) if r != root)
+    need_r = sum(n for r, n in enumerate(rows) if r != root)
+    if bufs is None or bufs[0].numel() < need_b or bufs[1].numel() < need_r:
+        bufs = (torch.empty(max(need_b, 1), dtype=torch.uint8, device=dev),
+                torch.empty(max(need_r, 1), dtype=torch.int64, device=dev),
+                torch.empty(max(need_r, 1), dtype=torch.int32, device=dev))
+    parts, ops, ob, orow = [], [], 0, 0
+    for r in range(world):
+        if r == root:
+            parts.append((offsets[:rows[r]], lengths[:rows[r]], arena[:sizes[r]]))
+            continue
+        cb, co, cl = bufs[0][ob:ob + sizes[r]], bufs[1][orow:orow + rows[r]], bufs[2][orow:orow + rows[r]]
+        ob += sizes[r]
+        orow += rows[r]
+        ops += [dist.P2POp(dist.irecv, cb, r), dist.P2POp(dist.irecv, co, r), dist.P2POp(dist.irecv, cl, r)]
+        parts.append((co, cl, cb))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return parts, bufs
 
 
-def gather_tile_parts_device(used, offsets, lengths, arena, dst=0, scratch=None):
-    """The same exchange with everything already on the device and ONE host synchronisation (the byte counts,
-    which size the transfer): `used` int64[1] bytes used in `arena` (uint8[>= used]), `offsets` int64[n],
-    `lengths` int32[n] -- views of the encoder's own device table (grk_amd_table_device_ptr).
-    Returns on dst ([(offsets, lengths, coded uint8 tensor) per rank], scratch), elsewhere (None, scratch);
-    parts_to_numpy() turns them into what merge_tile_parts() takes."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    device = arena.device
-    meta = torch.cat([used.reshape(1).to(torch.int64), torch.tensor([offsets.numel()], dtype=torch.int64, device=device)])
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    m = torch.stack(metas).cpu()                       # the one synchronisation
-    sizes, nrows = [int(v) for v in m[:, 0]], [int(v) for v in m[:, 1]]
-    pad = (max(sizes) + 4095) & ~4095
-    maxrows = max(nrows)
-    if arena.numel() < pad:
-        buf = torch.zeros(pad, dtype=torch.uint8, device=device)
-        buf[:arena.numel()] = arena
-    else:
-        buf = arena[:pad]
-    if offsets.numel() < maxrows:
-        offsets = torch.cat([offsets, offsets.new_zeros(maxrows - offsets.numel())])
-        lengths = torch.cat([lengths, lengths.new_zeros(maxrows - lengths.numel())])
-    if rank == dst:
-        if scratch is None or scratch[0][0].numel() < pad or scratch[1][0].numel() != maxrows:
-            scratch = ([torch.empty(pad, dtype=torch.uint8, device=device) for _ in range(world)],
-                       [torch.empty(maxrows, dtype=torch.int64, device=device) for _ in range(world)],
-                       [torch.empty(maxrows, dtype=torch.int32, device=device) for _ in range(world)])
-        bufs = [s[:pad] for s in scratch[0]]
-        dist.gather(buf, bufs, dst=dst)
-        dist.gather(offsets, scratch[1], dst=dst)
-        dist.gather(lengths, scratch[2], dst=dst)
-        return [(scratch[1][r][:nrows[r]], scratch[2][r][:nrows[r]], bufs[r][:sizes[r]]) for r in range(world)], scratch
-    dist.gather(buf, None, dst=dst)
-    dist.gather(offsets, None, dst=dst)
-    dist.gather(lengths, None, dst=dst)
-    return None, scratch
+class FramePipeline:
+    """The per-frame exchange of a sequence of frames, one frame behind the encoder (see the module docstring).
+
+        pipe = FramePipeline(device)
+        per frame f:   encode ...;  pipe.submit(f, used, offsets, lengths, arena)     # queues the counts exchange of frame f
+                                                                                       # and the gather of frame f - 1
+        at the end:    parts = pipe.flush()                                            # gather of the last frame
+
+    `streams`: (encode stream, comm stream) as torch.cuda streams, or None on the CPU (gloo tests: everything in order).
+    The caller keeps a frame's tensors valid until the gather of that frame has been issued AND the stream that overwrites
+    them next has waited for `pipe.done_event(frame)`.  The gather of frame f is issued while frame f + 1 is being submitted,
+    after a host wait for f's byte counts: an encoder that rotates THREE buffer sets (grk_amd_set_pipelining(ctx, 2)) reuses
+    f's set for frame f + 3 and so never waits for that host round trip; with two sets it would sit between frames.  The number of block-table rows per rank is a property of the tile geometry: it is exchanged with the
+    first frame only; per frame the ranks exchange 8 bytes each (the bytes used in their coded arena), straight out of
+    the encoder's own device word -- no kernel, no allocation, no host synchronisation on the submitting side."""
+
+    def __init__(self, device, streams=None):
+        self.dev = device
+        self.streams = streams
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.rows = None               # block-table rows per rank
+        self.pending = None            # (frame, slot, offsets, lengths, arena)
+        self.bufs = None
+        self.last_parts = None         # on the last frame's writer: [(offsets, lengths, coded)] per rank
+        self.last_root = None
+        self.gather_done = None        # event: the most recent gather has finished reading its source tensors
+        cuda = device.type == "cuda"
+        self._host = [torch.empty(self.world, dtype=torch.int64).pin_memory() if cuda else torch.empty(self.world, dtype=torch.int64)
+                      for _ in range(2)]
+        self._dev = [torch.empty(self.world, dtype=torch.int64, device=device) for _ in range(2)]
+        self._ready = [torch.cuda.Event() for _ in range(2)] if cuda else [None, None]
+        self._done = {}                # frame -> event: the gather of that frame has read its source tensors
 
 
-def exchange_tile_part_offsets(used, counts=None):
-    """What a parallel codestream writer needs per step, and all it needs: every rank's coded byte count, from which
-    each rank knows where its tile-parts start in the file (exclusive prefix sum; headers are a host-side constant).
-    One all_gather of 8 bytes per rank over RCCL, enqueued on the current stream behind the encode -- no host
-    synchronisation, no coded byte leaves its GPU (each rank writes its own tile-parts at its offset; funnelling
-    N x ~100 MB per step into one GPU would bound the job by that GPU's xGMI ingress instead).
-    used: int64[1] device tensor (grk_amd_table_device_ptr(ctx, 2)).  Returns (counts int64[world], my offset int64[1])."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    if counts is None:
-        counts = torch.zeros(world, dtype=torch.int64, device=used.device)
-    dist.all_gather_into_tensor(counts, used.reshape(1).to(torch.int64))
-    starts = torch.cumsum(counts, 0) - counts
-    return counts, starts[rank:rank + 1]
+    def _issue_gather(self, pending):
+        f, slot, offs, lens, arena = pending
+        if self._ready[slot] is not None:          # the counts of frame f are on the host (frame f + 1 is already queued):
+            ev = self._ready[slot]                 # polled -- a blocking wait wakes up late, and the next frame's launches
+            while not ev.query():                  # have to be queued while this one runs
+                pass
+        counts = [[int(v), self.rows[r]] for r, v in enumerate(self._host[slot].tolist())]
+        root = f % self.world
+        mine = self.bufs if self.rank == root else None
+        if self.streams is not None:
+            with torch.cuda.stream(self.streams[1]):
+                parts, bufs = gather_frame(counts, offs, lens, arena, root, mine)
+                ev = self._done.pop(f - 4, None) or torch.cuda.Event()
+                ev.record(self.streams[1])
+                self._done[f] = ev
+                self.gather_done = ev
+        else:
+            parts, bufs = gather_frame(counts, offs, lens, arena, root, mine)
+        if bufs is not None:
+            self.bufs = bufs
+        self.last_parts, self.last_root = parts, root
+
+    def submit(self, frame, used, offsets, lengths, arena, wait_results=None):
+        """Queues the counts exchange of `frame` and issues the gather of the frame before it.
+        used: int64[1] tensor on the device (the encoder's own word);  wait_results: callable(comm stream handle) that makes
+        the comm stream wait for this frame's encode (grk_amd_stream_wait_results) -- CUDA only."""
+        if self.rows is None:
+            r = torch.tensor([offsets.numel()], dtype=torch.int64, device=self.dev)
+            allr = torch.empty(self.world, dtype=torch.int64, device=self.dev)
+            dist.all_gather_into_tensor(allr, r)
+            self.rows = [int(v) for v in allr.cpu()]
+        # first the gather of the frame before (its done-event must not sit behind anything that waits for THIS frame's
+        # encode: the encoder's next frame waits for that event before it reuses the buffer set), then this frame's counts
+        prev, self.pending = self.pending, None
+        if prev is not None:
+            self._issue_gather(prev)
+        slot = frame & 1
+        u = used.reshape(1)
+        if u.dtype != torch.int64:
+            u = u.to(torch.int64)
+        if self.streams is not None:
+            comm = self.streams[1]
+            if wait_results is not None:
+                wait_results(comm.cuda_stream)
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(self._dev[slot], u)
+                self._host[slot].copy_(self._dev[slot], non_blocking=True)
+                self._ready[slot].record(comm)
+        else:
+            dist.all_gather_into_tensor(self._dev[slot], u)
+            self._host[slot].copy_(self._dev[slot])
+        self.pending = (frame, slot, offsets, lengths, arena)
+
+    def done_event(self, frame):
+        """The event after which the tensors submitted for `frame` may be overwritten (None: nothing to wait for)."""
+        return self._done.get(frame)
+
+    def flush(self):
+        """Issues the gather of the last submitted frame; returns (parts on that frame's writer else None, writer rank)."""
+        if self.pending is not None:
+            self._issue_gather(self.pending)
+            self.pending = None
+        if self.streams is not None:
+            self.streams[1].synchronize()
+        return self.last_parts, self.last_root
 
 
 def parts_to_numpy(parts):

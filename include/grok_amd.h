@@ -220,7 +220,10 @@ int    grk_amd_set_overlap(grk_amd_ctx* ctx, int on);
  * streams, so the next call's DWT runs while the blocks of this one are still being coded.  The results of a call stay
  * valid until the second next call.  Every grk_amd_* function that reads them (fetch_table, fetch_coded, synchronize,
  * decode, the stage entry points) joins first; a caller that consumes grk_amd_coded_device_ptr / _table_device_ptr on
- * its own stream must call grk_amd_synchronize before.  Needs the overlap (above) to be on. */
+ * its own stream must call grk_amd_synchronize before.  Needs the overlap (above) to be on.
+ * on = 2: THREE buffer sets in rotation -- the results of a call stay valid until the third next call, for a consumer
+ * that works one frame behind the encoder (the tile-part gather of a tile-sharded job, grok_amd/dist.py: the receive sizes
+ * have to pass through the host, and with two sets that round trip would sit between consecutive frames). */
 int    grk_amd_set_pipelining(grk_amd_ctx* ctx, int on);
 /* Makes `hip_stream` (the caller's, e.g. the one its RCCL collectives run on) wait for the results of the latest encode
  * -- the context's stream and, when pipelined, its side streams -- without blocking the context's own stream: the
@@ -236,6 +239,30 @@ double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
 int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
                                  const grk_amd_coded_block* table, const uint8_t* coded,
                                  uint8_t* out, uint64_t cap);
+
+/* The same with the optional pointer marker segments of the reference's encoder (grk_compress -L / -X, grok.h
+ * grk_cparameters::writePLT / writeTLM; codestream/markers/LengthMarkers.cpp): TLM in the main header (one-byte tile index +
+ * four-byte tile-part length, <= 255 tiles), PLT (packet lengths) in every tile-part header. */
+#define GRK_AMD_CS_TLM 1u
+#define GRK_AMD_CS_PLT 2u
+int64_t grk_amd_write_codestream_ex(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
+                                    const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
+                                    uint8_t* out, uint64_t cap);
+/* The pieces of the above, for a tile-sharded job whose ranks write their own tile-parts (parallel writer: every rank sizes
+ * its tile-parts, the sizes are exchanged, each rank then knows its offsets in the file -- CodeStreamCompress.cpp:535-603
+ * writes the tile-parts in index order).  out == NULL: only the size is returned.
+ *   grk_amd_write_main_header  SOC SIZ CAP COD QCD [TLM with tile_part_bytes[tile], needed when flags has GRK_AMD_CS_TLM] COM
+ *   grk_amd_write_tile_part    SOT [PLT] SOD + LRCP packets of tile `tile_index`; tile_table = that tile's rows
+ *   (the codestream ends with EOC, 0xFFD9) */
+int64_t grk_amd_write_main_header(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h, uint32_t flags,
+                                  const uint32_t* tile_part_bytes, uint8_t* out, uint64_t cap);
+int64_t grk_amd_write_tile_part(const grk_amd_tile_params* p, uint32_t tile_index, uint32_t flags,
+                                const grk_amd_coded_block* tile_table, const uint8_t* coded, uint8_t* out, uint64_t cap);
+/* Random access (the reader's side of markers/LengthMarkers.cpp:91-164): offset, length and tile index of every tile-part
+ * of a codestream -- from its TLM marker segments when present (*used_tlm = 1: no byte of a tile-part is read), else by
+ * hopping over Psot.  Returns the number of tile-parts (entries beyond `cap` are counted, not stored) or < 0. */
+int64_t grk_amd_locate_tile_parts(const uint8_t* cs, uint64_t len, uint64_t* offsets, uint32_t* lengths,
+                                  uint16_t* tile_index, uint64_t cap, int* used_tlm);
 
 #ifdef __cplusplus
 }

@@ -165,6 +165,9 @@ static void fill_params(grk_cparameters& p, const EncCfg& c)
 	p.rateControlAlgorithm = (uint32_t)c.rate_algo;
 	if (c.cblk_w) p.cblockw_init = (uint32_t)c.cblk_w;
 	if (c.cblk_h) p.cblockh_init = (uint32_t)c.cblk_h;
+	// grk_compress -X / -L: pointer marker segments (TLM in the main header, PLT in the tile-part headers)
+	if (const char* e = getenv("REF_WRITE_TLM")) p.writeTLM = atoi(e) != 0;
+	if (const char* e = getenv("REF_WRITE_PLT")) p.writePLT = atoi(e) != 0;
 }
 
 static grk_image* make_image(const EncCfg& c, bool alloc)

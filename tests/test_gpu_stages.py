@@ -281,36 +281,40 @@ def _dev_view(ptr, n, typestr):
     return torch.as_tensor(h, device="cuda")
 
 
-def test_pipelined_encodes_keep_their_results_until_the_second_next_call():
+@pytest.mark.parametrize("depth", [1, 2])
+def test_pipelined_encodes_keep_their_results_until_the_second_next_call(depth):
     """grk_amd_set_pipelining: consecutive encodes overlap (the next one's DWT runs while this one's blocks are still
-    being coded), each working in its own buffer set.  Three different images back to back without any fetch in between:
-    the device-resident results of encode k are read AFTER encode k+1 has been issued, and equal a plain encode's."""
+    being coded), each working in its own buffer set.  Different images back to back without any fetch in between:
+    the device-resident results of encode k are read AFTER encode k+1 (two sets) / k+2 (three sets: set_pipelining(2))
+    has been issued, and equal a plain encode's."""
     p = G.TileParams.make(1024, 768, 3, 8, 5)
-    imgs = [synth.g2(3, 768, 1024, 8), (synth.g2(3, 768, 1024, 8)[:, ::-1, :]).copy(), (255 - synth.g2(3, 768, 1024, 8)).astype(np.uint8)]
+    imgs = [synth.g2(3, 768, 1024, 8), (synth.g2(3, 768, 1024, 8)[:, ::-1, :]).copy(), (255 - synth.g2(3, 768, 1024, 8)).astype(np.uint8),
+            synth.g2(3, 768, 1024, 8, seed=7), (synth.g2(3, 768, 1024, 8, seed=8)[:, :, ::-1]).copy()]
     want = []
     for im in imgs:
         t, coded = U.ctx().encode_host(p, im)
         want.append(U.split_blocks(t, coded))
     c = G.Context(0)
-    c.set_pipelining(True)
+    c.set_pipelining(depth)
     nb = G.lib().grk_amd_tile_num_blocks(p)
     d = [torch.from_numpy(im.reshape(-1)).cuda() for im in imgs]
     held = []
-    for k in range(3):
+    for k in range(len(imgs)):
         c.encode_tiles(p, 1, d[k].data_ptr(), True, fetch=False)
         held.append((c.coded_device_ptr(), c.table_device_ptr(0), c.table_device_ptr(1), c.table_device_ptr(2)))
-        if k >= 1:                       # look at encode k-1 now that encode k is in flight
+        if k >= depth:                   # look at encode k - depth now that `depth` more encodes are in flight
             torch.cuda.synchronize()
-            arena_p, off_p, len_p, used_p = held[k - 1]
+            arena_p, off_p, len_p, used_p = held[k - depth]
             used = int(_dev_view(used_p, 1, "<i8").cpu()[0])
             offs = _dev_view(off_p, nb, "<i8").cpu().numpy()
             lens = _dev_view(len_p, nb, "<i4").cpu().numpy()
             arena = _dev_view(arena_p, used, "|u1").cpu().numpy()
             got = [bytes(arena[int(o):int(o) + int(l)]) for o, l in zip(offs, lens)]
-            assert got == want[k - 1], "encode %d" % (k - 1)
+            assert got == want[k - depth], "encode %d" % (k - depth)
+    assert len({h[0] for h in held}) == depth + 1        # that many coded arenas in rotation
     t, tot = c.fetch_table(nb)           # the last one through the ordinary path (joins the side streams)
     coded = c.fetch_coded(tot)
-    assert U.split_blocks(t, coded) == want[2]
+    assert U.split_blocks(t, coded) == want[-1]
     c.set_pipelining(False)
     c.close()
 

@@ -1,0 +1,83 @@
+"""CPU: the pointer marker segments (TLM in the main header, PLT in the tile-part headers -- SURVEY.md §8f N4's
+"PLT/TLM random access", codestream/markers/LengthMarkers.cpp) as the reference's encoder writes them with
+grk_compress -X / -L, the tile-part pieces a parallel writer puts together, and the tile-part locator."""
+import os
+
+import numpy as np
+import pytest
+
+import grok_amd as G
+import cshelp
+import oracle as O
+import refharness as R
+import synth
+from grok_amd.capi import CODED_DTYPE
+
+needs_ref = pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref (the real reference) not built here")
+
+
+def _oracle_tiles(px, prec, L, TW, TH):
+    C, H, W = px.shape
+    p = G.TileParams.make(TW, TH, C, prec, L)
+    tabs, chunks, off = [], [], 0
+    for ty in range(H // TH):
+        for tx in range(W // TW):
+            tile = np.ascontiguousarray(px[:, ty * TH:(ty + 1) * TH, tx * TW:(tx + 1) * TW])
+            _, lens, coded = O.encode_tile_rev(tile, prec, L)
+            t = np.zeros(len(lens), CODED_DTYPE)
+            t["length"] = lens
+            t["offset"] = off + np.concatenate([[0], np.cumsum(lens)[:-1]])
+            off += int(lens.sum())
+            tabs.append(t)
+            chunks.append(coded)
+    return p, np.concatenate(tabs), np.concatenate(chunks)
+
+
+@needs_ref
+@pytest.mark.parametrize("tlm,plt", [(1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("C,H,W,TW,TH,L", [(3, 256, 256, 128, 128, 3), (1, 192, 320, 320, 192, 4), (3, 128, 384, 128, 128, 2)])
+def test_tlm_plt_as_grk_compress_writes_them(monkeypatch, tlm, plt, C, H, W, TW, TH, L):
+    px = synth.g2(C, H, W, 8)
+    monkeypatch.setenv("REF_WRITE_TLM", str(tlm))
+    monkeypatch.setenv("REF_WRITE_PLT", str(plt))
+    want, _ = R.encode(px, 8, TW=TW, TH=TH, numres=L + 1, mode=1)
+    p, table, coded = _oracle_tiles(px, 8, L, TW, TH)
+    got = G.write_codestream(p, W, H, table, coded, flags=(G.CS_TLM if tlm else 0) | (G.CS_PLT if plt else 0))
+    assert got == want
+    assert np.array_equal(R.decode(got, C, H, W), px.astype(np.int32))
+
+
+def test_parallel_writer_pieces_make_the_same_file_and_the_locator_finds_them():
+    """main header + every tile-part written on its own (sizes first: TLM needs them) + EOC == the one-call writer;
+    grk_amd_locate_tile_parts returns the same places from the TLM marker as from hopping over the SOTs."""
+    px = synth.g2(3, 256, 384, 8)
+    p, table, coded = _oracle_tiles(px, 8, 3, 128, 128)
+    ntiles, bpt = 6, len(table) // 6
+    for flags in (0, G.CS_TLM, G.CS_PLT, G.CS_TLM | G.CS_PLT):
+        whole = G.write_codestream(p, 384, 256, table, coded, flags=flags)
+        sizes = [G.write_tile_part(p, t, table[t * bpt:(t + 1) * bpt], None, flags=flags, size_only=True) for t in range(ntiles)]
+        parts = [G.write_tile_part(p, t, table[t * bpt:(t + 1) * bpt], coded, flags=flags) for t in range(ntiles)]
+        assert [len(x) for x in parts] == sizes
+        hdr = G.write_main_header(p, 384, 256, flags=flags, tile_part_bytes=sizes)
+        assert hdr + b"".join(parts) + b"\xff\xd9" == whole
+        where, used_tlm = G.locate_tile_parts(whole)
+        assert used_tlm == bool(flags & G.CS_TLM)
+        assert [w[2] for w in where] == list(range(ntiles)) and [w[1] for w in where] == sizes
+        at = len(hdr)
+        for (o, n, _), part in zip(where, parts):
+            assert o == at and whole[o:o + n] == part
+            at += n
+
+
+@needs_ref
+def test_locator_on_reference_streams(monkeypatch):
+    px = synth.g2(3, 256, 256, 8)
+    plain, _ = R.encode(px, 8, TW=128, TH=128, numres=4, mode=1)
+    monkeypatch.setenv("REF_WRITE_TLM", "1")
+    with_tlm, _ = R.encode(px, 8, TW=128, TH=128, numres=4, mode=1)
+    a, ua = G.locate_tile_parts(plain)
+    b, ub = G.locate_tile_parts(with_tlm)
+    assert (ua, ub) == (False, True) and len(a) == len(b) == 4
+    assert [x[1:] for x in a] == [x[1:] for x in b]
+    shift = len(with_tlm) - len(plain)
+    assert [x[0] + shift for x in a] == [x[0] for x in b]
