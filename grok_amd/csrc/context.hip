@@ -483,6 +483,29 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     a.quads = (uint32_t*)c->dec_quads.p; a.ms_len = (uint32_t*)c->dec_mslen.p; a.status = (unsigned int*)c->flag.p;
     a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.irreversible = g.p.irreversible;
+    if (!c->dec_seg_first.empty()) {
+        // HT blocks with refinement passes: segment 0 = the cleanup pass, segment 1 = SigProp (+ MagRef), end to end
+        if (c->dec_seg_first.size() != nblocks + 1 || c->dec_seg_first.back() != c->dec_segs.size())
+            return fail(c, GRK_AMD_ERR_INVALID, "segment list does not match the number of blocks");
+        std::vector<uint2> ref(nblocks, make_uint2(0u, 1u));
+        for (uint64_t i = 0; i < nblocks; ++i) {
+            const uint32_t s0 = c->dec_seg_first[i], ns = c->dec_seg_first[i + 1] - s0;
+            if (ns > 2) return fail(c, GRK_AMD_ERR_INVALID, "an HT code-block has at most two codeword segments");
+            uint64_t sum = 0;
+            for (uint32_t k = 0; k < ns; ++k) sum += c->dec_segs[s0 + k].length;
+            if (ns && sum != table[i].length) return fail(c, GRK_AMD_ERR_INVALID, "segment lengths do not add up to the block's length");
+            if (ns == 2 && c->dec_segs[s0 + 1].length) {
+                const uint32_t passes = 1u + std::min<uint32_t>(c->dec_segs[s0 + 1].numpasses, 2u);
+                ref[i] = make_uint2(c->dec_segs[s0 + 1].length, passes);
+                a.max_refine_bytes = std::max(a.max_refine_bytes, ref[i].x);
+            }
+        }
+        if (a.max_refine_bytes > (16u << 10)) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "refinement segment longer than 16 KiB");
+        HIP_TRY(c, c->dec_seg_dev.ensure(nblocks * sizeof(uint2) + 16), "alloc refinement table");
+        HIP_TRY(c, hipMemcpyAsync(c->dec_seg_dev.p, ref.data(), nblocks * sizeof(uint2), hipMemcpyHostToDevice, c->stream), "upload refinement table");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync refinement table");       // (uploaded from a local)
+        a.refine = (const uint2*)c->dec_seg_dev.p;
+    }
     ScopedTimer t(c, 5);
     HIP_TRY(c, launch_ht_decode(a, max_len, c->stream), "launch ht decode");
     return GRK_AMD_OK;

@@ -103,6 +103,9 @@ struct HtDecArgs {
     unsigned int* status;                      // bit 2: a block was rejected
     int32_t* mallat; uint32_t stride; uint64_t pitch;
     int irreversible;
+    const uint2* refine;                       // [nblocks] {bytes of the SigProp / MagRef segment at the end of the block's
+                                               // data, coding passes in total (1..3)}, or null: cleanup passes only
+    uint32_t max_refine_bytes;                 // largest such segment
 };
 hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s);
 

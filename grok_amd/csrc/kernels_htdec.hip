@@ -173,7 +173,8 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
     const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
     const uint32_t mm = in.missing_msbs;
     const uint8_t* D = a.coded + in.offset;
-    const int lcup = (int)in.length;
+    // (blocks with refinement passes: their SigProp / MagRef segment follows the cleanup segment)
+    const int lcup = (int)in.length - (a.refine ? (int)a.refine[blk].x : 0);
 
     if (in.length == 0) return;                            // absent (K5b writes the zeros) or outside the decoded region
     bool bad = mm > 29 || lcup < 2;
@@ -290,6 +291,13 @@ __device__ __forceinline__ uint32_t bperm(int addr, uint32_t v)
     return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v);
 }
 
+// the block carries SigProp (/ MagRef) data that the reference's decoder would use (ojph_block_decoder.cpp:1014-1019:
+// the passes need p = 30 - missing_msbs >= 2 and a non-empty second segment)
+__device__ __forceinline__ bool ht_block_refined(const HtDecArgs& a, uint32_t blk, uint32_t mm)
+{
+    return a.refine && a.refine[blk].x > 0 && a.refine[blk].y >= 2 && mm <= 28;
+}
+
 template <bool IRREV>
 __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw_words)
 {
@@ -346,6 +354,7 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
     // ---- quad rows ---------------------------------------------------------------------------------
     const uint32_t mm = in.missing_msbs;
     const uint32_t p = 30u - mm;
+    const bool refined = ht_block_refined(a, blk, mm);
     const uint32_t* qi = a.quads + (size_t)blk * kQuadWords;
     const uint32_t q = x >> 1, right = x & 1u;
     const int a_l1 = ((lane - 1) & 63) << 2, a_l2 = ((lane - 2) & 63) << 2;
@@ -391,9 +400,11 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
         const uint32_t wt = st ? ((bt << 31) | ((vt + 2u) << (p - 1u))) : 0u;
         const uint32_t wb = sb ? ((bb << 31) | ((vb + 2u) << (p - 1u))) : 0u;
         Eprev = sb ? 32u - (uint32_t)__clz((int)vb) : 0u;
-        // dequantise and store (PostDecompressFilters.h: ShiftHTFilter shift = 31 - (k_msbs + 1) = p)
+        // dequantise and store (PostDecompressFilters.h: ShiftHTFilter shift = 31 - (k_msbs + 1) = p); a block with
+        // refinement passes keeps the decoder's words: K5c refines them and dequantises
         int32_t ot, ob;
-        if constexpr (IRREV) {
+        if (refined) { ot = (int32_t)wt; ob = (int32_t)wb; }
+        else if constexpr (IRREV) {
             const float ft = (float)(int32_t)(wt & 0x7FFFFFFFu) * bd.inv_step;       // inv_step holds the decode scale here
             const float fb = (float)(int32_t)(wb & 0x7FFFFFFFu) * bd.inv_step;
             ot = __float_as_int((wt & 0x80000000u) ? -ft : ft);
@@ -407,6 +418,167 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
             const uint32_t y0 = 2 * qy;
             dst[(size_t)y0 * a.stride + x] = ot;
             if (y0 + 1 < h) dst[(size_t)(y0 + 1) * a.stride + x] = ob;
+        }
+    }
+}
+
+// ---- K5c: the refinement passes, ONE WAVEFRONT PER CODE-BLOCK ---------------------------------------------------------
+// Replaces the SigProp / MagRef half of ojph_decode_codeblock (t1/t1_ht/coding/ojph_block_decoder.cpp:1627-2100; bit
+// readers :466-550 rev_*_mrp, :875-945 frwd_* with X = 0).  Grok never reaches that code (T1HT.cpp:158-166 passes
+// lengths2 = 0): this is reachable through grk_amd_set_decode_segments only.  K5b left the cleanup pass's words in the
+// block's place in the Mallat plane; here, lane <-> column, one stripe of 4 rows at a time:
+//   * both segments are un-stuffed in parallel into LDS bit arrays, as K5b does with MagSgn (SigProp: forward, the byte
+//     after 0xFF has 7 bits; MagRef: backward from the end, a byte whose 7 low bits are ones has 7 bits after a byte > 0x8F);
+//   * MagRef is data-parallel: a sample's bit is at (significant samples before it in scan order) -- popcount of the lane's
+//     significance nibble, a wave prefix sum per stripe;
+//   * SigProp is one chain through the block (a newly significant sample makes its later neighbours members, and every bit's
+//     position depends on the members before it): the wave runs it as a uniform program on 64-bit row bitmaps (ballots), the
+//     way K8 runs its passes -- the column loop hops from member to member with find-first-set;
+//   * the stripe is dequantised (ShiftHTFilter / ScaleHTFilter) and stored as K5b would have.
+template <bool IRREV>
+__global__ __launch_bounds__(64) void ht_dec_refine_kernel(HtDecArgs a, uint32_t seg_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* spp_raw = lds;                    // un-stuffed SigProp bits (zeros beyond the end)
+    uint32_t* mrp_raw = lds + seg_words;        // un-stuffed MagRef bits, in reading order
+    const int lane = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const HtDecBlock in = a.table[blk];
+    if (in.length == 0 || !ht_block_refined(a, blk, in.missing_msbs) || a.ms_len[blk] == 0xFFFFFFFFu) return;
+    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
+    const uint32_t tile = blk / a.blocks_per_tile;
+    const uint32_t w = bd.w, h = bd.h;
+    const uint32_t len2 = a.refine[blk].x, npasses = a.refine[blk].y;
+    const uint32_t p = 30u - in.missing_msbs;
+    const uint8_t* seg = a.coded + in.offset + (in.length - len2);
+    int32_t* dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
+    const uint32_t x = lane;
+    const bool col_ok = x < w;
+
+    for (uint32_t i = lane; i < 2 * seg_words; i += 64) lds[i] = 0;
+    __syncthreads();
+    {   // un-stuff: byte i (SigProp: seg[i]; MagRef: seg[len2 - 1 - i]) contributes 8 or 7 bits
+        uint32_t base_s = 0, base_m = 0;
+        for (uint32_t i0 = 0; i0 < len2; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint32_t bs = 0, ws = 0, bm = 0, wm = 0;
+            if (i < len2) {
+                bs = seg[i];
+                const bool st = i > 0 && seg[i - 1] == 0xFFu;
+                ws = st ? 7u : 8u;
+                bs &= st ? 0x7Fu : 0xFFu;
+                bm = seg[len2 - 1 - i];
+                const bool un = i == 0 || seg[len2 - i] > 0x8Fu;
+                const bool sm = un && (bm & 0x7Fu) == 0x7Fu;
+                wm = sm ? 7u : 8u;
+                bm &= sm ? 0x7Fu : 0xFFu;
+            }
+            const uint32_t incl = wave_incl_scan(ws | (wm << 16));
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (i < len2) {
+                const uint32_t ps = base_s + (incl & 0xFFFFu) - ws, pm = base_m + (incl >> 16) - wm;
+                const uint64_t vs = (uint64_t)bs << (ps & 31), vm = (uint64_t)bm << (pm & 31);
+                lds_or(&spp_raw[ps >> 5], (uint32_t)vs); lds_or(&spp_raw[(ps >> 5) + 1], (uint32_t)(vs >> 32));
+                lds_or(&mrp_raw[pm >> 5], (uint32_t)vm); lds_or(&mrp_raw[(pm >> 5) + 1], (uint32_t)(vm >> 32));
+            }
+            base_s += tot & 0xFFFFu; base_m += tot >> 16;
+        }
+    }
+    __syncthreads();
+
+    const uint64_t wmask = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+    auto dilh = [&](uint64_t v) { return (v | (v << 1) | (v >> 1)) & wmask; };
+    uint32_t spp_pos = 0, mrp_pos = 0;          // bits consumed (wave-uniform)
+    auto spp_bit = [&]() -> uint32_t {
+        const uint32_t v = spp_pos < seg_words * 32u ? (spp_raw[spp_pos >> 5] >> (spp_pos & 31)) & 1u : 0u;
+        ++spp_pos;
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    uint64_t above = 0;                         // bottom row of the stripe above: significant after both passes
+    uint32_t nxt[4];                            // the next stripe's words (its top row feeds this stripe's membership)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nxt[j] = (col_ok && (uint32_t)j < h) ? (uint32_t)dst[(size_t)j * a.stride + x] : 0u;
+    for (uint32_t y0 = 0; y0 < h; y0 += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = nxt[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nxt[j] = (col_ok && y0 + 4 + j < h) ? (uint32_t)dst[(size_t)(y0 + 4 + j) * a.stride + x] : 0u;
+        const uint32_t nr = min(4u, h - y0);
+        uint64_t S[4];                           // cleanup significance of the stripe's rows
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[j] = __ballot(v[j] != 0u);
+        const uint64_t below = __ballot(nxt[0] != 0u);
+        // ---- MagRef: one bit per cleanup-significant sample, column by column
+        if (npasses >= 3) {
+            const uint32_t cnt = (v[0] != 0u) + (v[1] != 0u) + (v[2] != 0u) + (v[3] != 0u);
+            const uint32_t incl = wave_incl_scan(cnt);
+            uint32_t at = mrp_pos + incl - cnt;
+            mrp_pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (v[j] != 0u) {
+                    const uint32_t sym = at < seg_words * 32u ? (mrp_raw[at >> 5] >> (at & 31)) & 1u : 0u;
+                    ++at;
+                    v[j] = (v[j] ^ ((1u - sym) << (p - 1u))) | (1u << (p - 2u));
+                }
+        }
+        // ---- SigProp: members = insignificant samples with a significant neighbour; scanned in groups of 4 columns
+        uint64_t M[4], NEW[4] = {0, 0, 0, 0}, SG[4] = {0, 0, 0, 0};
+        {
+            const uint64_t rows_ok[4] = {wmask, nr > 1 ? wmask : 0ull, nr > 2 ? wmask : 0ull, nr > 3 ? wmask : 0ull};
+            const uint64_t d0 = dilh(S[0]), d1 = dilh(S[1]), d2 = dilh(S[2]), d3 = dilh(S[3]);
+            M[0] = (dilh(above) | d0 | d1) & ~S[0] & rows_ok[0];
+            M[1] = (d0 | d1 | d2) & ~S[1] & rows_ok[1];
+            M[2] = (d1 | d2 | d3) & ~S[2] & rows_ok[2];
+            M[3] = (d2 | d3 | dilh(below)) & ~S[3] & rows_ok[3];
+            for (uint32_t g0 = 0; g0 < w; g0 += 4) {
+                const uint64_t gm = (0xFull << g0) & wmask;
+                uint32_t xs = g0;
+                while (true) {                   // columns of the group that hold a member, left to right
+                    const uint64_t cm = (M[0] | M[1] | M[2] | M[3]) & gm & (~0ull << xs);
+                    if (!cm) break;
+                    const uint32_t xc = (uint32_t)__ffsll((long long)cm) - 1u;
+                    const uint64_t bitx = 1ull << xc, nb = (bitx << 1) & wmask;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!(M[j] & bitx)) continue;
+                        if (!spp_bit()) continue;
+                        NEW[j] |= bitx;
+                        // its later neighbours become members: the sample below, the three in the next column
+                        if (j < 3) M[j + 1] |= bitx & ~S[j + 1] & rows_ok[j + 1];
+                        if (j > 0) M[j - 1] |= nb & ~S[j - 1] & rows_ok[j - 1];
+                        M[j] |= nb & ~S[j] & rows_ok[j];
+                        if (j < 3) M[j + 1] |= nb & ~S[j + 1] & rows_ok[j + 1];
+                    }
+                    xs = xc + 1;
+                    if (xs >= 64) break;
+                }
+                uint64_t nm = (NEW[0] | NEW[1] | NEW[2] | NEW[3]) & gm;         // then the signs of the group's new samples
+                while (nm) {
+                    const uint32_t xc = (uint32_t)__ffsll((long long)nm) - 1u;
+                    const uint64_t bitx = 1ull << xc;
+                    nm &= nm - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (NEW[j] & bitx) { if (spp_bit()) SG[j] |= bitx; }
+                }
+            }
+        }
+        above = (S[nr - 1] | NEW[nr - 1]);
+        // ---- the stripe leaves dequantised
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((NEW[j] >> x) & 1ull) v[j] = ((uint32_t)((SG[j] >> x) & 1ull) << 31) | (3u << (p - 2u));
+            int32_t o;
+            if constexpr (IRREV) {
+                const float f = (float)(int32_t)(v[j] & 0x7FFFFFFFu) * bd.inv_step;
+                o = __float_as_int((v[j] & 0x80000000u) ? -f : f);
+            } else {
+                const int32_t mg = (int32_t)((v[j] & 0x7FFFFFFFu) >> p);
+                o = (v[j] & 0x80000000u) ? -mg : mg;
+            }
+            if (col_ok && (uint32_t)j < nr) dst[(size_t)(y0 + j) * a.stride + x] = o;
         }
     }
 }
@@ -439,6 +611,13 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
         hipLaunchKernelGGL(ht_dec_ms_kernel<true>, dim3(a.nblocks), dim3(64), raw_words * 4, s, a, raw_words);
     else
         hipLaunchKernelGGL(ht_dec_ms_kernel<false>, dim3(a.nblocks), dim3(64), raw_words * 4, s, a, raw_words);
+    if (a.refine && a.max_refine_bytes) {          // some block carries SigProp / MagRef data
+        const uint32_t seg_words = (a.max_refine_bytes * 8u) / 32u + 4u;
+        if (a.irreversible)
+            hipLaunchKernelGGL(ht_dec_refine_kernel<true>, dim3(a.nblocks), dim3(64), seg_words * 8, s, a, seg_words);
+        else
+            hipLaunchKernelGGL(ht_dec_refine_kernel<false>, dim3(a.nblocks), dim3(64), seg_words * 8, s, a, seg_words);
+    }
     return hipGetLastError();
 }
 

@@ -185,7 +185,11 @@ int grk_amd_set_decode_steps(grk_amd_ctx* ctx, const float* steps, uint32_t coun
  * t1/t1_part1/T1.cpp:1280-1318; Grok's own plugin bridge refuses those, plugin_bridge.cpp:50-61, so this is
  * reachable through this C ABI only).  Segments of block i are first_segment[i] .. first_segment[i+1]-1, their
  * bytes lie end to end at the block's offset.  Applies to the following decode calls; nblocks = 0 returns to
- * one segment per block (length and pass count of the table row). */
+ * one segment per block (length and pass count of the table row).
+ * HT blocks (reserved[0] = 0) with the refinement passes of T.814 -- SigProp, MagRef; ojph_decode_codeblock with
+ * lengths2 != 0, t1/t1_ht/coding/ojph_block_decoder.cpp:1627-2100, which Grok itself never reaches (T1HT.cpp:158-166) --
+ * use the same list: segment 0 = the cleanup pass {Lcup, 1}, segment 1 = {bytes of SigProp + MagRef, 1 or 2 passes}; the
+ * table row's length is their sum. */
 typedef struct grk_amd_segment { uint32_t length; uint32_t numpasses; } grk_amd_segment;
 int grk_amd_set_decode_segments(grk_amd_ctx* ctx, const uint32_t* first_segment, const grk_amd_segment* segments,
                                 uint32_t nblocks);

@@ -83,6 +83,13 @@ int32_t orc_encode_tile_rev(const void* pixels, int bytes_per_sample, uint32_t n
  *           words `sign<<31 | (2*mu+1) << (29-missing_msbs)`, row stride `stride`.  0 ok, -1 bad stream. */
 int32_t orc_ht_decode_block(const uint8_t* coded, uint32_t len, uint32_t missing_msbs,
                             uint32_t w, uint32_t h, uint32_t* out, uint32_t stride);
+/* ---- N3: the HT refinement passes (SigProp, MagRef) on top of the cleanup pass's output -- oracle/ht_refine_oracle.c
+ *           (t1/t1_ht/coding/ojph_block_decoder.cpp:1627-2100; bit readers :466-550, :875-945) and an encoder of them
+ *           that makes the test vectors (Grok's encoder never emits the passes) */
+int32_t orc_ht_refine_encode(const uint32_t* mag, const uint8_t* sign, uint32_t w, uint32_t h, uint32_t npasses,
+                             uint8_t* out, uint32_t cap, uint32_t* spp_len);
+int32_t orc_ht_refine_decode(uint32_t* words, uint32_t w, uint32_t h, uint32_t stride, uint32_t missing_msbs,
+                             const uint8_t* seg, uint32_t len2, uint32_t npasses);
 /* ---- a15: dequantisation (filters/PostDecompressFilters.h:94-106 ShiftHTFilter, :128-140 ScaleHTFilter) */
 void orc_ht_dequant_rev(const uint32_t* sm, uint32_t n, uint32_t k_msbs, int32_t* out);
 void orc_ht_dequant_irrev(const uint32_t* sm, uint32_t n, float scale, float* out);

@@ -142,6 +142,22 @@ int32_t ref_ht_decode_block(const uint8_t* coded, uint32_t len, uint32_t missing
 	return ok ? 0 : -1;
 }
 
+// The same with the refinement passes: coded = cleanup segment (lengths1 bytes) followed by the SigProp / MagRef segment
+// (lengths2 bytes); num_passes 1..3.  Grok never calls the decoder this way (T1HT.cpp:158-166: lengths2 = 0); the
+// function itself handles it (ojph_block_decoder.cpp:1054-1058, :1627-2100), which is what pins oracle/ht_refine_oracle.c.
+int32_t ref_ht_decode_block_passes(const uint8_t* coded, uint32_t lengths1, uint32_t lengths2, uint32_t num_passes,
+								   uint32_t missing_msbs, uint32_t w, uint32_t h, uint32_t* out)
+{
+	const uint32_t len = lengths1 + lengths2;
+	std::vector<uint8_t> buf(len + 64, 0);
+	memcpy(buf.data() + 16, coded, len);
+	const uint32_t stride = ((w + 7u) & ~7u) + 8u;
+	std::vector<uint32_t> tmp((size_t)stride * (h + 8), 0);
+	bool ok = ojph::local::ojph_decode_codeblock(buf.data() + 16, tmp.data(), missing_msbs, num_passes, lengths1, lengths2, w, h, stride);
+	for (uint32_t y = 0; y < h; ++y) memcpy(out + (size_t)y * w, tmp.data() + (size_t)y * stride, w * 4);
+	return ok ? 0 : -1;
+}
+
 // ---------------------------------------------------------------- whole codec
 struct EncCfg {
 	int32_t C, W, H, TW, TH, prec, irrev, numres, ht, mode; // mode 0: grk_compress_tile, 1: grk_compress(image data)

@@ -120,6 +120,36 @@ def ht_decode_block(coded, missing_msbs, w, h):
     return out if rc == 0 else None
 
 
+def ht_refine_encode(mag, sign, npasses):
+    """mag: (h, w) magnitudes whose LSB is bit-plane p - 1 (the cleanup pass codes mag >> 1), sign: (h, w) 0 / 1.
+    -> (refinement segment bytes, length of its SigProp part)"""
+    L = lib()
+    L.orc_ht_refine_encode.restype = C.c_int32
+    L.orc_ht_refine_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                       C.POINTER(C.c_uint32)]
+    m = np.ascontiguousarray(mag, np.uint32)
+    sg = np.ascontiguousarray(sign, np.uint8)
+    h, w = m.shape
+    out = np.zeros(w * h + 64, np.uint8)
+    spp = C.c_uint32(0)
+    n = L.orc_ht_refine_encode(m.ctypes.data, sg.ctypes.data, w, h, npasses, out.ctypes.data, out.size, C.byref(spp))
+    assert n >= 0
+    return out[:n].tobytes(), spp.value
+
+
+def ht_refine_decode(words, missing_msbs, seg, npasses):
+    """words: (h, w) uint32 output of the cleanup pass; returns them refined by the passes in `seg`."""
+    L = lib()
+    L.orc_ht_refine_decode.restype = C.c_int32
+    L.orc_ht_refine_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+    o = np.ascontiguousarray(words, np.uint32).copy()
+    h, w = o.shape
+    buf = np.frombuffer(bytes(seg) + b"\0" * 8, np.uint8).copy()
+    rc = L.orc_ht_refine_decode(o.ctypes.data, w, h, w, missing_msbs, buf.ctypes.data, len(seg), npasses)
+    assert rc == 0
+    return o
+
+
 def ht_dequant_rev(sm, k_msbs):
     a = np.ascontiguousarray(sm, np.uint32)
     out = np.zeros(a.shape, np.int32)

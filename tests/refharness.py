@@ -115,6 +115,18 @@ def ht_decode_block(coded, missing_msbs, w, h):
     return out
 
 
+def ht_decode_block_passes(coded, lengths1, lengths2, num_passes, missing_msbs, w, h):
+    """ojph_decode_codeblock with the SigProp / MagRef segment: -> (h, w) uint32 words, or None when it rejects."""
+    L = lib()
+    L.ref_ht_decode_block_passes.restype = C.c_int32
+    L.ref_ht_decode_block_passes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    buf = np.frombuffer(bytes(coded), np.uint8).copy()
+    assert buf.size == lengths1 + lengths2
+    out = np.zeros((h, w), np.uint32)
+    rc = L.ref_ht_decode_block_passes(buf.ctypes.data, lengths1, lengths2, num_passes, missing_msbs, w, h, out.ctypes.data)
+    return out if rc == 0 else None
+
+
 def t1_encode_block(coef, orient):
     """Reference Part-1 (EBCOT) block encoder -> (bytes, numpasses, numbps)."""
     L = lib()
