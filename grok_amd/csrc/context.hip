@@ -85,6 +85,7 @@ struct grk_amd_ctx {
     std::vector<uint32_t> h_len;
     uint32_t last_ntiles = 0;
     uint64_t last_nblocks = 0;
+    bool last_h16 = false;           // the latest encode left int16 coefficients in the Mallat planes
     // timing
     bool timing = false;
     Timer timers[10];
@@ -967,6 +968,29 @@ int grk_amd_fetch_coded(grk_amd_ctx* c, uint8_t* dst, uint64_t nbytes)
     return GRK_AMD_OK;
 }
 
+int grk_amd_fetch_coefficients(grk_amd_ctx* c, uint32_t comp, int32_t* dst, uint32_t dst_stride)
+{
+    if (!c || !dst || !c->have_geom || !c->last_nblocks || comp >= c->geom.p.num_comps || dst_stride < c->geom.p.tile_w)
+        return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    { const int jr = join_side(c); if (jr) return jr; }
+    const TileGeom& g = c->geom;
+    const uint32_t W = g.p.tile_w, H = g.p.tile_h;
+    if (c->last_h16) {              // 16-bit planes between K2 and K3 (8-bit reversible content): widened here
+        std::vector<int16_t> tmp((size_t)g.stride * H);
+        HIP_TRY(c, hipMemcpyAsync(tmp.data(), (const int16_t*)c->p1.p + (size_t)comp * g.plane_elems, tmp.size() * 2,
+                                  hipMemcpyDeviceToHost, c->stream), "fetch coefficients");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+        for (uint32_t y = 0; y < H; ++y)
+            for (uint32_t x = 0; x < W; ++x) dst[(size_t)y * dst_stride + x] = tmp[(size_t)y * g.stride + x];
+    } else {
+        HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)dst_stride * 4, (const int32_t*)c->p1.p + (size_t)comp * g.plane_elems,
+                                    (size_t)g.stride * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, c->stream), "fetch coefficients");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    }
+    return GRK_AMD_OK;
+}
+
 void* grk_amd_coded_device_ptr(grk_amd_ctx* c) { return c ? c->arena.p : nullptr; }
 void* grk_amd_table_device_ptr(grk_amd_ctx* c, int which)
 {
@@ -1041,6 +1065,7 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         // 8-bit reversible content: int16 LL / Mallat planes between K2 and K3 (half the bytes written and read back);
         // needs the fused level 0 (the stand-alone ingest kernel writes int32 planes)
         const bool h16 = c->planes16 && fused && planes16_ok(g.p);
+        c->last_h16 = h16;
         if (ov) {       // the allocator must be reset before the first K3 launch of either stream
             int rc2 = GRK_AMD_OK;
             const HtArgs h = make_ht_args(c, ntiles, c->p1.p, &rc2, h16);

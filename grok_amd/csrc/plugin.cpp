@@ -23,11 +23,17 @@
 #include <thread>
 #include <vector>
 #include <dirent.h>
+#include <dlfcn.h>
 
 namespace {
 
 grk_amd_ctx* g_ctx = nullptr;
 bool g_verbose = false;
+// Self-check mode (grok.h:1719-1739, GRK_PLUGIN_STATE_DEBUG; set by the environment, GRK_AMD_PLUGIN_DEBUG=1, at
+// plugin_init): the host skips its DC shift, MCT and DWT, runs its own Tier-1 over the coefficients the plugin hands it
+// as "image" data, and compares every code-block (bytes, rates, pass counts, bounding boxes, step sizes) with the plugin's
+// (TileProcessor.cpp:667-690, plugin_bridge.cpp:138-252).  A free parity check by the reference itself.
+uint32_t g_debug_state = GRA_PLUGIN_STATE_NO_DEBUG;
 std::mutex g_mu;
 
 // ---- the tile tree ------------------------------------------------------------------------------
@@ -190,7 +196,30 @@ int32_t encode_file(gra_cparameters* cp, const char* in, const char* out, gra_en
     info.image = nullptr;                 // the host callback loads the image itself (grk_compress.cpp:1636)
     info.tile = tile;
     info.error_code = 0;
+    // self-check mode: the "image" the host gets holds our sub-band coefficients (it skips its own DC shift / MCT / DWT and
+    // codes them with its own Tier-1).  The image object is made by the host library itself (grk_image_new, resolved from
+    // the process we were loaded into) so that the host can treat it as any other.
+    void* dbg_image = nullptr;
+    void (*unref)(void*) = nullptr;
+    if (g_debug_state & GRA_PLUGIN_STATE_DEBUG) {
+        typedef gra_image* (*image_new_fn)(uint16_t, gra_image_cmptparm*, int32_t, bool);
+        auto image_new = reinterpret_cast<image_new_fn>(dlsym(RTLD_DEFAULT, "grk_image_new"));
+        unref = reinterpret_cast<void (*)(void*)>(dlsym(RTLD_DEFAULT, "grk_object_unref"));
+        if (!image_new || !unref) { grk_amd_plugin_tile_destroy(tile); return -1; }
+        std::vector<gra_image_cmptparm> cps(comps);
+        for (auto& c : cps) { c.dx = 1; c.dy = 1; c.w = w; c.stride = 0; c.h = h; c.x0 = 0; c.y0 = 0; c.prec = (uint8_t)prec; c.sgnd = false; }
+        gra_image* img = image_new((uint16_t)comps, cps.data(), comps >= 3 ? 1 /* GRK_CLRSPC_SRGB */ : 2 /* GRK_CLRSPC_GRAY */, true);
+        if (!img) { grk_amd_plugin_tile_destroy(tile); return -1; }
+        img->x0 = 0; img->y0 = 0; img->x1 = w; img->y1 = h;
+        bool ok = true;
+        for (uint32_t c = 0; c < comps && ok; ++c)
+            ok = img->comps[c].data && grk_amd_fetch_coefficients(g_ctx, c, img->comps[c].data, img->comps[c].stride) == GRK_AMD_OK;
+        if (!ok) { unref(&img->obj); grk_amd_plugin_tile_destroy(tile); return -1; }
+        dbg_image = img;
+        info.image = img;
+    }
     cb(&info);
+    if (dbg_image) unref(&static_cast<gra_image*>(dbg_image)->obj);
     grk_amd_plugin_tile_destroy(tile);
     return info.error_code;
 }
@@ -528,6 +557,7 @@ GRA_EXPORT bool plugin_init(gra_plugin_init_info info)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     g_verbose = info.verbose;
+    if (const char* e = std::getenv("GRK_AMD_PLUGIN_DEBUG")) g_debug_state = std::atoi(e) ? GRA_PLUGIN_STATE_DEBUG : GRA_PLUGIN_STATE_NO_DEBUG;
     if (g_ctx) return true;
     const int rc = grk_amd_create(info.deviceId, info.verbose ? 1 : 0, &g_ctx);
     if (rc != GRK_AMD_OK) {
@@ -614,7 +644,7 @@ GRA_EXPORT int32_t plugin_init_batch_decompress(const char*, const char*, void*,
 GRA_EXPORT int32_t plugin_batch_decompress(void) { return -1; }
 GRA_EXPORT void plugin_stop_batch_decompress(void) {}
 
-GRA_EXPORT uint32_t plugin_get_debug_state(void) { return GRA_PLUGIN_STATE_NO_DEBUG; }
+GRA_EXPORT uint32_t plugin_get_debug_state(void) { return g_debug_state; }
 GRA_EXPORT void plugin_debug_mqc_next_cxd(void*, uint32_t) {}
 GRA_EXPORT void plugin_debug_next_cxd(void*, uint32_t) {}
 GRA_EXPORT void plugin_debug_mqc_next_plane(void*) {}

@@ -36,6 +36,7 @@ extern "C" {
 #define GRA_J2K_MAXRLVLS            33     /* GRK_J2K_MAXRLVLS             grok.h:102 */
 #define GRA_NUM_COMMENTS_SUPPORTED  256    /* GRK_NUM_COMMENTS_SUPPORTED   grok.h:351 */
 #define GRA_CBLKSTY_HT              0x40   /* GRK_CBLKSTY_HT */
+#define GRA_PLUGIN_STATE_DEBUG      0x1   /* grok.h:1738: the host compares every code-block with its own Tier-1 */
 #define GRA_PLUGIN_STATE_NO_DEBUG   0x0    /* GRK_PLUGIN_STATE_NO_DEBUG    grok.h:1719 */
 #define GRA_MAX_PASSES              67     /* grk_plugin_code_block.passes[] */
 
@@ -216,6 +217,13 @@ typedef struct gra_image {
     gra_image_comp* comps;
 } gra_image;
 typedef int (*gra_init_decompressors_func)(gra_header_info* header_info, gra_image* image);
+/* grk_image_cmptparm (grok.h:934-955): what grk_image_new() takes -- the plugin's self-check mode asks the host library
+ * for the image it hands back with its coefficients */
+typedef struct gra_image_cmptparm {
+    uint32_t dx, dy, w, stride, h, x0, y0;
+    uint8_t  prec;
+    bool     sgnd;
+} gra_image_cmptparm;
 /* head of grk_decompress_parameters (grok.h:692-732 grk_dparameters, :754-760): the input path is all the plugin
  * reads out of it -- plugin_decompress takes the stream's QCD and the file size from the file (see plugin.cpp) */
 typedef struct gra_dparameters {

@@ -133,6 +133,11 @@ void* grk_amd_plane_device_ptr(grk_amd_ctx* ctx, int which /*0: ingest planes, 1
  *    worst-case buffers instead) */
 void* grk_amd_table_device_ptr(grk_amd_ctx* ctx, int which);
 int  grk_amd_synchronize(grk_amd_ctx* ctx);
+/* The sub-band coefficients of the latest grk_amd_encode_tiles (one tile), component `comp`, as the reference holds them
+ * after its DWT: Mallat layout, int32 (float32 bit patterns when irreversible), dst_stride elements per row.  What the
+ * plugin hands the host in its self-check mode (GRK_PLUGIN_STATE_DEBUG, grok.h:1719-1739: the host then runs its own
+ * Tier-1 over the plugin's coefficients and compares every code-block). */
+int  grk_amd_fetch_coefficients(grk_amd_ctx* ctx, uint32_t comp, int32_t* dst, uint32_t dst_stride);
 
 /* ---- stage entry points (parity tests and per-kernel benchmarks call these) ------------------
  * All pointers are DEVICE pointers; planes are int32 (or float32 bit patterns for 9/7) with

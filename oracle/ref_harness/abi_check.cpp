@@ -134,3 +134,8 @@ SAME_OFF(gra_dparameters, grk_dparameters, tileCacheStrategy);
 static_assert(offsetof(gra_decompress_parameters_head, core) == offsetof(grk_decompress_parameters, core), "core");
 static_assert(offsetof(gra_decompress_parameters_head, infile) == offsetof(grk_decompress_parameters, infile), "infile");
 static_assert(offsetof(gra_decompress_parameters_head, outfile) == offsetof(grk_decompress_parameters, outfile), "outfile");
+
+SAME_SIZE(gra_image_cmptparm, grk_image_cmptparm);
+SAME_OFF(gra_image_cmptparm, grk_image_cmptparm, stride); SAME_OFF(gra_image_cmptparm, grk_image_cmptparm, prec);
+SAME_OFF(gra_image_cmptparm, grk_image_cmptparm, sgnd);
+static_assert(GRA_PLUGIN_STATE_DEBUG == GRK_PLUGIN_STATE_DEBUG, "debug state");

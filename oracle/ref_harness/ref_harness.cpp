@@ -29,6 +29,11 @@ static bool g_inited = false;
 static int g_verbose = 0;
 
 static void msg_quiet(const char*, void*) {}
+// warnings are counted: in the plugin's self-check mode (GRK_PLUGIN_STATE_DEBUG) every disagreement between the host's own
+// Tier-1 and the plugin's code-blocks is reported as one (plugin_bridge.cpp:149-251)
+static int g_warnings = 0;
+static char g_last_warning[256] = {0};
+static void msg_warn(const char* m, void*) { ++g_warnings; strncpy(g_last_warning, m ? m : "", sizeof(g_last_warning) - 1); if (g_verbose) fprintf(stderr, "[grok warning] %s\n", m); }
 static void msg_err(const char* m, void*) { if (g_verbose) fprintf(stderr, "[grok] %s\n", m); }
 
 extern "C" {
@@ -39,7 +44,7 @@ int ref_init(int threads, int verbose)
 	if (!g_inited) {
 		grk_initialize(nullptr, (uint32_t)threads);
 		grk_set_info_handler(msg_quiet, nullptr);
-		grk_set_warning_handler(msg_quiet, nullptr);
+		grk_set_warning_handler(msg_warn, nullptr);
 		grk_set_error_handler(msg_err, nullptr);
 		g_inited = true;
 	}
@@ -351,8 +356,12 @@ static bool host_compress_callback(grk_plugin_compress_user_callback_info* info)
 	g_cb_len = -101;
 	if (!info || !info->tile) { if (info) info->error_code = 1; return false; }
 	const int bps = (c.prec + 7) / 8;
-	grk_image* image = make_image(c, true);
-	for (int k = 0; k < c.C; ++k) {
+	// as grk_compress.cpp:1609-1636: an image the plugin passes is used as it is (its self-check mode hands over its
+	// sub-band coefficients that way), otherwise the host loads the source
+	const bool plugin_image = info->image != nullptr;
+	grk_image* image = plugin_image ? info->image : make_image(c, true);
+	if (plugin_image && getenv("REF_DEBUG_PERTURB")) image->comps[0].data[5 * image->comps[0].stride + 7] ^= 1;   // (test: must be noticed)
+	for (int k = 0; k < c.C && !plugin_image; ++k) {
 		auto comp = image->comps + k;
 		const uint8_t* src = g_cb_pixels + (size_t)k * c.W * c.H * bps;
 		for (int y = 0; y < c.H; ++y)
@@ -371,7 +380,7 @@ static bool host_compress_callback(grk_plugin_compress_user_callback_info* info)
 	info->error_code = ok ? 0 : 1;
 	grk_object_unref(stream);
 	grk_object_unref(codec);
-	grk_object_unref(&image->obj);
+	if (!plugin_image) grk_object_unref(&image->obj);
 	return ok;
 }
 
@@ -476,7 +485,7 @@ int ref_plugin_load(const char* dir, int threads)
 	bool ok = grk_initialize(dir, (uint32_t)threads);
 	g_inited = true;
 	grk_set_info_handler(msg_quiet, nullptr);
-	grk_set_warning_handler(msg_quiet, nullptr);
+	grk_set_warning_handler(msg_warn, nullptr);
 	grk_set_error_handler(msg_err, nullptr);
 	return ok ? 1 : 0;
 }
@@ -486,6 +495,13 @@ int ref_plugin_init(int device, int verbose)
 	return grk_plugin_init(info) ? 1 : 0;
 }
 uint32_t ref_plugin_debug_state(void) { return grk_plugin_get_debug_state(); }
+int ref_warning_count(int reset, char* last, int cap)
+{
+	const int n = g_warnings;
+	if (last && cap > 0) { strncpy(last, g_last_warning, (size_t)cap - 1); last[cap - 1] = 0; }
+	if (reset) { g_warnings = 0; g_last_warning[0] = 0; }
+	return n;
+}
 
 // sizes/offsets of the ABI structs, for the mirror check in tests/test_abi.py
 uint64_t ref_abi_sizeof(int which)

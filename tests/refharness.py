@@ -174,6 +174,22 @@ def plugin_init(device=0, verbose=0):
     return L.ref_plugin_init(device, verbose)
 
 
+def warning_count(reset=True):
+    """(warnings the reference has emitted since the last reset, text of the last one)"""
+    L = lib()
+    L.ref_warning_count.restype = C.c_int
+    L.ref_warning_count.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(256)
+    n = L.ref_warning_count(int(reset), buf, 256)
+    return n, buf.value.decode(errors="replace")
+
+
+def plugin_debug_state():
+    L = lib()
+    L.ref_plugin_debug_state.restype = C.c_uint32
+    return L.ref_plugin_debug_state()
+
+
 def plugin_compress_file(pixels, prec, infile, numres=6, irrev=0):
     """grk_plugin_compress(params{infile}, host callback) -> bytes, or a negative refusal code."""
     L = lib()

@@ -104,6 +104,43 @@ def test_file_protocol_with_mct_not_set_on_the_command_line(tmp_path, monkeypatc
     assert isinstance(R.plugin_compress_file(px, 8, path, numres=4), int)
 
 
+@needs_ref
+def test_plugin_self_check_mode_the_reference_compares_every_block(tmp_path, monkeypatch):
+    """GRK_PLUGIN_STATE_DEBUG (grok.h:1719-1739; ours under GRK_AMD_PLUGIN_DEBUG=1): the host skips its own DC shift / MCT / DWT,
+    runs its own Tier-1 over the sub-band coefficients the plugin hands it, and compares every code-block -- bytes, rates,
+    passes, bounding boxes, step sizes -- with the plugin's (plugin_bridge.cpp:138-252): not one warning; with a single
+    coefficient changed behind the plugin's back (test hook of the harness) it reports the block."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    cases = ((3, 8, 5), (1, 8, 4), (1, 12, 3))
+    # the pure-CPU files first: the debug state is a property of the loaded plugin, and the host's CPU path obeys it too
+    # (TileProcessor.cpp:676-690 skips DC shift / MCT / DWT whenever it is set)
+    cpu = {k: R.encode(synth.g2(k[0], 192, 256, k[1]), k[1], numres=k[2], mode=1)[0] for k in cases}
+    monkeypatch.setenv("GRK_AMD_PLUGIN_DEBUG", "1")
+    assert R.plugin_init(0) == 1
+    assert R.plugin_debug_state() == 1
+    try:
+        for Cn, prec, numres in cases:
+            px = synth.g2(Cn, 192, 256, prec)
+            path = str(tmp_path / ("dbg_%d_%d.%s" % (Cn, prec, "pgm" if Cn == 1 else "ppm")))
+            R.write_pnm(path, px, prec)
+            R.warning_count()
+            got = R.plugin_compress_file(px, prec, path, numres=numres)
+            n, last = R.warning_count()
+            assert not isinstance(got, int), "plugin refused: %s" % got
+            assert n == 0, "the reference disagrees with the plugin: %d warnings, last: %s" % (n, last)
+            assert got == cpu[(Cn, prec, numres)]
+        monkeypatch.setenv("REF_DEBUG_PERTURB", "1")
+        R.warning_count()
+        got = R.plugin_compress_file(px, prec, path, numres=numres)
+        n, last = R.warning_count()
+        assert n >= 1 and "differ" in last, (n, last)
+    finally:
+        monkeypatch.setenv("GRK_AMD_PLUGIN_DEBUG", "0")
+        R.plugin_init(0)                       # back to production state for the tests that follow
+    assert R.plugin_debug_state() == 0
+
+
 def _patch_guard_bits(cs, guard):
     """The same codestream with another number of guard bits in QCD: band numbps = expn + G - 1 moves, the blocks'
     zero-bit-plane counts in the packet headers stay, so every block's numbps moves with it and missing_msbs (their
