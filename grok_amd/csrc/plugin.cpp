@@ -14,6 +14,7 @@
 // The plugin owns the coded bytes the tile tree points at; they stay alive until the callback
 // returns (the host aliases them: plugin_bridge.cpp:198-201).
 #include "../../include/grk_plugin_abi.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -325,13 +326,17 @@ int dec_init_decompressors(gra_header_info* h, gra_image* img)
 //   3. block decode, inverse DWT, inverse MCT on the GPU; the pixels go into the host's grk_image
 //   4. GRK_DECODE_POST_T1: the host stores the image;  5. GRK_PLUGIN_DECODE_CLEAN
 // Anything outside the hot path's scope is declined (non-zero) and the host decodes on its CPU.
-int32_t decompress_file(void* params, DecodeUserCallback cb)
+// in_path / out_path: batch mode -- the host's callback takes them as input_file_name / output_file_name (grok.cpp:698-725),
+// otherwise it reads parameters->infile / outfile
+int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path = nullptr, const char* out_path = nullptr)
 {
     if (!g_ctx || !cb) return -1;
     std::lock_guard<std::mutex> lk(g_mu);
     DecodeCallbackInfo info;
     std::memset(&info.header_info, 0, sizeof(info.header_info));
     info.decompressor_parameters = params;
+    if (in_path) info.inputFile = in_path;
+    if (out_path) info.outputFile = out_path;
     info.init_decompressors_func = dec_init_decompressors;
     info.decompress_flags = GRA_DECODE_HEADER;
     g_dec_image = nullptr;
@@ -348,7 +353,7 @@ int32_t decompress_file(void* params, DecodeUserCallback cb)
     StreamHeader sh;
     {
         const gra_decompress_parameters_head* dp = static_cast<const gra_decompress_parameters_head*>(params);
-        const char* path = !dp ? nullptr : dp->infile[0] ? dp->infile : dp->core.infile[0] ? dp->core.infile : nullptr;
+        const char* path = in_path ? in_path : !dp ? nullptr : dp->infile[0] ? dp->infile : dp->core.infile[0] ? dp->core.infile : nullptr;
         if (!path || !read_stream_header(path, sh) || sh.overrides) return clean(-1);
     }
     // the scope of the hot path: one tile at the origin, equal full-resolution components, default
@@ -446,6 +451,23 @@ int32_t decompress_file(void* params, DecodeUserCallback cb)
     const int32_t rc = cb(&info);
     info.tile = nullptr;
     return done(rc == 0 ? 0 : -1);
+}
+
+// ---- batch decode (plugin/plugin_interface.h:131-143; the host side: grk_decompress.cpp:874-900): a worker thread walks the
+//      input directory; a stream outside the hot path's scope is handed back to the host's own decoder in the same callback
+//      protocol (all stages in one call, grok.h:1254 GRK_DECODE_ALL), so that every file of the directory comes out
+std::thread g_dbatch;
+std::atomic<bool> g_dbatch_done{true}, g_dbatch_stop{false};
+std::atomic<int> g_dbatch_gpu{0}, g_dbatch_cpu{0}, g_dbatch_failed{0};
+struct { std::string in, out; void* params = nullptr; DecodeUserCallback cb = nullptr; } g_dbatch_job;
+
+const char* out_extension(int32_t cod_format)
+{
+    switch (cod_format) {           // GRK_SUPPORTED_FILE_FMT, grok.h:59-72
+    case 3: return ".ppm"; case 4: return ".pgx"; case 5: return ".pam"; case 6: return ".bmp"; case 7: return ".tif";
+    case 8: return ".raw"; case 9: return ".png"; case 10: return ".rawl"; case 11: return ".jpg";
+    default: return ".ppm";
+    }
 }
 
 int32_t plugin_exit() { return 0; }
@@ -602,7 +624,7 @@ GRA_EXPORT int32_t plugin_batch_encode(const char* input_dir, const char* output
     return 0;
 }
 
-GRA_EXPORT bool plugin_is_batch_complete(void) { return g_batch_done.load(); }
+GRA_EXPORT bool plugin_is_batch_complete(void) { return g_batch_done.load() && g_dbatch_done.load(); }
 
 GRA_EXPORT void plugin_stop_batch_encode(void)
 {
@@ -640,9 +662,70 @@ GRA_EXPORT size_t grk_amd_plugin_decode_info_layout(int which)
     default: return 0;
     }
 }
-GRA_EXPORT int32_t plugin_init_batch_decompress(const char*, const char*, void*, gra_decode_callback) { return -1; }
-GRA_EXPORT int32_t plugin_batch_decompress(void) { return -1; }
-GRA_EXPORT void plugin_stop_batch_decompress(void) {}
+GRA_EXPORT int32_t plugin_init_batch_decompress(const char* input_dir, const char* output_dir, void* decompress_parameters,
+                                                gra_decode_callback callback)
+{
+    if (!g_ctx || !input_dir || !output_dir || !decompress_parameters || !callback) return -1;
+    if (!g_dbatch_done.load()) return -1;
+    if (g_dbatch.joinable()) g_dbatch.join();
+    g_dbatch_job.in = input_dir; g_dbatch_job.out = output_dir; g_dbatch_job.params = decompress_parameters;
+    g_dbatch_job.cb = reinterpret_cast<DecodeUserCallback>(callback);
+    return 0;
+}
+GRA_EXPORT int32_t plugin_batch_decompress(void)
+{
+    if (!g_ctx || !g_dbatch_job.cb || !g_dbatch_done.load()) return -1;
+    if (g_dbatch.joinable()) g_dbatch.join();
+    g_dbatch_done = false; g_dbatch_stop = false;
+    g_dbatch_gpu = 0; g_dbatch_cpu = 0; g_dbatch_failed = 0;
+    g_dbatch = std::thread([]() {
+        const auto job = g_dbatch_job;
+        const auto* dp = static_cast<const gra_decompress_parameters_head*>(job.params);
+        std::vector<std::string> names;
+        if (DIR* d = opendir(job.in.c_str())) {
+            while (dirent* e = readdir(d)) {
+                const std::string name(e->d_name);
+                const size_t dot = name.rfind('.');
+                if (dot == std::string::npos) continue;
+                const std::string ext = name.substr(dot);
+                if (ext == ".j2k" || ext == ".j2c" || ext == ".jp2" || ext == ".jph" || ext == ".jhc") names.push_back(name);
+            }
+            closedir(d);
+        }
+        std::sort(names.begin(), names.end());
+        for (const auto& name : names) {
+            if (g_dbatch_stop.load()) break;
+            const std::string src = job.in + "/" + name;
+            const std::string dst = job.out + "/" + name.substr(0, name.rfind('.')) + out_extension(dp->cod_format);
+            if (decompress_file(job.params, job.cb, src.c_str(), dst.c_str()) == 0) { ++g_dbatch_gpu; continue; }
+            // outside the hot path: the host decodes this one itself, all stages in one call
+            DecodeCallbackInfo info;
+            std::memset(&info.header_info, 0, sizeof(info.header_info));
+            info.decompressor_parameters = job.params;
+            info.inputFile = src; info.outputFile = dst;
+            info.decompress_flags = GRA_DECODE_HEADER | GRA_DECODE_T2 | GRA_DECODE_T1 | GRA_DECODE_POST_T1;
+            const int32_t rc = job.cb(&info);
+            info.decompress_flags = GRA_PLUGIN_DECODE_CLEAN;
+            (void)job.cb(&info);
+            if (rc == 0) ++g_dbatch_cpu; else ++g_dbatch_failed;
+        }
+        g_dbatch_done = true;
+    });
+    return 0;
+}
+GRA_EXPORT void plugin_stop_batch_decompress(void)
+{
+    g_dbatch_stop = true;
+    if (g_dbatch.joinable()) g_dbatch.join();
+    g_dbatch_done = true;
+}
+// how the last decode batch went: files decoded on the GPU, handed back to the host's decoder, failed
+GRA_EXPORT void grk_amd_plugin_batch_decode_counts(int32_t* gpu, int32_t* cpu, int32_t* failed)
+{
+    if (gpu) *gpu = g_dbatch_gpu.load();
+    if (cpu) *cpu = g_dbatch_cpu.load();
+    if (failed) *failed = g_dbatch_failed.load();
+}
 
 GRA_EXPORT uint32_t plugin_get_debug_state(void) { return g_debug_state; }
 GRA_EXPORT void plugin_debug_mqc_next_cxd(void*, uint32_t) {}

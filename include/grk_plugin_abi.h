@@ -240,6 +240,7 @@ typedef struct gra_dparameters {
 typedef struct gra_decompress_parameters_head {
     gra_dparameters core;
     char infile[GRA_PATH_LEN], outfile[GRA_PATH_LEN];
+    int32_t decod_format, cod_format;       /* GRK_SUPPORTED_FILE_FMT (grok.h:59-72): input / output file type */
 } gra_decompress_parameters_head;
 
 /* ---- minimal plugin framework registration (plugin/minpf_plugin.h:25-60) --------------------- */
@@ -275,6 +276,9 @@ uint32_t plugin_get_debug_state(void);
 void     plugin_debug_mqc_next_cxd(void* mqc, uint32_t d);    /* name looked up by plugin_bridge.cpp:288 */
 void     plugin_debug_next_cxd(void* mqc, uint32_t d);        /* name exported by the stub */
 void     plugin_debug_mqc_next_plane(void* mqc);
+
+/* how the last decode batch went: files decoded on the GPU / handed back to the host's own decoder / failed */
+void grk_amd_plugin_batch_decode_counts(int32_t* gpu, int32_t* cpu, int32_t* failed);
 
 /* ---- library-level drop-in (no file I/O): build the tile tree for grk_compress_with_plugin() ---
  * (grok.cpp:438).  `pixels`: one tile, layout of grk_amd_encode_tiles.

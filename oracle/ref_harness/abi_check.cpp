@@ -139,3 +139,4 @@ SAME_SIZE(gra_image_cmptparm, grk_image_cmptparm);
 SAME_OFF(gra_image_cmptparm, grk_image_cmptparm, stride); SAME_OFF(gra_image_cmptparm, grk_image_cmptparm, prec);
 SAME_OFF(gra_image_cmptparm, grk_image_cmptparm, sgnd);
 static_assert(GRA_PLUGIN_STATE_DEBUG == GRK_PLUGIN_STATE_DEBUG, "debug state");
+static_assert(offsetof(gra_decompress_parameters_head, cod_format) == offsetof(grk_decompress_parameters, cod_format), "cod_format");

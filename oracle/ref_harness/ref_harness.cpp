@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <vector>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdio>
 
@@ -423,7 +424,10 @@ static int32_t host_decompress_callback(grk_plugin_decompress_callback_info* inf
 	}
 	if (info->decompress_flags & GRK_DECODE_HEADER) {
 		g_dcb_stage[0]++;
-		if (!info->stream) info->stream = grk_stream_create_mem_stream((uint8_t*)g_dcb_j2k, g_dcb_len, false, true);
+		// batch mode: the plugin names the file (grk_decompress.cpp:1018-1019); otherwise the test's memory buffer
+		if (!info->stream)
+			info->stream = (!g_dcb_j2k && info->input_file_name) ? grk_stream_create_file_stream(info->input_file_name, 1 << 20, true)
+																 : grk_stream_create_mem_stream((uint8_t*)g_dcb_j2k, g_dcb_len, false, true);
 		if (!info->stream) return 1;
 		if (!info->codec) {
 			info->codec = grk_decompress_create(GRK_CODEC_J2K, info->stream);
@@ -432,23 +436,40 @@ static int32_t host_decompress_callback(grk_plugin_decompress_callback_info* inf
 		}
 		if (!grk_decompress_read_header(info->codec, &info->header_info)) return 1;
 		info->image = grk_decompress_get_composited_image(info->codec);
-		if (info->init_decompressors_func) return info->init_decompressors_func(&info->header_info, info->image);
-		return 0;
+		if (info->init_decompressors_func) { int rc = info->init_decompressors_func(&info->header_info, info->image); if (rc || !(info->decompress_flags & (GRK_DECODE_T2 | GRK_DECODE_T1))) return rc; }
+		else if (!(info->decompress_flags & (GRK_DECODE_T2 | GRK_DECODE_T1))) return 0;
 	}
 	if (info->decompress_flags & (GRK_DECODE_T2 | GRK_DECODE_T1)) {
 		g_dcb_stage[1]++;
-		if (!info->codec || !info->tile) return 1;
-		info->tile->decompress_flags = info->decompress_flags;
+		if (!info->codec) return 1;
+		if (!info->tile && !(info->decompress_flags & GRK_DECODE_T1)) return 1;      // (no tile: the host decodes everything itself)
+		if (info->tile) info->tile->decompress_flags = info->decompress_flags;
 		if (getenv("REF_HARNESS_DEBUG")) grk_set_error_handler([](const char* m, void*) { fprintf(stderr, "[grk error] %s\n", m); }, nullptr);
 		if (!grk_decompress_set_window(info->codec, 0, 0, 0, 0)) { if (getenv("REF_HARNESS_DEBUG")) fprintf(stderr, "set_window failed\n"); return 1; }
 		if (!grk_decompress(info->codec, info->tile)) { if (getenv("REF_HARNESS_DEBUG")) fprintf(stderr, "grk_decompress failed\n"); return 1; }
 		if (!grk_decompress_end(info->codec)) { if (getenv("REF_HARNESS_DEBUG")) fprintf(stderr, "decompress_end failed\n"); return 1; }
-		return 0;
+		// T2 | POST_T1 is the plugin's Tier-2 stage (it asks for both because of defect D11): the image is stored in the
+		// POST_T1 call that follows its own decode; only a full host decode (T1 set) goes on to store the image here
+		if (!(info->decompress_flags & GRK_DECODE_T1) || !(info->decompress_flags & GRK_DECODE_POST_T1)) return 0;
 	}
 	if (info->decompress_flags & GRK_DECODE_POST_T1) {
 		g_dcb_stage[2]++;
 		auto img = info->image;
-		if (!img || img->numcomps != g_dcb_C) return 1;
+		if (!img) return 1;
+		if (!g_dcb_out) {
+			// batch mode: the decoded image goes to the file the plugin names, as "C W H\n" + int32 planes (test format)
+			if (!info->output_file_name) return 1;
+			FILE* f = fopen(info->output_file_name, "wb");
+			if (!f) return 1;
+			fprintf(f, "%d %d %d\n", (int)img->numcomps, (int)img->comps[0].w, (int)img->comps[0].h);
+			for (uint16_t k = 0; k < img->numcomps; ++k)
+				for (uint32_t y = 0; y < img->comps[k].h; ++y)
+					fwrite(img->comps[k].data + (size_t)y * img->comps[k].stride, 4, img->comps[k].w, f);
+			fclose(f);
+			++g_dcb_stage[2];
+			return 0;
+		}
+		if (img->numcomps != g_dcb_C) return 1;
 		for (int k = 0; k < g_dcb_C; ++k) {
 			auto comp = img->comps + k;
 			if ((int)comp->w != g_dcb_W || (int)comp->h != g_dcb_H || !comp->data) return 1;
@@ -476,6 +497,27 @@ int32_t ref_plugin_decompress(const uint8_t* j2k, uint64_t len, int32_t* out, in
 	int32_t rc = grk_plugin_decompress(&param, host_decompress_callback);
 	if (stages) memcpy(stages, g_dcb_stage, sizeof(g_dcb_stage));
 	return rc;
+}
+
+// grk_plugin_init_batch_decompress + grk_plugin_batch_decompress over a directory, polled as grk_decompress.cpp:874-900 does;
+// returns 0 when the batch ran to completion, the plugin's refusal otherwise
+int32_t ref_plugin_batch_decompress(const char* in_dir, const char* out_dir, int timeout_s)
+{
+	static grk_decompress_parameters param;
+	memset(&param, 0, sizeof(param));
+	grk_decompress_set_default_params(&param.core);
+	param.decod_format = GRK_J2K_FMT;
+	param.cod_format = GRK_RAW_FMT;
+	g_dcb_j2k = nullptr; g_dcb_len = 0; g_dcb_out = nullptr;
+	memset(g_dcb_stage, 0, sizeof(g_dcb_stage));
+	int32_t rc = grk_plugin_init_batch_decompress(in_dir, out_dir, &param, host_decompress_callback);
+	if (rc) return rc;
+	rc = grk_plugin_batch_decompress();
+	if (rc) return rc;
+	for (int i = 0; i < timeout_s * 10 && !grk_plugin_is_batch_complete(); ++i) usleep(100000);
+	const bool done = grk_plugin_is_batch_complete();
+	grk_plugin_stop_batch_decompress();
+	return done ? 0 : -7;
 }
 
 // Load a real plugin .so through the reference's own minpf loader (grk_initialize(pluginPath)),

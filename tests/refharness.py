@@ -231,6 +231,20 @@ def plugin_decompress(j2k, Cn, H, W, as_file=True):
     return (out if rc == 0 else int(rc)), [int(v) for v in stages]
 
 
+def plugin_batch_decompress(in_dir, out_dir, timeout_s=60):
+    L = lib()
+    L.ref_plugin_batch_decompress.restype = C.c_int32
+    L.ref_plugin_batch_decompress.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    return L.ref_plugin_batch_decompress(in_dir.encode(), out_dir.encode(), timeout_s)
+
+
+def read_batch_output(path):
+    """what the harness's batch callback writes: 'C W H\\n' + int32 planes -> (C, H, W) int32"""
+    with open(path, "rb") as f:
+        Cn, W, H = [int(v) for v in f.readline().split()]
+        return np.frombuffer(f.read(), np.int32).reshape(Cn, H, W)
+
+
 def write_pnm(path, px, prec):
     Cn, H, W = px.shape
     assert Cn in (1, 3)

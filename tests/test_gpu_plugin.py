@@ -184,6 +184,34 @@ def test_decode_protocol_declines_without_a_file_to_read_the_qcd_from():
 
 
 @needs_ref
+def test_batch_decompress_through_grok_loader(tmp_path):
+    """grk_plugin_init_batch_decompress + grk_plugin_batch_decompress (plugin/plugin_interface.h:131-143; grk_decompress
+    -y <dir> -a <dir>, grk_decompress.cpp:874-900): the plugin's worker walks the directory, decodes what is inside the hot
+    path on the GPU and hands the rest (here an HT + 9/7 stream and a multi-tile one) back to the host's own decoder in the
+    same callback protocol -- every file of the directory comes out, pixel-identical to grk_decompress."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir(); outd.mkdir()
+    want = {}
+    jobs = [("a_rgb", dict(ht=1), (3, 192, 256, 8)), ("b_mono12", dict(ht=1), (1, 128, 128, 12)), ("c_classic", dict(ht=0), (3, 96, 160, 8)),
+            ("d_classic97", dict(ht=0, irrev=1), (3, 128, 192, 10)), ("e_ht97", dict(ht=1, irrev=1), (3, 128, 128, 8)),
+            ("f_tiles", dict(ht=1, TW=64, TH=64), (3, 128, 128, 8))]
+    for name, kw, (Cn, H, W, prec) in jobs:
+        cs, _ = R.encode(synth.g2(Cn, H, W, prec), prec, numres=4, mode=1, **kw)
+        (ind / (name + ".j2k")).write_bytes(cs)
+        want[name] = R.decode(cs, Cn, H, W)
+    assert R.plugin_batch_decompress(str(ind), str(outd)) == 0
+    L = C.CDLL(PLUGIN)
+    g, c, f = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    L.grk_amd_plugin_batch_decode_counts(C.byref(g), C.byref(c), C.byref(f))
+    assert (g.value, c.value, f.value) == (4, 2, 0)
+    for name in want:
+        got = R.read_batch_output(str(outd / (name + ".raw")))
+        assert np.array_equal(got, want[name]), name
+
+
+@needs_ref
 def test_decode_protocol_declines_outside_the_hot_path():
     """HT + 9/7 streams (D1), multi-segment code-block styles and multi-tile images are answered with non-zero:
     the host keeps its CPU decoder (grk_decompress.cpp:953-955)."""
