@@ -19,16 +19,31 @@ class TileParams(C.Structure):
     _fields_ = [("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("num_comps", C.c_uint16),
                 ("prec", C.c_uint8), ("sgnd", C.c_uint8), ("irreversible", C.c_uint8),
                 ("mct", C.c_uint8), ("num_levels", C.c_uint8), ("cblk_w_exp", C.c_uint8),
-                ("cblk_h_exp", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+                ("cblk_h_exp", C.c_uint8), ("reserved", C.c_uint8 * 3),
+                ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32)]
 
     @classmethod
-    def make(cls, w, h, comps, prec, levels, irreversible=False, mct=None, sgnd=False, cblk=(6, 6), part1=False, cblksty=0):
+    def make(cls, w, h, comps, prec, levels, irreversible=False, mct=None, sgnd=False, cblk=(6, 6), part1=False, cblksty=0,
+             origin=(0, 0)):
+        """origin = (x0, y0): where the tile lies on the canonical grid (image offset / tile grid position)."""
         if mct is None:
             mct = comps >= 3
         p = cls(w, h, comps, prec, int(sgnd), int(irreversible), int(mct), levels, cblk[0], cblk[1])
         p.reserved[0] = int(part1)
         p.reserved[1] = int(cblksty)       # Part-1 decode: LAZY 1, RESET 2, TERMALL 4, VSC 8, PTERM 16, SEGSYM 32
+        p.tile_x0, p.tile_y0 = int(origin[0]), int(origin[1])
         return p
+
+
+class ImageLayout(C.Structure):
+    """grk_amd_image_layout: image area [x0, x1) x [y0, y1) on the canonical grid, tile grid anchored at (tx0, ty0)."""
+    _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
+                ("tx0", C.c_uint32), ("ty0", C.c_uint32), ("t_width", C.c_uint32), ("t_height", C.c_uint32)]
+
+    @classmethod
+    def make(cls, w, h, tile_w=None, tile_h=None, offset=(0, 0), tile_origin=(0, 0)):
+        return cls(offset[0], offset[1], offset[0] + w, offset[1] + h, tile_origin[0], tile_origin[1],
+                   tile_w or offset[0] + w - tile_origin[0], tile_h or offset[1] + h - tile_origin[1])
 
 
 class Block(C.Structure):
@@ -109,6 +124,17 @@ def lib():
         L.grk_amd_write_tile_part.argtypes = [PP, u32, u32, vp, vp, vp, u64]
         L.grk_amd_locate_tile_parts.restype = C.c_int64
         L.grk_amd_locate_tile_parts.argtypes = [vp, u64, vp, vp, vp, u64, C.POINTER(i32)]
+        PL = C.POINTER(ImageLayout)
+        L.grk_amd_layout_num_tiles.restype = C.c_int64
+        L.grk_amd_layout_num_tiles.argtypes = [PL]
+        L.grk_amd_layout_tile.argtypes = [PL, PP, u32, PP]
+        L.grk_amd_same_tile_geometry.argtypes = [PP, PP]
+        L.grk_amd_write_codestream_layout.restype = C.c_int64
+        L.grk_amd_write_codestream_layout.argtypes = [PL, PP, vp, vp, u32, vp, u64]
+        L.grk_amd_write_main_header_layout.restype = C.c_int64
+        L.grk_amd_write_main_header_layout.argtypes = [PL, PP, u32, vp, vp, u64]
+        L.grk_amd_encode_image.restype = C.c_int64
+        L.grk_amd_encode_image.argtypes = [vp, PL, PP, vp, u32, vp, u64]
         _lib = L
     return _lib
 
@@ -140,6 +166,42 @@ def write_codestream(params, img_w, img_h, table, coded, flags=0):
     n = L.grk_amd_write_codestream_ex(C.byref(params), img_w, img_h, tptr, cbuf.ctypes.data, flags, out.ctypes.data, cap)
     if n < 0:
         raise RuntimeError("grk_amd_write_codestream failed: %d" % n)
+    return out[:n].tobytes()
+
+
+def layout_tiles(layout, base):
+    """The parameters of every tile of the layout (raster order): base with the tile's size and origin."""
+    L = lib()
+    n = L.grk_amd_layout_num_tiles(C.byref(layout))
+    if n < 0:
+        raise ValueError("grk_amd_layout_num_tiles failed: %d" % n)
+    out = []
+    for t in range(n):
+        p = TileParams()
+        rc = L.grk_amd_layout_tile(C.byref(layout), C.byref(base), t, C.byref(p))
+        if rc:
+            raise ValueError("grk_amd_layout_tile failed: %d" % rc)
+        out.append(p)
+    return out
+
+
+def same_tile_geometry(a, b):
+    rc = lib().grk_amd_same_tile_geometry(C.byref(a), C.byref(b))
+    if rc < 0:
+        raise ValueError("grk_amd_same_tile_geometry failed: %d" % rc)
+    return bool(rc)
+
+
+def write_codestream_layout(layout, base, table, coded, flags=0):
+    """table: the tiles' rows one tile after the other (every tile with the rows of ITS geometry, layout_tiles())."""
+    L = lib()
+    cbuf = np.frombuffer(coded, np.uint8) if not isinstance(coded, np.ndarray) else coded
+    cap = int(cbuf.size) + len(table) * 8 + (1 << 20)
+    out = np.empty(cap, np.uint8)
+    t = np.ascontiguousarray(table)
+    n = L.grk_amd_write_codestream_layout(C.byref(layout), C.byref(base), t.ctypes.data, cbuf.ctypes.data, flags, out.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError("grk_amd_write_codestream_layout failed: %d" % n)
     return out[:n].tobytes()
 
 
@@ -241,6 +303,16 @@ class Context:
         if tot:
             self._check(self._L.grk_amd_fetch_coded(self._h, coded.ctypes.data, tot), "fetch_coded")
         return table, coded
+
+    def encode_image(self, layout, base, pixels, flags=0):
+        """Whole image (C, H, W) of any tile layout -> codestream bytes (grk_amd_encode_image)."""
+        px = np.ascontiguousarray(pixels)
+        cap = px.size * 4 + (1 << 20)
+        out = np.empty(cap, np.uint8)
+        n = self._L.grk_amd_encode_image(self._h, C.byref(layout), C.byref(base), px.ctypes.data, flags, out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("encode_image failed: %d (%s)" % (n, self._L.grk_amd_last_error(self._h).decode()))
+        return out[:n].tobytes()
 
     def fetch_table(self, nblocks):
         table = np.zeros(nblocks, CODED_DTYPE)

@@ -115,7 +115,7 @@ bool same_params(const grk_amd_tile_params& a, const grk_amd_tile_params& b)
     return a.tile_w == b.tile_w && a.tile_h == b.tile_h && a.num_comps == b.num_comps && a.prec == b.prec &&
            a.sgnd == b.sgnd && a.irreversible == b.irreversible && a.mct == b.mct &&
            a.num_levels == b.num_levels && a.cblk_w_exp == b.cblk_w_exp && a.cblk_h_exp == b.cblk_h_exp &&
-           a.reserved[0] == b.reserved[0] && a.reserved[1] == b.reserved[1];
+           a.reserved[0] == b.reserved[0] && a.reserved[1] == b.reserved[1] && a.tile_x0 == b.tile_x0 && a.tile_y0 == b.tile_y0;
 }
 
 int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
@@ -311,7 +311,8 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
     ScopedTimer t(c, 1);
     for (uint32_t l = 0; l < L; ++l) {
         DwtLevelArgs a{};
-        a.cw = ceil_div_pow2(W, l); a.ch = ceil_div_pow2(H, l);
+        a.cw = level_geom(g, l).w; a.ch = level_geom(g, l).h;
+        a.px = level_geom(g, l).x0 & 1u; a.py = level_geom(g, l).y0 & 1u;
         if (l == 0) { a.in = (const int32_t*)d_in; a.in_stride = g.stride; a.in_pitch = g.plane_elems; }
         else if (l & 1) { a.in = (const int32_t*)c->llA.p; a.in_stride = sA; a.in_pitch = pitchA; }
         else { a.in = (const int32_t*)c->llB.p; a.in_stride = sB; a.in_pitch = pitchB; }
@@ -323,9 +324,9 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         a.irreversible = g.p.irreversible;
         a.h16 = h16 ? 1 : 0;
         // enough workgroups to cover the chip several times, few enough to amortise warm-up rows
-        const uint32_t sh = (a.ch + 1) >> 1;
+        const uint32_t sh = (a.ch + a.py + 1) >> 1;           // row pairs on the coordinate grid
         uint32_t seg = 64;
-        const uint64_t strips = (a.cw + dwt_strip_cols() - 1) / dwt_strip_cols();
+        const uint64_t strips = (a.cw + a.px + dwt_strip_cols() - 1) / dwt_strip_cols();
         // workgroups along z: planes, or for the fused level 0 tiles (x components when there is no MCT triple)
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
@@ -418,7 +419,8 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
     ScopedTimer t(c, 6);
     for (int32_t l = (int32_t)L - 1; l >= 0; --l) {
         IdwtLevelArgs a{};
-        a.cw = ceil_div_pow2(W, (uint32_t)l); a.ch = ceil_div_pow2(H, (uint32_t)l);
+        a.cw = level_geom(g, (uint32_t)l).w; a.ch = level_geom(g, (uint32_t)l).h;
+        a.px = level_geom(g, (uint32_t)l).x0 & 1u; a.py = level_geom(g, (uint32_t)l).y0 & 1u;
         if ((uint32_t)l + 1 == L) { a.ll = (const int32_t*)d_mallat; a.ll_stride = g.stride; a.ll_pitch = g.plane_elems; }
         else if ((l + 1) & 1) { a.ll = (const int32_t*)c->llA.p; a.ll_stride = sA; a.ll_pitch = pitchA; }
         else { a.ll = (const int32_t*)c->llB.p; a.ll_stride = sB; a.ll_pitch = pitchB; }
@@ -428,9 +430,9 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
         else { a.out = (int32_t*)c->llB.p; a.out_stride = sB; a.out_pitch = pitchB; }
         a.nplanes = nplanes;
         a.irreversible = g.p.irreversible;
-        const uint32_t sh = (a.ch + 1) >> 1;
+        const uint32_t sh = (a.ch + a.py + 1) >> 1;
         uint32_t seg = 64;
-        const uint64_t strips = (((a.cw + 1) >> 1) + idwt_strip_pairs() - 1) / idwt_strip_pairs();
+        const uint64_t strips = (((a.cw + a.px + 1) >> 1) + idwt_strip_pairs() - 1) / idwt_strip_pairs();
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
         a.seg_pairs = seg;
@@ -822,6 +824,7 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
         if (ntiles != 1 || win->x0 >= win->x1 || win->y0 >= win->y1 || win->x1 > g.p.tile_w || win->y1 > g.p.tile_h)
             return fail(c, GRK_AMD_ERR_INVALID, "window outside the tile");
         if (!fuse_out) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "region decode needs at least one DWT level and 8-/16-bit pixels");
+        if (g.p.tile_x0 || g.p.tile_y0) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "region decode of a tile off the origin");
         plan = plan_region(g.p, *win);
         const uint32_t L = g.p.num_levels;
         wtable.assign(table, table + (size_t)g.blocks_per_comp * g.p.num_comps);

@@ -1,5 +1,6 @@
 // grok_amd/csrc/geometry.cpp -- see geometry.h for the reference citations.
 #include "geometry.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -69,6 +70,7 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
     if (p.mct && p.num_comps < 3) return GRK_AMD_ERR_INVALID;
     // one precinct per resolution (default exponent 15, CodeStreamCompress.cpp:514-518)
     if (p.tile_w > 32768 || p.tile_h > 32768) return GRK_AMD_ERR_UNSUPPORTED;
+    if ((uint64_t)p.tile_x0 + p.tile_w > 0x7FFFFFFFull || (uint64_t)p.tile_y0 + p.tile_h > 0x7FFFFFFFull) return GRK_AMD_ERR_UNSUPPORTED;
 
     g.p = p;
     g.stride = (p.tile_w + 31u) & ~31u;                       // util/MemManager.cpp:38-43
@@ -80,18 +82,35 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
     g.blocks_comp0.clear();
     const uint32_t cbw = 1u << p.cblk_w_exp, cbh = 1u << p.cblk_h_exp;
     uint32_t nblk = 0;
+    // tile-component origin on the canonical grid (dx = dy = 1: the tile's own): resolution r covers
+    // [ceil(x0 / 2^(L-r)), ceil((x0 + w) / 2^(L-r))), band b of it [ceil((x0 - 2^(n-1) xb) / 2^n), ...) with n = L - r + 1
+    // (TileComponent.cpp:131-138, util/util.cpp:49-58).  The code-blocks of a band are the cells of the 2^cblk grid anchored
+    // at the origin of the BAND's coordinates that the band touches (T1Structs.cpp:118-136): a band that starts off that
+    // grid begins with a partial block.
+    const uint64_t X0 = p.tile_x0, Y0 = p.tile_y0, X1 = X0 + p.tile_w, Y1 = Y0 + p.tile_h;
+    auto res_lo = [](uint64_t v, uint32_t n) { return (uint32_t)((v + (1ull << n) - 1) >> n); };
+    auto band_lo = [](uint64_t v, uint32_t n, uint32_t hi) {
+        const uint64_t off = hi ? (1ull << (n - 1)) : 0;
+        return v <= off ? 0u : (uint32_t)((v - off + (1ull << n) - 1) >> n);
+    };
     for (uint32_t r = 0; r <= L; ++r) {
         ResGeom& R = g.res[r];
-        R.w = ceil_div_pow2(p.tile_w, L - r);
-        R.h = ceil_div_pow2(p.tile_h, L - r);
-        uint32_t lw = r ? ceil_div_pow2(p.tile_w, L - r + 1) : 0;
-        uint32_t lh = r ? ceil_div_pow2(p.tile_h, L - r + 1) : 0;
+        R.x0 = res_lo(X0, L - r); R.y0 = res_lo(Y0, L - r);
+        R.w = res_lo(X1, L - r) - R.x0;
+        R.h = res_lo(Y1, L - r) - R.y0;
+        uint32_t lw = r ? res_lo(X1, L - r + 1) - res_lo(X0, L - r + 1) : 0;
+        uint32_t lh = r ? res_lo(Y1, L - r + 1) - res_lo(Y0, L - r + 1) : 0;
         R.num_bands = r ? 3 : 1;
         for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
             BandGeom& B = R.band[bi];
             B.orient = (uint8_t)(r ? bi + 1 : 0);
-            B.w = r ? ((B.orient & 1) ? R.w - lw : lw) : R.w;
-            B.h = r ? ((B.orient & 2) ? R.h - lh : lh) : R.h;
+            const uint32_t n = r ? L - r + 1 : L;
+            if (n == 0) { B.x0 = (uint32_t)X0; B.y0 = (uint32_t)Y0; B.w = p.tile_w; B.h = p.tile_h; }
+            else {
+                B.x0 = band_lo(X0, n, B.orient & 1u); B.y0 = band_lo(Y0, n, B.orient >> 1);
+                B.w = band_lo(X1, n, B.orient & 1u) - B.x0;
+                B.h = band_lo(Y1, n, B.orient >> 1) - B.y0;
+            }
             B.ox = (B.orient & 1) ? lw : 0;
             B.oy = (B.orient & 2) ? lh : 0;
             uint32_t qi = r ? 3 * (r - 1) + 1 + bi : 0;
@@ -109,16 +128,17 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
             if (B.kmax > 30) return GRK_AMD_ERR_UNSUPPORTED;
             B.first_block = nblk;
             if (B.w == 0 || B.h == 0) { B.gw = B.gh = 0; continue; }
-            B.gw = (B.w + cbw - 1) >> p.cblk_w_exp;
-            B.gh = (B.h + cbh - 1) >> p.cblk_h_exp;
+            const uint32_t gx0 = B.x0 >> p.cblk_w_exp, gy0 = B.y0 >> p.cblk_h_exp;
+            B.gw = ((B.x0 + B.w + cbw - 1) >> p.cblk_w_exp) - gx0;
+            B.gh = ((B.y0 + B.h + cbh - 1) >> p.cblk_h_exp) - gy0;
             for (uint32_t by = 0; by < B.gh; ++by)
                 for (uint32_t bx = 0; bx < B.gw; ++bx) {
                     grk_amd_block b;
                     std::memset(&b, 0, sizeof(b));
-                    b.x0 = bx * cbw; b.y0 = by * cbh;
-                    b.x1 = (bx + 1) * cbw < B.w ? (bx + 1) * cbw : B.w;
-                    b.y1 = (by + 1) * cbh < B.h ? (by + 1) * cbh : B.h;
-                    b.px = B.ox + b.x0; b.py = B.oy + b.y0;
+                    b.x0 = std::max((gx0 + bx) * cbw, B.x0); b.y0 = std::max((gy0 + by) * cbh, B.y0);
+                    b.x1 = std::min((gx0 + bx + 1) * cbw, B.x0 + B.w);
+                    b.y1 = std::min((gy0 + by + 1) * cbh, B.y0 + B.h);
+                    b.px = B.ox + (b.x0 - B.x0); b.py = B.oy + (b.y0 - B.y0);
                     b.comp = 0; b.res = (uint8_t)r; b.band = B.orient; b.kmax = B.kmax;
                     b.stepsize = B.stepsize;
                     g.blocks_comp0.push_back(b);
@@ -129,5 +149,21 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
     g.blocks_per_comp = nblk;
     return GRK_AMD_OK;
 }
+
+// the same sub-band partition, block partition and lifting variants: what one batch of grk_amd_encode_tiles needs
+bool same_geometry(const TileGeom& a, const TileGeom& b)
+{
+    if (a.p.tile_w != b.p.tile_w || a.p.tile_h != b.p.tile_h || a.blocks_per_comp != b.blocks_per_comp) return false;
+    for (size_t r = 0; r < a.res.size(); ++r)
+        if (a.res[r].w != b.res[r].w || a.res[r].h != b.res[r].h || ((a.res[r].x0 ^ b.res[r].x0) & 1u) || ((a.res[r].y0 ^ b.res[r].y0) & 1u))
+            return false;
+    for (size_t i = 0; i < a.blocks_comp0.size(); ++i) {
+        const grk_amd_block &x = a.blocks_comp0[i], &y = b.blocks_comp0[i];
+        if (x.px != y.px || x.py != y.py || x.x1 - x.x0 != y.x1 - y.x0 || x.y1 - x.y0 != y.y1 - y.y0 || x.res != y.res || x.band != y.band)
+            return false;
+    }
+    return true;
+}
+
 
 } // namespace grk_amd

@@ -1,6 +1,6 @@
 // grok_amd/csrc/geometry.h -- host-side tile geometry and quantiser parameters.
 //
-// Restates, for the hot path's restricted case (dx=dy=1, tile origin on a 2^levels grid, one
+// Restates, for the hot path's case (dx=dy=1, a tile-component anywhere on the canonical grid, one
 // precinct per resolution), what the reference derives in
 //   tile/TileComponent.cpp:69-170 (resolutions / bands),  util/util.cpp:34-59 (band windows),
 //   t1/T1Structs.cpp:109-136, :449-493 (precinct + code-block grid),
@@ -15,6 +15,7 @@ namespace grk_amd {
 
 struct BandGeom {
     uint8_t  orient;        // 0 LL 1 HL 2 LH 3 HH
+    uint32_t x0, y0;        // origin in the band's own coordinates (0 for a tile at the origin)
     uint32_t w, h;          // band size
     uint32_t ox, oy;        // origin in the Mallat plane
     uint32_t gw, gh;        // code-block grid of the (single) precinct
@@ -24,6 +25,8 @@ struct BandGeom {
     uint32_t first_block;   // index (within the component) of the band's first block
 };
 struct ResGeom {
+    uint32_t x0, y0;        // origin on the resolution's grid: its parity picks the lifting variant (odd start: the
+                            // first sample is a high-pass one, WaveletFwd.cpp:884-905)
     uint32_t w, h;
     uint32_t num_bands;
     BandGeom band[3];
@@ -41,6 +44,17 @@ struct TileGeom {
 
 // returns GRK_AMD_OK or an error code
 int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g);
+
+// the same sub-band partition, block partition and lifting variants: what one batch of grk_amd_encode_tiles needs
+bool same_geometry(const TileGeom& a, const TileGeom& b);
+
+// decomposition level l (0 = the tile itself) is resolution L - l
+inline const ResGeom& level_geom(const TileGeom& g, uint32_t l) { return g.res[g.p.num_levels - l]; }
+inline bool on_even_grid(const TileGeom& g)
+{
+    for (uint32_t l = 0; l < g.p.num_levels; ++l) if ((level_geom(g, l).x0 | level_geom(g, l).y0) & 1u) return false;
+    return true;
+}
 
 inline uint32_t ceil_div_pow2(uint32_t v, uint32_t n) { return (uint32_t)(((uint64_t)v + (1ull << n) - 1) >> n); }
 

@@ -1,0 +1,83 @@
+// grok_amd/csrc/image.cpp -- a whole image of any tile layout through the tile processor (host side, on top of the
+// C ABI's own entry points).
+//
+// grk_amd_encode_tiles codes a batch of tiles that share ONE geometry.  An image whose tile grid does not sit on
+// multiples of 2^levels x code-block size -- image offsets (grk_image x0 / y0), tile sizes such as 1000 x 1000, ragged
+// last rows and columns -- has tiles of several geometries: sub-band sizes differ by a sample, bands start with partial
+// code-blocks, and where a resolution begins on an odd coordinate the lifting starts with a high-pass sample
+// (tile/TileProcessor.cpp:100-170 tile rectangle; tile/TileComponent.cpp:131-138 bands; WaveletFwd.cpp:884-905).
+// Here the tiles are grouped by geometry, each group goes through grk_amd_encode_tiles as one batch, and the
+// tile-parts are written in tile order (codestream/CodeStreamCompress.cpp:535-603).
+#include "../../include/grok_amd.h"
+#include "geometry.h"
+#include <cstring>
+#include <vector>
+
+using namespace grk_amd;
+
+extern "C" int grk_amd_same_tile_geometry(const grk_amd_tile_params* a, const grk_amd_tile_params* b)
+{
+    if (!a || !b) return GRK_AMD_ERR_INVALID;
+    TileGeom ga, gb;
+    int rc = build_tile_geom(*a, ga); if (rc) return rc;
+    rc = build_tile_geom(*b, gb); if (rc) return rc;
+    return same_geometry(ga, gb) ? 1 : 0;
+}
+
+extern "C" int64_t grk_amd_encode_image(grk_amd_ctx* ctx, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                        const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap)
+{
+    if (!ctx || !im || !base || !pixels || !out) return GRK_AMD_ERR_INVALID;
+    const int64_t nt = grk_amd_layout_num_tiles(im);
+    if (nt < 0) return nt;
+    const uint32_t ntiles = (uint32_t)nt;
+    const uint32_t W = im->x1 - im->x0, H = im->y1 - im->y0;
+    const uint32_t bps = (base->prec + 7u) / 8u, nc = base->num_comps;
+    std::vector<grk_amd_tile_params> tp(ntiles);
+    std::vector<TileGeom> geoms;                       // one per group
+    std::vector<std::vector<uint32_t>> groups;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        int rc = grk_amd_layout_tile(im, base, t, &tp[t]);
+        if (rc) return rc;
+        TileGeom g;
+        rc = build_tile_geom(tp[t], g);
+        if (rc) return rc;
+        size_t k = 0;
+        for (; k < geoms.size(); ++k) if (same_geometry(geoms[k], g)) break;
+        if (k == geoms.size()) { geoms.push_back(std::move(g)); groups.emplace_back(); }
+        groups[k].push_back(t);
+    }
+    // per tile: its rows and where its group's coded bytes start in `coded`
+    std::vector<std::vector<grk_amd_coded_block>> rows(ntiles);
+    std::vector<uint8_t> coded, staging;
+    for (size_t k = 0; k < groups.size(); ++k) {
+        const auto& G = groups[k];
+        const grk_amd_tile_params& p = tp[G[0]];
+        const size_t tile_bytes = (size_t)p.tile_w * p.tile_h * nc * bps;
+        staging.resize(tile_bytes * G.size());
+        for (size_t i = 0; i < G.size(); ++i) {
+            const grk_amd_tile_params& q = tp[G[i]];
+            const size_t ox = q.tile_x0 - im->x0, oy = q.tile_y0 - im->y0;
+            for (uint32_t c = 0; c < nc; ++c)
+                for (uint32_t y = 0; y < q.tile_h; ++y)
+                    std::memcpy(&staging[i * tile_bytes + ((size_t)c * q.tile_h + y) * q.tile_w * bps],
+                                (const uint8_t*)pixels + (((size_t)c * H + oy + y) * W + ox) * bps, (size_t)q.tile_w * bps);
+        }
+        const uint64_t bpt = (uint64_t)geoms[k].blocks_per_comp * nc;
+        std::vector<grk_amd_coded_block> table(bpt * G.size());
+        uint64_t total = 0;
+        int rc = grk_amd_encode_tiles(ctx, &p, (uint32_t)G.size(), staging.data(), 0, table.data(), &total);
+        if (rc) return rc;
+        const size_t at = coded.size();
+        coded.resize(at + total);
+        rc = grk_amd_fetch_coded(ctx, coded.data() + at, total);
+        if (rc) return rc;
+        for (size_t i = 0; i < G.size(); ++i) {
+            rows[G[i]].assign(table.begin() + i * bpt, table.begin() + (i + 1) * bpt);
+            for (auto& r : rows[G[i]]) r.offset += at;
+        }
+    }
+    std::vector<grk_amd_coded_block> all;
+    for (uint32_t t = 0; t < ntiles; ++t) all.insert(all.end(), rows[t].begin(), rows[t].end());
+    return grk_amd_write_codestream_layout(im, base, all.data(), coded.data(), flags, out, cap);
+}

@@ -26,6 +26,7 @@ struct DwtLevelArgs {
     int32_t* ll;        uint32_t ll_stride;  uint64_t ll_pitch;    // next LL (sw x sh)
     int32_t* mallat;    uint32_t m_stride;   uint64_t m_pitch;     // HL/LH/HH go to their Mallat slots
     uint32_t cw, ch;      // size of the level being transformed
+    uint32_t px, py;      // parity of the level's origin on its grid: 1 = the first column / row is a high-pass sample
     uint32_t nplanes;
     uint32_t seg_pairs;   // row pairs per workgroup
     int      irreversible;
@@ -131,6 +132,7 @@ struct IdwtLevelArgs {
     const int32_t* mallat; uint32_t m_stride;   uint64_t m_pitch;    // HL/LH/HH read from their Mallat slots
     int32_t* out;          uint32_t out_stride; uint64_t out_pitch;  // synthesised level, cw x ch
     uint32_t cw, ch;
+    uint32_t px, py;      // parity of the level's origin (as DwtLevelArgs)
     uint32_t nplanes;
     uint32_t seg_pairs;
     int      irreversible;

@@ -24,6 +24,12 @@
 //
 // Image borders use whole-sample symmetric extension by index mirroring, which reproduces the
 // reference's edge formulas exactly (the mirrored operands are the same numbers; A.3/A.4).
+// A level whose origin lies on an ODD coordinate of its grid (a.px / a.py; tiles and images off the origin) starts with a
+// high-pass sample (WaveletFwd.cpp:884-905, :782-842).  Lifting works on coordinates, so the kernel runs on the
+// coordinate grid shifted by the parity: pair i = coordinates (2i, 2i + 1), sample k of the level sits at coordinate
+// k + parity, and position 0 of an odd start is a phantom that mirrors into the level like any other outside sample; its
+// low-pass output is dropped (low index = pair - parity).  A lone high-pass sample is doubled by the 5/3 (:885-887,
+// :812-815) and left alone by the 9/7 (:924-926, :985-987).
 // fp32 9/7: (l + r) * c and the accumulate are separately rounded (__fadd_rn/__fmul_rn, no FMA),
 // the order of WaveletFwd.cpp:143-160; scaling low*invK, high*K as in :46, :203-213.
 #include "kernels.h"
@@ -173,8 +179,10 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 
     const uint32_t t = threadIdx.x;
     const uint32_t cw = a.cw, ch = a.ch;
-    const uint32_t sw = (cw + 1) >> 1, dw = cw - sw;
-    const uint32_t sh = (ch + 1) >> 1, dh = ch - sh;
+    const uint32_t px = a.px, py = a.py;
+    const uint32_t sw = (cw + 1 - px) >> 1, dw = cw - sw;
+    const uint32_t sh = (ch + 1 - py) >> 1, dh = ch - sh;
+    const uint32_t vpairs = (ch + py + 1) >> 1;            // row pairs on the coordinate grid
     const float inv_k = (float)(1.0 / 1.230174105);
 
     const int32_t c_first = (int32_t)(blockIdx.x * kOutCols) - kHalo;    // global column of local 0
@@ -183,9 +191,9 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     // right of it; whatever lanes remain ride along on columns nobody reads.
     constexpr uint32_t HP = kHalo / 2;
     const uint32_t lp = t < (uint32_t)kOutPairs ? t + HP : (t < kOutPairs + HP ? t - kOutPairs : t);
-    const int32_t cA = c_first + 2 * (int32_t)lp;
-    const uint32_t mA = mirror_idx(cA, cw), mB = mirror_idx(cA + 1, cw);
-    const bool vec = (cA >= 0) && ((uint32_t)cA + 1 < cw);
+    const int32_t cA = c_first + 2 * (int32_t)lp;        // (coordinate grid: sample index = coordinate - px)
+    const uint32_t mA = mirror_idx(cA - (int32_t)px, cw), mB = mirror_idx(cA + 1 - (int32_t)px, cw);
+    const bool vec = px == 0 && (cA >= 0) && ((uint32_t)cA + 1 < cw);
 
     // first plane this workgroup produces
     uint32_t plane0 = blockIdx.z;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     const bool pvec = vec && (cw & 1u) == 0;          // tightly packed rows: pairs aligned only for even widths
 
     const int32_t J0 = (int32_t)(blockIdx.y * a.seg_pairs);
-    const int32_t J1 = min((int32_t)sh, J0 + (int32_t)a.seg_pairs);
+    const int32_t J1 = min((int32_t)vpairs, J0 + (int32_t)a.seg_pairs);
     constexpr int lag  = F97 ? 1 : 0;
     constexpr int warm = F97 ? 2 : 1;
 
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         // raw row fetch (no arithmetic, so that prefetched rows stay in flight) and its conversion
         struct Raw { int32_t a[NC], b[NC]; };
         auto fetch_row = [&](int32_t r, Raw& q) {
-            const uint32_t rr = mirror_row<FAST>(r, ch);
+            const uint32_t rr = mirror_row<FAST>(FAST ? r : r - (int32_t)py, ch);
             if constexpr (PX == 0) {
                 if constexpr (H16) {
                     const int16_t* row = reinterpret_cast<const int16_t*>(in) + (size_t)rr * a.in_stride;
@@ -301,7 +309,8 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         const uint32_t th = tp + kHalo / 2;                                  // its pair index inside the staged line
         const bool h_lane = FAST || t < (uint32_t)kOutPairs;
         const uint32_t Jc = blockIdx.x * kOutPairs + tp;                     // global pair column
-        const bool st_s = h_lane && (FAST || Jc < sw), st_d = h_lane && (FAST || Jc < dw);
+        const bool st_s = h_lane && (FAST || (Jc >= px && Jc - px < sw)), st_d = h_lane && (FAST || Jc < dw);
+        const uint32_t Js = Jc - (FAST ? 0u : px);                           // its column in the low-pass bands
 
         const int32_t i_end = J1 - 1 + lag;
         T sA[NC], dA[NC], sB[NC], dB[NC];
@@ -328,10 +337,17 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         for (; i - lag < J0; ++i) vstep();   // warm-up steps produce no output
         // horizontal phase of the row pair the vertical step just finished: exchange through the LDS line, local stencil
         auto hphase = [&](int par, int32_t j, T (&o)[NC][4]) {
-            if (!FAST && ch == 1) {          // single-row level: vertical pass is the identity
-                Raw q;
-                fetch_row(0, q);
+            if (!FAST && ch == 1) {          // single-row level: vertical pass is the identity -- or, for a lone HIGH-pass
+                Raw q;                       // row (odd start), the doubling of the 5/3
+                fetch_row((int32_t)py, q);
                 convert(q, sA, sB);
+                if (py) {
+    #pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        if constexpr (F97) { dA[k] = sA[k]; dB[k] = sB[k]; }
+                        else { dA[k] = sA[k] * 2; dB[k] = sB[k] * 2; }
+                    }
+                }
             }
     #pragma unroll
             for (int k = 0; k < NC; ++k) {
@@ -346,12 +362,14 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     #pragma unroll
                 for (int k = 0; k < NC; ++k) {
                     T ls, ld, hs = 0, hd = 0;
-                    if constexpr (F97) {
-                        if (!FAST && cw == 1) { ls = line[par][k][0][2 * th]; ld = 0; if (has_h) hs = line[par][k][1][2 * th]; }
-                        else {
-                            h97(&line[par][k][0][2 * th], ls, ld, inv_k);
-                            if (has_h) h97(&line[par][k][1][2 * th], hs, hd, inv_k);
-                        }
+                    if (!FAST && cw == 1) {        // single column: a low-pass sample passes, a lone high-pass one (odd start)
+                                                   // is doubled by the 5/3; it sits at coordinate px of the staged line
+                        const T v0 = line[par][k][0][2 * th + px], v1 = line[par][k][1][2 * th + px];
+                        if (px) { ls = 0; hs = 0; ld = F97 ? v0 : v0 * 2; hd = F97 ? v1 : v1 * 2; }
+                        else    { ls = v0; hs = v1; ld = 0; hd = 0; }
+                    } else if constexpr (F97) {
+                        h97(&line[par][k][0][2 * th], ls, ld, inv_k);
+                        if (has_h) h97(&line[par][k][1][2 * th], hs, hd, inv_k);
                     } else {
                         h53(&line[par][k][0][2 * th], ls, ld);
                         if (has_h) h53(&line[par][k][1][2 * th], hs, hd);
@@ -373,10 +391,16 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
                         mpk[(size_t)(sh + j) * a.m_stride + Jc] = (PT)o[k][2];
                         mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = (PT)o[k][3];
                     } else {
-                        if (st_s) llk[(size_t)j * a.ll_stride + Jc] = (PT)o[k][0];
-                        if (st_d) mpk[(size_t)j * a.m_stride + sw + Jc] = (PT)o[k][1];
+                        // pair j of the coordinate grid: its low-pass row is row j - py of LL / HL (none for the phantom
+                        // pair of an odd start), its high-pass row is row j of LH / HH
+                        const bool has_l = (uint32_t)j >= py && (uint32_t)j - py < sh;
+                        const size_t jl = (size_t)((uint32_t)j - py);
+                        if (has_l) {
+                            if (st_s) llk[jl * a.ll_stride + Js] = (PT)o[k][0];
+                            if (st_d) mpk[jl * a.m_stride + sw + Jc] = (PT)o[k][1];
+                        }
                         if (has_h) {
-                            if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Jc] = (PT)o[k][2];
+                            if (st_s) mpk[(size_t)(sh + j) * a.m_stride + Js] = (PT)o[k][2];
                             if (st_d) mpk[(size_t)(sh + j) * a.m_stride + sw + Jc] = (PT)o[k][3];
                         }
                     }
@@ -410,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
             }
         }
     };
-    const bool even = (cw & 1u) == 0 && cw >= 4 && ch >= 16 && (ch & 1u) == 0;
+    const bool even = (px | py) == 0 && (cw & 1u) == 0 && cw >= 4 && ch >= 16 && (ch & 1u) == 0;
     const bool interior = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (blockIdx.x + 1) * kOutPairs <= dw;
     if (even && interior) strip(std::true_type{}, std::false_type{});
     else if (even) strip(std::true_type{}, std::true_type{});
@@ -423,8 +447,8 @@ uint32_t dwt_strip_cols() { return kOutCols; }
 
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
 {
-    const uint32_t sh = (a.ch + 1) >> 1;
-    dim3 grid((a.cw + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
+    const uint32_t sh = (a.ch + a.py + 1) >> 1;
+    dim3 grid((a.cw + a.px + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
     dim3 block(kThreads);
     if (a.irreversible)
         hipLaunchKernelGGL((dwt_level_kernel<true, 1, 0>), grid, block, 0, s, a);
@@ -439,12 +463,12 @@ hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
 // a.nplanes is ignored: the grid covers ntiles x (MCT triple | every component on its own).
 hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, int mct, hipStream_t s)
 {
-    const uint32_t sh = (a0.ch + 1) >> 1;
+    const uint32_t sh = (a0.ch + a0.py + 1) >> 1;
     dim3 block(kThreads);
     auto go = [&](uint32_t comp0, uint32_t zdiv, int nc) {
         DwtLevelArgs a = a0;
         a.comp0 = comp0; a.zdiv = zdiv; a.ncomp = ncomp;
-        dim3 grid((a.cw + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, ntiles * zdiv);
+        dim3 grid((a.cw + a.px + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, ntiles * zdiv);
 #define GRK_L0(F97, NC, PX) hipLaunchKernelGGL((dwt_level_kernel<F97, NC, PX>), grid, block, 0, s, a)
         const int px = a.px_bytes == 1 ? 1 : 2;
         if (a.irreversible) {

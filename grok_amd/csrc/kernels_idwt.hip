@@ -20,6 +20,9 @@
 //
 // Borders: whole-sample symmetric extension by mirroring the interleaved index (lifting preserves
 // the symmetry, so the extended synthesis equals the reference's edge formulas, :104-184, :990-1060).
+// A level that starts on an odd coordinate (a.px / a.py, see kernels_dwt.hip) is synthesised on the coordinate grid:
+// pair J = coordinates (2J, 2J + 1), sample k of the level = coordinate k + parity; a lone high-pass sample is halved by
+// the 5/3 (rows: / 2, columns: >> 1 -- WaveletReverse.cpp:598, :646) and passes through the 9/7 (:1064-1066).
 // 9/7: low*K, high*(2/K) first, then the four lifting sweeps with coefficients -delta, -gamma,
 // -beta, -alpha, each `x + ((l + r) * c)` separately rounded (:1068-1073, :1005-1008).
 #include "kernels.h"
@@ -166,7 +169,9 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
 
     const uint32_t t = threadIdx.x;
     const uint32_t cw = a.cw, ch = a.ch;
-    const uint32_t sw = (cw + 1) >> 1, sh = (ch + 1) >> 1;
+    const uint32_t px = a.px, py = a.py;
+    const uint32_t sw = (cw + 1 - px) >> 1, sh = (ch + 1 - py) >> 1;        // low-pass columns / rows
+    const uint32_t vpairs = (ch + py + 1) >> 1;                               // row pairs on the coordinate grid
 
     uint32_t plane0 = blockIdx.z;
     if constexpr (PXO != 0) plane0 = (blockIdx.z / a.zdiv) * a.ncomp + a.comp0 + (blockIdx.z % a.zdiv);
@@ -184,13 +189,15 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     const uint32_t lp = t < (uint32_t)kOutPairs ? t + kHaloPairs : (t < (uint32_t)(kOutPairs + kHaloPairs) ? t - kOutPairs : t);
     const int32_t J = (int32_t)((blockIdx.x + a.strip0) * kOutPairs) - kHaloPairs + (int32_t)lp;
     // horizontal mirror in the interleaved domain: low sample 2J, high sample 2J+1
-    const uint32_t js = mirror_idx(2 * J, cw) >> 1;
-    const uint32_t jd = cw > 1 ? (mirror_idx(2 * J + 1, cw) - 1) >> 1 : 0;
+    // (coordinate c holds sample c - px; a mirrored coordinate keeps its parity)
+    const uint32_t js = sw ? ((mirror_idx(2 * J - (int32_t)px, cw) + px) >> 1) - px : 0;
+    const uint32_t jd = cw > sw ? (mirror_idx(2 * J + 1 - (int32_t)px, cw) + px - 1) >> 1 : 0;
     const bool h_lane = t < (uint32_t)kOutPairs;
-    const bool st_e = h_lane && (uint32_t)(2 * J) < cw, st_o = h_lane && (uint32_t)(2 * J + 1) < cw;
+    const int32_t cE = 2 * J - (int32_t)px, cO = cE + 1;                 // the samples (columns of the level) this lane makes
+    const bool st_e = h_lane && cE >= 0 && (uint32_t)cE < cw, st_o = h_lane && cO >= 0 && (uint32_t)cO < cw;
 
     const int32_t I0 = (int32_t)((blockIdx.y + a.seg0) * a.seg_pairs);
-    const int32_t I1 = min((int32_t)sh, I0 + (int32_t)a.seg_pairs);
+    const int32_t I1 = min((int32_t)vpairs, I0 + (int32_t)a.seg_pairs);
     // rows [2*I0, 2*I1) are this workgroup's; the recurrences lag behind the input by `lag` pairs
     constexpr int lag  = F97 ? 2 : 1;       // rows 2i and 2i+1 are complete after step i + lag
     constexpr int warm = F97 ? 2 : 1;       // steps before I0 whose outputs are discarded
@@ -198,27 +205,31 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     struct Raw { T ls[NC], ld[NC], hs[NC], hd[NC]; };
     auto fetch = [&](int32_t i, Raw& q) {
         // vertical mirror in the interleaved domain: low row 2i, high row 2i+1
-        const uint32_t is = mirror_row(2 * i, ch) >> 1;
-        const uint32_t id = ch > 1 ? (mirror_row(2 * i + 1, ch) - 1) >> 1 : 0;
+        const uint32_t is = sh ? ((mirror_row(2 * i - (int32_t)py, ch) + py) >> 1) - py : 0;
+        const uint32_t id = ch > sh ? (mirror_row(2 * i + 1 - (int32_t)py, ch) + py - 1) >> 1 : 0;
+        const bool lc = sw > 0, hc = cw > sw, lr = sh > 0, hr = ch > sh;    // which halves exist (single row / column)
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const T* llk = ll + (size_t)k * a.ll_pitch;
             const T* mpk = mp + (size_t)k * a.m_pitch;
-            q.ls[k] = llk[(size_t)is * a.ll_stride + js];
-            q.ld[k] = cw > 1 ? mpk[(size_t)is * a.m_stride + sw + jd] : T(0);
-            q.hs[k] = ch > 1 ? mpk[(size_t)(sh + id) * a.m_stride + js] : T(0);
-            q.hd[k] = (ch > 1 && cw > 1) ? mpk[(size_t)(sh + id) * a.m_stride + sw + jd] : T(0);
+            q.ls[k] = (lr && lc) ? llk[(size_t)is * a.ll_stride + js] : T(0);
+            q.ld[k] = (lr && hc) ? mpk[(size_t)is * a.m_stride + sw + jd] : T(0);
+            q.hs[k] = (hr && lc) ? mpk[(size_t)(sh + id) * a.m_stride + js] : T(0);
+            q.hd[k] = (hr && hc) ? mpk[(size_t)(sh + id) * a.m_stride + sw + jd] : T(0);
         }
     };
     // one finished row of this lane's two columns leaves the kernel: as a plane row, or as pixels
-    const bool px_vec = ((win_w | a.wx0) & 1u) == 0;   // tightly packed pixel rows: pairs are aligned only for even widths / origins
-    const bool in_e = (uint32_t)(2 * J) >= a.wx0 && (uint32_t)(2 * J) < a.wx1;
-    const bool in_o = (uint32_t)(2 * J + 1) >= a.wx0 && (uint32_t)(2 * J + 1) < a.wx1;
+    const bool px_vec = ((win_w | a.wx0 | px) & 1u) == 0;   // tightly packed pixel rows: pairs are aligned only for even widths / origins
+    const bool in_e = cE >= (int32_t)a.wx0 && cE < (int32_t)a.wx1;
+    const bool in_o = cO >= (int32_t)a.wx0 && cO < (int32_t)a.wx1;
     auto emit = [&](int32_t r, const T (&vA)[NC], const T (&vB)[NC]) {
         if constexpr (PXO == 0) {
-            T* row = out + (size_t)r * a.out_stride + 2 * J;
-            if (st_o) { T2 v; v.x = vA[0]; v.y = vB[0]; *reinterpret_cast<T2*>(row) = v; }
-            else if (st_e) row[0] = vA[0];
+            T* row = out + (size_t)r * a.out_stride + cE;
+            if (st_e && st_o && !px) { T2 v; v.x = vA[0]; v.y = vB[0]; *reinterpret_cast<T2*>(row) = v; }
+            else {
+                if (st_e) row[0] = vA[0];
+                if (st_o) row[1] = vB[0];
+            }
         } else {
             int32_t cA[NC], cB[NC];
 #pragma unroll
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 if ((uint32_t)r < a.wy0 || (uint32_t)r >= a.wy1) continue;
-                PIX* row = pix + (size_t)k * comp_px + (size_t)((uint32_t)r - a.wy0) * win_w + (2 * J - (int32_t)a.wx0);
+                PIX* row = pix + (size_t)k * comp_px + (size_t)((uint32_t)r - a.wy0) * win_w + (cE - (int32_t)a.wx0);
                 if (st_o && px_vec && in_e && in_o) {
                     if constexpr (PXO == 1) *reinterpret_cast<uchar2*>(row) = make_uchar2((uint8_t)cA[k], (uint8_t)cB[k]);
                     else                    *reinterpret_cast<ushort2*>(row) = make_ushort2((uint16_t)cA[k], (uint16_t)cB[k]);
@@ -263,7 +274,13 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 T se, so, de, dodd;                           // low row / high row, even / odd column
-                if (cw == 1) { se = line[par][k][0][0][lp]; so = 0; de = line[par][k][1][0][lp]; dodd = 0; }
+                if (cw == 1) {
+                    if (px) {          // a lone high-pass column: coordinate 1 of pair 0
+                        const T v0 = line[par][k][0][1][lp], v1 = line[par][k][1][1][lp];
+                        se = 0; de = 0;
+                        if constexpr (F97) { so = v0; dodd = v1; } else { so = v0 / 2; dodd = v1 / 2; }
+                    } else { se = line[par][k][0][0][lp]; so = 0; de = line[par][k][1][0][lp]; dodd = 0; }
+                }
                 else if constexpr (F97) {
                     hs97(&line[par][k][0][0][lp], &line[par][k][0][1][lp], se, so);
                     hs97(&line[par][k][1][0][lp], &line[par][k][1][1][lp], de, dodd);
@@ -271,16 +288,21 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
                     hs53(&line[par][k][0][0][lp], &line[par][k][0][1][lp], se, so);
                     hs53(&line[par][k][1][0][lp], &line[par][k][1][1][lp], de, dodd);
                 }
-                if (ch == 1) { eA[k] = se; eB[k] = so; oA[k] = oB[k] = 0; }
+                if (ch == 1) {
+                    if (py) {          // a lone high-pass row
+                        if constexpr (F97) { eA[k] = de; eB[k] = dodd; } else { eA[k] = de >> 1; eB[k] = dodd >> 1; }
+                    } else { eA[k] = se; eB[k] = so; }
+                    oA[k] = oB[k] = 0;
+                }
                 else { colA[k].step(se, de, oA[k], eA[k]); colB[k].step(so, dodd, oB[k], eB[k]); }
             }
-            // which output rows these are
-            const int32_t r_even = ch == 1 ? 0 : 2 * (i - (lag - 1));
+            // which output rows these are: coordinates, then rows of the level (coordinate - py)
+            const int32_t r_even = ch == 1 ? (int32_t)py : 2 * (i - (lag - 1));
             const int32_t r_odd = r_even - 1;              // 5/3: 2i-1 ; 9/7: 2(i-2)+1
-            const bool ok_e = ch == 1 ? (i == 0) : (r_even >= 2 * I0 && r_even < 2 * I1 && (uint32_t)r_even < ch);
-            const bool ok_o = ch > 1 && r_odd >= 2 * I0 && r_odd < 2 * I1 && (uint32_t)r_odd < ch;
-            if (ok_e) emit(r_even, eA, eB);
-            if (ok_o) emit(r_odd, oA, oB);
+            const bool ok_e = ch == 1 ? (i == 0) : (r_even >= 2 * I0 && r_even < 2 * I1 && r_even >= (int32_t)py && (uint32_t)(r_even - (int32_t)py) < ch);
+            const bool ok_o = ch > 1 && r_odd >= 2 * I0 && r_odd < 2 * I1 && r_odd >= (int32_t)py && (uint32_t)(r_odd - (int32_t)py) < ch;
+            if (ok_e) emit(r_even - (int32_t)py, eA, eB);
+            if (ok_o) emit(r_odd - (int32_t)py, oA, oB);
         }
         cur = nxt;
     }
@@ -350,7 +372,7 @@ uint32_t idwt_strip_pairs() { return kOutPairs; }
 
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s)
 {
-    const uint32_t sw = (a.cw + 1) >> 1, sh = (a.ch + 1) >> 1;
+    const uint32_t sw = (a.cw + a.px + 1) >> 1, sh = (a.ch + a.py + 1) >> 1;      // pairs on the coordinate grid
     // strips x row segments: all of them, or the caller's sub-grid (region decode)
     dim3 grid(a.nstrips ? a.nstrips : (sw + kOutPairs - 1) / kOutPairs, a.nsegs ? a.nsegs : (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
     dim3 block(kThreads);
@@ -365,7 +387,7 @@ hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s)
 // a0.nplanes is ignored: the grid covers ntiles x (MCT triple | every component on its own).
 hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, hipStream_t s)
 {
-    const uint32_t sw = (a0.cw + 1) >> 1, sh = (a0.ch + 1) >> 1;
+    const uint32_t sw = (a0.cw + a0.px + 1) >> 1, sh = (a0.ch + a0.py + 1) >> 1;
     dim3 block(kThreads);
     auto go = [&](uint32_t comp0, uint32_t zdiv, int nc) {
         IdwtLevelArgs a = a0;

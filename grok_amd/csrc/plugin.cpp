@@ -160,13 +160,18 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
                              grk_amd_tile_params& p)
 {
     if (!cp->isHT || !(cp->cblk_sty & GRA_CBLKSTY_HT)) return false;             // hot path = HTJ2K only
-    if (cp->tile_size_on && (cp->t_width < w || cp->t_height < h)) return false;    // single tile (D3)
+    // single tile (D3): the tile grid cell anchored at (tx0, ty0) has to cover the image area, which starts at
+    // (image_offset_x0, image_offset_y0) -- grk_compress -d, stored as grk_image x0 / y0 by the host's image readers
+    const uint64_t ox = cp->image_offset_x0, oy = cp->image_offset_y0;
+    if (cp->tile_size_on && (cp->tx0 > ox || cp->ty0 > oy || (uint64_t)cp->tx0 + cp->t_width < ox + w ||
+                             (uint64_t)cp->ty0 + cp->t_height < oy + h)) return false;
     if (cp->tcp_numlayers > 1 || cp->numpocs || cp->res_spec || cp->roi_compno >= 0) return false;
-    if (cp->subsampling_dx != 1 || cp->subsampling_dy != 1 || cp->image_offset_x0 || cp->image_offset_y0) return false;
+    if (cp->subsampling_dx != 1 || cp->subsampling_dy != 1) return false;
     if (cp->numresolution < 1 || cp->numresolution > GRK_AMD_MAX_LEVELS + 1) return false;
     auto lg = [](uint32_t v) { int e = 0; while ((1u << e) < v) ++e; return e; };
     std::memset(&p, 0, sizeof p);
     p.tile_w = w; p.tile_h = h; p.num_comps = (uint16_t)comps; p.prec = (uint8_t)prec; p.sgnd = 0;
+    p.tile_x0 = cp->image_offset_x0; p.tile_y0 = cp->image_offset_y0;       // the tile = the image area, wherever it lies
     p.irreversible = cp->irreversible ? 1 : 0;
     // tcp_mct as grk_compress leaves it: 255 = "not set" (the library then applies RCT/ICT to >= 3 components,
     // CodeStreamCompress.cpp:345-352), 0 / 1 as given, 2 = custom array MCT (mct_data) -- outside the hot path
@@ -208,10 +213,10 @@ int32_t encode_file(gra_cparameters* cp, const char* in, const char* out, gra_en
         unref = reinterpret_cast<void (*)(void*)>(dlsym(RTLD_DEFAULT, "grk_object_unref"));
         if (!image_new || !unref) { grk_amd_plugin_tile_destroy(tile); return -1; }
         std::vector<gra_image_cmptparm> cps(comps);
-        for (auto& c : cps) { c.dx = 1; c.dy = 1; c.w = w; c.stride = 0; c.h = h; c.x0 = 0; c.y0 = 0; c.prec = (uint8_t)prec; c.sgnd = false; }
+        for (auto& c : cps) { c.dx = 1; c.dy = 1; c.w = w; c.stride = 0; c.h = h; c.x0 = p.tile_x0; c.y0 = p.tile_y0; c.prec = (uint8_t)prec; c.sgnd = false; }
         gra_image* img = image_new((uint16_t)comps, cps.data(), comps >= 3 ? 1 /* GRK_CLRSPC_SRGB */ : 2 /* GRK_CLRSPC_GRAY */, true);
         if (!img) { grk_amd_plugin_tile_destroy(tile); return -1; }
-        img->x0 = 0; img->y0 = 0; img->x1 = w; img->y1 = h;
+        img->x0 = p.tile_x0; img->y0 = p.tile_y0; img->x1 = p.tile_x0 + w; img->y1 = p.tile_y0 + h;
         bool ok = true;
         for (uint32_t c = 0; c < comps && ok; ++c)
             ok = img->comps[c].data && grk_amd_fetch_coefficients(g_ctx, c, img->comps[c].data, img->comps[c].stride) == GRK_AMD_OK;
@@ -356,10 +361,10 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
         const char* path = in_path ? in_path : !dp ? nullptr : dp->infile[0] ? dp->infile : dp->core.infile[0] ? dp->core.infile : nullptr;
         if (!path || !read_stream_header(path, sh) || sh.overrides) return clean(-1);
     }
-    // the scope of the hot path: one tile at the origin, equal full-resolution components, default
+    // the scope of the hot path: one tile (anywhere on the canonical grid), equal full-resolution components, default
     // precincts, one codeword segment per block (the host's bridge throws on more); irreversible only for classic
     // blocks (the reference's own HT + 9/7 encoder is broken, D1: there is no stream to be compatible with)
-    if (h.t_grid_width * h.t_grid_height != 1 || img->numcomps == 0 || img->x0 || img->y0 || (h.csty & 1u) ||
+    if (h.t_grid_width * h.t_grid_height != 1 || img->numcomps == 0 || (h.csty & 1u) ||
         (h.irreversible && (h.cblk_sty & 0x40u)) || (h.cblk_sty & 0x05u) || h.numresolutions == 0)
         return clean(-1);
     const gra_image_comp& c0 = img->comps[0];
@@ -370,6 +375,7 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
     }
     grk_amd_tile_params tp{};
     tp.tile_w = img->x1 - img->x0; tp.tile_h = img->y1 - img->y0; tp.num_comps = img->numcomps;
+    tp.tile_x0 = img->x0; tp.tile_y0 = img->y0;
     tp.prec = c0.prec; tp.sgnd = c0.sgnd; tp.irreversible = h.irreversible ? 1 : 0; tp.mct = h.mct ? 1 : 0;
     tp.num_levels = (uint8_t)(h.numresolutions - 1);
     uint32_t ew = 0, eh = 0;

@@ -13,6 +13,7 @@
 // It is O(#code-blocks) host work plus one memcpy of the coded bytes.
 #include "../../include/grok_amd.h"
 #include "geometry.h"
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -93,14 +94,14 @@ struct TagTree {
 int floor_log2(uint32_t v) { int r = 0; while (v >>= 1) ++r; return r; }
 
 // tlm_at: where the Ptlm fields of the TLM marker segment start (0: none written)
-void write_main_header(Out& o, const TileGeom& g, uint32_t img_w, uint32_t img_h, uint32_t flags, uint32_t ntiles, uint64_t* tlm_at)
+void write_main_header(Out& o, const TileGeom& g, const grk_amd_image_layout& im, uint32_t flags, uint32_t ntiles, uint64_t* tlm_at)
 {
     if (tlm_at) *tlm_at = 0;
     const grk_amd_tile_params& p = g.p;
     o.u16(0xFF4F);                                                     // SOC
     o.u16(0xFF51); o.u16(38 + 3 * p.num_comps); o.u16(0x4000);         // SIZ, Rsiz: HTJ2K (Part 15)
-    o.u32(img_w); o.u32(img_h); o.u32(0); o.u32(0);
-    o.u32(p.tile_w); o.u32(p.tile_h); o.u32(0); o.u32(0);
+    o.u32(im.x1); o.u32(im.y1); o.u32(im.x0); o.u32(im.y0);            // Xsiz Ysiz XOsiz YOsiz (markers/SIZMarker.cpp)
+    o.u32(im.t_width); o.u32(im.t_height); o.u32(im.tx0); o.u32(im.ty0);
     o.u16(p.num_comps);
     for (uint32_t c = 0; c < p.num_comps; ++c) { o.u8((p.prec - 1) | (p.sgnd ? 0x80 : 0)); o.u8(1); o.u8(1); }
     // CAP (CodeStreamCompress.cpp:936-981; MAGBp HTParams.cpp:313-329)
@@ -143,6 +144,7 @@ void write_main_header(Out& o, const TileGeom& g, uint32_t img_w, uint32_t img_h
 void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_block* comp_table, const uint8_t* coded)
 {
     const ResGeom& R = g.res[r];
+    if (R.w == 0 || R.h == 0) return;      // an empty resolution has no precinct, hence no packet (t2/PacketIter.cpp)
     HeaderBits hb(o);
     hb.bit(1);
     TagTree incl, zbp;
@@ -175,25 +177,33 @@ void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_blo
     }
 }
 
-// checks shared by the entry points below; fills g
-int check_layout(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h, TileGeom& g, uint32_t& tcols, uint32_t& trows)
+// The tiles of an image (ISO 15444-1 B.3; the reference: TileProcessor::init, tile/TileProcessor.cpp:100-170): tile
+// (tx, ty) of the grid anchored at (tx0, ty0) is its cell clipped to the image area.
+struct Layout { grk_amd_image_layout im; uint32_t tcols, trows; };
+int check_layout(const grk_amd_image_layout* im, Layout& l)
 {
-    int rc = build_tile_geom(*p, g);
-    if (rc != GRK_AMD_OK) return rc;
-    // equally sized tiles on a grid whose pitch keeps every band aligned (see geometry.h)
-    if (img_w % p->tile_w || img_h % p->tile_h) return GRK_AMD_ERR_UNSUPPORTED;
-    tcols = img_w / p->tile_w; trows = img_h / p->tile_h;
-    if ((uint64_t)tcols * trows > 65535) return GRK_AMD_ERR_UNSUPPORTED;
-    if (tcols * trows > 1 && ((p->tile_w | p->tile_h) & ((1u << p->num_levels) - 1))) return GRK_AMD_ERR_UNSUPPORTED;
-    for (uint32_t r = 0; r <= p->num_levels && tcols * trows > 1; ++r)
-        for (uint32_t b = 0; b < g.res[r].num_bands; ++b) {
-            // a band narrower than a code-block must not straddle a global code-block grid line
-            const BandGeom& B = g.res[r].band[b];
-            const uint32_t cw = 1u << p->cblk_w_exp, chh = 1u << p->cblk_h_exp;
-            if ((B.w % cw) && (cw % B.w)) return GRK_AMD_ERR_UNSUPPORTED;
-            if ((B.h % chh) && (chh % B.h)) return GRK_AMD_ERR_UNSUPPORTED;
-        }
+    if (!im || im->x1 <= im->x0 || im->y1 <= im->y0 || !im->t_width || !im->t_height) return GRK_AMD_ERR_INVALID;
+    if (im->tx0 > im->x0 || im->ty0 > im->y0) return GRK_AMD_ERR_INVALID;                              // B.3: XTOsiz <= XOsiz
+    if ((uint64_t)im->tx0 + im->t_width <= im->x0 || (uint64_t)im->ty0 + im->t_height <= im->y0) return GRK_AMD_ERR_INVALID;
+    l.im = *im;
+    l.tcols = (uint32_t)(((uint64_t)im->x1 - im->tx0 + im->t_width - 1) / im->t_width);
+    l.trows = (uint32_t)(((uint64_t)im->y1 - im->ty0 + im->t_height - 1) / im->t_height);
+    if ((uint64_t)l.tcols * l.trows > 65535) return GRK_AMD_ERR_UNSUPPORTED;
     return GRK_AMD_OK;
+}
+void tile_of(const Layout& l, const grk_amd_tile_params& base, uint32_t t, grk_amd_tile_params& p)
+{
+    const uint32_t tx = t % l.tcols, ty = t / l.tcols;
+    const uint64_t cx0 = (uint64_t)l.im.tx0 + (uint64_t)tx * l.im.t_width, cy0 = (uint64_t)l.im.ty0 + (uint64_t)ty * l.im.t_height;
+    const uint64_t x0 = std::max<uint64_t>(cx0, l.im.x0), y0 = std::max<uint64_t>(cy0, l.im.y0);
+    const uint64_t x1 = std::min<uint64_t>(cx0 + l.im.t_width, l.im.x1), y1 = std::min<uint64_t>(cy0 + l.im.t_height, l.im.y1);
+    p = base;
+    p.tile_x0 = (uint32_t)x0; p.tile_y0 = (uint32_t)y0;
+    p.tile_w = (uint32_t)(x1 - x0); p.tile_h = (uint32_t)(y1 - y0);
+}
+grk_amd_image_layout plain_layout(const grk_amd_tile_params& p, uint32_t img_w, uint32_t img_h)
+{
+    return grk_amd_image_layout{p.tile_x0, p.tile_y0, p.tile_x0 + img_w, p.tile_y0 + img_h, p.tile_x0, p.tile_y0, p.tile_w, p.tile_h};
 }
 
 // SOT, (PLT,) SOD and the LRCP packets of one tile; returns the tile-part's length
@@ -231,28 +241,72 @@ uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, 
 
 } // namespace
 
-extern "C" int64_t grk_amd_write_codestream_ex(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
-                                               const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
-                                               uint8_t* out, uint64_t cap)
+extern "C" int64_t grk_amd_layout_num_tiles(const grk_amd_image_layout* im)
 {
-    if (!p || !table || !coded || !out) return GRK_AMD_ERR_INVALID;
-    TileGeom g;
-    uint32_t tcols = 0, trows = 0;
-    int rc = check_layout(p, img_w, img_h, g, tcols, trows);
+    Layout l;
+    const int rc = check_layout(im, l);
+    return rc != GRK_AMD_OK ? rc : (int64_t)l.tcols * l.trows;
+}
+
+extern "C" int grk_amd_layout_tile(const grk_amd_image_layout* im, const grk_amd_tile_params* base, uint32_t tile_index,
+                                   grk_amd_tile_params* out)
+{
+    Layout l;
+    const int rc = check_layout(im, l);
     if (rc != GRK_AMD_OK) return rc;
-    const uint32_t ntiles = tcols * trows;
+    if (!base || !out || tile_index >= l.tcols * l.trows) return GRK_AMD_ERR_INVALID;
+    tile_of(l, *base, tile_index, *out);
+    return GRK_AMD_OK;
+}
+
+extern "C" int64_t grk_amd_write_codestream_layout(const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                                   const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
+                                                   uint8_t* out, uint64_t cap)
+{
+    if (!base || !table || !coded || !out) return GRK_AMD_ERR_INVALID;
+    Layout l;
+    int rc = check_layout(im, l);
+    if (rc != GRK_AMD_OK) return rc;
+    const uint32_t ntiles = l.tcols * l.trows;
     if ((flags & GRK_AMD_CS_TLM) && ntiles > 255) return GRK_AMD_ERR_UNSUPPORTED;     // (one-byte Ttlm, as the reference writes it)
+    TileGeom g;
+    grk_amd_tile_params p;
     Out o{out, cap};
-    uint64_t tlm_at = 0;
-    write_main_header(o, g, img_w, img_h, flags, ntiles, &tlm_at);
-    const uint64_t bpt = (uint64_t)g.blocks_per_comp * p->num_comps;
+    uint64_t tlm_at = 0, row = 0;
     for (uint32_t t = 0; t < ntiles; ++t) {
-        const uint64_t len = write_tile_part(o, g, t, flags, table + t * bpt, coded);
+        tile_of(l, *base, t, p);
+        rc = build_tile_geom(p, g);
+        if (rc != GRK_AMD_OK) return rc;
+        if (t == 0) write_main_header(o, g, l.im, flags, ntiles, &tlm_at);
+        const uint64_t len = write_tile_part(o, g, t, flags, table + row, coded);
+        row += (uint64_t)g.blocks_per_comp * p.num_comps;
         if (tlm_at) o.patch32(tlm_at + 5ull * t + 1, (uint32_t)len);
     }
     o.u16(0xFFD9);
     if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
     return (int64_t)o.n;
+}
+
+extern "C" int64_t grk_amd_write_codestream_ex(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
+                                               const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
+                                               uint8_t* out, uint64_t cap)
+{
+    if (!p) return GRK_AMD_ERR_INVALID;
+    const grk_amd_image_layout im = plain_layout(*p, img_w, img_h);
+    // this entry point serves tables of ONE grk_amd_encode_tiles batch: every tile has to have *p's geometry
+    Layout l;
+    int rc = check_layout(&im, l);
+    if (rc != GRK_AMD_OK) return rc;
+    TileGeom g0, g;
+    grk_amd_tile_params q;
+    rc = build_tile_geom(*p, g0);
+    if (rc != GRK_AMD_OK) return rc;
+    for (uint32_t t = 1; t < l.tcols * l.trows; ++t) {
+        tile_of(l, *p, t, q);
+        if ((rc = build_tile_geom(q, g)) != GRK_AMD_OK) return rc;
+        if (!same_geometry(g0, g)) return GRK_AMD_ERR_UNSUPPORTED;
+    }
+    return grk_amd_write_codestream_layout(&im, p, table, coded, flags, out, cap);
 }
 
 extern "C" int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
@@ -262,22 +316,34 @@ extern "C" int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32
     return grk_amd_write_codestream_ex(p, img_w, img_h, table, coded, 0, out, cap);
 }
 
+extern "C" int64_t grk_amd_write_main_header_layout(const grk_amd_image_layout* im, const grk_amd_tile_params* base, uint32_t flags,
+                                                    const uint32_t* tile_part_bytes, uint8_t* out, uint64_t cap)
+{
+    if (!base) return GRK_AMD_ERR_INVALID;
+    Layout l;
+    int rc = check_layout(im, l);
+    if (rc != GRK_AMD_OK) return rc;
+    const uint32_t ntiles = l.tcols * l.trows;
+    if (flags & GRK_AMD_CS_TLM) { if (ntiles > 255) return GRK_AMD_ERR_UNSUPPORTED; if (!tile_part_bytes) return GRK_AMD_ERR_INVALID; }
+    TileGeom g;
+    grk_amd_tile_params p;
+    tile_of(l, *base, 0, p);
+    rc = build_tile_geom(p, g);
+    if (rc != GRK_AMD_OK) return rc;
+    Out o{out, cap};
+    uint64_t tlm_at = 0;
+    write_main_header(o, g, l.im, flags, ntiles, &tlm_at);
+    for (uint32_t t = 0; tlm_at && t < ntiles; ++t) o.patch32(tlm_at + 5ull * t + 1, tile_part_bytes[t]);
+    if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
+    return (int64_t)o.n;
+}
+
 extern "C" int64_t grk_amd_write_main_header(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h, uint32_t flags,
                                              const uint32_t* tile_part_bytes, uint8_t* out, uint64_t cap)
 {
     if (!p) return GRK_AMD_ERR_INVALID;
-    TileGeom g;
-    uint32_t tcols = 0, trows = 0;
-    int rc = check_layout(p, img_w, img_h, g, tcols, trows);
-    if (rc != GRK_AMD_OK) return rc;
-    const uint32_t ntiles = tcols * trows;
-    if (flags & GRK_AMD_CS_TLM) { if (ntiles > 255) return GRK_AMD_ERR_UNSUPPORTED; if (!tile_part_bytes) return GRK_AMD_ERR_INVALID; }
-    Out o{out, cap};
-    uint64_t tlm_at = 0;
-    write_main_header(o, g, img_w, img_h, flags, ntiles, &tlm_at);
-    for (uint32_t t = 0; tlm_at && t < ntiles; ++t) o.patch32(tlm_at + 5ull * t + 1, tile_part_bytes[t]);
-    if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
-    return (int64_t)o.n;
+    const grk_amd_image_layout im = plain_layout(*p, img_w, img_h);
+    return grk_amd_write_main_header_layout(&im, p, flags, tile_part_bytes, out, cap);
 }
 
 extern "C" int64_t grk_amd_write_tile_part(const grk_amd_tile_params* p, uint32_t tile_index, uint32_t flags,

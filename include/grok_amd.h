@@ -48,7 +48,7 @@ typedef struct grk_amd_ctx grk_amd_ctx;      /* one per process per GPU */
 
 /* What the hot path needs out of grk_cparameters / grk_image (grok.h:451-573, :866-929). */
 typedef struct grk_amd_tile_params {
-    uint32_t tile_w, tile_h;     /* tile-component size (dx=dy=1, tile origin on an even grid) */
+    uint32_t tile_w, tile_h;     /* tile-component size (dx=dy=1)                                 */
     uint16_t num_comps;          /* 1..4 ; MCT needs >=3                                        */
     uint8_t  prec;               /* bits per sample, 1..16                                      */
     uint8_t  sgnd;               /* signed samples (DC shift 0)                                 */
@@ -63,6 +63,10 @@ typedef struct grk_amd_tile_params {
                                     [1]: Part-1 decode -- the COD code-block style bits as the reference
                                     names them (grok.h GRK_CBLKSTY_*): LAZY 0x01, RESET 0x02, TERMALL 0x04,
                                     VSC 0x08, PTERM 0x10, SEGSYM 0x20                                 */
+    uint32_t tile_x0, tile_y0;   /* the tile's origin on the canonical grid (grk_image x0/y0, tile grid: the tile's x0/y0 as
+                                    TileProcessor::init computes it).  0, 0 for an image at the origin with one tile; any
+                                    other value changes the sub-band sizes, the code-block partition and, where a
+                                    resolution starts on an odd coordinate, the lifting variant (WaveletFwd.cpp:884-905) */
 } grk_amd_tile_params;
 
 /* One code-block of the tile, in the reference's enumeration order
@@ -107,7 +111,7 @@ uint32_t grk_amd_plane_stride(const grk_amd_tile_params* p);
 uint64_t grk_amd_plane_elems(const grk_amd_tile_params* p);
 
 /* ---- whole hot path -------------------------------------------------------------------------
- * Encode `num_tiles` equally sized tiles in one batch.  `pixels` holds the tiles back to back,
+ * Encode `num_tiles` tiles of one geometry (grk_amd_same_tile_geometry; the batch is coded with *p) in one batch.  `pixels` holds the tiles back to back,
  * each tile component-major planar, row-major, tightly packed, ceil(prec/8) bytes per sample,
  * host endian -- the layout grk_compress_tile() takes (TileProcessor.cpp:1177-1213).
  * pixels_on_device != 0: `pixels` is a device pointer (HBM-resident input, what bench.py times).
@@ -248,6 +252,35 @@ double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
 int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
                                  const grk_amd_coded_block* table, const uint8_t* coded,
                                  uint8_t* out, uint64_t cap);
+
+/* ---- images of any tile layout (tiles / images off the origin, ragged edge tiles) ----------------------------------
+ * What SIZ says about the image (ISO 15444-1 B.2, B.3; grok.h grk_image x0..y1, grk_cparameters tx0 ty0 t_width t_height):
+ * the image area [x0, x1) x [y0, y1) on the canonical grid and the tile grid anchored at (tx0, ty0) <= (x0, y0).  Tile t
+ * (raster order) is its grid cell clipped to the image area (tile/TileProcessor.cpp:100-170). */
+typedef struct grk_amd_image_layout {
+    uint32_t x0, y0, x1, y1;
+    uint32_t tx0, ty0, t_width, t_height;
+} grk_amd_image_layout;
+int64_t grk_amd_layout_num_tiles(const grk_amd_image_layout* im);
+/* *out = *base with tile_w / tile_h / tile_x0 / tile_y0 of tile `tile_index` */
+int grk_amd_layout_tile(const grk_amd_image_layout* im, const grk_amd_tile_params* base, uint32_t tile_index,
+                        grk_amd_tile_params* out);
+/* 1 when two tiles can share one grk_amd_encode_tiles / grk_amd_decode_tiles batch: same sub-band and code-block partition,
+ * same lifting variant at every level (0: they cannot, < 0: error) */
+int grk_amd_same_tile_geometry(const grk_amd_tile_params* a, const grk_amd_tile_params* b);
+/* The codestream of such an image: table = the tiles' rows one tile after the other, tile t having the
+ * grk_amd_tile_num_blocks() rows of ITS parameters (grk_amd_layout_tile).  grk_amd_write_codestream(_ex) is this with the
+ * layout {origin of p, img_w x img_h, tiles of p->tile_w x p->tile_h}. */
+int64_t grk_amd_write_codestream_layout(const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                        const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
+                                        uint8_t* out, uint64_t cap);
+int64_t grk_amd_write_main_header_layout(const grk_amd_image_layout* im, const grk_amd_tile_params* base, uint32_t flags,
+                                         const uint32_t* tile_part_bytes, uint8_t* out, uint64_t cap);
+/* Whole image -> codestream: `pixels` (host) is the image area, component-major planar, row-major, tight, ceil(prec/8)
+ * bytes per sample.  Tiles are grouped by geometry and every group is coded as one grk_amd_encode_tiles batch (one group
+ * for an image at the origin whose tile size is a multiple of 2^levels x the code-block size); returns the length. */
+int64_t grk_amd_encode_image(grk_amd_ctx* ctx, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                             const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap);
 
 /* The same with the optional pointer marker segments of the reference's encoder (grk_compress -L / -X, grok.h
  * grk_cparameters::writePLT / writeTLM; codestream/markers/LengthMarkers.cpp): TLM in the main header (one-byte tile index +

@@ -259,16 +259,48 @@ static void idwt97_line(float* x, size_t stride, uint32_t n, float* t)
     for (uint32_t i = 0; i < n; ++i) x[(size_t)i * stride] = t[i];
 }
 static uint32_t cdiv2n(uint32_t v, uint32_t n) { return (uint32_t)(((uint64_t)v + (1ull << n) - 1) >> n); }
-void orc_dwt97_inv(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+static uint32_t mirror97(int32_t i, uint32_t n)
+{
+    if (n == 1) return 0;
+    const int32_t p = 2 * ((int32_t)n - 1);
+    i %= p; if (i < 0) i += p;
+    return (uint32_t)(i < (int32_t)n ? i : p - i);
+}
+/* the same line whose first sample lies on an ODD canonical coordinate (WaveletReverse.cpp:1011-1062 with a = 1, b = 0):
+ * whole-sample symmetric extension written as index mirroring -- at an edge (l + l) * c, which is the reference's
+ * nbr * (c + c) to the bit (both are the once-rounded product 2 * nbr * c) */
+static void idwt97_line_odd(float* x, size_t stride, uint32_t n, float* t)
+{
+    if (n == 1) return;
+    const uint32_t sn = n >> 1, dn = n - sn;                /* lows sit on the odd INDICES now */
+    const float K = 1.230174105f, twice_invK = 1.625732422f;
+    const float cs[4] = {-0.443506852f, -0.882911075f, 0.052980118f, 1.586134342f};
+    for (uint32_t i = 0; i < sn; ++i) t[2 * i + 1] = x[(size_t)i * stride] * K;
+    for (uint32_t i = 0; i < dn; ++i) t[2 * i] = x[(size_t)(sn + i) * stride] * twice_invK;
+    for (int s = 0; s < 4; ++s) {
+        const float c = cs[s];
+        for (uint32_t k = (s & 1) ? 0u : 1u; k < n; k += 2) {    /* delta, beta: the low samples; gamma, alpha: the high ones */
+            const float l = t[mirror97((int32_t)k - 1, n)], r = t[mirror97((int32_t)k + 1, n)];
+            t[k] = t[k] + ((l + r) * c);
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i) x[(size_t)i * stride] = t[i];
+}
+void orc_dwt97_inv_at(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0)
 {
     uint32_t m = (w > h ? w : h) + 4;
     float* t = (float*)malloc(m * sizeof(float));
     for (int32_t l = (int32_t)levels - 1; l >= 0; --l) {
-        const uint32_t cw = cdiv2n(w, (uint32_t)l), ch = cdiv2n(h, (uint32_t)l);
-        for (uint32_t y = 0; y < ch; ++y) idwt97_line(plane + (size_t)y * stride, 1, cw, t);
-        for (uint32_t x = 0; x < cw; ++x) idwt97_line(plane + x, stride, ch, t);
+        const uint32_t lx = cdiv2n(x0, (uint32_t)l), ly = cdiv2n(y0, (uint32_t)l);
+        const uint32_t cw = cdiv2n(x0 + w, (uint32_t)l) - lx, ch = cdiv2n(y0 + h, (uint32_t)l) - ly;
+        for (uint32_t y = 0; y < ch; ++y) { if (lx & 1u) idwt97_line_odd(plane + (size_t)y * stride, 1, cw, t); else idwt97_line(plane + (size_t)y * stride, 1, cw, t); }
+        for (uint32_t x = 0; x < cw; ++x) { if (ly & 1u) idwt97_line_odd(plane + x, stride, ch, t); else idwt97_line(plane + x, stride, ch, t); }
     }
     free(t);
+}
+void orc_dwt97_inv(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{
+    orc_dwt97_inv_at(plane, w, h, stride, levels, 0, 0);
 }
 
 /* ---- a17: inverse colour transforms + DC shift + clamp ------------------------------------------- */

@@ -77,44 +77,53 @@ static inline uint32_t mirror(int32_t i, uint32_t n)
     return (uint32_t)(i < (int32_t)n ? i : p - i);
 }
 
+/* par = parity of the first sample's canonical coordinate (tiles / images on odd origins: WaveletFwd.cpp:884-905 rows,
+ * :782-842 columns): the samples on ODD coordinates are predicted, the ones on even coordinates updated, whatever index
+ * they have; a single sample is left alone when it is a low one and doubled when it is a high one (:885-887, :812-815) */
 static void dwt53_line(const int32_t* in, size_t istride, int32_t* out, size_t ostride, uint32_t n,
-                       int32_t* tmp)
+                       int32_t* tmp, uint32_t par)
 {
-    if (n == 1) { out[0] = in[0]; return; }
-    uint32_t sn = (n + 1) >> 1, dn = n - sn;
+    if (n == 1) { out[0] = par ? in[0] * 2 : in[0]; return; }
+    uint32_t sn = (n + 1 - par) >> 1, dn = n - sn;
     for (uint32_t k = 0; k < n; ++k) tmp[k] = in[k * istride];
-    /* predict: odd samples */
-    for (uint32_t k = 1; k < n; k += 2)
-        tmp[k] -= (tmp[k - 1] + tmp[mirror((int32_t)k + 1, n)]) >> 1;
-    /* update: even samples */
-    for (uint32_t k = 0; k < n; k += 2)
+    /* predict: samples on odd coordinates */
+    for (uint32_t k = 1 - par; k < n; k += 2)
+        tmp[k] -= (tmp[mirror((int32_t)k - 1, n)] + tmp[mirror((int32_t)k + 1, n)]) >> 1;
+    /* update: samples on even coordinates */
+    for (uint32_t k = par; k < n; k += 2)
         tmp[k] += (tmp[mirror((int32_t)k - 1, n)] + tmp[mirror((int32_t)k + 1, n)] + 2) >> 2;
-    for (uint32_t i = 0; i < sn; ++i) out[i * ostride] = tmp[2 * i];
-    for (uint32_t i = 0; i < dn; ++i) out[(sn + i) * ostride] = tmp[2 * i + 1];
+    for (uint32_t i = 0; i < sn; ++i) out[i * ostride] = tmp[2 * i + par];
+    for (uint32_t i = 0; i < dn; ++i) out[(sn + i) * ostride] = tmp[2 * i + 1 - par];
 }
 
 void orc_dwt53_fwd_1d(int32_t* x, uint32_t n)
 {
     int32_t* tmp = (int32_t*)malloc((n + 1) * sizeof(int32_t));
-    dwt53_line(x, 1, x, 1, n, tmp);
+    dwt53_line(x, 1, x, 1, n, tmp, 0);
+    free(tmp);
+}
+void orc_dwt53_fwd_1d_par(int32_t* x, uint32_t n, uint32_t par)
+{
+    int32_t* tmp = (int32_t*)malloc((n + 1) * sizeof(int32_t));
+    dwt53_line(x, 1, x, 1, n, tmp, par);
     free(tmp);
 }
 
 /* a7 9/7 lifting: four sweeps + scaling; (a+b)*c with three separate fp32 roundings
  * (WaveletFwd.cpp:134-214). */
 static void dwt97_line(const float* in, size_t istride, float* out, size_t ostride, uint32_t n,
-                       float* w)
+                       float* w, uint32_t par)
 {
     static const float alpha = -1.586134342f, beta = -0.052980118f;
     static const float gamma_ = 0.882911075f, delta = 0.443506852f;
     static const float K = 1.230174105f;
     const float invK = (float)(1.0 / 1.230174105);
-    if (n == 1) { out[0] = in[0]; return; }
-    uint32_t sn = (n + 1) >> 1, dn = n - sn;
+    if (n == 1) { out[0] = in[0]; return; }      /* either parity (WaveletFwd.cpp:924-926, :985-987) */
+    uint32_t sn = (n + 1 - par) >> 1, dn = n - sn;
     for (uint32_t k = 0; k < n; ++k) w[k] = in[k * istride];
     const float c[4] = {alpha, beta, gamma_, delta};
     for (int s = 0; s < 4; ++s) {
-        uint32_t first = (s & 1) ? 0u : 1u;      /* alpha,gamma: odd ; beta,delta: even */
+        uint32_t first = (s & 1) ? par : 1u - par;      /* alpha,gamma: odd coordinates ; beta,delta: even */
         for (uint32_t k = first; k < n; k += 2) {
             float l = w[mirror((int32_t)k - 1, n)], r = w[mirror((int32_t)k + 1, n)];
             float sum = l + r;
@@ -122,14 +131,20 @@ static void dwt97_line(const float* in, size_t istride, float* out, size_t ostri
             w[k] = w[k] + prod;
         }
     }
-    for (uint32_t i = 0; i < sn; ++i) out[i * ostride] = w[2 * i] * invK;
-    for (uint32_t i = 0; i < dn; ++i) out[(sn + i) * ostride] = w[2 * i + 1] * K;
+    for (uint32_t i = 0; i < sn; ++i) out[i * ostride] = w[2 * i + par] * invK;
+    for (uint32_t i = 0; i < dn; ++i) out[(sn + i) * ostride] = w[2 * i + 1 - par] * K;
 }
 
 void orc_dwt97_fwd_1d(float* x, uint32_t n)
 {
     float* tmp = (float*)malloc((n + 1) * sizeof(float));
-    dwt97_line(x, 1, x, 1, n, tmp);
+    dwt97_line(x, 1, x, 1, n, tmp, 0);
+    free(tmp);
+}
+void orc_dwt97_fwd_1d_par(float* x, uint32_t n, uint32_t par)
+{
+    float* tmp = (float*)malloc((n + 1) * sizeof(float));
+    dwt97_line(x, 1, x, 1, n, tmp, par);
     free(tmp);
 }
 
@@ -137,52 +152,68 @@ static uint32_t cdivp2(uint32_t v, uint32_t n) { return (uint32_t)(((uint64_t)v 
 
 /* a5: level loop -- vertical pass over every column, then horizontal over every row
  * (WaveletFwd.cpp:491-602). */
-void orc_dwt53_fwd(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+/* (x0, y0): the tile-component's origin on the canonical grid; level l works on [ceil(x0 / 2^l), ceil((x0 + w) / 2^l)) */
+void orc_dwt53_fwd_at(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0)
 {
     uint32_t m = (w > h ? w : h) + 2;
     int32_t* tmp = (int32_t*)malloc(m * sizeof(int32_t));
     for (uint32_t l = 0; l < levels; ++l) {
-        uint32_t cw = cdivp2(w, l), ch = cdivp2(h, l);
-        for (uint32_t x = 0; x < cw; ++x) dwt53_line(plane + x, stride, plane + x, stride, ch, tmp);
-        for (uint32_t y = 0; y < ch; ++y) dwt53_line(plane + (size_t)y * stride, 1, plane + (size_t)y * stride, 1, cw, tmp);
+        const uint32_t lx = cdivp2(x0, l), ly = cdivp2(y0, l);
+        const uint32_t cw = cdivp2(x0 + w, l) - lx, ch = cdivp2(y0 + h, l) - ly;
+        for (uint32_t x = 0; x < cw; ++x) dwt53_line(plane + x, stride, plane + x, stride, ch, tmp, ly & 1u);
+        for (uint32_t y = 0; y < ch; ++y) dwt53_line(plane + (size_t)y * stride, 1, plane + (size_t)y * stride, 1, cw, tmp, lx & 1u);
+    }
+    free(tmp);
+}
+void orc_dwt53_fwd(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{
+    orc_dwt53_fwd_at(plane, w, h, stride, levels, 0, 0);
+}
+void orc_dwt97_fwd_at(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0)
+{
+    uint32_t m = (w > h ? w : h) + 2;
+    float* tmp = (float*)malloc(m * sizeof(float));
+    for (uint32_t l = 0; l < levels; ++l) {
+        const uint32_t lx = cdivp2(x0, l), ly = cdivp2(y0, l);
+        const uint32_t cw = cdivp2(x0 + w, l) - lx, ch = cdivp2(y0 + h, l) - ly;
+        for (uint32_t x = 0; x < cw; ++x) dwt97_line(plane + x, stride, plane + x, stride, ch, tmp, ly & 1u);
+        for (uint32_t y = 0; y < ch; ++y) dwt97_line(plane + (size_t)y * stride, 1, plane + (size_t)y * stride, 1, cw, tmp, lx & 1u);
     }
     free(tmp);
 }
 void orc_dwt97_fwd(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
 {
-    uint32_t m = (w > h ? w : h) + 2;
-    float* tmp = (float*)malloc(m * sizeof(float));
-    for (uint32_t l = 0; l < levels; ++l) {
-        uint32_t cw = cdivp2(w, l), ch = cdivp2(h, l);
-        for (uint32_t x = 0; x < cw; ++x) dwt97_line(plane + x, stride, plane + x, stride, ch, tmp);
-        for (uint32_t y = 0; y < ch; ++y) dwt97_line(plane + (size_t)y * stride, 1, plane + (size_t)y * stride, 1, cw, tmp);
-    }
-    free(tmp);
+    orc_dwt97_fwd_at(plane, w, h, stride, levels, 0, 0);
 }
 
 /* inverse 5/3 (for round-trip property tests): horizontal then vertical per level, low->high */
-static void idwt53_line(int32_t* io, size_t st, uint32_t n, int32_t* tmp)
+static void idwt53_line(int32_t* io, size_t st, uint32_t n, int32_t* tmp, uint32_t par)
 {
-    if (n == 1) return;
-    uint32_t sn = (n + 1) >> 1, dn = n - sn;
-    for (uint32_t i = 0; i < sn; ++i) tmp[2 * i] = io[i * st];
-    for (uint32_t i = 0; i < dn; ++i) tmp[2 * i + 1] = io[(sn + i) * st];
-    for (uint32_t k = 0; k < n; k += 2)
+    if (n == 1) { if (par) io[0] /= 2; return; }        /* a lone high sample was doubled (WaveletReverse.cpp:466-468) */
+    uint32_t sn = (n + 1 - par) >> 1, dn = n - sn;
+    for (uint32_t i = 0; i < sn; ++i) tmp[2 * i + par] = io[i * st];
+    for (uint32_t i = 0; i < dn; ++i) tmp[2 * i + 1 - par] = io[(sn + i) * st];
+    for (uint32_t k = par; k < n; k += 2)
         tmp[k] -= (tmp[mirror((int32_t)k - 1, n)] + tmp[mirror((int32_t)k + 1, n)] + 2) >> 2;
-    for (uint32_t k = 1; k < n; k += 2)
-        tmp[k] += (tmp[k - 1] + tmp[mirror((int32_t)k + 1, n)]) >> 1;
+    for (uint32_t k = 1 - par; k < n; k += 2)
+        tmp[k] += (tmp[mirror((int32_t)k - 1, n)] + tmp[mirror((int32_t)k + 1, n)]) >> 1;
     for (uint32_t k = 0; k < n; ++k) io[k * st] = tmp[k];
 }
-void orc_dwt53_inv(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+void orc_dwt53_inv_at(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0)
 {
     uint32_t m = (w > h ? w : h) + 2;
     int32_t* tmp = (int32_t*)malloc(m * sizeof(int32_t));
     for (int32_t l = (int32_t)levels - 1; l >= 0; --l) {
-        uint32_t cw = cdivp2(w, (uint32_t)l), ch = cdivp2(h, (uint32_t)l);
-        for (uint32_t y = 0; y < ch; ++y) idwt53_line(plane + (size_t)y * stride, 1, cw, tmp);
-        for (uint32_t x = 0; x < cw; ++x) idwt53_line(plane + x, stride, ch, tmp);
+        const uint32_t lx = cdivp2(x0, (uint32_t)l), ly = cdivp2(y0, (uint32_t)l);
+        const uint32_t cw = cdivp2(x0 + w, (uint32_t)l) - lx, ch = cdivp2(y0 + h, (uint32_t)l) - ly;
+        for (uint32_t y = 0; y < ch; ++y) idwt53_line(plane + (size_t)y * stride, 1, cw, tmp, lx & 1u);
+        for (uint32_t x = 0; x < cw; ++x) idwt53_line(plane + x, stride, ch, tmp, ly & 1u);
     }
     free(tmp);
+}
+void orc_dwt53_inv(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
+{
+    orc_dwt53_inv_at(plane, w, h, stride, levels, 0, 0);
 }
 
 /* ------------------------------------------------------------------ a8 exponents / step sizes */
@@ -254,39 +285,56 @@ void orc_ht_irrev_stepsizes(uint32_t prec, uint32_t levels, uint16_t* spqcd, flo
 }
 
 /* ------------------------------------------------------------------ a9 block enumeration */
-uint32_t orc_enumerate_blocks(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp,
-                              const uint8_t* expn, orc_block* out, uint32_t cap)
+/* band b of resolution r covers [ceil((v - 2^(n-1) bx) / 2^n)) per coordinate, n = levels - r + 1 (util/util.cpp:49-58,
+ * tile/TileComponent.cpp:131-138); its code-blocks are the cells of the 2^cblk_exp grid ANCHORED AT THE ORIGIN OF THE BAND'S
+ * COORDINATES that it touches (t1/T1Structs.cpp:118-136), so a band that starts off the grid begins with a partial block */
+static uint32_t band_lo(uint32_t v, uint32_t n, uint32_t hi)
+{
+    if (n == 0) return v;
+    const uint64_t off = hi ? (1ull << (n - 1)) : 0;
+    return v <= off ? 0u : (uint32_t)(((uint64_t)v - off + (1ull << n) - 1) >> n);
+}
+uint32_t orc_enumerate_blocks_at(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp, uint32_t x0, uint32_t y0,
+                                 const uint8_t* expn, orc_block* out, uint32_t cap)
 {
     uint32_t n = 0;
     const uint32_t cb = 1u << cblk_exp;
     for (uint32_t r = 0; r <= levels; ++r) {
-        uint32_t rw = cdivp2(w, levels - r), rh = cdivp2(h, levels - r);
-        uint32_t lw = r ? cdivp2(w, levels - r + 1) : 0, lh = r ? cdivp2(h, levels - r + 1) : 0;
+        const uint32_t nn = r ? levels - r + 1 : levels;                 /* decomposition the band belongs to */
+        const uint32_t lw = r ? cdivp2(x0 + w, nn) - cdivp2(x0, nn) : 0, lh = r ? cdivp2(y0 + h, nn) - cdivp2(y0, nn) : 0;
         uint32_t nb = r ? 3 : 1;
         for (uint32_t bi = 0; bi < nb; ++bi) {
             uint32_t orient = r ? bi + 1 : 0;
-            uint32_t bw = r ? ((orient & 1) ? rw - lw : lw) : rw;
-            uint32_t bh = r ? ((orient & 2) ? rh - lh : lh) : rh;
+            const uint32_t bx0 = band_lo(x0, nn, orient & 1), bx1 = band_lo(x0 + w, nn, orient & 1);
+            const uint32_t by0 = band_lo(y0, nn, orient >> 1), by1 = band_lo(y0 + h, nn, orient >> 1);
+            const uint32_t bw = bx1 - bx0, bh = by1 - by0;
             uint32_t ox = (orient & 1) ? lw : 0, oy = (orient & 2) ? lh : 0;
             uint32_t qcd_idx = r ? 3 * (r - 1) + 1 + bi : 0;
             if (bw == 0 || bh == 0) continue;
-            uint32_t gx = (bw + cb - 1) >> cblk_exp, gy = (bh + cb - 1) >> cblk_exp;
-            for (uint32_t by = 0; by < gy; ++by)
-                for (uint32_t bx = 0; bx < gx; ++bx) {
+            const uint32_t gx0 = bx0 >> cblk_exp, gx1 = (bx1 + cb - 1) >> cblk_exp;
+            const uint32_t gy0 = by0 >> cblk_exp, gy1 = (by1 + cb - 1) >> cblk_exp;
+            for (uint32_t gy = gy0; gy < gy1; ++gy)
+                for (uint32_t gx = gx0; gx < gx1; ++gx) {
                     if (n < cap) {
                         orc_block* b = &out[n];
-                        b->x = ox + bx * cb; b->y = oy + by * cb;
-                        b->w = (bx + 1) * cb <= bw ? cb : bw - bx * cb;
-                        b->h = (by + 1) * cb <= bh ? cb : bh - by * cb;
+                        const uint32_t cx0 = gx * cb > bx0 ? gx * cb : bx0, cx1 = (gx + 1) * cb < bx1 ? (gx + 1) * cb : bx1;
+                        const uint32_t cy0 = gy * cb > by0 ? gy * cb : by0, cy1 = (gy + 1) * cb < by1 ? (gy + 1) * cb : by1;
+                        b->x = ox + (cx0 - bx0); b->y = oy + (cy0 - by0);
+                        b->w = cx1 - cx0; b->h = cy1 - cy0;
                         b->res = (uint8_t)r; b->band = (uint8_t)orient;
                         b->kmax = expn ? expn[qcd_idx] : 0; b->pad = 0;
-                        b->bx = bx; b->by = by;
+                        b->bx = gx - gx0; b->by = gy - gy0;
                     }
                     ++n;
                 }
         }
     }
     return n;
+}
+uint32_t orc_enumerate_blocks(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp,
+                              const uint8_t* expn, orc_block* out, uint32_t cap)
+{
+    return orc_enumerate_blocks_at(w, h, levels, cblk_exp, 0, 0, expn, out, cap);
 }
 
 /* ------------------------------------------------------------------ a10 sign-magnitude */
@@ -581,10 +629,22 @@ int32_t orc_ht_encode_block_rev(const int32_t* src, uint32_t stride, uint32_t w,
 /* ------------------------------------------------------------------ whole tile, reversible */
 static uint32_t stride_for(uint32_t w) { return (w + 31) & ~31u; }     /* util/MemManager.cpp:38-43 */
 
+int32_t orc_encode_tile_rev_at(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
+                               uint32_t prec, uint32_t levels, int mct, uint32_t x0, uint32_t y0, orc_block* blocks_out,
+                               uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
+                               uint64_t* total_bytes);
 int32_t orc_encode_tile_rev(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
                             uint32_t prec, uint32_t levels, int mct, orc_block* blocks_out,
                             uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
                             uint64_t* total_bytes)
+{
+    return orc_encode_tile_rev_at(pixels, bps, ncomp, w, h, prec, levels, mct, 0, 0, blocks_out, lens, max_blocks, coded, cap,
+                                  total_bytes);
+}
+int32_t orc_encode_tile_rev_at(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
+                               uint32_t prec, uint32_t levels, int mct, uint32_t x0, uint32_t y0, orc_block* blocks_out,
+                               uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
+                               uint64_t* total_bytes)
 {
     uint32_t stride = stride_for(w);
     size_t plane_n = (size_t)stride * h;
@@ -595,13 +655,13 @@ int32_t orc_encode_tile_rev(const void* pixels, int bps, uint32_t ncomp, uint32_
         orc_ingest((const uint8_t*)pixels + (size_t)c * w * h * bps, bps, planes + c * plane_n, w, h, stride,
                    1 << (prec - 1));
     if (mct && ncomp >= 3) orc_rct_fwd(planes, planes + plane_n, planes + 2 * plane_n, plane_n);
-    for (uint32_t c = 0; c < ncomp; ++c) orc_dwt53_fwd(planes + c * plane_n, w, h, stride, levels);
+    for (uint32_t c = 0; c < ncomp; ++c) orc_dwt53_fwd_at(planes + c * plane_n, w, h, stride, levels, x0, y0);
     orc_ht_rev_exponents(prec, levels, expn);
-    uint32_t nb = orc_enumerate_blocks(w, h, levels, 6, expn, NULL, 0);
+    uint32_t nb = orc_enumerate_blocks_at(w, h, levels, 6, x0, y0, expn, NULL, 0);
     if (nb * ncomp > max_blocks) { free(planes); return -2; }
     uint64_t off = 0; uint32_t k = 0;
     for (uint32_t c = 0; c < ncomp; ++c) {
-        orc_enumerate_blocks(w, h, levels, 6, expn, blocks_out + k, nb);
+        orc_enumerate_blocks_at(w, h, levels, 6, x0, y0, expn, blocks_out + k, nb);
         for (uint32_t i = 0; i < nb; ++i, ++k) {
             orc_block* b = &blocks_out[k];
             b->pad = (uint8_t)c;

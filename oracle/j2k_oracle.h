@@ -83,6 +83,20 @@ int32_t orc_encode_tile_rev(const void* pixels, int bytes_per_sample, uint32_t n
  *           words `sign<<31 | (2*mu+1) << (29-missing_msbs)`, row stride `stride`.  0 ok, -1 bad stream. */
 int32_t orc_ht_decode_block(const uint8_t* coded, uint32_t len, uint32_t missing_msbs,
                             uint32_t w, uint32_t h, uint32_t* out, uint32_t stride);
+/* ---- tiles / images on odd origins (SURVEY.md Appendix A.3 "odd-start variant"; WaveletFwd.cpp:884-905, :812-815,
+ *      band coordinates util/util.cpp:49-58): the same functions with the tile-component's origin (x0, y0) on the
+ *      canonical grid -- the parity of ceil(origin / 2^l) decides at every level which samples are predicted / updated */
+void orc_dwt53_fwd_1d_par(int32_t* x, uint32_t n, uint32_t par);
+void orc_dwt97_fwd_1d_par(float* x, uint32_t n, uint32_t par);
+void orc_dwt53_fwd_at(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0);
+void orc_dwt97_fwd_at(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0);
+void orc_dwt53_inv_at(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0);
+void orc_dwt97_inv_at(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0);
+uint32_t orc_enumerate_blocks_at(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp, uint32_t x0, uint32_t y0,
+                                 const uint8_t* expn, orc_block* out, uint32_t cap);
+int32_t orc_encode_tile_rev_at(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
+                               uint32_t prec, uint32_t levels, int mct, uint32_t x0, uint32_t y0, orc_block* blocks_out,
+                               uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap, uint64_t* total_bytes);
 /* ---- N3: the HT refinement passes (SigProp, MagRef) on top of the cleanup pass's output -- oracle/ht_refine_oracle.c
  *           (t1/t1_ht/coding/ojph_block_decoder.cpp:1627-2100; bit readers :466-550, :875-945) and an encoder of them
  *           that makes the test vectors (Grok's encoder never emits the passes) */

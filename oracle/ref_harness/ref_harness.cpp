@@ -66,32 +66,36 @@ void ref_ict(int32_t* c0, int32_t* c1, int32_t* c2, uint64_t n) { mct_staged(c0,
 
 } // extern "C"
 template <typename T, typename DWT>
-static void fwd_levels(T* user, uint32_t w, uint32_t h, uint32_t ustride, uint32_t levels)
+static void fwd_levels(T* user, uint32_t w, uint32_t h, uint32_t ustride, uint32_t levels, uint32_t x0 = 0, uint32_t y0 = 0)
 {
 	// aligned staging plane with the reference's own stride rule (util/MemManager.cpp:38-43)
 	uint32_t stride = (w + 31u) & ~31u;
 	T* plane = (T*)grkAlignedMalloc(((size_t)stride * h + 64) * sizeof(T));
 	for (uint32_t y = 0; y < h; ++y) memcpy(plane + (size_t)y * stride, user + (size_t)y * ustride, w * sizeof(T));
-	// resolution sizes for an origin-0 tile component: ceil(w / 2^l)
-	std::vector<uint32_t> rw(levels + 1), rh(levels + 1);
+	// resolution windows of a tile component at (x0, y0): [ceil(x0 / 2^l), ceil((x0 + w) / 2^l)); the parity of the
+	// window's origin is what WaveletFwdImpl::encode_procedure passes as `even` (WaveletFwd.cpp:478-604)
+	std::vector<uint32_t> rw(levels + 1), rh(levels + 1), ox(levels + 1), oy(levels + 1);
 	for (uint32_t l = 0; l <= levels; ++l) {
-		rw[l] = (uint32_t)(((uint64_t)w + (1ull << l) - 1) >> l);
-		rh[l] = (uint32_t)(((uint64_t)h + (1ull << l) - 1) >> l);
+		ox[l] = (uint32_t)(((uint64_t)x0 + (1ull << l) - 1) >> l);
+		oy[l] = (uint32_t)(((uint64_t)y0 + (1ull << l) - 1) >> l);
+		rw[l] = (uint32_t)(((uint64_t)x0 + w + (1ull << l) - 1) >> l) - ox[l];
+		rh[l] = (uint32_t)(((uint64_t)y0 + h + (1ull << l) - 1) >> l) - oy[l];
 	}
 	size_t tmpn = (size_t)std::max(w, h) * 8 + 64;
 	T* tmp = (T*)grkAlignedMalloc(tmpn * sizeof(T));
 	DWT dwt;
 	for (uint32_t l = 0; l < levels; ++l) {
 		uint32_t cw = rw[l], ch = rh[l];
+		const bool even_x = (ox[l] & 1u) == 0, even_y = (oy[l] & 1u) == 0;
 		// vertical pass, 8 columns at a time (WaveletFwd.cpp:491-507)
 		uint32_t j = 0;
 		for (; j + 8 - 1 < cw; j += 8)
-			dwt.encode_and_deinterleave_v(plane + j, tmp, ch, true, stride, 8);
+			dwt.encode_and_deinterleave_v(plane + j, tmp, ch, even_y, stride, 8);
 		if (j < cw)
-			dwt.encode_and_deinterleave_v(plane + j, tmp, ch, true, stride, cw - j);
+			dwt.encode_and_deinterleave_v(plane + j, tmp, ch, even_y, stride, cw - j);
 		// horizontal pass (WaveletFwd.cpp:553-561)
 		for (uint32_t r = 0; r < ch; ++r)
-			dwt.encode_and_deinterleave_h_one_row(plane + (size_t)r * stride, tmp, cw, true);
+			dwt.encode_and_deinterleave_h_one_row(plane + (size_t)r * stride, tmp, cw, even_x);
 	}
 	grkAlignedFree(tmp);
 	for (uint32_t y = 0; y < h; ++y) memcpy(user + (size_t)y * ustride, plane + (size_t)y * stride, w * sizeof(T));
@@ -103,6 +107,10 @@ void ref_dwt53_fwd(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint
 { fwd_levels<int32_t, dwt53>(plane, w, h, stride, levels); }
 void ref_dwt97_fwd(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels)
 { fwd_levels<float, dwt97>(plane, w, h, stride, levels); }
+void ref_dwt53_fwd_at(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0)
+{ fwd_levels<int32_t, dwt53>(plane, w, h, stride, levels, x0, y0); }
+void ref_dwt97_fwd_at(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32_t levels, uint32_t x0, uint32_t y0)
+{ fwd_levels<float, dwt97>(plane, w, h, stride, levels, x0, y0); }
 
 void ref_dwt53_row(int32_t* row, uint32_t n, int even)
 {
@@ -190,19 +198,24 @@ static void fill_params(grk_cparameters& p, const EncCfg& c)
 	// grk_compress -X / -L: pointer marker segments (TLM in the main header, PLT in the tile-part headers)
 	if (const char* e = getenv("REF_WRITE_TLM")) p.writeTLM = atoi(e) != 0;
 	if (const char* e = getenv("REF_WRITE_PLT")) p.writePLT = atoi(e) != 0;
+	// grk_compress -d: the image area's origin on the canonical grid (the tile grid stays anchored at 0, 0)
+	if (const char* e = getenv("REF_IMG_X0")) p.image_offset_x0 = (uint32_t)atoi(e);
+	if (const char* e = getenv("REF_IMG_Y0")) p.image_offset_y0 = (uint32_t)atoi(e);
 }
 
 static grk_image* make_image(const EncCfg& c, bool alloc)
 {
 	std::vector<grk_image_cmptparm> cp((size_t)c.C);
 	memset(cp.data(), 0, sizeof(grk_image_cmptparm) * cp.size());
+	const uint32_t ix0 = getenv("REF_IMG_X0") ? (uint32_t)atoi(getenv("REF_IMG_X0")) : 0;
+	const uint32_t iy0 = getenv("REF_IMG_Y0") ? (uint32_t)atoi(getenv("REF_IMG_Y0")) : 0;
 	for (auto& q : cp) {
 		q.dx = 1; q.dy = 1; q.w = (uint32_t)c.W; q.h = (uint32_t)c.H;
-		q.x0 = 0; q.y0 = 0; q.prec = (uint8_t)c.prec; q.sgnd = false;
+		q.x0 = ix0; q.y0 = iy0; q.prec = (uint8_t)c.prec; q.sgnd = false;
 	}
 	auto img = grk_image_new((uint16_t)c.C, cp.data(), c.C >= 3 ? GRK_CLRSPC_SRGB : GRK_CLRSPC_GRAY, alloc);
 	if (!img) return nullptr;
-	img->x0 = 0; img->y0 = 0; img->x1 = (uint32_t)c.W; img->y1 = (uint32_t)c.H;
+	img->x0 = ix0; img->y0 = iy0; img->x1 = ix0 + (uint32_t)c.W; img->y1 = iy0 + (uint32_t)c.H;
 	return img;
 }
 

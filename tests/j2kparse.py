@@ -85,8 +85,8 @@ def parse(cs):
         body = cs[pos + 4:pos + 2 + ln]
         if marker == 0xFF51:        # SIZ
             _, xs, ys, xo, yo, xt, yt, xto, yto, nc = struct.unpack(">HIIIIIIIIH", body[:36])
-            info.update(W=xs - xo, H=ys - yo, C=nc, prec=(body[36] & 0x7F) + 1, tw=xt, th=yt)
-            assert xt >= xs and yt >= ys, "single-tile streams only"
+            info.update(W=xs - xo, H=ys - yo, C=nc, prec=(body[36] & 0x7F) + 1, tw=xt, th=yt, x0=xo, y0=yo)
+            assert xto + xt >= xs and yto + yt >= ys, "single-tile streams only"
         elif marker == 0xFF52:      # COD
             scod, prog, layers, mct, levels, cbw, cbh, sty, xf = struct.unpack(">BBHBBBBBB", body[:10])
             assert prog == 0 and layers == 1 and (scod & 1) == 0, "LRCP, 1 layer, default precincts only"
@@ -127,27 +127,31 @@ def parse(cs):
             return out
         return [npass]
 
+    X0, Y0 = info["x0"], info["y0"]
+
     def band_rect(r, b):
+        """(x0, y0, x1, y1) of the band in its own coordinates (B.5: the tile = the image area, anywhere on the grid)."""
         n = L - r + (1 if r > 0 else 0)
         if r == 0:
-            return _cdp2(W, L), _cdp2(H, L)
+            return _cdp2(X0, L), _cdp2(Y0, L), _cdp2(X0 + W, L), _cdp2(Y0 + H, L)
         bx, by = b & 1, b >> 1
-        x0 = _cdp2(max(0 - (1 << (n - 1)) * bx, 0), n)
-        x1 = _cdp2(max(W - (1 << (n - 1)) * bx, 0), n)
-        y1 = _cdp2(max(H - (1 << (n - 1)) * by, 0), n)
-        return x1 - x0, y1   # origins are 0 for tiles at the image origin
+        return (_cdp2(max(X0 - (1 << (n - 1)) * bx, 0), n), _cdp2(max(Y0 - (1 << (n - 1)) * by, 0), n),
+                _cdp2(max(X0 + W - (1 << (n - 1)) * bx, 0), n), _cdp2(max(Y0 + H - (1 << (n - 1)) * by, 0), n))
 
     for r in range(L + 1):
+        if _cdp2(X0 + W, L - r) == _cdp2(X0, L - r) or _cdp2(Y0 + H, L - r) == _cdp2(Y0, L - r):
+            continue              # a resolution without samples has no precinct and no packet
         for c in range(info["C"]):
             bands = [0] if r == 0 else [1, 2, 3]
             br = Bits(cs, pos)
             nonempty = br.bit()
             todo = []
             for b in bands:
-                bw, bh = band_rect(r, b)
-                gw, gh = _cdp2(bw, cexp[0]), _cdp2(bh, cexp[1])
-                if bw == 0 or bh == 0:
+                bx0, by0, bx1, by1 = band_rect(r, b)
+                if bx1 == bx0 or by1 == by0:
                     continue
+                # code-blocks: the cells of the grid anchored at the origin of the band's coordinates that it touches
+                gw, gh = _cdp2(bx1, cexp[0]) - (bx0 >> cexp[0]), _cdp2(by1, cexp[1]) - (by0 >> cexp[1])
                 key = (c, r, b)
                 if key not in state:
                     state[key] = (TagTree(gw, gh), TagTree(gw, gh), {})

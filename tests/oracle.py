@@ -75,6 +75,18 @@ def lib():
         L.orc_t1_dequant_rev.restype = None
         L.orc_t1_dequant_irrev.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
         L.orc_t1_dequant_irrev.restype = None
+        u32 = C.c_uint32
+        for f in ("orc_dwt53_fwd_at", "orc_dwt97_fwd_at", "orc_dwt53_inv_at", "orc_dwt97_inv_at"):
+            getattr(L, f).argtypes = [C.c_void_p] + [u32] * 6
+            getattr(L, f).restype = None
+        for f in ("orc_dwt53_fwd_1d_par", "orc_dwt97_fwd_1d_par"):
+            getattr(L, f).argtypes = [C.c_void_p, u32, u32]
+            getattr(L, f).restype = None
+        L.orc_enumerate_blocks_at.restype = u32
+        L.orc_enumerate_blocks_at.argtypes = [u32] * 6 + [C.c_void_p, C.c_void_p, u32]
+        L.orc_encode_tile_rev_at.restype = C.c_int32
+        L.orc_encode_tile_rev_at.argtypes = [C.c_void_p, C.c_int, u32, u32, u32, u32, u32, C.c_int, u32, u32, C.c_void_p,
+                                             C.c_void_p, u32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -164,10 +176,10 @@ def ht_dequant_irrev(sm, scale):
     return out
 
 
-def dwt97_inv(plane, levels):
+def dwt97_inv(plane, levels, origin=(0, 0)):
     p = np.ascontiguousarray(plane, np.float32).copy()
     h, w = p.shape
-    lib().orc_dwt97_inv(p.ctypes.data, w, h, w, levels)
+    lib().orc_dwt97_inv_at(p.ctypes.data, w, h, w, levels, origin[0], origin[1])
     return p
 
 
@@ -214,34 +226,42 @@ def irrev_stepsizes(prec, levels):
     return q, d
 
 
-def enumerate_blocks(w, h, levels, expn=None, cblk_exp=6):
+def enumerate_blocks(w, h, levels, expn=None, cblk_exp=6, origin=(0, 0)):
     L = lib()
     e = None if expn is None else np.ascontiguousarray(expn, np.uint8)
-    n = L.orc_enumerate_blocks(w, h, levels, cblk_exp, e.ctypes.data if e is not None else None, None, 0)
+    ep = e.ctypes.data if e is not None else None
+    n = L.orc_enumerate_blocks_at(w, h, levels, cblk_exp, origin[0], origin[1], ep, None, 0)
     arr = (Block * n)()
-    L.orc_enumerate_blocks(w, h, levels, cblk_exp, e.ctypes.data if e is not None else None, arr, n)
+    L.orc_enumerate_blocks_at(w, h, levels, cblk_exp, origin[0], origin[1], ep, arr, n)
     return list(arr)
 
 
-def dwt53_fwd(plane, levels):
+def dwt53_fwd(plane, levels, origin=(0, 0)):
     p = np.ascontiguousarray(plane, np.int32).copy()
     h, w = p.shape
-    lib().orc_dwt53_fwd(p.ctypes.data, w, h, w, levels)
+    lib().orc_dwt53_fwd_at(p.ctypes.data, w, h, w, levels, origin[0], origin[1])
     return p
 
 
-def dwt97_fwd(plane, levels):
+def dwt97_fwd(plane, levels, origin=(0, 0)):
     p = np.ascontiguousarray(plane, np.float32).copy()
     h, w = p.shape
-    lib().orc_dwt97_fwd(p.ctypes.data, w, h, w, levels)
+    lib().orc_dwt97_fwd_at(p.ctypes.data, w, h, w, levels, origin[0], origin[1])
     return p
 
 
-def dwt53_inv(plane, levels):
+def dwt53_inv(plane, levels, origin=(0, 0)):
     p = np.ascontiguousarray(plane, np.int32).copy()
     h, w = p.shape
-    lib().orc_dwt53_inv(p.ctypes.data, w, h, w, levels)
+    lib().orc_dwt53_inv_at(p.ctypes.data, w, h, w, levels, origin[0], origin[1])
     return p
+
+
+def dwt_row(row, par, irrev=False):
+    """One line of the forward transform whose first sample lies on a coordinate of parity `par`."""
+    a = np.ascontiguousarray(row, np.float32 if irrev else np.int32).copy()
+    (lib().orc_dwt97_fwd_1d_par if irrev else lib().orc_dwt53_fwd_1d_par)(a.ctypes.data, a.size, par)
+    return a
 
 
 def rct_fwd(r, g, b):
@@ -256,21 +276,21 @@ def ict_fwd(r, g, b):
     return [v.view(np.float32) for v in a]
 
 
-def encode_tile_rev(pixels, prec, levels, mct=None):
+def encode_tile_rev(pixels, prec, levels, mct=None, origin=(0, 0)):
     """pixels (C,H,W) u8/u16 -> (blocks, lens, coded bytes) in reference enumeration order."""
     px = np.ascontiguousarray(pixels)
     Cn, H, W = px.shape
     if mct is None:
         mct = Cn >= 3
     L = lib()
-    nb = L.orc_enumerate_blocks(W, H, levels, 6, None, None, 0) * Cn
+    nb = L.orc_enumerate_blocks_at(W, H, levels, 6, origin[0], origin[1], None, None, 0) * Cn
     blocks = (Block * nb)()
     lens = np.zeros(nb, np.uint32)
     cap = px.size * 4 + nb * 64 + (1 << 16)
     coded = np.zeros(cap, np.uint8)
     tot = C.c_uint64(0)
-    n = L.orc_encode_tile_rev(px.ctypes.data, px.dtype.itemsize, Cn, W, H, prec, levels, int(mct),
-                              blocks, lens.ctypes.data, nb, coded.ctypes.data, cap, C.byref(tot))
+    n = L.orc_encode_tile_rev_at(px.ctypes.data, px.dtype.itemsize, Cn, W, H, prec, levels, int(mct), origin[0], origin[1],
+                                 blocks, lens.ctypes.data, nb, coded.ctypes.data, cap, C.byref(tot))
     assert n == nb, n
     return list(blocks), lens, coded[:tot.value]
 

@@ -47,6 +47,9 @@ def lib(threads=0):
         for f in ("ref_dwt53_row", "ref_dwt97_row"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_uint32, C.c_int]
             getattr(L, f).restype = None
+        for f in ("ref_dwt53_fwd_at", "ref_dwt97_fwd_at"):
+            getattr(L, f).argtypes = [C.c_void_p] + [C.c_uint32] * 6
+            getattr(L, f).restype = None
         L.ref_abi_sizeof.restype = C.c_uint64
         L.ref_abi_sizeof.argtypes = [C.c_int]
         L.ref_init(threads, int(os.environ.get("REF_VERBOSE", "0")))

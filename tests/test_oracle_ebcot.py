@@ -92,7 +92,8 @@ import synth
 def _oracle_decode_stream(cs, part1):
     info = J.parse(cs)
     W, H, Cn, prec, L, irrev = info["W"], info["H"], info["C"], info["prec"], info["levels"], bool(info["irreversible"])
-    p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev, mct=bool(info["mct"]), part1=part1)
+    org = (info["x0"], info["y0"])
+    p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev, mct=bool(info["mct"]), part1=part1, origin=org)
     blocks, _ = G.tile_layout(p)
     rows, data = J.decode_table(info, blocks, part1)
     seglist = J.segment_list(info, blocks)
@@ -116,7 +117,7 @@ def _oracle_decode_stream(cs, part1):
             sm = O.ht_decode_block(data[off:off + ln], extra, bw, bh)
             v = O.ht_dequant_rev(sm, extra)
         mall[b.comp][b.py:b.py + bh, b.px:b.px + bw] = v
-    planes = [O.dwt97_inv(m, L) if irrev else O.dwt53_inv(m, L) for m in mall]
+    planes = [O.dwt97_inv(m, L, origin=org) if irrev else O.dwt53_inv(m, L, origin=org) for m in mall]
     planes = [pl.view(np.int32) if irrev else pl for pl in planes]
     return np.stack(O.color_inv_store(planes, prec, irrev, bool(info["mct"])))
 
@@ -130,6 +131,27 @@ def test_reference_part1_stream_oracle_chain_equals_grk_decompress(C, H, W, prec
     px = synth.g2(C, H, W, prec)
     cs, _ = R.encode(px, prec, numres=numres, mode=1, ht=0, irrev=irrev)
     assert np.array_equal(_oracle_decode_stream(cs, True), R.decode(cs, C, H, W))
+
+
+@pytest.mark.parametrize("off", [(1, 1), (7, 0), (32, 33), (95, 1)])
+@pytest.mark.parametrize("irrev", [0, 1])
+def test_reference_stream_off_the_origin_oracle_chain_equals_grk_decompress(monkeypatch, off, irrev):
+    """An image whose area starts off the origin (grk_compress -d): odd-start synthesis (WaveletReverse.cpp:595-606,
+    :1011-1062), band coordinates and partial first code-blocks on the decode side."""
+    monkeypatch.setenv("REF_IMG_X0", str(off[0]))
+    monkeypatch.setenv("REF_IMG_Y0", str(off[1]))
+    from test_offgrid_cpu import ref_defects
+    done = 0
+    for (C, H, W, numres) in [(3, 75, 131, 5), (1, 1, 40, 3), (1, 37, 1, 4), (1, 2, 2, 2), (1, 3, 40, 3), (1, 40, 3, 3), (1, 37, 1, 2),
+                              (1, 1, 1, 2), (1, 5, 1, 3), (1, 1, 5, 3)]:
+        d13, d14 = ref_defects(G.ImageLayout.make(W, H, W + off[0], H + off[1], offset=off), numres - 1)
+        if d13 or (d14 and not irrev):      # the reference's own defects (tests/test_offgrid_cpu.py); D14 is in the 5/3 only
+            continue
+        px = synth.g2(C, H, W, 8, seed=off[0] + numres)
+        cs, _ = R.encode(px, 8, TW=W + off[0], TH=H + off[1], numres=numres, mode=1, ht=0, irrev=irrev)     # (one tile)
+        assert np.array_equal(_oracle_decode_stream(cs, True), R.decode(cs, C, H, W)), (C, H, W, numres)
+        done += 1
+    assert done >= 7
 
 
 @pytest.mark.parametrize("sty", [0x01, 0x02, 0x04, 0x08, 0x20, 0x01 | 0x04, 0x3F])
