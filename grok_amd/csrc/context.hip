@@ -331,7 +331,10 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
         a.seg_pairs = seg;
-        if (l == 0 && d_pixels) {
+        if (a.cw == 0 || a.ch == 0) {
+            // a level without samples (a narrow tile off the origin: [ceil(x0 / 2^l), ceil((x0 + w) / 2^l)) can be empty):
+            // nothing to transform, and nothing deeper either
+        } else if (l == 0 && d_pixels) {
             a.pixels = d_pixels; a.px_bytes = (g.p.prec + 7) / 8;
             a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
             a.sext = g.p.sgnd ? (1 << (8 * a.px_bytes - 1)) : 0;
@@ -446,6 +449,7 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
             a.seg0 = (n.y0 / 2) / seg; a.nsegs = ((n.y1 - 1) / 2) / seg - a.seg0 + 1;
             if (l == 0) { a.wx0 = n.x0; a.wy0 = n.y0; a.wx1 = n.x1; a.wy1 = n.y1; }
         }
+        if (a.cw == 0 || a.ch == 0) continue;       // (a level without samples, see run_dwt)
         if (l == 0 && d_pixels) {
             a.pixels = d_pixels; a.px_bytes = out_bytes;
             a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));

@@ -187,9 +187,11 @@ void orc_dwt97_fwd(float* plane, uint32_t w, uint32_t h, uint32_t stride, uint32
 }
 
 /* inverse 5/3 (for round-trip property tests): horizontal then vertical per level, low->high */
-static void idwt53_line(int32_t* io, size_t st, uint32_t n, int32_t* tmp, uint32_t par)
+static void idwt53_line(int32_t* io, size_t st, uint32_t n, int32_t* tmp, uint32_t par, int vertical)
 {
-    if (n == 1) { if (par) io[0] /= 2; return; }        /* a lone high sample was doubled (WaveletReverse.cpp:466-468) */
+    /* a lone high-pass sample was doubled by the encoder: rows halve it with / 2 (decompress_h_53, WaveletReverse.cpp:598),
+     * columns with >> 1 (decompress_v_53, :646) -- the same for what an encoder writes, not for an odd negative value */
+    if (n == 1) { if (par) io[0] = vertical ? io[0] >> 1 : io[0] / 2; return; }
     uint32_t sn = (n + 1 - par) >> 1, dn = n - sn;
     for (uint32_t i = 0; i < sn; ++i) tmp[2 * i + par] = io[i * st];
     for (uint32_t i = 0; i < dn; ++i) tmp[2 * i + 1 - par] = io[(sn + i) * st];
@@ -206,8 +208,8 @@ void orc_dwt53_inv_at(int32_t* plane, uint32_t w, uint32_t h, uint32_t stride, u
     for (int32_t l = (int32_t)levels - 1; l >= 0; --l) {
         const uint32_t lx = cdivp2(x0, (uint32_t)l), ly = cdivp2(y0, (uint32_t)l);
         const uint32_t cw = cdivp2(x0 + w, (uint32_t)l) - lx, ch = cdivp2(y0 + h, (uint32_t)l) - ly;
-        for (uint32_t y = 0; y < ch; ++y) idwt53_line(plane + (size_t)y * stride, 1, cw, tmp, lx & 1u);
-        for (uint32_t x = 0; x < cw; ++x) idwt53_line(plane + x, stride, ch, tmp, ly & 1u);
+        for (uint32_t y = 0; y < ch; ++y) idwt53_line(plane + (size_t)y * stride, 1, cw, tmp, lx & 1u, 0);
+        for (uint32_t x = 0; x < cw; ++x) idwt53_line(plane + x, stride, ch, tmp, ly & 1u, 1);
     }
     free(tmp);
 }

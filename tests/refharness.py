@@ -193,14 +193,14 @@ def plugin_debug_state():
     return L.ref_plugin_debug_state()
 
 
-def plugin_compress_file(pixels, prec, infile, numres=6, irrev=0):
+def plugin_compress_file(pixels, prec, infile, numres=6, irrev=0, TW=None, TH=None):
     """grk_plugin_compress(params{infile}, host callback) -> bytes, or a negative refusal code."""
     L = lib()
     L.ref_plugin_compress_file.restype = C.c_int64
     L.ref_plugin_compress_file.argtypes = [C.POINTER(EncCfg), C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
     px = np.ascontiguousarray(pixels)
     Cn, H, W = px.shape
-    cfg = EncCfg(Cn, W, H, W, H, prec, irrev, numres, 1, 1, 1, 0, 0)
+    cfg = EncCfg(Cn, W, H, TW or W, TH or H, prec, irrev, numres, 1, 1, 1, 0, 0)
     cap = px.size * 4 + (1 << 20)
     out = np.zeros(cap, np.uint8)
     n = L.ref_plugin_compress_file(C.byref(cfg), px.ctypes.data, infile.encode(), out.ctypes.data, cap)

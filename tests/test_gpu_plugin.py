@@ -85,6 +85,29 @@ def test_decode_protocol_through_grok_loader(Cn, H, W, prec, numres, ht, sty, ir
 
 
 @needs_ref
+@pytest.mark.parametrize("off", [(1, 1), (33, 95)])
+def test_protocols_with_an_image_off_the_origin(tmp_path, monkeypatch, off):
+    """grk_compress -d x0,y0 (image_offset_x0 / y0 in the parameters, grk_image x0 / y0 in the host's callback): the tile
+    is the image area wherever it lies -- odd-start transforms, partial first code-blocks (the decline
+    is gone).  The file == the pure-CPU encode; and the decode protocol returns grk_decompress's pixels for such a stream."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    monkeypatch.setenv("REF_IMG_X0", str(off[0]))
+    monkeypatch.setenv("REF_IMG_Y0", str(off[1]))
+    for Cn, H, W, prec in ((3, 191, 255, 8), (1, 77, 300, 12)):
+        px = synth.g2(Cn, H, W, prec)
+        path = str(tmp_path / ("in_%d_%d.%s" % (Cn, prec, "pgm" if Cn == 1 else "ppm")))
+        R.write_pnm(path, px, prec)
+        got = R.plugin_compress_file(px, prec, path, numres=6, TW=W + off[0], TH=H + off[1])
+        assert not isinstance(got, int), "plugin refused: %s" % got
+        cpu, _ = R.encode(px, prec, TW=W + off[0], TH=H + off[1], numres=6, mode=1)
+        assert got == cpu
+        back, stages = R.plugin_decompress(cpu, Cn, H, W)
+        assert not isinstance(back, int), "plugin refused: %s (stages %s)" % (back, stages)
+        assert np.array_equal(back, px.astype(np.int32))
+
+
+@needs_ref
 def test_file_protocol_with_mct_not_set_on_the_command_line(tmp_path, monkeypatch):
     """grk_compress hands the plugin tcp_mct = 255 ("not set") unless -Y was given (grk_compress.cpp:1836; resolved
     only inside its callback, :1817-1820): the plugin resolves it the same way -- grayscale is coded without MCT, RGB
