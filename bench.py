@@ -75,12 +75,13 @@ def cpu_baseline(rank_threads, want_cfg5=True):
                 times.append(secs)
             return px, cs, sorted(times)[len(times) // 2], len(times)
 
-        _, _, med8, n8 = enc_sample(8192, 3, 12.0)
+        _, cs8, med8, n8 = enc_sample(8192, 3, 12.0)
         px, cs, med4, n4 = enc_sample(4096, 5, 8.0)
         out = {"value": round(8192 * 8192 / med8 / 1e6, 2), "unit": "Mpixels/s", "cores": rank_threads,
                "kind": "reference",
                "sample": "Grok 8.0.2 CPU encoder (oracle/_ref), %d x 8192x8192x3 8-bit G2 RCT+5/3 HTJ2K 5 levels (the GPU line's "
                          "workload), median of compress-call wall times, %d threads" % (n8, rank_threads),
+               "file_md5": __import__("hashlib").md5(cs8).hexdigest(),
                "cfg2": {"value": round(4096 * 4096 / med4 / 1e6, 2), "unit": "Mpixels/s",
                         "sample": "%d x 4096x4096x3 8-bit, same settings" % n4}}
         # the decode direction beside it: grk_decompress of the codestream just produced
@@ -242,6 +243,137 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
     return out
 
 
+def host_boundary(ctx, dev, stream, params, ntiles, host_pixels, nblocks, frames):
+    """What a caller that owns HOST buffers gets (never the headline `value`, whose inputs are resident
+    in HBM): per frame, pinned pixels -> H2D -> encode -> D2H of the block table and of the coded bytes into pinned memory.
+    The three legs run on three streams: uploads double-buffered one frame ahead of the encoder, the download one frame
+    behind it (its size -- the bytes used in the coded arena -- passes through the host first), the encoder rotating three
+    buffer sets (grk_amd_set_pipelining(ctx, 2)) so that it never waits for that round trip."""
+    raw = host_pixels.numel()
+    arena_cap = int(raw * 2)
+    h_px = host_pixels.pin_memory()
+    d_buf = [torch.empty(raw, dtype=torch.uint8, device=dev) for _ in range(2)]
+    h_coded = torch.empty(arena_cap, dtype=torch.uint8).pin_memory()
+    h_offs = torch.empty(nblocks, dtype=torch.int64).pin_memory()
+    h_lens = torch.empty(nblocks, dtype=torch.int32).pin_memory()
+    h_used = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(2)]
+    up, dl = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ev_up = [torch.cuda.Event() for _ in range(2)]
+    ev_enc = [torch.cuda.Event() for _ in range(2)]          # the encode that read d_buf[b] has finished with it
+    ev_used = [torch.cuda.Event() for _ in range(2)]
+    ev_dl = {}
+    pend = [None]
+    got_bytes = [0]
+
+    def download(prev):
+        f, used_slot, offs, lens, arena = prev
+        ev_used[used_slot].synchronize()                       # (long done: the next frame has been queued meanwhile)
+        n = int(h_used[used_slot][0])
+        with torch.cuda.stream(dl):
+            h_coded[:n].copy_(arena[:n], non_blocking=True)
+            h_offs.copy_(offs, non_blocking=True)
+            h_lens.copy_(lens, non_blocking=True)
+            e = torch.cuda.Event()
+            e.record(dl)
+            ev_dl[f] = e
+        got_bytes[0] = n
+
+    def one(f):
+        b = f & 1
+        with torch.cuda.stream(up):
+            if f >= 2:
+                up.wait_event(ev_enc[b])
+            d_buf[b].copy_(h_px, non_blocking=True)
+            ev_up[b].record(up)
+        with torch.cuda.stream(stream):
+            stream.wait_event(ev_up[b])
+            e = ev_dl.pop(f - 3, None)
+            if e is not None:
+                stream.wait_event(e)                           # frame f reuses frame f - 3's buffer set
+            ctx.encode_tiles(params, ntiles, d_buf[b].data_ptr(), True, fetch=False)
+            ev_enc[b].record(stream)
+        used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
+        offs = _as_tensor(ctx.table_device_ptr(0), nblocks, dev, "<i8")
+        lens = _as_tensor(ctx.table_device_ptr(1), nblocks, dev, "<i4")
+        arena = _as_tensor(ctx.coded_device_ptr(), arena_cap, dev)
+        ctx.stream_wait_results(dl.cuda_stream)
+        prev, pend[0] = pend[0], None
+        if prev is not None:
+            download(prev)
+        with torch.cuda.stream(dl):
+            h_used[b].copy_(used, non_blocking=True)
+            ev_used[b].record(dl)
+        pend[0] = (f, b, offs, lens, arena)
+
+    def flush():
+        if pend[0] is not None:
+            download(pend[0])
+            pend[0] = None
+        torch.cuda.synchronize(dev)
+
+    ctx.set_overlap(True)
+    ctx.set_pipelining(2)
+    for f in range(3):
+        one(f)
+    flush()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        one(3 + f)
+    flush()
+    dt = (time.perf_counter() - t0) / frames
+    ctx.set_pipelining(False)
+    # what arrived is the encoder's output: the table's byte ranges lie inside the downloaded arena prefix
+    ok = bool(((h_offs + h_lens.to(torch.int64)) <= got_bytes[0]).all()) and int(h_lens.sum()) > 0
+    px_per_frame = params.tile_w * params.tile_h * ntiles
+    return {"ms_per_frame": round(dt * 1e3, 3), "value": round(px_per_frame / dt / 1e6, 1), "unit": "Mpixels/s", "frames": frames,
+            "h2d_bytes_per_frame": int(raw), "d2h_bytes_per_frame": int(got_bytes[0] + nblocks * 12),
+            "h2d_GBps": round(raw / dt / 1e9, 1), "table_consistent": ok,
+            "what": "pinned host pixels -> H2D (double-buffered, one frame ahead) -> encode -> D2H of block table + coded bytes "
+                    "into pinned memory (one frame behind); bounded by the PCIe upload"}
+
+
+def via_grok_plugin(ctx, params, tile_pixels, prec, cpu_file_md5=None):
+    """The drop-in route itself, once: the plugin's tile tree (GPU encode + D2H + tree) handed to the real Grok library's
+    grk_compress_with_plugin(), which runs its own Tier-2 and writes the file (oracle/_ref = that library, built from the
+    reference's sources: here it is the HOST the plugin plugs into)."""
+    try:
+        import hashlib
+        import refharness as R
+        if not R.have_ref():
+            return {"skipped": "oracle/_ref missing"}
+        plug = os.path.join(os.path.dirname(G.lib_path()), "libgrokj2k_plugin.so")
+        L = C.CDLL(plug)
+        L.grk_amd_plugin_tile_create.restype = C.c_void_p
+        L.grk_amd_plugin_tile_create.argtypes = [C.c_void_p, C.POINTER(G.TileParams), C.c_void_p, C.c_int]
+        L.grk_amd_plugin_tile_destroy.argtypes = [C.c_void_p]
+        px = np.ascontiguousarray(tile_pixels)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            tile = L.grk_amd_plugin_tile_create(ctx._h, C.byref(params), px.ctypes.data, 0)
+            t_tile = time.perf_counter() - t0
+            if not tile:
+                return {"error": "grk_amd_plugin_tile_create failed"}
+            try:
+                t0 = time.perf_counter()
+                cs, _ = R.encode(px, prec, numres=params.num_levels + 1, mode=1, rate_algo=1, plugin_tile=tile)
+                t_host = time.perf_counter() - t0
+            finally:
+                L.grk_amd_plugin_tile_destroy(tile)
+            if best is None or t_tile + t_host < best[0] + best[1]:
+                best = (t_tile, t_host, cs)
+        t_tile, t_host, cs = best
+        npx = params.tile_w * params.tile_h
+        return {"ms_per_frame": round((t_tile + t_host) * 1e3, 1), "value": round(npx / (t_tile + t_host) / 1e6, 1), "unit": "Mpixels/s",
+                "plugin_tile_ms": round(t_tile * 1e3, 1), "host_library_ms": round(t_host * 1e3, 1), "codestream_bytes": len(cs),
+                "file_equals_cpu_encode": (hashlib.md5(cs).hexdigest() == cpu_file_md5) if cpu_file_md5 else None,
+                "what": "grk_amd_plugin_tile_create (host pixels -> H2D -> GPU encode -> D2H -> grk_plugin_tile tree) + "
+                        "grk_compress_init/start/grk_compress_with_plugin/end of the real Grok 8.0.2 library (image set-up, its "
+                        "own Tier-2, codestream write to memory), best of 2"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +382,8 @@ def main():
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` object (cfg2, cfg3, cfg4tile, cfg5 decode)")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` object (PCIe-inclusive end-to-end "
+                    "rate, the route through grk_compress_with_plugin)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="every kernel alone on the GPU, also in the timed region (what the rocprofv3 kernel-trace summary "
                          "that the roofline durations are checked against is taken with)")
@@ -585,6 +719,15 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and not use_dist and not args.no_workloads and args.workload == "8k":
             out["workloads"] = extra_workloads(ctx, dev, stream, max(3, min(args.steps, 10)), cfg5)
+        if world == 1 and not use_dist and not args.no_host_boundary:
+            try:
+                hb = {"end_to_end": host_boundary(ctx, dev, stream, params, ntiles, torch.from_numpy(host.view(np.uint8)), nblocks,
+                                                  max(3, min(args.steps, 10)))}
+            except Exception as e:  # noqa: BLE001
+                hb = {"end_to_end": {"error": str(e)}}
+            if args.workload == "8k" and not args.no_cpu_baseline:
+                hb["via_grok_plugin"] = via_grok_plugin(ctx, params, tile, prec, (out.get("cpu_baseline") or {}).get("file_md5"))
+            out["host_boundary"] = hb
         line = json.dumps(out)
     else:
         line = None

@@ -19,6 +19,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -183,51 +185,77 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
     return grk_amd_tile_num_blocks(&p) > 0;
 }
 
-int32_t encode_file(gra_cparameters* cp, const char* in, const char* out, gra_encode_callback cb)
-{
-    if (!g_ctx || !cp || !cb) return -1;
+// One file through the protocol in three steps, so that the batch mode can overlap them across files:
+//   load      read + de-interleave the PNM                                                  (disk, host)
+//   gpu_step  H2D, encode, D2H, the grk_plugin_tile tree (+ the self-check image)            (GPU; holds g_mu)
+//   host_step the host's callback: its own Tier-2 over our blocks, the file                  (host library)
+struct EncodeJob {
+    std::string in, out;
     std::vector<uint8_t> px;
-    uint32_t w, h, comps, prec;
-    if (!read_pnm(in, px, w, h, comps, prec)) return -1;
-    grk_amd_tile_params p;
-    if (!params_from_cparameters(cp, w, h, comps, prec, p)) return -1;
+    uint32_t w = 0, h = 0, comps = 0, prec = 0;
+    grk_amd_tile_params p{};
+    gra_plugin_tile* tile = nullptr;
+    void* dbg_image = nullptr;
+    void (*unref)(void*) = nullptr;
+};
+
+bool load_step(EncodeJob& j) { return read_pnm(j.in.c_str(), j.px, j.w, j.h, j.comps, j.prec); }
+
+bool gpu_step(gra_cparameters* cp, EncodeJob& j)
+{
+    if (!params_from_cparameters(cp, j.w, j.h, j.comps, j.prec, j.p)) return false;
     std::lock_guard<std::mutex> lk(g_mu);
-    gra_plugin_tile* tile = grk_amd_plugin_tile_create(g_ctx, &p, px.data(), 0);
-    if (!tile) return -1;
-    gra_encode_callback_info info{};
-    info.input_file_name = in;
-    info.outputFileNameIsRelative = false;
-    info.output_file_name = out;
-    info.compressor_parameters = cp;
-    info.image = nullptr;                 // the host callback loads the image itself (grk_compress.cpp:1636)
-    info.tile = tile;
-    info.error_code = 0;
+    j.tile = grk_amd_plugin_tile_create(g_ctx, &j.p, j.px.data(), 0);
+    if (!j.tile) return false;
+    std::vector<uint8_t>().swap(j.px);          // the pixels are on the device / coded: the host callback loads its own copy
     // self-check mode: the "image" the host gets holds our sub-band coefficients (it skips its own DC shift / MCT / DWT and
     // codes them with its own Tier-1).  The image object is made by the host library itself (grk_image_new, resolved from
     // the process we were loaded into) so that the host can treat it as any other.
-    void* dbg_image = nullptr;
-    void (*unref)(void*) = nullptr;
     if (g_debug_state & GRA_PLUGIN_STATE_DEBUG) {
         typedef gra_image* (*image_new_fn)(uint16_t, gra_image_cmptparm*, int32_t, bool);
         auto image_new = reinterpret_cast<image_new_fn>(dlsym(RTLD_DEFAULT, "grk_image_new"));
-        unref = reinterpret_cast<void (*)(void*)>(dlsym(RTLD_DEFAULT, "grk_object_unref"));
-        if (!image_new || !unref) { grk_amd_plugin_tile_destroy(tile); return -1; }
-        std::vector<gra_image_cmptparm> cps(comps);
-        for (auto& c : cps) { c.dx = 1; c.dy = 1; c.w = w; c.stride = 0; c.h = h; c.x0 = p.tile_x0; c.y0 = p.tile_y0; c.prec = (uint8_t)prec; c.sgnd = false; }
-        gra_image* img = image_new((uint16_t)comps, cps.data(), comps >= 3 ? 1 /* GRK_CLRSPC_SRGB */ : 2 /* GRK_CLRSPC_GRAY */, true);
-        if (!img) { grk_amd_plugin_tile_destroy(tile); return -1; }
-        img->x0 = p.tile_x0; img->y0 = p.tile_y0; img->x1 = p.tile_x0 + w; img->y1 = p.tile_y0 + h;
+        j.unref = reinterpret_cast<void (*)(void*)>(dlsym(RTLD_DEFAULT, "grk_object_unref"));
+        const grk_amd_tile_params& p = j.p;
+        auto fail = [&]() { grk_amd_plugin_tile_destroy(j.tile); j.tile = nullptr; return false; };
+        if (!image_new || !j.unref) return fail();
+        std::vector<gra_image_cmptparm> cps(j.comps);
+        for (auto& c : cps) { c.dx = 1; c.dy = 1; c.w = j.w; c.stride = 0; c.h = j.h; c.x0 = p.tile_x0; c.y0 = p.tile_y0; c.prec = (uint8_t)j.prec; c.sgnd = false; }
+        gra_image* img = image_new((uint16_t)j.comps, cps.data(), j.comps >= 3 ? 1 /* GRK_CLRSPC_SRGB */ : 2 /* GRK_CLRSPC_GRAY */, true);
+        if (!img) return fail();
+        img->x0 = p.tile_x0; img->y0 = p.tile_y0; img->x1 = p.tile_x0 + j.w; img->y1 = p.tile_y0 + j.h;
         bool ok = true;
-        for (uint32_t c = 0; c < comps && ok; ++c)
+        for (uint32_t c = 0; c < j.comps && ok; ++c)
             ok = img->comps[c].data && grk_amd_fetch_coefficients(g_ctx, c, img->comps[c].data, img->comps[c].stride) == GRK_AMD_OK;
-        if (!ok) { unref(&img->obj); grk_amd_plugin_tile_destroy(tile); return -1; }
-        dbg_image = img;
-        info.image = img;
+        if (!ok) { j.unref(&img->obj); return fail(); }
+        j.dbg_image = img;
     }
+    return true;
+}
+
+int32_t host_step(gra_cparameters* cp, EncodeJob& j, gra_encode_callback cb)
+{
+    gra_encode_callback_info info{};
+    info.input_file_name = j.in.c_str();
+    info.outputFileNameIsRelative = false;
+    info.output_file_name = j.out.c_str();
+    info.compressor_parameters = cp;
+    info.image = static_cast<gra_image*>(j.dbg_image);     // nullptr: the host callback loads the image itself (grk_compress.cpp:1636)
+    info.tile = j.tile;
+    info.error_code = 0;
     cb(&info);
-    if (dbg_image) unref(&static_cast<gra_image*>(dbg_image)->obj);
-    grk_amd_plugin_tile_destroy(tile);
+    if (j.dbg_image) j.unref(&static_cast<gra_image*>(j.dbg_image)->obj);
+    grk_amd_plugin_tile_destroy(j.tile);
+    j.tile = nullptr; j.dbg_image = nullptr;
     return info.error_code;
+}
+
+int32_t encode_file(gra_cparameters* cp, const char* in, const char* out, gra_encode_callback cb)
+{
+    if (!g_ctx || !cp || !cb || !in || !out) return -1;
+    EncodeJob j;
+    j.in = in; j.out = out;
+    if (!load_step(j) || !gpu_step(cp, j)) return -1;
+    return host_step(cp, j, cb);
 }
 
 // ---- batch mode: a worker thread walks the input directory ----------------------------------------
@@ -612,19 +640,47 @@ GRA_EXPORT int32_t plugin_batch_encode(const char* input_dir, const char* output
     std::string in(input_dir), out(output_dir);
     gra_cparameters* cp = params;
     g_batch = std::thread([in, out, cp, callback]() {
+        // the files of the directory, then three overlapped stages over them (a file is in one stage at a time, every stage
+        // works on one file at a time): while the GPU codes file n, file n + 1 is being read and de-interleaved and the host
+        // library runs its Tier-2 and writes file n - 1.  Hand-over slots hold one job each, so at most three images are
+        // in flight.
+        std::vector<std::pair<std::string, std::string>> files;
         if (DIR* d = opendir(in.c_str())) {
             while (dirent* e = readdir(d)) {
-                if (g_batch_stop.load()) break;
                 std::string name(e->d_name);
                 const size_t dot = name.rfind('.');
                 if (dot == std::string::npos) continue;
                 const std::string ext = name.substr(dot);
                 if (ext != ".pgm" && ext != ".ppm" && ext != ".pnm") continue;
-                const std::string src = in + "/" + name, dst = out + "/" + name.substr(0, dot) + ".j2k";
-                encode_file(cp, src.c_str(), dst.c_str(), callback);
+                files.emplace_back(in + "/" + name, out + "/" + name.substr(0, dot) + ".j2k");
             }
             closedir(d);
         }
+        struct Slot {
+            std::mutex m; std::condition_variable cv; std::unique_ptr<EncodeJob> job; bool closed = false;
+            void put(std::unique_ptr<EncodeJob> j) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !job; }); job = std::move(j); cv.notify_all(); }
+            std::unique_ptr<EncodeJob> take() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return job || closed; }); auto j = std::move(job); cv.notify_all(); return j; }
+            void close() { std::lock_guard<std::mutex> lk(m); closed = true; cv.notify_all(); }
+        } loaded, coded;
+        std::thread reader([&]() {
+            for (const auto& f : files) {
+                if (g_batch_stop.load()) break;
+                auto j = std::make_unique<EncodeJob>();
+                j->in = f.first; j->out = f.second;
+                if (load_step(*j)) loaded.put(std::move(j));
+            }
+            loaded.close();
+        });
+        std::thread writer([&]() {
+            while (auto j = coded.take()) host_step(cp, *j, callback);
+        });
+        while (auto j = loaded.take()) {
+            if (g_batch_stop.load()) continue;          // (drain the reader)
+            if (gpu_step(cp, *j)) coded.put(std::move(j));
+        }
+        coded.close();
+        reader.join();
+        writer.join();
         g_batch_done = true;
     });
     return 0;

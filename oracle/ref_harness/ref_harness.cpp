@@ -13,6 +13,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <chrono>
+#include <atomic>
 #include <vector>
 #include <unistd.h>
 #include <algorithm>
@@ -412,6 +413,79 @@ int64_t ref_plugin_compress_file(const EncCfg* cfg, const uint8_t* pixels, const
 	int32_t rc = grk_plugin_compress(&param, host_compress_callback);
 	if (rc != 0) return rc < 0 ? rc : -rc;
 	return g_cb_len;
+}
+
+// ---- batch compress: grk_plugin_batch_compress(in_dir, out_dir, params, callback) (grok.cpp:683-707) -- what
+// `grk_compress -y in_dir -a out_dir` does (grk_compress.cpp:1540-1590): the plugin walks the directory and calls back once
+// per image; the callback loads the image named by info->input_file_name itself and writes info->output_file_name.
+static bool read_pnm_planar(const char* path, std::vector<int32_t>& planes, int& C, int& W, int& H, int& prec)
+{
+	FILE* f = fopen(path, "rb");
+	if (!f) return false;
+	char magic[3] = {0, 0, 0};
+	unsigned w = 0, h = 0, maxv = 0;
+	bool ok = fscanf(f, "%2s %u %u %u", magic, &w, &h, &maxv) == 4 && fgetc(f) != EOF && (!strcmp(magic, "P5") || !strcmp(magic, "P6"));
+	if (ok) {
+		C = magic[1] == '6' ? 3 : 1; W = (int)w; H = (int)h;
+		prec = 1; while ((1u << prec) <= maxv) ++prec;
+		const size_t bps = prec > 8 ? 2 : 1, n = (size_t)w * h;
+		std::vector<uint8_t> raw(n * C * bps);
+		ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
+		planes.resize(n * C);
+		for (int c = 0; c < C && ok; ++c)
+			for (size_t i = 0; i < n; ++i)
+				planes[c * n + i] = bps == 1 ? raw[i * C + c] : (raw[(i * C + c) * 2] << 8 | raw[(i * C + c) * 2 + 1]);
+	}
+	fclose(f);
+	return ok;
+}
+static std::atomic<int> g_batch_ok{0}, g_batch_bad{0};
+static bool host_batch_compress_callback(grk_plugin_compress_user_callback_info* info)
+{
+	if (!info || !info->tile || !info->input_file_name || !info->output_file_name) { g_batch_bad++; if (info) info->error_code = 1; return false; }
+	std::vector<int32_t> planes;
+	EncCfg c{};
+	int prec = 0;
+	if (!read_pnm_planar(info->input_file_name, planes, c.C, c.W, c.H, prec)) { g_batch_bad++; info->error_code = 1; return false; }
+	c.prec = prec;
+	grk_image* image = make_image(c, true);
+	for (int k = 0; k < c.C; ++k)
+		for (int y = 0; y < c.H; ++y)
+			memcpy(image->comps[k].data + (size_t)y * image->comps[k].stride, planes.data() + ((size_t)k * c.H + y) * c.W, (size_t)c.W * 4);
+	grk_cparameters param = *info->compressor_parameters;           // (every image of the batch starts from the same parameters)
+	if (param.tcp_mct == 255) param.tcp_mct = (image->numcomps >= 3) ? 1 : 0;
+	std::vector<uint8_t> out((size_t)c.W * c.H * c.C * 4 + (1u << 20));
+	grk_stream* stream = grk_stream_create_mem_stream(out.data(), out.size(), false, false);
+	grk_codec* codec = grk_compress_create(GRK_CODEC_J2K, stream);
+	bool ok = codec && grk_compress_init(codec, &param, image) && grk_compress_start(codec) &&
+			  grk_compress_with_plugin(codec, info->tile) && grk_compress_end(codec);
+	if (ok) {
+		FILE* f = fopen(info->output_file_name, "wb");
+		ok = f && fwrite(out.data(), 1, grk_stream_get_write_mem_stream_length(stream), f) == grk_stream_get_write_mem_stream_length(stream);
+		if (f) fclose(f);
+	}
+	info->error_code = ok ? 0 : 1;
+	(ok ? g_batch_ok : g_batch_bad)++;
+	grk_object_unref(stream);
+	grk_object_unref(codec);
+	grk_object_unref(&image->obj);
+	return ok;
+}
+// returns the number of files written (callbacks that succeeded), or < 0: refused / timed out / a callback failed
+int32_t ref_plugin_batch_compress(const EncCfg* cfg, const char* in_dir, const char* out_dir, int timeout_s)
+{
+	static grk_cparameters param;        // (read by the plugin's worker after this call returns)
+	fill_params(param, *cfg);
+	param.tile_size_on = false;          // the images of a directory differ in size
+	param.tcp_mct = 255;
+	g_batch_ok = 0; g_batch_bad = 0;
+	int32_t rc = grk_plugin_batch_compress(in_dir, out_dir, &param, host_batch_compress_callback);
+	if (rc != 0) return rc < 0 ? rc : -rc;
+	for (int i = 0; i < timeout_s * 10 && !grk_plugin_is_batch_complete(); ++i) usleep(100000);
+	const bool done = grk_plugin_is_batch_complete();
+	grk_plugin_stop_batch_compress();
+	if (!done) return -1000;
+	return g_batch_bad.load() ? -2000 - g_batch_bad.load() : g_batch_ok.load();
 }
 
 // ---- the decode protocol: grk_plugin_decompress(params, callback) (grok.cpp:727-743) ------------------------

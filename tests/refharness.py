@@ -207,6 +207,16 @@ def plugin_compress_file(pixels, prec, infile, numres=6, irrev=0, TW=None, TH=No
     return out[:n].tobytes() if n >= 0 else int(n)
 
 
+def plugin_batch_compress(in_dir, out_dir, numres=6, timeout_s=120):
+    """grk_plugin_batch_compress over a directory of PNM files (what `grk_compress -y in -a out` does): -> number of files the
+    host callback wrote, or a negative code."""
+    L = lib()
+    L.ref_plugin_batch_compress.restype = C.c_int32
+    L.ref_plugin_batch_compress.argtypes = [C.POINTER(EncCfg), C.c_char_p, C.c_char_p, C.c_int]
+    cfg = EncCfg(1, 1, 1, 1, 1, 8, 0, numres, 1, 1, 1, 0, 0)
+    return int(L.ref_plugin_batch_compress(C.byref(cfg), in_dir.encode(), out_dir.encode(), timeout_s))
+
+
 def plugin_decompress(j2k, Cn, H, W, as_file=True):
     """grk_plugin_decompress(params, host callback): Grok dlsym()s plugin_decompress in our .so and the two sides run the
     decode protocol (header -> T2 into the plugin's tile tree -> plugin decodes -> post-T1 -> clean).  as_file: the stream

@@ -207,6 +207,34 @@ def test_decode_protocol_declines_without_a_file_to_read_the_qcd_from():
 
 
 @needs_ref
+def test_batch_compress_through_grok_loader(tmp_path):
+    """grk_plugin_batch_compress (grok.cpp:683-707; `grk_compress -y dir -a dir`): our worker walks the directory with three
+    overlapped stages -- read + de-interleave the next file, GPU encode of the current one, the host's callback (its Tier-2 +
+    file write) for the one before -- and every output file == the pure-CPU encode of its image.  Images of different sizes,
+    component counts and depths, one file the hot path declines (it is skipped, the batch goes on)."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir(); outd.mkdir()
+    imgs = {}
+    for i, (Cn, H, W, prec) in enumerate([(3, 192, 256, 8), (1, 300, 200, 8), (3, 257, 129, 8), (1, 128, 128, 12), (3, 512, 384, 8),
+                                          (3, 64, 64, 8), (1, 1000, 40, 8)]):
+        px = synth.g2(Cn, H, W, prec, seed=100 + i)
+        name = "img%02d" % i
+        R.write_pnm(str(ind / (name + (".pgm" if Cn == 1 else ".ppm"))), px, prec)
+        imgs[name] = (px, prec)
+    (ind / "broken.pgm").write_bytes(b"P5\n10 10\n255\nshort")
+    (ind / "notes.txt").write_text("not an image")
+    n = R.plugin_batch_compress(str(ind), str(outd), numres=6)
+    assert n == len(imgs), n
+    for name, (px, prec) in imgs.items():
+        got = (outd / (name + ".j2k")).read_bytes()
+        cpu, _ = R.encode(px, prec, numres=6, mode=1)
+        assert got == cpu, name
+    assert not (outd / "broken.j2k").exists()
+
+
+@needs_ref
 def test_batch_decompress_through_grok_loader(tmp_path):
     """grk_plugin_init_batch_decompress + grk_plugin_batch_decompress (plugin/plugin_interface.h:131-143; grk_decompress
     -y <dir> -a <dir>, grk_decompress.cpp:874-900): the plugin's worker walks the directory, decodes what is inside the hot
