@@ -603,6 +603,10 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
     // K5a is one serial chain per lane.  A wave costs the same issue slots however many lanes are
     // live, so few lanes per wave multiply the instruction count, while few waves per SIMD leave the
     // chain's own latency exposed: aim for ~1.5-2 waves per SIMD (1024 SIMDs), measured optimum.
+    // (r02, 8K, 49 152 blocks: 32, 48 and 64 lanes per wave take the same time -- what lasts is the chain of one wave, and a
+    //  second wave on the SIMD interleaves for free; 16 and 24 lanes are slower.  Running this kernel BESIDE the wide ones of
+    //  another frame does not pay either: next to K5b both take twice as long, next to the inverse DWT 1.4x / 1.5x -- the
+    //  chain's next instruction waits behind whatever holds the SIMD's ALU for its four cycles, wave priority or not)
     uint32_t lanes = 64;
     while (lanes > 16 && (a.nblocks + lanes - 1) / lanes < 1280) lanes >>= 1;
     hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nblocks + lanes - 1) / lanes), dim3(lanes), 0, s, a);
