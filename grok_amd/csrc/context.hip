@@ -78,6 +78,7 @@ struct grk_amd_ctx {
     bool pipelining = false;
     hipEvent_t ev_main = nullptr;
     bool side_pending = false;       // side-stream work of the latest encode has not been joined on the main stream yet
+    int dwt_xcd = 1;                                        // XCD-aware workgroup order in K2 / K6 (GRK_AMD_DWT_XCD=0: plain)
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
     bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
     DevBuf ht_sel;
@@ -323,6 +324,7 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         a.nplanes = nplanes;
         a.irreversible = g.p.irreversible;
         a.h16 = h16 ? 1 : 0;
+        a.xcd = c->dwt_xcd;
         // enough workgroups to cover the chip several times, few enough to amortise warm-up rows
         const uint32_t sh = (a.ch + a.py + 1) >> 1;           // row pairs on the coordinate grid
         uint32_t seg = 64;
@@ -433,6 +435,7 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
         else { a.out = (int32_t*)c->llB.p; a.out_stride = sB; a.out_pitch = pitchB; }
         a.nplanes = nplanes;
         a.irreversible = g.p.irreversible;
+        a.xcd = c->dwt_xcd;
         const uint32_t sh = (a.ch + a.py + 1) >> 1;
         uint32_t seg = 64;
         const uint64_t strips = (((a.cw + a.px + 1) >> 1) + idwt_strip_pairs() - 1) / idwt_strip_pairs();
@@ -671,6 +674,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (const char* e16 = getenv("GRK_AMD_PLANES16")) c->planes16 = atoi(e16) != 0;
         if (const char* ef = getenv("GRK_AMD_FUSE_EGRESS")) c->fuse_egress = atoi(ef) != 0;
+        if (const char* ex = getenv("GRK_AMD_DWT_XCD")) c->dwt_xcd = atoi(ex) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;

@@ -38,6 +38,7 @@ struct DwtLevelArgs {
     uint32_t ncomp;       // components per tile
     uint32_t comp0, zdiv; // set by the launcher: first component of a z slot, z slots per tile
     int      h16;         // reversible, 8-bit pixels: every plane (in, ll, mallat) holds int16 instead of int32
+    int      xcd;         // XCD-aware workgroup order (kernels_dwt.hip)
 };
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s);
 hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, int mct, hipStream_t s);
@@ -146,6 +147,7 @@ struct IdwtLevelArgs {
     uint32_t wx0, wy0, wx1, wy1;   // window of the tile the pixels are for (the whole tile: 0, 0, cw, ch)
     // region decode: only the strips [strip0, strip0 + nstrips) x row segments [seg0, seg0 + nsegs) (0 = all)
     uint32_t strip0, nstrips, seg0, nsegs;
+    int      xcd;         // XCD-aware workgroup order (as DwtLevelArgs)
 };
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s);
 hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, hipStream_t s);

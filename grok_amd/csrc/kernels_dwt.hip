@@ -178,6 +178,18 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     __shared__ __attribute__((aligned(16))) T line[2][NC][2][kCols];   // [parity][comp][low/high][column]
 
     const uint32_t t = threadIdx.x;
+    // Which (strip, row segment, plane) this workgroup takes.  Workgroups go to the 8 XCDs round-robin in dispatch order, and
+    // every XCD has its own L2: with the plain mapping the two neighbours of a strip -- whose halo columns lie in cache lines
+    // it also reads -- run on OTHER XCDs and those lines are fetched once per XCD.  xcd != 0: XCD k (= dispatch id mod 8)
+    // takes a contiguous run of the linear (strip fastest) order instead, so that neighbours share an L2.
+    uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd) {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint32_t id = bx + gx * (by + gy * bz);
+        const uint32_t q = total >> 3, r = total & 7u, k = id & 7u;
+        const uint32_t lid = k * q + min(k, r) + (id >> 3);
+        bx = lid % gx; by = (lid / gx) % gy; bz = lid / (gx * gy);
+    }
     const uint32_t cw = a.cw, ch = a.ch;
     const uint32_t px = a.px, py = a.py;
     const uint32_t sw = (cw + 1 - px) >> 1, dw = cw - sw;
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     const uint32_t vpairs = (ch + py + 1) >> 1;            // row pairs on the coordinate grid
     const float inv_k = (float)(1.0 / 1.230174105);
 
-    const int32_t c_first = (int32_t)(blockIdx.x * kOutCols) - kHalo;    // global column of local 0
+    const int32_t c_first = (int32_t)(bx * kOutCols) - kHalo;    // global column of local 0
     // Which pair of the staged line this lane carries through the vertical pass: lanes [0, kOutPairs) take the strip's
     // own pairs IN ORDER (their row loads start on a cache-line boundary), the next kHalo lanes the halo pairs left and
     // right of it; whatever lanes remain ride along on columns nobody reads.
@@ -196,8 +208,8 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     const bool vec = px == 0 && (cA >= 0) && ((uint32_t)cA + 1 < cw);
 
     // first plane this workgroup produces
-    uint32_t plane0 = blockIdx.z;
-    if constexpr (PX != 0) plane0 = (blockIdx.z / a.zdiv) * a.ncomp + a.comp0 + (blockIdx.z % a.zdiv);
+    uint32_t plane0 = bz;
+    if constexpr (PX != 0) plane0 = (bz / a.zdiv) * a.ncomp + a.comp0 + (bz % a.zdiv);
     using PT = typename std::conditional<H16, int16_t, T>::type;             // element type of the planes in memory
     const PT* in = reinterpret_cast<const PT*>(a.in) + (size_t)plane0 * a.in_pitch;
     PT* ll = reinterpret_cast<PT*>(a.ll) + (size_t)plane0 * a.ll_pitch;
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     const PIX* pix = reinterpret_cast<const PIX*>(a.pixels) + (size_t)plane0 * comp_px;
     const bool pvec = vec && (cw & 1u) == 0;          // tightly packed rows: pairs aligned only for even widths
 
-    const int32_t J0 = (int32_t)(blockIdx.y * a.seg_pairs);
+    const int32_t J0 = (int32_t)(by * a.seg_pairs);
     const int32_t J1 = min((int32_t)vpairs, J0 + (int32_t)a.seg_pairs);
     constexpr int lag  = F97 ? 1 : 0;
     constexpr int warm = F97 ? 2 : 1;
@@ -304,11 +316,11 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         // the prefetched rows does not also wait for the stores issued after them
         // lane t owns output pair t of the strip (local columns kHalo + 2t, + 1); lanes past the strip's last pair idle
         // (EDGE: the strip may end before its 224th pair; the lanes past the last real pair repeat it as well)
-        const uint32_t nvalid = EDGE ? min((uint32_t)kOutPairs, sw - blockIdx.x * kOutPairs) : (uint32_t)kOutPairs;
+        const uint32_t nvalid = EDGE ? min((uint32_t)kOutPairs, sw - bx * kOutPairs) : (uint32_t)kOutPairs;
         const uint32_t tp = FAST ? min(t, nvalid - 1u) : t;
         const uint32_t th = tp + kHalo / 2;                                  // its pair index inside the staged line
         const bool h_lane = FAST || t < (uint32_t)kOutPairs;
-        const uint32_t Jc = blockIdx.x * kOutPairs + tp;                     // global pair column
+        const uint32_t Jc = bx * kOutPairs + tp;                     // global pair column
         const bool st_s = h_lane && (FAST || (Jc >= px && Jc - px < sw)), st_d = h_lane && (FAST || Jc < dw);
         const uint32_t Js = Jc - (FAST ? 0u : px);                           // its column in the low-pass bands
 
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
         }
     };
     const bool even = (px | py) == 0 && (cw & 1u) == 0 && cw >= 4 && ch >= 16 && (ch & 1u) == 0;
-    const bool interior = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (blockIdx.x + 1) * kOutPairs <= dw;
+    const bool interior = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (bx + 1) * kOutPairs <= dw;
     if (even && interior) strip(std::true_type{}, std::false_type{});
     else if (even) strip(std::true_type{}, std::true_type{});
     else strip(std::false_type{}, std::false_type{});

@@ -168,13 +168,23 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     __shared__ __attribute__((aligned(16))) T line[2][NC][2][2][kThreads];
 
     const uint32_t t = threadIdx.x;
+    // XCD-aware workgroup order, as in kernels_dwt.hip: the neighbours of a strip share its halo cache lines, so XCD k
+    // (= dispatch id mod 8) takes a contiguous run of the linear (strip fastest) order
+    uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd) {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint32_t id = bx + gx * (by + gy * bz);
+        const uint32_t q = total >> 3, r = total & 7u, k = id & 7u;
+        const uint32_t lid = k * q + min(k, r) + (id >> 3);
+        bx = lid % gx; by = (lid / gx) % gy; bz = lid / (gx * gy);
+    }
     const uint32_t cw = a.cw, ch = a.ch;
     const uint32_t px = a.px, py = a.py;
     const uint32_t sw = (cw + 1 - px) >> 1, sh = (ch + 1 - py) >> 1;        // low-pass columns / rows
     const uint32_t vpairs = (ch + py + 1) >> 1;                               // row pairs on the coordinate grid
 
-    uint32_t plane0 = blockIdx.z;
-    if constexpr (PXO != 0) plane0 = (blockIdx.z / a.zdiv) * a.ncomp + a.comp0 + (blockIdx.z % a.zdiv);
+    uint32_t plane0 = bz;
+    if constexpr (PXO != 0) plane0 = (bz / a.zdiv) * a.ncomp + a.comp0 + (bz % a.zdiv);
     const T* ll = reinterpret_cast<const T*>(a.ll) + (size_t)plane0 * a.ll_pitch;
     const T* mp = reinterpret_cast<const T*>(a.mallat) + (size_t)plane0 * a.m_pitch;
     T* out = reinterpret_cast<T*>(a.out) + (size_t)plane0 * a.out_pitch;
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     // wave's loads and stores start on cache-line boundaries; the next 2 * kHaloPairs lanes fetch the halo pairs left
     // and right of the strip.  lp = position in the staged line.
     const uint32_t lp = t < (uint32_t)kOutPairs ? t + kHaloPairs : (t < (uint32_t)(kOutPairs + kHaloPairs) ? t - kOutPairs : t);
-    const int32_t J = (int32_t)((blockIdx.x + a.strip0) * kOutPairs) - kHaloPairs + (int32_t)lp;
+    const int32_t J = (int32_t)((bx + a.strip0) * kOutPairs) - kHaloPairs + (int32_t)lp;
     // horizontal mirror in the interleaved domain: low sample 2J, high sample 2J+1
     // (coordinate c holds sample c - px; a mirrored coordinate keeps its parity)
     const uint32_t js = sw ? ((mirror_idx(2 * J - (int32_t)px, cw) + px) >> 1) - px : 0;
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     const int32_t cE = 2 * J - (int32_t)px, cO = cE + 1;                 // the samples (columns of the level) this lane makes
     const bool st_e = h_lane && cE >= 0 && (uint32_t)cE < cw, st_o = h_lane && cO >= 0 && (uint32_t)cO < cw;
 
-    const int32_t I0 = (int32_t)((blockIdx.y + a.seg0) * a.seg_pairs);
+    const int32_t I0 = (int32_t)((by + a.seg0) * a.seg_pairs);
     const int32_t I1 = min((int32_t)vpairs, I0 + (int32_t)a.seg_pairs);
     // rows [2*I0, 2*I1) are this workgroup's; the recurrences lag behind the input by `lag` pairs
     constexpr int lag  = F97 ? 2 : 1;       // rows 2i and 2i+1 are complete after step i + lag
