@@ -320,27 +320,48 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
         return;
     }
     // ---- un-stuff the MagSgn segment: byte i contributes 8 bits, or 7 if byte i-1 is 0xFF ----------
+    // FOUR bytes per lane and step (256 per wave): the bytes i-1 .. i+3 come out of three aligned dwords with two
+    // v_alignbit, which of them follow a 0xFF is one SWAR test on (prev, b0, b1, b2), the lane packs its <= 32 bits and
+    // a wave prefix sum of the lanes' bit counts places them
     const uint8_t* D = a.coded + in.offset;
     for (uint32_t i = lane; i < raw_words; i += 64) raw[i] = 0;
     __syncthreads();
     uint32_t base_bits = 0;
-    for (uint32_t i0 = 0; i0 < ms_len; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        uint32_t b = 0, wd = 0;
-        if (i < ms_len) {
-            b = D[i];
-            const bool st = i > 0 && D[i - 1] == 0xFFu;
-            wd = st ? 7u : 8u;
-            b &= st ? 0x7Fu : 0xFFu;
+    {
+        const uint8_t* buf_hi = a.coded + a.coded_bytes;
+        // (an aligned dword that starts inside the buffer lies in a mapped page; its bytes past ms_len are masked)
+        auto ld = [&](const uint8_t* q) { return (q >= a.coded && q < buf_hi) ? *reinterpret_cast<const uint32_t*>(q) : 0u; };
+        for (uint32_t i0 = 0; i0 < ms_len; i0 += 256) {
+            const uint32_t i = i0 + 4u * (uint32_t)lane;
+            uint32_t val = 0, tot = 0;
+            if (i < ms_len) {
+                const uint8_t* P = D + i - 1;                                  // the byte before this lane's four
+                const uint8_t* A = P - ((uintptr_t)P & 3u);
+                const uint32_t sh = (uint32_t)((uintptr_t)P & 3u) * 8u;
+                const uint32_t w0 = ld(A), w1 = ld(A + 4), w2 = ld(A + 8);
+                const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);     // prev, b0, b1, b2
+                const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);     // b3, ...
+                uint32_t b = (lo >> 8) | (hi << 24);
+                const uint32_t nv = min(ms_len - i, 4u);
+                b &= 0xFFFFFFFFu >> (32u - 8u * nv);                           // bytes past the segment: dropped
+                uint32_t st = ((lo & 0x7F7F7F7Fu) + 0x01010101u) & lo & 0x80808080u;   // bit 7 of byte k: byte k follows a 0xFF
+                st &= (i == 0) ? 0xFFFFFF00u : 0xFFFFFFFFu;                    // (the first byte follows nothing)
+                b &= ~st;
+                const uint32_t s0 = (st >> 7) & 1u, s1 = (st >> 15) & 1u, s2 = (st >> 23) & 1u, s3 = st >> 31;
+                const uint32_t h1 = 8u - s0, h2 = h1 + 8u - s1, h3 = h2 + 8u - s2;
+                val = (b & 0xFFu) | (((b >> 8) & 0xFFu) << h1) | (((b >> 16) & 0xFFu) << h2) | ((b >> 24) << h3);
+                const uint32_t full = h3 + 8u - s3;                            // bits of four bytes
+                tot = nv == 4 ? full : (nv == 3 ? h3 : (nv == 2 ? h2 : h1));
+            }
+            const uint32_t incl = wave_incl_scan(tot);
+            const uint32_t pos = base_bits + incl - tot;
+            if (tot) {
+                const uint64_t v = (uint64_t)val << (pos & 31);
+                lds_or(&raw[pos >> 5], (uint32_t)v);
+                lds_or(&raw[(pos >> 5) + 1], (uint32_t)(v >> 32));
+            }
+            base_bits += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        const uint32_t incl = wave_incl_scan(wd);
-        const uint32_t pos = base_bits + incl - wd;
-        if (wd) {
-            const uint64_t v = (uint64_t)b << (pos & 31);
-            lds_or(&raw[pos >> 5], (uint32_t)v);
-            lds_or(&raw[(pos >> 5) + 1], (uint32_t)(v >> 32));
-        }
-        base_bits += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     __syncthreads();
     // an exhausted MagSgn segment reads as ones (frwd_read<0xFF>, :823-850)
@@ -357,8 +378,6 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
     const bool refined = ht_block_refined(a, blk, mm);
     const uint32_t* qi = a.quads + (size_t)blk * kQuadWords;
     const uint32_t q = x >> 1, right = x & 1u;
-    const int a_l1 = ((lane - 1) & 63) << 2, a_l2 = ((lane - 2) & 63) << 2;
-    const int a_r1 = ((lane + 1) & 63) << 2, a_r2 = ((lane + 2) & 63) << 2;
     uint32_t Eprev = 0;                                   // exponent of this column's bottom sample, row above
     uint32_t bitpos = 0;
     uint32_t info = col_ok ? qi[q] : 0u;
@@ -367,17 +386,16 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
         if (qy + 1 < QH) info = col_ok ? qi[(qy + 1) * kQuadStride + q] : 0u;     // prefetch next row's quad info
         const uint32_t rho = (cur >> 4) & 0xFu, e1 = (cur >> 8) & 0xFu, ek = (cur >> 12) & 0xFu;
         uint32_t U = cur >> 16;
-        // kappa: max exponent over columns 2q-1 .. 2q+2 of the row above, when more than one sample is significant
+        // kappa: max exponent over columns 2q-1 .. 2q+2 of the row above, when more than one sample is significant.
+        // With lane shifts (DPP wave_shl / wave_shr, zero beyond the wave's ends = outside the block): P[x] = max(E[x], E[x+1]);
+        // the quad's left lane (x = 2q) takes max(P[x-1], P[x+1]), the right lane that lane's value.
         {
-            const uint32_t El1 = bperm(a_l1, Eprev), El2 = bperm(a_l2, Eprev);
-            const uint32_t Er1 = bperm(a_r1, Eprev), Er2 = bperm(a_r2, Eprev);
-            // left lane (x = 2q):  2q-1 = x-1, 2q+1 = x+1, 2q+2 = x+2 ; right lane (x = 2q+1): 2q-1 = x-2, 2q = x-1, 2q+2 = x+1
-            uint32_t far_l = right ? El2 : El1;           // column 2q-1
-            uint32_t far_r = right ? Er1 : Er2;           // column 2q+2
-            const uint32_t mate = right ? El1 : Er1;      // the other column of this quad
-            if (x < (right ? 2u : 1u)) far_l = 0;         // outside the block
-            if (x + (right ? 1u : 2u) > 63u) far_r = 0;
-            const uint32_t E = max(max(Eprev, mate), max(far_l, far_r));
+            const uint32_t Pm = max(Eprev, dpp0<0x130, 0xF>(Eprev));            // wave_shl:1 -> lane x reads x + 1
+            const uint32_t Al = max(max(dpp0<0x138, 0xF>(Pm), dpp0<0x130, 0xF>(Pm)), Eprev);  // wave_shr:1 -> lane x reads x - 1
+                                                                                   // (E[x] itself: lane 0 has no P[-1])
+            // (selected with a mask, not a branch: a lane shift inside a predicated region reads zeros from the disabled lanes)
+            const uint32_t Ar = dpp0<0x138, 0xF>(Al);
+            const uint32_t E = Al ^ ((Al ^ Ar) & (0u - right));
             if (qy > 0 && (rho & (rho - 1))) U += E > 2 ? E - 2 : 0;
         }
         // this lane's two samples: i = 2*right (top) and 2*right + 1 (bottom)
@@ -390,11 +408,10 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
         bitpos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         // up to 62 bits from the raw stream
         const uint32_t wi = pos >> 5, sh = pos & 31;
-        const uint64_t lo = raw[wi] | ((uint64_t)raw[wi + 1] << 32);
-        const uint32_t hi = raw[wi + 2];
-        const uint64_t win = (lo >> sh) | (sh ? ((uint64_t)hi << (64 - sh)) : 0ull);
-        const uint32_t bt = (uint32_t)win & ((1u << mt) - 1u);
-        const uint32_t bb = (uint32_t)(win >> mt) & ((1u << mb) - 1u);
+        const uint32_t r0 = raw[wi], r1 = raw[wi + 1], r2 = raw[wi + 2];
+        const uint32_t win0 = __builtin_amdgcn_alignbit(r1, r0, sh), win1 = __builtin_amdgcn_alignbit(r2, r1, sh);   // 64 bits from pos on
+        const uint32_t bt = win0 & ((1u << mt) - 1u);                                                          // mt, mb <= 31
+        const uint32_t bb = __builtin_amdgcn_alignbit(win1, win0, mt) & ((1u << mb) - 1u);
         const uint32_t vt = bt | (((e1 >> it) & 1u) << mt) | 1u;
         const uint32_t vb = bb | (((e1 >> ib) & 1u) << mb) | 1u;
         const uint32_t wt = st ? ((bt << 31) | ((vt + 2u) << (p - 1u))) : 0u;
@@ -410,9 +427,12 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
             ot = __float_as_int((wt & 0x80000000u) ? -ft : ft);
             ob = __float_as_int((wb & 0x80000000u) ? -fb : fb);
         } else {
-            const int32_t mgt = (int32_t)((wt & 0x7FFFFFFFu) >> p), mgb = (int32_t)((wb & 0x7FFFFFFFu) >> p);
-            ot = (wt & 0x80000000u) ? -mgt : mgt;
-            ob = (wb & 0x80000000u) ? -mgb : mgb;
+            // ((v + 2) << (p - 1)) >> p is (v + 2) >> 1 whatever p: the magnitude comes straight from v, the sign is bit 0 of
+            // the MagSgn value, applied arithmetically
+            const int32_t mgt = st ? (int32_t)((vt + 2u) >> 1) : 0, mgb = sb ? (int32_t)((vb + 2u) >> 1) : 0;
+            const int32_t sgt = -(int32_t)(bt & 1u), sgb = -(int32_t)(bb & 1u);
+            ot = (mgt ^ sgt) - sgt;
+            ob = (mgb ^ sgb) - sgb;
         }
         if (col_ok) {
             const uint32_t y0 = 2 * qy;
