@@ -129,22 +129,22 @@ struct MelReader : WordWindow {   // MEL: forward, MSB first; byte after 0xFF ca
             nxt = load(bp - ((uintptr_t)bp & 7u) + 8);
         }
     }
-    // One MEL event if `need` (:1101-1111): returns 1 if the run ends here with a one.  Written without branches:
-    // lanes of a wave disagree about needing an event / a new run almost every time.
+    // One MEL event if `need` (:1101-1111): returns 1 if the run ends here with a one.  The decode of the next run sits
+    // behind a branch the whole wave skips when no lane has used its run up: in dense blocks (contexts rarely zero) and in
+    // empty ones (long runs) that is most of the time, and every instruction on this chain costs the wave ~8 cycles.
     __device__ __forceinline__ uint32_t event(bool need)
     {
         run -= need ? 2 : 0;
         const uint32_t ev = run == -1;
-        const bool take = run < 0;                                                  // decode the next run (:196-235)
-        const uint32_t e = (uint32_t)(0x5433222111000ull >> (4 * k)) & 0xFu;        // MEL exponents (:196)
-        const uint32_t top = (uint32_t)(tmp >> 32);
-        const bool one = (top >> 31) != 0;                 // '1': 2^e zero events; '0' + e bits: that many, then a one
-        const int r = one ? (int)((2u << e) - 2u) : (int)((((top >> (31u - e)) & ((1u << e) - 1u)) << 1) | 1u);
-        const int kn = one ? (k < 12 ? k + 1 : 12) : (k > 0 ? k - 1 : 0);
-        const uint32_t used = take ? (one ? 1u : e + 1u) : 0u;
-        run = take ? r : run;
-        k = take ? kn : k;
-        tmp <<= used; bits -= (int)used;
+        if (run < 0) {                                                              // decode the next run (:196-235)
+            const uint32_t e = (k < 8 ? 0x22111000u >> (4 * k) : 0x54332u >> (4 * (k - 8))) & 0xFu;   // MEL exponents (:196)
+            const uint32_t top = (uint32_t)(tmp >> 32);
+            const bool one = (top >> 31) != 0;             // '1': 2^e zero events; '0' + e bits: that many, then a one
+            run = one ? (int)((2u << e) - 2u) : (int)((((top >> (31u - e)) & ((1u << e) - 1u)) << 1) | 1u);
+            k = one ? (k < 12 ? k + 1 : 12) : (k > 0 ? k - 1 : 0);
+            const uint32_t used = one ? 1u : e + 1u;
+            tmp <<= used; bits -= (int)used;
+        }
         return ev;
     }
 };
