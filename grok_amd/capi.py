@@ -108,6 +108,7 @@ def lib():
         L.grk_amd_set_decode_steps.argtypes = [vp, vp, u32]
         L.grk_amd_decode_region.argtypes = [vp, PP, vp, vp, u64, i32, u32, u32, u32, u32, vp, i32]
         L.grk_amd_set_overlap.argtypes = [vp, i32]
+        L.grk_amd_set_decode_planes16.argtypes = [vp, i32]
         L.grk_amd_set_pipelining.argtypes = [vp, i32]
         L.grk_amd_stream_wait_results.argtypes = [vp, vp]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
@@ -391,6 +392,9 @@ class Context:
     def set_pipelining(self, on):
         """False / True (two buffer sets) / 2 (three: results valid until the third next call)."""
         self._check(self._L.grk_amd_set_pipelining(self._h, int(on)), "set_pipelining")
+
+    def set_decode_planes16(self, on):
+        self._check(self._L.grk_amd_set_decode_planes16(self._h, int(on)), "set_decode_planes16")
 
     def set_overlap(self, on):
         self._check(self._L.grk_amd_set_overlap(self._h, int(bool(on))), "set_overlap")

@@ -78,6 +78,8 @@ struct grk_amd_ctx {
     bool pipelining = false;
     hipEvent_t ev_main = nullptr;
     bool side_pending = false;       // side-stream work of the latest encode has not been joined on the main stream yet
+    bool dec_planes16 = true;                               // 16-bit planes between K5b and K6 for 8-bit reversible HT tiles
+                                                            // (GRK_AMD_DEC_PLANES16=0 / grk_amd_set_decode_planes16: int32)
     int dwt_xcd = 1;                                        // XCD-aware workgroup order in K2 / K6 (GRK_AMD_DWT_XCD=0: plain)
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
     bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
@@ -406,7 +408,7 @@ RegionPlan plan_region(const grk_amd_tile_params& p, Rect win)
 // d_pixels != nullptr: the last level writes the pixels itself (K7 fused, out_bytes 1 or 2) and d_out is not touched;
 // plan != nullptr: only what the window needs is synthesised, and d_pixels is the window (K7 fused required)
 int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out, void* d_pixels = nullptr,
-             uint32_t ntiles = 0, uint32_t out_bytes = 0, const RegionPlan* plan = nullptr)
+             uint32_t ntiles = 0, uint32_t out_bytes = 0, const RegionPlan* plan = nullptr, bool h16 = false)
 {
     const TileGeom& g = c->geom;
     const uint32_t L = g.p.num_levels;
@@ -436,6 +438,7 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
         a.nplanes = nplanes;
         a.irreversible = g.p.irreversible;
         a.xcd = c->dwt_xcd;
+        a.h16 = h16 ? 1 : 0; a.status = (unsigned int*)c->flag.p;
         const uint32_t sh = (a.ch + a.py + 1) >> 1;
         uint32_t seg = 64;
         const uint64_t strips = (((a.cw + a.px + 1) >> 1) + idwt_strip_pairs() - 1) / idwt_strip_pairs();
@@ -467,7 +470,8 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
     return GRK_AMD_OK;
 }
 
-int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes, void* d_mallat)
+int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes, void* d_mallat,
+                  bool h16 = false)
 {
     const TileGeom& g = c->geom;
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
@@ -493,6 +497,7 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     a.quads = (uint32_t*)c->dec_quads.p; a.ms_len = (uint32_t*)c->dec_mslen.p; a.status = (unsigned int*)c->flag.p;
     a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.irreversible = g.p.irreversible;
+    a.h16 = h16 ? 1 : 0;
     if (!c->dec_seg_first.empty()) {
         // HT blocks with refinement passes: segment 0 = the cleanup pass, segment 1 = SigProp (+ MagRef), end to end
         if (c->dec_seg_first.size() != nblocks + 1 || c->dec_seg_first.back() != c->dec_segs.size())
@@ -565,6 +570,7 @@ int check_decode_status(grk_amd_ctx* c)
     HIP_TRY(c, hipMemcpyAsync(&st, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream), "fetch status");
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     if (st & 4u) return fail(c, GRK_AMD_ERR_INVALID, "corrupt HT code-block (bad Scup or U_q > missing_msbs)");
+    if (st & 8u) return fail(c, GRK_AMD_ERR_RANGE, "a coefficient left the 16-bit planes: decode again after grk_amd_set_decode_planes16(ctx, 0)");
     return GRK_AMD_OK;
 }
 
@@ -675,6 +681,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* e16 = getenv("GRK_AMD_PLANES16")) c->planes16 = atoi(e16) != 0;
         if (const char* ef = getenv("GRK_AMD_FUSE_EGRESS")) c->fuse_egress = atoi(ef) != 0;
         if (const char* ex = getenv("GRK_AMD_DWT_XCD")) c->dwt_xcd = atoi(ex) != 0;
+        if (const char* ed = getenv("GRK_AMD_DEC_PLANES16")) c->dec_planes16 = atoi(ed) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
@@ -815,9 +822,10 @@ int grk_amd_stage_ht_decode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32
 
 static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
                        const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
-                       void* pixels, int pixels_on_device, const Rect* win)
+                       void* pixels, int pixels_on_device, const Rect* win, bool force32 = false)
 {
     if (!c || !p || !table || !coded || !pixels || ntiles == 0) return GRK_AMD_ERR_INVALID;
+    const grk_amd_coded_block* table_in = table;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = join_side(c); if (rc) return rc;        // (the Mallat planes and the status word are shared with the encoder)
     rc = ensure_geom(c, p); if (rc) return rc;
@@ -862,15 +870,21 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
     }
     if (!fuse_out) HIP_TRY(c, c->p0.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc planes");
     HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
+    // 8-bit reversible HT tiles: int16 planes between K5b and K6 (both HBM-side halves of the decode move half the bytes).
+    // Every coefficient and every synthesised LL sample of a stream that an 8-bit image produced fits (the encoder's
+    // planes16_ok bound); a stream whose values do not is reported by decode_status (GRK_AMD_ERR_RANGE), and a synchronous
+    // call decodes it again with int32 planes right here -- never other pixels.
+    const bool h16 = c->dec_planes16 && !force32 && fuse_out && !p->reserved[0] && !g.p.irreversible && g.p.prec <= 8 &&
+                     c->dec_seg_first.empty();
     {
         ScopedTimer t(c, 3);
         rc = p->reserved[0] ? run_t1_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p)
-                            : run_ht_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p);
+                            : run_ht_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p, h16);
         if (rc) return rc;
         // with at least one DWT level and 8-/16-bit pixels the last level writes the pixels itself (K7 fused): the
         // int32 image planes (4 bytes per sample written and read back) never exist
         if (fuse_out) {
-            rc = run_idwt(c, nplanes, c->p1.p, nullptr, d_px, ntiles, bps, win ? &plan : nullptr); if (rc) return rc;
+            rc = run_idwt(c, nplanes, c->p1.p, nullptr, d_px, ntiles, bps, win ? &plan : nullptr, h16); if (rc) return rc;
         } else {
             rc = run_idwt(c, nplanes, c->p1.p, c->p0.p); if (rc) return rc;
             rc = run_egress(c, ntiles, c->p0.p, d_px, bps); if (rc) return rc;
@@ -878,7 +892,10 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
     }
     if (!pixels_on_device) {
         HIP_TRY(c, hipMemcpyAsync(pixels, d_px, px_bytes, hipMemcpyDeviceToHost, c->stream), "download pixels");
-        return check_decode_status(c);
+        rc = check_decode_status(c);
+        if (rc == GRK_AMD_ERR_RANGE && h16)           // (synchronous call: the exact path, at once)
+            return decode_impl(c, p, ntiles, table_in, coded, coded_bytes, coded_on_device, pixels, pixels_on_device, win, true);
+        return rc;
     }
     if (win) HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");      // the adapted table was uploaded from a local
     return GRK_AMD_OK;
@@ -1116,6 +1133,13 @@ int grk_amd_set_pipelining(grk_amd_ctx* c, int on)
     c->pipelining = on != 0 && c->side != nullptr && c->side2 != nullptr;
     c->pipe_depth = on >= 2 ? 3 : 2;
     return rc;
+}
+
+int grk_amd_set_decode_planes16(grk_amd_ctx* c, int on)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    c->dec_planes16 = on != 0;
+    return GRK_AMD_OK;
 }
 
 int grk_amd_set_overlap(grk_amd_ctx* c, int on)

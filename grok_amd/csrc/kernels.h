@@ -102,9 +102,10 @@ struct HtDecArgs {
     const uint8_t* coded; uint64_t coded_bytes; // device buffer holding every block's bytes
     uint32_t* quads;                           // [nblocks][32*32] K5a -> K5b: CxtVLC entry | (u_q + 1) << 16 per quad
     uint32_t* ms_len;                          // [nblocks] MagSgn bytes (0xFFFFFFFF: block rejected)
-    unsigned int* status;                      // bit 2: a block was rejected
+    unsigned int* status;                      // bit 2: a block was rejected; bit 3: a value did not fit the 16-bit planes
     int32_t* mallat; uint32_t stride; uint64_t pitch;
     int irreversible;
+    int h16;                                   // reversible: the planes hold int16 (strides / pitches in elements all the same)
     const uint2* refine;                       // [nblocks] {bytes of the SigProp / MagRef segment at the end of the block's
                                                // data, coding passes in total (1..3)}, or null: cleanup passes only
     uint32_t max_refine_bytes;                 // largest such segment
@@ -148,6 +149,8 @@ struct IdwtLevelArgs {
     // region decode: only the strips [strip0, strip0 + nstrips) x row segments [seg0, seg0 + nsegs) (0 = all)
     uint32_t strip0, nstrips, seg0, nsegs;
     int      xcd;         // XCD-aware workgroup order (as DwtLevelArgs)
+    int      h16;         // reversible: ll / mallat / out hold int16; a synthesised value that does not fit sets bit 3 of *status
+    unsigned int* status;
 };
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s);
 hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, hipStream_t s);

@@ -309,14 +309,18 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
     const uint32_t tile = blk / a.blocks_per_tile;
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t QH = (h + 1) >> 1;
-    int32_t* dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
+    const size_t dst_at = ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
+    int32_t* dst = a.mallat + dst_at;
+    int16_t* dst16 = reinterpret_cast<int16_t*>(a.mallat) + dst_at;       // (a.h16: the same planes with int16 elements)
+    const bool h16 = !IRREV && a.h16 != 0;
     const uint32_t ms_len = a.ms_len[blk];
     const uint32_t x = lane;                              // sample column of this lane
     const bool col_ok = x < w;
 
     if (in.length == 0 && in.missing_msbs == kSkipBlock) return;   // region decode: nobody reads this block's samples
     if (in.length == 0 || ms_len == 0xFFFFFFFFu) {        // absent or rejected block: zeros
-        for (uint32_t y = 0; y < h; ++y) if (col_ok) dst[(size_t)y * a.stride + x] = 0;
+        for (uint32_t y = 0; y < h; ++y)
+            if (col_ok) { if (h16) dst16[(size_t)y * a.stride + x] = 0; else dst[(size_t)y * a.stride + x] = 0; }
         return;
     }
     // ---- un-stuff the MagSgn segment: byte i contributes 8 bits, or 7 if byte i-1 is 0xFF ----------
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
     const uint32_t q = x >> 1, right = x & 1u;
     uint32_t Eprev = 0;                                   // exponent of this column's bottom sample, row above
     uint32_t bitpos = 0;
+    uint32_t range = 0;
     uint32_t info = col_ok ? qi[q] : 0u;
     for (uint32_t qy = 0; qy < QH; ++qy) {
         const uint32_t cur = info;
@@ -436,10 +441,17 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
         }
         if (col_ok) {
             const uint32_t y0 = 2 * qy;
-            dst[(size_t)y0 * a.stride + x] = ot;
-            if (y0 + 1 < h) dst[(size_t)(y0 + 1) * a.stride + x] = ob;
+            if (h16) {
+                dst16[(size_t)y0 * a.stride + x] = (int16_t)ot;
+                if (y0 + 1 < h) dst16[(size_t)(y0 + 1) * a.stride + x] = (int16_t)ob;
+                range |= (uint32_t)(ot + 32768) | (uint32_t)(ob + 32768);          // >= 65536: does not fit
+            } else {
+                dst[(size_t)y0 * a.stride + x] = ot;
+                if (y0 + 1 < h) dst[(size_t)(y0 + 1) * a.stride + x] = ob;
+            }
         }
     }
+    if (h16 && __builtin_amdgcn_ballot_w64(range > 0xFFFFu) != 0 && lane == 0) atomicOr(a.status, 8u);
 }
 
 // ---- K5c: the refinement passes, ONE WAVEFRONT PER CODE-BLOCK ---------------------------------------------------------

@@ -157,10 +157,15 @@ __device__ __forceinline__ void egress_px(int32_t (&c)[NC], bool irrev, bool mct
 // PXO = 1 / 2: the LAST level fused with K7 -- NC (= 3 with MCT) components are synthesised side by side and the
 //   finished rows leave as 8- / 16-bit pixels after the inverse colour transform, DC shift and clamp, so the
 //   int32 image planes (4 B/sample written + read back by K7) never exist.
-template <bool F97, int NC, int PXO>
+// H16 (reversible only): ll / mallat / out hold int16 coefficients -- half the bytes this HBM-bound kernel moves; a synthesised
+//   value that does not fit (only a stream no 8-bit image produces) raises bit 3 of *a.status and the decode is reported
+//   as out of range instead of returning other pixels.
+template <bool F97, int NC, int PXO, bool H16 = false>
 __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
 {
+    static_assert(!(F97 && H16), "16-bit planes are for the reversible transform");
     using T  = typename std::conditional<F97, float, int32_t>::type;
+    using PT = typename std::conditional<H16, int16_t, T>::type;             // element type of the planes in memory
     using T2 = typename std::conditional<F97, float2, int2>::type;
     using PIX = typename std::conditional<PXO == 2, uint16_t, uint8_t>::type;
     static_assert(PXO != 0 || NC == 1, "plane output is one component per workgroup");
@@ -185,9 +190,10 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
 
     uint32_t plane0 = bz;
     if constexpr (PXO != 0) plane0 = (bz / a.zdiv) * a.ncomp + a.comp0 + (bz % a.zdiv);
-    const T* ll = reinterpret_cast<const T*>(a.ll) + (size_t)plane0 * a.ll_pitch;
-    const T* mp = reinterpret_cast<const T*>(a.mallat) + (size_t)plane0 * a.m_pitch;
-    T* out = reinterpret_cast<T*>(a.out) + (size_t)plane0 * a.out_pitch;
+    const PT* ll = reinterpret_cast<const PT*>(a.ll) + (size_t)plane0 * a.ll_pitch;
+    const PT* mp = reinterpret_cast<const PT*>(a.mallat) + (size_t)plane0 * a.m_pitch;
+    PT* out = reinterpret_cast<PT*>(a.out) + (size_t)plane0 * a.out_pitch;
+    uint32_t range = 0;
     // pixel output: the window [wx0, wx1) x [wy0, wy1) of the tile (the whole tile unless a region is decoded), tight
     const uint32_t win_w = a.wx1 - a.wx0;
     const size_t comp_px = (size_t)win_w * (a.wy1 - a.wy0);
@@ -220,12 +226,12 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
         const bool lc = sw > 0, hc = cw > sw, lr = sh > 0, hr = ch > sh;    // which halves exist (single row / column)
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-            const T* llk = ll + (size_t)k * a.ll_pitch;
-            const T* mpk = mp + (size_t)k * a.m_pitch;
-            q.ls[k] = (lr && lc) ? llk[(size_t)is * a.ll_stride + js] : T(0);
-            q.ld[k] = (lr && hc) ? mpk[(size_t)is * a.m_stride + sw + jd] : T(0);
-            q.hs[k] = (hr && lc) ? mpk[(size_t)(sh + id) * a.m_stride + js] : T(0);
-            q.hd[k] = (hr && hc) ? mpk[(size_t)(sh + id) * a.m_stride + sw + jd] : T(0);
+            const PT* llk = ll + (size_t)k * a.ll_pitch;
+            const PT* mpk = mp + (size_t)k * a.m_pitch;
+            q.ls[k] = (lr && lc) ? (T)llk[(size_t)is * a.ll_stride + js] : T(0);
+            q.ld[k] = (lr && hc) ? (T)mpk[(size_t)is * a.m_stride + sw + jd] : T(0);
+            q.hs[k] = (hr && lc) ? (T)mpk[(size_t)(sh + id) * a.m_stride + js] : T(0);
+            q.hd[k] = (hr && hc) ? (T)mpk[(size_t)(sh + id) * a.m_stride + sw + jd] : T(0);
         }
     };
     // one finished row of this lane's two columns leaves the kernel: as a plane row, or as pixels
@@ -234,8 +240,15 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     const bool in_o = cO >= (int32_t)a.wx0 && cO < (int32_t)a.wx1;
     auto emit = [&](int32_t r, const T (&vA)[NC], const T (&vB)[NC]) {
         if constexpr (PXO == 0) {
-            T* row = out + (size_t)r * a.out_stride + cE;
-            if (st_e && st_o && !px) { T2 v; v.x = vA[0]; v.y = vB[0]; *reinterpret_cast<T2*>(row) = v; }
+            PT* row = out + (size_t)r * a.out_stride + cE;
+            if constexpr (H16) {
+                if (st_e && st_o && !px) *reinterpret_cast<uint32_t*>(row) = ((uint32_t)vA[0] & 0xFFFFu) | ((uint32_t)vB[0] << 16);
+                else {
+                    if (st_e) row[0] = (int16_t)vA[0];
+                    if (st_o) row[1] = (int16_t)vB[0];
+                }
+                range |= (st_e ? (uint32_t)(vA[0] + 32768) : 0u) | (st_o ? (uint32_t)(vB[0] + 32768) : 0u);
+            } else if (st_e && st_o && !px) { T2 v; v.x = vA[0]; v.y = vB[0]; *reinterpret_cast<T2*>(row) = v; }
             else {
                 if (st_e) row[0] = vA[0];
                 if (st_o) row[1] = vB[0];
@@ -316,6 +329,9 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
         }
         cur = nxt;
     }
+    if constexpr (H16 && PXO == 0) {
+        if (range > 0xFFFFu) atomicOr(a.status, 8u);
+    }
 }
 
 // ---- K7 egress, stand-alone (stage entry point; pixel sizes the fused last level does not cover) ----------
@@ -388,6 +404,8 @@ hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s)
     dim3 block(kThreads);
     if (a.irreversible)
         hipLaunchKernelGGL((idwt_level_kernel<true, 1, 0>), grid, block, 0, s, a);
+    else if (a.h16)
+        hipLaunchKernelGGL((idwt_level_kernel<false, 1, 0, true>), grid, block, 0, s, a);
     else
         hipLaunchKernelGGL((idwt_level_kernel<false, 1, 0>), grid, block, 0, s, a);
     return hipGetLastError();
@@ -408,6 +426,11 @@ hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, ui
         if (a.irreversible) {
             if (nc == 3) { if (px == 1) GRK_I0(true, 3, 1); else GRK_I0(true, 3, 2); }
             else         { if (px == 1) GRK_I0(true, 1, 1); else GRK_I0(true, 1, 2); }
+        } else if (a.h16) {
+            if (nc == 3) { if (px == 1) hipLaunchKernelGGL((idwt_level_kernel<false, 3, 1, true>), grid, block, 0, s, a);
+                           else         hipLaunchKernelGGL((idwt_level_kernel<false, 3, 2, true>), grid, block, 0, s, a); }
+            else         { if (px == 1) hipLaunchKernelGGL((idwt_level_kernel<false, 1, 1, true>), grid, block, 0, s, a);
+                           else         hipLaunchKernelGGL((idwt_level_kernel<false, 1, 2, true>), grid, block, 0, s, a); }
         } else {
             if (nc == 3) { if (px == 1) GRK_I0(false, 3, 1); else GRK_I0(false, 3, 2); }
             else         { if (px == 1) GRK_I0(false, 1, 1); else GRK_I0(false, 1, 2); }

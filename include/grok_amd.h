@@ -41,6 +41,7 @@ extern "C" {
 #define GRK_AMD_ERR_INVALID      -3   /* bad argument                                   */
 #define GRK_AMD_ERR_NOMEM        -4
 #define GRK_AMD_ERR_OVERFLOW     -5   /* coded data did not fit the arena               */
+#define GRK_AMD_ERR_RANGE        -6   /* decode: a value left the 16-bit planes (see grk_amd_set_decode_planes16) */
 
 #define GRK_AMD_MAX_LEVELS 10
 
@@ -171,6 +172,12 @@ int grk_amd_decode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes,
                          int coded_on_device, void* pixels, int pixels_on_device);
 int grk_amd_decode_status(grk_amd_ctx* ctx);
+/* 8-bit reversible HT tiles are decoded with int16 planes between the block decoder and the inverse DWT (default on; half
+ * the bytes of the two HBM-bound halves of the decode).  Every coefficient and every synthesised LL sample of a stream that
+ * an 8-bit image produced fits; a stream whose values do not is never decoded to other pixels: a synchronous call (host
+ * pixels) decodes it again with int32 planes by itself, an asynchronous one reports GRK_AMD_ERR_RANGE from
+ * grk_amd_decode_status() and the caller repeats the call after grk_amd_set_decode_planes16(ctx, 0). */
+int grk_amd_set_decode_planes16(grk_amd_ctx* ctx, int on);
 /* Region (windowed) decode of ONE tile -- what grk_decompress_set_window() + grk_decompress() do on the host
  * (grok.h; partial synthesis: transform/WaveletReverse.cpp:1466-2213, tile/SparseBuffer.h): the pixels of the window
  * [x0, x1) x [y0, y1) of the tile, component-major planar, tight, (x1 - x0) * (y1 - y0) samples per component --

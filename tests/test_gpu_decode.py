@@ -628,3 +628,48 @@ def test_fused_last_level_equals_separate_egress(C, H, W, prec, L, irrev, monkey
     assert np.array_equal(out["1"], out["0"])
     if not irrev:
         assert np.array_equal(out["1"], px)
+
+
+def test_decode_int16_planes_and_their_range_check():
+    """8-bit reversible HT tiles are decoded with int16 planes between K5b and K6 (default).  Same pixels as with int32
+    planes on ordinary and on extreme (0 / 255 checkerboard) content; a stream whose values do NOT fit -- here the blocks of
+    a 16-bit checkerboard decoded as if they belonged to an 8-bit tile -- is never decoded to other pixels: the
+    synchronous call repeats itself with int32 planes, the asynchronous one reports it."""
+    c = U.ctx()
+    H, W, L = 256, 320, 5
+    yy, xx = np.mgrid[0:H, 0:W]
+    # (a 0 / 255 checkerboard itself is rejected by both decoders, defect D5; so is one with different phases per channel: the RCT doubles it)
+    for px in (synth.g2(3, H, W, 8), np.stack([((yy + xx) & 1) * 150 + 50 for k in range(3)]).astype(np.uint8)):
+        p = G.TileParams.make(W, H, 3, 8, L)
+        table, coded = c.encode_host(p, px)
+        a = c.decode_host(p, table, coded)[0]
+        c.set_decode_planes16(False)
+        try:
+            b = c.decode_host(p, table, coded)[0]
+        finally:
+            c.set_decode_planes16(True)
+        assert np.array_equal(a, px) and np.array_equal(b, px)
+    # out of range for int16: the blocks of a 16-bit half-scale checkerboard under 8-bit parameters
+    px12 = (((yy + xx) & 1) * 30000 + 10000).astype(np.uint16)[None]
+    p12 = G.TileParams.make(W, H, 1, 16, L)
+    table, coded = c.encode_host(p12, px12)
+    p8 = G.TileParams.make(W, H, 1, 8, L)
+    c.set_decode_planes16(False)
+    try:
+        want = c.decode_host(p8, table, coded)[0]
+    finally:
+        c.set_decode_planes16(True)
+    got = c.decode_host(p8, table, coded)[0]                # int16 planes -> range flag -> repeated with int32 planes
+    assert np.array_equal(got, want)
+    d_c = U.to_dev(np.concatenate([coded, np.zeros(64, np.uint8)]))
+    out = torch.zeros(H * W, dtype=torch.uint8, device="cuda")
+    c.decode_device(p8, 1, table, d_c.data_ptr(), coded.size, out.data_ptr())
+    with pytest.raises(RuntimeError, match="16-bit planes"):
+        c.decode_status()
+    c.set_decode_planes16(False)
+    try:
+        c.decode_device(p8, 1, table, d_c.data_ptr(), coded.size, out.data_ptr())
+        c.decode_status()
+    finally:
+        c.set_decode_planes16(True)
+    assert np.array_equal(out.cpu().numpy().reshape(1, H, W), want)
