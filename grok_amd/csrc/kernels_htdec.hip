@@ -234,6 +234,9 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
             sn = (sn >> 4) | ((uint64_t)sb << 60);
             // ---- u values of the pair (:668-777), written without branches: prefix0, prefix1, suffix0, suffix1,
             // each present only if its quad has u_off set
+            // (r02: the same by ONE look-up in a 256-entry LDS table -- u_off of both quads + six bits -> prefix / suffix
+            //  lengths and bases -- removed ~25 instructions from the chain and was 3 % SLOWER: the look-up's latency sits on
+            //  the chain as well)
             const uint32_t uo0 = (t0 >> 3) & 1u, uo1 = (t1 >> 3) & 1u;
             uint32_t add = 1, onebit = 0;
             uint32_t v = vlc.peek();
