@@ -385,22 +385,31 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
 // A synthesised sample depends on the pairs within 1 (5/3) or 2 (9/7) of its own, the kernel's strip halo and the
 // recurrence warm-up reach 2 pairs further: the margins below are conservative on purpose.
 struct Rect { uint32_t x0, y0, x1, y1; };
-struct RegionPlan { std::vector<Rect> need, pairs; };
-RegionPlan plan_region(const grk_amd_tile_params& p, Rect win)
+struct RegionPlan { std::vector<Rect> need, pairs; std::vector<uint32_t> px, py; };
+// (a level that starts on an odd coordinate works on the coordinate grid shifted by the parity, kernels_idwt.hip: sample c
+//  of the level belongs to pair (c + parity) / 2, pair J's low-pass sample has index J - parity, its high-pass sample J)
+RegionPlan plan_region(const TileGeom& g, Rect win)
 {
     RegionPlan r;
-    const uint32_t L = p.num_levels, M = p.irreversible ? 4u : 2u;
-    r.need.resize(L + 1); r.pairs.resize(L);
+    const uint32_t L = g.p.num_levels, M = g.p.irreversible ? 4u : 2u;
+    r.need.resize(L + 1); r.pairs.resize(L); r.px.resize(L); r.py.resize(L);
     r.need[0] = win;
+    auto sat = [](uint32_t a, uint32_t b) { return a > b ? a - b : 0u; };
     for (uint32_t l = 0; l < L; ++l) {
-        const uint32_t cw = ceil_div_pow2(p.tile_w, l), ch = ceil_div_pow2(p.tile_h, l);
-        const uint32_t sw = (cw + 1) >> 1, sh = (ch + 1) >> 1;
+        const ResGeom& R = level_geom(g, l);
+        const uint32_t px = R.x0 & 1u, py = R.y0 & 1u;
+        const uint32_t npx = (R.w + px + 1) >> 1, npy = (R.h + py + 1) >> 1;       // pairs on the coordinate grid
+        const uint32_t sw = (R.w + 1 - px) >> 1, sh = (R.h + 1 - py) >> 1;         // low-pass samples
+        r.px[l] = px; r.py[l] = py;
         const Rect n = r.need[l];
         Rect q;
-        q.x0 = n.x0 / 2 > M ? n.x0 / 2 - M : 0; q.y0 = n.y0 / 2 > M ? n.y0 / 2 - M : 0;
-        q.x1 = std::min(sw, (n.x1 - 1) / 2 + M + 1); q.y1 = std::min(sh, (n.y1 - 1) / 2 + M + 1);
+        q.x0 = sat((n.x0 + px) / 2, M); q.y0 = sat((n.y0 + py) / 2, M);
+        q.x1 = std::min(npx, (n.x1 - 1 + px) / 2 + M + 1); q.y1 = std::min(npy, (n.y1 - 1 + py) / 2 + M + 1);
         r.pairs[l] = q;
-        r.need[l + 1] = q;
+        Rect lo;                                             // what of LL_{l+1} those pairs read
+        lo.x0 = std::min(sat(q.x0, px), sw); lo.y0 = std::min(sat(q.y0, py), sh);
+        lo.x1 = std::min(std::max(sat(q.x1, px), lo.x0 + 1), sw); lo.y1 = std::min(std::max(sat(q.y1, py), lo.y0 + 1), sh);
+        r.need[l + 1] = lo;
     }
     return r;
 }
@@ -451,8 +460,8 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
             const uint32_t op = idwt_strip_pairs();
             seg = 16;
             a.seg_pairs = seg;
-            a.strip0 = (n.x0 / 2) / op; a.nstrips = ((n.x1 - 1) / 2) / op - a.strip0 + 1;
-            a.seg0 = (n.y0 / 2) / seg; a.nsegs = ((n.y1 - 1) / 2) / seg - a.seg0 + 1;
+            a.strip0 = ((n.x0 + a.px) / 2) / op; a.nstrips = ((n.x1 - 1 + a.px) / 2) / op - a.strip0 + 1;
+            a.seg0 = ((n.y0 + a.py) / 2) / seg; a.nsegs = ((n.y1 - 1 + a.py) / 2) / seg - a.seg0 + 1;
             if (l == 0) { a.wx0 = n.x0; a.wy0 = n.y0; a.wx1 = n.x1; a.wy1 = n.y1; }
         }
         if (a.cw == 0 || a.ch == 0) continue;       // (a level without samples, see run_dwt)
@@ -840,15 +849,27 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
         if (ntiles != 1 || win->x0 >= win->x1 || win->y0 >= win->y1 || win->x1 > g.p.tile_w || win->y1 > g.p.tile_h)
             return fail(c, GRK_AMD_ERR_INVALID, "window outside the tile");
         if (!fuse_out) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "region decode needs at least one DWT level and 8-/16-bit pixels");
-        if (g.p.tile_x0 || g.p.tile_y0) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "region decode of a tile off the origin");
-        plan = plan_region(g.p, *win);
+        plan = plan_region(g, *win);
         const uint32_t L = g.p.num_levels;
         wtable.assign(table, table + (size_t)g.blocks_per_comp * g.p.num_comps);
         size_t i = 0;
+        auto sat = [](uint32_t a, uint32_t b) { return a > b ? a - b : 0u; };
         for (uint32_t k = 0; k < g.p.num_comps; ++k)
             for (const auto& b : g.blocks_comp0) {
-                const Rect& need = b.res == 0 ? plan.need[L] : plan.pairs[L - b.res];
-                if (b.x0 >= need.x1 || b.x1 <= need.x0 || b.y0 >= need.y1 || b.y1 <= need.y0) {
+                // the block in its band's own index space against what the synthesis reads of that band: low-pass indices
+                // are pair - parity, high-pass indices the pair itself
+                const BandGeom& B = g.res[b.res].band[b.res ? b.band - 1 : 0];
+                Rect need;
+                if (b.res == 0) need = plan.need[L];
+                else {
+                    const uint32_t l = L - b.res;
+                    const Rect& q = plan.pairs[l];
+                    const uint32_t px = plan.px[l], py = plan.py[l];
+                    need.x0 = (b.band & 1) ? q.x0 : sat(q.x0, px); need.x1 = (b.band & 1) ? q.x1 : sat(q.x1, px);
+                    need.y0 = (b.band & 2) ? q.y0 : sat(q.y0, py); need.y1 = (b.band & 2) ? q.y1 : sat(q.y1, py);
+                }
+                const uint32_t bx0 = b.x0 - B.x0, bx1 = b.x1 - B.x0, by0 = b.y0 - B.y0, by1 = b.y1 - B.y0;
+                if (bx0 >= need.x1 || bx1 <= need.x0 || by0 >= need.y1 || by1 <= need.y0) {
                     wtable[i].offset = 0; wtable[i].length = 0; wtable[i].missing_msbs = kSkipBlock;
                 }
                 ++i;

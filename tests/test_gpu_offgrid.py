@@ -178,9 +178,25 @@ def test_decode_reference_stream_off_the_origin(monkeypatch, off, ht, irrev):
     assert done >= 7
 
 
-def test_region_decode_declines_off_the_origin():
-    px = synth.g2(1, 64, 64, 8)
-    p = G.TileParams.make(64, 64, 1, 8, 3, origin=(1, 1))
-    table, coded = U.ctx().encode_host(p, px)
-    with pytest.raises(RuntimeError):
-        U.ctx().decode_region_host(p, table, coded, 8, 8, 24, 24)
+@pytest.mark.parametrize("C,W,H,L,org,irrev", [(1, 64, 64, 3, (1, 1), False), (3, 469, 311, 5, (33, 95), False), (3, 300, 200, 4, (7, 0), True),
+                                                  (1, 999, 999, 5, (1, 1), False), (3, 130, 70, 2, (7, 3), False), (1, 40, 1, 2, (0, 1), False)])
+def test_region_decode_off_the_origin_equals_crop_of_full_decode(C, W, H, L, org, irrev):
+    """grk_amd_decode_region of a tile anywhere on the canonical grid: the window's pixels == the same crop of the full decode
+    (the planes are poisoned with another image's coefficients first, so a block or strip wrongly skipped would show)."""
+    rng = np.random.default_rng(W + org[0])
+    px = synth.g2(C, H, W, 8, seed=5 + W)
+    p = G.TileParams.make(W, H, C, 8, L, irreversible=irrev, origin=org)
+    c = U.ctx()
+    table, coded = c.encode_host(p, px)
+    t2, c2 = c.encode_host(p, synth.g2(C, H, W, 8, seed=77 + W))
+    full = c.decode_host(p, table, coded)[0]
+    if not irrev:
+        assert np.array_equal(full, px)
+    wins = [(0, 0, W, H), (0, 0, min(W, 9), min(H, 7)), (W - min(W, 5), H - min(H, 3), W, H)]
+    for _ in range(6):
+        x0, y0 = int(rng.integers(0, W)), int(rng.integers(0, H))
+        wins.append((x0, y0, int(rng.integers(x0 + 1, W + 1)), int(rng.integers(y0 + 1, H + 1))))
+    for (x0, y0, x1, y1) in wins:
+        c.decode_host(p, t2, c2)                                  # poison
+        got = c.decode_region_host(p, table, coded, x0, y0, x1, y1)
+        assert np.array_equal(got, full[:, y0:y1, x0:x1]), (x0, y0, x1, y1)

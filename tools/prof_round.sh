@@ -14,7 +14,7 @@ if [[ "$WHAT" == *stats* ]]; then
   cp $(find /tmp/ks1 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
   timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks2 -o p --output-format csv -- python $R/bench.py --steps 20 --no-overlap --no-host-boundary > $OUT/${TAG}_bench_under_rocprof_no_overlap.json 2> /tmp/ks2.err
   cp $(find /tmp/ks2 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_no_overlap.csv
-  tail -2 /tmp/ks1.err /tmp/ks2.err
+  tail -n 2 /tmp/ks1.err; tail -n 2 /tmp/ks2.err
 fi
 if [[ "$WHAT" == *pmc* ]]; then
   export GRK_AMD_OVERLAP=0 PROF_N=4
