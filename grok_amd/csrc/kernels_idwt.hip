@@ -203,14 +203,20 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     // wave's loads and stores start on cache-line boundaries; the next 2 * kHaloPairs lanes fetch the halo pairs left
     // and right of the strip.  lp = position in the staged line.
     const uint32_t lp = t < (uint32_t)kOutPairs ? t + kHaloPairs : (t < (uint32_t)(kOutPairs + kHaloPairs) ? t - kOutPairs : t);
-    const int32_t J = (int32_t)((bx + a.strip0) * kOutPairs) - kHaloPairs + (int32_t)lp;
-    // horizontal mirror in the interleaved domain: low sample 2J, high sample 2J+1
-    // (coordinate c holds sample c - px; a mirrored coordinate keeps its parity)
-    const uint32_t js = sw ? ((mirror_idx(2 * J - (int32_t)px, cw) + px) >> 1) - px : 0;
-    const uint32_t jd = cw > sw ? (mirror_idx(2 * J + 1 - (int32_t)px, cw) + px - 1) >> 1 : 0;
+    // (lanes past the halo pairs ride along: they repeat the last halo lane's loads)
+    const int32_t J = (int32_t)((bx + a.strip0) * kOutPairs) - kHaloPairs + (int32_t)min(lp, (uint32_t)(kOutPairs + 2 * kHaloPairs - 1));
     const bool h_lane = t < (uint32_t)kOutPairs;
     const int32_t cE = 2 * J - (int32_t)px, cO = cE + 1;                 // the samples (columns of the level) this lane makes
-    const bool st_e = h_lane && cE >= 0 && (uint32_t)cE < cw, st_o = h_lane && cO >= 0 && (uint32_t)cO < cw;
+    // Interior strips of an even-sized level on an even origin, the whole tile wanted, take the FAST instance: no column
+    // mirroring, no per-lane store predicates, no window tests -- the last level is as VALU-bound as it is HBM-bound
+    // (SQ counters: 286 VALU per row pair and wave against the forward level 0's 184).
+    auto body = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    // horizontal mirror in the interleaved domain: low sample 2J, high sample 2J+1
+    // (coordinate c holds sample c - px; a mirrored coordinate keeps its parity)
+    const uint32_t js = FAST ? (uint32_t)J : (sw ? ((mirror_idx(2 * J - (int32_t)px, cw) + px) >> 1) - px : 0);
+    const uint32_t jd = FAST ? (uint32_t)J : (cw > sw ? (mirror_idx(2 * J + 1 - (int32_t)px, cw) + px - 1) >> 1 : 0);
+    const bool st_e = h_lane && (FAST || (cE >= 0 && (uint32_t)cE < cw)), st_o = h_lane && (FAST || (cO >= 0 && (uint32_t)cO < cw));
 
     const int32_t I0 = (int32_t)((by + a.seg0) * a.seg_pairs);
     const int32_t I1 = min((int32_t)vpairs, I0 + (int32_t)a.seg_pairs);
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
         // vertical mirror in the interleaved domain: low row 2i, high row 2i+1
         const uint32_t is = sh ? ((mirror_row(2 * i - (int32_t)py, ch) + py) >> 1) - py : 0;
         const uint32_t id = ch > sh ? (mirror_row(2 * i + 1 - (int32_t)py, ch) + py - 1) >> 1 : 0;
-        const bool lc = sw > 0, hc = cw > sw, lr = sh > 0, hr = ch > sh;    // which halves exist (single row / column)
+        const bool lc = FAST || sw > 0, hc = FAST || cw > sw, lr = FAST || sh > 0, hr = FAST || ch > sh;    // which halves exist (single row / column)
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const PT* llk = ll + (size_t)k * a.ll_pitch;
@@ -235,9 +241,9 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
         }
     };
     // one finished row of this lane's two columns leaves the kernel: as a plane row, or as pixels
-    const bool px_vec = ((win_w | a.wx0 | px) & 1u) == 0;   // tightly packed pixel rows: pairs are aligned only for even widths / origins
-    const bool in_e = cE >= (int32_t)a.wx0 && cE < (int32_t)a.wx1;
-    const bool in_o = cO >= (int32_t)a.wx0 && cO < (int32_t)a.wx1;
+    const bool px_vec = FAST || ((win_w | a.wx0 | px) & 1u) == 0;   // tightly packed pixel rows: pairs are aligned only for even widths / origins
+    const bool in_e = FAST || (cE >= (int32_t)a.wx0 && cE < (int32_t)a.wx1);
+    const bool in_o = FAST || (cO >= (int32_t)a.wx0 && cO < (int32_t)a.wx1);
     auto emit = [&](int32_t r, const T (&vA)[NC], const T (&vB)[NC]) {
         if constexpr (PXO == 0) {
             PT* row = out + (size_t)r * a.out_stride + cE;
@@ -264,8 +270,9 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
             egress_px<NC>(cB, F97, a.mct != 0, a.dc, a.lo, a.hi);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                if ((uint32_t)r < a.wy0 || (uint32_t)r >= a.wy1) continue;
-                PIX* row = pix + (size_t)k * comp_px + (size_t)((uint32_t)r - a.wy0) * win_w + (cE - (int32_t)a.wx0);
+                if (!FAST && ((uint32_t)r < a.wy0 || (uint32_t)r >= a.wy1)) continue;
+                PIX* row = FAST ? pix + (size_t)k * comp_px + (size_t)r * cw + cE
+                                : pix + (size_t)k * comp_px + (size_t)((uint32_t)r - a.wy0) * win_w + (cE - (int32_t)a.wx0);
                 if (st_o && px_vec && in_e && in_o) {
                     if constexpr (PXO == 1) *reinterpret_cast<uchar2*>(row) = make_uchar2((uint8_t)cA[k], (uint8_t)cB[k]);
                     else                    *reinterpret_cast<ushort2*>(row) = make_ushort2((uint16_t)cA[k], (uint16_t)cB[k]);
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 T se, so, de, dodd;                           // low row / high row, even / odd column
-                if (cw == 1) {
+                if (!FAST && cw == 1) {
                     if (px) {          // a lone high-pass column: coordinate 1 of pair 0
                         const T v0 = line[par][k][0][1][lp], v1 = line[par][k][1][1][lp];
                         se = 0; de = 0;
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
                     hs53(&line[par][k][0][0][lp], &line[par][k][0][1][lp], se, so);
                     hs53(&line[par][k][1][0][lp], &line[par][k][1][1][lp], de, dodd);
                 }
-                if (ch == 1) {
+                if (!FAST && ch == 1) {
                     if (py) {          // a lone high-pass row
                         if constexpr (F97) { eA[k] = de; eB[k] = dodd; } else { eA[k] = de >> 1; eB[k] = dodd >> 1; }
                     } else { eA[k] = se; eB[k] = so; }
@@ -320,14 +327,23 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
                 else { colA[k].step(se, de, oA[k], eA[k]); colB[k].step(so, dodd, oB[k], eB[k]); }
             }
             // which output rows these are: coordinates, then rows of the level (coordinate - py)
-            const int32_t r_even = ch == 1 ? (int32_t)py : 2 * (i - (lag - 1));
+            const int32_t r_even = (!FAST && ch == 1) ? (int32_t)py : 2 * (i - (lag - 1));
             const int32_t r_odd = r_even - 1;              // 5/3: 2i-1 ; 9/7: 2(i-2)+1
-            const bool ok_e = ch == 1 ? (i == 0) : (r_even >= 2 * I0 && r_even < 2 * I1 && r_even >= (int32_t)py && (uint32_t)(r_even - (int32_t)py) < ch);
-            const bool ok_o = ch > 1 && r_odd >= 2 * I0 && r_odd < 2 * I1 && r_odd >= (int32_t)py && (uint32_t)(r_odd - (int32_t)py) < ch;
-            if (ok_e) emit(r_even - (int32_t)py, eA, eB);
-            if (ok_o) emit(r_odd - (int32_t)py, oA, oB);
+            const int32_t pyi = FAST ? 0 : (int32_t)py;
+            const bool ok_e = (!FAST && ch == 1) ? (i == 0) : (r_even >= 2 * I0 && r_even < 2 * I1 && r_even >= pyi && (uint32_t)(r_even - pyi) < ch);
+            const bool ok_o = (FAST || ch > 1) && r_odd >= 2 * I0 && r_odd < 2 * I1 && r_odd >= pyi && (uint32_t)(r_odd - pyi) < ch;
+            if (ok_e) emit(r_even - pyi, eA, eB);
+            if (ok_o) emit(r_odd - pyi, oA, oB);
         }
         cur = nxt;
+    }
+    };
+    {
+        // every pair any lane touches lies inside both half-bands (halo and ride-along lanes included)
+        const int32_t Jlo = (int32_t)((bx + a.strip0) * kOutPairs) - kHaloPairs, Jhi = Jlo + kOutPairs + 2 * kHaloPairs - 1;
+        bool fast = (px | py) == 0 && (cw & 1u) == 0 && ch >= 16 && Jlo >= 0 && (uint32_t)Jhi < (cw >> 1);
+        if constexpr (PXO != 0) fast = fast && a.wx0 == 0 && a.wy0 == 0 && a.wx1 == cw && a.wy1 == ch;
+        if (fast) body(std::true_type{}); else body(std::false_type{});
     }
     if constexpr (H16 && PXO == 0) {
         if (range > 0xFFFFu) atomicOr(a.status, 8u);

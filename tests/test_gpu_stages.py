@@ -400,3 +400,27 @@ def test_random_geometries_encode_and_decode(C, H, W, prec, L, irrev, sgnd, mct)
     assert np.array_equal(back.view(px.dtype).astype(np.int32), ref.astype(np.int32))
     if not irrev:
         assert np.array_equal(back.view(px.dtype), px)
+
+
+@pytest.mark.parametrize("C,H,W,L,irrev", [(3, 1024, 1536, 5, False), (3, 700, 1500, 4, True), (1, 333, 2111, 3, False)])
+def test_xcd_aware_workgroup_order_changes_nothing_but_the_order(C, H, W, L, irrev, monkeypatch):
+    """K2 / K6 map workgroups to (strip, row segment, plane) so that the strips an XCD works on are neighbours
+    (GRK_AMD_DWT_XCD, default 1; grids whose size is no multiple of 8 included): identical blocks and identical pixels
+    with the plain order of GRK_AMD_DWT_XCD=0, and both equal to the oracle."""
+    px = synth.g2(C, H, W, 8, seed=H)
+    p = G.TileParams.make(W, H, C, 8, L, irreversible=irrev)
+    got = {}
+    for xcd in ("1", "0"):
+        monkeypatch.setenv("GRK_AMD_DWT_XCD", xcd)
+        c = G.Context(0)
+        try:
+            t, coded = c.encode_host(p, px)
+            got[xcd] = (U.split_blocks(t, coded), c.decode_host(p, t, coded)[0])
+        finally:
+            c.close()
+    assert got["1"][0] == got["0"][0]
+    assert np.array_equal(got["1"][1], got["0"][1])
+    if not irrev:
+        assert np.array_equal(got["1"][1], px)
+        _, _, _, otable, ocoded = chain.encode_tile_oracle(px, 8, L)
+        assert got["1"][0] == [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
