@@ -200,3 +200,34 @@ def test_region_decode_off_the_origin_equals_crop_of_full_decode(C, W, H, L, org
         c.decode_host(p, t2, c2)                                  # poison
         got = c.decode_region_host(p, table, coded, x0, y0, x1, y1)
         assert np.array_equal(got, full[:, y0:y1, x0:x1]), (x0, y0, x1, y1)
+
+
+def test_random_layouts_gpu_equals_oracle_and_decodes():
+    """A sweep like tests/test_offgrid_cpu.py's, on the GPU: random image sizes, offsets, tile sizes, level counts -- the
+    codestream of grk_amd_encode_image == oracle tiles through the same writer, and every tile decodes back to its pixels
+    (its own table rows, parameters with its origin; region decode of a random window of it == the crop)."""
+    rng = np.random.default_rng(2024)
+    c = U.ctx()
+    for it in range(30):
+        W, H = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        off = (int(rng.integers(0, 70)), int(rng.integers(0, 70)))
+        TW, TH = int(rng.integers(max(off[0] + 1, 16), 260)), int(rng.integers(max(off[1] + 1, 16), 260))
+        L = int(rng.integers(0, 6))
+        Cn = int(rng.choice([1, 3]))
+        prec = int(rng.choice([8, 8, 12]))
+        layout = G.ImageLayout.make(W, H, TW, TH, offset=off)
+        px = synth.g2(Cn, H, W, prec, seed=int(rng.integers(1, 1000)))
+        base = G.TileParams.make(1, 1, Cn, prec, L)
+        got = c.encode_image(layout, base, px)
+        assert got == oracle_image_codestream(px, prec, L, layout), (W, H, TW, TH, L, off, Cn, prec)
+        for p in G.layout_tiles(layout, base):
+            ox, oy = p.tile_x0 - off[0], p.tile_y0 - off[1]
+            tile = np.ascontiguousarray(px[:, oy:oy + p.tile_h, ox:ox + p.tile_w])
+            table, coded = c.encode_host(p, tile)
+            back = c.decode_host(p, table, coded)[0]
+            assert np.array_equal(back, tile), (W, H, TW, TH, L, off, Cn, prec, p.tile_x0, p.tile_y0)
+            if L >= 1:
+                x0, y0 = int(rng.integers(0, p.tile_w)), int(rng.integers(0, p.tile_h))
+                x1, y1 = int(rng.integers(x0 + 1, p.tile_w + 1)), int(rng.integers(y0 + 1, p.tile_h + 1))
+                win = c.decode_region_host(p, table, coded, x0, y0, x1, y1)
+                assert np.array_equal(win, tile[:, y0:y1, x0:x1]), (W, H, TW, TH, L, off, p.tile_x0, p.tile_y0, x0, y0, x1, y1)
