@@ -626,6 +626,39 @@ def main():
             except Exception as e:        # noqa: BLE001
                 decode["region"] = {"error": str(e)}
 
+    # ---- the decode direction in its throughput form: THREE frames per call (a batch of tiles of one geometry, what
+    #      grk_amd_decode_tiles takes).  K5a is one serial chain per code-block at under two waves per SIMD: its time is the
+    #      chain's, not the block count's, so a second and third frame ride along for little -- as consecutive encodes are
+    #      pipelined, consecutive frames of a sequence are decoded a few per call
+    if decode is not None and decode.get("rejected") is None and ntiles == 1 and args.workload == "8k":
+        decode["frames_per_call"] = {}
+        for NB in (2, 3):
+            try:
+                ctx.enable_timing(False)
+                d3 = d_px.repeat(NB)
+                ctx.encode_tiles(params, NB, d3.data_ptr(), True, fetch=False)
+                t3, tot3 = ctx.fetch_table(nblocks * NB)
+                back3 = torch.empty_like(d3)
+                with torch.cuda.stream(stream):
+                    for _ in range(3):
+                        ctx.decode_device(params, NB, t3, ctx.coded_device_ptr(), tot3, back3.data_ptr())
+                torch.cuda.synchronize(dev)
+                n3 = max(4, min(args.steps, 10))
+                t0 = time.perf_counter()
+                with torch.cuda.stream(stream):
+                    for _ in range(n3):
+                        ctx.decode_device(params, NB, t3, ctx.coded_device_ptr(), tot3, back3.data_ptr())
+                torch.cuda.synchronize(dev)
+                dt3 = (time.perf_counter() - t0) / n3
+                ctx.decode_status()
+                decode["frames_per_call"][str(NB)] = {"ms_per_frame": round(dt3 / NB * 1e3, 4), "value": round(pixels_per_step * NB / dt3 / 1e6, 1),
+                                                      "unit": "Mpixels/s", "lossless_round_trip": bool(torch.equal(back3, d3))}
+                del d3, back3
+            except Exception as e:  # noqa: BLE001
+                decode["frames_per_call"][str(NB)] = {"error": str(e)}
+        ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)      # back to the headline shape
+        ctx.synchronize()
+
     # ---- per-kernel-family durations: HIP events on the stream each kernel is launched on, `steps` more encodes.
     # K3 runs up to three times per step -- top resolution on a side stream beside DWT levels >= 1 (timer 4), the rest
     # on the context's stream (2), large-LDS classes on a second side stream (8) -- its time per step is their sum.
