@@ -135,27 +135,39 @@ def test_plugin_self_check_mode_the_reference_compares_every_block(tmp_path, mon
     coefficient changed behind the plugin's back (test hook of the harness) it reports the block."""
     assert R.plugin_load() == 1
     assert R.plugin_init(0) == 1
-    cases = ((3, 8, 5), (1, 8, 4), (1, 12, 3))
+    cases = ((3, 8, 5, (0, 0)), (1, 8, 4, (0, 0)), (1, 12, 3, (0, 0)), (3, 8, 5, (1, 1)), (1, 8, 4, (33, 95)))   # (last two: image off the origin)
+    H, W = 192, 256
+
+    def offsets(off):
+        monkeypatch.setenv("REF_IMG_X0", str(off[0]))
+        monkeypatch.setenv("REF_IMG_Y0", str(off[1]))
     # the pure-CPU files first: the debug state is a property of the loaded plugin, and the host's CPU path obeys it too
     # (TileProcessor.cpp:676-690 skips DC shift / MCT / DWT whenever it is set)
-    cpu = {k: R.encode(synth.g2(k[0], 192, 256, k[1]), k[1], numres=k[2], mode=1)[0] for k in cases}
+    cpu = {}
+    for k in cases:
+        offsets(k[3])
+        cpu[k] = R.encode(synth.g2(k[0], H, W, k[1]), k[1], TW=W + k[3][0], TH=H + k[3][1], numres=k[2], mode=1)[0]
     monkeypatch.setenv("GRK_AMD_PLUGIN_DEBUG", "1")
     assert R.plugin_init(0) == 1
     assert R.plugin_debug_state() == 1
     try:
-        for Cn, prec, numres in cases:
-            px = synth.g2(Cn, 192, 256, prec)
+        for Cn, prec, numres, off in cases:
+            offsets(off)
+            px = synth.g2(Cn, H, W, prec)
             path = str(tmp_path / ("dbg_%d_%d.%s" % (Cn, prec, "pgm" if Cn == 1 else "ppm")))
             R.write_pnm(path, px, prec)
             R.warning_count()
-            got = R.plugin_compress_file(px, prec, path, numres=numres)
+            got = R.plugin_compress_file(px, prec, path, numres=numres, TW=W + off[0], TH=H + off[1])
             n, last = R.warning_count()
             assert not isinstance(got, int), "plugin refused: %s" % got
             assert n == 0, "the reference disagrees with the plugin: %d warnings, last: %s" % (n, last)
-            assert got == cpu[(Cn, prec, numres)]
+            assert got == cpu[(Cn, prec, numres, off)]
+        offsets((0, 0))
         monkeypatch.setenv("REF_DEBUG_PERTURB", "1")
         R.warning_count()
-        got = R.plugin_compress_file(px, prec, path, numres=numres)
+        px = synth.g2(1, H, W, 12)
+        path = str(tmp_path / "dbg_1_12.pgm")
+        got = R.plugin_compress_file(px, 12, path, numres=3)
         n, last = R.warning_count()
         assert n >= 1 and "differ" in last, (n, last)
     finally:
