@@ -50,6 +50,11 @@ WORKLOADS = {
 }
 
 
+# md5 of the codestream Grok 8.0.2's CPU encoder writes for the workload's image (G2; re-derived from
+# the reference built under oracle/_ref by the parity tests and by cpu_baseline below)
+GOLDEN_MD5 = {"8k": "7e5275ef3d61edd7b95332bef74a986c"}
+
+
 def sigma(levels):
     return sum(4.0 ** -l for l in range(levels))
 
@@ -683,6 +688,17 @@ def main():
     fam = family_pass(False)
     ctx.set_overlap(not args.no_overlap)
     table, total = ctx.fetch_table(nblocks)
+    # north_star: "bit-exact lossless HTJ2K encode of an 8K x 8K image at 1 and 8 GPUs" -- every rank turns the blocks of its
+    # last encode into the tile's codestream and compares its md5 with that of the file Grok 8.0.2's own encoder writes for
+    # this image (the constant the parity tests pin against the reference built here, tests/test_gpu_stages.py)
+    bit_exact = None
+    if args.workload in GOLDEN_MD5 and ntiles == 1:
+        import hashlib
+        cs_md5 = hashlib.md5(G.write_codestream(params, W, H, table, ctx.fetch_coded(total))).hexdigest()
+        ok = torch.tensor([1 if cs_md5 == GOLDEN_MD5[args.workload] else 0], dtype=torch.int32, device=dev)
+        if use_dist:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        bit_exact = {"codestream_md5": cs_md5, "equals_grok_cpu_file_on_all_ranks": bool(ok.item()), "ranks": world}
     b_in = (prec + 7) // 8
     algo = {"ingest_mct": samples * (b_in + 4), "dwt53_5levels": 8.0 * samples * sigma(levels),
             "ht_cleanup_encode": 4.0 * samples + float(total)}
@@ -738,6 +754,7 @@ def main():
                          "dram_traffic_bytes_per_step": pipe_traffic,
                          "dram_GBps": round(pipe_traffic / (ms_per_step * 1e-3) / 1e9, 1) if pipe_traffic else None,
                          "dram_frac_of_hbm_peak": round(pipe_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if pipe_traffic else None},
+            "bit_exact": bit_exact,
             "kernels": kernels,
             "kernels_overlapped": kernels_overlapped,
             "decode": decode,
