@@ -154,7 +154,12 @@ def tile_layout(params):
     return list(blocks), list(qcd)[:3 * params.num_levels + 1]
 
 
-CS_TLM, CS_PLT = 1, 2
+CS_TLM, CS_PLT, CS_SOP, CS_EPH = 1, 2, 4, 8
+
+
+def CS_PROG(order):
+    """progression order for the writer's flags: 0 LRCP, 1 RLCP, 2 RPCL, 3 PCRL, 4 CPRL"""
+    return int(order) << 8
 
 
 def write_codestream(params, img_w, img_h, table, coded, flags=0):

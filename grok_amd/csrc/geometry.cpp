@@ -71,6 +71,10 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
     // one precinct per resolution (default exponent 15, CodeStreamCompress.cpp:514-518)
     if (p.tile_w > 32768 || p.tile_h > 32768) return GRK_AMD_ERR_UNSUPPORTED;
     if ((uint64_t)p.tile_x0 + p.tile_w > 0x7FFFFFFFull || (uint64_t)p.tile_y0 + p.tile_h > 0x7FFFFFFFull) return GRK_AMD_ERR_UNSUPPORTED;
+    // (the precinct grid is anchored at the origin of every resolution's coordinates: a tile that straddles a multiple of
+    //  2^15 has two precincts there)
+    if ((p.tile_x0 >> 15) != ((p.tile_x0 + p.tile_w - 1) >> 15) || (p.tile_y0 >> 15) != ((p.tile_y0 + p.tile_h - 1) >> 15))
+        return GRK_AMD_ERR_UNSUPPORTED;
 
     g.p = p;
     g.stride = (p.tile_w + 31u) & ~31u;                       // util/MemManager.cpp:38-43

@@ -116,8 +116,9 @@ void write_main_header(Out& o, const TileGeom& g, const grk_amd_image_layout& im
     }
     uint32_t Bp = B <= 8 ? 0 : (B < 28 ? B - 8 : (B < 48 ? 13 + (B >> 2) : 31));
     o.u16(0xFF50); o.u16(8); o.u32(0x00020000); o.u16((p.irreversible ? 0x0020 : 0) | Bp);
-    // COD
-    o.u16(0xFF52); o.u16(12); o.u8(0); o.u8(0); o.u16(1); o.u8(p.mct ? 1 : 0);
+    // COD: Scod = SOP (2) | EPH (4), SGcod = progression order, one layer, MCT
+    o.u16(0xFF52); o.u16(12); o.u8(((flags & GRK_AMD_CS_SOP) ? 2u : 0u) | ((flags & GRK_AMD_CS_EPH) ? 4u : 0u));
+    o.u8((flags >> GRK_AMD_CS_PROG_SHIFT) & 7u); o.u16(1); o.u8(p.mct ? 1 : 0);
     o.u8(p.num_levels); o.u8(p.cblk_w_exp - 2); o.u8(p.cblk_h_exp - 2); o.u8(0x40); o.u8(p.irreversible ? 0 : 1);
     // QCD: one guard bit
     if (!p.irreversible) {
@@ -141,10 +142,13 @@ void write_main_header(Out& o, const TileGeom& g, const grk_amd_image_layout& im
     o.bytes(reinterpret_cast<const uint8_t*>(kCom), cl);
 }
 
-void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_block* comp_table, const uint8_t* coded)
+// sop: the packet's number in the tile (SOP marker segment in front, T2Compress.cpp:149-164) or < 0; eph: EPH after the header
+void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_block* comp_table, const uint8_t* coded, int32_t sop = -1,
+                  bool eph = false)
 {
     const ResGeom& R = g.res[r];
     if (R.w == 0 || R.h == 0) return;      // an empty resolution has no precinct, hence no packet (t2/PacketIter.cpp)
+    if (sop >= 0) { o.u16(0xFF91); o.u16(4); o.u16((uint32_t)sop & 0xFFFFu); }
     HeaderBits hb(o);
     hb.bit(1);
     TagTree incl, zbp;
@@ -168,6 +172,7 @@ void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_blo
             }
     }
     hb.flush();
+    if (eph) o.u16(0xFF92);
     for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
         const BandGeom& B = R.band[bi];
         for (uint32_t k = 0; k < B.gw * B.gh; ++k) {
@@ -206,35 +211,48 @@ grk_amd_image_layout plain_layout(const grk_amd_tile_params& p, uint32_t img_w, 
     return grk_amd_image_layout{p.tile_x0, p.tile_y0, p.tile_x0 + img_w, p.tile_y0 + img_h, p.tile_x0, p.tile_y0, p.tile_w, p.tile_h};
 }
 
-// SOT, (PLT,) SOD and the LRCP packets of one tile; returns the tile-part's length
+// SOT, (PLT,) SOD and the packets of one tile in the progression order of `flags`; returns the tile-part's length.
+// With one layer and one precinct per resolution the five orders (t2/PacketIter.cpp:805-1100) come down to two loop nests:
+// LRCP, RLCP and RPCL walk resolution -> component, PCRL and CPRL component -> resolution.
 uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, const grk_amd_coded_block* tt, const uint8_t* coded)
 {
     const grk_amd_tile_params& p = g.p;
     const uint64_t sot = o.n;
+    const bool comp_major = ((flags >> GRK_AMD_CS_PROG_SHIFT) & 7u) >= 3u;
+    const bool sop = (flags & GRK_AMD_CS_SOP) != 0, eph = (flags & GRK_AMD_CS_EPH) != 0;
+    auto packets = [&](Out& dst, std::vector<uint8_t>* plt) {
+        int32_t n = 0;
+        const uint32_t outer = comp_major ? p.num_comps : p.num_levels + 1u, inner = comp_major ? p.num_levels + 1u : p.num_comps;
+        for (uint32_t a = 0; a < outer; ++a)
+            for (uint32_t b = 0; b < inner; ++b) {
+                const uint32_t r = comp_major ? b : a, c = comp_major ? a : b;
+                if (g.res[r].w == 0 || g.res[r].h == 0) continue;
+                const uint64_t at = dst.n;
+                write_packet(dst, g, r, tt + (uint64_t)c * g.blocks_per_comp, coded, sop ? n : -1, eph);
+                ++n;
+                if (plt) {                      // the packet's length as a big-endian base-128 number (continuation bit 0x80)
+                    uint8_t tmp[10]; int k = 0;
+                    uint64_t v = dst.n - at;
+                    tmp[k++] = (uint8_t)(v & 0x7F);
+                    while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
+                    while (k) plt->push_back(tmp[--k]);
+                }
+            }
+    };
     o.u16(0xFF90); o.u16(10); o.u16(t); o.u32(0); o.u8(0); o.u8(1);
     if (flags & GRK_AMD_CS_PLT) {
         // PLT (markers/LengthMarkers.cpp:313-374, written in front of SOD: TileProcessor.cpp:719-726): Zplt 0, then every
-        // packet's length as a big-endian base-128 number (continuation bit 0x80).  The packets are sized with a counting pass.
+        // packet's length.  The packets are sized with a counting pass.
         std::vector<uint8_t> body;
-        for (uint32_t r = 0; r <= p.num_levels; ++r)
-            for (uint32_t c = 0; c < p.num_comps; ++c) {
-                Out cnt{nullptr, 0};
-                write_packet(cnt, g, r, tt + (uint64_t)c * g.blocks_per_comp, coded);
-                uint8_t tmp[5]; int k = 0;
-                uint64_t v = cnt.n;
-                tmp[k++] = (uint8_t)(v & 0x7F);
-                while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
-                while (k) body.push_back(tmp[--k]);
-            }
+        Out cnt{nullptr, 0};
+        packets(cnt, &body);
         // (one marker segment: 18 packets of a 6-resolution RGB tile need < 100 bytes; the reference starts another
         //  segment near 64 KiB, LengthMarkers.cpp:315-316)
         o.u16(0xFF58); o.u16((uint32_t)(3 + body.size())); o.u8(0);
         o.bytes(body.data(), body.size());
     }
     o.u16(0xFF93);
-    for (uint32_t r = 0; r <= p.num_levels; ++r)
-        for (uint32_t c = 0; c < p.num_comps; ++c)
-            write_packet(o, g, r, tt + (uint64_t)c * g.blocks_per_comp, coded);
+    packets(o, nullptr);
     o.patch32(sot + 6, (uint32_t)(o.n - sot));
     return o.n - sot;
 }

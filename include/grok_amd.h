@@ -294,6 +294,13 @@ int64_t grk_amd_encode_image(grk_amd_ctx* ctx, const grk_amd_image_layout* im, c
  * four-byte tile-part length, <= 255 tiles), PLT (packet lengths) in every tile-part header. */
 #define GRK_AMD_CS_TLM 1u
 #define GRK_AMD_CS_PLT 2u
+/* SOP marker segments in front of the packets / EPH markers after the packet headers (grk_cparameters::csty bits 0x02 / 0x04,
+ * grk_compress -S / -E; t2/T2Compress.cpp:149-164, :321-327) */
+#define GRK_AMD_CS_SOP 4u
+#define GRK_AMD_CS_EPH 8u
+/* progression order (grk_cparameters::prog_order, GRK_PROG_ORDER: 0 LRCP, 1 RLCP, 2 RPCL, 3 PCRL, 4 CPRL) << 8 */
+#define GRK_AMD_CS_PROG_SHIFT 8
+#define GRK_AMD_CS_PROG(order) ((uint32_t)(order) << GRK_AMD_CS_PROG_SHIFT)
 int64_t grk_amd_write_codestream_ex(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
                                     const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
                                     uint8_t* out, uint64_t cap);

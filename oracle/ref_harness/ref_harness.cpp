@@ -199,6 +199,9 @@ static void fill_params(grk_cparameters& p, const EncCfg& c)
 	// grk_compress -X / -L: pointer marker segments (TLM in the main header, PLT in the tile-part headers)
 	if (const char* e = getenv("REF_WRITE_TLM")) p.writeTLM = atoi(e) != 0;
 	if (const char* e = getenv("REF_WRITE_PLT")) p.writePLT = atoi(e) != 0;
+	// grk_compress -p / -S / -E: progression order, SOP and EPH markers
+	if (const char* e = getenv("REF_PROG_ORDER")) p.prog_order = (GRK_PROG_ORDER)atoi(e);
+	if (const char* e = getenv("REF_CSTY")) p.csty = (uint8_t)(p.csty | atoi(e));
 	// grk_compress -d: the image area's origin on the canonical grid (the tile grid stays anchored at 0, 0)
 	if (const char* e = getenv("REF_IMG_X0")) p.image_offset_x0 = (uint32_t)atoi(e);
 	if (const char* e = getenv("REF_IMG_Y0")) p.image_offset_y0 = (uint32_t)atoi(e);

@@ -6,7 +6,7 @@ import oracle as O
 from grok_amd.capi import CODED_DTYPE
 
 
-def oracle_codestream(px, prec, L, TW=None, TH=None):
+def oracle_codestream(px, prec, L, TW=None, TH=None, flags=0):
     C, H, W = px.shape
     TW = TW or W
     TH = TH or H
@@ -22,4 +22,4 @@ def oracle_codestream(px, prec, L, TW=None, TH=None):
             off += int(lens.sum())
             tabs.append(t)
             chunks.append(coded)
-    return G.write_codestream(p, W, H, np.concatenate(tabs), np.concatenate(chunks))
+    return G.write_codestream(p, W, H, np.concatenate(tabs), np.concatenate(chunks), flags)

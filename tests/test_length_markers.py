@@ -81,3 +81,25 @@ def test_locator_on_reference_streams(monkeypatch):
     assert [x[1:] for x in a] == [x[1:] for x in b]
     shift = len(with_tlm) - len(plain)
     assert [x[0] + shift for x in a] == [x[0] for x in b]
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("csty", [0, 2, 4, 6])
+def test_progression_orders_sop_eph_are_the_reference_files(monkeypatch, order, csty):
+    """grk_compress -p LRCP|RLCP|RPCL|PCRL|CPRL, -S (SOP), -E (EPH): with one layer and one precinct per resolution the five
+    orders are two loop nests; SOP numbers the packets of a tile, EPH closes every packet header.  Oracle tiles + the
+    product's writer == the reference's file, with PLT + TLM as well (the packet lengths include the markers); multi-tile."""
+    import cshelp
+    px = synth.g2(3, 192, 256, 8, seed=order * 7 + csty)
+    monkeypatch.setenv("REF_PROG_ORDER", str(order))
+    monkeypatch.setenv("REF_CSTY", str(csty))
+    flags = G.CS_PROG(order) | (G.CS_SOP if csty & 2 else 0) | (G.CS_EPH if csty & 4 else 0)
+    for tlmplt in (0, 1):
+        monkeypatch.setenv("REF_WRITE_TLM", str(tlmplt))
+        monkeypatch.setenv("REF_WRITE_PLT", str(tlmplt))
+        f = flags | ((G.CS_TLM | G.CS_PLT) if tlmplt else 0)
+        want, _ = R.encode(px, 8, TW=128, TH=64, numres=4, mode=1)
+        got = cshelp.oracle_codestream(px, 8, 3, 128, 64, flags=f)
+        assert got == want, (order, csty, tlmplt)
+    assert np.array_equal(R.decode(got, 3, 192, 256), px.astype(np.int32))
