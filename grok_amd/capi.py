@@ -20,18 +20,24 @@ class TileParams(C.Structure):
                 ("prec", C.c_uint8), ("sgnd", C.c_uint8), ("irreversible", C.c_uint8),
                 ("mct", C.c_uint8), ("num_levels", C.c_uint8), ("cblk_w_exp", C.c_uint8),
                 ("cblk_h_exp", C.c_uint8), ("reserved", C.c_uint8 * 3),
-                ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32)]
+                ("tile_x0", C.c_uint32), ("tile_y0", C.c_uint32), ("precinct_exp", C.c_uint8 * 12)]
 
     @classmethod
     def make(cls, w, h, comps, prec, levels, irreversible=False, mct=None, sgnd=False, cblk=(6, 6), part1=False, cblksty=0,
-             origin=(0, 0)):
-        """origin = (x0, y0): where the tile lies on the canonical grid (image offset / tile grid position)."""
+             origin=(0, 0), precincts=None):
+        """origin = (x0, y0): where the tile lies on the canonical grid (image offset / tile grid position).
+        precincts = [(PPx, PPy), ...] for resolutions 0 (coarsest) .. levels, exponents as in the COD marker; None: one
+        precinct per resolution."""
         if mct is None:
             mct = comps >= 3
         p = cls(w, h, comps, prec, int(sgnd), int(irreversible), int(mct), levels, cblk[0], cblk[1])
         p.reserved[0] = int(part1)
         p.reserved[1] = int(cblksty)       # Part-1 decode: LAZY 1, RESET 2, TERMALL 4, VSC 8, PTERM 16, SEGSYM 32
         p.tile_x0, p.tile_y0 = int(origin[0]), int(origin[1])
+        if precincts is not None:
+            assert len(precincts) == levels + 1
+            for r, (ppx, ppy) in enumerate(precincts):
+                p.precinct_exp[r] = int(ppx) | (int(ppy) << 4)
         return p
 
 
@@ -50,7 +56,7 @@ class Block(C.Structure):
     _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
                 ("px", C.c_uint32), ("py", C.c_uint32), ("comp", C.c_uint16), ("res", C.c_uint8),
                 ("band", C.c_uint8), ("kmax", C.c_uint8), ("reserved", C.c_uint8 * 3),
-                ("stepsize", C.c_float)]
+                ("stepsize", C.c_float), ("precinct", C.c_uint32)]
 
 
 class CodedBlock(C.Structure):
@@ -82,6 +88,7 @@ def lib():
         L.grk_amd_tile_num_blocks.argtypes = [PP]
         L.grk_amd_tile_layout.restype = C.c_int64
         L.grk_amd_tile_layout.argtypes = [PP, vp, u64, vp]
+        L.grk_amd_tile_precincts.argtypes = [PP, vp]
         L.grk_amd_plane_stride.restype = u32
         L.grk_amd_plane_stride.argtypes = [PP]
         L.grk_amd_plane_elems.restype = u64

@@ -118,7 +118,8 @@ bool same_params(const grk_amd_tile_params& a, const grk_amd_tile_params& b)
     return a.tile_w == b.tile_w && a.tile_h == b.tile_h && a.num_comps == b.num_comps && a.prec == b.prec &&
            a.sgnd == b.sgnd && a.irreversible == b.irreversible && a.mct == b.mct &&
            a.num_levels == b.num_levels && a.cblk_w_exp == b.cblk_w_exp && a.cblk_h_exp == b.cblk_h_exp &&
-           a.reserved[0] == b.reserved[0] && a.reserved[1] == b.reserved[1] && a.tile_x0 == b.tile_x0 && a.tile_y0 == b.tile_y0;
+           a.reserved[0] == b.reserved[0] && a.reserved[1] == b.reserved[1] && a.tile_x0 == b.tile_x0 && a.tile_y0 == b.tile_y0 &&
+           std::memcmp(a.precinct_exp, b.precinct_exp, sizeof a.precinct_exp) == 0;
 }
 
 int ensure_geom(grk_amd_ctx* c, const grk_amd_tile_params* p)
@@ -776,6 +777,16 @@ int64_t grk_amd_tile_layout(const grk_amd_tile_params* p, grk_amd_block* blocks,
     }
     if (qcd) std::memcpy(qcd, g.qcd_words, sizeof(uint16_t) * g.num_bands_total);
     return (int64_t)n;
+}
+
+int grk_amd_tile_precincts(const grk_amd_tile_params* p, uint32_t* counts)
+{
+    if (!p || !counts) return GRK_AMD_ERR_INVALID;
+    TileGeom g;
+    const int rc = build_tile_geom(*p, g);
+    if (rc != GRK_AMD_OK) return rc;
+    for (uint32_t r = 0; r <= p->num_levels; ++r) counts[r] = g.res[r].npw * g.res[r].nph;
+    return GRK_AMD_OK;
 }
 
 uint32_t grk_amd_plane_stride(const grk_amd_tile_params* p) { return p ? ((p->tile_w + 31u) & ~31u) : 0; }

@@ -71,10 +71,7 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
     // one precinct per resolution (default exponent 15, CodeStreamCompress.cpp:514-518)
     if (p.tile_w > 32768 || p.tile_h > 32768) return GRK_AMD_ERR_UNSUPPORTED;
     if ((uint64_t)p.tile_x0 + p.tile_w > 0x7FFFFFFFull || (uint64_t)p.tile_y0 + p.tile_h > 0x7FFFFFFFull) return GRK_AMD_ERR_UNSUPPORTED;
-    // (the precinct grid is anchored at the origin of every resolution's coordinates: a tile that straddles a multiple of
-    //  2^15 has two precincts there)
-    if ((p.tile_x0 >> 15) != ((p.tile_x0 + p.tile_w - 1) >> 15) || (p.tile_y0 >> 15) != ((p.tile_y0 + p.tile_h - 1) >> 15))
-        return GRK_AMD_ERR_UNSUPPORTED;
+
 
     g.p = p;
     g.stride = (p.tile_w + 31u) & ~31u;                       // util/MemManager.cpp:38-43
@@ -84,7 +81,6 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
     g.num_bands_total = 3 * L + 1;
     g.res.assign(L + 1, ResGeom{});
     g.blocks_comp0.clear();
-    const uint32_t cbw = 1u << p.cblk_w_exp, cbh = 1u << p.cblk_h_exp;
     uint32_t nblk = 0;
     // tile-component origin on the canonical grid (dx = dy = 1: the tile's own): resolution r covers
     // [ceil(x0 / 2^(L-r)), ceil((x0 + w) / 2^(L-r))), band b of it [ceil((x0 - 2^(n-1) xb) / 2^n), ...) with n = L - r + 1
@@ -105,6 +101,18 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
         uint32_t lw = r ? res_lo(X1, L - r + 1) - res_lo(X0, L - r + 1) : 0;
         uint32_t lh = r ? res_lo(Y1, L - r + 1) - res_lo(Y0, L - r + 1) : 0;
         R.num_bands = r ? 3 : 1;
+        // precincts (T1Structs.cpp:449-493, TileComponent.cpp:100-118): the grid of 2^PPx x 2^PPy cells anchored at the
+        // origin of the resolution's coordinates that the resolution touches; in a band of resolution r > 0 a precinct is
+        // half as large, and a code-block is never larger than the band's part of a precinct
+        const uint32_t pe = p.precinct_exp[r];
+        R.ppx = pe ? (pe & 15u) : 15u; R.ppy = pe ? (pe >> 4) : 15u;
+        if (r && (R.ppx == 0 || R.ppy == 0)) return GRK_AMD_ERR_INVALID;
+        R.npw = R.w ? (uint32_t)((((uint64_t)R.x0 + R.w + (1ull << R.ppx) - 1) >> R.ppx) - (R.x0 >> R.ppx)) : 0;
+        R.nph = R.h ? (uint32_t)((((uint64_t)R.y0 + R.h + (1ull << R.ppy) - 1) >> R.ppy) - (R.y0 >> R.ppy)) : 0;
+        if ((uint64_t)R.npw * R.nph > (1u << 22)) return GRK_AMD_ERR_UNSUPPORTED;
+        const uint32_t bpx = R.ppx - (r ? 1u : 0u), bpy = R.ppy - (r ? 1u : 0u);                 // precinct exponents in the bands
+        const uint32_t psx = ((R.x0 >> R.ppx) << R.ppx) >> (r ? 1u : 0u), psy = ((R.y0 >> R.ppy) << R.ppy) >> (r ? 1u : 0u);
+        const uint32_t cxe = std::min<uint32_t>(p.cblk_w_exp, bpx), cye = std::min<uint32_t>(p.cblk_h_exp, bpy);
         for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
             BandGeom& B = R.band[bi];
             B.orient = (uint8_t)(r ? bi + 1 : 0);
@@ -131,23 +139,36 @@ int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
             }
             if (B.kmax > 30) return GRK_AMD_ERR_UNSUPPORTED;
             B.first_block = nblk;
-            if (B.w == 0 || B.h == 0) { B.gw = B.gh = 0; continue; }
-            const uint32_t gx0 = B.x0 >> p.cblk_w_exp, gy0 = B.y0 >> p.cblk_h_exp;
-            B.gw = ((B.x0 + B.w + cbw - 1) >> p.cblk_w_exp) - gx0;
-            B.gh = ((B.y0 + B.h + cbh - 1) >> p.cblk_h_exp) - gy0;
-            for (uint32_t by = 0; by < B.gh; ++by)
-                for (uint32_t bx = 0; bx < B.gw; ++bx) {
-                    grk_amd_block b;
-                    std::memset(&b, 0, sizeof(b));
-                    b.x0 = std::max((gx0 + bx) * cbw, B.x0); b.y0 = std::max((gy0 + by) * cbh, B.y0);
-                    b.x1 = std::min((gx0 + bx + 1) * cbw, B.x0 + B.w);
-                    b.y1 = std::min((gy0 + by + 1) * cbh, B.y0 + B.h);
-                    b.px = B.ox + (b.x0 - B.x0); b.py = B.oy + (b.y0 - B.y0);
-                    b.comp = 0; b.res = (uint8_t)r; b.band = B.orient; b.kmax = B.kmax;
-                    b.stepsize = B.stepsize;
-                    g.blocks_comp0.push_back(b);
-                    ++nblk;
+            B.prec.assign((size_t)R.npw * R.nph, BandGeom::Prec{0, 0, nblk});
+            for (uint32_t pj = 0; pj < R.nph; ++pj)
+                for (uint32_t pi = 0; pi < R.npw; ++pi) {
+                    BandGeom::Prec& P = B.prec[(size_t)pj * R.npw + pi];
+                    P.first_block = nblk;
+                    // the band's part of the precinct, in the band's coordinates
+                    const uint64_t qx0 = (uint64_t)psx + ((uint64_t)pi << bpx), qy0 = (uint64_t)psy + ((uint64_t)pj << bpy);
+                    const uint64_t rx0 = std::max<uint64_t>(qx0, B.x0), rx1 = std::min<uint64_t>(qx0 + (1ull << bpx), (uint64_t)B.x0 + B.w);
+                    const uint64_t ry0 = std::max<uint64_t>(qy0, B.y0), ry1 = std::min<uint64_t>(qy0 + (1ull << bpy), (uint64_t)B.y0 + B.h);
+                    if (rx0 >= rx1 || ry0 >= ry1) continue;
+                    const uint32_t gx0 = (uint32_t)(rx0 >> cxe), gy0 = (uint32_t)(ry0 >> cye);
+                    P.gw = (uint32_t)((rx1 + (1ull << cxe) - 1) >> cxe) - gx0;
+                    P.gh = (uint32_t)((ry1 + (1ull << cye) - 1) >> cye) - gy0;
+                    for (uint32_t by = 0; by < P.gh; ++by)
+                        for (uint32_t bx = 0; bx < P.gw; ++bx) {
+                            grk_amd_block b;
+                            std::memset(&b, 0, sizeof(b));
+                            b.x0 = (uint32_t)std::max<uint64_t>((uint64_t)(gx0 + bx) << cxe, rx0);
+                            b.y0 = (uint32_t)std::max<uint64_t>((uint64_t)(gy0 + by) << cye, ry0);
+                            b.x1 = (uint32_t)std::min<uint64_t>((uint64_t)(gx0 + bx + 1) << cxe, rx1);
+                            b.y1 = (uint32_t)std::min<uint64_t>((uint64_t)(gy0 + by + 1) << cye, ry1);
+                            b.px = B.ox + (b.x0 - B.x0); b.py = B.oy + (b.y0 - B.y0);
+                            b.comp = 0; b.res = (uint8_t)r; b.band = B.orient; b.kmax = B.kmax;
+                            b.stepsize = B.stepsize;
+                            b.precinct = pj * R.npw + pi;
+                            g.blocks_comp0.push_back(b);
+                            ++nblk;
+                        }
                 }
+            B.num_blocks = nblk - B.first_block;
         }
     }
     g.blocks_per_comp = nblk;
@@ -159,11 +180,12 @@ bool same_geometry(const TileGeom& a, const TileGeom& b)
 {
     if (a.p.tile_w != b.p.tile_w || a.p.tile_h != b.p.tile_h || a.blocks_per_comp != b.blocks_per_comp) return false;
     for (size_t r = 0; r < a.res.size(); ++r)
-        if (a.res[r].w != b.res[r].w || a.res[r].h != b.res[r].h || ((a.res[r].x0 ^ b.res[r].x0) & 1u) || ((a.res[r].y0 ^ b.res[r].y0) & 1u))
+        if (a.res[r].w != b.res[r].w || a.res[r].h != b.res[r].h || a.res[r].npw != b.res[r].npw || a.res[r].nph != b.res[r].nph || ((a.res[r].x0 ^ b.res[r].x0) & 1u) || ((a.res[r].y0 ^ b.res[r].y0) & 1u))
             return false;
     for (size_t i = 0; i < a.blocks_comp0.size(); ++i) {
         const grk_amd_block &x = a.blocks_comp0[i], &y = b.blocks_comp0[i];
-        if (x.px != y.px || x.py != y.py || x.x1 - x.x0 != y.x1 - y.x0 || x.y1 - x.y0 != y.y1 - y.y0 || x.res != y.res || x.band != y.band)
+        if (x.px != y.px || x.py != y.py || x.x1 - x.x0 != y.x1 - y.x0 || x.y1 - x.y0 != y.y1 - y.y0 || x.res != y.res || x.band != y.band ||
+            x.precinct != y.precinct)
             return false;
     }
     return true;

@@ -18,16 +18,20 @@ struct BandGeom {
     uint32_t x0, y0;        // origin in the band's own coordinates (0 for a tile at the origin)
     uint32_t w, h;          // band size
     uint32_t ox, oy;        // origin in the Mallat plane
-    uint32_t gw, gh;        // code-block grid of the (single) precinct
+    struct Prec { uint32_t gw, gh, first_block; };      // code-block grid of the band's part of a precinct (0 x 0: none),
+    std::vector<Prec> prec;                             // first block (index within the component); [npw * nph] of the resolution
     uint8_t  kmax;          // numbps
     uint16_t qcd;           // SPqcd word (expn<<3 | or expn<<11|mant)
     float    stepsize;      // band->stepsize on the encoder side
     uint32_t first_block;   // index (within the component) of the band's first block
+    uint32_t num_blocks;
 };
 struct ResGeom {
     uint32_t x0, y0;        // origin on the resolution's grid: its parity picks the lifting variant (odd start: the
                             // first sample is a high-pass one, WaveletFwd.cpp:884-905)
     uint32_t w, h;
+    uint32_t ppx, ppy;      // precinct exponents of the resolution (15, 15: one precinct)
+    uint32_t npw, nph;      // its precinct grid (0 x 0 for a resolution without samples)
     uint32_t num_bands;
     BandGeom band[3];
 };

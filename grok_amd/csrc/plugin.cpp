@@ -62,7 +62,14 @@ gra_plugin_tile* build_tree(const grk_amd_tile_params& p, const std::vector<grk_
     o->comps.resize(p.num_comps); o->comp_ptr.resize(p.num_comps);
     o->ress.resize((size_t)p.num_comps * nres); o->res_ptr.resize(o->ress.size());
     o->bands.resize((size_t)p.num_comps * nbands_c); o->band_ptr.resize(o->bands.size());
-    o->precs.resize(o->bands.size()); o->prec_ptr.resize(o->bands.size());
+    // precincts per band of every resolution (the same for its three bands)
+    std::vector<uint32_t> nprec((size_t)nres, 1u);
+    (void)grk_amd_tile_precincts(&p, nprec.data());
+    for (auto& n : nprec) n = std::max(n, 1u);          // (a resolution without samples: the host's tree has none either,
+                                                        //  one empty entry keeps the arrays well-formed)
+    size_t total_prec = 0;
+    for (uint32_t r = 0; r < nres; ++r) total_prec += (size_t)nprec[r] * (r ? 3 : 1);
+    o->precs.resize(total_prec * p.num_comps); o->prec_ptr.resize(o->precs.size());
     o->blocks.resize(nb); o->block_ptr.resize(nb);
     std::memset(o->blocks.data(), 0, nb * sizeof(gra_plugin_code_block));
     for (size_t i = 0; i < nb; ++i) {
@@ -79,7 +86,7 @@ gra_plugin_tile* build_tree(const grk_amd_tile_params& p, const std::vector<grk_
         cb.passes[0].distortionDecrease = 0.0;
         o->block_ptr[i] = &cb;
     }
-    size_t bi = 0, blk = 0;
+    size_t bi = 0, blk = 0, pk = 0;
     for (uint32_t c = 0; c < p.num_comps; ++c) {
         gra_plugin_tile_component& tc = o->comps[c];
         tc.numResolutions = nres;
@@ -96,15 +103,18 @@ gra_plugin_tile* build_tree(const grk_amd_tile_params& p, const std::vector<grk_
                 o->band_ptr[bi] = &B;
                 const uint8_t orient = (uint8_t)(r ? k + 1 : 0);
                 B.orientation = orient;
-                B.numPrecincts = 1;
-                B.precincts = &o->prec_ptr[bi];
-                o->prec_ptr[bi] = &o->precs[bi];
-                // blocks of this band are contiguous in enumeration order
-                size_t first = blk;
-                while (blk < nb && layout[blk].comp == c && layout[blk].res == r && layout[blk].band == orient) ++blk;
-                o->precs[bi].numBlocks = blk - first;
-                o->precs[bi].blocks = first < nb ? &o->block_ptr[first] : nullptr;
-                B.stepsize = blk > first ? layout[first].stepsize : 1.0f;
+                B.numPrecincts = nprec[r];
+                B.precincts = &o->prec_ptr[pk];
+                // the blocks of a band are contiguous in enumeration order, precinct by precinct
+                const size_t band_first = blk;
+                for (uint32_t q = 0; q < nprec[r]; ++q, ++pk) {
+                    o->prec_ptr[pk] = &o->precs[pk];
+                    const size_t first = blk;
+                    while (blk < nb && layout[blk].comp == c && layout[blk].res == r && layout[blk].band == orient && layout[blk].precinct == q) ++blk;
+                    o->precs[pk].numBlocks = blk - first;
+                    o->precs[pk].blocks = first < nb ? &o->block_ptr[first] : nullptr;
+                }
+                B.stepsize = blk > band_first ? layout[band_first].stepsize : 1.0f;
             }
         }
     }
@@ -167,7 +177,7 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
     const uint64_t ox = cp->image_offset_x0, oy = cp->image_offset_y0;
     if (cp->tile_size_on && (cp->tx0 > ox || cp->ty0 > oy || (uint64_t)cp->tx0 + cp->t_width < ox + w ||
                              (uint64_t)cp->ty0 + cp->t_height < oy + h)) return false;
-    if (cp->tcp_numlayers > 1 || cp->numpocs || cp->res_spec || cp->roi_compno >= 0) return false;
+    if (cp->tcp_numlayers > 1 || cp->numpocs || cp->roi_compno >= 0) return false;
     if (cp->subsampling_dx != 1 || cp->subsampling_dy != 1) return false;
     if (cp->numresolution < 1 || cp->numresolution > GRK_AMD_MAX_LEVELS + 1) return false;
     auto lg = [](uint32_t v) { int e = 0; while ((1u << e) < v) ++e; return e; };
@@ -182,6 +192,20 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
     p.num_levels = (uint8_t)(cp->numresolution - 1);
     p.cblk_w_exp = (uint8_t)lg(cp->cblockw_init ? cp->cblockw_init : 64);
     p.cblk_h_exp = (uint8_t)lg(cp->cblockh_init ? cp->cblockh_init : 64);
+    // precincts (grk_compress -c): sizes from the highest resolution down, the last one halved for the resolutions beyond
+    // the list, exponent = floor(log2), at least 1 -- CodeStreamCompress.cpp:475-514
+    if ((cp->csty & 1u) && cp->res_spec) {
+        auto fl = [](uint32_t v) { uint32_t e = 0; while (v >>= 1) ++e; return e; };
+        const uint32_t rs = std::min<uint32_t>(cp->res_spec, GRA_J2K_MAXRLVLS);
+        for (uint32_t q = 0; q < cp->numresolution; ++q) {
+            const uint32_t r = cp->numresolution - 1 - q;
+            const uint32_t pw = q < rs ? cp->prcw_init[q] : cp->prcw_init[rs - 1] >> (q - (rs - 1));
+            const uint32_t ph = q < rs ? cp->prch_init[q] : cp->prch_init[rs - 1] >> (q - (rs - 1));
+            const uint32_t ex = pw < 1 ? 1 : fl(pw), ey = ph < 1 ? 1 : fl(ph);
+            if (ex > 15 || ey > 15) return false;
+            p.precinct_exp[r] = (uint8_t)(ex | (ey << 4));
+        }
+    }
     return grk_amd_tile_num_blocks(&p) > 0;
 }
 

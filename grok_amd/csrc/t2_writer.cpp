@@ -117,9 +117,13 @@ void write_main_header(Out& o, const TileGeom& g, const grk_amd_image_layout& im
     uint32_t Bp = B <= 8 ? 0 : (B < 28 ? B - 8 : (B < 48 ? 13 + (B >> 2) : 31));
     o.u16(0xFF50); o.u16(8); o.u32(0x00020000); o.u16((p.irreversible ? 0x0020 : 0) | Bp);
     // COD: Scod = SOP (2) | EPH (4), SGcod = progression order, one layer, MCT
-    o.u16(0xFF52); o.u16(12); o.u8(((flags & GRK_AMD_CS_SOP) ? 2u : 0u) | ((flags & GRK_AMD_CS_EPH) ? 4u : 0u));
+    bool prt = false;                       // user-defined precincts: Scod bit 0 and one size byte per resolution
+    for (uint32_t r = 0; r <= p.num_levels; ++r) prt = prt || p.precinct_exp[r] != 0;
+    o.u16(0xFF52); o.u16(12 + (prt ? p.num_levels + 1u : 0u));
+    o.u8((prt ? 1u : 0u) | ((flags & GRK_AMD_CS_SOP) ? 2u : 0u) | ((flags & GRK_AMD_CS_EPH) ? 4u : 0u));
     o.u8((flags >> GRK_AMD_CS_PROG_SHIFT) & 7u); o.u16(1); o.u8(p.mct ? 1 : 0);
     o.u8(p.num_levels); o.u8(p.cblk_w_exp - 2); o.u8(p.cblk_h_exp - 2); o.u8(0x40); o.u8(p.irreversible ? 0 : 1);
+    for (uint32_t r = 0; prt && r <= p.num_levels; ++r) o.u8(p.precinct_exp[r] ? p.precinct_exp[r] : 0xFFu);
     // QCD: one guard bit
     if (!p.irreversible) {
         o.u16(0xFF5C); o.u16(3 + nb); o.u8(0x20);
@@ -143,24 +147,25 @@ void write_main_header(Out& o, const TileGeom& g, const grk_amd_image_layout& im
 }
 
 // sop: the packet's number in the tile (SOP marker segment in front, T2Compress.cpp:149-164) or < 0; eph: EPH after the header
-void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_block* comp_table, const uint8_t* coded, int32_t sop = -1,
-                  bool eph = false)
+// the packet of precinct `pi` of resolution r
+void write_packet(Out& o, const TileGeom& g, uint32_t r, uint32_t pi, const grk_amd_coded_block* comp_table, const uint8_t* coded,
+                  int32_t sop = -1, bool eph = false)
 {
     const ResGeom& R = g.res[r];
-    if (R.w == 0 || R.h == 0) return;      // an empty resolution has no precinct, hence no packet (t2/PacketIter.cpp)
     if (sop >= 0) { o.u16(0xFF91); o.u16(4); o.u16((uint32_t)sop & 0xFFFFu); }
     HeaderBits hb(o);
     hb.bit(1);
     TagTree incl, zbp;
     for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
         const BandGeom& B = R.band[bi];
-        if (!B.gw || !B.gh) continue;
-        incl.init(B.gw, B.gh); zbp.init(B.gw, B.gh);
-        for (uint32_t y = 0; y < B.gh; ++y)
-            for (uint32_t x = 0; x < B.gw; ++x) { incl.set(x, y, 0); zbp.set(x, y, (int32_t)B.kmax - 1); }
-        for (uint32_t y = 0; y < B.gh; ++y)
-            for (uint32_t x = 0; x < B.gw; ++x) {
-                const grk_amd_coded_block& cb = comp_table[B.first_block + y * B.gw + x];
+        const BandGeom::Prec& P = B.prec[pi];
+        if (!P.gw || !P.gh) continue;
+        incl.init(P.gw, P.gh); zbp.init(P.gw, P.gh);
+        for (uint32_t y = 0; y < P.gh; ++y)
+            for (uint32_t x = 0; x < P.gw; ++x) { incl.set(x, y, 0); zbp.set(x, y, (int32_t)B.kmax - 1); }
+        for (uint32_t y = 0; y < P.gh; ++y)
+            for (uint32_t x = 0; x < P.gw; ++x) {
+                const grk_amd_coded_block& cb = comp_table[P.first_block + y * P.gw + x];
                 incl.encode(hb, x, y, 1);
                 zbp.encode(hb, x, y, 0x7FFFFFFF);
                 hb.bit(0);                                            // one coding pass
@@ -174,9 +179,9 @@ void write_packet(Out& o, const TileGeom& g, uint32_t r, const grk_amd_coded_blo
     hb.flush();
     if (eph) o.u16(0xFF92);
     for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
-        const BandGeom& B = R.band[bi];
-        for (uint32_t k = 0; k < B.gw * B.gh; ++k) {
-            const grk_amd_coded_block& cb = comp_table[B.first_block + k];
+        const BandGeom::Prec& P = R.band[bi].prec[pi];
+        for (uint32_t k = 0; k < P.gw * P.gh; ++k) {
+            const grk_amd_coded_block& cb = comp_table[P.first_block + k];
             o.bytes(coded + cb.offset, cb.length);
         }
     }
@@ -211,6 +216,15 @@ grk_amd_image_layout plain_layout(const grk_amd_tile_params& p, uint32_t img_w, 
     return grk_amd_image_layout{p.tile_x0, p.tile_y0, p.tile_x0 + img_w, p.tile_y0 + img_h, p.tile_x0, p.tile_y0, p.tile_w, p.tile_h};
 }
 
+// RPCL, PCRL and CPRL walk precinct POSITIONS across resolutions and components: with one precinct per resolution that is
+// the loop nests below; more precincts would need the position iterator of t2/PacketIter.cpp:870-1100
+bool order_ok(const TileGeom& g, uint32_t flags)
+{
+    if (((flags >> GRK_AMD_CS_PROG_SHIFT) & 7u) < 2u) return true;
+    for (const auto& R : g.res) if ((uint64_t)R.npw * R.nph > 1) return false;
+    return true;
+}
+
 // SOT, (PLT,) SOD and the packets of one tile in the progression order of `flags`; returns the tile-part's length.
 // With one layer and one precinct per resolution the five orders (t2/PacketIter.cpp:805-1100) come down to two loop nests:
 // LRCP, RLCP and RPCL walk resolution -> component, PCRL and CPRL component -> resolution.
@@ -226,16 +240,19 @@ uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, 
         for (uint32_t a = 0; a < outer; ++a)
             for (uint32_t b = 0; b < inner; ++b) {
                 const uint32_t r = comp_major ? b : a, c = comp_major ? a : b;
-                if (g.res[r].w == 0 || g.res[r].h == 0) continue;
-                const uint64_t at = dst.n;
-                write_packet(dst, g, r, tt + (uint64_t)c * g.blocks_per_comp, coded, sop ? n : -1, eph);
-                ++n;
-                if (plt) {                      // the packet's length as a big-endian base-128 number (continuation bit 0x80)
-                    uint8_t tmp[10]; int k = 0;
-                    uint64_t v = dst.n - at;
-                    tmp[k++] = (uint8_t)(v & 0x7F);
-                    while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
-                    while (k) plt->push_back(tmp[--k]);
+                // one packet per precinct of the resolution, in raster order (none for a resolution without samples); the
+                // position-first orders are only taken with one precinct per resolution (checked by the entry points)
+                for (uint32_t pi = 0; pi < g.res[r].npw * g.res[r].nph; ++pi) {
+                    const uint64_t at = dst.n;
+                    write_packet(dst, g, r, pi, tt + (uint64_t)c * g.blocks_per_comp, coded, sop ? n : -1, eph);
+                    ++n;
+                    if (plt) {                  // the packet's length as a big-endian base-128 number (continuation bit 0x80)
+                        uint8_t tmp[10]; int k = 0;
+                        uint64_t v = dst.n - at;
+                        tmp[k++] = (uint8_t)(v & 0x7F);
+                        while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
+                        while (k) plt->push_back(tmp[--k]);
+                    }
                 }
             }
     };
@@ -295,6 +312,7 @@ extern "C" int64_t grk_amd_write_codestream_layout(const grk_amd_image_layout* i
         tile_of(l, *base, t, p);
         rc = build_tile_geom(p, g);
         if (rc != GRK_AMD_OK) return rc;
+        if (!order_ok(g, flags)) return GRK_AMD_ERR_UNSUPPORTED;
         if (t == 0) write_main_header(o, g, l.im, flags, ntiles, &tlm_at);
         const uint64_t len = write_tile_part(o, g, t, flags, table + row, coded);
         row += (uint64_t)g.blocks_per_comp * p.num_comps;
@@ -371,6 +389,7 @@ extern "C" int64_t grk_amd_write_tile_part(const grk_amd_tile_params* p, uint32_
     TileGeom g;
     int rc = build_tile_geom(*p, g);
     if (rc != GRK_AMD_OK) return rc;
+    if (!order_ok(g, flags)) return GRK_AMD_ERR_UNSUPPORTED;
     Out o{out, cap};
     write_tile_part(o, g, tile_index, flags, tile_table, coded);
     if (o.ovf) return GRK_AMD_ERR_OVERFLOW;

@@ -68,6 +68,13 @@ typedef struct grk_amd_tile_params {
                                     TileProcessor::init computes it).  0, 0 for an image at the origin with one tile; any
                                     other value changes the sub-band sizes, the code-block partition and, where a
                                     resolution starts on an odd coordinate, the lifting variant (WaveletFwd.cpp:884-905) */
+    uint8_t  precinct_exp[12];   /* [r] = PPx | PPy << 4 of resolution r (0 = coarsest), as the COD marker carries them
+                                    (grk_compress -c; TileComponentCodingParams::precinctWidthExp / HeightExp); 0 = not set
+                                    = 15 | 15 << 4: one precinct per resolution (so PPx = PPy = 0, legal for r = 0 only, cannot
+                                    be asked for).  Precincts cut the code-block partition
+                                    (code-block exponent <= precinct exponent of the band) and make one packet each; the
+                                    codestream writer takes them with LRCP / RLCP (the position-first orders need one
+                                    precinct per resolution) */
 } grk_amd_tile_params;
 
 /* One code-block of the tile, in the reference's enumeration order
@@ -81,6 +88,7 @@ typedef struct grk_amd_block {
     uint8_t  kmax;               /* band->numbps (= QCD exponent for HT, numgbits 1)           */
     uint8_t  reserved[3];
     float    stepsize;           /* band->stepsize (1.0 reversible)                            */
+    uint32_t precinct;           /* index of its precinct in the resolution's precinct grid (raster)  */
 } grk_amd_block;
 
 /* Result row per coded block. `offset` is relative to the start of the coded arena. */
@@ -107,6 +115,8 @@ int64_t grk_amd_tile_num_blocks(const grk_amd_tile_params* p);
  * Also returns per-band QCD words: reversible -> expn<<3 (u8), irreversible -> (expn<<11)|mant. */
 int64_t grk_amd_tile_layout(const grk_amd_tile_params* p, grk_amd_block* blocks, uint64_t cap,
                             uint16_t* qcd_words /* [3*levels+1] or NULL */);
+/* precincts of every resolution (counts[r], r = 0 coarsest .. num_levels): the packets a tile-component has per layer */
+int grk_amd_tile_precincts(const grk_amd_tile_params* p, uint32_t* counts);
 /* int32 elements between consecutive rows / planes of the device working planes */
 uint32_t grk_amd_plane_stride(const grk_amd_tile_params* p);
 uint64_t grk_amd_plane_elems(const grk_amd_tile_params* p);

@@ -296,42 +296,65 @@ static uint32_t band_lo(uint32_t v, uint32_t n, uint32_t hi)
     const uint64_t off = hi ? (1ull << (n - 1)) : 0;
     return v <= off ? 0u : (uint32_t)(((uint64_t)v - off + (1ull << n) - 1) >> n);
 }
-uint32_t orc_enumerate_blocks_at(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp, uint32_t x0, uint32_t y0,
-                                 const uint8_t* expn, orc_block* out, uint32_t cap)
+/* prc: precinct exponents per resolution (r = 0 coarsest), PPx | PPy << 4 as in the COD marker, or NULL / 0 = 15, 15.  The
+ * precincts of a resolution are the cells of the 2^PPx x 2^PPy grid anchored at the origin of ITS coordinates that it touches
+ * (t1/T1Structs.cpp:449-493, tile/TileComponent.cpp:100-118); in the bands of a resolution r > 0 a precinct is half as large;
+ * a code-block is never larger than that (cblk exponent = min(cblk_exp, precinct exponent of the band)); the blocks are
+ * enumerated band -> precinct (raster) -> block (raster) (T1CompressScheduler.cpp:44-85). */
+uint32_t orc_enumerate_blocks_prc(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp, uint32_t x0, uint32_t y0,
+                                  const uint8_t* prc, const uint8_t* expn, orc_block* out, uint32_t cap)
 {
     uint32_t n = 0;
-    const uint32_t cb = 1u << cblk_exp;
     for (uint32_t r = 0; r <= levels; ++r) {
         const uint32_t nn = r ? levels - r + 1 : levels;                 /* decomposition the band belongs to */
         const uint32_t lw = r ? cdivp2(x0 + w, nn) - cdivp2(x0, nn) : 0, lh = r ? cdivp2(y0 + h, nn) - cdivp2(y0, nn) : 0;
+        const uint32_t rx0 = cdivp2(x0, levels - r), rx1 = cdivp2(x0 + w, levels - r);
+        const uint32_t ry0 = cdivp2(y0, levels - r), ry1 = cdivp2(y0 + h, levels - r);
+        const uint32_t pe = prc ? prc[r] : 0;
+        const uint32_t ppx = pe ? (pe & 15u) : 15u, ppy = pe ? (pe >> 4) : 15u;
+        const uint32_t npw = rx1 > rx0 ? (uint32_t)((((uint64_t)rx1 + (1ull << ppx) - 1) >> ppx) - (rx0 >> ppx)) : 0;
+        const uint32_t nph = ry1 > ry0 ? (uint32_t)((((uint64_t)ry1 + (1ull << ppy) - 1) >> ppy) - (ry0 >> ppy)) : 0;
+        const uint32_t bpx = ppx - (r ? 1u : 0u), bpy = ppy - (r ? 1u : 0u);
+        const uint32_t psx = ((rx0 >> ppx) << ppx) >> (r ? 1u : 0u), psy = ((ry0 >> ppy) << ppy) >> (r ? 1u : 0u);
+        const uint32_t cxe = cblk_exp < bpx ? cblk_exp : bpx, cye = cblk_exp < bpy ? cblk_exp : bpy;
         uint32_t nb = r ? 3 : 1;
         for (uint32_t bi = 0; bi < nb; ++bi) {
             uint32_t orient = r ? bi + 1 : 0;
             const uint32_t bx0 = band_lo(x0, nn, orient & 1), bx1 = band_lo(x0 + w, nn, orient & 1);
             const uint32_t by0 = band_lo(y0, nn, orient >> 1), by1 = band_lo(y0 + h, nn, orient >> 1);
-            const uint32_t bw = bx1 - bx0, bh = by1 - by0;
             uint32_t ox = (orient & 1) ? lw : 0, oy = (orient & 2) ? lh : 0;
             uint32_t qcd_idx = r ? 3 * (r - 1) + 1 + bi : 0;
-            if (bw == 0 || bh == 0) continue;
-            const uint32_t gx0 = bx0 >> cblk_exp, gx1 = (bx1 + cb - 1) >> cblk_exp;
-            const uint32_t gy0 = by0 >> cblk_exp, gy1 = (by1 + cb - 1) >> cblk_exp;
-            for (uint32_t gy = gy0; gy < gy1; ++gy)
-                for (uint32_t gx = gx0; gx < gx1; ++gx) {
-                    if (n < cap) {
-                        orc_block* b = &out[n];
-                        const uint32_t cx0 = gx * cb > bx0 ? gx * cb : bx0, cx1 = (gx + 1) * cb < bx1 ? (gx + 1) * cb : bx1;
-                        const uint32_t cy0 = gy * cb > by0 ? gy * cb : by0, cy1 = (gy + 1) * cb < by1 ? (gy + 1) * cb : by1;
-                        b->x = ox + (cx0 - bx0); b->y = oy + (cy0 - by0);
-                        b->w = cx1 - cx0; b->h = cy1 - cy0;
-                        b->res = (uint8_t)r; b->band = (uint8_t)orient;
-                        b->kmax = expn ? expn[qcd_idx] : 0; b->pad = 0;
-                        b->bx = gx - gx0; b->by = gy - gy0;
-                    }
-                    ++n;
+            for (uint32_t pj = 0; pj < nph; ++pj)
+                for (uint32_t pi = 0; pi < npw; ++pi) {
+                    const uint64_t qx0 = (uint64_t)psx + ((uint64_t)pi << bpx), qy0 = (uint64_t)psy + ((uint64_t)pj << bpy);
+                    const uint64_t cx0 = qx0 > bx0 ? qx0 : bx0, cx1 = qx0 + (1ull << bpx) < bx1 ? qx0 + (1ull << bpx) : bx1;
+                    const uint64_t cy0 = qy0 > by0 ? qy0 : by0, cy1 = qy0 + (1ull << bpy) < by1 ? qy0 + (1ull << bpy) : by1;
+                    if (cx0 >= cx1 || cy0 >= cy1) continue;
+                    const uint64_t gx0 = cx0 >> cxe, gx1 = (cx1 + (1ull << cxe) - 1) >> cxe;
+                    const uint64_t gy0 = cy0 >> cye, gy1 = (cy1 + (1ull << cye) - 1) >> cye;
+                    for (uint64_t gy = gy0; gy < gy1; ++gy)
+                        for (uint64_t gx = gx0; gx < gx1; ++gx) {
+                            if (n < cap) {
+                                orc_block* b = &out[n];
+                                const uint64_t ax0 = (gx << cxe) > cx0 ? (gx << cxe) : cx0, ax1 = ((gx + 1) << cxe) < cx1 ? ((gx + 1) << cxe) : cx1;
+                                const uint64_t ay0 = (gy << cye) > cy0 ? (gy << cye) : cy0, ay1 = ((gy + 1) << cye) < cy1 ? ((gy + 1) << cye) : cy1;
+                                b->x = ox + (uint32_t)(ax0 - bx0); b->y = oy + (uint32_t)(ay0 - by0);
+                                b->w = (uint32_t)(ax1 - ax0); b->h = (uint32_t)(ay1 - ay0);
+                                b->res = (uint8_t)r; b->band = (uint8_t)orient;
+                                b->kmax = expn ? expn[qcd_idx] : 0; b->pad = 0;
+                                b->bx = (uint32_t)(gx - gx0); b->by = (uint32_t)(gy - gy0);
+                            }
+                            ++n;
+                        }
                 }
         }
     }
     return n;
+}
+uint32_t orc_enumerate_blocks_at(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp, uint32_t x0, uint32_t y0,
+                                 const uint8_t* expn, orc_block* out, uint32_t cap)
+{
+    return orc_enumerate_blocks_prc(w, h, levels, cblk_exp, x0, y0, NULL, expn, out, cap);
 }
 uint32_t orc_enumerate_blocks(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp,
                               const uint8_t* expn, orc_block* out, uint32_t cap)
@@ -635,6 +658,10 @@ int32_t orc_encode_tile_rev_at(const void* pixels, int bps, uint32_t ncomp, uint
                                uint32_t prec, uint32_t levels, int mct, uint32_t x0, uint32_t y0, orc_block* blocks_out,
                                uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
                                uint64_t* total_bytes);
+int32_t orc_encode_tile_rev_prc(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
+                                uint32_t prec, uint32_t levels, int mct, uint32_t x0, uint32_t y0, const uint8_t* prc,
+                                orc_block* blocks_out, uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
+                                uint64_t* total_bytes);
 int32_t orc_encode_tile_rev(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
                             uint32_t prec, uint32_t levels, int mct, orc_block* blocks_out,
                             uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
@@ -648,6 +675,14 @@ int32_t orc_encode_tile_rev_at(const void* pixels, int bps, uint32_t ncomp, uint
                                uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
                                uint64_t* total_bytes)
 {
+    return orc_encode_tile_rev_prc(pixels, bps, ncomp, w, h, prec, levels, mct, x0, y0, NULL, blocks_out, lens, max_blocks, coded, cap,
+                                   total_bytes);
+}
+int32_t orc_encode_tile_rev_prc(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
+                                uint32_t prec, uint32_t levels, int mct, uint32_t x0, uint32_t y0, const uint8_t* prc,
+                                orc_block* blocks_out, uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
+                                uint64_t* total_bytes)
+{
     uint32_t stride = stride_for(w);
     size_t plane_n = (size_t)stride * h;
     int32_t* planes = (int32_t*)calloc(plane_n * ncomp, sizeof(int32_t));
@@ -659,11 +694,11 @@ int32_t orc_encode_tile_rev_at(const void* pixels, int bps, uint32_t ncomp, uint
     if (mct && ncomp >= 3) orc_rct_fwd(planes, planes + plane_n, planes + 2 * plane_n, plane_n);
     for (uint32_t c = 0; c < ncomp; ++c) orc_dwt53_fwd_at(planes + c * plane_n, w, h, stride, levels, x0, y0);
     orc_ht_rev_exponents(prec, levels, expn);
-    uint32_t nb = orc_enumerate_blocks_at(w, h, levels, 6, x0, y0, expn, NULL, 0);
+    uint32_t nb = orc_enumerate_blocks_prc(w, h, levels, 6, x0, y0, prc, expn, NULL, 0);
     if (nb * ncomp > max_blocks) { free(planes); return -2; }
     uint64_t off = 0; uint32_t k = 0;
     for (uint32_t c = 0; c < ncomp; ++c) {
-        orc_enumerate_blocks_at(w, h, levels, 6, x0, y0, expn, blocks_out + k, nb);
+        orc_enumerate_blocks_prc(w, h, levels, 6, x0, y0, prc, expn, blocks_out + k, nb);
         for (uint32_t i = 0; i < nb; ++i, ++k) {
             orc_block* b = &blocks_out[k];
             b->pad = (uint8_t)c;

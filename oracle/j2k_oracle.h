@@ -97,6 +97,13 @@ uint32_t orc_enumerate_blocks_at(uint32_t w, uint32_t h, uint32_t levels, uint32
 int32_t orc_encode_tile_rev_at(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
                                uint32_t prec, uint32_t levels, int mct, uint32_t x0, uint32_t y0, orc_block* blocks_out,
                                uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap, uint64_t* total_bytes);
+/* ---- precincts (grk_compress -c; COD precinct sizes): prc[r] = PPx | PPy << 4 for resolution r, NULL / 0 = 15, 15 ---- */
+uint32_t orc_enumerate_blocks_prc(uint32_t w, uint32_t h, uint32_t levels, uint32_t cblk_exp, uint32_t x0, uint32_t y0,
+                                  const uint8_t* prc, const uint8_t* expn, orc_block* out, uint32_t cap);
+int32_t orc_encode_tile_rev_prc(const void* pixels, int bps, uint32_t ncomp, uint32_t w, uint32_t h,
+                                uint32_t prec, uint32_t levels, int mct, uint32_t x0, uint32_t y0, const uint8_t* prc,
+                                orc_block* blocks_out, uint32_t* lens, uint32_t max_blocks, uint8_t* coded, uint64_t cap,
+                                uint64_t* total_bytes);
 /* ---- N3: the HT refinement passes (SigProp, MagRef) on top of the cleanup pass's output -- oracle/ht_refine_oracle.c
  *           (t1/t1_ht/coding/ojph_block_decoder.cpp:1627-2100; bit readers :466-550, :875-945) and an encoder of them
  *           that makes the test vectors (Grok's encoder never emits the passes) */

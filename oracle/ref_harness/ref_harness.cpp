@@ -202,6 +202,17 @@ static void fill_params(grk_cparameters& p, const EncCfg& c)
 	// grk_compress -p / -S / -E: progression order, SOP and EPH markers
 	if (const char* e = getenv("REF_PROG_ORDER")) p.prog_order = (GRK_PROG_ORDER)atoi(e);
 	if (const char* e = getenv("REF_CSTY")) p.csty = (uint8_t)(p.csty | atoi(e));
+	// grk_compress -c [w,h],[w,h],...: precinct sizes from the highest resolution down (REF_PRECINCTS="w,h,w,h,...")
+	if (const char* e = getenv("REF_PRECINCTS")) {
+		uint32_t n = 0; const char* q = e;
+		while (*q && n < GRK_J2K_MAXRLVLS) {
+			unsigned pw = 0, ph = 0; int used = 0;
+			if (sscanf(q, "%u,%u%n", &pw, &ph, &used) != 2) break;
+			p.prcw_init[n] = pw; p.prch_init[n] = ph; ++n;
+			q += used; if (*q == ',') ++q;
+		}
+		if (n) { p.res_spec = n; p.csty |= 0x01; }
+	}
 	// grk_compress -d: the image area's origin on the canonical grid (the tile grid stays anchored at 0, 0)
 	if (const char* e = getenv("REF_IMG_X0")) p.image_offset_x0 = (uint32_t)atoi(e);
 	if (const char* e = getenv("REF_IMG_Y0")) p.image_offset_y0 = (uint32_t)atoi(e);

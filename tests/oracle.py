@@ -84,6 +84,11 @@ def lib():
             getattr(L, f).restype = None
         L.orc_enumerate_blocks_at.restype = u32
         L.orc_enumerate_blocks_at.argtypes = [u32] * 6 + [C.c_void_p, C.c_void_p, u32]
+        L.orc_enumerate_blocks_prc.restype = u32
+        L.orc_enumerate_blocks_prc.argtypes = [u32] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p, u32]
+        L.orc_encode_tile_rev_prc.restype = C.c_int32
+        L.orc_encode_tile_rev_prc.argtypes = [C.c_void_p, C.c_int, u32, u32, u32, u32, u32, C.c_int, u32, u32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, u32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_encode_tile_rev_at.restype = C.c_int32
         L.orc_encode_tile_rev_at.argtypes = [C.c_void_p, C.c_int, u32, u32, u32, u32, u32, C.c_int, u32, u32, C.c_void_p,
                                              C.c_void_p, u32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -226,13 +231,23 @@ def irrev_stepsizes(prec, levels):
     return q, d
 
 
-def enumerate_blocks(w, h, levels, expn=None, cblk_exp=6, origin=(0, 0)):
+def _prc(precincts, levels):
+    """[(PPx, PPy)] per resolution (0 = coarsest) -> the COD bytes, or None"""
+    if precincts is None:
+        return None
+    assert len(precincts) == levels + 1
+    return np.array([ppx | (ppy << 4) for ppx, ppy in precincts], np.uint8)
+
+
+def enumerate_blocks(w, h, levels, expn=None, cblk_exp=6, origin=(0, 0), precincts=None):
     L = lib()
     e = None if expn is None else np.ascontiguousarray(expn, np.uint8)
     ep = e.ctypes.data if e is not None else None
-    n = L.orc_enumerate_blocks_at(w, h, levels, cblk_exp, origin[0], origin[1], ep, None, 0)
+    pr = _prc(precincts, levels)
+    pp = pr.ctypes.data if pr is not None else None
+    n = L.orc_enumerate_blocks_prc(w, h, levels, cblk_exp, origin[0], origin[1], pp, ep, None, 0)
     arr = (Block * n)()
-    L.orc_enumerate_blocks_at(w, h, levels, cblk_exp, origin[0], origin[1], ep, arr, n)
+    L.orc_enumerate_blocks_prc(w, h, levels, cblk_exp, origin[0], origin[1], pp, ep, arr, n)
     return list(arr)
 
 
@@ -276,21 +291,23 @@ def ict_fwd(r, g, b):
     return [v.view(np.float32) for v in a]
 
 
-def encode_tile_rev(pixels, prec, levels, mct=None, origin=(0, 0)):
+def encode_tile_rev(pixels, prec, levels, mct=None, origin=(0, 0), precincts=None):
     """pixels (C,H,W) u8/u16 -> (blocks, lens, coded bytes) in reference enumeration order."""
     px = np.ascontiguousarray(pixels)
     Cn, H, W = px.shape
     if mct is None:
         mct = Cn >= 3
     L = lib()
-    nb = L.orc_enumerate_blocks_at(W, H, levels, 6, origin[0], origin[1], None, None, 0) * Cn
+    pr = _prc(precincts, levels)
+    pp = pr.ctypes.data if pr is not None else None
+    nb = L.orc_enumerate_blocks_prc(W, H, levels, 6, origin[0], origin[1], pp, None, None, 0) * Cn
     blocks = (Block * nb)()
     lens = np.zeros(nb, np.uint32)
     cap = px.size * 4 + nb * 64 + (1 << 16)
     coded = np.zeros(cap, np.uint8)
     tot = C.c_uint64(0)
-    n = L.orc_encode_tile_rev_at(px.ctypes.data, px.dtype.itemsize, Cn, W, H, prec, levels, int(mct), origin[0], origin[1],
-                                 blocks, lens.ctypes.data, nb, coded.ctypes.data, cap, C.byref(tot))
+    n = L.orc_encode_tile_rev_prc(px.ctypes.data, px.dtype.itemsize, Cn, W, H, prec, levels, int(mct), origin[0], origin[1], pp,
+                                  blocks, lens.ctypes.data, nb, coded.ctypes.data, cap, C.byref(tot))
     assert n == nb, n
     return list(blocks), lens, coded[:tot.value]
 
