@@ -216,45 +216,68 @@ grk_amd_image_layout plain_layout(const grk_amd_tile_params& p, uint32_t img_w, 
     return grk_amd_image_layout{p.tile_x0, p.tile_y0, p.tile_x0 + img_w, p.tile_y0 + img_h, p.tile_x0, p.tile_y0, p.tile_w, p.tile_h};
 }
 
-// RPCL, PCRL and CPRL walk precinct POSITIONS across resolutions and components: with one precinct per resolution that is
-// the loop nests below; more precincts would need the position iterator of t2/PacketIter.cpp:870-1100
-bool order_ok(const TileGeom& g, uint32_t flags)
-{
-    if (((flags >> GRK_AMD_CS_PROG_SHIFT) & 7u) < 2u) return true;
-    for (const auto& R : g.res) if ((uint64_t)R.npw * R.nph > 1) return false;
-    return true;
-}
-
 // SOT, (PLT,) SOD and the packets of one tile in the progression order of `flags`; returns the tile-part's length.
-// With one layer and one precinct per resolution the five orders (t2/PacketIter.cpp:805-1100) come down to two loop nests:
-// LRCP, RLCP and RPCL walk resolution -> component, PCRL and CPRL component -> resolution.
+// One layer, every component with the same geometry: the five orders (ISO 15444-1 B.12.1; t2/PacketIter.cpp:805-1100) are
+//   LRCP, RLCP  resolution -> component -> precinct (raster)
+//   RPCL        resolution -> precinct position -> component
+//   PCRL        precinct position -> component -> resolution
+//   CPRL        component -> precinct position -> resolution
+// where a precinct's position is its top-left corner on the canonical grid, clipped to the tile -- the (y, x) at which
+// the standard's position loops meet it; positions are walked in raster order, several resolutions can share one.
 uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, const grk_amd_coded_block* tt, const uint8_t* coded)
 {
     const grk_amd_tile_params& p = g.p;
     const uint64_t sot = o.n;
-    const bool comp_major = ((flags >> GRK_AMD_CS_PROG_SHIFT) & 7u) >= 3u;
+    const uint32_t order = (flags >> GRK_AMD_CS_PROG_SHIFT) & 7u;
     const bool sop = (flags & GRK_AMD_CS_SOP) != 0, eph = (flags & GRK_AMD_CS_EPH) != 0;
+    struct Pk { uint32_t r, pi; uint64_t x, y; };
+    std::vector<Pk> prec;                                   // every precinct of a tile-component, resolution-major, raster
+    for (uint32_t r = 0; r <= p.num_levels; ++r) {
+        const ResGeom& R = g.res[r];
+        const uint32_t sh = p.num_levels - r;
+        for (uint32_t pj = 0; pj < R.nph; ++pj)
+            for (uint32_t pi = 0; pi < R.npw; ++pi) {
+                const uint64_t cx = ((uint64_t)((R.x0 >> R.ppx) + pi) << R.ppx) << sh, cy = ((uint64_t)((R.y0 >> R.ppy) + pj) << R.ppy) << sh;
+                prec.push_back(Pk{r, pj * R.npw + pi, std::max<uint64_t>(cx, p.tile_x0), std::max<uint64_t>(cy, p.tile_y0)});
+            }
+    }
+    std::vector<Pk> by_pos = prec;                          // PCRL / CPRL: by position, then resolution
+    std::stable_sort(by_pos.begin(), by_pos.end(), [](const Pk& a, const Pk& b) { return a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.r < b.r; });
     auto packets = [&](Out& dst, std::vector<uint8_t>* plt) {
         int32_t n = 0;
-        const uint32_t outer = comp_major ? p.num_comps : p.num_levels + 1u, inner = comp_major ? p.num_levels + 1u : p.num_comps;
-        for (uint32_t a = 0; a < outer; ++a)
-            for (uint32_t b = 0; b < inner; ++b) {
-                const uint32_t r = comp_major ? b : a, c = comp_major ? a : b;
-                // one packet per precinct of the resolution, in raster order (none for a resolution without samples); the
-                // position-first orders are only taken with one precinct per resolution (checked by the entry points)
-                for (uint32_t pi = 0; pi < g.res[r].npw * g.res[r].nph; ++pi) {
-                    const uint64_t at = dst.n;
-                    write_packet(dst, g, r, pi, tt + (uint64_t)c * g.blocks_per_comp, coded, sop ? n : -1, eph);
-                    ++n;
-                    if (plt) {                  // the packet's length as a big-endian base-128 number (continuation bit 0x80)
-                        uint8_t tmp[10]; int k = 0;
-                        uint64_t v = dst.n - at;
-                        tmp[k++] = (uint8_t)(v & 0x7F);
-                        while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
-                        while (k) plt->push_back(tmp[--k]);
-                    }
-                }
+        auto one = [&](uint32_t r, uint32_t c, uint32_t pi) {
+            const uint64_t at = dst.n;
+            write_packet(dst, g, r, pi, tt + (uint64_t)c * g.blocks_per_comp, coded, sop ? n : -1, eph);
+            ++n;
+            if (plt) {                          // the packet's length as a big-endian base-128 number (continuation bit 0x80)
+                uint8_t tmp[10]; int k = 0;
+                uint64_t v = dst.n - at;
+                tmp[k++] = (uint8_t)(v & 0x7F);
+                while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
+                while (k) plt->push_back(tmp[--k]);
             }
+        };
+        if (order <= 1) {
+            size_t i = 0;
+            for (uint32_t r = 0; r <= p.num_levels; ++r) {
+                const size_t first = i;
+                while (i < prec.size() && prec[i].r == r) ++i;
+                for (uint32_t c = 0; c < p.num_comps; ++c)
+                    for (size_t k = first; k < i; ++k) one(r, c, prec[k].pi);
+            }
+        } else if (order == 2) {
+            for (const Pk& q : prec) for (uint32_t c = 0; c < p.num_comps; ++c) one(q.r, c, q.pi);
+        } else if (order == 3) {
+            // (precincts at one position: component, then resolution)
+            for (size_t i = 0; i < by_pos.size();) {
+                size_t j = i;
+                while (j < by_pos.size() && by_pos[j].x == by_pos[i].x && by_pos[j].y == by_pos[i].y) ++j;
+                for (uint32_t c = 0; c < p.num_comps; ++c) for (size_t k = i; k < j; ++k) one(by_pos[k].r, c, by_pos[k].pi);
+                i = j;
+            }
+        } else {
+            for (uint32_t c = 0; c < p.num_comps; ++c) for (const Pk& q : by_pos) one(q.r, c, q.pi);
+        }
     };
     o.u16(0xFF90); o.u16(10); o.u16(t); o.u32(0); o.u8(0); o.u8(1);
     if (flags & GRK_AMD_CS_PLT) {
@@ -312,7 +335,6 @@ extern "C" int64_t grk_amd_write_codestream_layout(const grk_amd_image_layout* i
         tile_of(l, *base, t, p);
         rc = build_tile_geom(p, g);
         if (rc != GRK_AMD_OK) return rc;
-        if (!order_ok(g, flags)) return GRK_AMD_ERR_UNSUPPORTED;
         if (t == 0) write_main_header(o, g, l.im, flags, ntiles, &tlm_at);
         const uint64_t len = write_tile_part(o, g, t, flags, table + row, coded);
         row += (uint64_t)g.blocks_per_comp * p.num_comps;
@@ -389,7 +411,6 @@ extern "C" int64_t grk_amd_write_tile_part(const grk_amd_tile_params* p, uint32_
     TileGeom g;
     int rc = build_tile_geom(*p, g);
     if (rc != GRK_AMD_OK) return rc;
-    if (!order_ok(g, flags)) return GRK_AMD_ERR_UNSUPPORTED;
     Out o{out, cap};
     write_tile_part(o, g, tile_index, flags, tile_table, coded);
     if (o.ovf) return GRK_AMD_ERR_OVERFLOW;

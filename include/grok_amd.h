@@ -72,9 +72,8 @@ typedef struct grk_amd_tile_params {
                                     (grk_compress -c; TileComponentCodingParams::precinctWidthExp / HeightExp); 0 = not set
                                     = 15 | 15 << 4: one precinct per resolution (so PPx = PPy = 0, legal for r = 0 only, cannot
                                     be asked for).  Precincts cut the code-block partition
-                                    (code-block exponent <= precinct exponent of the band) and make one packet each; the
-                                    codestream writer takes them with LRCP / RLCP (the position-first orders need one
-                                    precinct per resolution) */
+                                    (code-block exponent <= precinct exponent of the band) and make one packet each, in
+                                    any of the five progression orders */
 } grk_amd_tile_params;
 
 /* One code-block of the tile, in the reference's enumeration order

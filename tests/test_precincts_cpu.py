@@ -3,7 +3,7 @@
   * the product's host geometry with precinct exponents == the oracle's enumeration (random sizes, origins, exponents),
   * oracle tiles + the product's Tier-2 writer == the files grk_compress writes with -c (several size lists, LRCP and RLCP,
     multi-tile, image offsets, TLM + PLT + SOP + EPH),
-  * the position-first progression orders are refused with more than one precinct in a resolution."""
+  * RPCL / PCRL / CPRL walk the precincts' positions on the canonical grid: == grk_compress -p files as well."""
 import numpy as np
 import pytest
 
@@ -104,14 +104,30 @@ def test_oracle_codestream_with_precincts_is_the_reference_file(monkeypatch, W, 
     assert np.array_equal(R.decode(got, 3, H, W), px.astype(np.int32))
 
 
-def test_position_first_orders_need_one_precinct_per_resolution():
-    p = G.TileParams.make(256, 256, 1, 8, 3, precincts=[(5, 5)] * 4)
-    n = G.lib().grk_amd_tile_num_blocks(p)
-    t = np.zeros(n, CODED_DTYPE)
-    for order in (2, 3, 4):
-        with pytest.raises(RuntimeError):
-            G.write_codestream(p, 256, 256, t, np.zeros(16, np.uint8), G.CS_PROG(order))
-    G.write_codestream(p, 256, 256, t, np.zeros(16, np.uint8), G.CS_PROG(1))
+@needs_ref
+@pytest.mark.parametrize("order", [2, 3, 4])
+@pytest.mark.parametrize("W,H,TW,TH,L,off,sizes", [(256, 192, 256, 192, 4, (0, 0), [(128, 128)]), (300, 210, 128, 128, 3, (0, 0), [(64, 32), (32, 64)]),
+                                                   (257, 129, 300, 200, 5, (33, 95), [(128, 64), (64, 64), (16, 16)]),
+                                                   (199, 159, 100, 100, 2, (1, 1), [(32, 32)]), (256, 256, 256, 256, 5, (0, 0), [(256, 256), (64, 64), (128, 128)])])
+def test_position_first_orders_with_precincts_are_the_reference_files(monkeypatch, order, W, H, TW, TH, L, off, sizes):
+    """RPCL, PCRL, CPRL with several precincts per resolution: packets in the order of the precincts' positions on the
+    canonical grid (resolutions with different precinct sizes interleave) == grk_compress -p; with PLT."""
+    from test_offgrid_cpu import ref_defects
+    px = synth.g2(3, H, W, 8, seed=W + L + order)
+    layout = G.ImageLayout.make(W, H, TW, TH, offset=off)
+    assert ref_defects(layout, L) == (False, False)
+    monkeypatch.setenv("REF_IMG_X0", str(off[0]))
+    monkeypatch.setenv("REF_IMG_Y0", str(off[1]))
+    monkeypatch.setenv("REF_PRECINCTS", ",".join("%d,%d" % s for s in sizes))
+    monkeypatch.setenv("REF_PROG_ORDER", str(order))
+    # (PLT only where every band of every precinct has samples: the reference's PLT entries of packets with an empty band
+    #  are too large, D15 -- e.g. +5 each for the 24-row tile of the third layout -- while the packets agree)
+    plt = off == (0, 0) and W % TW == 0
+    monkeypatch.setenv("REF_WRITE_PLT", "1" if plt else "0")
+    want, _ = R.encode(px, 8, TW=TW, TH=TH, numres=L + 1, mode=1)
+    got = oracle_codestream_prc(px, 8, L, layout, exps_from_sizes(sizes, L), G.CS_PROG(order) | (G.CS_PLT if plt else 0))
+    assert got == want
+    assert np.array_equal(R.decode(got, 3, H, W), px.astype(np.int32))
 
 
 @needs_ref
