@@ -413,10 +413,10 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
         const char* path = in_path ? in_path : !dp ? nullptr : dp->infile[0] ? dp->infile : dp->core.infile[0] ? dp->core.infile : nullptr;
         if (!path || !read_stream_header(path, sh) || sh.overrides) return clean(-1);
     }
-    // the scope of the hot path: one tile (anywhere on the canonical grid), equal full-resolution components, default
-    // precincts, one codeword segment per block (the host's bridge throws on more); irreversible only for classic
+    // the scope of the hot path: one tile (anywhere on the canonical grid), equal full-resolution components, one
+    // layer, one codeword segment per block (the host's bridge throws on more); irreversible only for classic
     // blocks (the reference's own HT + 9/7 encoder is broken, D1: there is no stream to be compatible with)
-    if (h.t_grid_width * h.t_grid_height != 1 || img->numcomps == 0 || (h.csty & 1u) ||
+    if (h.t_grid_width * h.t_grid_height != 1 || img->numcomps == 0 ||
         (h.irreversible && (h.cblk_sty & 0x40u)) || (h.cblk_sty & 0x05u) || h.numresolutions == 0)
         return clean(-1);
     const gra_image_comp& c0 = img->comps[0];
@@ -434,6 +434,15 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
     while ((1u << ew) < h.cblockw_init) ++ew;
     while ((1u << eh) < h.cblockh_init) ++eh;
     tp.cblk_w_exp = (uint8_t)ew; tp.cblk_h_exp = (uint8_t)eh;
+    if (h.csty & 1u) {                                      // precinct partition: sizes 2^PPx x 2^PPy per resolution (0 = coarsest)
+        for (uint32_t r = 0; r < h.numresolutions; ++r) {
+            uint32_t ex = 0, ey = 0;
+            while ((1u << ex) < h.prcw_init[r]) ++ex;
+            while ((1u << ey) < h.prch_init[r]) ++ey;
+            if (ex > 15 || ey > 15 || (ex | (ey << 4)) == 0) return clean(-1);
+            tp.precinct_exp[r] = (uint8_t)(ex | (ey << 4));
+        }
+    }
     tp.reserved[0] = (h.cblk_sty & 0x40u) ? 0 : 1;         // HT bit clear: classic Part-1 blocks
     tp.reserved[1] = h.cblk_sty & 0x3Fu;
     const int64_t nb = grk_amd_tile_num_blocks(&tp);

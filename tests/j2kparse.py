@@ -89,9 +89,10 @@ def parse(cs):
             assert xto + xt >= xs and yto + yt >= ys, "single-tile streams only"
         elif marker == 0xFF52:      # COD
             scod, prog, layers, mct, levels, cbw, cbh, sty, xf = struct.unpack(">BBHBBBBBB", body[:10])
-            assert prog == 0 and layers == 1 and (scod & 1) == 0, "LRCP, 1 layer, default precincts only"
+            assert prog in (0, 1) and layers == 1, "LRCP / RLCP, 1 layer only"
+            prc = [(b & 15, b >> 4) for b in body[10:10 + levels + 1]] if scod & 1 else [(15, 15)] * (levels + 1)
             info.update(levels=levels, cbw=cbw + 2, cbh=cbh + 2, mct=mct, cblk_sty=sty, irreversible=int(xf == 0),
-                        ht=int((sty & 0x40) != 0))
+                        ht=int((sty & 0x40) != 0), prc=prc, scod=scod)
         elif marker == 0xFF5C:      # QCD
             sq = body[0]
             info["guard"] = sq >> 5
@@ -110,7 +111,6 @@ def parse(cs):
         pos += 2 + ln
     pos += 2
     W, H, L = info["W"], info["H"], info["levels"]
-    cexp = min(info["cbw"], 15), min(info["cbh"], 15)
     state = {}
     blocks = {}
     segments = {}                 # key -> [(bytes, passes), ...] codeword segments (B.10.7.2: TERMALL / LAZY split them)
@@ -138,26 +138,55 @@ def parse(cs):
         return (_cdp2(max(X0 - (1 << (n - 1)) * bx, 0), n), _cdp2(max(Y0 - (1 << (n - 1)) * by, 0), n),
                 _cdp2(max(X0 + W - (1 << (n - 1)) * bx, 0), n), _cdp2(max(Y0 + H - (1 << (n - 1)) * by, 0), n))
 
+    sop, eph = bool(info.get("scod", 0) & 2), bool(info.get("scod", 0) & 4)
     for r in range(L + 1):
-        if _cdp2(X0 + W, L - r) == _cdp2(X0, L - r) or _cdp2(Y0 + H, L - r) == _cdp2(Y0, L - r):
+        rx0, rx1, ry0, ry1 = _cdp2(X0, L - r), _cdp2(X0 + W, L - r), _cdp2(Y0, L - r), _cdp2(Y0 + H, L - r)
+        if rx1 == rx0 or ry1 == ry0:
             continue              # a resolution without samples has no precinct and no packet
+        # precincts: the cells of the 2^PPx x 2^PPy grid anchored at the origin of the resolution's coordinates (B.6); in the
+        # bands of a resolution r > 0 a precinct is half as large, and a code-block is never larger than that
+        ppx, ppy = info["prc"][r]
+        npw, nph = _cdp2(rx1, ppx) - (rx0 >> ppx), _cdp2(ry1, ppy) - (ry0 >> ppy)
+        sub = 1 if r else 0
+        bpx, bpy = ppx - sub, ppy - sub
+        psx, psy = ((rx0 >> ppx) << ppx) >> sub, ((ry0 >> ppy) << ppy) >> sub
+        cexp = min(info["cbw"], bpx), min(info["cbh"], bpy)
+        bands = [0] if r == 0 else [1, 2, 3]
+        grids = {}                # band -> [(gw, gh, first index)] per precinct
+        for b in bands:
+            bx0, by0, bx1, by1 = band_rect(r, b)
+            lst, first = [], 0
+            for pj in range(nph):
+                for pi in range(npw):
+                    qx0, qy0 = psx + (pi << bpx), psy + (pj << bpy)
+                    cx0, cx1 = max(qx0, bx0), min(qx0 + (1 << bpx), bx1)
+                    cy0, cy1 = max(qy0, by0), min(qy0 + (1 << bpy), by1)
+                    if cx0 >= cx1 or cy0 >= cy1:
+                        lst.append((0, 0, first))
+                        continue
+                    gw, gh = _cdp2(cx1, cexp[0]) - (cx0 >> cexp[0]), _cdp2(cy1, cexp[1]) - (cy0 >> cexp[1])
+                    lst.append((gw, gh, first))
+                    first += gw * gh
+            grids[b] = lst
         for c in range(info["C"]):
-            bands = [0] if r == 0 else [1, 2, 3]
+          for pk in range(npw * nph):
+            if sop:
+                assert cs[pos:pos + 2] == b"\xff\x91"
+                pos += 6
             br = Bits(cs, pos)
             nonempty = br.bit()
             todo = []
             for b in bands:
-                bx0, by0, bx1, by1 = band_rect(r, b)
-                if bx1 == bx0 or by1 == by0:
+                gw, gh, first = grids[b][pk]
+                if gw == 0 or gh == 0:
                     continue
-                # code-blocks: the cells of the grid anchored at the origin of the band's coordinates that it touches
-                gw, gh = _cdp2(bx1, cexp[0]) - (bx0 >> cexp[0]), _cdp2(by1, cexp[1]) - (by0 >> cexp[1])
-                key = (c, r, b)
+                key = (c, r, b, pk)
                 if key not in state:
                     state[key] = (TagTree(gw, gh), TagTree(gw, gh), {})
                 incl, zbp, lblock = state[key]
-                for idx in range(gw * gh):
-                    x, y = idx % gw, idx // gw
+                for loc in range(gw * gh):
+                    idx = first + loc
+                    x, y = loc % gw, loc // gw
                     if not nonempty:
                         blocks[(c, r, b, idx)] = (b"", 0, 0)
                         continue
@@ -184,16 +213,19 @@ def parse(cs):
                         else:
                             v = br.bits(5)
                             npass = 6 + v if v < 31 else 37 + br.bits(7)
-                    lb = lblock.get(idx, 3)
+                    lb = lblock.get(loc, 3)
                     while br.bit():
                         lb += 1
-                    lblock[idx] = lb
+                    lblock[loc] = lb
                     # one length per codeword segment, lblock + floor(log2(passes in the segment)) bits each; HT: the
                     # reference's encoder emits the single cleanup pass as one segment
                     segs = [(br.bits(lb + int(np.floor(np.log2(k)))), k) for k in ([npass] if info["ht"] else split_passes(npass))]
                     segments[(c, r, b, idx)] = segs
                     todo.append(((c, r, b, idx), npass, zero_bp, sum(a for a, _ in segs)))
             pos = br.align()
+            if eph:
+                assert cs[pos:pos + 2] == b"\xff\x92"
+                pos += 2
             for key, npass, zero_bp, ln in todo:
                 blocks[key] = (cs[pos:pos + ln], npass, zero_bp)
                 pos += ln

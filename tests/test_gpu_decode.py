@@ -374,7 +374,8 @@ def _gpu_decode_reference_stream(cs, part1):
     info = J.parse(cs)
     p = G.TileParams.make(info["W"], info["H"], info["C"], info["prec"], info["levels"],
                           irreversible=bool(info["irreversible"]), mct=bool(info["mct"]), part1=part1,
-                          cblksty=info["cblk_sty"] & 0x3F if part1 else 0)
+                          cblksty=info["cblk_sty"] & 0x3F if part1 else 0, origin=(info["x0"], info["y0"]),
+                          precincts=info["prc"] if info["scod"] & 1 else None)
     blocks, _ = G.tile_layout(p)
     rows, data = J.decode_table(info, blocks, part1)
     table = np.array(rows, dtype=G.capi.CODED_DTYPE)

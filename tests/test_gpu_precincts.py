@@ -68,3 +68,25 @@ def test_plugin_file_protocol_with_precincts(tmp_path, monkeypatch, sizes):
         assert not isinstance(got, int), "plugin refused: %s" % got
         cpu, _ = R.encode(px, prec, numres=5, mode=1)
         assert got == cpu
+
+
+@needs_ref
+@pytest.mark.parametrize("sizes", ["128,128", "64,32,32,64", "256,256,64,64,16,16"])
+@pytest.mark.parametrize("ht,irrev", [(1, 0), (0, 0), (0, 1)])
+def test_decode_reference_streams_with_precincts(monkeypatch, sizes, ht, irrev):
+    """grk_compress -c streams decoded on the GPU through the C ABI and through the plugin's decode protocol == grk_decompress."""
+    from test_gpu_decode import _gpu_decode_reference_stream
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    monkeypatch.setenv("REF_PRECINCTS", sizes)
+    for (C, H, W, numres, order, csty) in [(3, 192, 256, 5, 0, 0), (1, 130, 77, 4, 1, 6)]:
+        monkeypatch.setenv("REF_PROG_ORDER", str(order))
+        monkeypatch.setenv("REF_CSTY", str(csty))
+        px = synth.g2(C, H, W, 8, seed=numres)
+        cs, _ = R.encode(px, 8, numres=numres, mode=1, ht=ht, irrev=irrev)
+        want = R.decode(cs, C, H, W)
+        got = _gpu_decode_reference_stream(cs, part1=not ht).astype(np.int32)
+        assert np.array_equal(got, want), (C, H, W, numres)
+        back, stages = R.plugin_decompress(cs, C, H, W)
+        assert not isinstance(back, int), "plugin refused: %s (stages %s)" % (back, stages)
+        assert np.array_equal(back, want)

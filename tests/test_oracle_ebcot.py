@@ -93,7 +93,8 @@ def _oracle_decode_stream(cs, part1):
     info = J.parse(cs)
     W, H, Cn, prec, L, irrev = info["W"], info["H"], info["C"], info["prec"], info["levels"], bool(info["irreversible"])
     org = (info["x0"], info["y0"])
-    p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev, mct=bool(info["mct"]), part1=part1, origin=org)
+    p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev, mct=bool(info["mct"]), part1=part1, origin=org,
+                          precincts=info["prc"] if info["scod"] & 1 else None)
     blocks, _ = G.tile_layout(p)
     rows, data = J.decode_table(info, blocks, part1)
     seglist = J.segment_list(info, blocks)
@@ -152,6 +153,25 @@ def test_reference_stream_off_the_origin_oracle_chain_equals_grk_decompress(monk
         assert np.array_equal(_oracle_decode_stream(cs, True), R.decode(cs, C, H, W)), (C, H, W, numres)
         done += 1
     assert done >= 7
+
+
+@pytest.mark.parametrize("sizes", ["128,128", "64,32,32,64", "256,256,64,64,16,16"])
+@pytest.mark.parametrize("ht,irrev", [(1, 0), (0, 0), (0, 1)])
+def test_reference_stream_with_precincts_oracle_chain_equals_grk_decompress(monkeypatch, sizes, ht, irrev):
+    """grk_compress -c streams (HT 5/3, Part-1 5/3, Part-1 9/7; with SOP + EPH, RLCP, an image offset): the code-block
+    partition cut by the precincts and the packet per precinct on the decode side."""
+    monkeypatch.setenv("REF_PRECINCTS", sizes)
+    for (C, H, W, numres, off, order, csty) in [(3, 192, 256, 5, (0, 0), 0, 0), (1, 130, 77, 4, (0, 0), 1, 6), (3, 100, 150, 4, (33, 95), 0, 2)]:
+        monkeypatch.setenv("REF_IMG_X0", str(off[0]))
+        monkeypatch.setenv("REF_IMG_Y0", str(off[1]))
+        monkeypatch.setenv("REF_PROG_ORDER", str(order))
+        monkeypatch.setenv("REF_CSTY", str(csty))
+        px = synth.g2(C, H, W, 8, seed=numres)
+        cs, _ = R.encode(px, 8, TW=W + off[0], TH=H + off[1], numres=numres, mode=1, ht=ht, irrev=irrev)
+        got = _oracle_decode_stream(cs, not ht)
+        assert np.array_equal(got, R.decode(cs, C, H, W)), (C, H, W, numres, off)
+        if not irrev:
+            assert np.array_equal(got, px.astype(np.int32))
 
 
 @pytest.mark.parametrize("sty", [0x01, 0x02, 0x04, 0x08, 0x20, 0x01 | 0x04, 0x3F])
