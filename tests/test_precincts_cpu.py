@@ -161,3 +161,42 @@ def test_plt_of_one_sample_wide_tiles_with_precincts_reference_defect_d15(monkey
         ours, theirs = total(g[17:sod]), total(w[17:sod])
         assert ours == ln - sod - 2
         assert (theirs == ours) == (t not in (2, 5))               # the one-sample-wide tiles: the reference's sums are off
+
+
+@needs_ref
+def test_random_layouts_precincts_orders_against_the_reference(monkeypatch):
+    """A sweep: random image sizes, offsets, tile sizes, level counts, precinct size lists, progression orders, SOP / EPH --
+    oracle tiles + the product's writer == grk_compress, and grk_decompress returns the image (where the reference is free
+    of its own defects D13 / D14, tests/test_offgrid_cpu.py)."""
+    from test_offgrid_cpu import ref_defects
+    rng = np.random.default_rng(4242)
+    checked = 0
+    for _ in range(60):
+        W, H = int(rng.integers(8, 200)), int(rng.integers(8, 200))
+        off = (int(rng.integers(0, 40)), int(rng.integers(0, 40))) if rng.integers(0, 2) else (0, 0)
+        TW, TH = int(rng.integers(max(off[0] + 1, 32), 220)), int(rng.integers(max(off[1] + 1, 32), 220))
+        L = int(rng.integers(1, 6))
+        Cn = int(rng.choice([1, 3]))
+        nlist = int(rng.integers(1, 4))
+        sizes = [(1 << int(rng.integers(3, 9)), 1 << int(rng.integers(3, 9))) for _ in range(nlist)]
+        order = int(rng.integers(0, 5))
+        csty = int(rng.choice([0, 2, 4, 6]))
+        layout = G.ImageLayout.make(W, H, TW, TH, offset=off)
+        d13, d14 = ref_defects(layout, L)
+        if d13:
+            continue
+        prc = exps_from_sizes(sizes, L)
+        if any(e[0] < 1 or e[1] < 1 for e in prc[1:]):
+            continue
+        px = synth.g2(Cn, H, W, 8, seed=int(rng.integers(1, 1000)))
+        for k, v in (("REF_IMG_X0", off[0]), ("REF_IMG_Y0", off[1]), ("REF_PROG_ORDER", order), ("REF_CSTY", csty)):
+            monkeypatch.setenv(k, str(v))
+        monkeypatch.setenv("REF_PRECINCTS", ",".join("%d,%d" % s for s in sizes))
+        want, _ = R.encode(px, 8, TW=TW, TH=TH, numres=L + 1, mode=1)
+        flags = G.CS_PROG(order) | (G.CS_SOP if csty & 2 else 0) | (G.CS_EPH if csty & 4 else 0)
+        got = oracle_codestream_prc(px, 8, L, layout, prc, flags)
+        assert got == want, (W, H, TW, TH, L, off, Cn, sizes, order, csty)
+        if not d14:
+            assert np.array_equal(R.decode(got, Cn, H, W), px.astype(np.int32)), (W, H, TW, TH, L, off, Cn, sizes, order, csty)
+        checked += 1
+    assert checked >= 35
