@@ -16,6 +16,7 @@
 #include "../../include/grk_plugin_abi.h"
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -168,15 +169,22 @@ bool read_pnm(const char* path, std::vector<uint8_t>& planar, uint32_t& w, uint3
     return true;
 }
 
+// does the tile grid cell anchored at (tx0, ty0) cover the image area, which starts at (image_offset_x0, image_offset_y0)
+// (grk_compress -d, stored as grk_image x0 / y0 by the host's image readers)?
+bool single_tile(const gra_cparameters* cp, uint32_t w, uint32_t h)
+{
+    const uint64_t ox = cp->image_offset_x0, oy = cp->image_offset_y0;
+    return !cp->tile_size_on || !(cp->tx0 > ox || cp->ty0 > oy || (uint64_t)cp->tx0 + cp->t_width < ox + w ||
+                                  (uint64_t)cp->ty0 + cp->t_height < oy + h);
+}
+
+// multi = false: the parameters of THE tile of a single-tile image (what the plugin protocol can carry, D3);
+// multi = true: the base parameters of an image of several tiles (tile size / origin filled per tile by grk_amd_layout_tile)
 bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, uint32_t comps, uint32_t prec,
-                             grk_amd_tile_params& p)
+                             grk_amd_tile_params& p, bool multi = false)
 {
     if (!cp->isHT || !(cp->cblk_sty & GRA_CBLKSTY_HT)) return false;             // hot path = HTJ2K only
-    // single tile (D3): the tile grid cell anchored at (tx0, ty0) has to cover the image area, which starts at
-    // (image_offset_x0, image_offset_y0) -- grk_compress -d, stored as grk_image x0 / y0 by the host's image readers
-    const uint64_t ox = cp->image_offset_x0, oy = cp->image_offset_y0;
-    if (cp->tile_size_on && (cp->tx0 > ox || cp->ty0 > oy || (uint64_t)cp->tx0 + cp->t_width < ox + w ||
-                             (uint64_t)cp->ty0 + cp->t_height < oy + h)) return false;
+    if (!multi && !single_tile(cp, w, h)) return false;
     if (cp->tcp_numlayers > 1 || cp->numpocs || cp->roi_compno >= 0) return false;
     if (cp->subsampling_dx != 1 || cp->subsampling_dy != 1) return false;
     if (cp->numresolution < 1 || cp->numresolution > GRK_AMD_MAX_LEVELS + 1) return false;
@@ -206,6 +214,7 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
             p.precinct_exp[r] = (uint8_t)(ex | (ey << 4));
         }
     }
+    if (multi) { p.tile_w = std::min(w, cp->t_width); p.tile_h = std::min(h, cp->t_height); p.tile_x0 = p.tile_y0 = 0; }
     return grk_amd_tile_num_blocks(&p) > 0;
 }
 
@@ -273,12 +282,50 @@ int32_t host_step(gra_cparameters* cp, EncodeJob& j, gra_encode_callback cb)
     return info.error_code;
 }
 
+// An image of SEVERAL tiles.  The plugin protocol attaches one grk_plugin_tile to every tile of an image (D3), so the host
+// cannot be handed the blocks tile by tile; but the whole file is within reach: every tile through the hot path
+// (grk_amd_encode_image: tiles grouped by geometry, one batch per group) and the codestream through our own Tier-2 writer,
+// which writes what the reference writes byte for byte (SIZ / COD / QCD / TLM / PLT / SOP / EPH, the progression orders,
+// precincts).  Only raw codestreams (.j2k / .j2c / .jpc): the JP2 boxes stay with the host.  Returns 0 (handled: the file
+// is written, the host's callback is not needed) or -1 (the host takes its CPU path).
+int32_t encode_multi_tile(gra_cparameters* cp, EncodeJob& j)
+{
+    if (g_debug_state & GRA_PLUGIN_STATE_DEBUG) return -1;
+    const size_t dot = j.out.rfind('.');
+    if (dot == std::string::npos) return -1;
+    std::string ext = j.out.substr(dot + 1);
+    for (auto& ch : ext) ch = (char)std::tolower((unsigned char)ch);
+    if (ext != "j2k" && ext != "j2c" && ext != "jpc") return -1;
+    grk_amd_tile_params base;
+    if (!params_from_cparameters(cp, j.w, j.h, j.comps, j.prec, base, true)) return -1;
+    if (cp->prog_order < 0 || cp->prog_order > 4 || cp->cp_num_comments) return -1;
+    grk_amd_image_layout im{cp->image_offset_x0, cp->image_offset_y0, cp->image_offset_x0 + j.w, cp->image_offset_y0 + j.h,
+                            cp->tx0, cp->ty0, cp->t_width, cp->t_height};
+    const uint32_t flags = (cp->writeTLM ? GRK_AMD_CS_TLM : 0u) | (cp->writePLT ? GRK_AMD_CS_PLT : 0u) |
+                           ((cp->csty & 2u) ? GRK_AMD_CS_SOP : 0u) | ((cp->csty & 4u) ? GRK_AMD_CS_EPH : 0u) |
+                           GRK_AMD_CS_PROG((uint32_t)cp->prog_order);
+    std::vector<uint8_t> out(j.px.size() * 2 + (1u << 20));
+    int64_t n;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        n = grk_amd_encode_image(g_ctx, &im, &base, j.px.data(), flags, out.data(), out.size());
+    }
+    if (n <= 0) return -1;
+    FILE* f = std::fopen(j.out.c_str(), "wb");
+    if (!f) return -1;
+    const bool ok = std::fwrite(out.data(), 1, (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    return ok ? 0 : -1;
+}
+
 int32_t encode_file(gra_cparameters* cp, const char* in, const char* out, gra_encode_callback cb)
 {
     if (!g_ctx || !cp || !cb || !in || !out) return -1;
     EncodeJob j;
     j.in = in; j.out = out;
-    if (!load_step(j) || !gpu_step(cp, j)) return -1;
+    if (!load_step(j)) return -1;
+    if (!single_tile(cp, j.w, j.h)) return encode_multi_tile(cp, j);
+    if (!gpu_step(cp, j)) return -1;
     return host_step(cp, j, cb);
 }
 
@@ -709,6 +756,7 @@ GRA_EXPORT int32_t plugin_batch_encode(const char* input_dir, const char* output
         });
         while (auto j = loaded.take()) {
             if (g_batch_stop.load()) continue;          // (drain the reader)
+            if (!single_tile(cp, j->w, j->h)) { (void)encode_multi_tile(cp, *j); continue; }     // several tiles: the whole file here
             if (gpu_step(cp, *j)) coded.put(std::move(j));
         }
         coded.close();

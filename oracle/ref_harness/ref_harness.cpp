@@ -419,13 +419,23 @@ int64_t ref_plugin_compress_file(const EncCfg* cfg, const uint8_t* pixels, const
 	grk_cparameters param;
 	fill_params(param, *cfg);
 	strncpy(param.infile, infile, GRK_PATH_LEN - 1);
-	strncpy(param.outfile, "mem.j2k", GRK_PATH_LEN - 1);
+	// (single-tile images: the plugin calls back and the callback writes into `out`; images of several tiles: the plugin writes
+	//  the codestream file itself, next to the input)
+	snprintf(param.outfile, GRK_PATH_LEN, "%s.j2k", infile);
 	// grk_compress leaves tcp_mct at 255 ("not set") until its callback has loaded the image (grk_compress.cpp:1836,
 	// :1708-1720): REF_TCP_MCT=255 hands the plugin that sentinel, the callback below resolves it as the CLI does
 	if (const char* e = getenv("REF_TCP_MCT")) param.tcp_mct = (uint8_t)atoi(e);
 	g_cb_cfg = cfg; g_cb_pixels = pixels; g_cb_out = out; g_cb_cap = cap; g_cb_len = -100;
+	remove(param.outfile);
 	int32_t rc = grk_plugin_compress(&param, host_compress_callback);
 	if (rc != 0) return rc < 0 ? rc : -rc;
+	if (g_cb_len == -100) {              // no callback: the plugin wrote the file
+		FILE* f = fopen(param.outfile, "rb");
+		if (!f) return -200;
+		const size_t n = fread(out, 1, cap, f);
+		fclose(f);
+		return (int64_t)n;
+	}
 	return g_cb_len;
 }
 

@@ -16,13 +16,19 @@ def ctx():
     return _ctx
 
 
+def _settled(t):
+    """torch fills / copies on ITS stream; the context works on its own -- finish torch's work before handing the buffer over."""
+    torch.cuda.synchronize()
+    return t
+
+
 def to_dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return _settled(torch.from_numpy(np.ascontiguousarray(a)).cuda())
 
 
 def dev_planes(params, nplanes):
     n = G.lib().grk_amd_plane_elems(params) * nplanes
-    return torch.zeros(int(n), dtype=torch.int32, device="cuda")
+    return _settled(torch.zeros(int(n), dtype=torch.int32, device="cuda"))
 
 
 def planes_to_numpy(t, params, nplanes):

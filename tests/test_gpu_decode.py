@@ -76,7 +76,7 @@ def test_egress(C, H, W, prec, irrev):
     p = G.TileParams.make(W, H, C, prec, 0, irreversible=bool(irrev))
     d_pl = U.upload_planes(raw.reshape(2 * C, H, W), p)
     bps = (prec + 7) // 8
-    d_px = torch.zeros(2 * C * H * W * bps, dtype=torch.uint8, device="cuda")
+    d_px = U._settled(torch.zeros(2 * C * H * W * bps, dtype=torch.uint8, device="cuda"))
     U.ctx().stage_egress(p, 2, d_pl.data_ptr(), d_px.data_ptr())
     U.ctx().synchronize()
     got = d_px.cpu().numpy().view(np.uint8 if bps == 1 else np.uint16).reshape(2, C, H, W)
@@ -199,7 +199,7 @@ def test_round_trip_8k_property():
     c = U.ctx()
     d_px = U.to_dev(px.reshape(-1))
     table, tot = c.encode_tiles(p, 1, d_px.data_ptr(), True)
-    d_out = torch.zeros(px.size, dtype=torch.uint8, device="cuda")
+    d_out = U._settled(torch.zeros(px.size, dtype=torch.uint8, device="cuda"))
     c.decode_device(p, 1, table, c.coded_device_ptr(), tot, d_out.data_ptr())
     c.decode_status()
     assert torch.equal(d_out, d_px)
@@ -663,7 +663,7 @@ def test_decode_int16_planes_and_their_range_check():
     got = c.decode_host(p8, table, coded)[0]                # int16 planes -> range flag -> repeated with int32 planes
     assert np.array_equal(got, want)
     d_c = U.to_dev(np.concatenate([coded, np.zeros(64, np.uint8)]))
-    out = torch.zeros(H * W, dtype=torch.uint8, device="cuda")
+    out = U._settled(torch.zeros(H * W, dtype=torch.uint8, device="cuda"))
     c.decode_device(p8, 1, table, d_c.data_ptr(), coded.size, out.data_ptr())
     with pytest.raises(RuntimeError, match="16-bit planes"):
         c.decode_status()

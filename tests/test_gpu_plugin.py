@@ -108,6 +108,36 @@ def test_protocols_with_an_image_off_the_origin(tmp_path, monkeypatch, off):
 
 
 @needs_ref
+@pytest.mark.parametrize("case", [
+    # (C, H, W, prec, TW, TH, offset, env)
+    (3, 200, 300, 8, 128, 128, (0, 0), {}),
+    (1, 250, 190, 12, 100, 64, (0, 0), {"REF_WRITE_TLM": "1", "REF_WRITE_PLT": "1"}),     # (no empty bands: D15)
+    (3, 150, 220, 8, 96, 80, (7, 5), {"REF_PROG_ORDER": "2", "REF_CSTY": "6"}),
+    (3, 130, 130, 8, 64, 64, (0, 0), {"REF_PRECINCTS": "64,64,32,32", "REF_PROG_ORDER": "4"}),
+])
+def test_image_of_several_tiles_through_the_plugin(tmp_path, monkeypatch, case):
+    """The plugin protocol cannot carry an image of several tiles (D3: one grk_plugin_tile per image), so the plugin writes
+    the whole .j2k itself -- every tile through the hot path, the codestream through its own writer -- and answers 0
+    without the host's callback; the file equals the one grk_compress writes on its CPU path, tile grid, image offset,
+    TLM / PLT, SOP / EPH, progression order and precincts included.  A .jp2 target stays with the host (non-zero)."""
+    Cn, H, W, prec, TW, TH, off, env = case
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    monkeypatch.setenv("REF_IMG_X0", str(off[0]))
+    monkeypatch.setenv("REF_IMG_Y0", str(off[1]))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    px = synth.g2(Cn, H, W, prec)
+    path = str(tmp_path / ("t.%s" % ("pgm" if Cn == 1 else "ppm")))
+    R.write_pnm(path, px, prec)
+    got = R.plugin_compress_file(px, prec, path, numres=4, TW=TW, TH=TH)
+    assert not isinstance(got, int), "plugin refused: %s" % got
+    cpu, _ = R.encode(px, prec, TW=TW, TH=TH, numres=4, mode=1)
+    assert got == cpu
+    assert np.array_equal(R.decode(got, Cn, H, W), px.astype(np.int32))
+
+
+@needs_ref
 def test_file_protocol_with_mct_not_set_on_the_command_line(tmp_path, monkeypatch):
     """grk_compress hands the plugin tcp_mct = 255 ("not set") unless -Y was given (grk_compress.cpp:1836; resolved
     only inside its callback, :1817-1820): the plugin resolves it the same way -- grayscale is coded without MCT, RGB

@@ -297,7 +297,7 @@ def test_pipelined_encodes_keep_their_results_until_the_second_next_call(depth):
     c = G.Context(0)
     c.set_pipelining(depth)
     nb = G.lib().grk_amd_tile_num_blocks(p)
-    d = [torch.from_numpy(im.reshape(-1)).cuda() for im in imgs]
+    d = [U.to_dev(im.reshape(-1)) for im in imgs]
     held = []
     for k in range(len(imgs)):
         c.encode_tiles(p, 1, d[k].data_ptr(), True, fetch=False)
