@@ -80,6 +80,8 @@ struct grk_amd_ctx {
     bool side_pending = false;       // side-stream work of the latest encode has not been joined on the main stream yet
     bool dec_planes16 = true;                               // 16-bit planes between K5b and K6 for 8-bit reversible HT tiles
                                                             // (GRK_AMD_DEC_PLANES16=0 / grk_amd_set_decode_planes16: int32)
+    uint32_t dwt_seg = 0;                                   // GRK_AMD_DWT_SEG: row pairs per K2 workgroup (experiments; 0 = the heuristic)
+    int dwt_pk = 1;                                         // packed int16 pairs in K2 / K6 where the range allows (GRK_AMD_DWT_PK=0: 32-bit)
     int dwt_xcd = 1;                                        // XCD-aware workgroup order in K2 / K6 (GRK_AMD_DWT_XCD=0: plain)
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
     bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
@@ -296,6 +298,18 @@ bool planes16_ok(const grk_amd_tile_params& p)
     return bound + 8.0 * p.num_levels < 32767.0;
 }
 
+// Level l of such a tile on PACKED int16 pairs (kernels_dwt.hip, strip_pk): every intermediate of the 2-D lifting step has to
+// stay inside 16 bits as well.  With M the largest magnitude entering the level (2^prec after DC shift and RCT, times the
+// low-pass gain 1.5 x 1.5 per level before, plus rounding), the largest is the horizontal update's sum of two high-pass
+// values of a vertically high-pass row: 2 x 2 x 2M each, 8M + 2 in all.
+bool pk16_level_ok(const grk_amd_tile_params& p, uint32_t l)
+{
+    if (p.sgnd) return false;                        // (the packed unpacking is written for unsigned pixels)
+    double m = (double)(1u << p.prec);
+    for (uint32_t i = 0; i < l; ++i) m = m * 2.25 + 4.0;
+    return 8.0 * m + 16.0 < 32767.0;
+}
+
 int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const void* d_pixels = nullptr, uint32_t ntiles = 0,
             bool overlap_ht = false, bool h16 = false)
 {
@@ -327,14 +341,16 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         a.nplanes = nplanes;
         a.irreversible = g.p.irreversible;
         a.h16 = h16 ? 1 : 0;
+        a.pk = h16 && c->dwt_pk && pk16_level_ok(g.p, l);
         a.xcd = c->dwt_xcd;
         // enough workgroups to cover the chip several times, few enough to amortise warm-up rows
         const uint32_t sh = (a.ch + a.py + 1) >> 1;           // row pairs on the coordinate grid
         uint32_t seg = 64;
-        const uint64_t strips = (a.cw + a.px + dwt_strip_cols() - 1) / dwt_strip_cols();
+        const uint64_t strips = (a.cw + a.px + dwt_level_strip_cols(a) - 1) / dwt_level_strip_cols(a);
         // workgroups along z: planes, or for the fused level 0 tiles (x components when there is no MCT triple)
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
+        if (c->dwt_seg) seg = c->dwt_seg;
         a.seg_pairs = seg;
         if (a.cw == 0 || a.ch == 0) {
             // a level without samples (a narrow tile off the origin: [ceil(x0 / 2^l), ceil((x0 + w) / 2^l)) can be empty):
@@ -691,6 +707,8 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* e16 = getenv("GRK_AMD_PLANES16")) c->planes16 = atoi(e16) != 0;
         if (const char* ef = getenv("GRK_AMD_FUSE_EGRESS")) c->fuse_egress = atoi(ef) != 0;
         if (const char* ex = getenv("GRK_AMD_DWT_XCD")) c->dwt_xcd = atoi(ex) != 0;
+        if (const char* ex = getenv("GRK_AMD_DWT_PK")) c->dwt_pk = atoi(ex) != 0;
+        if (const char* ex = getenv("GRK_AMD_DWT_SEG")) c->dwt_seg = (uint32_t)atoi(ex);
         if (const char* ed = getenv("GRK_AMD_DEC_PLANES16")) c->dec_planes16 = atoi(ed) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");

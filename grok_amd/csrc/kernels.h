@@ -39,6 +39,7 @@ struct DwtLevelArgs {
     uint32_t comp0, zdiv; // set by the launcher: first component of a z slot, z slots per tile
     int      h16;         // reversible, 8-bit pixels: every plane (in, ll, mallat) holds int16 instead of int32
     int      xcd;         // XCD-aware workgroup order (kernels_dwt.hip)
+    int      pk;          // h16 and every intermediate of this level within 16 bits: arithmetic on packed int16 pairs
 };
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s);
 hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, int mct, hipStream_t s);
@@ -86,6 +87,7 @@ hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);          // allocat
 hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s);
 hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hipStream_t s);   // classes [first, last)
 uint32_t   dwt_strip_cols();      // output columns a K2 workgroup owns
+uint32_t   dwt_level_strip_cols(const DwtLevelArgs& a);   // ... for this level (the packed 5/3 kernel's strips are wider)
 uint32_t   idwt_strip_pairs();    // coefficient pairs a K6 workgroup owns
 
 // ---- K5: HT cleanup decoder + dequantisation (kernels_htdec.hip) --------------------------------

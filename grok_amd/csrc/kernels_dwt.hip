@@ -105,6 +105,22 @@ struct V97 {
     }
 };
 
+// ---- the same on PAIRS of int16 in one register (v_pk_add / sub / ashr: one instruction, two samples) ----------------
+// The arithmetic is the 5/3's own -- sums, differences and floor shifts -- so while nothing leaves 16 bits the halves are
+// exactly what the 32-bit form computes; the host vouches for the range level by level (context.hip: pk16_level_ok).
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ uint32_t as_u32(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+struct V53pk {
+    pk16 xe, dp;
+    __device__ __forceinline__ void init(pk16 x_even) { xe = x_even; dp = (pk16)(0); }
+    __device__ __forceinline__ void step(pk16 x1, pk16 x2, pk16& s, pk16& d)
+    {
+        d = x1 - ((xe + x2) >> 1);
+        s = xe + ((dp + d + (pk16)(2)) >> 2);
+        xe = x2; dp = d;
+    }
+};
 // ---- horizontal local stencils on an LDS line; w points at local column 2t ------------------
 __device__ __forceinline__ void h53(const int32_t* w, int32_t& s, int32_t& d)
 {
@@ -453,15 +469,246 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     else strip(std::false_type{}, std::false_type{});
 }
 
+// ---- the 5/3 level on packed int16 pairs, four columns per lane ------------------------------------------------------
+// For levels the launcher knows to be reversible with 16-bit planes, on the origin, of even height >= 16 and a width that is a
+// multiple of 4, with every intermediate inside 16 bits (DwtLevelArgs::pk).  Same plan as dwt_level_kernel's FAST strips --
+// vertical recurrence in registers, one exchange line per row pair, horizontal stencil, four sub-band stores -- recast for
+// what the 32-bit form is short of:
+//  * memory INSTRUCTIONS.  The texture addresser takes a wave64 access at four lanes a clock whatever its width, so a CU
+//    moves 16 x (bytes per lane) / 4 bytes a clock: 2-byte accesses (8-bit pixel pairs in, int16 coefficients out) cap
+//    the chip at ~4.9 TB/s of reads + writes together, and the 2-columns-per-lane level 0 sat at 3.9 (measured:
+//    tools/mem_width_bench.hip; profiles/r02_mem_width.txt).  Here a lane owns FOUR columns: one dword of pixels (or 8
+//    bytes of int16 plane) per row and component in, one dword (two coefficients) per sub-band row out;
+//  * vector instructions.  The two columns of a pair ride in one register through unpacking, colour transform and the
+//    vertical recurrence (v_pk_add / sub / ashr); the exchange line holds (low row | high row << 16) per column, so the
+//    horizontal stencil does both rows of the pair at once, and two output pairs share their middle high-pass term;
+//  * addresses.  Buffer descriptors per plane + scalar row offset + a constant 32-bit lane offset: no vector
+//    instruction goes into an address;
+//  * latency.  Rows are fetched two steps ahead.
+constexpr int kPkLaneCols = 4;
+constexpr int kPkCols     = kThreads * kPkLaneCols;        // columns staged per line: 1024
+constexpr int kPkHalo     = kPkLaneCols;                   // one lane's worth each side (the stencil needs 2 left, 1 right)
+constexpr int kPkOutCols  = 960;                           // at most: 480 pairs = 15 x 64 bytes of every sub-band row; 240 lanes
+static_assert(kPkOutCols + 2 * kPkHalo <= kPkCols, "strip does not fit the staged line");
+// The strips of a level share its width evenly, in multiples of 64 columns (64 bytes of every sub-band row)
+__host__ __device__ inline uint32_t pk_strip_cols(uint32_t cw)
+{
+    const uint32_t n = (cw + kPkOutCols - 1) / kPkOutCols;
+    return min((uint32_t)kPkOutCols, ((cw + n - 1) / n + 63u) & ~63u);
+}
+
+template <int NC, int PX>
+__global__ __launch_bounds__(kThreads) void dwt53_pk_kernel(DwtLevelArgs a)
+{
+    static_assert(PX == 0 || PX == 1, "int16 planes or 8-bit pixels");
+    static_assert(PX != 0 || NC == 1, "plane input is one component per workgroup");
+    __builtin_amdgcn_s_setprio(3);                         // (as dwt_level_kernel: the DWT chain is the critical path)
+    __shared__ __attribute__((aligned(16))) uint32_t line[2][NC][kPkCols];   // [parity][comp][column] = low row | high row << 16
+
+    const uint32_t t = threadIdx.x;
+    uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd) {                                           // XCD k takes a contiguous run of the strip-fastest order (see above)
+        const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint32_t id = bx + gx * (by + gy * bz);
+        const uint32_t q = total >> 3, r = total & 7u, k = id & 7u;
+        const uint32_t lid = k * q + min(k, r) + (id >> 3);
+        bx = lid % gx; by = (lid / gx) % gy; bz = lid / (gx * gy);
+    }
+    const uint32_t cw = a.cw, ch = a.ch;
+    const uint32_t sw = cw >> 1, sh = ch >> 1;
+    const uint32_t scols = pk_strip_cols(cw), slanes = scols / kPkLaneCols;     // this level's strip: columns, lanes
+
+    uint32_t plane0 = bz;
+    if constexpr (PX != 0) plane0 = (bz / a.zdiv) * a.ncomp + a.comp0 + (bz % a.zdiv);
+    const int16_t* in = reinterpret_cast<const int16_t*>(a.in) + (size_t)plane0 * a.in_pitch;
+    int16_t* ll = reinterpret_cast<int16_t*>(a.ll) + (size_t)plane0 * a.ll_pitch;
+    int16_t* mp = reinterpret_cast<int16_t*>(a.mallat) + (size_t)plane0 * a.m_pitch;
+    const size_t comp_px = (size_t)cw * ch;
+    const uint8_t* pix = reinterpret_cast<const uint8_t*>(a.pixels) + (size_t)plane0 * comp_px;
+
+    // Lane t < slanes carries group t + 1 of the staged line (groups of four columns; group 0 and group slanes + 1 are the
+    // halo, on the two lanes after; the rest repeat lane 0) -- the strip's own groups in lane order, so that row loads and
+    // sub-band stores of a wave are whole runs of lines.
+    const uint32_t grp = t < slanes ? t + 1 : (t == slanes ? 0u : (t == slanes + 1 ? t : 1u));
+    const int32_t c0 = (int32_t)(bx * scols) - kPkHalo + (int32_t)(grp * kPkLaneCols);     // first of its four columns
+    // A group outside the image is a mirrored one: (-4 .. -1) is x[4], x[3], x[2], x[1], and (cw + 4m ..) is x[cw-2-4m] downwards:
+    // four consecutive samples read backwards (the width is a multiple of 4, so no group straddles an edge).  One load
+    // from the lowest of them -- off its natural alignment by one sample -- and a reversal.  (Groups further out than the
+    // halo are never read; they load from inside the row all the same.)
+    const bool rev = c0 < 0 || c0 >= (int32_t)cw;
+    int32_t lo = c0 < 0 ? -c0 - 3 : (c0 >= (int32_t)cw ? 2 * ((int32_t)cw - 1) - c0 - 3 : c0);
+    lo = max(0, min(lo, (int32_t)cw - kPkLaneCols));
+    const uint32_t lane_off = (uint32_t)lo * (PX == 0 ? 2u : 1u);          // bytes into a row
+    // v_perm selectors that unpack a load into the pairs (A: columns 0, 1; B: columns 2, 3), reversed for mirrored groups
+    const uint32_t selA = PX == 1 ? (rev ? 0x0c020c03u : 0x0c010c00u) : (rev ? 0x05040706u : 0x03020100u);
+    const uint32_t selB = PX == 1 ? (rev ? 0x0c000c01u : 0x0c030c02u) : (rev ? 0x01000302u : 0x07060504u);
+    const pk16 dc2 = as_pk((uint32_t)a.dc * 0x10001u);       // (unsigned pixels: the launcher sends signed ones elsewhere)
+
+    auto rsrc = [](const void* p, int nbytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, nbytes, 0x00020000); };
+    __amdgpu_buffer_rsrc_t r_in[NC], r_ll[NC], r_mp[NC];
+    #pragma unroll
+    for (int k = 0; k < NC; ++k) {                         // (offsets stay below 2^32: a plane is at most 2^31 samples)
+        r_in[k] = PX == 0 ? rsrc(in, -1) : rsrc(pix + (size_t)k * comp_px, -1);
+        r_ll[k] = rsrc(ll + (size_t)k * a.ll_pitch, -1);
+        r_mp[k] = rsrc(mp + (size_t)k * a.m_pitch, -1);
+    }
+    __amdgpu_buffer_rsrc_t r_none = rsrc(a.mallat, 0);       // zero length: the memory pipeline drops what goes through it
+
+    const int32_t J0 = (int32_t)(by * a.seg_pairs);
+    const int32_t J1 = min((int32_t)sh, J0 + (int32_t)a.seg_pairs);
+
+    struct Raw { uint32_t v[NC]; uint2 w[NC]; };
+    auto fetch_row = [&](int32_t r, Raw& q) {                // raw row fetch: no arithmetic, so that the rows stay in flight
+        const uint32_t rr = mirror_row<true>(r, ch);
+        if constexpr (PX == 0) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(r_in[0], lane_off, rr * a.in_stride * 2u, 0);
+            q.w[0].x = v[0]; q.w[0].y = v[1];
+        } else {
+    #pragma unroll
+            for (int k = 0; k < NC; ++k) q.v[k] = __builtin_amdgcn_raw_buffer_load_b32(r_in[k], lane_off, rr * cw, 0);
+        }
+    };
+    auto convert = [&](const Raw& q, pk16 (&va)[NC], pk16 (&vb)[NC]) {
+        if constexpr (PX == 0) {
+            va[0] = as_pk(__builtin_amdgcn_perm(q.w[0].y, q.w[0].x, selA));
+            vb[0] = as_pk(__builtin_amdgcn_perm(q.w[0].y, q.w[0].x, selB));
+        } else {
+            pk16 xa[NC], xb[NC];
+    #pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                xa[k] = as_pk(__builtin_amdgcn_perm(0u, q.v[k], selA));
+                xb[k] = as_pk(__builtin_amdgcn_perm(0u, q.v[k], selB));
+            }
+            if constexpr (NC == 3) {   // RCT (mct.cpp:94-104) after the DC shift: Cb = B - G and Cr = R - G lose the shift,
+                                       // Y = (R + 2G + B) >> 2 = G + ((Cb + Cr) >> 2) exactly, minus the shift
+                const pk16 cba = xa[2] - xa[1], cra = xa[0] - xa[1], cbb = xb[2] - xb[1], crb = xb[0] - xb[1];
+                va[0] = xa[1] + ((cba + cra) >> 2) - dc2; va[1] = cba; va[2] = cra;
+                vb[0] = xb[1] + ((cbb + crb) >> 2) - dc2; vb[1] = cbb; vb[2] = crb;
+            } else { va[0] = xa[0] - dc2; vb[0] = xb[0] - dc2; }
+        }
+    };
+
+    V53pk colA[NC], colB[NC];
+    {
+        Raw q; pk16 xa[NC], xb[NC];
+        fetch_row(2 * (J0 - 1), q);
+        convert(q, xa, xb);
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) { colA[k].init(xa[k]); colB[k].init(xb[k]); }
+    }
+    Raw ra1, ra2, rb1, rb2;                                  // rows of the next step (a) and of the one after (b)
+    fetch_row(2 * J0 - 1, ra1); fetch_row(2 * J0, ra2);
+    fetch_row(2 * J0 + 1, rb1); fetch_row(2 * J0 + 2, rb2);
+
+    // horizontal phase: lane t produces the two output pairs of group t + 1; lanes past the strip's last group (the halo
+    // lanes, the idle ones, and in the last strip those beyond the image) repeat the last one -- same reads, same values
+    // to the same addresses -- so that the loop has no branch
+    const uint32_t nv = min(slanes, (sw - bx * (scols / 2) + 1u) >> 1);
+    const uint32_t tp = min(t, nv - 1u);
+    const uint32_t hc = (tp + 1u) * kPkLaneCols;             // its first column in the staged line
+    const uint32_t oc = (bx * (scols / 2) + tp * 2u) * 2u;   // byte offset of its two coefficients in a sub-band row
+
+    pk16 sA[NC], dA[NC], sB[NC], dB[NC];
+    auto vstep = [&](int32_t ii, Raw& r1, Raw& r2) {         // step ii: consumes r1, r2 and refills them two steps ahead
+        pk16 x1a[NC], x1b[NC], x2a[NC], x2b[NC];
+        convert(r1, x1a, x1b); convert(r2, x2a, x2b);
+        fetch_row(2 * ii + 5, r1); fetch_row(2 * ii + 6, r2);
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) { colA[k].step(x1a[k], x2a[k], sA[k], dA[k]); colB[k].step(x1b[k], x2b[k], sB[k], dB[k]); }
+    };
+    auto hphase = [&](int par, uint32_t (&o)[NC][4]) {
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            uint4 w;                                         // per column (vertical low | vertical high << 16)
+            w.x = __builtin_amdgcn_perm(as_u32(dA[k]), as_u32(sA[k]), 0x05040100u);
+            w.y = __builtin_amdgcn_perm(as_u32(dA[k]), as_u32(sA[k]), 0x07060302u);
+            w.z = __builtin_amdgcn_perm(as_u32(dB[k]), as_u32(sB[k]), 0x05040100u);
+            w.w = __builtin_amdgcn_perm(as_u32(dB[k]), as_u32(sB[k]), 0x07060302u);
+            *reinterpret_cast<uint4*>(&line[par][k][grp * kPkLaneCols]) = w;
+        }
+        __syncthreads();
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const uint32_t* w = &line[par][k][hc];
+            const uint2 m = *reinterpret_cast<const uint2*>(w - 2);
+            const uint4 c = *reinterpret_cast<const uint4*>(w);
+            const pk16 m2 = as_pk(m.x), m1 = as_pk(m.y), c0 = as_pk(c.x), c1 = as_pk(c.y), c2 = as_pk(c.z), c3 = as_pk(c.w),
+                       p4 = as_pk(w[4]);
+            const pk16 dm = m1 - ((m2 + c0) >> 1);
+            const pk16 d0 = c1 - ((c0 + c2) >> 1);
+            const pk16 d1 = c3 - ((c2 + p4) >> 1);
+            const pk16 s0 = c0 + ((dm + d0 + (pk16)(2)) >> 2);
+            const pk16 s1 = c2 + ((d0 + d1 + (pk16)(2)) >> 2);
+            // (horizontal low | .. of the vertical low row, of the vertical high row): regroup by sub-band row
+            o[k][0] = __builtin_amdgcn_perm(as_u32(s1), as_u32(s0), 0x05040100u);       // LL: two columns
+            o[k][1] = __builtin_amdgcn_perm(as_u32(s1), as_u32(s0), 0x07060302u);       // LH
+            o[k][2] = __builtin_amdgcn_perm(as_u32(d1), as_u32(d0), 0x05040100u);       // HL
+            o[k][3] = __builtin_amdgcn_perm(as_u32(d1), as_u32(d0), 0x07060302u);       // HH
+        }
+    };
+    auto store_out = [&](int32_t j, const uint32_t (&o)[NC][4]) {
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const uint32_t ju = (uint32_t)j;               // (uniform; said so for the sake of the store after the loop)
+            const uint32_t lrow = __builtin_amdgcn_readfirstlane(ju * a.ll_stride * 2u),
+                           mlo = __builtin_amdgcn_readfirstlane(ju * a.m_stride * 2u),
+                           mhi = __builtin_amdgcn_readfirstlane((sh + ju) * a.m_stride * 2u);
+            __builtin_amdgcn_raw_buffer_store_b32(o[k][0], r_ll[k], oc, lrow, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(o[k][1], r_mp[k], oc, mhi, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(o[k][2], r_mp[k], oc + 2u * sw, mlo, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(o[k][3], r_mp[k], oc + 2u * sw, mhi, 0);
+        }
+    };
+    // All memory operations of a step are issued in one place: the rows two steps ahead, then the PREVIOUS pair's results
+    // (held in registers for one step).  Steps alternate between the two row sets and the two halves of the exchange line.
+    // The compiler's wait for a row allows as many younger operations in flight as the SHORTEST path to that point has
+    // issued, and the path into the loop would be the short one -- so the two steps before the loop issue the same
+    // sequence as every later pair of steps (rows, 4 NC stores, rows, 4 NC stores), their stores going through the
+    // descriptor of zero length.
+    auto no_stores = [&]() {
+    #pragma unroll
+        for (int k = 0; k < 4 * NC; ++k) __builtin_amdgcn_raw_buffer_store_b32(0u, r_none, oc, 4 * k, 0);   // (distinct, or they fold into one)
+    };
+    const int32_t i_end = J1 - 1;
+    uint32_t o[NC][4];
+    int32_t ii = J0, jp;
+    vstep(J0 - 1, ra1, ra2); no_stores();                  // warm-up step: no output
+    __builtin_amdgcn_sched_barrier(0);
+    vstep(ii, rb1, rb2); no_stores(); hphase(0, o); jp = ii; ++ii;
+    __builtin_amdgcn_sched_barrier(0);
+    while (ii + 1 <= i_end) {         // (the fences keep the scheduler from pulling a step's first touch of its rows -- and with
+                                      //  it the wait for them -- up into the step before)
+        vstep(ii, ra1, ra2); store_out(jp, o); hphase(1, o); jp = ii; ++ii;
+        __builtin_amdgcn_sched_barrier(0);
+        vstep(ii, rb1, rb2); store_out(jp, o); hphase(0, o); jp = ii; ++ii;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ii <= i_end) { vstep(ii, ra1, ra2); store_out(jp, o); hphase(1, o); jp = ii; }
+    store_out(jp, o);
+}
+
 } // namespace
 
 uint32_t dwt_strip_cols() { return kOutCols; }
+
+// the level shape dwt53_pk_kernel takes
+static bool dwt_level_is_pk(const DwtLevelArgs& a)
+{
+    return a.h16 && a.pk && !a.irreversible && (a.px | a.py) == 0 && (a.cw & 3u) == 0 && a.cw >= (uint32_t)kPkOutCols &&
+           a.ch >= 16 && (a.ch & 1u) == 0;
+}
+uint32_t dwt_level_strip_cols(const DwtLevelArgs& a) { return dwt_level_is_pk(a) ? pk_strip_cols(a.cw) : (uint32_t)kOutCols; }
 
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
 {
     const uint32_t sh = (a.ch + a.py + 1) >> 1;
     dim3 grid((a.cw + a.px + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
     dim3 block(kThreads);
+    if (dwt_level_is_pk(a)) {
+        grid.x = (a.cw + pk_strip_cols(a.cw) - 1) / pk_strip_cols(a.cw);
+        hipLaunchKernelGGL((dwt53_pk_kernel<1, 0>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if (a.irreversible)
         hipLaunchKernelGGL((dwt_level_kernel<true, 1, 0>), grid, block, 0, s, a);
     else if (a.h16)
@@ -486,6 +733,10 @@ hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint
         if (a.irreversible) {
             if (nc == 3) { if (px == 1) GRK_L0(true, 3, 1); else GRK_L0(true, 3, 2); }
             else         { if (px == 1) GRK_L0(true, 1, 1); else GRK_L0(true, 1, 2); }
+        } else if (px == 1 && dwt_level_is_pk(a)) {
+            grid.x = (a.cw + pk_strip_cols(a.cw) - 1) / pk_strip_cols(a.cw);
+            if (nc == 3) hipLaunchKernelGGL((dwt53_pk_kernel<3, 1>), grid, block, 0, s, a);
+            else         hipLaunchKernelGGL((dwt53_pk_kernel<1, 1>), grid, block, 0, s, a);
         } else if (a.h16 && px == 1) {       // 16-bit planes exist for 8-bit pixels only (context.hip: planes16_ok)
             if (nc == 3) hipLaunchKernelGGL((dwt_level_kernel<false, 3, 1, true>), grid, block, 0, s, a);
             else         hipLaunchKernelGGL((dwt_level_kernel<false, 1, 1, true>), grid, block, 0, s, a);

@@ -273,6 +273,35 @@ def test_int16_planes_equal_int32_planes(C, H, W, L, sgnd, mct, monkeypatch):
     assert got[("1", "1")] == want
 
 
+@pytest.mark.parametrize("cell", [1, 2, 4, 8, 0])
+def test_packed_int16_dwt_at_the_extremes(cell, monkeypatch):
+    """Levels whose every intermediate stays inside 16 bits run on packed int16 pairs (kernels_dwt.hip strip_pk;
+    context.hip pk16_level_ok gives the levels).  Content made to drive the lifting sums as far as 8-bit pixels can --
+    0 / 255 checkerboards with cells of 1, 2, 4, 8 pixels (each resonates with one level), and binary noise (cell 0) -- through
+    5 levels, with different phases per component so that the RCT's chroma reaches +-255: blocks identical to the 32-bit
+    arithmetic (GRK_AMD_DWT_PK=0) and to the oracle chain."""
+    H, W, L = 512, 1024, 5
+    rng = np.random.default_rng(cell)
+    yy, xx = np.mgrid[0:H, 0:W]
+    if cell:
+        base = (((yy // cell) + (xx // cell)) & 1).astype(np.uint8) * 255
+        px = np.stack([base, 255 - base, np.roll(base, cell, axis=1)])
+    else:
+        px = (rng.integers(0, 2, size=(3, H, W)) * 255).astype(np.uint8)
+    px = np.ascontiguousarray(px)
+    p = G.TileParams.make(W, H, 3, 8, L)
+    got = {}
+    for pk in ("1", "0"):
+        monkeypatch.setenv("GRK_AMD_DWT_PK", pk)
+        c = G.Context(0)
+        t, coded = c.encode_host(p, px)
+        got[pk] = U.split_blocks(t, coded)
+    assert got["1"] == got["0"]
+    _, _, _, otable, ocoded = chain.encode_tile_oracle(px, 8, L, mct=True)
+    want = [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
+    assert got["1"] == want
+
+
 def _dev_view(ptr, n, typestr):
     class _H:
         pass
