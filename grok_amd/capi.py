@@ -12,7 +12,8 @@ class NativeLibraryMissing(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libgrok_amd.so")
+    # (GRK_AMD_LIB: another build of the same library, for A/B timing on one box -- tools/build_variant.sh)
+    return os.environ.get("GRK_AMD_LIB") or os.path.join(_HERE, "lib", "libgrok_amd.so")
 
 
 class TileParams(C.Structure):

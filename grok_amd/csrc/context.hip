@@ -465,9 +465,10 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
         a.irreversible = g.p.irreversible;
         a.xcd = c->dwt_xcd;
         a.h16 = h16 ? 1 : 0; a.status = (unsigned int*)c->flag.p;
+        a.pk = h16 && c->dwt_pk && !plan;            // (the block decoder flagged every coefficient outside the packed range)
         const uint32_t sh = (a.ch + a.py + 1) >> 1;
         uint32_t seg = 64;
-        const uint64_t strips = (((a.cw + a.px + 1) >> 1) + idwt_strip_pairs() - 1) / idwt_strip_pairs();
+        const uint64_t strips = (((a.cw + a.px + 1) >> 1) + idwt_level_strip_pairs(a) - 1) / idwt_level_strip_pairs(a);
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
         a.seg_pairs = seg;
@@ -524,6 +525,7 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.irreversible = g.p.irreversible;
     a.h16 = h16 ? 1 : 0;
+    a.h16_bias = (h16 && c->dwt_pk) ? 2048 : 32768;        // (pk16.h kPkDecodeBound + 1: the inverse transform runs on packed pairs)
     if (!c->dec_seg_first.empty()) {
         // HT blocks with refinement passes: segment 0 = the cleanup pass, segment 1 = SigProp (+ MagRef), end to end
         if (c->dec_seg_first.size() != nblocks + 1 || c->dec_seg_first.back() != c->dec_segs.size())
@@ -713,7 +715,11 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
-        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
+        hipError_t sk = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least);
+        if (const char* ek = getenv("GRK_AMD_STREAM_SKIP")) {          // (experiment: which hardware queue side2 lands on)
+            for (int i = 0; i < atoi(ek); ++i) { hipStream_t dummy; (void)hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, least); }
+        }
+        if (sk != hipSuccess ||
             hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->alt.ev_side, hipEventDisableTiming) != hipSuccess ||

@@ -108,6 +108,8 @@ struct HtDecArgs {
     int32_t* mallat; uint32_t stride; uint64_t pitch;
     int irreversible;
     int h16;                                   // reversible: the planes hold int16 (strides / pitches in elements all the same)
+    int h16_bias;                              // ... and a coefficient outside [-bias, bias) raises bit 3 of *status (32768: what fits; 2048:
+                                               // what the packed inverse transform takes, pk16.h)
     const uint2* refine;                       // [nblocks] {bytes of the SigProp / MagRef segment at the end of the block's
                                                // data, coding passes in total (1..3)}, or null: cleanup passes only
     uint32_t max_refine_bytes;                 // largest such segment
@@ -152,10 +154,12 @@ struct IdwtLevelArgs {
     uint32_t strip0, nstrips, seg0, nsegs;
     int      xcd;         // XCD-aware workgroup order (as DwtLevelArgs)
     int      h16;         // reversible: ll / mallat / out hold int16; a synthesised value that does not fit sets bit 3 of *status
+    int      pk;          // h16 and every coefficient within +-kPkDecodeBound (pk16.h): arithmetic on packed int16 pairs
     unsigned int* status;
 };
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s);
 hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, hipStream_t s);
+uint32_t   idwt_level_strip_pairs(const IdwtLevelArgs& a);   // coefficient pairs a K6 workgroup owns at this level
 
 // ---- K7: inverse colour transform + DC shift + clamp + store as pixels (kernels_idwt.hip) --------
 struct EgressArgs {

@@ -33,6 +33,7 @@
 // fp32 9/7: (l + r) * c and the accumulate are separately rounded (__fadd_rn/__fmul_rn, no FMA),
 // the order of WaveletFwd.cpp:143-160; scaling low*invK, high*K as in :46, :203-213.
 #include "kernels.h"
+#include "pk16.h"
 #include <type_traits>
 
 namespace grk_amd {
@@ -105,12 +106,8 @@ struct V97 {
     }
 };
 
-// ---- the same on PAIRS of int16 in one register (v_pk_add / sub / ashr: one instruction, two samples) ----------------
-// The arithmetic is the 5/3's own -- sums, differences and floor shifts -- so while nothing leaves 16 bits the halves are
-// exactly what the 32-bit form computes; the host vouches for the range level by level (context.hip: pk16_level_ok).
-typedef short pk16 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
-__device__ __forceinline__ uint32_t as_u32(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+// ---- the same on PAIRS of int16 in one register (pk16.h); the host vouches for the range level by level
+//      (context.hip: pk16_level_ok) ------------------------------------------------------------------------------------
 struct V53pk {
     pk16 xe, dp;
     __device__ __forceinline__ void init(pk16 x_even) { xe = x_even; dp = (pk16)(0); }
@@ -544,15 +541,14 @@ __global__ __launch_bounds__(kThreads) void dwt53_pk_kernel(DwtLevelArgs a)
     const uint32_t selB = PX == 1 ? (rev ? 0x0c000c01u : 0x0c030c02u) : (rev ? 0x01000302u : 0x07060504u);
     const pk16 dc2 = as_pk((uint32_t)a.dc * 0x10001u);       // (unsigned pixels: the launcher sends signed ones elsewhere)
 
-    auto rsrc = [](const void* p, int nbytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, nbytes, 0x00020000); };
     __amdgpu_buffer_rsrc_t r_in[NC], r_ll[NC], r_mp[NC];
     #pragma unroll
-    for (int k = 0; k < NC; ++k) {                         // (offsets stay below 2^32: a plane is at most 2^31 samples)
-        r_in[k] = PX == 0 ? rsrc(in, -1) : rsrc(pix + (size_t)k * comp_px, -1);
-        r_ll[k] = rsrc(ll + (size_t)k * a.ll_pitch, -1);
-        r_mp[k] = rsrc(mp + (size_t)k * a.m_pitch, -1);
+    for (int k = 0; k < NC; ++k) {
+        r_in[k] = PX == 0 ? buffer_from(in) : buffer_from(pix + (size_t)k * comp_px);
+        r_ll[k] = buffer_from(ll + (size_t)k * a.ll_pitch);
+        r_mp[k] = buffer_from(mp + (size_t)k * a.m_pitch);
     }
-    __amdgpu_buffer_rsrc_t r_none = rsrc(a.mallat, 0);       // zero length: the memory pipeline drops what goes through it
+    __amdgpu_buffer_rsrc_t r_none = buffer_from(a.mallat, true);
 
     const int32_t J0 = (int32_t)(by * a.seg_pairs);
     const int32_t J1 = min((int32_t)sh, J0 + (int32_t)a.seg_pairs);
@@ -620,10 +616,10 @@ __global__ __launch_bounds__(kThreads) void dwt53_pk_kernel(DwtLevelArgs a)
     #pragma unroll
         for (int k = 0; k < NC; ++k) {
             uint4 w;                                         // per column (vertical low | vertical high << 16)
-            w.x = __builtin_amdgcn_perm(as_u32(dA[k]), as_u32(sA[k]), 0x05040100u);
-            w.y = __builtin_amdgcn_perm(as_u32(dA[k]), as_u32(sA[k]), 0x07060302u);
-            w.z = __builtin_amdgcn_perm(as_u32(dB[k]), as_u32(sB[k]), 0x05040100u);
-            w.w = __builtin_amdgcn_perm(as_u32(dB[k]), as_u32(sB[k]), 0x07060302u);
+            w.x = __builtin_amdgcn_perm(as_u32(dA[k]), as_u32(sA[k]), kSelLoLo);
+            w.y = __builtin_amdgcn_perm(as_u32(dA[k]), as_u32(sA[k]), kSelHiHi);
+            w.z = __builtin_amdgcn_perm(as_u32(dB[k]), as_u32(sB[k]), kSelLoLo);
+            w.w = __builtin_amdgcn_perm(as_u32(dB[k]), as_u32(sB[k]), kSelHiHi);
             *reinterpret_cast<uint4*>(&line[par][k][grp * kPkLaneCols]) = w;
         }
         __syncthreads();
@@ -640,10 +636,10 @@ __global__ __launch_bounds__(kThreads) void dwt53_pk_kernel(DwtLevelArgs a)
             const pk16 s0 = c0 + ((dm + d0 + (pk16)(2)) >> 2);
             const pk16 s1 = c2 + ((d0 + d1 + (pk16)(2)) >> 2);
             // (horizontal low | .. of the vertical low row, of the vertical high row): regroup by sub-band row
-            o[k][0] = __builtin_amdgcn_perm(as_u32(s1), as_u32(s0), 0x05040100u);       // LL: two columns
-            o[k][1] = __builtin_amdgcn_perm(as_u32(s1), as_u32(s0), 0x07060302u);       // LH
-            o[k][2] = __builtin_amdgcn_perm(as_u32(d1), as_u32(d0), 0x05040100u);       // HL
-            o[k][3] = __builtin_amdgcn_perm(as_u32(d1), as_u32(d0), 0x07060302u);       // HH
+            o[k][0] = __builtin_amdgcn_perm(as_u32(s1), as_u32(s0), kSelLoLo);       // LL: two columns
+            o[k][1] = __builtin_amdgcn_perm(as_u32(s1), as_u32(s0), kSelHiHi);       // LH
+            o[k][2] = __builtin_amdgcn_perm(as_u32(d1), as_u32(d0), kSelLoLo);       // HL
+            o[k][3] = __builtin_amdgcn_perm(as_u32(d1), as_u32(d0), kSelHiHi);       // HH
         }
     };
     auto store_out = [&](int32_t j, const uint32_t (&o)[NC][4]) {
@@ -667,7 +663,7 @@ __global__ __launch_bounds__(kThreads) void dwt53_pk_kernel(DwtLevelArgs a)
     // descriptor of zero length.
     auto no_stores = [&]() {
     #pragma unroll
-        for (int k = 0; k < 4 * NC; ++k) __builtin_amdgcn_raw_buffer_store_b32(0u, r_none, oc, 4 * k, 0);   // (distinct, or they fold into one)
+        for (int k = 0; k < 4 * NC; ++k) __builtin_amdgcn_raw_buffer_store_b32(0u, r_none, oc + 64 * k, 0, 0);   // (apart, or they merge into wider ones)
     };
     const int32_t i_end = J1 - 1;
     uint32_t o[NC][4];
@@ -694,7 +690,7 @@ uint32_t dwt_strip_cols() { return kOutCols; }
 // the level shape dwt53_pk_kernel takes
 static bool dwt_level_is_pk(const DwtLevelArgs& a)
 {
-    return a.h16 && a.pk && !a.irreversible && (a.px | a.py) == 0 && (a.cw & 3u) == 0 && a.cw >= (uint32_t)kPkOutCols &&
+    return a.h16 && a.pk && !a.irreversible && (a.px | a.py) == 0 && (a.cw & 3u) == 0 && a.cw >= 256u &&
            a.ch >= 16 && (a.ch & 1u) == 0;
 }
 uint32_t dwt_level_strip_cols(const DwtLevelArgs& a) { return dwt_level_is_pk(a) ? pk_strip_cols(a.cw) : (uint32_t)kOutCols; }

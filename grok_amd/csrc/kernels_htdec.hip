@@ -447,14 +447,14 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
             if (h16) {
                 dst16[(size_t)y0 * a.stride + x] = (int16_t)ot;
                 if (y0 + 1 < h) dst16[(size_t)(y0 + 1) * a.stride + x] = (int16_t)ob;
-                range |= (uint32_t)(ot + 32768) | (uint32_t)(ob + 32768);          // >= 65536: does not fit
+                range |= (uint32_t)(ot + a.h16_bias) | (uint32_t)(ob + a.h16_bias);          // >= 2 bias: outside [-bias, bias)
             } else {
                 dst[(size_t)y0 * a.stride + x] = ot;
                 if (y0 + 1 < h) dst[(size_t)(y0 + 1) * a.stride + x] = ob;
             }
         }
     }
-    if (h16 && __builtin_amdgcn_ballot_w64(range > 0xFFFFu) != 0 && lane == 0) atomicOr(a.status, 8u);
+    if (h16 && __builtin_amdgcn_ballot_w64(range >= 2u * (uint32_t)a.h16_bias) != 0 && lane == 0) atomicOr(a.status, 8u);
 }
 
 // ---- K5c: the refinement passes, ONE WAVEFRONT PER CODE-BLOCK ---------------------------------------------------------

@@ -26,6 +26,7 @@
 // 9/7: low*K, high*(2/K) first, then the four lifting sweeps with coefficients -delta, -gamma,
 // -beta, -alpha, each `x + ((l + r) * c)` separately rounded (:1068-1073, :1005-1008).
 #include "kernels.h"
+#include "pk16.h"
 #include <type_traits>
 
 namespace grk_amd {
@@ -350,6 +351,250 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     }
 }
 
+// ---- the inverse 5/3 level on packed int16 pairs, two coefficient pairs (four output columns) per lane ---------------
+// The mirror image of dwt53_pk_kernel (kernels_dwt.hip), for the same reasons: dword accesses instead of 2-byte ones (the
+// texture addresser takes four lanes a clock whatever the width), a third of the vector instructions, addresses from
+// buffer descriptors + scalar row offsets, rows two steps ahead.  For levels the launcher knows to be reversible with
+// 16-bit planes, on the origin, whole (no window), of even height >= 16 and a width that is a multiple of 4; PXO = 1: the
+// last level, 8-bit unsigned pixels out.
+//   per row pair i a lane loads LL / HL (low row) and LH / HH (high row) of its two pairs J, J + 1 -- four dwords per
+//   component --, regroups them per pair as S = (LL | LH << 16), D = (HL | HH << 16), so that ONE horizontal synthesis
+//   does the low and the high row, regroups the four columns it made as (two columns of the low row), (of the high row)
+//   for the vertical recurrence on packed pairs, and stores finished rows four columns at a time.
+// Range: every sum stays inside 16 bits as long as the level's inputs lie within +-kPkDecodeBound (pk16.h) -- the block
+// decoder's flag vouches for the coefficients, and an intermediate level checks the LL it writes (status bit 3 otherwise;
+// the decode is then done again in 32 bits, context.hip decode_impl).
+struct IV53pk {       // yields rows 2i-1 and 2i
+    pk16 dprev, xprev;
+    __device__ __forceinline__ void init() { dprev = (pk16)(0); xprev = (pk16)(0); }
+    __device__ __forceinline__ void step(pk16 s, pk16 d, pk16& r_odd, pk16& r_even)
+    {
+        r_even = s - ((dprev + d + (pk16)(2)) >> 2);
+        r_odd = dprev + ((xprev + r_even) >> 1);
+        dprev = d; xprev = r_even;
+    }
+};
+__device__ __forceinline__ uint32_t sat_pk_u8(pk16 v)      // two int16 -> two bytes, each clamped to [0, 255]
+{
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(as_u32(v)));
+    return r;
+}
+
+constexpr int kPkLanePairs = 2;
+constexpr int kPkPairs     = kThreads * kPkLanePairs;      // pairs staged per line: 512
+constexpr int kPkOutCols   = 960;                          // output columns per strip at most (240 lanes; one halo lane each side)
+static_assert(kPkOutCols / 4 + 2 <= kThreads, "strip does not fit the staged line");
+// the strips of a level share its width evenly, in multiples of 64 output columns
+__host__ __device__ inline uint32_t ipk_strip_cols(uint32_t cw)
+{
+    const uint32_t n = (cw + kPkOutCols - 1) / kPkOutCols;
+    return min((uint32_t)kPkOutCols, ((cw + n - 1) / n + 63u) & ~63u);
+}
+
+#define IPK_FENCE __builtin_amdgcn_sched_barrier(0)
+template <int NC, int PXO>
+__global__ __launch_bounds__(kThreads) void idwt53_pk_kernel(IdwtLevelArgs a)
+{
+    static_assert(PXO == 0 || PXO == 1, "int16 planes or 8-bit pixels");
+    static_assert(PXO != 0 || NC == 1, "plane output is one component per workgroup");
+    // [parity][comp][pair][S, D]: S = LL | LH << 16, D = HL | HH << 16
+    __shared__ __attribute__((aligned(16))) uint32_t line[2][NC][kPkPairs * 2];
+
+    const uint32_t t = threadIdx.x;
+    uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd) {                                           // XCD k takes a contiguous run of the strip-fastest order (see above)
+        const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint32_t id = bx + gx * (by + gy * bz);
+        const uint32_t q = total >> 3, r = total & 7u, k = id & 7u;
+        const uint32_t lid = k * q + min(k, r) + (id >> 3);
+        bx = lid % gx; by = (lid / gx) % gy; bz = lid / (gx * gy);
+    }
+    const uint32_t cw = a.cw, ch = a.ch;
+    const uint32_t sw = cw >> 1, sh = ch >> 1;
+    const uint32_t scols = ipk_strip_cols(cw), slanes = scols / 4;
+
+    uint32_t plane0 = bz;
+    if constexpr (PXO != 0) plane0 = (bz / a.zdiv) * a.ncomp + a.comp0 + (bz % a.zdiv);
+    const int16_t* ll = reinterpret_cast<const int16_t*>(a.ll) + (size_t)plane0 * a.ll_pitch;
+    const int16_t* mp = reinterpret_cast<const int16_t*>(a.mallat) + (size_t)plane0 * a.m_pitch;
+    int16_t* out = reinterpret_cast<int16_t*>(a.out) + (size_t)plane0 * a.out_pitch;
+    const size_t comp_px = (size_t)cw * ch;
+    uint8_t* pix = reinterpret_cast<uint8_t*>(a.pixels) + (size_t)plane0 * comp_px;
+
+    // Lane t < slanes carries group t + 1 of the staged line (groups of two pairs; group 0 and group slanes + 1 are the halo,
+    // on the two lanes after; the rest repeat lane 0).
+    const uint32_t grp = t < slanes ? t + 1 : (t == slanes ? 0u : (t == slanes + 1 ? t : 1u));
+    const int32_t J = (int32_t)(bx * (scols / 2)) - kPkLanePairs + (int32_t)(grp * kPkLanePairs);     // first of its two pairs
+    // A group outside the level is a mirrored one, in the interleaved domain (low sample 2J, high sample 2J + 1): pairs
+    // (-2, -1) hold s[2], s[1] and d[1], d[0]; pairs (sw, sw + 1) hold s[sw-1], s[sw-2] and d[sw-2], d[sw-3] -- two consecutive
+    // coefficients read backwards, from different places for the two halves.  (Only the nearest pair of a halo group is
+    // used; groups further out load from inside the row.)
+    const bool rev = J < 0 || J >= (int32_t)sw;
+    int32_t js = J < 0 ? -J - 1 : (J >= (int32_t)sw ? 2 * (int32_t)sw - 2 - J : J);          // lowest s index of the two
+    int32_t jd = J < 0 ? -J - 2 : (J >= (int32_t)sw ? 2 * (int32_t)sw - 3 - J : J);          // lowest d index
+    js = max(0, min(js, (int32_t)sw - 2)); jd = max(0, min(jd, (int32_t)sw - 2));
+    const uint32_t off_s = (uint32_t)js * 2u, off_d = (uint32_t)jd * 2u;                     // bytes into a half-row
+    // regrouping selectors (v_perm over hi : lo): pair J takes the low halves of the two loads, pair J + 1 the high halves --
+    // the other way round for a mirrored group
+    const uint32_t sel0 = rev ? kSelHiHi : kSelLoLo, sel1 = rev ? kSelLoLo : kSelHiHi;
+
+    __amdgpu_buffer_rsrc_t r_ll[NC], r_mp[NC], r_out[NC];
+    #pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        r_ll[k] = buffer_from(ll + (size_t)k * a.ll_pitch);
+        r_mp[k] = buffer_from(mp + (size_t)k * a.m_pitch);
+        r_out[k] = PXO == 0 ? buffer_from(out) : buffer_from(pix + (size_t)k * comp_px);
+    }
+    __amdgpu_buffer_rsrc_t r_none = buffer_from(a.mallat, true);
+
+    const int32_t I0 = (int32_t)(by * a.seg_pairs);
+    const int32_t I1 = min((int32_t)sh, I0 + (int32_t)a.seg_pairs);
+
+    struct Raw { uint32_t ls[NC], ld[NC], hs[NC], hd[NC]; };
+    auto fetch = [&](int32_t i, Raw& q) {                    // row pair i: low row 2i, high row 2i + 1 (mirrored past the ends)
+        // (ch >= 16 and the rows leave [0, ch) by a few samples at most: one reflection, no division, no branch)
+        auto mirror = [&](int32_t r) { r = r < 0 ? -r : r; return (uint32_t)(r < (int32_t)ch ? r : 2 * ((int32_t)ch - 1) - r); };
+        const uint32_t is = mirror(2 * i) >> 1, id = (mirror(2 * i + 1) - 1u) >> 1;
+        const uint32_t lrow = is * a.ll_stride * 2u, mlo = is * a.m_stride * 2u + sw * 2u, mhi = (sh + id) * a.m_stride * 2u;
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            q.ls[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ll[k], off_s, lrow, 0);
+            q.ld[k] = __builtin_amdgcn_raw_buffer_load_b32(r_mp[k], off_d, mlo, 0);
+            q.hs[k] = __builtin_amdgcn_raw_buffer_load_b32(r_mp[k], off_s, mhi, 0);
+            q.hd[k] = __builtin_amdgcn_raw_buffer_load_b32(r_mp[k], off_d, mhi + sw * 2u, 0);
+        }
+    };
+
+    // horizontal phase: lane t synthesises the four columns of group t + 1; lanes past the strip's last group (halo, idle,
+    // beyond the level in the last strip) repeat the last one -- same reads, same values to the same addresses
+    const uint32_t nv = min(slanes, (cw - bx * scols + 3u) >> 2);
+    const uint32_t tp = min(t, nv - 1u);
+    const uint32_t hp = (tp + 1u) * kPkLanePairs;            // its first pair in the staged line
+    const uint32_t oc = (bx * scols + tp * 4u) * (PXO == 0 ? 2u : 1u);      // byte offset of its four samples in an output row
+
+    IV53pk colA[NC], colB[NC];
+    #pragma unroll
+    for (int k = 0; k < NC; ++k) { colA[k].init(); colB[k].init(); }
+    uint32_t range = 0;
+    struct Rows { pk16 oA[NC], oB[NC], eA[NC], eB[NC]; };    // finished rows 2i - 1 (o) and 2i (e): columns (0, 1) and (2, 3)
+
+    struct Grouped { uint4 w[NC]; };
+    auto regroup = [&](const Raw& q, Grouped& g) {           // (the first touch of a fetched row pair: before its registers are refilled)
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            g.w[k].x = __builtin_amdgcn_perm(q.hs[k], q.ls[k], sel0);     // S of pair J
+            g.w[k].y = __builtin_amdgcn_perm(q.hd[k], q.ld[k], sel0);     // D of pair J
+            g.w[k].z = __builtin_amdgcn_perm(q.hs[k], q.ls[k], sel1);     // S of pair J + 1
+            g.w[k].w = __builtin_amdgcn_perm(q.hd[k], q.ld[k], sel1);     // D
+        }
+    };
+    auto step = [&](int par, const Grouped& g, Rows& f) {
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) *reinterpret_cast<uint4*>(&line[par][k][grp * kPkLanePairs * 2]) = g.w[k];
+        __syncthreads();
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(&line[par][k][hp * 2], 16));
+            const pk16 dm = as_pk(w[-1]);
+            const uint4 c = *reinterpret_cast<const uint4*>(w);
+            const uint2 n = *reinterpret_cast<const uint2*>(w + 4);
+            const pk16 s0 = as_pk(c.x), d0 = as_pk(c.y), s1 = as_pk(c.z), d1 = as_pk(c.w), s2 = as_pk(n.x), d2 = as_pk(n.y);
+            const pk16 two = (pk16)(2);
+            const pk16 e0 = s0 - ((dm + d0 + two) >> 2);
+            const pk16 e1 = s1 - ((d0 + d1 + two) >> 2);
+            const pk16 e2 = s2 - ((d1 + d2 + two) >> 2);
+            const pk16 o0 = d0 + ((e0 + e1) >> 1);
+            const pk16 o1 = d1 + ((e1 + e2) >> 1);
+            // columns 0..3 = e0, o0, e1, o1, each (low row | high row << 16): regroup as two columns of one row
+            const pk16 lA = as_pk(__builtin_amdgcn_perm(as_u32(o0), as_u32(e0), kSelLoLo)), hA = as_pk(__builtin_amdgcn_perm(as_u32(o0), as_u32(e0), kSelHiHi));
+            const pk16 lB = as_pk(__builtin_amdgcn_perm(as_u32(o1), as_u32(e1), kSelLoLo)), hB = as_pk(__builtin_amdgcn_perm(as_u32(o1), as_u32(e1), kSelHiHi));
+            colA[k].step(lA, hA, f.oA[k], f.eA[k]);
+            colB[k].step(lB, hB, f.oB[k], f.eB[k]);
+        }
+    };
+    // one finished row (four columns of it per lane) leaves the kernel; `voff` = oc, or all ones for a row that is not this
+    // workgroup's to write (beyond any buffer: dropped)
+    auto emit = [&](int32_t r, const pk16 (&vA)[NC], const pk16 (&vB)[NC], uint32_t voff) {
+        const uint32_t ru = __builtin_amdgcn_readfirstlane((uint32_t)r);
+        if constexpr (PXO == 0) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r_none, 0, 0, 0)), uint2{as_u32(vA[0]), as_u32(vB[0])}),
+                                                  r_out[0], voff, ru * a.out_stride * 2u, 0);
+            // what the next level reads has to lie inside its range as well
+            const pk16 bias = (pk16)((short)(kPkDecodeBound + 1));
+            range |= (as_u32(vA[0] + bias) | as_u32(vB[0] + bias)) & (voff == 0xFFFFFFFFu ? 0u : 0xFFFFFFFFu);
+        } else {
+            pk16 cA[NC], cB[NC];
+            if constexpr (NC == 3) {           // inverse RCT (mct.cpp:454-464): G = Y - ((U + V) >> 2), R = V + G, B = U + G
+                const pk16 gA = vA[0] - ((vA[1] + vA[2]) >> 2), gB = vB[0] - ((vB[1] + vB[2]) >> 2);
+                cA[0] = vA[2] + gA; cA[1] = gA; cA[2] = vA[1] + gA;
+                cB[0] = vB[2] + gB; cB[1] = gB; cB[2] = vB[1] + gB;
+            } else { cA[0] = vA[0]; cB[0] = vB[0]; }
+            const pk16 dc2 = as_pk((uint32_t)a.dc * 0x10001u);
+    #pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const uint32_t four = __builtin_amdgcn_perm(sat_pk_u8(cB[k] + dc2), sat_pk_u8(cA[k] + dc2), kSelLoLo);
+                __builtin_amdgcn_raw_buffer_store_b32(four, r_out[k], voff, ru * cw, 0);
+            }
+        }
+    };
+    constexpr int kStores = PXO == 0 ? 2 : 2 * NC;           // memory stores per step
+    auto no_stores = [&]() {
+    #pragma unroll
+        for (int k = 0; k < kStores; ++k) {
+            if constexpr (PXO == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r_none, 0, 0, 0)), uint2{0u, 0u}), r_none, oc + 64 * k, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(0u, r_none, oc + 64 * k, 0, 0);          // (apart, or they merge into wider ones)
+        }
+    };
+    // Step i consumes row pair i and finishes rows 2i - 1 and 2i; steps I0 - 1 .. I1, the first a warm-up.  Row pairs are fetched
+    // two steps ahead into two alternating sets; the rows a step finishes are stored during the next one, after its
+    // fetches -- every memory operation of a step in one place.  As in dwt53_pk_kernel the two steps before the loop issue
+    // the same sequence as every later pair (fetches, stores, fetches, stores) with their stores dropped, so that the
+    // compiler's wait at the loop head allows a full two steps of operations in flight.
+    Raw ra, rb;
+    fetch(I0 - 1, ra); fetch(I0, rb);
+    Rows f;
+    const uint32_t none = 0xFFFFFFFFu;
+    int32_t i = I0 - 1;
+    auto run = [&](Raw& q, int par, bool first) {            // one step: regroup + synthesise row pair i, refill q, store the rows before
+        Grouped g;
+        regroup(q, g);
+        // (the regrouping stays HERE -- the optimiser would sink it to the exchange below, past the refill, and the old rows
+        //  would have to be copied out of the refill's way)
+    #pragma unroll
+        for (int k = 0; k < NC; ++k) asm volatile("" : "+v"(g.w[k].x), "+v"(g.w[k].y), "+v"(g.w[k].z), "+v"(g.w[k].w));
+        IPK_FENCE;
+        fetch(i + 2, q);
+        if (first) no_stores();
+        else {
+            const int32_t ip = i - 1;                        // the step whose rows are stored now: rows 2ip - 1, 2ip
+            emit(2 * ip - 1, f.oA, f.oB, ip > I0 ? oc : none);                  // (row 2 I0 - 1 is the segment above's)
+            emit(2 * ip, f.eA, f.eB, ip < I1 ? oc : none);                      // (row 2 I1 the segment below's)
+        }
+        step(par, g, f);
+        ++i;
+    };
+    run(ra, 0, true);
+    IPK_FENCE;
+    run(rb, 1, true);
+    IPK_FENCE;
+    while (i + 1 <= I1) {
+        run(ra, 0, false);
+        IPK_FENCE;
+        run(rb, 1, false);
+        IPK_FENCE;
+    }
+    if (i <= I1) run(ra, 0, false);
+    {
+        const int32_t ip = i - 1;
+        emit(2 * ip - 1, f.oA, f.oB, ip > I0 ? oc : none);
+        emit(2 * ip, f.eA, f.eB, ip < I1 ? oc : none);
+    }
+    if constexpr (PXO == 0) {
+        if (__builtin_amdgcn_ballot_w64((range & 0xF000F000u) != 0) != 0 && (t & 63u) == 0) atomicOr(a.status, 8u);
+    }
+}
+
 // ---- K7 egress, stand-alone (stage entry point; pixel sizes the fused last level does not cover) ----------
 template <typename PIX, int NC>
 __global__ __launch_bounds__(256) void egress_kernel(EgressArgs a)
@@ -412,12 +657,25 @@ __global__ __launch_bounds__(256) void egress_kernel(EgressArgs a)
 
 uint32_t idwt_strip_pairs() { return kOutPairs; }
 
+// the level shape idwt53_pk_kernel takes (a.pk: the launcher's word that the inputs are inside the packed range)
+static bool idwt_level_is_pk(const IdwtLevelArgs& a)
+{
+    return a.h16 && a.pk && !a.irreversible && (a.px | a.py) == 0 && (a.cw & 3u) == 0 && a.cw >= 256u && a.ch >= 16 && (a.ch & 1u) == 0 &&
+           a.nstrips == 0 && a.nsegs == 0;
+}
+uint32_t idwt_level_strip_pairs(const IdwtLevelArgs& a) { return idwt_level_is_pk(a) ? ipk_strip_cols(a.cw) / 2 : (uint32_t)kOutPairs; }
+
 hipError_t launch_idwt_level(const IdwtLevelArgs& a, hipStream_t s)
 {
     const uint32_t sw = (a.cw + a.px + 1) >> 1, sh = (a.ch + a.py + 1) >> 1;      // pairs on the coordinate grid
     // strips x row segments: all of them, or the caller's sub-grid (region decode)
     dim3 grid(a.nstrips ? a.nstrips : (sw + kOutPairs - 1) / kOutPairs, a.nsegs ? a.nsegs : (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
     dim3 block(kThreads);
+    if (idwt_level_is_pk(a)) {
+        grid.x = (a.cw + ipk_strip_cols(a.cw) - 1) / ipk_strip_cols(a.cw);
+        hipLaunchKernelGGL((idwt53_pk_kernel<1, 0>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if (a.irreversible)
         hipLaunchKernelGGL((idwt_level_kernel<true, 1, 0>), grid, block, 0, s, a);
     else if (a.h16)
@@ -442,6 +700,11 @@ hipError_t launch_idwt_level0_fused(const IdwtLevelArgs& a0, uint32_t ntiles, ui
         if (a.irreversible) {
             if (nc == 3) { if (px == 1) GRK_I0(true, 3, 1); else GRK_I0(true, 3, 2); }
             else         { if (px == 1) GRK_I0(true, 1, 1); else GRK_I0(true, 1, 2); }
+        } else if (px == 1 && idwt_level_is_pk(a) && a.lo == 0 && a.hi == 255 && a.wx0 == 0 && a.wy0 == 0 && a.wx1 == a.cw && a.wy1 == a.ch &&
+                   (nc == 1 || a.mct)) {
+            grid.x = (a.cw + ipk_strip_cols(a.cw) - 1) / ipk_strip_cols(a.cw);
+            if (nc == 3) hipLaunchKernelGGL((idwt53_pk_kernel<3, 1>), grid, block, 0, s, a);
+            else         hipLaunchKernelGGL((idwt53_pk_kernel<1, 1>), grid, block, 0, s, a);
         } else if (a.h16) {
             if (nc == 3) { if (px == 1) hipLaunchKernelGGL((idwt_level_kernel<false, 3, 1, true>), grid, block, 0, s, a);
                            else         hipLaunchKernelGGL((idwt_level_kernel<false, 3, 2, true>), grid, block, 0, s, a); }
