@@ -662,6 +662,24 @@ def test_decode_int16_planes_and_their_range_check():
         c.set_decode_planes16(True)
     got = c.decode_host(p8, table, coded)[0]                # int16 planes -> range flag -> repeated with int32 planes
     assert np.array_equal(got, want)
+    # in between: values that fit int16 but not the packed inverse transform's range (+-2047, pk16.h) -- coefficients beyond it
+    # (flagged by the block decoder), or coefficients inside it whose synthesis grows past it (flagged by the level that
+    # writes such an LL): smooth ramps, noise and checkerboards of rising amplitude, all the same pixels as with int32 planes
+    rng = np.random.default_rng(5)
+    for amp in (300, 700, 1500, 4000, 9000):
+        for kind in range(3):
+            if kind == 0: v = (yy * amp // H + xx * amp // W) // 2
+            elif kind == 1: v = rng.integers(0, amp, size=(H, W))
+            else: v = (((yy // 4) + (xx // 4)) & 1) * amp
+            pxa = (v + 32768 - amp // 2).astype(np.uint16)[None]
+            table, coded = c.encode_host(p12, pxa)
+            c.set_decode_planes16(False)
+            try:
+                want_a = c.decode_host(p8, table, coded)[0]
+            finally:
+                c.set_decode_planes16(True)
+            assert np.array_equal(c.decode_host(p8, table, coded)[0], want_a), (amp, kind)
+    table, coded = c.encode_host(p12, px12)
     d_c = U.to_dev(np.concatenate([coded, np.zeros(64, np.uint8)]))
     out = U._settled(torch.zeros(H * W, dtype=torch.uint8, device="cuda"))
     c.decode_device(p8, 1, table, d_c.data_ptr(), coded.size, out.data_ptr())

@@ -302,6 +302,24 @@ def test_packed_int16_dwt_at_the_extremes(cell, monkeypatch):
     assert got["1"] == want
 
 
+@pytest.mark.parametrize("C,H,W,L", [(3, 16, 256, 1), (1, 18, 260, 1), (3, 50, 1000, 2), (1, 34, 1924, 1), (3, 130, 2044, 3), (3, 64, 4100, 2),
+                                     (3, 96, 964, 1), (1, 200, 3844, 2)])
+def test_packed_dwt_strip_geometries(C, H, W, L):
+    """The packed 5/3 kernels (four columns per lane, strips of up to 960 columns shared evenly) at widths that leave
+    ragged last strips, one-lane last strips, mirrored halo groups on both sides: encode == oracle chain block for block,
+    and the decode (packed inverse kernels) returns the pixels."""
+    px = synth.g2(C, H, W, 8)
+    px[:, :, -3:] = 255 - px[:, :, -3:]            # (something to mirror at the right edge)
+    p = G.TileParams.make(W, H, C, 8, L)
+    t, coded = U.ctx().encode_host(p, px)
+    got = U.split_blocks(t, coded)
+    _, _, _, otable, ocoded = chain.encode_tile_oracle(px, 8, L, mct=(C >= 3))
+    want = [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
+    assert got == want
+    back = U.ctx().decode_host(p, t, coded)
+    assert np.array_equal(np.asarray(back).reshape(px.shape), px)
+
+
 def _dev_view(ptr, n, typestr):
     class _H:
         pass
