@@ -80,7 +80,6 @@ struct grk_amd_ctx {
     bool side_pending = false;       // side-stream work of the latest encode has not been joined on the main stream yet
     bool dec_planes16 = true;                               // 16-bit planes between K5b and K6 for 8-bit reversible HT tiles
                                                             // (GRK_AMD_DEC_PLANES16=0 / grk_amd_set_decode_planes16: int32)
-    uint32_t dwt_seg = 0;                                   // GRK_AMD_DWT_SEG: row pairs per K2 workgroup (experiments; 0 = the heuristic)
     int dwt_pk = 1;                                         // packed int16 pairs in K2 / K6 where the range allows (GRK_AMD_DWT_PK=0: 32-bit)
     int dwt_xcd = 1;                                        // XCD-aware workgroup order in K2 / K6 (GRK_AMD_DWT_XCD=0: plain)
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
@@ -350,7 +349,6 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         // workgroups along z: planes, or for the fused level 0 tiles (x components when there is no MCT triple)
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
-        if (c->dwt_seg) seg = c->dwt_seg;
         a.seg_pairs = seg;
         if (a.cw == 0 || a.ch == 0) {
             // a level without samples (a narrow tile off the origin: [ceil(x0 / 2^l), ceil((x0 + w) / 2^l)) can be empty):
@@ -710,16 +708,11 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* ef = getenv("GRK_AMD_FUSE_EGRESS")) c->fuse_egress = atoi(ef) != 0;
         if (const char* ex = getenv("GRK_AMD_DWT_XCD")) c->dwt_xcd = atoi(ex) != 0;
         if (const char* ex = getenv("GRK_AMD_DWT_PK")) c->dwt_pk = atoi(ex) != 0;
-        if (const char* ex = getenv("GRK_AMD_DWT_SEG")) c->dwt_seg = (uint32_t)atoi(ex);
         if (const char* ed = getenv("GRK_AMD_DEC_PLANES16")) c->dec_planes16 = atoi(ed) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
-        hipError_t sk = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least);
-        if (const char* ek = getenv("GRK_AMD_STREAM_SKIP")) {          // (experiment: which hardware queue side2 lands on)
-            for (int i = 0; i < atoi(ek); ++i) { hipStream_t dummy; (void)hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, least); }
-        }
-        if (sk != hipSuccess ||
+        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
             hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->alt.ev_side, hipEventDisableTiming) != hipSuccess ||

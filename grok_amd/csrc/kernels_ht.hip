@@ -809,9 +809,6 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
 template <bool IRREV, bool H16>
 __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, HtLds L, uint32_t class_id)
 {
-#ifdef GRK_K3_RESERVE_V87
-    asm volatile("" ::: "v87");
-#endif
     ht_encode_block<IRREV, H16>(a, blockIdx.x % a.sel_count, blockIdx.x / a.sel_count, L, class_id);
 }
 

@@ -22,10 +22,12 @@ import json
 import sys
 
 FAMILIES = [  # (family, test on the kernel name); the inverse kernels first: "idwt_level_kernel" contains "dwt_level_kernel"
-    ("idwt_last_level_fused", lambda n: "idwt_level_kernel<" in n and not n.split("idwt_level_kernel<")[1].startswith(("false, 1, 0", "true, 1, 0"))),
-    ("idwt_level_kernel", lambda n: "idwt_level_kernel<" in n),
-    ("dwt_levels_1plus", lambda n: "dwt_level_kernel<false, 1, 0" in n or "dwt_level_kernel<true, 1, 0" in n),
-    ("dwt_level0_fused", lambda n: "dwt_level_kernel<" in n),
+    # (r02: the packed 5/3 kernels dwt53_pk_kernel<NC, PX> / idwt53_pk_kernel<NC, PXO> belong to the same families)
+    ("idwt_last_level_fused", lambda n: ("idwt_level_kernel<" in n and not n.split("idwt_level_kernel<")[1].startswith(("false, 1, 0", "true, 1, 0")))
+                                        or ("idwt53_pk_kernel<" in n and not n.split("idwt53_pk_kernel<")[1].startswith("1, 0"))),
+    ("idwt_level_kernel", lambda n: "idwt_level_kernel<" in n or "idwt53_pk_kernel<" in n),
+    ("dwt_levels_1plus", lambda n: "dwt_level_kernel<false, 1, 0" in n or "dwt_level_kernel<true, 1, 0" in n or "dwt53_pk_kernel<1, 0" in n),
+    ("dwt_level0_fused", lambda n: "dwt_level_kernel<" in n or "dwt53_pk_kernel<" in n),
     ("ht_encode_kernel", lambda n: "ht_encode_kernel" in n),
     ("ht_dec_vlc_kernel", lambda n: "ht_dec_vlc_kernel" in n),
     ("ht_dec_ms_kernel", lambda n: "ht_dec_ms_kernel" in n),

@@ -18,7 +18,7 @@ if [[ "$WHAT" == *stats* ]]; then
 fi
 if [[ "$WHAT" == *pmc* ]]; then
   export GRK_AMD_OVERLAP=0 PROF_N=4
-  for WL in 8k cfg3 cfg5; do
+  for WL in ${PROF_WLS:-8k cfg3 cfg5}; do
     export PROF_WORKLOAD=$WL PROF_DECODE=1
     for C in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/pm_$C
