@@ -182,8 +182,9 @@ int grk_amd_decode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
                          int coded_on_device, void* pixels, int pixels_on_device);
 int grk_amd_decode_status(grk_amd_ctx* ctx);
 /* 8-bit reversible HT tiles are decoded with int16 planes between the block decoder and the inverse DWT (default on; half
- * the bytes of the two HBM-bound halves of the decode).  Every coefficient and every synthesised LL sample of a stream that
- * an 8-bit image produced fits; a stream whose values do not is never decoded to other pixels: a synchronous call (host
+ * the bytes of the two HBM-bound halves of the decode), and the inverse 5/3 runs on packed pairs of them, which takes every
+ * coefficient and every synthesised LL sample within +-2047 (an 8-bit image's are: |HH| <= 1020 at the top resolution, the
+ * LL of every level is image-sized); a stream whose values are not is never decoded to other pixels: a synchronous call (host
  * pixels) decodes it again with int32 planes by itself, an asynchronous one reports GRK_AMD_ERR_RANGE from
  * grk_amd_decode_status() and the caller repeats the call after grk_amd_set_decode_planes16(ctx, 0). */
 int grk_amd_set_decode_planes16(grk_amd_ctx* ctx, int on);
