@@ -320,6 +320,30 @@ def test_packed_dwt_strip_geometries(C, H, W, L):
     assert np.array_equal(np.asarray(back).reshape(px.shape), px)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_packed_dwt_random_shapes(seed):
+    """Random shapes on the packed kernels' side of the launch conditions (width a multiple of 4 from 256 up, even height from
+    16 up) and just off it (odd heights, widths that are not: the 32-bit kernels take those levels), 1 / 3 / 4 components,
+    1-5 levels, batches of tiles: blocks == oracle chain, decode == pixels."""
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.choice([1, 3, 3, 4]))
+    W = int(rng.integers(64, 700)) * 4 + (int(rng.integers(0, 4)) if seed % 3 == 2 else 0)
+    H = int(rng.integers(8, 120)) * 2 + (1 if seed % 4 == 3 else 0)
+    L = int(rng.integers(1, 6))
+    nt = int(rng.choice([1, 1, 2, 3]))
+    px = np.stack([synth.g2(C, H, W, 8, seed=seed * 7 + t) for t in range(nt)])
+    p = G.TileParams.make(W, H, C, 8, L)
+    t, coded = U.ctx().encode_host(p, px, ntiles=nt)
+    got = U.split_blocks(t, coded)
+    want = []
+    for k in range(nt):
+        _, _, _, otable, ocoded = chain.encode_tile_oracle(px[k], 8, L, mct=(C >= 3))
+        want += [bytes(ocoded[int(o):int(o) + int(l)]) for o, l in zip(otable["offset"], otable["length"])]
+    assert got == want, (C, H, W, L, nt)
+    back = U.ctx().decode_host(p, t, coded, ntiles=nt)
+    assert np.array_equal(np.asarray(back).reshape(px.shape), px), (C, H, W, L, nt)
+
+
 def _dev_view(ptr, n, typestr):
     class _H:
         pass
