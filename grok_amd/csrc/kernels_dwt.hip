@@ -557,8 +557,8 @@ __global__ __launch_bounds__(kThreads) void dwt53_pk_kernel(DwtLevelArgs a)
     auto fetch_row = [&](int32_t r, Raw& q) {                // raw row fetch: no arithmetic, so that the rows stay in flight
         const uint32_t rr = mirror_row<true>(r, ch);
         if constexpr (PX == 0) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(r_in[0], lane_off, rr * a.in_stride * 2u, 0);
-            q.w[0].x = v[0]; q.w[0].y = v[1];
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_in[0], lane_off, rr * a.in_stride * 2u, 0);
+            q.w[0].x = v.x; q.w[0].y = v.y;
         } else {
     #pragma unroll
             for (int k = 0; k < NC; ++k) q.v[k] = __builtin_amdgcn_raw_buffer_load_b32(r_in[k], lane_off, rr * cw, 0);

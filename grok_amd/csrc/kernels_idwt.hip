@@ -518,8 +518,7 @@ __global__ __launch_bounds__(kThreads) void idwt53_pk_kernel(IdwtLevelArgs a)
     auto emit = [&](int32_t r, const pk16 (&vA)[NC], const pk16 (&vB)[NC], uint32_t voff) {
         const uint32_t ru = __builtin_amdgcn_readfirstlane((uint32_t)r);
         if constexpr (PXO == 0) {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r_none, 0, 0, 0)), uint2{as_u32(vA[0]), as_u32(vB[0])}),
-                                                  r_out[0], voff, ru * a.out_stride * 2u, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{as_u32(vA[0]), as_u32(vB[0])}, r_out[0], voff, ru * a.out_stride * 2u, 0);
             // what the next level reads has to lie inside its range as well
             const pk16 bias = (pk16)((short)(kPkDecodeBound + 1));
             range |= (as_u32(vA[0] + bias) | as_u32(vB[0] + bias)) & (voff == 0xFFFFFFFFu ? 0u : 0xFFFFFFFFu);
@@ -542,7 +541,7 @@ __global__ __launch_bounds__(kThreads) void idwt53_pk_kernel(IdwtLevelArgs a)
     auto no_stores = [&]() {
     #pragma unroll
         for (int k = 0; k < kStores; ++k) {
-            if constexpr (PXO == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r_none, 0, 0, 0)), uint2{0u, 0u}), r_none, oc + 64 * k, 0, 0);
+            if constexpr (PXO == 0) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_none, oc + 64 * k, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b32(0u, r_none, oc + 64 * k, 0, 0);          // (apart, or they merge into wider ones)
         }
     };

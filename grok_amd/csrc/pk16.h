@@ -12,6 +12,7 @@ namespace grk_amd {
 typedef short pk16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
 __device__ __forceinline__ uint32_t as_u32(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));      // what the 8-byte buffer loads / stores carry
 
 // v_perm_b32 selectors over (hi = S0 : lo = S1): the low halves / the high halves of two registers side by side
 constexpr uint32_t kSelLoLo = 0x05040100u;      // (S1.lo | S0.lo << 16)
