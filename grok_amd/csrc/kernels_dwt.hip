@@ -690,8 +690,10 @@ uint32_t dwt_strip_cols() { return kOutCols; }
 // the level shape dwt53_pk_kernel takes
 static bool dwt_level_is_pk(const DwtLevelArgs& a)
 {
+    // (row offsets are 32-bit byte offsets from a plane's first sample: planes of 2^31 samples and more keep the flat addressing)
+    const bool near = (uint64_t)a.m_stride * a.ch < (1ull << 31) && (uint64_t)a.cw * a.ch < (1ull << 31) && (uint64_t)a.in_stride * a.ch < (1ull << 31);
     return a.h16 && a.pk && !a.irreversible && (a.px | a.py) == 0 && (a.cw & 3u) == 0 && a.cw >= 256u &&
-           a.ch >= 16 && (a.ch & 1u) == 0;
+           a.ch >= 16 && (a.ch & 1u) == 0 && near;
 }
 uint32_t dwt_level_strip_cols(const DwtLevelArgs& a) { return dwt_level_is_pk(a) ? pk_strip_cols(a.cw) : (uint32_t)kOutCols; }
 

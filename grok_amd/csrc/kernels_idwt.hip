@@ -659,8 +659,10 @@ uint32_t idwt_strip_pairs() { return kOutPairs; }
 // the level shape idwt53_pk_kernel takes (a.pk: the launcher's word that the inputs are inside the packed range)
 static bool idwt_level_is_pk(const IdwtLevelArgs& a)
 {
+    // (row offsets are 32-bit byte offsets from a plane's first sample: planes of 2^31 samples and more keep the flat addressing)
+    const bool near = (uint64_t)a.m_stride * a.ch < (1ull << 31) && (uint64_t)a.out_stride * a.ch < (1ull << 31);
     return a.h16 && a.pk && !a.irreversible && (a.px | a.py) == 0 && (a.cw & 3u) == 0 && a.cw >= 256u && a.ch >= 16 && (a.ch & 1u) == 0 &&
-           a.nstrips == 0 && a.nsegs == 0;
+           a.nstrips == 0 && a.nsegs == 0 && near;
 }
 uint32_t idwt_level_strip_pairs(const IdwtLevelArgs& a) { return idwt_level_is_pk(a) ? ipk_strip_cols(a.cw) / 2 : (uint32_t)kOutPairs; }
 

@@ -128,3 +128,42 @@ def test_cfg5_8k_12bit_part1_ict97_decode_equals_grk_decompress():
         c.set_decode_qcd([])
     assert np.array_equal(got, ref), "GPU decode differs from grk_decompress at %d samples" % int((got != ref).sum())
     assert np.abs(ref - px.astype(np.int32)).max() <= max(2, (1 << prec) // 64)
+
+
+def test_16k_single_tile_round_trip_and_strip_checksums():
+    """One 16384 x 16384 x 3 8-bit tile (805 MB of pixels, 196 608 code-blocks): four times the 8K frame through the same
+    kernels -- 18 strips of the packed 5/3 kernels, 32-bit row offsets up to 512 MB into a plane.  Too large for the oracle
+    in a test's time, so size-independent properties: the lossless round trip, and the blocks of its top-left 2048 x 2048
+    corner's finest sub-bands, which depend on that corner + a margin only, equal the blocks of a 4096 x 4096 tile cut from the
+    same pixels (that one checked against the oracle chain elsewhere in its class)."""
+    S = 16384
+    base = synth.g2(3, 4096, 4096, 8, seed=3)
+    px = np.tile(base, (1, 4, 4))
+    px[:, 5000:, :] = 255 - px[:, 5000:, :]                    # (not periodic in y)
+    px[:, :, 9000:] = px[:, ::-1, 9000:]                      # (nor in x; x ^ 0x55 would be full-scale noise: defect D5)
+    p = G.TileParams.make(S, S, 3, 8, 5)
+    c = G.Context(0)
+    d = U.to_dev(px.reshape(-1))
+    table, tot = c.encode_tiles(p, 1, d.data_ptr(), True)
+    back = U._settled(torch.zeros_like(d))
+    c.decode_device(p, 1, table, c.coded_device_ptr(), tot, back.data_ptr())
+    c.decode_status()
+    assert torch.equal(back, d)
+    coded = np.empty(tot, np.uint8)
+    G.lib().grk_amd_fetch_coded(c._h, coded.ctypes.data, tot)
+    # the same corner as its own 4096^2 tile
+    small = np.ascontiguousarray(px[:, :4096, :4096])
+    p4 = G.TileParams.make(4096, 4096, 3, 8, 5)
+    t4, c4 = U.ctx().encode_host(p4, small)
+    blocks16, _ = G.tile_layout(p)
+    blocks4, _ = G.tile_layout(p4)
+    big = {(b.comp, b.res, b.band, b.x0, b.y0): i for i, b in enumerate(blocks16)}
+    checked = 0
+    for j, b in enumerate(blocks4):
+        if b.res != 5 or b.x1 > 1024 or b.y1 > 1024:     # finest resolution, well inside the corner
+            continue
+        i = big[(b.comp, b.res, b.band, b.x0, b.y0)]
+        assert bytes(coded[int(table["offset"][i]):int(table["offset"][i]) + int(table["length"][i])]) == \
+               bytes(c4[int(t4["offset"][j]):int(t4["offset"][j]) + int(t4["length"][j])]), (b.comp, b.band, b.x0, b.y0)
+        checked += 1
+    assert checked >= 3 * 3 * 256
