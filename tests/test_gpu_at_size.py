@@ -167,3 +167,22 @@ def test_16k_single_tile_round_trip_and_strip_checksums():
                bytes(c4[int(t4["offset"][j]):int(t4["offset"][j]) + int(t4["length"][j])]), (b.comp, b.band, b.x0, b.y0)
         checked += 1
     assert checked >= 3 * 3 * 256
+
+
+def test_32k_single_tile_round_trip():
+    """32768 x 32768 x 3 8-bit as ONE tile (3.2 G samples, 786 432 code-blocks, 2 GB per int16 plane -- the largest the packed
+    kernels' 32-bit row offsets reach; larger planes take the flat-addressing kernels): lossless round trip."""
+    S = 32768
+    base = synth.g2(3, 4096, 4096, 8, seed=5)
+    px = np.tile(base, (1, S // 4096, S // 4096))
+    px[:, S // 3:, :] = 255 - px[:, S // 3:, :]
+    p = G.TileParams.make(S, S, 3, 8, 5)
+    c = G.Context(0)
+    d = U.to_dev(px.reshape(-1))
+    del px
+    table, tot = c.encode_tiles(p, 1, d.data_ptr(), True)
+    assert len(table) == 786432 and tot > 0
+    back = U._settled(torch.zeros_like(d))
+    c.decode_device(p, 1, table, c.coded_device_ptr(), tot, back.data_ptr())
+    c.decode_status()
+    assert torch.equal(back, d)
