@@ -7,12 +7,14 @@ TAG=$1; shift
 WHAT="$*"; [ -z "$WHAT" ] && WHAT="stats pmc sq"
 OUT=$R/gpurun_out/prof; mkdir -p $OUT
 if [[ "$WHAT" == *stats* ]]; then
-  # per-kernel durations of the bench command itself: as the timed region runs, and every kernel alone (what the roofline
-  # figures are quoted on); the second run carries the CPU baseline and with it the cfg5 stream
+  # per-kernel durations of the bench command itself: as the timed region runs (with the other workloads: cfg2, cfg3, cfg4tile,
+  # cfg5 -- and the CPU baseline, which writes the cfg5 stream), and every kernel alone (what the roofline figures are quoted on)
   rm -rf /tmp/ks1 /tmp/ks2
-  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/ks1 -o p --output-format csv -- python $R/bench.py --steps 20 --no-cpu-baseline --no-host-boundary > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/ks1.err
+  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/ks1 -o p --output-format csv -- python $R/bench.py --steps 20 --no-host-boundary > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/ks1.err
   cp $(find /tmp/ks1 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
-  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks2 -o p --output-format csv -- python $R/bench.py --steps 20 --no-overlap --no-host-boundary > $OUT/${TAG}_bench_under_rocprof_no_overlap.json 2> /tmp/ks2.err
+  # (the 8K workload only: every ht_encode_kernel launch of this run is the one-launch-of-all-blocks form the roofline is quoted on,
+  #  so the csv's average for that kernel IS roofline.avg_launch_ms of the line beside it)
+  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks2 -o p --output-format csv -- python $R/bench.py --steps 20 --no-overlap --no-host-boundary --no-workloads > $OUT/${TAG}_bench_under_rocprof_no_overlap.json 2> /tmp/ks2.err
   cp $(find /tmp/ks2 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_no_overlap.csv
   tail -n 2 /tmp/ks1.err; tail -n 2 /tmp/ks2.err
 fi
