@@ -483,23 +483,25 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 //    instruction goes into an address;
 //  * latency.  Rows are fetched two steps ahead.
 constexpr int kPkLaneCols = 4;
-constexpr int kPkCols     = kThreads * kPkLaneCols;        // columns staged per line: 1024
+// NT lanes per workgroup: 256 (strips of up to 960 columns), or 128 -- half the footprint (two waves, 12 KiB of LDS with three
+// components), which finds room beside K3's one-wave workgroups far more often (DwtLevelArgs::pk_nt)
 constexpr int kPkHalo     = kPkLaneCols;                   // one lane's worth each side (the stencil needs 2 left, 1 right)
-constexpr int kPkOutCols  = 960;                           // at most: 480 pairs = 15 x 64 bytes of every sub-band row; 240 lanes
-static_assert(kPkOutCols + 2 * kPkHalo <= kPkCols, "strip does not fit the staged line");
-// The strips of a level share its width evenly, in multiples of 64 columns (64 bytes of every sub-band row)
-__host__ __device__ inline uint32_t pk_strip_cols(uint32_t cw)
+// The strips of a level share its width evenly, in multiples of 64 columns (64 bytes of every sub-band row); at most nt - 2
+// lanes of four columns (one halo lane each side): 960 columns for 256 lanes, 448 for 128
+__host__ __device__ inline uint32_t pk_strip_cols(uint32_t cw, uint32_t nt)
 {
-    const uint32_t n = (cw + kPkOutCols - 1) / kPkOutCols;
-    return min((uint32_t)kPkOutCols, ((cw + n - 1) / n + 63u) & ~63u);
+    const uint32_t most = ((nt - 2u) * kPkLaneCols) & ~63u;
+    const uint32_t n = (cw + most - 1) / most;
+    return min(most, ((cw + n - 1) / n + 63u) & ~63u);
 }
 
-template <int NC, int PX>
-__global__ __launch_bounds__(kThreads) void dwt53_pk_kernel(DwtLevelArgs a)
+template <int NC, int PX, int NT>
+__global__ __launch_bounds__(NT) void dwt53_pk_kernel(DwtLevelArgs a)
 {
     static_assert(PX == 0 || PX == 1, "int16 planes or 8-bit pixels");
     static_assert(PX != 0 || NC == 1, "plane input is one component per workgroup");
     __builtin_amdgcn_s_setprio(3);                         // (as dwt_level_kernel: the DWT chain is the critical path)
+    constexpr int kPkCols = NT * kPkLaneCols;                // columns staged per line
     __shared__ __attribute__((aligned(16))) uint32_t line[2][NC][kPkCols];   // [parity][comp][column] = low row | high row << 16
 
     const uint32_t t = threadIdx.x;
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(kThreads) void dwt53_pk_kernel(DwtLevelArgs a)
     }
     const uint32_t cw = a.cw, ch = a.ch;
     const uint32_t sw = cw >> 1, sh = ch >> 1;
-    const uint32_t scols = pk_strip_cols(cw), slanes = scols / kPkLaneCols;     // this level's strip: columns, lanes
+    const uint32_t scols = pk_strip_cols(cw, NT), slanes = scols / kPkLaneCols;     // this level's strip: columns, lanes
 
     uint32_t plane0 = bz;
     if constexpr (PX != 0) plane0 = (bz / a.zdiv) * a.ncomp + a.comp0 + (bz % a.zdiv);
@@ -695,7 +697,10 @@ static bool dwt_level_is_pk(const DwtLevelArgs& a)
     return a.h16 && a.pk && !a.irreversible && (a.px | a.py) == 0 && (a.cw & 3u) == 0 && a.cw >= 256u &&
            a.ch >= 16 && (a.ch & 1u) == 0 && near;
 }
-uint32_t dwt_level_strip_cols(const DwtLevelArgs& a) { return dwt_level_is_pk(a) ? pk_strip_cols(a.cw) : (uint32_t)kOutCols; }
+// 256 lanes for wide levels (8K level 0: 127 us against 138 with 128 lanes), 128 for narrow ones, whose strips would leave half of
+// 256 lanes idle (64 tiles of 1024^2: levels 0-2 238 -> 203 us); DwtLevelArgs::pk_nt overrides
+static uint32_t pk_nt(const DwtLevelArgs& a) { return a.pk_nt == 128 || a.pk_nt == 256 ? (uint32_t)a.pk_nt : (a.cw <= 2048u ? 128u : 256u); }
+uint32_t dwt_level_strip_cols(const DwtLevelArgs& a) { return dwt_level_is_pk(a) ? pk_strip_cols(a.cw, pk_nt(a)) : (uint32_t)kOutCols; }
 
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
 {
@@ -703,8 +708,10 @@ hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
     dim3 grid((a.cw + a.px + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, a.nplanes);
     dim3 block(kThreads);
     if (dwt_level_is_pk(a)) {
-        grid.x = (a.cw + pk_strip_cols(a.cw) - 1) / pk_strip_cols(a.cw);
-        hipLaunchKernelGGL((dwt53_pk_kernel<1, 0>), grid, block, 0, s, a);
+        const uint32_t sc = pk_strip_cols(a.cw, pk_nt(a));
+        grid.x = (a.cw + sc - 1) / sc;
+        if (pk_nt(a) == 128) hipLaunchKernelGGL((dwt53_pk_kernel<1, 0, 128>), grid, dim3(128), 0, s, a);
+        else                 hipLaunchKernelGGL((dwt53_pk_kernel<1, 0, 256>), grid, block, 0, s, a);
         return hipGetLastError();
     }
     if (a.irreversible)
@@ -732,9 +739,15 @@ hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint
             if (nc == 3) { if (px == 1) GRK_L0(true, 3, 1); else GRK_L0(true, 3, 2); }
             else         { if (px == 1) GRK_L0(true, 1, 1); else GRK_L0(true, 1, 2); }
         } else if (px == 1 && dwt_level_is_pk(a)) {
-            grid.x = (a.cw + pk_strip_cols(a.cw) - 1) / pk_strip_cols(a.cw);
-            if (nc == 3) hipLaunchKernelGGL((dwt53_pk_kernel<3, 1>), grid, block, 0, s, a);
-            else         hipLaunchKernelGGL((dwt53_pk_kernel<1, 1>), grid, block, 0, s, a);
+            const uint32_t sc = pk_strip_cols(a.cw, pk_nt(a));
+            grid.x = (a.cw + sc - 1) / sc;
+            if (pk_nt(a) == 128) {
+                if (nc == 3) hipLaunchKernelGGL((dwt53_pk_kernel<3, 1, 128>), grid, dim3(128), 0, s, a);
+                else         hipLaunchKernelGGL((dwt53_pk_kernel<1, 1, 128>), grid, dim3(128), 0, s, a);
+            } else {
+                if (nc == 3) hipLaunchKernelGGL((dwt53_pk_kernel<3, 1, 256>), grid, block, 0, s, a);
+                else         hipLaunchKernelGGL((dwt53_pk_kernel<1, 1, 256>), grid, block, 0, s, a);
+            }
         } else if (a.h16 && px == 1) {       // 16-bit planes exist for 8-bit pixels only (context.hip: planes16_ok)
             if (nc == 3) hipLaunchKernelGGL((dwt_level_kernel<false, 3, 1, true>), grid, block, 0, s, a);
             else         hipLaunchKernelGGL((dwt_level_kernel<false, 1, 1, true>), grid, block, 0, s, a);
