@@ -47,6 +47,62 @@ __device__ const uint32_t g_mq_table[47] = {
 
 constexpr int kCtxZC = 0, kCtxAgg = 17, kCtxUni = 18, kNumCtx = 19;
 
+// Zero-coding contexts (Table D.1) as a look-up by the eight neighbour significance bits: index = row above (x-1, x, x+1) in bits
+// 0-2, left and right neighbour in bits 3-4, row below in bits 5-7; one table per sub-band orientation, 4 bits per entry, eight
+// entries per dword -> 32 dwords that live across the lanes of ONE register (lane i: entries 8 i .. 8 i + 7) and are read with
+// v_readlane like the MQ tables -- the arithmetic form was ~25 scalar instructions of every zero-coding decision's ~110.
+constexpr int zc_context(int orient, uint32_t idx)
+{
+    const uint32_t w0 = idx & 7u, l = (idx >> 3) & 1u, r = (idx >> 4) & 1u, w2 = idx >> 5;
+    int hh = (int)l + (int)r;
+    int vv = (int)((w0 >> 1) & 1u) + (int)((w2 >> 1) & 1u);
+    const int dd = (int)(w0 & 1u) + (int)((w0 >> 2) & 1u) + (int)(w2 & 1u) + (int)((w2 >> 2) & 1u);
+    if (orient == 1) { const int t = hh; hh = vv; vv = t; }
+    if (orient == 3) {
+        const int hv = hh + vv;
+        if (dd >= 3) return 8;
+        if (dd == 2) return hv >= 1 ? 7 : 6;
+        if (dd == 1) return hv >= 2 ? 5 : (hv == 1 ? 4 : 3);
+        return hv >= 2 ? 2 : hv;
+    }
+    if (hh == 2) return 8;
+    if (hh == 1) return vv >= 1 ? 7 : (dd >= 1 ? 6 : 5);
+    if (vv == 2) return 4;
+    if (vv == 1) return 3;
+    return dd >= 2 ? 2 : dd;
+}
+struct ZcLut {
+    uint32_t w[4][32];
+    constexpr ZcLut() : w{}
+    {
+        for (int o = 0; o < 4; ++o)
+            for (uint32_t i = 0; i < 256; ++i) w[o][i >> 3] |= (uint32_t)zc_context(o, i) << (4 * (i & 7u));
+    }
+};
+__device__ const ZcLut g_zc_lut{};
+// Sign-coding context and XOR bit (Table D.3) by the significance and sign of the four horizontal / vertical neighbours: index =
+// significant (left, right, up, down) in bits 0-3, negative (same order) in bits 4-7; entry = context | xor << 4, one byte each,
+// 64 dwords across the lanes of one register.
+constexpr uint32_t sign_context(uint32_t idx)
+{
+    auto contrib = [&](int k) { return ((idx >> k) & 1u) ? (((idx >> (k + 4)) & 1u) ? -1 : 1) : 0; };
+    int hc = contrib(0) + contrib(1), vc = contrib(2) + contrib(3);
+    hc = hc > 1 ? 1 : (hc < -1 ? -1 : hc); vc = vc > 1 ? 1 : (vc < -1 ? -1 : vc);
+    int cxn = 0, xr = 0;
+    if (hc == 1)      { cxn = vc == 1 ? 13 : (vc == 0 ? 12 : 11); xr = 0; }
+    else if (hc == 0) { cxn = vc == 0 ? 9 : 10; xr = vc == -1; }
+    else              { cxn = vc == 1 ? 11 : (vc == 0 ? 12 : 13); xr = 1; }
+    return (uint32_t)cxn | ((uint32_t)xr << 4);
+}
+struct SignLut {
+    uint32_t w[64];
+    constexpr SignLut() : w{}
+    {
+        for (uint32_t i = 0; i < 256; ++i) w[i >> 2] |= sign_context(i) << (8 * (i & 3u));
+    }
+};
+__device__ const SignLut g_sign_lut{};
+
 // One block per wave: everything the decoder touches is wave-uniform, so the compiler keeps it on the scalar unit, and
 // the two lookups on every decision's dependency chain -- context state and Table C.2 -- come out of VGPRs whose LANE i
 // holds entry i (v_readlane / v_writelane with a scalar index: a few cycles) instead of LDS (> 100).
@@ -169,6 +225,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t orient = bd.pad;                        // 0 LL, 1 HL, 2 LH, 3 HH
+    const uint32_t zcv = g_zc_lut.w[orient & 3u][threadIdx.x & 31u];           // this orientation's zero-coding contexts across the lanes
+    const uint32_t sgv = g_sign_lut.w[threadIdx.x & 63u];                      // sign-coding contexts
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
     // value workspace of the block, [y * 64 + x] (the first pass writes every row, K8b zeroes absent blocks)
     int32_t* ws = a.work + (size_t)blockIdx.x * 4096u;
@@ -236,35 +294,18 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 const uint32_t ws1 = win3(S[(j) + 1], x), wn1 = win3(N[(j) + 1], x);                              \
                 const uint32_t su = (uint32_t)(S[(j)] >> (x)) & 1u, nu = (uint32_t)(N[(j)] >> (x)) & 1u;          \
                 const uint32_t sd = (uint32_t)(S[(j) + 2] >> (x)) & 1u, nd = (uint32_t)(N[(j) + 2] >> (x)) & 1u;  \
-                int hc = (int)((ws1 & 1u) ? ((wn1 & 1u) ? -1 : 1) : 0) + (int)((ws1 & 4u) ? ((wn1 & 4u) ? -1 : 1) : 0); \
-                int vc = (int)(su ? (nu ? -1 : 1) : 0) + (int)(sd ? (nd ? -1 : 1) : 0);                           \
-                hc = max(-1, min(1, hc)); vc = max(-1, min(1, vc));                                               \
-                int cxn, xr;                                                                                      \
-                if (hc == 1)      { cxn = vc == 1 ? 13 : (vc == 0 ? 12 : 11); xr = 0; }                            \
-                else if (hc == 0) { cxn = vc == 0 ? 9 : 10; xr = vc == -1; }                                      \
-                else              { cxn = vc == 1 ? 11 : (vc == 0 ? 12 : 13); xr = 1; }                            \
+                const uint32_t sidx = (ws1 & 1u) | ((ws1 >> 1) & 2u) | (su << 2) | (sd << 3) |                     \
+                                      ((wn1 & 1u) << 4) | ((wn1 & 4u) << 3) | (nu << 6) | (nd << 7);                \
+                const uint32_t se = ((uint32_t)__builtin_amdgcn_readlane((int)sgv, (int)(sidx >> 2)) >> (8u * (sidx & 3u))) & 0xFFu; \
+                const int cxn = (int)(se & 0xFu), xr = (int)(se >> 4);                                             \
                 const uint32_t ng = raw ? mq.raw_decode() : (mq.decode(cxn) ^ (uint32_t)xr);                      \
                 { const int32_t sm = -(int32_t)ng; V[(j)] = tl == (x) ? (oph ^ sm) - sm : V[(j)]; }                \
                 S[(j) + 1] |= 1ull << (x);                                                                        \
                 if (ng) N[(j) + 1] |= 1ull << (x);                                                                \
             }
-            auto zc_ctx = [&](uint32_t w0, uint32_t w1, uint32_t w2) -> int {       // Table D.1
-                int hh = (int)(w1 & 1u) + (int)((w1 >> 2) & 1u);
-                int vv = (int)((w0 >> 1) & 1u) + (int)((w2 >> 1) & 1u);
-                const int dd = (int)(w0 & 1u) + (int)((w0 >> 2) & 1u) + (int)(w2 & 1u) + (int)((w2 >> 2) & 1u);
-                if (orient == 1) { const int t = hh; hh = vv; vv = t; }
-                if (orient == 3) {
-                    const int hv = hh + vv;
-                    if (dd >= 3) return 8;
-                    if (dd == 2) return hv >= 1 ? 7 : 6;
-                    if (dd == 1) return hv >= 2 ? 5 : (hv == 1 ? 4 : 3);
-                    return hv >= 2 ? 2 : hv;
-                }
-                if (hh == 2) return 8;
-                if (hh == 1) return vv >= 1 ? 7 : (dd >= 1 ? 6 : 5);
-                if (vv == 2) return 4;
-                if (vv == 1) return 3;
-                return dd >= 2 ? 2 : dd;
+            auto zc_ctx = [&](uint32_t w0, uint32_t w1, uint32_t w2) -> int {       // Table D.1, looked up (zc_context above)
+                const uint32_t idx = w0 | ((w1 & 1u) << 3) | ((w1 & 4u) << 2) | (w2 << 5);
+                return (int)(((uint32_t)__builtin_amdgcn_readlane((int)zcv, (int)(idx >> 3)) >> (4u * (idx & 7u))) & 0xFu);
             };
 
             if (type == 0) {                                           // significance propagation (T1.cpp:1024-1152)
