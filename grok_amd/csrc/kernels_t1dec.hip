@@ -71,22 +71,28 @@ constexpr int zc_context(int orient, uint32_t idx)
     if (vv == 1) return 3;
     return dd >= 2 ? 2 : dd;
 }
+// ... indexed by the NINE bits of a sample's 3 x 3 neighbourhood as they lie in a column's neighbourhood word (row above in bits
+// 0-2, own row in 3-5 -- the centre bit does not matter --, row below in 6-8): 512 entries of 4 bits, 64 dwords, one per lane
 struct ZcLut {
-    uint32_t w[4][32];
+    uint32_t w[4][64];
     constexpr ZcLut() : w{}
     {
         for (int o = 0; o < 4; ++o)
-            for (uint32_t i = 0; i < 256; ++i) w[o][i >> 3] |= (uint32_t)zc_context(o, i) << (4 * (i & 7u));
+            for (uint32_t i = 0; i < 512; ++i) {
+                const uint32_t w0 = i & 7u, w1 = (i >> 3) & 7u, w2 = i >> 6;
+                w[o][i >> 3] |= (uint32_t)zc_context(o, w0 | ((w1 & 1u) << 3) | ((w1 & 4u) << 2) | (w2 << 5)) << (4 * (i & 7u));
+            }
     }
 };
 __device__ const ZcLut g_zc_lut{};
-// Sign-coding context and XOR bit (Table D.3) by the significance and sign of the four horizontal / vertical neighbours: index =
-// significant (left, right, up, down) in bits 0-3, negative (same order) in bits 4-7; entry = context | xor << 4, one byte each,
-// 64 dwords across the lanes of one register.
+// Sign-coding context and XOR bit (Table D.3) by the significance and sign of the four horizontal / vertical neighbours.  The index
+// takes the bits as they lie in the neighbourhood words: significant (up, left, right, down) in bits 0, 2, 4, 6 -- bits 1, 3, 5, 7
+// of a 3 x 3 window shifted down by one --, negative in the bit above each; entry = context | xor << 4, one byte each, 64 dwords
+// across the lanes of one register.
 constexpr uint32_t sign_context(uint32_t idx)
 {
-    auto contrib = [&](int k) { return ((idx >> k) & 1u) ? (((idx >> (k + 4)) & 1u) ? -1 : 1) : 0; };
-    int hc = contrib(0) + contrib(1), vc = contrib(2) + contrib(3);
+    auto contrib = [&](int k) { return ((idx >> (2 * k)) & 1u) ? (((idx >> (2 * k + 1)) & 1u) ? -1 : 1) : 0; };
+    int hc = contrib(1) + contrib(2), vc = contrib(0) + contrib(3);
     hc = hc > 1 ? 1 : (hc < -1 ? -1 : hc); vc = vc > 1 ? 1 : (vc < -1 ? -1 : vc);
     int cxn = 0, xr = 0;
     if (hc == 1)      { cxn = vc == 1 ? 13 : (vc == 0 ? 12 : 11); xr = 0; }
@@ -225,7 +231,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t orient = bd.pad;                        // 0 LL, 1 HL, 2 LH, 3 HH
-    const uint32_t zcv = g_zc_lut.w[orient & 3u][threadIdx.x & 31u];           // this orientation's zero-coding contexts across the lanes
+    const uint32_t zcv = g_zc_lut.w[orient & 3u][threadIdx.x & 63u];           // this orientation's zero-coding contexts across the lanes
     const uint32_t sgv = g_sign_lut.w[threadIdx.x & 63u];                      // sign-coding contexts
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
     // value workspace of the block, [y * 64 + x] (the first pass writes every row, K8b zeroes absent blocks)
@@ -275,6 +281,16 @@ __global__ void t1_dec_kernel(T1DecArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { P[j] = pi[k + 1 + j]; M[j] = mu[k + 1 + j]; }
             if (vsc) { S[5] = 0; N[5] = 0; }       // vertically causal: a stripe never sees the one below (T1.cpp:198-221)
+            // LANE x keeps column x's significance neighbourhood: bit 3 r + c = column x - 1 + c of row S[r] (r = 0: the row above
+            // the stripe ... 5: the row below).  One v_readlane per column then gives every window of the column -- the scalar unit,
+            // the scarce one here, would spend three 64-bit shifts with a select per SAMPLE on them -- and the vector unit keeps the
+            // three lanes around a sample that turns significant up to date.
+            uint32_t nbv = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) nbv |= ((uint32_t)(tl ? (S[r] >> (tl - 1u)) : (S[r] << 1)) & 7u) << (3 * r);
+            uint32_t nnv = 0;                  // the same for the signs (bit set: negative)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) nnv |= ((uint32_t)(tl ? (N[r] >> (tl - 1u)) : (N[r] << 1)) & 7u) << (3 * r);
             const uint32_t nr = min(4u, h - k);
             // the stripe's decoded values live in registers, lane <-> column: one coalesced row load at the start (not
             // in the first pass) and one coalesced row store at the end instead of a store / an atomic per sample
@@ -291,21 +307,20 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             // per-sample pieces (j is a compile-time constant after unrolling)
 #define T1_SIGN_AND_SET(j, x)                                                                                     \
             {                                                                                                     \
-                const uint32_t ws1 = win3(S[(j) + 1], x), wn1 = win3(N[(j) + 1], x);                              \
-                const uint32_t su = (uint32_t)(S[(j)] >> (x)) & 1u, nu = (uint32_t)(N[(j)] >> (x)) & 1u;          \
-                const uint32_t sd = (uint32_t)(S[(j) + 2] >> (x)) & 1u, nd = (uint32_t)(N[(j) + 2] >> (x)) & 1u;  \
-                const uint32_t sidx = (ws1 & 1u) | ((ws1 >> 1) & 2u) | (su << 2) | (sd << 3) |                     \
-                                      ((wn1 & 1u) << 4) | ((wn1 & 4u) << 3) | (nu << 6) | (nd << 7);                \
+                const uint32_t sidx = (((nbx >> (3 * (j))) & 0xAAu) >> 1) | ((nnx >> (3 * (j))) & 0xAAu);           \
                 const uint32_t se = ((uint32_t)__builtin_amdgcn_readlane((int)sgv, (int)(sidx >> 2)) >> (8u * (sidx & 3u))) & 0xFFu; \
                 const int cxn = (int)(se & 0xFu), xr = (int)(se >> 4);                                             \
                 const uint32_t ng = raw ? mq.raw_decode() : (mq.decode(cxn) ^ (uint32_t)xr);                      \
                 { const int32_t sm = -(int32_t)ng; V[(j)] = tl == (x) ? (oph ^ sm) - sm : V[(j)]; }                \
                 S[(j) + 1] |= 1ull << (x);                                                                        \
                 if (ng) N[(j) + 1] |= 1ull << (x);                                                                \
+                nbx |= 1u << (3 * ((j) + 1) + 1);                                                                 \
+                nnx |= ng << (3 * ((j) + 1) + 1);                                                                 \
+                { const uint32_t dl = tl - (x) + 1u, pat = dl < 3u ? (4u << (3 * ((j) + 1))) >> dl : 0u;           \
+                  nbv |= pat; nnv |= ng ? pat : 0u; }                                                             \
             }
-            auto zc_ctx = [&](uint32_t w0, uint32_t w1, uint32_t w2) -> int {       // Table D.1, looked up (zc_context above)
-                const uint32_t idx = w0 | ((w1 & 1u) << 3) | ((w1 & 4u) << 2) | (w2 << 5);
-                return (int)(((uint32_t)__builtin_amdgcn_readlane((int)zcv, (int)(idx >> 3)) >> (4u * (idx & 7u))) & 0xFu);
+            auto zc_ctx9 = [&](uint32_t nine) -> int {             // Table D.1, looked up (zc_context above)
+                return (int)(((uint32_t)__builtin_amdgcn_readlane((int)zcv, (int)(nine >> 3)) >> (4u * (nine & 7u))) & 0xFu);
             };
 
             if (type == 0) {                                           // significance propagation (T1.cpp:1024-1152)
@@ -318,12 +333,14 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                     cm &= ~0ull << x;
                     if (!cm) break;
                     x = (uint32_t)__ffsll((long long)cm) - 1u;
+                    uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (!((rowok[j] >> x) & 1ull) || (((S[j + 1] | P[j]) >> x) & 1ull)) continue;
-                        const uint32_t w0 = win3(S[j], x), w1 = win3(S[j + 1], x), w2 = win3(S[j + 2], x);
-                        if (!((w0 | w2) | (w1 & 5u))) continue;
-                        if (raw ? mq.raw_decode() : mq.decode(kCtxZC + zc_ctx(w0, w1, w2))) T1_SIGN_AND_SET(j, x)
+                        // (the candidate mask only has columns < w; rows past the block's last are the ones to leave out)
+                        if ((uint32_t)j >= nr || ((((uint32_t)(P[j] >> x)) | (nbx >> (3 * j + 4))) & 1u)) continue;
+                        const uint32_t nine = (nbx >> (3 * j)) & 0x1FFu;
+                        if (!(nine & 0x1EFu)) continue;                         // no significant neighbour
+                        if (raw ? mq.raw_decode() : mq.decode(kCtxZC + zc_ctx9(nine))) T1_SIGN_AND_SET(j, x)
                         P[j] |= 1ull << x;
                     }
                     ++x;
@@ -335,11 +352,11 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 while (cm) {
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
+                    const uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (!((S[j + 1] & ~P[j] & rowok[j]) >> x & 1ull)) continue;
-                        const uint32_t w0 = win3(S[j], x), w1 = win3(S[j + 1], x), w2 = win3(S[j + 2], x);
-                        const int cxn = ((M[j] >> x) & 1ull) ? 16 : (((w0 | w2) | (w1 & 5u)) ? 15 : 14);    // Table D.4
+                        const int cxn = ((M[j] >> x) & 1ull) ? 16 : (((nbx >> (3 * j)) & 0x1EFu) ? 15 : 14);    // Table D.4
                         const uint32_t b = raw ? mq.raw_decode() : mq.decode(cxn);
                         const uint32_t isneg = (uint32_t)(N[j + 1] >> x) & 1u;   // the value's sign, without reading it back
                         const int32_t dm = (int32_t)(b ^ isneg) - 1, dv = (poshalf ^ dm) - dm;     // +half | -half
@@ -355,6 +372,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
                     uint32_t first = 0;                                // first row still to be coded normally
+                    uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
                     if (nr == 4) {                                     // run-length mode: whole column quiet (D.3.4)
                         uint64_t busy = 0;
 #pragma unroll
@@ -371,9 +389,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if ((uint32_t)j < first || !((rowok[j] >> x) & 1ull) || (((S[j + 1] | P[j]) >> x) & 1ull)) continue;
-                        const uint32_t w0 = win3(S[j], x), w1 = win3(S[j + 1], x), w2 = win3(S[j + 2], x);
-                        if (mq.decode(kCtxZC + zc_ctx(w0, w1, w2))) T1_SIGN_AND_SET(j, x)
+                        if ((uint32_t)j < first || (uint32_t)j >= nr || ((((uint32_t)(P[j] >> x)) | (nbx >> (3 * j + 4))) & 1u)) continue;
+                        if (mq.decode(kCtxZC + zc_ctx9((nbx >> (3 * j)) & 0x1FFu))) T1_SIGN_AND_SET(j, x)
                     }
                 }
 #pragma unroll
