@@ -352,13 +352,13 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 while (cm) {
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
-                    const uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x);
+                    const uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (!((S[j + 1] & ~P[j] & rowok[j]) >> x & 1ull)) continue;
+                        if ((uint32_t)j >= nr || !((nbx >> (3 * j + 4)) & ~(uint32_t)(P[j] >> x) & 1u)) continue;
                         const int cxn = ((M[j] >> x) & 1ull) ? 16 : (((nbx >> (3 * j)) & 0x1EFu) ? 15 : 14);    // Table D.4
                         const uint32_t b = raw ? mq.raw_decode() : mq.decode(cxn);
-                        const uint32_t isneg = (uint32_t)(N[j + 1] >> x) & 1u;   // the value's sign, without reading it back
+                        const uint32_t isneg = (nnx >> (3 * j + 4)) & 1u;        // the value's sign, without reading it back
                         const int32_t dm = (int32_t)(b ^ isneg) - 1, dv = (poshalf ^ dm) - dm;     // +half | -half
                         V[j] += tl == x ? dv : 0;
                         M[j] |= 1ull << x;
