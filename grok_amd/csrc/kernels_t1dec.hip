@@ -300,9 +300,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) V[j] = ws[(k + j) * 64u + tl];
             }
             // rows of the stripe that do not exist behave as "already coded"
-            uint64_t rowok[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rowok[j] = (uint32_t)j < nr ? wmask : 0ull;
+            for (int j = 0; j < 4; ++j) if ((uint32_t)j >= nr) P[j] = ~0ull;          // ("visited": never a candidate in any pass)
 
             // per-sample pieces (j is a compile-time constant after unrolling)
 #define T1_SIGN_AND_SET(j, x)                                                                                     \
@@ -329,15 +328,15 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                     uint64_t cm = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        cm |= ~(S[j + 1] | P[j]) & (dil(S[j]) | dil(S[j + 2]) | (S[j + 1] << 1) | (S[j + 1] >> 1)) & rowok[j];
-                    cm &= ~0ull << x;
+                        cm |= ~(S[j + 1] | P[j]) & (dil(S[j]) | dil(S[j + 2]) | (S[j + 1] << 1) | (S[j + 1] >> 1));
+                    cm &= wmask & (~0ull << x);
                     if (!cm) break;
                     x = (uint32_t)__ffsll((long long)cm) - 1u;
                     uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // (the candidate mask only has columns < w; rows past the block's last are the ones to leave out)
-                        if ((uint32_t)j >= nr || ((((uint32_t)(P[j] >> x)) | (nbx >> (3 * j + 4))) & 1u)) continue;
+                        if ((((uint32_t)(P[j] >> x)) | (nbx >> (3 * j + 4))) & 1u) continue;
                         const uint32_t nine = (nbx >> (3 * j)) & 0x1FFu;
                         if (!(nine & 0x1EFu)) continue;                         // no significant neighbour
                         if (raw ? mq.raw_decode() : mq.decode(kCtxZC + zc_ctx9(nine))) T1_SIGN_AND_SET(j, x)
@@ -348,14 +347,15 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             } else if (type == 1) {                                    // magnitude refinement (T1.cpp:1160-1255)
                 uint64_t cm = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cm |= S[j + 1] & ~P[j] & rowok[j];
+                for (int j = 0; j < 4; ++j) cm |= S[j + 1] & ~P[j];
+                cm &= wmask;
                 while (cm) {
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
                     const uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if ((uint32_t)j >= nr || !((nbx >> (3 * j + 4)) & ~(uint32_t)(P[j] >> x) & 1u)) continue;
+                        if (!((nbx >> (3 * j + 4)) & ~(uint32_t)(P[j] >> x) & 1u)) continue;
                         const int cxn = ((M[j] >> x) & 1ull) ? 16 : (((nbx >> (3 * j)) & 0x1EFu) ? 15 : 14);    // Table D.4
                         const uint32_t b = raw ? mq.raw_decode() : mq.decode(cxn);
                         const uint32_t isneg = (nnx >> (3 * j + 4)) & 1u;        // the value's sign, without reading it back
@@ -367,7 +367,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             } else {                                                   // cleanup (T1.cpp:854-1007)
                 uint64_t cm = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cm |= ~(S[j + 1] | P[j]) & rowok[j];
+                for (int j = 0; j < 4; ++j) cm |= ~(S[j + 1] | P[j]);
+                cm &= wmask;
                 while (cm) {
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
@@ -389,7 +390,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if ((uint32_t)j < first || (uint32_t)j >= nr || ((((uint32_t)(P[j] >> x)) | (nbx >> (3 * j + 4))) & 1u)) continue;
+                        if ((uint32_t)j < first || ((((uint32_t)(P[j] >> x)) | (nbx >> (3 * j + 4))) & 1u)) continue;
                         if (mq.decode(kCtxZC + zc_ctx9((nbx >> (3 * j)) & 0x1FFu))) T1_SIGN_AND_SET(j, x)
                     }
                 }
