@@ -275,12 +275,12 @@ __global__ void t1_dec_kernel(T1DecArgs a)
         const bool raw = raw_seg && type < 2;
         const int32_t one = 1 << bp, oph = one | (one >> 1), poshalf = one >> 1;
         for (uint32_t k = 0; k < h; k += 4) {
-            uint64_t S[6], N[6], P[4], M[4];
+            uint64_t S[6], P[4], M[4];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { S[j] = sig[k + j]; N[j] = neg[k + j]; }
+            for (int j = 0; j < 6; ++j) S[j] = sig[k + j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { P[j] = pi[k + 1 + j]; M[j] = mu[k + 1 + j]; }
-            if (vsc) { S[5] = 0; N[5] = 0; }       // vertically causal: a stripe never sees the one below (T1.cpp:198-221)
+            if (vsc) S[5] = 0;                     // vertically causal: a stripe never sees the one below (T1.cpp:198-221)
             // LANE x keeps column x's significance neighbourhood: bit 3 r + c = column x - 1 + c of row S[r] (r = 0: the row above
             // the stripe ... 5: the row below).  One v_readlane per column then gives every window of the column -- the scalar unit,
             // the scarce one here, would spend three 64-bit shifts with a select per SAMPLE on them -- and the vector unit keeps the
@@ -288,9 +288,14 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             uint32_t nbv = 0;
 #pragma unroll
             for (int r = 0; r < 6; ++r) nbv |= ((uint32_t)(tl ? (S[r] >> (tl - 1u)) : (S[r] << 1)) & 7u) << (3 * r);
-            uint32_t nnv = 0;                  // the same for the signs (bit set: negative)
+            // the same for the signs (bit set: negative).  The sign rows are only read here: they stay in LDS, where lane 0 sets the
+            // bit of a sample that turns out negative (one wave: its LDS operations keep their order, so the next stripe reads it)
+            uint32_t nnv = 0;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) nnv |= ((uint32_t)(tl ? (N[r] >> (tl - 1u)) : (N[r] << 1)) & 7u) << (3 * r);
+            for (int r = 0; r < 6; ++r) {
+                const uint64_t nr6 = (vsc && r == 5) ? 0ull : neg[k + r];
+                nnv |= ((uint32_t)(tl ? (nr6 >> (tl - 1u)) : (nr6 << 1)) & 7u) << (3 * r);
+            }
             const uint32_t nr = min(4u, h - k);
             // the stripe's decoded values live in registers, lane <-> column: one coalesced row load at the start (not
             // in the first pass) and one coalesced row store at the end instead of a store / an atomic per sample
@@ -312,7 +317,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 const uint32_t ng = raw ? mq.raw_decode() : (mq.decode(cxn) ^ (uint32_t)xr);                      \
                 { const int32_t sm = -(int32_t)ng; V[(j)] = tl == (x) ? (oph ^ sm) - sm : V[(j)]; }                \
                 S[(j) + 1] |= 1ull << (x);                                                                        \
-                if (ng) N[(j) + 1] |= 1ull << (x);                                                                \
+                if (ng && writer) neg[k + 1 + (j)] |= 1ull << (x);                                                \
                 nbx |= 1u << (3 * ((j) + 1) + 1);                                                                 \
                 nnx |= ng << (3 * ((j) + 1) + 1);                                                                 \
                 { const uint32_t dl = tl - (x) + 1u, pat = dl < 3u ? (4u << (3 * ((j) + 1))) >> dl : 0u;           \
@@ -402,7 +407,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws[(k + j) * 64u + tl] = V[j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (writer) { sig[k + 1 + j] = S[j + 1]; neg[k + 1 + j] = N[j + 1]; pi[k + 1 + j] = P[j]; mu[k + 1 + j] = M[j]; }
+                if (writer) { sig[k + 1 + j] = S[j + 1]; pi[k + 1 + j] = P[j]; mu[k + 1 + j] = M[j]; }
             }
         }
         if (type == 2 && segsym)                               // dec_clnpass_check_segsym (:977-993): 0xA expected, only warned about
