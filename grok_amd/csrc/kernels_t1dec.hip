@@ -275,11 +275,11 @@ __global__ void t1_dec_kernel(T1DecArgs a)
         const bool raw = raw_seg && type < 2;
         const int32_t one = 1 << bp, oph = one | (one >> 1), poshalf = one >> 1;
         for (uint32_t k = 0; k < h; k += 4) {
-            uint64_t S[6], P[4], M[4];
+            uint64_t S[6], P[4];
 #pragma unroll
             for (int j = 0; j < 6; ++j) S[j] = sig[k + j];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { P[j] = pi[k + 1 + j]; M[j] = mu[k + 1 + j]; }
+            for (int j = 0; j < 4; ++j) P[j] = pi[k + 1 + j];
             if (vsc) S[5] = 0;                     // vertically causal: a stripe never sees the one below (T1.cpp:198-221)
             // LANE x keeps column x's significance neighbourhood: bit 3 r + c = column x - 1 + c of row S[r] (r = 0: the row above
             // the stripe ... 5: the row below).  One v_readlane per column then gives every window of the column -- the scalar unit,
@@ -350,6 +350,10 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                     ++x;
                 }
             } else if (type == 1) {                                    // magnitude refinement (T1.cpp:1160-1255)
+                // "refined before" (Table D.4) is this pass's own state: its rows stay in LDS, lane x holds column x's four bits
+                uint32_t mv = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mv |= ((uint32_t)(mu[k + 1 + j] >> tl) & 1u) << j;
                 uint64_t cm = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cm |= S[j + 1] & ~P[j];
@@ -358,16 +362,22 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
                     const uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
+                    const uint32_t mvx = (uint32_t)__builtin_amdgcn_readlane((int)mv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (!((nbx >> (3 * j + 4)) & ~(uint32_t)(P[j] >> x) & 1u)) continue;
-                        const int cxn = ((M[j] >> x) & 1ull) ? 16 : (((nbx >> (3 * j)) & 0x1EFu) ? 15 : 14);    // Table D.4
+                        const int cxn = ((mvx >> j) & 1u) ? 16 : (((nbx >> (3 * j)) & 0x1EFu) ? 15 : 14);    // Table D.4
                         const uint32_t b = raw ? mq.raw_decode() : mq.decode(cxn);
                         const uint32_t isneg = (nnx >> (3 * j + 4)) & 1u;        // the value's sign, without reading it back
                         const int32_t dm = (int32_t)(b ^ isneg) - 1, dv = (poshalf ^ dm) - dm;     // +half | -half
                         V[j] += tl == x ? dv : 0;
-                        M[j] |= 1ull << x;
+                        mv |= tl == x ? 1u << j : 0u;
                     }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                          // the rows back to LDS: one ballot each
+                    const uint64_t row = __builtin_amdgcn_ballot_w64(((mv >> j) & 1u) != 0);
+                    if (writer) mu[k + 1 + j] = row;
                 }
             } else {                                                   // cleanup (T1.cpp:854-1007)
                 uint64_t cm = 0;
@@ -407,7 +417,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws[(k + j) * 64u + tl] = V[j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (writer) { sig[k + 1 + j] = S[j + 1]; pi[k + 1 + j] = P[j]; mu[k + 1 + j] = M[j]; }
+                if (writer) { sig[k + 1 + j] = S[j + 1]; pi[k + 1 + j] = P[j]; }
             }
         }
         if (type == 2 && segsym)                               // dec_clnpass_check_segsym (:977-993): 0xA expected, only warned about
