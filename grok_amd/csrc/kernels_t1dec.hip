@@ -384,17 +384,15 @@ __global__ void t1_dec_kernel(T1DecArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cm |= ~(S[j + 1] | P[j]);
                 cm &= wmask;
+                const uint64_t pany = P[0] | P[1] | P[2] | P[3];    // columns with a sample the earlier passes of this plane coded
                 while (cm) {
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
                     uint32_t first = 0;                                // first row still to be coded normally
                     uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
-                    if (nr == 4) {                                     // run-length mode: whole column quiet (D.3.4)
-                        uint64_t busy = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            busy |= S[j + 1] | P[j] | dil(S[j]) | dil(S[j + 2]) | (S[j + 1] << 1) | (S[j + 1] >> 1);
-                        if (!((busy >> x) & 1ull)) {
+                    if (nr == 4) {                                     // run-length mode: whole column quiet (D.3.4) --
+                        // nothing significant in the column's 3 x 6 neighbourhood (the lane's word is exactly that) and none coded
+                        if (nbx == 0 && !((uint32_t)(pany >> x) & 1u)) {
                             if (!mq.decode(kCtxAgg)) continue;
                             uint32_t r = mq.decode(kCtxUni);
                             r = (r << 1) | mq.decode(kCtxUni);
