@@ -330,11 +330,14 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             if (type == 0) {                                           // significance propagation (T1.cpp:1024-1152)
                 uint32_t x = 0;
                 while (x < w) {
-                    uint64_t cm = 0;
+                    // candidate columns -- an uncoded, insignificant sample with a significant neighbour -- from the lanes' words
+                    uint32_t cand = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        cm |= ~(S[j + 1] | P[j]) & (dil(S[j]) | dil(S[j + 2]) | (S[j + 1] << 1) | (S[j + 1] >> 1));
-                    cm &= wmask & (~0ull << x);
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t t9 = nbv >> (3 * j);
+                        cand |= ((t9 & 0x1EFu) != 0u ? 1u : 0u) & ~((t9 >> 4) | (uint32_t)(P[j] >> tl));
+                    }
+                    uint64_t cm = __builtin_amdgcn_ballot_w64((cand & 1u) != 0) & wmask & (~0ull << x);
                     if (!cm) break;
                     x = (uint32_t)__ffsll((long long)cm) - 1u;
                     uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
