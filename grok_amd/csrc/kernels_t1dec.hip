@@ -260,7 +260,6 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     //      significance / sign rows of stripe row j (S[0], S[5]: the rows above and below), P[j] / M[j] its
     //      visited / refined rows.  Columns that cannot code anything are skipped with a candidate mask.
     const uint64_t wmask = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
-    auto dil = [](uint64_t v) { return v | (v << 1) | (v >> 1); };
 
     int bp = (int)numbps, type = 2;
     bool first_pass = true;                                 // nothing in the workspace yet
@@ -275,19 +274,19 @@ __global__ void t1_dec_kernel(T1DecArgs a)
         const bool raw = raw_seg && type < 2;
         const int32_t one = 1 << bp, oph = one | (one >> 1), poshalf = one >> 1;
         for (uint32_t k = 0; k < h; k += 4) {
-            uint64_t S[6], P[4];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) S[j] = sig[k + j];
+            uint64_t P[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) P[j] = pi[k + 1 + j];
-            if (vsc) S[5] = 0;                     // vertically causal: a stripe never sees the one below (T1.cpp:198-221)
             // LANE x keeps column x's significance neighbourhood: bit 3 r + c = column x - 1 + c of row S[r] (r = 0: the row above
             // the stripe ... 5: the row below).  One v_readlane per column then gives every window of the column -- the scalar unit,
             // the scarce one here, would spend three 64-bit shifts with a select per SAMPLE on them -- and the vector unit keeps the
             // three lanes around a sample that turns significant up to date.
             uint32_t nbv = 0;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) nbv |= ((uint32_t)(tl ? (S[r] >> (tl - 1u)) : (S[r] << 1)) & 7u) << (3 * r);
+            for (int r = 0; r < 6; ++r) {          // (vertically causal: a stripe never sees the one below, T1.cpp:198-221)
+                const uint64_t sr6 = (vsc && r == 5) ? 0ull : sig[k + r];
+                nbv |= ((uint32_t)(tl ? (sr6 >> (tl - 1u)) : (sr6 << 1)) & 7u) << (3 * r);
+            }
             // the same for the signs (bit set: negative).  The sign rows are only read here: they stay in LDS, where lane 0 sets the
             // bit of a sample that turns out negative (one wave: its LDS operations keep their order, so the next stripe reads it)
             uint32_t nnv = 0;
@@ -316,7 +315,6 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 const int cxn = (int)(se & 0xFu), xr = (int)(se >> 4);                                             \
                 const uint32_t ng = raw ? mq.raw_decode() : (mq.decode(cxn) ^ (uint32_t)xr);                      \
                 { const int32_t sm = -(int32_t)ng; V[(j)] = tl == (x) ? (oph ^ sm) - sm : V[(j)]; }                \
-                S[(j) + 1] |= 1ull << (x);                                                                        \
                 if (ng && writer) neg[k + 1 + (j)] |= 1ull << (x);                                                \
                 nbx |= 1u << (3 * ((j) + 1) + 1);                                                                 \
                 nnx |= ng << (3 * ((j) + 1) + 1);                                                                 \
@@ -359,7 +357,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 for (int j = 0; j < 4; ++j) mv |= ((uint32_t)(mu[k + 1 + j] >> tl) & 1u) << j;
                 uint64_t cm = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cm |= S[j + 1] & ~P[j];
+                for (int j = 0; j < 4; ++j) cm |= __builtin_amdgcn_ballot_w64((((nbv >> (3 * j + 4)) & ~(uint32_t)(P[j] >> tl)) & 1u) != 0);
                 cm &= wmask;
                 while (cm) {
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
@@ -385,7 +383,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             } else {                                                   // cleanup (T1.cpp:854-1007)
                 uint64_t cm = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cm |= ~(S[j + 1] | P[j]);
+                for (int j = 0; j < 4; ++j) cm |= __builtin_amdgcn_ballot_w64(((~((nbv >> (3 * j + 4)) | (uint32_t)(P[j] >> tl))) & 1u) != 0);
                 cm &= wmask;
                 const uint64_t pany = P[0] | P[1] | P[2] | P[3];    // columns with a sample the earlier passes of this plane coded
                 while (cm) {
@@ -418,7 +416,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws[(k + j) * 64u + tl] = V[j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (writer) { sig[k + 1 + j] = S[j + 1]; pi[k + 1 + j] = P[j]; }
+                const uint64_t srow = __builtin_amdgcn_ballot_w64(((nbv >> (3 * j + 4)) & 1u) != 0);      // the row, from the lanes' centre bits
+                if (writer) { sig[k + 1 + j] = srow; pi[k + 1 + j] = P[j]; }
             }
         }
         if (type == 2 && segsym)                               // dec_clnpass_check_segsym (:977-993): 0xA expected, only warned about
