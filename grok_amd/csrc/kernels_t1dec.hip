@@ -274,9 +274,10 @@ __global__ void t1_dec_kernel(T1DecArgs a)
         const bool raw = raw_seg && type < 2;
         const int32_t one = 1 << bp, oph = one | (one >> 1), poshalf = one >> 1;
         for (uint32_t k = 0; k < h; k += 4) {
-            uint64_t P[4];
+            // "coded in an earlier pass of this plane" (pi): lane x holds column x's four bits
+            uint32_t pv = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) P[j] = pi[k + 1 + j];
+            for (int j = 0; j < 4; ++j) pv |= ((uint32_t)(pi[k + 1 + j] >> tl) & 1u) << j;
             // LANE x keeps column x's significance neighbourhood: bit 3 r + c = column x - 1 + c of row S[r] (r = 0: the row above
             // the stripe ... 5: the row below).  One v_readlane per column then gives every window of the column -- the scalar unit,
             // the scarce one here, would spend three 64-bit shifts with a select per SAMPLE on them -- and the vector unit keeps the
@@ -305,7 +306,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             }
             // rows of the stripe that do not exist behave as "already coded"
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if ((uint32_t)j >= nr) P[j] = ~0ull;          // ("visited": never a candidate in any pass)
+            for (int j = 0; j < 4; ++j) if ((uint32_t)j >= nr) pv |= 1u << j;          // ("visited": never a candidate in any pass)
 
             // per-sample pieces (j is a compile-time constant after unrolling)
 #define T1_SIGN_AND_SET(j, x)                                                                                     \
@@ -333,20 +334,20 @@ __global__ void t1_dec_kernel(T1DecArgs a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t t9 = nbv >> (3 * j);
-                        cand |= ((t9 & 0x1EFu) != 0u ? 1u : 0u) & ~((t9 >> 4) | (uint32_t)(P[j] >> tl));
+                        cand |= ((t9 & 0x1EFu) != 0u ? 1u : 0u) & ~((t9 >> 4) | (pv >> j));
                     }
                     uint64_t cm = __builtin_amdgcn_ballot_w64((cand & 1u) != 0) & wmask & (~0ull << x);
                     if (!cm) break;
                     x = (uint32_t)__ffsll((long long)cm) - 1u;
                     uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
+                    const uint32_t pvx = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        // (the candidate mask only has columns < w; rows past the block's last are the ones to leave out)
-                        if ((((uint32_t)(P[j] >> x)) | (nbx >> (3 * j + 4))) & 1u) continue;
+                        if (((pvx >> j) | (nbx >> (3 * j + 4))) & 1u) continue;
                         const uint32_t nine = (nbx >> (3 * j)) & 0x1FFu;
                         if (!(nine & 0x1EFu)) continue;                         // no significant neighbour
                         if (raw ? mq.raw_decode() : mq.decode(kCtxZC + zc_ctx9(nine))) T1_SIGN_AND_SET(j, x)
-                        P[j] |= 1ull << x;
+                        pv |= tl == x ? 1u << j : 0u;
                     }
                     ++x;
                 }
@@ -357,16 +358,16 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 for (int j = 0; j < 4; ++j) mv |= ((uint32_t)(mu[k + 1 + j] >> tl) & 1u) << j;
                 uint64_t cm = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cm |= __builtin_amdgcn_ballot_w64((((nbv >> (3 * j + 4)) & ~(uint32_t)(P[j] >> tl)) & 1u) != 0);
+                for (int j = 0; j < 4; ++j) cm |= __builtin_amdgcn_ballot_w64((((nbv >> (3 * j + 4)) & ~(pv >> j)) & 1u) != 0);
                 cm &= wmask;
                 while (cm) {
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
                     const uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
-                    const uint32_t mvx = (uint32_t)__builtin_amdgcn_readlane((int)mv, (int)x);
+                    const uint32_t mvx = (uint32_t)__builtin_amdgcn_readlane((int)mv, (int)x), pvx = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (!((nbx >> (3 * j + 4)) & ~(uint32_t)(P[j] >> x) & 1u)) continue;
+                        if (!((nbx >> (3 * j + 4)) & ~(pvx >> j) & 1u)) continue;
                         const int cxn = ((mvx >> j) & 1u) ? 16 : (((nbx >> (3 * j)) & 0x1EFu) ? 15 : 14);    // Table D.4
                         const uint32_t b = raw ? mq.raw_decode() : mq.decode(cxn);
                         const uint32_t isneg = (nnx >> (3 * j + 4)) & 1u;        // the value's sign, without reading it back
@@ -383,17 +384,17 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             } else {                                                   // cleanup (T1.cpp:854-1007)
                 uint64_t cm = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cm |= __builtin_amdgcn_ballot_w64(((~((nbv >> (3 * j + 4)) | (uint32_t)(P[j] >> tl))) & 1u) != 0);
+                for (int j = 0; j < 4; ++j) cm |= __builtin_amdgcn_ballot_w64(((~((nbv >> (3 * j + 4)) | (pv >> j))) & 1u) != 0);
                 cm &= wmask;
-                const uint64_t pany = P[0] | P[1] | P[2] | P[3];    // columns with a sample the earlier passes of this plane coded
                 while (cm) {
                     const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     cm &= cm - 1;
                     uint32_t first = 0;                                // first row still to be coded normally
                     uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
+                    const uint32_t pvx = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)x);
                     if (nr == 4) {                                     // run-length mode: whole column quiet (D.3.4) --
                         // nothing significant in the column's 3 x 6 neighbourhood (the lane's word is exactly that) and none coded
-                        if (nbx == 0 && !((uint32_t)(pany >> x) & 1u)) {
+                        if (nbx == 0 && pvx == 0) {
                             if (!mq.decode(kCtxAgg)) continue;
                             uint32_t r = mq.decode(kCtxUni);
                             r = (r << 1) | mq.decode(kCtxUni);
@@ -404,12 +405,11 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if ((uint32_t)j < first || ((((uint32_t)(P[j] >> x)) | (nbx >> (3 * j + 4))) & 1u)) continue;
+                        if ((uint32_t)j < first || (((pvx >> j) | (nbx >> (3 * j + 4))) & 1u)) continue;
                         if (mq.decode(kCtxZC + zc_ctx9((nbx >> (3 * j)) & 0x1FFu))) T1_SIGN_AND_SET(j, x)
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) P[j] = 0;                  // the plane is complete
+                pv = 0;                                                // the plane is complete
             }
 #undef T1_SIGN_AND_SET
 #pragma unroll
@@ -417,7 +417,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint64_t srow = __builtin_amdgcn_ballot_w64(((nbv >> (3 * j + 4)) & 1u) != 0);      // the row, from the lanes' centre bits
-                if (writer) { sig[k + 1 + j] = srow; pi[k + 1 + j] = P[j]; }
+                const uint64_t prow = __builtin_amdgcn_ballot_w64(((pv >> j) & 1u) != 0);
+                if (writer) { sig[k + 1 + j] = srow; pi[k + 1 + j] = prow; }
             }
         }
         if (type == 2 && segsym)                               // dec_clnpass_check_segsym (:977-993): 0xA expected, only warned about
