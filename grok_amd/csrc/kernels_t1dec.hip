@@ -16,11 +16,15 @@
 //      lane x of V[0..3] holds the decoded values of column x of the current stripe (one coalesced row load / store
 //      per stripe and pass instead of a store / an atomic per sample), and the coded bytes come through a 16-byte
 //      register window.  Significance / sign / visited / refined state is one 64-bit row bitmap each (code-blocks
-//      are at most 64 wide) in LDS, a stripe's rows in registers while it is processed; columns that cannot code
-//      anything in a pass are skipped by a mask.  Measured: ~110 executed instructions and ~800
-//      cycles per MQ decision with one wave alone on a SIMD; with many blocks resident the CU's single scalar unit
-//      and its four vector units are about equally loaded, which is why this mixed scalar / vector form beats an
-//      all-scalar one (a hand-scheduled 45-instruction scalar decoder was 1.5x slower on whole images).
+//      are at most 64 wide) in LDS; while a stripe is processed it lives ON THE LANES: lane x holds column x's 3 x 6
+//      significance neighbourhood, the same for the signs, and its four visited / refined bits, so that one v_readlane
+//      per column gives every window of the column, the context tables (zero coding, sign) are indexed straight by
+//      those bits, candidate columns are a ballot over a per-lane test, and a sample that turns significant is three
+//      vector instructions on the lanes around it (r02: the uniform 64-bit rows in scalar registers -- most of them
+//      spilled to vector registers -- cost 40 % of the kernel's time).  Measured in r01: ~110 executed
+//      instructions and ~800 cycles per MQ decision with one wave alone on a SIMD; with many blocks resident the CU's
+//      single scalar unit and its four vector units are about equally loaded, which is why this mixed scalar / vector
+//      form beats an all-scalar one (a hand-scheduled 45-instruction scalar decoder was 1.5x slower on whole images).
 //      (An earlier several-blocks-per-wave form -- branch divergence makes the lanes take turns -- measured 80 ms
 //      with 16 lanes, 38.6 ms with 4 and 41 ms with 2 where this form takes 23 ms, on 12 288 blocks.)
 //  K8b t1_store_kernel -- one wavefront per code-block: workspace -> dequantise -> Mallat plane rows.
@@ -256,9 +260,9 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     const uint32_t sg_end = a.seg_first ? a.seg_first[blk + 1] : 1u;
     uint32_t seg_off = 0;
 
-    // ---- the passes work stripe by stripe with the stripe's rows in REGISTERS: S[j+1] / N[j+1] are the
-    //      significance / sign rows of stripe row j (S[0], S[5]: the rows above and below), P[j] / M[j] its
-    //      visited / refined rows.  Columns that cannot code anything are skipped with a candidate mask.
+    // ---- the passes work stripe by stripe with the stripe's state on the LANES (nbv / nnv: significance / sign
+    //      neighbourhoods of the lane's column over the stripe's rows + the rows above and below; pv / mv: its visited /
+    //      refined bits).  Columns that cannot code anything are skipped with a candidate mask (a ballot).
     const uint64_t wmask = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
 
     int bp = (int)numbps, type = 2;
