@@ -80,7 +80,6 @@ struct grk_amd_ctx {
     bool side_pending = false;       // side-stream work of the latest encode has not been joined on the main stream yet
     bool dec_planes16 = true;                               // 16-bit planes between K5b and K6 for 8-bit reversible HT tiles
                                                             // (GRK_AMD_DEC_PLANES16=0 / grk_amd_set_decode_planes16: int32)
-    int dwt_pk_nt = 0;                                      // GRK_AMD_PK_NT: lanes per workgroup of the packed forward 5/3 kernel (0: by the level's width)
     int dwt_pk = 1;                                         // packed int16 pairs in K2 / K6 where the range allows (GRK_AMD_DWT_PK=0: 32-bit)
     int dwt_xcd = 1;                                        // XCD-aware workgroup order in K2 / K6 (GRK_AMD_DWT_XCD=0: plain)
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
@@ -342,7 +341,6 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         a.irreversible = g.p.irreversible;
         a.h16 = h16 ? 1 : 0;
         a.pk = h16 && c->dwt_pk && pk16_level_ok(g.p, l);
-        a.pk_nt = c->dwt_pk_nt;
         a.xcd = c->dwt_xcd;
         // enough workgroups to cover the chip several times, few enough to amortise warm-up rows
         const uint32_t sh = (a.ch + a.py + 1) >> 1;           // row pairs on the coordinate grid
@@ -710,7 +708,6 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* ef = getenv("GRK_AMD_FUSE_EGRESS")) c->fuse_egress = atoi(ef) != 0;
         if (const char* ex = getenv("GRK_AMD_DWT_XCD")) c->dwt_xcd = atoi(ex) != 0;
         if (const char* ex = getenv("GRK_AMD_DWT_PK")) c->dwt_pk = atoi(ex) != 0;
-        if (const char* ex = getenv("GRK_AMD_PK_NT")) c->dwt_pk_nt = atoi(ex);
         if (const char* ed = getenv("GRK_AMD_DEC_PLANES16")) c->dec_planes16 = atoi(ed) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");

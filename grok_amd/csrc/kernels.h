@@ -40,7 +40,6 @@ struct DwtLevelArgs {
     int      h16;         // reversible, 8-bit pixels: every plane (in, ll, mallat) holds int16 instead of int32
     int      xcd;         // XCD-aware workgroup order (kernels_dwt.hip)
     int      pk;          // h16 and every intermediate of this level within 16 bits: arithmetic on packed int16 pairs
-    int      pk_nt;       // lanes per workgroup of the packed kernel: 256 or 128; 0 = by the level's width
 };
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s);
 hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint32_t ncomp, int mct, hipStream_t s);

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 //  * latency.  Rows are fetched two steps ahead.
 constexpr int kPkLaneCols = 4;
 // NT lanes per workgroup: 256 (strips of up to 960 columns), or 128 -- half the footprint (two waves, 12 KiB of LDS with three
-// components), which finds room beside K3's one-wave workgroups far more often (DwtLevelArgs::pk_nt)
+// components): the better fit for narrow levels (pk_nt below)
 constexpr int kPkHalo     = kPkLaneCols;                   // one lane's worth each side (the stencil needs 2 left, 1 right)
 // The strips of a level share its width evenly, in multiples of 64 columns (64 bytes of every sub-band row); at most nt - 2
 // lanes of four columns (one halo lane each side): 960 columns for 256 lanes, 448 for 128
@@ -698,8 +698,8 @@ static bool dwt_level_is_pk(const DwtLevelArgs& a)
            a.ch >= 16 && (a.ch & 1u) == 0 && near;
 }
 // 256 lanes for wide levels (8K level 0: 127 us against 138 with 128 lanes), 128 for narrow ones, whose strips would leave half of
-// 256 lanes idle (64 tiles of 1024^2: levels 0-2 238 -> 203 us); DwtLevelArgs::pk_nt overrides
-static uint32_t pk_nt(const DwtLevelArgs& a) { return a.pk_nt == 128 || a.pk_nt == 256 ? (uint32_t)a.pk_nt : (a.cw <= 2048u ? 128u : 256u); }
+// 256 lanes idle (64 tiles of 1024^2: levels 0-2 238 -> 203 us)
+static uint32_t pk_nt(const DwtLevelArgs& a) { return a.cw <= 2048u ? 128u : 256u; }
 uint32_t dwt_level_strip_cols(const DwtLevelArgs& a) { return dwt_level_is_pk(a) ? pk_strip_cols(a.cw, pk_nt(a)) : (uint32_t)kOutCols; }
 
 hipError_t launch_dwt_level(const DwtLevelArgs& a, hipStream_t s)
