@@ -331,19 +331,22 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             };
 
             if (type == 0) {                                           // significance propagation (T1.cpp:1024-1152)
-                uint32_t x = 0;
-                while (x < w) {
-                    // candidate columns -- an uncoded, insignificant sample with a significant neighbour -- from the lanes' words
+                // candidate columns -- an uncoded, insignificant sample with a significant neighbour -- from the lanes' words;
+                // looked for again only after a column in which a sample turned significant (nothing else makes new candidates)
+                auto candidates = [&]() -> uint64_t {
                     uint32_t cand = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t t9 = nbv >> (3 * j);
                         cand |= ((t9 & 0x1EFu) != 0u ? 1u : 0u) & ~((t9 >> 4) | (pv >> j));
                     }
-                    uint64_t cm = __builtin_amdgcn_ballot_w64((cand & 1u) != 0) & wmask & (~0ull << x);
-                    if (!cm) break;
-                    x = (uint32_t)__ffsll((long long)cm) - 1u;
+                    return __builtin_amdgcn_ballot_w64((cand & 1u) != 0) & wmask;
+                };
+                uint64_t cm = candidates();
+                while (cm) {
+                    const uint32_t x = (uint32_t)__ffsll((long long)cm) - 1u;
                     uint32_t nbx = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)x), nnx = (uint32_t)__builtin_amdgcn_readlane((int)nnv, (int)x);
+                    const uint32_t nbx0 = nbx;
                     const uint32_t pvx = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)x);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -353,7 +356,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                         if (raw ? mq.raw_decode() : mq.decode(kCtxZC + zc_ctx9(nine))) T1_SIGN_AND_SET(j, x)
                         pv |= tl == x ? 1u << j : 0u;
                     }
-                    ++x;
+                    const uint64_t beyond = (~1ull) << x;                  // columns right of x
+                    cm = (nbx != nbx0 ? candidates() : cm) & beyond;
                 }
             } else if (type == 1) {                                    // magnitude refinement (T1.cpp:1160-1255)
                 // "refined before" (Table D.4) is this pass's own state: its rows stay in LDS, lane x holds column x's four bits
