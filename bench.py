@@ -59,6 +59,47 @@ def sigma(levels):
     return sum(4.0 ** -l for l in range(levels))
 
 
+# ---- ALGORITHMIC bytes, at the storage width the launched kernels really use.
+# SURVEY.md §8(d) states them for int32 planes (4 B per coefficient); 8-bit reversible content runs on int16 planes
+# (grk_amd_plane_sample_bytes = 2: exact, range-proven on the host, int32 otherwise), so a plane access counts b_pl bytes.
+def dwt_bytes(samples, b_in, b_pl, levels, fused):
+    """forward DWT family: level l reads S*4^-l samples and writes as many; the fused level 0 reads the caller's pixels
+    (b_in B) instead of a plane (K1 folded in)"""
+    if fused:
+        return samples * (b_in + b_pl) + 2.0 * b_pl * samples * (sigma(levels) - 1.0)
+    return 2.0 * b_pl * samples * sigma(levels)
+
+
+def dwt_bytes_unfused(samples, b_pl, levels):
+    """§8(d)'s DWT-only definition (one plane read + one plane write per sample and level) at the storage width"""
+    return 2.0 * b_pl * samples * sigma(levels)
+
+
+def ht_bytes(samples, b_pl, coded_sum):
+    """K3 / K5: every coefficient once + the coded bytes (sum of the block lengths, not the arena's extent)"""
+    return b_pl * samples + float(coded_sum)
+
+
+def idwt_bytes(samples, b_out, b_pl, levels, fused):
+    if fused:
+        return 2.0 * b_pl * samples * (sigma(levels) - 1.0) + samples * (b_pl + b_out)
+    return 2.0 * b_pl * samples * sigma(levels)
+
+
+def rate(nbytes, ms):
+    """(GB/s, fraction of the HBM peak) of nbytes moved in ms"""
+    if not ms or ms <= 0:
+        return None, None
+    g = nbytes / ms / 1e6
+    return round(g, 1), round(g / HBM_PEAK_GBPS, 4)
+
+
+def dtype_label(irrev, b_pl):
+    if irrev:
+        return "f32"
+    return "int16x2 packed (exact: range-proven on the host, int32 fallback)" if b_pl == 2 else "int32"
+
+
 def cpu_baseline(rank_threads, want_cfg5=True):
     """Grok's own CPU encoder / decoder (oracle/_ref = the real reference built from its sources) on this box's host
     cores, on bounded samples of the same workloads.  Returns (json object, cfg5 stream or None): the classic
@@ -144,66 +185,101 @@ def _pmc_traffic(workload, fams):
         return None
 
 
+def _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, desc, irrev, traffic_key, host=None):
+    """A few pipelined steps of one encode configuration + its kernel families one at a time (HIP events on the stream each
+    kernel is launched on).  Bytes at the storage width of the planes (grk_amd_plane_sample_bytes)."""
+    params = G.TileParams.make(W, H, Cn, prec, levels, irreversible=irrev)
+    if host is None:
+        tile = synth.g2(Cn, H, W, prec)
+        host = np.ascontiguousarray(np.broadcast_to(tile.reshape(1, -1), (ntiles, tile.size))).reshape(-1)
+    d_px = torch.from_numpy(host.view(np.uint8)).to(dev)
+    samples = W * H * ntiles * Cn
+    b_in = (prec + 7) // 8
+    b_pl, pk_levels = ctx.plane_sample_bytes(params)
+    nblocks = G.lib().grk_amd_tile_num_blocks(C.byref(params)) * ntiles
+    ctx.set_overlap(True)
+    ctx.set_pipelining(True)
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(steps):
+            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ctx.set_pipelining(False)
+    ctx.set_overlap(False)
+    ctx.enable_timing(True)
+    with torch.cuda.stream(stream):
+        for _ in range(steps):
+            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+    torch.cuda.synchronize(dev)
+    dwt_ms = ctx.kernel_ms(1)[0]
+    parts = [ctx.kernel_ms(i) for i in (2, 4, 8)]
+    n_ht = max([n for _, n in parts] + [1])
+    ht_ms = sum(m * n for m, n in parts) / n_ht
+    ctx.enable_timing(False)
+    ctx.set_overlap(True)
+    table, arena_used = ctx.fetch_table(nblocks)
+    coded_sum = int(table["length"].astype(np.int64).sum())
+    fam_d = "dwt97_5levels" if irrev else "dwt53_5levels"
+    db, du, hb = dwt_bytes(samples, b_in, b_pl, levels, True), dwt_bytes_unfused(samples, b_pl, levels), ht_bytes(samples, b_pl, coded_sum)
+    t_d = _pmc_traffic(traffic_key, ("dwt_level0_fused", "dwt_levels_1plus")) if traffic_key else None
+    t_h = _pmc_traffic(traffic_key, ("ht_encode_kernel",)) if traffic_key else None
+    w = {"workload": desc, "ms_per_step": round(ms, 4), "value": round(W * H * ntiles / ms / 1e3, 1), "unit": "Mpixels/s",
+         "dtype": dtype_label(irrev, b_pl), "plane_bytes_per_coefficient": b_pl, "packed_dwt_levels": pk_levels,
+         "coded_bytes": coded_sum, "arena_bytes_used": int(arena_used), "code_blocks": int(nblocks),
+         "kernels": {
+             fam_d: {"avg_ms": round(dwt_ms, 4), "algorithmic_bytes": int(db), "algorithmic_GBps": rate(db, dwt_ms)[0],
+                     "frac": rate(db, dwt_ms)[1],
+                     # SURVEY.md §8(d)'s unfused DWT-only figure (one plane read + one write per sample and level) at this
+                     # storage width -- for 4-byte planes the 8*S*sigma_L north_star's ">= 40 % on the 9/7 DWT" is stated on
+                     "frac_on_unfused_dwt_only_bytes": rate(du, dwt_ms)[1],
+                     "traffic": t_d, "frac_on_traffic": rate(t_d, dwt_ms)[1] if t_d else None},
+             "ht_cleanup_encode": {"avg_ms": round(ht_ms, 4), "algorithmic_bytes": int(hb), "algorithmic_GBps": rate(hb, ht_ms)[0],
+                                   "frac": rate(hb, ht_ms)[1], "traffic": t_h, "frac_on_traffic": rate(t_h, ht_ms)[1] if t_h else None}}}
+    del d_px
+    return w
+
+
 def extra_workloads(ctx, dev, stream, steps, cfg5):
     """The other BASELINE configurations on the same GPU, a few steps each: cfg2, cfg3 with its
-    9/7 DWT family against the HBM roofline (north_star's >= 40 % target), the cfg4 tiling, and the cfg5 decode."""
+    9/7 DWT family against the HBM roofline (north_star's >= 40 % target), the cfg4 tiling and the whole cfg4 image (256
+    tiles) at N = 1, the 8K workload at the reference's int32 width, and the cfg5 decode."""
     out = {}
     for name in ("cfg2", "cfg3", "cfg4tile"):
         Cn, W, H, prec, levels, ntiles, desc = WORKLOADS[name]
-        irrev = name == "cfg3"
-        params = G.TileParams.make(W, H, Cn, prec, levels, irreversible=irrev)
-        tile = synth.g2(Cn, H, W, prec)
-        host = np.ascontiguousarray(np.broadcast_to(tile.reshape(1, -1), (ntiles, tile.size))).reshape(-1)
-        d_px = torch.from_numpy(host.view(np.uint8)).to(dev)
-        samples = W * H * ntiles * Cn
-        b_in = (prec + 7) // 8
-        nblocks = G.lib().grk_amd_tile_num_blocks(C.byref(params)) * ntiles
-        ctx.set_overlap(True)
-        ctx.set_pipelining(True)
-        with torch.cuda.stream(stream):
-            for _ in range(3):
-                ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        with torch.cuda.stream(stream):
-            for _ in range(steps):
-                ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
-        torch.cuda.synchronize(dev)
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        ctx.set_pipelining(False)
-        # kernel families one at a time (HIP events on the stream each kernel is launched on)
-        ctx.set_overlap(False)
-        ctx.enable_timing(True)
-        with torch.cuda.stream(stream):
-            for _ in range(steps):
-                ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
-        torch.cuda.synchronize(dev)
-        dwt_ms = ctx.kernel_ms(1)[0]
-        parts = [ctx.kernel_ms(i) for i in (2, 4, 8)]
-        n_ht = max([n for _, n in parts] + [1])
-        ht_ms = sum(m * n for m, n in parts) / n_ht
-        ctx.enable_timing(False)
-        ctx.set_overlap(True)
-        _, total = ctx.fetch_table(nblocks)
-        dwt_bytes = samples * (b_in + 4.0) + 8.0 * samples * (sigma(levels) - 1.0)       # level 0 reads the pixels (K1 fused)
-        w = {"workload": desc, "ms_per_step": round(ms, 4), "value": round(W * H * ntiles / ms / 1e3, 1), "unit": "Mpixels/s",
-             "dtype": "f32" if irrev else "int32", "coded_bytes": int(total),
-             "kernels": {
-                 ("dwt97_5levels" if irrev else "dwt53_5levels"): {
-                     "avg_ms": round(dwt_ms, 4), "algorithmic_bytes": int(dwt_bytes),
-                     "algorithmic_GBps": round(dwt_bytes / dwt_ms / 1e6, 1) if dwt_ms > 0 else None,
-                     "frac": round(dwt_bytes / dwt_ms / 1e6 / HBM_PEAK_GBPS, 4) if dwt_ms > 0 else None,
-                     # SURVEY.md §8(d)'s unfused DWT-only figure 8*S*sigma_L (4 B read + 4 B written per sample and level),
-                     # the one north_star's ">= 40 % of the HBM roofline on the 5-level 9/7 DWT" is stated on
-                     "frac_on_8S_sigma": round(8.0 * samples * sigma(levels) / dwt_ms / 1e6 / HBM_PEAK_GBPS, 4) if dwt_ms > 0 else None,
-                     "traffic": _pmc_traffic(name, ("dwt_level0_fused", "dwt_levels_1plus"))},
-                 "ht_cleanup_encode": {
-                     "avg_ms": round(ht_ms, 4), "algorithmic_bytes": int(4.0 * samples + total),
-                     "algorithmic_GBps": round((4.0 * samples + total) / ht_ms / 1e6, 1) if ht_ms > 0 else None,
-                     "frac": round((4.0 * samples + total) / ht_ms / 1e6 / HBM_PEAK_GBPS, 4) if ht_ms > 0 else None,
-                     "traffic": _pmc_traffic(name, ("ht_encode_kernel",))}}}
-        out[name] = w
-        del d_px
+        out[name] = _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, desc, name == "cfg3", name)
+    # BASELINE configs[3] whole: 16384 x 16384 as 256 tiles of 1024 x 1024 on ONE GPU (the N = 1 point of its scaling curve)
+    try:
+        out["cfg4"] = _encode_workload(ctx, dev, stream, max(3, steps // 2), 3, 1024, 1024, 8, 5, 256,
+                                       "16384x16384x3 8-bit RGB as 256 tiles of 1024x1024, RCT+5/3 lossless HTJ2K, 5 levels, one GPU "
+                                       "(BASELINE configs[3] at N = 1)", False, "cfg4")
+        out["cfg4"]["value"] = round(16384.0 * 16384.0 / out["cfg4"]["ms_per_step"] / 1e3, 1)
+    except Exception as e:  # noqa: BLE001
+        out["cfg4"] = {"error": str(e)}
+    # the headline workload at the REFERENCE's arithmetic width: int32 planes, no packed kernels (SURVEY.md §8(d) bytes as
+    # written: 4 B per coefficient) -- beside the int16 path the headline runs, so that a reader sees both
+    try:
+        saved = {k: os.environ.get(k) for k in ("GRK_AMD_DWT_PK", "GRK_AMD_PLANES16")}
+        os.environ["GRK_AMD_DWT_PK"] = "0"
+        os.environ["GRK_AMD_PLANES16"] = "0"
+        c32 = G.Context(dev.index or 0)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        c32.set_stream(stream.cuda_stream)
+        Cn, W, H, prec, levels, ntiles, desc = WORKLOADS["8k"]
+        out["8k_int32"] = _encode_workload(c32, dev, stream, steps, Cn, W, H, prec, levels, ntiles,
+                                           desc + " -- int32 planes, unpacked 5/3 kernels (GRK_AMD_PLANES16=0 GRK_AMD_DWT_PK=0)",
+                                           False, "8k_int32")
+        c32.close()
+    except Exception as e:  # noqa: BLE001
+        out["8k_int32"] = {"error": str(e)}
     if cfg5 is not None:
         try:
             import j2kparse as J
@@ -236,11 +312,14 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
                            "ms_per_step": round(ms, 3), "value": round(S * S / ms / 1e3, 1), "unit": "Mpixels/s", "dtype": "f32",
                            "coded_bytes": int(len(data)), "pixels_equal_grk_decompress": bool(np.array_equal(got.astype(np.int32), ref5)),
                            "kernels": {"t1_ebcot_decode": {"avg_ms": round(k8, 3), "algorithmic_bytes": int(4 * samples + len(data)),
-                                                           "algorithmic_GBps": round((4 * samples + len(data)) / k8 / 1e6, 1) if k8 > 0 else None,
-                                                           "traffic": _pmc_traffic("cfg5", ("t1_dec_kernel",))},
+                                                           "algorithmic_GBps": rate(4 * samples + len(data), k8)[0],
+                                                           "frac": rate(4 * samples + len(data), k8)[1],
+                                                           "traffic": _pmc_traffic("cfg5", ("t1_dec_kernel",)),
+                                                           "frac_on_traffic": rate(_pmc_traffic("cfg5", ("t1_dec_kernel",)) or 0, k8)[1]},
                                        "idwt97_5levels": {"avg_ms": round(k6, 3),
-                                                          "algorithmic_bytes": int(8 * samples * (sigma(5) - 1) + samples * 6),
-                                                          "algorithmic_GBps": round((8 * samples * (sigma(5) - 1) + samples * 6) / k6 / 1e6, 1) if k6 > 0 else None,
+                                                          "algorithmic_bytes": int(idwt_bytes(samples, 2, 4, 5, True)),
+                                                          "algorithmic_GBps": rate(idwt_bytes(samples, 2, 4, 5, True), k6)[0],
+                                                          "frac": rate(idwt_bytes(samples, 2, 4, 5, True), k6)[1],
                                                           "traffic": _pmc_traffic("cfg5", ("idwt_last_level_fused", "idwt_level_kernel"))}}}
             ctx.set_decode_qcd([])
         except Exception as e:  # noqa: BLE001
@@ -406,7 +485,11 @@ def main():
     use_dist = world > 1 or os.environ.get("GROK_AMD_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:                      # (a launcher sets it; the forced world-1 run picks a free one)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
@@ -588,19 +671,23 @@ def main():
             decode_err = str(e)
         dk = {name: ctx.kernel_ms(idx) for idx, name in ((5, "ht_cleanup_decode"), (6, "idwt53_5levels"), (7, "egress_mct"))}
         b_in_d = (prec + 7) // 8
-        dalgo = {"ht_cleanup_decode": 4.0 * samples + float(total_d), "idwt53_5levels": 8.0 * samples * sigma(levels),
+        b_pl_d, _ = ctx.plane_sample_bytes(params, decode=True)
+        coded_sum_d = int(table_d["length"].astype(np.int64).sum())
+        # K7 fused into the last inverse level (no egress launches): that launch writes the pixels instead of a plane
+        dalgo = {"ht_cleanup_decode": ht_bytes(samples, b_pl_d, coded_sum_d),
+                 "idwt53_5levels": idwt_bytes(samples, b_in_d, b_pl_d, levels, dk["egress_mct"][1] == 0),
                  "egress_mct": samples * (4.0 + b_in_d)}
-        if dk["egress_mct"][1] == 0:
-            # K7 is fused into the last inverse DWT level: that launch writes the pixels (b_in B/sample) instead of an
-            # int32 plane, so the family's algorithmic bytes are 8*S*(sigma_L - 1) + 4*S + S*b_in
-            dalgo["idwt53_5levels"] = 8.0 * samples * (sigma(levels) - 1.0) + samples * (4.0 + b_in_d)
+        dtraffic = {"ht_cleanup_decode": _pmc_traffic(args.workload, ("ht_dec_vlc_kernel", "ht_dec_ms_kernel")),
+                    "idwt53_5levels": _pmc_traffic(args.workload, ("idwt_last_level_fused", "idwt_level_kernel")), "egress_mct": None}
         decode = {"value": round(pixels_per_step * dsteps / ddt / 1e6, 1), "unit": "Mpixels/s",
                   "ms_per_step": round(ddt / dsteps * 1e3, 4), "steps": dsteps, "lossless_round_trip": (bool(torch.equal(d_back, d_px)) if not irrev else None),
                   "max_abs_error": (int((d_back.view(torch.int16 if prec > 8 else torch.uint8).to(torch.int32) -
                                          d_px.view(torch.int16 if prec > 8 else torch.uint8).to(torch.int32)).abs().max().item())
                                     if irrev else 0),
-                  "kernels": {k: {"avg_ms": round(v[0], 4), "launches": v[1],
-                                  "algorithmic_GBps": round(dalgo[k] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+                  "plane_bytes_per_coefficient": b_pl_d,
+                  "kernels": {k: {"avg_ms": round(v[0], 4), "launches": v[1], "algorithmic_bytes": int(dalgo[k]),
+                                  "algorithmic_GBps": rate(dalgo[k], v[0])[0], "frac": rate(dalgo[k], v[0])[1],
+                                  "traffic": dtraffic[k], "frac_on_traffic": rate(dtraffic[k], v[0])[1] if dtraffic[k] else None}
                               for k, v in dk.items()}}
         if decode_err:
             decode["rejected"] = decode_err
@@ -700,27 +787,33 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         bit_exact = {"codestream_md5": cs_md5, "equals_grok_cpu_file_on_all_ranks": bool(ok.item()), "ranks": world}
     b_in = (prec + 7) // 8
-    algo = {"ingest_mct": samples * (b_in + 4), "dwt53_5levels": 8.0 * samples * sigma(levels),
-            "ht_cleanup_encode": 4.0 * samples + float(total)}
-    if fam["ingest_mct"][1] == 0:
-        # K1 is fused into DWT level 0: that launch reads the pixels (b_in B/sample) instead of an
-        # int32 plane, so the family's algorithmic bytes are S*b_in + 4*S + 8*S*(sigma_L - 1)
-        algo["dwt53_5levels"] = samples * (b_in + 4.0) + 8.0 * samples * (sigma(levels) - 1.0)
+    b_pl, pk_levels = ctx.plane_sample_bytes(params)
+    coded_sum = int(table["length"].astype(np.int64).sum())      # B_out = the blocks' bytes (the arena's extent `total` carries chunk slack)
+    fused_in = fam["ingest_mct"][1] == 0                         # K1 folded into DWT level 0: that launch reads the pixels
+    algo = {"ingest_mct": samples * (b_in + 4), "dwt53_5levels": dwt_bytes(samples, b_in, b_pl, levels, fused_in),
+            "ht_cleanup_encode": ht_bytes(samples, b_pl, coded_sum)}
+    fam_kernels = {"ingest_mct": ("ingest_kernel",), "dwt53_5levels": ("dwt_level0_fused", "dwt_levels_1plus"),
+                   "ht_cleanup_encode": ("ht_encode_kernel",)}
     dom = max(("ingest_mct", "dwt53_5levels", "ht_cleanup_encode"), key=lambda k: fam[k][0])
-    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this
-    # process; they come from the committed rocprofv3 --pmc passes of this same command
-    # (profiles/summarize_pmc.py: FETCH_SIZE x1024 x2 [gfx950 half-count] + WRITE_SIZE x1024).
-    traffic = _pmc_traffic(args.workload, {"ingest_mct": ("ingest_kernel",), "dwt53_5levels": ("dwt_level0_fused", "dwt_levels_1plus"),
-                                            "ht_cleanup_encode": ("ht_encode_kernel",)}[dom])
-    ach = algo[dom] / (fam[dom][0] * 1e-3) / 1e9 if fam[dom][0] > 0 else 0.0
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+    # HBM traffic per launch of each family: PMC counters cannot be read from inside this process; they come from the
+    # committed rocprofv3 --pmc passes of this same command (profiles/summarize_pmc.py: FETCH_SIZE x1024 x2 [gfx950
+    # half-count] + WRITE_SIZE x1024).
+    traffic = {k: _pmc_traffic(args.workload, v) for k, v in fam_kernels.items()}
+    ach, frac = rate(algo[dom], fam[dom][0])
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": ach or 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": frac or 0.0, "traffic": traffic[dom],
+                "frac_on_traffic": rate(traffic[dom], fam[dom][0])[1] if traffic[dom] else None,
                 "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": round(fam[dom][0], 4),
-                "launches": fam[dom][1],
+                "launches": fam[dom][1], "plane_bytes_per_coefficient": b_pl,
+                "bytes_convention": "SURVEY.md 8(d) per-unit figures at the storage width the launched instances use: %d B per "
+                                    "coefficient read (planes are int%d here) + the coded bytes written (sum of the block lengths); "
+                                    "workloads.8k_int32 is the same frame on the reference's int32 planes" % (b_pl, 8 * b_pl),
                 "measured": "HIP events around the kernel's launches, kernels one at a time (grk_amd_set_overlap(0)); "
                             "the timed region runs K3 of the top resolution beside DWT levels >= 1, see kernels_overlapped"}
-    kernels = {k: {"avg_ms": round(v[0], 4), "launches": v[1],
-                   "algorithmic_GBps": round(algo[k] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+    kernels = {k: {"avg_ms": round(v[0], 4), "launches": v[1], "algorithmic_bytes": int(algo[k]) if v[1] else 0,
+                   "algorithmic_GBps": rate(algo[k], v[0])[0], "frac": rate(algo[k], v[0])[1],
+                   "traffic": traffic[k] if v[1] else None,
+                   "frac_on_traffic": rate(traffic[k], v[0])[1] if (traffic[k] and v[1]) else None}
                for k, v in fam.items()}
     if not use_dist:
         parallelism = "1 GPU, consecutive encodes pipelined (grk_amd_set_pipelining)" if pipelined else "1 GPU"
@@ -731,8 +824,8 @@ def main():
         parallelism = ("tile-sharded x%d, per frame the coded tile-parts (exact sizes) gathered over RCCL on the frame's writer "
                        "rank, which rotates with the frame number; the gather runs one frame behind the encoder" % world)
     kernels_overlapped = {k: {"avg_ms": round(v[0], 4), "launches": v[1]} for k, v in fam_overlapped.items()}
-    # whole-pipeline figure of SURVEY.md §8(d) (unfused definition, kept so that rounds compare)
-    pipeline_bytes = samples * (b_in + 4) + 8.0 * samples * sigma(levels) + algo["ht_cleanup_encode"]
+    # whole-pipeline figure: the families' algorithmic bytes as launched (fused level 0, storage width)
+    pipeline_bytes = algo["dwt53_5levels"] + algo["ht_cleanup_encode"] + (algo["ingest_mct"] if not fused_in else 0.0)
 
     pipe_traffic = _pmc_traffic(args.workload, ("ingest_kernel", "dwt_level0_fused", "dwt_levels_1plus", "ht_encode_kernel"))
     if rank == 0:
@@ -742,15 +835,16 @@ def main():
             "metric": "encode Mpixels/s (whole node), 8K RGB HTJ2K lossless",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if irrev else "int32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(irrev, b_pl), "data": "synthetic",
             "config": {"workload": desc, "tiles_per_gpu": ntiles, "code_blocks_per_gpu": int(nblocks),
-                       "coded_bytes_per_gpu": int(total), "generator": "G2 (SURVEY.md §8d)",
-                       "parallelism": parallelism},
+                       "coded_bytes_per_gpu": coded_sum, "arena_bytes_used_per_gpu": int(total), "packed_dwt_levels": pk_levels,
+                       "generator": "G2 (SURVEY.md §8d)", "parallelism": parallelism},
             "roofline": roofline,
-            # equivalent-work figure (SURVEY.md §8d's UNFUSED definition: int32 planes between every stage), kept so that
-            # rounds compare; the fused pipeline moves far fewer bytes -- `dram_*` is what the PMC counters saw per step
-            "pipeline": {"unfused_equivalent_bytes_per_step": int(pipeline_bytes),
-                         "unfused_equivalent_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            # the whole step against the HBM roofline: algorithmic bytes of its kernel families as launched, and what the PMC
+            # counters saw per step (`dram_*`)
+            "pipeline": {"algorithmic_bytes_per_step": int(pipeline_bytes),
+                         "algorithmic_GBps": rate(pipeline_bytes, ms_per_step)[0],
+                         "algorithmic_frac_of_hbm_peak": rate(pipeline_bytes, ms_per_step)[1],
                          "dram_traffic_bytes_per_step": pipe_traffic,
                          "dram_GBps": round(pipe_traffic / (ms_per_step * 1e-3) / 1e9, 1) if pipe_traffic else None,
                          "dram_frac_of_hbm_peak": round(pipe_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if pipe_traffic else None},
@@ -763,9 +857,11 @@ def main():
             out["config"]["assembled_codestream_bytes"] = cs_len
             out["multi_gpu"] = multi_gpu
         cfg5 = None
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], cfg5 = cpu_baseline(os.cpu_count() or 1, want_cfg5=not args.no_workloads and args.workload == "8k")
-        elif world == 1:
+        if not args.no_cpu_baseline:
+            # rank 0, at every N (the other ranks wait in the final barrier): Grok's CPU encoder on this box's host cores
+            out["cpu_baseline"], cfg5 = cpu_baseline(os.cpu_count() or 1,
+                                                     want_cfg5=world == 1 and not use_dist and not args.no_workloads and args.workload == "8k")
+        else:
             out["cpu_baseline"] = None
         if world == 1 and not use_dist and not args.no_workloads and args.workload == "8k":
             out["workloads"] = extra_workloads(ctx, dev, stream, max(3, min(args.steps, 10)), cfg5)

@@ -117,6 +117,8 @@ def lib():
         L.grk_amd_decode_region.argtypes = [vp, PP, vp, vp, u64, i32, u32, u32, u32, u32, vp, i32]
         L.grk_amd_set_overlap.argtypes = [vp, i32]
         L.grk_amd_set_decode_planes16.argtypes = [vp, i32]
+        if hasattr(L, "grk_amd_plane_sample_bytes"):      # (absent from older builds loaded through GRK_AMD_LIB for A/B timing)
+            L.grk_amd_plane_sample_bytes.argtypes = [vp, PP, i32, C.POINTER(u32)]
         L.grk_amd_set_pipelining.argtypes = [vp, i32]
         L.grk_amd_stream_wait_results.argtypes = [vp, vp]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
@@ -408,6 +410,14 @@ class Context:
 
     def set_decode_planes16(self, on):
         self._check(self._L.grk_amd_set_decode_planes16(self._h, int(on)), "set_decode_planes16")
+
+    def plane_sample_bytes(self, params, decode=False):
+        """(bytes per coefficient of the LL / Mallat planes the encode / decode path keeps for such tiles: 2 or 4, forward DWT
+        levels that run on packed int16 pairs)"""
+        n = C.c_uint32(0)
+        b = self._L.grk_amd_plane_sample_bytes(self._h, C.byref(params), int(decode), C.byref(n))
+        self._check(min(b, 0), "plane_sample_bytes")
+        return b, n.value
 
     def set_overlap(self, on):
         self._check(self._L.grk_amd_set_overlap(self._h, int(bool(on))), "set_overlap")

@@ -1184,6 +1184,24 @@ int grk_amd_set_pipelining(grk_amd_ctx* c, int on)
     return rc;
 }
 
+int grk_amd_plane_sample_bytes(grk_amd_ctx* c, const grk_amd_tile_params* p, int decode, uint32_t* packed_levels)
+{
+    if (!c || !p) return GRK_AMD_ERR_INVALID;
+    const uint32_t bps = (p->prec + 7u) / 8u;
+    bool h16;
+    if (decode)
+        h16 = c->dec_planes16 && p->num_levels >= 1 && bps <= 2 && c->fuse_egress && !p->reserved[0] && !p->irreversible &&
+              p->prec <= 8 && c->dec_seg_first.empty();
+    else
+        h16 = c->planes16 && p->num_levels >= 1 && planes16_ok(*p);
+    if (packed_levels) {
+        *packed_levels = 0;
+        if (h16 && c->dwt_pk && !decode)
+            for (uint32_t l = 0; l < p->num_levels; ++l) *packed_levels += pk16_level_ok(*p, l) ? 1u : 0u;
+    }
+    return h16 ? 2 : 4;
+}
+
 int grk_amd_set_decode_planes16(grk_amd_ctx* c, int on)
 {
     if (!c) return GRK_AMD_ERR_INVALID;

@@ -27,6 +27,18 @@
 #include "ht_vlc_tables.h"
 #include <type_traits>
 
+// A/B switches of round 3 (one build per setting, tools/k3_time.py): the neighbour exchange of phase A by lane shifts
+// instead of ds_bpermute, phase B as speculative windows instead of walker + bitmaps
+#ifndef GRK_HT_DPP
+#define GRK_HT_DPP 2
+#endif
+#ifndef GRK_HT_SPEC
+#define GRK_HT_SPEC 1
+#endif
+#ifndef GRK_HT_SKIP3
+#define GRK_HT_SKIP3 1
+#endif
+
 namespace grk_amd {
 
 namespace {
@@ -94,7 +106,13 @@ __device__ __forceinline__ void or_bits64(uint32_t* raw, uint32_t pos, uint64_t 
     const uint32_t top = ((uint32_t)(val >> 32) >> 1) >> (31 - sh);
     lds_or(w, (uint32_t)lo);
     lds_or(w + 1, (uint32_t)(lo >> 32));
+#if GRK_HT_SKIP3
+    // the value reaches into a third word only when it is longer than 64 - sh bits: for most iterations of most blocks no
+    // lane's does (a quad of 8-bit content has ~13 MagSgn bits), and a compare + scalar branch is a quarter of a ds_or
+    if (__ballot(top != 0)) lds_or(w + 2, top);
+#else
     lds_or(w + 2, top);
+#endif
 }
 __device__ __forceinline__ void or_bits32(uint32_t* raw, uint32_t pos, uint32_t val)
 {
@@ -230,7 +248,7 @@ __device__ __forceinline__ uint32_t bperm(int addr, uint32_t v)
 // (8 resp. 7 consecutive ones; VLC additionally needs the previous byte > 0x8F); the candidates do
 // not depend on the byte phase, so all events inside one window are resolved without reloading.
 // Every event marks one OUTPUT byte index as "7 bits wide".
-template <bool VLC>
+template <bool VLC, bool MARK = true>
 __device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nwords, uint32_t nbits,
                                                 uint32_t* marks, uint32_t& last_p, int lane)
 {
@@ -270,7 +288,7 @@ __device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nw
             const uint32_t p = 32 * (B + (uint32_t)L) + (uint32_t)(__ffs((int)hl) - 1);
             const uint32_t j = (p + K) >> 3;
             const uint32_t mj = VLC ? j : j + 1;
-            if (lane == 0) marks[mj >> 5] |= 1u << (mj & 31);
+            if constexpr (MARK) { if (lane == 0) marks[mj >> 5] |= 1u << (mj & 31); }
             ++K; last_p = p;
             s = p + 15;
             if (s >= wend) break;
@@ -509,11 +527,28 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
 
         // ---- neighbourhood: exponents / significance of the sample row above, left quad's rho ----
         const uint32_t Bcur = __builtin_amdgcn_perm(C, C, 0x0C030C01u);         // lo16 = byte 1 (sample 1), hi16 = byte 3 (sample 3)
+#if GRK_HT_DPP >= 2
+        // the row above lives in the other half of the wave: this iteration's upper quad row (half 0) takes the lower row of
+        // the iteration before from lanes 32..63 (Bprev), the lower quad row (half 1) this iteration's upper row from lanes
+        // 0..31 (Bcur).  v_permlane32_swap(Bprev, Bcur) leaves [Bprev.lo | Bcur.lo] and [Bprev.hi | Bcur.hi]: 8 cycles
+        // against a ds_bpermute's 24 (profiles/r02_valu_issue_rates.txt)
+        const auto sw32 = __builtin_amdgcn_permlane32_swap(Bprev, Bcur, false, false);
+        const uint32_t above = bitop3<0xE4>((uint32_t)sw32[0], (uint32_t)sw32[1], hmask);     // half ? [.. | Bcur.lo] : [Bprev.hi | ..]
+#else
         const uint32_t sel = bitop3<0xE4>(Bprev, Bcur, hmask);                  // half ? Bprev : Bcur
         const uint32_t above = bperm(a_x32, sel);
+#endif
+#if GRK_HT_DPP >= 1
+        // left / right neighbours by lane shifts (DPP wave_shr / wave_shl, 4 cycles each): the lanes at the ends of a quad row
+        // (0 | 32, 31 | 63) are masked anyway
+        const uint32_t above_l = dpp0<0x138, 0xF>(above) | q0m;                 // lane x reads x - 1
+        const uint32_t above_r = dpp0<0x130, 0xF>(above) | q31m;                // lane x reads x + 1
+        const uint32_t rho_l = dpp0<0x138, 0xF>(rho) & ~q0m;
+#else
         const uint32_t above_l = bperm(a_up, above) | q0m;
         const uint32_t above_r = bperm(a_dn, above) | q31m;
         const uint32_t rho_l = bperm(a_up, rho) & ~q0m;
+#endif
         // max exponent of {w, n0, n1, e} = 32 - min of their leading-zero counts
         const uint32_t Y = __builtin_amdgcn_perm(above_l, above_r, 0x07060100u);   // lo16 = e, hi16 = w
         const u16x2 pm = __builtin_elementwise_min(__builtin_bit_cast(u16x2, above), __builtin_bit_cast(u16x2, Y));
@@ -678,7 +713,193 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     unsigned long long base_off = 0;
     if (lane == 0) base_off = arena_alloc(a.alloc, gid & a.region_mask, len_ub);
 
-    // ================= phase B: stuffing, termination, emission (see oracle/ht_wave_model.c) =====
+    // ================= phase B: stuffing, termination, emission (oracle/ht_wave_model.c, orc_ht_model_phase_b2) =====
+    // Byte stuffing only moves byte boundaries after rare events (MagSgn: the byte after a 0xFF has 7 bits; VLC: a byte after
+    // one > 0x8F whose low 7 bits are ones has 7).  "Speculative windows": 64 lanes cut 4 output bytes each out of the raw
+    // stream as if no event fell into the window and test their own bytes; without an event (one ballot) the 256 bytes are
+    // final and stored as they are, otherwise everything before the first event is, the event's 7-bit byte is dealt with on
+    // the spot and the next window starts behind it.  r02 found the events with a walker first, kept them in bitmaps with
+    // prefix counts, and looked every output dword's start up afterwards (~2.2x the vector instructions of this form).
+#if GRK_HT_SPEC
+    const uint32_t vw = vlc_words;
+    // ---- B1: VLC bytes are stored backwards from the block's END, so their number comes first: the walker, counting only
+    uint32_t vlast = 0;
+    const uint32_t Kv = walk_events<true, false>(vlc_raw, vw, vlc_bits, nullptr, vlast, lane);
+    const uint32_t vs0 = Kv ? vlast + 7 : 0;
+    const uint32_t vposr = vs0 + 8 * ((vlc_bits - vs0) >> 3);
+    const uint32_t vused = vlc_bits - vposr;
+    const uint32_t vacc = vused ? get_bits(vlc_raw, vposr, vused) : 0;
+    const uint32_t nv = (vposr + Kv) >> 3;
+
+    // ---- B2: MEL / VLC termination (terminate_mel_vlc :357-385), wave-uniform
+    if (mel.run > 0) mel_put_bit(mel, mel_buf, 1, lane == 0);
+    uint32_t vextra = 0;
+    {
+        const int macc = mel.acc << mel.left;
+        const int mel_mask = (0xFF << mel.left) & 0xFF;
+        const int vlc_mask = 0xFF >> (8 - (int)vused);
+        if ((mel_mask | vlc_mask) != 0) {
+            const int fuse = macc | (int)vacc;
+            if ((((fuse ^ macc) & mel_mask) | ((fuse ^ (int)vacc) & vlc_mask)) == 0 && fuse != 0xFF && nv >= 1) {
+                if (lane == 0 && mel.pos < 250) mel_buf[mel.pos] = (uint8_t)fuse;
+            } else {
+                if (lane == 0 && mel.pos < 250) mel_buf[mel.pos] = (uint8_t)macc;
+                vextra = 1;
+            }
+            mel.pos++;
+        }
+    }
+    const uint32_t mel_len = mel.pos;
+    const uint32_t vcount = nv + vextra;
+    const uint32_t scup = mel_len + vcount + 1;
+
+    // ---- the reserved bytes (16-byte aligned, order of arrival); nothing is written outside them
+    base_off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base_off >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base_off);
+    if (base_off + len_ub > a.arena_bytes) {
+        if (lane == 0) { a.lengths[gid] = 0; a.offsets[gid] = base_off; atomicOr(reinterpret_cast<unsigned int*>(a.alloc), 1u); }
+        return;
+    }
+    uint8_t* const out = a.arena + base_off;
+    typedef uint32_t u32_any __attribute__((aligned(1)));
+    const uint32_t lane32 = 32u * (uint32_t)lane, lane4 = 4u * (uint32_t)lane;
+
+    // ---- B3: MagSgn bytes (emit_ms of the model): s = raw bit the next byte starts at, j = its index in the output
+    uint32_t ms_len;
+    {
+        uint32_t s = 0, j = 0;
+        bool done = false;
+        while (s + 8u <= ms_bits) {
+            const uint32_t avail = (ms_bits - s) >> 3;               // whole bytes left if no event comes
+            const uint32_t start = s + lane32;
+            const uint32_t sw = start >> 5;
+            const uint32_t win = __builtin_amdgcn_alignbit(ms_raw[sw + 1], ms_raw[sw], start);    // (the shift takes the low 5 bits)
+            // a byte of win is 0xFF <=> that byte of ~win is zero: (x - 0x01010101) & ~x & 0x80808080, exact for the LOWEST flag
+            uint32_t z = bitop3<0x80>(~win - 0x01010101u, win, 0x80808080u);
+            uint32_t nb = 4;
+            if (avail < 256u) {                                      // last window: lanes beyond the stream, a partial lane
+                nb = min(avail - min(avail, lane4), 4u);
+                z &= nb >= 4u ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+            }
+            const uint64_t ballot = __ballot(z != 0);
+            if (!ballot) {
+                if (avail >= 256u) {                                 // (wave-uniform: the common window costs ~10 vector instructions)
+                    *reinterpret_cast<u32_any*>(out + j + lane4) = win;
+                    s += 2048u; j += 256u;
+                    continue;
+                }
+                if (nb == 4u) *reinterpret_cast<u32_any*>(out + j + lane4) = win;
+                else {
+#pragma unroll 1
+                    for (uint32_t k = 0; k < nb; ++k) out[j + lane4 + k] = (uint8_t)(win >> (8u * k));
+                }
+                s += 8u * avail; j += avail;
+                continue;
+            }
+            const uint32_t F = (uint32_t)__ffsll((long long)ballot) - 1u;
+            const uint32_t zF = (uint32_t)__builtin_amdgcn_readlane((int)z, (int)F);
+            const uint32_t winF = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)F);
+            const uint32_t b = (uint32_t)(__ffs((int)zF) - 1) >> 3;
+            if ((uint32_t)lane < F) *reinterpret_cast<u32_any*>(out + j + lane4) = win;
+            const uint32_t p7 = s + 32u * F + 8u * (b + 1u);         // where the 7-bit byte after the 0xFF starts
+            j += 4u * F;
+            if (p7 == ms_bits) {                                     // the stream ends with the 0xFF: dropped (ms_terminate)
+                if ((uint32_t)lane < b) out[j + lane] = (uint8_t)(winF >> (8u * lane));
+                ms_len = j + b; done = true;
+                break;
+            }
+            if ((uint32_t)lane <= b) out[j + lane] = (uint8_t)(winF >> (8u * lane));
+            j += b + 1u;
+            if (p7 + 7u > ms_bits) {                                 // incomplete 7-bit byte: padded with ones, never 0xFF
+                const uint32_t rem = ms_bits - p7;
+                const uint32_t fin = get_bits(ms_raw, p7, rem) | ((((1u << (7u - rem)) - 1u) << rem) & 0x7Fu);
+                if (lane == 0) out[j] = (uint8_t)fin;
+                ms_len = j + 1u; done = true;
+                break;
+            }
+            const uint32_t b7 = get_bits(ms_raw, p7, 7u);
+            if (lane == 0) out[j] = (uint8_t)b7;
+            j += 1u;
+            s = p7 + 7u;
+        }
+        if (!done) {
+            const uint32_t rem = ms_bits - s;
+            if (rem) {
+                const uint32_t fin = get_bits(ms_raw, s, rem) | ((((1u << (8u - rem)) - 1u) << rem) & 0xFFu);
+                if (fin != 0xFFu) {
+                    if (lane == 0) out[j] = (uint8_t)fin;
+                    j += 1u;
+                }
+            }
+            ms_len = j;
+        }
+    }
+    const uint32_t total = ms_len + mel_len + vcount + 1;
+    if (lane == 0) { a.lengths[gid] = total; a.offsets[gid] = base_off; }
+    if (total > len_ub) {                                            // (cannot happen: the bound counts every stuffing bit)
+        if (lane == 0) atomicOr(reinterpret_cast<unsigned int*>(a.alloc), 1u);
+        return;
+    }
+    __syncthreads();                                                 // lane 0's last MEL byte
+#pragma unroll 1
+    for (uint32_t i = lane; i < mel_len; i += 64) out[ms_len + i] = mel_buf[i < 250 ? i : 249];
+
+    // ---- B4: VLC bytes 0 .. nv - 1, byte i at out[total - 2 - i] (emit_vlc of the model); the first one carries Scup's low nibble
+    {
+        uint8_t* const last = out + total - 2;
+        uint32_t s = 0, i = 0, prev = 0xFFu << 24;
+        while (i < nv) {
+            const uint32_t left = nv - i;
+            const uint32_t start = s + lane32;
+            const uint32_t sw = start >> 5;
+            const uint32_t win = __builtin_amdgcn_alignbit(vlc_raw[sw + 1], vlc_raw[sw], start);
+            // the byte before each of the four: lane - 1's top byte (lane 0: the window before, `prev`)
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)prev, (int)win, 0x138, 0xF, 0xF, false);
+            const uint32_t pw = __builtin_amdgcn_alignbit(win, before, 24);
+            const uint32_t e = (win & 0x7F7F7F7Fu) + 0x01010101u;   // bit 7 of a byte: its low 7 bits are ones
+            // flag at bit 4 of a byte: the byte before has bit 7 and one of bits 6..4 (it is > 0x8F), this one's low 7 bits are ones
+            uint32_t z = bitop3<0x80>(pw >> 3, (pw >> 2) | (pw >> 1) | pw, e >> 3) & 0x10101010u;
+            uint32_t nb = 4;
+            if (left < 256u) {
+                nb = min(left - min(left, lane4), 4u);
+                z &= nb >= 4u ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+            }
+            const uint64_t ballot = __ballot(z != 0);
+            const uint32_t F = ballot ? (uint32_t)__ffsll((long long)ballot) - 1u : 64u;
+            {   // lanes before the event (all of them without one): their four bytes, reversed
+                uint32_t word = win;
+                if (i == 0 && lane == 0) word = (word & ~0xFu) | (scup & 0xFu);
+                if ((uint32_t)lane < F) {
+                    if (nb == 4u) *reinterpret_cast<u32_any*>(last - 3 - (int)(i + lane4)) = __builtin_bswap32(word);
+                    else {
+#pragma unroll 1
+                        for (uint32_t k = 0; k < nb; ++k) *(last - (int)(i + lane4 + k)) = (uint8_t)(word >> (8u * k));
+                    }
+                }
+            }
+            if (!ballot) {
+                const uint32_t n = min(left, 256u);
+                prev = (uint32_t)__builtin_amdgcn_readlane((int)win, 63) & 0xFF000000u;
+                s += 8u * n; i += n;
+                continue;
+            }
+            const uint32_t zF = (uint32_t)__builtin_amdgcn_readlane((int)z, (int)F);
+            const uint32_t winF = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)F);
+            const uint32_t b = (uint32_t)(__ffs((int)zF) - 1) >> 3;
+            i += 4u * F;
+            if ((uint32_t)lane <= b) {                               // the event lane's bytes up to the 7-bit one (0x7F)
+                uint32_t v = (winF >> (8u * lane)) & ((uint32_t)lane == b ? 0x7Fu : 0xFFu);
+                if (i + lane == 0) v = (v & 0xF0u) | (scup & 0xFu);
+                *(last - (int)(i + lane)) = (uint8_t)v;
+            }
+            s += 32u * F + 8u * b + 7u; i += b + 1u; prev = 0x7Fu << 24;
+        }
+    }
+    if (lane == 0) {
+        if (vextra) out[total - 2 - nv] = (uint8_t)(nv == 0 ? ((vacc & 0xF0) | (scup & 0xF)) : vacc);
+        out[total - 1] = (uint8_t)(scup >> 4);
+    }
+#else
     const uint32_t msw = ms_words, vw = vlc_words;
 #pragma unroll 1
     for (uint32_t i = lane; i < mark_words + vmark_words; i += 64) marks[i] = 0;      // the UVLC table is dead now
@@ -804,6 +1025,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         if (vextra) out[total - 2 - nv] = (uint8_t)(nv == 0 ? ((vacc & 0xF0) | (scup & 0xF)) : vacc);
         out[total - 1] = (uint8_t)(scup >> 4);
     }
+#endif
 }
 
 template <bool IRREV, bool H16>

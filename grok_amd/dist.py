@@ -137,9 +137,12 @@ class FramePipeline:
     def _issue_gather(self, pending):
         f, slot, offs, lens, arena = pending
         if self._ready[slot] is not None:          # the counts of frame f are on the host (frame f + 1 is already queued):
-            ev = self._ready[slot]                 # polled -- a blocking wait wakes up late, and the next frame's launches
-            while not ev.query():                  # have to be queued while this one runs
-                pass
+            ev = self._ready[slot]                 # polled briefly -- a blocking wait wakes up late, and the next frame's
+            spins = 0                              # launches have to be queued while this one runs -- then a blocking wait
+            while spins < 20000 and not ev.query():    # (a peer that is late or has failed must not leave this rank
+                spins += 1                             # burning a core forever: the collective's own timeout applies)
+            if not ev.query():
+                ev.synchronize()
         counts = [[int(v), self.rows[r]] for r, v in enumerate(self._host[slot].tolist())]
         root = f % self.world
         mine = self.bufs if self.rank == root else None

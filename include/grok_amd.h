@@ -188,6 +188,11 @@ int grk_amd_decode_status(grk_amd_ctx* ctx);
  * pixels) decodes it again with int32 planes by itself, an asynchronous one reports GRK_AMD_ERR_RANGE from
  * grk_amd_decode_status() and the caller repeats the call after grk_amd_set_decode_planes16(ctx, 0). */
 int grk_amd_set_decode_planes16(grk_amd_ctx* ctx, int on);
+/* Bytes per coefficient of the LL / Mallat planes that grk_amd_encode_tiles (decode = 0, device pixels) or grk_amd_decode_tiles
+ * (decode = 1) keeps for tiles of these parameters: 2 for 8-bit reversible content (int16 planes: every coefficient provably
+ * fits, results identical to the int32 path), else 4.  *packed_levels (may be NULL) = the forward DWT levels that run on packed
+ * int16 pairs.  What a roofline figure has to count the plane traffic with (bench.py). */
+int grk_amd_plane_sample_bytes(grk_amd_ctx* ctx, const grk_amd_tile_params* p, int decode, uint32_t* packed_levels);
 /* Region (windowed) decode of ONE tile -- what grk_decompress_set_window() + grk_decompress() do on the host
  * (grok.h; partial synthesis: transform/WaveletReverse.cpp:1466-2213, tile/SparseBuffer.h): the pixels of the window
  * [x0, x1) x [y0, y1) of the tile, component-major planar, tight, (x1 - x0) * (y1 - y0) samples per component --

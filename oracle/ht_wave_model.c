@@ -71,7 +71,7 @@ static uint32_t walk(const uint32_t* raw, uint32_t nwords, uint32_t nbits, int v
         const uint32_t p = 32 * (B + (uint32_t)L) + (uint32_t)__builtin_ctz(hit[L]);
         const uint32_t j = (p + K) >> 3;                         /* output index of the byte at p */
         const uint32_t mj = vlc_rule ? j : j + 1;
-        marks[mj >> 5] |= 1u << (mj & 31);
+        if (marks) marks[mj >> 5] |= 1u << (mj & 31);
         ++K; *last_p = p;
         s = p + 15;
     }
@@ -160,5 +160,150 @@ int32_t orc_ht_model_phase_b(const uint32_t* ms_raw, uint32_t ms_bits, const uin
     out[total - 1] = (uint8_t)(scup >> 4);
     out[total - 2] = (uint8_t)((out[total - 2] & 0xF0) | (scup & 0xF));
     free(marks); free(pref); free(vmarks); free(vpref);
+    return (int32_t)total;
+}
+
+/* ---- r03: phase B without bitmaps ("speculative windows", kernels_ht.hip emit_ms / emit_vlc) -------------------------------
+ * The walker above finds the events first and the emission looks every byte's start up afterwards.  The second form does
+ * both at once: a window of 64 lanes x 4 output bytes is cut out of the raw stream as if no event fell into it; every lane
+ * tests its own four bytes; with no event in the window (ballot == 0) all 256 bytes are final, otherwise everything before
+ * the first event is, the event's 7-bit byte is handled on the spot and the next window starts right behind it.
+ * MagSgn needs no other pass at all (its byte count falls out at the end); VLC bytes are stored backwards from the END of
+ * the block, so their count has to be known first: the walker above still counts them (marks == NULL). */
+static uint32_t get32(const uint32_t* raw, uint32_t nwords, uint32_t pos)
+{
+    uint64_t v = rd(raw, nwords, pos >> 5, 0) | ((uint64_t)rd(raw, nwords, (pos >> 5) + 1, 0) << 32);
+    return (uint32_t)(v >> (pos & 31));
+}
+static uint32_t valid_mask(uint32_t nb, uint32_t flags) { return nb >= 4 ? flags : ((1u << (8 * nb)) - 1u) & flags; }
+
+static uint32_t emit_ms(const uint32_t* raw, uint32_t nwords, uint32_t nbits, uint8_t* out)
+{
+    uint32_t s = 0, j = 0;
+    while (s + 8 <= nbits) {
+        const uint32_t avail = (nbits - s) >> 3;                 /* whole bytes left if no event comes */
+        uint32_t win[LANES], z[LANES], nbl[LANES];
+        uint64_t ballot = 0;
+        for (int l = 0; l < LANES; ++l) {                        /* ---- one lane each */
+            win[l] = get32(raw, nwords, s + 32u * l);
+            nbl[l] = avail > 4u * l ? (avail - 4u * l < 4 ? avail - 4u * l : 4) : 0;
+            const uint32_t x = ~win[l];
+            z[l] = (x - 0x01010101u) & win[l] & valid_mask(nbl[l], 0x80808080u);      /* lowest flag = first 0xFF byte (exact) */
+            if (z[l]) ballot |= 1ull << l;
+        }
+        if (!ballot) {
+            for (int l = 0; l < LANES; ++l)
+                for (uint32_t b = 0; b < nbl[l]; ++b) out[j + 4u * l + b] = (uint8_t)(win[l] >> (8 * b));
+            const uint32_t n = avail < 256 ? avail : 256;
+            s += 8 * n; j += n;
+            continue;
+        }
+        const uint32_t F = (uint32_t)__builtin_ctzll(ballot), b = (uint32_t)__builtin_ctz(z[F]) >> 3;
+        for (uint32_t l = 0; l < F; ++l)
+            for (uint32_t k = 0; k < 4; ++k) out[j + 4u * l + k] = (uint8_t)(win[l] >> (8 * k));
+        const uint32_t p7 = s + 32u * F + 8u * (b + 1);          /* where the 7-bit byte after the 0xFF starts */
+        if (p7 == nbits) {                                       /* the stream ends with the 0xFF: dropped (fb_finish) */
+            for (uint32_t k = 0; k < b; ++k) out[j + 4u * F + k] = (uint8_t)(win[F] >> (8 * k));
+            return j + 4u * F + b;
+        }
+        for (uint32_t k = 0; k <= b; ++k) out[j + 4u * F + k] = (uint8_t)(win[F] >> (8 * k));
+        j += 4u * F + b + 1;
+        if (p7 + 7 > nbits) {                                    /* incomplete 7-bit byte: padded with ones, never 0xFF */
+            const uint32_t rem = nbits - p7;
+            out[j++] = (uint8_t)(get_bits(raw, nwords, p7, rem) | ((((1u << (7 - rem)) - 1u) << rem) & 0x7F));
+            return j;
+        }
+        out[j++] = (uint8_t)get_bits(raw, nwords, p7, 7);
+        s = p7 + 7;
+    }
+    const uint32_t rem = nbits - s;
+    if (rem) {
+        const uint32_t fin = get_bits(raw, nwords, s, rem) | ((((1u << (8 - rem)) - 1u) << rem) & 0xFF);
+        if (fin != 0xFF) out[j++] = (uint8_t)fin;
+    }
+    return j;
+}
+
+/* VLC bytes 0 .. nv-1, byte i stored at last[-i] */
+static void emit_vlc(const uint32_t* raw, uint32_t nwords, uint32_t nv, uint8_t* last)
+{
+    uint32_t s = 0, i = 0, prev = 0xFF;
+    while (i < nv) {
+        const uint32_t left = nv - i;
+        uint32_t win[LANES], z[LANES], nbl[LANES];
+        uint64_t ballot = 0;
+        for (int l = 0; l < LANES; ++l) {
+            win[l] = get32(raw, nwords, s + 32u * l);
+            nbl[l] = left > 4u * l ? (left - 4u * l < 4 ? left - 4u * l : 4) : 0;
+        }
+        for (int l = 0; l < LANES; ++l) {
+            const uint32_t prevsrc = l ? win[l - 1] : prev << 24;
+            const uint32_t pw = (win[l] << 8) | (prevsrc >> 24);       /* byte k of pw = the byte before byte k of win */
+            const uint32_t e = (win[l] & 0x7F7F7F7Fu) + 0x01010101u;   /* bit 7 of a byte: its low 7 bits are ones */
+            /* flag at bit 4 of a byte (right shifts are the cheap ones on the GPU): bit 7 of the byte before and any of its
+               bits 6..4 (it is > 0x8F), and the low 7 bits of this one are ones */
+            z[l] = (pw >> 3) & ((pw >> 2) | (pw >> 1) | pw) & (e >> 3) & valid_mask(nbl[l], 0x10101010u);
+            if (z[l]) ballot |= 1ull << l;
+        }
+        if (!ballot) {
+            for (int l = 0; l < LANES; ++l)
+                for (uint32_t b = 0; b < nbl[l]; ++b) last[-(int32_t)(i + 4u * l + b)] = (uint8_t)(win[l] >> (8 * b));
+            const uint32_t n = left < 256 ? left : 256;
+            prev = win[LANES - 1] >> 24;
+            s += 8 * n; i += n;
+            continue;
+        }
+        const uint32_t F = (uint32_t)__builtin_ctzll(ballot), b = (uint32_t)__builtin_ctz(z[F]) >> 3;
+        for (uint32_t l = 0; l < F; ++l)
+            for (uint32_t k = 0; k < 4; ++k) last[-(int32_t)(i + 4u * l + k)] = (uint8_t)(win[l] >> (8 * k));
+        for (uint32_t k = 0; k < b; ++k) last[-(int32_t)(i + 4u * F + k)] = (uint8_t)(win[F] >> (8 * k));
+        last[-(int32_t)(i + 4u * F + b)] = 0x7F;
+        s += 32u * F + 8u * b + 7u; i += 4u * F + b + 1; prev = 0x7F;
+    }
+}
+
+int32_t orc_ht_model_phase_b2(const uint32_t* ms_raw, uint32_t ms_bits, const uint32_t* vlc_raw, uint32_t vlc_bits,
+                              const uint8_t* mel_bytes, const int* mel_state, uint8_t* out)
+{
+    const uint32_t msw = (ms_bits + 31) / 32, vw = (vlc_bits + 31) / 32;
+    const uint32_t ms_len = emit_ms(ms_raw, msw, ms_bits, out);
+
+    uint32_t vlast;
+    const uint32_t Kv = walk(vlc_raw, vw, vlc_bits, 1, NULL, &vlast);
+    const uint32_t vs0 = Kv ? vlast + 7 : 0;
+    const uint32_t vposr = vs0 + 8 * ((vlc_bits - vs0) / 8);
+    const uint32_t vused = vlc_bits - vposr;
+    const uint32_t vacc = vused ? get_bits(vlc_raw, vw, vposr, vused) : 0;
+    const uint32_t nv = (vposr + Kv) >> 3;
+
+    uint32_t mel_pos = (uint32_t)mel_state[0];
+    int mel_acc = mel_state[1], mel_left = mel_state[2], mel_run = mel_state[3];
+    uint8_t mel_tail[2]; uint32_t mel_tail_n = 0;
+    if (mel_run > 0) {
+        mel_acc = (mel_acc << 1) | 1;
+        if (--mel_left == 0) { mel_tail[mel_tail_n++] = (uint8_t)mel_acc; mel_left = (mel_acc == 0xFF) ? 7 : 8; mel_acc = 0; }
+    }
+    uint32_t vextra = 0, vextra_byte = 0;
+    {
+        const int macc = mel_acc << mel_left;
+        const int mel_mask = (0xFF << mel_left) & 0xFF;
+        const int vlc_mask = 0xFF >> (8 - (int)vused);
+        if ((mel_mask | vlc_mask) != 0) {
+            const int fuse = macc | (int)vacc;
+            if ((((fuse ^ macc) & mel_mask) | ((fuse ^ (int)vacc) & vlc_mask)) == 0 && fuse != 0xFF && nv >= 1)
+                mel_tail[mel_tail_n++] = (uint8_t)fuse;
+            else { mel_tail[mel_tail_n++] = (uint8_t)macc; vextra = 1; vextra_byte = vacc; }
+        }
+    }
+    const uint32_t mel_len = mel_pos + mel_tail_n;
+    const uint32_t vcount = nv + vextra;
+    const uint32_t total = ms_len + mel_len + vcount + 1;
+    memcpy(out + ms_len, mel_bytes, mel_pos);
+    for (uint32_t i = 0; i < mel_tail_n; ++i) out[ms_len + mel_pos + i] = mel_tail[i];
+    emit_vlc(vlc_raw, vw, nv, out + total - 2);
+    if (vextra) out[total - 2 - nv] = (uint8_t)vextra_byte;
+    const uint32_t scup = mel_len + vcount + 1;
+    out[total - 1] = (uint8_t)(scup >> 4);
+    out[total - 2] = (uint8_t)((out[total - 2] & 0xF0) | (scup & 0xF));
     return (int32_t)total;
 }

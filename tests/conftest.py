@@ -26,6 +26,14 @@ def pytest_collection_modifyitems(config, items):
     # a GPU test on a box without a GPU is an error of the invocation, not a skip: fail loudly
     # only when the user selected -m gpu; in mixed runs they are skipped.
     if _gpu_available():
+        # on a GPU box the pins on the real reference are mandatory (product and oracle share the generated
+        # CxtVLC table, what vouches for it is ojph_* run live): a `needs_ref` skip would hide that oracle/_ref did not travel,
+        # so the skip is taken off and the test fails on loading the harness
+        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_harness.so")):
+            for it in items:
+                if "gpu" in it.keywords:
+                    it.own_markers = [m for m in it.own_markers
+                                      if not (m.name == "skipif" and "oracle/_ref" in str(m.kwargs.get("reason", "")))]
         return
     sel = config.getoption("-m") or ""
     if "gpu" in sel and "not gpu" not in sel:

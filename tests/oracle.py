@@ -319,11 +319,14 @@ def _bind_model():
     L.orc_ht_raw_streams.argtypes = [vp, u32, u32, u32, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), vp, vp]
     L.orc_ht_model_phase_b.restype = C.c_int32
     L.orc_ht_model_phase_b.argtypes = [vp, u32, vp, u32, vp, vp, vp]
+    L.orc_ht_model_phase_b2.restype = C.c_int32
+    L.orc_ht_model_phase_b2.argtypes = [vp, u32, vp, u32, vp, vp, vp]
     return L
 
 
-def ht_wave_model(sm, kmax):
-    """raw streams of the oracle encoder -> wave-parallel phase-B model -> bytes"""
+def ht_wave_model(sm, kmax, form=1):
+    """raw streams of the oracle encoder -> wave-parallel phase-B model -> bytes (form 1: walker + bitmaps, r01; form 2: speculative
+    windows, r03 -- what kernels_ht.hip runs)"""
     L = _bind_model()
     a = np.ascontiguousarray(sm, np.uint32)
     h, w = a.shape
@@ -337,5 +340,5 @@ def ht_wave_model(sm, kmax):
     nref = L.orc_ht_raw_streams(a.ctypes.data, kmax, w, h, ms.ctypes.data, msw, C.byref(mb),
                                 vl.ctypes.data, vw, C.byref(vb), mel.ctypes.data, st)
     out = np.zeros(nref + 64, np.uint8)
-    nm = L.orc_ht_model_phase_b(ms.ctypes.data, mb.value, vl.ctypes.data, vb.value, mel.ctypes.data, st, out.ctypes.data)
+    nm = (L.orc_ht_model_phase_b if form == 1 else L.orc_ht_model_phase_b2)(ms.ctypes.data, mb.value, vl.ctypes.data, vb.value, mel.ctypes.data, st, out.ctypes.data)
     return out[:nm].tobytes()
