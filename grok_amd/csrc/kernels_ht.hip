@@ -27,18 +27,6 @@
 #include "ht_vlc_tables.h"
 #include <type_traits>
 
-// A/B switches of round 3 (one build per setting, tools/k3_time.py): the neighbour exchange of phase A by lane shifts
-// instead of ds_bpermute, phase B as speculative windows instead of walker + bitmaps
-#ifndef GRK_HT_DPP
-#define GRK_HT_DPP 2
-#endif
-#ifndef GRK_HT_SPEC
-#define GRK_HT_SPEC 1
-#endif
-#ifndef GRK_HT_SKIP3
-#define GRK_HT_SKIP3 1
-#endif
-
 namespace grk_amd {
 
 namespace {
@@ -106,13 +94,9 @@ __device__ __forceinline__ void or_bits64(uint32_t* raw, uint32_t pos, uint64_t 
     const uint32_t top = ((uint32_t)(val >> 32) >> 1) >> (31 - sh);
     lds_or(w, (uint32_t)lo);
     lds_or(w + 1, (uint32_t)(lo >> 32));
-#if GRK_HT_SKIP3
     // the value reaches into a third word only when it is longer than 64 - sh bits: for most iterations of most blocks no
     // lane's does (a quad of 8-bit content has ~13 MagSgn bits), and a compare + scalar branch is a quarter of a ds_or
     if (__ballot(top != 0)) lds_or(w + 2, top);
-#else
-    lds_or(w + 2, top);
-#endif
 }
 __device__ __forceinline__ void or_bits32(uint32_t* raw, uint32_t pos, uint32_t val)
 {
@@ -238,23 +222,16 @@ __device__ __forceinline__ uint32_t quad_swap(uint32_t v)          // value of l
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
-__device__ __forceinline__ uint32_t bperm(int addr, uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v);
-}
 
-// Event walker shared by the MagSgn and VLC streams (oracle/ht_wave_model.c: walk()).
-// A window of 64 raw words is tested at once for positions where a stuffing event can happen
-// (8 resp. 7 consecutive ones; VLC additionally needs the previous byte > 0x8F); the candidates do
-// not depend on the byte phase, so all events inside one window are resolved without reloading.
-// Every event marks one OUTPUT byte index as "7 bits wide".
-template <bool VLC, bool MARK = true>
-__device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nwords, uint32_t nbits,
-                                                uint32_t* marks, uint32_t& last_p, int lane)
+// Counts the 7-bit bytes of the VLC stream (oracle/ht_wave_model.c: walk(), marks == NULL): VLC bytes are stored backwards
+// from the END of the block, so their number has to be known before the first one is placed.  A byte that follows a byte
+// > 0x8F and whose low 7 bits are ones is 7 bits wide.  A window of 64 raw words is tested at once for positions where that
+// can happen (7 consecutive ones behind such a byte); the candidates do not depend on the byte phase, so all events inside one
+// window are resolved without reloading.  Returns the number of events, last_p = the raw bit the last one starts at.
+__device__ __forceinline__ uint32_t count_vlc_events(const uint32_t* raw, uint32_t nwords, uint32_t nbits, uint32_t& last_p, int lane)
 {
     uint32_t K = 0, s = 0;
-    constexpr uint32_t need = VLC ? 7 : 8;
-    while (s + need <= nbits) {
+    while (s + 7u <= nbits) {
         const uint32_t B = s >> 5;
         const uint32_t i = B + lane;
         const uint32_t w0 = i < nwords ? raw[i] : 0u;
@@ -262,17 +239,11 @@ __device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nw
         const uint64_t hi = w0 | ((uint64_t)w1 << 32);
         uint64_t c = hi & (hi >> 1);
         c &= c >> 2;
-        uint32_t cand;
-        if constexpr (!VLC) {
-            c &= c >> 4;
-            cand = (uint32_t)c;
-        } else {
-            c &= c >> 3;
-            const uint32_t wm = i == 0 ? 0xFFFFFFFFu : (i - 1 < nwords ? raw[i - 1] : 0u);
-            const uint64_t lo = wm | ((uint64_t)w0 << 32);
-            const uint64_t pv = (lo >> 31) & ((lo >> 30) | (lo >> 29) | (lo >> 28));
-            cand = (uint32_t)c & (uint32_t)pv;
-        }
+        c &= c >> 3;
+        const uint32_t wm = i == 0 ? 0xFFFFFFFFu : (i - 1 < nwords ? raw[i - 1] : 0u);
+        const uint64_t lo = wm | ((uint64_t)w0 << 32);
+        const uint64_t pv = (lo >> 31) & ((lo >> 30) | (lo >> 29) | (lo >> 28));
+        const uint32_t cand = (uint32_t)c & (uint32_t)pv;
         const uint32_t wend = 32 * (B + 64);
         // resolve every event of this window; `s` (wave-uniform) is the next byte start
         while (true) {
@@ -286,9 +257,6 @@ __device__ __forceinline__ uint32_t walk_events(const uint32_t* raw, uint32_t nw
             const int L = __ffsll((long long)ballot) - 1;
             const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)hit, L);
             const uint32_t p = 32 * (B + (uint32_t)L) + (uint32_t)(__ffs((int)hl) - 1);
-            const uint32_t j = (p + K) >> 3;
-            const uint32_t mj = VLC ? j : j + 1;
-            if constexpr (MARK) { if (lane == 0) marks[mj >> 5] |= 1u << (mj & 31); }
             ++K; last_p = p;
             s = p + 15;
             if (s >= wend) break;
@@ -335,47 +303,24 @@ __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* fl
     }
 }
 
-// Output bytes j .. j + 3 (first byte in bits 0-7) of a raw bit stream whose 7-bit bytes are marked in the bitmap `mk`;
-// pre[w] = marks in the bitmap words before w, lsh = j & 31, lowm = (1 << lsh) - 1
-__device__ __forceinline__ uint32_t stuffed_dword(const uint32_t* raw, const uint32_t* mk, const uint16_t* pre, uint32_t j,
-                                                  uint32_t lsh, uint32_t lowm)
-{
-    const uint32_t mw = mk[j >> 5];
-    const uint32_t flags = (mw >> lsh) & 0xFu;
-    const uint32_t k = pre[j >> 5] + __popc(mw & lowm);
-    const uint32_t start = 8 * j - k;
-    const uint32_t sw = start >> 5;
-    const uint32_t win = __builtin_amdgcn_alignbit(raw[sw + 1], raw[sw], start & 31u);    // the 32 raw bits from `start`
-    if (flags == 0) return win;
-    uint32_t word = 0, o = 0;                     // a 7-bit byte among them: byte by byte (they take fewer than 32 bits)
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-        const uint32_t seven = (flags >> bb) & 1u;
-        word |= ((win >> o) & (0xFFu >> seven)) << (8 * bb);
-        o += 8u - seven;
-    }
-    return word;
-}
-
 // LDS words of the two raw streams, the two bitmaps, and what the raw streams may hold (bits) before the block is
 // handed to the fallback launch
-struct HtLds { uint32_t ms_words, vlc_words, mark_words, vmark_words, ms_cap_bits, vlc_cap_bits; };
+struct HtLds { uint32_t ms_words, vlc_words, ms_cap_bits, vlc_cap_bits; };
 
 // One code-block, by one wavefront.  li = index of the block in the launch's class list, tile = tile index.
 // H16: the Mallat planes hold int16 coefficients (reversible, 8-bit pixels; kernels_dwt.hip H16)
 template <bool IRREV, bool H16>
 __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, uint32_t tile, const HtLds& L, uint32_t class_id)
 {
-    const uint32_t ms_words = L.ms_words, vlc_words = L.vlc_words, mark_words = L.mark_words, vmark_words = L.vmark_words;
+    const uint32_t ms_words = L.ms_words, vlc_words = L.vlc_words;
     // LDS (sized by the launch, HtLds: for real content rather than the worst case, so that 24 waves fit a CU): raw MagSgn bits | raw VLC bits |
-    // 7-bit-byte bitmaps (phase B) aliased with the UVLC table (phase A) | MEL bytes
+    // UVLC table | MEL bytes.  (Phase B's windows read up to 65 words past the end of a raw stream: the table and the MEL bytes
+    // are 192 words -- what they read there belongs to lanes whose bytes are masked out.)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* ms_raw  = smem;
     uint32_t* vlc_raw = ms_raw + ms_words;
-    uint32_t* marks   = vlc_raw + vlc_words;
-    uint32_t* vmarks  = marks + mark_words;
-    uint2*    uvlc_l  = reinterpret_cast<uint2*>(marks);                         // 64 entries, phase A only
-    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(marks + max(mark_words + vmark_words + (mark_words + vmark_words + 1u) / 2u, 128u));   // 256 bytes
+    uint2*    uvlc_l  = reinterpret_cast<uint2*>(vlc_raw + vlc_words);           // 64 entries (phase A)
+    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(uvlc_l + 64);                 // 256 bytes
 
     const int lane = threadIdx.x;
     // this launch covers the blocks sel[0..sel_count) of every tile (all blocks when sel == nullptr)
@@ -408,7 +353,6 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     const uint32_t qx = lane & 31, half = lane >> 5;
     const bool odd = lane & 1;
     const bool isq0 = qx == 0, isq31 = qx == 31;
-    const int a_x32 = (lane ^ 32) << 2, a_up = ((lane - 1) & 63) << 2, a_dn = ((lane + 1) & 63) << 2;
     const uint32_t iters = (QH + 1) >> 1;
     const uint32_t stride_b = a.stride * EB;
     const char* srcb = src;
@@ -527,28 +471,17 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
 
         // ---- neighbourhood: exponents / significance of the sample row above, left quad's rho ----
         const uint32_t Bcur = __builtin_amdgcn_perm(C, C, 0x0C030C01u);         // lo16 = byte 1 (sample 1), hi16 = byte 3 (sample 3)
-#if GRK_HT_DPP >= 2
         // the row above lives in the other half of the wave: this iteration's upper quad row (half 0) takes the lower row of
         // the iteration before from lanes 32..63 (Bprev), the lower quad row (half 1) this iteration's upper row from lanes
         // 0..31 (Bcur).  v_permlane32_swap(Bprev, Bcur) leaves [Bprev.lo | Bcur.lo] and [Bprev.hi | Bcur.hi]: 8 cycles
         // against a ds_bpermute's 24 (profiles/r02_valu_issue_rates.txt)
         const auto sw32 = __builtin_amdgcn_permlane32_swap(Bprev, Bcur, false, false);
         const uint32_t above = bitop3<0xE4>((uint32_t)sw32[0], (uint32_t)sw32[1], hmask);     // half ? [.. | Bcur.lo] : [Bprev.hi | ..]
-#else
-        const uint32_t sel = bitop3<0xE4>(Bprev, Bcur, hmask);                  // half ? Bprev : Bcur
-        const uint32_t above = bperm(a_x32, sel);
-#endif
-#if GRK_HT_DPP >= 1
         // left / right neighbours by lane shifts (DPP wave_shr / wave_shl, 4 cycles each): the lanes at the ends of a quad row
         // (0 | 32, 31 | 63) are masked anyway
         const uint32_t above_l = dpp0<0x138, 0xF>(above) | q0m;                 // lane x reads x - 1
         const uint32_t above_r = dpp0<0x130, 0xF>(above) | q31m;                // lane x reads x + 1
         const uint32_t rho_l = dpp0<0x138, 0xF>(rho) & ~q0m;
-#else
-        const uint32_t above_l = bperm(a_up, above) | q0m;
-        const uint32_t above_r = bperm(a_dn, above) | q31m;
-        const uint32_t rho_l = bperm(a_up, rho) & ~q0m;
-#endif
         // max exponent of {w, n0, n1, e} = 32 - min of their leading-zero counts
         const uint32_t Y = __builtin_amdgcn_perm(above_l, above_r, 0x07060100u);   // lo16 = e, hi16 = w
         const u16x2 pm = __builtin_elementwise_min(__builtin_bit_cast(u16x2, above), __builtin_bit_cast(u16x2, Y));
@@ -720,11 +653,10 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     // final and stored as they are, otherwise everything before the first event is, the event's 7-bit byte is dealt with on
     // the spot and the next window starts behind it.  r02 found the events with a walker first, kept them in bitmaps with
     // prefix counts, and looked every output dword's start up afterwards (~2.2x the vector instructions of this form).
-#if GRK_HT_SPEC
     const uint32_t vw = vlc_words;
     // ---- B1: VLC bytes are stored backwards from the block's END, so their number comes first: the walker, counting only
     uint32_t vlast = 0;
-    const uint32_t Kv = walk_events<true, false>(vlc_raw, vw, vlc_bits, nullptr, vlast, lane);
+    const uint32_t Kv = count_vlc_events(vlc_raw, vw, vlc_bits, vlast, lane);
     const uint32_t vs0 = Kv ? vlast + 7 : 0;
     const uint32_t vposr = vs0 + 8 * ((vlc_bits - vs0) >> 3);
     const uint32_t vused = vlc_bits - vposr;
@@ -899,133 +831,6 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         if (vextra) out[total - 2 - nv] = (uint8_t)(nv == 0 ? ((vacc & 0xF0) | (scup & 0xF)) : vacc);
         out[total - 1] = (uint8_t)(scup >> 4);
     }
-#else
-    const uint32_t msw = ms_words, vw = vlc_words;
-#pragma unroll 1
-    for (uint32_t i = lane; i < mark_words + vmark_words; i += 64) marks[i] = 0;      // the UVLC table is dead now
-    __syncthreads();
-
-    // ---- B1: MagSgn events
-    uint32_t last_p = 0;
-    const uint32_t K = walk_events<false>(ms_raw, msw, ms_bits, marks, last_p, lane);
-    uint32_t pos, limit, nfull;
-    if (K && last_p + 15 > ms_bits) { pos = last_p + 8; limit = 7; nfull = (pos + K - 1) >> 3; }
-    else { const uint32_t s0 = K ? last_p + 15 : 0; pos = s0 + 8 * ((ms_bits - s0) >> 3); limit = 8; nfull = (pos + K) >> 3; }
-    const uint32_t rem = ms_bits - pos;
-    uint32_t ms_len, final_byte = 0, has_final = 0;
-    if (rem > 0) {
-        final_byte = get_bits(ms_raw, pos, rem) | ((((1u << (limit - rem)) - 1u) << rem) & 0xFF);
-        has_final = final_byte != 0xFF;
-        ms_len = nfull + has_final;
-    } else {
-        ms_len = (limit == 7) ? nfull - 1 : nfull;
-    }
-    const uint32_t ms_emit = min(nfull, ms_len);
-
-    // ---- B2: VLC events + tail
-    uint32_t vlast = 0;
-    const uint32_t Kv = walk_events<true>(vlc_raw, vw, vlc_bits, vmarks, vlast, lane);
-    const uint32_t vs0 = Kv ? vlast + 7 : 0;
-    const uint32_t vposr = vs0 + 8 * ((vlc_bits - vs0) >> 3);
-    const uint32_t vused = vlc_bits - vposr;
-    const uint32_t vacc = vused ? get_bits(vlc_raw, vposr, vused) : 0;
-    const uint32_t nv = (vposr + Kv) >> 3;
-
-    // ---- B3: MEL / VLC termination (terminate_mel_vlc :357-385), wave-uniform
-    if (mel.run > 0) mel_put_bit(mel, mel_buf, 1, lane == 0);
-    uint32_t vextra = 0;
-    {
-        const int macc = mel.acc << mel.left;
-        const int mel_mask = (0xFF << mel.left) & 0xFF;
-        const int vlc_mask = 0xFF >> (8 - (int)vused);
-        if ((mel_mask | vlc_mask) != 0) {
-            const int fuse = macc | (int)vacc;
-            if ((((fuse ^ macc) & mel_mask) | ((fuse ^ (int)vacc) & vlc_mask)) == 0 && fuse != 0xFF && nv >= 1) {
-                if (lane == 0 && mel.pos < 250) mel_buf[mel.pos] = (uint8_t)fuse;
-            } else {
-                if (lane == 0 && mel.pos < 250) mel_buf[mel.pos] = (uint8_t)macc;
-                vextra = 1;
-            }
-            mel.pos++;
-        }
-    }
-    const uint32_t mel_len = mel.pos;
-    const uint32_t vcount = nv + vextra;
-    const uint32_t total = ms_len + mel_len + vcount + 1;
-    const uint32_t scup = mel_len + vcount + 1;
-
-    // ---- the reserved bytes (16-byte aligned, order of arrival)
-    base_off = ((unsigned long long)__shfl((uint32_t)(base_off >> 32), 0) << 32) | __shfl((uint32_t)base_off, 0);
-    if (lane == 0) { a.lengths[gid] = total; a.offsets[gid] = base_off; }
-    if (base_off + total > a.arena_bytes || total > len_ub) {
-        if (lane == 0) atomicOr(reinterpret_cast<unsigned int*>(a.alloc), 1u);
-        return;
-    }
-    uint8_t* out = a.arena + base_off;
-    __syncthreads();
-
-    // ---- B4: how many 7-bit bytes lie before each word of the two bitmaps (one wave scan per 64 words)
-    uint16_t* const pre16 = reinterpret_cast<uint16_t*>(vmarks + vmark_words);      // [mark_words | vmark_words]
-    {
-        const uint32_t nmw = (ms_emit + 31u) >> 5, nvw = (nv + 31u) >> 5;
-        uint32_t kb = 0;
-#pragma unroll 1
-        for (uint32_t w0 = 0; w0 < nmw; w0 += 64) {
-            const uint32_t wi = w0 + lane;
-            const uint32_t cnt = wi < nmw ? __popc(marks[wi]) : 0u;
-            const uint32_t incl = wave_incl_scan(cnt);
-            if (wi < nmw) pre16[wi] = (uint16_t)(kb + incl - cnt);
-            kb += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        kb = 0;
-#pragma unroll 1
-        for (uint32_t w0 = 0; w0 < nvw; w0 += 64) {
-            const uint32_t wi = w0 + lane;
-            const uint32_t cnt = wi < nvw ? __popc(vmarks[wi]) : 0u;
-            const uint32_t incl = wave_incl_scan(cnt);
-            if (wi < nvw) pre16[mark_words + wi] = (uint16_t)(kb + incl - cnt);
-            kb += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-    }
-    __syncthreads();
-
-    // ---- B5: emission, one dword (4 output bytes) per lane and iteration.  Byte j starts at raw bit 8 j - (7-bit bytes
-    //      before it); with no 7-bit byte among the four -- all but ~1 dword in 64 -- the dword is 32 raw bits as they lie
-    const uint32_t lsh = (4u * lane) & 31u, lowm = (1u << lsh) - 1u;         // the lane's place in its bitmap word
-#pragma unroll 1
-    for (uint32_t j0 = 0; j0 < ms_emit; j0 += 256) {
-        const uint32_t j = j0 + 4 * lane;
-        if (j >= ms_emit) continue;
-        const uint32_t word = stuffed_dword(ms_raw, marks, pre16, j, lsh, lowm);
-        if (j + 4 <= ms_emit) *reinterpret_cast<uint32_t*>(out + j) = word;      // coalesced, aligned
-        else {
-#pragma unroll 1
-            for (uint32_t bb = 0; j + bb < ms_emit; ++bb) out[j + bb] = (uint8_t)(word >> (8 * bb));
-        }
-    }
-    if (has_final && lane == 0) out[ms_len - 1] = (uint8_t)final_byte;
-#pragma unroll 1
-    for (uint32_t i = lane; i < mel_len; i += 64) out[ms_len + i] = mel_buf[i < 250 ? i : 249];
-    // VLC bytes are stored in reverse order of generation (byte j at total - 2 - j); the first one carries Scup's low nibble
-#pragma unroll 1
-    for (uint32_t j0 = 0; j0 < nv; j0 += 256) {
-        const uint32_t j = j0 + 4 * lane;
-        if (j >= nv) continue;
-        uint32_t word = stuffed_dword(vlc_raw, vmarks, pre16 + mark_words, j, lsh, lowm);
-        if (j == 0) word = (word & ~0xFu) | (scup & 0xFu);
-        if (j + 4 <= nv) {
-            typedef uint32_t u32_any __attribute__((aligned(1)));
-            *reinterpret_cast<u32_any*>(out + total - 5 - j) = __builtin_bswap32(word);
-        } else {
-#pragma unroll 1
-            for (uint32_t bb = 0; j + bb < nv; ++bb) out[total - 2 - j - bb] = (uint8_t)(word >> (8 * bb));
-        }
-    }
-    if (lane == 0) {
-        if (vextra) out[total - 2 - nv] = (uint8_t)(nv == 0 ? ((vacc & 0xF0) | (scup & 0xF)) : vacc);
-        out[total - 1] = (uint8_t)(scup >> 4);
-    }
-#endif
 }
 
 template <bool IRREV, bool H16>
@@ -1088,7 +893,7 @@ static hipError_t upload_tables()
 // average for 8-bit content (Kmax <= 11), Kmax - 3 beyond; quantised (irreversible) coefficients: 8 bits whatever the
 // exponent (the default step sizes leave ~3 bits per sample of a 16-bit image); 10 VLC bits per quad.
 static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool capped, bool irrev, uint32_t& ms_words, uint32_t& vlc_words,
-                          uint32_t& mark_words, uint32_t& vmark_words, size_t& bytes, uint32_t* ms_cap = nullptr, uint32_t* vlc_cap = nullptr)
+                          size_t& bytes, uint32_t* ms_cap = nullptr, uint32_t* vlc_cap = nullptr)
 {
     const uint32_t per_sample = !capped ? kmax + 2u : irrev ? std::min(kmax + 2u, 8u) : std::min(kmax + 2u, kmax <= 11u ? 8u : kmax - 3u);
     const uint32_t ms_bits = samples * per_sample;
@@ -1097,17 +902,13 @@ static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool 
     if (vlc_cap) *vlc_cap = vlc_bits;
     ms_words = ((ms_bits + 31u) / 32u + 4u + 3u) & ~3u;             // slack: or_bits64 / window reads touch two words beyond;
     vlc_words = ((vlc_bits + 31u) / 32u + 4u + 3u) & ~3u;           // multiples of 4 words: cleared as uint4
-    mark_words = ((ms_bits + ms_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;   // one bit per stuffed output byte
-    vmark_words = ((vlc_bits + vlc_bits / 15u) / 8u + 2u + 31u) / 32u + 2u;
-    uint32_t mk = mark_words + vmark_words + (mark_words + vmark_words + 1u) / 2u;    // + 16-bit prefix counts per bitmap word
-    if (mk < 128u) mk = 128u;                                       // the UVLC table lives there during phase A
-    bytes = (size_t)(ms_words + vlc_words + mk) * 4u + 256u;
+    bytes = (size_t)(ms_words + vlc_words + 128u) * 4u + 256u;       // + the UVLC table (64 x 8 bytes) + 256 MEL bytes
 }
 
 size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax)
 {
-    uint32_t a, b, c, d; size_t n;
-    ht_lds_layout(samples, quads, kmax, false, false, a, b, c, d, n);
+    uint32_t a, b; size_t n;
+    ht_lds_layout(samples, quads, kmax, false, false, a, b, n);
     return n;
 }
 
@@ -1151,10 +952,10 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
         // capped LDS when that buys occupancy (waves per CU = 160 KiB / LDS per wave, at most 32), else worst-case buffers
         HtLds full{}, cap{};
         size_t shmem_full, shmem_cap;
-        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, false, false, full.ms_words, full.vlc_words, full.mark_words, full.vmark_words,
-                      shmem_full, &full.ms_cap_bits, &full.vlc_cap_bits);
-        ht_lds_layout(c.max_samples, c.max_quads, c.cap_kmax, true, a.irreversible != 0, cap.ms_words, cap.vlc_words, cap.mark_words,
-                      cap.vmark_words, shmem_cap, &cap.ms_cap_bits, &cap.vlc_cap_bits);
+        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, false, false, full.ms_words, full.vlc_words, shmem_full, &full.ms_cap_bits,
+                      &full.vlc_cap_bits);
+        ht_lds_layout(c.max_samples, c.max_quads, c.cap_kmax, true, a.irreversible != 0, cap.ms_words, cap.vlc_words, shmem_cap,
+                      &cap.ms_cap_bits, &cap.vlc_cap_bits);
         auto waves = [](size_t lds) { return std::min<size_t>(32, (160u << 10) / std::max<size_t>(lds, 1)); };
         const bool use_cap = a.ovf_list && waves(shmem_cap) > waves(shmem_full);
         const HtLds& L = use_cap ? cap : full;
