@@ -160,7 +160,9 @@ __device__ __forceinline__ void egress_px(int32_t (&c)[NC], bool irrev, bool mct
 //   int32 image planes (4 B/sample written + read back by K7) never exist.
 // H16 (reversible only): ll / mallat / out hold int16 coefficients -- half the bytes this HBM-bound kernel moves; a synthesised
 //   value that does not fit (only a stream no 8-bit image produces) raises bit 3 of *a.status and the decode is reported
-//   as out of range instead of returning other pixels.
+//   as out of range instead of returning other pixels.  "Fit" is the packed kernels' input range when the chain runs its
+//   larger levels packed (a.pk, set for the whole chain: a level too small or too odd for idwt53_pk_kernel comes here and
+//   may feed a packed one -- ADVICE r2).
 template <bool F97, int NC, int PXO, bool H16 = false>
 __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
 {
@@ -195,6 +197,9 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
     const PT* mp = reinterpret_cast<const PT*>(a.mallat) + (size_t)plane0 * a.m_pitch;
     PT* out = reinterpret_cast<PT*>(a.out) + (size_t)plane0 * a.out_pitch;
     uint32_t range = 0;
+    // what an LL written as int16 has to stay inside: the 16 bits, or -- when packed levels follow in this chain (a.pk) -- the
+    // packed kernels' input range (pk16.h); the bound is a power of two, so OR-ing the biased values finds any that is outside
+    const int32_t rbias = a.pk ? kPkDecodeBound + 1 : 32768;
     // pixel output: the window [wx0, wx1) x [wy0, wy1) of the tile (the whole tile unless a region is decoded), tight
     const uint32_t win_w = a.wx1 - a.wx0;
     const size_t comp_px = (size_t)win_w * (a.wy1 - a.wy0);
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
                     if (st_e) row[0] = (int16_t)vA[0];
                     if (st_o) row[1] = (int16_t)vB[0];
                 }
-                range |= (st_e ? (uint32_t)(vA[0] + 32768) : 0u) | (st_o ? (uint32_t)(vB[0] + 32768) : 0u);
+                range |= (st_e ? (uint32_t)(vA[0] + rbias) : 0u) | (st_o ? (uint32_t)(vB[0] + rbias) : 0u);
             } else if (st_e && st_o && !px) { T2 v; v.x = vA[0]; v.y = vB[0]; *reinterpret_cast<T2*>(row) = v; }
             else {
                 if (st_e) row[0] = vA[0];
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void idwt_level_kernel(IdwtLevelArgs a)
         if (fast) body(std::true_type{}); else body(std::false_type{});
     }
     if constexpr (H16 && PXO == 0) {
-        if (range > 0xFFFFu) atomicOr(a.status, 8u);
+        if (range > 2u * (uint32_t)rbias - 1u) atomicOr(a.status, 8u);
     }
 }
 

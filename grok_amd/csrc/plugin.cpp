@@ -211,6 +211,9 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
             const uint32_t ph = q < rs ? cp->prch_init[q] : cp->prch_init[rs - 1] >> (q - (rs - 1));
             const uint32_t ex = pw < 1 ? 1 : fl(pw), ey = ph < 1 ? 1 : fl(ph);
             if (ex > 15 || ey > 15) return false;
+            // (a precinct of ONE sample: exponent byte 0, which grk_amd_tile_params reads as "the default 15 / 15" -- the host
+            //  would cut 1 x 1 precincts where we built one; its CPU path takes such a list, as on the decode side)
+            if ((ex | (ey << 4)) == 0) return false;
             p.precinct_exp[r] = (uint8_t)(ex | (ey << 4));
         }
     }
@@ -299,6 +302,11 @@ int32_t encode_multi_tile(gra_cparameters* cp, EncodeJob& j)
     grk_amd_tile_params base;
     if (!params_from_cparameters(cp, j.w, j.h, j.comps, j.prec, base, true)) return -1;
     if (cp->prog_order < 0 || cp->prog_order > 4 || cp->cp_num_comments) return -1;
+    // what this writer does not write the host's way stays with the host (its CPU path): tile-part division (grk_compress -u),
+    // profiles / extensions (-Z ...: rsiz beyond the JPH flag the library sets for HT itself), size caps, rate or quality targets
+    if (cp->tp_on || (cp->rsiz & ~0x4000u) || cp->max_cs_size || cp->max_comp_size) return -1;
+    for (uint32_t l = 0; l < std::max<uint32_t>(cp->tcp_numlayers, 1u); ++l)
+        if (cp->tcp_rates[l] != 0.0 || cp->tcp_distoratio[l] != 0.0) return -1;
     grk_amd_image_layout im{cp->image_offset_x0, cp->image_offset_y0, cp->image_offset_x0 + j.w, cp->image_offset_y0 + j.h,
                             cp->tx0, cp->ty0, cp->t_width, cp->t_height};
     const uint32_t flags = (cp->writeTLM ? GRK_AMD_CS_TLM : 0u) | (cp->writePLT ? GRK_AMD_CS_PLT : 0u) |
@@ -367,7 +375,8 @@ bool read_stream_header(const char* path, StreamHeader& h)
             if (len == 1) { if (at + 16 > b.size()) return false; len = (uint64_t)be32(at + 8) << 32 | be32(at + 12); hdr = 16; }
             if (type == 0x6A703263u) { at += hdr; break; }                    // 'jp2c'
             if (len < hdr) return false;                                      // (0 = to the end of the file: no codestream box follows)
-            at += len;
+            if (len > b.size() - at) return false;                            // (a length from the file: never past what was read,
+            at += (size_t)len;                                                //  never wrapping back -- the lock is held here)
         }
     }
     if (at + 4 > b.size() || be16(at) != 0xFF4F) return false;
@@ -388,6 +397,17 @@ bool read_stream_header(const char* path, StreamHeader& h)
             h.overrides = true;
         }
         at += 2 + len;
+    }
+    // the first tile-part header as well: a COD / COC / QCD / QCC / RGN / POC there overrides the main header for that tile,
+    // and band_numbps (with it every block's missing_msbs) would come out of the wrong exponents
+    if (at + 4 <= b.size() && be16(at) == 0xFF90) {
+        at += 2 + be16(at + 2);
+        while (at + 4 <= b.size()) {
+            const uint32_t m = be16(at), len = be16(at + 2);
+            if (m == 0xFF93 || m < 0xFF00 || len < 2) break;
+            if (m == 0xFF52 || m == 0xFF53 || m == 0xFF5C || m == 0xFF5D || m == 0xFF5E || m == 0xFF5F) h.overrides = true;
+            at += 2 + len;
+        }
     }
     return have_qcd;
 }

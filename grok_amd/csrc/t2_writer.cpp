@@ -286,10 +286,27 @@ uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, 
         std::vector<uint8_t> body;
         Out cnt{nullptr, 0};
         packets(cnt, &body);
-        // (one marker segment: 18 packets of a 6-resolution RGB tile need < 100 bytes; the reference starts another
-        //  segment near 64 KiB, LengthMarkers.cpp:315-316)
-        o.u16(0xFF58); o.u16((uint32_t)(3 + body.size())); o.u8(0);
-        o.bytes(body.data(), body.size());
+        // Marker segments of at most 65535 bytes (Lplt is 16 bits: Lplt, Zplt and 65532 bytes of lengths), Zplt = 0, 1, ...;
+        // a packet's length (1-5 bytes, the last one without the continuation bit) is never split over two segments.
+        // 18 packets of a 6-resolution RGB tile need < 100 bytes; small precincts multiply that: the reference starts another
+        // segment near 64 KiB as well (LengthMarkers.cpp:313-331 -- its continuation segments lack the Zplt byte, a defect
+        // this writer does not copy: T.800 A.7.3).
+        size_t at = 0;
+        uint32_t z = 0;
+        do {
+            size_t end = at, next = at;
+            while (next < body.size()) {
+                size_t e = next;
+                while (body[e] & 0x80) ++e;                        // one length: bytes with the continuation bit, then one without
+                ++e;
+                if (e - at > 65532) break;
+                end = next = e;
+            }
+            if (z > 255) { o.ovf = true; break; }                  // (Zplt is one byte: > 16 MB of packet lengths in one tile-part does not fit the syntax)
+            o.u16(0xFF58); o.u16((uint32_t)(3 + (end - at))); o.u8((uint8_t)z++);
+            o.bytes(body.data() + at, end - at);
+            at = end;
+        } while (at < body.size());
     }
     o.u16(0xFF93);
     packets(o, nullptr);

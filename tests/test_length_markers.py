@@ -103,3 +103,47 @@ def test_progression_orders_sop_eph_are_the_reference_files(monkeypatch, order, 
         got = cshelp.oracle_codestream(px, 8, 3, 128, 64, flags=f)
         assert got == want, (order, csty, tlmplt)
     assert np.array_equal(R.decode(got, 3, 192, 256), px.astype(np.int32))
+
+
+@needs_ref
+def test_plt_longer_than_one_marker_segment_is_split(monkeypatch):
+    """Small precincts multiply the packets: 2048 x 2048 x 3 with 16 x 16 precincts has 65 280 of them, ~125 KB of packet
+    lengths -- more than Lplt (16 bits) can announce (the writer used to wrap the length).  The lengths go into
+    marker segments Zplt = 0, 1, ... of at most 65535 bytes, no length split between two; they add up to the tile-part's
+    packets; the reference's decoder reads the file back.  (The reference's own continuation segments lack the Zplt byte,
+    LengthMarkers.cpp:313-331 -- a defect -- so its -L file is not the yardstick here; without PLT the files are equal.)"""
+    from test_precincts_cpu import oracle_codestream_prc, exps_from_sizes
+    W = H = 2048
+    L = 3
+    px = synth.g2(3, H, W, 8, seed=5)
+    layout = G.ImageLayout.make(W, H, W, H)
+    sizes = [(16, 16)] * (L + 1)
+    monkeypatch.setenv("REF_PRECINCTS", ",".join("%d,%d" % s for s in sizes))
+    want, _ = R.encode(px, 8, TW=W, TH=H, numres=L + 1, mode=1)
+    prc = exps_from_sizes(sizes, L)
+    plain = oracle_codestream_prc(px, 8, L, layout, prc, 0)
+    assert plain == want
+    got = oracle_codestream_prc(px, 8, L, layout, prc, G.CS_PLT)
+    sot = got.index(b"\xff\x90")
+    psot = int.from_bytes(got[sot + 6:sot + 10], "big")
+    at, z, lens, segs = sot + 12, 0, [], 0
+    while got[at:at + 2] == b"\xff\x58":
+        lplt = int.from_bytes(got[at + 2:at + 4], "big")
+        assert 3 <= lplt <= 65535 and got[at + 4] == z
+        body = got[at + 5:at + 2 + lplt]
+        assert body[-1] < 0x80                                   # a segment ends with the end of a length
+        v = 0
+        for b in body:
+            v = (v << 7) | (b & 0x7F)
+            if b < 0x80:
+                lens.append(v)
+                v = 0
+        at += 2 + lplt
+        z += 1
+        segs += 1
+    assert segs >= 2 and got[at:at + 2] == b"\xff\x93"
+    assert len(lens) == 3 * sum((W >> (L - r)) // 16 * ((H >> (L - r)) // 16) for r in range(L + 1))
+    assert sum(lens) == sot + psot - (at + 2)                    # the packets are what is left of the tile-part
+    # the same packets as without PLT
+    assert got[at + 2:sot + psot] == plain[plain.index(b"\xff\x93") + 2:-2]
+    assert np.array_equal(R.decode(got, 3, H, W), px.astype(np.int32))
