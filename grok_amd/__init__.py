@@ -7,8 +7,8 @@ itself and raises loudly when the native library is missing.
 """
 from .capi import (TileParams, Block, CodedBlock, Context, lib, lib_path, NativeLibraryMissing,
                    tile_layout, write_codestream, write_tile_part, write_main_header, locate_tile_parts,
-                   CS_TLM, CS_PLT, CS_SOP, CS_EPH, CS_PROG, ImageLayout, layout_tiles, same_tile_geometry, write_codestream_layout)
+                   CS_TLM, CS_PLT, CS_SOP, CS_EPH, CS_PROG, ImageLayout, layout_tiles, same_tile_geometry, write_codestream_layout, Node, NODE_GATHER)
 
 __all__ = ["TileParams", "Block", "CodedBlock", "Context", "lib", "lib_path", "NativeLibraryMissing",
            "tile_layout", "write_codestream", "write_tile_part", "write_main_header", "locate_tile_parts", "CS_TLM", "CS_PLT", "CS_SOP", "CS_EPH", "CS_PROG",
-           "ImageLayout", "layout_tiles", "same_tile_geometry", "write_codestream_layout"]
+           "ImageLayout", "layout_tiles", "same_tile_geometry", "write_codestream_layout", "Node", "NODE_GATHER"]

@@ -133,6 +133,20 @@ def lib():
         L.grk_amd_write_main_header.argtypes = [PP, u32, u32, u32, vp, vp, u64]
         L.grk_amd_write_tile_part.restype = C.c_int64
         L.grk_amd_write_tile_part.argtypes = [PP, u32, u32, vp, vp, vp, u64]
+        if hasattr(L, "grk_amd_node_create"):
+            L.grk_amd_host_alloc.restype = vp
+            L.grk_amd_host_alloc.argtypes = [vp, u64]
+            L.grk_amd_host_free.argtypes = [vp, vp]
+            L.grk_amd_node_create.argtypes = [vp, u32, i32, C.POINTER(vp)]
+            L.grk_amd_node_destroy.argtypes = [vp]
+            L.grk_amd_node_size.restype = u32
+            L.grk_amd_node_size.argtypes = [vp]
+            L.grk_amd_node_ctx.restype = vp
+            L.grk_amd_node_ctx.argtypes = [vp, u32]
+            L.grk_amd_node_last_error.restype = C.c_char_p
+            L.grk_amd_node_last_error.argtypes = [vp]
+            L.grk_amd_node_encode_image.restype = C.c_int64
+            L.grk_amd_node_encode_image.argtypes = [vp, C.POINTER(ImageLayout), PP, vp, u32, vp, u64]
         L.grk_amd_locate_tile_parts.restype = C.c_int64
         L.grk_amd_locate_tile_parts.argtypes = [vp, u64, vp, vp, vp, u64, C.POINTER(i32)]
         PL = C.POINTER(ImageLayout)
@@ -320,6 +334,19 @@ class Context:
             self._check(self._L.grk_amd_fetch_coded(self._h, coded.ctypes.data, tot), "fetch_coded")
         return table, coded
 
+    def host_array(self, nbytes):
+        """A uint8 numpy array over pinned host memory (grk_amd_host_alloc): crosses the link in one DMA.  Freed with the
+        array (keep a reference while the context uses it)."""
+        p = self._L.grk_amd_host_alloc(self._h, int(nbytes))
+        if not p:
+            raise MemoryError("grk_amd_host_alloc(%d) failed" % nbytes)
+        buf = (C.c_uint8 * int(nbytes)).from_address(p)
+        arr = np.frombuffer(buf, np.uint8)
+        L = self._L
+        import weakref
+        weakref.finalize(buf, lambda: L.grk_amd_host_free(None, C.c_void_p(p)))     # (no context needed: it may be gone by then)
+        return arr
+
     def encode_image(self, layout, base, pixels, flags=0):
         """Whole image (C, H, W) of any tile layout -> codestream bytes (grk_amd_encode_image)."""
         px = np.ascontiguousarray(pixels)
@@ -454,3 +481,48 @@ class Context:
         n = C.c_uint32(0)
         ms = self._L.grk_amd_kernel_ms(self._h, which, C.byref(n))
         return ms, n.value
+
+
+NODE_GATHER = 0x80000000
+
+
+class Node:
+    """grk_amd_node: one image over several GPUs natively -- a context + a host thread per entry of `devices` (None: all of
+    the node; an entry may repeat: two contexts on one GPU), tiles t -> device t mod R, one codestream."""
+
+    def __init__(self, devices=None, verbose=False):
+        self._L = lib()
+        h = C.c_void_p()
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self._L.grk_amd_node_create(arr, len(devices), int(verbose), C.byref(h))
+        else:
+            rc = self._L.grk_amd_node_create(None, 0, int(verbose), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("grk_amd_node_create failed: %d" % rc)
+        self._h = h
+
+    @property
+    def size(self):
+        return int(self._L.grk_amd_node_size(self._h))
+
+    def encode_image(self, layout, base, pixels, flags=0, out=None):
+        px = pixels if isinstance(pixels, np.ndarray) and pixels.flags["C_CONTIGUOUS"] else np.ascontiguousarray(pixels)
+        cap = px.size * px.itemsize * 2 + (1 << 20)
+        if out is None:
+            out = np.empty(cap, np.uint8)
+        n = self._L.grk_amd_node_encode_image(self._h, C.byref(layout), C.byref(base), px.ctypes.data, flags, out.ctypes.data, out.size)
+        if n < 0:
+            raise RuntimeError("node_encode_image failed: %d (%s)" % (n, self._L.grk_amd_node_last_error(self._h).decode()))
+        return out[:n]
+
+    def close(self):
+        if self._h:
+            self._L.grk_amd_node_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -15,6 +15,7 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <thread>
 
 using namespace grk_amd;
 
@@ -39,6 +40,49 @@ struct DevBuf {
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     double total_ms = 0; uint32_t launches = 0;
+};
+
+// Pinned staging for the host-pointer entry points (pixels in, coded bytes / pixels out).  A buffer that IS pinned
+// (grk_amd_host_alloc, hipHostMalloc, a pinned torch tensor) goes over the link as it lies -- one DMA at the link's rate.
+// Pageable memory is moved through context-owned pinned chunks by kLanes copy threads, each double-buffered on its own
+// stream (a memcpy into / out of one chunk while the other chunk's DMA runs): the threads' memcpy rate adds up, where one
+// thread -- what a plain hipMemcpy of pageable memory amounts to -- is the limit otherwise.
+struct HostStage {
+    static constexpr size_t kChunk = 8u << 20;
+    static constexpr int kLanes = 4;
+    void* buf[kLanes][2] = {};
+    hipEvent_t ev[kLanes][2] = {};
+    hipEvent_t ev_in = nullptr, ev_out[kLanes] = {};
+    hipStream_t st[kLanes] = {};
+    bool ready = false;
+    hipError_t ensure()
+    {
+        if (ready) return hipSuccess;
+        hipError_t e = hipEventCreateWithFlags(&ev_in, hipEventDisableTiming);
+        for (int t = 0; t < kLanes && e == hipSuccess; ++t) {
+            e = hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_out[t], hipEventDisableTiming);
+            for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+                e = hipHostMalloc(&buf[t][k], kChunk, hipHostMallocDefault);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[t][k], hipEventDisableTiming);
+            }
+        }
+        ready = e == hipSuccess;
+        return e;
+    }
+    void release()
+    {
+        for (int t = 0; t < kLanes; ++t) {
+            if (st[t]) { (void)hipStreamSynchronize(st[t]); (void)hipStreamDestroy(st[t]); st[t] = nullptr; }
+            if (ev_out[t]) { (void)hipEventDestroy(ev_out[t]); ev_out[t] = nullptr; }
+            for (int k = 0; k < 2; ++k) {
+                if (buf[t][k]) { (void)hipHostFree(buf[t][k]); buf[t][k] = nullptr; }
+                if (ev[t][k]) { (void)hipEventDestroy(ev[t][k]); ev[t][k] = nullptr; }
+            }
+        }
+        if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
+        ready = false;
+    }
 };
 
 } // namespace
@@ -90,6 +134,11 @@ struct grk_amd_ctx {
     uint32_t last_ntiles = 0;
     uint64_t last_nblocks = 0;
     bool last_h16 = false;           // the latest encode left int16 coefficients in the Mallat planes
+    HostStage stage;                 // pinned chunks for pageable host buffers (copy_h2d / copy_d2h)
+    // grk_amd_decode_region: the table with the skipped blocks marked, in pinned memory the context owns (two, used in turn:
+    // the upload of one call is a DMA that may still run when the next call fills its table)
+    struct RegionTable { grk_amd_coded_block* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; } region_table[2];
+    uint32_t region_turn = 0;
     // timing
     bool timing = false;
     Timer timers[10];
@@ -113,6 +162,97 @@ int fail(grk_amd_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
 #ifndef GRK_AMD_OVERLAP_DEFAULT
 #define GRK_AMD_OVERLAP_DEFAULT 1
 #endif
+
+bool host_is_pinned(const void* p)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (plain malloc'ed memory: "invalid value")
+    return a.type == hipMemoryTypeHost;
+}
+
+// Host -> device, ordered after what the context's stream holds so far; on return the source may be reused (pageable) or the
+// copy is queued on the stream (pinned).  Device -> host likewise; the caller synchronises the stream before reading pinned
+// memory, pageable memory is complete on return.
+int copy_h2d(grk_amd_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (bytes < 2 * HostStage::kChunk || host_is_pinned(src)) {
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream), "upload");
+        return GRK_AMD_OK;
+    }
+    HostStage& hs = c->stage;
+    HIP_TRY(c, hs.ensure(), "alloc pinned staging");
+    HIP_TRY(c, hipEventRecord(hs.ev_in, c->stream), "record");
+    const size_t nchunks = (bytes + HostStage::kChunk - 1) / HostStage::kChunk;
+    hipError_t errs[HostStage::kLanes] = {};
+    std::thread th[HostStage::kLanes];
+    for (int t = 0; t < HostStage::kLanes; ++t)
+        th[t] = std::thread([&, t]() {
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(hs.st[t], hs.ev_in, 0);
+            int k = 0;
+            for (size_t i = (size_t)t; i < nchunks && e == hipSuccess; i += HostStage::kLanes, k ^= 1) {
+                const size_t off = i * HostStage::kChunk, n = std::min(HostStage::kChunk, bytes - off);
+                e = hipEventSynchronize(hs.ev[t][k]);                  // the DMA that last read this chunk (never recorded: returns at once)
+                if (e != hipSuccess) break;
+                std::memcpy(hs.buf[t][k], (const char*)src + off, n);
+                e = hipMemcpyAsync((char*)dst + off, hs.buf[t][k], n, hipMemcpyHostToDevice, hs.st[t]);
+                if (e == hipSuccess) e = hipEventRecord(hs.ev[t][k], hs.st[t]);
+            }
+            if (e == hipSuccess) e = hipEventRecord(hs.ev_out[t], hs.st[t]);
+            errs[t] = e;
+        });
+    for (auto& x : th) x.join();
+    for (int t = 0; t < HostStage::kLanes; ++t) {
+        HIP_TRY(c, errs[t], "staged upload");
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, hs.ev_out[t], 0), "join the copy streams");
+    }
+    return GRK_AMD_OK;
+}
+
+int copy_d2h(grk_amd_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (bytes < 2 * HostStage::kChunk || host_is_pinned(dst)) {
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream), "download");
+        return GRK_AMD_OK;
+    }
+    HostStage& hs = c->stage;
+    HIP_TRY(c, hs.ensure(), "alloc pinned staging");
+    HIP_TRY(c, hipEventRecord(hs.ev_in, c->stream), "record");
+    const size_t nchunks = (bytes + HostStage::kChunk - 1) / HostStage::kChunk;
+    hipError_t errs[HostStage::kLanes] = {};
+    std::thread th[HostStage::kLanes];
+    for (int t = 0; t < HostStage::kLanes; ++t)
+        th[t] = std::thread([&, t]() {
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(hs.st[t], hs.ev_in, 0);
+            // chunk i's DMA is queued before chunk i - 1 (the lane's previous one) is copied out of its pinned buffer
+            size_t prev_off = 0, prev_n = 0; int prev_k = -1, k = 0;
+            for (size_t i = (size_t)t; e == hipSuccess; i += HostStage::kLanes, k ^= 1) {
+                const bool more = i < nchunks;
+                if (more) {
+                    const size_t off = i * HostStage::kChunk, n = std::min(HostStage::kChunk, bytes - off);
+                    e = hipMemcpyAsync(hs.buf[t][k], (const char*)src + off, n, hipMemcpyDeviceToHost, hs.st[t]);
+                    if (e == hipSuccess) e = hipEventRecord(hs.ev[t][k], hs.st[t]);
+                    if (e != hipSuccess) break;
+                    if (prev_k >= 0) {
+                        e = hipEventSynchronize(hs.ev[t][prev_k]);
+                        if (e == hipSuccess) std::memcpy((char*)dst + prev_off, hs.buf[t][prev_k], prev_n);
+                    }
+                    prev_off = off; prev_n = n; prev_k = k;
+                } else {
+                    if (prev_k >= 0) {
+                        e = hipEventSynchronize(hs.ev[t][prev_k]);
+                        if (e == hipSuccess) std::memcpy((char*)dst + prev_off, hs.buf[t][prev_k], prev_n);
+                    }
+                    break;
+                }
+            }
+            errs[t] = e;
+        });
+    for (auto& x : th) x.join();
+    for (int t = 0; t < HostStage::kLanes; ++t) HIP_TRY(c, errs[t], "staged download");
+    return GRK_AMD_OK;
+}
 
 bool same_params(const grk_amd_tile_params& a, const grk_amd_tile_params& b)
 {
@@ -752,6 +892,11 @@ void grk_amd_destroy(grk_amd_ctx* c)
     if (c->ev_level0) (void)hipEventDestroy(c->ev_level0);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     for (DevBuf* b : {&c->dec_seg_dev}) b->release();
+    c->stage.release();
+    for (auto& rt : c->region_table) {
+        if (rt.p) (void)hipHostFree(rt.p);
+        if (rt.ev) (void)hipEventDestroy(rt.ev);
+    }
     delete c;
 }
 
@@ -872,14 +1017,25 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
     const bool fuse_out = g.p.num_levels >= 1 && bps <= 2 && c->fuse_egress;
     // region decode: the blocks no sample of the window depends on are not decoded, the synthesis covers what is needed
     RegionPlan plan;
-    std::vector<grk_amd_coded_block> wtable;
+    grk_amd_ctx::RegionTable* wt = nullptr;
     if (win) {
         if (ntiles != 1 || win->x0 >= win->x1 || win->y0 >= win->y1 || win->x1 > g.p.tile_w || win->y1 > g.p.tile_h)
             return fail(c, GRK_AMD_ERR_INVALID, "window outside the tile");
         if (!fuse_out) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "region decode needs at least one DWT level and 8-/16-bit pixels");
         plan = plan_region(g, *win);
         const uint32_t L = g.p.num_levels;
-        wtable.assign(table, table + (size_t)g.blocks_per_comp * g.p.num_comps);
+        const size_t nrows = (size_t)g.blocks_per_comp * g.p.num_comps;
+        wt = &c->region_table[c->region_turn++ & 1u];
+        if (!wt->ev) HIP_TRY(c, hipEventCreateWithFlags(&wt->ev, hipEventDisableTiming), "create event");
+        HIP_TRY(c, hipEventSynchronize(wt->ev), "wait for the table's last upload");       // (two calls ago: long done)
+        if (wt->cap < nrows) {
+            if (wt->p) (void)hipHostFree(wt->p);
+            wt->p = nullptr; wt->cap = 0;
+            HIP_TRY(c, hipHostMalloc((void**)&wt->p, nrows * sizeof(grk_amd_coded_block), hipHostMallocDefault), "alloc pinned table");
+            wt->cap = nrows;
+        }
+        grk_amd_coded_block* const wtable = wt->p;
+        std::memcpy(wtable, table, nrows * sizeof(grk_amd_coded_block));
         size_t i = 0;
         auto sat = [](uint32_t a, uint32_t b) { return a > b ? a - b : 0u; };
         for (uint32_t k = 0; k < g.p.num_comps; ++k)
@@ -902,12 +1058,12 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
                 }
                 ++i;
             }
-        table = wtable.data();
+        table = wtable;
     }
     const void* d_coded = coded;
     if (!coded_on_device) {
         HIP_TRY(c, c->dec_coded.ensure(coded_bytes + 64), "alloc coded staging");
-        HIP_TRY(c, hipMemcpyAsync(c->dec_coded.p, coded, coded_bytes, hipMemcpyHostToDevice, c->stream), "upload coded");
+        rc = copy_h2d(c, c->dec_coded.p, coded, coded_bytes); if (rc) return rc;
         d_coded = c->dec_coded.p;
     }
     const size_t px_bytes = win ? (size_t)g.p.num_comps * (win->x1 - win->x0) * (win->y1 - win->y0) * bps
@@ -930,6 +1086,7 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
         rc = p->reserved[0] ? run_t1_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p)
                             : run_ht_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p, h16);
         if (rc) return rc;
+        if (wt) HIP_TRY(c, hipEventRecord(wt->ev, c->stream), "record the table's upload");
         // with at least one DWT level and 8-/16-bit pixels the last level writes the pixels itself (K7 fused): the
         // int32 image planes (4 bytes per sample written and read back) never exist
         if (fuse_out) {
@@ -940,14 +1097,13 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
         }
     }
     if (!pixels_on_device) {
-        HIP_TRY(c, hipMemcpyAsync(pixels, d_px, px_bytes, hipMemcpyDeviceToHost, c->stream), "download pixels");
+        rc = copy_d2h(c, pixels, d_px, px_bytes); if (rc) return rc;
         rc = check_decode_status(c);
         if (rc == GRK_AMD_ERR_RANGE && h16)           // (synchronous call: the exact path, at once)
             return decode_impl(c, p, ntiles, table_in, coded, coded_bytes, coded_on_device, pixels, pixels_on_device, win, true);
         return rc;
     }
-    if (win) HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");      // the adapted table was uploaded from a local
-    return GRK_AMD_OK;
+    return GRK_AMD_OK;                 // (a window's adapted table lives in the context's pinned memory: nothing to wait for)
 }
 
 int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
@@ -1040,7 +1196,7 @@ int grk_amd_fetch_coded(grk_amd_ctx* c, uint8_t* dst, uint64_t nbytes)
     if (nbytes > c->arena.cap) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     { const int jr = join_side(c); if (jr) return jr; }
-    HIP_TRY(c, hipMemcpyAsync(dst, c->arena.p, nbytes, hipMemcpyDeviceToHost, c->stream), "fetch coded");
+    { const int rc = copy_d2h(c, dst, c->arena.p, nbytes); if (rc) return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     return GRK_AMD_OK;
 }
@@ -1103,7 +1259,7 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     const void* d_px = pixels;
     if (!on_device) {
         HIP_TRY(c, c->pixels.ensure(tile_bytes * ntiles), "alloc pixel staging");
-        HIP_TRY(c, hipMemcpyAsync(c->pixels.p, pixels, tile_bytes * ntiles, hipMemcpyHostToDevice, c->stream), "upload pixels");
+        rc = copy_h2d(c, c->pixels.p, pixels, tile_bytes * ntiles); if (rc) return rc;
         d_px = c->pixels.p;
     }
     const uint32_t nplanes = ntiles * g.p.num_comps;
@@ -1182,6 +1338,20 @@ int grk_amd_set_pipelining(grk_amd_ctx* c, int on)
     c->pipelining = on != 0 && c->side != nullptr && c->side2 != nullptr;
     c->pipe_depth = on >= 2 ? 3 : 2;
     return rc;
+}
+
+void* grk_amd_host_alloc(grk_amd_ctx* c, uint64_t bytes)
+{
+    if (!c || !bytes) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void grk_amd_host_free(grk_amd_ctx* c, void* p)
+{
+    if (p) { if (c) (void)hipSetDevice(c->device); (void)hipHostFree(p); }
 }
 
 int grk_amd_plane_sample_bytes(grk_amd_ctx* c, const grk_amd_tile_params* p, int decode, uint32_t* packed_levels)

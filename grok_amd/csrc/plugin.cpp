@@ -31,8 +31,14 @@
 
 namespace {
 
-grk_amd_ctx* g_ctx = nullptr;
+grk_amd_ctx* g_ctx = nullptr;          // the device Grok named (grk_plugin_init_info.deviceId): the single-file entry points
 bool g_verbose = false;
+// Every GPU the plugin may use: g_ctx first, then the node's other GPUs (GRK_AMD_PLUGIN_DEVICES=0,2,5 names them instead; an
+// entry may repeat -- two contexts on one GPU).  Grok's batch protocol (grk_compress.cpp:2024-2050: a directory of images,
+// each its own codestream) is where a node's GPUs run side by side with no exchange at all: file i goes to whichever device
+// is free.
+struct Dev { grk_amd_ctx* ctx = nullptr; std::mutex* mu = nullptr; std::mutex own; };
+std::vector<std::unique_ptr<Dev>> g_devs;
 // Self-check mode (grok.h:1719-1739, GRK_PLUGIN_STATE_DEBUG; set by the environment, GRK_AMD_PLUGIN_DEBUG=1, at
 // plugin_init): the host skips its DC shift, MCT and DWT, runs its own Tier-1 over the coefficients the plugin hands it
 // as "image" data, and compares every code-block (bytes, rates, pass counts, bounding boxes, step sizes) with the plugin's
@@ -41,23 +47,56 @@ uint32_t g_debug_state = GRA_PLUGIN_STATE_NO_DEBUG;
 std::mutex g_mu;
 
 // ---- the tile tree ------------------------------------------------------------------------------
+// 49 152 blocks of an 8K frame are 82 MB of gra_plugin_code_block: allocating, zeroing and filling that per frame (and as much
+// again for the coded bytes) cost more than the transfers.  A tree is therefore built once per geometry and kept (a few per
+// geometry: the batch pipeline holds up to three tiles at a time); a frame patches the three per-block fields that change.
+// The coded bytes live in pinned memory (grk_amd_host_alloc): the download is one DMA at the link's rate.
 struct TileOwner {
     gra_plugin_tile tile{};
+    grk_amd_tile_params params{};
     std::vector<gra_plugin_tile_component> comps;   std::vector<gra_plugin_tile_component*> comp_ptr;
     std::vector<gra_plugin_resolution> ress;        std::vector<gra_plugin_resolution*> res_ptr;
     std::vector<gra_plugin_band> bands;             std::vector<gra_plugin_band*> band_ptr;
     std::vector<gra_plugin_precinct> precs;         std::vector<gra_plugin_precinct*> prec_ptr;
     std::vector<gra_plugin_code_block> blocks;      std::vector<gra_plugin_code_block*> block_ptr;
-    std::vector<uint8_t> coded;
+    std::vector<grk_amd_coded_block> table;
+    uint8_t* coded = nullptr; size_t coded_cap = 0; bool coded_pinned = false;
+    ~TileOwner() { free_coded(); }
+    void free_coded()
+    {
+        if (coded) { if (coded_pinned) grk_amd_host_free(nullptr, coded); else std::free(coded); }
+        coded = nullptr; coded_cap = 0;
+    }
+    bool ensure_coded(grk_amd_ctx* ctx, size_t n)
+    {
+        if (n <= coded_cap) return true;
+        free_coded();
+        const size_t want = n + (n >> 3) + 4096;
+        coded = static_cast<uint8_t*>(grk_amd_host_alloc(ctx, want));
+        coded_pinned = coded != nullptr;
+        if (!coded) coded = static_cast<uint8_t*>(std::malloc(want));
+        if (!coded) return false;
+        coded_cap = want;
+        return true;
+    }
 };
 static_assert(offsetof(TileOwner, tile) == 0, "tile must be the first member: destroy() casts back");
 
-gra_plugin_tile* build_tree(const grk_amd_tile_params& p, const std::vector<grk_amd_block>& layout,
-                            const std::vector<grk_amd_coded_block>& table, std::vector<uint8_t>&& coded)
+std::mutex g_cache_mu;
+std::vector<TileOwner*> g_tile_cache;           // trees not in use, any geometry
+constexpr size_t kTileCacheMax = 8;
+
+// the geometry-dependent part of the tree: everything but compressedData / compressedDataLength / passes[0] of the blocks
+TileOwner* make_owner(const grk_amd_tile_params& p)
 {
+    const int64_t nbl = grk_amd_tile_num_blocks(&p);
+    if (nbl <= 0) return nullptr;
+    std::vector<grk_amd_block> layout((size_t)nbl);
+    if (grk_amd_tile_layout(&p, layout.data(), (uint64_t)nbl, nullptr) != nbl) return nullptr;
     auto* o = new TileOwner();
-    o->coded = std::move(coded);
+    o->params = p;
     const size_t nb = layout.size();
+    o->table.resize(nb);
     const uint32_t nres = p.num_levels + 1u;
     const size_t nbands_c = 3 * p.num_levels + 1;
     o->comps.resize(p.num_comps); o->comp_ptr.resize(p.num_comps);
@@ -71,19 +110,14 @@ gra_plugin_tile* build_tree(const grk_amd_tile_params& p, const std::vector<grk_
     size_t total_prec = 0;
     for (uint32_t r = 0; r < nres; ++r) total_prec += (size_t)nprec[r] * (r ? 3 : 1);
     o->precs.resize(total_prec * p.num_comps); o->prec_ptr.resize(o->precs.size());
-    o->blocks.resize(nb); o->block_ptr.resize(nb);
-    std::memset(o->blocks.data(), 0, nb * sizeof(gra_plugin_code_block));
+    o->blocks.resize(nb); o->block_ptr.resize(nb);     // (value-initialised: zeros)
     for (size_t i = 0; i < nb; ++i) {
         const grk_amd_block& b = layout[i];
         gra_plugin_code_block& cb = o->blocks[i];
         cb.x0 = b.x0; cb.y0 = b.y0; cb.x1 = b.x1; cb.y1 = b.y1;
         cb.numPix = (b.x1 - b.x0) * (b.y1 - b.y0);
-        cb.compressedData = o->coded.data() + table[i].offset;
-        cb.compressedDataLength = table[i].length;
         cb.numBitPlanes = 1;                     // T1HT::compress sets cblk->numbps = 1 (T1HT.cpp:123)
         cb.numPasses = 1;
-        cb.passes[0].rate = table[i].length ? table[i].length - 1 : 0;   // host uses rate+1 (plugin_bridge.cpp:230)
-        cb.passes[0].length = table[i].length;
         cb.passes[0].distortionDecrease = 0.0;
         o->block_ptr[i] = &cb;
     }
@@ -122,11 +156,88 @@ gra_plugin_tile* build_tree(const grk_amd_tile_params& p, const std::vector<grk_
     o->tile.decompress_flags = 0;
     o->tile.numComponents = p.num_comps;
     o->tile.tileComponents = o->comp_ptr.data();
-    return &o->tile;
+    return o;
 }
 
+// what a frame changes: where each block's bytes are and how many
+void patch_owner(TileOwner* o)
+{
+    const size_t nb = o->blocks.size();
+    for (size_t i = 0; i < nb; ++i) {
+        gra_plugin_code_block& cb = o->blocks[i];
+        const uint32_t len = o->table[i].length;
+        cb.compressedData = o->coded + o->table[i].offset;
+        cb.compressedDataLength = len;
+        cb.numBitPlanes = 1;                            // (a tree that served a decode comes back with the host's values)
+        cb.numPasses = 1;
+        cb.passes[0].rate = len ? len - 1 : 0;          // host uses rate + 1 (plugin_bridge.cpp:230)
+        cb.passes[0].length = len;
+    }
+}
+
+TileOwner* acquire_owner(const grk_amd_tile_params& p)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_tile_cache.size(); ++i)
+            if (std::memcmp(&g_tile_cache[i]->params, &p, sizeof p) == 0) {
+                TileOwner* o = g_tile_cache[i];
+                g_tile_cache.erase(g_tile_cache.begin() + (long)i);
+                return o;
+            }
+    }
+    return make_owner(p);
+}
+
+void release_owner(TileOwner* o)
+{
+    if (!o) return;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_tile_cache.size() < kTileCacheMax) { g_tile_cache.push_back(o); return; }
+        // full: the oldest goes (another geometry has taken over)
+        TileOwner* old = g_tile_cache.front();
+        g_tile_cache.erase(g_tile_cache.begin());
+        g_tile_cache.push_back(o);
+        o = old;
+    }
+    delete o;
+}
+
+void drop_tile_cache()
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (TileOwner* o : g_tile_cache) delete o;
+    g_tile_cache.clear();
+}
+
+// pixels of an image the plugin loads itself: pinned when a context exists (the upload is then one DMA at the link's rate)
+struct HostPixels {
+    uint8_t* p = nullptr; size_t n = 0; bool pinned = false;
+    HostPixels() = default;
+    HostPixels(const HostPixels&) = delete;
+    HostPixels& operator=(const HostPixels&) = delete;
+    ~HostPixels() { reset(); }
+    void reset()
+    {
+        if (p) { if (pinned) grk_amd_host_free(nullptr, p); else std::free(p); }
+        p = nullptr; n = 0;
+    }
+    bool alloc(size_t bytes)
+    {
+        reset();
+        p = g_ctx ? static_cast<uint8_t*>(grk_amd_host_alloc(g_ctx, bytes)) : nullptr;
+        pinned = p != nullptr;
+        if (!p) p = static_cast<uint8_t*>(std::malloc(bytes ? bytes : 1));
+        n = p ? bytes : 0;
+        return p != nullptr;
+    }
+    uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+};
+
 // ---- minimal PNM (P5/P6, binary) reader: enough for plugin_encode's "read params->infile" -----------
-bool read_pnm(const char* path, std::vector<uint8_t>& planar, uint32_t& w, uint32_t& h, uint32_t& comps, uint32_t& prec)
+bool read_pnm(const char* path, HostPixels& planar, uint32_t& w, uint32_t& h, uint32_t& comps, uint32_t& prec)
 {
     FILE* f = std::fopen(path, "rb");
     if (!f) return false;
@@ -157,13 +268,14 @@ bool read_pnm(const char* path, std::vector<uint8_t>& planar, uint32_t& w, uint3
     ok = std::fread(raw.data(), 1, raw.size(), f) == raw.size();
     std::fclose(f);
     if (!ok) return false;
-    planar.resize(raw.size());
+    if (!planar.alloc(raw.size())) return false;
+    uint8_t* const dst = planar.data();
     for (uint32_t c = 0; c < comps; ++c)
         for (size_t i = 0; i < n; ++i) {
-            if (bps == 1) planar[c * n + i] = raw[i * comps + c];
+            if (bps == 1) dst[c * n + i] = raw[i * comps + c];
             else {   // PNM 16-bit is big endian; the tile buffer is host endian
                 const uint8_t* s = &raw[(i * comps + c) * 2];
-                reinterpret_cast<uint16_t*>(planar.data())[c * n + i] = (uint16_t)((s[0] << 8) | s[1]);
+                reinterpret_cast<uint16_t*>(dst)[c * n + i] = (uint16_t)((s[0] << 8) | s[1]);
             }
         }
     return true;
@@ -227,7 +339,7 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
 //   host_step the host's callback: its own Tier-2 over our blocks, the file                  (host library)
 struct EncodeJob {
     std::string in, out;
-    std::vector<uint8_t> px;
+    HostPixels px;
     uint32_t w = 0, h = 0, comps = 0, prec = 0;
     grk_amd_tile_params p{};
     gra_plugin_tile* tile = nullptr;
@@ -237,13 +349,14 @@ struct EncodeJob {
 
 bool load_step(EncodeJob& j) { return read_pnm(j.in.c_str(), j.px, j.w, j.h, j.comps, j.prec); }
 
-bool gpu_step(gra_cparameters* cp, EncodeJob& j)
+bool gpu_step(gra_cparameters* cp, EncodeJob& j, Dev* dev = nullptr)
 {
     if (!params_from_cparameters(cp, j.w, j.h, j.comps, j.prec, j.p)) return false;
-    std::lock_guard<std::mutex> lk(g_mu);
-    j.tile = grk_amd_plugin_tile_create(g_ctx, &j.p, j.px.data(), 0);
+    grk_amd_ctx* const ctx = dev ? dev->ctx : g_ctx;
+    std::lock_guard<std::mutex> lk(dev ? *dev->mu : g_mu);
+    j.tile = grk_amd_plugin_tile_create(ctx, &j.p, j.px.data(), 0);
     if (!j.tile) return false;
-    std::vector<uint8_t>().swap(j.px);          // the pixels are on the device / coded: the host callback loads its own copy
+    j.px.reset();                               // the pixels are on the device / coded: the host callback loads its own copy
     // self-check mode: the "image" the host gets holds our sub-band coefficients (it skips its own DC shift / MCT / DWT and
     // codes them with its own Tier-1).  The image object is made by the host library itself (grk_image_new, resolved from
     // the process we were loaded into) so that the host can treat it as any other.
@@ -261,7 +374,7 @@ bool gpu_step(gra_cparameters* cp, EncodeJob& j)
         img->x0 = p.tile_x0; img->y0 = p.tile_y0; img->x1 = p.tile_x0 + j.w; img->y1 = p.tile_y0 + j.h;
         bool ok = true;
         for (uint32_t c = 0; c < j.comps && ok; ++c)
-            ok = img->comps[c].data && grk_amd_fetch_coefficients(g_ctx, c, img->comps[c].data, img->comps[c].stride) == GRK_AMD_OK;
+            ok = img->comps[c].data && grk_amd_fetch_coefficients(ctx, c, img->comps[c].data, img->comps[c].stride) == GRK_AMD_OK;
         if (!ok) { j.unref(&img->obj); return fail(); }
         j.dbg_image = img;
     }
@@ -291,7 +404,7 @@ int32_t host_step(gra_cparameters* cp, EncodeJob& j, gra_encode_callback cb)
 // which writes what the reference writes byte for byte (SIZ / COD / QCD / TLM / PLT / SOP / EPH, the progression orders,
 // precincts).  Only raw codestreams (.j2k / .j2c / .jpc): the JP2 boxes stay with the host.  Returns 0 (handled: the file
 // is written, the host's callback is not needed) or -1 (the host takes its CPU path).
-int32_t encode_multi_tile(gra_cparameters* cp, EncodeJob& j)
+int32_t encode_multi_tile(gra_cparameters* cp, EncodeJob& j, Dev* dev = nullptr)
 {
     if (g_debug_state & GRA_PLUGIN_STATE_DEBUG) return -1;
     const size_t dot = j.out.rfind('.');
@@ -315,8 +428,8 @@ int32_t encode_multi_tile(gra_cparameters* cp, EncodeJob& j)
     std::vector<uint8_t> out(j.px.size() * 2 + (1u << 20));
     int64_t n;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        n = grk_amd_encode_image(g_ctx, &im, &base, j.px.data(), flags, out.data(), out.size());
+        std::lock_guard<std::mutex> lk(dev ? *dev->mu : g_mu);
+        n = grk_amd_encode_image(dev ? dev->ctx : g_ctx, &im, &base, j.px.data(), flags, out.data(), out.size());
     }
     if (n <= 0) return -1;
     FILE* f = std::fopen(j.out.c_str(), "wb");
@@ -541,8 +654,13 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
             band_numbps.push_back((uint8_t)v);
         }
     }
-    gra_plugin_tile* tree = build_tree(tp, layout, slots, std::vector<uint8_t>(cap + sh.file_size + 64, 0));
-    for (auto* b : reinterpret_cast<TileOwner*>(tree)->block_ptr) { b->numBitPlanes = 0; b->numPasses = 0; }
+    TileOwner* const owner = acquire_owner(tp);
+    if (!owner || !owner->ensure_coded(g_ctx, cap + sh.file_size + 64)) { release_owner(owner); return clean(-1); }
+    std::memset(owner->coded, 0, cap + sh.file_size + 64);
+    owner->table = slots;
+    patch_owner(owner);
+    gra_plugin_tile* tree = &owner->tile;
+    for (auto* b : owner->block_ptr) { b->numBitPlanes = 0; b->numPasses = 0; }
     auto done = [&](int32_t rc) { grk_amd_plugin_tile_destroy(tree); return clean(rc); };
     info.tile = tree;
     // T2 alone cannot be asked for: without GRK_DECODE_POST_T1 the host never advances to the next tile-part
@@ -618,23 +736,22 @@ GRA_EXPORT gra_plugin_tile* grk_amd_plugin_tile_create(grk_amd_ctx* ctx, const g
                                                        const void* pixels, int on_device)
 {
     if (!ctx || !p || !pixels) return nullptr;
-    const int64_t nb = grk_amd_tile_num_blocks(p);
-    if (nb <= 0) return nullptr;
-    std::vector<grk_amd_block> layout((size_t)nb);
-    if (grk_amd_tile_layout(p, layout.data(), (uint64_t)nb, nullptr) != nb) return nullptr;
-    std::vector<grk_amd_coded_block> table((size_t)nb);
+    TileOwner* o = acquire_owner(*p);            // a kept tree of this geometry, or a new one
+    if (!o) return nullptr;
     uint64_t total = 0;
-    if (grk_amd_encode_tiles(ctx, p, 1, pixels, on_device, table.data(), &total) != GRK_AMD_OK) return nullptr;
-    for (const auto& t : table)
-        if (t.length > 65535) return nullptr;          // host keeps rates in uint16_t (plugin_bridge.cpp:174, D7)
-    std::vector<uint8_t> coded(total ? total : 1);
-    if (total && grk_amd_fetch_coded(ctx, coded.data(), total) != GRK_AMD_OK) return nullptr;
-    return build_tree(*p, layout, table, std::move(coded));
+    bool ok = grk_amd_encode_tiles(ctx, p, 1, pixels, on_device, o->table.data(), &total) == GRK_AMD_OK;
+    for (size_t i = 0; ok && i < o->table.size(); ++i)
+        if (o->table[i].length > 65535) ok = false;    // host keeps rates in uint16_t (plugin_bridge.cpp:174, D7)
+    ok = ok && o->ensure_coded(ctx, total ? total : 1);
+    ok = ok && (!total || grk_amd_fetch_coded(ctx, o->coded, total) == GRK_AMD_OK);      // (pinned: one DMA)
+    if (!ok) { release_owner(o); return nullptr; }
+    patch_owner(o);
+    return &o->tile;
 }
 
 GRA_EXPORT void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile)
 {
-    delete reinterpret_cast<TileOwner*>(tile);
+    release_owner(reinterpret_cast<TileOwner*>(tile));      // kept for the next frame of this geometry
 }
 
 GRA_EXPORT int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
@@ -721,8 +838,38 @@ GRA_EXPORT bool plugin_init(gra_plugin_init_info info)
         g_ctx = nullptr;
         return false;
     }
+    // the devices of the batch mode: the one Grok named first (it shares g_mu with the single-file entry points), then the
+    // node's other GPUs, or what GRK_AMD_PLUGIN_DEVICES lists after it (e.g. "0,0": a second context on GPU 0)
+    g_devs.clear();
+    g_devs.emplace_back(new Dev());
+    g_devs[0]->ctx = g_ctx; g_devs[0]->mu = &g_mu;
+    std::vector<int> more;
+    if (const char* e = std::getenv("GRK_AMD_PLUGIN_DEVICES")) {
+        bool first = true;
+        for (const char* q = e; *q;) {
+            char* end = nullptr;
+            const long v = std::strtol(q, &end, 10);
+            if (end == q) break;
+            if (!first) more.push_back((int)v);          // (the first entry is deviceId's place)
+            first = false;
+            q = *end == ',' ? end + 1 : end;
+        }
+    } else {
+        const int n = grk_amd_device_count();
+        for (int d = 0; d < n; ++d) if (d != info.deviceId) more.push_back(d);
+    }
+    for (int d : more) {
+        grk_amd_ctx* c = nullptr;
+        if (grk_amd_create(d, info.verbose ? 1 : 0, &c) != GRK_AMD_OK) continue;       // (a GPU that is not there is not used)
+        g_devs.emplace_back(new Dev());
+        g_devs.back()->ctx = c; g_devs.back()->mu = &g_devs.back()->own;
+    }
+    if (g_verbose) std::fprintf(stderr, "[grok_amd plugin] %zu device context(s)\n", g_devs.size());
     return true;
 }
+
+// (for tests and embedders: how many device contexts the batch mode spreads files over)
+GRA_EXPORT uint32_t grk_amd_plugin_num_devices(void) { return (uint32_t)g_devs.size(); }
 
 GRA_EXPORT int32_t plugin_encode(gra_cparameters* params, gra_encode_callback callback)
 {
@@ -774,11 +921,19 @@ GRA_EXPORT int32_t plugin_batch_encode(const char* input_dir, const char* output
         std::thread writer([&]() {
             while (auto j = coded.take()) host_step(cp, *j, callback);
         });
-        while (auto j = loaded.take()) {
-            if (g_batch_stop.load()) continue;          // (drain the reader)
-            if (!single_tile(cp, j->w, j->h)) { (void)encode_multi_tile(cp, *j); continue; }     // several tiles: the whole file here
-            if (gpu_step(cp, *j)) coded.put(std::move(j));
-        }
+        // one GPU stage per device context: whichever is free takes the next loaded file (files are independent: replicas,
+        // no exchange -- SURVEY.md 8(e) "single-tile configs: replicas only")
+        std::vector<std::thread> gpus;
+        for (size_t d = 0; d < g_devs.size(); ++d)
+            gpus.emplace_back([&, d]() {
+                Dev* dev = g_devs[d].get();
+                while (auto j = loaded.take()) {
+                    if (g_batch_stop.load()) continue;          // (drain the reader)
+                    if (!single_tile(cp, j->w, j->h)) { (void)encode_multi_tile(cp, *j, dev); continue; }     // several tiles: the whole file here
+                    if (gpu_step(cp, *j, dev)) coded.put(std::move(j));
+                }
+            });
+        for (auto& g : gpus) g.join();
         coded.close();
         reader.join();
         writer.join();

@@ -286,6 +286,9 @@ void grk_amd_plugin_batch_decode_counts(int32_t* gpu, int32_t* cpu, int32_t* fai
 gra_plugin_tile* grk_amd_plugin_tile_create(grk_amd_ctx* ctx, const grk_amd_tile_params* p,
                                             const void* pixels, int pixels_on_device);
 void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile);
+/* device contexts the batch mode spreads files over (plugin_init: the device Grok named + the node's other GPUs, or what the
+ * environment variable GRK_AMD_PLUGIN_DEVICES lists, e.g. "0,0": two contexts on GPU 0) */
+uint32_t grk_amd_plugin_num_devices(void);
 
 /* ---- the decode counterpart: a tile tree as the HOST fills it after its Tier-2 parse in
  * decompress_synch_plugin_with_host (plugin/plugin_bridge.cpp:63-76: per block compressedData,

@@ -106,6 +106,12 @@ const char* grk_amd_version(void);
 const char* grk_amd_last_error(grk_amd_ctx* ctx);
 /* use an externally owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own */
 int  grk_amd_set_stream(grk_amd_ctx* ctx, void* hip_stream);
+/* Pinned (page-locked) host memory for the buffers handed to the host-pointer entry points below (on_device = 0): such a
+ * buffer crosses the link in one DMA at the link's rate (~50 GB/s each way on MI355X hosts).  Any other host memory works
+ * too -- it is moved through context-owned pinned chunks by a few copy threads, at those threads' memcpy rate.  What the
+ * reference would do in grk_plugin_compress's image reader: the plugin's own loader reads files into such memory. */
+void* grk_amd_host_alloc(grk_amd_ctx* ctx, uint64_t bytes);
+void  grk_amd_host_free(grk_amd_ctx* ctx, void* p);
 
 /* ---- geometry (host only, no GPU needed) ---------------------------------------------------- */
 /* Number of code-blocks in one tile (all components). */
@@ -334,6 +340,28 @@ int64_t grk_amd_write_tile_part(const grk_amd_tile_params* p, uint32_t tile_inde
  * hopping over Psot.  Returns the number of tile-parts (entries beyond `cap` are counted, not stored) or < 0. */
 int64_t grk_amd_locate_tile_parts(const uint8_t* cs, uint64_t len, uint64_t* offsets, uint32_t* lengths,
                                   uint16_t* tile_index, uint64_t cap, int* used_tlm);
+
+/* ---- one image over the GPUs of a node (node.cpp) -------------------------------------------------------
+ * Replaces the reference's tile-level task pool (codestream/CodeStreamCompress.cpp:535-603: tiles are independent tasks whose
+ * tile-parts are written in index order) with one grk_amd_ctx + one host thread per device: tile t is coded on device
+ * t mod R, and the coded tile-parts are brought together into ONE codestream, byte-identical to the single-GPU file
+ *   - flags without GRK_AMD_NODE_GATHER ("parallel writers"): every worker fetches its own coded bytes over its own PCIe
+ *     link and runs Tier-2 for its own tiles; the calling thread writes main header (TLM from the sizes) + tile-parts + EOC;
+ *   - flags | GRK_AMD_NODE_GATHER: the workers' coded bytes are copied device to device (hipMemcpyPeer: xGMI between GPUs)
+ *     into the frame's writer device -- rotating with the frame number -- which brings them to the host in one piece and
+ *     runs Tier-2 for all tiles.
+ * `devices` lists the HIP devices to use (NULL / 0: all of the node); an entry may repeat (several contexts on one GPU).
+ * `pixels` is the whole image, component-major planar, tight, in host memory (pinned or not). */
+typedef struct grk_amd_node grk_amd_node;
+#define GRK_AMD_NODE_GATHER 0x80000000u
+int  grk_amd_device_count(void);
+int  grk_amd_node_create(const int* devices, uint32_t num_devices, int verbose, grk_amd_node** out);
+void grk_amd_node_destroy(grk_amd_node* node);
+uint32_t grk_amd_node_size(const grk_amd_node* node);
+grk_amd_ctx* grk_amd_node_ctx(grk_amd_node* node, uint32_t i);
+const char* grk_amd_node_last_error(grk_amd_node* node);
+int64_t grk_amd_node_encode_image(grk_amd_node* node, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                  const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,80 @@
+"""-m gpu: one image over several GPUs natively (grk_amd_node_*, node.cpp) -- one context + one host thread per device entry,
+tiles t -> device t mod R, ONE codestream.  A one-GPU box runs every code path with the device list {0, 0} (two contexts on one
+GPU; three for the uneven split): the files equal the single-context file and Grok's own, for both forms of the exchange
+(parallel writers / device-to-device gather on a rotating writer)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import grok_amd as G
+import gpuutil as U
+import refharness as R
+import synth
+
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not shipped")
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("W,H,TW,TH,L,off,prec,irrev,flags", [
+    (640, 512, 256, 256, 4, (0, 0), 8, False, 0),                                   # 3 x 2 tiles, ragged right column
+    (700, 530, 200, 150, 3, (33, 17), 8, False, G.CS_TLM | G.CS_PLT),               # offsets, 1000-pitch-like tiling, markers
+    (512, 384, 128, 128, 3, (0, 0), 12, True, 0),                                   # ICT + 9/7, 12 tiles
+])
+def test_node_image_equals_single_context_image(devices, W, H, TW, TH, L, off, prec, irrev, flags):
+    px = synth.g2(3, H, W, prec, seed=W + len(devices))
+    layout = G.ImageLayout.make(W, H, TW, TH, offset=off)
+    base = G.TileParams.make(1, 1, 3, prec, L, irreversible=irrev)
+    want = U.ctx().encode_image(layout, base, px, flags)
+    node = G.Node(devices)
+    try:
+        assert node.size == len(devices)
+        assert bytes(node.encode_image(layout, base, px, flags)) == want
+        # the gather form, three frames: the writer device rotates, the file does not change
+        for _ in range(3):
+            assert bytes(node.encode_image(layout, base, px, flags | G.NODE_GATHER)) == want
+    finally:
+        node.close()
+
+
+@needs_ref
+def test_node_cfg4_shape_equals_grk_compress():
+    """BASELINE configs[3]'s shape at a quarter of its size: 4096 x 4096 as 16 tiles of 1024 x 1024 over two contexts, pixels
+    in pinned host memory == the file Grok's CPU encoder writes."""
+    W = H = 4096
+    T, L = 1024, 5
+    px = synth.g2(3, H, W, 8)
+    R.lib(threads=os.cpu_count() or 1)
+    want, _ = R.encode(px, 8, TW=T, TH=T, numres=L + 1, mode=1)
+    node = G.Node([0, 0])
+    try:
+        hp = U.ctx().host_array(px.size).reshape(px.shape)
+        hp[...] = px
+        layout = G.ImageLayout.make(W, H, T, T)
+        base = G.TileParams.make(1, 1, 3, 8, L)
+        for fl in (0, G.NODE_GATHER):
+            got = node.encode_image(layout, base, hp, fl)
+            assert len(got) == len(want) and hashlib.md5(got).hexdigest() == hashlib.md5(want).hexdigest()
+        del hp
+    finally:
+        node.close()
+
+
+def test_host_pixels_pinned_and_pageable_give_the_same_blocks():
+    """grk_amd_encode_tiles / fetch_coded with host pointers: pinned memory (grk_amd_host_alloc) crosses the link as it lies,
+    pageable memory goes through the context's pinned chunks on four copy threads (> 16 MiB) -- same table, same bytes."""
+    c = U.ctx()
+    W = H = 3072                       # 28 MB of pixels: the staged path
+    px = synth.g2(3, H, W, 8, seed=9)
+    p = G.TileParams.make(W, H, 3, 8, 5)
+    t0, c0 = c.encode_host(p, px)
+    hp = c.host_array(px.size).reshape(px.shape)
+    hp[...] = px
+    t1, c1 = c.encode_host(p, hp)
+    assert np.array_equal(t0["length"], t1["length"])
+    got0, got1 = U.split_blocks(t0, c0), U.split_blocks(t1, c1)
+    assert got0 == got1
+    back = c.decode_host(p, t0, c0)
+    assert np.array_equal(back[0], px)

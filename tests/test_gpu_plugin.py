@@ -337,3 +337,39 @@ def test_plugin_tile_decode_round_trip(Cn, H, W, prec, L):
         assert np.array_equal(out, px)
     finally:
         Lp.grk_amd_plugin_tile_destroy(tile)
+
+
+@needs_ref
+def test_batch_compress_spreads_files_over_device_contexts(tmp_path):
+    """The batch mode runs one GPU stage per device context (plugin.cpp: the device Grok named + the node's other GPUs; here
+    GRK_AMD_PLUGIN_DEVICES=0,0,0 -- three contexts on the one GPU of the box -- so that the multi-device code path runs): every
+    output file == the pure-CPU encode of its image.  In a process of its own: the plugin's device list is fixed at plugin_init."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, os, ctypes as C
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import numpy as np, refharness as R, synth, grok_amd as G
+assert R.plugin_load() == 1 and R.plugin_init(0) == 1
+P = C.CDLL(os.path.join(os.path.dirname(G.lib_path()), "libgrokj2k_plugin.so"))
+P.grk_amd_plugin_num_devices.restype = C.c_uint32
+assert P.grk_amd_plugin_num_devices() == 3, P.grk_amd_plugin_num_devices()
+ind, outd = sys.argv[1], sys.argv[2]
+imgs = {}
+for i in range(9):
+    Cn, H, W = (3, 256 + 64 * (i %% 3), 320) if i %% 2 == 0 else (1, 200, 500 + 10 * i)
+    px = synth.g2(Cn, H, W, 8, seed=300 + i)
+    name = "f%%02d" %% i
+    R.write_pnm(os.path.join(ind, name + (".pgm" if Cn == 1 else ".ppm")), px, 8)
+    imgs[name] = px
+assert R.plugin_batch_compress(ind, outd, numres=6) == len(imgs)
+for name, px in imgs.items():
+    cpu, _ = R.encode(px, 8, numres=6, mode=1)
+    assert open(os.path.join(outd, name + ".j2k"), "rb").read() == cpu, name
+print("ok")
+''' % {"tests": os.path.dirname(os.path.abspath(__file__)), "root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir(); outd.mkdir()
+    env = dict(os.environ, GRK_AMD_PLUGIN_DEVICES="0,0,0")
+    r = subprocess.run([sys.executable, "-c", script, str(ind), str(outd)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
