@@ -30,6 +30,7 @@ struct grk_amd_node {
         uint8_t* pin_px = nullptr; size_t pin_px_cap = 0;        // tile pixels of one geometry group, pinned
         uint8_t* pin_coded = nullptr; size_t pin_coded_cap = 0;  // coded bytes on the host, pinned
         void* gather = nullptr; size_t gather_cap = 0;           // device memory: where the other workers' bytes land when this one is the writer
+        hipStream_t copy = nullptr;                              // this worker's device-to-device / download stream
         std::vector<uint8_t> parts;                              // this worker's tile-parts, one after the other
     };
     std::vector<Worker> w;
@@ -79,6 +80,11 @@ extern "C" int grk_amd_node_create(const int* devices, uint32_t n, int verbose, 
         nd->w[i].device = devs[i];
         const int rc = grk_amd_create(devs[i], verbose, &nd->w[i].ctx);
         if (rc != GRK_AMD_OK) { grk_amd_node_destroy(nd); return rc; }
+        if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&nd->w[i].copy, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            grk_amd_node_destroy(nd);
+            return GRK_AMD_ERR_NO_DEVICE;
+        }
     }
     // device-to-device copies between distinct GPUs go over xGMI once peer access is on (without it they pass through the host)
     for (size_t i = 0; i < devs.size(); ++i)
@@ -100,6 +106,7 @@ extern "C" void grk_amd_node_destroy(grk_amd_node* nd)
         if (w.pin_px) grk_amd_host_free(w.ctx, w.pin_px);
         if (w.pin_coded) grk_amd_host_free(w.ctx, w.pin_coded);
         if (w.gather) { (void)hipSetDevice(w.device); (void)hipFree(w.gather); }
+        if (w.copy) { (void)hipSetDevice(w.device); (void)hipStreamDestroy(w.copy); }
         if (w.ctx) grk_amd_destroy(w.ctx);
     }
     delete nd;
@@ -190,8 +197,11 @@ extern "C" int64_t grk_amd_node_encode_image(grk_amd_node* nd, const grk_amd_ima
                     // device to device into the writer's buffer (the fetch above has joined the encode's streams)
                     auto& ww = nd->w[writer];
                     if (gather_at[r] + coded_used + total > gather_at[r + 1]) { rc = GRK_AMD_ERR_OVERFLOW; break; }
-                    if (total && hipMemcpyPeer((char*)ww.gather + gather_at[r] + coded_used, ww.device, grk_amd_coded_device_ptr(w.ctx),
-                                               w.device, total) != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                    // (a device-to-device copy returns before it is done: waited for here, the next group's encode writes the same arena)
+                    if (total && (hipSetDevice(w.device) != hipSuccess ||
+                                  hipMemcpyPeerAsync((char*)ww.gather + gather_at[r] + coded_used, ww.device, grk_amd_coded_device_ptr(w.ctx),
+                                                     w.device, total, w.copy) != hipSuccess ||
+                                  hipStreamSynchronize(w.copy) != hipSuccess)) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
                 } else {
                     if (!pin_ensure(w.ctx, w.pin_coded, w.pin_coded_cap, coded_used + total)) {
                         // (growing: what is there has been consumed by the tile-parts already written)
@@ -233,10 +243,12 @@ extern "C" int64_t grk_amd_node_encode_image(grk_amd_node* nd, const grk_amd_ima
         if (!pin_ensure(ww.ctx, ww.pin_coded, ww.pin_coded_cap, host_total + 16)) return GRK_AMD_ERR_NOMEM;
         if (hipSetDevice(ww.device) != hipSuccess) return GRK_AMD_ERR_NO_DEVICE;
         for (uint32_t r = 0; r < R; ++r)
-            if (used[r] && hipMemcpy(ww.pin_coded + host_at[r], (const char*)ww.gather + gather_at[r], used[r], hipMemcpyDeviceToHost) != hipSuccess) {
+            if (used[r] && hipMemcpyAsync(ww.pin_coded + host_at[r], (const char*)ww.gather + gather_at[r], used[r], hipMemcpyDeviceToHost,
+                                          ww.copy) != hipSuccess) {
                 (void)hipGetLastError();
                 return GRK_AMD_ERR_NO_DEVICE;
             }
+        if (hipStreamSynchronize(ww.copy) != hipSuccess) { (void)hipGetLastError(); return GRK_AMD_ERR_NO_DEVICE; }
         std::vector<grk_amd_coded_block> all;
         for (uint32_t t = 0; t < ntiles; ++t) {
             const uint64_t at = host_at[t % R];

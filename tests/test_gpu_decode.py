@@ -695,20 +695,22 @@ def test_decode_int16_planes_and_their_range_check():
 
 
 def test_mixed_packed_and_unpacked_inverse_levels_keep_the_packed_range():
-    """a 1024 x 1024 tile with 5 levels runs its inverse levels 4 and 3 (64 and 128 columns) through the generic
+    """a 1024 x 1024 tile with 6 levels runs its inverse levels 5, 4 and 3 (32 .. 128 columns) through the generic
     int16 kernel and levels 2 .. 0 through the packed one, whose sums need inputs inside +-2047.  Coefficients all inside that
-    range (the block decoder raises nothing) whose synthesis grows past it -- LL = 2000 and every detail band of the three
-    coarsest levels = +2000: the synthesised LL reaches ~10^4 -- used to pass the generic level's "fits int16" check and wrap in
-    the packed sums.  Now the level that writes such an LL raises the range flag: the synchronous decode repeats itself with
-    int32 planes (same pixels as with int32 planes from the start), the asynchronous one reports GRK_AMD_ERR_RANGE."""
+    range (the block decoder raises nothing; 2^(Kmax - 2), the largest magnitude both decoders accept everywhere, in every band
+    of the five coarsest resolutions) whose synthesis grows past it -- the 128 x 128 LL reaches 2560 -- used to pass the generic
+    level's "fits int16" check.  Now the level that writes such an LL raises the range flag: the synchronous decode repeats
+    itself with int32 planes (same pixels as with int32 planes from the start, and as the oracle's inverse chain), the
+    asynchronous one reports GRK_AMD_ERR_RANGE."""
     W = H = 1024
-    L = 5
+    L = 6
     p = G.TileParams.make(W, H, 1, 8, L)
     blocks, _ = G.tile_layout(p)
     planes = np.zeros((1, H, W), np.int32)
     for b in blocks:
-        if b.res <= 3:
-            planes[0, b.py:b.py + (b.y1 - b.y0), b.px:b.px + (b.x1 - b.x0)] = 2000
+        if b.res <= L - 2:
+            planes[0, b.py:b.py + (b.y1 - b.y0), b.px:b.px + (b.x1 - b.x0)] = 1 << (b.kmax - 2)
+    assert np.abs(planes).max() <= 2047 and np.abs(O.dwt53_inv(planes[0, :128, :128].copy(), L - 3)).max() > 2047
     c = U.ctx()
     d_m = U.upload_planes(planes, p)
     c.stage_ht_encode(p, 1, d_m.data_ptr())
@@ -719,7 +721,6 @@ def test_mixed_packed_and_unpacked_inverse_levels_keep_the_packed_range():
         want = c.decode_host(p, table, coded)[0]
     finally:
         c.set_decode_planes16(True)
-    # the oracle's inverse chain on the same coefficients
     px = np.clip(O.dwt53_inv(planes[0], L) + 128, 0, 255).astype(np.uint8)
     assert np.array_equal(want[0], px)
     assert np.array_equal(c.decode_host(p, table, coded)[0], want)
