@@ -95,7 +95,8 @@ struct grk_amd_ctx {
     std::string err;
     // working set
     DevBuf pixels, p0, p1, llA, llB, blockdesc, lengths, offsets, arena, flag;
-    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels, dec_work;
+    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels, dec_work, dec_vraw, dec_vbase;
+    std::vector<uint32_t> h_vbase;                          // HT decode: [nblocks] scratch offsets, then the list of blocks with data
     // geometry cache
     grk_amd_tile_params gp{};
     bool have_geom = false;
@@ -642,13 +643,27 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
     uint32_t max_len = 0;
+    // per block: where K5p puts its un-stuffed MEL / VLC bits (scratch words); behind that the blocks that have data at all --
+    // K5p's waves and K5a's lanes (a window's skipped blocks and absent blocks cost neither a wave nor a lane of a serial chain)
+    c->h_vbase.resize(2 * nblocks);
+    uint64_t vwords = 0;
+    uint32_t nactive = 0;
     for (uint64_t i = 0; i < nblocks; ++i) {
         max_len = std::max(max_len, table[i].length);
         if (table[i].offset > coded_bytes || table[i].length > coded_bytes - table[i].offset)
             return fail(c, GRK_AMD_ERR_INVALID, "block table row points outside the coded buffer");
+        c->h_vbase[i] = (uint32_t)vwords;
+        if (table[i].length) {
+            vwords += ht_dec_scratch_words(table[i].length);
+            c->h_vbase[nblocks + nactive++] = (uint32_t)i;
+        }
     }
     if (max_len > (48u << 10)) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "code-block longer than 48 KiB");
+    if (vwords > 0xFFFFFFF0ull) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "more than 8 GB of coded data in one call");
     static_assert(sizeof(HtDecBlock) == sizeof(grk_amd_coded_block), "decode table rows are grk_amd_coded_block");
+    HIP_TRY(c, c->dec_vraw.ensure((vwords + 64) * 4), "alloc VLC / MEL scratch");
+    HIP_TRY(c, c->dec_vbase.ensure(2 * nblocks * 4), "alloc scratch index");
+    HIP_TRY(c, hipMemcpyAsync(c->dec_vbase.p, c->h_vbase.data(), (nblocks + nactive) * 4, hipMemcpyHostToDevice, c->stream), "upload scratch index");
     HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
     HIP_TRY(c, c->dec_quads.ensure(nblocks * 1024 * 4), "alloc quad info");
     HIP_TRY(c, c->dec_mslen.ensure(nblocks * 4), "alloc ms lengths");
@@ -660,6 +675,8 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     a.blocks = (const HtBlockDesc*)c->dec_desc.p; a.blocks_per_tile = bpt; a.nblocks = (uint32_t)nblocks; a.ncomp = g.p.num_comps;
     a.coded = (const uint8_t*)d_coded; a.coded_bytes = coded_bytes;
     a.quads = (uint32_t*)c->dec_quads.p; a.ms_len = (uint32_t*)c->dec_mslen.p; a.status = (unsigned int*)c->flag.p;
+    a.vraw = (uint32_t*)c->dec_vraw.p; a.vbase = (const uint32_t*)c->dec_vbase.p;
+    a.active = nactive == nblocks ? nullptr : (const uint32_t*)c->dec_vbase.p + nblocks; a.nactive = nactive;
     a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.irreversible = g.p.irreversible;
     a.h16 = h16 ? 1 : 0;
@@ -876,7 +893,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     drain_timers(c);
     for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
                       &c->offsets, &c->arena, &c->flag, &c->dec_desc, &c->dec_table, &c->dec_quads, &c->dec_mslen,
-                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->ht_sel})
+                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->dec_vraw, &c->dec_vbase, &c->ht_sel})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }

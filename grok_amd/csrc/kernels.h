@@ -102,6 +102,10 @@ struct HtDecArgs {
     const HtBlockDesc* blocks;                 // geometry per block of one tile; inv_step = decode scale (irreversible)
     uint32_t blocks_per_tile, nblocks, ncomp;
     const uint8_t* coded; uint64_t coded_bytes; // device buffer holding every block's bytes
+    uint32_t* vraw;                            // K5p -> K5a: the un-stuffed MEL and VLC bits of every block (scratch)
+    const uint32_t* vbase;                     // [nblocks] first word of each block's part of vraw (ht_dec_scratch_words apart)
+    const uint32_t* active;                    // [nactive] the blocks with data, K5p's waves / K5a's lanes (null: all nblocks)
+    uint32_t nactive;
     uint32_t* quads;                           // [nblocks][32*32] K5a -> K5b: CxtVLC entry | (u_q + 1) << 16 per quad
     uint32_t* ms_len;                          // [nblocks] MagSgn bytes (0xFFFFFFFF: block rejected)
     unsigned int* status;                      // bit 2: a block was rejected; bit 3: a value did not fit the 16-bit planes
@@ -115,6 +119,8 @@ struct HtDecArgs {
     uint32_t max_refine_bytes;                 // largest such segment
 };
 hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s);
+// scratch words K5p may write / K5a may read for a block of `length` coded bytes (MEL + VLC bits + padding)
+inline uint32_t ht_dec_scratch_words(uint32_t length) { return length / 2u + 16u; }
 
 // ---- K8: Part-1 (EBCOT) block decoder + dequantisation (kernels_t1dec.hip) -----------------------
 struct T1DecArgs {

@@ -30,246 +30,24 @@ namespace grk_amd {
 
 namespace {
 
-__device__ uint16_t g_vlc_dec[2048];         // [0..1023] first quad row, [1024..2047] others; index (c_q<<7)|7 bits
-
 constexpr uint32_t kQuadStride = 32;         // quads per row in the per-block quad-info array (blocks <= 64 wide)
 constexpr uint32_t kQuadWords  = 32 * 32;
 
-// ---- K5a --------------------------------------------------------------------------------------------
-// Both readers keep the aligned 8-byte word under the cursor and the next one in registers (fetched one
-// word ahead of use, so the serial decoder never waits for memory) and refill FOUR bytes at a time with
-// straight-line SWAR code: which bytes are bit-stuffed depends only on the byte read just before, so the
-// four widths are computed at once and the bytes packed with three shifts.  One refill check per quad
-// pair is enough for both (a pair consumes <= 31 VLC bits and <= 18 MEL bits).
-struct WordWindow {
-    const uint8_t* lo; const uint8_t* hi;      // readable range [lo, hi) of the coded buffer
-    __device__ __forceinline__ uint64_t load(const uint8_t* p) const
-    {
-        // an aligned word that overlaps the buffer lies in a mapped page (words do not straddle pages);
-        // its bytes outside [lo, hi) are never consumed (the readers count the bytes they may use)
-        return (p + 8 > lo && p < hi) ? *reinterpret_cast<const uint64_t*>(p) : 0ull;
-    }
-};
+// ---- K5p --------------------------------------------------------------------------------------------
+// Un-stuffs the VLC and the MEL segment of every block into raw bit arrays (global scratch, HtDecArgs::vraw), ONE
+// WAVEFRONT PER BLOCK: which bytes carry 7 bits depends only on the byte read just before, so the widths are independent,
+// a wave prefix sum places every byte, and K5a's serial chain reads plain bits -- r02's K5a spent ~70 of its ~250
+// instructions per quad pair on refilling two bit-stuffed byte readers with SWAR code.
+//   VLC (ojph_block_decoder.cpp rev_read / rev_init): read backwards from D[lcup - 3]; first the upper nibble of D[lcup - 2]
+//       (3 bits if its low three are ones, else 4); a byte that follows a byte > 0x8F carries 7 bits when its low 7 are ones.
+//       Stored LSB first: stream bit k is bit (k & 31) of word k >> 5; zeros behind the end.
+//   MEL (mel_read / mel_init): forward from D[lcup - scup], scup - 1 bytes, the last one with its low nibble set; a byte after
+//       0xFF carries 7 bits (its MSB is dropped).  Consumed MSB first, so stored MSB first: stream bit k is bit 31 - (k & 31)
+//       of word k >> 5; ones behind the end.
+// Layout of a block's scratch: [mel_words(scup)] MEL words, then the VLC words (+ 3 words of padding each).
+__host__ __device__ __forceinline__ uint32_t mel_words(uint32_t scup) { return ((scup - 1u) * 8u + 31u) / 32u + 3u; }
+__host__ __device__ __forceinline__ uint32_t vlc_words(uint32_t scup) { return ((scup - 2u) * 8u + 4u + 31u) / 32u + 3u; }
 
-struct RevReader : WordWindow {   // VLC: backward, LSB first; after a byte > 0x8F a byte whose 7 LSBs are ones carries 7 bits
-    const uint8_t* bp;                         // next byte to read (addresses go down)
-    uint64_t cur, prv;                         // the aligned word holding *bp and the word below it
-    int left;                                  // bytes of the segment still unread; beyond it zeros are fed
-    uint64_t acc; int n; uint32_t unstuff;
-    __device__ __forceinline__ void init(const uint8_t* first, int count, const uint8_t* lo_, const uint8_t* hi_)
-    {
-        lo = lo_; hi = hi_; bp = first; left = count;
-        const uint8_t* wp = first - ((uintptr_t)first & 7u);
-        cur = load(wp); prv = load(wp - 8);
-    }
-    __device__ __forceinline__ void fill()
-    {
-        if (n > 32) return;
-        const uint32_t o = (uint32_t)((uintptr_t)bp & 7u);
-        // bytes bp-3 .. bp as a little-endian word: byte 3 (= *bp) is read first, so byte i follows byte i+1
-        uint32_t w = o >= 3 ? (uint32_t)(cur >> (8 * (o - 3))) : (uint32_t)((cur << (8 * (3 - o))) | (prv >> (8 * (o + 5))));
-        const int v = left < 0 ? 0 : (left > 4 ? 4 : left);
-        w &= (uint32_t)(0xFFFFFFFF00000000ull >> (8 * v));                          // bytes past the segment read as 0
-        const uint32_t l7 = w & 0x7F7F7F7Fu;
-        const uint32_t g = (l7 + 0x70707070u) & w & 0x80808080u;                    // byte > 0x8F
-        const uint32_t e = (l7 + 0x01010101u) & 0x80808080u;                        // 7 LSBs all ones
-        const uint32_t st = e & ((g >> 8) | (unstuff << 31));                       // byte carries 7 bits
-        unstuff = (g >> 7) & 1u;
-        const uint32_t s3 = st >> 31, s2 = (st >> 23) & 1u, s1 = (st >> 15) & 1u;
-        const uint32_t sh2 = 8u - s3, sh1 = sh2 + 8u - s2, sh0 = sh1 + 8u - s1;
-        const uint32_t val = (w >> 24) | (((w >> 16) & 0xFFu) << sh2) | (((w >> 8) & 0xFFu) << sh1) | ((w & 0xFFu) << sh0);
-        acc |= (uint64_t)val << n;
-        n += 32 - (int)__builtin_popcount(st);
-        bp -= 4; left -= 4;
-        if (o < 4) {                                       // moved into the word below: fetch the next one ahead
-            cur = prv;
-            prv = load(bp - ((uintptr_t)bp & 7u) - 8);
-        }
-    }
-    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)acc; }      // valid after fill(): > 32 bits
-    __device__ __forceinline__ void skip(uint32_t nb) { acc >>= nb; n -= (int)nb; }
-};
-
-struct MelReader : WordWindow {   // MEL: forward, MSB first; byte after 0xFF carries 7 bits; last byte |= 0x0F; then 0xFF
-    const uint8_t* bp; uint64_t cur, nxt; int left; uint32_t unstuff;
-    uint64_t tmp; int bits;             // un-stuffed bits, next bit at the MSB
-    int k;
-    int run;                            // what is left of the current run, in the reference's coding (:196-235, :1101-1111):
-                                        // 2 * (zero events) + 1 if it ends with a one, 2 * (zero events - 1) otherwise
-    __device__ __forceinline__ void init(const uint8_t* p, int size, const uint8_t* lo_, const uint8_t* hi_)
-    {
-        lo = lo_; hi = hi_; bp = p; left = size;
-        const uint8_t* wp = p - ((uintptr_t)p & 7u);
-        cur = load(wp); nxt = load(wp + 8);
-        unstuff = 0; tmp = 0; bits = 0; k = 0; run = -1;
-        fill();
-        (void)event(false);                                // run < 0: decodes the first run
-    }
-    __device__ __forceinline__ void fill()
-    {
-        if (bits > 32) return;
-        const uint32_t o = (uint32_t)((uintptr_t)bp & 7u);
-        uint32_t w = o <= 4 ? (uint32_t)(cur >> (8 * o)) : (uint32_t)((cur >> (8 * o)) | (nxt << (64 - 8 * o)));   // byte 0 first
-        const int v = left < 0 ? 0 : (left > 4 ? 4 : left);
-        const uint32_t valid = (uint32_t)((1ull << (8 * v)) - 1ull);
-        w = (w & valid) | ~valid;                                                   // past the segment: 0xFF
-        w |= (left >= 1 && left <= 4) ? 0x0Fu << (8 * (left - 1)) : 0u;             // the segment's last byte
-        const uint32_t ff = ((w & 0x7F7F7F7Fu) + 0x01010101u) & w & 0x80808080u;    // byte == 0xFF
-        const uint32_t st = (ff << 8) | (unstuff << 7);                             // byte follows a 0xFF: 7 bits, MSB dropped
-        unstuff = ff >> 31;
-        w &= ~st;
-        const uint32_t f0 = (st >> 7) & 1u, f1 = (st >> 15) & 1u, f2 = (st >> 23) & 1u, f3 = st >> 31;
-        const uint32_t h0 = 24u + f0, h1 = h0 - 8u + f1, h2 = h1 - 8u + f2, h3 = h2 - 8u + f3;
-        const uint32_t val = ((w & 0xFFu) << h0) | (((w >> 8) & 0xFFu) << h1) | (((w >> 16) & 0xFFu) << h2) | ((w >> 24) << h3);
-        tmp |= (uint64_t)val << (32 - bits);
-        bits += 32 - (int)h3;
-        bp += 4; left -= 4;
-        if (o >= 4) {
-            cur = nxt;
-            nxt = load(bp - ((uintptr_t)bp & 7u) + 8);
-        }
-    }
-    // One MEL event if `need` (:1101-1111): returns 1 if the run ends here with a one.  The decode of the next run sits
-    // behind a branch the whole wave skips when no lane has used its run up: in dense blocks (contexts rarely zero) and in
-    // empty ones (long runs) that is most of the time, and every instruction on this chain costs the wave ~8 cycles.
-    __device__ __forceinline__ uint32_t event(bool need)
-    {
-        run -= need ? 2 : 0;
-        const uint32_t ev = run == -1;
-        if (run < 0) {                                                              // decode the next run (:196-235)
-            const uint32_t e = (k < 8 ? 0x22111000u >> (4 * k) : 0x54332u >> (4 * (k - 8))) & 0xFu;   // MEL exponents (:196)
-            const uint32_t top = (uint32_t)(tmp >> 32);
-            const bool one = (top >> 31) != 0;             // '1': 2^e zero events; '0' + e bits: that many, then a one
-            run = one ? (int)((2u << e) - 2u) : (int)((((top >> (31u - e)) & ((1u << e) - 1u)) << 1) | 1u);
-            k = one ? (k < 12 ? k + 1 : 12) : (k > 0 ? k - 1 : 0);
-            const uint32_t used = one ? 1u : e + 1u;
-            tmp <<= used; bits -= (int)used;
-        }
-        return ev;
-    }
-};
-
-// UVLC prefix: '1' -> 1, '01' -> 2, '001' -> 3 + 1-bit suffix, '000' -> 5 + 5-bit suffix (:706-716), looked up by
-// the three next bits in a table packed into one 64-bit constant: entry = prefix_len | suffix_len << 2 | base << 5
-__device__ __forceinline__ void uvlc_prefix(uint32_t bits, uint32_t& pl, uint32_t& sl, uint32_t& base)
-{
-    const uint32_t d = (uint32_t)(0x21422167214221B7ull >> (8 * (bits & 7u))) & 0xFFu;
-    pl = d & 3u; sl = (d >> 2) & 7u; base = d >> 5;
-}
-
-__global__ void ht_dec_vlc_kernel(HtDecArgs a)
-{
-    // CxtVLC decode tables in LDS: one dependent lookup per quad sits on the serial chain
-    __shared__ uint16_t tbl_l[2048];
-    for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x)
-        reinterpret_cast<uint32_t*>(tbl_l)[i] = reinterpret_cast<const uint32_t*>(g_vlc_dec)[i];
-    __syncthreads();
-    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= a.nblocks) return;
-    const HtDecBlock in = a.table[blk];
-    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
-    uint32_t* qi = a.quads + (size_t)blk * kQuadWords;
-    const uint32_t w = bd.w, h = bd.h;
-    const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
-    const uint32_t mm = in.missing_msbs;
-    const uint8_t* D = a.coded + in.offset;
-    // (blocks with refinement passes: their SigProp / MagRef segment follows the cleanup segment)
-    const int lcup = (int)in.length - (a.refine ? (int)a.refine[blk].x : 0);
-
-    if (in.length == 0) return;                            // absent (K5b writes the zeros) or outside the decoded region
-    bool bad = mm > 29 || lcup < 2;
-    int scup = 0;
-    if (!bad) {
-        scup = ((int)D[lcup - 1] << 4) + (D[lcup - 2] & 0xF);
-        bad = scup < 2 || scup > lcup || scup > 4079;
-    }
-    if (bad) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; return; }
-    a.ms_len[blk] = (uint32_t)(lcup - scup);
-
-    const uint8_t* buf_hi = a.coded + a.coded_bytes;
-    MelReader mel;
-    mel.init(D + (lcup - scup), scup - 1, a.coded, buf_hi);
-    RevReader vlc;
-    {
-        const uint32_t d0 = D[lcup - 2];
-        vlc.init(D + (lcup - 3), scup - 2, a.coded, buf_hi);
-        vlc.acc = d0 >> 4; vlc.n = 4 - (((d0 >> 4) & 7u) == 7u ? 1 : 0);
-        vlc.unstuff = (d0 | 0xFu) > 0x8Fu;
-    }
-    const uint32_t NP = (QW + 1) >> 1;  // quad pairs per row
-    uint64_t sa = 0;                     // significance of the bottom sample row of the quad row above: bit x
-    // One quad row; the first row has its own contexts, table and u-value rules, so it gets its own instance.
-    auto quad_row = [&](auto first_tag, uint32_t qy) -> bool {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const uint16_t* tbl = tbl_l + (FIRST ? 0 : 1024);
-        uint32_t* qrow = qi + qy * kQuadStride;
-        uint64_t sw = sa, sn = 0;
-        uint32_t west = 0, chain = 0;    // sample 2 * q0 - 1 of the row above; the west quad's contribution to c_q
-        for (uint32_t q0 = 0; q0 < QW; q0 += 2) {
-            vlc.fill();                  // > 32 bits: a quad pair consumes at most 7 + 7 + 17
-            mel.fill();                  // > 18 bits: at most three runs of 6 bits
-            const bool has1 = q0 + 1 < QW;
-            const uint32_t up = (uint32_t)sw;            // samples 2 * q0 ... of the row above
-            const uint32_t nb0 = ((up << 1) | west) & 0xFu, nb1 = (up >> 1) & 0xFu;   // nw, n, ne, nf of each quad
-            west = (up >> 3) & 1u; sw >>= 4;
-            // ---- quad q0
-            uint32_t c = chain;
-            if (!FIRST) c |= ((nb0 & 3u) ? 1u : 0u) | ((nb0 & 12u) ? 4u : 0u);
-            uint32_t t0 = tbl[(c << 7) | (vlc.peek() & 0x7Fu)];
-            uint32_t ev = mel.event(c == 0);
-            t0 = (c == 0 && !ev) ? 0u : t0;
-            vlc.skip(t0 & 7u);
-            const uint32_t rho0 = (t0 >> 4) & 0xFu;
-            chain = FIRST ? ((rho0 & 1u) | (rho0 >> 1)) : ((((rho0 >> 2) | (rho0 >> 3)) & 1u) << 1);
-            // ---- quad q0 + 1 (absent when the row has an odd number of quads)
-            c = chain;
-            if (!FIRST) c |= ((nb1 & 3u) ? 1u : 0u) | ((nb1 & 12u) ? 4u : 0u);
-            uint32_t t1 = tbl[(c << 7) | (vlc.peek() & 0x7Fu)];
-            ev = mel.event(has1 && c == 0);
-            t1 = (!has1 || (c == 0 && !ev)) ? 0u : t1;
-            vlc.skip(t1 & 7u);
-            const uint32_t rho1 = (t1 >> 4) & 0xFu;
-            chain = FIRST ? ((rho1 & 1u) | (rho1 >> 1)) : ((((rho1 >> 2) | (rho1 >> 3)) & 1u) << 1);
-            const uint32_t sb = ((rho0 >> 1) & 1u) | (((rho0 >> 3) & 1u) << 1) | (((rho1 >> 1) & 1u) << 2) | (((rho1 >> 3) & 1u) << 3);
-            sn = (sn >> 4) | ((uint64_t)sb << 60);
-            // ---- u values of the pair (:668-777), written without branches: prefix0, prefix1, suffix0, suffix1,
-            // each present only if its quad has u_off set
-            // (r02: the same by ONE look-up in a 256-entry LDS table -- u_off of both quads + six bits -> prefix / suffix
-            //  lengths and bases -- removed ~25 instructions from the chain and was 3 % SLOWER: the look-up's latency sits on
-            //  the chain as well)
-            const uint32_t uo0 = (t0 >> 3) & 1u, uo1 = (t1 >> 3) & 1u;
-            uint32_t add = 1, onebit = 0;
-            uint32_t v = vlc.peek();
-            uint32_t pl, sl, base, pl2, sl2, base2;
-            uvlc_prefix(v, pl, sl, base);
-            pl = uo0 ? pl : 0; sl = uo0 ? sl : 0; base = uo0 ? base : 0;
-            v >>= pl;
-            if (FIRST) {                                           // both quads: a MEL event picks the variant
-                const uint32_t both = uo0 & uo1;
-                const uint32_t e2 = mel.event(both != 0);
-                add = (both & e2) ? 3u : 1u;
-                onebit = both & (e2 ^ 1u) & (pl > 2 ? 1u : 0u);    // second quad is a single bit
-            }
-            uvlc_prefix(v, pl2, sl2, base2);
-            pl2 = uo1 ? pl2 : 0; sl2 = uo1 ? sl2 : 0; base2 = uo1 ? base2 : 0;
-            if (FIRST) { pl2 = onebit ? 1u : pl2; sl2 = onebit ? 0u : sl2; base2 = onebit ? (v & 1u) + 1u : base2; }
-            v >>= pl2;
-            const uint32_t U0 = base + (v & ((1u << sl) - 1u)) + (uo0 ? add : 1u);
-            v >>= sl;
-            const uint32_t U1 = base2 + (v & ((1u << sl2) - 1u)) + (uo1 ? add : 1u);
-            vlc.skip(pl + pl2 + sl + sl2);
-            if (U0 > mm || U1 > mm) return false;                  // :1194
-            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(t0 | (U0 << 16), t1 | (U1 << 16));
-        }
-        sa = sn >> (64u - 4u * NP);
-        return true;
-    };
-    bool ok = quad_row(std::true_type{}, 0);
-    for (uint32_t qy = 1; ok && qy < QH; ++qy) ok = quad_row(std::false_type{}, qy);
-    if (!ok) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; }
-}
-
-// ---- K5b --------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
     (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -289,6 +67,371 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     v += dpp0<0x143, 0xC>(v);
     return v;
 }
+
+// lcup, scup of a block as both K5p and K5a take them from its last two bytes (:1067-1090); false: the block is rejected
+__device__ __forceinline__ bool ht_segments(const HtDecArgs& a, uint32_t blk, const HtDecBlock& in, int& lcup, int& scup)
+{
+    const uint8_t* D = a.coded + in.offset;
+    lcup = (int)in.length - (a.refine ? (int)a.refine[blk].x : 0);      // (refinement passes: their segment follows the cleanup segment)
+    if (in.missing_msbs > 29 || lcup < 2) return false;
+    scup = ((int)D[lcup - 1] << 4) + (D[lcup - 2] & 0xF);
+    return !(scup < 2 || scup > lcup || scup > 4079);
+}
+
+// FOUR bytes per lane and step, 256 per wave; the raw bits of up to kPrepSteps steps collect in an LDS array (one
+// ds_or pair per lane and step), then the finished words leave for the scratch and a partial last word carries over.
+// A dword that straddles the ends of the coded buffer is not read (its bytes past the segment are masked anyway).
+constexpr uint32_t kPrepSteps = 4;                       // 1024 bytes = at most 256 words between two flushes
+constexpr uint32_t kPrepWords = kPrepSteps * 64 + 8;
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
+__global__ __launch_bounds__(64) void ht_dec_prep_kernel(HtDecArgs a)
+{
+    __shared__ uint32_t acc[2][kPrepWords];              // [0] VLC, [1] MEL
+    const uint32_t lane = threadIdx.x;
+    const uint32_t blk = a.active ? a.active[blockIdx.x] : blockIdx.x;
+    const HtDecBlock in = a.table[blk];
+    if (in.length == 0) return;
+    int lcup, scup;
+    if (!ht_segments(a, blk, in, lcup, scup)) return;              // (K5a raises the flag)
+    const uint8_t* D = a.coded + in.offset;
+    const uint8_t* const buf_lo = a.coded, * const buf_hi = a.coded + a.coded_bytes;
+    auto ld4 = [&](const uint8_t* q) -> uint32_t {                  // bytes q .. q + 3, little endian (outside the buffer: 0)
+        return (q >= buf_lo && q + 4 <= buf_hi) ? *reinterpret_cast<const u32_unaligned*>(q)
+               : ((q + 0 >= buf_lo && q + 0 < buf_hi ? (uint32_t)q[0] : 0u) | (q + 1 >= buf_lo && q + 1 < buf_hi ? (uint32_t)q[1] << 8 : 0u) |
+                  (q + 2 >= buf_lo && q + 2 < buf_hi ? (uint32_t)q[2] << 16 : 0u) | (q + 3 >= buf_lo && q + 3 < buf_hi ? (uint32_t)q[3] << 24 : 0u));
+    };
+    const uint32_t mwords = mel_words((uint32_t)scup), vwords = vlc_words((uint32_t)scup);
+    uint32_t* const out_m = a.vraw + a.vbase[blk];
+    uint32_t* const out_v = out_m + mwords;
+    const uint32_t nv = (uint32_t)scup - 2u, nm = (uint32_t)scup - 1u;
+    const uint32_t d0 = D[lcup - 2];
+    for (uint32_t i = lane; i < kPrepWords; i += 64) { acc[0][i] = 0; acc[1][i] = 0; }
+    __syncthreads();
+
+    // ---- VLC: bytes D[lcup - 3], D[lcup - 4], ... ; lane k of a step takes the four at p - 3 .. p, p = lcup - 3 - 4 k, read p first
+    {
+        const uint32_t n0 = 4u - (((d0 >> 4) & 7u) == 7u ? 1u : 0u);
+        if (lane == 0) acc[0][0] = (d0 >> 4) & ((1u << n0) - 1u);
+        __syncthreads();
+        uint32_t bits = n0, flushed = 0;                               // bits in the array, words already in the scratch
+        const uint32_t steps = (nv + 255u) / 256u;
+        for (uint32_t st = 0; st < steps; ++st) {
+            const uint32_t k = st * 256u + 4u * lane;                  // index (reading order) of this lane's first byte
+            uint32_t val = 0, nb = 0;
+            if (k < nv) {
+                const uint8_t* p = D + lcup - 3 - (int)k;
+                uint32_t w = ld4(p - 3);
+                const uint32_t prev = k == 0 ? (d0 | 0xFu) : (uint32_t)p[1];
+                const uint32_t v = min(nv - k, 4u);
+                w &= (uint32_t)(0xFFFFFFFF00000000ull >> (8u * v));                 // bytes past the segment read as 0
+                const uint32_t l7 = w & 0x7F7F7F7Fu;
+                const uint32_t g = (l7 + 0x70707070u) & w & 0x80808080u;          // byte > 0x8F
+                const uint32_t e = (l7 + 0x01010101u) & 0x80808080u;              // 7 LSBs all ones
+                const uint32_t s7 = e & ((g >> 8) | ((prev > 0x8Fu ? 1u : 0u) << 31));   // byte carries 7 bits
+                const uint32_t s3 = s7 >> 31, s2 = (s7 >> 23) & 1u, s1 = (s7 >> 15) & 1u, s0 = (s7 >> 7) & 1u;
+                const uint32_t sh2 = 8u - s3, sh1 = sh2 + 8u - s2, sh0 = sh1 + 8u - s1;
+                val = ((w >> 24) & (0xFFu >> s3)) | ((((w >> 16) & 0xFFu) & (0xFFu >> s2)) << sh2) |
+                      ((((w >> 8) & 0xFFu) & (0xFFu >> s1)) << sh1) | (((w & 0xFFu) & (0xFFu >> s0)) << sh0);
+                nb = 32u - s3 - s2 - s1 - s0;
+            }
+            const uint32_t incl = wave_incl_scan(nb);
+            if (nb) {
+                const uint32_t pos = bits + incl - nb - 32u * flushed;
+                const uint64_t x = (uint64_t)val << (pos & 31u);
+                lds_or(&acc[0][pos >> 5], (uint32_t)x);
+                lds_or(&acc[0][(pos >> 5) + 1], (uint32_t)(x >> 32));
+            }
+            bits += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if ((st + 1) % kPrepSteps == 0 && st + 1 < steps) {        // the finished words leave, the partial one moves to the front
+                __syncthreads();
+                const uint32_t full = (bits >> 5) - flushed;
+                for (uint32_t i = lane; i < full; i += 64) out_v[flushed + i] = acc[0][i];
+                const uint32_t carry = acc[0][full];
+                __syncthreads();
+                for (uint32_t i = lane; i < kPrepWords; i += 64) acc[0][i] = 0;
+                __syncthreads();
+                if (lane == 0) acc[0][0] = carry;
+                flushed += full;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = flushed + lane; i < vwords; i += 64) out_v[i] = i - flushed < kPrepWords ? acc[0][i - flushed] : 0u;   // zeros behind the end
+    }
+    // ---- MEL: bytes D[lcup - scup + i], forward; lane k of a step takes four, MSB-first bits
+    {
+        const uint8_t* M = D + lcup - scup;
+        uint32_t bits = 0, flushed = 0;
+        const uint32_t steps = (nm + 255u) / 256u;
+        for (uint32_t st = 0; st < steps; ++st) {
+            const uint32_t k = st * 256u + 4u * lane;
+            uint32_t val = 0, nb = 0;                                  // val: the lane's bits, MSB aligned
+            if (k < nm) {
+                uint32_t w = ld4(M + k);                               // byte 0 first
+                const uint32_t v = min(nm - k, 4u);
+                const uint32_t valid = (uint32_t)((1ull << (8u * v)) - 1ull);
+                w &= valid;
+                if (k + v == nm) w |= 0x0Fu << (8u * (v - 1u));        // the segment's last byte
+                const uint32_t prev = k == 0 ? 0u : (uint32_t)M[k - 1];
+                const uint32_t ff = ((w & 0x7F7F7F7Fu) + 0x01010101u) & w & 0x80808080u;    // byte == 0xFF
+                const uint32_t s7 = ((ff << 8) | ((prev == 0xFFu ? 1u : 0u) << 7)) & 0x80808080u & valid;
+                // byte j follows a 0xFF: 7 bits, its MSB dropped
+                const uint32_t f0 = (s7 >> 7) & 1u, f1 = (s7 >> 15) & 1u, f2 = (s7 >> 23) & 1u, f3 = s7 >> 31;
+                const uint32_t b0 = w & (0xFFu >> f0), b1 = (w >> 8) & (0xFFu >> f1), b2 = (w >> 16) & (0xFFu >> f2), b3 = (w >> 24) & (0xFFu >> f3);
+                const uint32_t w0 = 8u - f0, w1 = v > 1 ? 8u - f1 : 0u, w2 = v > 2 ? 8u - f2 : 0u, w3 = v > 3 ? 8u - f3 : 0u;
+                nb = w0 + w1 + w2 + w3;
+                uint64_t t = b0;
+                t = (t << w1) | (v > 1 ? b1 : 0u);
+                t = (t << w2) | (v > 2 ? b2 : 0u);
+                t = (t << w3) | (v > 3 ? b3 : 0u);
+                val = (uint32_t)(t << (32u - nb));
+            }
+            const uint32_t incl = wave_incl_scan(nb);
+            if (nb) {
+                const uint32_t pos = bits + incl - nb - 32u * flushed;
+                const uint64_t x = ((uint64_t)val << 32) >> (pos & 31u);
+                lds_or(&acc[1][pos >> 5], (uint32_t)(x >> 32));
+                lds_or(&acc[1][(pos >> 5) + 1], (uint32_t)x);
+            }
+            bits += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if ((st + 1) % kPrepSteps == 0 && st + 1 < steps) {
+                __syncthreads();
+                const uint32_t full = (bits >> 5) - flushed;
+                for (uint32_t i = lane; i < full; i += 64) out_m[flushed + i] = acc[1][i];
+                const uint32_t carry = acc[1][full];
+                __syncthreads();
+                for (uint32_t i = lane; i < kPrepWords; i += 64) acc[1][i] = 0;
+                __syncthreads();
+                if (lane == 0) acc[1][0] = carry;
+                flushed += full;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        // ones behind the data (an exhausted MEL segment reads as 0xFF bytes)
+        const uint32_t lastw = (bits >> 5) - flushed;
+        if (lane == 0) acc[1][lastw] |= 0xFFFFFFFFu >> (bits & 31u);
+        __syncthreads();
+        for (uint32_t i = flushed + lane; i < mwords; i += 64)
+            out_m[i] = i - flushed <= lastw ? acc[1][i - flushed] : 0xFFFFFFFFu;
+    }
+}
+
+// ---- K5a --------------------------------------------------------------------------------------------
+// One lane per code-block walks the block's VLC and MEL bits (K5p's raw arrays: no stuffing left) and emits one word per
+// quad: CxtVLC table entry | (u_q + 1) << 16.  The kernel is one dependent chain per lane, issue-bound at ~8.5 cycles per
+// instruction while a SIMD holds <= 2 waves, so it is written for instruction COUNT: 32-bit windows over the raw
+// bits (one 64-bit shift per quad pair, plain 32-bit shifts inside the pair; the next word is fetched a pair ahead), the
+// neighbour-significance part of both quads' contexts out of one shift-or of the row above, table entries that carry what
+// the chain needs next in place (the next quad's context bits at their position in the table ADDRESS, the quad's bottom-row
+// significance for the row below), UVLC prefixes by v_perm from a register-resident 8-entry table.
+__device__ uint2 g_vlc_dec2[2048];          // [0..1023] first quad row, [1024..2047] others; index (c_q << 7) | 7 bits;
+                                            // .x = the 16-bit CxtVLC entry (len | u_off << 3 | rho << 4 | e_1 << 8 | e_k << 12),
+                                            // .y = next context bits << 9 (address position) | bottom-row significance << 16
+
+// The VLC bits of one quad ROW pass through LDS: a quad row of <= 16 pairs consumes <= 16 x 30 bits, so the <= 18 words it can
+// reach are fetched in one batch at the row's start (independent loads, one wait) and the pair loop refills its window from
+// LDS.  A global load per pair would put `s_waitcnt vmcnt(0)` -- gfx9 counts loads and stores with one counter, and the
+// compiler merges the wait over the loop's back edge -- and with it the round trip of the pair's own quad-info STORE on the
+// serial chain (measured: the kernel was no faster than r02's with half the instructions).
+constexpr uint32_t kRowWords = 18, kRowStride = 19;       // (odd stride: the lanes' copies of word j lie in different banks)
+struct VlcBits {      // LSB first
+    const uint32_t* w; uint32_t* row; uint32_t wi, wi0, a, b, c, pos;
+    __device__ __forceinline__ void init(const uint32_t* p, uint32_t* lds_row) { w = p; row = lds_row; wi = 0; wi0 = 0; pos = 0; a = p[0]; b = p[1]; c = 0; }
+    // the words wi + 2 .. wi + 2 + kRowWords - 1 into the lane's LDS row (wi is where the window stands now)
+    __device__ __forceinline__ void begin_row()
+    {
+        wi0 = wi;
+        uint32_t t[kRowWords];
+#pragma unroll
+        for (uint32_t j = 0; j < kRowWords; ++j) t[j] = w[wi0 + 2 + j];
+#pragma unroll
+        for (uint32_t j = 0; j < kRowWords; ++j) row[j] = t[j];
+        c = t[0];
+    }
+    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)((((uint64_t)b << 32) | a) >> (pos & 31u)); }   // 32 valid bits
+    __device__ __forceinline__ void advance(uint32_t used)       // used <= 32
+    {
+        pos += used;
+        const uint32_t nwi = pos >> 5;
+        const bool step = nwi != wi;
+        a = step ? b : a; b = step ? c : b; wi = nwi;
+        c = row[wi - wi0];                                       // word wi + 2 (a pair ahead of its use; the same word again without a step)
+    }
+};
+
+struct MelBits {      // MSB first
+    const uint32_t* w; uint32_t wi, a, b, c, pos;
+    int k, run;       // run: what is left of the current run, in the reference's coding (:196-235, :1101-1111):
+                      // 2 * (zero events) + 1 if it ends with a one, 2 * (zero events - 1) otherwise
+    __device__ __forceinline__ void init(const uint32_t* p)
+    {
+        w = p; wi = 0; pos = 0; a = p[0]; b = p[1]; c = p[2]; k = 0; run = -1;
+        decode_run();
+    }
+    __device__ __forceinline__ void decode_run()                 // (:196-235)
+    {
+        const uint32_t e = (k < 8 ? 0x22111000u >> (4 * k) : 0x54332u >> (4 * (k - 8))) & 0xFu;   // MEL exponents (:196)
+        const uint32_t top = (uint32_t)(((((uint64_t)a << 32) | b) << (pos & 31u)) >> 32);
+        const bool one = (top >> 31) != 0;                       // '1': 2^e zero events; '0' + e bits: that many, then a one
+        run = one ? (int)((2u << e) - 2u) : (int)((((top >> (31u - e)) & ((1u << e) - 1u)) << 1) | 1u);
+        k = one ? (k < 12 ? k + 1 : 12) : (k > 0 ? k - 1 : 0);
+        pos += one ? 1u : e + 1u;
+        const uint32_t nwi = pos >> 5;
+        const bool step = nwi != wi;
+        a = step ? b : a; b = step ? c : b; wi = nwi;
+        c = w[wi + 2];
+    }
+    // One MEL event if `need` (:1101-1111): returns 1 if the run ends here with a one.  The decode of the next run sits
+    // behind a branch the whole wave skips when no lane has used its run up: in dense blocks (contexts rarely zero) and in
+    // empty ones (long runs) that is most of the time.
+    __device__ __forceinline__ uint32_t event(bool need)
+    {
+        run -= need ? 2 : 0;
+        const uint32_t ev = run == -1;
+        if (run < 0) decode_run();
+        return ev;
+    }
+};
+
+// UVLC prefix: '1' -> 1, '01' -> 2, '001' -> 3 + 1-bit suffix, '000' -> 5 + 5-bit suffix (:706-716), looked up by
+// the three next bits: entry = prefix_len | suffix_len << 2 | base << 5, eight entries in two registers, picked by v_perm
+__device__ __forceinline__ uint32_t uvlc_entry(uint32_t bits)
+{
+    // entries for bits & 7 = 0 .. 7: 000 -> (3, 5, 5), xx1 -> (1, 0, 1), x10 -> (2, 0, 2), 100 -> (3, 1, 3)
+    return __builtin_amdgcn_perm(0x21422167u, 0x214221B7u, (bits & 7u) | 0x0C0C0C00u);
+}
+
+__global__ void ht_dec_vlc_kernel(HtDecArgs a)
+{
+    // CxtVLC decode tables in LDS: one dependent lookup per quad sits on the serial chain
+    __shared__ uint2 tbl_l[2048];
+    __shared__ uint32_t rows_l[64 * kRowStride];
+    for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) tbl_l[i] = g_vlc_dec2[i];
+    __syncthreads();
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.nactive) return;
+    const uint32_t blk = a.active ? a.active[li] : li;
+    const HtDecBlock in = a.table[blk];
+    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
+    uint32_t* qi = a.quads + (size_t)blk * kQuadWords;
+    const uint32_t w = bd.w, h = bd.h;
+    const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
+    const uint32_t mm = in.missing_msbs;
+
+    if (in.length == 0) return;                            // absent (K5b writes the zeros) or outside the decoded region
+    int lcup, scup;
+    if (!ht_segments(a, blk, in, lcup, scup)) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; return; }
+    a.ms_len[blk] = (uint32_t)(lcup - scup);
+
+    const uint32_t* raw = a.vraw + a.vbase[blk];
+    MelBits mel;
+    mel.init(raw);
+    VlcBits vlc;
+    vlc.init(raw + mel_words((uint32_t)scup), rows_l + threadIdx.x * kRowStride);
+    const uint32_t NP = (QW + 1) >> 1;  // quad pairs per row
+    uint64_t sa = 0;                     // significance of the bottom sample row of the quad row above: bit x
+    uint32_t umax = 0;                   // largest u_q + 1 of the block (:1194: > missing_msbs rejects it)
+    // ---- the first quad row: its own contexts (the quad to the left only), table and u-value rules (:1093-1190)
+    {
+        const uint2* tbl = tbl_l;
+        uint32_t* qrow = qi;
+        uint64_t sn = 0;
+        uint32_t caddr = 0;                                // context of the next quad, << 9
+        vlc.begin_row();
+        for (uint32_t q0 = 0; q0 < QW; q0 += 2) {
+            const bool has1 = q0 + 1 < QW;
+            uint32_t v = vlc.peek(), used = 0;
+            // ---- quad q0
+            uint2 t0 = tbl[(caddr >> 9 << 7) | (v & 0x7Fu)];
+            uint32_t ev = mel.event(caddr == 0);
+            if (caddr == 0 && !ev) t0 = make_uint2(0, 0);
+            uint32_t len = t0.x & 7u;
+            v >>= len; used += len;
+            caddr = t0.y & 0xE00u;
+            // ---- quad q0 + 1 (absent when the row has an odd number of quads)
+            uint2 t1 = tbl[(caddr >> 9 << 7) | (v & 0x7Fu)];
+            ev = mel.event(has1 && caddr == 0);
+            if (!has1 || (caddr == 0 && !ev)) t1 = make_uint2(0, 0);
+            len = t1.x & 7u;
+            v >>= len; used += len;
+            caddr = t1.y & 0xE00u;
+            sn = (sn >> 4) | ((uint64_t)(((t0.y >> 16) & 3u) | (((t1.y >> 16) & 3u) << 2)) << 60);
+            // ---- u values of the pair (:668-777): prefix0, prefix1, suffix0, suffix1, each present only if its quad has u_off
+            const uint32_t uo0 = (t0.x >> 3) & 1u, uo1 = (t1.x >> 3) & 1u;
+            uint32_t d = uo0 ? uvlc_entry(v) : 0u;
+            const uint32_t pl = d & 3u, sl = (d >> 2) & 7u, base = d >> 5;
+            v >>= pl;
+            const uint32_t both = uo0 & uo1;               // both quads: a MEL event picks the variant
+            const uint32_t e2 = mel.event(both != 0);
+            const uint32_t add = (both & e2) ? 3u : 1u;
+            const uint32_t onebit = both & (e2 ^ 1u) & (pl > 2 ? 1u : 0u);    // second quad is a single bit
+            d = uo1 ? uvlc_entry(v) : 0u;
+            uint32_t pl2 = d & 3u, sl2 = (d >> 2) & 7u, base2 = d >> 5;
+            pl2 = onebit ? 1u : pl2; sl2 = onebit ? 0u : sl2; base2 = onebit ? (v & 1u) + 1u : base2;
+            v >>= pl2;
+            const uint32_t U0 = base + (v & ((1u << sl) - 1u)) + (uo0 ? add : 1u);
+            v >>= sl;
+            const uint32_t U1 = base2 + (v & ((1u << sl2) - 1u)) + (uo1 ? add : 1u);
+            vlc.advance(used + pl + pl2 + sl + sl2);
+            umax = max(umax, max(U0, U1));
+            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(t0.x | (U0 << 16), t1.x | (U1 << 16));
+        }
+        sa = sn >> (64u - 4u * NP);
+    }
+    // ---- the other quad rows (:1192-1330)
+    const uint2* tbl = tbl_l + 1024;
+    for (uint32_t qy = 1; qy < QH; ++qy) {
+        uint32_t* qrow = qi + qy * kQuadStride;
+        uint64_t sw = sa, sn = 0;
+        uint32_t west = 0, chain = 0;    // sample 2 * q0 - 1 of the row above; the west quad's contribution to the context, << 9
+        vlc.begin_row();
+        for (uint32_t q0 = 0; q0 < QW; q0 += 2) {
+            const bool has1 = q0 + 1 < QW;
+            uint32_t v = vlc.peek(), used;
+            // the row above over the pair: x = (sample 2 q0 - 1) | samples 2 q0 .. 2 q0 + 4 << 1; y = x | x >> 1 has
+            // (nw | n) of quad q0 at bit 0, (ne | nf) at bit 2, the same of quad q0 + 1 two bits up
+            const uint32_t up = (uint32_t)sw;
+            const uint32_t x = ((up << 1) | west) & 0x3Fu;
+            const uint32_t y9 = (x | (x >> 1)) << 9;
+            west = (up >> 3) & 1u; sw >>= 4;
+            // ---- quad q0
+            uint32_t caddr = chain | (y9 & 0xA00u);
+            uint2 t0 = tbl[(caddr >> 2) | (v & 0x7Fu)];
+            uint32_t ev = mel.event(caddr == 0);
+            if (caddr == 0 && !ev) t0 = make_uint2(0, 0);
+            uint32_t len = t0.x & 7u;
+            v >>= len; used = len;
+            // ---- quad q0 + 1
+            caddr = (t0.y & 0x400u) | ((y9 >> 2) & 0xA00u);
+            uint2 t1 = tbl[(caddr >> 2) | (v & 0x7Fu)];
+            ev = mel.event(has1 && caddr == 0);
+            if (!has1 || (caddr == 0 && !ev)) t1 = make_uint2(0, 0);
+            len = t1.x & 7u;
+            v >>= len; used += len;
+            chain = t1.y & 0x400u;
+            sn = (sn >> 4) | ((uint64_t)(((t0.y >> 16) & 3u) | (((t1.y >> 16) & 3u) << 2)) << 60);
+            // ---- u values: prefix0, prefix1, suffix0, suffix1
+            uint32_t d = ((t0.x >> 3) & 1u) ? uvlc_entry(v) : 0u;
+            const uint32_t pl = d & 3u, sl = (d >> 2) & 7u, base = d >> 5;
+            v >>= pl;
+            d = ((t1.x >> 3) & 1u) ? uvlc_entry(v) : 0u;
+            const uint32_t pl2 = d & 3u, sl2 = (d >> 2) & 7u, base2 = d >> 5;
+            v >>= pl2;
+            const uint32_t U0 = base + __builtin_amdgcn_ubfe(v, 0u, sl) + 1u;
+            v >>= sl;
+            const uint32_t U1 = base2 + __builtin_amdgcn_ubfe(v, 0u, sl2) + 1u;
+            vlc.advance(used + pl + pl2 + sl + sl2);
+            umax = max(umax, max(U0, U1));
+            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(t0.x | (U0 << 16), t1.x | (U1 << 16));
+        }
+        sa = sn >> (64u - 4u * NP);
+    }
+    if (umax > mm) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; }      // :1194
+}
+
+// ---- K5b --------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bperm(int addr, uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v);
@@ -628,13 +771,24 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 16 && !g_dec_tables_ready[dev]) {
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_dec), HT_VLC_DEC0, sizeof(HT_VLC_DEC0), 0, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return e;
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_dec), HT_VLC_DEC1, sizeof(HT_VLC_DEC1), sizeof(HT_VLC_DEC0), hipMemcpyHostToDevice);
+        // the CxtVLC decode tables with what K5a's chain needs next to each entry (kernels above: g_vlc_dec2)
+        static uint2 tab[2048];
+        for (uint32_t i = 0; i < 2048; ++i) {
+            const uint32_t t = i < 1024 ? HT_VLC_DEC0[i] : HT_VLC_DEC1[i - 1024];
+            const uint32_t rho = (t >> 4) & 0xFu;
+            const uint32_t next = i < 1024 ? ((rho & 1u) | (rho >> 1))                        // first row: c_q of the quad to the right (:1117)
+                                           : ((((rho >> 2) | (rho >> 3)) & 1u) << 1);         // other rows: its west part (:1216)
+            const uint32_t sb = ((rho >> 1) & 1u) | (((rho >> 3) & 1u) << 1);                 // the quad's bottom samples
+            tab[i].x = t;
+            tab[i].y = (next << 9) | (sb << 16);
+        }
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_dec2), tab, sizeof(tab), 0, hipMemcpyHostToDevice);
         if (e != hipSuccess) return e;
         g_dec_tables_ready[dev] = true;
     }
-    // K5a: few lanes per wave when blocks are few, so that >= ~4 waves per SIMD overlap their latencies
+    if (a.nactive == 0) return hipSuccess;
+    // K5p: one wave per block with data
+    hipLaunchKernelGGL(ht_dec_prep_kernel, dim3(a.nactive), dim3(64), 0, s, a);
     // K5a is one serial chain per lane.  A wave costs the same issue slots however many lanes are
     // live, so few lanes per wave multiply the instruction count, while few waves per SIMD leave the
     // chain's own latency exposed: aim for ~1.5-2 waves per SIMD (1024 SIMDs), measured optimum.
@@ -643,8 +797,8 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
     //  another frame does not pay either: next to K5b both take twice as long, next to the inverse DWT 1.4x / 1.5x -- the
     //  chain's next instruction waits behind whatever holds the SIMD's ALU for its four cycles, wave priority or not)
     uint32_t lanes = 64;
-    while (lanes > 16 && (a.nblocks + lanes - 1) / lanes < 1280) lanes >>= 1;
-    hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nblocks + lanes - 1) / lanes), dim3(lanes), 0, s, a);
+    while (lanes > 16 && (a.nactive + lanes - 1) / lanes < 1280) lanes >>= 1;
+    hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nactive + lanes - 1) / lanes), dim3(lanes), 0, s, a);
     const uint32_t raw_words = (max_ms_bytes * 8u) / 32u + 8u;
     if (a.irreversible)
         hipLaunchKernelGGL(ht_dec_ms_kernel<true>, dim3(a.nblocks), dim3(64), raw_words * 4, s, a, raw_words);

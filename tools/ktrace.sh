@@ -11,7 +11,7 @@ f = glob.glob("/tmp/kt/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 def short(k):
     m = re.search(r"(\w+)<([^>]*)>", k)
-    return (m.group(1) + "<" + m.group(2).replace(" ", "") + ">") if m else k.split("(")[0][:40]
+    return (m.group(1) + "<" + m.group(2).replace(" ", "") + ">") if m else k.replace("grk_amd::(anonymous namespace)::", "").split("(")[0][:40]
 seq = [(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]),
         (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
 # mean duration per (kernel, grid) over all steps, listed in first-occurrence order
