@@ -92,10 +92,17 @@ __global__ __launch_bounds__(64) void ht_dec_prep_kernel(HtDecArgs a)
     const uint32_t blk = a.active ? a.active[blockIdx.x] : blockIdx.x;
     const HtDecBlock in = a.table[blk];
     if (in.length == 0) return;
-    int lcup, scup;
-    if (!ht_segments(a, blk, in, lcup, scup)) return;              // (K5a raises the flag)
     const uint8_t* D = a.coded + in.offset;
     const uint8_t* const buf_lo = a.coded, * const buf_hi = a.coded + a.coded_bytes;
+    int lcup = (int)in.length - (a.refine ? (int)a.refine[blk].x : 0), scup;
+    if (in.missing_msbs > 29 || lcup < 2) return;                  // (K5a raises the flag)
+    // The VLC bytes lie at the block's end whatever Scup says (only their NUMBER depends on it): the first step's loads go out
+    // together with the two bytes that hold Scup, one memory round trip instead of two on this kernel's short chain
+    const uint8_t* const p_first = D + lcup - 3 - 4 * (int)lane;
+    const uint32_t w_first = (p_first - 3 >= buf_lo && p_first + 1 <= buf_hi) ? *reinterpret_cast<const u32_unaligned*>(p_first - 3) : 0u;
+    const uint32_t prev_first = (lane > 0 && p_first + 1 >= buf_lo && p_first + 1 < buf_hi) ? (uint32_t)p_first[1] : 0u;
+    scup = ((int)D[lcup - 1] << 4) + (D[lcup - 2] & 0xF);
+    if (scup < 2 || scup > lcup || scup > 4079) return;
     auto ld4 = [&](const uint8_t* q) -> uint32_t {                  // bytes q .. q + 3, little endian (outside the buffer: 0)
         return (q >= buf_lo && q + 4 <= buf_hi) ? *reinterpret_cast<const u32_unaligned*>(q)
                : ((q + 0 >= buf_lo && q + 0 < buf_hi ? (uint32_t)q[0] : 0u) | (q + 1 >= buf_lo && q + 1 < buf_hi ? (uint32_t)q[1] << 8 : 0u) |
@@ -121,8 +128,9 @@ __global__ __launch_bounds__(64) void ht_dec_prep_kernel(HtDecArgs a)
             uint32_t val = 0, nb = 0;
             if (k < nv) {
                 const uint8_t* p = D + lcup - 3 - (int)k;
-                uint32_t w = ld4(p - 3);
-                const uint32_t prev = k == 0 ? (d0 | 0xFu) : (uint32_t)p[1];
+                // (the first step's dword, when it lay inside the buffer, is already here)
+                uint32_t w = (st == 0 && p - 3 >= buf_lo) ? w_first : ld4(p - 3);
+                const uint32_t prev = k == 0 ? (d0 | 0xFu) : (st == 0 ? prev_first : (uint32_t)p[1]);
                 const uint32_t v = min(nv - k, 4u);
                 w &= (uint32_t)(0xFFFFFFFF00000000ull >> (8u * v));                 // bytes past the segment read as 0
                 const uint32_t l7 = w & 0x7F7F7F7Fu;
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(64) void ht_dec_prep_kernel(HtDecArgs a)
 // significance for the row below), UVLC prefixes by v_perm from a register-resident 8-entry table.
 __device__ uint2 g_vlc_dec2[2048];          // [0..1023] first quad row, [1024..2047] others; index (c_q << 7) | 7 bits;
                                             // .x = the 16-bit CxtVLC entry (len | u_off << 3 | rho << 4 | e_1 << 8 | e_k << 12),
-                                            // .y = next context bits << 9 (address position) | bottom-row significance << 16
+                                            // .y = next context bits << 9 (address position) | bottom-row significance << 28
 
 // The VLC bits of one quad ROW pass through LDS: a quad row of <= 16 pairs consumes <= 16 x 30 bits, so the <= 18 words it can
 // reach are fetched in one batch at the row's start (independent loads, one wait) and the pair loop refills its window from
@@ -286,10 +294,10 @@ struct MelBits {      // MSB first
     // One MEL event if `need` (:1101-1111): returns 1 if the run ends here with a one.  The decode of the next run sits
     // behind a branch the whole wave skips when no lane has used its run up: in dense blocks (contexts rarely zero) and in
     // empty ones (long runs) that is most of the time.
-    __device__ __forceinline__ uint32_t event(bool need)
+    __device__ __forceinline__ bool event(bool need)
     {
         run -= need ? 2 : 0;
-        const uint32_t ev = run == -1;
+        const bool ev = run == -1;
         if (run < 0) decode_run();
         return ev;
     }
@@ -344,27 +352,29 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
             const bool has1 = q0 + 1 < QW;
             uint32_t v = vlc.peek(), used = 0;
             // ---- quad q0
-            uint2 t0 = tbl[(caddr >> 9 << 7) | (v & 0x7Fu)];
-            uint32_t ev = mel.event(caddr == 0);
-            if (caddr == 0 && !ev) t0 = make_uint2(0, 0);
+            uint2 t0 = tbl[(caddr >> 2) | (v & 0x7Fu)];
+            bool need = caddr == 0;
+            bool zero = need && !mel.event(need);
+            if (zero) t0 = make_uint2(0, 0);
             uint32_t len = t0.x & 7u;
             v >>= len; used += len;
             caddr = t0.y & 0xE00u;
             // ---- quad q0 + 1 (absent when the row has an odd number of quads)
-            uint2 t1 = tbl[(caddr >> 9 << 7) | (v & 0x7Fu)];
-            ev = mel.event(has1 && caddr == 0);
-            if (!has1 || (caddr == 0 && !ev)) t1 = make_uint2(0, 0);
+            uint2 t1 = tbl[(caddr >> 2) | (v & 0x7Fu)];
+            need = has1 && caddr == 0;
+            zero = !has1 || (need && !mel.event(need));
+            if (zero) t1 = make_uint2(0, 0);
             len = t1.x & 7u;
             v >>= len; used += len;
             caddr = t1.y & 0xE00u;
-            sn = (sn >> 4) | ((uint64_t)(((t0.y >> 16) & 3u) | (((t1.y >> 16) & 3u) << 2)) << 60);
+            sn = (sn >> 4) | ((uint64_t)((t0.y & 0x30000000u) | ((t1.y & 0x30000000u) << 2)) << 32);
             // ---- u values of the pair (:668-777): prefix0, prefix1, suffix0, suffix1, each present only if its quad has u_off
             const uint32_t uo0 = (t0.x >> 3) & 1u, uo1 = (t1.x >> 3) & 1u;
             uint32_t d = uo0 ? uvlc_entry(v) : 0u;
             const uint32_t pl = d & 3u, sl = (d >> 2) & 7u, base = d >> 5;
             v >>= pl;
             const uint32_t both = uo0 & uo1;               // both quads: a MEL event picks the variant
-            const uint32_t e2 = mel.event(both != 0);
+            const uint32_t e2 = mel.event(both != 0) ? 1u : 0u;
             const uint32_t add = (both & e2) ? 3u : 1u;
             const uint32_t onebit = both & (e2 ^ 1u) & (pl > 2 ? 1u : 0u);    // second quad is a single bit
             d = uo1 ? uvlc_entry(v) : 0u;
@@ -376,7 +386,7 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
             const uint32_t U1 = base2 + (v & ((1u << sl2) - 1u)) + (uo1 ? add : 1u);
             vlc.advance(used + pl + pl2 + sl + sl2);
             umax = max(umax, max(U0, U1));
-            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(t0.x | (U0 << 16), t1.x | (U1 << 16));
+            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(__builtin_amdgcn_perm(U0, t0.x, 0x05040100u), __builtin_amdgcn_perm(U1, t1.x, 0x05040100u));
         }
         sa = sn >> (64u - 4u * NP);
     }
@@ -399,19 +409,21 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
             // ---- quad q0
             uint32_t caddr = chain | (y9 & 0xA00u);
             uint2 t0 = tbl[(caddr >> 2) | (v & 0x7Fu)];
-            uint32_t ev = mel.event(caddr == 0);
-            if (caddr == 0 && !ev) t0 = make_uint2(0, 0);
+            bool need = caddr == 0;
+            bool zero = need && !mel.event(need);
+            if (zero) t0 = make_uint2(0, 0);
             uint32_t len = t0.x & 7u;
             v >>= len; used = len;
             // ---- quad q0 + 1
             caddr = (t0.y & 0x400u) | ((y9 >> 2) & 0xA00u);
             uint2 t1 = tbl[(caddr >> 2) | (v & 0x7Fu)];
-            ev = mel.event(has1 && caddr == 0);
-            if (!has1 || (caddr == 0 && !ev)) t1 = make_uint2(0, 0);
+            need = has1 && caddr == 0;
+            zero = !has1 || (need && !mel.event(need));
+            if (zero) t1 = make_uint2(0, 0);
             len = t1.x & 7u;
             v >>= len; used += len;
             chain = t1.y & 0x400u;
-            sn = (sn >> 4) | ((uint64_t)(((t0.y >> 16) & 3u) | (((t1.y >> 16) & 3u) << 2)) << 60);
+            sn = (sn >> 4) | ((uint64_t)((t0.y & 0x30000000u) | ((t1.y & 0x30000000u) << 2)) << 32);
             // ---- u values: prefix0, prefix1, suffix0, suffix1
             uint32_t d = ((t0.x >> 3) & 1u) ? uvlc_entry(v) : 0u;
             const uint32_t pl = d & 3u, sl = (d >> 2) & 7u, base = d >> 5;
@@ -424,7 +436,7 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
             const uint32_t U1 = base2 + __builtin_amdgcn_ubfe(v, 0u, sl2) + 1u;
             vlc.advance(used + pl + pl2 + sl + sl2);
             umax = max(umax, max(U0, U1));
-            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(t0.x | (U0 << 16), t1.x | (U1 << 16));
+            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(__builtin_amdgcn_perm(U0, t0.x, 0x05040100u), __builtin_amdgcn_perm(U1, t1.x, 0x05040100u));
         }
         sa = sn >> (64u - 4u * NP);
     }
@@ -780,7 +792,7 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
                                            : ((((rho >> 2) | (rho >> 3)) & 1u) << 1);         // other rows: its west part (:1216)
             const uint32_t sb = ((rho >> 1) & 1u) | (((rho >> 3) & 1u) << 1);                 // the quad's bottom samples
             tab[i].x = t;
-            tab[i].y = (next << 9) | (sb << 16);
+            tab[i].y = (next << 9) | (sb << 28);
         }
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_dec2), tab, sizeof(tab), 0, hipMemcpyHostToDevice);
         if (e != hipSuccess) return e;
