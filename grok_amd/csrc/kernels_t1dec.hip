@@ -27,7 +27,7 @@
 //      form beats an all-scalar one (a hand-scheduled 45-instruction scalar decoder was 1.5x slower on whole images).
 //      (An earlier several-blocks-per-wave form -- branch divergence makes the lanes take turns -- measured 80 ms
 //      with 16 lanes, 38.6 ms with 4 and 41 ms with 2 where this form takes 23 ms, on 12 288 blocks.)
-//  K8b t1_store_kernel -- one wavefront per code-block: workspace -> dequantise -> Mallat plane rows.
+//  The wave then dequantises and stores its block's rows (r02: a second kernel, K8b, from a global workspace).
 #include "kernels.h"
 
 namespace grk_amd {
@@ -222,6 +222,15 @@ __device__ __forceinline__ uint32_t win3(uint64_t s, uint32_t x)
     return (uint32_t)(x ? (s >> (x - 1)) : (s << 1)) & 7u;
 }
 
+// Where a block's decoded values live between the passes: a workspace in global memory, one row load / store per stripe row
+// and pass.  A block's magnitudes need numbps + 1 bits and a sign, so a block of at most 14 bit planes -- every block of 8- to
+// 12-bit content with the default guard bits -- keeps int16 there (half of r02's int32 traffic), deeper ones int32.  The wave
+// dequantises and stores the block's rows itself at the end (r02's separate store kernel read the workspace once more).
+// (Measured and not kept in r03: the same int16 values in LDS, 8 KB per block -- no workspace traffic at all, but 15 instead of
+//  32 waves per CU: the scalar unit this kernel is bound by then idles, 45 -> 61 ms.)
+constexpr uint32_t kNarrowPlanes = 14;
+
+template <bool IRREV>
 __global__ void t1_dec_kernel(T1DecArgs a)
 {
     __shared__ uint64_t bm_l[4][66];
@@ -238,11 +247,19 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     const uint32_t zcv = g_zc_lut.w[orient & 3u][threadIdx.x & 63u];           // this orientation's zero-coding contexts across the lanes
     const uint32_t sgv = g_sign_lut.w[threadIdx.x & 63u];                      // sign-coding contexts
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
-    // value workspace of the block, [y * 64 + x] (the first pass writes every row, K8b zeroes absent blocks)
+    // value workspace of a deep block, [y * 64 + x] (the first pass writes every row)
     int32_t* ws = a.work + (size_t)blockIdx.x * 4096u;
     if (in.length == 0 && in.missing_msbs == kSkipBlock) return;       // region decode: outside the decoded region
-    if (in.length == 0 || numpasses == 0 || numbps == 0) return;
-    if (numbps >= 25u) { if (writer) atomicOr(a.status, 4u); return; }         // k_max_bit_planes (t1_common.h:70)
+    const uint32_t tile = blk / a.blocks_per_tile;
+    int32_t* const dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
+    if (in.length == 0 || numpasses == 0 || numbps == 0 || numbps >= 25u) {   // absent (or beyond k_max_bit_planes, t1_common.h:70): zeros
+        if (numbps >= 25u && in.length != 0 && numpasses != 0 && writer) atomicOr(a.status, 4u);
+        if (threadIdx.x < w)
+            for (uint32_t y = 0; y < h; ++y) dst[(size_t)y * a.stride + threadIdx.x] = 0;
+        return;
+    }
+    const bool narrow = numbps <= kNarrowPlanes;
+    int16_t* const ws16 = reinterpret_cast<int16_t*>(ws);
 
     // row bitmaps with one border row above and below (index y + 1)
     uint64_t* const sig = bm_l[0]; uint64_t* const neg = bm_l[1]; uint64_t* const pi = bm_l[2]; uint64_t* const mu = bm_l[3];
@@ -305,8 +322,13 @@ __global__ void t1_dec_kernel(T1DecArgs a)
             // in the first pass) and one coalesced row store at the end instead of a store / an atomic per sample
             int32_t V[4] = {0, 0, 0, 0};
             if (!first_pass) {
+                if (narrow) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) V[j] = ws[(k + j) * 64u + tl];
+                    for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) V[j] = ws16[(k + j) * 64u + tl];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) V[j] = ws[(k + j) * 64u + tl];
+                }
             }
             // rows of the stripe that do not exist behave as "already coded"
 #pragma unroll
@@ -420,8 +442,13 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 pv = 0;                                                // the plane is complete
             }
 #undef T1_SIGN_AND_SET
+            if (narrow) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws[(k + j) * 64u + tl] = V[j];
+                for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws16[(k + j) * 64u + tl] = (int16_t)V[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if ((uint32_t)j < nr) ws[(k + j) * 64u + tl] = V[j];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint64_t srow = __builtin_amdgcn_ballot_w64(((nbv >> (3 * j + 4)) & 1u) != 0);      // the row, from the lanes' centre bits
@@ -436,29 +463,18 @@ __global__ void t1_dec_kernel(T1DecArgs a)
         if (++type == 3) { type = 0; --bp; }
     }
     }
-}
-
-// K8b: workspace -> dequantise -> Mallat plane (one wavefront per code-block, lane <-> column)
-template <bool IRREV>
-__global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a)
-{
-    const uint32_t blk = blockIdx.x, x = threadIdx.x;
-    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
-    const uint32_t tile = blk / a.blocks_per_tile;
-    if (x >= bd.w) return;
-    const HtDecBlock in = a.table[blk];
-    if (in.length == 0 && in.missing_msbs == kSkipBlock) return;
-    const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
-    const bool absent = in.length == 0 || numpasses == 0 || numbps == 0 || numbps >= 25u;    // K8a wrote nothing
-    const int32_t* ws = a.work + (size_t)blk * 4096u;
-    int32_t* dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
-    const float scale = bd.inv_step / 2;                            // ScaleFilter: stepsize / 2
-    for (uint32_t y = 0; y < bd.h; ++y) {
-        const int32_t v = absent ? 0 : ws[y * 64u + x];
-        int32_t o;
-        if constexpr (IRREV) o = __float_as_int(__fmul_rn((float)v, scale));
-        else o = v / 2;                                             // ShiftFilter: truncation toward zero
-        dst[(size_t)y * a.stride + x] = o;
+    // ---- the block leaves dequantised (ShiftFilter: v / 2 truncating toward zero; ScaleFilter: v x stepsize / 2 --
+    //      filters/PostDecompressFilters.h:26-35, :60-71), lane <-> column, coalesced rows
+    __syncthreads();
+    if (threadIdx.x < w) {
+        const float scale = bd.inv_step / 2;
+        for (uint32_t y = 0; y < h; ++y) {
+            const int32_t v = first_pass ? 0 : (narrow ? (int32_t)ws16[y * 64u + threadIdx.x] : ws[y * 64u + threadIdx.x]);
+            int32_t o;
+            if constexpr (IRREV) o = __float_as_int(__fmul_rn((float)v, scale));
+            else o = v / 2;
+            dst[(size_t)y * a.stride + threadIdx.x] = o;
+        }
     }
 }
 
@@ -466,11 +482,8 @@ __global__ __launch_bounds__(64) void t1_store_kernel(T1DecArgs a)
 
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(t1_dec_kernel, dim3(a.nblocks), dim3(64), 0, s, a);
-    if (a.irreversible)
-        hipLaunchKernelGGL(t1_store_kernel<true>, dim3(a.nblocks), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL(t1_store_kernel<false>, dim3(a.nblocks), dim3(64), 0, s, a);
+    if (a.irreversible) hipLaunchKernelGGL(t1_dec_kernel<true>, dim3(a.nblocks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_dec_kernel<false>, dim3(a.nblocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
