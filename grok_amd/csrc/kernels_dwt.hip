@@ -483,6 +483,10 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 //    instruction goes into an address;
 //  * latency.  Rows are fetched two steps ahead.
 constexpr int kPkLaneCols = 4;
+// the rows are read once: non-temporal loads (cache policy bit 1 on gfx950) keep them from pushing the block coder's tables and
+// streams out of the caches it shares with this kernel in the pipelined encode (measured r03: period 0.49 -> 0.47 ms, alone unchanged;
+// non-temporal STORES made this kernel 10 % slower)
+constexpr int kPkLoadAux = 2;
 // NT lanes per workgroup: 256 (strips of up to 960 columns), or 128 -- half the footprint (two waves, 12 KiB of LDS with three
 // components): the better fit for narrow levels (pk_nt below)
 constexpr int kPkHalo     = kPkLaneCols;                   // one lane's worth each side (the stencil needs 2 left, 1 right)
@@ -559,11 +563,11 @@ __global__ __launch_bounds__(NT) void dwt53_pk_kernel(DwtLevelArgs a)
     auto fetch_row = [&](int32_t r, Raw& q) {                // raw row fetch: no arithmetic, so that the rows stay in flight
         const uint32_t rr = mirror_row<true>(r, ch);
         if constexpr (PX == 0) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_in[0], lane_off, rr * a.in_stride * 2u, 0);
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_in[0], lane_off, rr * a.in_stride * 2u, kPkLoadAux);
             q.w[0].x = v.x; q.w[0].y = v.y;
         } else {
     #pragma unroll
-            for (int k = 0; k < NC; ++k) q.v[k] = __builtin_amdgcn_raw_buffer_load_b32(r_in[k], lane_off, rr * cw, 0);
+            for (int k = 0; k < NC; ++k) q.v[k] = __builtin_amdgcn_raw_buffer_load_b32(r_in[k], lane_off, rr * cw, kPkLoadAux);
         }
     };
     auto convert = [&](const Raw& q, pk16 (&va)[NC], pk16 (&vb)[NC]) {

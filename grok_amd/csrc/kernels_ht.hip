@@ -25,6 +25,8 @@
 // pixels); larger magnitudes raise GRK_AMD_ERR_UNSUPPORTED instead of producing other bytes.
 #include "kernels.h"
 #include "ht_vlc_tables.h"
+// the coded bytes are written once and read by nobody on the device: non-temporal stores
+#define GRK_K3_STORE(p, v) __builtin_nontemporal_store((uint32_t)(v), (p))
 #include <type_traits>
 
 namespace grk_amd {
@@ -716,11 +718,11 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             const uint64_t ballot = __ballot(z != 0);
             if (!ballot) {
                 if (avail >= 256u) {                                 // (wave-uniform: the common window costs ~10 vector instructions)
-                    *reinterpret_cast<u32_any*>(out + j + lane4) = win;
+                    GRK_K3_STORE(reinterpret_cast<u32_any*>(out + j + lane4), win);
                     s += 2048u; j += 256u;
                     continue;
                 }
-                if (nb == 4u) *reinterpret_cast<u32_any*>(out + j + lane4) = win;
+                if (nb == 4u) GRK_K3_STORE(reinterpret_cast<u32_any*>(out + j + lane4), win);
                 else {
 #pragma unroll 1
                     for (uint32_t k = 0; k < nb; ++k) out[j + lane4 + k] = (uint8_t)(win >> (8u * k));
@@ -732,7 +734,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             const uint32_t zF = (uint32_t)__builtin_amdgcn_readlane((int)z, (int)F);
             const uint32_t winF = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)F);
             const uint32_t b = (uint32_t)(__ffs((int)zF) - 1) >> 3;
-            if ((uint32_t)lane < F) *reinterpret_cast<u32_any*>(out + j + lane4) = win;
+            if ((uint32_t)lane < F) GRK_K3_STORE(reinterpret_cast<u32_any*>(out + j + lane4), win);
             const uint32_t p7 = s + 32u * F + 8u * (b + 1u);         // where the 7-bit byte after the 0xFF starts
             j += 4u * F;
             if (p7 == ms_bits) {                                     // the stream ends with the 0xFF: dropped (ms_terminate)
@@ -802,7 +804,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 uint32_t word = win;
                 if (i == 0 && lane == 0) word = (word & ~0xFu) | (scup & 0xFu);
                 if ((uint32_t)lane < F) {
-                    if (nb == 4u) *reinterpret_cast<u32_any*>(last - 3 - (int)(i + lane4)) = __builtin_bswap32(word);
+                    if (nb == 4u) GRK_K3_STORE(reinterpret_cast<u32_any*>(last - 3 - (int)(i + lane4)), __builtin_bswap32(word));
                     else {
 #pragma unroll 1
                         for (uint32_t k = 0; k < nb; ++k) *(last - (int)(i + lane4 + k)) = (uint8_t)(word >> (8u * k));

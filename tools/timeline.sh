@@ -11,7 +11,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # the timed region: the longest run of back-to-back steps; take the encode launches before the decode kernels start
 enc = [r for r in rows if "dwt" in r["Kernel_Name"] and "idwt" not in r["Kernel_Name"] or "ht_encode" in r["Kernel_Name"]]
 # find the last level-0 launches (grid y largest) and print three steps in the middle of the timed run
-l0 = [i for i, r in enumerate(enc) if "<3, 1>" in r["Kernel_Name"] or "false, 3, 1" in r["Kernel_Name"]]
+l0 = [i for i, r in enumerate(enc) if "<3, 1" in r["Kernel_Name"] or "false, 3, 1" in r["Kernel_Name"]]
 mid = l0[int(__import__('os').environ.get('TL_FRAME', '8'))] if len(l0) > 8 else 0       # (frames 3 .. 14 are bench.py's timed, pipelined region)
 sel = enc[mid:mid + 30]
 t0 = int(sel[0]["Start_Timestamp"])
