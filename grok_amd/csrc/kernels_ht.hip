@@ -585,7 +585,9 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         // coded again by the fallback launch with worst-case buffers (wave-uniform test, never taken on natural images).
         lds_full = lds_full || ms_bits > L.ms_cap_bits || vlc_bits > L.vlc_cap_bits;
         if (lds_full) return;
-        if (narrow) {
+        // `narrow`: the exponent bounds every quad's four values to 64 bits.  Deep content (16-bit, quantised) is not bounded that
+        // way but mostly is that small: one wave-uniform test of the pair sums takes the one-piece path whenever every lane's fit
+        if (narrow || !__ballot(max(m01, m23) > 32u)) {
             const uint32_t v01 = vm[0] | (vm[1] << (M02 & 31u));
             const uint32_t v23 = vm[2] | (vm[3] << m2);
             or_bits64(ms_raw, mpos, (uint64_t)v01 | ((uint64_t)v23 << m01));
