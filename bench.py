@@ -680,7 +680,7 @@ def main():
         dalgo = {"ht_cleanup_decode": ht_bytes(samples, b_pl_d, coded_sum_d),
                  "idwt53_5levels": idwt_bytes(samples, b_in_d, b_pl_d, levels, dk["egress_mct"][1] == 0),
                  "egress_mct": samples * (4.0 + b_in_d)}
-        dtraffic = {"ht_cleanup_decode": _pmc_traffic(args.workload, ("ht_dec_vlc_kernel", "ht_dec_ms_kernel")),
+        dtraffic = {"ht_cleanup_decode": _pmc_traffic(args.workload, ("ht_dec_prep_kernel", "ht_dec_vlc_kernel", "ht_dec_ms_kernel")),
                     "idwt53_5levels": _pmc_traffic(args.workload, ("idwt_last_level_fused", "idwt_level_kernel")), "egress_mct": None}
         decode = {"value": round(pixels_per_step * dsteps / ddt / 1e6, 1), "unit": "Mpixels/s",
                   "ms_per_step": round(ddt / dsteps * 1e3, 4), "steps": dsteps, "lossless_round_trip": (bool(torch.equal(d_back, d_px)) if not irrev else None),

@@ -665,7 +665,7 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
     HIP_TRY(c, c->dec_vbase.ensure(2 * nblocks * 4), "alloc scratch index");
     HIP_TRY(c, hipMemcpyAsync(c->dec_vbase.p, c->h_vbase.data(), (nblocks + nactive) * 4, hipMemcpyHostToDevice, c->stream), "upload scratch index");
     HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
-    HIP_TRY(c, c->dec_quads.ensure(nblocks * 1024 * 4), "alloc quad info");
+    HIP_TRY(c, c->dec_quads.ensure(nblocks * 1024 * 2 + 64), "alloc quad info");
     HIP_TRY(c, c->dec_mslen.ensure(nblocks * 4), "alloc ms lengths");
     HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc status");
     HIP_TRY(c, hipMemcpyAsync(c->dec_table.p, table, nblocks * sizeof(HtDecBlock), hipMemcpyHostToDevice, c->stream), "upload decode table");

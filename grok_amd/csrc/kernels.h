@@ -106,7 +106,7 @@ struct HtDecArgs {
     const uint32_t* vbase;                     // [nblocks] first word of each block's part of vraw (ht_dec_scratch_words apart)
     const uint32_t* active;                    // [nactive] the blocks with data, K5p's waves / K5a's lanes (null: all nblocks)
     uint32_t nactive;
-    uint32_t* quads;                           // [nblocks][32*32] K5a -> K5b: CxtVLC entry | (u_q + 1) << 16 per quad
+    uint32_t* quads;                           // K5a -> K5b: 16 bits per quad, [nblocks][32 * 32] (kernels_htdec.hip: 9 bits of the CxtVLC entry | (u_q + 1) << 9)
     uint32_t* ms_len;                          // [nblocks] MagSgn bytes (0xFFFFFFFF: block rejected)
     unsigned int* status;                      // bit 2: a block was rejected; bit 3: a value did not fit the 16-bit planes
     int32_t* mallat; uint32_t stride; uint64_t pitch;

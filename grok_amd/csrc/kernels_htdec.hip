@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void ht_dec_prep_kernel(HtDecArgs a)
 
 // ---- K5a --------------------------------------------------------------------------------------------
 // One lane per code-block walks the block's VLC and MEL bits (K5p's raw arrays: no stuffing left) and emits one word per
-// quad: CxtVLC table entry | (u_q + 1) << 16.  The kernel is one dependent chain per lane, issue-bound at ~8.5 cycles per
+// quad, 16 bits: what K5b needs of the CxtVLC table entry (9 bits) | (u_q + 1) << 9.  The kernel is one dependent chain per lane, issue-bound at ~8.5 cycles per
 // instruction while a SIMD holds <= 2 waves, so it is written for instruction COUNT: 32-bit windows over the raw
 // bits (one 64-bit shift per quad pair, plain 32-bit shifts inside the pair; the next word is fetched a pair ahead), the
 // neighbour-significance part of both quads' contexts out of one shift-or of the row above, table entries that carry what
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) void ht_dec_prep_kernel(HtDecArgs a)
 // significance for the row below), UVLC prefixes by v_perm from a register-resident 8-entry table.
 __device__ uint2 g_vlc_dec2[2048];          // [0..1023] first quad row, [1024..2047] others; index (c_q << 7) | 7 bits;
                                             // .x = the 16-bit CxtVLC entry (len | u_off << 3 | rho << 4 | e_1 << 8 | e_k << 12),
-                                            // .y = next context bits << 9 (address position) | bottom-row significance << 28
+                                            // .y = K5b's 9 bits of the entry | next context bits << 9 (address position) | bottom-row significance << 28
 
 // The VLC bits of one quad ROW pass through LDS: a quad row of <= 16 pairs consumes <= 16 x 30 bits, so the <= 18 words it can
 // reach are fetched in one batch at the row's start (independent loads, one wait) and the pair loop refills its window from
@@ -323,7 +323,7 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
     const uint32_t blk = a.active ? a.active[li] : li;
     const HtDecBlock in = a.table[blk];
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
-    uint32_t* qi = a.quads + (size_t)blk * kQuadWords;
+    uint16_t* qi = reinterpret_cast<uint16_t*>(a.quads) + (size_t)blk * kQuadWords;     // per quad: 9 table bits | (u_q + 1) << 9
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
     const uint32_t mm = in.missing_msbs;
@@ -344,7 +344,7 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
     // ---- the first quad row: its own contexts (the quad to the left only), table and u-value rules (:1093-1190)
     {
         const uint2* tbl = tbl_l;
-        uint32_t* qrow = qi;
+        uint16_t* qrow = qi;
         uint64_t sn = 0;
         uint32_t caddr = 0;                                // context of the next quad, << 9
         vlc.begin_row();
@@ -386,14 +386,14 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
             const uint32_t U1 = base2 + (v & ((1u << sl2) - 1u)) + (uo1 ? add : 1u);
             vlc.advance(used + pl + pl2 + sl + sl2);
             umax = max(umax, max(U0, U1));
-            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(__builtin_amdgcn_perm(U0, t0.x, 0x05040100u), __builtin_amdgcn_perm(U1, t1.x, 0x05040100u));
+            *reinterpret_cast<uint32_t*>(&qrow[q0]) = ((t0.y & 0x1FFu) | (U0 << 9)) | (((t1.y & 0x1FFu) | (U1 << 9)) << 16);
         }
         sa = sn >> (64u - 4u * NP);
     }
     // ---- the other quad rows (:1192-1330)
     const uint2* tbl = tbl_l + 1024;
     for (uint32_t qy = 1; qy < QH; ++qy) {
-        uint32_t* qrow = qi + qy * kQuadStride;
+        uint16_t* qrow = qi + qy * kQuadStride;
         uint64_t sw = sa, sn = 0;
         uint32_t west = 0, chain = 0;    // sample 2 * q0 - 1 of the row above; the west quad's contribution to the context, << 9
         vlc.begin_row();
@@ -436,7 +436,7 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
             const uint32_t U1 = base2 + __builtin_amdgcn_ubfe(v, 0u, sl2) + 1u;
             vlc.advance(used + pl + pl2 + sl + sl2);
             umax = max(umax, max(U0, U1));
-            *reinterpret_cast<uint2*>(&qrow[q0]) = make_uint2(__builtin_amdgcn_perm(U0, t0.x, 0x05040100u), __builtin_amdgcn_perm(U1, t1.x, 0x05040100u));
+            *reinterpret_cast<uint32_t*>(&qrow[q0]) = ((t0.y & 0x1FFu) | (U0 << 9)) | (((t1.y & 0x1FFu) | (U1 << 9)) << 16);
         }
         sa = sn >> (64u - 4u * NP);
     }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
     const uint32_t mm = in.missing_msbs;
     const uint32_t p = 30u - mm;
     const bool refined = ht_block_refined(a, blk, mm);
-    const uint32_t* qi = a.quads + (size_t)blk * kQuadWords;
+    const uint16_t* qi = reinterpret_cast<const uint16_t*>(a.quads) + (size_t)blk * kQuadWords;     // K5a's 16 bits per quad
     const uint32_t q = x >> 1, right = x & 1u;
     uint32_t Eprev = 0;                                   // exponent of this column's bottom sample, row above
     uint32_t bitpos = 0;
@@ -547,8 +547,12 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
     for (uint32_t qy = 0; qy < QH; ++qy) {
         const uint32_t cur = info;
         if (qy + 1 < QH) info = col_ok ? qi[(qy + 1) * kQuadStride + q] : 0u;     // prefetch next row's quad info
-        const uint32_t rho = (cur >> 4) & 0xFu, e1 = (cur >> 8) & 0xFu, ek = (cur >> 12) & 0xFu;
-        uint32_t U = cur >> 16;
+        // this lane's two samples (top: i = 2 * right, bottom: the next): their states -- 0 insignificant, 1 significant, 2 with
+        // e_k, 3 with e_k and e_1 --, whether the quad has two or more significant samples, and u_q + 1
+        const uint32_t nib = cur >> (4u * right);
+        const uint32_t s_t = nib & 3u, s_b = (nib >> 2) & 3u;
+        const bool many = (cur & 0x100u) != 0;
+        uint32_t U = cur >> 9;
         // kappa: max exponent over columns 2q-1 .. 2q+2 of the row above, when more than one sample is significant.
         // With lane shifts (DPP wave_shl / wave_shr, zero beyond the wave's ends = outside the block): P[x] = max(E[x], E[x+1]);
         // the quad's left lane (x = 2q) takes max(P[x-1], P[x+1]), the right lane that lane's value.
@@ -559,13 +563,11 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
             // (selected with a mask, not a branch: a lane shift inside a predicated region reads zeros from the disabled lanes)
             const uint32_t Ar = dpp0<0x138, 0xF>(Al);
             const uint32_t E = Al ^ ((Al ^ Ar) & (0u - right));
-            if (qy > 0 && (rho & (rho - 1))) U += E > 2 ? E - 2 : 0;
+            if (qy > 0 && many) U += E > 2 ? E - 2 : 0;
         }
-        // this lane's two samples: i = 2*right (top) and 2*right + 1 (bottom)
-        const uint32_t it = 2 * right, ib = it + 1;
-        const uint32_t st = (rho >> it) & 1u, sb = (rho >> ib) & 1u;
-        const uint32_t mt = st ? U - ((ek >> it) & 1u) : 0u;
-        const uint32_t mb = sb ? U - ((ek >> ib) & 1u) : 0u;
+        const uint32_t st = s_t ? 1u : 0u, sb = s_b ? 1u : 0u;
+        const uint32_t mt = st ? U - (s_t >> 1) : 0u;
+        const uint32_t mb = sb ? U - (s_b >> 1) : 0u;
         const uint32_t incl = wave_incl_scan(mt + mb);
         const uint32_t pos = bitpos + incl - (mt + mb);
         bitpos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -575,8 +577,8 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
         const uint32_t win0 = __builtin_amdgcn_alignbit(r1, r0, sh), win1 = __builtin_amdgcn_alignbit(r2, r1, sh);   // 64 bits from pos on
         const uint32_t bt = win0 & ((1u << mt) - 1u);                                                          // mt, mb <= 31
         const uint32_t bb = __builtin_amdgcn_alignbit(win1, win0, mt) & ((1u << mb) - 1u);
-        const uint32_t vt = bt | (((e1 >> it) & 1u) << mt) | 1u;
-        const uint32_t vb = bb | (((e1 >> ib) & 1u) << mb) | 1u;
+        const uint32_t vt = bt | (((s_t + 1u) >> 2) << mt) | 1u;        // (state 3: e_1 set)
+        const uint32_t vb = bb | (((s_b + 1u) >> 2) << mb) | 1u;
         const uint32_t wt = st ? ((bt << 31) | ((vt + 2u) << (p - 1u))) : 0u;
         const uint32_t wb = sb ? ((bb << 31) | ((vb + 2u) << (p - 1u))) : 0u;
         Eprev = sb ? 32u - (uint32_t)__clz((int)vb) : 0u;
@@ -791,8 +793,13 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
             const uint32_t next = i < 1024 ? ((rho & 1u) | (rho >> 1))                        // first row: c_q of the quad to the right (:1117)
                                            : ((((rho >> 2) | (rho >> 3)) & 1u) << 1);         // other rows: its west part (:1216)
             const uint32_t sb = ((rho >> 1) & 1u) | (((rho >> 3) & 1u) << 1);                 // the quad's bottom samples
+            // what K5b needs of the entry, in 9 bits: per sample rho_i + e_k,i + e_1,i (e_1 <= e_k <= rho holds for every codeword of
+            // T.814 Annex C: 0 insignificant, 1 significant, 2 with e_k, 3 with e_k and e_1), and "two or more samples significant"
+            const uint32_t e1 = (t >> 8) & 0xFu, ek = (t >> 12) & 0xFu;
+            uint32_t pay = (rho & (rho - 1u)) ? 0x100u : 0u;
+            for (uint32_t k = 0; k < 4; ++k) pay |= (((rho >> k) & 1u) + ((ek >> k) & 1u) + ((e1 >> k) & 1u)) << (2 * k);
             tab[i].x = t;
-            tab[i].y = (next << 9) | (sb << 28);
+            tab[i].y = pay | (next << 9) | (sb << 28);
         }
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_dec2), tab, sizeof(tab), 0, hipMemcpyHostToDevice);
         if (e != hipSuccess) return e;

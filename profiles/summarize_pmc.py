@@ -29,6 +29,7 @@ FAMILIES = [  # (family, test on the kernel name); the inverse kernels first: "i
     ("dwt_levels_1plus", lambda n: "dwt_level_kernel<false, 1, 0" in n or "dwt_level_kernel<true, 1, 0" in n or "dwt53_pk_kernel<1, 0" in n),
     ("dwt_level0_fused", lambda n: "dwt_level_kernel<" in n or "dwt53_pk_kernel<" in n),
     ("ht_encode_kernel", lambda n: "ht_encode_kernel" in n),
+    ("ht_dec_prep_kernel", lambda n: "ht_dec_prep_kernel" in n),
     ("ht_dec_vlc_kernel", lambda n: "ht_dec_vlc_kernel" in n),
     ("ht_dec_ms_kernel", lambda n: "ht_dec_ms_kernel" in n),
     ("t1_dec_kernel", lambda n: "t1_dec_kernel" in n),

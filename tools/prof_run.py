@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, grok_amd as G, synth
 wl = os.environ.get("PROF_WORKLOAD", "8k")
+if wl == "8k_int32":          # the headline frame on the reference's int32 planes (bench.py workloads.8k_int32)
+    os.environ["GRK_AMD_DWT_PK"] = "0"; os.environ["GRK_AMD_PLANES16"] = "0"
 n = int(os.environ.get("PROF_N", "4"))
 S = int(os.environ.get("PROF_SIZE", "8192"))
 ctx = G.Context(0)
@@ -32,8 +34,8 @@ if wl == "cfg5":
     ctx.decode_status()
     print("done cfg5")
     sys.exit(0)
-shape = {"8k": (3, S, S, 8, 5, 1, False), "cfg2": (3, 4096, 4096, 8, 5, 1, False), "cfg3": (3, 8192, 8192, 16, 5, 1, True),
-         "cfg4tile": (3, 1024, 1024, 8, 5, 64, False)}[wl]
+shape = {"8k": (3, S, S, 8, 5, 1, False), "8k_int32": (3, S, S, 8, 5, 1, False), "cfg2": (3, 4096, 4096, 8, 5, 1, False),
+         "cfg3": (3, 8192, 8192, 16, 5, 1, True), "cfg4tile": (3, 1024, 1024, 8, 5, 64, False), "cfg4": (3, 1024, 1024, 8, 5, 256, False)}[wl]
 Cn, W, H, prec, L, nt, irrev = shape
 px = synth.g2(Cn, H, W, prec)
 p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev)
