@@ -100,3 +100,26 @@ def test_product_never_touches_the_oracle():
         if os.path.exists(path):
             needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
             assert "oracle" not in needed
+
+
+def _build_node_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "node_example")
+    libdir = os.path.dirname(G.lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "node_example.c"), "-o", exe, "-L" + libdir, "-lgrok_amd",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_c_host_of_the_node_api_compiles_and_fails_loudly_without_a_gpu(tmp_path):
+    """INTEGRATION.md 5a's C host (tests/c/node_example.c) is real code: plain C99 against include/grok_amd.h, linked with
+    libgrok_amd.so.  Without a GPU grk_amd_node_create reports GRK_AMD_ERR_NO_DEVICE (no CPU fallback)."""
+    import subprocess
+    import torch
+    exe = _build_node_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "no device" in r.stdout, r.stdout + r.stderr

@@ -78,3 +78,13 @@ def test_host_pixels_pinned_and_pageable_give_the_same_blocks():
     assert got0 == got1
     back = c.decode_host(p, t0, c0)
     assert np.array_equal(back[0], px)
+
+
+def test_c_host_example_over_two_contexts(tmp_path):
+    """tests/c/node_example.c (plain C99 + libgrok_amd.so) with the device list {0, 0}: both exchanges and the
+    single-context encode give one file."""
+    import subprocess
+    from test_capi_host import _build_node_example
+    exe = _build_node_example(tmp_path)
+    r = subprocess.run([exe, "0", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "devices 2" in r.stdout and "identical" in r.stdout, r.stdout + r.stderr
