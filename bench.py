@@ -659,7 +659,6 @@ def main():
             for _ in range(2):
                 ctx.decode_device(params, ntiles, table_d, ctx.coded_device_ptr(), total_d, d_back.data_ptr())
         torch.cuda.synchronize(dev)
-        ctx.enable_timing(True)
         dsteps = max(3, min(args.steps, 10))
         t0 = time.perf_counter()
         with torch.cuda.stream(stream):
@@ -667,12 +666,22 @@ def main():
                 ctx.decode_device(params, ntiles, table_d, ctx.coded_device_ptr(), total_d, d_back.data_ptr())
         torch.cuda.synchronize(dev)
         ddt = time.perf_counter() - t0
+        # the kernel families one at a time, with HIP events around them (a pass of its own: the events cost the timed calls
+        # a few microseconds each, and with the overlap on K5b of the top resolution runs beside the small inverse levels)
+        ctx.set_overlap(False)
+        ctx.enable_timing(True)
+        with torch.cuda.stream(stream):
+            for _ in range(dsteps):
+                ctx.decode_device(params, ntiles, table_d, ctx.coded_device_ptr(), total_d, d_back.data_ptr())
+        torch.cuda.synchronize(dev)
         try:
             ctx.decode_status()
             decode_err = None
         except RuntimeError as e:       # e.g. full-scale content: both decoders reject U_q > missing_msbs (defect D5)
             decode_err = str(e)
         dk = {name: ctx.kernel_ms(idx) for idx, name in ((5, "ht_cleanup_decode"), (6, "idwt53_5levels"), (7, "egress_mct"))}
+        ctx.enable_timing(False)
+        ctx.set_overlap(not args.no_overlap)
         b_in_d = (prec + 7) // 8
         b_pl_d, _ = ctx.plane_sample_bytes(params, decode=True)
         coded_sum_d = int(table_d["length"].astype(np.int64).sum())

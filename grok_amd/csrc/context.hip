@@ -95,8 +95,7 @@ struct grk_amd_ctx {
     std::string err;
     // working set
     DevBuf pixels, p0, p1, llA, llB, blockdesc, lengths, offsets, arena, flag;
-    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels, dec_work, dec_vraw, dec_vbase;
-    std::vector<uint32_t> h_vbase;                          // HT decode: [nblocks] scratch offsets, then the list of blocks with data
+    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels, dec_work, dec_vraw;
     // geometry cache
     grk_amd_tile_params gp{};
     bool have_geom = false;
@@ -136,10 +135,15 @@ struct grk_amd_ctx {
     uint64_t last_nblocks = 0;
     bool last_h16 = false;           // the latest encode left int16 coefficients in the Mallat planes
     HostStage stage;                 // pinned chunks for pageable host buffers (copy_h2d / copy_d2h)
-    // grk_amd_decode_region: the table with the skipped blocks marked, in pinned memory the context owns (two, used in turn:
-    // the upload of one call is a DMA that may still run when the next call fills its table)
-    struct RegionTable { grk_amd_coded_block* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; } region_table[2];
-    uint32_t region_turn = 0;
+    // A decode call's tables -- the code-block rows (a window's skipped blocks marked), behind them K5's scratch index and the list
+    // of blocks with data -- are put together in pinned memory the context owns and fetched by a kernel of the call's stream
+    // (launch_dec_upload); two sets in turn: the kernel of one call may still be queued when the next call fills its tables
+    // Full decode with overlap on: K5b of the top resolution's blocks (3/4 of them) runs on the side stream beside K5b of the
+    // other blocks and the inverse levels that need only those; the last inverse level waits for it
+    hipEvent_t ev_dec_front = nullptr, ev_dec_top = nullptr;
+    bool dec_top_pending = false;
+    struct DecUpload { char* p = nullptr; char* dp = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; } dec_up[2];
+    uint32_t dec_turn = 0;
     // timing
     bool timing = false;
     Timer timers[10];
@@ -622,6 +626,10 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
             if (l == 0) { a.wx0 = n.x0; a.wy0 = n.y0; a.wx1 = n.x1; a.wy1 = n.y1; }
         }
         if (a.cw == 0 || a.ch == 0) continue;       // (a level without samples, see run_dwt)
+        if (l == 0 && c->dec_top_pending) {           // the top resolution's blocks are decoded on the side stream
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_dec_top, 0), "wait for the top resolution's blocks");
+            c->dec_top_pending = false;
+        }
         if (l == 0 && d_pixels) {
             a.pixels = d_pixels; a.px_bytes = out_bytes;
             a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
@@ -636,47 +644,74 @@ int run_idwt(grk_amd_ctx* c, uint32_t nplanes, const void* d_mallat, void* d_out
     return GRK_AMD_OK;
 }
 
-int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes, void* d_mallat,
-                  bool h16 = false)
+// The pinned tables of this call with the caller's rows in them (room for K5's index behind the rows); the set's last upload
+// has been waited for (two calls ago: long done)
+int stage_table(grk_amd_ctx* c, const grk_amd_coded_block* table, uint64_t nblocks, grk_amd_ctx::DecUpload** out)
+{
+    grk_amd_ctx::DecUpload* u = &c->dec_up[c->dec_turn++ & 1u];
+    if (!u->ev) HIP_TRY(c, hipEventCreateWithFlags(&u->ev, hipEventDisableTiming), "create event");
+    HIP_TRY(c, hipEventSynchronize(u->ev), "wait for the tables' last upload");
+    const size_t need = (size_t)nblocks * (sizeof(grk_amd_coded_block) + 8) + 64;
+    if (u->cap < need) {
+        if (u->p) (void)hipHostFree(u->p);
+        u->p = u->dp = nullptr; u->cap = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&u->p, need, hipHostMallocDefault), "alloc pinned tables");
+        HIP_TRY(c, hipHostGetDevicePointer((void**)&u->dp, u->p, 0), "map pinned tables");
+        u->cap = need;
+    }
+    std::memcpy(u->p, table, (size_t)nblocks * sizeof(grk_amd_coded_block));
+    *out = u;
+    return GRK_AMD_OK;
+}
+
+// rows (+ `extra` bytes behind them) -> dec_table on the call's stream, the status block cleared
+int upload_table(grk_amd_ctx* c, grk_amd_ctx::DecUpload* u, size_t bytes)
+{
+    HIP_TRY(c, c->dec_table.ensure(bytes + 64), "alloc decode table");
+    HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc status");
+    HIP_TRY(c, launch_dec_upload(u->dp, c->dec_table.p, bytes, c->flag.p, c->stream), "upload decode tables");
+    HIP_TRY(c, hipEventRecord(u->ev, c->stream), "record the tables' upload");
+    return GRK_AMD_OK;
+}
+
+int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, const void* d_coded, uint64_t coded_bytes, void* d_mallat,
+                  bool h16 = false, bool split = false)
 {
     const TileGeom& g = c->geom;
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
+    const grk_amd_coded_block* const table = (const grk_amd_coded_block*)up->p;
     uint32_t max_len = 0;
     // per block: where K5p puts its un-stuffed MEL / VLC bits (scratch words); behind that the blocks that have data at all --
     // K5p's waves and K5a's lanes (a window's skipped blocks and absent blocks cost neither a wave nor a lane of a serial chain)
-    c->h_vbase.resize(2 * nblocks);
+    uint32_t* const h_vbase = (uint32_t*)(up->p + nblocks * sizeof(grk_amd_coded_block));
     uint64_t vwords = 0;
     uint32_t nactive = 0;
     for (uint64_t i = 0; i < nblocks; ++i) {
         max_len = std::max(max_len, table[i].length);
         if (table[i].offset > coded_bytes || table[i].length > coded_bytes - table[i].offset)
             return fail(c, GRK_AMD_ERR_INVALID, "block table row points outside the coded buffer");
-        c->h_vbase[i] = (uint32_t)vwords;
+        h_vbase[i] = (uint32_t)vwords;
         if (table[i].length) {
             vwords += ht_dec_scratch_words(table[i].length);
-            c->h_vbase[nblocks + nactive++] = (uint32_t)i;
+            h_vbase[nblocks + nactive++] = (uint32_t)i;
         }
     }
     if (max_len > (48u << 10)) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "code-block longer than 48 KiB");
     if (vwords > 0xFFFFFFF0ull) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "more than 8 GB of coded data in one call");
     static_assert(sizeof(HtDecBlock) == sizeof(grk_amd_coded_block), "decode table rows are grk_amd_coded_block");
     HIP_TRY(c, c->dec_vraw.ensure((vwords + 64) * 4), "alloc VLC / MEL scratch");
-    HIP_TRY(c, c->dec_vbase.ensure(2 * nblocks * 4), "alloc scratch index");
-    HIP_TRY(c, hipMemcpyAsync(c->dec_vbase.p, c->h_vbase.data(), (nblocks + nactive) * 4, hipMemcpyHostToDevice, c->stream), "upload scratch index");
-    HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
     HIP_TRY(c, c->dec_quads.ensure(nblocks * 1024 * 2 + 64), "alloc quad info");
     HIP_TRY(c, c->dec_mslen.ensure(nblocks * 4), "alloc ms lengths");
-    HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc status");
-    HIP_TRY(c, hipMemcpyAsync(c->dec_table.p, table, nblocks * sizeof(HtDecBlock), hipMemcpyHostToDevice, c->stream), "upload decode table");
-    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, 16, c->stream), "clear status");
+    { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock) + (nblocks + nactive) * 4); if (rc) return rc; }
+    const uint32_t* const d_vbase = (const uint32_t*)((const char*)c->dec_table.p + nblocks * sizeof(HtDecBlock));
     HtDecArgs a{};
     a.table = (const HtDecBlock*)c->dec_table.p;
     a.blocks = (const HtBlockDesc*)c->dec_desc.p; a.blocks_per_tile = bpt; a.nblocks = (uint32_t)nblocks; a.ncomp = g.p.num_comps;
     a.coded = (const uint8_t*)d_coded; a.coded_bytes = coded_bytes;
     a.quads = (uint32_t*)c->dec_quads.p; a.ms_len = (uint32_t*)c->dec_mslen.p; a.status = (unsigned int*)c->flag.p;
-    a.vraw = (uint32_t*)c->dec_vraw.p; a.vbase = (const uint32_t*)c->dec_vbase.p;
-    a.active = nactive == nblocks ? nullptr : (const uint32_t*)c->dec_vbase.p + nblocks; a.nactive = nactive;
+    a.vraw = (uint32_t*)c->dec_vraw.p; a.vbase = d_vbase;
+    a.active = nactive == nblocks ? nullptr : d_vbase + nblocks; a.nactive = nactive;
     a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.irreversible = g.p.irreversible;
     a.h16 = h16 ? 1 : 0;
@@ -704,24 +739,42 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* ta
         HIP_TRY(c, hipStreamSynchronize(c->stream), "sync refinement table");       // (uploaded from a local)
         a.refine = (const uint2*)c->dec_seg_dev.p;
     }
+    // K5b in two parts when the call goes on with the inverse transform (decode_impl): the levels below the last one need the
+    // blocks of the lower resolutions only -- a quarter of them --, and those short, latency-bound launches hide beside the
+    // top resolution's K5b on the low-priority side stream
+    const uint32_t L = g.p.num_levels;
+    const uint32_t first_top = L >= 1 ? g.res[L].band[0].first_block : 0;
+    if (split && c->overlap && c->side && L >= 2 && !a.refine && first_top > 0 && first_top < g.blocks_per_comp) {
+        if (!c->ev_dec_front) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_dec_front, hipEventDisableTiming), "create event");
+        if (!c->ev_dec_top) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_dec_top, hipEventDisableTiming), "create event");
+        HIP_TRY(c, launch_ht_decode_front(a, c->stream), "launch ht decode");
+        HIP_TRY(c, hipEventRecord(c->ev_dec_front, c->stream), "record K5a");
+        HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_dec_front, 0), "side stream waits for K5a");
+        a.ms_bpc = g.blocks_per_comp;
+        a.ms_first = first_top; a.ms_count = g.blocks_per_comp - first_top;
+        HIP_TRY(c, launch_ht_decode_ms(a, max_len, c->side), "launch K5b, top resolution");
+        HIP_TRY(c, hipEventRecord(c->ev_dec_top, c->side), "record K5b");
+        c->dec_top_pending = true;
+        a.ms_first = 0; a.ms_count = first_top;
+        HIP_TRY(c, launch_ht_decode_ms(a, max_len, c->stream), "launch K5b, lower resolutions");
+        return GRK_AMD_OK;
+    }
     ScopedTimer t(c, 5);
     HIP_TRY(c, launch_ht_decode(a, max_len, c->stream), "launch ht decode");
     return GRK_AMD_OK;
 }
 
-int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, const grk_amd_coded_block* table, const void* d_coded, uint64_t coded_bytes, void* d_mallat)
+int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, const void* d_coded, uint64_t coded_bytes, void* d_mallat)
 {
     const TileGeom& g = c->geom;
     const uint32_t bpt = g.blocks_per_comp * g.p.num_comps;
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
+    const grk_amd_coded_block* const table = (const grk_amd_coded_block*)up->p;
     for (uint64_t i = 0; i < nblocks; ++i)
         if (table[i].offset > coded_bytes || table[i].length > coded_bytes - table[i].offset)
             return fail(c, GRK_AMD_ERR_INVALID, "block table row points outside the coded buffer");
-    HIP_TRY(c, c->dec_table.ensure(nblocks * sizeof(HtDecBlock)), "alloc decode table");
     HIP_TRY(c, c->dec_work.ensure(nblocks * 4096 * 4), "alloc Part-1 workspace");
-    HIP_TRY(c, c->flag.ensure(kHtAllocBytes), "alloc status");
-    HIP_TRY(c, hipMemcpyAsync(c->dec_table.p, table, nblocks * sizeof(HtDecBlock), hipMemcpyHostToDevice, c->stream), "upload decode table");
-    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, 16, c->stream), "clear status");
+    { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock)); if (rc) return rc; }
     T1DecArgs a{};
     a.table = (const HtDecBlock*)c->dec_table.p;
     a.blocks = (const HtBlockDesc*)c->dec_desc.p; a.blocks_per_tile = bpt; a.nblocks = (uint32_t)nblocks; a.ncomp = g.p.num_comps;
@@ -893,7 +946,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     drain_timers(c);
     for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
                       &c->offsets, &c->arena, &c->flag, &c->dec_desc, &c->dec_table, &c->dec_quads, &c->dec_mslen,
-                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->dec_vraw, &c->dec_vbase, &c->ht_sel})
+                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->dec_vraw, &c->ht_sel})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
@@ -910,9 +963,11 @@ void grk_amd_destroy(grk_amd_ctx* c)
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     for (DevBuf* b : {&c->dec_seg_dev}) b->release();
     c->stage.release();
-    for (auto& rt : c->region_table) {
-        if (rt.p) (void)hipHostFree(rt.p);
-        if (rt.ev) (void)hipEventDestroy(rt.ev);
+    if (c->ev_dec_front) (void)hipEventDestroy(c->ev_dec_front);
+    if (c->ev_dec_top) (void)hipEventDestroy(c->ev_dec_top);
+    for (auto& u : c->dec_up) {
+        if (u.p) (void)hipHostFree(u.p);
+        if (u.ev) (void)hipEventDestroy(u.ev);
     }
     delete c;
 }
@@ -1013,8 +1068,10 @@ int grk_amd_stage_ht_decode(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32
     if (!c || !p || !table || !d_coded || !d_mallat || ntiles == 0) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = ensure_geom(c, p); if (rc) return rc;
-    rc = p->reserved[0] ? run_t1_decode(c, ntiles, table, d_coded, coded_bytes, d_mallat)
-                        : run_ht_decode(c, ntiles, table, d_coded, coded_bytes, d_mallat);
+    grk_amd_ctx::DecUpload* up = nullptr;
+    rc = stage_table(c, table, (uint64_t)c->geom.blocks_per_comp * c->geom.p.num_comps * ntiles, &up); if (rc) return rc;
+    rc = p->reserved[0] ? run_t1_decode(c, ntiles, up, d_coded, coded_bytes, d_mallat)
+                        : run_ht_decode(c, ntiles, up, d_coded, coded_bytes, d_mallat);
     if (rc) return rc;
     return check_decode_status(c);
 }
@@ -1034,25 +1091,15 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
     const bool fuse_out = g.p.num_levels >= 1 && bps <= 2 && c->fuse_egress;
     // region decode: the blocks no sample of the window depends on are not decoded, the synthesis covers what is needed
     RegionPlan plan;
-    grk_amd_ctx::RegionTable* wt = nullptr;
+    grk_amd_ctx::DecUpload* up = nullptr;
+    rc = stage_table(c, table, (uint64_t)g.blocks_per_comp * g.p.num_comps * ntiles, &up); if (rc) return rc;
     if (win) {
         if (ntiles != 1 || win->x0 >= win->x1 || win->y0 >= win->y1 || win->x1 > g.p.tile_w || win->y1 > g.p.tile_h)
             return fail(c, GRK_AMD_ERR_INVALID, "window outside the tile");
         if (!fuse_out) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "region decode needs at least one DWT level and 8-/16-bit pixels");
         plan = plan_region(g, *win);
         const uint32_t L = g.p.num_levels;
-        const size_t nrows = (size_t)g.blocks_per_comp * g.p.num_comps;
-        wt = &c->region_table[c->region_turn++ & 1u];
-        if (!wt->ev) HIP_TRY(c, hipEventCreateWithFlags(&wt->ev, hipEventDisableTiming), "create event");
-        HIP_TRY(c, hipEventSynchronize(wt->ev), "wait for the table's last upload");       // (two calls ago: long done)
-        if (wt->cap < nrows) {
-            if (wt->p) (void)hipHostFree(wt->p);
-            wt->p = nullptr; wt->cap = 0;
-            HIP_TRY(c, hipHostMalloc((void**)&wt->p, nrows * sizeof(grk_amd_coded_block), hipHostMallocDefault), "alloc pinned table");
-            wt->cap = nrows;
-        }
-        grk_amd_coded_block* const wtable = wt->p;
-        std::memcpy(wtable, table, nrows * sizeof(grk_amd_coded_block));
+        grk_amd_coded_block* const wtable = (grk_amd_coded_block*)up->p;
         size_t i = 0;
         auto sat = [](uint32_t a, uint32_t b) { return a > b ? a - b : 0u; };
         for (uint32_t k = 0; k < g.p.num_comps; ++k)
@@ -1075,7 +1122,6 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
                 }
                 ++i;
             }
-        table = wtable;
     }
     const void* d_coded = coded;
     if (!coded_on_device) {
@@ -1100,10 +1146,9 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
                      c->dec_seg_first.empty();
     {
         ScopedTimer t(c, 3);
-        rc = p->reserved[0] ? run_t1_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p)
-                            : run_ht_decode(c, ntiles, table, d_coded, coded_bytes, c->p1.p, h16);
+        rc = p->reserved[0] ? run_t1_decode(c, ntiles, up, d_coded, coded_bytes, c->p1.p)
+                            : run_ht_decode(c, ntiles, up, d_coded, coded_bytes, c->p1.p, h16, true);
         if (rc) return rc;
-        if (wt) HIP_TRY(c, hipEventRecord(wt->ev, c->stream), "record the table's upload");
         // with at least one DWT level and 8-/16-bit pixels the last level writes the pixels itself (K7 fused): the
         // int32 image planes (4 bytes per sample written and read back) never exist
         if (fuse_out) {

@@ -117,8 +117,15 @@ struct HtDecArgs {
     const uint2* refine;                       // [nblocks] {bytes of the SigProp / MagRef segment at the end of the block's
                                                // data, coding passes in total (1..3)}, or null: cleanup passes only
     uint32_t max_refine_bytes;                 // largest such segment
+    uint32_t ms_first, ms_count, ms_bpc;       // K5b of a part of the blocks: [ms_first, ms_first + ms_count) of every component's
+                                               // ms_bpc blocks (ms_count = 0: all nblocks)
 };
+// K5p + K5a + K5b (+ K5c) on one stream, or in two parts: front = tables + K5p + K5a, ms = K5b (+ K5c) of a.ms_first / ms_count
 hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s);
+hipError_t launch_ht_decode_front(const HtDecArgs& a, hipStream_t s);
+hipError_t launch_ht_decode_ms(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s);
+// a decode call's tables: `bytes` of pinned host memory (device-visible address) -> dst, the 16-byte status block cleared
+hipError_t launch_dec_upload(const void* pinned, void* dst, size_t bytes, void* status, hipStream_t s);
 // scratch words K5p may write / K5a may read for a block of `length` coded bytes (MEL + VLC bits + padding)
 inline uint32_t ht_dec_scratch_words(uint32_t length) { return length / 2u + 16u; }
 

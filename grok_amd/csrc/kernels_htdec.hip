@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t raw[];       // un-stuffed MagSgn bits + 4 words of ones
     const int lane = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
+    const uint32_t blk = a.ms_count ? blockIdx.y * a.ms_bpc + a.ms_first + blockIdx.x : blockIdx.x;
     const HtDecBlock in = a.table[blk];
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
     const uint32_t tile = blk / a.blocks_per_tile;
@@ -777,9 +777,38 @@ __global__ __launch_bounds__(64) void ht_dec_refine_kernel(HtDecArgs a, uint32_t
 
 } // namespace
 
+namespace {
+
+// The per-call tables of a decode (code-block rows, K5's scratch index) come out of pinned host memory by a kernel of the call's own
+// stream: two engine copies + a fill cost the 8K decode 63 us per call (13 + 21 + 3.5 us and four ~9 us hand-overs between the copy
+// engine and the compute queue, tools/dec_timeline.sh), a kernel that reads the same bytes over the link starts where the last
+// kernel of the call before ended.  The status word of the call is cleared on the way.
+typedef unsigned int up_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void dec_upload_kernel(const up_u32x4* __restrict__ src, up_u32x4* __restrict__ dst, uint32_t n, up_u32x4* status)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = __builtin_nontemporal_load(src + i);
+    if (i == 0 && status) *status = up_u32x4{0u, 0u, 0u, 0u};
+}
+
+} // namespace
+
+hipError_t launch_dec_upload(const void* pinned, void* dst, size_t bytes, void* status, hipStream_t s)
+{
+    const uint32_t n = (uint32_t)((bytes + 15) / 16);
+    hipLaunchKernelGGL(dec_upload_kernel, dim3(n ? (n + 255) / 256 : 1), dim3(256), 0, s, (const up_u32x4*)pinned, (up_u32x4*)dst, n, (up_u32x4*)status);
+    return hipGetLastError();
+}
+
 static bool g_dec_tables_ready[16] = {false};
 
 hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s)
+{
+    const hipError_t e = launch_ht_decode_front(a, s);
+    return e != hipSuccess ? e : launch_ht_decode_ms(a, max_ms_bytes, s);
+}
+
+hipError_t launch_ht_decode_front(const HtDecArgs& a, hipStream_t s)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -818,11 +847,21 @@ hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream
     uint32_t lanes = 64;
     while (lanes > 16 && (a.nactive + lanes - 1) / lanes < 1280) lanes >>= 1;
     hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nactive + lanes - 1) / lanes), dim3(lanes), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ht_decode_ms(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s)
+{
+    // (runs even when no block has data: absent blocks are zeros in the planes)
     const uint32_t raw_words = (max_ms_bytes * 8u) / 32u + 8u;
+    const dim3 grid = a.ms_count ? dim3(a.ms_count, a.nblocks / a.ms_bpc) : dim3(a.nblocks);
+    // (measured and not kept: the side-stream part capped at 6 / 5 / 4 waves per SIMD so that the four-wave workgroups of the small
+    //  inverse levels find room beside it -- they do, 227 us for the four instead of 290, but K5b wants its eight waves: 267 -> 320 us
+    //  at 5, the call 0.833 -> 0.852 / 0.861 / 0.880 ms)
     if (a.irreversible)
-        hipLaunchKernelGGL(ht_dec_ms_kernel<true>, dim3(a.nblocks), dim3(64), raw_words * 4, s, a, raw_words);
+        hipLaunchKernelGGL(ht_dec_ms_kernel<true>, grid, dim3(64), raw_words * 4, s, a, raw_words);
     else
-        hipLaunchKernelGGL(ht_dec_ms_kernel<false>, dim3(a.nblocks), dim3(64), raw_words * 4, s, a, raw_words);
+        hipLaunchKernelGGL(ht_dec_ms_kernel<false>, grid, dim3(64), raw_words * 4, s, a, raw_words);
     if (a.refine && a.max_refine_bytes) {          // some block carries SigProp / MagRef data
         const uint32_t seg_words = (a.max_refine_bytes * 8u) / 32u + 4u;
         if (a.irreversible)

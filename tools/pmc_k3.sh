@@ -25,7 +25,7 @@ for f in sorted(glob.glob(R+"/gpurun_out/pmc_k3/pass*.csv")):
         inv = "idwt" in k
         top = "dwt_level_kernel<false, 3" in k or "dwt53_pk_kernel<3" in k
         s=("ht_fallback" if "ht_encode_fallback" in k else "ht" if "ht_encode" in k else "idwt0" if inv and top else "idwt" if inv
-           else "dwt0" if top else "dwtN" if "dwt_level" in k or "dwt53_pk" in k else "vlc" if "ht_dec_vlc" in k else "ms" if "ht_dec_ms" in k else None)
+           else "dwt0" if top else "dwtN" if "dwt_level" in k or "dwt53_pk" in k else "prep" if "ht_dec_prep" in k else "vlc" if "ht_dec_vlc" in k else "ms" if "ht_dec_ms" in k else None)
         if s: acc[(s,r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (s,c),v in sorted(acc.items()):
         print("%-12s %-26s mean %14.1f  launches %d  sum/4 steps %14.1f" % (s,c,sum(v)/len(v),len(v),sum(v)/4))
