@@ -729,3 +729,46 @@ def test_mixed_packed_and_unpacked_inverse_levels_keep_the_packed_range():
     c.decode_device(p, 1, table, d_c.data_ptr(), coded.size, out.data_ptr())
     with pytest.raises(RuntimeError, match="16-bit planes"):
         c.decode_status()
+
+
+def test_tile_without_any_coded_block_decodes_to_the_dc_level():
+    """Every row of the table empty (length 0): no K5p wave and no K5a lane has anything to do, K5b still writes the zeros the
+    inverse transform reads -- stale coefficients of the call before must not come back."""
+    p = G.TileParams.make(192, 128, 3, 8, 3)
+    c = U.ctx()
+    px = synth.g2(3, 128, 192, 8)
+    table, coded = c.encode_host(p, px)
+    assert np.array_equal(c.decode_host(p, table, coded)[0], px)      # (leaves its coefficients in the planes)
+    empty = table.copy()
+    empty["length"] = 0; empty["offset"] = 0
+    back = c.decode_host(p, empty, coded)
+    assert np.all(back[0] == 128)
+
+
+def test_decode_with_and_without_the_side_stream_and_tables_of_consecutive_calls():
+    """K5b of the top resolution on the side stream (overlap on) == everything on one stream; consecutive calls on the device with
+    DIFFERENT tables -- each call's pinned table set is refilled while the call before may still be queued -- keep their own."""
+    import torch
+    p = G.TileParams.make(512, 384, 3, 8, 4)
+    c = G.Context(0)
+    imgs = [synth.g2(3, 384, 512, 8, seed=s) for s in (3, 4, 5)]
+    enc = [c.encode_host(p, im) for im in imgs]
+    tot = sum(len(cd) + 64 for _, cd in enc)
+    blob = np.zeros(tot, np.uint8)
+    tabs, at = [], 0
+    for t, cd in enc:
+        blob[at:at + len(cd)] = np.frombuffer(cd, np.uint8)
+        t2 = t.copy(); t2["offset"] += at
+        tabs.append(t2); at += len(cd) + 64
+    d_c = torch.from_numpy(blob).cuda()
+    outs = [torch.empty(imgs[0].size, dtype=torch.uint8, device="cuda") for _ in range(6)]
+    for ov in (True, False):
+        c.set_overlap(ov)
+        for rep in range(2):
+            for i in range(3):
+                c.decode_device(p, 1, tabs[i], d_c.data_ptr(), d_c.numel(), outs[3 * rep + i].data_ptr())
+        c.decode_status()
+        torch.cuda.synchronize()
+        for k in range(6):
+            assert np.array_equal(outs[k].cpu().numpy().reshape(imgs[0].shape), imgs[k % 3]), (ov, k)
+            outs[k].zero_()
