@@ -846,6 +846,7 @@ hipError_t launch_ht_decode_front(const HtDecArgs& a, hipStream_t s)
     //  chain's next instruction waits behind whatever holds the SIMD's ALU for its four cycles, wave priority or not)
     uint32_t lanes = 64;
     while (lanes > 16 && (a.nactive + lanes - 1) / lanes < 1280) lanes >>= 1;
+    if (const char* e = getenv("GRK_AMD_K5A_LANES")) lanes = (uint32_t)atoi(e);
     hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nactive + lanes - 1) / lanes), dim3(lanes), 0, s, a);
     return hipGetLastError();
 }
