@@ -11,7 +11,7 @@ import csv, glob
 ev = []
 for f in glob.glob("/tmp/dtl/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("grk_amd::(anonymous namespace)::", "")[:44]))
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), ("q%s " % r.get("Queue_Id", "?")) + r["Kernel_Name"].replace("void ", "").replace("grk_amd::(anonymous namespace)::", "").split("(")[0][:40]))
 for f in glob.glob("/tmp/dtl/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") + " " + r.get("Bytes", r.get("Size", "?"))))
