@@ -404,10 +404,22 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         }
     };
 
-    // samples are fetched two iterations ahead, even and odd iterations into their own registers
-    int32_t nE[4], nO[4] = {0, 0, 0, 0};
-    fetch(0, nE);
-    if (iters > 1) fetch(1, nO);
+    // Samples are fetched FOUR iterations ahead (two sets per parity: the samples of iteration it + 2 j wait in set j).  27 % of a
+    // wave's time is spent in s_waitcnt, and two iterations -- ~270 instructions, ~3 700 cycles at five to six waves per SIMD --
+    // do not cover a plane read that comes from HBM or the MALL beside the next frame's DWT (r03, same box: two ahead K3 0.340 /
+    // 0.338 ms alone, pipelined step 0.4665 / 0.4667; four ahead 0.326 / 0.323 and 0.4395 / 0.4431; six and eight the same as
+    // four at 8K and 4 % slower on the unpacked 16-bit path, whose sets are four registers)
+#ifndef GRK_K3_PF
+#define GRK_K3_PF 4
+#endif
+    constexpr int kAhead = GRK_K3_PF / 2;
+    int32_t nE[kAhead][4], nO[kAhead][4];
+    #pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+        nE[j][0] = nE[j][1] = nE[j][2] = nE[j][3] = 0; nO[j][0] = nO[j][1] = nO[j][2] = nO[j][3] = 0;
+        if (2u * j < iters) fetch(2u * j, nE[j]);
+        if (2u * j + 1u < iters) fetch(2u * j + 1u, nO[j]);
+    }
 
     // The loop is software-pipelined: stage 1 of iteration it+1 (sample analysis, neighbourhood,
     // VLC table index -> table load issued) runs before stage 2 of iteration it (everything that
@@ -419,13 +431,20 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         uint64_t H, V;           // MEL: quads coded with context 0, and which of them are significant (ballots: scalar registers)
     };
 
-    auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) {
+    auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nb)[kAhead][4]) {
+        int32_t (&nbuf)[4] = nb[0];
+        // the sets move up by one (register copies: two per set with packed samples) and the last one is refilled
+        auto refill = [&]() {
+    #pragma unroll
+            for (int j = 0; j + 1 < kAhead; ++j) { nb[j][0] = nb[j + 1][0]; nb[j][1] = nb[j + 1][1]; nb[j][2] = nb[j + 1][2]; nb[j][3] = nb[j + 1][3]; }
+            if (it + 2u * kAhead < iters) fetch(it + 2u * kAhead, nb[kAhead - 1]);
+        };
         // C: the four exponents as leading-zero counts of 2 mag - 1, one per byte (sample i in byte i; 0xFF: insignificant)
         uint32_t C;
         if constexpr (PK) {
             const int32_t nw0 = nbuf[0], nw1 = nbuf[1];
             const i16x2 w0 = __builtin_bit_cast(i16x2, nw0), w1 = __builtin_bit_cast(i16x2, nw1);
-            if (it + 2 < iters) fetch(it + 2, nbuf);
+            refill();
             const u16x2 p0 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w0, -w0));      // magnitudes
             const u16x2 p1 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w1, -w1));
             ovf |= __builtin_bit_cast(uint32_t, p0) | __builtin_bit_cast(uint32_t, p1);
@@ -445,7 +464,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 r[0] = (ox0 && oy0) ? r[0] : 0; r[2] = (ox1 && oy0) ? r[2] : 0;
                 r[1] = (ox0 && oy1) ? r[1] : 0; r[3] = (ox1 && oy1) ? r[3] : 0;
             }
-            if (it + 2 < iters) fetch(it + 2, nbuf);
+            refill();
             // ---- per-sample analysis (:513-563): magnitude, MagSgn value, exponent as leading-zero count
             uint32_t t[4];
 #pragma unroll
