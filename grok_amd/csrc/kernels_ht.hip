@@ -404,22 +404,19 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         }
     };
 
-    // Samples are fetched FOUR iterations ahead (two sets per parity: the samples of iteration it + 2 j wait in set j).  27 % of a
-    // wave's time is spent in s_waitcnt, and two iterations -- ~270 instructions, ~3 700 cycles at five to six waves per SIMD --
-    // do not cover a plane read that comes from HBM or the MALL beside the next frame's DWT (r03, same box: two ahead K3 0.340 /
-    // 0.338 ms alone, pipelined step 0.4665 / 0.4667; four ahead 0.326 / 0.323 and 0.4395 / 0.4431; six and eight the same as
-    // four at 8K and 4 % slower on the unpacked 16-bit path, whose sets are four registers)
-#ifndef GRK_K3_PF
-#define GRK_K3_PF 4
-#endif
-    constexpr int kAhead = GRK_K3_PF / 2;
-    int32_t nE[kAhead][4], nO[kAhead][4];
-    #pragma unroll
-    for (int j = 0; j < kAhead; ++j) {
-        nE[j][0] = nE[j][1] = nE[j][2] = nE[j][3] = 0; nO[j][0] = nO[j][1] = nO[j][2] = nO[j][3] = 0;
-        if (2u * j < iters) fetch(2u * j, nE[j]);
-        if (2u * j + 1u < iters) fetch(2u * j + 1u, nO[j]);
-    }
+    // Samples are fetched FOUR iterations ahead, into four register sets used in turn (the loop below is unrolled by four, so no
+    // set is ever copied).  A set is refilled at the END of stage 1, when the last use of its old samples is behind: issued
+    // earlier, the load needs a register of its own and its result a copy into the set -- which the compiler places at the end of
+    // the iteration, with a wait for the load just issued in front of it (r03: what the two-ahead form of r01 / r02 compiled to;
+    // 27 % of a wave's time went into s_waitcnt).  Same box: two ahead with the copy K3 0.340 / 0.338 ms alone, pipelined step
+    // 0.4665 / 0.4667; four ahead with rotating copies 0.326 / 0.323, 0.4395 / 0.4431.
+    const uint32_t itn = FULL ? 16u : iters;              // (a FULL block is 64 x 64: the loop's conditions fold, and with them the
+                                                          //  merges at which the compiler would wait for every load in flight)
+    int32_t n0[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0}, n2[4] = {0, 0, 0, 0}, n3[4] = {0, 0, 0, 0};
+    fetch(0, n0);
+    if (itn > 1) fetch(1, n1);
+    if (itn > 2) fetch(2, n2);
+    if (itn > 3) fetch(3, n3);
 
     // The loop is software-pipelined: stage 1 of iteration it+1 (sample analysis, neighbourhood,
     // VLC table index -> table load issued) runs before stage 2 of iteration it (everything that
@@ -431,20 +428,12 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         uint64_t H, V;           // MEL: quads coded with context 0, and which of them are significant (ballots: scalar registers)
     };
 
-    auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nb)[kAhead][4]) {
-        int32_t (&nbuf)[4] = nb[0];
-        // the sets move up by one (register copies: two per set with packed samples) and the last one is refilled
-        auto refill = [&]() {
-    #pragma unroll
-            for (int j = 0; j + 1 < kAhead; ++j) { nb[j][0] = nb[j + 1][0]; nb[j][1] = nb[j + 1][1]; nb[j][2] = nb[j + 1][2]; nb[j][3] = nb[j + 1][3]; }
-            if (it + 2u * kAhead < iters) fetch(it + 2u * kAhead, nb[kAhead - 1]);
-        };
+    auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) {
         // C: the four exponents as leading-zero counts of 2 mag - 1, one per byte (sample i in byte i; 0xFF: insignificant)
         uint32_t C;
         if constexpr (PK) {
             const int32_t nw0 = nbuf[0], nw1 = nbuf[1];
             const i16x2 w0 = __builtin_bit_cast(i16x2, nw0), w1 = __builtin_bit_cast(i16x2, nw1);
-            refill();
             const u16x2 p0 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w0, -w0));      // magnitudes
             const u16x2 p1 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w1, -w1));
             ovf |= __builtin_bit_cast(uint32_t, p0) | __builtin_bit_cast(uint32_t, p1);
@@ -464,7 +453,6 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 r[0] = (ox0 && oy0) ? r[0] : 0; r[2] = (ox1 && oy0) ? r[2] : 0;
                 r[1] = (ox0 && oy1) ? r[1] : 0; r[3] = (ox1 && oy1) ? r[3] : 0;
             }
-            refill();
             // ---- per-sample analysis (:513-563): magnitude, MagSgn value, exponent as leading-zero count
             uint32_t t[4];
 #pragma unroll
@@ -539,6 +527,10 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         o.V = o.H & __ballot(rho != 0);
         o.R = N; o.U = U; o.u = u;
         Bprev = Bcur;
+        // (unconditional -- past the block's end the last rows once more --: a refill that only some paths issue leaves the
+        //  compiler's wait for the table entry no load in flight it may count on, and it waits for all of them)
+        __builtin_amdgcn_sched_barrier(0);                 // (behind the table load, on every path: the same count of loads in flight)
+        fetch(min(it + 4u, itn - 1u), nbuf);
     };
 
     auto stage2 = [&](uint32_t it, const Stage1& s) {
@@ -637,13 +629,22 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     };
 
     Stage1 sE, sO;                       // unrolled by two so that no pipeline register is ever copied
-    stage1(0, sE, nE);
-    for (uint32_t it = 0; it < iters; it += 2) {
-        if (it + 1 < iters) stage1(it + 1, sO, nO);
-        stage2(it, sE);
-        if (it + 1 < iters) {
-            if (it + 2 < iters) stage1(it + 2, sE, nE);
-            stage2(it + 1, sO);
+    stage1(0, sE, n0);
+    if constexpr (FULL) {
+        for (uint32_t it = 0;; it += 4) {                  // (the back edge always follows a stage 1: one path, one count of loads in flight)
+            stage1(it + 1, sO, n1); stage2(it, sE);
+            stage1(it + 2, sE, n2); stage2(it + 1, sO);
+            stage1(it + 3, sO, n3); stage2(it + 2, sE);
+            if (it + 4 >= itn) { stage2(it + 3, sO); break; }
+            stage1(it + 4, sE, n0); stage2(it + 3, sO);
+        }
+    } else {
+        for (uint32_t it = 0; it < itn; it += 4) {
+            if (it + 1 < itn) stage1(it + 1, sO, n1);
+            stage2(it, sE);
+            if (it + 1 < itn) { if (it + 2 < itn) stage1(it + 2, sE, n2); stage2(it + 1, sO); }
+            if (it + 2 < itn) { if (it + 3 < itn) stage1(it + 3, sO, n3); stage2(it + 2, sE); }
+            if (it + 3 < itn) { if (it + 4 < itn) stage1(it + 4, sE, n0); stage2(it + 3, sO); }
         }
     }
     };   // phase_a
