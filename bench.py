@@ -762,6 +762,35 @@ def main():
                 decode["frames_per_call"][str(NB)] = {"error": str(e)}
         ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)      # back to the headline shape
         ctx.synchronize()
+        # ---- ... or TWO / THREE CONTEXTS fed in turn, one frame per call each (a sequence decoded round-robin): K5a's serial
+        #      chains leave most of the machine idle, and another context's kernels take what is free
+        decode["contexts_in_turn"] = {}
+        try:
+            table_d, total_d = ctx.fetch_table(nblocks)      # (the arena was written again: the blocks have new offsets)
+            others = [G.Context(dev.index) for _ in range(2)]
+            ctxs = [ctx] + others
+            backs = [d_back] + [torch.empty_like(d_back) for _ in others]
+            # (the others keep the streams they created: kernels of different contexts must not queue behind each other)
+            for nc in (2, 3):
+                for _ in range(2):
+                    for i in range(nc):
+                        ctxs[i].decode_device(params, ntiles, table_d, ctx.coded_device_ptr(), total_d, backs[i].data_ptr())
+                torch.cuda.synchronize(dev)
+                n4 = max(4, min(args.steps, 10))
+                t0 = time.perf_counter()
+                for _ in range(n4):
+                    for i in range(nc):
+                        ctxs[i].decode_device(params, ntiles, table_d, ctx.coded_device_ptr(), total_d, backs[i].data_ptr())
+                torch.cuda.synchronize(dev)
+                dt4 = (time.perf_counter() - t0) / (n4 * nc)
+                for i in range(nc):
+                    ctxs[i].decode_status()
+                decode["contexts_in_turn"][str(nc)] = {"ms_per_frame": round(dt4 * 1e3, 4), "value": round(pixels_per_step / dt4 / 1e6, 1),
+                                                       "unit": "Mpixels/s",
+                                                       "lossless_round_trip": all(bool(torch.equal(b, d_px)) for b in backs[:nc])}
+            del others, ctxs, backs
+        except Exception as e:        # noqa: BLE001
+            decode["contexts_in_turn"] = {"error": str(e)}
 
     # ---- per-kernel-family durations: HIP events on the stream each kernel is launched on, `steps` more encodes.
     # K3 runs up to three times per step -- top resolution on a side stream beside DWT levels >= 1 (timer 4), the rest
