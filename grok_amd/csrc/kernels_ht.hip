@@ -428,7 +428,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         uint64_t H, V;           // MEL: quads coded with context 0, and which of them are significant (ballots: scalar registers)
     };
 
-    auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) {
+    auto stage1r = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4], auto refill_c) {
         // C: the four exponents as leading-zero counts of 2 mag - 1, one per byte (sample i in byte i; 0xFF: insignificant)
         uint32_t C;
         if constexpr (PK) {
@@ -527,11 +527,17 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         o.V = o.H & __ballot(rho != 0);
         o.R = N; o.U = U; o.u = u;
         Bprev = Bcur;
-        // (unconditional -- past the block's end the last rows once more --: a refill that only some paths issue leaves the
-        //  compiler's wait for the table entry no load in flight it may count on, and it waits for all of them)
-        __builtin_amdgcn_sched_barrier(0);                 // (behind the table load, on every path: the same count of loads in flight)
-        fetch(min(it + 4u, itn - 1u), nbuf);
+        // (in the FULL loop unconditional: a refill that only some paths issue leaves the compiler's wait for the table entry no
+        //  load in flight it may count on, and it waits for all of them)
+        if constexpr (decltype(refill_c)::value) {
+            if constexpr (FULL) {
+                __builtin_amdgcn_sched_barrier(0);         // (behind the table load, on every path: the same count of loads in flight)
+                fetch(it + 4u, nbuf);
+            } else if (it + 4u < itn) fetch(it + 4u, nbuf);
+        }
     };
+    auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) { stage1r(it, o, nbuf, std::true_type{}); };
+    auto stage1_last = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[4]) { stage1r(it, o, nbuf, std::false_type{}); };   // nothing left to fetch
 
     auto stage2 = [&](uint32_t it, const Stage1& s) {
         const uint32_t qy = 2 * it + half;
@@ -631,13 +637,23 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     Stage1 sE, sO;                       // unrolled by two so that no pipeline register is ever copied
     stage1(0, sE, n0);
     if constexpr (FULL) {
-        for (uint32_t it = 0;; it += 4) {                  // (the back edge always follows a stage 1: one path, one count of loads in flight)
+        uint32_t it = 0;
+        for (; it + 8 < itn; it += 4) {                    // (the back edge always follows a stage 1: one path, one count of loads in flight)
             stage1(it + 1, sO, n1); stage2(it, sE);
             stage1(it + 2, sE, n2); stage2(it + 1, sO);
             stage1(it + 3, sO, n3); stage2(it + 2, sE);
-            if (it + 4 >= itn) { stage2(it + 3, sO); break; }
             stage1(it + 4, sE, n0); stage2(it + 3, sO);
         }
+        // the last eight iterations: the sets of the last four are not refilled -- a load nobody reads still has to land before
+        // its register is written again, and phase B would begin with a wait for four of them
+        stage1(it + 1, sO, n1); stage2(it, sE);
+        stage1(it + 2, sE, n2); stage2(it + 1, sO);
+        stage1(it + 3, sO, n3); stage2(it + 2, sE);
+        stage1_last(it + 4, sE, n0); stage2(it + 3, sO);
+        stage1_last(it + 5, sO, n1); stage2(it + 4, sE);
+        stage1_last(it + 6, sE, n2); stage2(it + 5, sO);
+        stage1_last(it + 7, sO, n3); stage2(it + 6, sE);
+        stage2(it + 7, sO);
     } else {
         for (uint32_t it = 0; it < itn; it += 4) {
             if (it + 1 < itn) stage1(it + 1, sO, n1);
@@ -646,6 +662,10 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             if (it + 2 < itn) { if (it + 3 < itn) stage1(it + 3, sO, n3); stage2(it + 2, sE); }
             if (it + 3 < itn) { if (it + 4 < itn) stage1(it + 4, sE, n0); stage2(it + 3, sO); }
         }
+        // (a use of every set: the compiler's bookkeeping of loads in flight is path-insensitive, and what it cannot prove consumed
+        //  here would cost the code behind phase A -- shared with the FULL blocks -- a wait for everything at its first register reuse)
+        asm volatile("" : : "v"(n0[0]), "v"(n0[1]), "v"(n0[2]), "v"(n0[3]), "v"(n1[0]), "v"(n1[1]), "v"(n1[2]), "v"(n1[3]),
+                            "v"(n2[0]), "v"(n2[1]), "v"(n2[2]), "v"(n2[3]), "v"(n3[0]), "v"(n3[1]), "v"(n3[2]), "v"(n3[3]));
     }
     };   // phase_a
     if (full) phase_a(std::true_type{}); else phase_a(std::false_type{});
