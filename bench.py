@@ -602,6 +602,14 @@ def main():
 
     pipelined = not args.no_overlap
     exchange = (args.exchange if use_dist else None)
+    # The GPU's clocks take some ten milliseconds of load to settle (tools measurement, r03: the first region of 20 frames after an
+    # idle second 0.458-0.476 ms per frame, every later one 0.435-0.444): the job's steady state is what the metric is about, so a
+    # fixed stretch of the same encodes runs before the W warm-up steps (untimed, reported in config.prewarm_steps)
+    PREWARM = 40
+    with torch.cuda.stream(stream):
+        for _ in range(PREWARM):
+            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
+    torch.cuda.synchronize(dev)
     dt, last_parts, last_root = run_frames(params, ntiles, d_px, nblocks, exchange, args.steps, args.warmup)
     multi_gpu = None
     if use_dist:
@@ -879,7 +887,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(irrev, b_pl), "data": "synthetic",
             "config": {"workload": desc, "tiles_per_gpu": ntiles, "code_blocks_per_gpu": int(nblocks),
                        "coded_bytes_per_gpu": coded_sum, "arena_bytes_used_per_gpu": int(total), "packed_dwt_levels": pk_levels,
-                       "generator": "G2 (SURVEY.md §8d)", "parallelism": parallelism},
+                       "generator": "G2 (SURVEY.md §8d)", "parallelism": parallelism, "prewarm_steps": PREWARM},
             "roofline": roofline,
             # the whole step against the HBM roofline: algorithmic bytes of its kernel families as launched, and what the PMC
             # counters saw per step (`dram_*`)
