@@ -474,11 +474,13 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="every kernel alone on the GPU, also in the timed region (what the rocprofv3 kernel-trace summary "
                          "that the roofline durations are checked against is taken with)")
-    ap.add_argument("--exchange", default="gather", choices=("gather", "counts"),
-                    help="N > 1, per frame, what the headline number is timed with: 'gather' = every rank's coded tile-parts "
-                         "(exact sizes) to the frame's writer rank, which rotates with the frame number; 'counts' = all_gather of "
-                         "the coded byte counts only (parallel writers: the bytes stay on their GPU).  The other one is reported "
-                         "under multi_gpu as well")
+    ap.add_argument("--exchange", default="counts", choices=("gather", "counts"),
+                    help="N > 1, per frame, what the headline number is timed with: 'counts' = all_gather of the coded byte counts "
+                         "only (parallel writers: tiles are independent, every rank writes its own tile-parts at offsets the sizes "
+                         "give, the bytes leave each GPU over its own PCIe link -- no data-path collective); 'gather' = every "
+                         "rank's coded tile-parts (exact sizes) over xGMI to the frame's writer rank, which rotates with the frame "
+                         "number (one stream of ~100 MB per 8K frame and rank: link-bound at this frame rate).  The other one is "
+                         "reported under multi_gpu as well")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -606,10 +608,7 @@ def main():
     # idle second 0.458-0.476 ms per frame, every later one 0.435-0.444): the job's steady state is what the metric is about, so a
     # fixed stretch of the same encodes runs before the W warm-up steps (untimed, reported in config.prewarm_steps)
     PREWARM = 40
-    with torch.cuda.stream(stream):
-        for _ in range(PREWARM):
-            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
-    torch.cuda.synchronize(dev)
+    run_frames(params, ntiles, d_px, nblocks, exchange, PREWARM, 0)      # (the same frames, the same exchange: every path warm)
     dt, last_parts, last_root = run_frames(params, ntiles, d_px, nblocks, exchange, args.steps, args.warmup)
     multi_gpu = None
     if use_dist:
