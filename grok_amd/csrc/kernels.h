@@ -80,9 +80,13 @@ struct HtArgs {
     int irreversible;
 };
 size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax);
-constexpr size_t   kHtAllocBytes = 8192;
-constexpr uint32_t kHtAllocRegions = 16;           // region words available; a launch uses region_mask + 1 of them
-constexpr uint32_t kHtAllocChunk = 256u << 10;     // bytes a region takes from the shared cursor at a time
+// r03: 64 region words and 64 KiB chunks (r01 / r02: 16 and 256 KiB -- the same 4 MiB of slack at most).  An atomic on a region word
+// executes at the memory side, one after the other per word, and a block coder waits for its answer: with 16 words the round trip
+// was 10.8 % of K3's time (counters of a build that stops behind it), with 64 the 8K frame's K3 takes 0.30 instead of 0.315 ms and
+// the pipelined step 0.422 instead of 0.437 (128 / 256 words: the same; two words: 0.77 ms)
+constexpr uint32_t kHtAllocRegions = 64;           // region words available; a launch uses region_mask + 1 of them
+constexpr uint32_t kHtAllocChunk = 64u << 10;      // bytes a region takes from the shared cursor at a time (> the largest block)
+constexpr size_t   kHtAllocBytes = 256u * (1u + kHtAllocRegions);   // 32 status / cursor / class words, then one 256-byte line per region word
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);          // allocator reset + every class
 hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s);
 hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hipStream_t s);   // classes [first, last)

@@ -271,7 +271,7 @@ __device__ __forceinline__ uint32_t count_vlc_events(const uint32_t* raw, uint32
 // A single device-scope cursor serialises at the memory side (measured 13.6 ns per atomic on
 // MI355X = 0.67 ms for the 49 152 blocks of an 8K image, more than the coding itself), so blocks
 // allocate from one of kAllocRegions region words (own cache line each) that hand out space inside
-// a chunk; only a chunk refill (every ~100 blocks) touches the shared cursor.  The arena stays one
+// a chunk; only a chunk refill (every ~30 blocks) touches the shared cursor.  The arena stays one
 // compact extent [0, *cursor) with at most a block-sized gap at chunk ends.
 // Region word: bits 63..24 = chunk start / 16, bits 23..0 = 16-byte units used in the chunk.
 constexpr uint32_t kAllocRegions = kHtAllocRegions;
@@ -283,7 +283,7 @@ __global__ void ht_alloc_init_kernel(unsigned long long* flagbuf)
     if (t < 32) flagbuf[t] = 0;                                 // [0] status flags, [1] cursor (bytes), [2 + class] blocks handed to the fallback launch
     // "chunk full" so that the first allocation refills; the start field holds a value no real chunk
     // has, otherwise waves waiting for the refill could not tell the first chunk (start 0) from this state
-    if (t < kAllocRegions) flagbuf[32 * (1 + t)] = (0xFFFFFFFFFFull << 24) | kChunkUnits;
+    for (uint32_t r = t; r < kAllocRegions; r += blockDim.x) flagbuf[32 * (1 + r)] = (0xFFFFFFFFFFull << 24) | kChunkUnits;
 }
 
 __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* flagbuf, uint32_t region, uint32_t bytes)
