@@ -463,6 +463,52 @@ def via_grok_plugin(ctx, params, tile_pixels, prec, cpu_file_md5=None):
         return {"error": str(e)}
 
 
+def launch_ranks(n, dry_run):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks, one per GPU, under
+    torch.distributed.run on 127.0.0.1 (what the driver's own N > 1 command does).  Returns the launcher's exit code; the
+    ranks' stdout is this process's stdout, so rank 0's JSON line stays the last line."""
+    import socket
+    import subprocess
+    if not dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print("bench.py: --gpus %d asked for, %d GPU(s) visible -- refusing to report a %d-GPU number from fewer devices"
+                  % (n, have, n), file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(world, rank, args):
+    """The launch path without kernels: the ranks form a gloo group, meet at the barrier and count each other."""
+    arrived = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        arrived = int(t.item())
+        n_group = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        n_group = 1
+    if rank == 0:
+        print(json.dumps({"metric": "encode Mpixels/s (whole node), 8K RGB HTJ2K lossless", "value": None, "unit": "Mpixels/s",
+                          "dry_run": True, "n_gpus": n_group, "ranks_at_barrier": arrived, "steps": args.steps,
+                          "warmup": args.warmup, "backend": "gloo"}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -483,11 +529,22 @@ def main():
                          "rank's coded tile-parts (exact sizes) over xGMI to the frame's writer rank, which rotates with the frame "
                          "number (one stream of ~100 MB per 8K frame and rank: link-bound at this frame rate).  The other one is "
                          "reported under multi_gpu as well")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU: the ranks meet over gloo, count each other at the barrier and rank 0 prints "
+                         "a line with n_gpus = the ranks that really arrived; no kernels run")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` starts its N ranks ITSELF (the reference's analogue is its in-process tile pool,
+    # codestream/CodeStreamCompress.cpp:535-603: one command, all workers); under a launcher (WORLD_SIZE set) it is one rank
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, args.dry_run))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(world, rank, args)
     # GROK_AMD_FORCE_DIST=1 exercises the exchange step on a 1-GPU box (world_size 1 over RCCL)
     use_dist = world > 1 or os.environ.get("GROK_AMD_FORCE_DIST") == "1"
     if use_dist:

@@ -37,8 +37,38 @@ def test_rates_and_labels():
     assert B.dtype_label(False, 2).startswith("int16x2 packed")
 
 
-def test_defaults_of_the_command_line_contract():
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    # python bench.py with no flags: one GPU, a K / W that finish within minutes; N > 1: no data-path collective in the headline
-    assert '"--gpus", type=int, default=1' in src and '"--steps", type=int, default=20' in src and '"--warmup", type=int, default=3' in src
-    assert '"--exchange", default="counts"' in src
+def _run_bench(*flags, env_extra=None):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) must come back as TWO ranks that met at a barrier, and the JSON
+    line -- rank 0's, the last line on stdout -- must say n_gpus = the size of the process group that really formed."""
+    import json
+    r = _run_bench("--gpus", "2", "--dry-run", "--steps", "7", "--warmup", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["ranks_at_barrier"] == 2
+    assert line["steps"] == 7 and line["warmup"] == 2
+
+
+def test_no_flags_is_one_rank_and_a_short_run():
+    import json
+    r = _run_bench("--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["ranks_at_barrier"] == 1 and line["steps"] <= 50 and line["warmup"] <= 10
+
+
+def test_more_gpus_than_the_box_has_is_refused_loudly():
+    r = _run_bench("--gpus", "64")
+    assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_a_launcher_with_another_world_size_is_refused():
+    r = _run_bench("--gpus", "4", "--dry-run", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
