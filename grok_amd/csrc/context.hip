@@ -142,6 +142,10 @@ struct grk_amd_ctx {
     // other blocks and the inverse levels that need only those; the last inverse level waits for it
     hipEvent_t ev_dec_front = nullptr, ev_dec_top = nullptr;
     bool dec_top_pending = false;
+    // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
+    // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
+    bool t1_lanes = true;
+    float t1_tail_ratio = 0.25f;
     struct DecUpload { char* p = nullptr; char* dp = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; } dec_up[2];
     uint32_t dec_turn = 0;
     // timing
@@ -773,8 +777,41 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
     for (uint64_t i = 0; i < nblocks; ++i)
         if (table[i].offset > coded_bytes || table[i].length > coded_bytes - table[i].offset)
             return fail(c, GRK_AMD_ERR_INVALID, "block table row points outside the coded buffer");
-    HIP_TRY(c, c->dec_work.ensure(nblocks * 4096 * 4), "alloc Part-1 workspace");
-    { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock)); if (rc) return rc; }
+    static_assert(kT1WorkBytes == 4096 * 4, "K8 and K8L share a block's part of the workspace");
+    HIP_TRY(c, c->dec_work.ensure(nblocks * kT1WorkBytes), "alloc Part-1 workspace");
+    // Which decoder takes which block.  A block is one dependent chain of MQ decisions (about ten per coded byte); 64 chains
+    // to a wave (K8L) make the throughput, but a chain alone in a wave (K8) advances ~2.5 times faster, and a frame's time
+    // is its longest chain's: the blocks longer than t1_tail_ratio x the longest one -- a handful: the LL band -- and
+    // whatever the lane form does not take go to K8, longest first; the rest to K8L, sorted by length so that the lanes of a
+    // wave finish together.  Both lists behind the rows in the pinned tables (stage_table leaves 8 bytes per block).
+    uint32_t* const h_lane = (uint32_t*)(up->p + nblocks * sizeof(grk_amd_coded_block));
+    uint32_t* const h_tail = h_lane + nblocks;
+    uint32_t n_lane = 0, n_tail = 0;
+    const bool lanes_on = c->t1_lanes && g.p.reserved[1] == 0 && c->dec_seg_first.empty() && nblocks <= 0xFFFFFFFFull;
+    if (lanes_on) {
+        auto eligible = [&](uint64_t i) {
+            const uint32_t bps = table[i].missing_msbs & 0xFFu, np = table[i].missing_msbs >> 8;
+            return table[i].length != 0 && table[i].missing_msbs != kSkipBlock && np != 0 && bps != 0 && bps <= kT1LaneMaxPlanes &&
+                   c->h_desc_dec[i % bpt].h >= kT1LaneMinRows;
+        };
+        uint32_t max_len = 0;
+        for (uint64_t i = 0; i < nblocks; ++i) max_len = std::max(max_len, table[i].length);
+        const uint32_t thr = (uint32_t)std::min<double>((double)max_len, std::max(64.0, (double)c->t1_tail_ratio * max_len));
+        // counting sort by length (4-byte buckets), longest first
+        const uint32_t nb = (max_len >> 2) + 2u;
+        std::vector<uint32_t> cnt(nb + 1, 0u), order(nblocks);
+        for (uint64_t i = 0; i < nblocks; ++i) cnt[nb - 1u - (table[i].length >> 2)]++;
+        uint32_t run = 0;
+        for (uint32_t k = 0; k <= nb; ++k) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
+        for (uint64_t i = 0; i < nblocks; ++i) order[cnt[nb - 1u - (table[i].length >> 2)]++] = (uint32_t)i;
+        for (uint64_t k = 0; k < nblocks; ++k) {
+            const uint32_t i = order[k];
+            if (table[i].length <= thr && eligible(i)) h_lane[n_lane++] = i; else h_tail[n_tail++] = i;
+        }
+        if (n_lane < 64u) { n_lane = 0; n_tail = 0; }                   // not worth a second launch: K8 in table order
+    }
+    { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock) + nblocks * 8); if (rc) return rc; }
+    const uint32_t* const d_lane = (const uint32_t*)((const char*)c->dec_table.p + nblocks * sizeof(HtDecBlock));
     T1DecArgs a{};
     a.table = (const HtDecBlock*)c->dec_table.p;
     a.blocks = (const HtBlockDesc*)c->dec_desc.p; a.blocks_per_tile = bpt; a.nblocks = (uint32_t)nblocks; a.ncomp = g.p.num_comps;
@@ -796,6 +833,30 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
         a.segs = (const uint2*)((const char*)c->dec_seg_dev.p + ns_off);
     }
     ScopedTimer t(c, 5);
+    if (n_lane) {
+        T1LaneArgs la{};
+        la.table = a.table; la.blocks = a.blocks; la.blocks_per_tile = bpt; la.ncomp = a.ncomp;
+        la.list = d_lane; la.count = n_lane;
+        la.coded = a.coded; la.coded_bytes = coded_bytes;
+        la.work = (uint64_t*)c->dec_work.p;
+        la.mallat = a.mallat; la.stride = a.stride; la.pitch = a.pitch; la.irreversible = a.irreversible;
+        a.list = d_lane + nblocks; a.count = n_tail;
+        if (c->overlap && c->side) {
+            // the long chains on the call's stream, the lanes beside them on the side stream
+            if (!c->ev_dec_front) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_dec_front, hipEventDisableTiming), "create event");
+            if (!c->ev_dec_top) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_dec_top, hipEventDisableTiming), "create event");
+            HIP_TRY(c, hipEventRecord(c->ev_dec_front, c->stream), "record the tables");
+            HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_dec_front, 0), "side stream waits for the tables");
+            HIP_TRY(c, launch_t1_decode(a, c->stream), "launch Part-1 decode (long blocks)");
+            HIP_TRY(c, launch_t1_lanes(la, c->side), "launch Part-1 decode (lanes)");
+            HIP_TRY(c, hipEventRecord(c->ev_dec_top, c->side), "record the lanes");
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_dec_top, 0), "join the lanes");
+        } else {
+            HIP_TRY(c, launch_t1_decode(a, c->stream), "launch Part-1 decode (long blocks)");
+            HIP_TRY(c, launch_t1_lanes(la, c->stream), "launch Part-1 decode (lanes)");
+        }
+        return GRK_AMD_OK;
+    }
     HIP_TRY(c, launch_t1_decode(a, c->stream), "launch Part-1 decode");
     return GRK_AMD_OK;
 }
@@ -920,6 +981,8 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* ex = getenv("GRK_AMD_DWT_PK")) c->dwt_pk = atoi(ex) != 0;
         if (const char* ed = getenv("GRK_AMD_DEC_PLANES16")) c->dec_planes16 = atoi(ed) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
+        if (const char* et = getenv("GRK_AMD_T1_LANES")) c->t1_lanes = atoi(et) != 0;
+        if (const char* er = getenv("GRK_AMD_T1_TAIL_RATIO")) c->t1_tail_ratio = (float)atof(er);
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||

@@ -146,8 +146,25 @@ struct T1DecArgs {
     uint32_t cblksty;                          // COD code-block style bits (LAZY 1, RESET 2, TERMALL 4, VSC 8, PTERM 16, SEGSYM 32)
     const uint32_t* seg_first;                 // [nblocks + 1] first codeword segment of each block, or null: one segment
     const uint2* segs;                         // {bytes, passes} per segment
+    const uint32_t* list; uint32_t count;      // the blocks this launch decodes (one wave each, in this order), or null: all nblocks
 };
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s);
+
+// ---- K8L: the same decoder with one code-block per LANE + reconstruction from bit-plane bitmaps (kernels_t1lanes.hip) ----
+constexpr uint32_t kT1WorkBytes = 16384;       // a block's share of the Part-1 workspace (K8: 64 x 64 values; K8L: t1_lanes.h)
+constexpr uint32_t kT1LaneMaxPlanes = 14;      // bit-planes whose bitmaps fit behind a block's state there
+constexpr uint32_t kT1LaneMinRows = 9;         // a lane block has at least three stripes (t1_lanes.h: stripe hand-over)
+struct T1LaneArgs {
+    const HtDecBlock* table;                   // as T1DecArgs
+    const HtBlockDesc* blocks;
+    uint32_t blocks_per_tile, ncomp;
+    const uint32_t* list; uint32_t count;      // the blocks of this launch: lane i of wave k decodes list[64 k + i]
+    const uint8_t* coded; uint64_t coded_bytes;
+    uint64_t* work;                            // [nblocks][kT1WorkBytes / 8]
+    int32_t* mallat; uint32_t stride; uint64_t pitch;
+    int irreversible;
+};
+hipError_t launch_t1_lanes(const T1LaneArgs& a, hipStream_t s);       // t1_lanes_kernel, then t1_recon_kernel
 
 // ---- K6: one inverse DWT level, horizontal + vertical fused (kernels_idwt.hip) ------------------
 struct IdwtLevelArgs {

@@ -238,7 +238,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     // all 64 lanes run the same (uniform) program -- lane-resident tables need every lane's registers to stay live
     // through the compiler's copies -- and only lane 0 performs the side effects
     const bool writer = threadIdx.x == 0;
-    const uint32_t blk = blockIdx.x;
+    const uint32_t blk = a.list ? a.list[blockIdx.x] : blockIdx.x;
     if (blk >= a.nblocks) return;
     const HtDecBlock in = a.table[blk];
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
@@ -248,7 +248,7 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     const uint32_t sgv = g_sign_lut.w[threadIdx.x & 63u];                      // sign-coding contexts
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
     // value workspace of a deep block, [y * 64 + x] (the first pass writes every row)
-    int32_t* ws = a.work + (size_t)blockIdx.x * 4096u;
+    int32_t* ws = a.work + (size_t)blk * 4096u;
     if (in.length == 0 && in.missing_msbs == kSkipBlock) return;       // region decode: outside the decoded region
     const uint32_t tile = blk / a.blocks_per_tile;
     int32_t* const dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
@@ -482,8 +482,10 @@ __global__ void t1_dec_kernel(T1DecArgs a)
 
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s)
 {
-    if (a.irreversible) hipLaunchKernelGGL(t1_dec_kernel<true>, dim3(a.nblocks), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(t1_dec_kernel<false>, dim3(a.nblocks), dim3(64), 0, s, a);
+    const uint32_t n = a.list ? a.count : a.nblocks;
+    if (!n) return hipSuccess;
+    if (a.irreversible) hipLaunchKernelGGL(t1_dec_kernel<true>, dim3(n), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_dec_kernel<false>, dim3(n), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,122 @@
+// grok_amd/csrc/kernels_t1lanes.hip -- K8L: Part-1 (EBCOT / MQ) block decoding with one code-block per LANE, gfx950.
+//
+// The bulk of a frame's blocks (default code-block style, one codeword segment, 9..64 rows, at most 14 bit-planes) is
+// decoded 64 blocks to a wave by t1_lanes_kernel; the lane logic and the reasoning are in t1_lanes.h.  The few blocks that
+// are much longer than the rest (a frame's LL band: 17 bit-planes of 4096 mag-ref decisions each in BASELINE configs[4]) are one
+// dependent chain of 5-7 times the decisions, and a chain is faster alone in a wave: those, and everything the lane form does
+// not take (code-block styles, segments, tiny blocks), stay with kernels_t1dec.hip (K8), which runs beside this kernel.
+//   t1_lanes_kernel  -- lanes = blocks of `list` (sorted by coded length, longest first: a wave's lanes finish together).
+//                       Wave-uniform loop, at most one MQ decision per lane and iteration; a block's state between stripes
+//                       and its per-plane result bitmaps live in its 16 KB of `work`.
+//   t1_recon_kernel  -- one wave per block of `list`, lanes = columns: significance / refinement bitmaps -> coefficients,
+//                       dequantised (ShiftFilter / ScaleFilter, filters/PostDecompressFilters.h:26-35, :60-71) into the Mallat plane.
+#include "kernels.h"
+#include "t1_lanes.h"
+
+namespace grk_amd {
+
+namespace {
+
+using namespace t1l;
+
+struct LaneTables {
+    uint32_t mq[96];
+    uint16_t zc[4][512];
+    uint16_t sc[256];
+    constexpr LaneTables() : mq{}, zc{}, sc{}
+    {
+        for (uint32_t e = 0; e < 94; ++e) mq[e] = mq_entry(e);
+        for (int o = 0; o < 4; ++o)
+            for (uint32_t i = 0; i < 512; ++i) zc[o][i] = (uint16_t)(zc_context9(o, i) * 256u);
+        for (uint32_t i = 0; i < 256; ++i) sc[i] = (uint16_t)sign_context(i);
+    }
+};
+static_assert(sizeof(LaneTables) == kLdsBytes - kCtxBytes, "the tables follow the context rows in LDS");
+__device__ const LaneTables g_lane_tables{};
+
+__global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds32[kLdsBytes / 4];
+    uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds32);
+    const uint32_t lane = threadIdx.x;
+    {   // the look-up tables behind the context rows
+        const uint32_t* const src = reinterpret_cast<const uint32_t*>(&g_lane_tables);
+        for (uint32_t i = lane; i < (kLdsBytes - kCtxBytes) / 4; i += 64) lds32[kCtxBytes / 4 + i] = src[i];
+    }
+    // mqc_resetstates (mqc_dec.cpp:168-175): every context in state 0 but UNI (46), AGG (3), ZC 0 (4)
+#pragma unroll
+    for (uint32_t cx = 0; cx < 19; ++cx) lds32[cx * 64 + lane] = mq_entry(cx == 18 ? 46u : cx == 17 ? 3u : cx == 0 ? 4u : 0u);
+    Lane L;
+    const uint32_t idx = blockIdx.x * 64u + lane;
+    if (idx < a.count) {
+        const uint32_t blk = a.list[idx];
+        const HtDecBlock in = a.table[blk];
+        const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
+        BlockIn b;
+        b.data = a.coded + in.offset; b.len = in.length;
+        b.numbps = in.missing_msbs & 0xFFu; b.numpasses = in.missing_msbs >> 8;
+        b.w = bd.w; b.h = bd.h; b.orient = bd.pad;
+        b.work = a.work + (size_t)blk * kWorkU64;
+        b.lo = a.coded; b.hi = a.coded + a.coded_bytes;
+        lane_init(L, b);
+    } else {
+        L = Lane{};
+        L.st = ST_DONE; L.nv = 8; L.pend = 0;
+    }
+    __syncthreads();
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t phase = it & 3u;
+        if (phase == 0) {                          // every fourth iteration: stripes stored, the next ones and coded bytes requested
+            if (L.st == ST_NEEDSTRIPE) lane_stripe_exit(L);
+            if (lane_wants_bytes(L)) lane_fetch_issue(L);
+        } else if (phase == 2) {                   // two iterations later they are there
+            if (L.st == ST_WAIT) lane_stripe_enter(L);
+            if (L.pend) lane_fetch_arrive(L);
+        }
+        if (L.st == ST_NEEDCOL) lane_column_enter(L);
+        if (L.st <= ST_UNI2 && L.nv >= 3u) {
+            const uint32_t off = lane_context(L, lds16);
+            const uint32_t d = lane_mq_decode(L, lds32, (off >> 2) + lane);
+            lane_apply(L, d);
+        }
+        if (__builtin_amdgcn_ballot_w64(L.st != ST_DONE) == 0) break;
+    }
+}
+
+template <bool IRREV>
+__global__ __launch_bounds__(64) void t1_recon_kernel(T1LaneArgs a)
+{
+    const uint32_t blk = a.list[blockIdx.x];
+    const HtDecBlock in = a.table[blk];
+    const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
+    const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
+    const uint64_t* const wk = a.work + (size_t)blk * kWorkU64;
+    const uint32_t x = threadIdx.x;
+    const uint32_t tile = blk / a.blocks_per_tile;
+    int32_t* const dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
+    const float scale = bd.inv_step / 2;
+    for (uint32_t y = 0; y < bd.h; ++y) {
+        auto snap = [&](uint32_t i) { return ((wk[kPlaneBase + i * kPlaneU64 + y] >> x) & 1u) != 0; };
+        auto ref = [&](uint32_t i) { return ((wk[kPlaneBase + i * kPlaneU64 + 64u + y] >> x) & 1u) != 0; };
+        const uint32_t mag = recon_magnitude(numbps, numpasses, snap, ref);
+        const bool neg = ((wk[(y >> 2) * 16u + 4u + (y & 3u)] >> x) & 1u) != 0;
+        const int32_t v = neg ? -(int32_t)mag : (int32_t)mag;
+        int32_t o;
+        if constexpr (IRREV) o = __float_as_int(__fmul_rn((float)v, scale));
+        else o = v / 2;
+        if (x < bd.w) dst[(size_t)y * a.stride + x] = o;
+    }
+}
+
+} // namespace
+
+hipError_t launch_t1_lanes(const T1LaneArgs& a, hipStream_t s)
+{
+    if (!a.count) return hipSuccess;
+    hipLaunchKernelGGL(t1_lanes_kernel, dim3((a.count + 63u) / 64u), dim3(64), 0, s, a);
+    if (a.irreversible) hipLaunchKernelGGL(t1_recon_kernel<true>, dim3(a.count), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_recon_kernel<false>, dim3(a.count), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace grk_amd

@@ -28,8 +28,10 @@
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define T1L_FN __device__ __forceinline__
+#define T1L_UNROLL _Pragma("unroll")
 #else
 #define T1L_FN static inline
+#define T1L_UNROLL
 #endif
 
 namespace t1l {
@@ -170,6 +172,7 @@ T1L_FN uint32_t fetch_dword(const uint8_t* fsrc, int32_t p, const uint8_t* lo, c
     const uint8_t* q = fsrc + p;
     if (q >= lo && q + 4 <= hi) return *reinterpret_cast<const uint32_t*>(q);
     uint32_t v = 0;
+    T1L_UNROLL
     for (int b = 0; b < 4; ++b) v |= (uint32_t)((q + b >= lo && q + b < hi) ? q[b] : 0xFFu) << (8 * b);
     return v;
 }
@@ -211,7 +214,9 @@ T1L_FN void lane_init(Lane& L, const BlockIn& b)
     L.C = c << 7; L.ct = ct - 7u; L.A = 0x80000000u;
     // the first stripe of the first pass: nothing is significant, nothing to load
     L.s = 0;
+    T1L_UNROLL
     for (int r = 0; r < 6; ++r) { L.S[r] = 0; L.N[r] = 0; }
+    T1L_UNROLL
     for (int r = 0; r < 4; ++r) { L.P[r] = 0; L.M[r] = 0; L.R[r] = 0; }
     L.cm = 0; L.Q = 0; L.x = 0; L.nbx = 0; L.nnx = 0; L.pv = 0; L.mv = 0; L.rf = 0; L.todo = 0; L.t = 0; L.xr = 0; L.r = 0; L.bx = 0;
     L.st = ST_WAIT;              // lane_stripe_enter makes the stripe's masks
@@ -222,6 +227,7 @@ T1L_FN void lane_stripe_enter(Lane& L)
 {
     if (L.s + 1u == L.ns || L.fresh) { L.S[5] = 0; L.N[5] = 0; }
     L.nr = umin(4u, L.h - 4u * L.s);
+    T1L_UNROLL
     for (int r = 0; r < 4; ++r) if ((uint32_t)r >= L.nr) L.P[r] = ~0ull;      // absent rows count as visited
     const uint64_t U = L.S[0] | L.S[1] | L.S[2] | L.S[3] | L.S[4] | L.S[5];
     const uint64_t D = U | (U << 1) | (U >> 1);
@@ -242,6 +248,7 @@ T1L_FN void lane_stripe_exit(Lane& L)
 {
     uint64_t* const sp = L.work + L.s * 16u;
     if (L.type == 2) { L.P[0] = 0; L.P[1] = 0; L.P[2] = 0; L.P[3] = 0; }         // the plane is complete (T1.cpp: pi cleared)
+    T1L_UNROLL
     for (int r = 0; r < 4; ++r) { sp[r] = L.S[r + 1]; sp[4 + r] = L.N[r + 1]; sp[8 + r] = L.P[r]; sp[12 + r] = L.M[r]; }
     uint64_t* const pl = L.work + kPlaneBase + L.pidx * kPlaneU64 + 4u * L.s;
     if (L.type == 1) { for (int r = 0; r < 4; ++r) pl[64 + r] = L.R[r]; }
@@ -259,10 +266,13 @@ T1L_FN void lane_stripe_exit(Lane& L)
     }
     L.s = s;
     if (L.fresh) {
+        T1L_UNROLL
         for (int r = 1; r < 6; ++r) { L.S[r] = 0; L.N[r] = 0; }
+        T1L_UNROLL
         for (int r = 0; r < 4; ++r) { L.P[r] = 0; L.M[r] = 0; }
     } else {
         const uint64_t* const np = L.work + s * 16u;
+        T1L_UNROLL
         for (int r = 0; r < 4; ++r) { L.S[r + 1] = np[r]; L.N[r + 1] = np[4 + r]; L.P[r] = np[8 + r]; L.M[r] = np[12 + r]; }
         if (s + 1u < L.ns) { L.S[5] = np[16]; L.N[5] = np[20]; }      // the row below: the next stripe's first, from the pass before
     }
@@ -285,24 +295,28 @@ T1L_FN void lane_fetch_arrive(Lane& L)
 }
 
 // 3-bit windows (x-1, x, x+1) of six rows, row r at bits 3r..3r+2
-T1L_FN uint32_t extract3(const uint64_t* rows, uint32_t x)
+T1L_FN uint32_t extract3(const uint64_t (&rows)[6], uint32_t x)
 {
     const uint32_t sh = x ? x - 1u : 0u;
     uint32_t v = 0;
+    T1L_UNROLL
     for (int r = 0; r < 6; ++r) v |= ((uint32_t)(rows[r] >> sh) & 7u) << (3 * r);
     return x ? v : ((v << 1) & 0x36DB6u);             // column -1 does not exist
 }
 // bit x of four rows, row r at bit 3r
-T1L_FN uint32_t extract1(const uint64_t* rows, uint32_t x)
+T1L_FN uint32_t extract1(const uint64_t (&rows)[4], uint32_t x)
 {
     uint32_t v = 0;
+    T1L_UNROLL
     for (int r = 0; r < 4; ++r) v |= ((uint32_t)(rows[r] >> x) & 1u) << (3 * r);
     return v;
 }
-// rows[r] |= bx where bit 3r of m is set
-T1L_FN void scatter1(uint64_t* rows, uint32_t m, uint64_t bx)
+// rows[r + O] |= bx where bit 3r of m is set
+template <int O, int NROWS>
+T1L_FN void scatter1(uint64_t (&rows)[NROWS], uint32_t m, uint64_t bx)
 {
-    for (int r = 0; r < 4; ++r) rows[r] |= ((m >> (3 * r)) & 1u) ? bx : 0ull;
+    T1L_UNROLL
+    for (int r = 0; r < 4; ++r) rows[r + O] |= ((m >> (3 * r)) & 1u) ? bx : 0ull;
 }
 
 // ---- column enter: the next candidate column of the stripe, its neighbourhood words, the first sample to code --------------
@@ -340,12 +354,13 @@ T1L_FN void lane_column_enter(Lane& L)
 // the column is finished: its new bits go back into the stripe's rows
 T1L_FN void lane_column_exit(Lane& L)
 {
-    if (L.type == 1) { scatter1(L.M, L.mv, L.bx); scatter1(L.R, L.rf, L.bx); }
-    else {
-        scatter1(L.S + 1, (L.nbx >> 4) & 0x249u, L.bx);
-        scatter1(L.N + 1, (L.nnx >> 4) & 0x249u, L.bx);
-        if (L.type == 0) scatter1(L.P, L.pv & 0x249u, L.bx);
-    }
+    // (every array addressed on every path: a pointer chosen by the pass type would keep the rows out of registers)
+    const bool mr = L.type == 1;
+    scatter1<0>(L.M, mr ? L.mv : 0u, L.bx);
+    scatter1<0>(L.R, mr ? L.rf : 0u, L.bx);
+    scatter1<1>(L.S, mr ? 0u : (L.nbx >> 4) & 0x249u, L.bx);
+    scatter1<1>(L.N, mr ? 0u : (L.nnx >> 4) & 0x249u, L.bx);
+    scatter1<0>(L.P, L.type == 0 ? L.pv & 0x249u : 0u, L.bx);
     L.st = ST_NEEDCOL;
 }
 
