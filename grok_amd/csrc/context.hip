@@ -146,6 +146,7 @@ struct grk_amd_ctx {
     // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
     bool t1_lanes = true;
     float t1_tail_ratio = 0.25f;
+    float t1_tail_share = 0.0f;          // ... and at least this share of the blocks (the longest ones) to K8 as well
     struct DecUpload { char* p = nullptr; char* dp = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; } dec_up[2];
     uint32_t dec_turn = 0;
     // timing
@@ -804,9 +805,10 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
         uint32_t run = 0;
         for (uint32_t k = 0; k <= nb; ++k) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
         for (uint64_t i = 0; i < nblocks; ++i) order[cnt[nb - 1u - (table[i].length >> 2)]++] = (uint32_t)i;
+        const uint64_t share = (uint64_t)((double)c->t1_tail_share * (double)nblocks);
         for (uint64_t k = 0; k < nblocks; ++k) {
             const uint32_t i = order[k];
-            if (table[i].length <= thr && eligible(i)) h_lane[n_lane++] = i; else h_tail[n_tail++] = i;
+            if (k >= share && table[i].length <= thr && eligible(i)) h_lane[n_lane++] = i; else h_tail[n_tail++] = i;
         }
         if (n_lane < 64u) { n_lane = 0; n_tail = 0; }                   // not worth a second launch: K8 in table order
     }
@@ -983,6 +985,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         if (const char* et = getenv("GRK_AMD_T1_LANES")) c->t1_lanes = atoi(et) != 0;
         if (const char* er = getenv("GRK_AMD_T1_TAIL_RATIO")) c->t1_tail_ratio = (float)atof(er);
+        if (const char* es = getenv("GRK_AMD_T1_TAIL_SHARE")) c->t1_tail_share = (float)atof(es);
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||

@@ -64,6 +64,33 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
         L.st = ST_DONE; L.nv = 8; L.pend = 0;
     }
     __syncthreads();
+    // one step: the lanes that need one pick their next column; every lane with a pending decision makes it
+    auto step = [&]() {
+        if (L.st == ST_NEEDCOL) lane_column_enter(L);
+        if (L.st <= ST_UNI2 && L.nv >= 3u) {
+#ifdef T1L_BRANCHY
+            const uint32_t off = lane_context(L, lds16);
+            const uint32_t d = lane_mq_decode(L, lds32, (off >> 2) + lane);
+            lane_apply(L, d);
+#else
+            const uint32_t off = lane_context_sel(L, lds16);
+            const uint32_t d = lane_mq_decode(L, lds32, (off >> 2) + lane);
+            lane_apply_sel(L, d);
+#endif
+        }
+    };
+#ifndef T1L_NO_UNROLL4
+    // four steps to a round: stripes stored / the next ones and coded bytes requested before the first, delivery before the third
+    for (;;) {
+        if (L.st == ST_NEEDSTRIPE) lane_stripe_exit(L);
+        if (lane_wants_bytes(L)) lane_fetch_issue(L);
+        step(); step();
+        if (L.st == ST_WAIT) lane_stripe_enter(L);
+        if (L.pend) lane_fetch_arrive(L);
+        step(); step();
+        if (__builtin_amdgcn_ballot_w64(L.st != ST_DONE) == 0) break;
+    }
+#else
     for (uint32_t it = 0;; ++it) {
         const uint32_t phase = it & 3u;
         if (phase == 0) {                          // every fourth iteration: stripes stored, the next ones and coded bytes requested
@@ -73,14 +100,10 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
             if (L.st == ST_WAIT) lane_stripe_enter(L);
             if (L.pend) lane_fetch_arrive(L);
         }
-        if (L.st == ST_NEEDCOL) lane_column_enter(L);
-        if (L.st <= ST_UNI2 && L.nv >= 3u) {
-            const uint32_t off = lane_context(L, lds16);
-            const uint32_t d = lane_mq_decode(L, lds32, (off >> 2) + lane);
-            lane_apply(L, d);
-        }
+        step();
         if (__builtin_amdgcn_ballot_w64(L.st != ST_DONE) == 0) break;
     }
+#endif
 }
 
 template <bool IRREV>

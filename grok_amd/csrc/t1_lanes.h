@@ -445,6 +445,61 @@ T1L_FN void lane_apply(Lane& L, uint32_t d)
     }
 }
 
+// ---- the same two steps without branches (selects on the lane's mode): every lane of a wave runs every path anyway ---------
+T1L_FN uint32_t lane_context_sel(Lane& L, const uint16_t* lds16)
+{
+    const uint32_t nb = L.nbx >> L.t, nn = L.nnx >> L.t;
+    const bool isSC = L.st == ST_SC;
+    const uint32_t zi = (L.zcbase >> 1) + (nb & 0x1FFu);
+    const uint32_t si = (kOffSc >> 1) + (((nb & 0xAAu) >> 1) | (nn & 0xAAu));
+    const uint32_t e = lds16[isSC ? si : zi];                         // one look-up for both kinds (others: a harmless read)
+    L.xr = isSC ? (e & 1u) : L.xr;
+    const uint32_t mr = ((L.mv >> L.t) & 1u) ? 16u * 256u : ((nb & 0x1EFu) ? 15u * 256u : 14u * 256u);
+    uint32_t off = L.st == ST_AGG ? 17u * 256u : 18u * 256u;
+    off = L.st == ST_MR ? mr : off;
+    off = L.st <= ST_SC ? (e & ~1u) : off;
+    return off;
+}
+
+T1L_FN void lane_apply_sel(Lane& L, uint32_t d)
+{
+    const uint32_t st = L.st, t = L.t;
+    const bool isZC = st == ST_ZC, isSC = st == ST_SC, isMR = st == ST_MR, isAGG = st == ST_AGG, isU1 = st == ST_UNI1, isU2 = st == ST_UNI2;
+    const bool sp = L.type == 0, mrp = L.type == 1;
+    const bool one = d != 0;
+    const uint32_t bit = 1u << t;
+    // visited (sig-prop: every sample the pass looks at)
+    L.pv |= (sp && (isSC || (isZC && !one))) ? bit : 0u;
+    // a sample turns significant: sign decoded
+    const uint32_t neg = d ^ L.xr;
+    L.nbx |= isSC ? bit << 4 : 0u;
+    L.nnx |= (isSC && neg) ? bit << 4 : 0u;
+    uint32_t todo = L.todo | ((isSC && sp) ? ((bit << 3) & ~((L.nbx >> 4) | L.pv) & 0x249u) : 0u);
+    const uint64_t bx1 = L.bx << 1;
+    L.cm |= (isSC && sp) ? (bx1 & L.wmask) : 0ull;
+    L.Q &= (isSC && !sp) ? ~bx1 : ~0ull;
+    // refinement
+    L.rf |= isMR ? d << t : 0u;
+    L.mv |= isMR ? bit : 0u;
+    // run-length position
+    const uint32_t r2 = L.r * 2u + d, t2 = r2 * 3u;
+    L.r = isU1 ? d : L.r;
+    // where next
+    const bool adv = isSC || isMR || (isZC && !one);
+    const bool more = todo != 0u;
+    const uint32_t tn = ctz32(todo | 0x80000000u), todon = todo & (todo - 1u);
+    uint32_t nst = (mrp ? (uint32_t)ST_MR : (uint32_t)ST_ZC);             // adv && more
+    nst = (adv && !more) ? (uint32_t)ST_NEEDCOL : nst;
+    nst = (isZC && one) ? (uint32_t)ST_SC : nst;
+    nst = isAGG ? (one ? (uint32_t)ST_UNI1 : (uint32_t)ST_NEEDCOL) : nst;
+    nst = isU1 ? (uint32_t)ST_UNI2 : nst;
+    nst = isU2 ? (uint32_t)ST_SC : nst;
+    L.t = (adv && more) ? tn : (isU2 ? t2 : t);
+    L.todo = (adv && more) ? todon : (isU2 ? (0x249u & ~((2u << t2) - 1u)) : todo);
+    L.st = nst;
+    if (adv && !more) lane_column_exit(L);
+}
+
 // ---- reconstruction of one sample from the planes a block left (t1_recon_kernel; the values T1 keeps in its data array) --------
 // snap(i) / ref(i): the sample's bit in plane i's significance / refinement bitmap; numbps, numpasses as decoded.
 // Returns the magnitude in T1's fixed point (one fraction bit: the block leaves v / 2 or v * stepsize / 2).

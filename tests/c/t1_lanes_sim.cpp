@@ -14,7 +14,7 @@ extern "C" {
 struct SimBlock { uint64_t offset; uint32_t length, numbps, numpasses, w, h, orient; };
 
 // out: [nblocks][64 * 64] decoded values (T1's data array: sign * magnitude with one fraction bit), row stride 64
-// stats: [0] iterations summed over waves, [1] decisions, [2] lane-iterations a lane had no decision, [3] max iterations of a wave
+// stats: [0] iterations summed over waves, [1] decisions, [2] lane-slots without a decision, [3] max iterations of a wave, [4] decision slots
 int t1l_sim_decode(const uint8_t* coded, uint64_t coded_bytes, uint32_t nblocks, const SimBlock* blk, int32_t* out, uint64_t* stats)
 {
     std::vector<uint8_t> lds(kLdsBytes);
@@ -26,6 +26,11 @@ int t1l_sim_decode(const uint8_t* coded, uint64_t coded_bytes, uint32_t nblocks,
     for (uint32_t i = 0; i < 256; ++i) lds16[(kOffSc >> 1) + i] = (uint16_t)sign_context(i);
     std::vector<uint64_t> work((size_t)64 * kWorkU64);
     FILE* trace = std::getenv("T1L_SIM_TRACE") ? std::fopen(std::getenv("T1L_SIM_TRACE"), "w") : nullptr;
+    const uint32_t kslots_max = std::getenv("T1L_KMAX") ? (uint32_t)std::atoi(std::getenv("T1L_KMAX")) : 1u;
+    const uint32_t kslots_min = std::getenv("T1L_KMIN") ? (uint32_t)std::atoi(std::getenv("T1L_KMIN")) : 1u;
+    const uint32_t frac_pct = std::getenv("T1L_FRAC") ? (uint32_t)std::atoi(std::getenv("T1L_FRAC")) : 0u;
+    const bool branchy = std::getenv("T1L_BRANCHY") != nullptr;        // the two forms of the decision step (t1_lanes.h)
+    uint64_t slots_total = 0;
     uint64_t it_total = 0, dec_total = 0, idle_total = 0, it_max = 0;
     for (uint32_t base = 0; base < nblocks; base += 64) {
         const uint32_t nl = nblocks - base < 64 ? nblocks - base : 64;
@@ -58,17 +63,27 @@ int t1l_sim_decode(const uint8_t* coded, uint64_t coded_bytes, uint32_t nblocks,
                 }
             }
             bool all_done = true;
-            for (uint32_t l = 0; l < 64; ++l) {
-                if (L[l].st == ST_NEEDCOL) lane_column_enter(L[l]);
-                if (L[l].st <= ST_UNI2 && L[l].nv >= 3u) {
-                    const uint32_t off = lane_context(L[l], lds16);
-                    const uint32_t d = lane_mq_decode(L[l], lds32, (off >> 2) + l);
-                    if (trace && l == 0) std::fprintf(trace, "%u %u\n", off >> 8, d);
-                    lane_apply(L[l], d);
-                    ++dec_total;
-                } else if (L[l].st != ST_DONE) ++idle_total;
-                if (L[l].st != ST_DONE) all_done = false;
+            for (uint32_t l = 0; l < 64; ++l) if (L[l].st == ST_NEEDCOL) lane_column_enter(L[l]);
+            // decision slots of this iteration: policy from the environment (experiments): K fixed slots, or while at least
+            // `frac` of the lanes that can decode still have a decision in their column
+            for (uint32_t slot = 0;; ++slot) {
+                uint32_t can = 0, live = 0;
+                for (uint32_t l = 0; l < 64; ++l) { if (L[l].st != ST_DONE) ++live; if (L[l].st <= ST_UNI2 && L[l].nv >= 3u) ++can; }
+                if (slot >= kslots_max) break;
+                if (slot >= kslots_min && can * 100u < live * frac_pct) break;
+                if (can == 0) break;
+                ++slots_total;
+                for (uint32_t l = 0; l < 64; ++l) {
+                    if (L[l].st <= ST_UNI2 && L[l].nv >= 3u) {
+                        const uint32_t off = branchy ? lane_context(L[l], lds16) : lane_context_sel(L[l], lds16);
+                        const uint32_t d = lane_mq_decode(L[l], lds32, (off >> 2) + l);
+                        if (trace && l == 0) std::fprintf(trace, "%u %u\n", off >> 8, d);
+                        if (branchy) lane_apply(L[l], d); else lane_apply_sel(L[l], d);
+                        ++dec_total;
+                    } else if (L[l].st != ST_DONE) ++idle_total;
+                }
             }
+            for (uint32_t l = 0; l < 64; ++l) if (L[l].st != ST_DONE) all_done = false;
             if (all_done) break;
             if (it > 4000000) return -1;
         }
@@ -89,7 +104,7 @@ int t1l_sim_decode(const uint8_t* coded, uint64_t coded_bytes, uint32_t nblocks,
         }
     }
     if (trace) std::fclose(trace);
-    if (stats) { stats[0] = it_total; stats[1] = dec_total; stats[2] = idle_total; stats[3] = it_max; }
+    if (stats) { stats[0] = it_total; stats[1] = dec_total; stats[2] = idle_total; stats[3] = it_max; stats[4] = slots_total; }
     return 0;
 }
 

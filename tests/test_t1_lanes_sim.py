@@ -43,7 +43,7 @@ def decode(blocks, pad_front=0):
         buf += b"\x5A" * (i % 3)                       # blocks at every alignment
     coded = np.frombuffer(bytes(buf), np.uint8)
     out = np.zeros((len(blocks), 64, 64), np.int32)
-    st = np.zeros(4, np.uint64)
+    st = np.zeros(8, np.uint64)
     rc = sim().t1l_sim_decode(coded.ctypes.data, coded.size, len(blocks), rows.ctypes.data, out.ctypes.data, st.ctypes.data)
     assert rc == 0
     return [out[i, :b[5], :b[4]] for i, b in enumerate(blocks)], st

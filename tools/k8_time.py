@@ -3,8 +3,10 @@ python tools/k8_time.py [S]   -- prints ms per frame, K8 family ms (timer 5), pi
 import os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-VARIANTS = [("lanes", {}), ("k8 only", {"GRK_AMD_T1_LANES": "0"}), ("lanes ratio .25", {"GRK_AMD_T1_TAIL_RATIO": "0.25"}),
-            ("lanes ratio .6", {"GRK_AMD_T1_TAIL_RATIO": "0.6"}), ("lanes, no overlap", {"GRK_AMD_OVERLAP": "0"})]
+VARIANTS = [("lanes", {}), ("k8 only", {"GRK_AMD_T1_LANES": "0"})] + \
+    [("share %s" % v, {"GRK_AMD_T1_TAIL_SHARE": v}) for v in ("0.2", "0.3", "0.4", "0.5", "0.6")]
+if os.environ.get("K8_VARIANTS"):
+    VARIANTS = [(v, dict(kv.split("=") for kv in v.split(",") if kv)) for v in os.environ["K8_VARIANTS"].split(";")]
 if os.environ.get("K8_CHILD"):
     import numpy as np, torch, grok_amd as G, synth, j2kparse as J, refharness as R
     S = int(os.environ.get("K8_SIZE", "8192"))
