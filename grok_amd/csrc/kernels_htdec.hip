@@ -245,15 +245,22 @@ __device__ uint2 g_vlc_dec2[2048];          // [0..1023] first quad row, [1024..
 // serial chain (measured: the kernel was no faster than r02's with half the instructions).
 constexpr uint32_t kRowWords = 18, kRowStride = 19;       // (odd stride: the lanes' copies of word j lie in different banks)
 struct VlcBits {      // LSB first
-    const uint32_t* w; uint32_t* row; uint32_t wi, wi0, a, b, c, pos;
-    __device__ __forceinline__ void init(const uint32_t* p, uint32_t* lds_row) { w = p; row = lds_row; wi = 0; wi0 = 0; pos = 0; a = p[0]; b = p[1]; c = 0; }
+    const uint32_t* w; uint32_t* row; uint32_t wi, wi0, a, b, c, pos, last;
+    // `words`: what K5p wrote for this block (vlc_words: the bits, then zeros).  A malformed stream can push the cursor past them;
+    // it then reads the block's own last (zero) word again and again -- never a neighbour's scratch or memory behind the buffer
+    __device__ __forceinline__ void init(const uint32_t* p, uint32_t* lds_row, uint32_t words) { w = p; row = lds_row; wi = 0; wi0 = 0; pos = 0; a = p[0]; b = p[1]; c = 0; last = words - 1u; }
     // the words wi + 2 .. wi + 2 + kRowWords - 1 into the lane's LDS row (wi is where the window stands now)
     __device__ __forceinline__ void begin_row()
     {
         wi0 = wi;
         uint32_t t[kRowWords];
+        if (wi0 + 1u + kRowWords <= last) {
 #pragma unroll
-        for (uint32_t j = 0; j < kRowWords; ++j) t[j] = w[wi0 + 2 + j];
+            for (uint32_t j = 0; j < kRowWords; ++j) t[j] = w[wi0 + 2 + j];
+        } else {                                                 // the block's last rows: index by index
+#pragma unroll
+            for (uint32_t j = 0; j < kRowWords; ++j) t[j] = w[min(wi0 + 2 + j, last)];
+        }
 #pragma unroll
         for (uint32_t j = 0; j < kRowWords; ++j) row[j] = t[j];
         c = t[0];
@@ -270,12 +277,12 @@ struct VlcBits {      // LSB first
 };
 
 struct MelBits {      // MSB first
-    const uint32_t* w; uint32_t wi, a, b, c, pos;
+    const uint32_t* w; uint32_t wi, a, b, c, pos, last;        // last: the block's last MEL word (ones: an exhausted segment), read for ever
     int k, run;       // run: what is left of the current run, in the reference's coding (:196-235, :1101-1111):
                       // 2 * (zero events) + 1 if it ends with a one, 2 * (zero events - 1) otherwise
-    __device__ __forceinline__ void init(const uint32_t* p)
+    __device__ __forceinline__ void init(const uint32_t* p, uint32_t words)
     {
-        w = p; wi = 0; pos = 0; a = p[0]; b = p[1]; c = p[2]; k = 0; run = -1;
+        w = p; wi = 0; pos = 0; a = p[0]; b = p[1]; c = p[2]; k = 0; run = -1; last = words - 1u;
         decode_run();
     }
     __device__ __forceinline__ void decode_run()                 // (:196-235)
@@ -289,7 +296,7 @@ struct MelBits {      // MSB first
         const uint32_t nwi = pos >> 5;
         const bool step = nwi != wi;
         a = step ? b : a; b = step ? c : b; wi = nwi;
-        c = w[wi + 2];
+        c = w[min(wi + 2u, last)];
     }
     // One MEL event if `need` (:1101-1111): returns 1 if the run ends here with a one.  The decode of the next run sits
     // behind a branch the whole wave skips when no lane has used its run up: in dense blocks (contexts rarely zero) and in
@@ -335,9 +342,9 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
 
     const uint32_t* raw = a.vraw + a.vbase[blk];
     MelBits mel;
-    mel.init(raw);
+    mel.init(raw, mel_words((uint32_t)scup));
     VlcBits vlc;
-    vlc.init(raw + mel_words((uint32_t)scup), rows_l + threadIdx.x * kRowStride);
+    vlc.init(raw + mel_words((uint32_t)scup), rows_l + threadIdx.x * kRowStride, vlc_words((uint32_t)scup));
     const uint32_t NP = (QW + 1) >> 1;  // quad pairs per row
     uint64_t sa = 0;                     // significance of the bottom sample row of the quad row above: bit x
     uint32_t umax = 0;                   // largest u_q + 1 of the block (:1194: > missing_msbs rejects it)
@@ -846,7 +853,10 @@ hipError_t launch_ht_decode_front(const HtDecArgs& a, hipStream_t s)
     //  chain's next instruction waits behind whatever holds the SIMD's ALU for its four cycles, wave priority or not)
     uint32_t lanes = 64;
     while (lanes > 16 && (a.nactive + lanes - 1) / lanes < 1280) lanes >>= 1;
-    if (const char* e = getenv("GRK_AMD_K5A_LANES")) lanes = (uint32_t)atoi(e);
+    if (const char* e = getenv("GRK_AMD_K5A_LANES")) {              // (experiments; anything but a wave-sized power of two is ignored)
+        const int v = atoi(e);
+        if (v == 16 || v == 32 || v == 64) lanes = (uint32_t)v;
+    }
     hipLaunchKernelGGL(ht_dec_vlc_kernel, dim3((a.nactive + lanes - 1) / lanes), dim3(lanes), 0, s, a);
     return hipGetLastError();
 }

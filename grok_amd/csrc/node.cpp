@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -36,6 +37,7 @@ struct grk_amd_node {
     std::vector<Worker> w;
     uint64_t frame = 0;
     std::string err;
+    std::mutex mu;                                               // one grk_amd_node_encode_image at a time
 };
 
 namespace {
@@ -116,10 +118,31 @@ extern "C" uint32_t grk_amd_node_size(const grk_amd_node* nd) { return nd ? (uin
 extern "C" grk_amd_ctx* grk_amd_node_ctx(grk_amd_node* nd, uint32_t i) { return nd && i < nd->w.size() ? nd->w[i].ctx : nullptr; }
 extern "C" const char* grk_amd_node_last_error(grk_amd_node* nd) { return nd ? nd->err.c_str() : "null node"; }
 
+static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                 const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap);
+
+// One image at a time per node: the call owns the workers' contexts, their pinned buffers and the gather buffers for its duration
+// (callers from several threads queue on the node's mutex).  Every error return leaves its reason in grk_amd_node_last_error.
 extern "C" int64_t grk_amd_node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
                                              const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap)
 {
-    if (!nd || nd->w.empty() || !im || !base || !pixels || !out) return GRK_AMD_ERR_INVALID;
+    if (!nd) return GRK_AMD_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(nd->mu);
+    nd->err.clear();
+    const int64_t rc = node_encode_image(nd, im, base, pixels, flags, out, cap);
+    if (rc < 0 && nd->err.empty()) {
+        nd->err = rc == GRK_AMD_ERR_INVALID ? "invalid argument" : rc == GRK_AMD_ERR_UNSUPPORTED ? "unsupported layout (TLM with more than 255 tiles?)"
+                : rc == GRK_AMD_ERR_NOMEM ? "out of (pinned or device) memory" : rc == GRK_AMD_ERR_NO_DEVICE ? "a HIP call failed (device lost or peer copy refused)"
+                : rc == GRK_AMD_ERR_OVERFLOW ? "output or gather buffer too small" : "encode failed";
+        nd->err += " (code " + std::to_string((long long)rc) + ")";
+    }
+    return rc;
+}
+
+static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                 const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap)
+{
+    if (nd->w.empty() || !im || !base || !pixels || !out) return GRK_AMD_ERR_INVALID;
     const int64_t nt = grk_amd_layout_num_tiles(im);
     if (nt < 0) return nt;
     const uint32_t ntiles = (uint32_t)nt, R = (uint32_t)nd->w.size();
@@ -194,7 +217,10 @@ extern "C" int64_t grk_amd_node_encode_image(grk_amd_node* nd, const grk_amd_ima
                 rc = grk_amd_encode_tiles(w.ctx, &p, (uint32_t)mine.size(), w.pin_px, 0, table.data(), &total);
                 if (rc) break;
                 if (gather) {
-                    // device to device into the writer's buffer (the fetch above has joined the encode's streams)
+                    // device to device into the writer's buffer.  Ordering contract: grk_amd_encode_tiles was given a table pointer, so it
+                    // returned through grk_amd_fetch_table -- side streams joined and the context's stream synchronised --: the arena
+                    // is complete on the device before this copy is queued on w.copy (an asynchronous encode_tiles would need an
+                    // event from the context's stream here instead)
                     auto& ww = nd->w[writer];
                     if (gather_at[r] + coded_used + total > gather_at[r + 1]) { rc = GRK_AMD_ERR_OVERFLOW; break; }
                     // (a device-to-device copy returns before it is done: waited for here, the next group's encode writes the same arena)

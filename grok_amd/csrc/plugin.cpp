@@ -60,6 +60,8 @@ struct TileOwner {
     std::vector<gra_plugin_precinct> precs;         std::vector<gra_plugin_precinct*> prec_ptr;
     std::vector<gra_plugin_code_block> blocks;      std::vector<gra_plugin_code_block*> block_ptr;
     std::vector<grk_amd_coded_block> table;
+    std::vector<float> band_steps;                   // the bands' step sizes as make_owner set them (a decode lets the host overwrite them)
+    bool served_decode = false;                      // the coded buffer was sized for a decode (every block's worst case + the file)
     uint8_t* coded = nullptr; size_t coded_cap = 0; bool coded_pinned = false;
     ~TileOwner() { free_coded(); }
     void free_coded()
@@ -85,6 +87,7 @@ static_assert(offsetof(TileOwner, tile) == 0, "tile must be the first member: de
 std::mutex g_cache_mu;
 std::vector<TileOwner*> g_tile_cache;           // trees not in use, any geometry
 constexpr size_t kTileCacheMax = 8;
+constexpr size_t kTileCacheBytes = 512u << 20;   // pinned coded buffers the kept trees may hold together
 
 // the geometry-dependent part of the tree: everything but compressedData / compressedDataLength / passes[0] of the blocks
 TileOwner* make_owner(const grk_amd_tile_params& p)
@@ -156,6 +159,8 @@ TileOwner* make_owner(const grk_amd_tile_params& p)
     o->tile.decompress_flags = 0;
     o->tile.numComponents = p.num_comps;
     o->tile.tileComponents = o->comp_ptr.data();
+    o->band_steps.resize(o->bands.size());
+    for (size_t i = 0; i < o->bands.size(); ++i) o->band_steps[i] = o->bands[i].stepsize;
     return o;
 }
 
@@ -163,6 +168,9 @@ TileOwner* make_owner(const grk_amd_tile_params& p)
 void patch_owner(TileOwner* o)
 {
     const size_t nb = o->blocks.size();
+    // (a tree that served a decode comes back with the step sizes the host wrote, plugin_bridge.cpp:40)
+    for (size_t i = 0; i < o->bands.size() && i < o->band_steps.size(); ++i) o->bands[i].stepsize = o->band_steps[i];
+    o->tile.decompress_flags = 0;
     for (size_t i = 0; i < nb; ++i) {
         gra_plugin_code_block& cb = o->blocks[i];
         const uint32_t len = o->table[i].length;
@@ -192,8 +200,17 @@ TileOwner* acquire_owner(const grk_amd_tile_params& p)
 void release_owner(TileOwner* o)
 {
     if (!o) return;
+    // a decode's buffer (16 KB per block + the file: ~0.8 GB pinned for an 8K frame) does not stay with the kept tree; an encode's
+    // (the coded bytes of a frame) does, within a budget over the whole cache
+    if (o->served_decode || o->coded_cap > kTileCacheBytes) { o->free_coded(); o->served_decode = false; }
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
+        size_t held = o->coded_cap;
+        for (TileOwner* t : g_tile_cache) held += t->coded_cap;
+        for (size_t i = 0; held > kTileCacheBytes && i < g_tile_cache.size(); ++i) {          // oldest first
+            held -= g_tile_cache[i]->coded_cap;
+            g_tile_cache[i]->free_coded();
+        }
         if (g_tile_cache.size() < kTileCacheMax) { g_tile_cache.push_back(o); return; }
         // full: the oldest goes (another geometry has taken over)
         TileOwner* old = g_tile_cache.front();
@@ -212,24 +229,49 @@ void drop_tile_cache()
 }
 
 // pixels of an image the plugin loads itself: pinned when a context exists (the upload is then one DMA at the link's rate)
+// (the batch reader takes one per file: the pinned ones are recycled through a two-slot pool -- hipHostMalloc / hipHostFree per
+//  file cost milliseconds each, and the free waits for the device while the device lock is held)
+struct PinnedSlot { uint8_t* p = nullptr; size_t cap = 0; };
+std::mutex g_pin_mu;
+PinnedSlot g_pin_pool[2];
+void drop_pinned_pool()
+{
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto& sl : g_pin_pool) { if (sl.p) grk_amd_host_free(nullptr, sl.p); sl = PinnedSlot{}; }
+}
 struct HostPixels {
-    uint8_t* p = nullptr; size_t n = 0; bool pinned = false;
+    uint8_t* p = nullptr; size_t n = 0, cap = 0; bool pinned = false;
     HostPixels() = default;
     HostPixels(const HostPixels&) = delete;
     HostPixels& operator=(const HostPixels&) = delete;
     ~HostPixels() { reset(); }
     void reset()
     {
+        if (p && pinned) {
+            std::lock_guard<std::mutex> lk(g_pin_mu);
+            PinnedSlot* sl = !g_pin_pool[0].p ? &g_pin_pool[0] : !g_pin_pool[1].p ? &g_pin_pool[1]
+                             : (g_pin_pool[0].cap <= g_pin_pool[1].cap ? &g_pin_pool[0] : &g_pin_pool[1]);
+            if (!sl->p) { sl->p = p; sl->cap = cap; p = nullptr; }
+            else if (sl->cap < cap) { std::swap(sl->p, p); std::swap(sl->cap, cap); }      // keep the larger, free the smaller below
+        }
         if (p) { if (pinned) grk_amd_host_free(nullptr, p); else std::free(p); }
-        p = nullptr; n = 0;
+        p = nullptr; n = 0; cap = 0;
     }
     bool alloc(size_t bytes)
     {
         reset();
+        if (g_ctx) {
+            std::lock_guard<std::mutex> lk(g_pin_mu);
+            int best = -1;                                                                 // the smallest kept buffer that fits
+            for (int i = 0; i < 2; ++i)
+                if (g_pin_pool[i].p && g_pin_pool[i].cap >= bytes && (best < 0 || g_pin_pool[i].cap < g_pin_pool[best].cap)) best = i;
+            if (best >= 0) { p = g_pin_pool[best].p; cap = g_pin_pool[best].cap; g_pin_pool[best] = PinnedSlot{}; }
+        }
+        if (p) { pinned = true; n = bytes; return true; }
         p = g_ctx ? static_cast<uint8_t*>(grk_amd_host_alloc(g_ctx, bytes)) : nullptr;
         pinned = p != nullptr;
         if (!p) p = static_cast<uint8_t*>(std::malloc(bytes ? bytes : 1));
-        n = p ? bytes : 0;
+        n = p ? bytes : 0; cap = n;
         return p != nullptr;
     }
     uint8_t* data() const { return p; }
@@ -655,6 +697,7 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
         }
     }
     TileOwner* const owner = acquire_owner(tp);
+    if (owner) owner->served_decode = true;
     if (!owner || !owner->ensure_coded(g_ctx, cap + sh.file_size + 64)) { release_owner(owner); return clean(-1); }
     std::memset(owner->coded, 0, cap + sh.file_size + 64);
     owner->table = slots;
@@ -722,7 +765,7 @@ const char* out_extension(int32_t cod_format)
     }
 }
 
-int32_t plugin_exit() { return 0; }
+int32_t plugin_exit() { drop_tile_cache(); drop_pinned_pool(); return 0; }
 void* plugin_create(gra_minpf_object_params*) { return nullptr; }
 int32_t plugin_destroy(void*) { return 0; }
 

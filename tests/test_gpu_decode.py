@@ -159,6 +159,46 @@ def test_ht_decode_rejects_corrupt_block():
         U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
 
 
+def test_ht_decode_vlc_cursor_past_its_segment_reads_the_blocks_own_padding():
+    """A stream whose Scup claims a VLC / MEL segment much shorter than the block needs: K5a's cursors run past the
+    words K5p prepared.  They must then read the block's OWN padding (zeros / ones) -- not the neighbour block's scratch, not memory
+    behind the buffer: the planes such a call leaves (whether or not the block ends up rejected) do not depend on what the
+    neighbours hold or on what an earlier call left in the scratch."""
+    p = G.TileParams.make(128, 64, 1, 8, 0)
+    blocks, _ = G.tile_layout(p)
+    rng = np.random.default_rng(5)
+    kmax = blocks[0].kmax
+
+    def coded(mag_bits):
+        coef = (rng.integers(0, 1 << mag_bits, size=(64, 64)) * np.where(rng.random((64, 64)) < 0.5, -1, 1)).astype(np.int32)
+        return bytearray(O.ht_encode_sm(O.signmag(coef, kmax), kmax))
+
+    bad = coded(kmax - 2)
+    bad[-1] = 0x00; bad[-2] = (bad[-2] & 0xF0) | 0x03            # Scup = 3: one VLC byte, two MEL bytes
+    outs = []
+    for neighbour_bits, warm in ((kmax - 2, False), (2, True), (kmax - 3, True)):
+        nb = coded(neighbour_bits)
+        table = np.zeros(2, G.capi.CODED_DTYPE)
+        # the malformed block LAST: its scratch ends the buffer
+        table["offset"][0] = 0; table["length"][0] = len(nb); table["missing_msbs"][0] = kmax - 1
+        off1 = (len(nb) + 15) & ~15
+        table["offset"][1] = off1; table["length"][1] = len(bad); table["missing_msbs"][1] = kmax - 1
+        buf = bytes(nb) + b"\0" * (off1 - len(nb)) + bytes(bad)
+        if warm:                                                      # other contents in the scratch from a call before
+            t2 = table.copy(); t2["length"][1] = 0
+            d2 = U.to_dev(np.frombuffer(buf, np.uint8)); m2 = U.dev_planes(p, 1)
+            U.ctx().stage_ht_decode(p, 1, t2, d2.data_ptr(), d2.numel(), m2.data_ptr()); U.ctx().synchronize()
+        d_c = U.to_dev(np.frombuffer(buf, np.uint8))
+        d_m = U.dev_planes(p, 1)
+        try:
+            U.ctx().stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
+        except RuntimeError:
+            pass                                                      # (rejected: fine -- what it wrote must still be the same)
+        U.ctx().synchronize()
+        outs.append(U.planes_to_numpy(d_m, p, 1)[0, :, 64:128].copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 # ---- whole decode path ------------------------------------------------------------------------------
 @pytest.mark.parametrize("C,H,W,prec,L,gen", [(1, 512, 512, 8, 3, "g2"), (3, 256, 384, 8, 5, "g2"), (3, 128, 128, 16, 4, "g2"),
                                                (3, 100, 77, 8, 3, "g2"), (1, 64, 64, 12, 0, "g2"), (3, 1024, 1024, 8, 5, "g2")])
