@@ -6,12 +6,15 @@ One "step" = one pass of the hot path (ingest+DC+RCT -> 5-level 5/3 DWT -> HT cl
 64x64 code-blocks -> compaction) over one 8192x8192x3 8-bit tile whose pixels are already
 resident in HBM.  With N ranks (torchrun, one process per GPU) the job is a sequence of (N*8192)x8192
 frames cut into N tiles of 8192x8192: tile t is encoded on rank t (tiles are independent, SURVEY.md
-§8e: no data-path collective) and every frame ends with the path's one real exchange over RCCL/xGMI,
-the gather of the ranks' coded tile-parts (exact sizes) on the frame's writer rank, which rotates with
-the frame number (grok_amd.dist: funnelling every frame into rank 0 would bound the job by one GPU's
-xGMI ingress).  Per-GPU work is fixed => weak scaling.  The same line reports, under "multi_gpu", the
-counts-only exchange (parallel-writer design: the bytes stay on their GPU) and the BASELINE configs[3]
-shape -- 16384x16384 as 256 tiles of 1024x1024 split over the ranks, strong scaling.
+§8e: no data-path collective) and every frame ends with an exchange over RCCL/xGMI.  TWO forms are timed
+and both are in the line (top-level `exchange`): "gather" -- the ranks' coded tile-parts (exact sizes) to
+the frame's writer rank, which rotates with the frame number, `--gather-depth` frames' gathers in flight
+at once on communicators of their own (grok_amd.dist.FramePipeline) -- and "counts" -- only the byte
+counts travel, every rank writes its own tile-parts (parallel writers).  `value` is the GATHER figure
+(what BASELINE's north_star words) when that region completed, the counts figure otherwise;
+`config.headline_exchange` says which.  Per-GPU work is fixed => weak scaling.  "multi_gpu" also carries
+the BASELINE configs[3] shape -- 16384x16384 as 256 tiles of 1024x1024 split over the ranks, strong
+scaling.  `python bench.py --gpus N` starts its N ranks itself (launch_ranks).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 8k|cfg2|cfg1|cfg3|cfg4tile]
 """
@@ -171,15 +174,63 @@ def cpu_baseline(rank_threads, want_cfg5=True):
                 "sample": "oracle/j2k_oracle.c scalar port, 1 x 1024x1024x3 (reference harness unavailable: %s)" % e}, None
 
 
-def _pmc_traffic(workload, fams):
-    """HBM bytes per step of the kernel families `fams` from the committed rocprofv3 --pmc passes of the same workload
-    (profiles/summarize_pmc.py: FETCH_SIZE x1024 x2 [gfx950 half-count] + WRITE_SIZE x1024); None without a summary."""
+_PMC_LIVE = {}          # workload -> (family -> {hbm_bytes_per_step ...}) measured by THIS run (live_pmc_traffic)
+_PMC_SOURCE = {}        # workload -> where _pmc_traffic's numbers for it came from
+
+
+def live_pmc_traffic(workload, seconds=100):
+    """HBM traffic of `workload`'s kernel families measured in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE --
+    separately, as MI355X_MICROARCH.md prescribes; no trace flags beside --pmc) over tools/prof_run.py, two steps of the workload
+    with every kernel alone, summarised by profiles/summarize_pmc.py's rules (x1024; FETCH x2 on gfx950).  Rank 0 at N = 1 only;
+    leaves the committed summary in place (and says so) when rocprofv3 is missing or a pass fails / takes too long."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return False
     try:
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % workload)))
-        if not cands:
-            return None
-        pm = json.load(open(cands[-1]))
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import summarize_pmc as SP
+        tmp = tempfile.mkdtemp(prefix="grk_pmc_")
+        env = dict(os.environ, TMPDIR=tmp, GRK_AMD_OVERLAP="0", PROF_WORKLOAD=workload, PROF_N="2", PROF_DECODE="1")
+        paths = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            subprocess.run([exe, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "prof_run.py")],
+                           cwd=tmp, env=env, timeout=seconds, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            hits = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if not hits:
+                return False
+            paths[counter] = hits[0]
+        js = os.path.join(tmp, "traffic.json")
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            SP.main(paths["FETCH_SIZE"], paths["WRITE_SIZE"], js)
+        _PMC_LIVE[workload] = json.load(open(js))
+        shutil.rmtree(tmp, ignore_errors=True)
+        return True
+    except Exception:
+        return False
+
+
+def _pmc_traffic(workload, fams):
+    """HBM bytes per step of the kernel families `fams`: from this run's own rocprofv3 --pmc passes when they were taken
+    (live_pmc_traffic), else from the committed passes of the same command (profiles/r*_pmc_traffic_<workload>.json;
+    profiles/summarize_pmc.py: FETCH_SIZE x1024 x2 [gfx950 half-count] + WRITE_SIZE x1024); None without either."""
+    try:
+        if workload in _PMC_LIVE:
+            pm = _PMC_LIVE[workload]
+            _PMC_SOURCE[workload] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes taken by this run"
+        else:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % workload)))
+            if not cands:
+                return None
+            pm = json.load(open(cands[-1]))
+            _PMC_SOURCE[workload] = "committed " + os.path.relpath(cands[-1], ROOT)
         return int(sum(pm[k]["hbm_bytes_per_step"] for k in fams if k in pm)) or None
     except Exception:
         return None
@@ -316,8 +367,8 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
                            "kernels": {"t1_ebcot_decode": {"avg_ms": round(k8, 3), "algorithmic_bytes": int(4 * samples + len(data)),
                                                            "algorithmic_GBps": rate(4 * samples + len(data), k8)[0],
                                                            "frac": rate(4 * samples + len(data), k8)[1],
-                                                           "traffic": _pmc_traffic("cfg5", ("t1_dec_kernel",)),
-                                                           "frac_on_traffic": rate(_pmc_traffic("cfg5", ("t1_dec_kernel",)) or 0, k8)[1]},
+                                                           "traffic": _pmc_traffic("cfg5", ("t1_dec_kernel", "t1_lanes_kernel", "t1_recon_kernel")),
+                                                           "frac_on_traffic": rate(_pmc_traffic("cfg5", ("t1_dec_kernel", "t1_lanes_kernel", "t1_recon_kernel")) or 0, k8)[1]},
                                        "idwt97_5levels": {"avg_ms": round(k6, 3),
                                                           "algorithmic_bytes": int(idwt_bytes(samples, 2, 4, 5, True)),
                                                           "algorithmic_GBps": rate(idwt_bytes(samples, 2, 4, 5, True), k6)[0],
@@ -519,16 +570,23 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` object (cfg2, cfg3, cfg4tile, cfg5 decode)")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` object (PCIe-inclusive end-to-end "
                     "rate, the route through grk_compress_with_plugin)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not take the HBM-traffic counters in this run (two short rocprofv3 --pmc passes of the headline "
+                         "workload, ~20 s); the committed summaries under profiles/ are quoted instead")
     ap.add_argument("--no-overlap", action="store_true",
                     help="every kernel alone on the GPU, also in the timed region (what the rocprofv3 kernel-trace summary "
                          "that the roofline durations are checked against is taken with)")
-    ap.add_argument("--exchange", default="counts", choices=("gather", "counts"),
-                    help="N > 1, per frame, what the headline number is timed with: 'counts' = all_gather of the coded byte counts "
-                         "only (parallel writers: tiles are independent, every rank writes its own tile-parts at offsets the sizes "
-                         "give, the bytes leave each GPU over its own PCIe link -- no data-path collective); 'gather' = every "
-                         "rank's coded tile-parts (exact sizes) over xGMI to the frame's writer rank, which rotates with the frame "
-                         "number (one stream of ~100 MB per 8K frame and rank: link-bound at this frame rate).  The other one is "
-                         "reported under multi_gpu as well")
+    ap.add_argument("--exchange", default="gather", choices=("gather", "counts"),
+                    help="N > 1: which exchange the headline `value` is (both are always timed and reported, `exchange` in the "
+                         "line): 'gather' = every rank's coded tile-parts (exact sizes) over xGMI to the frame's writer rank, "
+                         "which rotates with the frame number, --gather-depth frames in flight; 'counts' = all_gather of the coded "
+                         "byte counts only (parallel writers: the bytes leave each GPU over its own PCIe link)")
+    ap.add_argument("--gather-depth", type=int, default=4,
+                    help="gathers in flight at once (each on its own communicator and stream; a gather is issued two frames behind "
+                         "the encoder, which then rotates depth + 3 buffer sets)")
+    ap.add_argument("--gather-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the gather regions may take before the line is printed without them (a transfer that "
+                         "never completes must not cost the run its counts figure)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks meet over gloo, count each other at the barrier and rank 0 prints "
                          "a line with n_gpus = the ranks that really arrived; no kernels run")
@@ -602,13 +660,16 @@ def main():
         pipe = [None]
         cbuf = [None, None]
 
+        depth, lag = max(1, args.gather_depth), 2
+
         def one(f):
             with torch.cuda.stream(stream):
-                if pipe[0] is not None:                        # three buffer sets in rotation: this frame reuses frame f - 3's
-                    ev = pipe[0].done_event(f - 3)
+                if pipe[0] is not None:                        # depth + lag + 1 buffer sets in rotation: this frame reuses frame
+                    ev = pipe[0].done_event(f - (depth + lag + 1))   # f - (depth + lag + 1)'s
                     if ev is not None:
                         stream.wait_event(ev)                  # ... once its gather has read them
-                ctx.encode_tiles(prm, nt, d_pixels.data_ptr(), True, fetch=False)
+                src = d_pixels[f % len(d_pixels)] if isinstance(d_pixels, (list, tuple)) else d_pixels
+                ctx.encode_tiles(prm, nt, src.data_ptr(), True, fetch=False)
                 if exchange is None:
                     return
                 used = _as_tensor(ctx.table_device_ptr(2), 1, dev, "<i8")
@@ -631,9 +692,9 @@ def main():
                 return pipe[0].flush()
             return None, None
 
-        ctx.set_pipelining(False if args.no_overlap else (2 if exchange == "gather" else True))
+        ctx.set_pipelining(False if args.no_overlap else (depth + lag if exchange == "gather" else True))
         if exchange == "gather":
-            pipe[0] = D.FramePipeline(dev, (stream, comm))
+            pipe[0] = D.FramePipeline(dev, (stream, comm), depth=1 if args.no_overlap else depth, lag=1 if args.no_overlap else lag)
         for f in range(warmup):
             one(f)
         flush()
@@ -662,37 +723,38 @@ def main():
         return int(n.item())
 
     pipelined = not args.no_overlap
-    exchange = (args.exchange if use_dist else None)
+    # N > 1: the counts exchange first -- no data-path transfer, nothing that can stall --; the gather regions run LAST (below),
+    # under a watchdog, so that a transfer that never completes costs the line its gather figures and nothing else
+    exchange = ("counts" if use_dist else None)
     # The GPU's clocks take some ten milliseconds of load to settle (tools measurement, r03: the first region of 20 frames after an
     # idle second 0.458-0.476 ms per frame, every later one 0.435-0.444): the job's steady state is what the metric is about, so a
     # fixed stretch of the same encodes runs before the W warm-up steps (untimed, reported in config.prewarm_steps)
     PREWARM = 40
-    run_frames(params, ntiles, d_px, nblocks, exchange, PREWARM, 0)      # (the same frames, the same exchange: every path warm)
-    dt, last_parts, last_root = run_frames(params, ntiles, d_px, nblocks, exchange, args.steps, args.warmup)
+    # THREE distinct frames in rotation (other noise seeds of the same generator): consecutive timed frames never read the same
+    # 201 MB of pixels, so the 256 MiB Infinity Cache cannot be what serves them; the same region over the
+    # ONE buffer is timed next to it (config.single_input_buffer_ms_per_step)
+    rot = [d_px]
+    for sd in (777, 424242):
+        t2 = synth.g2(Cn, H, W, prec, seed=sd)
+        h2 = np.ascontiguousarray(np.broadcast_to(t2.reshape(1, -1), (ntiles, t2.size))).reshape(-1)
+        rot.append(torch.from_numpy(h2.view(np.uint8)).to(dev))
+        del t2, h2
+    run_frames(params, ntiles, rot, nblocks, exchange, PREWARM, 0)      # (the same frames, the same exchange: every path warm)
+    dt, last_parts, last_root = run_frames(params, ntiles, rot, nblocks, exchange, args.steps, args.warmup)
+    dt_single, _, _ = run_frames(params, ntiles, d_px, nblocks, exchange, args.steps, args.warmup)
     multi_gpu = None
+    cs_len = 0
     if use_dist:
-        multi_gpu = {"world_size": world, "backend": "nccl (RCCL %s)" % ".".join(str(v) for v in torch.cuda.nccl.version()),
-                     "headline_exchange": args.exchange}
-        per = {}
-        per[args.exchange] = {"ms_per_step": round(dt / args.steps * 1e3, 4),
-                              "Mpixels_s": round(pixels_per_step * world * args.steps / dt / 1e6, 1)}
-        if args.exchange == "gather":
-            cs_len = assembled_bytes(params, ntiles, nblocks, W * world if ntiles == 1 else 0, H, last_parts, last_root)
-        other = "counts" if args.exchange == "gather" else "gather"
-        if not args.no_workloads:
-            dt2, parts2, root2 = run_frames(params, ntiles, d_px, nblocks, other, args.steps, args.warmup)
-            per[other] = {"ms_per_step": round(dt2 / args.steps * 1e3, 4),
-                          "Mpixels_s": round(pixels_per_step * world * args.steps / dt2 / 1e6, 1)}
-            if other == "gather":
-                cs_len = assembled_bytes(params, ntiles, nblocks, W * world if ntiles == 1 else 0, H, parts2, root2)
-        elif args.exchange != "gather":
-            cs_len = 0
+        multi_gpu = {"world_size": dist.get_world_size(), "backend": "nccl (RCCL %s)" % ".".join(str(v) for v in torch.cuda.nccl.version()),
+                     "gather_depth": args.gather_depth}
         multi_gpu["replica_%s" % args.workload] = {
             "shape": "one %dx%d tile per rank and frame (a %dx%d frame), weak scaling" % (W, H, W * world, H) if ntiles == 1 else desc,
-            "gather": per.get("gather"), "counts": per.get("counts"),
+            "gather": None,
+            "counts": {"ms_per_step": round(dt / args.steps * 1e3, 4), "Mpixels_s": round(pixels_per_step * world * args.steps / dt / 1e6, 1)},
             "note": "gather = coded tile-parts + block tables to the frame's writer (rank f mod N), exact sizes, issued one frame "
-                    "behind the encoder; counts = all_gather of 16 bytes per rank (parallel writers)"}
+                    "behind the encoder, gather_depth frames in flight; counts = all_gather of 8 bytes per rank (parallel writers)"}
         # BASELINE configs[3]: 16384x16384 as 256 tiles of 1024x1024, the tiles split over the ranks (strong scaling)
+        cfg4 = None
         if not args.no_workloads and args.workload == "8k" and 256 % world == 0:
             p4 = G.TileParams.make(1024, 1024, 3, 8, 5)
             nt4 = 256 // world
@@ -702,19 +764,19 @@ def main():
             nb4 = G.lib().grk_amd_tile_num_blocks(C.byref(p4)) * nt4
             ctx.encode_tiles(p4, nt4, d4.data_ptr(), True, fetch=False)
             ctx.synchronize()
-            res4 = {}
-            for ex in ("gather", "counts"):
-                st4 = max(3, args.steps // 2)
-                d_t, parts4, root4 = run_frames(p4, nt4, d4, nb4, ex, st4, 2)
-                res4[ex] = {"ms_per_step": round(d_t / st4 * 1e3, 4), "Mpixels_s": round(16384.0 * 16384.0 * st4 / d_t / 1e6, 1)}
-                if ex == "gather":
-                    res4["assembled_block_bytes"] = assembled_bytes(p4, nt4, nb4, 0, 0, parts4, root4)
+            st4 = max(3, args.steps // 2)
+            d_t, _, _ = run_frames(p4, nt4, d4, nb4, "counts", st4, 2)
             multi_gpu["cfg4_strong"] = {"shape": "16384x16384x3 8-bit as 256 tiles of 1024x1024, %d tiles per rank and frame, "
-                                                 "strong scaling (BASELINE configs[3])" % nt4, **res4}
-            del d4
+                                                 "strong scaling (BASELINE configs[3])" % nt4, "gather": None,
+                                        "counts": {"ms_per_step": round(d_t / st4 * 1e3, 4), "Mpixels_s": round(16384.0 * 16384.0 * st4 / d_t / 1e6, 1)}}
+            cfg4 = (p4, nt4, d4, nb4, st4)
             # back to the headline shape for the per-kernel passes below
             ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
             ctx.synchronize()
+
+    if rank == 0 and not use_dist and not args.no_live_pmc:
+        torch.cuda.synchronize(dev)
+        live_pmc_traffic(args.workload)          # this run's own HBM-traffic counters (encode and decode families of the workload)
 
     # ---- the decode direction on the blocks just produced (HBM-resident coded bytes -> pixels) ----
     decode = None
@@ -910,6 +972,7 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": ach or 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": frac or 0.0, "traffic": traffic[dom],
                 "frac_on_traffic": rate(traffic[dom], fam[dom][0])[1] if traffic[dom] else None,
+                "traffic_source": _PMC_SOURCE.get(args.workload),
                 "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": round(fam[dom][0], 4),
                 "launches": fam[dom][1], "plane_bytes_per_coefficient": b_pl,
                 "bytes_convention": "SURVEY.md 8(d) per-unit figures at the storage width the launched instances use: %d B per "
@@ -924,12 +987,9 @@ def main():
                for k, v in fam.items()}
     if not use_dist:
         parallelism = "1 GPU, consecutive encodes pipelined (grk_amd_set_pipelining)" if pipelined else "1 GPU"
-    elif args.exchange == "counts":
-        parallelism = ("tile-sharded x%d, per frame all_gather of the coded byte counts (RCCL): parallel writers, the bytes "
-                       "stay on their GPU" % world)
     else:
-        parallelism = ("tile-sharded x%d, per frame the coded tile-parts (exact sizes) gathered over RCCL on the frame's writer "
-                       "rank, which rotates with the frame number; the gather runs one frame behind the encoder" % world)
+        parallelism = ("tile-sharded x%d; per frame either the coded tile-parts (exact sizes) gathered over RCCL on the frame's "
+                       "writer rank (rotating, %d gathers in flight) or only the byte counts (parallel writers): `exchange`" % (world, args.gather_depth))
     kernels_overlapped = {k: {"avg_ms": round(v[0], 4), "launches": v[1]} for k, v in fam_overlapped.items()}
     # whole-pipeline figure: the families' algorithmic bytes as launched (fused level 0, storage width)
     pipeline_bytes = algo["dwt53_5levels"] + algo["ht_cleanup_encode"] + (algo["ingest_mct"] if not fused_in else 0.0)
@@ -940,12 +1000,14 @@ def main():
         value = pixels_per_step * world * args.steps / dt / 1e6
         out = {
             "metric": "encode Mpixels/s (whole node), 8K RGB HTJ2K lossless",
-            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": (dist.get_world_size() if use_dist else 1), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(irrev, b_pl), "data": "synthetic",
             "config": {"workload": desc, "tiles_per_gpu": ntiles, "code_blocks_per_gpu": int(nblocks),
                        "coded_bytes_per_gpu": coded_sum, "arena_bytes_used_per_gpu": int(total), "packed_dwt_levels": pk_levels,
-                       "generator": "G2 (SURVEY.md §8d)", "parallelism": parallelism, "prewarm_steps": PREWARM},
+                       "generator": "G2 (SURVEY.md §8d)", "parallelism": parallelism, "prewarm_steps": PREWARM,
+                       "input_frames_in_rotation": len(rot),
+                       "single_input_buffer_ms_per_step": round(dt_single / args.steps * 1e3, 4)},
             "roofline": roofline,
             # the whole step against the HBM roofline: algorithmic bytes of its kernel families as launched, and what the PMC
             # counters saw per step (`dram_*`)
@@ -961,7 +1023,6 @@ def main():
             "decode": decode,
         }
         if use_dist:
-            out["config"]["assembled_codestream_bytes"] = cs_len
             out["multi_gpu"] = multi_gpu
         cfg5 = None
         if not args.no_cpu_baseline:
@@ -981,20 +1042,60 @@ def main():
             if args.workload == "8k" and not args.no_cpu_baseline:
                 hb["via_grok_plugin"] = via_grok_plugin(ctx, params, tile, prec, (out.get("cpu_baseline") or {}).get("file_md5"))
             out["host_boundary"] = hb
-        line = json.dumps(out)
     else:
-        line = None
+        out = None
+
+    def emit(o):
+        # RCCL writes a version banner to stdout through C stdio: flush that first so that the JSON line is the LAST line on stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        if o is not None:
+            print(json.dumps(o), flush=True)
+
     if use_dist:
+        # ---- the gather regions, last and under a watchdog (see above): frame f's tile-parts to rank f mod N, depth frames in flight
+        import threading
+        rep = multi_gpu["replica_%s" % args.workload]
+        if out is not None:
+            out["exchange"] = {"counts": rep["counts"], "gather": None}
+            out["config"]["headline_exchange"] = "counts"
+
+        def bail():
+            if out is not None:
+                out["exchange"]["gather"] = {"error": "the gather regions did not complete within %.0f s" % args.gather_timeout}
+                emit(out)
+            os._exit(0 if out is not None else 0)
+        dog = threading.Timer(args.gather_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        dtg, parts_g, root_g = run_frames(params, ntiles, rot, nblocks, "gather", args.steps, args.warmup)
+        cs_len = assembled_bytes(params, ntiles, nblocks, W * world if ntiles == 1 else 0, H, parts_g, root_g)
+        g8 = {"ms_per_step": round(dtg / args.steps * 1e3, 4), "Mpixels_s": round(pixels_per_step * world * args.steps / dtg / 1e6, 1),
+              "assembled_codestream_bytes": cs_len}
+        g4 = None
+        if cfg4 is not None:
+            p4, nt4, d4, nb4, st4 = cfg4
+            ctx.encode_tiles(p4, nt4, d4.data_ptr(), True, fetch=False)
+            ctx.synchronize()
+            d_t, parts4, root4 = run_frames(p4, nt4, d4, nb4, "gather", st4, 2)
+            g4 = {"ms_per_step": round(d_t / st4 * 1e3, 4), "Mpixels_s": round(16384.0 * 16384.0 * st4 / d_t / 1e6, 1),
+                  "assembled_block_bytes": assembled_bytes(p4, nt4, nb4, 0, 0, parts4, root4)}
+        dog.cancel()
+        if out is not None:
+            rep["gather"] = g8
+            out["exchange"]["gather"] = g8
+            if g4 is not None:
+                multi_gpu["cfg4_strong"]["gather"] = g4
+            if args.exchange == "gather":          # north_star's wording: the headline is the figure WITH the tile-parts moved
+                out["value"] = g8["Mpixels_s"]
+                out["ms_per_step"] = g8["ms_per_step"]
+                out["config"]["headline_exchange"] = "gather"
+                out["config"]["assembled_codestream_bytes"] = cs_len
         dist.barrier()
         dist.destroy_process_group()
-    # RCCL writes a version banner to stdout through C stdio: flush that first so that the JSON line is the
-    # LAST line on stdout
-    try:
-        C.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    if line is not None:
-        print(line, flush=True)
+    emit(out)
 
 
 _views = {}

@@ -114,9 +114,11 @@ struct grk_amd_ctx {
     bool overlap = false;
     // Pipelining of consecutive encodes (grk_amd_set_pipelining): a second set of per-encode buffers, so that the next
     // encode's DWT can start while the side streams still code the blocks of this one
-    struct AltSet { DevBuf p1, arena, lengths, offsets, flag, ovf; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alt, alt2;
-    int pipe_depth = 2;              // buffer sets in rotation when pipelining: 2, or 3 (grk_amd_set_pipelining(ctx, 2): the
-                                     // results of a call then stay valid until the THIRD next call)
+    static constexpr int kMaxAltSets = 7;
+    struct AltSet { DevBuf p1, arena, lengths, offsets, flag, ovf; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alts[kMaxAltSets];
+    int alt_head = 0;                // the OLDEST of the sets not in use (a ring: the set a call retires becomes the newest)
+    int pipe_depth = 2;              // buffer sets in rotation when pipelining: grk_amd_set_pipelining(ctx, n) -> n + 1 of them (2 ..
+                                     // 8): the results of a call then stay valid until the (n + 1)-th next call
     DevBuf ovf;                      // K3: blocks handed to the fallback launch (kernels.h: HtArgs::ovf_list)
     bool lds_cap = true;             // K3 with capped LDS buffers + fallback launch (GRK_AMD_LDS_CAP=0: worst-case buffers)
     bool pipelining = false;
@@ -155,6 +157,14 @@ struct grk_amd_ctx {
 };
 
 namespace {
+
+bool create_alt_events(grk_amd_ctx* c)
+{
+    for (auto& as : c->alts)
+        if (hipEventCreateWithFlags(&as.ev_side, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&as.ev_side2, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
 
 int fail(grk_amd_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -991,10 +1001,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
             hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->alt.ev_side, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->alt.ev_side2, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->alt2.ev_side, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->alt2.ev_side2, hipEventDisableTiming) != hipSuccess ||
+            !create_alt_events(c) ||
             hipEventCreateWithFlags(&c->ev_level0, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) {
             c->side = nullptr; c->overlap = false;
@@ -1019,7 +1026,8 @@ void grk_amd_destroy(grk_amd_ctx* c)
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
-    for (auto* as : {&c->alt, &c->alt2}) {
+    for (auto& alt_set : c->alts) {
+        auto* as = &alt_set;
         if (as->ev_side) (void)hipEventDestroy(as->ev_side);
         if (as->ev_side2) (void)hipEventDestroy(as->ev_side2);
         for (DevBuf* b : {&as->p1, &as->arena, &as->lengths, &as->offsets, &as->flag, &as->ovf}) b->release();
@@ -1408,14 +1416,9 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
                 std::swap(c->offsets, as.offsets); std::swap(c->flag, as.flag); std::swap(c->ovf, as.ovf);
                 std::swap(c->ev_side, as.ev_side); std::swap(c->ev_side2, as.ev_side2);
             };
-            if (c->pipe_depth == 3) {       // (current, alt = last call's, alt2 = the call before) -> the oldest becomes current
-                swap_with(c->alt2);
-                std::swap(c->alt.p1, c->alt2.p1); std::swap(c->alt.arena, c->alt2.arena); std::swap(c->alt.lengths, c->alt2.lengths);
-                std::swap(c->alt.offsets, c->alt2.offsets); std::swap(c->alt.flag, c->alt2.flag); std::swap(c->alt.ovf, c->alt2.ovf);
-                std::swap(c->alt.ev_side, c->alt2.ev_side); std::swap(c->alt.ev_side2, c->alt2.ev_side2);
-            } else {
-                swap_with(c->alt);
-            }
+            // the oldest of the pipe_depth - 1 other sets becomes current; the set retired here takes its slot as the newest
+            swap_with(c->alts[c->alt_head]);
+            c->alt_head = (c->alt_head + 1) % (c->pipe_depth - 1);
             c->side_pending = false;
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0), "wait for the buffer set");
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side2, 0), "wait for the buffer set");
@@ -1464,7 +1467,8 @@ int grk_amd_set_pipelining(grk_amd_ctx* c, int on)
     if (!c) return GRK_AMD_ERR_INVALID;
     const int rc = grk_amd_synchronize(c);
     c->pipelining = on != 0 && c->side != nullptr && c->side2 != nullptr;
-    c->pipe_depth = on >= 2 ? 3 : 2;
+    c->pipe_depth = std::min(std::max(on, 1) + 1, grk_amd_ctx::kMaxAltSets + 1);
+    c->alt_head = 0;
     return rc;
 }
 

@@ -57,13 +57,14 @@ def exchange_counts(used, nrows, out=None):
     return out.view(world, 2)
 
 
-def gather_frame(counts_host, offsets, lengths, arena, root, bufs=None):
+def gather_frame(counts_host, offsets, lengths, arena, root, bufs=None, group=None):
     """Every rank's coded bytes + block table to `root`, exact sizes.
 
     counts_host : [[bytes used, table rows]] per rank, ON THE HOST (what exchange_counts() gathered)
     offsets     : int64[rows] / lengths: int32[rows] / arena: uint8[>= used] -- this rank's (device) tensors, e.g. views of
                   the encoder's own table and arena (grk_amd_table_device_ptr, grk_amd_coded_device_ptr)
     bufs        : root's receive storage from an earlier call (grown as needed) or None
+    group       : the process group (= communicator) the transfers run on; gathers on different groups run side by side
     Returns on root ([(offsets, lengths, coded) per rank], bufs) -- the root's own part is referenced, not copied --,
     elsewhere (None, None)."""
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -71,9 +72,9 @@ def gather_frame(counts_host, offsets, lengths, arena, root, bufs=None):
     rows = [int(c[1]) for c in counts_host]
     dev = arena.device
     if rank != root:
-        ops = [dist.P2POp(dist.isend, arena[:sizes[rank]], root),
-               dist.P2POp(dist.isend, offsets[:rows[rank]], root),
-               dist.P2POp(dist.isend, lengths[:rows[rank]], root)]
+        ops = [dist.P2POp(dist.isend, arena[:sizes[rank]], root, group),
+               dist.P2POp(dist.isend, offsets[:rows[rank]], root, group),
+               dist.P2POp(dist.isend, lengths[:rows[rank]], root, group)]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         return None, None
@@ -91,7 +92,7 @@ def gather_frame(counts_host, offsets, lengths, arena, root, bufs=None):
         cb, co, cl = bufs[0][ob:ob + sizes[r]], bufs[1][orow:orow + rows[r]], bufs[2][orow:orow + rows[r]]
         ob += sizes[r]
         orow += rows[r]
-        ops += [dist.P2POp(dist.irecv, cb, r), dist.P2POp(dist.irecv, co, r), dist.P2POp(dist.irecv, cl, r)]
+        ops += [dist.P2POp(dist.irecv, cb, r, group), dist.P2POp(dist.irecv, co, r, group), dist.P2POp(dist.irecv, cl, r, group)]
         parts.append((co, cl, cb))
     if ops:
         for w in dist.batch_isend_irecv(ops):
@@ -99,70 +100,109 @@ def gather_frame(counts_host, offsets, lengths, arena, root, bufs=None):
     return parts, bufs
 
 
+_gather_groups = []          # [0]: the counts' group, [1 + g]: gather slot g
+
+
 class FramePipeline:
-    """The per-frame exchange of a sequence of frames, one frame behind the encoder (see the module docstring).
+    """The per-frame exchange of a sequence of frames, behind the encoder (see the module docstring), `depth` gathers in flight.
 
-        pipe = FramePipeline(device)
+        pipe = FramePipeline(device, streams, depth=k, lag=l)
         per frame f:   encode ...;  pipe.submit(f, used, offsets, lengths, arena)     # queues the counts exchange of frame f
-                                                                                       # and the gather of frame f - 1
-        at the end:    parts = pipe.flush()                                            # gather of the last frame
+                                                                                       # and the gather of frame f - l
+        at the end:    parts = pipe.flush()                                            # the gathers still to be issued
 
-    `streams`: (encode stream, comm stream) as torch.cuda streams, or None on the CPU (gloo tests: everything in order).
-    The caller keeps a frame's tensors valid until the gather of that frame has been issued AND the stream that overwrites
-    them next has waited for `pipe.done_event(frame)`.  The gather of frame f is issued while frame f + 1 is being submitted,
-    after a host wait for f's byte counts: an encoder that rotates THREE buffer sets (grk_amd_set_pipelining(ctx, 2)) reuses
-    f's set for frame f + 3 and so never waits for that host round trip; with two sets it would sit between frames.  The number of block-table rows per rank is a property of the tile geometry: it is exchanged with the
-    first frame only; per frame the ranks exchange 8 bytes each (the bytes used in their coded arena), straight out of
-    the encoder's own device word -- no kernel, no allocation, no host synchronisation on the submitting side."""
+    The gather of frame f goes to the frame's writer, rank f mod R: consecutive frames' gathers have different writers, so a
+    rank's sends of frames f, f + 1, ... leave over different xGMI links and the writers' ingress is spread over the node.  One
+    gather moves a frame's coded bytes (~100 MB per rank for an 8K tile) over ONE link pair and takes several frame times; with
+    `depth` = k of them in flight -- each on its own process group (communicator) and stream, frame f on slot f mod k -- the
+    gathers run side by side and the exchange keeps up with an encoder that is k times faster than one link.  The counts (8 bytes
+    per rank and frame, needed on the HOST to size the receives) travel on a group and stream of their own, so they never queue
+    behind a gather.
 
-    def __init__(self, device, streams=None):
+    `streams`: (encode stream, comm stream) as torch.cuda streams -- further comm streams are made here --, or None on the CPU
+    (gloo tests: everything in order).  The caller keeps a frame's tensors valid until the gather of that frame has been issued
+    AND the stream that overwrites them next has waited for `pipe.done_event(frame)`: the gather of frame f is issued while frame
+    f + lag is being submitted and may run until about frame f + lag + k, so an encoder that rotates k + lag + 1 buffer sets
+    (grk_amd_set_pipelining(ctx, k + lag)) reuses f's set for frame f + k + lag + 1 and never waits.  The number of block-table rows per rank
+    is a property of the tile geometry: it is exchanged with the first frame only; per frame the ranks exchange 8 bytes each (the
+    bytes used in their coded arena), straight out of the encoder's own device word -- no kernel, no allocation, no host
+    synchronisation on the submitting side."""
+
+    def __init__(self, device, streams=None, depth=1, lag=1):
         self.dev = device
         self.streams = streams
+        self.depth = max(1, int(depth))
+        # the gather of frame f is issued while frame f + lag is being submitted.  lag = 1 makes the submitting host wait for the
+        # counts of the frame it queued just before -- i.e. for that frame's encode to FINISH --, which keeps the device queue one
+        # frame deep; with lag = 2 the counts are always there already and the host never waits (one more buffer set)
+        self.lag = max(1, int(lag))
+        self.completed = []            # (frame, parts or None, root) of the gathers issued since the last pop_completed()
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.rows = None               # block-table rows per rank
-        self.pending = None            # (frame, slot, offsets, lengths, arena)
-        self.bufs = None
+        self.pending = []              # [(frame, slot, offsets, lengths, arena)] submitted, gather not issued yet (at most lag)
         self.last_parts = None         # on the last frame's writer: [(offsets, lengths, coded)] per rank
         self.last_root = None
         self.gather_done = None        # event: the most recent gather has finished reading its source tensors
         cuda = device.type == "cuda"
+        # one communicator per gather in flight (every rank creates the groups in the same order), one for the counts
+        # (kept for the process's lifetime: a communicator is expensive to make, and every rank must make them in the same order)
+        if self.depth > 1:
+            while len(_gather_groups) < self.depth + 1:
+                _gather_groups.append(dist.new_group(list(range(self.world))))
+            self.groups, self.ctrl_group = _gather_groups[1:self.depth + 1], _gather_groups[0]
+        else:
+            self.groups, self.ctrl_group = [None], None
+        if cuda:
+            self.gstreams = [streams[1]] + [torch.cuda.Stream(device=device) for _ in range(self.depth - 1)]
+            self.ctrl_stream = torch.cuda.Stream(device=device) if self.depth > 1 else streams[1]
+        else:
+            self.gstreams = [None] * self.depth
+            self.ctrl_stream = None
+        # a writer's receive storage: one per frame "generation" (f mod (depth + lag)), so that the parts of every gather a
+        # submit() or flush() issues stay readable until depth + lag frames later
+        self.bufs = [None] * (self.depth + self.lag)
+        nslot = self.lag + 2                               # counts of the frames whose gather has not been issued yet
         self._host = [torch.empty(self.world, dtype=torch.int64).pin_memory() if cuda else torch.empty(self.world, dtype=torch.int64)
-                      for _ in range(2)]
-        self._dev = [torch.empty(self.world, dtype=torch.int64, device=device) for _ in range(2)]
-        self._ready = [torch.cuda.Event() for _ in range(2)] if cuda else [None, None]
+                      for _ in range(nslot)]
+        self._dev = [torch.empty(self.world, dtype=torch.int64, device=device) for _ in range(nslot)]
+        self._ready = [torch.cuda.Event() for _ in range(nslot)] if cuda else [None] * nslot
         self._done = {}                # frame -> event: the gather of that frame has read its source tensors
 
-
     def _issue_gather(self, pending):
-        f, slot, offs, lens, arena = pending
-        if self._ready[slot] is not None:          # the counts of frame f are on the host (frame f + 1 is already queued):
-            ev = self._ready[slot]                 # polled briefly -- a blocking wait wakes up late, and the next frame's
+        f, cslot, offs, lens, arena = pending
+        if self._ready[cslot] is not None:         # the counts of frame f are on the host (frame f + 1 is already queued):
+            ev = self._ready[cslot]                # polled briefly -- a blocking wait wakes up late, and the next frame's
             spins = 0                              # launches have to be queued while this one runs -- then a blocking wait
             while spins < 20000 and not ev.query():    # (a peer that is late or has failed must not leave this rank
                 spins += 1                             # burning a core forever: the collective's own timeout applies)
             if not ev.query():
                 ev.synchronize()
-        counts = [[int(v), self.rows[r]] for r, v in enumerate(self._host[slot].tolist())]
+        counts = [[int(v), self.rows[r]] for r, v in enumerate(self._host[cslot].tolist())]
         root = f % self.world
-        mine = self.bufs if self.rank == root else None
+        g, b = f % self.depth, f % len(self.bufs)
+        mine = self.bufs[b] if self.rank == root else None
         if self.streams is not None:
-            with torch.cuda.stream(self.streams[1]):
-                parts, bufs = gather_frame(counts, offs, lens, arena, root, mine)
-                ev = self._done.pop(f - 4, None) or torch.cuda.Event()
-                ev.record(self.streams[1])
+            before = self._done.get(f - len(self.bufs))        # the gather that used this receive storage last (another stream)
+            if before is not None:
+                self.gstreams[g].wait_event(before)
+            with torch.cuda.stream(self.gstreams[g]):
+                parts, bufs = gather_frame(counts, offs, lens, arena, root, mine, self.groups[g])
+                ev = self._done.pop(f - 2 * (self.depth + self.lag + 2), None) or torch.cuda.Event()
+                ev.record(self.gstreams[g])
                 self._done[f] = ev
                 self.gather_done = ev
         else:
-            parts, bufs = gather_frame(counts, offs, lens, arena, root, mine)
+            parts, bufs = gather_frame(counts, offs, lens, arena, root, mine, self.groups[g])
         if bufs is not None:
-            self.bufs = bufs
+            self.bufs[b] = bufs
         self.last_parts, self.last_root = parts, root
+        self.completed.append((f, parts, root))
 
     def submit(self, frame, used, offsets, lengths, arena, wait_results=None):
         """Queues the counts exchange of `frame` and issues the gather of the frame before it.
-        used: int64[1] tensor on the device (the encoder's own word);  wait_results: callable(comm stream handle) that makes
-        the comm stream wait for this frame's encode (grk_amd_stream_wait_results) -- CUDA only."""
+        used: int64[1] tensor on the device (the encoder's own word);  wait_results: callable(stream handle) that makes
+        that stream wait for this frame's encode (grk_amd_stream_wait_results) -- CUDA only."""
         if self.rows is None:
             r = torch.tensor([offsets.numel()], dtype=torch.int64, device=self.dev)
             allr = torch.empty(self.world, dtype=torch.int64, device=self.dev)
@@ -170,25 +210,30 @@ class FramePipeline:
             self.rows = [int(v) for v in allr.cpu()]
         # first the gather of the frame before (its done-event must not sit behind anything that waits for THIS frame's
         # encode: the encoder's next frame waits for that event before it reuses the buffer set), then this frame's counts
-        prev, self.pending = self.pending, None
-        if prev is not None:
-            self._issue_gather(prev)
-        slot = frame & 1
+        while len(self.pending) >= self.lag:
+            self._issue_gather(self.pending.pop(0))
+        cslot = frame % len(self._host)
         u = used.reshape(1)
         if u.dtype != torch.int64:
             u = u.to(torch.int64)
         if self.streams is not None:
-            comm = self.streams[1]
-            if wait_results is not None:
-                wait_results(comm.cuda_stream)
-            with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(self._dev[slot], u)
-                self._host[slot].copy_(self._dev[slot], non_blocking=True)
-                self._ready[slot].record(comm)
+            if wait_results is not None:           # the frame's results: its gather's stream and the counts' stream wait for them
+                wait_results(self.gstreams[frame % self.depth].cuda_stream)
+                if self.ctrl_stream is not self.gstreams[frame % self.depth]:
+                    wait_results(self.ctrl_stream.cuda_stream)
+            with torch.cuda.stream(self.ctrl_stream):
+                dist.all_gather_into_tensor(self._dev[cslot], u, group=self.ctrl_group)
+                self._host[cslot].copy_(self._dev[cslot], non_blocking=True)
+                self._ready[cslot].record(self.ctrl_stream)
         else:
-            dist.all_gather_into_tensor(self._dev[slot], u)
-            self._host[slot].copy_(self._dev[slot])
-        self.pending = (frame, slot, offsets, lengths, arena)
+            dist.all_gather_into_tensor(self._dev[cslot], u, group=self.ctrl_group)
+            self._host[cslot].copy_(self._dev[cslot])
+        self.pending.append((frame, cslot, offsets, lengths, arena))
+
+    def pop_completed(self):
+        """[(frame, parts on that frame's writer else None, writer rank)] of the gathers issued since the last call."""
+        out, self.completed = self.completed, []
+        return out
 
     def done_event(self, frame):
         """The event after which the tensors submitted for `frame` may be overwritten (None: nothing to wait for)."""
@@ -196,11 +241,11 @@ class FramePipeline:
 
     def flush(self):
         """Issues the gather of the last submitted frame; returns (parts on that frame's writer else None, writer rank)."""
-        if self.pending is not None:
-            self._issue_gather(self.pending)
-            self.pending = None
+        while self.pending:
+            self._issue_gather(self.pending.pop(0))
         if self.streams is not None:
-            self.streams[1].synchronize()
+            for st in self.gstreams:
+                st.synchronize()
         return self.last_parts, self.last_root
 
 

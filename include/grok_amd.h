@@ -262,9 +262,10 @@ int    grk_amd_set_overlap(grk_amd_ctx* ctx, int on);
  * valid until the second next call.  Every grk_amd_* function that reads them (fetch_table, fetch_coded, synchronize,
  * decode, the stage entry points) joins first; a caller that consumes grk_amd_coded_device_ptr / _table_device_ptr on
  * its own stream must call grk_amd_synchronize before.  Needs the overlap (above) to be on.
- * on = 2: THREE buffer sets in rotation -- the results of a call stay valid until the third next call, for a consumer
- * that works one frame behind the encoder (the tile-part gather of a tile-sharded job, grok_amd/dist.py: the receive sizes
- * have to pass through the host, and with two sets that round trip would sit between consecutive frames). */
+ * on = n >= 2 (up to 7): n + 1 buffer sets in rotation -- the results of a call stay valid until the (n + 1)-th next call, for a
+ * consumer that works behind the encoder: n = 2 for the tile-part gather of a tile-sharded job one frame behind
+ * (grok_amd/dist.py: the receive sizes have to pass through the host, and with two sets that round trip would sit between
+ * consecutive frames), n = k + 1 for k gathers in flight at once (each towards another writer, over another xGMI link). */
 int    grk_amd_set_pipelining(grk_amd_ctx* ctx, int on);
 /* Makes `hip_stream` (the caller's, e.g. the one its RCCL collectives run on) wait for the results of the latest encode
  * -- the context's stream and, when pipelined, its side streams -- without blocking the context's own stream: the

@@ -33,6 +33,8 @@ FAMILIES = [  # (family, test on the kernel name); the inverse kernels first: "i
     ("ht_dec_vlc_kernel", lambda n: "ht_dec_vlc_kernel" in n),
     ("ht_dec_ms_kernel", lambda n: "ht_dec_ms_kernel" in n),
     ("t1_dec_kernel", lambda n: "t1_dec_kernel" in n),
+    ("t1_lanes_kernel", lambda n: "t1_lanes_kernel" in n),
+    ("t1_recon_kernel", lambda n: "t1_recon_kernel" in n),
     ("egress_kernel", lambda n: "egress_kernel" in n),
     ("ingest_kernel", lambda n: "ingest_kernel" in n),
 ]
@@ -64,7 +66,10 @@ def main(fetch_csv, write_csv, out_json):
 
     def steps(cnt, enc):
         keys = ("ht_alloc_init_kernel",) if enc else ("ht_dec_vlc_kernel", "t1_dec_kernel")
-        return max(1, sum(v for k, v in cnt.items() if any(s in k for s in keys)))
+        n = sum(v for k, v in cnt.items() if any(s in k for s in keys))
+        if not enc and n == 0:                   # (a Part-1 frame whose blocks all went to the lane decoder)
+            n = sum(v for k, v in cnt.items() if "t1_lanes_kernel" in k)
+        return max(1, n)
     out = {}
     for fam, _ in FAMILIES:
         if fam not in f and fam not in w:

@@ -46,7 +46,7 @@ def _encode_my_tiles(px, TW, TH, tcols, mine, prec, L):
     return table, coded
 
 
-def _worker(rank, world, port, q, W, H, TW, TH, L, frames, tmpfile):
+def _worker(rank, world, port, q, W, H, TW, TH, L, frames, tmpfile, depth=1, lag=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -59,7 +59,7 @@ def _worker(rank, world, port, q, W, H, TW, TH, L, frames, tmpfile):
     bpt = G.lib().grk_amd_tile_num_blocks(p)
     mine = D.shard_tiles(ntiles, world, rank)            # uneven when world does not divide the tile count
     # ---- a sequence of frames through the pipeline: counts exchange of frame f, gather of frame f - 1, rotating writer
-    pipe = D.FramePipeline(dev)
+    pipe = D.FramePipeline(dev, depth=depth, lag=lag)    # depth > 1: one process group per gather in flight + one for the counts
     files = {}
     for f in range(frames):
         px = synth.g2(3, H, W, 8, seed=12345 + f)
@@ -67,16 +67,17 @@ def _worker(rank, world, port, q, W, H, TW, TH, L, frames, tmpfile):
         offs = torch.from_numpy(table["offset"].astype(np.int64))
         lens = torch.from_numpy(table["length"].astype(np.int32))
         pipe.submit(f, torch.tensor([coded.numel()]), offs, lens, coded)
-        done = f - 1
-        if done >= 0 and pipe.last_root == rank:         # this rank is the writer of the frame just gathered
-            assert pipe.last_root == done % world
-            ft, fc = D.merge_tile_parts(D.parts_to_numpy(pipe.last_parts), ntiles, bpt)
-            files[done] = G.write_codestream(p, W, H, ft, fc)
+        for done, parts, root in pipe.pop_completed():   # the gathers this submit issued (frame f - lag)
+            assert done == f - lag and root == done % world
+            if root == rank:                             # this rank is that frame's writer
+                ft, fc = D.merge_tile_parts(D.parts_to_numpy(parts), ntiles, bpt)
+                files[done] = G.write_codestream(p, W, H, ft, fc)
     parts, root = pipe.flush()
     assert root == (frames - 1) % world
-    if rank == root:
-        ft, fc = D.merge_tile_parts(D.parts_to_numpy(parts), ntiles, bpt)
-        files[frames - 1] = G.write_codestream(p, W, H, ft, fc)
+    for done, parts, root in pipe.pop_completed():
+        if root == rank:
+            ft, fc = D.merge_tile_parts(D.parts_to_numpy(parts), ntiles, bpt)
+            files[done] = G.write_codestream(p, W, H, ft, fc)
     # ---- the parallel-writer route over the C ABI pieces: every rank sizes and writes its own tile-parts; the sizes are
     #      exchanged, so that each rank knows its offsets in the file (and rank 0 can write TLM into the main header)
     px = synth.g2(3, H, W, 8, seed=12345)
@@ -103,12 +104,12 @@ def _worker(rank, world, port, q, W, H, TW, TH, L, frames, tmpfile):
     dist.destroy_process_group()
 
 
-def _run(world, W, H, TW, TH, L, frames, tmp_path):
+def _run(world, W, H, TW, TH, L, frames, tmp_path, depth=1, lag=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     tmpfile = str(tmp_path / "parallel.j2k")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, W, H, TW, TH, L, frames, tmpfile)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, W, H, TW, TH, L, frames, tmpfile, depth, lag)) for r in range(world)]
     for pr in procs:
         pr.start()
     files = {}
@@ -151,6 +152,17 @@ def test_four_ranks_seven_tiles_uneven_shards(tmp_path):
     if R.have_ref():
         assert np.array_equal(R.decode(parallel, 3, H, W), synth.g2(3, H, W, 8).astype(np.int32))
         assert np.array_equal(R.decode(files[3], 3, H, W), synth.g2(3, H, W, 8, seed=12348).astype(np.int32))
+
+
+@pytest.mark.parametrize("world,depth,lag,frames", [(2, 3, 1, 7), (4, 4, 2, 9), (2, 1, 3, 6)])
+def test_gathers_of_several_frames_in_flight(tmp_path, world, depth, lag, frames):
+    """FramePipeline(depth = k): frame f's gather on communicator f mod k, the counts on one of their own; more frames than
+    slots, so every slot and every writer comes round more than once.  Every frame's file == a single process's."""
+    W, H, T, L = 7 * 64, 64, 64, 2
+    files, _ = _run(world, W, H, T, T, L, frames, tmp_path, depth=depth, lag=lag)
+    assert sorted(files) == list(range(frames))
+    for f in range(frames):
+        assert files[f] == cshelp.oracle_codestream(synth.g2(3, H, W, 8, seed=12345 + f), 8, L, T, T), "frame %d" % f
 
 
 def test_shard_tiles_partition():
