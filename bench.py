@@ -1070,7 +1070,9 @@ def main():
         dog = threading.Timer(args.gather_timeout, bail)
         dog.daemon = True
         dog.start()
-        dtg, parts_g, root_g = run_frames(params, ntiles, rot, nblocks, "gather", args.steps, args.warmup)
+        # (every buffer set of the rotation exists and every communicator has carried a frame before the timed frames)
+        gw = max(args.warmup, 2 * (args.gather_depth + 3) + 2)
+        dtg, parts_g, root_g = run_frames(params, ntiles, rot, nblocks, "gather", args.steps, gw)
         cs_len = assembled_bytes(params, ntiles, nblocks, W * world if ntiles == 1 else 0, H, parts_g, root_g)
         g8 = {"ms_per_step": round(dtg / args.steps * 1e3, 4), "Mpixels_s": round(pixels_per_step * world * args.steps / dtg / 1e6, 1),
               "assembled_codestream_bytes": cs_len}
@@ -1079,7 +1081,7 @@ def main():
             p4, nt4, d4, nb4, st4 = cfg4
             ctx.encode_tiles(p4, nt4, d4.data_ptr(), True, fetch=False)
             ctx.synchronize()
-            d_t, parts4, root4 = run_frames(p4, nt4, d4, nb4, "gather", st4, 2)
+            d_t, parts4, root4 = run_frames(p4, nt4, d4, nb4, "gather", st4, gw)
             g4 = {"ms_per_step": round(d_t / st4 * 1e3, 4), "Mpixels_s": round(16384.0 * 16384.0 * st4 / d_t / 1e6, 1),
                   "assembled_block_bytes": assembled_bytes(p4, nt4, nb4, 0, 0, parts4, root4)}
         dog.cancel()
