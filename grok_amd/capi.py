@@ -120,6 +120,8 @@ def lib():
         if hasattr(L, "grk_amd_plane_sample_bytes"):      # (absent from older builds loaded through GRK_AMD_LIB for A/B timing)
             L.grk_amd_plane_sample_bytes.argtypes = [vp, PP, i32, C.POINTER(u32)]
         L.grk_amd_set_pipelining.argtypes = [vp, i32]
+        if hasattr(L, "grk_amd_set_decode_pipelining"):
+            L.grk_amd_set_decode_pipelining.argtypes = [vp, i32]
         L.grk_amd_stream_wait_results.argtypes = [vp, vp]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
@@ -430,6 +432,10 @@ class Context:
 
     def stream_wait_results(self, hip_stream):
         self._check(self._L.grk_amd_stream_wait_results(self._h, C.c_void_p(hip_stream)), "stream_wait_results")
+
+    def set_decode_pipelining(self, frames_in_flight):
+        """2..4: consecutive decode_device calls run on that many internal buffer / stream sets in turn (0 / 1: off)"""
+        self._check(self._L.grk_amd_set_decode_pipelining(self._h, int(frames_in_flight)), "set_decode_pipelining")
 
     def set_pipelining(self, on):
         """False / True (two buffer sets) / 2 (three: results valid until the third next call)."""

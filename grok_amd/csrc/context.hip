@@ -146,6 +146,13 @@ struct grk_amd_ctx {
     bool dec_top_pending = false;
     // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
     // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
+    // Decode of a SEQUENCE of frames (grk_amd_set_decode_pipelining): consecutive grk_amd_decode_tiles calls with device buffers
+    // go in turn to this context and to `dec_kids` -- contexts of their own on the same device: own streams, tables, planes --,
+    // each behind an event on the caller's stream.  A frame's serial block-decoding chains (K5a / K8) leave most of the machine
+    // idle; the next frame's kernels take what is free.  grk_amd_synchronize / grk_amd_decode_status cover them all.
+    std::vector<grk_amd_ctx*> dec_kids;
+    uint32_t dec_seq = 0;
+    hipEvent_t ev_seq = nullptr;
     bool t1_lanes = true;
     float t1_tail_ratio = 0.25f;
     float t1_tail_share = 0.0f;          // ... and at least this share of the blocks (the longest ones) to K8 as well
@@ -1014,7 +1021,10 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
 void grk_amd_destroy(grk_amd_ctx* c)
 {
     if (!c) return;
+    for (grk_amd_ctx* k : c->dec_kids) grk_amd_destroy(k);
+    c->dec_kids.clear();
     (void)hipSetDevice(c->device);
+    if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
     for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
@@ -1246,7 +1256,46 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
                          void* pixels, int pixels_on_device)
 {
+    if (c && !c->dec_kids.empty() && coded_on_device && pixels_on_device) {
+        const uint32_t turn = c->dec_seq++ % (uint32_t)(c->dec_kids.size() + 1);
+        if (turn) {
+            grk_amd_ctx* k = c->dec_kids[turn - 1];
+            // what the caller set on the context applies to the frame wherever it is decoded
+            if (k->dec_qcd != c->dec_qcd || k->dec_steps != c->dec_steps) { k->dec_qcd = c->dec_qcd; k->dec_steps = c->dec_steps; k->have_geom = false; }
+            if (k->dec_seg_first != c->dec_seg_first) k->dec_seg_first = c->dec_seg_first;
+            if (k->dec_segs.size() != c->dec_segs.size() ||
+                (!c->dec_segs.empty() && std::memcmp(k->dec_segs.data(), c->dec_segs.data(), c->dec_segs.size() * sizeof(c->dec_segs[0])) != 0))
+                k->dec_segs = c->dec_segs;
+            k->dec_planes16 = c->dec_planes16; k->fuse_egress = c->fuse_egress; k->dwt_pk = c->dwt_pk; k->dwt_xcd = c->dwt_xcd;
+            k->overlap = c->overlap && k->side != nullptr; k->t1_lanes = c->t1_lanes; k->t1_tail_ratio = c->t1_tail_ratio;
+            // ... behind whatever the caller queued on this context's stream (its uploads of the coded bytes)
+            HIP_TRY(c, hipSetDevice(c->device), "set device");
+            HIP_TRY(c, hipEventRecord(c->ev_seq, c->stream), "record the caller's stream");
+            HIP_TRY(c, hipStreamWaitEvent(k->stream, c->ev_seq, 0), "order the frame behind the caller's stream");
+            const int rc = decode_impl(k, p, ntiles, table, coded, coded_bytes, 1, pixels, 1, nullptr);
+            if (rc) c->err = k->err;
+            return rc;
+        }
+    }
     return decode_impl(c, p, ntiles, table, coded, coded_bytes, coded_on_device, pixels, pixels_on_device, nullptr);
+}
+
+int grk_amd_set_decode_pipelining(grk_amd_ctx* c, int frames_in_flight)
+{
+    if (!c || frames_in_flight < 0 || frames_in_flight > 4) return GRK_AMD_ERR_INVALID;
+    int rc = grk_amd_synchronize(c);
+    for (grk_amd_ctx* k : c->dec_kids) grk_amd_destroy(k);
+    c->dec_kids.clear();
+    c->dec_seq = 0;
+    if (rc) return rc;
+    if (frames_in_flight >= 2 && !c->ev_seq) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_seq, hipEventDisableTiming), "create event");
+    for (int i = 1; i < frames_in_flight; ++i) {
+        grk_amd_ctx* k = nullptr;
+        rc = grk_amd_create(c->device, c->verbose, &k);
+        if (rc) return fail(c, rc, "a further decode context could not be made");
+        c->dec_kids.push_back(k);
+    }
+    return GRK_AMD_OK;
 }
 
 int grk_amd_decode_region(grk_amd_ctx* c, const grk_amd_tile_params* p,
@@ -1288,7 +1337,12 @@ int grk_amd_decode_status(grk_amd_ctx* c)
 {
     if (!c) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
-    return check_decode_status(c);
+    int rc = check_decode_status(c);
+    for (grk_amd_ctx* k : c->dec_kids) {            // (a sequence: the frames decoded on the other contexts as well)
+        const int kr = check_decode_status(k);
+        if (kr && !rc) { rc = kr; c->err = k->err; }
+    }
+    return rc;
 }
 
 int grk_amd_stage_egress(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const void* d_planes, void* d_pixels)
@@ -1381,6 +1435,7 @@ int grk_amd_synchronize(grk_amd_ctx* c)
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     if (c->side) HIP_TRY(c, hipStreamSynchronize(c->side), "sync side stream");        // (a pipelined predecessor)
     if (c->side2) HIP_TRY(c, hipStreamSynchronize(c->side2), "sync side stream 2");
+    for (grk_amd_ctx* k : c->dec_kids) { const int kr = grk_amd_synchronize(k); if (kr) { c->err = k->err; return kr; } }
     return GRK_AMD_OK;
 }
 

@@ -187,6 +187,15 @@ int grk_amd_decode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes,
                          int coded_on_device, void* pixels, int pixels_on_device);
 int grk_amd_decode_status(grk_amd_ctx* ctx);
+/* A SEQUENCE of frames: with frames_in_flight = n in 2..4, consecutive grk_amd_decode_tiles calls whose coded bytes and pixels
+ * are device buffers are decoded on n internal buffer / stream sets in turn, each queued behind what the caller has on the
+ * context's stream at the time of the call, so that frame f + 1's block decoding (serial chains that leave most of the GPU
+ * idle) runs beside frame f's dequantisation and inverse transform.  The reference decodes a frame's tiles as pooled tasks
+ * (codestream/CodeStreamDecompress.cpp:450-519); this is the same idea across frames.  A call returns when its kernels are
+ * queued; a frame's pixels are complete after grk_amd_synchronize (all frames) -- grk_amd_decode_status reports the worst
+ * status of all of them.  0 or 1: off (every call on the context's own stream, as before).  Calls with host buffers and
+ * grk_amd_decode_region always run on the context itself. */
+int grk_amd_set_decode_pipelining(grk_amd_ctx* ctx, int frames_in_flight);
 /* 8-bit reversible HT tiles are decoded with int16 planes between the block decoder and the inverse DWT (default on; half
  * the bytes of the two HBM-bound halves of the decode), and the inverse 5/3 runs on packed pairs of them, which takes every
  * coefficient and every synthesised LL sample within +-2047 (an 8-bit image's are: |HH| <= 1020 at the top resolution, the

@@ -812,3 +812,44 @@ def test_decode_with_and_without_the_side_stream_and_tables_of_consecutive_calls
         for k in range(6):
             assert np.array_equal(outs[k].cpu().numpy().reshape(imgs[0].shape), imgs[k % 3]), (ov, k)
             outs[k].zero_()
+
+
+def test_decode_sequence_mode_frames_in_flight():
+    """grk_amd_set_decode_pipelining(ctx, 3): consecutive decode calls on three internal buffer / stream sets in turn.  Every frame of a
+    sequence of DIFFERENT frames comes out as the one-at-a-time decode gives it; a corrupt frame in the middle is reported by
+    grk_amd_decode_status whichever set decoded it; switching the mode off again leaves a context that works as before."""
+    C, H, W, prec, L = 3, 256, 384, 8, 4
+    p = G.TileParams.make(W, H, C, prec, L)
+    c = G.Context(0)
+    frames = []
+    for f in range(7):
+        px = synth.g2(C, H, W, prec, seed=100 + f)
+        table, coded = c.encode_host(p, px)
+        frames.append((px, table, U.to_dev(np.frombuffer(bytes(coded), np.uint8).copy())))
+    c.set_decode_pipelining(3)
+    try:
+        outs = [torch.zeros(C * H * W, dtype=torch.uint8, device="cuda") for _ in frames]
+        for rep in range(2):                                  # (twice: every set has decoded, then decodes again)
+            for (px, table, d_c), o in zip(frames, outs):
+                c.decode_device(p, 1, table, d_c.data_ptr(), d_c.numel(), o.data_ptr())
+        c.synchronize()
+        c.decode_status()
+        for (px, _, _), o in zip(frames, outs):
+            assert np.array_equal(o.cpu().numpy().reshape(C, H, W), px)
+        # a frame with a corrupt block, decoded by one of the other sets
+        px, table, d_c = frames[1]
+        bad = d_c.clone()
+        i = int(np.argmax(table["length"]))
+        off, ln = int(table["offset"][i]), int(table["length"][i])
+        bad[off + ln - 1] = 0xFF; bad[off + ln - 2] |= 0x0F         # Scup > Lcup
+        c.decode_device(p, 1, frames[0][1], frames[0][2].data_ptr(), frames[0][2].numel(), outs[0].data_ptr())
+        c.decode_device(p, 1, table, bad.data_ptr(), bad.numel(), outs[1].data_ptr())
+        c.decode_device(p, 1, frames[2][1], frames[2][2].data_ptr(), frames[2][2].numel(), outs[2].data_ptr())
+        with pytest.raises(RuntimeError):
+            c.decode_status()
+    finally:
+        c.set_decode_pipelining(0)
+    o = torch.zeros(C * H * W, dtype=torch.uint8, device="cuda")
+    c.decode_device(p, 1, frames[3][1], frames[3][2].data_ptr(), frames[3][2].numel(), o.data_ptr())
+    c.synchronize()
+    assert np.array_equal(o.cpu().numpy().reshape(C, H, W), frames[3][0])
