@@ -924,6 +924,8 @@ def main():
     if decode is not None and decode.get("rejected") is None and ntiles == 1 and args.workload == "8k":
         decode["sequence_mode"] = {}
         try:
+            # (a decode on this context clears the status block the encoder's allocator shares: a fresh encode, then its table)
+            ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
             table_d, total_d = ctx.fetch_table(nblocks)
             backs = [d_back] + [torch.empty_like(d_back) for _ in range(2)]
             for nfl in (2, 3):

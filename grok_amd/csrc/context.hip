@@ -156,6 +156,7 @@ struct grk_amd_ctx {
     bool t1_lanes = true;
     float t1_tail_ratio = 0.25f;
     float t1_tail_share = 0.0f;          // ... and at least this share of the blocks (the longest ones) to K8 as well
+    bool t1_pass_sync = true;            // K8L's waves hold blocks of equal bit-plane / pass counts and run pass by pass (GRK_AMD_T1_SYNC=0: free-running lanes)
     struct DecUpload { char* p = nullptr; char* dp = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; } dec_up[2];
     uint32_t dec_turn = 0;
     // timing
@@ -673,7 +674,7 @@ int stage_table(grk_amd_ctx* c, const grk_amd_coded_block* table, uint64_t nbloc
     grk_amd_ctx::DecUpload* u = &c->dec_up[c->dec_turn++ & 1u];
     if (!u->ev) HIP_TRY(c, hipEventCreateWithFlags(&u->ev, hipEventDisableTiming), "create event");
     HIP_TRY(c, hipEventSynchronize(u->ev), "wait for the tables' last upload");
-    const size_t need = (size_t)nblocks * (sizeof(grk_amd_coded_block) + 8) + 64;
+    const size_t need = (size_t)nblocks * (sizeof(grk_amd_coded_block) + 16) + 64;        // rows + the launch lists behind them
     if (u->cap < need) {
         if (u->p) (void)hipHostFree(u->p);
         u->p = u->dp = nullptr; u->cap = 0;
@@ -802,8 +803,8 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
     // is its longest chain's: the blocks longer than t1_tail_ratio x the longest one -- a handful: the LL band -- and
     // whatever the lane form does not take go to K8, longest first; the rest to K8L, sorted by length so that the lanes of a
     // wave finish together.  Both lists behind the rows in the pinned tables (stage_table leaves 8 bytes per block).
-    uint32_t* const h_lane = (uint32_t*)(up->p + nblocks * sizeof(grk_amd_coded_block));
-    uint32_t* const h_tail = h_lane + nblocks;
+    uint32_t* const h_lane = (uint32_t*)(up->p + nblocks * sizeof(grk_amd_coded_block));      // (room for 2 nblocks entries: padding)
+    uint32_t* const h_tail = h_lane + 2 * nblocks;
     uint32_t n_lane = 0, n_tail = 0;
     const bool lanes_on = c->t1_lanes && g.p.reserved[1] == 0 && c->dec_seg_first.empty() && nblocks <= 0xFFFFFFFFull;
     if (lanes_on) {
@@ -827,9 +828,31 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
             const uint32_t i = order[k];
             if (k >= share && table[i].length <= thr && eligible(i)) h_lane[n_lane++] = i; else h_tail[n_tail++] = i;
         }
+        if (n_lane >= 64u && c->t1_pass_sync) {
+            // pass-synchronous waves: a wave's lanes go from pass to pass together, so a wave holds blocks with the SAME number of
+            // bit-planes and passes (table word missing_msbs), longest first within the group; a group fills whole waves (spare
+            // lanes: kT1NoBlock); groups too small for a wave go to K8
+            std::vector<uint32_t> lane(h_lane, h_lane + n_lane);
+            auto key = [&](uint32_t i) { return (((table[i].missing_msbs >> 8) & 0xFFu) << 4) | (table[i].missing_msbs & 0xFu); };   // passes, planes (<= 14)
+            constexpr uint32_t kKeys = 256u << 4;
+            std::vector<uint32_t> cnt(kKeys, 0u), at(kKeys, 0u);
+            for (uint32_t i : lane) cnt[key(i)]++;
+            uint32_t out = 0;
+            for (uint32_t k = kKeys; k-- > 0;) {                              // (more passes first: the longest-running waves start first)
+                if (cnt[k] < 64u) { at[k] = kT1NoBlock; continue; }
+                at[k] = out;
+                out += (cnt[k] + 63u) & ~63u;
+            }
+            for (uint32_t j = 0; j < out; ++j) h_lane[j] = kT1NoBlock;
+            for (uint32_t i : lane) {                                         // (the groups keep the longest-first order)
+                const uint32_t k = key(i);
+                if (at[k] == kT1NoBlock) h_tail[n_tail++] = i; else h_lane[at[k]++] = i;
+            }
+            n_lane = out;
+        }
         if (n_lane < 64u) { n_lane = 0; n_tail = 0; }                   // not worth a second launch: K8 in table order
     }
-    { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock) + nblocks * 8); if (rc) return rc; }
+    { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock) + nblocks * 12); if (rc) return rc; }
     const uint32_t* const d_lane = (const uint32_t*)((const char*)c->dec_table.p + nblocks * sizeof(HtDecBlock));
     T1DecArgs a{};
     a.table = (const HtDecBlock*)c->dec_table.p;
@@ -859,7 +882,8 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
         la.coded = a.coded; la.coded_bytes = coded_bytes;
         la.work = (uint64_t*)c->dec_work.p;
         la.mallat = a.mallat; la.stride = a.stride; la.pitch = a.pitch; la.irreversible = a.irreversible;
-        a.list = d_lane + nblocks; a.count = n_tail;
+        la.pass_sync = c->t1_pass_sync ? 1 : 0;
+        a.list = d_lane + 2 * nblocks; a.count = n_tail;
         if (c->overlap && c->side) {
             // the long chains on the call's stream, the lanes beside them on the side stream
             if (!c->ev_dec_front) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_dec_front, hipEventDisableTiming), "create event");
@@ -1003,6 +1027,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* et = getenv("GRK_AMD_T1_LANES")) c->t1_lanes = atoi(et) != 0;
         if (const char* er = getenv("GRK_AMD_T1_TAIL_RATIO")) c->t1_tail_ratio = (float)atof(er);
         if (const char* es = getenv("GRK_AMD_T1_TAIL_SHARE")) c->t1_tail_share = (float)atof(es);
+        if (const char* ey = getenv("GRK_AMD_T1_SYNC")) c->t1_pass_sync = atoi(ey) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||

@@ -163,7 +163,9 @@ struct T1LaneArgs {
     uint64_t* work;                            // [nblocks][kT1WorkBytes / 8]
     int32_t* mallat; uint32_t stride; uint64_t pitch;
     int irreversible;
+    int pass_sync;                             // the waves hold blocks of equal bit-plane / pass counts and run them pass by pass
 };
+constexpr uint32_t kT1NoBlock = 0xFFFFFFFFu;   // list entry of a lane without a block
 hipError_t launch_t1_lanes(const T1LaneArgs& a, hipStream_t s);       // t1_lanes_kernel, then t1_recon_kernel
 
 // ---- K6: one inverse DWT level, horizontal + vertical fused (kernels_idwt.hip) ------------------

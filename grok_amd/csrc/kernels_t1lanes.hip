@@ -12,6 +12,7 @@
 //                       dequantised (ShiftFilter / ScaleFilter, filters/PostDecompressFilters.h:26-35, :60-71) into the Mallat plane.
 #include "kernels.h"
 #include "t1_lanes.h"
+#include <type_traits>
 
 namespace grk_amd {
 
@@ -34,6 +35,9 @@ struct LaneTables {
 static_assert(sizeof(LaneTables) == kLdsBytes - kCtxBytes, "the tables follow the context rows in LDS");
 __device__ const LaneTables g_lane_tables{};
 
+// SYNC: the wave's lanes run their passes in step, one specialised copy of the loop per pass type (t1_lanes.h) -- the host puts
+// blocks with the same number of bit-planes and passes into a wave.  !SYNC: every lane at its own pace, one general loop.
+template <bool SYNC>
 __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds32[kLdsBytes / 4];
@@ -48,8 +52,8 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
     for (uint32_t cx = 0; cx < 19; ++cx) lds32[cx * 64 + lane] = mq_entry(cx == 18 ? 46u : cx == 17 ? 3u : cx == 0 ? 4u : 0u);
     Lane L;
     const uint32_t idx = blockIdx.x * 64u + lane;
-    if (idx < a.count) {
-        const uint32_t blk = a.list[idx];
+    const uint32_t blk = idx < a.count ? a.list[idx] : kT1NoBlock;
+    if (blk != kT1NoBlock) {
         const HtDecBlock in = a.table[blk];
         const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
         BlockIn b;
@@ -59,57 +63,50 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
         b.work = a.work + (size_t)blk * kWorkU64;
         b.lo = a.coded; b.hi = a.coded + a.coded_bytes;
         lane_init(L, b);
-    } else {
+    } else {                                       // (a wave's spare lanes: the host fills waves per group of equal blocks)
         L = Lane{};
         L.st = ST_DONE; L.nv = 8; L.pend = 0;
     }
     __syncthreads();
-    // one step: the lanes that need one pick their next column; every lane with a pending decision makes it
-    auto step = [&]() {
-        if (L.st == ST_NEEDCOL) lane_column_enter(L);
-        if (L.st <= ST_UNI2 && L.nv >= 3u) {
-#ifdef T1L_BRANCHY
-            const uint32_t off = lane_context(L, lds16);
-            const uint32_t d = lane_mq_decode(L, lds32, (off >> 2) + lane);
-            lane_apply(L, d);
-#else
-            const uint32_t off = lane_context_sel(L, lds16);
-            const uint32_t d = lane_mq_decode(L, lds32, (off >> 2) + lane);
-            lane_apply_sel(L, d);
-#endif
-        }
-    };
-#ifndef T1L_NO_UNROLL4
-    // four steps to a round: stripes stored / the next ones and coded bytes requested before the first, delivery before the third
-    for (;;) {
-        if (L.st == ST_NEEDSTRIPE) lane_stripe_exit(L);
+    // one step: the lanes that need one pick their next column; every lane with a pending decision makes it.
+    // A round is four steps: stripes stored / the next ones and coded bytes requested before the first, delivery before the third.
+    auto round = [&](auto TT) {
+        constexpr int T = decltype(TT)::value;
+        auto step = [&]() {
+            if (L.st == ST_NEEDCOL) lane_column_enter<T>(L);
+            if (L.st <= ST_UNI2 && L.nv >= 3u) {
+                const uint32_t off = lane_context<T>(L, lds16);
+                const uint32_t d = lane_mq_decode(L, lds32, (off >> 2) + lane);
+                lane_apply<T>(L, d);
+            }
+        };
+        if (L.st == ST_NEEDSTRIPE) lane_stripe_exit<T, SYNC>(L);
         if (lane_wants_bytes(L)) lane_fetch_issue(L);
         step(); step();
-        if (L.st == ST_WAIT) lane_stripe_enter(L);
+        if (L.st == ST_WAIT) lane_stripe_enter<T>(L);
         if (L.pend) lane_fetch_arrive(L);
         step(); step();
-        if (__builtin_amdgcn_ballot_w64(L.st != ST_DONE) == 0) break;
-    }
-#else
-    for (uint32_t it = 0;; ++it) {
-        const uint32_t phase = it & 3u;
-        if (phase == 0) {                          // every fourth iteration: stripes stored, the next ones and coded bytes requested
-            if (L.st == ST_NEEDSTRIPE) lane_stripe_exit(L);
-            if (lane_wants_bytes(L)) lane_fetch_issue(L);
-        } else if (phase == 2) {                   // two iterations later they are there
-            if (L.st == ST_WAIT) lane_stripe_enter(L);
-            if (L.pend) lane_fetch_arrive(L);
+    };
+    if constexpr (SYNC) {
+        uint32_t T = 2;                            // every block starts with the cleanup pass of its top plane
+        for (;;) {
+            if (T == 0) { do round(std::integral_constant<int, 0>{}); while (__builtin_amdgcn_ballot_w64(L.st < ST_DONE) != 0); }
+            else if (T == 1) { do round(std::integral_constant<int, 1>{}); while (__builtin_amdgcn_ballot_w64(L.st < ST_DONE) != 0); }
+            else { do round(std::integral_constant<int, 2>{}); while (__builtin_amdgcn_ballot_w64(L.st < ST_DONE) != 0); }
+            if (__builtin_amdgcn_ballot_w64(L.st == ST_PASSWAIT) == 0) break;
+            if (L.st == ST_PASSWAIT) lane_next_pass(L);
+            T = T == 2 ? 0u : T + 1u;
         }
-        step();
-        if (__builtin_amdgcn_ballot_w64(L.st != ST_DONE) == 0) break;
+    } else {
+        do round(std::integral_constant<int, -1>{}); while (__builtin_amdgcn_ballot_w64(L.st < ST_DONE) != 0);
     }
-#endif
 }
 
 template <bool IRREV>
 __global__ __launch_bounds__(64) void t1_recon_kernel(T1LaneArgs a)
 {
     const uint32_t blk = a.list[blockIdx.x];
+    if (blk == kT1NoBlock) return;                 // (a spare lane of a lane-decoder wave)
     const HtDecBlock in = a.table[blk];
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
     const uint32_t numbps = in.missing_msbs & 0xFFu, numpasses = in.missing_msbs >> 8;
@@ -136,7 +133,8 @@ __global__ __launch_bounds__(64) void t1_recon_kernel(T1LaneArgs a)
 hipError_t launch_t1_lanes(const T1LaneArgs& a, hipStream_t s)
 {
     if (!a.count) return hipSuccess;
-    hipLaunchKernelGGL(t1_lanes_kernel, dim3((a.count + 63u) / 64u), dim3(64), 0, s, a);
+    if (a.pass_sync) hipLaunchKernelGGL(t1_lanes_kernel<true>, dim3((a.count + 63u) / 64u), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_lanes_kernel<false>, dim3((a.count + 63u) / 64u), dim3(64), 0, s, a);
     if (a.irreversible) hipLaunchKernelGGL(t1_recon_kernel<true>, dim3(a.count), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(t1_recon_kernel<false>, dim3(a.count), dim3(64), 0, s, a);
     return hipGetLastError();

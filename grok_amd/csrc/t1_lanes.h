@@ -38,7 +38,8 @@ namespace t1l {
 
 // ---- lane modes ------------------------------------------------------------------------------------------------------
 enum : uint32_t { ST_ZC = 0, ST_SC = 1, ST_MR = 2, ST_AGG = 3, ST_UNI1 = 4, ST_UNI2 = 5,     // one MQ decision this iteration
-                  ST_NEEDCOL = 6, ST_NEEDSTRIPE = 7, ST_WAIT = 8, ST_DONE = 9 };
+                  ST_NEEDCOL = 6, ST_NEEDSTRIPE = 7, ST_WAIT = 8, ST_DONE = 9,
+                  ST_PASSWAIT = 10 };      // the lane's pass is complete: it waits for the wave's other lanes (pass-synchronous waves)
 
 // ---- LDS tables of a wave (byte offsets into one LDS block) ---------------------------------------------------------------
 // ctxrow [19][64] dwords: context cx of lane l at cx * 256 + l * 4
@@ -222,9 +223,17 @@ T1L_FN void lane_init(Lane& L, const BlockIn& b)
     L.st = ST_WAIT;              // lane_stripe_enter makes the stripe's masks
 }
 
+// The pass type (0 sig-prop, 1 mag-ref, 2 cleanup) is a TEMPLATE parameter of the pass-dependent steps: a wave's lanes run
+// their passes in step (a lane that has finished a pass waits for the others, ST_PASSWAIT), so the kernel runs one specialised
+// copy of the loop per pass type and the code of the other two types is not there to be executed (T < 0: the lane's own
+// L.type at run time -- the simulator's free-running mode).
+template <int T> T1L_FN uint32_t pass_type(const Lane& L) { return T < 0 ? L.type : (uint32_t)T; }
+
 // ---- stripe enter: the rows are in the registers (loaded, or zero in the first pass); masks of candidate columns ----
+template <int T>
 T1L_FN void lane_stripe_enter(Lane& L)
 {
+    const uint32_t type = pass_type<T>(L);
     if (L.s + 1u == L.ns || L.fresh) { L.S[5] = 0; L.N[5] = 0; }
     L.nr = umin(4u, L.h - 4u * L.s);
     T1L_UNROLL
@@ -233,37 +242,51 @@ T1L_FN void lane_stripe_enter(Lane& L)
     const uint64_t D = U | (U << 1) | (U >> 1);
     const uint64_t coded = (L.S[1] | L.P[0]) & (L.S[2] | L.P[1]) & (L.S[3] | L.P[2]) & (L.S[4] | L.P[3]);
     uint64_t cm;
-    if (L.type == 0) cm = D & ~coded;                                                         // near something significant, not all coded
-    else if (L.type == 1) cm = (L.S[1] & ~L.P[0]) | (L.S[2] & ~L.P[1]) | (L.S[3] & ~L.P[2]) | (L.S[4] & ~L.P[3]);
+    if (type == 0) cm = D & ~coded;                                                         // near something significant, not all coded
+    else if (type == 1) cm = (L.S[1] & ~L.P[0]) | (L.S[2] & ~L.P[1]) | (L.S[3] & ~L.P[2]) | (L.S[4] & ~L.P[3]);
     else cm = ~coded;
     L.cm = cm & L.wmask;
-    L.Q = (L.type == 2 && L.nr == 4u) ? ~D & ~(L.P[0] | L.P[1] | L.P[2] | L.P[3]) : 0ull;
-    if (L.type == 1) { L.R[0] = 0; L.R[1] = 0; L.R[2] = 0; L.R[3] = 0; }
+    L.Q = (type == 2 && L.nr == 4u) ? ~D & ~(L.P[0] | L.P[1] | L.P[2] | L.P[3]) : 0ull;
+    if (type == 1) { L.R[0] = 0; L.R[1] = 0; L.R[2] = 0; L.R[3] = 0; }
     L.st = ST_NEEDCOL;
 }
 
-// ---- stripe exit: store the stripe, move on (next stripe / next pass / done), issue the next stripe's loads ----------------
-// Returns with st = ST_WAIT (rows requested: lane_stripe_enter two iterations later) or ST_DONE.
+// ---- the next pass of the block (or none): bookkeeping, the first stripe's rows requested --------------------------------------
+T1L_FN void lane_next_pass(Lane& L)
+{
+    L.fresh = 0;
+    L.np_left -= 1u;
+    if (++L.type == 3u) { L.type = 0; L.bp -= 1; L.pidx += 1u; }
+    if (L.np_left == 0u || L.bp < 1) { L.st = ST_DONE; return; }
+    L.S[0] = 0; L.N[0] = 0;
+    L.s = 0;
+    const uint64_t* const np = L.work;
+    T1L_UNROLL
+    for (int r = 0; r < 4; ++r) { L.S[r + 1] = np[r]; L.N[r + 1] = np[4 + r]; L.P[r] = np[8 + r]; L.M[r] = np[12 + r]; }
+    if (1u < L.ns) { L.S[5] = np[16]; L.N[5] = np[20]; }
+    L.st = ST_WAIT;
+}
+
+// ---- stripe exit: store the stripe; the next stripe's loads, or the end of the pass ----------------------------------------
+// Returns with st = ST_WAIT (rows requested: lane_stripe_enter two steps later), ST_PASSWAIT (SYNC: the wave moves on to the
+// next pass together, lane_next_pass) or, free-running, whatever lane_next_pass leaves.
+template <int T, bool SYNC>
 T1L_FN void lane_stripe_exit(Lane& L)
 {
+    const uint32_t type = pass_type<T>(L);
     uint64_t* const sp = L.work + L.s * 16u;
-    if (L.type == 2) { L.P[0] = 0; L.P[1] = 0; L.P[2] = 0; L.P[3] = 0; }         // the plane is complete (T1.cpp: pi cleared)
+    if (type == 2) { L.P[0] = 0; L.P[1] = 0; L.P[2] = 0; L.P[3] = 0; }         // the plane is complete (T1.cpp: pi cleared)
     T1L_UNROLL
     for (int r = 0; r < 4; ++r) { sp[r] = L.S[r + 1]; sp[4 + r] = L.N[r + 1]; sp[8 + r] = L.P[r]; sp[12 + r] = L.M[r]; }
     uint64_t* const pl = L.work + kPlaneBase + L.pidx * kPlaneU64 + 4u * L.s;
-    if (L.type == 1) { for (int r = 0; r < 4; ++r) pl[64 + r] = L.R[r]; }
-    else             { for (int r = 0; r < 4; ++r) pl[r] = L.S[r + 1]; }
-    // next stripe-pass
-    uint32_t s = L.s + 1u;
+    if (type == 1) { T1L_UNROLL for (int r = 0; r < 4; ++r) pl[64 + r] = L.R[r]; }
+    else           { T1L_UNROLL for (int r = 0; r < 4; ++r) pl[r] = L.S[r + 1]; }
+    const uint32_t s = L.s + 1u;
     if (s == L.ns) {
-        s = 0; L.fresh = 0;
-        L.np_left -= 1u;
-        if (++L.type == 3u) { L.type = 0; L.bp -= 1; L.pidx += 1u; }
-        if (L.np_left == 0u || L.bp < 1) { L.st = ST_DONE; return; }
-        L.S[0] = 0; L.N[0] = 0;
-    } else {
-        L.S[0] = L.S[4]; L.N[0] = L.N[4];                 // the row above the next stripe: this stripe's last, as it is now
+        if (SYNC) L.st = ST_PASSWAIT; else lane_next_pass(L);
+        return;
     }
+    L.S[0] = L.S[4]; L.N[0] = L.N[4];                     // the row above the next stripe: this stripe's last, as it is now
     L.s = s;
     if (L.fresh) {
         T1L_UNROLL
@@ -320,13 +343,15 @@ T1L_FN void scatter1(uint64_t (&rows)[NROWS], uint32_t m, uint64_t bx)
 }
 
 // ---- column enter: the next candidate column of the stripe, its neighbourhood words, the first sample to code --------------
+template <int T>
 T1L_FN void lane_column_enter(Lane& L)
 {
+    const uint32_t type = pass_type<T>(L);
     if (L.cm == 0) { L.st = ST_NEEDSTRIPE; return; }
     const uint32_t x = ctz64(L.cm);
     const uint64_t bx = 1ull << x;
     L.cm &= ~bx; L.x = x; L.bx = bx;
-    if (L.Q & bx) {                                   // run-length mode (D.3.4): nothing significant around, nothing coded
+    if (type == 2 && (L.Q & bx)) {                    // run-length mode (D.3.4): nothing significant around, nothing coded
         L.nbx = 0; L.nnx = 0; L.pv = 0; L.todo = 0; L.st = ST_AGG;
         return;
     }
@@ -335,12 +360,12 @@ T1L_FN void lane_column_enter(Lane& L)
     L.nbx = nbx; L.pv = pv;
     const uint32_t sig4 = (nbx >> 4) & 0x249u;
     uint32_t todo;
-    if (L.type == 1) {
+    if (type == 1) {
         L.mv = extract1(L.M, x); L.rf = 0;
         todo = sig4 & ~pv;
     } else {
         L.nnx = extract3(L.N, x);
-        if (L.type == 0) {
+        if (type == 0) {
             const uint32_t rowany = nbx | (nbx >> 1) | (nbx >> 2);      // bit 3r: anything in row r's window
             const uint32_t sides = nbx | (nbx >> 2);                    // bit 3r: left or right of row r
             todo = (rowany | (sides >> 3) | (rowany >> 6)) & ~(sig4 | pv) & 0x249u;
@@ -348,35 +373,30 @@ T1L_FN void lane_column_enter(Lane& L)
     }
     if (todo == 0) return;                            // (sig-prop: the column mask is a superset) -- next column next iteration
     L.t = ctz32(todo); L.todo = todo & (todo - 1u);
-    L.st = L.type == 1 ? ST_MR : ST_ZC;
+    L.st = type == 1 ? ST_MR : ST_ZC;
 }
 
 // the column is finished: its new bits go back into the stripe's rows
+template <int T>
 T1L_FN void lane_column_exit(Lane& L)
 {
-    // (every array addressed on every path: a pointer chosen by the pass type would keep the rows out of registers)
-    const bool mr = L.type == 1;
-    scatter1<0>(L.M, mr ? L.mv : 0u, L.bx);
-    scatter1<0>(L.R, mr ? L.rf : 0u, L.bx);
-    scatter1<1>(L.S, mr ? 0u : (L.nbx >> 4) & 0x249u, L.bx);
-    scatter1<1>(L.N, mr ? 0u : (L.nnx >> 4) & 0x249u, L.bx);
-    scatter1<0>(L.P, L.type == 0 ? L.pv & 0x249u : 0u, L.bx);
+    if (T < 0) {
+        // (every array addressed on every path: a pointer chosen by the pass type would keep the rows out of registers)
+        const bool mr = L.type == 1;
+        scatter1<0>(L.M, mr ? L.mv : 0u, L.bx);
+        scatter1<0>(L.R, mr ? L.rf : 0u, L.bx);
+        scatter1<1>(L.S, mr ? 0u : (L.nbx >> 4) & 0x249u, L.bx);
+        scatter1<1>(L.N, mr ? 0u : (L.nnx >> 4) & 0x249u, L.bx);
+        scatter1<0>(L.P, L.type == 0 ? L.pv & 0x249u : 0u, L.bx);
+    } else if (T == 1) {
+        scatter1<0>(L.M, L.mv, L.bx);
+        scatter1<0>(L.R, L.rf, L.bx);
+    } else {
+        scatter1<1>(L.S, (L.nbx >> 4) & 0x249u, L.bx);
+        scatter1<1>(L.N, (L.nnx >> 4) & 0x249u, L.bx);
+        if (T == 0) scatter1<0>(L.P, L.pv & 0x249u, L.bx);
+    }
     L.st = ST_NEEDCOL;
-}
-
-// ---- which context the lane's decision uses: the LDS byte offset of its ctxrow row, via the look-up tables --------------
-// (lds16: the wave's LDS block as uint16_t[]; returns the offset of context row; sets L.xr for sign decisions)
-T1L_FN uint32_t lane_context(Lane& L, const uint16_t* lds16)
-{
-    const uint32_t nb = L.nbx >> L.t, nn = L.nnx >> L.t;
-    uint32_t off;
-    if (L.st == ST_ZC) off = lds16[(L.zcbase >> 1) + (nb & 0x1FFu)];
-    else if (L.st == ST_SC) {
-        const uint32_t e = lds16[(kOffSc >> 1) + (((nb & 0xAAu) >> 1) | (nn & 0xAAu))];
-        L.xr = e & 1u; off = e & ~1u;
-    } else if (L.st == ST_MR) off = ((L.mv >> L.t) & 1u) ? 16u * 256u : ((nb & 0x1EFu) ? 15u * 256u : 14u * 256u);
-    else off = L.st == ST_AGG ? 17u * 256u : 18u * 256u;
-    return off;
 }
 
 // ---- one MQ decision (mqc_dec_inl.h DECODE / RENORMD / BYTEIN).  lds32: the wave's LDS block as dwords ------------------------
@@ -413,61 +433,43 @@ T1L_FN uint32_t lane_mq_decode(Lane& L, uint32_t* lds32, uint32_t ctx_dword)
     return d;
 }
 
-// ---- what the decision means: the pass logic (T1.cpp:854-1255) ------------------------------------------------------------------
-T1L_FN void lane_apply(Lane& L, uint32_t d)
+// ---- which context the lane's decision uses and what the decision means (T1.cpp:854-1255), without branches: selects on
+// the lane's mode -- every lane of a wave runs every path anyway.  lds16: the wave's LDS block as uint16_t[].
+template <int T>
+T1L_FN uint32_t lane_context(Lane& L, const uint16_t* lds16)
 {
-    bool advance = false;
-    if (L.st == ST_ZC) {
-        if (d) L.st = ST_SC;
-        else { if (L.type == 0) L.pv |= 1u << L.t; advance = true; }
-    } else if (L.st == ST_SC) {
-        const uint32_t neg = d ^ L.xr;
-        L.nbx |= 16u << L.t; L.nnx |= (neg << 4) << L.t;
-        if (L.type == 0) {
-            L.pv |= 1u << L.t;
-            // the sample below now has a significant neighbour: a candidate of this pass unless significant or coded already
-            L.todo |= (8u << L.t) & ~(((L.nbx >> 4) | L.pv)) & 0x249u;
-            L.cm |= (L.bx << 1) & L.wmask;             // ... and so has the column to the right
-        } else L.Q &= ~(L.bx << 1);                    // cleanup: the column to the right is no longer quiet
-        advance = true;
-    } else if (L.st == ST_MR) {
-        L.rf |= d << L.t; L.mv |= 1u << L.t; advance = true;
-    } else if (L.st == ST_AGG) {
-        if (d) L.st = ST_UNI1; else L.st = ST_NEEDCOL;          // (a quiet column that stays quiet: nothing to write back)
-    } else if (L.st == ST_UNI1) { L.r = d; L.st = ST_UNI2; }
-    else {                                                      // ST_UNI2: the first significant sample of the column, sign only
-        const uint32_t r = L.r * 2u + d;
-        L.t = 3u * r; L.todo = 0x249u & ~((2u << L.t) - 1u); L.st = ST_SC;
-    }
-    if (advance) {
-        if (L.todo) { L.t = ctz32(L.todo); L.todo &= L.todo - 1u; L.st = L.type == 1 ? ST_MR : ST_ZC; }
-        else lane_column_exit(L);
-    }
-}
-
-// ---- the same two steps without branches (selects on the lane's mode): every lane of a wave runs every path anyway ---------
-T1L_FN uint32_t lane_context_sel(Lane& L, const uint16_t* lds16)
-{
-    const uint32_t nb = L.nbx >> L.t, nn = L.nnx >> L.t;
+    const uint32_t nb = L.nbx >> L.t;
+    if (T == 1) return ((L.mv >> L.t) & 1u) ? 16u * 256u : ((nb & 0x1EFu) ? 15u * 256u : 14u * 256u);      // Table D.4
+    const uint32_t nn = L.nnx >> L.t;
     const bool isSC = L.st == ST_SC;
     const uint32_t zi = (L.zcbase >> 1) + (nb & 0x1FFu);
     const uint32_t si = (kOffSc >> 1) + (((nb & 0xAAu) >> 1) | (nn & 0xAAu));
     const uint32_t e = lds16[isSC ? si : zi];                         // one look-up for both kinds (others: a harmless read)
     L.xr = isSC ? (e & 1u) : L.xr;
+    if (T == 0) return e & ~1u;                                       // sig-prop: zero coding or sign, nothing else
     const uint32_t mr = ((L.mv >> L.t) & 1u) ? 16u * 256u : ((nb & 0x1EFu) ? 15u * 256u : 14u * 256u);
     uint32_t off = L.st == ST_AGG ? 17u * 256u : 18u * 256u;
-    off = L.st == ST_MR ? mr : off;
+    if (T < 0) off = L.st == ST_MR ? mr : off;
     off = L.st <= ST_SC ? (e & ~1u) : off;
     return off;
 }
 
-T1L_FN void lane_apply_sel(Lane& L, uint32_t d)
+template <int T>
+T1L_FN void lane_apply(Lane& L, uint32_t d)
 {
     const uint32_t st = L.st, t = L.t;
-    const bool isZC = st == ST_ZC, isSC = st == ST_SC, isMR = st == ST_MR, isAGG = st == ST_AGG, isU1 = st == ST_UNI1, isU2 = st == ST_UNI2;
-    const bool sp = L.type == 0, mrp = L.type == 1;
-    const bool one = d != 0;
     const uint32_t bit = 1u << t;
+    if (T == 1) {                                                     // mag-ref: the bit, then the column's next sample
+        L.rf |= d << t; L.mv |= bit;
+        const uint32_t todo = L.todo;
+        if (todo) { L.t = ctz32(todo); L.todo = todo & (todo - 1u); }
+        else lane_column_exit<T>(L);
+        return;
+    }
+    const bool isZC = st == ST_ZC, isSC = st == ST_SC, isMR = T < 0 && st == ST_MR;
+    const bool isAGG = T != 0 && st == ST_AGG, isU1 = T != 0 && st == ST_UNI1, isU2 = T != 0 && st == ST_UNI2;
+    const bool sp = pass_type<T>(L) == 0, mrp = T < 0 && L.type == 1;
+    const bool one = d != 0;
     // visited (sig-prop: every sample the pass looks at)
     L.pv |= (sp && (isSC || (isZC && !one))) ? bit : 0u;
     // a sample turns significant: sign decoded
@@ -476,11 +478,10 @@ T1L_FN void lane_apply_sel(Lane& L, uint32_t d)
     L.nnx |= (isSC && neg) ? bit << 4 : 0u;
     uint32_t todo = L.todo | ((isSC && sp) ? ((bit << 3) & ~((L.nbx >> 4) | L.pv) & 0x249u) : 0u);
     const uint64_t bx1 = L.bx << 1;
-    L.cm |= (isSC && sp) ? (bx1 & L.wmask) : 0ull;
-    L.Q &= (isSC && !sp) ? ~bx1 : ~0ull;
-    // refinement
-    L.rf |= isMR ? d << t : 0u;
-    L.mv |= isMR ? bit : 0u;
+    if (T <= 0) L.cm |= (isSC && sp) ? (bx1 & L.wmask) : 0ull;
+    if (T != 0) L.Q &= (isSC && !sp) ? ~bx1 : ~0ull;
+    // refinement (free-running mode only: the specialised mag-ref pass is above)
+    if (T < 0) { L.rf |= isMR ? d << t : 0u; L.mv |= isMR ? bit : 0u; }
     // run-length position
     const uint32_t r2 = L.r * 2u + d, t2 = r2 * 3u;
     L.r = isU1 ? d : L.r;
@@ -497,7 +498,7 @@ T1L_FN void lane_apply_sel(Lane& L, uint32_t d)
     L.t = (adv && more) ? tn : (isU2 ? t2 : t);
     L.todo = (adv && more) ? todon : (isU2 ? (0x249u & ~((2u << t2) - 1u)) : todo);
     L.st = nst;
-    if (adv && !more) lane_column_exit(L);
+    if (adv && !more) lane_column_exit<T>(L);
 }
 
 // ---- reconstruction of one sample from the planes a block left (t1_recon_kernel; the values T1 keeps in its data array) --------

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include <cstdio>
+#include <type_traits>
 
 using namespace t1l;
 
@@ -29,7 +30,7 @@ int t1l_sim_decode(const uint8_t* coded, uint64_t coded_bytes, uint32_t nblocks,
     const uint32_t kslots_max = std::getenv("T1L_KMAX") ? (uint32_t)std::atoi(std::getenv("T1L_KMAX")) : 1u;
     const uint32_t kslots_min = std::getenv("T1L_KMIN") ? (uint32_t)std::atoi(std::getenv("T1L_KMIN")) : 1u;
     const uint32_t frac_pct = std::getenv("T1L_FRAC") ? (uint32_t)std::atoi(std::getenv("T1L_FRAC")) : 0u;
-    const bool branchy = std::getenv("T1L_BRANCHY") != nullptr;        // the two forms of the decision step (t1_lanes.h)
+    const bool free_running = std::getenv("T1L_FREE") != nullptr;      // lanes at their own pace instead of pass by pass
     uint64_t slots_total = 0;
     uint64_t it_total = 0, dec_total = 0, idle_total = 0, it_max = 0;
     for (uint32_t base = 0; base < nblocks; base += 64) {
@@ -49,43 +50,61 @@ int t1l_sim_decode(const uint8_t* coded, uint64_t coded_bytes, uint32_t nblocks,
             for (uint32_t cx = 0; cx < 19; ++cx) lds32[cx * 64 + l] = mq_entry(cx == 18 ? 46u : cx == 17 ? 3u : cx == 0 ? 4u : 0u);
         }
         uint64_t it = 0;
-        for (;; ++it) {
-            const uint32_t phase = (uint32_t)it & 3u;
-            if (phase == 0) {
-                for (uint32_t l = 0; l < 64; ++l) {
-                    if (L[l].st == ST_NEEDSTRIPE) lane_stripe_exit(L[l]);
-                    if (lane_wants_bytes(L[l])) lane_fetch_issue(L[l]);
-                }
-            } else if (phase == 2) {
-                for (uint32_t l = 0; l < 64; ++l) {
-                    if (L[l].st == ST_WAIT) lane_stripe_enter(L[l]);
-                    if (L[l].pend) lane_fetch_arrive(L[l]);
-                }
-            }
-            bool all_done = true;
-            for (uint32_t l = 0; l < 64; ++l) if (L[l].st == ST_NEEDCOL) lane_column_enter(L[l]);
-            // decision slots of this iteration: policy from the environment (experiments): K fixed slots, or while at least
-            // `frac` of the lanes that can decode still have a decision in their column
+        // one step of every lane: column enter where needed, then the decision slots of this step (policy: experiments)
+        auto steps = [&](auto TT) {
+            constexpr int T = decltype(TT)::value;
+            for (uint32_t l = 0; l < 64; ++l) if (L[l].st == ST_NEEDCOL) lane_column_enter<T>(L[l]);
             for (uint32_t slot = 0;; ++slot) {
                 uint32_t can = 0, live = 0;
-                for (uint32_t l = 0; l < 64; ++l) { if (L[l].st != ST_DONE) ++live; if (L[l].st <= ST_UNI2 && L[l].nv >= 3u) ++can; }
+                for (uint32_t l = 0; l < 64; ++l) { if (L[l].st < ST_DONE) ++live; if (L[l].st <= ST_UNI2 && L[l].nv >= 3u) ++can; }
                 if (slot >= kslots_max) break;
                 if (slot >= kslots_min && can * 100u < live * frac_pct) break;
                 if (can == 0) break;
                 ++slots_total;
                 for (uint32_t l = 0; l < 64; ++l) {
                     if (L[l].st <= ST_UNI2 && L[l].nv >= 3u) {
-                        const uint32_t off = branchy ? lane_context(L[l], lds16) : lane_context_sel(L[l], lds16);
+                        const uint32_t off = lane_context<T>(L[l], lds16);
                         const uint32_t d = lane_mq_decode(L[l], lds32, (off >> 2) + l);
                         if (trace && l == 0) std::fprintf(trace, "%u %u\n", off >> 8, d);
-                        if (branchy) lane_apply(L[l], d); else lane_apply_sel(L[l], d);
+                        lane_apply<T>(L[l], d);
                         ++dec_total;
-                    } else if (L[l].st != ST_DONE) ++idle_total;
+                    } else if (L[l].st < ST_DONE) ++idle_total;
                 }
             }
-            for (uint32_t l = 0; l < 64; ++l) if (L[l].st != ST_DONE) all_done = false;
-            if (all_done) break;
-            if (it > 4000000) return -1;
+            ++it;
+        };
+        // a round = four steps, stripes stored / requested before the first, delivered before the third (kernels_t1lanes.hip)
+        auto round = [&](auto TT, auto SS) {
+            constexpr int T = decltype(TT)::value;
+            constexpr bool SYNC = decltype(SS)::value;
+            for (uint32_t l = 0; l < 64; ++l) {
+                if (L[l].st == ST_NEEDSTRIPE) lane_stripe_exit<T, SYNC>(L[l]);
+                if (lane_wants_bytes(L[l])) lane_fetch_issue(L[l]);
+            }
+            steps(TT); steps(TT);
+            for (uint32_t l = 0; l < 64; ++l) {
+                if (L[l].st == ST_WAIT) lane_stripe_enter<T>(L[l]);
+                if (L[l].pend) lane_fetch_arrive(L[l]);
+            }
+            steps(TT); steps(TT);
+        };
+        auto active = [&]() { for (uint32_t l = 0; l < 64; ++l) if (L[l].st < ST_DONE) return true; return false; };
+        if (free_running) {                       // every lane at its own pace through its passes (the lane's own L.type)
+            while (active()) { round(std::integral_constant<int, -1>{}, std::false_type{}); if (it > 4000000) return -1; }
+        } else {                                  // the kernel's form: the wave's lanes go from pass to pass together
+            uint32_t T = 2;
+            for (;;) {
+                while (active()) {
+                    if (T == 0) round(std::integral_constant<int, 0>{}, std::true_type{});
+                    else if (T == 1) round(std::integral_constant<int, 1>{}, std::true_type{});
+                    else round(std::integral_constant<int, 2>{}, std::true_type{});
+                    if (it > 4000000) return -1;
+                }
+                bool any = false;
+                for (uint32_t l = 0; l < 64; ++l) if (L[l].st == ST_PASSWAIT) { lane_next_pass(L[l]); any = true; }
+                if (!any) break;
+                T = (T + 1u) % 3u;
+            }
         }
         it_total += it; if (it > it_max) it_max = it;
         // reconstruction
