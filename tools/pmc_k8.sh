@@ -10,6 +10,7 @@ f = glob.glob("/tmp/pk8/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    if "t1_dec_kernel" in k: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for c, v in sorted(acc.items()): print("t1_dec_kernel %-24s mean %16.1f  (%d launches)" % (c, sum(v) / len(v), len(v)))
+    for fam in ("t1_dec_kernel", "t1_lanes_kernel", "t1_recon_kernel"):
+        if fam in k: acc[(fam, r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (f, c), v in sorted(acc.items()): print("%-16s %-24s mean %16.1f  (%d launches)" % (f, c, sum(v) / len(v), len(v)))
 PY
