@@ -1282,9 +1282,10 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
                          void* pixels, int pixels_on_device)
 {
     if (c && !c->dec_kids.empty() && coded_on_device && pixels_on_device) {
-        const uint32_t turn = c->dec_seq++ % (uint32_t)(c->dec_kids.size() + 1);
-        if (turn) {
-            grk_amd_ctx* k = c->dec_kids[turn - 1];
+        {
+            // (every frame of the sequence on one of the internal contexts, none on this one: the event below must stand for what the
+            //  CALLER queued on this context's stream, not for an earlier frame of the sequence)
+            grk_amd_ctx* k = c->dec_kids[c->dec_seq++ % (uint32_t)c->dec_kids.size()];
             // what the caller set on the context applies to the frame wherever it is decoded
             if (k->dec_qcd != c->dec_qcd || k->dec_steps != c->dec_steps) { k->dec_qcd = c->dec_qcd; k->dec_steps = c->dec_steps; k->have_geom = false; }
             if (k->dec_seg_first != c->dec_seg_first) k->dec_seg_first = c->dec_seg_first;
@@ -1314,7 +1315,7 @@ int grk_amd_set_decode_pipelining(grk_amd_ctx* c, int frames_in_flight)
     c->dec_seq = 0;
     if (rc) return rc;
     if (frames_in_flight >= 2 && !c->ev_seq) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_seq, hipEventDisableTiming), "create event");
-    for (int i = 1; i < frames_in_flight; ++i) {
+    for (int i = 0; i < frames_in_flight && frames_in_flight >= 2; ++i) {
         grk_amd_ctx* k = nullptr;
         rc = grk_amd_create(c->device, c->verbose, &k);
         if (rc) return fail(c, rc, "a further decode context could not be made");
