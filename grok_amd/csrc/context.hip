@@ -838,8 +838,11 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
             std::vector<uint32_t> cnt(kKeys, 0u), at(kKeys, 0u);
             for (uint32_t i : lane) cnt[key(i)]++;
             uint32_t out = 0;
+            // (a group that would fill only a few waves runs them from pass to pass half empty, and with more passes than the
+            //  bulk it is the kernel's last wave to finish: groups below 0.5 % of the lane blocks go to K8 as well)
+            const uint32_t min_group = std::max<uint32_t>(64u, n_lane / 200u);
             for (uint32_t k = kKeys; k-- > 0;) {                              // (more passes first: the longest-running waves start first)
-                if (cnt[k] < 64u) { at[k] = kT1NoBlock; continue; }
+                if (cnt[k] < min_group) { at[k] = kT1NoBlock; continue; }
                 at[k] = out;
                 out += (cnt[k] + 63u) & ~63u;
             }

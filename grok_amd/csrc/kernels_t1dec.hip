@@ -266,6 +266,131 @@ __device__ __forceinline__ uint32_t win3(uint64_t s, uint32_t x)
 // dequantises and stores the block's rows itself at the end (r02's separate store kernel read the workspace once more).
 // (Measured and not kept in r03: the same int16 values in LDS, 8 KB per block -- no workspace traffic at all, but 15 instead of
 //  32 waves per CU: the scalar unit this kernel is bound by then idles, 45 -> 61 ms.)
+// ---- a dense mag-ref stripe's 4 w decisions in ONE context, hand-scheduled on the scalar unit (r04) -------------------------
+// The chains of a frame's longest blocks (the LL band: 15 of 17 bit-planes are nothing but such stripes) set the frame's decode
+// time at (instructions per decision) x ~8.5 cycles; the compiler's form of MqDec::decode_run is ~45 instructions per decision,
+// this one ~28: DECODE with the LPS / MPS exchange as two s_cselect pairs, the table row of the next state by v_readlane,
+// RENORMD by s_flbit + whole shifts, BYTEIN out of an 8-byte scalar window refilled by s_load_dword (four bytes at a time,
+// bytes past the segment's end as 0xFF: the reference's artificial terminator).  State in / out: a, c, ct, the context's
+// state index / MPS / table row; bits: four 64-bit rows (row j: decisions of the stripe's row j, bit x).
+struct DenseRun {
+    uint32_t a, c, ct, idx, mps, row;          // MQ registers, context 16's state
+    uint32_t wlo, whi, nv;                     // stream window: byte k of the next nv bytes (4 < nv <= 8) at bits 8 k
+    uint32_t foff, flen;                       // offset of the next dword to fetch from fbase; the segment's end on the same scale
+    uint32_t used;                             // bytes consumed (advance of MqDec::pos)
+    const uint8_t* fbase;                      // dword-aligned
+    uint64_t b0, b1, b2, b3;
+};
+
+#define T1_DENSE_DECISION(J, BJ)                                                                                        \
+    "s_sub_u32 %[a], %[a], %[qe]\n\t"                                                                                   \
+    "s_cmp_lt_u32 %[c], %[qe16]\n\t"                                                                                    \
+    "s_cbranch_scc1 Llps" J "_%=\n\t"                                                                                   \
+    "s_sub_u32 %[c], %[c], %[qe16]\n\t"                                                                                 \
+    "s_bitcmp1_b32 %[a], 15\n\t"                                                                                        \
+    "s_cbranch_scc1 Lplain" J "_%=\n\t"                                                                                 \
+    "s_cmp_lt_u32 %[a], %[qe]\n\t"                       /* MPS path, renormalising: conditional exchange */          \
+    "s_cselect_b32 %[sh], 22, 16\n\t"                                                                                   \
+    "s_cselect_b32 %[fl], 1, 0\n\t"                                                                                     \
+    "s_branch Lupd" J "_%=\n"                                                                                           \
+    "Llps" J "_%=:\n\t"                                                                                                 \
+    "s_cmp_lt_u32 %[a], %[qe]\n\t"                                                                                      \
+    "s_cselect_b32 %[sh], 16, 22\n\t"                                                                                   \
+    "s_cselect_b32 %[fl], 0, 1\n\t"                                                                                     \
+    "s_mov_b32 %[a], %[qe]\n"                                                                                           \
+    "Lupd" J "_%=:\n\t"                                                                                                 \
+    "s_xor_b32 %[d], %[mps], %[fl]\n\t"                  /* the decision */                                            \
+    "s_lshr_b32 %[t], %[row], 28\n\t"                                                                                   \
+    "s_and_b32 %[t], %[t], %[fl]\n\t"                                                                                   \
+    "s_xor_b32 %[mps], %[mps], %[t]\n\t"                 /* SWITCH */                                                  \
+    "s_lshr_b32 %[t], %[row], %[sh]\n\t"                                                                                \
+    "s_and_b32 %[idx], %[t], 63\n\t"                                                                                    \
+    "s_nop 3\n\t"                                                                                                       \
+    "v_readlane_b32 %[row], %[tab], %[idx]\n\t"                                                                         \
+    "s_flbit_i32_b32 %[n], %[a]\n\t"                                                                                    \
+    "s_sub_u32 %[n], %[n], 16\n\t"                                                                                      \
+    "s_lshl_b32 %[a], %[a], %[n]\n\t"                                                                                   \
+    "s_and_b32 %[qe], %[row], 0xffff\n\t"                                                                               \
+    "s_lshl_b32 %[qe16], %[qe], 16\n"                                                                                   \
+    "Lshift" J "_%=:\n\t"                                                                                               \
+    "s_min_u32 %[sh], %[n], %[ct]\n\t"                                                                                  \
+    "s_lshl_b32 %[c], %[c], %[sh]\n\t"                                                                                  \
+    "s_sub_u32 %[ct], %[ct], %[sh]\n\t"                                                                                 \
+    "s_sub_u32 %[n], %[n], %[sh]\n\t"                                                                                   \
+    "s_cmp_eq_u32 %[n], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 Lrec" J "_%=\n\t"                                                                                   \
+    /* BYTEIN (ct == 0): cur = byte 0 of the window, nxt = byte 1 */                                                   \
+    "s_and_b32 %[t], %[wlo], 0xff\n\t"                                                                                  \
+    "s_bfe_u32 %[fl], %[wlo], 0x80008\n\t"                                                                              \
+    "s_cmp_eq_u32 %[t], 0xff\n\t"                                                                                       \
+    "s_cbranch_scc1 Lff" J "_%=\n\t"                                                                                    \
+    "s_lshl_b32 %[fl], %[fl], 8\n\t"                                                                                    \
+    "s_add_u32 %[c], %[c], %[fl]\n\t"                                                                                   \
+    "s_mov_b32 %[ct], 8\n\t"                                                                                            \
+    "s_branch Ladv" J "_%=\n"                                                                                           \
+    "Lff" J "_%=:\n\t"                                                                                                  \
+    "s_cmp_gt_u32 %[fl], 0x8f\n\t"                                                                                      \
+    "s_cbranch_scc1 Lmark" J "_%=\n\t"                                                                                  \
+    "s_lshl_b32 %[fl], %[fl], 9\n\t"                                                                                    \
+    "s_add_u32 %[c], %[c], %[fl]\n\t"                                                                                   \
+    "s_mov_b32 %[ct], 7\n"                                                                                              \
+    "Ladv" J "_%=:\n\t"                                   /* one byte consumed */                                       \
+    "s_lshr_b32 %[wlo], %[wlo], 8\n\t"                                                                                  \
+    "s_lshl_b32 %[t], %[whi], 24\n\t"                                                                                   \
+    "s_or_b32 %[wlo], %[wlo], %[t]\n\t"                                                                                 \
+    "s_lshr_b32 %[whi], %[whi], 8\n\t"                                                                                  \
+    "s_add_u32 %[used], %[used], 1\n\t"                                                                                 \
+    "s_sub_u32 %[nv], %[nv], 1\n\t"                                                                                     \
+    "s_cmp_lg_u32 %[nv], 4\n\t"                                                                                         \
+    "s_cbranch_scc1 Lshift" J "_%=\n\t"                                                                                 \
+    /* four more bytes: the dword at fbase + foff; bytes at or past flen read as 0xFF */                               \
+    "s_mov_b32 %[whi], -1\n\t"                                                                                          \
+    "s_cmp_ge_u32 %[foff], %[flen]\n\t"                                                                                 \
+    "s_cbranch_scc1 Lfed" J "_%=\n\t"                                                                                   \
+    "s_load_dword %[whi], %[fbase], %[foff]\n\t"                                                                        \
+    "s_sub_u32 %[t], %[flen], %[foff]\n\t"               /* bytes of it inside the segment: 1 .. */                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
+    "s_cmp_ge_u32 %[t], 4\n\t"                                                                                          \
+    "s_cbranch_scc1 Lfed" J "_%=\n\t"                                                                                   \
+    "s_lshl_b32 %[t], %[t], 3\n\t"                                                                                      \
+    "s_lshl_b32 %[t], -1, %[t]\n\t"                                                                                     \
+    "s_or_b32 %[whi], %[whi], %[t]\n"                                                                                   \
+    "Lfed" J "_%=:\n\t"                                                                                                 \
+    "s_add_u32 %[foff], %[foff], 4\n\t"                                                                                 \
+    "s_mov_b32 %[nv], 8\n\t"                                                                                            \
+    "s_branch Lshift" J "_%=\n"                                                                                         \
+    "Lmark" J "_%=:\n\t"                                  /* 0xFF then > 0x8F: a marker -- ones for ever, nothing consumed */ \
+    "s_add_u32 %[c], %[c], 0xff00\n\t"                                                                                  \
+    "s_mov_b32 %[ct], 8\n\t"                                                                                            \
+    "s_branch Lshift" J "_%=\n"                                                                                         \
+    "Lplain" J "_%=:\n\t"                                                                                               \
+    "s_mov_b32 %[d], %[mps]\n"                                                                                          \
+    "Lrec" J "_%=:\n\t"                                                                                                 \
+    "s_lshl_b32 %[t], %[d], %[xs]\n\t"                                                                                  \
+    "s_or_b32 " BJ ", " BJ ", %[t]\n\t"
+
+// 32 columns (or fewer) of a stripe: bits of row j into the low / high half picked by the caller (xs = x & 31)
+__device__ __forceinline__ void dense_run_half(DenseRun& r, uint32_t tabv, uint32_t ncols, uint32_t& h0, uint32_t& h1, uint32_t& h2, uint32_t& h3)
+{
+    uint32_t qe = r.row & 0xFFFFu, qe16 = qe << 16, sh, fl, d, t, n, xs = 0;
+    asm volatile(
+        "Lcol_%=:\n\t"
+        T1_DENSE_DECISION("0", "%[h0]")
+        T1_DENSE_DECISION("1", "%[h1]")
+        T1_DENSE_DECISION("2", "%[h2]")
+        T1_DENSE_DECISION("3", "%[h3]")
+        "s_add_u32 %[xs], %[xs], 1\n\t"
+        "s_cmp_lt_u32 %[xs], %[ncols]\n\t"
+        "s_cbranch_scc1 Lcol_%=\n\t"
+        : [a] "+s"(r.a), [c] "+s"(r.c), [ct] "+s"(r.ct), [idx] "+s"(r.idx), [mps] "+s"(r.mps), [row] "+s"(r.row),
+          [wlo] "+s"(r.wlo), [whi] "+s"(r.whi), [nv] "+s"(r.nv), [foff] "+s"(r.foff), [used] "+s"(r.used),
+          [h0] "+s"(h0), [h1] "+s"(h1), [h2] "+s"(h2), [h3] "+s"(h3),
+          [qe] "+s"(qe), [qe16] "+s"(qe16), [xs] "+s"(xs),
+          [sh] "=&s"(sh), [fl] "=&s"(fl), [d] "=&s"(d), [t] "=&s"(t), [n] "=&s"(n)
+        : [tab] "v"(tabv), [ncols] "s"(ncols), [flen] "s"(r.flen), [fbase] "s"(r.fbase)
+        : "scc", "memory");
+}
+
 constexpr uint32_t kNarrowPlanes = 14;
 
 template <bool IRREV>
@@ -278,6 +403,8 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     const bool writer = threadIdx.x == 0;
     const uint32_t blk = a.list ? a.list[blockIdx.x] : blockIdx.x;
     if (blk >= a.nblocks) return;
+    // beside the lane decoder this kernel holds the frame's longest chains: its waves win the issue arbitration of their SIMDs
+    if (a.list) __builtin_amdgcn_s_setprio(3);
     const HtDecBlock in = a.table[blk];
     const HtBlockDesc bd = a.blocks[blk % a.blocks_per_tile];
     const uint32_t w = bd.w, h = bd.h;
@@ -437,14 +564,44 @@ __global__ void t1_dec_kernel(T1DecArgs a)
                 if (dense) {
                     uint64_t rb0 = 0, rb1 = 0, rb2 = 0, rb3 = 0;
                     uint32_t st = mq.ctx_get(16), row = mq.tab_get(st & 0x7Fu);
-                    uint32_t sa = MqDec::uni(mq.a), sc = MqDec::uni(mq.c), sct = MqDec::uni(mq.ct);
-                    for (uint32_t x = 0; x < w; ++x) {
-                        rb0 |= (uint64_t)mq.decode_run(sa, sc, sct, st, row) << x;
-                        rb1 |= (uint64_t)mq.decode_run(sa, sc, sct, st, row) << x;
-                        rb2 |= (uint64_t)mq.decode_run(sa, sc, sct, st, row) << x;
-                        rb3 |= (uint64_t)mq.decode_run(sa, sc, sct, st, row) << x;
+                    // the scalar window reads whole dwords: the segment's last one must lie inside the coded buffer
+                    const uint8_t* const seg_end4 = reinterpret_cast<const uint8_t*>((reinterpret_cast<uintptr_t>(mq.d + mq.len) + 3u) & ~(uintptr_t)3u);
+                    if (seg_end4 <= mq.hi && mq.d >= mq.lo) {
+                        DenseRun r;
+                        r.a = MqDec::uni(mq.a); r.c = MqDec::uni(mq.c); r.ct = MqDec::uni(mq.ct);
+                        r.idx = st & 0x7Fu; r.mps = st >> 7; r.row = row;
+                        // bytes pos .. pos + nv - 1 into the window, nv such that the next fetch is dword-aligned
+                        const uint32_t skew = (uint32_t)(reinterpret_cast<uintptr_t>(mq.d) & 3u);
+                        const uint32_t p0 = mq.pos;
+                        r.nv = 8u - ((p0 + skew) & 3u);                       // 5 .. 8
+                        uint32_t wl = 0, wh = 0;
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) {
+                            const uint32_t bk = k < r.nv ? MqDec::uni(mq.byte_at(p0 + k)) : 0u;
+                            if (k < 4) wl |= bk << (8u * k); else wh |= bk << (8u * (k - 4u));
+                        }
+                        r.wlo = wl; r.whi = wh;
+                        r.fbase = mq.d - skew;                                // dword-aligned
+                        r.foff = p0 + skew + r.nv;                            // (a multiple of four)
+                        r.flen = mq.len + skew;
+                        r.used = 0;
+                        uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+                        dense_run_half(r, mq.tabv, w < 32u ? w : 32u, l0, l1, l2, l3);
+                        if (w > 32u) dense_run_half(r, mq.tabv, w - 32u, u0, u1, u2, u3);
+                        rb0 = l0 | ((uint64_t)u0 << 32); rb1 = l1 | ((uint64_t)u1 << 32);
+                        rb2 = l2 | ((uint64_t)u2 << 32); rb3 = l3 | ((uint64_t)u3 << 32);
+                        mq.a = r.a; mq.c = r.c; mq.ct = r.ct; mq.pos = p0 + r.used;
+                        st = r.idx | (r.mps << 7);
+                    } else {
+                        uint32_t sa = MqDec::uni(mq.a), sc = MqDec::uni(mq.c), sct = MqDec::uni(mq.ct);
+                        for (uint32_t x = 0; x < w; ++x) {
+                            rb0 |= (uint64_t)mq.decode_run(sa, sc, sct, st, row) << x;
+                            rb1 |= (uint64_t)mq.decode_run(sa, sc, sct, st, row) << x;
+                            rb2 |= (uint64_t)mq.decode_run(sa, sc, sct, st, row) << x;
+                            rb3 |= (uint64_t)mq.decode_run(sa, sc, sct, st, row) << x;
+                        }
+                        mq.a = sa; mq.c = sc; mq.ct = sct;
                     }
-                    mq.a = sa; mq.c = sc; mq.ct = sct;
                     mq.ctx_set(16, st);
                     const uint64_t rbs[4] = {rb0, rb1, rb2, rb3};
 #pragma unroll

@@ -8,11 +8,15 @@
 //   t1_lanes_kernel  -- lanes = blocks of `list` (sorted by coded length, longest first: a wave's lanes finish together).
 //                       Wave-uniform loop, at most one MQ decision per lane and iteration; a block's state between stripes
 //                       and its per-plane result bitmaps live in its 16 KB of `work`.
-//   t1_recon_kernel  -- one wave per block of `list`, lanes = columns: significance / refinement bitmaps -> coefficients,
+//   t1_recon_kernel  -- one wave per block of `list`: rows of the bitmaps loaded lane-per-row, then lanes = columns: significance / refinement bitmaps -> coefficients,
 //                       dequantised (ShiftFilter / ScaleFilter, filters/PostDecompressFilters.h:26-35, :60-71) into the Mallat plane.
 #include "kernels.h"
 #include "t1_lanes.h"
 #include <type_traits>
+
+#ifndef T1L_ROUND_STEPS
+#define T1L_ROUND_STEPS 4        // steps between two stripe hand-overs (4, 6 or 8: fewer hand-over passes, lanes wait longer for theirs)
+#endif
 
 namespace grk_amd {
 
@@ -83,9 +87,18 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
         if (L.st == ST_NEEDSTRIPE) lane_stripe_exit<T, SYNC>(L);
         if (lane_wants_bytes(L)) lane_fetch_issue(L);
         step(); step();
+#if T1L_ROUND_STEPS >= 6
+        step();
+#endif
         if (L.st == ST_WAIT) lane_stripe_enter<T>(L);
         if (L.pend) lane_fetch_arrive(L);
         step(); step();
+#if T1L_ROUND_STEPS >= 6
+        step();
+#endif
+#if T1L_ROUND_STEPS >= 8
+        step(); step();
+#endif
     };
     if constexpr (SYNC) {
         uint32_t T = 2;                            // every block starts with the cleanup pass of its top plane
@@ -102,6 +115,9 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
     }
 }
 
+// One wave per block.  Lane y first loads ROW y of every bitmap the block left (coalesced 512-byte loads, all in flight at once:
+// the sign rows and, per bit-plane, the significance rows at the end of the plane and the mag-ref bits); then the wave goes through
+// the rows, lane x taking bit x of each row's words as they are broadcast from lane y (v_readlane) -- no memory access on the chain.
 template <bool IRREV>
 __global__ __launch_bounds__(64) void t1_recon_kernel(T1LaneArgs a)
 {
@@ -115,12 +131,37 @@ __global__ __launch_bounds__(64) void t1_recon_kernel(T1LaneArgs a)
     const uint32_t tile = blk / a.blocks_per_tile;
     int32_t* const dst = a.mallat + ((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px;
     const float scale = bd.inv_step / 2;
+    // planes with a pass: plane i has one iff 1 + 3 (i - 1) < numpasses (i = 0: the first cleanup); at most kMaxPlanes
+    uint32_t nplanes = 0;
+    for (uint32_t i = 0; i < numbps && i < kMaxPlanes && (i == 0 || 3u * i - 2u < numpasses); ++i) nplanes = i + 1u;
+    uint64_t snap[kMaxPlanes], ref[kMaxPlanes];
+    const uint64_t neg = wk[(x >> 2) * 16u + 4u + (x & 3u)];
+#pragma unroll
+    for (uint32_t i = 0; i < kMaxPlanes; ++i) {
+        snap[i] = i < nplanes ? wk[kPlaneBase + i * kPlaneU64 + x] : 0ull;
+        ref[i] = i < nplanes ? wk[kPlaneBase + i * kPlaneU64 + 64u + x] : 0ull;
+    }
+    auto row_bit = [&](uint64_t v, uint32_t y) -> bool {           // bit x of lane y's word
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)y);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)y);
+        return (((x < 32u ? lo : hi) >> (x & 31u)) & 1u) != 0;
+    };
     for (uint32_t y = 0; y < bd.h; ++y) {
-        auto snap = [&](uint32_t i) { return ((wk[kPlaneBase + i * kPlaneU64 + y] >> x) & 1u) != 0; };
-        auto ref = [&](uint32_t i) { return ((wk[kPlaneBase + i * kPlaneU64 + 64u + y] >> x) & 1u) != 0; };
-        const uint32_t mag = recon_magnitude(numbps, numpasses, snap, ref);
-        const bool neg = ((wk[(y >> 2) * 16u + 4u + (y & 3u)] >> x) & 1u) != 0;
-        const int32_t v = neg ? -(int32_t)mag : (int32_t)mag;
+        uint32_t mag = 0; bool prev = false;
+#pragma unroll
+        for (uint32_t i = 0; i < kMaxPlanes; ++i) {
+            if (i < nplanes) {                                       // (uniform)
+                const uint32_t p = numbps - i;
+                const bool cur = row_bit(snap[i], y);
+                const bool rb = row_bit(ref[i], y);
+                const bool mr_ran = 3u * i <= numpasses && i > 0;
+                const uint32_t half = 1u << (p - 1u);
+                mag = (cur && !prev) ? 3u << (p - 1u) : ((prev && mr_ran) ? (rb ? mag + half : mag - half) : mag);
+                prev = cur;
+            }
+        }
+        const bool ng = row_bit(neg, y);
+        const int32_t v = ng ? -(int32_t)mag : (int32_t)mag;
         int32_t o;
         if constexpr (IRREV) o = __float_as_int(__fmul_rn((float)v, scale));
         else o = v / 2;
