@@ -332,8 +332,14 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
     constexpr uint32_t EB = H16 ? 2u : 4u;         // bytes per coefficient
+#ifdef GRK_WHATIF_NO_TOP_BAND_TRAFFIC      // what-if build: every block codes coefficients out of ONE block row of the top HH band
+    const HtBlockDesc bw = a.blocks[a.blocks_per_tile - 1u - (lb & 63u)];        // (64 blocks, 512 KB: resident in L2)
+    const char* src = reinterpret_cast<const char*>(a.mallat) +
+                      (((size_t)tile * a.ncomp + bw.comp) * a.pitch + (size_t)bw.py * a.stride + bw.px) * EB;
+#else
     const char* src = reinterpret_cast<const char*>(a.mallat) +
                       (((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px) * EB;
+#endif
     const bool full = w == 64 && h == 64 && ((bd.px | a.stride) & 1u) == 0;   // aligned row-pair loads, no edges
     const uint32_t kmax = bd.kmax;
     const bool narrow = kmax + 2 <= 16;           // a quad's four MagSgn values fit 64 bits
