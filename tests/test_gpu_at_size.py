@@ -172,6 +172,14 @@ def test_16k_single_tile_round_trip_and_strip_checksums():
     assert torch.equal(back, d)
     coded = np.empty(tot, np.uint8)
     G.lib().grk_amd_fetch_coded(c._h, coded.ctypes.data, tot)
+    # the whole file against the reference's own encoder on the same 16384 x 16384 single tile (the size
+    # was covered by properties only) -- every one of the 196 608 blocks, Tier-2 and headers, byte for byte
+    if R.have_ref():
+        R.lib(threads=os.cpu_count() or 1)
+        want, _ = R.encode(px, 8, numres=6, mode=1)
+        cs = G.write_codestream(p, S, S, table, coded)
+        assert len(cs) == len(want) and hashlib.md5(cs).hexdigest() == hashlib.md5(want).hexdigest()
+        del want, cs
     # the same corner as its own 4096^2 tile
     small = np.ascontiguousarray(px[:, :4096, :4096])
     p4 = G.TileParams.make(4096, 4096, 3, 8, 5)
@@ -207,3 +215,12 @@ def test_32k_single_tile_round_trip():
     c.decode_device(p, 1, table, c.coded_device_ptr(), tot, back.data_ptr())
     c.decode_status()
     assert torch.equal(back, d)
+    # ... and the whole file against the reference's encoder on the same single tile (786 432 blocks, ~0.4 GB of codestream)
+    if R.have_ref() and os.environ.get("GRK_AMD_SKIP_32K_REF") != "1":
+        coded = np.empty(tot, np.uint8)
+        G.lib().grk_amd_fetch_coded(c._h, coded.ctypes.data, tot)
+        px = d.cpu().numpy().reshape(3, S, S)
+        R.lib(threads=os.cpu_count() or 1)
+        want, _ = R.encode(px, 8, numres=6, mode=1)
+        cs = G.write_codestream(p, S, S, table, coded)
+        assert len(cs) == len(want) and hashlib.md5(cs).hexdigest() == hashlib.md5(want).hexdigest()
