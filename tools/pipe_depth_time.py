@@ -3,7 +3,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, grok_amd as G, synth
-S = 8192
+S = int(os.environ.get("PD_SIZE", "8192"))
 px = synth.g2(3, S, S, 8)
 p = G.TileParams.make(S, S, 3, 8, 5)
 ctx = G.Context(0)
