@@ -123,3 +123,27 @@ def test_c_host_of_the_node_api_compiles_and_fails_loudly_without_a_gpu(tmp_path
         assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
     else:
         assert r.returncode == 3 and "no device" in r.stdout, r.stdout + r.stderr
+
+
+def _build_rccl_host_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "rccl_host_example")
+    libdir = os.path.dirname(G.lib_path())
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "rccl_host_example.cpp"), "-o", exe, "-L" + libdir, "-lgrok_amd",
+                           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_native_rccl_host_compiles_and_fails_loudly_without_a_gpu(tmp_path):
+    """INTEGRATION.md 5c's native host -- one process per GPU, the C ABI + RCCL (ncclAllGather of the byte counts, exact-size
+    ncclSend / ncclRecv of the tile-parts to a rotating writer) -- is real code: it compiles and links here; with a GPU it runs
+    its one-rank form (tests/test_gpu_node.py), without one it says so."""
+    import subprocess
+    import torch
+    exe = _build_rccl_host_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "no device" in r.stdout, r.stdout + r.stderr

@@ -88,3 +88,14 @@ def test_c_host_example_over_two_contexts(tmp_path):
     exe = _build_node_example(tmp_path)
     r = subprocess.run([exe, "0", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "devices 2" in r.stdout and "identical" in r.stdout, r.stdout + r.stderr
+
+
+def test_native_rccl_host_one_rank(tmp_path):
+    """tests/c/rccl_host_example.cpp (C ABI + RCCL, one process per GPU) as the single rank a one-GPU box can
+    run: five pipelined frames, counts all-gathered on the device, the gather to the writer, Tier-2 over the gathered tables --
+    frame 0's codestream == the one a single context writes for the image."""
+    import subprocess
+    from test_capi_host import _build_rccl_host_example
+    exe = _build_rccl_host_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ranks 1" in r.stdout and "identical" in r.stdout, r.stdout + r.stderr
