@@ -145,7 +145,7 @@ struct grk_amd_ctx {
     hipEvent_t ev_dec_front = nullptr, ev_dec_top = nullptr;
     bool dec_top_pending = false;
     // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
-    // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
+    // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; 2: lanes wherever they can be used; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
     // Decode of a SEQUENCE of frames (grk_amd_set_decode_pipelining): consecutive grk_amd_decode_tiles calls with device buffers
     // go in turn to this context and to `dec_kids` -- contexts of their own on the same device: own streams, tables, planes --,
     // each behind an event on the caller's stream.  A frame's serial block-decoding chains (K5a / K8) leave most of the machine
@@ -153,7 +153,7 @@ struct grk_amd_ctx {
     std::vector<grk_amd_ctx*> dec_kids;
     uint32_t dec_seq = 0;
     hipEvent_t ev_seq = nullptr;
-    bool t1_lanes = true;
+    int t1_lanes = 1;                    // 0: never, 1: where the cost model below says they are faster, 2: wherever they can (tests)
     float t1_tail_ratio = 0.25f;
     float t1_tail_share = 0.0f;          // ... and at least this share of the blocks (the longest ones) to K8 as well
     bool t1_pass_sync = true;            // K8L's waves hold blocks of equal bit-plane / pass counts and run pass by pass (GRK_AMD_T1_SYNC=0: free-running lanes)
@@ -853,6 +853,20 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
             }
             n_lane = out;
         }
+        if (n_lane >= 64u) {
+            // Is the lane form the faster one for THIS call?  A lane's chain advances at ~10 ns per coded byte (0.85 us per step, ~10
+            // decisions per byte, ~30 % of the steps idle), a wave's at ~2.5 ns per byte, and K8's throughput with every SIMD full is
+            // ~0.9 ns per byte (r03: 55 MB in 48 ms): a small image -- fewer blocks than K8 has wave slots -- is done sooner by K8
+            // alone, in the time of its longest block.
+            uint64_t bytes_all = 0, bytes_tail = 0;
+            uint32_t max_lane = 0, max_tail = 0;
+            for (uint64_t i = 0; i < nblocks; ++i) bytes_all += table[i].length;
+            for (uint32_t j = 0; j < n_lane; ++j) if (h_lane[j] != kT1NoBlock) max_lane = std::max(max_lane, table[h_lane[j]].length);
+            for (uint32_t j = 0; j < n_tail; ++j) { bytes_tail += table[h_tail[j]].length; max_tail = std::max(max_tail, table[h_tail[j]].length); }
+            const double t_k8 = std::max(2.5e-9 * max_len, 0.9e-9 * (double)bytes_all);
+            const double t_mix = std::max(std::max(10.0e-9 * max_lane, 2.5e-9 * max_tail), 0.9e-9 * (double)bytes_tail);
+            if (t_k8 <= t_mix && c->t1_lanes != 2) n_lane = 0;
+        }
         if (n_lane < 64u) { n_lane = 0; n_tail = 0; }                   // not worth a second launch: K8 in table order
     }
     { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock) + nblocks * 12); if (rc) return rc; }
@@ -1027,7 +1041,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         if (const char* ex = getenv("GRK_AMD_DWT_PK")) c->dwt_pk = atoi(ex) != 0;
         if (const char* ed = getenv("GRK_AMD_DEC_PLANES16")) c->dec_planes16 = atoi(ed) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
-        if (const char* et = getenv("GRK_AMD_T1_LANES")) c->t1_lanes = atoi(et) != 0;
+        if (const char* et = getenv("GRK_AMD_T1_LANES")) c->t1_lanes = atoi(et);
         if (const char* er = getenv("GRK_AMD_T1_TAIL_RATIO")) c->t1_tail_ratio = (float)atof(er);
         if (const char* es = getenv("GRK_AMD_T1_TAIL_SHARE")) c->t1_tail_share = (float)atof(es);
         if (const char* ey = getenv("GRK_AMD_T1_SYNC")) c->t1_pass_sync = atoi(ey) != 0;

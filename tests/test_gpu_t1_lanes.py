@@ -62,7 +62,9 @@ def test_lane_decoder_equals_oracle_on_every_block_shape(W, H, L, bits, keep_few
     assert max(groups.values()) >= 64, "the case must reach the lane decoder"
     d_c = U.to_dev(np.frombuffer(coded, np.uint8))
     outs = {}
-    for name, env in (("lanes", {}), ("free", {"GRK_AMD_T1_SYNC": "0"}), ("waves", {"GRK_AMD_T1_LANES": "0"})):
+    # (GRK_AMD_T1_LANES=2: the lane decoder wherever it can be used -- by default a call this small goes to the wave decoder alone)
+    for name, env in (("lanes", {"GRK_AMD_T1_LANES": "2"}), ("free", {"GRK_AMD_T1_LANES": "2", "GRK_AMD_T1_SYNC": "0"}),
+                      ("waves", {"GRK_AMD_T1_LANES": "0"}), ("auto", {})):
         c = _ctx_with(env)
         d_m = U.dev_planes(p, 1)
         c.stage_ht_decode(p, 1, table, d_c.data_ptr(), d_c.numel(), d_m.data_ptr())
@@ -77,7 +79,7 @@ def test_lane_decoder_equals_oracle_on_every_block_shape(W, H, L, bits, keep_few
 def test_lane_decoder_irreversible_scale():
     rng = np.random.default_rng(3)
     p, blocks, table, coded, want = _tile(rng, 960, 448, 1, 6, 12, 0, irrev=True)
-    c = U.ctx()
+    c = _ctx_with({"GRK_AMD_T1_LANES": "2"})
     c.set_decode_qcd([])
     d_c = U.to_dev(np.frombuffer(coded, np.uint8))
     d_m = U.dev_planes(p, 1)
