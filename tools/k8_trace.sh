@@ -11,6 +11,8 @@ import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
     if any(k in n for k in ("t1_", "idwt", "dec_upload")):
-        short = n.split("::")[-1].split("(")[0]
+        import re
+        m = re.search(r"(t1_\w+|idwt\w+|dec_upload_kernel)(<[^>]*>)?", n)
+        short = (m.group(1) + (m.group(2) or "")) if m else n[:34]
         print("%-34s calls %4s  avg %10.3f ms  min %10.3f  max %10.3f" % (short, r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6))
 PY
