@@ -360,10 +360,39 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
             got = d_out.cpu().numpy().view(np.uint16).reshape(3, S, S)
             k8, k6 = ctx.kernel_ms(5)[0], ctx.kernel_ms(6)[0]
             ctx.enable_timing(False)
+            # a SEQUENCE of such frames through the one context, several in flight (grk_amd_set_decode_pipelining): the later frames'
+            # lane waves and long chains run beside the first's -- chain-bound kernels leave most of the machine's issue slots free.
+            # (three and more frames overlap only with more than the HIP runtime's default 4 hardware queues: grok_amd asks for 8,
+            #  profiles/r04_hw_queues.txt)
+            seq5 = {"hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")}
+            outs5 = [d_out]
+            try:
+                for nfl in (2, 6):
+                    while len(outs5) < nfl:
+                        outs5.append(torch.zeros_like(d_out))
+                    ctx.set_decode_pipelining(nfl)
+                    for k in range(2 * nfl):
+                        ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), outs5[k % nfl].data_ptr())
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                    for k in range(3 * nfl):
+                        ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), outs5[k % nfl].data_ptr())
+                    ctx.synchronize()
+                    msn = (time.perf_counter() - t0) / (3 * nfl) * 1e3
+                    ctx.decode_status()
+                    seq5[str(nfl)] = {"frames_in_flight": nfl, "ms_per_frame": round(msn, 3), "value": round(S * S / msn / 1e3, 1), "unit": "Mpixels/s",
+                                      "pixels_equal_grk_decompress": all(bool(np.array_equal(
+                                          o.cpu().numpy().view(np.uint16).reshape(3, S, S).astype(np.int32), ref5)) for o in (outs5[0], outs5[nfl - 1]))}
+            except Exception as e:      # noqa: BLE001
+                seq5["error"] = str(e)
+            finally:
+                ctx.set_decode_pipelining(0)
+                del outs5
             samples = 3.0 * S * S
             out["cfg5"] = {"workload": "8192x8192x3 12-bit decode, Part-1 EBCOT + ICT + 9/7 stream written by grk_compress (BASELINE configs[4])",
                            "ms_per_step": round(ms, 3), "value": round(S * S / ms / 1e3, 1), "unit": "Mpixels/s", "dtype": "f32",
                            "coded_bytes": int(len(data)), "pixels_equal_grk_decompress": bool(np.array_equal(got.astype(np.int32), ref5)),
+                           "sequence_mode": seq5,
                            "kernels": {"t1_ebcot_decode": {"avg_ms": round(k8, 3), "algorithmic_bytes": int(4 * samples + len(data)),
                                                            "algorithmic_GBps": rate(4 * samples + len(data), k8)[0],
                                                            "frac": rate(4 * samples + len(data), k8)[1],

@@ -21,6 +21,14 @@ using namespace grk_amd;
 
 namespace {
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says otherwise),
+// and kernels of two streams that share a queue run one after the other.  A decode sequence with three or more frames in
+// flight (grk_amd_set_decode_pipelining) has two streams of long kernels per frame: on 4 queues it gains nothing over two
+// frames, on 8 the Part-1 sequence goes from 10.2 to 7.2 ms per frame (profiles/r04_hw_queues.txt; encode is indifferent).
+// The runtime reads the variable when it initialises, so this only helps a host that loads the library before its first HIP
+// call (Grok loading the plugin; `import grok_amd` before the first torch.cuda call); a value the user has set is left alone.
+__attribute__((constructor)) void ask_for_hardware_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -1325,7 +1333,7 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
 
 int grk_amd_set_decode_pipelining(grk_amd_ctx* c, int frames_in_flight)
 {
-    if (!c || frames_in_flight < 0 || frames_in_flight > 4) return GRK_AMD_ERR_INVALID;
+    if (!c || frames_in_flight < 0 || frames_in_flight > 8) return GRK_AMD_ERR_INVALID;
     int rc = grk_amd_synchronize(c);
     for (grk_amd_ctx* k : c->dec_kids) grk_amd_destroy(k);
     c->dec_kids.clear();

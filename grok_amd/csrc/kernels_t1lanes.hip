@@ -41,6 +41,8 @@ __device__ const LaneTables g_lane_tables{};
 
 // SYNC: the wave's lanes run their passes in step, one specialised copy of the loop per pass type (t1_lanes.h) -- the host puts
 // blocks with the same number of bit-planes and passes into a wave.  !SYNC: every lane at its own pace, one general loop.
+// (188 vector registers, two waves per SIMD.  A version with packed lane state -- 124 / 154 registers -- was measured and lost
+//  15 % to the extra instructions: profiles/r04_hw_queues.txt; the limit of a decode sequence was the hardware queues.)
 template <bool SYNC>
 __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
 {

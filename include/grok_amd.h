@@ -187,7 +187,7 @@ int grk_amd_decode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes,
                          int coded_on_device, void* pixels, int pixels_on_device);
 int grk_amd_decode_status(grk_amd_ctx* ctx);
-/* A SEQUENCE of frames: with frames_in_flight = n in 2..4, consecutive grk_amd_decode_tiles calls whose coded bytes and pixels
+/* A SEQUENCE of frames: with frames_in_flight = n in 2..8, consecutive grk_amd_decode_tiles calls whose coded bytes and pixels
  * are device buffers are decoded on n internal buffer / stream sets in turn, each queued behind what the caller has on the
  * context's stream at the time of the call, so that frame f + 1's block decoding (serial chains that leave most of the GPU
  * idle) runs beside frame f's dequantisation and inverse transform.  The reference decodes a frame's tiles as pooled tasks
