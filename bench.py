@@ -297,6 +297,57 @@ def _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, de
     return w
 
 
+def cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, flights):
+    """ms per frame of the cfg5 (Part-1) stream decoded as a SEQUENCE through one context, by frames in flight; every figure
+    with the first and the last output buffer compared to grk_decompress's pixels."""
+    res = {}
+    outs = []
+    try:
+        for nfl in flights:
+            while len(outs) < nfl:
+                outs.append(torch.zeros(3 * S * S, dtype=torch.int16, device=dev))
+            ctx.set_decode_pipelining(nfl)
+            for k in range(2 * nfl):
+                ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), outs[k % nfl].data_ptr())
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for k in range(3 * nfl):
+                ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), outs[k % nfl].data_ptr())
+            ctx.synchronize()
+            msn = (time.perf_counter() - t0) / (3 * nfl) * 1e3
+            ctx.decode_status()
+            res[str(nfl)] = {"frames_in_flight": nfl, "ms_per_frame": round(msn, 3), "value": round(S * S / msn / 1e3, 1), "unit": "Mpixels/s",
+                             "pixels_equal_grk_decompress": all(bool(np.array_equal(
+                                 o.cpu().numpy().view(np.uint16).reshape(3, S, S).astype(np.int32), ref5)) for o in (outs[0], outs[nfl - 1]))}
+    except Exception as e:      # noqa: BLE001
+        res["error"] = str(e)
+    finally:
+        ctx.set_decode_pipelining(0)
+    return res
+
+
+def cfg5_sequence_child(fcs, fref, S, device):
+    """`bench.py --cfg5-sequence <codestream> <reference pixels .npy> <S> <device>`: the child process of the cfg5 leg (started with
+    GPU_MAX_HW_QUEUES=8 in its environment); prints one JSON object."""
+    import j2kparse as J
+    with open(fcs, "rb") as fh:
+        cs5 = fh.read()
+    ref5 = np.load(fref)
+    dev = torch.device("cuda", device)
+    torch.cuda.set_device(dev)
+    info = J.parse(cs5)
+    p5 = G.TileParams.make(S, S, 3, 12, info["levels"], irreversible=True, mct=True, part1=True)
+    blocks, _ = G.tile_layout(p5)
+    rows, data = J.decode_table(info, blocks, True)
+    table = np.array(rows, dtype=G.capi.CODED_DTYPE)
+    ctx = G.Context(device)
+    ctx.set_decode_qcd([(e << 11) | m for e, m in info["qcd"]])
+    d_c = torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(dev)
+    res = cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, (2, 3, 6))
+    res["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
+    print(json.dumps(res))
+
+
 def extra_workloads(ctx, dev, stream, steps, cfg5):
     """The other BASELINE configurations on the same GPU, a few steps each: cfg2, cfg3 with its
     9/7 DWT family against the HBM roofline (north_star's >= 40 % target), the cfg4 tiling and the whole cfg4 image (256
@@ -362,32 +413,28 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
             ctx.enable_timing(False)
             # a SEQUENCE of such frames through the one context, several in flight (grk_amd_set_decode_pipelining): the later frames'
             # lane waves and long chains run beside the first's -- chain-bound kernels leave most of the machine's issue slots free.
-            # (three and more frames overlap only with more than the HIP runtime's default 4 hardware queues: grok_amd asks for 8,
-            #  profiles/r04_hw_queues.txt)
-            seq5 = {"hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")}
-            outs5 = [d_out]
+            # Two in flight here; three and more overlap only with more than the HIP runtime's default 4 hardware queues, which
+            # is a process-wide setting read at the runtime's start (and one the encode-over-RCCL path does not like): that
+            # figure is measured by a child process of this one with GPU_MAX_HW_QUEUES=8 (profiles/r04_hw_queues.txt)
+            seq5 = cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, (2,))
+            seq5["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")
             try:
-                for nfl in (2, 6):
-                    while len(outs5) < nfl:
-                        outs5.append(torch.zeros_like(d_out))
-                    ctx.set_decode_pipelining(nfl)
-                    for k in range(2 * nfl):
-                        ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), outs5[k % nfl].data_ptr())
-                    ctx.synchronize()
-                    t0 = time.perf_counter()
-                    for k in range(3 * nfl):
-                        ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), outs5[k % nfl].data_ptr())
-                    ctx.synchronize()
-                    msn = (time.perf_counter() - t0) / (3 * nfl) * 1e3
-                    ctx.decode_status()
-                    seq5[str(nfl)] = {"frames_in_flight": nfl, "ms_per_frame": round(msn, 3), "value": round(S * S / msn / 1e3, 1), "unit": "Mpixels/s",
-                                      "pixels_equal_grk_decompress": all(bool(np.array_equal(
-                                          o.cpu().numpy().view(np.uint16).reshape(3, S, S).astype(np.int32), ref5)) for o in (outs5[0], outs5[nfl - 1]))}
+                import subprocess
+                import tempfile
+                with tempfile.TemporaryDirectory() as td:
+                    fcs, fref = os.path.join(td, "cfg5.j2k"), os.path.join(td, "cfg5_ref.npy")
+                    with open(fcs, "wb") as fh:
+                        fh.write(cs5)
+                    np.save(fref, ref5)
+                    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+                    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "GROK_AMD_FORCE_DIST"):
+                        env.pop(k, None)
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cfg5-sequence", fcs, fref, str(S), str(dev.index or 0)],
+                                       env=env, capture_output=True, text=True, timeout=300)
+                    seq5["child_process_GPU_MAX_HW_QUEUES_8"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else \
+                        {"error": (r.stderr or r.stdout)[-300:]}
             except Exception as e:      # noqa: BLE001
-                seq5["error"] = str(e)
-            finally:
-                ctx.set_decode_pipelining(0)
-                del outs5
+                seq5["child_process_GPU_MAX_HW_QUEUES_8"] = {"error": str(e)}
             samples = 3.0 * S * S
             out["cfg5"] = {"workload": "8192x8192x3 12-bit decode, Part-1 EBCOT + ICT + 9/7 stream written by grk_compress (BASELINE configs[4])",
                            "ms_per_step": round(ms, 3), "value": round(S * S / ms / 1e3, 1), "unit": "Mpixels/s", "dtype": "f32",
@@ -616,10 +663,15 @@ def main():
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="N > 1: seconds the gather regions may take before the line is printed without them (a transfer that "
                          "never completes must not cost the run its counts figure)")
+    ap.add_argument("--cfg5-sequence", nargs=4, metavar=("CODESTREAM", "REF_NPY", "S", "DEVICE"), default=None,
+                    help="(internal) child process of the cfg5 leg: the Part-1 stream as a sequence with 2, 3 and 6 frames in flight")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks meet over gloo, count each other at the barrier and rank 0 prints "
                          "a line with n_gpus = the ranks that really arrived; no kernels run")
     args = ap.parse_args()
+    if args.cfg5_sequence:
+        fcs, fref, S5, dv = args.cfg5_sequence
+        return cfg5_sequence_child(fcs, fref, int(S5), int(dv))
 
     # `python bench.py --gpus N` starts its N ranks ITSELF (the reference's analogue is its in-process tile pool,
     # codestream/CodeStreamCompress.cpp:535-603: one command, all workers); under a launcher (WORLD_SIZE set) it is one rank

@@ -5,10 +5,6 @@ host geometry / Tier-2) and the plugin shim grok_amd/lib/libgrokj2k_plugin.so.  
 package is only the ctypes binding used by bench.py and the tests; it never computes anything
 itself and raises loudly when the native library is missing.
 """
-import os as _os
-# (see ask_for_hardware_queues in csrc/context.hip: decode sequences of three and more frames want more than the HIP runtime's
-#  default 4 hardware queues; read by the runtime at its first call, a value already set wins)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from .capi import (TileParams, Block, CodedBlock, Context, lib, lib_path, NativeLibraryMissing,
                    tile_layout, write_codestream, write_tile_part, write_main_header, locate_tile_parts,
                    CS_TLM, CS_PLT, CS_SOP, CS_EPH, CS_PROG, ImageLayout, layout_tiles, same_tile_geometry, write_codestream_layout, Node, NODE_GATHER)

@@ -21,13 +21,12 @@ using namespace grk_amd;
 
 namespace {
 
-// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says otherwise),
-// and kernels of two streams that share a queue run one after the other.  A decode sequence with three or more frames in
-// flight (grk_amd_set_decode_pipelining) has two streams of long kernels per frame: on 4 queues it gains nothing over two
-// frames, on 8 the Part-1 sequence goes from 10.2 to 7.2 ms per frame (profiles/r04_hw_queues.txt; encode is indifferent).
-// The runtime reads the variable when it initialises, so this only helps a host that loads the library before its first HIP
-// call (Grok loading the plugin; `import grok_amd` before the first torch.cuda call); a value the user has set is left alone.
-__attribute__((constructor)) void ask_for_hardware_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (Streams and hardware queues: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless
+//  the variable says otherwise, and kernels of two streams that share a queue run one after the other.  A decode sequence with
+//  three or more frames in flight -- two streams of long kernels each -- gains nothing over two frames on 4 queues; on 8 the
+//  Part-1 sequence goes from 9.1 to 6.7 ms per frame.  It is the HOST's setting, process-wide and read when the runtime starts:
+//  the library does not touch it, because the encode pipeline beside an RCCL exchange was measured 25 % slower on anything but
+//  4 (profiles/r04_hw_queues.txt).)
 
 struct DevBuf {
     void* p = nullptr;
@@ -932,6 +931,7 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
 int check_decode_status(grk_amd_ctx* c)
 {
     uint32_t st = 0;
+    if (!c->flag.p) return GRK_AMD_OK;                 // nothing was decoded on this context (a sequence's frames are on its children)
     HIP_TRY(c, hipMemcpyAsync(&st, c->flag.p, 4, hipMemcpyDeviceToHost, c->stream), "fetch status");
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     if (st & 4u) return fail(c, GRK_AMD_ERR_INVALID, "corrupt HT code-block (bad Scup or U_q > missing_msbs)");

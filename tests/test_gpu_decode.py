@@ -853,3 +853,27 @@ def test_decode_sequence_mode_frames_in_flight():
     c.decode_device(p, 1, frames[3][1], frames[3][2].data_ptr(), frames[3][2].numel(), o.data_ptr())
     c.synchronize()
     assert np.array_equal(o.cpu().numpy().reshape(C, H, W), frames[3][0])
+
+
+def test_decode_sequence_on_a_context_that_did_nothing_else():
+    """A context whose FIRST use is a sequence (frames in flight set before any encode / decode on the context itself): every frame
+    runs on the internal sets, and grk_amd_decode_status has nothing of the context's own to fetch -- it reports the sets' status
+    (r04: it failed with "fetch status: invalid argument")."""
+    C, H, W, prec, L = 3, 128, 192, 8, 3
+    p = G.TileParams.make(W, H, C, prec, L)
+    enc = G.Context(0)
+    px = synth.g2(C, H, W, prec, seed=5)
+    table, coded = enc.encode_host(p, px)
+    d_c = U.to_dev(np.frombuffer(bytes(coded), np.uint8).copy())
+    c = G.Context(0)
+    c.set_decode_pipelining(3)
+    try:
+        outs = [torch.zeros(C * H * W, dtype=torch.uint8, device="cuda") for _ in range(4)]
+        for o in outs:
+            c.decode_device(p, 1, table, d_c.data_ptr(), d_c.numel(), o.data_ptr())
+        c.synchronize()
+        c.decode_status()
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy().reshape(C, H, W), px)
+    finally:
+        c.set_decode_pipelining(0)
