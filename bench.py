@@ -413,10 +413,11 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
             ctx.enable_timing(False)
             # a SEQUENCE of such frames through the one context, several in flight (grk_amd_set_decode_pipelining): the later frames'
             # lane waves and long chains run beside the first's -- chain-bound kernels leave most of the machine's issue slots free.
-            # Two in flight here; three and more overlap only with more than the HIP runtime's default 4 hardware queues, which
-            # is a process-wide setting read at the runtime's start (and one the encode-over-RCCL path does not like): that
-            # figure is measured by a child process of this one with GPU_MAX_HW_QUEUES=8 (profiles/r04_hw_queues.txt)
-            seq5 = cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, (2,))
+            # Two and six in flight here, on the HIP runtime's default 4 hardware queues and beside every other stream this process
+            # has made (streams that share a queue run in turn); the same in a child process of this one started with
+            # GPU_MAX_HW_QUEUES=8 -- process-wide, read at the runtime's start, and a setting the encode-over-RCCL path does not
+            # like, so it is the host's to make (profiles/r04_hw_queues.txt)
+            seq5 = cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, (2, 6))
             seq5["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")
             try:
                 import subprocess

@@ -1028,7 +1028,18 @@ extern "C" {
 
 const char* grk_amd_version(void) { return "grok_amd 0.1 (gfx950)"; }
 
-int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
+namespace {
+// decode_only: one of a decode sequence's internal contexts (grk_amd_set_decode_pipelining) -- the call's stream and ONE side
+// stream, nothing else: the HIP runtime deals its (default 4) hardware queues to streams in the order they are made, and two
+// frames in flight then sit on four queues of their own whatever else the process has made before (a third stream per context
+// that decoding never uses made frame 2's lane kernel share a queue with frame 1's long chains: 14.8 instead of 9.1 ms per frame)
+int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** out);
+}
+
+int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out) { return create_context(device_id, verbose, false, out); }
+
+namespace {
+int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** out)
 {
     if (!out) return GRK_AMD_ERR_INVALID;
     *out = nullptr;
@@ -1056,7 +1067,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
-            hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess ||
+            (!decode_only && hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess) ||
             hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
             !create_alt_events(c) ||
             hipEventCreateWithFlags(&c->ev_level0, hipEventDisableTiming) != hipSuccess ||
@@ -1067,6 +1078,7 @@ int grk_amd_create(int device_id, int verbose, grk_amd_ctx** out)
     *out = c;
     return GRK_AMD_OK;
 }
+} // namespace
 
 void grk_amd_destroy(grk_amd_ctx* c)
 {
@@ -1342,7 +1354,7 @@ int grk_amd_set_decode_pipelining(grk_amd_ctx* c, int frames_in_flight)
     if (frames_in_flight >= 2 && !c->ev_seq) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_seq, hipEventDisableTiming), "create event");
     for (int i = 0; i < frames_in_flight && frames_in_flight >= 2; ++i) {
         grk_amd_ctx* k = nullptr;
-        rc = grk_amd_create(c->device, c->verbose, &k);
+        rc = create_context(c->device, c->verbose, true, &k);
         if (rc) return fail(c, rc, "a further decode context could not be made");
         c->dec_kids.push_back(k);
     }
