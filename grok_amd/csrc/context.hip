@@ -115,6 +115,8 @@ struct grk_amd_ctx {
     DevBuf dec_seg_dev;
     HtClass ht_classes[kHtMaxClasses]; uint32_t ht_num_classes = 0;   // block classes of K3: {top resolution, rest} x {LDS small, large}
     uint8_t ht_class_top[kHtMaxClasses] = {}, ht_class_big[kHtMaxClasses] = {};
+    int seq_index = -1;               // >= 0: one of a decode sequence's internal contexts (grk_amd_set_decode_pipelining)
+    int seq_flavour = 0;              // ... whose two streams are made for 0: HT frames, 1: Part-1 frames (sequence_streams)
     hipStream_t side2 = nullptr; hipEvent_t ev_side2 = nullptr;      // the large-LDS classes run beside the small-LDS ones
     hipStream_t side = nullptr;                             // K3 of the top resolution runs here beside DWT levels >= 1
     hipEvent_t ev_level0 = nullptr, ev_side = nullptr;
@@ -1314,6 +1316,36 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
     return GRK_AMD_OK;                 // (a window's adapted table lives in the context's pinned memory: nothing to wait for)
 }
 
+namespace {
+// The two streams of one of a sequence's contexts, made for the kind of frames the sequence carries.  The HIP runtime keeps a pool
+// of (by default 4) hardware queues PER PRIORITY LEVEL, and kernels of streams that share a queue run one after the other.
+// Part-1 frames are two long kernels each (the long chains on the call's stream, the lane kernel on the side stream, ~13 ms
+// both): their streams go over the priority levels in turn, so that n frames in flight use the queues of every pool -- three
+// frames in flight 10.4 -> 7.4 ms per frame, six 6.8, eight 6.4, without GPU_MAX_HW_QUEUES (profiles/r04_hw_queues.txt).  The HT
+// decoder's kernels are short and lose with streams of mixed priority (0.74 -> 0.86 ms per frame): plain streams for those.
+// A sequence that changes its kind of frames pays one synchronisation per context.
+int sequence_streams(grk_amd_ctx* k, bool part1)
+{
+    const int flavour = part1 ? 1 : 0;
+    if (k->seq_index < 0 || k->seq_flavour == flavour || !k->own_stream) return GRK_AMD_OK;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int levels = least - greatest + 1;
+    const char* const epr = getenv("GRK_AMD_SEQ_PRIORITIES");
+    if (levels < 2 || (epr && atoi(epr) == 0)) { k->seq_flavour = flavour; return GRK_AMD_OK; }
+    const int rc = grk_amd_synchronize(k); if (rc) return rc;
+    hipStream_t ns = nullptr, nside = nullptr;
+    const int p0 = part1 ? greatest + k->seq_index % levels : least, p1 = part1 ? greatest + (k->seq_index + 1) % levels : least;
+    hipError_t e = part1 ? hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, p0) : hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
+    if (e == hipSuccess && k->side) e = hipStreamCreateWithPriority(&nside, hipStreamNonBlocking, p1);
+    if (e != hipSuccess) { if (ns) (void)hipStreamDestroy(ns); return fail(k, GRK_AMD_ERR_NO_DEVICE, "streams of a decode sequence", e); }
+    (void)hipStreamDestroy(k->stream); k->stream = ns;
+    if (k->side) { (void)hipStreamDestroy(k->side); k->side = nside; }
+    k->seq_flavour = flavour;
+    return GRK_AMD_OK;
+}
+} // namespace
+
 int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles,
                          const grk_amd_coded_block* table, const void* coded, uint64_t coded_bytes, int coded_on_device,
                          void* pixels, int pixels_on_device)
@@ -1331,8 +1363,9 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
                 k->dec_segs = c->dec_segs;
             k->dec_planes16 = c->dec_planes16; k->fuse_egress = c->fuse_egress; k->dwt_pk = c->dwt_pk; k->dwt_xcd = c->dwt_xcd;
             k->overlap = c->overlap && k->side != nullptr; k->t1_lanes = c->t1_lanes; k->t1_tail_ratio = c->t1_tail_ratio;
-            // ... behind whatever the caller queued on this context's stream (its uploads of the coded bytes)
             HIP_TRY(c, hipSetDevice(c->device), "set device");
+            { const int sr = sequence_streams(k, p && p->reserved[0] != 0); if (sr) { c->err = k->err; return sr; } }
+            // ... behind whatever the caller queued on this context's stream (its uploads of the coded bytes)
             HIP_TRY(c, hipEventRecord(c->ev_seq, c->stream), "record the caller's stream");
             HIP_TRY(c, hipStreamWaitEvent(k->stream, c->ev_seq, 0), "order the frame behind the caller's stream");
             const int rc = decode_impl(k, p, ntiles, table, coded, coded_bytes, 1, pixels, 1, nullptr);
@@ -1356,6 +1389,7 @@ int grk_amd_set_decode_pipelining(grk_amd_ctx* c, int frames_in_flight)
         grk_amd_ctx* k = nullptr;
         rc = create_context(c->device, c->verbose, true, &k);
         if (rc) return fail(c, rc, "a further decode context could not be made");
+        k->seq_index = i;
         c->dec_kids.push_back(k);
     }
     return GRK_AMD_OK;

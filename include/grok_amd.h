@@ -195,11 +195,12 @@ int grk_amd_decode_status(grk_amd_ctx* ctx);
  * queued; a frame's pixels are complete after grk_amd_synchronize (all frames) -- grk_amd_decode_status reports the worst
  * status of all of them.  0 or 1: off (every call on the context's own stream, as before).  Calls with host buffers and
  * grk_amd_decode_region always run on the context itself.
- * Three and more frames overlap only if the HIP runtime has more than its default 4 hardware queues (a frame in flight has
- * two streams of long kernels; streams that share a queue run in turn): a host that decodes sequences sets GPU_MAX_HW_QUEUES=8
- * in its environment before its first HIP call (Part-1, 8192x8192x3: 9.1 ms per frame with two in flight on 4 queues, 6.7 with
- * six on 8).  The library leaves the variable alone: it is process-wide, and the encode pipeline beside an RCCL exchange
- * measured 25 % slower on anything but the default. */
+ * Streams and hardware queues: the HIP runtime puts a process's streams on (by default) 4 hardware queues per priority level
+ * and kernels that share a queue run in turn; the internal sets therefore use two streams each, and for Part-1 frames (two
+ * long kernels per frame) streams of both priority levels in turn (8192x8192x3 12-bit: 15.0 ms one frame at a time, 9.1 with
+ * two in flight, 7.2 with six).  A host that decodes such sequences gains a little more from GPU_MAX_HW_QUEUES=8 in its
+ * environment before its first HIP call (6.2-6.8 with six); the library leaves the variable alone: it is process-wide, and the
+ * encode pipeline beside an RCCL exchange measured 25 % slower on anything but the default. */
 int grk_amd_set_decode_pipelining(grk_amd_ctx* ctx, int frames_in_flight);
 /* 8-bit reversible HT tiles are decoded with int16 planes between the block decoder and the inverse DWT (default on; half
  * the bytes of the two HBM-bound halves of the decode), and the inverse 5/3 runs on packed pairs of them, which takes every
