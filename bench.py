@@ -694,7 +694,7 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, pg_options=D.comm_options())
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -724,7 +724,7 @@ def main():
     # one encode up front: buffers exist
     ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
     _, total0 = ctx.fetch_table(nblocks)
-    comm = torch.cuda.Stream(device=dev) if use_dist else None
+    comm = torch.cuda.Stream(device=dev, priority=D.comm_priority()) if use_dist else None
 
     def sync():
         torch.cuda.synchronize(dev)

@@ -21,6 +21,7 @@ collective: rank r encodes tiles {t : t mod R == r}.  The exchanges are
 import ctypes as C
 
 import numpy as np
+import os
 import torch
 import torch.distributed as dist
 
@@ -103,6 +104,30 @@ def gather_frame(counts_host, offsets, lengths, arena, root, bufs=None, group=No
 _gather_groups = []          # [0]: the counts' group, [1 + g]: gather slot g
 
 
+def comm_priority():
+    """Priority of the streams the exchange's own work is queued on (packing, the waits for the encoder's results): the
+    encoder's level.  GROK_AMD_COMM_PRIORITY=-1 moves them to the high level (measured, world size 1 over RCCL, ms per 8K frame
+    counts / gather: 0.440 / 0.439 instead of 0.423 / 0.433 on the default hardware queues -- profiles/r04_hw_queues.txt)."""
+    return int(os.environ.get("GROK_AMD_COMM_PRIORITY", "0"))
+
+
+def comm_options():
+    """Process-group options: RCCL's OWN streams -- the ones the transfers run on -- at high priority (GROK_AMD_RCCL_PRIORITY=0:
+    the backend's default).  The HIP runtime keeps a pool of (by default 4) hardware queues per priority LEVEL, and kernels of
+    streams that share a queue run one after the other: at the encoder's level every communicator's stream shares a queue
+    with one of the encoder's three, and a transfer of most of a millisecond at the head of a queue holds back the K3 / DWT
+    launches behind it.  At the other level the transfers have a pool of their own (and a transfer's few workgroups are placed
+    before the coder's many).  At world size 1, where a "transfer" is a local copy, it makes no difference (0.423 / 0.438 against
+    0.423 / 0.433 ms per frame): the reason is the N > 1 case, which has not been measured."""
+    if int(os.environ.get("GROK_AMD_RCCL_PRIORITY", "-1")) >= 0:
+        return None
+    try:
+        from torch.distributed import ProcessGroupNCCL
+        return ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except Exception:      # noqa: BLE001  (a build without the NCCL backend: the CPU tests)
+        return None
+
+
 class FramePipeline:
     """The per-frame exchange of a sequence of frames, behind the encoder (see the module docstring), `depth` gathers in flight.
 
@@ -149,7 +174,7 @@ class FramePipeline:
         # (kept for the process's lifetime: a communicator is expensive to make, and every rank must make them in the same order)
         if self.depth > 1:
             while len(_gather_groups) < self.depth + 1:
-                _gather_groups.append(dist.new_group(list(range(self.world))))
+                _gather_groups.append(dist.new_group(list(range(self.world)), pg_options=comm_options() if cuda else None))
             self.groups, self.ctrl_group = _gather_groups[1:self.depth + 1], _gather_groups[0]
         else:
             self.groups, self.ctrl_group = [None], None
@@ -158,7 +183,7 @@ class FramePipeline:
             # (main + two side streams), and every further stream shares a queue with one of them (measured at world 1, 8K frames:
             # counts-only exchange 0.425 ms per frame; gather depth 4 with the counts on a stream of their own 0.504, with the
             # counts on slot 0's stream 0.453, everything on one stream 0.448).  The counts therefore ride on slot 0's stream.
-            self.gstreams = [streams[1]] + [torch.cuda.Stream(device=device) for _ in range(self.depth - 1)]
+            self.gstreams = [streams[1]] + [torch.cuda.Stream(device=device, priority=comm_priority()) for _ in range(self.depth - 1)]
             self.ctrl_stream = streams[1]
         else:
             self.gstreams = [None] * self.depth
