@@ -15,7 +15,7 @@
 #include <type_traits>
 
 #ifndef T1L_ROUND_STEPS
-#define T1L_ROUND_STEPS 4        // steps between two stripe hand-overs (4, 6 or 8: fewer hand-over passes, lanes wait longer for theirs)
+#define T1L_ROUND_STEPS 6        // steps between two stripe hand-overs (4, 6 or 8: fewer hand-over passes, lanes wait longer for theirs)
 #endif
 
 namespace grk_amd {
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
     }
     __syncthreads();
     // one step: the lanes that need one pick their next column; every lane with a pending decision makes it.
-    // A round is four steps: stripes stored / the next ones and coded bytes requested before the first, delivery before the third.
+    // A round is T1L_ROUND_STEPS (six) steps: stripes stored / the next ones and coded bytes requested before the first, delivery
+    // before the fourth (six against four: 1-3 % per frame in a decode sequence, the same for one frame alone; r04_hw_queues.txt).
     auto round = [&](auto TT) {
         constexpr int T = decltype(TT)::value;
         auto step = [&]() {

@@ -16,7 +16,7 @@
 //     ([context][lane]: conflict-free); the coded bytes through a 64-bit shift register refilled four bytes at a time.
 //   * The block's significance / sign / visited / refined bitmaps (T1's sigma, chi, pi, mu; one 64-bit row each per sample
 //     row) live in GLOBAL memory (2 KB per block) and only the stripe in work -- its 4 rows + the rows above and below --
-//     sits in registers.  Stripe changes are batched: every fourth iteration the lanes that finished a stripe store it and
+//     sits in registers.  Stripe changes are batched: every sixth iteration the lanes that finished a stripe store it and
 //     issue the loads of the next one, two iterations later they take delivery -- no lane ever waits on a load it just issued.
 //   * Decoded magnitudes are not kept as values at all: per bit-plane the block leaves the significance bitmap at the end of
 //     the plane and the refinement bits of the plane's mag-ref pass; t1_recon_kernel (kernels_t1lanes.hip) turns those into
