@@ -829,6 +829,7 @@ def test_decode_sequence_mode_frames_in_flight():
     c.set_decode_pipelining(3)
     try:
         outs = [torch.zeros(C * H * W, dtype=torch.uint8, device="cuda") for _ in frames]
+        torch.cuda.synchronize()                              # (torch's fills have landed before the context's streams write)
         for rep in range(2):                                  # (twice: every set has decoded, then decodes again)
             for (px, table, d_c), o in zip(frames, outs):
                 c.decode_device(p, 1, table, d_c.data_ptr(), d_c.numel(), o.data_ptr())
@@ -869,11 +870,48 @@ def test_decode_sequence_on_a_context_that_did_nothing_else():
     c.set_decode_pipelining(3)
     try:
         outs = [torch.zeros(C * H * W, dtype=torch.uint8, device="cuda") for _ in range(4)]
+        torch.cuda.synchronize()
         for o in outs:
             c.decode_device(p, 1, table, d_c.data_ptr(), d_c.numel(), o.data_ptr())
         c.synchronize()
         c.decode_status()
         for o in outs:
             assert np.array_equal(o.cpu().numpy().reshape(C, H, W), px)
+    finally:
+        c.set_decode_pipelining(0)
+
+
+@needs_ref
+def test_decode_sequence_that_changes_its_kind_of_frames():
+    """HT frames, then Part-1 frames, then HT frames again through ONE sequence (three in flight): the internal contexts re-make
+    their streams when the kind of frame changes (Part-1: over both priority levels' hardware-queue pools; HT: plain streams) --
+    every frame comes out as its source whichever streams decoded it, and the status stays clean."""
+    C, H, W, prec, L = 3, 128, 192, 8, 3
+    p_ht = G.TileParams.make(W, H, C, prec, L)
+    enc = G.Context(0)
+    ht = []
+    for f in range(4):
+        px = synth.g2(C, H, W, prec, seed=40 + f)
+        table, coded = enc.encode_host(p_ht, px)
+        ht.append((px, table, U.to_dev(np.frombuffer(bytes(coded), np.uint8).copy())))
+    p1 = []
+    for f in range(4):
+        px = synth.g2(C, H, W, prec, seed=60 + f)
+        p, _, _, table, coded = _part1_tile(px, prec, L)
+        p1.append((px, table, U.to_dev(np.frombuffer(coded, np.uint8).copy()), p))
+    c = G.Context(0)
+    c.set_decode_pipelining(3)
+    try:
+        outs = []
+        for rnd in range(2):                                  # HT, Part-1, HT, Part-1: two changes each way
+            for kind in ("ht", "p1"):
+                for fr in (ht if kind == "ht" else p1):
+                    o = U._settled(torch.zeros(C * H * W, dtype=torch.uint8, device="cuda"))     # (the fill has landed)
+                    c.decode_device(fr[3] if kind == "p1" else p_ht, 1, fr[1], fr[2].data_ptr(), fr[2].numel(), o.data_ptr())
+                    outs.append((o, fr[0]))
+        c.synchronize()
+        c.decode_status()
+        for i, (o, px) in enumerate(outs):
+            assert np.array_equal(o.cpu().numpy().reshape(C, H, W), px), "frame %d" % i
     finally:
         c.set_decode_pipelining(0)
