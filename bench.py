@@ -306,6 +306,7 @@ def cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, flights):
         for nfl in flights:
             while len(outs) < nfl:
                 outs.append(torch.zeros(3 * S * S, dtype=torch.int16, device=dev))
+            torch.cuda.synchronize(dev)                    # (torch's fills have landed before the context's streams write)
             ctx.set_decode_pipelining(nfl)
             for k in range(2 * nfl):
                 ctx.decode_device(p5, 1, table, d_c.data_ptr(), d_c.numel(), outs[k % nfl].data_ptr())
