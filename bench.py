@@ -547,6 +547,45 @@ def host_boundary(ctx, dev, stream, params, ntiles, host_pixels, nblocks, frames
                     "into pinned memory (one frame behind); bounded by the PCIe upload"}
 
 
+def node_native(dev, tile, prec, levels, d_px, cpu_file_md5=None):
+    """The native node host (grk_amd_node_*, node.cpp: one context + one host thread per device entry, Tier-2 and the codestream
+    written by the host) on THIS GPU, whole codestream per call: one worker and two workers ({d} / {d, d}), the frame as 1 tile
+    and as 64 tiles of 1024x1024, pixels in host memory and resident on the device, parallel writers and the gather form.
+    What it shows is the host side of that path (Tier-2 + assembling ~100 MB of codestream per 8K frame); the kernels are
+    the headline's."""
+    Cn, H, W = tile.shape
+    res = {}
+    d = dev.index or 0
+    for name, devices, T in (("1_worker_1_tile", [d], W), ("2_workers_64_tiles", [d, d], 1024)):
+        try:
+            node = G.Node(devices)
+            layout = G.ImageLayout.make(W, H, T, T)
+            base = G.TileParams.make(1, 1, Cn, prec, levels)
+            row = {}
+            out_buf = np.empty(tile.size * tile.itemsize * 2 + (1 << 20), np.uint8)
+            out_buf[::4096] = 0                          # (the pages exist: a caller in a loop reuses its output buffer)
+            for label, fl in (("parallel_writers", 0), ("gather", G.NODE_GATHER)):
+                for src in ("host_pixels", "device_pixels"):
+                    def once():
+                        if src == "host_pixels":
+                            return node.encode_image(layout, base, tile, fl, out=out_buf)
+                        return node.encode_image_device(layout, base, d_px.data_ptr(), d_px.numel(), d, fl, out=out_buf)
+                    cs = once()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        cs = once()
+                    row["%s_%s_ms" % (label, src)] = round((time.perf_counter() - t0) / 2 * 1e3, 2)
+                    if T == W and cpu_file_md5:
+                        import hashlib
+                        row["file_equals_cpu_encode"] = bool(row.get("file_equals_cpu_encode", True) and hashlib.md5(cs).hexdigest() == cpu_file_md5)
+            row["codestream_bytes"] = int(len(cs))
+            res[name] = row
+            node.close()
+        except Exception as e:  # noqa: BLE001
+            res[name] = {"error": str(e)}
+    return res
+
+
 def via_grok_plugin(ctx, params, tile_pixels, prec, cpu_file_md5=None):
     """The drop-in route itself, once: the plugin's tile tree (GPU encode + D2H + tree) handed to the real Grok library's
     grk_compress_with_plugin(), which runs its own Tier-2 and writes the file (oracle/_ref = that library, built from the
@@ -1162,6 +1201,8 @@ def main():
                 hb = {"end_to_end": {"error": str(e)}}
             if args.workload == "8k" and not args.no_cpu_baseline:
                 hb["via_grok_plugin"] = via_grok_plugin(ctx, params, tile, prec, (out.get("cpu_baseline") or {}).get("file_md5"))
+            if args.workload == "8k":
+                hb["node_native"] = node_native(dev, tile, prec, levels, d_px, (out.get("cpu_baseline") or {}).get("file_md5"))
             out["host_boundary"] = hb
     else:
         out = None

@@ -522,6 +522,18 @@ class Node:
             raise RuntimeError("node_encode_image failed: %d (%s)" % (n, self._L.grk_amd_node_last_error(self._h).decode()))
         return out[:n]
 
+    def encode_image_device(self, layout, base, pixels_ptr, nbytes, device, flags=0, out=None):
+        """The image resident in the memory of HIP device `device` at `pixels_ptr` (nbytes of it): grk_amd_node_encode_image_device."""
+        if out is None:
+            out = np.empty(nbytes * 2 + (1 << 20), np.uint8)
+        fn = self._L.grk_amd_node_encode_image_device
+        fn.restype = C.c_int64
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_uint64]
+        n = fn(self._h, C.cast(C.byref(layout), C.c_void_p), C.cast(C.byref(base), C.c_void_p), pixels_ptr, int(device), flags, out.ctypes.data, out.size)
+        if n < 0:
+            raise RuntimeError("node_encode_image_device failed: %d (%s)" % (n, self._L.grk_amd_node_last_error(self._h).decode()))
+        return out[:n]
+
     def close(self):
         if self._h:
             self._L.grk_amd_node_destroy(self._h)

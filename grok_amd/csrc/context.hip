@@ -1614,6 +1614,11 @@ int grk_amd_stream_wait_results(grk_amd_ctx* c, void* hip_stream)
     return GRK_AMD_OK;
 }
 
+int grk_amd_get_pipelining(grk_amd_ctx* c)
+{
+    return c && c->pipelining && c->overlap && c->side ? c->pipe_depth - 1 : 0;
+}
+
 int grk_amd_set_pipelining(grk_amd_ctx* c, int on)
 {
     if (!c) return GRK_AMD_ERR_INVALID;

@@ -15,6 +15,7 @@
 #include "../../include/grok_amd.h"
 #include "geometry.h"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <mutex>
@@ -29,10 +30,11 @@ struct grk_amd_node {
         int device = 0;
         grk_amd_ctx* ctx = nullptr;
         uint8_t* pin_px = nullptr; size_t pin_px_cap = 0;        // tile pixels of one geometry group, pinned
+        void* dev_px = nullptr; size_t dev_px_cap = 0;           // the same on the device (device-resident image: the tiles are cut out by 2-D copies)
+        std::vector<hipEvent_t> copied;                          // gather: group k's coded bytes have left this worker's arena
         uint8_t* pin_coded = nullptr; size_t pin_coded_cap = 0;  // coded bytes on the host, pinned
         void* gather = nullptr; size_t gather_cap = 0;           // device memory: where the other workers' bytes land when this one is the writer
         hipStream_t copy = nullptr;                              // this worker's device-to-device / download stream
-        std::vector<uint8_t> parts;                              // this worker's tile-parts, one after the other
     };
     std::vector<Worker> w;
     uint64_t frame = 0;
@@ -53,10 +55,53 @@ bool pin_ensure(grk_amd_ctx* ctx, uint8_t*& p, size_t& cap, size_t n)
     return true;
 }
 
+constexpr int kRing = 3;       // a worker's encodes rotate kRing + 1 buffer sets (a regular tiling has at most four geometry groups)
+
+// rows of `w` bytes, `src_pitch` apart -> tight; a few threads when there is enough to copy (one core moves ~10 GB/s, a worker of
+// BASELINE configs[3] stages 100 MB per image)
+void copy_rows(uint8_t* dst, const uint8_t* src, size_t w, size_t src_pitch, size_t rows)
+{
+    for (size_t y = 0; y < rows; ++y) std::memcpy(dst + y * w, src + y * src_pitch, w);
+}
+
+// the same, keeping the first `keep` bytes when the buffer has to grow
+bool pin_grow(grk_amd_ctx* ctx, uint8_t*& p, size_t& cap, size_t n, size_t keep)
+{
+    if (n <= cap) return true;
+    const size_t want = n + (n >> 2) + 4096;
+    uint8_t* q = (uint8_t*)grk_amd_host_alloc(ctx, want);
+    if (!q) return false;
+    if (p && keep) std::memcpy(q, p, keep);
+    if (p) grk_amd_host_free(ctx, p);
+    p = q; cap = want;
+    return true;
+}
+
 struct TileJob {               // what the workers leave per tile
-    std::vector<grk_amd_coded_block> rows;     // offsets into the owning worker's coded bytes
-    uint64_t part_at = 0, part_len = 0;        // parallel writers: the tile-part inside the owner's `parts`
+    std::vector<grk_amd_coded_block> rows;     // offsets into the coded bytes on the host (the owning worker's, or the writer's)
+    uint64_t part_len = 0;                     // the tile-part's size
 };
+
+// fn(t) for t in [0, n) on up to `threads` host threads; the first error wins
+template <class F> int parallel_tiles(uint32_t n, uint32_t threads, F fn)
+{
+    threads = std::max(1u, std::min(threads, n));
+    std::atomic<uint32_t> next{0};
+    std::atomic<int> rc{GRK_AMD_OK};
+    auto work = [&]() {
+        for (;;) {
+            const uint32_t t = next.fetch_add(1);
+            if (t >= n || rc.load() != GRK_AMD_OK) return;
+            const int r = fn(t);
+            if (r != GRK_AMD_OK) { int ok = GRK_AMD_OK; (void)rc.compare_exchange_strong(ok, r); }
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t i = 1; i < threads; ++i) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    return rc.load();
+}
 
 } // namespace
 
@@ -82,6 +127,9 @@ extern "C" int grk_amd_node_create(const int* devices, uint32_t n, int verbose, 
         nd->w[i].device = devs[i];
         const int rc = grk_amd_create(devs[i], verbose, &nd->w[i].ctx);
         if (rc != GRK_AMD_OK) { grk_amd_node_destroy(nd); return rc; }
+        // kRing + 1 buffer sets in rotation: the coded bytes of a geometry group stay where they are while the next groups are
+        // coded, so that their copy to the writer's device runs beside those encodes instead of being waited for
+        (void)grk_amd_set_pipelining(nd->w[i].ctx, kRing);
         if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&nd->w[i].copy, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
             grk_amd_node_destroy(nd);
@@ -107,6 +155,8 @@ extern "C" void grk_amd_node_destroy(grk_amd_node* nd)
     for (auto& w : nd->w) {
         if (w.pin_px) grk_amd_host_free(w.ctx, w.pin_px);
         if (w.pin_coded) grk_amd_host_free(w.ctx, w.pin_coded);
+        if (w.dev_px) { (void)hipSetDevice(w.device); (void)hipFree(w.dev_px); }
+        for (hipEvent_t e : w.copied) { (void)hipSetDevice(w.device); (void)hipEventDestroy(e); }
         if (w.gather) { (void)hipSetDevice(w.device); (void)hipFree(w.gather); }
         if (w.copy) { (void)hipSetDevice(w.device); (void)hipStreamDestroy(w.copy); }
         if (w.ctx) grk_amd_destroy(w.ctx);
@@ -119,17 +169,15 @@ extern "C" grk_amd_ctx* grk_amd_node_ctx(grk_amd_node* nd, uint32_t i) { return 
 extern "C" const char* grk_amd_node_last_error(grk_amd_node* nd) { return nd ? nd->err.c_str() : "null node"; }
 
 static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
-                                 const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap);
+                                 const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap);
 
-// One image at a time per node: the call owns the workers' contexts, their pinned buffers and the gather buffers for its duration
-// (callers from several threads queue on the node's mutex).  Every error return leaves its reason in grk_amd_node_last_error.
-extern "C" int64_t grk_amd_node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
-                                             const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap)
+static int64_t node_encode_locked(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                  const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap)
 {
     if (!nd) return GRK_AMD_ERR_INVALID;
     std::lock_guard<std::mutex> lk(nd->mu);
     nd->err.clear();
-    const int64_t rc = node_encode_image(nd, im, base, pixels, flags, out, cap);
+    const int64_t rc = node_encode_image(nd, im, base, pixels, pixels_device, flags, out, cap);
     if (rc < 0 && nd->err.empty()) {
         nd->err = rc == GRK_AMD_ERR_INVALID ? "invalid argument" : rc == GRK_AMD_ERR_UNSUPPORTED ? "unsupported layout (TLM with more than 255 tiles?)"
                 : rc == GRK_AMD_ERR_NOMEM ? "out of (pinned or device) memory" : rc == GRK_AMD_ERR_NO_DEVICE ? "a HIP call failed (device lost or peer copy refused)"
@@ -139,8 +187,28 @@ extern "C" int64_t grk_amd_node_encode_image(grk_amd_node* nd, const grk_amd_ima
     return rc;
 }
 
+// One image at a time per node: the call owns the workers' contexts, their pinned buffers and the gather buffers for its duration
+// (callers from several threads queue on the node's mutex).  Every error return leaves its reason in grk_amd_node_last_error.
+extern "C" int64_t grk_amd_node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                             const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap)
+{
+    return node_encode_locked(nd, im, base, pixels, -1, flags, out, cap);
+}
+
+// The image resident in the memory of HIP device `pixels_device` (component-major planar, tight): every worker cuts its tiles out
+// with 2-D device-to-device copies (over xGMI from another GPU's memory) -- no pixel crosses PCIe.
+extern "C" int64_t grk_amd_node_encode_image_device(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                                    const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap)
+{
+    if (pixels_device < 0 || pixels_device >= grk_amd_device_count()) {
+        if (nd) { std::lock_guard<std::mutex> lk(nd->mu); nd->err = "invalid argument: pixels_device"; }
+        return GRK_AMD_ERR_INVALID;
+    }
+    return node_encode_locked(nd, im, base, pixels, pixels_device, flags, out, cap);
+}
+
 static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
-                                 const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap)
+                                 const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap)
 {
     if (nd->w.empty() || !im || !base || !pixels || !out) return GRK_AMD_ERR_INVALID;
     const int64_t nt = grk_amd_layout_num_tiles(im);
@@ -195,44 +263,94 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
             auto& w = nd->w[r];
             int rc = GRK_AMD_OK;
             uint64_t coded_used = 0;                       // this worker's coded bytes so far (all its groups, one after the other)
-            w.parts.clear();
+            size_t ngroup = 0;                             // gather: groups whose bytes are on their way
             for (size_t k = 0; k < geoms.size() && rc == GRK_AMD_OK; ++k) {
                 std::vector<uint32_t> mine;
                 for (uint32_t t = r; t < ntiles; t += R) if (group_of[t] == k) mine.push_back(t);
                 if (mine.empty()) continue;
                 const grk_amd_tile_params& p = tp[mine[0]];
                 const size_t tile_bytes = (size_t)p.tile_w * p.tile_h * nc * bps;
-                if (!pin_ensure(w.ctx, w.pin_px, w.pin_px_cap, tile_bytes * mine.size())) { rc = GRK_AMD_ERR_NOMEM; break; }
-                for (size_t i = 0; i < mine.size(); ++i) {
-                    const grk_amd_tile_params& q = tp[mine[i]];
-                    const size_t ox = q.tile_x0 - im->x0, oy = q.tile_y0 - im->y0;
-                    for (uint32_t c = 0; c < nc; ++c)
-                        for (uint32_t y = 0; y < q.tile_h; ++y)
-                            std::memcpy(w.pin_px + i * tile_bytes + ((size_t)c * q.tile_h + y) * q.tile_w * bps,
-                                        (const uint8_t*)pixels + (((size_t)c * H + oy + y) * W + ox) * bps, (size_t)q.tile_w * bps);
+                const void* enc_px = nullptr;
+                if (pixels_device < 0) {
+                    if (!pin_ensure(w.ctx, w.pin_px, w.pin_px_cap, tile_bytes * mine.size())) { rc = GRK_AMD_ERR_NOMEM; break; }
+                    // the tiles' rows out of the caller's image into pinned memory; several threads when it is much, each taking
+                    // its share of the rows of every tile component (one tile of 8192 x 8192 x 3 is 200 MB for one worker)
+                    const size_t nthr = tile_bytes * mine.size() >= (32u << 20) ? 4 : 1;
+                    auto stage = [&](size_t j) {
+                        for (size_t i = 0; i < mine.size(); ++i) {
+                            const grk_amd_tile_params& q = tp[mine[i]];
+                            const size_t ox = q.tile_x0 - im->x0, oy = q.tile_y0 - im->y0;
+                            const size_t y0 = (size_t)q.tile_h * j / nthr, y1 = (size_t)q.tile_h * (j + 1) / nthr;
+                            for (uint32_t c = 0; c < nc; ++c)
+                                copy_rows(w.pin_px + i * tile_bytes + ((size_t)c * q.tile_h + y0) * q.tile_w * bps,
+                                          (const uint8_t*)pixels + (((size_t)c * H + oy + y0) * W + ox) * bps, (size_t)q.tile_w * bps, (size_t)W * bps, y1 - y0);
+                        }
+                    };
+                    if (nthr > 1) {
+                        std::vector<std::thread> st;
+                        for (size_t j = 1; j < nthr; ++j) st.emplace_back(stage, j);
+                        stage(0);
+                        for (auto& t : st) t.join();
+                    } else stage(0);
+                    enc_px = w.pin_px;
+                } else {
+                    // device-resident image: 2-D copies (rows of the tile out of rows of the image) on this worker's copy stream
+                    if (hipSetDevice(w.device) != hipSuccess) { rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                    if (w.dev_px_cap < tile_bytes * mine.size()) {
+                        // (the encode that read the old buffer has returned: grk_amd_encode_tiles below is synchronous)
+                        if (w.dev_px) (void)hipFree(w.dev_px);
+                        w.dev_px = nullptr; w.dev_px_cap = 0;
+                        if (hipMalloc(&w.dev_px, tile_bytes * mine.size() + 256) != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NOMEM; break; }
+                        w.dev_px_cap = tile_bytes * mine.size();
+                    }
+                    hipError_t e = hipSuccess;
+                    for (size_t i = 0; i < mine.size() && e == hipSuccess; ++i) {
+                        const grk_amd_tile_params& q = tp[mine[i]];
+                        const size_t ox = q.tile_x0 - im->x0, oy = q.tile_y0 - im->y0;
+                        for (uint32_t c = 0; c < nc && e == hipSuccess; ++c)
+                            e = hipMemcpy2DAsync((uint8_t*)w.dev_px + i * tile_bytes + (size_t)c * q.tile_h * q.tile_w * bps, (size_t)q.tile_w * bps,
+                                                 (const uint8_t*)pixels + (((size_t)c * H + oy) * W + ox) * bps, (size_t)W * bps,
+                                                 (size_t)q.tile_w * bps, q.tile_h, hipMemcpyDeviceToDevice, w.copy);
+                    }
+                    if (e == hipSuccess) e = hipStreamSynchronize(w.copy);
+                    if (e != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                    enc_px = w.dev_px;
                 }
                 const uint64_t bpt = (uint64_t)geoms[k].blocks_per_comp * nc;
                 std::vector<grk_amd_coded_block> table(bpt * mine.size());
                 uint64_t total = 0;
-                rc = grk_amd_encode_tiles(w.ctx, &p, (uint32_t)mine.size(), w.pin_px, 0, table.data(), &total);
+                // (the buffer set this encode takes was used kRing + 1 encodes ago: its bytes must have left by now; without the
+                //  rotation -- no DWT level, overlap switched off -- every encode writes the one arena: wait for the last copy)
+                const bool ring = p.num_levels >= 1 && grk_amd_get_pipelining(w.ctx) >= kRing;
+                if (gather && !ring && ngroup && hipStreamSynchronize(w.copy) != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                if (gather && ring && ngroup > (size_t)kRing) {
+                    if (hipEventSynchronize(w.copied[(ngroup - 1 - kRing) % w.copied.size()]) != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                }
+                rc = grk_amd_encode_tiles(w.ctx, &p, (uint32_t)mine.size(), enc_px, pixels_device >= 0, table.data(), &total);
                 if (rc) break;
                 if (gather) {
                     // device to device into the writer's buffer.  Ordering contract: grk_amd_encode_tiles was given a table pointer, so it
                     // returned through grk_amd_fetch_table -- side streams joined and the context's stream synchronised --: the arena
                     // is complete on the device before this copy is queued on w.copy (an asynchronous encode_tiles would need an
-                    // event from the context's stream here instead)
+                    // event from the context's stream here instead).  The copy is NOT waited for: the context rotates kRing + 1
+                    // buffer sets, the next groups are coded into other arenas while this one's bytes travel, and an event per group
+                    // says when its set may be written again (above) -- the worker waits once, behind its last group.
                     auto& ww = nd->w[writer];
                     if (gather_at[r] + coded_used + total > gather_at[r + 1]) { rc = GRK_AMD_ERR_OVERFLOW; break; }
-                    // (a device-to-device copy returns before it is done: waited for here, the next group's encode writes the same arena)
-                    if (total && (hipSetDevice(w.device) != hipSuccess ||
-                                  hipMemcpyPeerAsync((char*)ww.gather + gather_at[r] + coded_used, ww.device, grk_amd_coded_device_ptr(w.ctx),
-                                                     w.device, total, w.copy) != hipSuccess ||
-                                  hipStreamSynchronize(w.copy) != hipSuccess)) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
-                } else {
-                    if (!pin_ensure(w.ctx, w.pin_coded, w.pin_coded_cap, coded_used + total)) {
-                        // (growing: what is there has been consumed by the tile-parts already written)
-                        rc = GRK_AMD_ERR_NOMEM; break;
+                    if (hipSetDevice(w.device) != hipSuccess) { rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                    while (w.copied.size() < (size_t)kRing + 1) {
+                        hipEvent_t ev = nullptr;
+                        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                        w.copied.push_back(ev);
                     }
+                    if (rc) break;
+                    if ((total && hipMemcpyPeerAsync((char*)ww.gather + gather_at[r] + coded_used, ww.device, grk_amd_coded_device_ptr(w.ctx),
+                                                     w.device, total, w.copy) != hipSuccess) ||
+                        hipEventRecord(w.copied[ngroup % w.copied.size()], w.copy) != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                    ++ngroup;
+                } else {
+                    // (the worker's groups one after the other: Tier-2 runs over all of them once every worker is done)
+                    if (!pin_grow(w.ctx, w.pin_coded, w.pin_coded_cap, coded_used + total + 16, coded_used)) { rc = GRK_AMD_ERR_NOMEM; break; }
                     rc = grk_amd_fetch_coded(w.ctx, w.pin_coded + coded_used, total);
                     if (rc) break;
                 }
@@ -240,18 +358,12 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
                     TileJob& j = jobs[mine[i]];
                     j.rows.assign(table.begin() + i * bpt, table.begin() + (i + 1) * bpt);
                     for (auto& row : j.rows) row.offset += coded_used;
-                    if (!gather) {         // parallel writers: this tile's tile-part, now, by this thread
-                        const int64_t need = grk_amd_write_tile_part(&tp[mine[i]], mine[i], cs_flags, j.rows.data(), w.pin_coded, nullptr, 0);
-                        if (need < 0) { rc = (int)need; break; }
-                        j.part_at = w.parts.size(); j.part_len = (uint64_t)need;
-                        w.parts.resize(w.parts.size() + (size_t)need);
-                        const int64_t got = grk_amd_write_tile_part(&tp[mine[i]], mine[i], cs_flags, j.rows.data(), w.pin_coded,
-                                                                    w.parts.data() + j.part_at, (uint64_t)need);
-                        if (got != need) { rc = got < 0 ? (int)got : GRK_AMD_ERR_INVALID; break; }
-                    }
                 }
-                if (!gather && rc == GRK_AMD_OK) coded_used = 0;      // the group's bytes are in its tile-parts: the buffer is free again
-                else coded_used += total;
+                coded_used += total;
+            }
+            if (gather && (hipSetDevice(w.device) != hipSuccess || hipStreamSynchronize(w.copy) != hipSuccess)) {      // the last groups' bytes
+                (void)hipGetLastError();
+                if (!rc) rc = GRK_AMD_ERR_NO_DEVICE;
             }
             used[r] = coded_used;
             rcs[r] = rc;
@@ -260,8 +372,10 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
     for (uint32_t r = 0; r < R; ++r)
         if (rcs[r]) { nd->err = std::string("worker ") + std::to_string(r) + ": " + grk_amd_last_error(nd->w[r].ctx); return rcs[r]; }
 
+    // Where every tile's coded bytes are on the host: with parallel writers in its own worker's pinned buffer (fetched over
+    // that worker's PCIe link), in the gather form in the writer's (one piece per worker, brought over by the writer's device).
+    std::vector<const uint8_t*> src(ntiles, nullptr);
     if (gather) {
-        // the writer: everything to the host in one piece per worker, Tier-2 for all tiles, one codestream
         auto& ww = nd->w[writer];
         uint64_t host_total = 0;
         std::vector<uint64_t> host_at(R, 0);
@@ -275,24 +389,34 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
                 return GRK_AMD_ERR_NO_DEVICE;
             }
         if (hipStreamSynchronize(ww.copy) != hipSuccess) { (void)hipGetLastError(); return GRK_AMD_ERR_NO_DEVICE; }
-        std::vector<grk_amd_coded_block> all;
-        for (uint32_t t = 0; t < ntiles; ++t) {
-            const uint64_t at = host_at[t % R];
-            for (auto row : jobs[t].rows) { row.offset += at; all.push_back(row); }
-        }
-        return grk_amd_write_codestream_layout(im, base, all.data(), ww.pin_coded, cs_flags, out, cap);
+        for (uint32_t t = 0; t < ntiles; ++t) src[t] = ww.pin_coded + host_at[t % R];
+    } else {
+        for (uint32_t t = 0; t < ntiles; ++t) src[t] = nd->w[t % R].pin_coded;
     }
-    // parallel writers: main header (TLM from the tile-parts' sizes), the tile-parts in index order, EOC
+    // Tier-2 and the codestream, tiles on several host threads: the tile-parts' sizes (a dry run of the packet writer), the main
+    // header (TLM from the sizes) -- which fixes every tile-part's place --, then each tile-part written where it belongs: every
+    // coded byte is copied once, and not by one thread (a frame of BASELINE configs[3] is ~400 MB of codestream).
+    const uint32_t host_threads = std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency() / 4u));
+    int rc = parallel_tiles(ntiles, host_threads, [&](uint32_t t) -> int {
+        const int64_t need = grk_amd_write_tile_part(&tp[t], t, cs_flags, jobs[t].rows.data(), src[t], nullptr, 0);
+        if (need < 0) return (int)need;
+        jobs[t].part_len = (uint64_t)need;
+        return GRK_AMD_OK;
+    });
+    if (rc) return rc;
     std::vector<uint32_t> sizes(ntiles);
     for (uint32_t t = 0; t < ntiles; ++t) sizes[t] = (uint32_t)jobs[t].part_len;
     const int64_t hdr = grk_amd_write_main_header_layout(im, base, cs_flags, sizes.data(), out, cap);
     if (hdr < 0) return hdr;
-    uint64_t at = (uint64_t)hdr;
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        if (at + jobs[t].part_len + 2 > cap) return GRK_AMD_ERR_OVERFLOW;
-        std::memcpy(out + at, nd->w[t % R].parts.data() + jobs[t].part_at, (size_t)jobs[t].part_len);
-        at += jobs[t].part_len;
-    }
-    out[at++] = 0xFF; out[at++] = 0xD9;
-    return (int64_t)at;
+    std::vector<uint64_t> at(ntiles + 1, (uint64_t)hdr);
+    for (uint32_t t = 0; t < ntiles; ++t) at[t + 1] = at[t] + jobs[t].part_len;
+    if (at[ntiles] + 2 > cap) return GRK_AMD_ERR_OVERFLOW;
+    rc = parallel_tiles(ntiles, host_threads, [&](uint32_t t) -> int {
+        const int64_t got = grk_amd_write_tile_part(&tp[t], t, cs_flags, jobs[t].rows.data(), src[t], out + at[t], jobs[t].part_len);
+        return got == (int64_t)jobs[t].part_len ? GRK_AMD_OK : got < 0 ? (int)got : GRK_AMD_ERR_INVALID;
+    });
+    if (rc) return rc;
+    uint64_t end = at[ntiles];
+    out[end++] = 0xFF; out[end++] = 0xD9;
+    return (int64_t)end;
 }

@@ -282,6 +282,9 @@ int    grk_amd_set_overlap(grk_amd_ctx* ctx, int on);
  * (grok_amd/dist.py: the receive sizes have to pass through the host, and with two sets that round trip would sit between
  * consecutive frames), n = k + 1 for k gathers in flight at once (each towards another writer, over another xGMI link). */
 int    grk_amd_set_pipelining(grk_amd_ctx* ctx, int on);
+/* The number of OTHER buffer sets consecutive encodes of tiles with at least one DWT level rotate through right now (0: every
+ * encode writes the same arena -- pipelining off, or the overlap switched off). */
+int    grk_amd_get_pipelining(grk_amd_ctx* ctx);
 /* Makes `hip_stream` (the caller's, e.g. the one its RCCL collectives run on) wait for the results of the latest encode
  * -- the context's stream and, when pipelined, its side streams -- without blocking the context's own stream: the
  * consumer of grk_amd_coded_device_ptr / grk_amd_table_device_ptr in a pipelined sequence. */
@@ -367,7 +370,9 @@ int64_t grk_amd_locate_tile_parts(const uint8_t* cs, uint64_t len, uint64_t* off
  *     into the frame's writer device -- rotating with the frame number -- which brings them to the host in one piece and
  *     runs Tier-2 for all tiles.
  * `devices` lists the HIP devices to use (NULL / 0: all of the node); an entry may repeat (several contexts on one GPU).
- * `pixels` is the whole image, component-major planar, tight, in host memory (pinned or not). */
+ * `pixels` is the whole image, component-major planar, tight, in host memory (pinned or not).
+ * In gather mode a worker's encodes rotate four buffer sets, so that a geometry group's bytes travel to the writer while the
+ * worker's next groups are coded (an event per group, one wait behind the last). */
 typedef struct grk_amd_node grk_amd_node;
 #define GRK_AMD_NODE_GATHER 0x80000000u
 int  grk_amd_device_count(void);
@@ -378,6 +383,11 @@ grk_amd_ctx* grk_amd_node_ctx(grk_amd_node* node, uint32_t i);
 const char* grk_amd_node_last_error(grk_amd_node* node);
 int64_t grk_amd_node_encode_image(grk_amd_node* node, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
                                   const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap);
+/* The same with the image resident in the memory of HIP device `pixels_device` (same layout): every worker cuts its tiles out of it
+ * with 2-D device-to-device copies -- from another GPU's memory over xGMI, peer access is switched on by grk_amd_node_create --,
+ * so that no pixel crosses PCIe (the host-pixels entry is PCIe-bound by construction).  Same codestream, byte for byte. */
+int64_t grk_amd_node_encode_image_device(grk_amd_node* node, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                         const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap);
 
 #ifdef __cplusplus
 }

@@ -35,8 +35,30 @@ def test_node_image_equals_single_context_image(devices, W, H, TW, TH, L, off, p
         # the gather form, three frames: the writer device rotates, the file does not change
         for _ in range(3):
             assert bytes(node.encode_image(layout, base, px, flags | G.NODE_GATHER)) == want
+        # the image resident on the device: the workers cut their tiles out of it by 2-D device-to-device copies
+        d_px = U.to_dev(px.reshape(-1).view(np.uint8))
+        for fl in (flags, flags | G.NODE_GATHER):
+            assert bytes(node.encode_image_device(layout, base, d_px.data_ptr(), d_px.numel(), 0, fl)) == want
     finally:
         node.close()
+
+
+def test_node_gather_with_more_geometry_groups_than_buffer_sets():
+    """Nine geometry groups (first / middle / last tile column and row all differ: an offset tiling with ragged ends) through the
+    gather form: a worker's encodes rotate four buffer sets and the copies to the writer are not waited for group by group, so the
+    fifth group must wait for the first one's bytes to have left -- the file equals the single-context one, frame after frame."""
+    W, H, TW, TH, L = 1000, 900, 384, 320, 3
+    px = synth.g2(3, H, W, 8, seed=9)
+    layout = G.ImageLayout.make(W, H, TW, TH, offset=(100, 60))
+    base = G.TileParams.make(1, 1, 3, 8, L)
+    want = U.ctx().encode_image(layout, base, px, G.CS_TLM)
+    for devices in ([0], [0, 0]):
+        node = G.Node(devices)
+        try:
+            for _ in range(3):
+                assert bytes(node.encode_image(layout, base, px, G.CS_TLM | G.NODE_GATHER)) == want
+        finally:
+            node.close()
 
 
 @needs_ref
