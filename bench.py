@@ -1185,8 +1185,9 @@ def main():
         if use_dist:
             out["multi_gpu"] = multi_gpu
         cfg5 = None
-        if not args.no_cpu_baseline:
-            # rank 0, at every N (the other ranks wait in the final barrier): Grok's CPU encoder on this box's host cores
+        if not args.no_cpu_baseline and world == 1:
+            # rank 0 at N = 1 only (at N > 1 the other ranks would wait in the final barrier for it, and the N = 1 line of the same
+            # box has it): Grok's CPU encoder on this box's host cores
             out["cpu_baseline"], cfg5 = cpu_baseline(os.cpu_count() or 1,
                                                      want_cfg5=world == 1 and not use_dist and not args.no_workloads and args.workload == "8k")
         else:
