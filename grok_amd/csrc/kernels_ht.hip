@@ -23,6 +23,8 @@
 // Bit-exactness contract: the byte string per block equals ojph_encode_codeblock's for every
 // input with |coefficient| < 2^(Kmax+1) (guaranteed by the BIBO-derived exponents for in-range
 // pixels); larger magnitudes raise GRK_AMD_ERR_UNSUPPORTED instead of producing other bytes.
+#include <atomic>
+#include <mutex>
 #include "kernels.h"
 #include "ht_vlc_tables.h"
 // the coded bytes are written once and read by nobody on the device: non-temporal stores
@@ -904,7 +906,8 @@ __global__ __launch_bounds__(64) void ht_encode_fallback_kernel(HtArgs a, HtLds 
 
 } // namespace
 
-static bool g_tables_ready[16] = {false};
+static std::atomic<bool> g_tables_ready[16];                 // (zero-initialised: false)
+static std::mutex g_tables_mu;                               // first use from several host threads at once (node workers on one device)
 static const uint32_t* g_vlc_tab_dev[16] = {nullptr};     // device address of g_vlc_enc per device (a kernel argument: a scalar base register)
 
 static hipError_t upload_tables()
@@ -968,14 +971,17 @@ static hipError_t ensure_tables(const uint32_t** tab = nullptr)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    if (!g_tables_ready[dev]) {
-        e = upload_tables();
-        if (e != hipSuccess) return e;
-        void* p = nullptr;
-        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_vlc_enc));
-        if (e != hipSuccess) return e;
-        g_vlc_tab_dev[dev] = static_cast<const uint32_t*>(p);
-        g_tables_ready[dev] = true;
+    if (!g_tables_ready[dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(g_tables_mu);
+        if (!g_tables_ready[dev].load(std::memory_order_relaxed)) {
+            e = upload_tables();
+            if (e != hipSuccess) return e;
+            void* p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_vlc_enc));
+            if (e != hipSuccess) return e;
+            g_vlc_tab_dev[dev] = static_cast<const uint32_t*>(p);
+            g_tables_ready[dev].store(true, std::memory_order_release);
+        }
     }
     if (tab) *tab = g_vlc_tab_dev[dev];
     return hipSuccess;

@@ -22,6 +22,8 @@
 //
 // Results equal the reference's on every stream a conforming encoder produces; streams the
 // reference rejects (bad Scup, U_q > missing_msbs) are rejected here as well.
+#include <atomic>
+#include <mutex>
 #include "kernels.h"
 #include "ht_vlc_tables.h"
 #include <type_traits>
@@ -807,7 +809,8 @@ hipError_t launch_dec_upload(const void* pinned, void* dst, size_t bytes, void* 
     return hipGetLastError();
 }
 
-static bool g_dec_tables_ready[16] = {false};
+static std::atomic<bool> g_dec_tables_ready[16];             // (zero-initialised: false)
+static std::mutex g_dec_tables_mu;                           // first use from several host threads at once
 
 hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s)
 {
@@ -820,7 +823,9 @@ hipError_t launch_ht_decode_front(const HtDecArgs& a, hipStream_t s)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 16 && !g_dec_tables_ready[dev]) {
+    if (dev < 16 && !g_dec_tables_ready[dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(g_dec_tables_mu);
+        if (!g_dec_tables_ready[dev].load(std::memory_order_relaxed)) {
         // the CxtVLC decode tables with what K5a's chain needs next to each entry (kernels above: g_vlc_dec2)
         static uint2 tab[2048];
         for (uint32_t i = 0; i < 2048; ++i) {
@@ -839,7 +844,8 @@ hipError_t launch_ht_decode_front(const HtDecArgs& a, hipStream_t s)
         }
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlc_dec2), tab, sizeof(tab), 0, hipMemcpyHostToDevice);
         if (e != hipSuccess) return e;
-        g_dec_tables_ready[dev] = true;
+        g_dec_tables_ready[dev].store(true, std::memory_order_release);
+        }
     }
     if (a.nactive == 0) return hipSuccess;
     // K5p: one wave per block with data

@@ -97,3 +97,39 @@ def test_long_decode_sequence_every_frame_equals_its_source(flights):
             assert np.array_equal(outs[slot].cpu().numpy().reshape(C, H, W), px), "slot %d" % slot
     finally:
         c.set_decode_pipelining(0)
+
+
+def test_two_host_threads_with_a_context_each():
+    """Contexts are independent: two host threads, each with a context of its own on the one device, encode and decode different
+    images at the same time (ctypes calls release the GIL) -- every result equals the single-threaded one."""
+    import threading
+    C, H, W, L = 3, 384, 512, 4
+    p = G.TileParams.make(W, H, C, 8, L)
+    imgs = [synth.g2(C, H, W, 8, seed=70 + i) for i in range(4)]
+    want = []
+    for im in imgs:
+        t, coded = U.ctx().encode_host(p, im)
+        want.append(U.split_blocks(t, coded))
+    errors = []
+
+    def worker(tid):
+        try:
+            c = G.Context(0)
+            for rep in range(12):
+                k = (tid + rep) % len(imgs)
+                t, coded = c.encode_host(p, imgs[k])
+                if U.split_blocks(t, coded) != want[k]:
+                    errors.append("thread %d rep %d: encode differs" % (tid, rep))
+                back = c.decode_host(p, t, coded)
+                if not np.array_equal(np.asarray(back).reshape(imgs[k].shape), imgs[k]):
+                    errors.append("thread %d rep %d: decode differs" % (tid, rep))
+            c.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append("thread %d: %r" % (tid, e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
