@@ -53,21 +53,48 @@ __device__ uint32_t g_vlc_enc[4096];
 //   entries 33,34: the 1-bit code (u-1) of the second quad in the first-row "u0>2, u1 in 1..2" mode
 __device__ uint2 g_uvlc[64];
 
+// The MEL coder runs on the scalar unit throughout -- its state never touches a vector register: the finished bytes collect in
+// ONE vector register, dword j in lane j (v_writelane from scalar registers), and reach LDS once, at the end (mel_flush).  With
+// lane 0 storing every finished byte to LDS (address and data of a ds_write are vector operands) the compiler kept the whole
+// state machine in vector registers: 3 363 vector instructions per block against 3 088 now, 1 556 scalar against 1 894.
+// (r03 measured this form at K3 = 0.34 ms, 27 % of a wave's time in s_waitcnt, and found no difference; at 0.27 ms, the waits
+//  gone and the kernel bound by its vector issue, it is 3-4 % of K3 and 1.5-2 % of the pipelined frame:
+//  profiles/r04_k3_scalar_mel.txt.)
 struct MelState {
     int run, k, acc, left;
     uint32_t pos;
+    uint32_t word;           // the bytes of dword pos / 4 finished so far (scalar)
+    uint32_t vec;            // lane j: dword j of the MEL bytes
 };
-
-__device__ __forceinline__ void mel_put_bit(MelState& m, uint8_t* buf, int v, bool writer)
+// v_writelane_b32 through its LLVM intrinsic (this clang has no builtin for it; the compiler places the lane select in M0 itself)
+extern "C" __device__ int grk_amd_writelane(int value, int lane_select, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ void mel_writelane(uint32_t& vec, uint32_t word, uint32_t lane_index)
+{
+    vec = (uint32_t)grk_amd_writelane(__builtin_amdgcn_readfirstlane((int)word), __builtin_amdgcn_readfirstlane((int)lane_index), (int)vec);
+}
+__device__ __forceinline__ void mel_put_byte(MelState& m, uint32_t byte)
+{
+    if (m.pos < 252) {
+        m.word |= byte << (8u * (m.pos & 3u));
+        if ((m.pos & 3u) == 3u) { mel_writelane(m.vec, m.word, m.pos >> 2); m.word = 0; }
+    }
+    m.pos++;
+}
+__device__ __forceinline__ void mel_put_bit(MelState& m, uint8_t*, int v, bool)
 {
     m.acc = (m.acc << 1) | v;
     if (--m.left == 0) {
-        if (writer && m.pos < 250) buf[m.pos] = (uint8_t)m.acc;   // valid streams stay < 128 bytes (:475)
-        m.pos++;
+        mel_put_byte(m, (uint32_t)m.acc & 0xFFu);
         m.left = (m.acc == 0xFF) ? 7 : 8;
         m.acc = 0;
     }
 }
+__device__ __forceinline__ void mel_flush(MelState& m, uint8_t* buf, int lane)
+{
+    if (m.pos < 252 && (m.pos & 3u)) mel_writelane(m.vec, m.word, m.pos >> 2);
+    reinterpret_cast<uint32_t*>(buf)[lane] = m.vec;
+}
+
 __device__ __forceinline__ void mel_event(MelState& m, uint8_t* buf, int one, bool writer)
 {
     const int e = (int)((kMelE >> (4 * m.k)) & 0xF);
@@ -355,7 +382,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     if (lane == 0) vlc_raw[0] = 0xF;             // vlc_init: four 1 bits pending (:315-318)
     __syncthreads();
 
-    MelState mel{0, 0, 0, 8, 0};
+    MelState mel{0, 0, 0, 8, 0, 0, 0};
     uint32_t ms_bits = 0, vlc_bits = 4;
     bool lds_full = false;
     uint32_t Bprev = 0xFFFFFFFFu;                // "all insignificant" row above the block
@@ -725,14 +752,14 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         if ((mel_mask | vlc_mask) != 0) {
             const int fuse = macc | (int)vacc;
             if ((((fuse ^ macc) & mel_mask) | ((fuse ^ (int)vacc) & vlc_mask)) == 0 && fuse != 0xFF && nv >= 1) {
-                if (lane == 0 && mel.pos < 250) mel_buf[mel.pos] = (uint8_t)fuse;
+                mel_put_byte(mel, (uint32_t)fuse & 0xFFu);
             } else {
-                if (lane == 0 && mel.pos < 250) mel_buf[mel.pos] = (uint8_t)macc;
+                mel_put_byte(mel, (uint32_t)macc & 0xFFu);
                 vextra = 1;
             }
-            mel.pos++;
         }
     }
+    mel_flush(mel, mel_buf, lane);
     const uint32_t mel_len = mel.pos;
     const uint32_t vcount = nv + vextra;
     const uint32_t scup = mel_len + vcount + 1;
