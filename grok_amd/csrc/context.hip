@@ -972,10 +972,16 @@ HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* 
     // arena: worst case of the HT cleanup pass is ~ (kmax+1)/8 * 8/7 bytes per sample + VLC/MEL;
     // twice the raw input size plus per-block slack covers every lossless case we accept
     const uint64_t raw = (uint64_t)ntiles * g.p.num_comps * g.p.tile_w * g.p.tile_h * ((g.p.prec + 7) / 8);
-    // allocation regions: enough to keep the per-address atomic rate off the critical path, few enough
-    // that small jobs do not spread over many mostly empty chunks
+    // Allocation regions: every block reserves its bytes with an atomic on its region's word, and the blocks of a launch that fits
+    // the machine in one round (up to ~6 000) all arrive there within microseconds of each other -- atomics on ONE address are
+    // served one after the other, and a chunk refill makes the region's other waves wait.  At least one region per 64 blocks (r04:
+    // with one per 256, K3 of a 2048^2 frame took 0.151 ms, with this 0.048; 1024^2 0.079 -> 0.038, 3072^2 0.177 -> 0.069; from
+    // 4096^2 on all 64 regions were in use before: tools/k3_sizes.py); small jobs take smaller chunks, so that the slack of the
+    // regions' half-used chunks stays small against their coded bytes.
+    static const uint32_t kBlocksPerRegion = getenv("GRK_AMD_BLOCKS_PER_REGION") ? (uint32_t)std::max(1, atoi(getenv("GRK_AMD_BLOCKS_PER_REGION"))) : 64u;
     uint32_t regions = 1;
-    while (regions < kHtAllocRegions && nblocks / (regions * 2) >= 256) regions *= 2;
+    while (regions < kHtAllocRegions && nblocks / (regions * 2) >= kBlocksPerRegion) regions *= 2;
+    const uint32_t chunk = nblocks < 16384 ? kHtAllocChunkSmall : kHtAllocChunk;
     try_(c->arena.ensure(raw * 2 + nblocks * 64 + (size_t)(regions + 1) * kHtAllocChunk + (1u << 20)), "alloc coded arena");
     a.mallat = (const int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems; a.h16 = h16 ? 1 : 0;
     a.blocks = (const HtBlockDesc*)c->blockdesc.p; a.blocks_per_tile = bpt; a.ncomp = g.p.num_comps; a.ntiles = ntiles;
@@ -985,6 +991,7 @@ HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* 
     try_(c->ovf.ensure(2 * nblocks * 4 + 16), "alloc fallback list");      // (every block is in two classes)
     a.ovf_list = c->lds_cap ? (uint32_t*)c->ovf.p : nullptr;
     a.region_mask = regions - 1;
+    a.chunk_units = chunk / 16u;
     a.irreversible = g.p.irreversible;
     a.num_classes = c->ht_num_classes;
     uint32_t ovf_base = 0;

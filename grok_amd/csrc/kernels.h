@@ -76,6 +76,7 @@ struct HtArgs {
                                                 // by the fallback launch.  nullptr: worst-case buffers, no fallback
     HtClass classes[kHtMaxClasses]; uint32_t num_classes;   // block classes of a tile (= resolutions, finest first), each launched on its own
     uint32_t region_mask;         // (power of two <= kHtAllocRegions) - 1: block i allocates from region i & mask
+    uint32_t chunk_units;         // 16-byte units a region takes from the shared cursor at a time (kHtAllocChunk / 16, or half of it for small jobs)
     const uint32_t* vlc_tab;      // the CxtVLC encode table on the device (set by launch_ht_classes)
     int irreversible;
 };
@@ -85,7 +86,8 @@ size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax);
 // was 10.8 % of K3's time (counters of a build that stops behind it), with 64 the 8K frame's K3 takes 0.30 instead of 0.315 ms and
 // the pipelined step 0.422 instead of 0.437 (128 / 256 words: the same; two words: 0.77 ms)
 constexpr uint32_t kHtAllocRegions = 64;           // region words available; a launch uses region_mask + 1 of them
-constexpr uint32_t kHtAllocChunk = 64u << 10;      // bytes a region takes from the shared cursor at a time (> the largest block)
+constexpr uint32_t kHtAllocChunk = 64u << 10;      // bytes a region takes from the shared cursor at a time (> twice the largest block)
+constexpr uint32_t kHtAllocChunkSmall = 32u << 10; // ... in a job of few blocks (the slack of half-used chunks counts there)
 constexpr size_t   kHtAllocBytes = 256u * (1u + kHtAllocRegions);   // 32 status / cursor / class words, then one 256-byte line per region word
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);          // allocator reset + every class
 hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s);

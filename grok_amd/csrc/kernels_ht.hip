@@ -112,6 +112,21 @@ __device__ __forceinline__ void mel_event(MelState& m, uint8_t* buf, int one, bo
     }
 }
 
+// n events "quad not significant" in a row: a run of 2^E[k] of them is one 1 bit, so the loop runs once per emitted bit, not once
+// per event -- an all-zero 64 x 64 block is 1 024 such events and ~45 bits (r04: K3 on an all-zero 4096^2 frame 0.68 ms, seven
+// times the time of real content, because every event went through the state machine by itself)
+__device__ __forceinline__ void mel_zero_run(MelState& m, uint8_t* buf, uint32_t n, bool writer)
+{
+    while (n) {
+        const uint32_t need = (1u << ((kMelE >> (4 * m.k)) & 0xF)) - (uint32_t)m.run;
+        if (n < need) { m.run += (int)n; return; }
+        mel_put_bit(m, buf, 1, writer);
+        m.run = 0;
+        if (m.k < 12) m.k++;
+        n -= need;
+    }
+}
+
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
     (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -304,18 +319,17 @@ __device__ __forceinline__ uint32_t count_vlc_events(const uint32_t* raw, uint32
 // compact extent [0, *cursor) with at most a block-sized gap at chunk ends.
 // Region word: bits 63..24 = chunk start / 16, bits 23..0 = 16-byte units used in the chunk.
 constexpr uint32_t kAllocRegions = kHtAllocRegions;
-constexpr uint32_t kChunkUnits = kHtAllocChunk / 16u;
 
-__global__ void ht_alloc_init_kernel(unsigned long long* flagbuf)
+__global__ void ht_alloc_init_kernel(unsigned long long* flagbuf, uint32_t chunk_units)
 {
     const uint32_t t = threadIdx.x;
     if (t < 32) flagbuf[t] = 0;                                 // [0] status flags, [1] cursor (bytes), [2 + class] blocks handed to the fallback launch
     // "chunk full" so that the first allocation refills; the start field holds a value no real chunk
     // has, otherwise waves waiting for the refill could not tell the first chunk (start 0) from this state
-    for (uint32_t r = t; r < kAllocRegions; r += blockDim.x) flagbuf[32 * (1 + r)] = (0xFFFFFFFFFFull << 24) | kChunkUnits;
+    for (uint32_t r = t; r < kAllocRegions; r += blockDim.x) flagbuf[32 * (1 + r)] = (0xFFFFFFFFFFull << 24) | chunk_units;
 }
 
-__device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* flagbuf, uint32_t region, uint32_t bytes)
+__device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* flagbuf, uint32_t region, uint32_t bytes, uint32_t kChunkUnits)
 {
     unsigned long long* word = flagbuf + 32 * (1 + region);
     const unsigned long long n = (bytes + 15u) >> 4;
@@ -662,10 +676,15 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             }
             Hm &= 0xFFFFFFFF00000000ull;
         }
+        // the events in quad order: the zero events up to the next significant quad as one run, then that quad's event
         while (Hm) {
-            const int i = __ffsll((long long)Hm) - 1;
-            mel_event(mel, mel_buf, (int)((V >> i) & 1), lane == 0);
-            Hm &= Hm - 1;
+            const uint64_t ones = Hm & V;
+            const uint64_t first = ones & (0 - ones);                  // the next significant quad with context 0 (0: none left)
+            const uint64_t before = first ? Hm & (first - 1) : Hm;
+            mel_zero_run(mel, mel_buf, (uint32_t)__builtin_popcountll(before), lane == 0);
+            if (!first) break;
+            mel_event(mel, mel_buf, 1, lane == 0);
+            Hm &= ~(first | (first - 1));
         }
     };
 
@@ -723,7 +742,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     //      Stuffing adds at most one bit per 15 raw bits; MEL grows by at most 2 more bytes.
     const uint32_t len_ub = (ms_bits + ms_bits / 15u) / 8u + (vlc_bits + vlc_bits / 15u) / 8u + mel.pos + 8u;
     unsigned long long base_off = 0;
-    if (lane == 0) base_off = arena_alloc(a.alloc, gid & a.region_mask, len_ub);
+    if (lane == 0) base_off = arena_alloc(a.alloc, gid & a.region_mask, len_ub, a.chunk_units);
 
     // ================= phase B: stuffing, termination, emission (oracle/ht_wave_model.c, orc_ht_model_phase_b2) =====
     // Byte stuffing only moves byte boundaries after rare events (MagSgn: the byte after a 0xFF has 7 bits; VLC: a byte after
@@ -1018,7 +1037,7 @@ hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s)
 {
     hipError_t e = ensure_tables();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ht_alloc_init_kernel, dim3(1), dim3(64), 0, s, a.alloc);
+    hipLaunchKernelGGL(ht_alloc_init_kernel, dim3(1), dim3(64), 0, s, a.alloc, a.chunk_units);
     return hipGetLastError();
 }
 
