@@ -85,7 +85,10 @@ size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax);
 // executes at the memory side, one after the other per word, and a block coder waits for its answer: with 16 words the round trip
 // was 10.8 % of K3's time (counters of a build that stops behind it), with 64 the 8K frame's K3 takes 0.30 instead of 0.315 ms and
 // the pipelined step 0.422 instead of 0.437 (128 / 256 words: the same; two words: 0.77 ms)
-constexpr uint32_t kHtAllocRegions = 64;           // region words available; a launch uses region_mask + 1 of them
+#ifndef GRK_HT_ALLOC_REGIONS
+#define GRK_HT_ALLOC_REGIONS 64
+#endif
+constexpr uint32_t kHtAllocRegions = GRK_HT_ALLOC_REGIONS;           // region words available; a launch uses region_mask + 1 of them
 constexpr uint32_t kHtAllocChunk = 64u << 10;      // bytes a region takes from the shared cursor at a time (> twice the largest block)
 constexpr uint32_t kHtAllocChunkSmall = 32u << 10; // ... in a job of few blocks (the slack of half-used chunks counts there)
 constexpr size_t   kHtAllocBytes = 256u * (1u + kHtAllocRegions);   // 32 status / cursor / class words, then one 256-byte line per region word
