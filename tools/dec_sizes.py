@@ -10,8 +10,6 @@ for S in [int(v) for v in os.environ.get("DEC_SIZES", "512,1024,1536,2048,2304,2
     enc = G.Context(0)
     d_px = torch.from_numpy(px.reshape(-1)).cuda()
     table, tot = enc.encode_tiles(p, 1, d_px.data_ptr(), True)
-    d_c = torch.empty(int(tot), dtype=torch.uint8, device="cuda")
-    d_c.copy_(torch.as_tensor(G.capi._dev_view(enc.coded_device_ptr(), int(tot)), device="cuda")) if hasattr(G.capi, "_dev_view") else None
     coded = enc.fetch_coded(tot)
     d_c = torch.from_numpy(np.frombuffer(bytes(coded), np.uint8).copy()).cuda()
     d_out = torch.zeros(3 * S * S, dtype=torch.uint8, device="cuda")
