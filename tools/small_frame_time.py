@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, grok_amd as G, synth
 stream = torch.cuda.Stream()
-for S, L in ((512, 3), (1024, 5), (2048, 5), (4096, 5)):
+sizes = [(int(v), 5 if int(v) >= 1024 else 3) for v in os.environ.get('SF_SIZES', '512,1024,2048,4096').split(',')]
+for S, L in sizes:
     px = synth.g2(3, S, S, 8)
     p = G.TileParams.make(S, S, 3, 8, L)
     d = torch.from_numpy(px.reshape(-1)).cuda()
