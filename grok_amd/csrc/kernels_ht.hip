@@ -653,15 +653,21 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         if (lds_full) return;
         // `narrow`: the exponent bounds every quad's four values to 64 bits.  Deep content (16-bit, quantised) is not bounded that
         // way but mostly is that small: one wave-uniform test of the pair sums takes the one-piece path whenever every lane's fit
-        if (narrow || !__ballot(max(m01, m23) > 32u)) {
-            const uint32_t v01 = vm[0] | (vm[1] << (M02 & 31u));
-            const uint32_t v23 = vm[2] | (vm[3] << m2);
-            or_bits64(ms_raw, mpos, (uint64_t)v01 | ((uint64_t)v23 << m01));
-        } else {
-            or_bits64(ms_raw, mpos, (uint64_t)vm[0] | ((uint64_t)vm[1] << (M02 & 0xFFFFu)));
-            or_bits64(ms_raw, mpos + m01, (uint64_t)vm[2] | ((uint64_t)vm[3] << m2));
+        // Only the lanes that have bits to put take part in the LDS atomics: a quad without MagSgn bits (nothing significant in it)
+        // sits at the SAME bit position as its neighbours, and 64 atomic ORs on one dword are served one after the other -- on
+        // flat content (every quad empty) that made K3 0.68 ms per 8K frame against 0.27 for real content, the waves waiting on
+        // LDS (SQ_LDS_ADDR_CONFLICT 198 M cycles per frame; profiles/r04_small_frames.txt).  Costs the dense case one compare each.
+        if ((packed & 0xFFFFu) != 0u) {
+            if (narrow || !__ballot(max(m01, m23) > 32u)) {
+                const uint32_t v01 = vm[0] | (vm[1] << (M02 & 31u));
+                const uint32_t v23 = vm[2] | (vm[3] << m2);
+                or_bits64(ms_raw, mpos, (uint64_t)v01 | ((uint64_t)v23 << m01));
+            } else {
+                or_bits64(ms_raw, mpos, (uint64_t)vm[0] | ((uint64_t)vm[1] << (M02 & 0xFFFFu)));
+                or_bits64(ms_raw, mpos + m01, (uint64_t)vm[2] | ((uint64_t)vm[3] << m2));
+            }
         }
-        or_bits32(vlc_raw, vpos, wv);
+        if (cl != 0u) or_bits32(vlc_raw, vpos, wv);
 
         // ---- MEL events (wave-uniform, scalar unit) ------------------------------------------------
         const uint64_t H = s.H, V = s.V;

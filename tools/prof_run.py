@@ -38,6 +38,8 @@ shape = {"8k": (3, S, S, 8, 5, 1, False), "8k_int32": (3, S, S, 8, 5, 1, False),
          "cfg3": (3, 8192, 8192, 16, 5, 1, True), "cfg4tile": (3, 1024, 1024, 8, 5, 64, False), "cfg4": (3, 1024, 1024, 8, 5, 256, False)}[wl]
 Cn, W, H, prec, L, nt, irrev = shape
 px = synth.g2(Cn, H, W, prec)
+if os.environ.get("PROF_FLAT"):                       # a flat frame of that value (K3's other extreme: nothing to code)
+    px = np.full_like(px, int(os.environ["PROF_FLAT"]))
 p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev)
 host = np.ascontiguousarray(np.broadcast_to(px.reshape(1, -1), (nt, px.size))).reshape(-1)
 d = torch.from_numpy(host.view(np.uint8).copy()).cuda()
