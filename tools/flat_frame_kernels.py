@@ -6,8 +6,23 @@ import numpy as np, torch, grok_amd as G, synth
 S = int(os.environ.get("FF_SIZE", "8192"))
 p = G.TileParams.make(S, S, 3, 8, 5)
 nb = G.lib().grk_amd_tile_num_blocks(p)
-for name, px in (("G2", synth.g2(3, S, S, 8)), ("all zero", np.zeros((3, S, S), np.uint8)), ("all 255", np.full((3, S, S), 255, np.uint8)),
-                 ("all 128", np.full((3, S, S), 128, np.uint8)), ("all 129", np.full((3, S, S), 129, np.uint8))):
+def cases():
+    g = synth.g2(3, S, S, 8)
+    yield "G2", g
+    yield "all zero", np.zeros((3, S, S), np.uint8)
+    yield "all 128", np.full((3, S, S), 128, np.uint8)
+    h = g.copy(); h[:, S // 2:, :] = 40
+    yield "half flat", h
+    sp = np.full((3, S, S), 90, np.uint8); sp[:, ::97, :] = 200; sp[:, :, ::131] = 30          # flat with thin lines
+    yield "flat + lines", sp
+    sm = (np.add.outer(np.arange(S), np.arange(S)) // 64 % 256).astype(np.uint8)                 # a slow ramp: smooth, no noise
+    yield "ramp", np.ascontiguousarray(np.broadcast_to(sm, (3, S, S)))
+    rng = np.random.default_rng(5)
+    yield "noise +-2 on 100", (100 + rng.integers(-2, 3, (3, S, S))).astype(np.uint8)
+    yield "noise full", rng.integers(0, 256, (3, S, S), dtype=np.uint8)
+
+
+for name, px in cases():
     ctx = G.Context(0); ctx.set_overlap(False)
     d = torch.from_numpy(px.reshape(-1)).cuda()
     for _ in range(3):
@@ -20,5 +35,5 @@ for name, px in (("G2", synth.g2(3, S, S, 8)), ("all zero", np.zeros((3, S, S), 
     k3 = sum(m * c for m, c in parts) / max(max(x[1] for x in parts), 1)
     t, tot = ctx.fetch_table(nb)
     nz = int((t["length"] > 0).sum())
-    print("%-10s K3 %.4f ms  DWT %.4f ms  %d of %d blocks carry bytes, %d coded bytes" % (name, k3, ctx.kernel_ms(1)[0], nz, nb, tot))
+    print("%-18s K3 %.4f ms  DWT %.4f ms  %d of %d blocks carry bytes, %d coded bytes" % (name, k3, ctx.kernel_ms(1)[0], nz, nb, tot))
     ctx.close()
