@@ -857,6 +857,17 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             if (lane == 0) out[j] = (uint8_t)b7;
             j += 1u;
             s = p7 + 7u;
+            // A run of 0xFF bytes (flat areas whose MagSgn values are all ones: pixel value 0 is -128 after the DC shift -- the LL
+            // band of a black frame is nothing else): every one of them is an event, and an event through the window above costs
+            // a 256-byte look.  While the NEXT byte is 0xFF again and its 7-bit follower is whole, take the pair with one 15-bit
+            // look (r04: K3 of an all-zero 8K frame 0.59 ms, all of it this loop in 48 LL blocks; profiles/r04_small_frames.txt);
+            // everything else -- the stream's end, a partial follower -- goes back through the general path.
+            while (s + 15u <= ms_bits) {
+                const uint32_t two = (uint32_t)__builtin_amdgcn_readfirstlane((int)get_bits(ms_raw, s, 15u));
+                if ((two & 0xFFu) != 0xFFu) break;
+                if (lane == 0) { out[j] = 0xFFu; out[j + 1u] = (uint8_t)(two >> 8); }
+                j += 2u; s += 15u;
+            }
         }
         if (!done) {
             const uint32_t rem = ms_bits - s;

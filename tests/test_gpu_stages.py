@@ -138,6 +138,23 @@ def test_encode_tile_blocks_vs_oracle(C, H, W, prec, L, gen):
     assert not bad, "blocks differing from oracle: %s" % bad[:10]
 
 
+@pytest.mark.parametrize("value", [0, 1, 16, 127, 128, 129, 255])
+@pytest.mark.parametrize("C,H,W,L", [(3, 256, 384, 2), (1, 512, 512, 3)])
+def test_flat_frames_blocks_vs_oracle(value, C, H, W, L):
+    """A frame of ONE value: every band but LL is empty (quads without bits: the lanes that stay out of the LDS atomics), and LL is
+    a constant -- for value 0 that is -128, MagSgn bytes 0xFF throughout: the run form of the stuffing step, block after block."""
+    px = np.full((C, H, W), value, np.uint8)
+    p = G.TileParams.make(W, H, C, 8, L)
+    table, coded = U.ctx().encode_host(p, px)
+    got = U.split_blocks(table, coded)
+    blocks, lens, ocoded = O.encode_tile_rev(px, 8, L)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    bad = [i for i in range(len(blocks)) if got[i] != bytes(ocoded[off[i]:off[i + 1]])]
+    assert not bad, "blocks differing from oracle: %s" % bad[:10]
+    back = U.ctx().decode_host(p, table, coded)
+    assert np.array_equal(np.asarray(back).reshape(px.shape), px)
+
+
 # ---- whole files: HIP hot path + product Tier-2 == Grok's CPU encoder output (golden md5 / fixtures)
 import hashlib
 import os
