@@ -6,7 +6,11 @@ import numpy as np, torch, grok_amd as G, synth
 S = 8192
 p = G.TileParams.make(S, S, 3, 8, 5)
 for name, px in (("G2", synth.g2(3, S, S, 8)), ("all zero", np.zeros((3, S, S), np.uint8)), ("all 128", np.full((3, S, S), 128, np.uint8)),
-                 ("half flat", np.concatenate([synth.g2(3, S // 2, S, 8), np.full((3, S // 2, S), 40, np.uint8)], axis=1))):
+                 ("half flat", np.concatenate([synth.g2(3, S // 2, S, 8), np.full((3, S // 2, S), 40, np.uint8)], axis=1)),
+                 ("noise +-2", (100 + np.random.default_rng(5).integers(-2, 3, (3, S, S))).astype(np.uint8))):
+    # (full-range noise is outside the format's dynamic-range contract: its RCT chroma exceeds the bands' Kmax, the encoder's blocks
+    #  equal the oracle encoder's and BOTH decoders -- ours and the reference's ojph_decode_codeblock -- reject them:
+    #  tools/noise_block_bisect.py)
     px = np.ascontiguousarray(px)
     enc = G.Context(0)
     d_px = torch.from_numpy(px.reshape(-1)).cuda()
