@@ -385,6 +385,36 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
         c32.close()
     except Exception as e:  # noqa: BLE001
         out["8k_int32"] = {"error": str(e)}
+    # What the content does to the headline shape: frames with nothing in them (one value: every band but LL empty) and the all-zero
+    # frame (LL = -128: MagSgn bytes 0xFF throughout) against the G2 frame of the headline, pipelined as the headline is -- r04 found
+    # and removed two cliffs here (empty quads' LDS atomics on one address, one stuffing event per window look: a flat frame cost
+    # 0.80 ms, a black one 1.18; profiles/r04_small_frames.txt)
+    try:
+        Cn, W, H, prec, levels, ntiles, _ = WORKLOADS["8k"]
+        p8 = G.TileParams.make(W, H, Cn, prec, levels)
+        flat = {}
+        for name, val in (("all_zero", 0), ("all_128", 128)):
+            d_f = torch.full((Cn * H * W,), val, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)
+            ctx.set_overlap(True); ctx.set_pipelining(True)
+            with torch.cuda.stream(stream):
+                for _ in range(8):
+                    ctx.encode_tiles(p8, 1, d_f.data_ptr(), True, fetch=False)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                for _ in range(2 * steps):
+                    ctx.encode_tiles(p8, 1, d_f.data_ptr(), True, fetch=False)
+            torch.cuda.synchronize(dev)
+            msf = (time.perf_counter() - t0) / (2 * steps) * 1e3
+            ctx.set_pipelining(False)
+            tf, _ = ctx.fetch_table(G.lib().grk_amd_tile_num_blocks(C.byref(p8)))
+            flat[name] = {"ms_per_step": round(msf, 4), "value": round(W * H / msf / 1e3, 1), "unit": "Mpixels/s",
+                          "coded_bytes": int(tf["length"].astype(np.int64).sum())}
+            del d_f
+        out["flat_8k"] = dict(flat, workload="8192x8192x3 8-bit frames of one value, the headline's settings")
+    except Exception as e:  # noqa: BLE001
+        out["flat_8k"] = {"error": str(e)}
     if cfg5 is not None:
         try:
             import j2kparse as J

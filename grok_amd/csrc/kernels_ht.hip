@@ -656,7 +656,8 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         // Only the lanes that have bits to put take part in the LDS atomics: a quad without MagSgn bits (nothing significant in it)
         // sits at the SAME bit position as its neighbours, and 64 atomic ORs on one dword are served one after the other -- on
         // flat content (every quad empty) that made K3 0.68 ms per 8K frame against 0.27 for real content, the waves waiting on
-        // LDS (SQ_LDS_ADDR_CONFLICT 198 M cycles per frame; profiles/r04_small_frames.txt).  Costs the dense case one compare each.
+        // LDS (SQ_LDS_ADDR_CONFLICT 198 M cycles per frame; profiles/r04_small_frames.txt).  Costs the dense case one compare each: K3 +0.7 % on the headline
+        // frame, A/B on one box.
         if ((packed & 0xFFFFu) != 0u) {
             if (narrow || !__ballot(max(m01, m23) > 32u)) {
                 const uint32_t v01 = vm[0] | (vm[1] << (M02 & 31u));
