@@ -133,6 +133,29 @@ def cpu_baseline(rank_threads, want_cfg5=True):
                "file_md5": __import__("hashlib").md5(cs8).hexdigest(),
                "cfg2": {"value": round(4096 * 4096 / med4 / 1e6, 2), "unit": "Mpixels/s",
                         "sample": "%d x 4096x4096x3 8-bit, same settings" % n4}}
+        # BASELINE configs[0]: 512 x 512 mono, 3 levels -- the reference's own test_tile_encoder case (too small for its thread pool)
+        try:
+            px1 = synth.g2(1, 512, 512, 8)
+            t1 = sorted(R.encode(px1, 8, numres=4)[1] for _ in range(9))
+            out["cfg1"] = {"value": round(512 * 512 / t1[len(t1) // 2] / 1e6, 2), "unit": "Mpixels/s",
+                           "sample": "9 x 512x512x1 8-bit, 5/3 HTJ2K 3 levels (grk_compress_tile), median"}
+        except Exception as e:  # noqa: BLE001
+            out["cfg1"] = {"value": None, "error": str(e)}
+        # BASELINE configs[3] in the two forms BASELINE.md section 3 plans, on a bounded sample of the image: 16 of its 256 tiles
+        # (a 4096 x 4096 x 3 image as 1024 x 1024 tiles -- per-tile work and tile-level parallelism are the 16384^2 image's, and the
+        # whole image would take a minute of CPU time per run): (a) the grk_compress_tile loop (the reference test's sequence: tiles one
+        # after the other, each with the library's thread pool inside), (b) grk_compress() over the image (tiles as pooled tasks,
+        # codestream/CodeStreamCompress.cpp:535-603)
+        try:
+            px4 = synth.g2(3, 4096, 4096, 8)
+            forms = {}
+            for form, mode in (("grk_compress_tile_loop", 0), ("grk_compress_tile_parallel", 1)):
+                ts = sorted(R.encode(px4, 8, TW=1024, TH=1024, numres=6, mode=mode)[1] for _ in range(3))
+                forms[form] = {"value": round(4096 * 4096 / ts[1] / 1e6, 2), "unit": "Mpixels/s"}
+            out["cfg4"] = dict(forms, sample="3 x 16 tiles of 1024x1024x3 8-bit (a 4096x4096 image: 1/16 of configs[3]'s 256 tiles), "
+                                              "RCT+5/3 HTJ2K 5 levels, median, %d threads" % rank_threads)
+        except Exception as e:  # noqa: BLE001
+            out["cfg4"] = {"value": None, "error": str(e)}
         # the decode direction beside it: grk_decompress of the codestream just produced
         try:
             dts = []
@@ -354,9 +377,13 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
     9/7 DWT family against the HBM roofline (north_star's >= 40 % target), the cfg4 tiling and the whole cfg4 image (256
     tiles) at N = 1, the 8K workload at the reference's int32 width, and the cfg5 decode."""
     out = {}
-    for name in ("cfg2", "cfg3", "cfg4tile"):
+    for name in ("cfg1", "cfg2", "cfg3", "cfg4tile"):
         Cn, W, H, prec, levels, ntiles, desc = WORKLOADS[name]
-        out[name] = _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, desc, name == "cfg3", name)
+        try:
+            out[name] = _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, desc, name == "cfg3",
+                                         None if name == "cfg1" else name)
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)}
     # BASELINE configs[3] whole: 16384 x 16384 as 256 tiles of 1024 x 1024 on ONE GPU (the N = 1 point of its scaling curve)
     try:
         out["cfg4"] = _encode_workload(ctx, dev, stream, max(3, steps // 2), 3, 1024, 1024, 8, 5, 256,
@@ -661,6 +688,11 @@ def via_grok_plugin(ctx, params, tile_pixels, prec, cpu_file_md5=None):
         return {"error": str(e)}
 
 
+# (no measured N > 1 run stands behind these: 4 channels per peer at ~15-25 GB/s each saturate one link pair, 8 per communicator
+#  bound a gather's workgroups to 8 CUs; reported in multi_gpu.rccl_env so that the first real run can be read against them)
+RCCL_ENV_DEFAULTS = {"NCCL_MAX_NCHANNELS": "8", "NCCL_NCHANNELS_PER_PEER": "4"}
+
+
 def launch_ranks(n, dry_run):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks, one per GPU, under
     torch.distributed.run on 127.0.0.1 (what the driver's own N > 1 command does).  Returns the launcher's exit code; the
@@ -685,6 +717,33 @@ def launch_ranks(n, dry_run):
     return subprocess.call(cmd, env=env)
 
 
+def start_gather_watchdog(timeout, out, emit, rc):
+    """The gather regions run LAST and under this timer: if a transfer never completes, rank 0 still prints the line -- with the
+    counts figures it already holds and exchange.gather = {"error": ...} -- and every rank leaves with exit code `rc`
+    (--gather-timeout-rc, default 0: the line carries the failure; non-zero for callers that want the process status to say it)."""
+    import threading
+
+    def bail():
+        if out is not None:
+            out.setdefault("exchange", {})["gather"] = {"error": "the gather regions did not complete within %.0f s" % timeout}
+            emit(out)
+        os._exit(rc)
+    dog = threading.Timer(timeout, bail)
+    dog.daemon = True
+    dog.start()
+    return dog
+
+
+def _emit(o):
+    # RCCL writes a version banner to stdout through C stdio: flush that first so that the JSON line is the LAST line on stdout
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if o is not None:
+        print(json.dumps(o), flush=True)
+
+
 def dry_run(world, rank, args):
     """The launch path without kernels: the ranks form a gloo group, meet at the barrier and count each other."""
     arrived = 1
@@ -697,13 +756,24 @@ def dry_run(world, rank, args):
         arrived = int(t.item())
         n_group = dist.get_world_size()
         dist.barrier()
-        dist.destroy_process_group()
     else:
         n_group = 1
+    line = {"metric": "encode Mpixels/s (whole node), 8K RGB HTJ2K lossless", "value": None, "unit": "Mpixels/s",
+            "dry_run": True, "n_gpus": n_group, "ranks_at_barrier": arrived, "steps": args.steps,
+            "warmup": args.warmup, "backend": "gloo"}
+    if world > 1 and args.dry_run_stall >= 0:
+        # the watchdog path without a GPU: the "counts" phase above is done, now a "gather" in which one rank never arrives
+        line["exchange"] = {"counts": {"ranks": arrived}, "gather": None}
+        start_gather_watchdog(args.gather_timeout, line if rank == 0 else None, _emit, args.gather_timeout_rc)
+        if rank == args.dry_run_stall:
+            time.sleep(3600)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)                       # (never completes: a peer is missing)
+        time.sleep(3600)
+    if world > 1:
+        dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "encode Mpixels/s (whole node), 8K RGB HTJ2K lossless", "value": None, "unit": "Mpixels/s",
-                          "dry_run": True, "n_gpus": n_group, "ranks_at_barrier": arrived, "steps": args.steps,
-                          "warmup": args.warmup, "backend": "gloo"}), flush=True)
+        print(json.dumps(line), flush=True)
     return 0
 
 
@@ -720,6 +790,8 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not take the HBM-traffic counters in this run (two short rocprofv3 --pmc passes of the headline "
                          "workload, ~20 s); the committed summaries under profiles/ are quoted instead")
+    ap.add_argument("--region-repeats", type=int, default=5,
+                    help="the timed region (warm-up + steps) is run this many times; ms_per_step is the median region / steps")
     ap.add_argument("--no-overlap", action="store_true",
                     help="every kernel alone on the GPU, also in the timed region (what the rocprofv3 kernel-trace summary "
                          "that the roofline durations are checked against is taken with)")
@@ -728,12 +800,16 @@ def main():
                          "line): 'gather' = every rank's coded tile-parts (exact sizes) over xGMI to the frame's writer rank, "
                          "which rotates with the frame number, --gather-depth frames in flight; 'counts' = all_gather of the coded "
                          "byte counts only (parallel writers: the bytes leave each GPU over its own PCIe link)")
-    ap.add_argument("--gather-depth", type=int, default=4,
+    ap.add_argument("--gather-depth", type=int, default=4, choices=range(1, 6),
                     help="gathers in flight at once (each on its own communicator and stream; a gather is issued two frames behind "
                          "the encoder, which then rotates depth + 3 buffer sets)")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="N > 1: seconds the gather regions may take before the line is printed without them (a transfer that "
                          "never completes must not cost the run its counts figure)")
+    ap.add_argument("--gather-timeout-rc", type=int, default=0,
+                    help="exit code of every rank when the gather watchdog fires (the line is printed first, with the counts figures)")
+    ap.add_argument("--dry-run-stall", type=int, default=-1,
+                    help="with --dry-run: after the barrier this rank never joins the next collective -- the gather watchdog's path")
     ap.add_argument("--cfg5-sequence", nargs=4, metavar=("CODESTREAM", "REF_NPY", "S", "DEVICE"), default=None,
                     help="(internal) child process of the cfg5 leg: the Part-1 stream as a sequence with 2, 3 and 6 frames in flight")
     ap.add_argument("--dry-run", action="store_true",
@@ -758,6 +834,11 @@ def main():
     # GROK_AMD_FORCE_DIST=1 exercises the exchange step on a 1-GPU box (world_size 1 over RCCL)
     use_dist = world > 1 or os.environ.get("GROK_AMD_FORCE_DIST") == "1"
     if use_dist:
+        # RCCL's footprint, bounded unless the caller says otherwise: a gather is a point-to-point transfer over ONE xGMI link pair, depth
+        # of them run side by side on communicators of their own next to a coder that wants every CU -- a channel is a workgroup
+        # that holds a CU, and the default (up to 32 per communicator) is sized for ring collectives over all links at once
+        for k, v in RCCL_ENV_DEFAULTS.items():
+            os.environ.setdefault(k, v)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:                      # (a launcher sets it; the forced world-1 run picks a free one)
             import socket
@@ -802,7 +883,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def run_frames(prm, nt, d_pixels, nblk, exchange, steps, warmup):
+    def run_frames(prm, nt, d_pixels, nblk, exchange, steps, warmup, gather_depth=None):
         """`warmup` + `steps` frames of `nt` tiles on this rank, each followed by `exchange` (None / "counts" / "gather");
         consecutive frames are pipelined (the next frame's DWT runs while this one's blocks are still being coded and its
         tile-parts travel).  Returns (seconds for `steps` frames, MAX over ranks; the gathered parts of the last frame on its
@@ -812,7 +893,7 @@ def main():
         pipe = [None]
         cbuf = [None, None]
 
-        depth, lag = max(1, args.gather_depth), 2
+        depth, lag = max(1, gather_depth or args.gather_depth), 2
 
         def one(f):
             with torch.cuda.stream(stream):
@@ -892,13 +973,23 @@ def main():
         rot.append(torch.from_numpy(h2.view(np.uint8)).to(dev))
         del t2, h2
     run_frames(params, ntiles, rot, nblocks, exchange, PREWARM, 0)      # (the same frames, the same exchange: every path warm)
-    dt, last_parts, last_root = run_frames(params, ntiles, rot, nblocks, exchange, args.steps, args.warmup)
+    # The timed region (W warm-up + exactly K steps between barriers) is 8 ms long at 8K: it runs REGION_REPEATS times and the
+    # line reports the MEDIAN region (config.region_repeats carries every one), so that a 1 % A/B means something
+    regions = []
+    for _ in range(max(1, args.region_repeats)):
+        dt_r, last_parts, last_root = run_frames(params, ntiles, rot, nblocks, exchange, args.steps, args.warmup)
+        regions.append(dt_r)
+    dt = sorted(regions)[len(regions) // 2]
     dt_single, _, _ = run_frames(params, ntiles, d_px, nblocks, exchange, args.steps, args.warmup)
     multi_gpu = None
     cs_len = 0
     if use_dist:
-        multi_gpu = {"world_size": dist.get_world_size(), "backend": "nccl (RCCL %s)" % ".".join(str(v) for v in torch.cuda.nccl.version()),
-                     "gather_depth": args.gather_depth}
+        seen = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(seen)                      # every rank that is really in the RCCL group adds its one
+        multi_gpu = {"world_size": dist.get_world_size(), "ranks_seen_by_rccl": int(seen.item()),
+                     "backend": "nccl (RCCL %s)" % ".".join(str(v) for v in torch.cuda.nccl.version()),
+                     "gather_depth": args.gather_depth,
+                     "rccl_env": {k: os.environ.get(k) for k in sorted(set(RCCL_ENV_DEFAULTS) | {"NCCL_MIN_NCHANNELS", "GPU_MAX_HW_QUEUES"})}}
         multi_gpu["replica_%s" % args.workload] = {
             "shape": "one %dx%d tile per rank and frame (a %dx%d frame), weak scaling" % (W, H, W * world, H) if ntiles == 1 else desc,
             "gather": None,
@@ -969,7 +1060,7 @@ def main():
         dalgo = {"ht_cleanup_decode": ht_bytes(samples, b_pl_d, coded_sum_d),
                  "idwt53_5levels": idwt_bytes(samples, b_in_d, b_pl_d, levels, dk["egress_mct"][1] == 0),
                  "egress_mct": samples * (4.0 + b_in_d)}
-        dtraffic = {"ht_cleanup_decode": _pmc_traffic(args.workload, ("ht_dec_prep_kernel", "ht_dec_vlc_kernel", "ht_dec_ms_kernel")),
+        dtraffic = {"ht_cleanup_decode": _pmc_traffic(args.workload, ("ht_dec_vlc_kernel", "ht_dec_ms_kernel")),
                     "idwt53_5levels": _pmc_traffic(args.workload, ("idwt_last_level_fused", "idwt_level_kernel")), "egress_mct": None}
         decode = {"value": round(pixels_per_step * dsteps / ddt / 1e6, 1), "unit": "Mpixels/s",
                   "ms_per_step": round(ddt / dsteps * 1e3, 4), "steps": dsteps, "lossless_round_trip": (bool(torch.equal(d_back, d_px)) if not irrev else None),
@@ -1197,6 +1288,9 @@ def main():
                        "coded_bytes_per_gpu": coded_sum, "arena_bytes_used_per_gpu": int(total), "packed_dwt_levels": pk_levels,
                        "generator": "G2 (SURVEY.md §8d)", "parallelism": parallelism, "prewarm_steps": PREWARM,
                        "input_frames_in_rotation": len(rot),
+                       "region_repeats": {"n": len(regions), "ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
+                                          "median": round(dt / args.steps * 1e3, 4), "min": round(min(regions) / args.steps * 1e3, 4),
+                                          "max": round(max(regions) / args.steps * 1e3, 4)},
                        "single_input_buffer_ms_per_step": round(dt_single / args.steps * 1e3, 4)},
             "roofline": roofline,
             # the whole step against the HBM roofline: algorithmic bytes of its kernel families as launched, and what the PMC
@@ -1238,37 +1332,31 @@ def main():
     else:
         out = None
 
-    def emit(o):
-        # RCCL writes a version banner to stdout through C stdio: flush that first so that the JSON line is the LAST line on stdout
-        try:
-            C.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        if o is not None:
-            print(json.dumps(o), flush=True)
+    emit = _emit
 
     if use_dist:
         # ---- the gather regions, last and under a watchdog (see above): frame f's tile-parts to rank f mod N, depth frames in flight
-        import threading
         rep = multi_gpu["replica_%s" % args.workload]
         if out is not None:
             out["exchange"] = {"counts": rep["counts"], "gather": None}
             out["config"]["headline_exchange"] = "counts"
 
-        def bail():
+        dog = start_gather_watchdog(args.gather_timeout, out, emit, args.gather_timeout_rc)
+        # the gather with 1, 2 and 4 frames' transfers in flight (the depth asked for last: its figure is the line's): the first run
+        # on real links shows the TREND, not one number
+        by_depth = {}
+        g8 = None
+        for dpt in sorted(set([1, 2, 4]) - {args.gather_depth}) + [args.gather_depth]:
+            gw = max(args.warmup, 2 * (dpt + 3) + 2)
+            dtg, parts_g, root_g = run_frames(params, ntiles, rot, nblocks, "gather", args.steps, gw, gather_depth=dpt)
+            cs_len = assembled_bytes(params, ntiles, nblocks, W * world if ntiles == 1 else 0, H, parts_g, root_g)
+            g8 = {"ms_per_step": round(dtg / args.steps * 1e3, 4), "Mpixels_s": round(pixels_per_step * world * args.steps / dtg / 1e6, 1),
+                  "assembled_codestream_bytes": cs_len, "gather_depth": dpt}
+            by_depth[str(dpt)] = {"ms_per_step": g8["ms_per_step"], "Mpixels_s": g8["Mpixels_s"]}
             if out is not None:
-                out["exchange"]["gather"] = {"error": "the gather regions did not complete within %.0f s" % args.gather_timeout}
-                emit(out)
-            os._exit(0 if out is not None else 0)
-        dog = threading.Timer(args.gather_timeout, bail)
-        dog.daemon = True
-        dog.start()
-        # (every buffer set of the rotation exists and every communicator has carried a frame before the timed frames)
+                out["exchange"]["gather_by_depth"] = dict(by_depth)     # (what the watchdog prints if a later depth never completes)
+        g8["by_depth"] = by_depth
         gw = max(args.warmup, 2 * (args.gather_depth + 3) + 2)
-        dtg, parts_g, root_g = run_frames(params, ntiles, rot, nblocks, "gather", args.steps, gw)
-        cs_len = assembled_bytes(params, ntiles, nblocks, W * world if ntiles == 1 else 0, H, parts_g, root_g)
-        g8 = {"ms_per_step": round(dtg / args.steps * 1e3, 4), "Mpixels_s": round(pixels_per_step * world * args.steps / dtg / 1e6, 1),
-              "assembled_codestream_bytes": cs_len}
         g4 = None
         if cfg4 is not None:
             p4, nt4, d4, nb4, st4 = cfg4

@@ -123,6 +123,8 @@ def lib():
         if hasattr(L, "grk_amd_set_decode_pipelining"):
             L.grk_amd_set_decode_pipelining.argtypes = [vp, i32]
         L.grk_amd_stream_wait_results.argtypes = [vp, vp]
+        if hasattr(L, "grk_amd_decode_stream_wait_slot"):
+            L.grk_amd_decode_stream_wait_slot.argtypes = [vp, vp]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
         L.grk_amd_enable_timing.argtypes = [vp, i32]
         L.grk_amd_kernel_ms.restype = C.c_double
@@ -434,12 +436,17 @@ class Context:
         self._check(self._L.grk_amd_stream_wait_results(self._h, C.c_void_p(hip_stream)), "stream_wait_results")
 
     def set_decode_pipelining(self, frames_in_flight):
-        """2..4: consecutive decode_device calls run on that many internal buffer / stream sets in turn (0 / 1: off)"""
+        """2..8: consecutive decode_device calls run on that many internal buffer / stream sets in turn (0 / 1: off)"""
         self._check(self._L.grk_amd_set_decode_pipelining(self._h, int(frames_in_flight)), "set_decode_pipelining")
 
     def set_pipelining(self, on):
         """False / True (two buffer sets) / 2 (three: results valid until the third next call)."""
         self._check(self._L.grk_amd_set_pipelining(self._h, int(on)), "set_pipelining")
+
+    def decode_stream_wait_slot(self, stream_handle):
+        """Makes that stream wait until the internal set the NEXT decode call uses has finished its last frame: the buffers handed
+        over `frames in flight` calls ago may then be overwritten / read on it (include/grok_amd.h: buffer lifetime in a sequence)."""
+        self._check(self._L.grk_amd_decode_stream_wait_slot(self._h, C.c_void_p(stream_handle)), "decode_stream_wait_slot")
 
     def set_decode_planes16(self, on):
         self._check(self._L.grk_amd_set_decode_planes16(self._h, int(on)), "set_decode_planes16")

@@ -102,7 +102,7 @@ struct grk_amd_ctx {
     std::string err;
     // working set
     DevBuf pixels, p0, p1, llA, llB, blockdesc, lengths, offsets, arena, flag;
-    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels, dec_work, dec_vraw;
+    DevBuf dec_desc, dec_table, dec_quads, dec_mslen, dec_coded, dec_pixels, dec_work;
     // geometry cache
     grk_amd_tile_params gp{};
     bool have_geom = false;
@@ -162,6 +162,7 @@ struct grk_amd_ctx {
     std::vector<grk_amd_ctx*> dec_kids;
     uint32_t dec_seq = 0;
     hipEvent_t ev_seq = nullptr;
+    hipEvent_t ev_frame_done = nullptr;   // (an internal context of a sequence) behind the last frame it was given: grk_amd_decode_stream_wait_slot
     int t1_lanes = 1;                    // 0: never, 1: where the cost model below says they are faster, 2: wherever they can (tests)
     float t1_tail_ratio = 0.25f;
     float t1_tail_share = 0.0f;          // ... and at least this share of the blocks (the longest ones) to K8 as well
@@ -714,36 +715,28 @@ int run_ht_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
     const uint64_t nblocks = (uint64_t)bpt * ntiles;
     const grk_amd_coded_block* const table = (const grk_amd_coded_block*)up->p;
     uint32_t max_len = 0;
-    // per block: where K5p puts its un-stuffed MEL / VLC bits (scratch words); behind that the blocks that have data at all --
-    // K5p's waves and K5a's lanes (a window's skipped blocks and absent blocks cost neither a wave nor a lane of a serial chain)
-    uint32_t* const h_vbase = (uint32_t*)(up->p + nblocks * sizeof(grk_amd_coded_block));
-    uint64_t vwords = 0;
+    // behind the rows: the blocks that have data at all -- K5a's lanes (a window's skipped blocks and absent blocks do not cost a
+    // lane of a serial chain)
+    uint32_t* const h_active = (uint32_t*)(up->p + nblocks * sizeof(grk_amd_coded_block));
     uint32_t nactive = 0;
     for (uint64_t i = 0; i < nblocks; ++i) {
         max_len = std::max(max_len, table[i].length);
         if (table[i].offset > coded_bytes || table[i].length > coded_bytes - table[i].offset)
             return fail(c, GRK_AMD_ERR_INVALID, "block table row points outside the coded buffer");
-        h_vbase[i] = (uint32_t)vwords;
-        if (table[i].length) {
-            vwords += ht_dec_scratch_words(table[i].length);
-            h_vbase[nblocks + nactive++] = (uint32_t)i;
-        }
+        if (table[i].length) h_active[nactive++] = (uint32_t)i;
     }
     if (max_len > (48u << 10)) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "code-block longer than 48 KiB");
-    if (vwords > 0xFFFFFFF0ull) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "more than 8 GB of coded data in one call");
     static_assert(sizeof(HtDecBlock) == sizeof(grk_amd_coded_block), "decode table rows are grk_amd_coded_block");
-    HIP_TRY(c, c->dec_vraw.ensure((vwords + 64) * 4), "alloc VLC / MEL scratch");
     HIP_TRY(c, c->dec_quads.ensure(nblocks * 1024 * 2 + 64), "alloc quad info");
     HIP_TRY(c, c->dec_mslen.ensure(nblocks * 4), "alloc ms lengths");
-    { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock) + (nblocks + nactive) * 4); if (rc) return rc; }
-    const uint32_t* const d_vbase = (const uint32_t*)((const char*)c->dec_table.p + nblocks * sizeof(HtDecBlock));
+    { const int rc = upload_table(c, up, nblocks * sizeof(HtDecBlock) + (size_t)nactive * 4); if (rc) return rc; }
+    const uint32_t* const d_active = (const uint32_t*)((const char*)c->dec_table.p + nblocks * sizeof(HtDecBlock));
     HtDecArgs a{};
     a.table = (const HtDecBlock*)c->dec_table.p;
     a.blocks = (const HtBlockDesc*)c->dec_desc.p; a.blocks_per_tile = bpt; a.nblocks = (uint32_t)nblocks; a.ncomp = g.p.num_comps;
     a.coded = (const uint8_t*)d_coded; a.coded_bytes = coded_bytes;
     a.quads = (uint32_t*)c->dec_quads.p; a.ms_len = (uint32_t*)c->dec_mslen.p; a.status = (unsigned int*)c->flag.p;
-    a.vraw = (uint32_t*)c->dec_vraw.p; a.vbase = d_vbase;
-    a.active = nactive == nblocks ? nullptr : d_vbase + nblocks; a.nactive = nactive;
+    a.active = nactive == nblocks ? nullptr : d_active; a.nactive = nactive;
     a.mallat = (int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems;
     a.irreversible = g.p.irreversible;
     a.h16 = h16 ? 1 : 0;
@@ -819,19 +812,28 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
     if (lanes_on) {
         auto eligible = [&](uint64_t i) {
             const uint32_t bps = table[i].missing_msbs & 0xFFu, np = table[i].missing_msbs >> 8;
+            // (a row with more passes than its bit-planes can have -- a malformed packet header -- would alias into another group of
+            //  the pass-synchronous waves: K8 takes it and stops where the data does)
             return table[i].length != 0 && table[i].missing_msbs != kSkipBlock && np != 0 && bps != 0 && bps <= kT1LaneMaxPlanes &&
-                   c->h_desc_dec[i % bpt].h >= kT1LaneMinRows;
+                   np <= 3u * bps - 2u && c->h_desc_dec[i % bpt].h >= kT1LaneMinRows;
         };
         uint32_t max_len = 0;
         for (uint64_t i = 0; i < nblocks; ++i) max_len = std::max(max_len, table[i].length);
         const uint32_t thr = (uint32_t)std::min<double>((double)max_len, std::max(64.0, (double)c->t1_tail_ratio * max_len));
-        // counting sort by length (4-byte buckets), longest first
-        const uint32_t nb = (max_len >> 2) + 2u;
-        std::vector<uint32_t> cnt(nb + 1, 0u), order(nblocks);
-        for (uint64_t i = 0; i < nblocks; ++i) cnt[nb - 1u - (table[i].length >> 2)]++;
+        // counting sort by length (4-byte buckets), longest first.  The bucket index is clamped: a code-block of 64 x 64 samples
+        // cannot need more than 64 KiB, and a row that CLAIMS hundreds of megabytes (a malformed packet header: the length is
+        // bounded by the coded buffer only) must not cost a table of that size -- such rows share the top bucket, i.e. sort first
+        // and go to K8's list like every long block
+        constexpr uint32_t kMaxBucketLen = 64u << 10;
+        const uint32_t nb = (std::min(max_len, kMaxBucketLen) >> 2) + 2u;
+        auto bucket = [&](uint64_t i) { return nb - 1u - (std::min(table[i].length, kMaxBucketLen) >> 2); };
+        std::vector<uint32_t> cnt, order;
+        try { cnt.assign(nb + 1, 0u); order.resize(nblocks); }
+        catch (const std::bad_alloc&) { return fail(c, GRK_AMD_ERR_NOMEM, "host memory for the Part-1 launch lists"); }
+        for (uint64_t i = 0; i < nblocks; ++i) cnt[bucket(i)]++;
         uint32_t run = 0;
         for (uint32_t k = 0; k <= nb; ++k) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
-        for (uint64_t i = 0; i < nblocks; ++i) order[cnt[nb - 1u - (table[i].length >> 2)]++] = (uint32_t)i;
+        for (uint64_t i = 0; i < nblocks; ++i) order[cnt[bucket(i)]++] = (uint32_t)i;
         const uint64_t share = (uint64_t)((double)c->t1_tail_share * (double)nblocks);
         for (uint64_t k = 0; k < nblocks; ++k) {
             const uint32_t i = order[k];
@@ -981,7 +983,14 @@ HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* 
     static const uint32_t kBlocksPerRegion = getenv("GRK_AMD_BLOCKS_PER_REGION") ? (uint32_t)std::max(1, atoi(getenv("GRK_AMD_BLOCKS_PER_REGION"))) : 64u;
     uint32_t regions = 1;
     while (regions < kHtAllocRegions && nblocks / (regions * 2) >= kBlocksPerRegion) regions *= 2;
-    const uint32_t chunk = nblocks < 16384 ? kHtAllocChunkSmall : kHtAllocChunk;
+    // (a chunk holds at least two of the largest blocks the geometry can produce: worst case (Kmax + 2) bits per sample and 15 VLC
+    //  bits per quad, stuffing 1 bit in 15, 256 MEL bytes -- ~20 KiB for a 64 x 64 block at Kmax 31)
+    size_t worst_block = 0;
+    for (uint32_t k = 0; k < c->ht_num_classes; ++k) {
+        const HtClass& hc = c->ht_classes[k];
+        worst_block = std::max(worst_block, ((size_t)hc.max_samples * (hc.max_kmax + 2u) + (size_t)hc.max_quads * 15u) * 16u / 15u / 8u + 280u);
+    }
+    const uint32_t chunk = (nblocks < 16384 && 2 * worst_block <= kHtAllocChunkSmall) ? kHtAllocChunkSmall : kHtAllocChunk;
     try_(c->arena.ensure(raw * 2 + nblocks * 64 + (size_t)(regions + 1) * kHtAllocChunk + (1u << 20)), "alloc coded arena");
     a.mallat = (const int32_t*)d_mallat; a.stride = g.stride; a.pitch = g.plane_elems; a.h16 = h16 ? 1 : 0;
     a.blocks = (const HtBlockDesc*)c->blockdesc.p; a.blocks_per_tile = bpt; a.ncomp = g.p.num_comps; a.ntiles = ntiles;
@@ -1058,7 +1067,18 @@ int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** o
     if (hipSetDevice(device_id) != hipSuccess) return GRK_AMD_ERR_NO_DEVICE;
     auto* c = new grk_amd_ctx();
     c->device = device_id; c->verbose = verbose;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GRK_AMD_ERR_NO_DEVICE; }
+    // (experiment, r05: the DWT chain's stream on CUs of its own -- GRK_AMD_CU_MAIN = k: the main stream runs on mask bits [0, k);
+    //  GRK_AMD_CU_SIDE_EXCL = k: the K3 side streams stay off mask bits [0, k))
+    const int cu_main = getenv("GRK_AMD_CU_MAIN") ? atoi(getenv("GRK_AMD_CU_MAIN")) : 0;
+    const int cu_excl = getenv("GRK_AMD_CU_SIDE_EXCL") ? atoi(getenv("GRK_AMD_CU_SIDE_EXCL")) : 0;
+    auto masked_stream = [](hipStream_t* st, int lo, int hi) {
+        uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = lo; b < hi && b < 256; ++b) m[b >> 5] |= 1u << (b & 31);
+        return hipExtStreamCreateWithCUMask(st, 8, m);
+    };
+    if ((cu_main > 0 ? masked_stream(&c->stream, 0, cu_main) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c; return GRK_AMD_ERR_NO_DEVICE;
+    }
     c->own_stream = true;
     {   // side stream for K3 of the top resolution (lowest priority: the DWT chain on the main stream is the critical path)
         int least = 0, greatest = 0;
@@ -1075,8 +1095,8 @@ int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** o
         if (const char* ey = getenv("GRK_AMD_T1_SYNC")) c->t1_pass_sync = atoi(ey) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
-        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
-            (!decode_only && hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess) ||
+        if ((cu_excl > 0 ? masked_stream(&c->side, cu_excl, 256) : hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least)) != hipSuccess ||
+            (!decode_only && (cu_excl > 0 ? masked_stream(&c->side2, cu_excl, 256) : hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least)) != hipSuccess) ||
             hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
             !create_alt_events(c) ||
             hipEventCreateWithFlags(&c->ev_level0, hipEventDisableTiming) != hipSuccess ||
@@ -1096,11 +1116,12 @@ void grk_amd_destroy(grk_amd_ctx* c)
     c->dec_kids.clear();
     (void)hipSetDevice(c->device);
     if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
+    if (c->ev_frame_done) (void)hipEventDestroy(c->ev_frame_done);
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
     for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
                       &c->offsets, &c->arena, &c->flag, &c->dec_desc, &c->dec_table, &c->dec_quads, &c->dec_mslen,
-                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->dec_vraw, &c->ht_sel})
+                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->ht_sel})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
@@ -1376,11 +1397,23 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             HIP_TRY(c, hipEventRecord(c->ev_seq, c->stream), "record the caller's stream");
             HIP_TRY(c, hipStreamWaitEvent(k->stream, c->ev_seq, 0), "order the frame behind the caller's stream");
             const int rc = decode_impl(k, p, ntiles, table, coded, coded_bytes, 1, pixels, 1, nullptr);
-            if (rc) c->err = k->err;
+            if (rc) { c->err = k->err; return rc; }
+            // (the frame's last kernels -- the final inverse level, behind its join with the side stream -- are on k's stream)
+            if (!k->ev_frame_done) HIP_TRY(c, hipEventCreateWithFlags(&k->ev_frame_done, hipEventDisableTiming), "create event");
+            HIP_TRY(c, hipEventRecord(k->ev_frame_done, k->stream), "record the frame's end");
             return rc;
         }
     }
     return decode_impl(c, p, ntiles, table, coded, coded_bytes, coded_on_device, pixels, pixels_on_device, nullptr);
+}
+
+int grk_amd_decode_stream_wait_slot(grk_amd_ctx* c, void* hip_stream)
+{
+    if (!c || !hip_stream) return GRK_AMD_ERR_INVALID;
+    if (c->dec_kids.empty()) return grk_amd_stream_wait_results(c, hip_stream);       // no sequence: the context's own streams
+    grk_amd_ctx* k = c->dec_kids[c->dec_seq % (uint32_t)c->dec_kids.size()];          // the set the NEXT call uses
+    if (k->ev_frame_done) HIP_TRY(c, hipStreamWaitEvent((hipStream_t)hip_stream, k->ev_frame_done, 0), "wait for the set's last frame");
+    return GRK_AMD_OK;
 }
 
 int grk_amd_set_decode_pipelining(grk_amd_ctx* c, int frames_in_flight)

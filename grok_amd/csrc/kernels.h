@@ -111,9 +111,7 @@ struct HtDecArgs {
     const HtBlockDesc* blocks;                 // geometry per block of one tile; inv_step = decode scale (irreversible)
     uint32_t blocks_per_tile, nblocks, ncomp;
     const uint8_t* coded; uint64_t coded_bytes; // device buffer holding every block's bytes
-    uint32_t* vraw;                            // K5p -> K5a: the un-stuffed MEL and VLC bits of every block (scratch)
-    const uint32_t* vbase;                     // [nblocks] first word of each block's part of vraw (ht_dec_scratch_words apart)
-    const uint32_t* active;                    // [nactive] the blocks with data, K5p's waves / K5a's lanes (null: all nblocks)
+    const uint32_t* active;                    // [nactive] the blocks with data, K5a's lanes (null: all nblocks)
     uint32_t nactive;
     uint32_t* quads;                           // K5a -> K5b: 16 bits per quad, [nblocks][32 * 32] (kernels_htdec.hip: 9 bits of the CxtVLC entry | (u_q + 1) << 9)
     uint32_t* ms_len;                          // [nblocks] MagSgn bytes (0xFFFFFFFF: block rejected)
@@ -129,14 +127,12 @@ struct HtDecArgs {
     uint32_t ms_first, ms_count, ms_bpc;       // K5b of a part of the blocks: [ms_first, ms_first + ms_count) of every component's
                                                // ms_bpc blocks (ms_count = 0: all nblocks)
 };
-// K5p + K5a + K5b (+ K5c) on one stream, or in two parts: front = tables + K5p + K5a, ms = K5b (+ K5c) of a.ms_first / ms_count
+// K5a + K5b (+ K5c) on one stream, or in two parts: front = tables + K5a, ms = K5b (+ K5c) of a.ms_first / ms_count
 hipError_t launch_ht_decode(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s);
 hipError_t launch_ht_decode_front(const HtDecArgs& a, hipStream_t s);
 hipError_t launch_ht_decode_ms(const HtDecArgs& a, uint32_t max_ms_bytes, hipStream_t s);
 // a decode call's tables: `bytes` of pinned host memory (device-visible address) -> dst, the 16-byte status block cleared
 hipError_t launch_dec_upload(const void* pinned, void* dst, size_t bytes, void* status, hipStream_t s);
-// scratch words K5p may write / K5a may read for a block of `length` coded bytes (MEL + VLC bits + padding)
-inline uint32_t ht_dec_scratch_words(uint32_t length) { return length / 2u + 16u; }
 
 // ---- K8: Part-1 (EBCOT) block decoder + dequantisation (kernels_t1dec.hip) -----------------------
 struct T1DecArgs {

@@ -657,12 +657,7 @@ __global__ __launch_bounds__(NT) void dwt53_pk_kernel(DwtLevelArgs a)
                            mlo = __builtin_amdgcn_readfirstlane(ju * a.m_stride * 2u),
                            mhi = __builtin_amdgcn_readfirstlane((sh + ju) * a.m_stride * 2u);
             __builtin_amdgcn_raw_buffer_store_b32(o[k][0], r_ll[k], oc, lrow, 0);
-#ifdef GRK_WHATIF_NO_TOP_BAND_TRAFFIC      // what-if build (profiles/HISTORY.md r04): level 0's HL / LH / HH stores go nowhere, but for
-            // the last 64 band rows (the block row the what-if K3 codes everything from)
-            const __amdgpu_buffer_rsrc_t rm = (PX != 0 && ju + 64u < (uint32_t)sh) ? r_none : r_mp[k];
-#else
             const __amdgpu_buffer_rsrc_t rm = r_mp[k];
-#endif
             __builtin_amdgcn_raw_buffer_store_b32(o[k][1], rm, oc, mhi, 0);
             __builtin_amdgcn_raw_buffer_store_b32(o[k][2], rm, oc + 2u * sw, mlo, 0);
             __builtin_amdgcn_raw_buffer_store_b32(o[k][3], rm, oc + 2u * sw, mhi, 0);

@@ -46,8 +46,7 @@ constexpr uint64_t kMelE = 0x5433222111000ull;
 //   g_vlc_enc[0..2047]    first quad row : index (c_q<<8)|(rho<<4)|eps
 //   g_vlc_enc[2048..4095] other rows     : index (ctx<<8)|(rho<<4)|eps with ctx = n_w | rl<<1 | n_e<<2,
 //                                          n_w/n_e = "both upper neighbours insignificant" flags
-//   entry = cwd << 20 | len << 4 | e_k spread as the kernel's packed arithmetic wants it: bit 0 sample 0, bit 1 sample 1,
-//           bit 16 sample 2, bit 17 sample 3
+//   entry = cwd << 25 | len << 4 | e_k spread as the kernel's byte-wise arithmetic wants it: bit 0 of byte i = sample i
 __device__ uint32_t g_vlc_enc[4096];
 //   g_uvlc[u] : x = pre<<8 | suf<<16, y = pre_len<<8 | suf_len<<16 (ojph_block_encoder.cpp:189-210);
 //   entries 33,34: the 1-bit code (u-1) of the second quad in the first-row "u0>2, u1 in 1..2" mode
@@ -71,6 +70,14 @@ extern "C" __device__ int grk_amd_writelane(int value, int lane_select, int old)
 __device__ __forceinline__ void mel_writelane(uint32_t& vec, uint32_t word, uint32_t lane_index)
 {
     vec = (uint32_t)grk_amd_writelane(__builtin_amdgcn_readfirstlane((int)word), __builtin_amdgcn_readfirstlane((int)lane_index), (int)vec);
+}
+// (the state words as scalar registers, said so: with eight unrolled copies of the event code the compiler's SGPR-copy pass moved the whole
+//  state machine to the vector unit again)
+__device__ __forceinline__ void mel_pin(MelState& m)
+{
+    m.run = __builtin_amdgcn_readfirstlane(m.run); m.k = __builtin_amdgcn_readfirstlane(m.k);
+    m.acc = __builtin_amdgcn_readfirstlane(m.acc); m.left = __builtin_amdgcn_readfirstlane(m.left);
+    m.pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.pos); m.word = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.word);
 }
 __device__ __forceinline__ void mel_put_byte(MelState& m, uint32_t byte)
 {
@@ -132,17 +139,17 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
     (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // OR val (no bits at or above 64) into the little-endian bit array at bit `pos`
-__device__ __forceinline__ void or_bits64(uint32_t* raw, uint32_t pos, uint64_t val)
+__device__ __forceinline__ void or_bits64(uint32_t* raw, uint32_t pos, uint64_t val, uint32_t nbits)
 {
     const uint32_t sh = pos & 31;
     uint32_t* w = raw + (pos >> 5);
     const uint64_t lo = val << sh;
-    const uint32_t top = ((uint32_t)(val >> 32) >> 1) >> (31 - sh);
     lds_or(w, (uint32_t)lo);
     lds_or(w + 1, (uint32_t)(lo >> 32));
-    // the value reaches into a third word only when it is longer than 64 - sh bits: for most iterations of most blocks no
-    // lane's does (a quad of 8-bit content has ~13 MagSgn bits), and a compare + scalar branch is a quarter of a ds_or
-    if (__ballot(top != 0)) lds_or(w + 2, top);
+    // the value (nbits long) reaches into a third word only when it is longer than 64 - sh bits: for most iterations of most blocks no
+    // lane's does (a quad of 8-bit content has ~13 MagSgn bits), and an add + compare + scalar branch is a quarter of a ds_or
+    // (r05: tested on the length instead of on the third word itself, which then is not computed at all -- K3 -0.9 %)
+    if (__ballot(sh + nbits > 64u)) lds_or(w + 2, ((uint32_t)(val >> 32) >> 1) >> (31 - sh));
 }
 __device__ __forceinline__ void or_bits32(uint32_t* raw, uint32_t pos, uint32_t val)
 {
@@ -333,6 +340,10 @@ __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* fl
 {
     unsigned long long* word = flagbuf + 32 * (1 + region);
     const unsigned long long n = (bytes + 15u) >> 4;
+    // (a request that does not fit a chunk -- the host sizes chunks at twice the largest block, context.hip make_ht_args: only a
+    //  geometry it did not foresee gets here -- takes its bytes from the shared cursor itself and leaves the region's chunk alone;
+    //  handed a fresh chunk it would run past the chunk's end into the next region's)
+    if (n > kChunkUnits) return __hip_atomic_fetch_add(flagbuf + 1, n << 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (true) {
         const unsigned long long old = __hip_atomic_fetch_add(word, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long used = old & 0xFFFFFFull, start = old >> 24;
@@ -375,14 +386,8 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     const uint32_t w = bd.w, h = bd.h;
     const uint32_t QW = (w + 1) >> 1, QH = (h + 1) >> 1;
     constexpr uint32_t EB = H16 ? 2u : 4u;         // bytes per coefficient
-#ifdef GRK_WHATIF_NO_TOP_BAND_TRAFFIC      // what-if build: every block codes coefficients out of ONE block row of the top HH band
-    const HtBlockDesc bw = a.blocks[a.blocks_per_tile - 1u - (lb & 63u)];        // (64 blocks, 512 KB: resident in L2)
-    const char* src = reinterpret_cast<const char*>(a.mallat) +
-                      (((size_t)tile * a.ncomp + bw.comp) * a.pitch + (size_t)bw.py * a.stride + bw.px) * EB;
-#else
     const char* src = reinterpret_cast<const char*>(a.mallat) +
                       (((size_t)tile * a.ncomp + bd.comp) * a.pitch + (size_t)bd.py * a.stride + bd.px) * EB;
-#endif
     const bool full = w == 64 && h == 64 && ((bd.px | a.stride) & 1u) == 0;   // aligned row-pair loads, no edges
     const uint32_t kmax = bd.kmax;
     const bool narrow = kmax + 2 <= 16;           // a quad's four MagSgn values fit 64 bits
@@ -599,7 +604,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         //      (the table entry carries e_k spread the same way)
         const uint32_t U2 = __builtin_amdgcn_perm(U, U, 0x05040100u);
         const uint32_t M02 = pk_mul_lo_u16(s.R & 0x00010001u, U2) - (tuple & 0x00010001u);
-        const uint32_t M13 = pk_mul_lo_u16((s.R >> 8) & 0x00010001u, U2) - ((tuple >> 1) & 0x00010001u);
+        const uint32_t M13 = pk_mul_lo_u16((s.R >> 8) & 0x00010001u, U2) - ((tuple >> 8) & 0x00010001u);
         const uint32_t Msum = M02 + M13;
         const uint32_t m01 = Msum & 0xFFFFu, m23 = Msum >> 16;
         const uint32_t ms_len = m01 + m23;
@@ -626,7 +631,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             xv = xev && min(u, up) > 2;
         }
         const uint2 ue = uvlc_l[ui];
-        const uint32_t A = (tuple >> 20) | ue.x;                      // cwd | pre<<8 | suf<<16
+        const uint32_t A = (tuple >> 25) | ue.x;                      // cwd | pre<<8 | suf<<16
         const uint32_t Lw = ((tuple >> 4) & 7u) | ue.y;               // len | pl<<8 | sl<<16
         const uint32_t Lp = quad_swap(Lw);
         const uint32_t S = Lw + Lp;
@@ -662,10 +667,10 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             if (narrow || !__ballot(max(m01, m23) > 32u)) {
                 const uint32_t v01 = vm[0] | (vm[1] << (M02 & 31u));
                 const uint32_t v23 = vm[2] | (vm[3] << m2);
-                or_bits64(ms_raw, mpos, (uint64_t)v01 | ((uint64_t)v23 << m01));
+                or_bits64(ms_raw, mpos, (uint64_t)v01 | ((uint64_t)v23 << m01), ms_len);
             } else {
-                or_bits64(ms_raw, mpos, (uint64_t)vm[0] | ((uint64_t)vm[1] << (M02 & 0xFFFFu)));
-                or_bits64(ms_raw, mpos + m01, (uint64_t)vm[2] | ((uint64_t)vm[3] << m2));
+                or_bits64(ms_raw, mpos, (uint64_t)vm[0] | ((uint64_t)vm[1] << (M02 & 0xFFFFu)), m01);
+                or_bits64(ms_raw, mpos + m01, (uint64_t)vm[2] | ((uint64_t)vm[3] << m2), m23);
             }
         }
         if (cl != 0u) or_bits32(vlc_raw, vpos, wv);
@@ -729,7 +734,280 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                             "v"(n2[0]), "v"(n2[1]), "v"(n2[2]), "v"(n2[3]), "v"(n3[0]), "v"(n3[1]), "v"(n3[2]), "v"(n3[3]));
     }
     };   // phase_a
-    if (full) phase_a(std::true_type{}); else phase_a(std::false_type{});
+
+    // ---- Phase A of a FULL block with TWO quads per lane (r05) ------------------------------------------------------------
+    // Lane l: quad row r = l >> 4 of the iteration's FOUR, quads 2c and 2c + 1 (c = l & 15) -- the two quads of a VLC pair,
+    // neighbours in the MagSgn stream.  What a wave instruction costs does not depend on how many quads a lane holds, so
+    // everything that is per PAIR or per wave step is paid once for 128 quads instead of once for 64: one prefix sum, one
+    // position, one pair of LDS atomics for the pair's MagSgn bits (<= 64 bits on all but deep content) and one for its VLC
+    // window, the pair's VLC layout without a lane exchange, half the MEL ballots' scalar overhead; 8 iterations per block.
+    // The exponents of the row above come from the lanes 16 below (v_permlane16_swap + v_permlane32_swap: the four bottom-row
+    // exponents of a lane's two quads travel as the bytes of ONE register), the quads left and right by DPP lane shifts.
+    auto phase_a2 = [&]() {
+        constexpr bool PK = H16;
+        constexpr int NW = PK ? 4 : 8;                      // dwords of a sample set: PK [0] A top, [1] A bottom, [2] B top, [3] B bottom
+        const uint32_t rr = (uint32_t)lane >> 4, cc = (uint32_t)lane & 15u;
+        const uint32_t c0m = cc == 0 ? 0xFFFFFFFFu : 0u, c15m = cc == 15 ? 0xFFFFFFFFu : 0u;
+        const uint32_t oddm = (rr & 1u) ? 0xFFFFFFFFu : 0u, row0m = rr == 0 ? 0xFFFFFFFFu : 0u;
+        const uint32_t lane_off2 = 2u * rr * stride_b + 4u * cc * EB;
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+        auto fetch2 = [&](uint32_t it, int32_t (&r)[NW]) {
+            const uint32_t o0 = lane_off2 + it * (8u * stride_b), o1 = o0 + stride_b;
+            if constexpr (PK) {
+                const i32x2 q0 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + o0));
+                const i32x2 q1 = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(srcb + o1));
+                r[0] = q0.x; r[1] = q1.x; r[2] = q0.y; r[3] = q1.y;
+            } else {       // quad A: [0] (x0,y0) [1] (x0,y0+1) [2] (x0+1,y0) [3] (x0+1,y0+1); quad B: [4..7]
+                const i32x4 q0 = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(srcb + o0));
+                const i32x4 q1 = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(srcb + o1));
+                r[0] = q0.x; r[2] = q0.y; r[1] = q1.x; r[3] = q1.y;
+                r[4] = q0.z; r[6] = q0.w; r[5] = q1.z; r[7] = q1.w;
+            }
+        };
+        int32_t n0[NW], n1[NW], n2[NW], n3[NW];
+        fetch2(0, n0); fetch2(1, n1); fetch2(2, n2); fetch2(3, n3);
+
+        struct Stage1 {
+            uint32_t vv[2][PK ? 2 : 4];
+            uint32_t SM[2], U[2], u[2], tuple[2];      // SM: 0xFF in the byte of every significant sample
+            uint64_t H[2], V[2];
+        };
+        uint32_t Aprev = 0xFFFFFFFFu;          // (R1, R1, R3, R3) of the iteration before: its row 3 is this iteration's row above row 0
+
+        // one quad's samples -> exponents (leading-zero form, one per byte) and MagSgn values (as in phase_a)
+        auto analyse = [&](const int32_t* sm, uint32_t (&vv)[PK ? 2 : 4], uint32_t& C) {
+            if constexpr (PK) {
+                const int32_t nw0 = sm[0], nw1 = sm[1];
+                const i16x2 w0 = __builtin_bit_cast(i16x2, nw0), w1 = __builtin_bit_cast(i16x2, nw1);
+                const u16x2 p0 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w0, -w0));
+                const u16x2 p1 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w1, -w1));
+                ovf |= __builtin_bit_cast(uint32_t, p0) | __builtin_bit_cast(uint32_t, p1);
+                const u16x2 one2 = {1, 1};
+                const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(p0 + p0, one2));
+                const uint32_t t1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(p1 + p1, one2));
+                ffbh_u16_to_byte<0, 0>(C, t0); ffbh_u16_to_byte<1, 0>(C, t1);
+                ffbh_u16_to_byte<2, 1>(C, t0); ffbh_u16_to_byte<3, 1>(C, t1);
+                vv[0] = pk_sub_u16(t0, pk_lshr15_u16(~(uint32_t)nw0));
+                vv[1] = pk_sub_u16(t1, pk_lshr15_u16(~(uint32_t)nw1));
+            } else {
+                uint32_t t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t mag;
+                    if constexpr (IRREV) {
+                        const float cf = __int_as_float(sm[i]);
+                        const float q = __fmul_rn(fabsf(cf), inv_step);
+                        mag = min((uint32_t)q, lim);
+                    } else {
+                        mag = (uint32_t)max(sm[i], -sm[i]);
+                    }
+                    ovf |= mag;
+                    t[i] = (mag << 1) - 1u;
+                    vv[i] = t[i] - 1u + ((uint32_t)sm[i] >> 31);
+                }
+                ffbh_i32_to_byte<0>(C, t[0]); ffbh_i32_to_byte<1>(C, t[1]);
+                ffbh_i32_to_byte<2>(C, t[2]); ffbh_i32_to_byte<3>(C, t[3]);
+            }
+        };
+
+        auto stage1r = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[NW], auto refill_c) {
+            uint32_t C[2];
+            analyse(nbuf, o.vv[0], C[0]);
+            analyse(nbuf + NW / 2, o.vv[1], C[1]);
+            uint32_t N[2], rho[2], rho2[2], cm[2], emax[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                N[q] = bitop3<0x30>(0x01010101u, C[q] >> 7, 0u);
+                rho[q] = __builtin_amdgcn_udot4(N[q], 0x08040201u, 0u, false);
+                rho2[q] = __builtin_amdgcn_udot4(N[q], 0x20100804u, 0u, false);
+                cm[q] = min_of_bytes(C[q]);
+                emax[q] = 32u - min(cm[q], 32u);
+            }
+            // ---- the row above: the bottom-row exponents of sample columns 4c .. 4c + 3 as the four bytes of one register
+            const uint32_t Bp = __builtin_amdgcn_perm(C[1], C[0], 0x07050301u);      // A byte 1, A byte 3, B byte 1, B byte 3
+            // rows (R0 R1 R2 R3) -> (P3 R0 R1 R2), P = the iteration before:
+            //   permlane16_swap(X, X)        leaves (R0 R0 R2 R2) and (R1 R1 R3 R3)
+            //   permlane32_swap(Aprev, that) leaves (P1 P1 R1 R1) and (P3 P3 R3 R3)
+            const auto s16 = __builtin_amdgcn_permlane16_swap(Bp, Bp, false, false);
+            const uint32_t A1 = (uint32_t)s16[1];
+            const auto s32 = __builtin_amdgcn_permlane32_swap(Aprev, A1, false, false);
+            const uint32_t tsel = bitop3<0xE4>((uint32_t)s32[1], (uint32_t)s32[0], row0m);      // row 0 ? P3 : (row 2) R1
+            const uint32_t Y = bitop3<0xE4>((uint32_t)s16[0], tsel, oddm);                       // rows 1, 3 ? R0, R2
+            Aprev = A1;
+            const uint32_t Yl = dpp0<0x138, 0xF>(Y) | c0m;                      // lane x reads x - 1
+            const uint32_t Yr = dpp0<0x130, 0xF>(Y) | c15m;                     // lane x reads x + 1
+            const uint32_t rhoBl = dpp0<0x138, 0xF>(rho[1]) & ~c0m;             // the quad left of quad A
+            // (w, n0, n1, e) of the two quads: bytes of one register each
+            const uint32_t W[2] = {__builtin_amdgcn_alignbit(Y, Yl, 24), __builtin_amdgcn_alignbit(Yr, Y, 8)};
+            const uint32_t rl[2] = {rhoBl, rho[0]};
+            bool cq0[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t m4 = min_of_bytes(W[q]);
+                const int kap_e = 31 - (int)m4;
+                const uint32_t gmask = sign_mask(0xFEE80000u << (15u - rho[q]));
+                const uint32_t kappa = (uint32_t)max(1, kap_e & (int)gmask);
+                const uint32_t F = W[q] & (W[q] >> 8);         // bit 7: w & n0 both insignificant, bit 23: n1 & e
+                uint32_t coff = bitop3<0xEA>(F << 3, 0x400u, 0x2000u);
+                coff = bitop3<0xEA>(F >> 11, 0x1000u, coff);
+                coff = bitop3<0xEA>((rl[q] & 0xCu) + 0x7FCu, 0x800u, coff);
+                cq0[q] = (coff & 0x1C00u) == 0x1400u;
+                if (it == 0) {                                                  // first quad row of the block: lanes 0 .. 15
+                    const uint32_t cq_first = (rl[q] >> 1) | (rl[q] & 1u);
+                    coff = rr ? coff : cq_first << 10;
+                    cq0[q] = rr ? cq0[q] : cq_first == 0u;
+                }
+                const uint32_t U = max(emax[q], kappa);
+                const uint32_t u = U - kappa;
+                const uint32_t X = C[q] - __builtin_amdgcn_perm(cm[q], cm[q], 0u);
+                const uint32_t Yz = (X & 0x1F1F1F1Fu) + 0x7F7F7F7Fu;
+                const uint32_t e4 = __builtin_amdgcn_udot4(bitop3<0x30>(0x01010101u, Yz >> 7, 0u), 0x20100804u, 0u, false);
+                const uint32_t um = sign_mask(0u - u);
+                const uint32_t off = ((rho2[q] << 4) | coff) | bitop3<0x80>(e4, rho2[q], um);
+                o.tuple[q] = *reinterpret_cast<const uint32_t*>(vtab + off);
+                o.SM[q] = N[q] * 255u; o.U[q] = U; o.u[q] = u;
+            }
+            o.H[0] = __ballot(cq0[0]); o.V[0] = o.H[0] & __ballot(rho[0] != 0);
+            o.H[1] = __ballot(cq0[1]); o.V[1] = o.H[1] & __ballot(rho[1] != 0);
+            if constexpr (decltype(refill_c)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                fetch2(it + 4u, nbuf);
+            }
+        };
+        auto stage1 = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[NW]) { stage1r(it, o, nbuf, std::true_type{}); };
+        auto stage1_last = [&](uint32_t it, Stage1& o, int32_t (&nbuf)[NW]) { stage1r(it, o, nbuf, std::false_type{}); };
+
+        auto stage2 = [&](uint32_t it, const Stage1& s) {
+            // ---- MagSgn bit counts m_i = U - e_k,i of the significant samples, one per BYTE (sample i in byte i: the table entry
+            //      carries e_k spread that way), and the values cut to them
+            uint32_t vm[2][4], M4[2], m1[2], m2[2], m3[2], m01[2], m23[2], qlen[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                M4[q] = (__builtin_amdgcn_perm(s.U[q], s.U[q], 0u) - (s.tuple[q] & 0x01010101u)) & s.SM[q];
+                qlen[q] = __builtin_amdgcn_udot4(M4[q], 0x01010101u, 0u, false);
+                m01[q] = __builtin_amdgcn_udot4(M4[q], 0x00000101u, 0u, false);
+                m23[q] = qlen[q] - m01[q];
+                m1[q] = M4[q] >> 8; m2[q] = M4[q] >> 16; m3[q] = M4[q] >> 24;       // (bit-field widths and shift counts take the low 5 bits)
+                if constexpr (PK) {
+                    vm[q][0] = __builtin_amdgcn_ubfe(s.vv[q][0], 0u, M4[q]); vm[q][2] = __builtin_amdgcn_ubfe(s.vv[q][0], 16u, m2[q]);
+                    vm[q][1] = __builtin_amdgcn_ubfe(s.vv[q][1], 0u, m1[q]); vm[q][3] = __builtin_amdgcn_ubfe(s.vv[q][1], 16u, m3[q]);
+                } else {
+                    vm[q][0] = __builtin_amdgcn_ubfe(s.vv[q][0], 0u, M4[q]); vm[q][2] = __builtin_amdgcn_ubfe(s.vv[q][2], 0u, m2[q]);
+                    vm[q][1] = __builtin_amdgcn_ubfe(s.vv[q][1], 0u, m1[q]); vm[q][3] = __builtin_amdgcn_ubfe(s.vv[q][3], 0u, m3[q]);
+                }
+            }
+            const uint32_t ms_len = qlen[0] + qlen[1];
+
+            // ---- VLC + UVLC of the pair: cwd A | cwd B | prefix A | prefix B | suffix A | suffix B
+            uint32_t uiA = s.u[0], uiB = s.u[1];
+            bool xev = false, xv = false;
+            if (it == 0) {                                                      // first quad row (:652, :709): lanes 0 .. 15
+                const bool first = rr == 0;
+                const uint32_t uA = s.u[0], uB = s.u[1];
+                const bool both = first && uA > 2 && uB > 2;
+                uiA = both ? uA - 2 : uA;
+                uiB = both ? uB - 2 : uB;
+                uiB = (first && uA > 2 && uB > 0 && uB <= 2) ? 32u + uB : uiB;
+                xev = first && uA > 0 && uB > 0;
+                xv = xev && min(uA, uB) > 2;
+            }
+            const uint2 ueA = uvlc_l[uiA], ueB = uvlc_l[uiB];
+            const uint32_t AA = (s.tuple[0] >> 25) | ueA.x, AB = (s.tuple[1] >> 25) | ueB.x;       // cwd | pre << 8 | suf << 16
+            const uint32_t LA = ((s.tuple[0] >> 4) & 7u) | ueA.y, LB = ((s.tuple[1] >> 4) & 7u) | ueB.y;   // len | pl << 8 | sl << 16
+            const uint32_t S = LA + LB;
+            const uint32_t lenA = LA & 0xFFu, slen = S & 0xFFu;
+            const uint32_t o_preB = slen + ((LA >> 8) & 0xFFu);
+            const uint32_t o_sufA = slen + ((S >> 8) & 0xFFu);
+            const uint32_t o_sufB = o_sufA + (LA >> 16);
+            const uint32_t cl = o_sufA + (S >> 16);                             // bits of the whole pair
+            const uint32_t wv = (AA & 0xFFu) | ((AB & 0xFFu) << lenA) | (((AA >> 8) & 0xFFu) << slen) | (((AB >> 8) & 0xFFu) << o_preB) |
+                                ((AA >> 16) << o_sufA) | ((AB >> 16) << o_sufB);
+
+            // ---- one packed prefix sum: low 16 bits MagSgn, high 16 bits VLC
+            const uint32_t packed = ms_len | (cl << 16);
+            const uint32_t incl = wave_incl_scan(packed);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t mpos = ms_bits + ((incl - packed) & 0xFFFFu);
+            const uint32_t vpos = vlc_bits + (incl >> 16) - cl;
+            ms_bits += tot & 0xFFFFu;
+            vlc_bits += tot >> 16;
+            lds_full = lds_full || ms_bits > L.ms_cap_bits || vlc_bits > L.vlc_cap_bits;
+            if (lds_full) return;
+
+            if (ms_len != 0u) {
+                if (!__ballot(max(qlen[0], qlen[1]) > 32u)) {
+                    // both quads fit a word each (8-bit content: ~13 bits per quad): the pair goes out in one piece
+                    const uint32_t qa = (vm[0][0] | (vm[0][1] << (M4[0] & 31u))) | ((vm[0][2] | (vm[0][3] << (m2[0] & 31u))) << (m01[0] & 31u));
+                    const uint32_t qb = (vm[1][0] | (vm[1][1] << (M4[1] & 31u))) | ((vm[1][2] | (vm[1][3] << (m2[1] & 31u))) << (m01[1] & 31u));
+                    or_bits64(ms_raw, mpos, (uint64_t)qa | ((uint64_t)qb << qlen[0]), ms_len);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t at = q ? mpos + qlen[0] : mpos;
+                        if (narrow || !__ballot(max(m01[q], m23[q]) > 32u)) {
+                            const uint32_t v01 = vm[q][0] | (vm[q][1] << (M4[q] & 31u));
+                            const uint32_t v23 = vm[q][2] | (vm[q][3] << (m2[q] & 31u));
+                            or_bits64(ms_raw, at, (uint64_t)v01 | ((uint64_t)v23 << m01[q]), qlen[q]);
+                        } else {
+                            or_bits64(ms_raw, at, (uint64_t)vm[q][0] | ((uint64_t)vm[q][1] << (M4[q] & 0xFFu)), m01[q]);
+                            or_bits64(ms_raw, at + m01[q], (uint64_t)vm[q][2] | ((uint64_t)vm[q][3] << (m2[q] & 0xFFu)), m23[q]);
+                        }
+                    }
+                }
+            }
+            if (cl != 0u) or_bits32(vlc_raw, vpos, wv);
+
+            // ---- MEL events (wave-uniform, scalar unit): in quad order = lane by lane, quad A before quad B
+            mel_pin(mel);
+            uint64_t HA = s.H[0], VA = s.V[0], HB = s.H[1], VB = s.V[1];
+            if (it == 0) {
+                const uint64_t XH = __ballot(xev), XV = __ballot(xv);
+                for (int pr = 0; pr < 16; ++pr) {
+                    if ((HA >> pr) & 1) mel_event(mel, mel_buf, (int)((VA >> pr) & 1), lane == 0);
+                    if ((HB >> pr) & 1) mel_event(mel, mel_buf, (int)((VB >> pr) & 1), lane == 0);
+                    if ((XH >> pr) & 1) mel_event(mel, mel_buf, (int)((XV >> pr) & 1), lane == 0);
+                }
+                HA &= ~0xFFFFull; HB &= ~0xFFFFull;
+            }
+            while (HA | HB) {
+                const uint64_t oa = HA & VA, ob = HB & VB;
+                if (!(oa | ob)) {
+                    mel_zero_run(mel, mel_buf, (uint32_t)(__builtin_popcountll(HA) + __builtin_popcountll(HB)), lane == 0);
+                    break;
+                }
+                const uint32_t la = oa ? (uint32_t)__builtin_ctzll(oa) : 64u, lb = ob ? (uint32_t)__builtin_ctzll(ob) : 64u;
+                const bool a_first = (int)(la - lb) <= 0;          // (the same lane: quad A comes first)
+                const uint32_t ln = a_first ? la : lb;
+                const uint64_t bit = 1ull << ln, below = bit - 1;
+                // everything of the lanes below, and quad A of this lane when the event is quad B's
+                const uint64_t ma = a_first ? below : (below | bit);
+                mel_zero_run(mel, mel_buf, (uint32_t)(__builtin_popcountll(HA & ma) + __builtin_popcountll(HB & below)), lane == 0);
+                mel_event(mel, mel_buf, 1, lane == 0);
+                HA &= ~(below | bit);
+                HB &= a_first ? ~below : ~(below | bit);
+            }
+        };
+
+        Stage1 sE, sO;
+        stage1(0, sE, n0);
+        stage1(1, sO, n1); stage2(0, sE);
+        stage1(2, sE, n2); stage2(1, sO);
+        stage1(3, sO, n3); stage2(2, sE);
+        stage1_last(4, sE, n0); stage2(3, sO);
+        stage1_last(5, sO, n1); stage2(4, sE);
+        stage1_last(6, sE, n2); stage2(5, sO);
+        stage1_last(7, sO, n3); stage2(6, sE);
+        stage2(7, sO);
+    };   // phase_a2
+    // The pair form for packed (8-bit reversible) content only: with four 32-bit samples per quad it needs 110 - 141 registers, four or
+    // three waves per SIMD, and codes cfg3 13 % SLOWER than the one-quad form (same box: 0.537 against 0.476 ms).
+    // (8-byte row loads: block origin and stride multiples of four samples -- every 64 x 64 block of a Mallat plane)
+    if constexpr (H16) {
+        if (full && ((bd.px | a.stride) & 3u) == 0) phase_a2(); else phase_a(std::false_type{});
+    } else {
+        if (full) phase_a(std::true_type{}); else phase_a(std::false_type{});
+    }
     if (lds_full) {                       // hand the block to the fallback launch (kernels.h: HtArgs::ovf_list)
         if (lane == 0) {
             const unsigned long long at = __hip_atomic_fetch_add(a.alloc + 2 + class_id, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -863,6 +1141,10 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             // a 256-byte look.  While the NEXT byte is 0xFF again and its 7-bit follower is whole, take the pair with one 15-bit
             // look (r04: K3 of an all-zero 8K frame 0.59 ms, all of it this loop in 48 LL blocks; profiles/r04_small_frames.txt);
             // everything else -- the stream's end, a partial follower -- goes back through the general path.
+            // (one look decides whether the run loop is entered at all -- r05: with the loop directly behind the event K3 of dense
+            //  content, which never takes it, was 0.7 % slower, and 2.2 % slower than without the loop: code placement, the registers
+            //  and spills are the same; profiles/r05_k3_pairs.txt)
+            if (s + 15u <= ms_bits && ((uint32_t)__builtin_amdgcn_readfirstlane((int)get_bits(ms_raw, s, 8u)) == 0xFFu))
             while (s + 15u <= ms_bits) {
                 const uint32_t two = (uint32_t)__builtin_amdgcn_readfirstlane((int)get_bits(ms_raw, s, 15u));
                 if ((two & 0xFFu) != 0xFFu) break;
@@ -980,7 +1262,7 @@ static hipError_t upload_tables()
     static uint32_t enc[4096];
     auto entry = [](uint32_t t) {          // generated (cwd << 8 | len << 4 | e_k) -> the kernel's layout
         const uint32_t ek = t & 15u;
-        return ((t >> 8) << 20) | (((t >> 4) & 7u) << 4) | (ek & 3u) | ((ek >> 2) << 16);
+        return ((t >> 8) << 25) | (((t >> 4) & 7u) << 4) | (ek & 1u) | (((ek >> 1) & 1u) << 8) | (((ek >> 2) & 1u) << 16) | ((ek >> 3) << 24);
     };
     for (uint32_t i = 0; i < 2048; ++i) {
         enc[i] = entry(HT_VLC_ENC0[i]);

@@ -35,21 +35,18 @@ namespace {
 constexpr uint32_t kQuadStride = 32;         // quads per row in the per-block quad-info array (blocks <= 64 wide)
 constexpr uint32_t kQuadWords  = 32 * 32;
 
-// ---- K5p --------------------------------------------------------------------------------------------
-// Un-stuffs the VLC and the MEL segment of every block into raw bit arrays (global scratch, HtDecArgs::vraw), ONE
-// WAVEFRONT PER BLOCK: which bytes carry 7 bits depends only on the byte read just before, so the widths are independent,
-// a wave prefix sum places every byte, and K5a's serial chain reads plain bits -- r02's K5a spent ~70 of its ~250
-// instructions per quad pair on refilling two bit-stuffed byte readers with SWAR code.
-//   VLC (ojph_block_decoder.cpp rev_read / rev_init): read backwards from D[lcup - 3]; first the upper nibble of D[lcup - 2]
+// ---- bit readers of K5a --------------------------------------------------------------------------------
+// r03 / r04 ran a kernel of its own in front of K5a (K5p, one wave per block) that un-stuffed every block's VLC and MEL bytes into a
+// global scratch K5a then read: 86 MB written and read back per 8K frame and 0.13 ms of kernel.  Since r05 the lane that walks a
+// block un-stuffs its own bytes: a 64-bit shift register per stream, refilled FOUR coded bytes at a time -- the dword is taken as it
+// is unless one of its bytes is a 7-bit byte (one SWAR test; on real streams one dword in ~70 has one) --, the VLC bytes of a quad
+// row fetched in one batch at the row's start and handed on through the lane's LDS row (the pair loop must not wait on global
+// loads: gfx9 counts loads and stores with one counter, see below), the MEL bytes -- a few per row -- a refill ahead of their use.
+//   VLC (ojph_block_decoder.cpp rev_read / rev_init :380-421): read backwards from D[lcup - 3]; first the upper nibble of D[lcup - 2]
 //       (3 bits if its low three are ones, else 4); a byte that follows a byte > 0x8F carries 7 bits when its low 7 are ones.
-//       Stored LSB first: stream bit k is bit (k & 31) of word k >> 5; zeros behind the end.
-//   MEL (mel_read / mel_init): forward from D[lcup - scup], scup - 1 bytes, the last one with its low nibble set; a byte after
-//       0xFF carries 7 bits (its MSB is dropped).  Consumed MSB first, so stored MSB first: stream bit k is bit 31 - (k & 31)
-//       of word k >> 5; ones behind the end.
-// Layout of a block's scratch: [mel_words(scup)] MEL words, then the VLC words (+ 3 words of padding each).
-__host__ __device__ __forceinline__ uint32_t mel_words(uint32_t scup) { return ((scup - 1u) * 8u + 31u) / 32u + 3u; }
-__host__ __device__ __forceinline__ uint32_t vlc_words(uint32_t scup) { return ((scup - 2u) * 8u + 4u + 31u) / 32u + 3u; }
-
+//       LSB first; zeros behind the end.
+//   MEL (mel_read / mel_init :270-330): forward from D[lcup - scup], scup - 1 bytes, the last one with its low nibble set; a byte
+//       after 0xFF carries 7 bits (its MSB is dropped).  MSB first; ones behind the end.
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
     (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -70,7 +67,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
-// lcup, scup of a block as both K5p and K5a take them from its last two bytes (:1067-1090); false: the block is rejected
+// lcup, scup of a block as K5a takes them from its last two bytes (:1067-1090); false: the block is rejected
 __device__ __forceinline__ bool ht_segments(const HtDecArgs& a, uint32_t blk, const HtDecBlock& in, int& lcup, int& scup)
 {
     const uint8_t* D = a.coded + in.offset;
@@ -80,159 +77,20 @@ __device__ __forceinline__ bool ht_segments(const HtDecArgs& a, uint32_t blk, co
     return !(scup < 2 || scup > lcup || scup > 4079);
 }
 
-// FOUR bytes per lane and step, 256 per wave; the raw bits of up to kPrepSteps steps collect in an LDS array (one
-// ds_or pair per lane and step), then the finished words leave for the scratch and a partial last word carries over.
-// A dword that straddles the ends of the coded buffer is not read (its bytes past the segment are masked anyway).
-constexpr uint32_t kPrepSteps = 4;                       // 1024 bytes = at most 256 words between two flushes
-constexpr uint32_t kPrepWords = kPrepSteps * 64 + 8;
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-
-__global__ __launch_bounds__(64) void ht_dec_prep_kernel(HtDecArgs a)
+// bytes q .. q + 3, little endian; a byte outside the coded buffer reads as 0 (the caller masks what lies outside its segment anyway)
+__device__ __forceinline__ uint32_t ld4_guarded(const uint8_t* q, const uint8_t* lo, const uint8_t* hi)
 {
-    __shared__ uint32_t acc[2][kPrepWords];              // [0] VLC, [1] MEL
-    const uint32_t lane = threadIdx.x;
-    const uint32_t blk = a.active ? a.active[blockIdx.x] : blockIdx.x;
-    const HtDecBlock in = a.table[blk];
-    if (in.length == 0) return;
-    const uint8_t* D = a.coded + in.offset;
-    const uint8_t* const buf_lo = a.coded, * const buf_hi = a.coded + a.coded_bytes;
-    int lcup = (int)in.length - (a.refine ? (int)a.refine[blk].x : 0), scup;
-    if (in.missing_msbs > 29 || lcup < 2) return;                  // (K5a raises the flag)
-    // The VLC bytes lie at the block's end whatever Scup says (only their NUMBER depends on it): the first step's loads go out
-    // together with the two bytes that hold Scup, one memory round trip instead of two on this kernel's short chain
-    const uint8_t* const p_first = D + lcup - 3 - 4 * (int)lane;
-    const uint32_t w_first = (p_first - 3 >= buf_lo && p_first + 1 <= buf_hi) ? *reinterpret_cast<const u32_unaligned*>(p_first - 3) : 0u;
-    const uint32_t prev_first = (lane > 0 && p_first + 1 >= buf_lo && p_first + 1 < buf_hi) ? (uint32_t)p_first[1] : 0u;
-    scup = ((int)D[lcup - 1] << 4) + (D[lcup - 2] & 0xF);
-    if (scup < 2 || scup > lcup || scup > 4079) return;
-    auto ld4 = [&](const uint8_t* q) -> uint32_t {                  // bytes q .. q + 3, little endian (outside the buffer: 0)
-        return (q >= buf_lo && q + 4 <= buf_hi) ? *reinterpret_cast<const u32_unaligned*>(q)
-               : ((q + 0 >= buf_lo && q + 0 < buf_hi ? (uint32_t)q[0] : 0u) | (q + 1 >= buf_lo && q + 1 < buf_hi ? (uint32_t)q[1] << 8 : 0u) |
-                  (q + 2 >= buf_lo && q + 2 < buf_hi ? (uint32_t)q[2] << 16 : 0u) | (q + 3 >= buf_lo && q + 3 < buf_hi ? (uint32_t)q[3] << 24 : 0u));
-    };
-    const uint32_t mwords = mel_words((uint32_t)scup), vwords = vlc_words((uint32_t)scup);
-    uint32_t* const out_m = a.vraw + a.vbase[blk];
-    uint32_t* const out_v = out_m + mwords;
-    const uint32_t nv = (uint32_t)scup - 2u, nm = (uint32_t)scup - 1u;
-    const uint32_t d0 = D[lcup - 2];
-    for (uint32_t i = lane; i < kPrepWords; i += 64) { acc[0][i] = 0; acc[1][i] = 0; }
-    __syncthreads();
-
-    // ---- VLC: bytes D[lcup - 3], D[lcup - 4], ... ; lane k of a step takes the four at p - 3 .. p, p = lcup - 3 - 4 k, read p first
-    {
-        const uint32_t n0 = 4u - (((d0 >> 4) & 7u) == 7u ? 1u : 0u);
-        if (lane == 0) acc[0][0] = (d0 >> 4) & ((1u << n0) - 1u);
-        __syncthreads();
-        uint32_t bits = n0, flushed = 0;                               // bits in the array, words already in the scratch
-        const uint32_t steps = (nv + 255u) / 256u;
-        for (uint32_t st = 0; st < steps; ++st) {
-            const uint32_t k = st * 256u + 4u * lane;                  // index (reading order) of this lane's first byte
-            uint32_t val = 0, nb = 0;
-            if (k < nv) {
-                const uint8_t* p = D + lcup - 3 - (int)k;
-                // (the first step's dword, when it lay inside the buffer, is already here)
-                uint32_t w = (st == 0 && p - 3 >= buf_lo) ? w_first : ld4(p - 3);
-                const uint32_t prev = k == 0 ? (d0 | 0xFu) : (st == 0 ? prev_first : (uint32_t)p[1]);
-                const uint32_t v = min(nv - k, 4u);
-                w &= (uint32_t)(0xFFFFFFFF00000000ull >> (8u * v));                 // bytes past the segment read as 0
-                const uint32_t l7 = w & 0x7F7F7F7Fu;
-                const uint32_t g = (l7 + 0x70707070u) & w & 0x80808080u;          // byte > 0x8F
-                const uint32_t e = (l7 + 0x01010101u) & 0x80808080u;              // 7 LSBs all ones
-                const uint32_t s7 = e & ((g >> 8) | ((prev > 0x8Fu ? 1u : 0u) << 31));   // byte carries 7 bits
-                const uint32_t s3 = s7 >> 31, s2 = (s7 >> 23) & 1u, s1 = (s7 >> 15) & 1u, s0 = (s7 >> 7) & 1u;
-                const uint32_t sh2 = 8u - s3, sh1 = sh2 + 8u - s2, sh0 = sh1 + 8u - s1;
-                val = ((w >> 24) & (0xFFu >> s3)) | ((((w >> 16) & 0xFFu) & (0xFFu >> s2)) << sh2) |
-                      ((((w >> 8) & 0xFFu) & (0xFFu >> s1)) << sh1) | (((w & 0xFFu) & (0xFFu >> s0)) << sh0);
-                nb = 32u - s3 - s2 - s1 - s0;
-            }
-            const uint32_t incl = wave_incl_scan(nb);
-            if (nb) {
-                const uint32_t pos = bits + incl - nb - 32u * flushed;
-                const uint64_t x = (uint64_t)val << (pos & 31u);
-                lds_or(&acc[0][pos >> 5], (uint32_t)x);
-                lds_or(&acc[0][(pos >> 5) + 1], (uint32_t)(x >> 32));
-            }
-            bits += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if ((st + 1) % kPrepSteps == 0 && st + 1 < steps) {        // the finished words leave, the partial one moves to the front
-                __syncthreads();
-                const uint32_t full = (bits >> 5) - flushed;
-                for (uint32_t i = lane; i < full; i += 64) out_v[flushed + i] = acc[0][i];
-                const uint32_t carry = acc[0][full];
-                __syncthreads();
-                for (uint32_t i = lane; i < kPrepWords; i += 64) acc[0][i] = 0;
-                __syncthreads();
-                if (lane == 0) acc[0][0] = carry;
-                flushed += full;
-                __syncthreads();
-            }
-        }
-        __syncthreads();
-        for (uint32_t i = flushed + lane; i < vwords; i += 64) out_v[i] = i - flushed < kPrepWords ? acc[0][i - flushed] : 0u;   // zeros behind the end
-    }
-    // ---- MEL: bytes D[lcup - scup + i], forward; lane k of a step takes four, MSB-first bits
-    {
-        const uint8_t* M = D + lcup - scup;
-        uint32_t bits = 0, flushed = 0;
-        const uint32_t steps = (nm + 255u) / 256u;
-        for (uint32_t st = 0; st < steps; ++st) {
-            const uint32_t k = st * 256u + 4u * lane;
-            uint32_t val = 0, nb = 0;                                  // val: the lane's bits, MSB aligned
-            if (k < nm) {
-                uint32_t w = ld4(M + k);                               // byte 0 first
-                const uint32_t v = min(nm - k, 4u);
-                const uint32_t valid = (uint32_t)((1ull << (8u * v)) - 1ull);
-                w &= valid;
-                if (k + v == nm) w |= 0x0Fu << (8u * (v - 1u));        // the segment's last byte
-                const uint32_t prev = k == 0 ? 0u : (uint32_t)M[k - 1];
-                const uint32_t ff = ((w & 0x7F7F7F7Fu) + 0x01010101u) & w & 0x80808080u;    // byte == 0xFF
-                const uint32_t s7 = ((ff << 8) | ((prev == 0xFFu ? 1u : 0u) << 7)) & 0x80808080u & valid;
-                // byte j follows a 0xFF: 7 bits, its MSB dropped
-                const uint32_t f0 = (s7 >> 7) & 1u, f1 = (s7 >> 15) & 1u, f2 = (s7 >> 23) & 1u, f3 = s7 >> 31;
-                const uint32_t b0 = w & (0xFFu >> f0), b1 = (w >> 8) & (0xFFu >> f1), b2 = (w >> 16) & (0xFFu >> f2), b3 = (w >> 24) & (0xFFu >> f3);
-                const uint32_t w0 = 8u - f0, w1 = v > 1 ? 8u - f1 : 0u, w2 = v > 2 ? 8u - f2 : 0u, w3 = v > 3 ? 8u - f3 : 0u;
-                nb = w0 + w1 + w2 + w3;
-                uint64_t t = b0;
-                t = (t << w1) | (v > 1 ? b1 : 0u);
-                t = (t << w2) | (v > 2 ? b2 : 0u);
-                t = (t << w3) | (v > 3 ? b3 : 0u);
-                val = (uint32_t)(t << (32u - nb));
-            }
-            const uint32_t incl = wave_incl_scan(nb);
-            if (nb) {
-                const uint32_t pos = bits + incl - nb - 32u * flushed;
-                const uint64_t x = ((uint64_t)val << 32) >> (pos & 31u);
-                lds_or(&acc[1][pos >> 5], (uint32_t)(x >> 32));
-                lds_or(&acc[1][(pos >> 5) + 1], (uint32_t)x);
-            }
-            bits += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if ((st + 1) % kPrepSteps == 0 && st + 1 < steps) {
-                __syncthreads();
-                const uint32_t full = (bits >> 5) - flushed;
-                for (uint32_t i = lane; i < full; i += 64) out_m[flushed + i] = acc[1][i];
-                const uint32_t carry = acc[1][full];
-                __syncthreads();
-                for (uint32_t i = lane; i < kPrepWords; i += 64) acc[1][i] = 0;
-                __syncthreads();
-                if (lane == 0) acc[1][0] = carry;
-                flushed += full;
-                __syncthreads();
-            }
-        }
-        __syncthreads();
-        // ones behind the data (an exhausted MEL segment reads as 0xFF bytes)
-        const uint32_t lastw = (bits >> 5) - flushed;
-        if (lane == 0) acc[1][lastw] |= 0xFFFFFFFFu >> (bits & 31u);
-        __syncthreads();
-        for (uint32_t i = flushed + lane; i < mwords; i += 64)
-            out_m[i] = i - flushed <= lastw ? acc[1][i - flushed] : 0xFFFFFFFFu;
-    }
+    if (q >= lo && q + 4 <= hi) return *reinterpret_cast<const u32_unaligned*>(q);
+    return (q + 0 >= lo && q + 0 < hi ? (uint32_t)q[0] : 0u) | (q + 1 >= lo && q + 1 < hi ? (uint32_t)q[1] << 8 : 0u) |
+           (q + 2 >= lo && q + 2 < hi ? (uint32_t)q[2] << 16 : 0u) | (q + 3 >= lo && q + 3 < hi ? (uint32_t)q[3] << 24 : 0u);
 }
 
 // ---- K5a --------------------------------------------------------------------------------------------
-// One lane per code-block walks the block's VLC and MEL bits (K5p's raw arrays: no stuffing left) and emits one word per
+// One lane per code-block walks the block's VLC and MEL bits and emits one word per
 // quad, 16 bits: what K5b needs of the CxtVLC table entry (9 bits) | (u_q + 1) << 9.  The kernel is one dependent chain per lane, issue-bound at ~8.5 cycles per
-// instruction while a SIMD holds <= 2 waves, so it is written for instruction COUNT: 32-bit windows over the raw
-// bits (one 64-bit shift per quad pair, plain 32-bit shifts inside the pair; the next word is fetched a pair ahead), the
+// instruction while a SIMD holds <= 2 waves, so it is written for instruction COUNT: the pair's 32 VLC bits are the
+// low word of the shift register, plain 32-bit shifts inside the pair, the
 // neighbour-significance part of both quads' contexts out of one shift-or of the row above, table entries that carry what
 // the chain needs next in place (the next quad's context bits at their position in the table ADDRESS, the quad's bottom-row
 // significance for the row below), UVLC prefixes by v_perm from a register-resident 8-entry table.
@@ -240,65 +98,135 @@ __device__ uint2 g_vlc_dec2[2048];          // [0..1023] first quad row, [1024..
                                             // .x = the 16-bit CxtVLC entry (len | u_off << 3 | rho << 4 | e_1 << 8 | e_k << 12),
                                             // .y = K5b's 9 bits of the entry | next context bits << 9 (address position) | bottom-row significance << 28
 
-// The VLC bits of one quad ROW pass through LDS: a quad row of <= 16 pairs consumes <= 16 x 30 bits, so the <= 18 words it can
-// reach are fetched in one batch at the row's start (independent loads, one wait) and the pair loop refills its window from
+// The VLC bytes of one quad ROW pass through LDS: a quad row of <= 16 pairs consumes <= 16 x 30 bits and the register holds <= 63
+// more, 543 bits -- 20 dwords even if every byte carried 7 bits (a conforming stream: every other byte at most) --, so they are
+// fetched in one batch at the row's start (independent loads, one wait) and the pair loop refills its register from
 // LDS.  A global load per pair would put `s_waitcnt vmcnt(0)` -- gfx9 counts loads and stores with one counter, and the
 // compiler merges the wait over the loop's back edge -- and with it the round trip of the pair's own quad-info STORE on the
-// serial chain (measured: the kernel was no faster than r02's with half the instructions).
-constexpr uint32_t kRowWords = 18, kRowStride = 19;       // (odd stride: the lanes' copies of word j lie in different banks)
+// serial chain (measured in r03: the kernel was no faster than r02's with half the instructions).
+constexpr uint32_t kRowWords = 20, kRowStride = 21;       // (odd stride: the lanes' copies of word j lie in different banks)
 struct VlcBits {      // LSB first
-    const uint32_t* w; uint32_t* row; uint32_t wi, wi0, a, b, c, pos, last;
-    // `words`: what K5p wrote for this block (vlc_words: the bits, then zeros).  A malformed stream can push the cursor past them;
-    // it then reads the block's own last (zero) word again and again -- never a neighbour's scratch or memory behind the buffer
-    __device__ __forceinline__ void init(const uint32_t* p, uint32_t* lds_row, uint32_t words) { w = p; row = lds_row; wi = 0; wi0 = 0; pos = 0; a = p[0]; b = p[1]; c = 0; last = words - 1u; }
-    // the words wi + 2 .. wi + 2 + kRowWords - 1 into the lane's LDS row (wi is where the window stands now)
+    const uint8_t* first;             // the byte read first: D + lcup - 3; byte k of the reading order is first[-k]
+    const uint8_t* lo; const uint8_t* hi;
+    uint32_t* row;                    // the lane's LDS row: the dwords of bytes k0 .. k0 + 4 * kRowWords - 1 as loaded (memory order)
+    uint64_t acc; uint32_t n;         // n valid bits, the next one is bit 0
+    uint32_t unst;                    // 0x80: the byte before byte k is > 0x8F
+    uint32_t k, nv;                   // bytes handed to acc so far; bytes of the segment (behind them: zeros)
+    uint32_t ri, nxt;                 // next dword of the row; the dword of bytes k .. k + 3 (read a refill ahead)
+    __device__ __forceinline__ void init(const uint8_t* D, int lcup, int scup, uint32_t* lds_row, const uint8_t* buf_lo, const uint8_t* buf_hi)
+    {
+        first = D + lcup - 3; lo = buf_lo; hi = buf_hi; row = lds_row;
+        const uint32_t d0 = D[lcup - 2];
+        n = 4u - (((d0 >> 4) & 7u) == 7u ? 1u : 0u);
+        acc = (d0 >> 4) & ((1u << n) - 1u);
+        unst = (d0 | 0xFu) > 0x8Fu ? 0x80u : 0u;
+        k = 0; nv = (uint32_t)scup - 2u; ri = 0; nxt = 0;
+    }
+    // the dwords of bytes k .. k + 4 kRowWords - 1 into the lane's LDS row, bytes behind the segment's end as zeros
     __device__ __forceinline__ void begin_row()
     {
-        wi0 = wi;
         uint32_t t[kRowWords];
-        if (wi0 + 1u + kRowWords <= last) {
+        const uint8_t* p = first - k - 3;                        // lowest address of the first dword
+        if (k + 4u * kRowWords <= nv && p - 4 * (int)(kRowWords - 1) >= lo && p + 4 <= hi) {
 #pragma unroll
-            for (uint32_t j = 0; j < kRowWords; ++j) t[j] = w[wi0 + 2 + j];
-        } else {                                                 // the block's last rows: index by index
+            for (uint32_t j = 0; j < kRowWords; ++j) t[j] = *reinterpret_cast<const u32_unaligned*>(p - 4 * (int)j);
+        } else {                                                 // the segment's last rows (or a block at the buffer's start)
 #pragma unroll
-            for (uint32_t j = 0; j < kRowWords; ++j) t[j] = w[min(wi0 + 2 + j, last)];
+            for (uint32_t j = 0; j < kRowWords; ++j) {
+                const uint32_t kk = k + 4u * j;
+                const uint32_t v = kk < nv ? min(nv - kk, 4u) : 0u;           // valid bytes: the HIGH addresses of the dword
+                const uint32_t w = v ? ld4_guarded(p - 4 * (int)j, lo, hi) : 0u;
+                t[j] = v >= 4u ? w : (v ? w & (0xFFFFFFFFu << (8u * (4u - v))) : 0u);
+            }
         }
 #pragma unroll
-        for (uint32_t j = 0; j < kRowWords; ++j) row[j] = t[j];
-        c = t[0];
+        for (uint32_t j = 1; j < kRowWords; ++j) row[j] = t[j];
+        nxt = t[0]; ri = 1;
     }
-    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)((((uint64_t)b << 32) | a) >> (pos & 31u)); }   // 32 valid bits
-    __device__ __forceinline__ void advance(uint32_t used)       // used <= 32
+    // four more bytes into the register (rev_read): at most once per pair, 28 .. 32 bits
+    __device__ __forceinline__ void refill()
     {
-        pos += used;
-        const uint32_t nwi = pos >> 5;
-        const bool step = nwi != wi;
-        a = step ? b : a; b = step ? c : b; wi = nwi;
-        c = row[wi - wi0];                                       // word wi + 2 (a pair ahead of its use; the same word again without a step)
+        const uint32_t w = __builtin_bswap32(nxt);               // reading order: first byte in bits 7..0
+        const uint32_t l7 = w & 0x7F7F7F7Fu;
+        const uint32_t g = (l7 + 0x70707070u) & w & 0x80808080u;             // byte > 0x8F
+        const uint32_t e = (l7 + 0x01010101u) & 0x80808080u;                 // 7 LSBs all ones
+        const uint32_t s7 = e & ((g << 8) | unst);                           // bit 7 of a byte that carries 7 bits
+        unst = g >> 24;
+        uint32_t val = w, nb = 32u;
+        if (s7) {                                                            // (rare: K5p's packing, the 7-bit bytes' MSBs dropped)
+            const uint32_t m = w & ~s7;
+            const uint32_t s0 = (s7 >> 7) & 1u, s1 = (s7 >> 15) & 1u, s2 = (s7 >> 23) & 1u, s3 = s7 >> 31;
+            const uint32_t h1 = 8u - s0, h2 = h1 + 8u - s1, h3 = h2 + 8u - s2;
+            val = (m & 0xFFu) | (((m >> 8) & 0xFFu) << h1) | (((m >> 16) & 0xFFu) << h2) | ((m >> 24) << h3);
+            nb = h3 + 8u - s3;
+        }
+        acc |= (uint64_t)val << n;
+        n += nb;
+        k += 4u;
+        nxt = row[ri];
+        ri = min(ri + 1u, kRowWords - 1u);
     }
+    __device__ __forceinline__ uint32_t peek() { if (n < 32u) refill(); return (uint32_t)acc; }   // >= 30 valid bits (a pair takes <= 30)
+    __device__ __forceinline__ void advance(uint32_t used) { acc >>= used; n -= min(used, n); }
 };
 
 struct MelBits {      // MSB first
-    const uint32_t* w; uint32_t wi, a, b, c, pos, last;        // last: the block's last MEL word (ones: an exhausted segment), read for ever
+    const uint8_t* M; const uint8_t* lo; const uint8_t* hi;
+    uint64_t acc; uint32_t n;         // n valid bits, the next one is bit 63
+    uint32_t ff;                      // the byte before byte kb was 0xFF
+    uint32_t kb, nm;                  // bytes handed over so far; bytes of the segment (behind them: 0xFF for ever)
+    uint32_t nxt;                     // bytes kb .. kb + 3, the first one in bits 31..24, as the reader sees them
     int k, run;       // run: what is left of the current run, in the reference's coding (:196-235, :1101-1111):
                       // 2 * (zero events) + 1 if it ends with a one, 2 * (zero events - 1) otherwise
-    __device__ __forceinline__ void init(const uint32_t* p, uint32_t words)
+    __device__ __forceinline__ uint32_t fetch(uint32_t at) const
     {
-        w = p; wi = 0; pos = 0; a = p[0]; b = p[1]; c = p[2]; k = 0; run = -1; last = words - 1u;
+        if (at >= nm) return 0xFFFFFFFFu;
+        const uint32_t v = min(nm - at, 4u);
+        uint32_t w = __builtin_bswap32(ld4_guarded(M + at, lo, hi));
+        if (v < 4u) w |= 0xFFFFFFFFu >> (8u * v);                // behind the end: 0xFF
+        if (at + v == nm) w |= 0x0Fu << (8u * (4u - v));         // the segment's last byte
+        return w;
+    }
+    __device__ __forceinline__ void refill()                     // (mel_read)
+    {
+        const uint32_t w = nxt;
+        const uint32_t f = ((w & 0x7F7F7F7Fu) + 0x01010101u) & w & 0x80808080u;   // byte == 0xFF
+        const uint32_t s7 = (f >> 8) | (ff << 31);               // bit 7 of a byte that follows a 0xFF: 7 bits, its MSB dropped
+        ff = (f >> 7) & 1u;
+        uint32_t val = w, nb = 32u;
+        if (s7) {
+            const uint32_t f0 = s7 >> 31, f1 = (s7 >> 23) & 1u, f2 = (s7 >> 15) & 1u, f3 = (s7 >> 7) & 1u;     // byte 0 = the first read
+            const uint32_t b0 = (w >> 24) & (0xFFu >> f0), b1 = (w >> 16) & 0xFFu & (0xFFu >> f1);
+            const uint32_t b2 = (w >> 8) & 0xFFu & (0xFFu >> f2), b3 = w & 0xFFu & (0xFFu >> f3);
+            const uint32_t w1 = 8u - f1, w2 = 8u - f2, w3 = 8u - f3;
+            nb = 8u - f0 + w1 + w2 + w3;
+            uint64_t t = b0;
+            t = (t << w1) | b1; t = (t << w2) | b2; t = (t << w3) | b3;
+            val = (uint32_t)(t << (32u - nb));
+        }
+        acc |= ((uint64_t)val << 32) >> n;
+        n += nb;
+        kb += 4u;
+        nxt = fetch(kb);
+    }
+    __device__ __forceinline__ void init(const uint8_t* D, int lcup, int scup, const uint8_t* buf_lo, const uint8_t* buf_hi)
+    {
+        M = D + lcup - scup; lo = buf_lo; hi = buf_hi; nm = (uint32_t)scup - 1u;
+        acc = 0; n = 0; ff = 0; kb = 0; k = 0; run = -1;
+        nxt = fetch(0);
+        refill();
         decode_run();
     }
     __device__ __forceinline__ void decode_run()                 // (:196-235)
     {
         const uint32_t e = (k < 8 ? 0x22111000u >> (4 * k) : 0x54332u >> (4 * (k - 8))) & 0xFu;   // MEL exponents (:196)
-        const uint32_t top = (uint32_t)(((((uint64_t)a << 32) | b) << (pos & 31u)) >> 32);
+        const uint32_t top = (uint32_t)(acc >> 32);
         const bool one = (top >> 31) != 0;                       // '1': 2^e zero events; '0' + e bits: that many, then a one
         run = one ? (int)((2u << e) - 2u) : (int)((((top >> (31u - e)) & ((1u << e) - 1u)) << 1) | 1u);
         k = one ? (k < 12 ? k + 1 : 12) : (k > 0 ? k - 1 : 0);
-        pos += one ? 1u : e + 1u;
-        const uint32_t nwi = pos >> 5;
-        const bool step = nwi != wi;
-        a = step ? b : a; b = step ? c : b; wi = nwi;
-        c = w[min(wi + 2u, last)];
+        const uint32_t used = one ? 1u : e + 1u;
+        acc <<= used; n -= used;
+        if (n < 32u) refill();
     }
     // One MEL event if `need` (:1101-1111): returns 1 if the run ends here with a one.  The decode of the next run sits
     // behind a branch the whole wave skips when no lane has used its run up: in dense blocks (contexts rarely zero) and in
@@ -342,11 +270,12 @@ __global__ void ht_dec_vlc_kernel(HtDecArgs a)
     if (!ht_segments(a, blk, in, lcup, scup)) { atomicOr(a.status, 4u); a.ms_len[blk] = 0xFFFFFFFFu; return; }
     a.ms_len[blk] = (uint32_t)(lcup - scup);
 
-    const uint32_t* raw = a.vraw + a.vbase[blk];
+    const uint8_t* const D = a.coded + in.offset;
+    const uint8_t* const buf_hi = a.coded + a.coded_bytes;
     MelBits mel;
-    mel.init(raw, mel_words((uint32_t)scup));
+    mel.init(D, lcup, scup, a.coded, buf_hi);
     VlcBits vlc;
-    vlc.init(raw + mel_words((uint32_t)scup), rows_l + threadIdx.x * kRowStride, vlc_words((uint32_t)scup));
+    vlc.init(D, lcup, scup, rows_l + threadIdx.x * kRowStride, a.coded, buf_hi);
     const uint32_t NP = (QW + 1) >> 1;  // quad pairs per row
     uint64_t sa = 0;                     // significance of the bottom sample row of the quad row above: bit x
     uint32_t umax = 0;                   // largest u_q + 1 of the block (:1194: > missing_msbs rejects it)
@@ -848,8 +777,6 @@ hipError_t launch_ht_decode_front(const HtDecArgs& a, hipStream_t s)
         }
     }
     if (a.nactive == 0) return hipSuccess;
-    // K5p: one wave per block with data
-    hipLaunchKernelGGL(ht_dec_prep_kernel, dim3(a.nactive), dim3(64), 0, s, a);
     // K5a is one serial chain per lane.  A wave costs the same issue slots however many lanes are
     // live, so few lanes per wave multiply the instruction count, while few waves per SIMD leave the
     // chain's own latency exposed: aim for ~1.5-2 waves per SIMD (1024 SIMDs), measured optimum.

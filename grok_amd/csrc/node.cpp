@@ -127,9 +127,9 @@ extern "C" int grk_amd_node_create(const int* devices, uint32_t n, int verbose, 
         nd->w[i].device = devs[i];
         const int rc = grk_amd_create(devs[i], verbose, &nd->w[i].ctx);
         if (rc != GRK_AMD_OK) { grk_amd_node_destroy(nd); return rc; }
-        // kRing + 1 buffer sets in rotation: the coded bytes of a geometry group stay where they are while the next groups are
-        // coded, so that their copy to the writer's device runs beside those encodes instead of being waited for
-        (void)grk_amd_set_pipelining(nd->w[i].ctx, kRing);
+        // (the rotation of kRing + 1 buffer sets -- each a set of Mallat planes, arena and tables: several GB per 8K-tile worker --
+        //  is switched on by the first GATHER encode only: parallel writers never use it, and a context handed out through
+        //  grk_amd_node_ctx keeps the result lifetime and memory behaviour of a context the caller made itself)
         if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&nd->w[i].copy, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
             grk_amd_node_destroy(nd);
@@ -264,6 +264,10 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
             int rc = GRK_AMD_OK;
             uint64_t coded_used = 0;                       // this worker's coded bytes so far (all its groups, one after the other)
             size_t ngroup = 0;                             // gather: groups whose bytes are on their way
+            // gather: kRing + 1 buffer sets in rotation -- the coded bytes of a geometry group stay where they are while the next
+            // groups are coded, so that their copy to the writer's device runs beside those encodes instead of being waited for
+            // (memory: x (kRing + 1) of the worker's planes / arena / tables); parallel writers: one set
+            if (gather && geoms.size() > 1 && grk_amd_get_pipelining(w.ctx) < kRing) (void)grk_amd_set_pipelining(w.ctx, kRing);
             for (size_t k = 0; k < geoms.size() && rc == GRK_AMD_OK; ++k) {
                 std::vector<uint32_t> mine;
                 for (uint32_t t = r; t < ntiles; t += R) if (group_of[t] == k) mine.push_back(t);

@@ -22,6 +22,7 @@ import ctypes as C
 
 import numpy as np
 import os
+import time
 import torch
 import torch.distributed as dist
 
@@ -191,6 +192,7 @@ class FramePipeline:
         # a writer's receive storage: one per frame "generation" (f mod (depth + lag)), so that the parts of every gather a
         # submit() or flush() issues stay readable until depth + lag frames later
         self.bufs = [None] * (self.depth + self.lag)
+        self._buf_last = [None] * (self.depth + self.lag)      # per receive storage: the event of its last gather on this rank
         nslot = self.lag + 2                               # counts of the frames whose gather has not been issued yet
         self._host = [torch.empty(self.world, dtype=torch.int64).pin_memory() if cuda else torch.empty(self.world, dtype=torch.int64)
                       for _ in range(nslot)]
@@ -201,21 +203,22 @@ class FramePipeline:
 
     def _issue_gather(self, pending):
         f, cslot, offs, lens, arena, enc_ev = pending
-        if self._ready[cslot] is not None:         # the counts of frame f are on the host (frame f + 1 is already queued):
-            ev = self._ready[cslot]                # polled briefly -- a blocking wait wakes up late, and the next frame's
-            spins = 0                              # launches have to be queued while this one runs -- then a blocking wait
-            while spins < 20000 and not ev.query():    # (a peer that is late or has failed must not leave this rank
-                spins += 1                             # burning a core forever: the collective's own timeout applies)
-            if not ev.query():
-                ev.synchronize()
+        if self._ready[cslot] is not None:         # the counts of frame f are on the host (frame f + lag is already queued):
+            ev = self._ready[cslot]                # polled for at most ~50 us -- a blocking wait wakes up late, and the next frame's
+            if not ev.query():                     # launches have to be queued while this one runs --, then a blocking wait: a peer
+                t_end = time.perf_counter() + 50e-6    # that is late or has failed must not leave this rank burning a host core
+                while time.perf_counter() < t_end and not ev.query():     # (eight ranks share one host)
+                    pass
+                if not ev.query():
+                    ev.synchronize()
         counts = [[int(v), self.rows[r]] for r, v in enumerate(self._host[cslot].tolist())]
         root = f % self.world
         g, b = f % self.depth, f % len(self.bufs)
         mine = self.bufs[b] if self.rank == root else None
         if self.streams is not None:
-            before = self._done.get(f - len(self.bufs))        # the gather that used this receive storage last (another stream)
-            if before is not None:
-                self.gstreams[g].wait_event(before)
+            before = self._buf_last[b]                         # the gather that used this receive storage last ON THIS RANK (it may
+            if before is not None:                             # have run on another gather stream: frames b, b + len(bufs), ... share it,
+                self.gstreams[g].wait_event(before)            # and this rank is the writer of only some of them)
             if enc_ev is not None:                             # the frame's encode: long finished (lag frames ago) -- a gather
                 self.gstreams[g].wait_event(enc_ev)            # stream never sits waiting for work that is still to run
             with torch.cuda.stream(self.gstreams[g]):
@@ -224,12 +227,17 @@ class FramePipeline:
                 ev.record(self.gstreams[g])
                 self._done[f] = ev
                 self.gather_done = ev
+                if self.rank == root:
+                    self._buf_last[b] = ev
         else:
             parts, bufs = gather_frame(counts, offs, lens, arena, root, mine, self.groups[g])
         if bufs is not None:
             self.bufs[b] = bufs
         self.last_parts, self.last_root = parts, root
         self.completed.append((f, parts, root))
+        # (a caller that never pops: entries older than the receive storage's rotation point at bytes that have been overwritten)
+        if len(self.completed) > len(self.bufs):
+            del self.completed[:len(self.completed) - len(self.bufs)]
 
     def submit(self, frame, used, offsets, lengths, arena, wait_results=None):
         """Queues the counts exchange of `frame` and issues the gather of the frame before it.

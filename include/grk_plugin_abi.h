@@ -6,8 +6,8 @@
  * A plugin normally compiles against grok.h; this repository must not carry reference sources,
  * so the part of that ABI the hot path touches is RESTATED here under our own type names
  * (gra_*).  Field order, types and array bounds are the ABI and therefore identical; the mirror
- * is verified field by field against the real header by tests/test_plugin_abi.py (sizeof /
- * offsetof of every struct through oracle/_ref) -- if Grok's header changes, that test fails.
+ * is verified field by field against the real header by tests/test_plugin_host.py::test_abi_mirror_compiled_against_grok_headers (sizeof /
+ * offsetof of every struct through oracle/_ref, oracle/ref_harness/abi_check.cpp) -- if Grok's header changes, that test fails.
  *
  *   mirror type                      reference type (src/lib/jp2/grok.h)
  *   gra_plugin_pass                  grk_plugin_pass                 :1190-1194

@@ -202,6 +202,15 @@ int grk_amd_decode_status(grk_amd_ctx* ctx);
  * environment before its first HIP call (6.2-6.8 with six); the library leaves the variable alone: it is process-wide, and the
  * encode pipeline beside an RCCL exchange measured 25 % slower on anything but the default. */
 int grk_amd_set_decode_pipelining(grk_amd_ctx* ctx, int frames_in_flight);
+/* Buffer lifetime in a decode sequence.  With n frames in flight a call's device buffers -- the coded bytes it reads, the pixels
+ * it writes -- are in use until THAT frame has been decoded, which is up to n calls later and on streams of the library's own:
+ * work the caller queues on the context's stream (or any other) is NOT ordered behind it.  A caller therefore rotates n coded /
+ * pixel buffers (as many as frames in flight) and, before it overwrites or reads the buffers it handed over n calls ago -- the
+ * ones the NEXT grk_amd_decode_tiles call will reuse the same internal set for --, makes its stream wait:
+ *     grk_amd_decode_stream_wait_slot(ctx, stream);   upload frame f's coded bytes on `stream`;   grk_amd_decode_tiles(...);
+ * (no host synchronisation: a stream-side wait for the event behind that set's last frame; without a sequence it is
+ * grk_amd_stream_wait_results).  grk_amd_synchronize(ctx) remains the blunt form: all frames of all sets. */
+int grk_amd_decode_stream_wait_slot(grk_amd_ctx* ctx, void* hip_stream);
 /* 8-bit reversible HT tiles are decoded with int16 planes between the block decoder and the inverse DWT (default on; half
  * the bytes of the two HBM-bound halves of the decode), and the inverse 5/3 runs on packed pairs of them, which takes every
  * coefficient and every synthesised LL sample within +-2047 (an 8-bit image's are: |HH| <= 1020 at the top resolution, the
@@ -371,8 +380,10 @@ int64_t grk_amd_locate_tile_parts(const uint8_t* cs, uint64_t len, uint64_t* off
  *     runs Tier-2 for all tiles.
  * `devices` lists the HIP devices to use (NULL / 0: all of the node); an entry may repeat (several contexts on one GPU).
  * `pixels` is the whole image, component-major planar, tight, in host memory (pinned or not).
- * In gather mode a worker's encodes rotate four buffer sets, so that a geometry group's bytes travel to the writer while the
- * worker's next groups are coded (an event per group, one wait behind the last). */
+ * In gather mode a worker whose tiles fall into more than one geometry group rotates four buffer sets, so that a group's bytes
+ * travel to the writer while the worker's next groups are coded (an event per group, one wait behind the last); the rotation is
+ * switched on by the first such encode and multiplies that worker's device memory for planes, arena and tables by four (several
+ * GB for 8K tiles).  Parallel writers, and contexts taken through grk_amd_node_ctx before any gather, keep one set. */
 typedef struct grk_amd_node grk_amd_node;
 #define GRK_AMD_NODE_GATHER 0x80000000u
 int  grk_amd_device_count(void);

@@ -72,3 +72,21 @@ def test_more_gpus_than_the_box_has_is_refused_loudly():
 def test_a_launcher_with_another_world_size_is_refused():
     r = _run_bench("--gpus", "4", "--dry-run", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_gather_watchdog_prints_the_counts_figures_when_a_rank_stalls():
+    """A rank that never joins the gather's collective (--dry-run-stall, gloo): rank 0's watchdog prints the line with what it
+    already holds -- the counts exchange -- and exchange.gather = {"error": ...}; every rank leaves with --gather-timeout-rc, so
+    the launcher's status is non-zero exactly when asked for."""
+    import json
+    r = _run_bench("--gpus", "2", "--dry-run", "--dry-run-stall", "1", "--gather-timeout", "4", "--gather-timeout-rc", "3")
+    assert r.returncode != 0, r.stdout[-500:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    line = json.loads(lines[-1])
+    assert line["exchange"]["counts"] == {"ranks": 2}
+    assert "did not complete within 4 s" in line["exchange"]["gather"]["error"]
+    # default exit code: the line carries the failure, the process status stays clean
+    r = _run_bench("--gpus", "2", "--dry-run", "--dry-run-stall", "0", "--gather-timeout", "4")
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "error" in line["exchange"]["gather"]

@@ -915,3 +915,46 @@ def test_decode_sequence_that_changes_its_kind_of_frames():
             assert np.array_equal(o.cpu().numpy().reshape(C, H, W), px), "frame %d" % i
     finally:
         c.set_decode_pipelining(0)
+
+
+def test_decode_sequence_reuses_two_buffers_behind_the_slot_event():
+    """Buffer lifetime in a sequence (include/grok_amd.h): TWO coded and TWO pixel buffers for two frames in flight, every frame's
+    coded bytes copied into its buffer on a stream of the caller's that first waits for the set's last frame
+    (grk_amd_decode_stream_wait_slot) -- ten different frames come out right, and the pixels of frame f are read on that stream
+    behind the same wait, without a host synchronisation in between."""
+    C, H, W, prec, L = 3, 256, 384, 8, 4
+    p = G.TileParams.make(W, H, C, prec, L)
+    c = G.Context(0)
+    frames = []
+    for f in range(10):
+        px = synth.g2(C, H, W, prec, seed=500 + f)
+        table, coded = c.encode_host(p, px)
+        frames.append((px, table, U.to_dev(np.frombuffer(bytes(coded), np.uint8).copy())))
+    cap = max(int(d.numel()) for _, _, d in frames)
+    n = 2
+    cbuf = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    obuf = [torch.zeros(C * H * W, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    kept = [torch.zeros(C * H * W, dtype=torch.uint8, device="cuda") for _ in frames]
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    c.set_stream(st.cuda_stream)                                  # the caller's uploads and the calls share this stream
+    c.set_decode_pipelining(n)
+    try:
+        with torch.cuda.stream(st):
+            for f, (px, table, d_c) in enumerate(frames):
+                c.decode_stream_wait_slot(st.cuda_stream)         # the set of frame f - n is done with cbuf / obuf [f % n]
+                if f >= n:
+                    kept[f - n].copy_(obuf[f % n], non_blocking=True)     # ... so its pixels can be taken
+                cbuf[f % n][:d_c.numel()].copy_(d_c, non_blocking=True)   # ... and its coded buffer overwritten
+                c.decode_device(p, 1, table, cbuf[f % n].data_ptr(), d_c.numel(), obuf[f % n].data_ptr())
+        c.synchronize()
+        c.decode_status()
+        torch.cuda.synchronize()
+        for f in range(len(frames) - n, len(frames)):
+            kept[f].copy_(obuf[f % n])
+        torch.cuda.synchronize()
+        for f, (px, _, _) in enumerate(frames):
+            assert np.array_equal(kept[f].cpu().numpy().reshape(C, H, W), px), f
+    finally:
+        c.set_decode_pipelining(0)
+        c.set_stream(0)

@@ -43,9 +43,13 @@ if os.environ.get("PROF_FLAT"):                       # a flat frame of that val
 p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev)
 host = np.ascontiguousarray(np.broadcast_to(px.reshape(1, -1), (nt, px.size))).reshape(-1)
 d = torch.from_numpy(host.view(np.uint8).copy()).cuda()
+if os.environ.get("PROF_PIPELINE") == "1":          # as bench.py's timed region runs them: consecutive frames pipelined
+    ctx.set_pipelining(True)
 for _ in range(n):
     ctx.encode_tiles(p, nt, d.data_ptr(), True, fetch=False)
 ctx.synchronize()
+if os.environ.get("PROF_PIPELINE") == "1":
+    ctx.set_pipelining(False)
 if os.environ.get("PROF_DECODE", "1") == "1" and not irrev:
     nb = G.lib().grk_amd_tile_num_blocks(p) * nt
     table, tot = ctx.fetch_table(nb)
