@@ -153,6 +153,7 @@ struct grk_amd_ctx {
     // other blocks and the inverse levels that need only those; the last inverse level waits for it
     hipEvent_t ev_dec_front = nullptr, ev_dec_top = nullptr;
     bool dec_top_pending = false;
+    int k3_room = 3;                  // pipelined encodes: K3 launches that leave registers for the next frame's level 0 -- bit 0 the top class, bit 1 the rest (GRK_AMD_K3_ROOM)
     // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
     // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; 2: lanes wherever they can be used; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
     // Decode of a SEQUENCE of frames (grk_amd_set_decode_pipelining): consecutive grk_amd_decode_tiles calls with device buffers
@@ -561,7 +562,10 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
                 if (!st) continue;
                 HIP_TRY(c, hipStreamWaitEvent(st, c->ev_level0, 0), "side stream waits for the level");
                 ScopedTimer tt(c, st == c->side ? 4 : 8, st);
-                HIP_TRY(c, launch_ht_classes(h, k, k + 1, st), "launch ht encode (side stream)");
+                // (consecutive encodes pipelined: the top class is still running when the next encode's level 0 arrives)
+                HtArgs hs = h;
+                hs.room = (c->pipelining && (c->k3_room & (top ? 1 : 2))) ? 1 : 0;
+                HIP_TRY(c, launch_ht_classes(hs, k, k + 1, st), "launch ht encode (side stream)");
             }
             if (l + 1 == L) {
                 HIP_TRY(c, hipEventRecord(c->ev_side, c->side), "record side stream");
@@ -1067,18 +1071,7 @@ int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** o
     if (hipSetDevice(device_id) != hipSuccess) return GRK_AMD_ERR_NO_DEVICE;
     auto* c = new grk_amd_ctx();
     c->device = device_id; c->verbose = verbose;
-    // (experiment, r05: the DWT chain's stream on CUs of its own -- GRK_AMD_CU_MAIN = k: the main stream runs on mask bits [0, k);
-    //  GRK_AMD_CU_SIDE_EXCL = k: the K3 side streams stay off mask bits [0, k))
-    const int cu_main = getenv("GRK_AMD_CU_MAIN") ? atoi(getenv("GRK_AMD_CU_MAIN")) : 0;
-    const int cu_excl = getenv("GRK_AMD_CU_SIDE_EXCL") ? atoi(getenv("GRK_AMD_CU_SIDE_EXCL")) : 0;
-    auto masked_stream = [](hipStream_t* st, int lo, int hi) {
-        uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int b = lo; b < hi && b < 256; ++b) m[b >> 5] |= 1u << (b & 31);
-        return hipExtStreamCreateWithCUMask(st, 8, m);
-    };
-    if ((cu_main > 0 ? masked_stream(&c->stream, 0, cu_main) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
-        delete c; return GRK_AMD_ERR_NO_DEVICE;
-    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GRK_AMD_ERR_NO_DEVICE; }
     c->own_stream = true;
     {   // side stream for K3 of the top resolution (lowest priority: the DWT chain on the main stream is the critical path)
         int least = 0, greatest = 0;
@@ -1089,14 +1082,15 @@ int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** o
         if (const char* ex = getenv("GRK_AMD_DWT_PK")) c->dwt_pk = atoi(ex) != 0;
         if (const char* ed = getenv("GRK_AMD_DEC_PLANES16")) c->dec_planes16 = atoi(ed) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
+        if (const char* ek = getenv("GRK_AMD_K3_ROOM")) c->k3_room = atoi(ek) & 3;
         if (const char* et = getenv("GRK_AMD_T1_LANES")) c->t1_lanes = atoi(et);
         if (const char* er = getenv("GRK_AMD_T1_TAIL_RATIO")) c->t1_tail_ratio = (float)atof(er);
         if (const char* es = getenv("GRK_AMD_T1_TAIL_SHARE")) c->t1_tail_share = (float)atof(es);
         if (const char* ey = getenv("GRK_AMD_T1_SYNC")) c->t1_pass_sync = atoi(ey) != 0;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
-        if ((cu_excl > 0 ? masked_stream(&c->side, cu_excl, 256) : hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least)) != hipSuccess ||
-            (!decode_only && (cu_excl > 0 ? masked_stream(&c->side2, cu_excl, 256) : hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least)) != hipSuccess) ||
+        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
+            (!decode_only && hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, least) != hipSuccess) ||
             hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
             !create_alt_events(c) ||
             hipEventCreateWithFlags(&c->ev_level0, hipEventDisableTiming) != hipSuccess ||

@@ -64,6 +64,7 @@ struct HtClass {
 struct HtArgs {
     const int32_t* mallat; uint32_t stride; uint64_t pitch;   // planes [tile][comp] (stride, pitch in elements)
     int h16;                                                  // the planes hold int16 coefficients (reversible only)
+    int room;                                                 // the launch runs beside the next frame's DWT level 0: the instance that leaves it registers (kernels_ht.hip)
     const HtBlockDesc* blocks; uint32_t blocks_per_tile; uint32_t ncomp; uint32_t ntiles;
     uint8_t*  arena; uint64_t arena_bytes;      // coded bytes of all blocks (chunked region allocator, kernels_ht.hip)
     unsigned long long* alloc;                  // kHtAllocBytes of allocator state: [0] status flags (bit 0 arena

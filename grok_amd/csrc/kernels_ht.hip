@@ -96,6 +96,16 @@ __device__ __forceinline__ void mel_put_bit(MelState& m, uint8_t*, int v, bool)
         m.acc = 0;
     }
 }
+// n <= 6 bits (MSB first) at once: at most one byte is completed on the way (a byte has 8 bits, 7 behind a 0xFF)
+__device__ __forceinline__ void mel_put_bits(MelState& m, uint32_t v, uint32_t n)
+{
+    if ((int)n < m.left) { m.acc = (m.acc << n) | (int)v; m.left -= (int)n; return; }
+    const uint32_t rem = n - (uint32_t)m.left;
+    const uint32_t byte = (((uint32_t)m.acc << m.left) | (v >> rem)) & 0xFFu;
+    mel_put_byte(m, byte);
+    m.left = (byte == 0xFFu ? 7 : 8) - (int)rem;
+    m.acc = (int)(v & ((1u << rem) - 1u));
+}
 __device__ __forceinline__ void mel_flush(MelState& m, uint8_t* buf, int lane)
 {
     if (m.pos < 252 && (m.pos & 3u)) mel_writelane(m.vec, m.word, m.pos >> 2);
@@ -112,8 +122,8 @@ __device__ __forceinline__ void mel_event(MelState& m, uint8_t* buf, int one, bo
             if (m.k < 12) m.k++;
         }
     } else {
-        mel_put_bit(m, buf, 0, writer);
-        for (int t = e; t > 0;) mel_put_bit(m, buf, (m.run >> --t) & 1, writer);
+        // '0', then the e bits of the run so far (run < 2^e): e + 1 <= 6 bits in one piece
+        mel_put_bits(m, (uint32_t)m.run, (uint32_t)e + 1u);
         m.run = 0;
         if (m.k > 0) m.k--;
     }
@@ -679,12 +689,26 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         const uint64_t H = s.H, V = s.V;
         uint64_t Hm = H;
         if (it == 0) {
-            const uint64_t XH = __ballot(xev), XV = __ballot(xv);
-            for (int pr = 0; pr < 16; ++pr) {
-                const int l0 = 2 * pr, l1 = l0 + 1;
-                if ((H >> l0) & 1) mel_event(mel, mel_buf, (int)((V >> l0) & 1), lane == 0);
-                if ((H >> l1) & 1) mel_event(mel, mel_buf, (int)((V >> l1) & 1), lane == 0);
-                if ((XH >> l1) & 1) mel_event(mel, mel_buf, (int)((XV >> l1) & 1), lane == 0);
+            // the first quad row's events, pair by pair: quad 2p's, quad 2p + 1's, the pair's u-event (:652-730).  Laid out in that
+            // order over lanes 0 .. 47 (lane 3p + j takes its flag from lane 2p or 2p + 1: one ds_bpermute) and coded by the loop
+            // below like every other row's -- walked pair by pair on the scalar unit they cost ~1 000 scalar instructions per block
+            // on dense content, where the u-event of all 16 pairs is there (r05, profiles/r05_k3_pairs.txt)
+            const uint32_t lo = (uint32_t)lane & 31u;
+            const uint32_t fl = (((uint32_t)H >> lo) & 1u) | (xev ? 2u : 0u) | ((((uint32_t)V >> lo) & 1u) << 2) | (xv ? 8u : 0u);
+            const uint32_t third = ((uint32_t)lane * 43u) >> 7, j = (uint32_t)lane - 3u * third;      // lane / 3, lane % 3
+            const uint32_t src = 2u * third + (j ? 1u : 0u);
+            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src), (int)fl) >> (j == 2u ? 1u : 0u);
+            const uint64_t EH = __ballot(lane < 48 && (g & 1u));
+            const uint64_t EV = EH & __ballot((g & 4u) != 0u);
+            uint64_t Em = EH;
+            while (Em) {
+                const uint64_t ones = Em & EV;
+                const uint64_t first = ones & (0 - ones);
+                const uint64_t before = first ? Em & (first - 1) : Em;
+                mel_zero_run(mel, mel_buf, (uint32_t)__builtin_popcountll(before), lane == 0);
+                if (!first) break;
+                mel_event(mel, mel_buf, 1, lane == 0);
+                Em &= ~(first | (first - 1));
             }
             Hm &= 0xFFFFFFFF00000000ull;
         }
@@ -962,11 +986,26 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             mel_pin(mel);
             uint64_t HA = s.H[0], VA = s.V[0], HB = s.H[1], VB = s.V[1];
             if (it == 0) {
-                const uint64_t XH = __ballot(xev), XV = __ballot(xv);
-                for (int pr = 0; pr < 16; ++pr) {
-                    if ((HA >> pr) & 1) mel_event(mel, mel_buf, (int)((VA >> pr) & 1), lane == 0);
-                    if ((HB >> pr) & 1) mel_event(mel, mel_buf, (int)((VB >> pr) & 1), lane == 0);
-                    if ((XH >> pr) & 1) mel_event(mel, mel_buf, (int)((XV >> pr) & 1), lane == 0);
+                // The first quad row's events come pair by pair: quad A's, quad B's, the pair's u-event (:652-730) -- on dense content
+                // the u-event of all 16 pairs.  Walked pair by pair on the scalar unit (three tests and up to three trips through the
+                // state machine per pair) they were ~1 000 of K3's 2 300 scalar instructions per block, 15 % of its time for ~17 events
+                // (profiles/r05_k3_pairs.txt).  Now the 48 flags are laid out in event order over lanes 0 .. 47 -- lane 3p + j takes
+                // flag j of pair p from lane p (one ds_bpermute) -- and ONE ballot pair feeds the same run-skipping loop as every other row.
+                const uint32_t lo = (uint32_t)lane & 31u;
+                const uint32_t fl = (((uint32_t)HA >> lo) & 1u) | ((((uint32_t)HB >> lo) & 1u) << 1) | (xev ? 4u : 0u) |
+                                    ((((uint32_t)VA >> lo) & 1u) << 3) | ((((uint32_t)VB >> lo) & 1u) << 4) | (xv ? 32u : 0u);
+                const uint32_t third = ((uint32_t)lane * 43u) >> 7;                     // lane / 3
+                const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * third), (int)fl) >> ((uint32_t)lane - 3u * third);
+                const bool in_row = lane < 48;
+                uint64_t EH = __ballot(in_row && (g & 1u)), EV = EH & __ballot((g & 8u) != 0u);
+                while (EH) {
+                    const uint64_t ones = EH & EV;
+                    const uint64_t first = ones & (0 - ones);              // the next one-event (0: none left)
+                    const uint64_t before = first ? EH & (first - 1) : EH;
+                    mel_zero_run(mel, mel_buf, (uint32_t)__builtin_popcountll(before), lane == 0);
+                    if (!first) break;
+                    mel_event(mel, mel_buf, 1, lane == 0);
+                    EH &= ~(first | (first - 1));
                 }
                 HA &= ~0xFFFFull; HB &= ~0xFFFFull;
             }
@@ -1231,9 +1270,20 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     }
 }
 
-template <bool IRREV, bool H16>
+// ROOM: the launch runs beside the NEXT frame's DWT level 0 (the top class of a pipelined encode, on the low-priority side stream).
+// A level-0 workgroup is four waves of 72 registers and 24 KB of LDS; K3 at its natural 96 registers x 5 waves leaves a SIMD 32
+// registers, so a level-0 workgroup -- the critical path of the pipeline -- finds room on a CU only when a wave of K3 has retired on
+// EVERY SIMD of it.  The ROOM instance claims 104 registers (it uses 95): four waves per SIMD, 96 registers and 57 KB of LDS free
+// for the DWT.  Alone it is 10 % slower (0.295 against 0.267 ms for the 8K frame), beside the DWT the pipelined step goes from
+// 0.412 to 0.367-0.376 ms per frame on the same box; capping K3's waves with LDS instead takes the LDS the DWT needs (0.449), CU
+// masks lose outright (profiles/r05_k3_pairs.txt, profiles/r05_sq_overlapped_8k.txt).
+template <bool IRREV, bool H16, bool ROOM>
 __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, HtLds L, uint32_t class_id)
 {
+#ifndef GRK_K3_ROOM_REG
+#define GRK_K3_ROOM_REG "v103"
+#endif
+    if constexpr (ROOM) asm volatile("" ::: GRK_K3_ROOM_REG);
     ht_encode_block<IRREV, H16>(a, blockIdx.x % a.sel_count, blockIdx.x / a.sel_count, L, class_id);
 }
 
@@ -1369,11 +1419,15 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
         const uint32_t grid = c.count * a.ntiles;
 #define GRK_HT(KERNEL, G, SH, LL)                                                                                                   \
         do {                                                                                                                        \
-            if (a.irreversible) hipLaunchKernelGGL((KERNEL<true, false>), dim3(G), dim3(64), SH, s, b, LL, k);                   \
-            else if (a.h16)     hipLaunchKernelGGL((KERNEL<false, true>), dim3(G), dim3(64), SH, s, b, LL, k);                    \
-            else                hipLaunchKernelGGL((KERNEL<false, false>), dim3(G), dim3(64), SH, s, b, LL, k);                   \
+            if (a.h16 && !a.irreversible) hipLaunchKernelGGL((KERNEL<false, true>), dim3(G), dim3(64), SH, s, b, LL, k);         \
+            else if (a.irreversible)      hipLaunchKernelGGL((KERNEL<true, false>), dim3(G), dim3(64), SH, s, b, LL, k);          \
+            else                          hipLaunchKernelGGL((KERNEL<false, false>), dim3(G), dim3(64), SH, s, b, LL, k);         \
         } while (0)
-        GRK_HT(ht_encode_kernel, grid, shmem, L);
+        // (the packed 8-bit kernel first: its place in the code object does not move when the others change)
+        if (a.h16 && !a.irreversible && a.room) hipLaunchKernelGGL((ht_encode_kernel<false, true, true>), dim3(grid), dim3(64), shmem, s, b, L, k);
+        else if (a.h16 && !a.irreversible)      hipLaunchKernelGGL((ht_encode_kernel<false, true, false>), dim3(grid), dim3(64), shmem, s, b, L, k);
+        else if (a.irreversible)                hipLaunchKernelGGL((ht_encode_kernel<true, false, false>), dim3(grid), dim3(64), shmem, s, b, L, k);
+        else                                    hipLaunchKernelGGL((ht_encode_kernel<false, false, false>), dim3(grid), dim3(64), shmem, s, b, L, k);
         // the blocks that outgrew the capped buffers: a small fixed grid walks the list (with nothing on it -- natural
         // images at the top resolution -- its workgroups leave at once)
         if (use_cap) GRK_HT(ht_encode_fallback_kernel, std::min<uint32_t>(grid, 1024u), shmem_full, full);
