@@ -35,3 +35,10 @@ if [[ "$WHAT" == *sq* ]]; then
   PROF_DECODE=1 bash $R/tools/pmc_k3.sh > $OUT/${TAG}_sq_summary_8k.txt 2>&1
 fi
 ls -la $OUT
+if [[ "$WHAT" == *decstats* ]]; then
+  # the decode kernels alone (GRK_AMD_OVERLAP=0, one frame at a time): the csv K5's and the inverse DWT's fractions can be recomputed from
+  rm -rf /tmp/ks3
+  GRK_AMD_OVERLAP=0 PROF_N=10 PROF_DECODE=1 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/ks3 -o p --output-format csv -- python $R/tools/prof_run.py > /tmp/ks3.log 2>&1
+  cp $(find /tmp/ks3 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_decode_no_overlap.csv
+  tail -n 2 /tmp/ks3.log
+fi

@@ -1,5 +1,6 @@
 #!/bin/bash
 # scratch: one GPU-box call of round 5 (edited per call)
 cd $GRAFT_REPO_ROOT
-echo "=== which K3 launches leave room (GRK_AMD_K3_ROOM: bit 0 top class, bit 1 the rest), and how much (r119: 120 registers = 4 waves, 32 free; r135: 136 = 3 waves)"
-timeout 1500 python tools/k3_ab.py --rounds 2 head@GRK_AMD_K3_ROOM=0 head@GRK_AMD_K3_ROOM=1 head@GRK_AMD_K3_ROOM=2 head@GRK_AMD_K3_ROOM=3 r135@GRK_AMD_K3_ROOM=3 r119@GRK_AMD_K3_ROOM=3 2>&1 | grep -v amdgpu | tail -n 8
+echo "=== full gpu suite"; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -n 3
+echo "=== bench"; timeout 900 python bench.py > gpurun_out/bench_r05c.json 2> gpurun_out/bench_r05c.err; tail -c 300 gpurun_out/bench_r05c.err; python tools/show_bench.py gpurun_out/bench_r05c.json 2>&1 | head -40
+echo "=== profile round"; PROF_WLS="8k cfg2 cfg3 cfg5" bash tools/prof_round.sh r05 stats pmc sq decstats 2>&1 | tail -n 30
