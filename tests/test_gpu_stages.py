@@ -369,12 +369,15 @@ def _dev_view(ptr, n, typestr):
     return torch.as_tensor(h, device="cuda")
 
 
-@pytest.mark.parametrize("depth", [1, 2])
-def test_pipelined_encodes_keep_their_results_until_the_second_next_call(depth):
+@pytest.mark.parametrize("depth,room", [(1, None), (2, None), (1, "0"), (2, "1"), (1, "2")])
+def test_pipelined_encodes_keep_their_results_until_the_second_next_call(depth, room, monkeypatch):
     """grk_amd_set_pipelining: consecutive encodes overlap (the next one's DWT runs while this one's blocks are still
     being coded), each working in its own buffer set.  Different images back to back without any fetch in between:
     the device-resident results of encode k are read AFTER encode k+1 (two sets) / k+2 (three sets: set_pipelining(2))
-    has been issued, and equal a plain encode's."""
+    has been issued, and equal a plain encode's.  `room`: GRK_AMD_K3_ROOM -- which K3 launches of the sequence run the
+    instance that leaves registers for the next frame's DWT (default: both classes); the bytes are the same either way."""
+    if room is not None:
+        monkeypatch.setenv("GRK_AMD_K3_ROOM", room)
     p = G.TileParams.make(1024, 768, 3, 8, 5)
     imgs = [synth.g2(3, 768, 1024, 8), (synth.g2(3, 768, 1024, 8)[:, ::-1, :]).copy(), (255 - synth.g2(3, 768, 1024, 8)).astype(np.uint8),
             synth.g2(3, 768, 1024, 8, seed=7), (synth.g2(3, 768, 1024, 8, seed=8)[:, :, ::-1]).copy()]
