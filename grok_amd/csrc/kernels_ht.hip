@@ -18,7 +18,9 @@
 //   * MEL events are gathered with v_cmp (ballot) and run through the 13-state MEL coder on the
 //     scalar unit.
 //   phase B: byte-stuffing + termination + concatenation MagSgn | MEL | VLC(reversed) + Scup
-//     (event walker modelled in oracle/ht_wave_model.c).
+//     (speculative windows; the forms of rounds 1, 3 and 5 are modelled on the CPU in oracle/ht_wave_model.c).
+//   r05: packed 8-bit content is coded TWO quads per lane (phase_a2), pipelined encodes launch a ROOM instance that leaves the
+//     next frame's DWT registers, the VLC stream is emitted once (forwards, staged in LDS): profiles/r05_k3_pairs.txt.
 //
 // Bit-exactness contract: the byte string per block equals ojph_encode_codeblock's for every
 // input with |coefficient| < 2^(Kmax+1) (guaranteed by the BIBO-derived exponents for in-range
@@ -284,48 +286,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 __device__ __forceinline__ uint32_t quad_swap(uint32_t v)          // value of lane ^ 1
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
-}
-
-// Counts the 7-bit bytes of the VLC stream (oracle/ht_wave_model.c: walk(), marks == NULL): VLC bytes are stored backwards
-// from the END of the block, so their number has to be known before the first one is placed.  A byte that follows a byte
-// > 0x8F and whose low 7 bits are ones is 7 bits wide.  A window of 64 raw words is tested at once for positions where that
-// can happen (7 consecutive ones behind such a byte); the candidates do not depend on the byte phase, so all events inside one
-// window are resolved without reloading.  Returns the number of events, last_p = the raw bit the last one starts at.
-__device__ __forceinline__ uint32_t count_vlc_events(const uint32_t* raw, uint32_t nwords, uint32_t nbits, uint32_t& last_p, int lane)
-{
-    uint32_t K = 0, s = 0;
-    while (s + 7u <= nbits) {
-        const uint32_t B = s >> 5;
-        const uint32_t i = B + lane;
-        const uint32_t w0 = i < nwords ? raw[i] : 0u;
-        const uint32_t w1 = i + 1 < nwords ? raw[i + 1] : 0u;
-        const uint64_t hi = w0 | ((uint64_t)w1 << 32);
-        uint64_t c = hi & (hi >> 1);
-        c &= c >> 2;
-        c &= c >> 3;
-        const uint32_t wm = i == 0 ? 0xFFFFFFFFu : (i - 1 < nwords ? raw[i - 1] : 0u);
-        const uint64_t lo = wm | ((uint64_t)w0 << 32);
-        const uint64_t pv = (lo >> 31) & ((lo >> 30) | (lo >> 29) | (lo >> 28));
-        const uint32_t cand = (uint32_t)c & (uint32_t)pv;
-        const uint32_t wend = 32 * (B + 64);
-        // resolve every event of this window; `s` (wave-uniform) is the next byte start
-        while (true) {
-            const uint32_t phase = s & 7, sw = s >> 5;
-            uint32_t m = 0x01010101u << phase;
-            if (i < sw) m = 0;                                   // positions before s are no byte starts
-            else if (i == sw) m &= 0xFFFFFFFFu << (s & 31);
-            const uint32_t hit = cand & m;
-            const uint64_t ballot = __ballot(hit != 0);
-            if (!ballot) { s = wend + phase; break; }
-            const int L = __ffsll((long long)ballot) - 1;
-            const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)hit, L);
-            const uint32_t p = 32 * (B + (uint32_t)L) + (uint32_t)(__ffs((int)hl) - 1);
-            ++K; last_p = p;
-            s = p + 15;
-            if (s >= wend) break;
-        }
-    }
-    return K;
 }
 
 // ---- arena allocation ---------------------------------------------------------------------------
@@ -1075,15 +1035,70 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     // final and stored as they are, otherwise everything before the first event is, the event's 7-bit byte is dealt with on
     // the spot and the next window starts behind it.  r02 found the events with a walker first, kept them in bitmaps with
     // prefix counts, and looked every output dword's start up afterwards (~2.2x the vector instructions of this form).
-    const uint32_t vw = vlc_words;
-    // ---- B1: VLC bytes are stored backwards from the block's END, so their number comes first: the walker, counting only
-    uint32_t vlast = 0;
-    const uint32_t Kv = count_vlc_events(vlc_raw, vw, vlc_bits, vlast, lane);
-    const uint32_t vs0 = Kv ? vlast + 7 : 0;
-    const uint32_t vposr = vs0 + 8 * ((vlc_bits - vs0) >> 3);
+    // ---- B1: VLC bytes are stored backwards from the block's END, so their number comes first.
+    //      r01-r04: a walker that only counts the 7-bit bytes (count_vlc_events), the bytes themselves emitted at the end (B4) --
+    //      the stream is looked at twice, and the walker alone was 6 % of K3 (a what-if build without it: 0.2674 -> 0.2509 ms,
+    //      -199 vector / -155 scalar instructions per block; profiles/r05_k3_pairs.txt).  r05: the emission runs HERE, forwards,
+    //      into a staging area in LDS (vst: byte i of the VLC segment at vst[i]); what the termination needs -- the number of whole
+    //      bytes, the bits left over -- falls out of it, and B4 copies the staged bytes out reversed.
+    uint8_t* const vst = mel_buf + 256;
+    typedef uint32_t u32_lds_any __attribute__((aligned(1)));
+    uint32_t nv, vposr;
+    {
+        uint32_t s = 0, i = 0, prev = 0xFFu << 24;
+        while (true) {
+            const uint32_t avail = (vlc_bits - s) >> 3;              // whole 8-bit bytes left if no 7-bit byte comes
+            if (avail == 0) break;
+            const uint32_t start = s + 32u * (uint32_t)lane;
+            const uint32_t sw = start >> 5;
+            const uint32_t win = __builtin_amdgcn_alignbit(vlc_raw[sw + 1], vlc_raw[sw], start);
+            // the byte before each of the four: lane - 1's top byte (lane 0: the window before, `prev`)
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)prev, (int)win, 0x138, 0xF, 0xF, false);
+            const uint32_t pw = __builtin_amdgcn_alignbit(win, before, 24);
+            const uint32_t e = (win & 0x7F7F7F7Fu) + 0x01010101u;   // bit 7 of a byte: its low 7 bits are ones
+            // flag at bit 4 of a byte: the byte before has bit 7 and one of bits 6..4 (it is > 0x8F), this one's low 7 bits are ones
+            uint32_t z = bitop3<0x80>(pw >> 3, (pw >> 2) | (pw >> 1) | pw, e >> 3) & 0x10101010u;
+            const uint32_t lane4s = 4u * (uint32_t)lane;
+            uint32_t nb = 4;
+            if (avail < 256u) {
+                nb = min(avail - min(avail, lane4s), 4u);
+                z &= nb >= 4u ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+            }
+            const uint64_t ballot = __ballot(z != 0);
+            const uint32_t F = ballot ? (uint32_t)__ffsll((long long)ballot) - 1u : 64u;
+            if ((uint32_t)lane < F) {                                // lanes before the event (all of them without one): their bytes
+                if (nb == 4u) *reinterpret_cast<u32_lds_any*>(vst + i + lane4s) = win;
+                else {
+#pragma unroll 1
+                    for (uint32_t k = 0; k < nb; ++k) vst[i + lane4s + k] = (uint8_t)(win >> (8u * k));
+                }
+            }
+            if (!ballot) {
+                const uint32_t n = min(avail, 256u);
+                // the last byte handed out: what the next window's (or the tail's) first byte follows
+                const uint32_t lw = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)((n - 1u) >> 2));
+                prev = (lw >> (8u * ((n - 1u) & 3u))) << 24;
+                s += 8u * n; i += n;
+                continue;
+            }
+            const uint32_t zF = (uint32_t)__builtin_amdgcn_readlane((int)z, (int)F);
+            const uint32_t winF = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)F);
+            const uint32_t b = (uint32_t)(__ffs((int)zF) - 1) >> 3;
+            i += 4u * F;
+            if ((uint32_t)lane <= b)                                 // the event lane's bytes up to the 7-bit one (0x7F)
+                vst[i + lane] = (uint8_t)((winF >> (8u * lane)) & ((uint32_t)lane == b ? 0x7Fu : 0xFFu));
+            s += 32u * F + 8u * b + 7u; i += b + 1u; prev = 0x7Fu << 24;
+        }
+        // a 7-bit byte that takes the stream's last seven bits is a whole byte too
+        if (vlc_bits - s == 7u && (prev >> 24) > 0x8Fu &&
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)get_bits(vlc_raw, s, 7u)) == 0x7Fu) {
+            if (lane == 0) vst[i] = 0x7Fu;
+            i += 1u; s += 7u;
+        }
+        nv = i; vposr = s;
+    }
     const uint32_t vused = vlc_bits - vposr;
     const uint32_t vacc = vused ? get_bits(vlc_raw, vposr, vused) : 0;
-    const uint32_t nv = (vposr + Kv) >> 3;
 
     // ---- B2: MEL / VLC termination (terminate_mel_vlc :357-385), wave-uniform
     if (mel.run > 0) mel_put_bit(mel, mel_buf, 1, lane == 0);
@@ -1214,54 +1229,18 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     for (uint32_t i = lane; i < mel_len; i += 64) out[ms_len + i] = mel_buf[i < 250 ? i : 249];
 
     // ---- B4: VLC bytes 0 .. nv - 1, byte i at out[total - 2 - i] (emit_vlc of the model); the first one carries Scup's low nibble
-    {
+    {                                                                // the staged bytes, four per lane, reversed
         uint8_t* const last = out + total - 2;
-        uint32_t s = 0, i = 0, prev = 0xFFu << 24;
-        while (i < nv) {
-            const uint32_t left = nv - i;
-            const uint32_t start = s + lane32;
-            const uint32_t sw = start >> 5;
-            const uint32_t win = __builtin_amdgcn_alignbit(vlc_raw[sw + 1], vlc_raw[sw], start);
-            // the byte before each of the four: lane - 1's top byte (lane 0: the window before, `prev`)
-            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)prev, (int)win, 0x138, 0xF, 0xF, false);
-            const uint32_t pw = __builtin_amdgcn_alignbit(win, before, 24);
-            const uint32_t e = (win & 0x7F7F7F7Fu) + 0x01010101u;   // bit 7 of a byte: its low 7 bits are ones
-            // flag at bit 4 of a byte: the byte before has bit 7 and one of bits 6..4 (it is > 0x8F), this one's low 7 bits are ones
-            uint32_t z = bitop3<0x80>(pw >> 3, (pw >> 2) | (pw >> 1) | pw, e >> 3) & 0x10101010u;
-            uint32_t nb = 4;
-            if (left < 256u) {
-                nb = min(left - min(left, lane4), 4u);
-                z &= nb >= 4u ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
-            }
-            const uint64_t ballot = __ballot(z != 0);
-            const uint32_t F = ballot ? (uint32_t)__ffsll((long long)ballot) - 1u : 64u;
-            {   // lanes before the event (all of them without one): their four bytes, reversed
-                uint32_t word = win;
-                if (i == 0 && lane == 0) word = (word & ~0xFu) | (scup & 0xFu);
-                if ((uint32_t)lane < F) {
-                    if (nb == 4u) GRK_K3_STORE(reinterpret_cast<u32_any*>(last - 3 - (int)(i + lane4)), __builtin_bswap32(word));
-                    else {
 #pragma unroll 1
-                        for (uint32_t k = 0; k < nb; ++k) *(last - (int)(i + lane4 + k)) = (uint8_t)(word >> (8u * k));
-                    }
-                }
+        for (uint32_t k = 4u * (uint32_t)lane; k < nv; k += 256u) {
+            uint32_t word = *reinterpret_cast<const uint32_t*>(vst + k);
+            if (k == 0) word = (word & ~0xFu) | (scup & 0xFu);
+            const uint32_t n = min(nv - k, 4u);
+            if (n == 4u) GRK_K3_STORE(reinterpret_cast<u32_any*>(last - 3 - (int)k), __builtin_bswap32(word));
+            else {
+#pragma unroll 1
+                for (uint32_t t = 0; t < n; ++t) *(last - (int)(k + t)) = (uint8_t)(word >> (8u * t));
             }
-            if (!ballot) {
-                const uint32_t n = min(left, 256u);
-                prev = (uint32_t)__builtin_amdgcn_readlane((int)win, 63) & 0xFF000000u;
-                s += 8u * n; i += n;
-                continue;
-            }
-            const uint32_t zF = (uint32_t)__builtin_amdgcn_readlane((int)z, (int)F);
-            const uint32_t winF = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)F);
-            const uint32_t b = (uint32_t)(__ffs((int)zF) - 1) >> 3;
-            i += 4u * F;
-            if ((uint32_t)lane <= b) {                               // the event lane's bytes up to the 7-bit one (0x7F)
-                uint32_t v = (winF >> (8u * lane)) & ((uint32_t)lane == b ? 0x7Fu : 0xFFu);
-                if (i + lane == 0) v = (v & 0xF0u) | (scup & 0xFu);
-                *(last - (int)(i + lane)) = (uint8_t)v;
-            }
-            s += 32u * F + 8u * b + 7u; i += b + 1u; prev = 0x7Fu << 24;
         }
     }
     if (lane == 0) {
@@ -1408,6 +1387,11 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
                       &full.vlc_cap_bits);
         ht_lds_layout(c.max_samples, c.max_quads, c.cap_kmax, true, a.irreversible != 0, cap.ms_words, cap.vlc_words, shmem_cap,
                       &cap.ms_cap_bits, &cap.vlc_cap_bits);
+        // the VLC staging area behind the MEL bytes (phase B1 above): the stuffed bytes of the stream's capacity
+        {
+            shmem_full += ((full.vlc_cap_bits / 7u + 16u) + 15u) & ~(size_t)15;
+            shmem_cap += ((cap.vlc_cap_bits / 7u + 16u) + 15u) & ~(size_t)15;
+        }
         auto waves = [](size_t lds) { return std::min<size_t>(32, (160u << 10) / std::max<size_t>(lds, 1)); };
         const bool use_cap = a.ovf_list && waves(shmem_cap) > waves(shmem_full);
         const HtLds& L = use_cap ? cap : full;

@@ -307,3 +307,90 @@ int32_t orc_ht_model_phase_b2(const uint32_t* ms_raw, uint32_t ms_bits, const ui
     out[total - 2] = (uint8_t)((out[total - 2] & 0xF0) | (scup & 0xF));
     return (int32_t)total;
 }
+
+/* ---- third form (r05, what kernels_ht.hip runs for packed 8-bit content) ----------------------------------------------------------
+ * The VLC stream is looked at ONCE: the speculative windows run forwards BEFORE the termination and put byte i of the segment at
+ * stage[i]; the number of whole bytes and the bits left over -- what the termination needs, and what the second form got from the
+ * counting walker -- fall out of the same pass; the staged bytes are copied out reversed at the end.  A byte is whole when 8 bits
+ * are left for it, or 7 if it is a 7-bit byte (it follows a byte > 0x8F and its bits are all ones): the tail check below. */
+static uint32_t stage_vlc(const uint32_t* raw, uint32_t nwords, uint32_t nbits, uint8_t* stage, uint32_t* vposr)
+{
+    uint32_t s = 0, i = 0, prev = 0xFF;
+    while (1) {
+        const uint32_t avail = (nbits - s) >> 3;
+        if (avail == 0) break;
+        uint32_t win[LANES], z[LANES], nbl[LANES];
+        uint64_t ballot = 0;
+        for (int l = 0; l < LANES; ++l) {
+            win[l] = get32(raw, nwords, s + 32u * l);
+            nbl[l] = avail > 4u * l ? (avail - 4u * l < 4 ? avail - 4u * l : 4) : 0;
+        }
+        for (int l = 0; l < LANES; ++l) {
+            const uint32_t prevsrc = l ? win[l - 1] : prev << 24;
+            const uint32_t pw = (win[l] << 8) | (prevsrc >> 24);
+            const uint32_t e = (win[l] & 0x7F7F7F7Fu) + 0x01010101u;
+            z[l] = (pw >> 3) & ((pw >> 2) | (pw >> 1) | pw) & (e >> 3) & valid_mask(nbl[l], 0x10101010u);
+            if (z[l]) ballot |= 1ull << l;
+        }
+        if (!ballot) {
+            for (int l = 0; l < LANES; ++l)
+                for (uint32_t b = 0; b < nbl[l]; ++b) stage[i + 4u * l + b] = (uint8_t)(win[l] >> (8 * b));
+            const uint32_t n = avail < 256 ? avail : 256;
+            prev = (win[(n - 1) >> 2] >> (8 * ((n - 1) & 3))) & 0xFF;          /* the last byte handed out */
+            s += 8 * n; i += n;
+            continue;
+        }
+        const uint32_t F = (uint32_t)__builtin_ctzll(ballot), b = (uint32_t)__builtin_ctz(z[F]) >> 3;
+        for (uint32_t l = 0; l < F; ++l)
+            for (uint32_t k = 0; k < 4; ++k) stage[i + 4u * l + k] = (uint8_t)(win[l] >> (8 * k));
+        for (uint32_t k = 0; k < b; ++k) stage[i + 4u * F + k] = (uint8_t)(win[F] >> (8 * k));
+        stage[i + 4u * F + b] = 0x7F;
+        s += 32u * F + 8u * b + 7u; i += 4u * F + b + 1; prev = 0x7F;
+    }
+    if (nbits - s == 7 && prev > 0x8F && get_bits(raw, nwords, s, 7) == 0x7F) { stage[i++] = 0x7F; s += 7; }
+    *vposr = s;
+    return i;
+}
+
+int32_t orc_ht_model_phase_b3(const uint32_t* ms_raw, uint32_t ms_bits, const uint32_t* vlc_raw, uint32_t vlc_bits,
+                              const uint8_t* mel_bytes, const int* mel_state, uint8_t* out)
+{
+    const uint32_t msw = (ms_bits + 31) / 32, vw = (vlc_bits + 31) / 32;
+    static uint8_t stage[8192];
+    uint32_t vposr;
+    const uint32_t nv = stage_vlc(vlc_raw, vw, vlc_bits, stage, &vposr);
+    const uint32_t vused = vlc_bits - vposr;
+    const uint32_t vacc = vused ? get_bits(vlc_raw, vw, vposr, vused) : 0;
+
+    uint32_t mel_pos = (uint32_t)mel_state[0];
+    int mel_acc = mel_state[1], mel_left = mel_state[2], mel_run = mel_state[3];
+    uint8_t mel_tail[2]; uint32_t mel_tail_n = 0;
+    if (mel_run > 0) {
+        mel_acc = (mel_acc << 1) | 1;
+        if (--mel_left == 0) { mel_tail[mel_tail_n++] = (uint8_t)mel_acc; mel_left = (mel_acc == 0xFF) ? 7 : 8; mel_acc = 0; }
+    }
+    uint32_t vextra = 0, vextra_byte = 0;
+    {
+        const int macc = mel_acc << mel_left;
+        const int mel_mask = (0xFF << mel_left) & 0xFF;
+        const int vlc_mask = 0xFF >> (8 - (int)vused);
+        if ((mel_mask | vlc_mask) != 0) {
+            const int fuse = macc | (int)vacc;
+            if ((((fuse ^ macc) & mel_mask) | ((fuse ^ (int)vacc) & vlc_mask)) == 0 && fuse != 0xFF && nv >= 1)
+                mel_tail[mel_tail_n++] = (uint8_t)fuse;
+            else { mel_tail[mel_tail_n++] = (uint8_t)macc; vextra = 1; vextra_byte = vacc; }
+        }
+    }
+    const uint32_t ms_len = emit_ms(ms_raw, msw, ms_bits, out);
+    const uint32_t mel_len = mel_pos + mel_tail_n;
+    const uint32_t vcount = nv + vextra;
+    const uint32_t total = ms_len + mel_len + vcount + 1;
+    memcpy(out + ms_len, mel_bytes, mel_pos);
+    for (uint32_t i = 0; i < mel_tail_n; ++i) out[ms_len + mel_pos + i] = mel_tail[i];
+    for (uint32_t i = 0; i < nv; ++i) out[total - 2 - i] = stage[i];
+    if (vextra) out[total - 2 - nv] = (uint8_t)vextra_byte;
+    const uint32_t scup = mel_len + vcount + 1;
+    out[total - 1] = (uint8_t)(scup >> 4);
+    out[total - 2] = (uint8_t)((out[total - 2] & 0xF0) | (scup & 0xF));
+    return (int32_t)total;
+}

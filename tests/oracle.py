@@ -321,12 +321,15 @@ def _bind_model():
     L.orc_ht_model_phase_b.argtypes = [vp, u32, vp, u32, vp, vp, vp]
     L.orc_ht_model_phase_b2.restype = C.c_int32
     L.orc_ht_model_phase_b2.argtypes = [vp, u32, vp, u32, vp, vp, vp]
+    L.orc_ht_model_phase_b3.restype = C.c_int32
+    L.orc_ht_model_phase_b3.argtypes = [vp, u32, vp, u32, vp, vp, vp]
     return L
 
 
 def ht_wave_model(sm, kmax, form=1):
     """raw streams of the oracle encoder -> wave-parallel phase-B model -> bytes (form 1: walker + bitmaps, r01; form 2: speculative
-    windows, r03 -- what kernels_ht.hip runs)"""
+    windows, r03 -- what kernels_ht.hip runs for deep content; form 3: the VLC windows run once, forwards, into a staging area, r05 --
+    what it runs for packed 8-bit content)"""
     L = _bind_model()
     a = np.ascontiguousarray(sm, np.uint32)
     h, w = a.shape
@@ -340,5 +343,5 @@ def ht_wave_model(sm, kmax, form=1):
     nref = L.orc_ht_raw_streams(a.ctypes.data, kmax, w, h, ms.ctypes.data, msw, C.byref(mb),
                                 vl.ctypes.data, vw, C.byref(vb), mel.ctypes.data, st)
     out = np.zeros(nref + 64, np.uint8)
-    nm = (L.orc_ht_model_phase_b if form == 1 else L.orc_ht_model_phase_b2)(ms.ctypes.data, mb.value, vl.ctypes.data, vb.value, mel.ctypes.data, st, out.ctypes.data)
+    nm = {1: L.orc_ht_model_phase_b, 2: L.orc_ht_model_phase_b2, 3: L.orc_ht_model_phase_b3}[form](ms.ctypes.data, mb.value, vl.ctypes.data, vb.value, mel.ctypes.data, st, out.ctypes.data)
     return out[:nm].tobytes()

@@ -6,7 +6,7 @@ import pytest
 import oracle as O
 
 
-@pytest.mark.parametrize("form", (1, 2))
+@pytest.mark.parametrize("form", (1, 2, 3))
 @pytest.mark.parametrize("mode", range(8))
 def test_wave_model_matches_oracle(mode, form):
     rng = np.random.default_rng(100 + mode)
