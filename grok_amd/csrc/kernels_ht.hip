@@ -1259,10 +1259,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
 template <bool IRREV, bool H16, bool ROOM>
 __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, HtLds L, uint32_t class_id)
 {
-#ifndef GRK_K3_ROOM_REG
-#define GRK_K3_ROOM_REG "v103"
-#endif
-    if constexpr (ROOM) asm volatile("" ::: GRK_K3_ROOM_REG);
+    if constexpr (ROOM) asm volatile("" ::: "v103");
     ht_encode_block<IRREV, H16>(a, blockIdx.x % a.sel_count, blockIdx.x / a.sel_count, L, class_id);
 }
 
