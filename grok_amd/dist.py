@@ -104,6 +104,10 @@ def gather_frame(counts_host, offsets, lengths, arena, root, bufs=None, group=No
 
 _gather_groups = []          # [0]: the counts' group, [1 + g]: gather slot g
 
+# How long _issue_gather polls for a frame's counts before it blocks (GROK_AMD_GATHER_POLL_US).  The counts of frame f - lag are
+# normally there when frame f is submitted; when the host runs ahead of the GPU they arrive within about a frame time.
+_POLL_S = float(os.environ.get("GROK_AMD_GATHER_POLL_US", "50")) * 1e-6
+
 
 def comm_priority():
     """Priority of the streams the exchange's own work is queued on (packing, the waits for the encoder's results): the
@@ -204,9 +208,9 @@ class FramePipeline:
     def _issue_gather(self, pending):
         f, cslot, offs, lens, arena, enc_ev = pending
         if self._ready[cslot] is not None:         # the counts of frame f are on the host (frame f + lag is already queued):
-            ev = self._ready[cslot]                # polled for at most ~50 us -- a blocking wait wakes up late, and the next frame's
+            ev = self._ready[cslot]                # polled for at most _POLL_S -- a blocking wait wakes up late, and the next frame's
             if not ev.query():                     # launches have to be queued while this one runs --, then a blocking wait: a peer
-                t_end = time.perf_counter() + 50e-6    # that is late or has failed must not leave this rank burning a host core
+                t_end = time.perf_counter() + _POLL_S  # that is late or has failed must not leave this rank burning a host core
                 while time.perf_counter() < t_end and not ev.query():     # (eight ranks share one host)
                     pass
                 if not ev.query():
