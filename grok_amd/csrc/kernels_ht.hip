@@ -146,6 +146,12 @@ __device__ __forceinline__ void mel_zero_run(MelState& m, uint8_t* buf, uint32_t
     }
 }
 
+// acc |= a | b, HERE: a plain `acc |= a | b` in straight-line code is re-associated into one OR tree at the accumulator's only use (the
+// range check behind phase A), and every magnitude word of the block -- 32 registers in the pair form -- stays live until then
+__device__ __forceinline__ void or3_now(uint32_t& acc, uint32_t a, uint32_t b)
+{
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(acc) : "v"(acc), "v"(a), "v"(b));
+}
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
     (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -331,7 +337,7 @@ __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* fl
 
 // LDS words of the two raw streams, the two bitmaps, and what the raw streams may hold (bits) before the block is
 // handed to the fallback launch
-struct HtLds { uint32_t ms_words, vlc_words, ms_cap_bits, vlc_cap_bits; };
+struct HtLds { uint32_t ms_words, vlc_words, ms_cap_bits, vlc_cap_bits, stage_bytes; };
 
 // One code-block, by one wavefront.  li = index of the block in the launch's class list, tile = tile index.
 // H16: the Mallat planes hold int16 coefficients (reversible, 8-bit pixels; kernels_dwt.hip H16)
@@ -345,8 +351,8 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* ms_raw  = smem;
     uint32_t* vlc_raw = ms_raw + ms_words;
-    uint2*    uvlc_l  = reinterpret_cast<uint2*>(vlc_raw + vlc_words);           // 64 entries (phase A)
-    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(uvlc_l + 64);                 // 256 bytes
+    uint2*    uvlc_l  = reinterpret_cast<uint2*>(vlc_raw + vlc_words);           // 64 entries (phase A only: phase B stages the VLC bytes over them)
+    uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(uvlc_l) + L.stage_bytes;      // 256 bytes (written once, by mel_flush, behind phase A)
 
     const int lane = threadIdx.x;
     // this launch covers the blocks sel[0..sel_count) of every tile (all blocks when sel == nullptr)
@@ -766,7 +772,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 const i16x2 w0 = __builtin_bit_cast(i16x2, nw0), w1 = __builtin_bit_cast(i16x2, nw1);
                 const u16x2 p0 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w0, -w0));
                 const u16x2 p1 = __builtin_bit_cast(u16x2, __builtin_elementwise_max(w1, -w1));
-                ovf |= __builtin_bit_cast(uint32_t, p0) | __builtin_bit_cast(uint32_t, p1);
+                or3_now(ovf, __builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1));
                 const u16x2 one2 = {1, 1};
                 const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(p0 + p0, one2));
                 const uint32_t t1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(p1 + p1, one2));
@@ -1041,7 +1047,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     //      -199 vector / -155 scalar instructions per block; profiles/r05_k3_pairs.txt).  r05: the emission runs HERE, forwards,
     //      into a staging area in LDS (vst: byte i of the VLC segment at vst[i]); what the termination needs -- the number of whole
     //      bytes, the bits left over -- falls out of it, and B4 copies the staged bytes out reversed.
-    uint8_t* const vst = mel_buf + 256;
+    uint8_t* const vst = reinterpret_cast<uint8_t*>(uvlc_l);        // (the UVLC table is done with)
     typedef uint32_t u32_lds_any __attribute__((aligned(1)));
     uint32_t nv, vposr;
     {
@@ -1249,13 +1255,16 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     }
 }
 
-// ROOM: the launch runs beside the NEXT frame's DWT level 0 (the top class of a pipelined encode, on the low-priority side stream).
-// A level-0 workgroup is four waves of 72 registers and 24 KB of LDS; K3 at its natural 96 registers x 5 waves leaves a SIMD 32
-// registers, so a level-0 workgroup -- the critical path of the pipeline -- finds room on a CU only when a wave of K3 has retired on
-// EVERY SIMD of it.  The ROOM instance claims 104 registers (it uses 95): four waves per SIMD, 96 registers and 57 KB of LDS free
-// for the DWT.  Alone it is 10 % slower (0.295 against 0.267 ms for the 8K frame), beside the DWT the pipelined step goes from
-// 0.412 to 0.367-0.376 ms per frame on the same box; capping K3's waves with LDS instead takes the LDS the DWT needs (0.449), CU
-// masks lose outright (profiles/r05_k3_pairs.txt, profiles/r05_sq_overlapped_8k.txt).
+// ROOM: the launch runs beside the NEXT frame's DWT level 0 (the K3 launches of a pipelined encode, on the low-priority side streams).
+// A level-0 workgroup is four waves of 72 registers and 24 KB of LDS; K3 at five waves per SIMD leaves a CU neither the registers
+// (r05 first half: 96 x 5, 32 free) nor the LDS (7 KB per wave x 20, 17 KB free), so a level-0 workgroup -- the critical path of the
+// pipeline -- finds room on a CU only when waves of K3 have retired on EVERY SIMD of it.  The ROOM instance claims 104 registers (it
+// uses 83): four waves per SIMD, 96 registers and 48 KB of LDS free for the DWT.  Alone it is 10 % slower (0.295 against 0.267 ms for
+// the 8K frame), beside the DWT the pipelined step goes from 0.412 to 0.367-0.376 ms per frame on the same box.  What else was
+// measured (profiles/r05_k3_pairs.txt 6-7, 10-11): a claim of 112 (four waves, 64 registers free: no room for level 0) 0.423, of 128
+// 0.438, of 136 (three waves, 104 free) 0.405; FIVE waves with guaranteed room -- this kernel at 83 registers, LDS capacities cut to
+// 6.4 KB per wave, level 0 built at 60 registers -- 0.395-0.405: room is necessary, and four waves of K3 beside it is the balance;
+// capping K3's waves with LDS instead takes the LDS the DWT needs (0.449), CU masks lose outright (profiles/r05_sq_overlapped_8k.txt).
 template <bool IRREV, bool H16, bool ROOM>
 __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, HtLds L, uint32_t class_id)
 {
@@ -1317,23 +1326,26 @@ static hipError_t upload_tables()
 // bits per quad).  capped = true: what real content needs with room to spare -- reversible: 8 bits per sample on
 // average for 8-bit content (Kmax <= 11), Kmax - 3 beyond; quantised (irreversible) coefficients: 8 bits whatever the
 // exponent (the default step sizes leave ~3 bits per sample of a 16-bit image); 10 VLC bits per quad.
-static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool capped, bool irrev, uint32_t& ms_words, uint32_t& vlc_words,
-                          size_t& bytes, uint32_t* ms_cap = nullptr, uint32_t* vlc_cap = nullptr)
+static void ht_lds_layout(uint32_t samples, uint32_t quads, uint32_t kmax, bool capped, bool irrev, HtLds& L, size_t& bytes)
 {
     const uint32_t per_sample = !capped ? kmax + 2u : irrev ? std::min(kmax + 2u, 8u) : std::min(kmax + 2u, kmax <= 11u ? 8u : kmax - 3u);
     const uint32_t ms_bits = samples * per_sample;
     const uint32_t vlc_bits = quads * (capped ? 10u : 15u) + 4u;
-    if (ms_cap) *ms_cap = ms_bits;
-    if (vlc_cap) *vlc_cap = vlc_bits;
-    ms_words = ((ms_bits + 31u) / 32u + 4u + 3u) & ~3u;             // slack: or_bits64 / window reads touch two words beyond;
-    vlc_words = ((vlc_bits + 31u) / 32u + 4u + 3u) & ~3u;           // multiples of 4 words: cleared as uint4
-    bytes = (size_t)(ms_words + vlc_words + 128u) * 4u + 256u;       // + the UVLC table (64 x 8 bytes) + 256 MEL bytes
+    L.ms_cap_bits = ms_bits;
+    L.vlc_cap_bits = vlc_bits;
+    L.ms_words = ((ms_bits + 31u) / 32u + 4u + 3u) & ~3u;           // slack: or_bits64 / window reads touch two words beyond;
+    L.vlc_words = ((vlc_bits + 31u) / 32u + 4u + 3u) & ~3u;         // multiples of 4 words: cleared as uint4
+    // behind the raw streams: the UVLC table (64 x 8 bytes) while phase A runs, then the staged VLC bytes (phase B1: the stuffed
+    // bytes of the stream's capacity) in the same place; then 256 MEL bytes.  (A raw stream's windows read up to 65 words past its
+    // end: the two areas are at least 192 words.)
+    L.stage_bytes = std::max<uint32_t>(((vlc_bits / 7u + 16u) + 15u) & ~15u, 512u);
+    bytes = (size_t)(L.ms_words + L.vlc_words) * 4u + L.stage_bytes + 256u;
 }
 
 size_t ht_lds_bytes(uint32_t samples, uint32_t quads, uint32_t kmax)
 {
-    uint32_t a, b; size_t n;
-    ht_lds_layout(samples, quads, kmax, false, false, a, b, n);
+    HtLds L{}; size_t n;
+    ht_lds_layout(samples, quads, kmax, false, false, L, n);
     return n;
 }
 
@@ -1380,15 +1392,8 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
         // capped LDS when that buys occupancy (waves per CU = 160 KiB / LDS per wave, at most 32), else worst-case buffers
         HtLds full{}, cap{};
         size_t shmem_full, shmem_cap;
-        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, false, false, full.ms_words, full.vlc_words, shmem_full, &full.ms_cap_bits,
-                      &full.vlc_cap_bits);
-        ht_lds_layout(c.max_samples, c.max_quads, c.cap_kmax, true, a.irreversible != 0, cap.ms_words, cap.vlc_words, shmem_cap,
-                      &cap.ms_cap_bits, &cap.vlc_cap_bits);
-        // the VLC staging area behind the MEL bytes (phase B1 above): the stuffed bytes of the stream's capacity
-        {
-            shmem_full += ((full.vlc_cap_bits / 7u + 16u) + 15u) & ~(size_t)15;
-            shmem_cap += ((cap.vlc_cap_bits / 7u + 16u) + 15u) & ~(size_t)15;
-        }
+        ht_lds_layout(c.max_samples, c.max_quads, c.max_kmax, false, false, full, shmem_full);
+        ht_lds_layout(c.max_samples, c.max_quads, c.cap_kmax, true, a.irreversible != 0, cap, shmem_cap);
         auto waves = [](size_t lds) { return std::min<size_t>(32, (160u << 10) / std::max<size_t>(lds, 1)); };
         const bool use_cap = a.ovf_list && waves(shmem_cap) > waves(shmem_full);
         const HtLds& L = use_cap ? cap : full;
