@@ -131,6 +131,66 @@ __device__ __forceinline__ void mel_event(MelState& m, uint8_t* buf, int one, bo
     }
 }
 
+__device__ __forceinline__ void mel_zero_run(MelState& m, uint8_t* buf, uint32_t n, bool writer);
+// The events of one ballot pair (EH: lanes with an event, EV: its value), lane by lane.  The first quad row of a block on dense content
+// is ~17 events of mixed value -- the first quad's and the u-event of the 16 pairs; through mel_zero_run + mel_event (a run-skipping
+// loop made for long runs of zeros) they were ~50 scalar instructions and three taken branches each, 15 % of a block's instructions
+// (profiles/r05_k3_pairs.txt 4, 14).  Here an event is a handful of selects -- one: '0' and the E[k] bits of the run so far; zero: '1'
+// when it completes the run, else nothing -- its bits go to a 64-bit queue, and the queue to the byte packer six bits at a time
+// when the events are through (or 58 bits are queued).
+// (the event itself is written out on the scalar unit: from the C form of these selects the compiler made 35-50 instructions and up to
+//  three branches per event)
+template <bool FIRST_ROW>
+__device__ __forceinline__ void mel_events(MelState& m, uint8_t* buf, uint64_t EH, uint64_t EV, bool writer)
+{
+    if (!(EH & EV)) { mel_zero_run(m, buf, (uint32_t)__builtin_popcountll(EH), writer); return; }
+    uint32_t run = (uint32_t)__builtin_amdgcn_readfirstlane(m.run), k4 = (uint32_t)__builtin_amdgcn_readfirstlane(4 * m.k);
+    while (EH) {
+        uint64_t q = 0; uint32_t qn = 0;
+        while (true) {
+            uint32_t e = (uint32_t)(kMelE >> k4) & 0xFu;
+            uint32_t n, v, at, t0, t1, t2;
+            asm volatile("s_ff1_i32_b64 %[at], %[EH]\n\t"              // the next event's lane
+                         "s_bitset0_b64 %[EH], %[at]\n\t"
+                         "s_add_i32 %[t1], %[run], 1\n\t"
+                         "s_lshr_b32 %[t0], %[t1], %[e]\n\t"           // full: run + 1 <= 2^e, 1 when a zero completes the run
+                         "s_add_i32 %[t2], %[t0], -1\n\t"
+                         "s_and_b32 %[t1], %[t1], %[t2]\n\t"           // the run behind a zero: 0 when complete, else run + 1
+                         "s_lshl2_add_u32 %[t2], %[t0], %[k4]\n\t"
+                         "s_min_i32 %[t2], %[t2], 48\n\t"             // k behind a zero: + 1 when the run is complete (<= 12)
+                         "s_add_i32 %[k4], %[k4], -4\n\t"
+                         "s_max_i32 %[k4], %[k4], 0\n\t"              // k behind a one: - 1 (>= 0)
+                         "s_add_i32 %[e], %[e], 1\n\t"
+                         "s_bitcmp1_b64 %[EV], %[at]\n\t"             // SCC = the event's value
+                         "s_cselect_b32 %[n], %[e], %[t0]\n\t"        // one: '0' + the e bits of the run so far; zero: '1' when complete
+                         "s_cselect_b32 %[v], %[run], %[t0]\n\t"
+                         "s_cselect_b32 %[run], 0, %[t1]\n\t"
+                         "s_cselect_b32 %[k4], %[k4], %[t2]"
+                         : [EH] "+s"(EH), [run] "+s"(run), [k4] "+s"(k4), [e] "+s"(e), [n] "=&s"(n), [v] "=&s"(v), [at] "=&s"(at),
+                           [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2)
+                         : [EV] "s"(EV)
+                         : "scc");
+            q = (q << n) | v; qn += n;
+            if (!EH) break;
+            // (the first quad row: at most 32 events from the coder's initial state -- a quad behind a significant one has no event of
+            //  its own, a pair with a u-event has two significant quads -- and 32 events from there are at most 47 bits)
+            if (!FIRST_ROW && qn > 58u) break;
+        }
+        // the queue's bits (MSB first) to the byte packer, a byte at a time: a byte takes m.left more bits (8, 7 behind a 0xFF, less what
+        // it already holds)
+        while ((int)qn >= m.left) {
+            qn -= (uint32_t)m.left;
+            const uint32_t byte = (((uint32_t)m.acc << m.left) | ((uint32_t)(q >> qn) & ((1u << m.left) - 1u))) & 0xFFu;
+            mel_put_byte(m, byte);
+            m.left = byte == 0xFFu ? 7 : 8;
+            m.acc = 0;
+        }
+        m.acc = (int)(((uint32_t)m.acc << qn) | ((uint32_t)q & ((1u << qn) - 1u)));
+        m.left -= (int)qn;
+    }
+    m.run = (int)run; m.k = (int)(k4 >> 2);
+}
+
 // n events "quad not significant" in a row: a run of 2^E[k] of them is one 1 bit, so the loop runs once per emitted bit, not once
 // per event -- an all-zero 64 x 64 block is 1 024 such events and ~45 bits (r04: K3 on an all-zero 4096^2 frame 0.68 ms, seven
 // times the time of real content, because every event went through the state machine by itself)
@@ -666,16 +726,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src), (int)fl) >> (j == 2u ? 1u : 0u);
             const uint64_t EH = __ballot(lane < 48 && (g & 1u));
             const uint64_t EV = EH & __ballot((g & 4u) != 0u);
-            uint64_t Em = EH;
-            while (Em) {
-                const uint64_t ones = Em & EV;
-                const uint64_t first = ones & (0 - ones);
-                const uint64_t before = first ? Em & (first - 1) : Em;
-                mel_zero_run(mel, mel_buf, (uint32_t)__builtin_popcountll(before), lane == 0);
-                if (!first) break;
-                mel_event(mel, mel_buf, 1, lane == 0);
-                Em &= ~(first | (first - 1));
-            }
+            mel_events<true>(mel, mel_buf, EH, EV, lane == 0);
             Hm &= 0xFFFFFFFF00000000ull;
         }
         // the events in quad order: the zero events up to the next significant quad as one run, then that quad's event
@@ -963,16 +1014,8 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 const uint32_t third = ((uint32_t)lane * 43u) >> 7;                     // lane / 3
                 const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * third), (int)fl) >> ((uint32_t)lane - 3u * third);
                 const bool in_row = lane < 48;
-                uint64_t EH = __ballot(in_row && (g & 1u)), EV = EH & __ballot((g & 8u) != 0u);
-                while (EH) {
-                    const uint64_t ones = EH & EV;
-                    const uint64_t first = ones & (0 - ones);              // the next one-event (0: none left)
-                    const uint64_t before = first ? EH & (first - 1) : EH;
-                    mel_zero_run(mel, mel_buf, (uint32_t)__builtin_popcountll(before), lane == 0);
-                    if (!first) break;
-                    mel_event(mel, mel_buf, 1, lane == 0);
-                    EH &= ~(first | (first - 1));
-                }
+                const uint64_t EH = __ballot(in_row && (g & 1u)), EV = EH & __ballot((g & 8u) != 0u);
+                mel_events<true>(mel, mel_buf, EH, EV, lane == 0);
                 HA &= ~0xFFFFull; HB &= ~0xFFFFull;
             }
             while (HA | HB) {
