@@ -73,13 +73,23 @@ __device__ __forceinline__ void mel_writelane(uint32_t& vec, uint32_t word, uint
 {
     vec = (uint32_t)grk_amd_writelane(__builtin_amdgcn_readfirstlane((int)word), __builtin_amdgcn_readfirstlane((int)lane_index), (int)vec);
 }
-// (the state words as scalar registers, said so: with eight unrolled copies of the event code the compiler's SGPR-copy pass moved the whole
-//  state machine to the vector unit again)
-__device__ __forceinline__ void mel_pin(MelState& m)
+// Between the quad rows the coder's state travels packed -- run (6 bits) | k << 6 | acc << 10 | left << 18 | pos << 22, the unfinished
+// dword, the bytes' vector register -- and is unpacked only by a row that has events: carried as six scalars through the unrolled rows it
+// cost every row six copies and three v_readfirstlane (the compiler's SGPR-copy pass moves a state word that meets a vector value in a
+// phi to the vector unit), ~28 instructions per row without a single event.
+struct MelPacked { uint32_t st, word, vec; };
+__device__ __forceinline__ MelState mel_unpack(const MelPacked& p)
 {
-    m.run = __builtin_amdgcn_readfirstlane(m.run); m.k = __builtin_amdgcn_readfirstlane(m.k);
-    m.acc = __builtin_amdgcn_readfirstlane(m.acc); m.left = __builtin_amdgcn_readfirstlane(m.left);
-    m.pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.pos); m.word = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.word);
+    const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.st);
+    MelState m;
+    m.run = (int)(st & 63u); m.k = (int)((st >> 6) & 15u); m.acc = (int)((st >> 10) & 255u); m.left = (int)((st >> 18) & 15u);
+    m.pos = st >> 22; m.word = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.word); m.vec = p.vec;
+    return m;
+}
+__device__ __forceinline__ void mel_pack(MelPacked& p, const MelState& m)
+{
+    p.st = (uint32_t)m.run | ((uint32_t)m.k << 6) | (((uint32_t)m.acc & 255u) << 10) | ((uint32_t)m.left << 18) | (m.pos << 22);
+    p.word = m.word; p.vec = m.vec;
 }
 __device__ __forceinline__ void mel_put_byte(MelState& m, uint32_t byte)
 {
@@ -437,7 +447,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     if (lane == 0) vlc_raw[0] = 0xF;             // vlc_init: four 1 bits pending (:315-318)
     __syncthreads();
 
-    MelState mel{0, 0, 0, 8, 0, 0, 0};
+    MelPacked melp{8u << 18, 0, 0};               // run 0, k 0, no bits, 8 to go in byte 0
     uint32_t ms_bits = 0, vlc_bits = 4;
     bool lds_full = false;
     uint32_t Bprev = 0xFFFFFFFFu;                // "all insignificant" row above the block
@@ -714,6 +724,8 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         // ---- MEL events (wave-uniform, scalar unit) ------------------------------------------------
         const uint64_t H = s.H, V = s.V;
         uint64_t Hm = H;
+        if (it != 0 && !Hm) return;
+        MelState mel = mel_unpack(melp);
         if (it == 0) {
             // the first quad row's events, pair by pair: quad 2p's, quad 2p + 1's, the pair's u-event (:652-730).  Laid out in that
             // order over lanes 0 .. 47 (lane 3p + j takes its flag from lane 2p or 2p + 1: one ds_bpermute) and coded by the loop
@@ -739,6 +751,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             mel_event(mel, mel_buf, 1, lane == 0);
             Hm &= ~(first | (first - 1));
         }
+        mel_pack(melp, mel);
     };
 
     Stage1 sE, sO;                       // unrolled by two so that no pipeline register is ever copied
@@ -1000,8 +1013,9 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             if (cl != 0u) or_bits32(vlc_raw, vpos, wv);
 
             // ---- MEL events (wave-uniform, scalar unit): in quad order = lane by lane, quad A before quad B
-            mel_pin(mel);
             uint64_t HA = s.H[0], VA = s.V[0], HB = s.H[1], VB = s.V[1];
+            if (it != 0 && !(HA | HB)) return;
+            MelState mel = mel_unpack(melp);
             if (it == 0) {
                 // The first quad row's events come pair by pair: quad A's, quad B's, the pair's u-event (:652-730) -- on dense content
                 // the u-event of all 16 pairs.  Walked pair by pair on the scalar unit (three tests and up to three trips through the
@@ -1035,6 +1049,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 HA &= ~(below | bit);
                 HB &= a_first ? ~below : ~(below | bit);
             }
+            mel_pack(melp, mel);
         };
 
         Stage1 sE, sO;
@@ -1073,6 +1088,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     // ---- reserve the block's bytes in the arena now, from an upper bound of its length, so that the
     //      round trip of the device-scope atomic (it executes at the memory side) hides behind phase B.
     //      Stuffing adds at most one bit per 15 raw bits; MEL grows by at most 2 more bytes.
+    MelState mel = mel_unpack(melp);
     const uint32_t len_ub = (ms_bits + ms_bits / 15u) / 8u + (vlc_bits + vlc_bits / 15u) / 8u + mel.pos + 8u;
     unsigned long long base_off = 0;
     if (lane == 0) base_off = arena_alloc(a.alloc, gid & a.region_mask, len_ub, a.chunk_units);
