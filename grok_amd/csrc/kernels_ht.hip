@@ -142,6 +142,20 @@ __device__ __forceinline__ void mel_event(MelState& m, uint8_t* buf, int one, bo
 }
 
 __device__ __forceinline__ void mel_zero_run(MelState& m, uint8_t* buf, uint32_t n, bool writer);
+// qn queued bits (q, MSB first) to the byte packer, a byte at a time: a byte takes m.left more bits (8, 7 behind a 0xFF, less what it
+// already holds)
+__device__ __forceinline__ void mel_drain(MelState& m, uint64_t q, uint32_t qn)
+{
+    while ((int)qn >= m.left) {
+        qn -= (uint32_t)m.left;
+        const uint32_t byte = (((uint32_t)m.acc << m.left) | ((uint32_t)(q >> qn) & ((1u << m.left) - 1u))) & 0xFFu;
+        mel_put_byte(m, byte);
+        m.left = byte == 0xFFu ? 7 : 8;
+        m.acc = 0;
+    }
+    m.acc = (int)(((uint32_t)m.acc << qn) | ((uint32_t)q & ((1u << qn) - 1u)));
+    m.left -= (int)qn;
+}
 // The events of one ballot pair (EH: lanes with an event, EV: its value), lane by lane.  The first quad row of a block on dense content
 // is ~17 events of mixed value -- the first quad's and the u-event of the 16 pairs; through mel_zero_run + mel_event (a run-skipping
 // loop made for long runs of zeros) they were ~50 scalar instructions and three taken branches each, 15 % of a block's instructions
@@ -186,18 +200,43 @@ __device__ __forceinline__ void mel_events(MelState& m, uint8_t* buf, uint64_t E
             //  its own, a pair with a u-event has two significant quads -- and 32 events from there are at most 47 bits)
             if (!FIRST_ROW && qn > 58u) break;
         }
-        // the queue's bits (MSB first) to the byte packer, a byte at a time: a byte takes m.left more bits (8, 7 behind a 0xFF, less what
-        // it already holds)
-        while ((int)qn >= m.left) {
-            qn -= (uint32_t)m.left;
-            const uint32_t byte = (((uint32_t)m.acc << m.left) | ((uint32_t)(q >> qn) & ((1u << m.left) - 1u))) & 0xFFu;
-            mel_put_byte(m, byte);
-            m.left = byte == 0xFFu ? 7 : 8;
-            m.acc = 0;
-        }
-        m.acc = (int)(((uint32_t)m.acc << qn) | ((uint32_t)q & ((1u << qn) - 1u)));
-        m.left -= (int)qn;
+        mel_drain(m, q, qn);
     }
+    m.run = (int)run; m.k = (int)(k4 >> 2);
+}
+
+// A quad row's events where zeros are the rule (H: quads with an event, V: its value): the zeros up to the next one as a run -- one trip
+// per completed run, not per event --, then that one; the bits through the queue as above.  (Quantised 16-bit content, BASELINE
+// configs[2]: through mel_zero_run + mel_event, a byte packer behind every bit, these rows were 14.5 % of K3's time -- a what-if build
+// without them 0.362 against 0.423 ms.)
+__device__ __forceinline__ void mel_row(MelState& m, uint64_t H, uint64_t V)
+{
+    uint32_t run = (uint32_t)__builtin_amdgcn_readfirstlane(m.run), k4 = (uint32_t)__builtin_amdgcn_readfirstlane(4 * m.k);
+    uint64_t q = 0; uint32_t qn = 0;
+    // nz zeros that complete at least one run: a '1' per completed run of 2^E[k] (at most 14 from 64 zeros)
+    auto zeros = [&](uint32_t nz) {
+        while (true) {
+            const uint32_t need = (1u << ((uint32_t)(kMelE >> k4) & 0xFu)) - run;
+            if (nz < need) { run += nz; break; }
+            q = (q << 1) | 1u; qn += 1u;
+            run = 0; k4 = min(k4 + 4u, 48u); nz -= need;
+        }
+    };
+    uint64_t ones = H & V;
+    while (ones) {
+        const uint32_t first = (uint32_t)__builtin_ctzll(ones);
+        const uint64_t from = ~0ull << first;                       // the one's lane and above
+        const uint32_t nz = (uint32_t)__builtin_popcountll(H & ~from);
+        H &= from << 1; ones &= from << 1;
+        uint32_t e = (uint32_t)(kMelE >> k4) & 0xFu;
+        if (__builtin_expect(run + nz >= (1u << e), 0)) { zeros(nz); e = (uint32_t)(kMelE >> k4) & 0xFu; }
+        else run += nz;
+        q = (q << (e + 1u)) | run; qn += e + 1u;                   // the one: '0' and the E[k] bits of the run so far
+        run = 0; k4 = (uint32_t)max((int)k4 - 4, 0);
+        if (__builtin_expect(qn > 40u, 0)) { mel_drain(m, q, qn); q = 0; qn = 0; }   // (one trip adds at most 14 + 6 bits)
+    }
+    if (H) zeros((uint32_t)__builtin_popcountll(H));                // the zeros behind the last one
+    mel_drain(m, q, qn);
     m.run = (int)run; m.k = (int)(k4 >> 2);
 }
 
@@ -742,15 +781,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             Hm &= 0xFFFFFFFF00000000ull;
         }
         // the events in quad order: the zero events up to the next significant quad as one run, then that quad's event
-        while (Hm) {
-            const uint64_t ones = Hm & V;
-            const uint64_t first = ones & (0 - ones);                  // the next significant quad with context 0 (0: none left)
-            const uint64_t before = first ? Hm & (first - 1) : Hm;
-            mel_zero_run(mel, mel_buf, (uint32_t)__builtin_popcountll(before), lane == 0);
-            if (!first) break;
-            mel_event(mel, mel_buf, 1, lane == 0);
-            Hm &= ~(first | (first - 1));
-        }
+        if (Hm) mel_row(mel, Hm, V);
         mel_pack(melp, mel);
     };
 
