@@ -259,7 +259,7 @@ __device__ __forceinline__ void mel_zero_run(MelState& m, uint8_t* buf, uint32_t
 // range check behind phase A), and every magnitude word of the block -- 32 registers in the pair form -- stays live until then
 __device__ __forceinline__ void or3_now(uint32_t& acc, uint32_t a, uint32_t b)
 {
-    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(acc) : "v"(acc), "v"(a), "v"(b));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xfe" : "=v"(acc) : "v"(acc), "v"(a), "v"(b));      // (a | b | c at the 2-cycle rate; v_or3_b32 takes 4)
 }
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
 {
