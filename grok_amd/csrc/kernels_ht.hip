@@ -1017,8 +1017,8 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             const uint32_t vpos = vlc_bits + (incl >> 16) - cl;
             ms_bits += tot & 0xFFFFu;
             vlc_bits += tot >> 16;
-            lds_full = lds_full || ms_bits > L.ms_cap_bits || vlc_bits > L.vlc_cap_bits;
-            if (lds_full) return;
+            // (one test for both streams: a capacity minus a count that outgrew it has its top bit set)
+            if (((L.ms_cap_bits - ms_bits) | (L.vlc_cap_bits - vlc_bits)) >> 31) { lds_full = true; return; }
 
             if (ms_len != 0u) {
                 if (!__ballot(max(qlen[0], qlen[1]) > 32u)) {
@@ -1267,6 +1267,15 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             const uint32_t b = (uint32_t)(__ffs((int)zF) - 1) >> 3;
             if ((uint32_t)lane < F) GRK_K3_STORE(reinterpret_cast<u32_any*>(out + j + lane4), win);
             const uint32_t p7 = s + 32u * F + 8u * (b + 1u);         // where the 7-bit byte after the 0xFF starts
+            // the raw bits from p7 on -- the rest of lane F's window and the next lane's (32 bits at least: the 7-bit byte and the look
+            // at the byte behind it) -- are in registers already; r01-r05 went back to LDS for them twice per event
+            uint32_t winN;
+            if (F < 63u) winN = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(F + 1u));
+            else {
+                const uint32_t sn = s + 2048u;
+                winN = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_alignbit(ms_raw[(sn >> 5) + 1u], ms_raw[sn >> 5], sn));
+            }
+            const uint64_t tail = (((uint64_t)winN << 32) | winF) >> (8u * (b + 1u));
             j += 4u * F;
             if (p7 == ms_bits) {                                     // the stream ends with the 0xFF: dropped (ms_terminate)
                 if ((uint32_t)lane < b) out[j + lane] = (uint8_t)(winF >> (8u * lane));
@@ -1277,12 +1286,12 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             j += b + 1u;
             if (p7 + 7u > ms_bits) {                                 // incomplete 7-bit byte: padded with ones, never 0xFF
                 const uint32_t rem = ms_bits - p7;
-                const uint32_t fin = get_bits(ms_raw, p7, rem) | ((((1u << (7u - rem)) - 1u) << rem) & 0x7Fu);
+                const uint32_t fin = ((uint32_t)tail & ((1u << rem) - 1u)) | ((((1u << (7u - rem)) - 1u) << rem) & 0x7Fu);
                 if (lane == 0) out[j] = (uint8_t)fin;
                 ms_len = j + 1u; done = true;
                 break;
             }
-            const uint32_t b7 = get_bits(ms_raw, p7, 7u);
+            const uint32_t b7 = (uint32_t)tail & 0x7Fu;
             if (lane == 0) out[j] = (uint8_t)b7;
             j += 1u;
             s = p7 + 7u;
@@ -1294,7 +1303,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             // (one look decides whether the run loop is entered at all -- r05: with the loop directly behind the event K3 of dense
             //  content, which never takes it, was 0.7 % slower, and 2.2 % slower than without the loop: code placement, the registers
             //  and spills are the same; profiles/r05_k3_pairs.txt)
-            if (s + 15u <= ms_bits && ((uint32_t)__builtin_amdgcn_readfirstlane((int)get_bits(ms_raw, s, 8u)) == 0xFFu))
+            if (s + 15u <= ms_bits && ((uint32_t)(tail >> 7) & 0xFFu) == 0xFFu)
             while (s + 15u <= ms_bits) {
                 const uint32_t two = (uint32_t)__builtin_amdgcn_readfirstlane((int)get_bits(ms_raw, s, 15u));
                 if ((two & 0xFFu) != 0xFFu) break;
