@@ -74,22 +74,29 @@ __device__ __forceinline__ void mel_writelane(uint32_t& vec, uint32_t word, uint
     vec = (uint32_t)grk_amd_writelane(__builtin_amdgcn_readfirstlane((int)word), __builtin_amdgcn_readfirstlane((int)lane_index), (int)vec);
 }
 // Between the quad rows the coder's state travels packed -- run (6 bits) | k << 6 | acc << 10 | left << 18 | pos << 22, the unfinished
-// dword, the bytes' vector register -- and is unpacked only by a row that has events: carried as six scalars through the unrolled rows it
-// cost every row six copies and three v_readfirstlane (the compiler's SGPR-copy pass moves a state word that meets a vector value in a
-// phi to the vector unit), ~28 instructions per row without a single event.
-struct MelPacked { uint32_t st, word, vec; };
-__device__ __forceinline__ MelState mel_unpack(const MelPacked& p)
+// dword, the bytes' vector register, and a queue of up to 60 bits (MSB first) that have not been through the byte packer yet -- and a row
+// touches what it needs: no events, nothing; events, run / k and the queue (mel_first_row, mel_row); the byte packer only when 40 bits are
+// queued.  Carried as six scalars through the unrolled rows the state cost every row six copies and three v_readfirstlane (the compiler's
+// SGPR-copy pass moves a state word that meets a vector value in a phi to the vector unit), ~28 instructions per row without a single
+// event; unpacked, drained and packed again by every row WITH events (the first form of this) ~50 instructions per such row, on
+// quantised content 12 % of K3's instructions.
+struct MelPacked { uint32_t st, word, vec; uint64_t q; uint32_t qn; };
+__device__ __forceinline__ void mel_drain(MelState& m, uint64_t q, uint32_t qn);
+__device__ __forceinline__ MelState mel_unpack(const MelPacked& p)         // the whole state, the queue drained into it
 {
     const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.st);
     MelState m;
     m.run = (int)(st & 63u); m.k = (int)((st >> 6) & 15u); m.acc = (int)((st >> 10) & 255u); m.left = (int)((st >> 18) & 15u);
     m.pos = st >> 22; m.word = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.word); m.vec = p.vec;
+    const uint64_t q = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p.q >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p.q);
+    mel_drain(m, q, (uint32_t)__builtin_amdgcn_readfirstlane((int)p.qn));
     return m;
 }
 __device__ __forceinline__ void mel_pack(MelPacked& p, const MelState& m)
 {
     p.st = (uint32_t)m.run | ((uint32_t)m.k << 6) | (((uint32_t)m.acc & 255u) << 10) | ((uint32_t)m.left << 18) | (m.pos << 22);
-    p.word = m.word; p.vec = m.vec;
+    p.word = m.word; p.vec = m.vec; p.q = 0; p.qn = 0;
 }
 __device__ __forceinline__ void mel_put_byte(MelState& m, uint32_t byte)
 {
@@ -141,7 +148,6 @@ __device__ __forceinline__ void mel_event(MelState& m, uint8_t* buf, int one, bo
     }
 }
 
-__device__ __forceinline__ void mel_zero_run(MelState& m, uint8_t* buf, uint32_t n, bool writer);
 // qn queued bits (q, MSB first) to the byte packer, a byte at a time: a byte takes m.left more bits (8, 7 behind a 0xFF, less what it
 // already holds)
 __device__ __forceinline__ void mel_drain(MelState& m, uint64_t q, uint32_t qn)
@@ -156,72 +162,81 @@ __device__ __forceinline__ void mel_drain(MelState& m, uint64_t q, uint32_t qn)
     m.acc = (int)(((uint32_t)m.acc << qn) | ((uint32_t)q & ((1u << qn) - 1u)));
     m.left -= (int)qn;
 }
-// The events of one ballot pair (EH: lanes with an event, EV: its value), lane by lane.  The first quad row of a block on dense content
-// is ~17 events of mixed value -- the first quad's and the u-event of the 16 pairs; through mel_zero_run + mel_event (a run-skipping
-// loop made for long runs of zeros) they were ~50 scalar instructions and three taken branches each, 15 % of a block's instructions
-// (profiles/r05_k3_pairs.txt 4, 14).  Here an event is a handful of selects -- one: '0' and the E[k] bits of the run so far; zero: '1'
-// when it completes the run, else nothing -- its bits go to a 64-bit queue, and the queue to the byte packer six bits at a time
-// when the events are through (or 58 bits are queued).
-// (the event itself is written out on the scalar unit: from the C form of these selects the compiler made 35-50 instructions and up to
-//  three branches per event)
-template <bool FIRST_ROW>
-__device__ __forceinline__ void mel_events(MelState& m, uint8_t* buf, uint64_t EH, uint64_t EV, bool writer)
+// ... of a packed state: the byte packer's fields of st (acc, left, pos), the unfinished dword, the vector register; run and k stay
+__device__ __forceinline__ void mel_drain_packed(uint32_t& st, MelPacked& p, uint64_t& q, uint32_t& qn)
 {
-    if (!(EH & EV)) { mel_zero_run(m, buf, (uint32_t)__builtin_popcountll(EH), writer); return; }
-    uint32_t run = (uint32_t)__builtin_amdgcn_readfirstlane(m.run), k4 = (uint32_t)__builtin_amdgcn_readfirstlane(4 * m.k);
-    while (EH) {
-        uint64_t q = 0; uint32_t qn = 0;
-        while (true) {
-            uint32_t e = (uint32_t)(kMelE >> k4) & 0xFu;
-            uint32_t n, v, at, t0, t1, t2;
-            asm volatile("s_ff1_i32_b64 %[at], %[EH]\n\t"              // the next event's lane
-                         "s_bitset0_b64 %[EH], %[at]\n\t"
-                         "s_add_i32 %[t1], %[run], 1\n\t"
-                         "s_lshr_b32 %[t0], %[t1], %[e]\n\t"           // full: run + 1 <= 2^e, 1 when a zero completes the run
-                         "s_add_i32 %[t2], %[t0], -1\n\t"
-                         "s_and_b32 %[t1], %[t1], %[t2]\n\t"           // the run behind a zero: 0 when complete, else run + 1
-                         "s_lshl2_add_u32 %[t2], %[t0], %[k4]\n\t"
-                         "s_min_i32 %[t2], %[t2], 48\n\t"             // k behind a zero: + 1 when the run is complete (<= 12)
-                         "s_add_i32 %[k4], %[k4], -4\n\t"
-                         "s_max_i32 %[k4], %[k4], 0\n\t"              // k behind a one: - 1 (>= 0)
-                         "s_add_i32 %[e], %[e], 1\n\t"
-                         "s_bitcmp1_b64 %[EV], %[at]\n\t"             // SCC = the event's value
-                         "s_cselect_b32 %[n], %[e], %[t0]\n\t"        // one: '0' + the e bits of the run so far; zero: '1' when complete
-                         "s_cselect_b32 %[v], %[run], %[t0]\n\t"
-                         "s_cselect_b32 %[run], 0, %[t1]\n\t"
-                         "s_cselect_b32 %[k4], %[k4], %[t2]"
-                         : [EH] "+s"(EH), [run] "+s"(run), [k4] "+s"(k4), [e] "+s"(e), [n] "=&s"(n), [v] "=&s"(v), [at] "=&s"(at),
-                           [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2)
-                         : [EV] "s"(EV)
-                         : "scc");
-            q = (q << n) | v; qn += n;
-            if (!EH) break;
-            // (the first quad row: at most 32 events from the coder's initial state -- a quad behind a significant one has no event of
-            //  its own, a pair with a u-event has two significant quads -- and 32 events from there are at most 47 bits)
-            if (!FIRST_ROW && qn > 58u) break;
-        }
-        mel_drain(m, q, qn);
+    MelState m;
+    m.run = 0; m.k = 0; m.acc = (int)((st >> 10) & 255u); m.left = (int)((st >> 18) & 15u);
+    m.pos = st >> 22; m.word = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.word); m.vec = p.vec;
+    mel_drain(m, q, qn);
+    st = (st & 0x3FFu) | (((uint32_t)m.acc & 255u) << 10) | ((uint32_t)m.left << 18) | (m.pos << 22);
+    p.word = m.word; p.vec = m.vec;
+    q = 0; qn = 0;
+}
+// nz zero events (run / k4 = 4 k / queue in registers): a '1' per completed run of 2^E[k] -- one trip per completed run, not per
+// event (at most 14 from 64 zeros)
+__device__ __forceinline__ void mel_zeros(uint32_t& run, uint32_t& k4, uint64_t& q, uint32_t& qn, uint32_t nz)
+{
+    while (true) {
+        const uint32_t need = (1u << ((uint32_t)(kMelE >> k4) & 0xFu)) - run;
+        if (nz < need) { run += nz; break; }
+        q = (q << 1) | 1u; qn += 1u;
+        run = 0; k4 = min(k4 + 4u, 48u); nz -= need;
     }
-    m.run = (int)run; m.k = (int)(k4 >> 2);
+}
+// The first quad row's events (EH: lanes with an event, in event order; EV: its value), from the coder's initial state.  On dense
+// content ~17 events of mixed value -- the first quad's and the u-event of the 16 pairs; through mel_zero_run + mel_event (a
+// run-skipping loop made for long runs of zeros) they were ~50 scalar instructions and three taken branches each, 15 % of a block's
+// instructions (profiles/r05_k3_pairs.txt 4, 14).  Here an event is 16 instructions without a branch -- one: '0' and the E[k] bits of
+// the run so far; zero: '1' when it completes the run, else nothing; written out on the scalar unit: from the C form of these selects the
+// compiler made 35-50 instructions and up to three branches -- and its bits go to the state's queue: at most 32 events (a quad behind
+// a significant one has no event of its own, a pair with a u-event has two significant quads), at most 47 bits from the initial state.
+__device__ __forceinline__ void mel_first_row(MelPacked& p, uint64_t EH, uint64_t EV)
+{
+    uint32_t run = 0, k4 = 0, qn = 0;
+    uint64_t q = 0;
+    if (!(EH & EV)) mel_zeros(run, k4, q, qn, (uint32_t)__builtin_popcountll(EH));
+    else while (EH) {
+        uint32_t e = (uint32_t)(kMelE >> k4) & 0xFu;
+        uint32_t n, v, at, t0, t1, t2;
+        asm volatile("s_ff1_i32_b64 %[at], %[EH]\n\t"              // the next event's lane
+                     "s_bitset0_b64 %[EH], %[at]\n\t"
+                     "s_add_i32 %[t1], %[run], 1\n\t"
+                     "s_lshr_b32 %[t0], %[t1], %[e]\n\t"           // full: run + 1 <= 2^e, 1 when a zero completes the run
+                     "s_add_i32 %[t2], %[t0], -1\n\t"
+                     "s_and_b32 %[t1], %[t1], %[t2]\n\t"           // the run behind a zero: 0 when complete, else run + 1
+                     "s_lshl2_add_u32 %[t2], %[t0], %[k4]\n\t"
+                     "s_min_i32 %[t2], %[t2], 48\n\t"             // k behind a zero: + 1 when the run is complete (<= 12)
+                     "s_add_i32 %[k4], %[k4], -4\n\t"
+                     "s_max_i32 %[k4], %[k4], 0\n\t"              // k behind a one: - 1 (>= 0)
+                     "s_add_i32 %[e], %[e], 1\n\t"
+                     "s_bitcmp1_b64 %[EV], %[at]\n\t"             // SCC = the event's value
+                     "s_cselect_b32 %[n], %[e], %[t0]\n\t"        // one: '0' + the e bits of the run so far; zero: '1' when complete
+                     "s_cselect_b32 %[v], %[run], %[t0]\n\t"
+                     "s_cselect_b32 %[run], 0, %[t1]\n\t"
+                     "s_cselect_b32 %[k4], %[k4], %[t2]"
+                     : [EH] "+s"(EH), [run] "+s"(run), [k4] "+s"(k4), [e] "+s"(e), [n] "=&s"(n), [v] "=&s"(v), [at] "=&s"(at),
+                       [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2)
+                     : [EV] "s"(EV)
+                     : "scc");
+        q = (q << n) | v; qn += n;
+    }
+    p.st = (p.st & ~0x3FFu) | run | (k4 << 4);                     // (k << 6)
+    p.q = q; p.qn = qn;
 }
 
-// A quad row's events where zeros are the rule (H: quads with an event, V: its value): the zeros up to the next one as a run -- one trip
-// per completed run, not per event --, then that one; the bits through the queue as above.  (Quantised 16-bit content, BASELINE
-// configs[2]: through mel_zero_run + mel_event, a byte packer behind every bit, these rows were 14.5 % of K3's time -- a what-if build
-// without them 0.362 against 0.423 ms.)
-__device__ __forceinline__ void mel_row(MelState& m, uint64_t H, uint64_t V)
+// A later quad row's events, where zeros are the rule (H: quads with an event, V: its value): the zeros up to the next one are one
+// addition unless they complete a run, then that one's bits go to the queue.  (Quantised 16-bit content, BASELINE configs[2]: through
+// mel_zero_run + mel_event, a byte packer behind every bit, these rows were 14.5 % of K3's time -- a what-if build without them 0.362
+// against 0.423 ms.)
+__device__ __forceinline__ void mel_row(MelPacked& p, uint64_t H, uint64_t V)
 {
-    uint32_t run = (uint32_t)__builtin_amdgcn_readfirstlane(m.run), k4 = (uint32_t)__builtin_amdgcn_readfirstlane(4 * m.k);
-    uint64_t q = 0; uint32_t qn = 0;
-    // nz zeros that complete at least one run: a '1' per completed run of 2^E[k] (at most 14 from 64 zeros)
-    auto zeros = [&](uint32_t nz) {
-        while (true) {
-            const uint32_t need = (1u << ((uint32_t)(kMelE >> k4) & 0xFu)) - run;
-            if (nz < need) { run += nz; break; }
-            q = (q << 1) | 1u; qn += 1u;
-            run = 0; k4 = min(k4 + 4u, 48u); nz -= need;
-        }
-    };
+    uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.st);
+    uint32_t run = st & 63u, k4 = (st >> 4) & 0x3Cu;
+    uint64_t q = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p.q >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p.q);
+    uint32_t qn = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.qn);
+    if (__builtin_expect(qn > 40u, 0)) mel_drain_packed(st, p, q, qn);
     uint64_t ones = H & V;
     while (ones) {
         const uint32_t first = (uint32_t)__builtin_ctzll(ones);
@@ -229,15 +244,15 @@ __device__ __forceinline__ void mel_row(MelState& m, uint64_t H, uint64_t V)
         const uint32_t nz = (uint32_t)__builtin_popcountll(H & ~from);
         H &= from << 1; ones &= from << 1;
         uint32_t e = (uint32_t)(kMelE >> k4) & 0xFu;
-        if (__builtin_expect(run + nz >= (1u << e), 0)) { zeros(nz); e = (uint32_t)(kMelE >> k4) & 0xFu; }
+        if (__builtin_expect(run + nz >= (1u << e), 0)) { mel_zeros(run, k4, q, qn, nz); e = (uint32_t)(kMelE >> k4) & 0xFu; }
         else run += nz;
         q = (q << (e + 1u)) | run; qn += e + 1u;                   // the one: '0' and the E[k] bits of the run so far
         run = 0; k4 = (uint32_t)max((int)k4 - 4, 0);
-        if (__builtin_expect(qn > 40u, 0)) { mel_drain(m, q, qn); q = 0; qn = 0; }   // (one trip adds at most 14 + 6 bits)
+        if (__builtin_expect(qn > 40u, 0)) mel_drain_packed(st, p, q, qn);   // (one trip adds at most 14 + 6 bits)
     }
-    if (H) zeros((uint32_t)__builtin_popcountll(H));                // the zeros behind the last one
-    mel_drain(m, q, qn);
-    m.run = (int)run; m.k = (int)(k4 >> 2);
+    if (H) mel_zeros(run, k4, q, qn, (uint32_t)__builtin_popcountll(H));     // the zeros behind the last one
+    p.st = (st & ~0x3FFu) | run | (k4 << 4);
+    p.q = q; p.qn = qn;
 }
 
 // n events "quad not significant" in a row: a run of 2^E[k] of them is one 1 bit, so the loop runs once per emitted bit, not once
@@ -486,7 +501,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     if (lane == 0) vlc_raw[0] = 0xF;             // vlc_init: four 1 bits pending (:315-318)
     __syncthreads();
 
-    MelPacked melp{8u << 18, 0, 0};               // run 0, k 0, no bits, 8 to go in byte 0
+    MelPacked melp{8u << 18, 0, 0, 0, 0};         // run 0, k 0, no bits, 8 to go in byte 0, nothing queued
     uint32_t ms_bits = 0, vlc_bits = 4;
     bool lds_full = false;
     uint32_t Bprev = 0xFFFFFFFFu;                // "all insignificant" row above the block
@@ -764,7 +779,6 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         const uint64_t H = s.H, V = s.V;
         uint64_t Hm = H;
         if (it != 0 && !Hm) return;
-        MelState mel = mel_unpack(melp);
         if (it == 0) {
             // the first quad row's events, pair by pair: quad 2p's, quad 2p + 1's, the pair's u-event (:652-730).  Laid out in that
             // order over lanes 0 .. 47 (lane 3p + j takes its flag from lane 2p or 2p + 1: one ds_bpermute) and coded by the loop
@@ -777,12 +791,11 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src), (int)fl) >> (j == 2u ? 1u : 0u);
             const uint64_t EH = __ballot(lane < 48 && (g & 1u));
             const uint64_t EV = EH & __ballot((g & 4u) != 0u);
-            mel_events<true>(mel, mel_buf, EH, EV, lane == 0);
+            mel_first_row(melp, EH, EV);
             Hm &= 0xFFFFFFFF00000000ull;
         }
         // the events in quad order: the zero events up to the next significant quad as one run, then that quad's event
-        if (Hm) mel_row(mel, Hm, V);
-        mel_pack(melp, mel);
+        if (Hm) mel_row(melp, Hm, V);
     };
 
     Stage1 sE, sO;                       // unrolled by two so that no pipeline register is ever copied
@@ -1046,7 +1059,6 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
             // ---- MEL events (wave-uniform, scalar unit): in quad order = lane by lane, quad A before quad B
             uint64_t HA = s.H[0], VA = s.V[0], HB = s.H[1], VB = s.V[1];
             if (it != 0 && !(HA | HB)) return;
-            MelState mel = mel_unpack(melp);
             if (it == 0) {
                 // The first quad row's events come pair by pair: quad A's, quad B's, the pair's u-event (:652-730) -- on dense content
                 // the u-event of all 16 pairs.  Walked pair by pair on the scalar unit (three tests and up to three trips through the
@@ -1060,9 +1072,11 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * third), (int)fl) >> ((uint32_t)lane - 3u * third);
                 const bool in_row = lane < 48;
                 const uint64_t EH = __ballot(in_row && (g & 1u)), EV = EH & __ballot((g & 8u) != 0u);
-                mel_events<true>(mel, mel_buf, EH, EV, lane == 0);
+                mel_first_row(melp, EH, EV);
                 HA &= ~0xFFFFull; HB &= ~0xFFFFull;
             }
+            if (!(HA | HB)) return;
+            MelState mel = mel_unpack(melp);                       // (8-bit content with empty quads: the run-skipping loop on the whole state)
             while (HA | HB) {
                 const uint64_t oa = HA & VA, ob = HB & VB;
                 if (!(oa | ob)) {
