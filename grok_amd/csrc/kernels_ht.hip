@@ -478,7 +478,10 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
     uint2*    uvlc_l  = reinterpret_cast<uint2*>(vlc_raw + vlc_words);           // 64 entries (phase A only: phase B stages the VLC bytes over them)
     uint8_t*  mel_buf = reinterpret_cast<uint8_t*>(uvlc_l) + L.stage_bytes;      // 256 bytes (written once, by mel_flush, behind phase A)
 
-    const int lane = threadIdx.x;
+    // (the lane index through an opaque move: in a kernel whose workgroups walk a list of blocks -- the fallback launch -- the compiler
+    //  otherwise hoists everything derived from it out of the walk: 182 registers instead of 97)
+    int lane;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(threadIdx.x));
     // this launch covers the blocks sel[0..sel_count) of every tile (all blocks when sel == nullptr)
     const uint32_t lb = a.sel ? a.sel[li] : li;
     const uint32_t gid = tile * a.blocks_per_tile + lb;
@@ -1384,6 +1387,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(HtArgs a, HtLds L, uint32
     if constexpr (ROOM) asm volatile("" ::: "v103");
     ht_encode_block<IRREV, H16>(a, blockIdx.x % a.sel_count, blockIdx.x / a.sel_count, L, class_id);
 }
+
 
 // The blocks the launch above handed over (raw streams outgrew their LDS): worst-case buffers, a fixed grid that walks
 // the list.  With nothing on the list -- the normal case -- every workgroup leaves at once.
