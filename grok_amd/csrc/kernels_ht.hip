@@ -872,6 +872,8 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
         struct Stage1 {
             uint32_t vv[2][PK ? 2 : 4];
             uint32_t SM[2], U[2], u[2], tuple[2];      // SM: 0xFF in the byte of every significant sample
+            uint2 ue[2];                               // the UVLC entries of u (rows behind the first: looked up a stage ahead, so that
+                                                       // stage 2 does not begin with the LDS round trip)
             uint64_t H[2], V[2];
         };
         uint32_t Aprev = 0xFFFFFFFFu;          // (R1, R1, R3, R3) of the iteration before: its row 3 is this iteration's row above row 0
@@ -968,6 +970,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 const uint32_t off = ((rho2[q] << 4) | coff) | bitop3<0x80>(e4, rho2[q], um);
                 o.tuple[q] = *reinterpret_cast<const uint32_t*>(vtab + off);
                 o.SM[q] = N[q] * 255u; o.U[q] = U; o.u[q] = u;
+                if (it != 0) o.ue[q] = uvlc_l[u];
             }
             o.H[0] = __ballot(cq0[0]); o.V[0] = o.H[0] & __ballot(rho[0] != 0);
             o.H[1] = __ballot(cq0[1]); o.V[1] = o.H[1] & __ballot(rho[1] != 0);
@@ -1013,7 +1016,7 @@ __device__ __forceinline__ void ht_encode_block(const HtArgs& a, uint32_t li, ui
                 xev = first && uA > 0 && uB > 0;
                 xv = xev && min(uA, uB) > 2;
             }
-            const uint2 ueA = uvlc_l[uiA], ueB = uvlc_l[uiB];
+            const uint2 ueA = it == 0 ? uvlc_l[uiA] : s.ue[0], ueB = it == 0 ? uvlc_l[uiB] : s.ue[1];
             const uint32_t AA = (s.tuple[0] >> 25) | ueA.x, AB = (s.tuple[1] >> 25) | ueB.x;       // cwd | pre << 8 | suf << 16
             const uint32_t LA = ((s.tuple[0] >> 4) & 7u) | ueA.y, LB = ((s.tuple[1] >> 4) & 7u) | ueB.y;   // len | pl << 8 | sl << 16
             const uint32_t S = LA + LB;
