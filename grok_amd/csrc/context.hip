@@ -124,7 +124,7 @@ struct grk_amd_ctx {
     // Pipelining of consecutive encodes (grk_amd_set_pipelining): a second set of per-encode buffers, so that the next
     // encode's DWT can start while the side streams still code the blocks of this one
     static constexpr int kMaxAltSets = 7;
-    struct AltSet { DevBuf p1, arena, lengths, offsets, flag, ovf; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alts[kMaxAltSets];
+    struct AltSet { DevBuf p1, arena, lengths, offsets, flag, ovf, llA, llB; hipEvent_t ev_side = nullptr, ev_side2 = nullptr; } alts[kMaxAltSets];
     int alt_head = 0;                // the OLDEST of the sets not in use (a ring: the set a call retires becomes the newest)
     int pipe_depth = 2;              // buffer sets in rotation when pipelining: grk_amd_set_pipelining(ctx, n) -> n + 1 of them (2 ..
                                      // 8): the results of a call then stay valid until the (n + 1)-th next call
@@ -153,6 +153,13 @@ struct grk_amd_ctx {
     // other blocks and the inverse levels that need only those; the last inverse level waits for it
     hipEvent_t ev_dec_front = nullptr, ev_dec_top = nullptr;
     bool dec_top_pending = false;
+    // Pipelined encodes of SMALL frames (up to kFrameStreamSamples samples per call): a frame's whole chain on ONE of the two side streams,
+    // taken in turn -- no event inside a frame (12 instead of 18 runtime calls), consecutive frames overlap through the streams.  A call
+    // is bound by the host's launches below ~2048^2 x 3: 512^2 x 3 0.058 -> 0.045 ms, 2048^2 x 3 0.073 -> 0.058; at 4096^2 it makes no
+    // difference, at 8192^2 it loses 19 % (no top-resolution K3 beside the remaining levels, no stream priorities).
+    // GRK_AMD_FRAME_STREAMS = 0: never, 1 (default): by size, 2: always
+    static constexpr uint64_t kFrameStreamSamples = 16ull << 20;
+    int frame_streams = 1; int fs_parity = 0;
     int k3_room = 3;                  // pipelined encodes: K3 launches that leave registers for the next frame's level 0 -- bit 0 the top class, bit 1 the rest (GRK_AMD_K3_ROOM)
     // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
     // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; 2: lanes wherever they can be used; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
@@ -1017,11 +1024,12 @@ HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* 
 }
 
 // overlapped: the top resolution and the large-LDS classes are already running on the side streams (run_dwt)
-int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, bool overlapped = false, bool h16 = false)
+int run_ht(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, bool overlapped = false, bool h16 = false, bool room = false)
 {
     int rc = GRK_AMD_OK;
-    const HtArgs a = make_ht_args(c, ntiles, d_mallat, &rc, h16);
+    HtArgs a = make_ht_args(c, ntiles, d_mallat, &rc, h16);
     if (rc) return rc;
+    a.room = room ? 1 : 0;
     {
         ScopedTimer t(c, 2);
         if (!overlapped) {         // one launch of every block where there is such a class, else class by class
@@ -1083,6 +1091,7 @@ int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** o
         if (const char* ed = getenv("GRK_AMD_DEC_PLANES16")) c->dec_planes16 = atoi(ed) != 0;
         if (const char* el = getenv("GRK_AMD_LDS_CAP")) c->lds_cap = atoi(el) != 0;
         if (const char* ek = getenv("GRK_AMD_K3_ROOM")) c->k3_room = atoi(ek) & 3;
+        if (const char* ef2 = getenv("GRK_AMD_FRAME_STREAMS")) c->frame_streams = atoi(ef2);
         if (const char* et = getenv("GRK_AMD_T1_LANES")) c->t1_lanes = atoi(et);
         if (const char* er = getenv("GRK_AMD_T1_TAIL_RATIO")) c->t1_tail_ratio = (float)atof(er);
         if (const char* es = getenv("GRK_AMD_T1_TAIL_SHARE")) c->t1_tail_share = (float)atof(es);
@@ -1126,7 +1135,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
         auto* as = &alt_set;
         if (as->ev_side) (void)hipEventDestroy(as->ev_side);
         if (as->ev_side2) (void)hipEventDestroy(as->ev_side2);
-        for (DevBuf* b : {&as->p1, &as->arena, &as->lengths, &as->offsets, &as->flag, &as->ovf}) b->release();
+        for (DevBuf* b : {&as->p1, &as->arena, &as->lengths, &as->offsets, &as->flag, &as->ovf, &as->llA, &as->llB}) b->release();
     }
     c->ovf.release();
     if (c->ev_level0) (void)hipEventDestroy(c->ev_level0);
@@ -1593,6 +1602,9 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     {
         ScopedTimer t(c, 3);
         const bool ov = c->overlap && g.p.num_levels >= 1 && c->side != nullptr;
+        const bool fs = ov && c->pipelining && c->side2 != nullptr &&
+                        (c->frame_streams == 2 || (c->frame_streams == 1 && (uint64_t)nplanes * g.plane_elems <= grk_amd_ctx::kFrameStreamSamples));
+        hipStream_t fs_st = nullptr;
         if (ov && c->pipelining) {
             // take the other buffer set: the blocks of the previous encode may still be being coded from the set used
             // last; the set taken now was last used two encodes ago, and its side-stream work is waited for here
@@ -1604,10 +1616,17 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             };
             // the oldest of the pipe_depth - 1 other sets becomes current; the set retired here takes its slot as the newest
             swap_with(c->alts[c->alt_head]);
+            if (fs) { std::swap(c->llA, c->alts[c->alt_head].llA); std::swap(c->llB, c->alts[c->alt_head].llB); }
             c->alt_head = (c->alt_head + 1) % (c->pipe_depth - 1);
             c->side_pending = false;
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0), "wait for the buffer set");
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side2, 0), "wait for the buffer set");
+            if (fs) {
+                fs_st = c->fs_parity ? c->side2 : c->side; c->fs_parity ^= 1;
+                if (!c->ev_main) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming), "create event");
+                HIP_TRY(c, hipEventRecord(c->ev_main, c->stream), "record the caller's stream");
+                HIP_TRY(c, hipStreamWaitEvent(fs_st, c->ev_main, 0), "the frame's stream waits for the pixels");
+            }
+            HIP_TRY(c, hipStreamWaitEvent(fs ? fs_st : c->stream, c->ev_side, 0), "wait for the buffer set");
+            HIP_TRY(c, hipStreamWaitEvent(fs ? fs_st : c->stream, c->ev_side2, 0), "wait for the buffer set");
             HIP_TRY(c, c->p1.ensure((size_t)nplanes * g.plane_elems * 4 + 256), "alloc Mallat planes");
         } else {
             rc = join_side(c); if (rc) return rc;
@@ -1616,6 +1635,22 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         // needs the fused level 0 (the stand-alone ingest kernel writes int32 planes)
         const bool h16 = c->planes16 && fused && planes16_ok(g.p);
         c->last_h16 = h16;
+        if (fs) {
+            // the whole frame on its stream, as the non-overlapped path lays it out (one K3 launch of every block, the ROOM instance)
+            struct StreamSwap { grk_amd_ctx* c; hipStream_t keep; StreamSwap(grk_amd_ctx* c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
+                                ~StreamSwap() { c->stream = keep; } } on_frame_stream(c, fs_st);
+            if (fused) { rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, false, h16); if (rc) return rc; }
+            else {
+                rc = run_ingest(c, ntiles, d_px, c->p0.p); if (rc) return rc;
+                rc = run_dwt(c, nplanes, c->p0.p, c->p1.p, nullptr, ntiles, false); if (rc) return rc;
+            }
+            rc = run_ht(c, ntiles, c->p1.p, false, h16, (c->k3_room & 1) != 0); if (rc) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_side, fs_st), "record the frame's stream");
+            HIP_TRY(c, hipEventRecord(c->ev_side2, fs_st), "record the frame's stream");
+            c->side_pending = true;
+            if (table || total) return grk_amd_fetch_table(c, table, total);
+            return GRK_AMD_OK;
+        }
         if (ov) {       // the allocator must be reset before the first K3 launch of either stream
             int rc2 = GRK_AMD_OK;
             const HtArgs h = make_ht_args(c, ntiles, c->p1.p, &rc2, h16);

@@ -369,15 +369,20 @@ def _dev_view(ptr, n, typestr):
     return torch.as_tensor(h, device="cuda")
 
 
-@pytest.mark.parametrize("depth,room", [(1, None), (2, None), (1, "0"), (2, "1"), (1, "2")])
-def test_pipelined_encodes_keep_their_results_until_the_second_next_call(depth, room, monkeypatch):
+@pytest.mark.parametrize("depth,room,frame_streams", [(1, None, "0"), (2, None, "0"), (1, "0", "0"), (2, "1", "0"), (1, "2", "0"),
+                                                      (1, None, None), (2, None, None), (3, "0", "2")])
+def test_pipelined_encodes_keep_their_results_until_the_second_next_call(depth, room, frame_streams, monkeypatch):
     """grk_amd_set_pipelining: consecutive encodes overlap (the next one's DWT runs while this one's blocks are still
     being coded), each working in its own buffer set.  Different images back to back without any fetch in between:
     the device-resident results of encode k are read AFTER encode k+1 (two sets) / k+2 (three sets: set_pipelining(2))
     has been issued, and equal a plain encode's.  `room`: GRK_AMD_K3_ROOM -- which K3 launches of the sequence run the
-    instance that leaves registers for the next frame's DWT (default: both classes); the bytes are the same either way."""
+    instance that leaves registers for the next frame's DWT (default: both classes); `frame_streams`: GRK_AMD_FRAME_STREAMS -- "0":
+    the DWT chain on the main stream and K3 on the side streams behind events (what large frames take), default / "2": a frame's whole
+    chain on one of the side streams in turn (what frames of this size take); the bytes are the same either way."""
     if room is not None:
         monkeypatch.setenv("GRK_AMD_K3_ROOM", room)
+    if frame_streams is not None:
+        monkeypatch.setenv("GRK_AMD_FRAME_STREAMS", frame_streams)
     p = G.TileParams.make(1024, 768, 3, 8, 5)
     imgs = [synth.g2(3, 768, 1024, 8), (synth.g2(3, 768, 1024, 8)[:, ::-1, :]).copy(), (255 - synth.g2(3, 768, 1024, 8)).astype(np.uint8),
             synth.g2(3, 768, 1024, 8, seed=7), (synth.g2(3, 768, 1024, 8, seed=8)[:, :, ::-1]).copy()]
