@@ -1602,7 +1602,8 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     {
         ScopedTimer t(c, 3);
         const bool ov = c->overlap && g.p.num_levels >= 1 && c->side != nullptr;
-        const bool fs = ov && c->pipelining && c->side2 != nullptr &&
+        // (device-resident pixels only: the staging buffer of host pixels is filled on the main stream, which must then carry level 0)
+        const bool fs = ov && c->pipelining && c->side2 != nullptr && on_device &&
                         (c->frame_streams == 2 || (c->frame_streams == 1 && (uint64_t)nplanes * g.plane_elems <= grk_amd_ctx::kFrameStreamSamples));
         hipStream_t fs_st = nullptr;
         if (ov && c->pipelining) {
