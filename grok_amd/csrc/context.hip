@@ -1603,7 +1603,8 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         ScopedTimer t(c, 3);
         const bool ov = c->overlap && g.p.num_levels >= 1 && c->side != nullptr;
         // (device-resident pixels only: the staging buffer of host pixels is filled on the main stream, which must then carry level 0)
-        const bool fs = ov && c->pipelining && c->side2 != nullptr && on_device &&
+        // (... and the fused level 0: the stand-alone ingest writes planes that are not part of a buffer set)
+        const bool fs = ov && c->pipelining && c->side2 != nullptr && on_device && fused &&
                         (c->frame_streams == 2 || (c->frame_streams == 1 && (uint64_t)nplanes * g.plane_elems <= grk_amd_ctx::kFrameStreamSamples));
         hipStream_t fs_st = nullptr;
         if (ov && c->pipelining) {
@@ -1617,7 +1618,9 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             };
             // the oldest of the pipe_depth - 1 other sets becomes current; the set retired here takes its slot as the newest
             swap_with(c->alts[c->alt_head]);
-            if (fs) { std::swap(c->llA, c->alts[c->alt_head].llA); std::swap(c->llB, c->alts[c->alt_head].llB); }
+            // (the LL ping-pong buffers belong to the set as well: frames on different streams transform at the same time, and a call
+            //  of the other form -- the same geometry, more tiles -- must not take a running frame's)
+            std::swap(c->llA, c->alts[c->alt_head].llA); std::swap(c->llB, c->alts[c->alt_head].llB);
             c->alt_head = (c->alt_head + 1) % (c->pipe_depth - 1);
             c->side_pending = false;
             if (fs) {
@@ -1640,11 +1643,7 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             // the whole frame on its stream, as the non-overlapped path lays it out (one K3 launch of every block, the ROOM instance)
             struct StreamSwap { grk_amd_ctx* c; hipStream_t keep; StreamSwap(grk_amd_ctx* c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
                                 ~StreamSwap() { c->stream = keep; } } on_frame_stream(c, fs_st);
-            if (fused) { rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, false, h16); if (rc) return rc; }
-            else {
-                rc = run_ingest(c, ntiles, d_px, c->p0.p); if (rc) return rc;
-                rc = run_dwt(c, nplanes, c->p0.p, c->p1.p, nullptr, ntiles, false); if (rc) return rc;
-            }
+            rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, false, h16); if (rc) return rc;
             rc = run_ht(c, ntiles, c->p1.p, false, h16, (c->k3_room & 1) != 0); if (rc) return rc;
             HIP_TRY(c, hipEventRecord(c->ev_side, fs_st), "record the frame's stream");
             HIP_TRY(c, hipEventRecord(c->ev_side2, fs_st), "record the frame's stream");

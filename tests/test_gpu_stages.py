@@ -415,6 +415,47 @@ def test_pipelined_encodes_keep_their_results_until_the_second_next_call(depth, 
     c.close()
 
 
+def test_pipelined_encodes_of_both_forms_in_turn():
+    """Calls of one geometry with one tile (a frame's whole chain on one side stream: up to 16 M samples per call) and with eight
+    tiles (DWT chain on the main stream, K3 on the side streams) in turn, no fetch in between: each call's device-resident results,
+    read after the next call has been issued, equal a plain encode's -- the buffer sets (the LL ping-pong buffers among them) are
+    what keeps a running frame's intermediate data from the next call, whichever form it takes."""
+    W = H = 1024
+    p = G.TileParams.make(W, H, 3, 8, 5)
+    base = [synth.g2(3, H, W, 8, seed=20 + i) for i in range(8)]
+    calls = [base[:1], base[:8], base[1:2], [b[:, ::-1, :].copy() for b in base], base[2:3]]
+    nb1 = G.lib().grk_amd_tile_num_blocks(p)
+    want = []
+    for tiles in calls:
+        per = []
+        for im in tiles:
+            t, coded = U.ctx().encode_host(p, im)
+            per += U.split_blocks(t, coded)
+        want.append(per)
+    c = G.Context(0)
+    c.set_pipelining(1)
+    d = [U.to_dev(np.stack(tiles).reshape(-1)) for tiles in calls]
+    held = []
+
+    def check(k):
+        torch.cuda.synchronize()
+        arena_p, off_p, len_p, used_p = held[k]
+        nb = nb1 * len(calls[k])
+        used = int(_dev_view(used_p, 1, "<i8").cpu()[0])
+        offs = _dev_view(off_p, nb, "<i8").cpu().numpy()
+        lens = _dev_view(len_p, nb, "<i4").cpu().numpy()
+        arena = _dev_view(arena_p, used, "|u1").cpu().numpy()
+        assert [bytes(arena[int(o):int(o) + int(l)]) for o, l in zip(offs, lens)] == want[k], "call %d" % k
+    for k, tiles in enumerate(calls):
+        c.encode_tiles(p, len(tiles), d[k].data_ptr(), True, fetch=False)
+        held.append((c.coded_device_ptr(), c.table_device_ptr(0), c.table_device_ptr(1), c.table_device_ptr(2)))
+        if k >= 1:
+            check(k - 1)
+    check(len(calls) - 1)
+    c.set_pipelining(False)
+    c.close()
+
+
 @pytest.mark.parametrize("kind", ["noise", "smooth", "mixed"])
 def test_ht_encoder_lds_cap_and_fallback(kind, monkeypatch):
     """K3 sizes its LDS streams for what real content needs (occupancy); a block that outgrows them is coded again by
