@@ -132,7 +132,20 @@ def cpu_baseline(rank_threads, want_cfg5=True):
                          "workload), median of compress-call wall times, %d threads" % (n8, rank_threads),
                "file_md5": __import__("hashlib").md5(cs8).hexdigest(),
                "cfg2": {"value": round(4096 * 4096 / med4 / 1e6, 2), "unit": "Mpixels/s",
-                        "sample": "%d x 4096x4096x3 8-bit, same settings" % n4}}
+                        "sample": "%d x 4096x4096x3 8-bit, same settings" % n4,
+                        "file_md5": __import__("hashlib").md5(cs).hexdigest()}}
+        # BASELINE configs[2] as BASELINE.md section 3 asks for it: grk_compress() over the image's int32 planes (defect D10 rules out
+        # grk_compress_tile for 16-bit samples).  The reference's HT 9/7 encoder quantises wrongly (defect D1: its FILE is not a parity
+        # target) but it does all of the path's work, so its wall time is the CPU figure for this configuration
+        try:
+            px3 = synth.g2(3, 8192, 8192, 16)
+            t3 = sorted(R.encode(px3, 16, numres=6, mode=1, ht=1, irrev=1)[1] for _ in range(2))
+            out["cfg3"] = {"value": round(8192 * 8192 / t3[0] / 1e6, 2), "unit": "Mpixels/s",
+                           "sample": "2 x 8192x8192x3 16-bit ICT + 9/7 + quantiser + HTJ2K 5 levels, grk_compress() on int32 planes, best "
+                                     "of the compress-call wall times, %d threads (output not a parity target: reference defect D1)" % rank_threads}
+            del px3
+        except Exception as e:  # noqa: BLE001
+            out["cfg3"] = {"value": None, "error": str(e)}
         # BASELINE configs[0]: 512 x 512 mono, 3 levels -- the reference's own test_tile_encoder case (too small for its thread pool)
         try:
             px1 = synth.g2(1, 512, 512, 8)
@@ -259,10 +272,53 @@ def _pmc_traffic(workload, fams):
         return None
 
 
-def _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, desc, irrev, traffic_key, host=None):
+def _parity_vs_cpu_encode(ctx, params, tile, W, H, prec, levels, ntiles, table, arena_used, irrev, cpu_md5=None):
+    """The parity field of a `workloads` entry, measured by THIS run.  Reversible configurations: the md5 of the codestream made of
+    the GPU's blocks against the md5 of the file Grok's own CPU encoder (oracle/_ref) writes for the same image -- taken from
+    cpu_baseline when that leg encoded this very image, else encoded here.  cfg3 (irreversible HT: the reference's own ENCODER is
+    broken there, SURVEY.md defect D1, so no reference bytes exist): the GPU's codestream through the reference's DECODER
+    (grk_decompress) -- PSNR / max error against the source -- and the GPU's own decode of the stream against those pixels."""
+    import hashlib
+    try:
+        import refharness as R
+        if not R.have_ref():
+            return {"error": "oracle/_ref missing"}
+        g = int(round(ntiles ** 0.5))
+        if g * g != ntiles:
+            return {"error": "tile count is not a square grid"}
+        coded = ctx.fetch_coded(arena_used)
+        cs = G.write_codestream(params, W * g, H * g, table, coded)
+        if irrev:
+            ref = R.decode(cs, tile.shape[0], H, W)
+            err = np.abs(ref.astype(np.int64) - tile.astype(np.int64))
+            mse = float((err.astype(np.float64) ** 2).mean())
+            back = ctx.decode_host(params, table, coded)[0].astype(np.int32)
+            return {"reference_decoder": {"decoder": "grk_decompress (oracle/_ref) of the codestream made of the GPU's blocks",
+                                          "max_abs_error": int(err.max()),
+                                          "psnr_db": round(10.0 * np.log10(float((1 << prec) - 1) ** 2 / mse), 2) if mse else None,
+                                          "bound_in_tests": "max_abs_error <= 8, psnr_db >= 90 (tests/test_gpu_at_size.py, tests/test_oracle_decode.py)"},
+                    "gpu_decode_equals_reference_decoder": bool(np.array_equal(back, ref)),
+                    "blocks_vs_oracle_chain": "all 49 152 blocks == the oracle chain's bytes: tests/test_gpu_at_size.py::"
+                                              "test_cfg3_8k_16bit_ict_dwt97_coefficients_and_blocks (minutes of CPU: not repeated here)"}
+        md5 = hashlib.md5(cs).hexdigest()
+        if cpu_md5 is None:
+            img = np.ascontiguousarray(np.tile(tile, (1, g, g))) if g > 1 else tile
+            want, _ = R.encode(img, prec, TW=W if g > 1 else None, TH=H if g > 1 else None, numres=levels + 1, mode=1 if g > 1 else 0)
+            cpu_md5, src = hashlib.md5(want).hexdigest(), "encoded by this run"
+        else:
+            src = "cpu_baseline's file of the same image, this run"
+        return {"file_equals_cpu_encode": md5 == cpu_md5, "codestream_md5": md5, "codestream_bytes": len(cs),
+                "cpu_file": "Grok 8.0.2 (oracle/_ref), " + src}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[-200:]}
+
+
+def _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, desc, irrev, traffic_key, host=None, parity=False,
+                     cpu_md5=None):
     """A few pipelined steps of one encode configuration + its kernel families one at a time (HIP events on the stream each
     kernel is launched on).  Bytes at the storage width of the planes (grk_amd_plane_sample_bytes)."""
     params = G.TileParams.make(W, H, Cn, prec, levels, irreversible=irrev)
+    tile = None
     if host is None:
         tile = synth.g2(Cn, H, W, prec)
         host = np.ascontiguousarray(np.broadcast_to(tile.reshape(1, -1), (ntiles, tile.size))).reshape(-1)
@@ -315,8 +371,11 @@ def _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, de
                      "frac_on_unfused_dwt_only_bytes": rate(du, dwt_ms)[1],
                      "traffic": t_d, "frac_on_traffic": rate(t_d, dwt_ms)[1] if t_d else None},
              "ht_cleanup_encode": {"avg_ms": round(ht_ms, 4), "algorithmic_bytes": int(hb), "algorithmic_GBps": rate(hb, ht_ms)[0],
-                                   "frac": rate(hb, ht_ms)[1], "traffic": t_h, "frac_on_traffic": rate(t_h, ht_ms)[1] if t_h else None}}}
+                                   "frac": rate(hb, ht_ms)[1], "traffic": t_h, "frac_on_traffic": rate(t_h, ht_ms)[1] if t_h else None}},
+         "traffic_source": _PMC_SOURCE.get(traffic_key) if traffic_key else None}
     del d_px
+    if parity and tile is not None:
+        w["parity"] = _parity_vs_cpu_encode(ctx, params, tile, W, H, prec, levels, ntiles, table, arena_used, irrev, cpu_md5)
     return w
 
 
@@ -372,7 +431,7 @@ def cfg5_sequence_child(fcs, fref, S, device):
     print(json.dumps(res))
 
 
-def extra_workloads(ctx, dev, stream, steps, cfg5):
+def extra_workloads(ctx, dev, stream, steps, cfg5, cpu_md5s=None):
     """The other BASELINE configurations on the same GPU, a few steps each: cfg2, cfg3 with its
     9/7 DWT family against the HBM roofline (north_star's >= 40 % target), the cfg4 tiling and the whole cfg4 image (256
     tiles) at N = 1, the 8K workload at the reference's int32 width, and the cfg5 decode."""
@@ -381,14 +440,14 @@ def extra_workloads(ctx, dev, stream, steps, cfg5):
         Cn, W, H, prec, levels, ntiles, desc = WORKLOADS[name]
         try:
             out[name] = _encode_workload(ctx, dev, stream, steps, Cn, W, H, prec, levels, ntiles, desc, name == "cfg3",
-                                         None if name == "cfg1" else name)
+                                         None if name == "cfg1" else name, parity=True, cpu_md5=(cpu_md5s or {}).get(name))
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": str(e)}
     # BASELINE configs[3] whole: 16384 x 16384 as 256 tiles of 1024 x 1024 on ONE GPU (the N = 1 point of its scaling curve)
     try:
         out["cfg4"] = _encode_workload(ctx, dev, stream, max(3, steps // 2), 3, 1024, 1024, 8, 5, 256,
                                        "16384x16384x3 8-bit RGB as 256 tiles of 1024x1024, RCT+5/3 lossless HTJ2K, 5 levels, one GPU "
-                                       "(BASELINE configs[3] at N = 1)", False, "cfg4")
+                                       "(BASELINE configs[3] at N = 1)", False, "cfg4", parity=True)
         out["cfg4"]["value"] = round(16384.0 * 16384.0 / out["cfg4"]["ms_per_step"] / 1e3, 1)
     except Exception as e:  # noqa: BLE001
         out["cfg4"] = {"error": str(e)}
@@ -1317,7 +1376,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and not use_dist and not args.no_workloads and args.workload == "8k":
-            out["workloads"] = extra_workloads(ctx, dev, stream, max(3, min(args.steps, 10)), cfg5)
+            cb = out.get("cpu_baseline") or {}
+            out["workloads"] = extra_workloads(ctx, dev, stream, max(3, min(args.steps, 10)), cfg5,
+                                               {"cfg2": (cb.get("cfg2") or {}).get("file_md5")})
         if world == 1 and not use_dist and not args.no_host_boundary:
             try:
                 hb = {"end_to_end": host_boundary(ctx, dev, stream, params, ntiles, torch.from_numpy(host.view(np.uint8)), nblocks,

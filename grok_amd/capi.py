@@ -123,6 +123,9 @@ def lib():
         if hasattr(L, "grk_amd_set_decode_pipelining"):
             L.grk_amd_set_decode_pipelining.argtypes = [vp, i32]
         L.grk_amd_stream_wait_results.argtypes = [vp, vp]
+        if hasattr(L, "grk_amd_set_pixel_hold"):
+            L.grk_amd_set_pixel_hold.argtypes = [vp, i32]
+            L.grk_amd_stream_wait_pixels.argtypes = [vp, vp]
         if hasattr(L, "grk_amd_decode_stream_wait_slot"):
             L.grk_amd_decode_stream_wait_slot.argtypes = [vp, vp]
         L.grk_amd_stage_egress.argtypes = [vp, PP, u32, vp, vp]
@@ -434,6 +437,14 @@ class Context:
 
     def stream_wait_results(self, hip_stream):
         self._check(self._L.grk_amd_stream_wait_results(self._h, C.c_void_p(hip_stream)), "stream_wait_results")
+
+    def set_pixel_hold(self, on):
+        """True: the caller keeps a call's device pixels untouched until stream_wait_pixels / synchronize (include/grok_amd.h)."""
+        if hasattr(self._L, "grk_amd_set_pixel_hold"):
+            self._check(self._L.grk_amd_set_pixel_hold(self._h, int(bool(on))), "set_pixel_hold")
+
+    def stream_wait_pixels(self, hip_stream):
+        self._check(self._L.grk_amd_stream_wait_pixels(self._h, C.c_void_p(hip_stream)), "stream_wait_pixels")
 
     def set_decode_pipelining(self, frames_in_flight):
         """2..8: consecutive decode_device calls run on that many internal buffer / stream sets in turn (0 / 1: off)"""

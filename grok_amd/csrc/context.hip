@@ -160,6 +160,12 @@ struct grk_amd_ctx {
     // GRK_AMD_FRAME_STREAMS = 0: never, 1 (default): by size, 2: always
     static constexpr uint64_t kFrameStreamSamples = 16ull << 20;
     int frame_streams = 1; int fs_parity = 0;
+    // ... the caller's pixels are then read on the frame's stream, not on the context's: level 0 -- their only reader -- is followed by
+    // this event, and the context's stream waits for it, so that whatever the caller queues behind the call in stream order (the
+    // next frame's pixels into the same buffer, a stream-ordered free) still comes after the read, as it does on the other paths
+    // (grk_amd_set_pixel_hold(ctx, 1): the caller keeps a call's pixels untouched until grk_amd_stream_wait_pixels / a synchronisation;
+    //  the wait -- two queue hand-overs between consecutive small frames, 0.038 -> 0.057 ms per 512^2 call -- is then left out)
+    hipEvent_t ev_px = nullptr; bool want_px_event = false; bool px_hold = false; bool px_event_valid = false;
     int k3_room = 3;                  // pipelined encodes: K3 launches that leave registers for the next frame's level 0 -- bit 0 the top class, bit 1 the rest (GRK_AMD_K3_ROOM)
     // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
     // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; 2: lanes wherever they can be used; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
@@ -419,6 +425,7 @@ struct ScopedTimer {
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         (void)hipEventRecord(a, st);
     }
+    void cancel() { if (a) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); a = b = nullptr; } }
     ~ScopedTimer()
     {
         if (!a) return;
@@ -544,6 +551,7 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
             a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
             a.sext = g.p.sgnd ? (1 << (8 * a.px_bytes - 1)) : 0;
             HIP_TRY(c, launch_dwt_level0_fused(a, ntiles, g.p.num_comps, g.p.mct, c->stream), "launch fused dwt level 0");
+            if (c->want_px_event) HIP_TRY(c, hipEventRecord(c->ev_px, c->stream), "record the pixels' last read");
         } else {
             HIP_TRY(c, launch_dwt_level(a, c->stream), "launch dwt level");
         }
@@ -1131,6 +1139,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+    if (c->ev_px) (void)hipEventDestroy(c->ev_px);
     for (auto& alt_set : c->alts) {
         auto* as = &alt_set;
         if (as->ev_side) (void)hipEventDestroy(as->ev_side);
@@ -1400,10 +1409,18 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             HIP_TRY(c, hipEventRecord(c->ev_seq, c->stream), "record the caller's stream");
             HIP_TRY(c, hipStreamWaitEvent(k->stream, c->ev_seq, 0), "order the frame behind the caller's stream");
             const int rc = decode_impl(k, p, ntiles, table, coded, coded_bytes, 1, pixels, 1, nullptr);
-            if (rc) { c->err = k->err; return rc; }
-            // (the frame's last kernels -- the final inverse level, behind its join with the side stream -- are on k's stream)
+            // (the frame's last kernels -- the final inverse level, behind its join with the side stream -- are on k's stream; a call
+            //  that failed half-way may have queued kernels that still read the coded bytes or write the pixels: the set's event covers
+            //  those too, its side stream joined first)
             if (!k->ev_frame_done) HIP_TRY(c, hipEventCreateWithFlags(&k->ev_frame_done, hipEventDisableTiming), "create event");
+            if (rc && k->side) {
+                if (!k->ev_dec_top) HIP_TRY(c, hipEventCreateWithFlags(&k->ev_dec_top, hipEventDisableTiming), "create event");
+                HIP_TRY(c, hipEventRecord(k->ev_dec_top, k->side), "record the side stream");
+                HIP_TRY(c, hipStreamWaitEvent(k->stream, k->ev_dec_top, 0), "join the side stream");
+                k->dec_top_pending = false;
+            }
             HIP_TRY(c, hipEventRecord(k->ev_frame_done, k->stream), "record the frame's end");
+            if (rc) c->err = k->err;
             return rc;
         }
     }
@@ -1640,10 +1657,20 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
         const bool h16 = c->planes16 && fused && planes16_ok(g.p);
         c->last_h16 = h16;
         if (fs) {
+            t.cancel();
             // the whole frame on its stream, as the non-overlapped path lays it out (one K3 launch of every block, the ROOM instance)
             struct StreamSwap { grk_amd_ctx* c; hipStream_t keep; StreamSwap(grk_amd_ctx* c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
                                 ~StreamSwap() { c->stream = keep; } } on_frame_stream(c, fs_st);
-            rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, false, h16); if (rc) return rc;
+            if (!c->ev_px) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_px, hipEventDisableTiming), "create event");
+            ScopedTimer tf(c, 3);              // (the call's timer on the stream that carries the call)
+            c->want_px_event = true;
+            rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, false, h16);
+            c->want_px_event = false;
+            if (rc) return rc;
+            // the pixel-lifetime contract of every other path: work queued on the context's stream after this call comes after the read
+            c->px_event_valid = true;
+            if (!c->px_hold)
+                HIP_TRY(c, hipStreamWaitEvent(on_frame_stream.keep, c->ev_px, 0), "the context's stream waits for the pixels' last read");
             rc = run_ht(c, ntiles, c->p1.p, false, h16, (c->k3_room & 1) != 0); if (rc) return rc;
             HIP_TRY(c, hipEventRecord(c->ev_side, fs_st), "record the frame's stream");
             HIP_TRY(c, hipEventRecord(c->ev_side2, fs_st), "record the frame's stream");
@@ -1651,6 +1678,7 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             if (table || total) return grk_amd_fetch_table(c, table, total);
             return GRK_AMD_OK;
         }
+        c->px_event_valid = false;          // (the pixels are read on the context's stream itself from here on)
         if (ov) {       // the allocator must be reset before the first K3 launch of either stream
             int rc2 = GRK_AMD_OK;
             const HtArgs h = make_ht_args(c, ntiles, c->p1.p, &rc2, h16);
@@ -1680,6 +1708,25 @@ int grk_amd_stream_wait_results(grk_amd_ctx* c, void* hip_stream)
         HIP_TRY(c, hipStreamWaitEvent(s, c->ev_side, 0), "wait for the side stream");
         HIP_TRY(c, hipStreamWaitEvent(s, c->ev_side2, 0), "wait for the side stream 2");
     }
+    return GRK_AMD_OK;
+}
+
+int grk_amd_set_pixel_hold(grk_amd_ctx* c, int on)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    c->px_hold = on != 0;
+    return GRK_AMD_OK;
+}
+
+int grk_amd_stream_wait_pixels(grk_amd_ctx* c, void* hip_stream)
+{
+    if (!c || !hip_stream) return GRK_AMD_ERR_INVALID;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (c->px_event_valid) { HIP_TRY(c, hipStreamWaitEvent(s, c->ev_px, 0), "wait for the pixels' last read"); return GRK_AMD_OK; }
+    if (s == c->stream) return GRK_AMD_OK;        // (stream order)
+    if (!c->ev_main) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming), "create event");
+    HIP_TRY(c, hipEventRecord(c->ev_main, c->stream), "record main stream");
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_main, 0), "wait for the main stream");
     return GRK_AMD_OK;
 }
 

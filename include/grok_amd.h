@@ -130,7 +130,10 @@ uint64_t grk_amd_plane_elems(const grk_amd_tile_params* p);
  * Encode `num_tiles` tiles of one geometry (grk_amd_same_tile_geometry; the batch is coded with *p) in one batch.  `pixels` holds the tiles back to back,
  * each tile component-major planar, row-major, tightly packed, ceil(prec/8) bytes per sample,
  * host endian -- the layout grk_compress_tile() takes (TileProcessor.cpp:1177-1213).
- * pixels_on_device != 0: `pixels` is a device pointer (HBM-resident input, what bench.py times).
+ * pixels_on_device != 0: `pixels` is a device pointer (HBM-resident input, what bench.py times).  Lifetime of device pixels: they
+ * are read in the order of the context's stream (grk_amd_set_stream) -- whatever the caller queues on that stream behind the call (the
+ * next frame's pixels into the same buffer, a stream-ordered free) comes after the read, on every path, pipelined or not
+ * (grk_amd_set_pixel_hold below relaxes this for callers that rotate their input buffers).
  *
  * On return the coded bytes of all blocks live in the context's device arena; `table` (host,
  * num_tiles * blocks_per_tile rows, tile-major) describes them.  Pass table == NULL to leave the
@@ -138,6 +141,14 @@ uint64_t grk_amd_plane_elems(const grk_amd_tile_params* p);
 int grk_amd_encode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles,
                          const void* pixels, int pixels_on_device,
                          grk_amd_coded_block* table, uint64_t* total_bytes);
+/* Pixel lifetime, relaxed (default off).  Pipelined encodes of small frames run a frame's whole chain on a stream of the context's own
+ * (GRK_AMD_FRAME_STREAMS), so keeping the rule above costs a wait of the context's stream per call -- consecutive 512 x 512 frames:
+ * 0.057 instead of 0.038 ms per call.  on != 0: the caller PROMISES not to touch a call's device pixels before a stream of its own has
+ * passed grk_amd_stream_wait_pixels (or grk_amd_synchronize returned); the wait is then left out.  A ring of input buffers with
+ * one grk_amd_stream_wait_pixels before a buffer is refilled is the intended use. */
+int grk_amd_set_pixel_hold(grk_amd_ctx* ctx, int on);
+/* Makes `hip_stream` wait until the LATEST grk_amd_encode_tiles call has read its device pixels (not for its results). */
+int grk_amd_stream_wait_pixels(grk_amd_ctx* ctx, void* hip_stream);
 int grk_amd_fetch_table(grk_amd_ctx* ctx, grk_amd_coded_block* table, uint64_t* total_bytes);
 /* copy coded bytes [0,total) of the arena to host memory */
 int grk_amd_fetch_coded(grk_amd_ctx* ctx, uint8_t* dst, uint64_t nbytes);
@@ -274,7 +285,9 @@ int grk_amd_stage_egress(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
  * which: 0 ingest+mct, 1 dwt (all levels), 2 ht encode kernel (launches on the context's stream), 3 whole
  *        encode_tiles call, 4 ht encode kernel, top resolution (side stream, beside DWT levels >= 1),
  *        5 ht decode, 6 inverse dwt (all levels), 7 egress, 8 ht encode kernel, large-LDS classes (second side stream).
- * One encode runs the ht encode kernel up to three times (2, 4, 8): its time per step is their sum. */
+ * One encode runs the ht encode kernel up to three times (2, 4, 8): its time per step is their sum.
+ * Pipelined encodes of small frames (a frame's whole chain on one of the side streams, GRK_AMD_FRAME_STREAMS): families 1, 2 and 3
+ * are then measured on that stream -- the stream that carries the call -- and 4 / 8 stay empty. */
 int    grk_amd_enable_timing(grk_amd_ctx* ctx, int on);
 /* K3 of the top resolution beside DWT levels >= 1 on side streams (default on; environment GRK_AMD_OVERLAP=0/1
  * sets the default).  Off = every kernel alone on the GPU, one after the other: what per-kernel durations
@@ -383,7 +396,10 @@ int64_t grk_amd_locate_tile_parts(const uint8_t* cs, uint64_t len, uint64_t* off
  * In gather mode a worker whose tiles fall into more than one geometry group rotates four buffer sets, so that a group's bytes
  * travel to the writer while the worker's next groups are coded (an event per group, one wait behind the last); the rotation is
  * switched on by the first such encode and multiplies that worker's device memory for planes, arena and tables by four (several
- * GB for 8K tiles).  Parallel writers, and contexts taken through grk_amd_node_ctx before any gather, keep one set. */
+ * GB for 8K tiles).  Parallel writers, and contexts taken through grk_amd_node_ctx before any gather, keep one set.  The rotation
+ * STAYS on afterwards: a context taken through grk_amd_node_ctx after such a gather, and every later encode of that worker (gather or
+ * not), works with four sets and with the "results valid until the 4th next call" rule of grk_amd_set_pipelining(ctx, 3); a caller
+ * that wants the memory back calls grk_amd_set_pipelining(grk_amd_node_ctx(node, i), 0) between images. */
 typedef struct grk_amd_node grk_amd_node;
 #define GRK_AMD_NODE_GATHER 0x80000000u
 int  grk_amd_device_count(void);

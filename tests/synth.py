@@ -50,3 +50,10 @@ def g2(C, H, W, prec=8, seed=12345):
         v += s[c]
         out[c] = v
     return out
+
+
+def psnr_db(a, b, prec):
+    """PSNR of two sample arrays against the full scale of `prec` bits (inf when equal)."""
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float((d * d).mean())
+    return float("inf") if mse == 0.0 else float(10.0 * np.log10(float((1 << prec) - 1) ** 2 / mse))

@@ -79,6 +79,39 @@ def test_cfg3_8k_16bit_ict_dwt97_coefficients_and_blocks():
         if got[i] != O.ht_encode_sm(sm, b.kmax):
             bad.append(i)
     assert not bad, "blocks differing from the oracle chain: %s" % bad[:10]
+    del mall, ycc, mall_gpu
+    # The last link: the GPU's 16-bit cfg3 codestream through the REFERENCE's decoder (grk_decompress,
+    # T1HT.cpp:129-179 + ScaleHTFilter PostDecompressFilters.h:60-71 + inverse 9/7 + inverse ICT): close to the source within the
+    # bound tests/test_oracle_decode.py pins the oracle chain with at this bit depth, and the GPU's own decode of the same
+    # stream (K5 -> dequantisation -> K6 -> K7 at 16 bits, 8192 x 8192) returns the reference decoder's pixels exactly
+    if R.have_ref():
+        R.lib(threads=os.cpu_count() or 1)
+        cs = G.write_codestream(p, W, H, table, coded)
+        ref = R.decode(cs, Cn, H, W)
+        err = int(np.abs(ref.astype(np.int64) - px.astype(np.int64)).max())
+        psnr = synth.psnr_db(ref, px, prec)
+        assert err <= 8 and psnr >= 90.0, (err, psnr)
+        back = c.decode_host(p, table, coded)[0].astype(np.int32)
+        assert np.array_equal(back, ref), "GPU decode of the cfg3 stream differs from grk_decompress at %d samples" % int((back != ref).sum())
+
+
+@needs_ref
+@pytest.mark.parametrize("Cn,H,W,L", [(3, 256, 256, 5), (1, 200, 333, 3)])
+def test_cfg3_bit_depth_small_gpu_stream_through_reference_decoder(Cn, H, W, L):
+    """16-bit ICT + 9/7 + quantiser + HT at a size the whole oracle chain runs at: the GPU's codestream -> grk_decompress ==
+    the oracle's decode chain of the GPU's blocks == the GPU's decode, and all of them within 8 / 65 536 of the source."""
+    prec = 16
+    px = synth.g2(Cn, H, W, prec)
+    p = G.TileParams.make(W, H, Cn, prec, L, irreversible=True)
+    c = U.ctx()
+    table, coded = c.encode_host(p, px)
+    _, blocks, qcd, otable, ocoded = chain.encode_tile_oracle(px, prec, L, irrev=True)
+    assert U.split_blocks(table, coded) == [bytes(ocoded[int(o):int(o) + int(n)]) for o, n in zip(otable["offset"], otable["length"])]
+    cs = G.write_codestream(p, W, H, table, coded)
+    ref = R.decode(cs, Cn, H, W)
+    assert np.abs(ref.astype(np.int64) - px.astype(np.int64)).max() <= 8 and synth.psnr_db(ref, px, prec) >= 90.0
+    assert np.array_equal(chain.decode_tile_oracle(p, blocks, qcd, table, bytes(coded)), ref)
+    assert np.array_equal(c.decode_host(p, table, coded)[0].astype(np.int32), ref)
 
 
 @needs_ref

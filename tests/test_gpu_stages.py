@@ -415,6 +415,57 @@ def test_pipelined_encodes_keep_their_results_until_the_second_next_call(depth, 
     c.close()
 
 
+@pytest.mark.parametrize("frame_streams,hold", [("0", False), ("2", False), ("2", True), ("0", True)])
+def test_pipelined_encodes_out_of_one_pixel_buffer_rewritten_in_stream_order(frame_streams, hold, monkeypatch):
+    """The pixel-lifetime contract of grk_amd_encode_tiles with device pixels: the pixels are read in the order of the CONTEXT's stream,
+    so a caller that gave the context its own stream (grk_amd_set_stream) may overwrite the buffer on that stream right behind the
+    call.  With a frame's chain on one of the side streams (GRK_AMD_FRAME_STREAMS, what frames of this size take) level 0 reads the
+    pixels there: the context's stream waits for that read.  Ten frames through ONE buffer, each copied in on the caller's stream
+    directly behind the previous call, no host synchronisation in between; every frame's blocks equal a plain encode's.
+    `hold`: grk_amd_set_pixel_hold(ctx, 1) -- the context leaves that wait out and the caller's stream takes it explicitly
+    (grk_amd_stream_wait_pixels) before it refills the buffer."""
+    monkeypatch.setenv("GRK_AMD_FRAME_STREAMS", frame_streams)
+    W, H = 1536, 1024
+    p = G.TileParams.make(W, H, 3, 8, 5)
+    imgs = [synth.g2(3, H, W, 8, seed=40 + i) if i % 2 else (255 - synth.g2(3, H, W, 8, seed=40 + i)).astype(np.uint8) for i in range(10)]
+    want = []
+    for im in imgs:
+        t, coded = U.ctx().encode_host(p, im)
+        want.append(U.split_blocks(t, coded))
+    nb = G.lib().grk_amd_tile_num_blocks(p)
+    src = [U.to_dev(im.reshape(-1)) for im in imgs]
+    one = torch.empty_like(src[0])
+    st = torch.cuda.Stream()
+    c = G.Context(0)
+    c.set_stream(st.cuda_stream)
+    depth = 3
+    c.set_pipelining(depth)
+    c.set_pixel_hold(hold)
+    held = []
+    with torch.cuda.stream(st):
+        for k in range(len(imgs)):
+            if hold and k:
+                c.stream_wait_pixels(st.cuda_stream)
+            one.copy_(src[k], non_blocking=True)        # on the caller's stream = the context's stream: behind call k - 1
+            c.encode_tiles(p, 1, one.data_ptr(), True, fetch=False)
+            held.append((c.coded_device_ptr(), c.table_device_ptr(0), c.table_device_ptr(1), c.table_device_ptr(2)))
+            if k >= depth:
+                c.synchronize()
+                torch.cuda.synchronize()
+                arena_p, off_p, len_p, used_p = held[k - depth]
+                used = int(_dev_view(used_p, 1, "<i8").cpu()[0])
+                offs = _dev_view(off_p, nb, "<i8").cpu().numpy()
+                lens = _dev_view(len_p, nb, "<i4").cpu().numpy()
+                arena = _dev_view(arena_p, used, "|u1").cpu().numpy()
+                assert [bytes(arena[int(o):int(o) + int(l)]) for o, l in zip(offs, lens)] == want[k - depth], "frame %d" % (k - depth)
+    t, tot = c.fetch_table(nb)
+    coded = c.fetch_coded(tot)
+    assert U.split_blocks(t, coded) == want[-1]
+    c.set_pipelining(False)
+    c.set_stream(0)
+    c.close()
+
+
 def test_pipelined_encodes_of_both_forms_in_turn():
     """Calls of one geometry with one tile (a frame's whole chain on one side stream: up to 16 M samples per call) and with eight
     tiles (DWT chain on the main stream, K3 on the side streams) in turn, no fetch in between: each call's device-resident results,

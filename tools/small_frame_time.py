@@ -15,6 +15,7 @@ for S, L in sizes:
         ctx.set_stream(stream.cuda_stream)
         ctx.set_overlap(overlap)
         ctx.set_pipelining(pipe)
+        ctx.set_pixel_hold(os.environ.get("SF_HOLD", "0") == "1")
         with torch.cuda.stream(stream):
             for _ in range(30):
                 ctx.encode_tiles(p, 1, d.data_ptr(), True, fetch=False)
