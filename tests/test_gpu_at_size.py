@@ -80,12 +80,18 @@ def test_cfg3_8k_16bit_ict_dwt97_coefficients_and_blocks():
             bad.append(i)
     assert not bad, "blocks differing from the oracle chain: %s" % bad[:10]
     del mall, ycc, mall_gpu
-    # The last link: the GPU's 16-bit cfg3 codestream through the REFERENCE's decoder (grk_decompress,
+    # The last link: a GPU-made 16-bit cfg3 codestream through the REFERENCE's decoder (grk_decompress,
     # T1HT.cpp:129-179 + ScaleHTFilter PostDecompressFilters.h:60-71 + inverse 9/7 + inverse ICT): close to the source within the
     # bound tests/test_oracle_decode.py pins the oracle chain with at this bit depth, and the GPU's own decode of the same
-    # stream (K5 -> dequantisation -> K6 -> K7 at 16 bits, 8192 x 8192) returns the reference decoder's pixels exactly
+    # stream (K5 -> dequantisation -> K6 -> K7 at 16 bits, 8192 x 8192) returns the reference decoder's pixels exactly.
+    # Content: G2 clipped into the middle of the range -- the reference's decoder refuses plain G2's darkest LL block (defect D5,
+    # synth.g2_mid), and so, mirroring it, does ours.
     if R.have_ref():
+        with pytest.raises(RuntimeError):
+            c.decode_host(p, table, coded)                 # (plain G2: the D5 check of the reference's decoder, mirrored)
         R.lib(threads=os.cpu_count() or 1)
+        px = synth.g2_mid(Cn, H, W, prec)
+        table, coded = c.encode_host(p, px)
         cs = G.write_codestream(p, W, H, table, coded)
         ref = R.decode(cs, Cn, H, W)
         err = int(np.abs(ref.astype(np.int64) - px.astype(np.int64)).max())
@@ -96,12 +102,12 @@ def test_cfg3_8k_16bit_ict_dwt97_coefficients_and_blocks():
 
 
 @needs_ref
-@pytest.mark.parametrize("Cn,H,W,L", [(3, 256, 256, 5), (1, 200, 333, 3)])
-def test_cfg3_bit_depth_small_gpu_stream_through_reference_decoder(Cn, H, W, L):
+@pytest.mark.parametrize("Cn,H,W,L,gen", [(3, 256, 256, 5, "g2"), (1, 200, 333, 3, "g2"), (3, 1024, 1024, 5, "g2_mid"), (3, 1536, 640, 4, "g2_mid")])
+def test_cfg3_bit_depth_small_gpu_stream_through_reference_decoder(Cn, H, W, L, gen):
     """16-bit ICT + 9/7 + quantiser + HT at a size the whole oracle chain runs at: the GPU's codestream -> grk_decompress ==
     the oracle's decode chain of the GPU's blocks == the GPU's decode, and all of them within 8 / 65 536 of the source."""
     prec = 16
-    px = synth.g2(Cn, H, W, prec)
+    px = getattr(synth, gen)(Cn, H, W, prec)
     p = G.TileParams.make(W, H, Cn, prec, L, irreversible=True)
     c = U.ctx()
     table, coded = c.encode_host(p, px)

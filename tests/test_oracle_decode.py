@@ -79,11 +79,11 @@ def test_lossless_chain_vs_reference_decoder(Cn, H, W, prec, L, gen):
 
 @needs_ref
 @pytest.mark.parametrize("Cn,H,W,prec,L", [(1, 128, 128, 8, 3), (3, 96, 160, 8, 4), (3, 128, 192, 12, 5), (1, 67, 45, 8, 2),
-                                           (3, 128, 192, 16, 3), (3, 256, 256, 16, 5), (1, 100, 75, 16, 4)])
+                                           (3, 128, 192, 16, 3), (3, 256, 256, 16, 5), (1, 100, 75, 16, 4), (3, 1024, 1024, 16, 5)])
 def test_irreversible_chain_vs_reference_decoder(Cn, H, W, prec, L):
     """9/7 + ICT + dead-zone quantiser: our codestream through grk_decompress == the oracle's decode
     chain, pixel for pixel (both follow the same fp32 operation order)."""
-    px = synth.g2(Cn, H, W, prec)
+    px = (synth.g2_mid if W >= 1024 else synth.g2)(Cn, H, W, prec)       # (defect D5: synth.g2_mid)
     p, blocks, qcd, table, coded = chain.encode_tile_oracle(px, prec, L, irrev=True)
     cs = G.write_codestream(p, W, H, table, coded)
     ref = R.decode(cs, Cn, H, W)
