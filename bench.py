@@ -875,9 +875,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="every kernel alone on the GPU, also in the timed region (what the rocprofv3 kernel-trace summary "
                          "that the roofline durations are checked against is taken with)")
-    ap.add_argument("--exchange", default="gather", choices=("gather", "counts"),
+    ap.add_argument("--exchange", default="best", choices=("best", "gather", "counts"),
                     help="N > 1: which exchange the headline `value` is (both are always timed and reported, `exchange` in the "
-                         "line): 'gather' = every rank's coded tile-parts (exact sizes) over xGMI to the frame's writer rank, "
+                         "line; `config.headline_exchange` says which one the value is): 'best' (default) = whichever of the two is "
+                         "faster on this node -- DESIGN.md section 6's arithmetic says the gather is bound by xGMI ingress at N = 8 and "
+                         "the parallel writers are not, and no measured run has decided it --; 'gather' = every rank's coded tile-parts (exact sizes) over xGMI to the frame's writer rank, "
                          "which rotates with the frame number, --gather-depth frames in flight; 'counts' = all_gather of the coded "
                          "byte counts only (parallel writers: the bytes leave each GPU over its own PCIe link)")
     ap.add_argument("--gather-depth", type=int, default=4, choices=range(1, 6),
@@ -1453,10 +1455,18 @@ def main():
             out["exchange"]["gather"] = g8
             if g4 is not None:
                 multi_gpu["cfg4_strong"]["gather"] = g4
-            if args.exchange == "gather":          # north_star's wording: the headline is the figure WITH the tile-parts moved
-                out["value"] = g8["Mpixels_s"]
-                out["ms_per_step"] = g8["ms_per_step"]
-                out["config"]["headline_exchange"] = "gather"
+            # the headline: the faster of the two complete exchanges unless the caller named one; both stay in `exchange`
+            counts_v = (rep.get("counts") or {}).get("Mpixels_s") or 0.0
+            gbest = g8
+            if args.exchange == "best":            # ... at the depth that did best (every depth's figure is a complete gather)
+                dbest = max(by_depth, key=lambda k: by_depth[k]["Mpixels_s"])
+                gbest = dict(by_depth[dbest], gather_depth=int(dbest))
+            take_gather = args.exchange == "gather" or (args.exchange == "best" and gbest["Mpixels_s"] > counts_v)
+            out["config"]["headline_exchange_rule"] = args.exchange
+            if take_gather:
+                out["value"] = gbest["Mpixels_s"]
+                out["ms_per_step"] = gbest["ms_per_step"]
+                out["config"]["headline_exchange"] = "gather (depth %d)" % gbest["gather_depth"]
                 out["config"]["assembled_codestream_bytes"] = cs_len
         dist.barrier()
         dist.destroy_process_group()

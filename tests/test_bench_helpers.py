@@ -90,3 +90,14 @@ def test_gather_watchdog_prints_the_counts_figures_when_a_rank_stalls():
     assert r.returncode == 0, r.stderr[-1500:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and "error" in line["exchange"]["gather"]
+
+
+def test_gather_watchdog_at_world_8_with_a_stalled_rank():
+    """The same at the world size the driver's scaling run ends with: eight ranks meet over gloo, rank 5 never joins the gather's
+    collective; the line carries the counts of all eight and the gather's error, every rank leaves."""
+    import json
+    r = _run_bench("--gpus", "8", "--dry-run", "--dry-run-stall", "5", "--gather-timeout", "6", "--gather-timeout-rc", "3")
+    assert r.returncode != 0, r.stdout[-500:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["exchange"]["counts"] == {"ranks": 8}
+    assert "did not complete within 6 s" in line["exchange"]["gather"]["error"]

@@ -165,6 +165,24 @@ def test_gathers_of_several_frames_in_flight(tmp_path, world, depth, lag, frames
         assert files[f] == cshelp.oracle_codestream(synth.g2(3, H, W, 8, seed=12345 + f), 8, L, T, T), "frame %d" % f
 
 
+def test_world_8_cfg4_shape_scaled_down(tmp_path):
+    """BASELINE configs[3]'s shape at the world size its scaling curve ends with, scaled down to what eight CPU ranks do in seconds:
+    255 tiles of 64 x 64 (a 17 x 15 grid: ranks 0-6 own 32 tiles, rank 7 owns 31), four gathers in flight two frames behind the
+    encoder, ten frames -- every writer comes round, every communicator slot twice.  Every frame's file == a single process's, and
+    the parallel writers' file decodes to the image."""
+    W, H, T, L = 17 * 64, 15 * 64, 64, 2
+    frames = 10
+    files, parallel = _run(8, W, H, T, T, L, frames, tmp_path, depth=4, lag=2)
+    assert sorted(files) == list(range(frames))
+    for f in range(frames):
+        assert files[f] == cshelp.oracle_codestream(synth.g2(3, H, W, 8, seed=12345 + f), 8, L, T, T), "frame %d" % f
+    where, used_tlm = G.locate_tile_parts(parallel)
+    assert used_tlm and len(where) == 255
+    import refharness as R
+    if R.have_ref():
+        assert np.array_equal(R.decode(parallel, 3, H, W), synth.g2(3, H, W, 8).astype(np.int32))
+
+
 def test_shard_tiles_partition():
     for n, w in ((256, 8), (7, 3), (1, 4)):
         seen = sorted(t for r in range(w) for t in D.shard_tiles(n, w, r))
