@@ -123,6 +123,8 @@ def lib():
         if hasattr(L, "grk_amd_set_decode_pipelining"):
             L.grk_amd_set_decode_pipelining.argtypes = [vp, i32]
         L.grk_amd_stream_wait_results.argtypes = [vp, vp]
+        if hasattr(L, "grk_amd_block_distortion"):
+            L.grk_amd_block_distortion.argtypes = [vp, vp, u64]
         if hasattr(L, "grk_amd_set_pixel_hold"):
             L.grk_amd_set_pixel_hold.argtypes = [vp, i32]
             L.grk_amd_stream_wait_pixels.argtypes = [vp, vp]
@@ -437,6 +439,12 @@ class Context:
 
     def stream_wait_results(self, hip_stream):
         self._check(self._L.grk_amd_stream_wait_results(self._h, C.c_void_p(hip_stream)), "stream_wait_results")
+
+    def block_distortion(self, nblocks):
+        """Distortion decrease of every block of the latest encode (the rate-control hook, include/grok_amd.h)."""
+        out = np.zeros(int(nblocks), np.float64)
+        self._check(self._L.grk_amd_block_distortion(self._h, out.ctypes.data, int(nblocks)), "block_distortion")
+        return out
 
     def set_pixel_hold(self, on):
         """True: the caller keeps a call's device pixels untouched until stream_wait_pixels / synchronize (include/grok_amd.h)."""

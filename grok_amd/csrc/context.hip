@@ -140,6 +140,7 @@ struct grk_amd_ctx {
     bool fuse_egress = true;                                // K7 inside the last inverse DWT level (GRK_AMD_FUSE_EGRESS=0: separate)
     bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
     DevBuf ht_sel;
+    DevBuf energy;                   // grk_amd_block_distortion: sum of q^2 per block
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
     uint32_t last_ntiles = 0;
@@ -1132,7 +1133,7 @@ void grk_amd_destroy(grk_amd_ctx* c)
     drain_timers(c);
     for (DevBuf* b : {&c->pixels, &c->p0, &c->p1, &c->llA, &c->llB, &c->blockdesc, &c->lengths,
                       &c->offsets, &c->arena, &c->flag, &c->dec_desc, &c->dec_table, &c->dec_quads, &c->dec_mslen,
-                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->ht_sel})
+                      &c->dec_coded, &c->dec_pixels, &c->dec_work, &c->ht_sel, &c->energy})
         b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
@@ -1567,6 +1568,50 @@ int grk_amd_fetch_coefficients(grk_amd_ctx* c, uint32_t comp, int32_t* dst, uint
         HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)dst_stride * 4, (const int32_t*)c->p1.p + (size_t)comp * g.plane_elems,
                                     (size_t)g.stride * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, c->stream), "fetch coefficients");
         HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    }
+    return GRK_AMD_OK;
+}
+
+// Weights of T1::getwmsedec (t1/t1_part1/T1.cpp:394-414): L2 norms of the synthesis basis functions by orientation and decomposition
+// level (dwt_norms / dwt_norms_real, T1.cpp:224-235; T1::getnorm clamps the level, :258-267) and of the inverse colour transform's
+// columns (mct_norms_rev / _irrev, point_transform/mct.cpp:30-35)
+static double band_norm(uint32_t orient, uint32_t level, bool reversible)
+{
+    static const double n53[4][10] = {{1.000, 1.500, 2.750, 5.375, 10.68, 21.34, 42.67, 85.33, 170.7, 341.3},
+                                      {1.038, 1.592, 2.919, 5.703, 11.33, 22.64, 45.25, 90.48, 180.9, 0},
+                                      {1.038, 1.592, 2.919, 5.703, 11.33, 22.64, 45.25, 90.48, 180.9, 0},
+                                      {.7186, .9218, 1.586, 3.043, 6.019, 12.01, 24.00, 47.97, 95.93, 0}};
+    static const double n97[4][10] = {{1.000, 1.965, 4.177, 8.403, 16.90, 33.84, 67.69, 135.3, 270.6, 540.9},
+                                      {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0, 0},
+                                      {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0, 0},
+                                      {2.080, 3.865, 8.307, 17.18, 34.71, 69.59, 139.3, 278.6, 557.2, 0}};
+    if (orient == 0 && level > 9) level = 9;
+    else if (orient > 0 && level > 8) level = 8;
+    return reversible ? n53[orient & 3u][level] : n97[orient & 3u][level];
+}
+
+int grk_amd_block_distortion(grk_amd_ctx* c, double* out, uint64_t cap)
+{
+    if (!c || !out || !c->have_geom || !c->last_nblocks || cap < c->last_nblocks) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    { const int jr = join_side(c); if (jr) return jr; }
+    const TileGeom& g = c->geom;
+    const uint64_t n = c->last_nblocks;
+    const uint32_t bpt = (uint32_t)c->h_desc.size();
+    HIP_TRY(c, c->energy.ensure(n * 8), "alloc block energies");
+    HIP_TRY(c, launch_block_energy(c->p1.p, c->last_h16 ? 1 : 0, g.p.irreversible, g.stride, g.plane_elems, (const HtBlockDesc*)c->blockdesc.p,
+                                   bpt, g.p.num_comps, n, (unsigned long long*)c->energy.p, c->stream), "launch block energy");
+    std::vector<unsigned long long> e(n);
+    HIP_TRY(c, hipMemcpyAsync(e.data(), c->energy.p, n * 8, hipMemcpyDeviceToHost, c->stream), "fetch block energies");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    static const double mct_rev[3] = {1.732, .8292, .8292}, mct_irrev[3] = {1.732, 1.805, 1.573};
+    for (uint64_t i = 0; i < n; ++i) {
+        const grk_amd_block& b = g.blocks_comp0[(i % bpt) % g.blocks_per_comp];
+        const uint32_t comp = (uint32_t)((i % bpt) / g.blocks_per_comp);
+        const double w1 = (g.p.mct && g.p.num_comps >= 3 && comp < 3) ? (g.p.irreversible ? mct_irrev[comp] : mct_rev[comp]) : 1.0;
+        const double w2 = band_norm(b.band, g.p.num_levels - b.res, !g.p.irreversible);
+        const double w = w1 * w2 * (double)b.stepsize;
+        out[i] = w * w * (double)e[i];
     }
     return GRK_AMD_OK;
 }

@@ -96,6 +96,9 @@ constexpr size_t   kHtAllocBytes = 256u * (1u + kHtAllocRegions);   // 32 status
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);          // allocator reset + every class
 hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s);
 hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hipStream_t s);   // classes [first, last)
+// sum of q^2 over each block of the planes an encode left (kernels_ingest.hip: the rate-control hook)
+hipError_t launch_block_energy(const void* mallat, int h16, int irreversible, uint32_t stride, uint64_t pitch, const HtBlockDesc* blocks,
+                               uint32_t blocks_per_tile, uint32_t ncomp, uint64_t nblocks, unsigned long long* out, hipStream_t s);
 uint32_t   dwt_strip_cols();      // output columns a K2 workgroup owns
 uint32_t   dwt_level_strip_cols(const DwtLevelArgs& a);   // ... for this level (the packed 5/3 kernel's strips are wider)
 uint32_t   idwt_strip_pairs();    // coefficient pairs a K6 workgroup owns

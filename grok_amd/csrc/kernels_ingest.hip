@@ -106,4 +106,47 @@ hipError_t launch_ingest(const IngestArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- per-block energy of the quantised coefficients: the rate-control hook ----------------------------------
+// One wave per code-block of the latest encode: sum over the block's samples of q^2, q the integer magnitude K3 codes -- |x| for the
+// reversible path, trunc(|c| * (1 / step)) for the irreversible one (the quantiser of kernels_ht.hip, T1HT.cpp:58-101 as intended)
+// -- exact in 64 bits (q < 2^26, 4096 samples).  The host turns it into grk_plugin_pass::distortionDecrease with the weights the
+// reference's Tier-1 uses for its own passes (T1::getwmsedec, t1/t1_part1/T1.cpp:394-414).
+template <class PLANE, bool IRREV>
+__global__ __launch_bounds__(64) void block_energy_kernel(const PLANE* mallat, uint32_t stride, uint64_t pitch, const HtBlockDesc* blocks,
+                                                          uint32_t blocks_per_tile, uint32_t ncomp, unsigned long long* out)
+{
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
+    const HtBlockDesc bd = blocks[i % blocks_per_tile];
+    const uint32_t tile = i / blocks_per_tile;
+    const PLANE* src = mallat + ((size_t)tile * ncomp + bd.comp) * pitch + (size_t)bd.py * stride + bd.px;
+    unsigned long long acc = 0;
+    const uint32_t lim = (1u << bd.kmax) - 1u;
+    for (uint32_t y = 0; y < bd.h; ++y)
+        for (uint32_t x = lane; x < bd.w; x += 64) {
+            uint32_t q;
+            if constexpr (IRREV) {
+                const float c = __int_as_float((int32_t)src[(size_t)y * stride + x]);
+                q = (uint32_t)__fmul_rn(fabsf(c), bd.inv_step);
+                q = q > lim ? lim : q;
+            } else {
+                const int32_t v = (int32_t)src[(size_t)y * stride + x];
+                q = (uint32_t)(v < 0 ? -v : v);
+            }
+            acc += (unsigned long long)q * q;
+        }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) out[i] = acc;
+}
+
+hipError_t launch_block_energy(const void* mallat, int h16, int irreversible, uint32_t stride, uint64_t pitch, const HtBlockDesc* blocks,
+                               uint32_t blocks_per_tile, uint32_t ncomp, uint64_t nblocks, unsigned long long* out, hipStream_t s)
+{
+    if (!nblocks) return hipSuccess;
+    const dim3 grid((uint32_t)nblocks), block(64);
+    if (h16) hipLaunchKernelGGL((block_energy_kernel<int16_t, false>), grid, block, 0, s, (const int16_t*)mallat, stride, pitch, blocks, blocks_per_tile, ncomp, out);
+    else if (irreversible) hipLaunchKernelGGL((block_energy_kernel<int32_t, true>), grid, block, 0, s, (const int32_t*)mallat, stride, pitch, blocks, blocks_per_tile, ncomp, out);
+    else hipLaunchKernelGGL((block_energy_kernel<int32_t, false>), grid, block, 0, s, (const int32_t*)mallat, stride, pitch, blocks, blocks_per_tile, ncomp, out);
+    return hipGetLastError();
+}
+
 } // namespace grk_amd

@@ -180,6 +180,7 @@ void patch_owner(TileOwner* o)
         cb.numPasses = 1;
         cb.passes[0].rate = len ? len - 1 : 0;          // host uses rate + 1 (plugin_bridge.cpp:230)
         cb.passes[0].length = len;
+        cb.passes[0].distortionDecrease = 0.0;          // (grk_amd_plugin_tile_fill_distortion: only when the host makes layers)
     }
 }
 
@@ -324,12 +325,23 @@ bool read_pnm(const char* path, HostPixels& planar, uint32_t& w, uint32_t& h, ui
 }
 
 // does the tile grid cell anchored at (tx0, ty0) cover the image area, which starts at (image_offset_x0, image_offset_y0)
-// (grk_compress -d, stored as grk_image x0 / y0 by the host's image readers)?
+// (grk_compress -d, stored as grk_image x0 / y0 by the host's image readers)?  With sub-sampled components (grk_compress -s dx,dy:
+// every component of a PNM alike) the area on the reference grid is (w - 1) dx + 1 wide (image_format/PNMFormat.cpp:388-392).
 bool single_tile(const gra_cparameters* cp, uint32_t w, uint32_t h)
 {
     const uint64_t ox = cp->image_offset_x0, oy = cp->image_offset_y0;
-    return !cp->tile_size_on || !(cp->tx0 > ox || cp->ty0 > oy || (uint64_t)cp->tx0 + cp->t_width < ox + w ||
-                                  (uint64_t)cp->ty0 + cp->t_height < oy + h);
+    const uint64_t gw = (uint64_t)(w - 1) * cp->subsampling_dx + 1, gh = (uint64_t)(h - 1) * cp->subsampling_dy + 1;
+    return !cp->tile_size_on || !(cp->tx0 > ox || cp->ty0 > oy || (uint64_t)cp->tx0 + cp->t_width < ox + gw ||
+                                  (uint64_t)cp->ty0 + cp->t_height < oy + gh);
+}
+
+// does the host make quality layers from the passes' rates and distortions (TileProcessor::needs_rate_control,
+// tile/TileProcessor.cpp:75-90; grk_compress -r / -q set cp_disto_alloc / cp_fixed_quality and one entry per layer)?
+bool wants_rate_control(const gra_cparameters* cp)
+{
+    for (uint32_t l = 0; l < std::min<uint32_t>(std::max<uint32_t>(cp->tcp_numlayers, 1u), 100u); ++l)
+        if ((cp->cp_disto_alloc && cp->tcp_rates[l] > 0.0) || (cp->cp_fixed_quality && cp->tcp_distoratio[l] > 0.0)) return true;
+    return cp->tcp_numlayers > 1;
 }
 
 // multi = false: the parameters of THE tile of a single-tile image (what the plugin protocol can carry, D3);
@@ -339,13 +351,25 @@ bool params_from_cparameters(const gra_cparameters* cp, uint32_t w, uint32_t h, 
 {
     if (!cp->isHT || !(cp->cblk_sty & GRA_CBLKSTY_HT)) return false;             // hot path = HTJ2K only
     if (!multi && !single_tile(cp, w, h)) return false;
-    if (cp->tcp_numlayers > 1 || cp->numpocs || cp->roi_compno >= 0) return false;
-    if (cp->subsampling_dx != 1 || cp->subsampling_dy != 1) return false;
+    if (cp->numpocs || cp->roi_compno >= 0) return false;
+    // Quality layers / rate targets: the HOST forms the layers (its Tier-2, from the rates and the distortion decreases the tile tree
+    // carries: gpu_step fills them); this library's own writer -- the route an image of several tiles takes -- writes one layer
+    if (multi && wants_rate_control(cp)) return false;
+    // Sub-sampled components, every component alike (all a PNM can carry): component c of the tile is [ceil(x0 / dx), ceil(x1 / dx))
+    // (tile/TileProcessor.cpp:605-612) -- w x h samples whose origin is ceil(offset / d); the sub-sampling itself is the host's SIZ.
+    // The several-tiles route writes SIZ itself, with XRsiz = YRsiz = 1: declined there
+    if (cp->subsampling_dx < 1 || cp->subsampling_dy < 1 || cp->subsampling_dx > 255 || cp->subsampling_dy > 255) return false;
+    if (multi && (cp->subsampling_dx != 1 || cp->subsampling_dy != 1)) return false;
+    // (an offset that is not a multiple of the factor: the component the host derives, ceil(x1 / dx) - ceil(x0 / dx), is a column
+    //  short of the file's -- the host's own business)
+    if (cp->image_offset_x0 % cp->subsampling_dx || cp->image_offset_y0 % cp->subsampling_dy) return false;
     if (cp->numresolution < 1 || cp->numresolution > GRK_AMD_MAX_LEVELS + 1) return false;
     auto lg = [](uint32_t v) { int e = 0; while ((1u << e) < v) ++e; return e; };
     std::memset(&p, 0, sizeof p);
     p.tile_w = w; p.tile_h = h; p.num_comps = (uint16_t)comps; p.prec = (uint8_t)prec; p.sgnd = 0;
-    p.tile_x0 = cp->image_offset_x0; p.tile_y0 = cp->image_offset_y0;       // the tile = the image area, wherever it lies
+    // the tile = the image area, wherever it lies; in the component's own coordinates
+    p.tile_x0 = (cp->image_offset_x0 + cp->subsampling_dx - 1) / cp->subsampling_dx;
+    p.tile_y0 = (cp->image_offset_y0 + cp->subsampling_dy - 1) / cp->subsampling_dy;
     p.irreversible = cp->irreversible ? 1 : 0;
     // tcp_mct as grk_compress leaves it: 255 = "not set" (the library then applies RCT/ICT to >= 3 components,
     // CodeStreamCompress.cpp:345-352), 0 / 1 as given, 2 = custom array MCT (mct_data) -- outside the hot path
@@ -398,6 +422,10 @@ bool gpu_step(gra_cparameters* cp, EncodeJob& j, Dev* dev = nullptr)
     std::lock_guard<std::mutex> lk(dev ? *dev->mu : g_mu);
     j.tile = grk_amd_plugin_tile_create(ctx, &j.p, j.px.data(), 0);
     if (!j.tile) return false;
+    if (wants_rate_control(cp) && grk_amd_plugin_tile_fill_distortion(ctx, j.tile) != GRK_AMD_OK) {
+        grk_amd_plugin_tile_destroy(j.tile); j.tile = nullptr;
+        return false;
+    }
     j.px.reset();                               // the pixels are on the device / coded: the host callback loads its own copy
     // self-check mode: the "image" the host gets holds our sub-band coefficients (it skips its own DC shift / MCT / DWT and
     // codes them with its own Tier-1).  The image object is made by the host library itself (grk_image_new, resolved from
@@ -410,10 +438,11 @@ bool gpu_step(gra_cparameters* cp, EncodeJob& j, Dev* dev = nullptr)
         auto fail = [&]() { grk_amd_plugin_tile_destroy(j.tile); j.tile = nullptr; return false; };
         if (!image_new || !j.unref) return fail();
         std::vector<gra_image_cmptparm> cps(j.comps);
-        for (auto& c : cps) { c.dx = 1; c.dy = 1; c.w = j.w; c.stride = 0; c.h = j.h; c.x0 = p.tile_x0; c.y0 = p.tile_y0; c.prec = (uint8_t)j.prec; c.sgnd = false; }
+        for (auto& c : cps) { c.dx = cp->subsampling_dx; c.dy = cp->subsampling_dy; c.w = j.w; c.stride = 0; c.h = j.h; c.x0 = p.tile_x0; c.y0 = p.tile_y0; c.prec = (uint8_t)j.prec; c.sgnd = false; }
         gra_image* img = image_new((uint16_t)j.comps, cps.data(), j.comps >= 3 ? 1 /* GRK_CLRSPC_SRGB */ : 2 /* GRK_CLRSPC_GRAY */, true);
         if (!img) return fail();
-        img->x0 = p.tile_x0; img->y0 = p.tile_y0; img->x1 = p.tile_x0 + j.w; img->y1 = p.tile_y0 + j.h;
+        img->x0 = cp->image_offset_x0; img->y0 = cp->image_offset_y0;
+        img->x1 = img->x0 + (j.w - 1) * cp->subsampling_dx + 1; img->y1 = img->y0 + (j.h - 1) * cp->subsampling_dy + 1;
         bool ok = true;
         for (uint32_t c = 0; c < j.comps && ok; ++c)
             ok = img->comps[c].data && grk_amd_fetch_coefficients(ctx, c, img->comps[c].data, img->comps[c].stride) == GRK_AMD_OK;
@@ -790,6 +819,17 @@ GRA_EXPORT gra_plugin_tile* grk_amd_plugin_tile_create(grk_amd_ctx* ctx, const g
     if (!ok) { release_owner(o); return nullptr; }
     patch_owner(o);
     return &o->tile;
+}
+
+GRA_EXPORT int grk_amd_plugin_tile_fill_distortion(grk_amd_ctx* ctx, gra_plugin_tile* tile)
+{
+    if (!ctx || !tile) return GRK_AMD_ERR_INVALID;
+    TileOwner* o = reinterpret_cast<TileOwner*>(tile);
+    std::vector<double> dd(o->blocks.size());
+    const int rc = grk_amd_block_distortion(ctx, dd.data(), dd.size());
+    if (rc) return rc;
+    for (size_t i = 0; i < dd.size(); ++i) o->blocks[i].passes[0].distortionDecrease = dd[i];
+    return GRK_AMD_OK;
 }
 
 GRA_EXPORT void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile)

@@ -286,6 +286,10 @@ void grk_amd_plugin_batch_decode_counts(int32_t* gpu, int32_t* cpu, int32_t* fai
 gra_plugin_tile* grk_amd_plugin_tile_create(grk_amd_ctx* ctx, const grk_amd_tile_params* p,
                                             const void* pixels, int pixels_on_device);
 void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile);
+/* The rate-control hook: passes[0].distortionDecrease of every block of a tree just made by ..._tile_create, from
+ * grk_amd_block_distortion (what compress_synch_with_plugin copies into the host's passes when the job has rate or quality targets,
+ * plugin/plugin_bridge.cpp:214-226).  plugin_encode calls it for jobs with several layers or -r / -q targets. */
+int grk_amd_plugin_tile_fill_distortion(grk_amd_ctx* ctx, gra_plugin_tile* tile);
 /* device contexts the batch mode spreads files over (plugin_init: the device Grok named + the node's other GPUs, or what the
  * environment variable GRK_AMD_PLUGIN_DEVICES lists, e.g. "0,0": two contexts on GPU 0) */
 uint32_t grk_amd_plugin_num_devices(void);

@@ -150,6 +150,13 @@ int grk_amd_set_pixel_hold(grk_amd_ctx* ctx, int on);
 /* Makes `hip_stream` wait until the LATEST grk_amd_encode_tiles call has read its device pixels (not for its results). */
 int grk_amd_stream_wait_pixels(grk_amd_ctx* ctx, void* hip_stream);
 int grk_amd_fetch_table(grk_amd_ctx* ctx, grk_amd_coded_block* table, uint64_t* total_bytes);
+/* The rate-control hook (the host reads grk_plugin_pass::distortionDecrease when it makes quality layers,
+ * plugin/plugin_bridge.cpp:214-226, tile/TileProcessor.cpp:320-458): for every code-block of the LATEST grk_amd_encode_tiles call,
+ * in table order, the distortion decrease of coding its single HT cleanup pass, in the units T1::getwmsedec gives the passes of the
+ * reference's own Tier-1 (t1/t1_part1/T1.cpp:394-414): (w_mct * w_band * stepsize)^2 * sum of q^2 over the block, q the quantised
+ * integer magnitude that was coded.  (The reference's own HT encoder leaves the field unset, T1HT.cpp:102-127: on its CPU path an
+ * HTJ2K job with several layers has no slopes to work with.)  Not for pipelined sequences: reads the planes of the latest call. */
+int grk_amd_block_distortion(grk_amd_ctx* ctx, double* distortion, uint64_t capacity);
 /* copy coded bytes [0,total) of the arena to host memory */
 int grk_amd_fetch_coded(grk_amd_ctx* ctx, uint8_t* dst, uint64_t nbytes);
 /* device pointers for zero-copy consumers (RCCL gather of tile parts, tests) */

@@ -388,6 +388,37 @@ void orc_ht_signmag_irrev(const float* src, uint32_t stride, uint32_t w, uint32_
         }
 }
 
+/* ------------------------------------------------------------------ N3 rate-control hook: distortion decrease of a block's pass */
+/* T1::getwmsedec (t1/t1_part1/T1.cpp:394-414) gives every pass of the reference's Part-1 coder (w1 w2 stepsize 2^bpno)^2 nmsedec / 8192,
+ * nmsedec a table of squared-error decreases in units of the bit-plane: summed over the passes of a block that is coded to the last
+ * plane that is (w1 w2 stepsize)^2 times the energy of the quantised magnitudes.  An HT block is one pass, so its whole decrease is
+ * that sum; w2 = T1::getnorm (T1.cpp:224-235, :258-267), w1 = mct::get_norms_* (point_transform/mct.cpp:30-41), level =
+ * numresolutions - 1 - resno (t1/t1_part1/T1Part1.cpp:97).  `sm` = the block's sign-magnitude words (orc_ht_signmag_*). */
+double orc_ht_block_distortion(const uint32_t* sm, uint32_t n, uint32_t kmax, uint32_t orient, uint32_t level, int reversible,
+                               int mct, uint32_t comp, double stepsize)
+{
+    static const double n53[4][10] = {{1.000, 1.500, 2.750, 5.375, 10.68, 21.34, 42.67, 85.33, 170.7, 341.3},
+                                      {1.038, 1.592, 2.919, 5.703, 11.33, 22.64, 45.25, 90.48, 180.9, 0},
+                                      {1.038, 1.592, 2.919, 5.703, 11.33, 22.64, 45.25, 90.48, 180.9, 0},
+                                      {.7186, .9218, 1.586, 3.043, 6.019, 12.01, 24.00, 47.97, 95.93, 0}};
+    static const double n97[4][10] = {{1.000, 1.965, 4.177, 8.403, 16.90, 33.84, 67.69, 135.3, 270.6, 540.9},
+                                      {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0, 0},
+                                      {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0, 0},
+                                      {2.080, 3.865, 8.307, 17.18, 34.71, 69.59, 139.3, 278.6, 557.2, 0}};
+    static const double mrev[3] = {1.732, .8292, .8292}, mirr[3] = {1.732, 1.805, 1.573};
+    uint64_t e = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t q = (sm[i] & 0x7FFFFFFFu) >> (30 - kmax);
+        e += q * q;
+    }
+    if (orient == 0 && level > 9) level = 9;
+    else if (orient > 0 && level > 8) level = 8;
+    double w1 = (mct && comp < 3) ? (reversible ? mrev[comp] : mirr[comp]) : 1.0;
+    double w2 = reversible ? n53[orient & 3][level] : n97[orient & 3][level];
+    double w = w1 * w2 * stepsize;
+    return w * w * (double)e;
+}
+
 /* ------------------------------------------------------------------ a11 HT cleanup encoder */
 /* Optional taps that record the RAW (un-stuffed) MagSgn / VLC bit streams and the MEL state just
  * before termination; used by ht_wave_model.c to validate the wave-parallel phase-B formulation. */

@@ -67,6 +67,9 @@ int32_t  orc_ht_encode_block_rev(const int32_t* src, uint32_t stride, uint32_t w
 /* irreversible ("intended" dead-zone quantiser of SURVEY.md A.5, NOT the reference's D1 bug) */
 void     orc_ht_signmag_irrev(const float* src, uint32_t stride, uint32_t w, uint32_t h,
                               uint32_t kmax, float inv_delta, uint32_t* dst);
+/* N3: distortion decrease of an HT block's single pass in T1::getwmsedec's units (t1/t1_part1/T1.cpp:394-414) */
+double   orc_ht_block_distortion(const uint32_t* sm, uint32_t n, uint32_t kmax, uint32_t orient, uint32_t level, int reversible,
+                                 int mct, uint32_t comp, double stepsize);
 
 /* ---- whole tile, reversible: pixels (C planes, tight) -> per-block coded bytes.
  * blocks_out[i] describes block i (enumeration order comp -> res -> band -> raster), lens[i] its

@@ -213,6 +213,23 @@ static void fill_params(grk_cparameters& p, const EncCfg& c)
 		}
 		if (n) { p.res_spec = n; p.csty |= 0x01; }
 	}
+	// grk_compress -r r1,r2,...: quality layers by compression ratio, largest first; a last ratio of 1 = everything that is left
+	// (grk_compress.cpp: "-r 20,10,1"; cp_disto_alloc, tcp_rates[], tcp_numlayers -- the last layer's rate 0 = lossless)
+	if (const char* e = getenv("REF_LAYERS")) {
+		uint32_t n = 0; const char* q = e;
+		while (*q && n < 100) {
+			double r = 0; int used = 0;
+			if (sscanf(q, "%lf%n", &r, &used) != 1) break;
+			p.tcp_rates[n++] = r <= 1.0 ? 0.0 : r;
+			q += used; if (*q == ',') ++q;
+		}
+		if (n) { p.tcp_numlayers = (uint16_t)n; p.cp_disto_alloc = true; }
+	}
+	// grk_compress -s dx,dy: the sub-sampling factors of the components on the reference grid (all components alike)
+	if (const char* e = getenv("REF_SUBSAMPLING")) {
+		unsigned dx = 1, dy = 1;
+		if (sscanf(e, "%u,%u", &dx, &dy) == 2 && dx >= 1 && dy >= 1) { p.subsampling_dx = dx; p.subsampling_dy = dy; }
+	}
 	// grk_compress -d: the image area's origin on the canonical grid (the tile grid stays anchored at 0, 0)
 	if (const char* e = getenv("REF_IMG_X0")) p.image_offset_x0 = (uint32_t)atoi(e);
 	if (const char* e = getenv("REF_IMG_Y0")) p.image_offset_y0 = (uint32_t)atoi(e);
@@ -224,13 +241,17 @@ static grk_image* make_image(const EncCfg& c, bool alloc)
 	memset(cp.data(), 0, sizeof(grk_image_cmptparm) * cp.size());
 	const uint32_t ix0 = getenv("REF_IMG_X0") ? (uint32_t)atoi(getenv("REF_IMG_X0")) : 0;
 	const uint32_t iy0 = getenv("REF_IMG_Y0") ? (uint32_t)atoi(getenv("REF_IMG_Y0")) : 0;
+	// (sub-sampled components, grk_compress -s: the image area on the reference grid is what the image readers make of a w x h
+	//  component, x1 = x0 + (w - 1) dx + 1, src/bin/image_format: every component then has ceil(x1 / dx) - ceil(x0 / dx) = w columns)
+	unsigned sdx = 1, sdy = 1;
+	if (const char* e = getenv("REF_SUBSAMPLING")) { if (sscanf(e, "%u,%u", &sdx, &sdy) != 2 || !sdx || !sdy) sdx = sdy = 1; }
 	for (auto& q : cp) {
-		q.dx = 1; q.dy = 1; q.w = (uint32_t)c.W; q.h = (uint32_t)c.H;
+		q.dx = sdx; q.dy = sdy; q.w = (uint32_t)c.W; q.h = (uint32_t)c.H;
 		q.x0 = ix0; q.y0 = iy0; q.prec = (uint8_t)c.prec; q.sgnd = false;
 	}
 	auto img = grk_image_new((uint16_t)c.C, cp.data(), c.C >= 3 ? GRK_CLRSPC_SRGB : GRK_CLRSPC_GRAY, alloc);
 	if (!img) return nullptr;
-	img->x0 = ix0; img->y0 = iy0; img->x1 = ix0 + (uint32_t)c.W; img->y1 = iy0 + (uint32_t)c.H;
+	img->x0 = ix0; img->y0 = iy0; img->x1 = ix0 + ((uint32_t)c.W - 1) * sdx + 1; img->y1 = iy0 + ((uint32_t)c.H - 1) * sdy + 1;
 	return img;
 }
 
@@ -310,6 +331,7 @@ int32_t ref_decode(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, in
 {
 	grk_dparameters dp;
 	grk_decompress_set_default_params(&dp);
+	if (const char* e = getenv("REF_MAX_LAYERS")) dp.cp_layer = (uint16_t)atoi(e);      // grk_decompress -l: the first quality layers only
 	grk_stream* stream = grk_stream_create_mem_stream((uint8_t*)j2k, len, false, true);
 	grk_codec* codec = grk_decompress_create(GRK_CODEC_J2K, stream);
 	int32_t rc = -1;

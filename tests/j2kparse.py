@@ -268,3 +268,16 @@ def segment_list(info, layout_blocks):
         counters[key3] = idx + 1
         out.append([sg for sg in info["segments"].get((b.comp, b.res, b.band, idx), []) if sg[1]])
     return out
+
+
+def parse_cod_layers(cs):
+    """Number of quality layers the main header's COD marker segment declares (A.6.1: SGcod = progression order, layers (2 bytes), MCT)."""
+    i = 2
+    while i + 4 <= len(cs):
+        m, n = struct.unpack(">HH", cs[i:i + 4])
+        if m == 0xFF52:
+            return struct.unpack(">H", cs[i + 6:i + 8])[0]
+        if m == 0xFF90 or m == 0xFF93:
+            break
+        i += 2 + n
+    raise ValueError("no COD marker segment in the main header")

@@ -51,6 +51,9 @@ def lib():
         L.orc_ht_signmag_rev.restype = None
         L.orc_ht_signmag_irrev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
         L.orc_ht_signmag_irrev.restype = None
+        L.orc_ht_block_distortion.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32,
+                                              C.c_double]
+        L.orc_ht_block_distortion.restype = C.c_double
         L.orc_ht_decode_block.restype = C.c_int32
         L.orc_ht_decode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_ht_dequant_rev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -207,6 +210,11 @@ def color_inv_store(planes, prec, irrev, mct, sgnd=False):
 def signmag(coeffs, kmax):
     c = np.asarray(coeffs, np.int64)
     return (np.where(c < 0, 0x80000000, 0) | (np.abs(c) << (30 - kmax))).astype(np.uint32)
+
+
+def ht_block_distortion(sm, kmax, orient, level, reversible, mct, comp, stepsize):
+    sm = np.ascontiguousarray(sm, np.uint32)
+    return float(lib().orc_ht_block_distortion(sm.ctypes.data, sm.size, kmax, orient, level, int(reversible), int(mct), comp, float(stepsize)))
 
 
 def ht_encode_sm(sm, kmax):

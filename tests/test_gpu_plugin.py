@@ -61,6 +61,97 @@ def test_file_protocol_through_grok_loader(tmp_path):
     assert isinstance(R.plugin_compress_file(synth.g2(1, 64, 64, 8), 8, "/nonexistent.pgm", numres=3), int)
 
 
+@pytest.mark.parametrize("Cn,H,W,prec,L,irrev", [(3, 192, 256, 8, 4, False), (1, 130, 97, 8, 3, False), (3, 128, 160, 12, 3, True),
+                                                  (3, 256, 256, 16, 5, True)])
+def test_block_distortion_equals_the_oracles(Cn, H, W, prec, L, irrev):
+    """The rate-control hook: grk_amd_block_distortion of an encode == the oracle's restatement of T1::getwmsedec's
+    weights times the energy of the quantised magnitudes of the oracle's own coefficients -- the same double, bit for bit (the energy
+    is an integer sum; the weights are the reference's tables)."""
+    import oracle as O
+    import chain
+    px = synth.g2(Cn, H, W, prec)
+    p = G.TileParams.make(W, H, Cn, prec, L, irreversible=irrev)
+    c = U.ctx()
+    table, coded = c.encode_host(p, px)
+    got = c.block_distortion(len(table))
+    blocks, _ = G.tile_layout(p)
+    planes = [px[k].astype(np.int32) - (1 << (prec - 1)) for k in range(Cn)]
+    mct = Cn >= 3
+    if irrev:
+        if mct:
+            planes[:3] = [v.view(np.float32) for v in O.ict_fwd(*planes[:3])]
+        else:
+            planes = [v.astype(np.float32) for v in planes]
+        mall = [O.dwt97_fwd(v, L) for v in planes]
+    else:
+        if mct:
+            planes[:3] = O.rct_fwd(*planes[:3])
+        mall = [O.dwt53_fwd(v, L) for v in planes]
+    OL = O.lib()
+    for i, b in enumerate(blocks):
+        bw, bh = b.x1 - b.x0, b.y1 - b.y0
+        sub = np.ascontiguousarray(mall[b.comp][b.py:b.py + bh, b.px:b.px + bw])
+        if irrev:
+            sm = np.zeros((bh, bw), np.uint32)
+            OL.orc_ht_signmag_irrev(sub.ctypes.data, bw, bw, bh, b.kmax, C.c_float(np.float32(1.0) / np.float32(b.stepsize)), sm.ctypes.data)
+        else:
+            sm = O.signmag(sub, b.kmax)
+        want = O.ht_block_distortion(sm, b.kmax, b.band, L - b.res, not irrev, mct, b.comp, b.stepsize)
+        assert got[i] == want, (i, b.comp, b.res, b.band, got[i], want)
+    assert got.max() > 0
+
+
+@needs_ref
+def test_layered_job_through_grok_loader(tmp_path, monkeypatch):
+    """grk_compress -r 20,10,1 on an HTJ2K job through the plugin: the tile tree carries a distortion decrease per block
+    (grk_amd_plugin_tile_fill_distortion), the HOST's rate control makes three quality layers of the blocks' single passes
+    (TileProcessor::pcrd_bisect_feasible over the plugin's rates and slopes) and writes the file.  What can be said about it without
+    a reference to compare with -- the reference's own CPU path leaves an HT block's distortion unset (T1HT.cpp:102-127), so its
+    layers are arbitrary -- : all layers together decode to the source exactly; the first layer alone holds the blocks with the
+    steepest slopes, i.e. it decodes to a far better picture than the CPU path's first layer, within the size the ratio allows."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    Cn, H, W, prec = 3, 384, 512, 8
+    px = synth.g2(Cn, H, W, prec)
+    path = str(tmp_path / "in.ppm")
+    R.write_pnm(path, px, prec)
+    monkeypatch.setenv("REF_LAYERS", "20,10,1")
+    got = R.plugin_compress_file(px, prec, path, numres=6)
+    assert not isinstance(got, int), "plugin refused: %s" % got
+    cpu, _ = R.encode(px, prec, numres=6, mode=1, rate_algo=1)
+    import j2kparse as J
+    assert J.parse_cod_layers(got) == 3 and J.parse_cod_layers(cpu) == 3
+    assert np.array_equal(R.decode(got, Cn, H, W), px.astype(np.int32))            # every layer: lossless
+    monkeypatch.setenv("REF_MAX_LAYERS", "1")
+    first, first_cpu = R.decode(got, Cn, H, W), R.decode(cpu, Cn, H, W)
+    monkeypatch.delenv("REF_MAX_LAYERS")
+    p_gpu, p_cpu = synth.psnr_db(first, px, prec), synth.psnr_db(first_cpu, px, prec)
+    assert p_gpu > p_cpu + 3.0 and p_gpu > 20.0, (p_gpu, p_cpu)
+
+
+@needs_ref
+@pytest.mark.parametrize("sub,off", [((2, 2), (0, 0)), ((2, 1), (0, 0)), ((1, 2), (4, 6)), ((3, 2), (6, 4))])
+def test_subsampled_components_through_grok_loader(tmp_path, monkeypatch, sub, off):
+    """grk_compress -s dx,dy (every component of a PNM sub-sampled alike on the reference grid): the plugin codes the w x h
+    components as it does any tile -- their origin is ceil(offset / d) -- and the host writes SIZ with XRsiz / YRsiz; the file ==
+    the pure-CPU encode of the same job."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    monkeypatch.setenv("REF_SUBSAMPLING", "%d,%d" % sub)
+    monkeypatch.setenv("REF_IMG_X0", str(off[0]))
+    monkeypatch.setenv("REF_IMG_Y0", str(off[1]))
+    for Cn, H, W, prec in ((3, 191, 255, 8), (1, 80, 300, 12)):
+        px = synth.g2(Cn, H, W, prec)
+        path = str(tmp_path / ("in_%d.%s" % (Cn, "pgm" if Cn == 1 else "ppm")))
+        R.write_pnm(path, px, prec)
+        TW, TH = off[0] + (W - 1) * sub[0] + 1, off[1] + (H - 1) * sub[1] + 1           # one tile: the whole reference grid
+        got = R.plugin_compress_file(px, prec, path, numres=5, TW=TW, TH=TH)
+        assert not isinstance(got, int), "plugin refused: %s" % got
+        cpu, _ = R.encode(px, prec, TW=TW, TH=TH, numres=5, mode=1)
+        assert got == cpu
+        assert np.array_equal(R.decode(cpu, Cn, H, W), px.astype(np.int32))
+
+
 @needs_ref
 @pytest.mark.parametrize("Cn,H,W,prec,numres,ht,sty,irrev", [(3, 192, 256, 8, 5, 1, 0, 0), (1, 128, 128, 8, 4, 1, 0, 0), (3, 100, 77, 12, 3, 1, 0, 0),
                                                               (3, 128, 192, 8, 4, 0, 0, 0), (1, 96, 160, 10, 3, 0, 0x02 | 0x08 | 0x20, 0),
