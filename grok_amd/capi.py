@@ -366,6 +366,23 @@ class Context:
             raise RuntimeError("encode_image failed: %d (%s)" % (n, self._L.grk_amd_last_error(self._h).decode()))
         return out[:n].tobytes()
 
+    def encode_image_subsampled(self, layout, base, sampling, planes, flags=0):
+        """Image with sub-sampled components -> codestream bytes (grk_amd_encode_image_subsampled).  sampling: [(dx, dy)] per
+        component; planes: one 2-D array per component, component c of ceil(x1 / dx) - ceil(x0 / dx) columns."""
+        dx = (C.c_uint8 * len(sampling))(*[int(a) for a, _ in sampling])
+        dy = (C.c_uint8 * len(sampling))(*[int(b) for _, b in sampling])
+        px = np.concatenate([np.ascontiguousarray(pl).reshape(-1) for pl in planes])
+        cap = px.size * px.itemsize * 4 + (1 << 20)
+        out = np.empty(cap, np.uint8)
+        self._L.grk_amd_encode_image_subsampled.restype = C.c_int64
+        self._L.grk_amd_encode_image_subsampled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                            C.c_uint32, C.c_void_p, C.c_uint64]
+        n = self._L.grk_amd_encode_image_subsampled(self._h, C.addressof(layout), C.addressof(base), C.addressof(dx), C.addressof(dy),
+                                                    px.ctypes.data, flags, out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("encode_image_subsampled failed: %d (%s)" % (n, self._L.grk_amd_last_error(self._h).decode()))
+        return out[:n].tobytes()
+
     def fetch_table(self, nblocks):
         table = np.zeros(nblocks, CODED_DTYPE)
         tot = C.c_uint64(0)

@@ -536,13 +536,15 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         a.h16 = h16 ? 1 : 0;
         a.pk = h16 && c->dwt_pk && pk16_level_ok(g.p, l);
         a.xcd = c->dwt_xcd;
-        // enough workgroups to cover the chip several times, few enough to amortise warm-up rows
+        // enough workgroups to cover the chip several times, few enough to amortise warm-up rows (profiles/r06_dwt_reads.txt: at 4096
+        // the 8K level 0 ran 16-row segments and read 1.55 x its pixels; 2048 -> 32-row segments, 1.35 x, the DWT 1 % faster)
         const uint32_t sh = (a.ch + a.py + 1) >> 1;           // row pairs on the coordinate grid
         uint32_t seg = 64;
         const uint64_t strips = (a.cw + a.px + dwt_level_strip_cols(a) - 1) / dwt_level_strip_cols(a);
         // workgroups along z: planes, or for the fused level 0 tiles (x components when there is no MCT triple)
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
-        while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < 4096) seg >>= 1;
+        static const uint32_t kMinWgs = getenv("GRK_AMD_DWT_MIN_WGS") ? (uint32_t)std::max(1, atoi(getenv("GRK_AMD_DWT_MIN_WGS"))) : 2048u;
+        while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < kMinWgs) seg >>= 1;
         a.seg_pairs = seg;
         if (a.cw == 0 || a.ch == 0) {
             // a level without samples (a narrow tile off the origin: [ceil(x0 / 2^l), ceil((x0 + w) / 2^l)) can be empty):

@@ -81,3 +81,93 @@ extern "C" int64_t grk_amd_encode_image(grk_amd_ctx* ctx, const grk_amd_image_la
     for (uint32_t t = 0; t < ntiles; ++t) all.insert(all.end(), rows[t].begin(), rows[t].end());
     return grk_amd_write_codestream_layout(im, base, all.data(), coded.data(), flags, out, cap);
 }
+
+// ---- sub-sampled components (4:2:2, 4:2:0, ...) ---------------------------------------------------------------------------
+// Components of different size are tile-components of different geometry: a RUN of consecutive components with the same factors
+// is coded as one unit -- the tile's rectangle in their coordinates, `n` components, the multiple component transform only for a
+// run that holds components 0..2 --, the units of all tiles are grouped by geometry, every group is one grk_amd_encode_tiles batch,
+// and the codestream writer takes each component with its own geometry (grk_amd_write_codestream_subsampled).
+extern "C" int64_t grk_amd_encode_image_subsampled(grk_amd_ctx* ctx, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                                   const uint8_t* comp_dx, const uint8_t* comp_dy, const void* pixels, uint32_t flags,
+                                                   uint8_t* out, uint64_t cap)
+{
+    if (!ctx || !im || !base || !pixels || !out || !comp_dx || !comp_dy) return GRK_AMD_ERR_INVALID;
+    const int64_t nt = grk_amd_layout_num_tiles(im);
+    if (nt < 0) return nt;
+    const uint32_t ntiles = (uint32_t)nt, nc = base->num_comps;
+    const uint32_t bps = (base->prec + 7u) / 8u;
+    for (uint32_t c = 0; c < nc; ++c) if (!comp_dx[c] || !comp_dy[c]) return GRK_AMD_ERR_INVALID;
+    struct Run { uint32_t c0, n; };
+    std::vector<Run> runs;
+    for (uint32_t c = 0; c < nc; ++c) {
+        if (!runs.empty() && comp_dx[c] == comp_dx[runs.back().c0] && comp_dy[c] == comp_dy[runs.back().c0]) runs.back().n++;
+        else runs.push_back(Run{c, 1});
+    }
+    // (MCT over components of different size: switched off, as the reference does with a warning, CodeStreamCompress.cpp:434-447)
+    const bool mct = base->mct && nc >= 3 && runs[0].n >= 3;
+    // the image's components in `pixels`: component c is ceil(x1 / dx) - ceil(x0 / dx) columns wide, planes back to back
+    auto cdiv = [](uint64_t a, uint64_t b) { return (a + b - 1) / b; };
+    std::vector<uint64_t> cw(nc), ch(nc), cx0(nc), cy0(nc), plane_at(nc + 1, 0);
+    for (uint32_t c = 0; c < nc; ++c) {
+        cx0[c] = cdiv(im->x0, comp_dx[c]); cy0[c] = cdiv(im->y0, comp_dy[c]);
+        cw[c] = cdiv(im->x1, comp_dx[c]) - cx0[c]; ch[c] = cdiv(im->y1, comp_dy[c]) - cy0[c];
+        plane_at[c + 1] = plane_at[c] + cw[c] * ch[c] * bps;
+    }
+    struct Unit { uint32_t tile, run; grk_amd_tile_params p; size_t group; };
+    std::vector<Unit> units;
+    std::vector<TileGeom> geoms;
+    std::vector<grk_amd_tile_params> gparams;
+    std::vector<std::vector<size_t>> groups;
+    for (uint32_t t = 0; t < ntiles; ++t)
+        for (uint32_t k = 0; k < runs.size(); ++k) {
+            Unit u{t, k, {}, 0};
+            int rc = grk_amd_layout_tile_comp(im, base, comp_dx[runs[k].c0], comp_dy[runs[k].c0], t, &u.p);
+            if (rc) return rc;
+            u.p.num_comps = (uint16_t)runs[k].n;
+            u.p.mct = (mct && k == 0) ? 1 : 0;
+            TileGeom g;
+            rc = build_tile_geom(u.p, g);
+            if (rc) return rc;
+            size_t gi = 0;
+            for (; gi < geoms.size(); ++gi)
+                if (gparams[gi].num_comps == u.p.num_comps && gparams[gi].mct == u.p.mct && same_geometry(geoms[gi], g)) break;
+            if (gi == geoms.size()) { geoms.push_back(std::move(g)); gparams.push_back(u.p); groups.emplace_back(); }
+            u.group = gi;
+            groups[gi].push_back(units.size());
+            units.push_back(u);
+        }
+    std::vector<std::vector<grk_amd_coded_block>> rows(units.size());
+    std::vector<uint8_t> coded, staging;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const auto& G = groups[gi];
+        const grk_amd_tile_params& p = units[G[0]].p;
+        const size_t unit_bytes = (size_t)p.tile_w * p.tile_h * p.num_comps * bps;
+        staging.resize(unit_bytes * G.size());
+        for (size_t i = 0; i < G.size(); ++i) {
+            const Unit& u = units[G[i]];
+            for (uint32_t k = 0; k < u.p.num_comps; ++k) {
+                const uint32_t c = runs[u.run].c0 + k;
+                const size_t ox = u.p.tile_x0 - cx0[c], oy = u.p.tile_y0 - cy0[c];
+                for (uint32_t y = 0; y < u.p.tile_h; ++y)
+                    std::memcpy(&staging[i * unit_bytes + ((size_t)k * u.p.tile_h + y) * u.p.tile_w * bps],
+                                (const uint8_t*)pixels + plane_at[c] + ((oy + y) * cw[c] + ox) * bps, (size_t)u.p.tile_w * bps);
+            }
+        }
+        const uint64_t bpu = (uint64_t)geoms[gi].blocks_per_comp * p.num_comps;
+        std::vector<grk_amd_coded_block> table(bpu * G.size());
+        uint64_t total = 0;
+        int rc = grk_amd_encode_tiles(ctx, &p, (uint32_t)G.size(), staging.data(), 0, table.data(), &total);
+        if (rc) return rc;
+        const size_t at = coded.size();
+        coded.resize(at + total);
+        rc = grk_amd_fetch_coded(ctx, coded.data() + at, total);
+        if (rc) return rc;
+        for (size_t i = 0; i < G.size(); ++i) {
+            rows[G[i]].assign(table.begin() + i * bpu, table.begin() + (i + 1) * bpu);
+            for (auto& r : rows[G[i]]) r.offset += at;
+        }
+    }
+    std::vector<grk_amd_coded_block> all;                       // tile-major, within a tile component-major (the runs in order)
+    for (size_t i = 0; i < units.size(); ++i) all.insert(all.end(), rows[i].begin(), rows[i].end());
+    return grk_amd_write_codestream_subsampled(im, base, comp_dx, comp_dy, all.data(), coded.data(), flags, out, cap);
+}

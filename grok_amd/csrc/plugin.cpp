@@ -62,6 +62,7 @@ struct TileOwner {
     std::vector<grk_amd_coded_block> table;
     std::vector<float> band_steps;                   // the bands' step sizes as make_owner set them (a decode lets the host overwrite them)
     bool served_decode = false;                      // the coded buffer was sized for a decode (every block's worst case + the file)
+    bool no_cache = false;                           // per-component geometry (sub-sampled components): not the tree its parameters name
     uint8_t* coded = nullptr; size_t coded_cap = 0; bool coded_pinned = false;
     ~TileOwner() { free_coded(); }
     void free_coded()
@@ -90,29 +91,49 @@ constexpr size_t kTileCacheMax = 8;
 constexpr size_t kTileCacheBytes = 512u << 20;   // pinned coded buffers the kept trees may hold together
 
 // the geometry-dependent part of the tree: everything but compressedData / compressedDataLength / passes[0] of the blocks
-TileOwner* make_owner(const grk_amd_tile_params& p)
+// comp_params: sub-sampled components -- the rectangle of every component of the tile (grk_amd_layout_tile_comp, num_comps = 1), each
+// with its own block layout and precinct counts; nullptr: every component has p's
+TileOwner* make_owner(const grk_amd_tile_params& p, const std::vector<grk_amd_tile_params>* comp_params = nullptr)
 {
-    const int64_t nbl = grk_amd_tile_num_blocks(&p);
-    if (nbl <= 0) return nullptr;
-    std::vector<grk_amd_block> layout((size_t)nbl);
-    if (grk_amd_tile_layout(&p, layout.data(), (uint64_t)nbl, nullptr) != nbl) return nullptr;
+    std::vector<grk_amd_block> layout;
+    const uint32_t nres = p.num_levels + 1u;
+    std::vector<std::vector<uint32_t>> nprec_c(p.num_comps, std::vector<uint32_t>((size_t)nres, 1u));
+    if (!comp_params) {
+        const int64_t nbl = grk_amd_tile_num_blocks(&p);
+        if (nbl <= 0) return nullptr;
+        layout.resize((size_t)nbl);
+        if (grk_amd_tile_layout(&p, layout.data(), (uint64_t)nbl, nullptr) != nbl) return nullptr;
+        for (auto& v : nprec_c) (void)grk_amd_tile_precincts(&p, v.data());
+    } else {
+        if (comp_params->size() != p.num_comps) return nullptr;
+        for (uint32_t c = 0; c < p.num_comps; ++c) {
+            const grk_amd_tile_params& pc = (*comp_params)[c];
+            const int64_t nbl = grk_amd_tile_num_blocks(&pc);
+            if (nbl <= 0) return nullptr;
+            const size_t at = layout.size();
+            layout.resize(at + (size_t)nbl);
+            if (grk_amd_tile_layout(&pc, layout.data() + at, (uint64_t)nbl, nullptr) != nbl) return nullptr;
+            for (size_t i = at; i < layout.size(); ++i) layout[i].comp = (uint16_t)c;
+            (void)grk_amd_tile_precincts(&pc, nprec_c[c].data());
+        }
+    }
     auto* o = new TileOwner();
     o->params = p;
     const size_t nb = layout.size();
     o->table.resize(nb);
-    const uint32_t nres = p.num_levels + 1u;
     const size_t nbands_c = 3 * p.num_levels + 1;
     o->comps.resize(p.num_comps); o->comp_ptr.resize(p.num_comps);
     o->ress.resize((size_t)p.num_comps * nres); o->res_ptr.resize(o->ress.size());
     o->bands.resize((size_t)p.num_comps * nbands_c); o->band_ptr.resize(o->bands.size());
     // precincts per band of every resolution (the same for its three bands)
-    std::vector<uint32_t> nprec((size_t)nres, 1u);
-    (void)grk_amd_tile_precincts(&p, nprec.data());
-    for (auto& n : nprec) n = std::max(n, 1u);          // (a resolution without samples: the host's tree has none either,
-                                                        //  one empty entry keeps the arrays well-formed)
     size_t total_prec = 0;
-    for (uint32_t r = 0; r < nres; ++r) total_prec += (size_t)nprec[r] * (r ? 3 : 1);
-    o->precs.resize(total_prec * p.num_comps); o->prec_ptr.resize(o->precs.size());
+    for (auto& v : nprec_c)
+        for (uint32_t r = 0; r < nres; ++r) {
+            v[r] = std::max(v[r], 1u);                  // (a resolution without samples: the host's tree has none either,
+                                                        //  one empty entry keeps the arrays well-formed)
+            total_prec += (size_t)v[r] * (r ? 3 : 1);
+        }
+    o->precs.resize(total_prec); o->prec_ptr.resize(o->precs.size());
     o->blocks.resize(nb); o->block_ptr.resize(nb);     // (value-initialised: zeros)
     for (size_t i = 0; i < nb; ++i) {
         const grk_amd_block& b = layout[i];
@@ -126,6 +147,7 @@ TileOwner* make_owner(const grk_amd_tile_params& p)
     }
     size_t bi = 0, blk = 0, pk = 0;
     for (uint32_t c = 0; c < p.num_comps; ++c) {
+        const std::vector<uint32_t>& nprec = nprec_c[c];
         gra_plugin_tile_component& tc = o->comps[c];
         tc.numResolutions = nres;
         tc.resolutions = &o->res_ptr[(size_t)c * nres];
@@ -201,6 +223,7 @@ TileOwner* acquire_owner(const grk_amd_tile_params& p)
 void release_owner(TileOwner* o)
 {
     if (!o) return;
+    if (o->no_cache) { delete o; return; }
     // a decode's buffer (16 KB per block + the file: ~0.8 GB pinned for an 8K frame) does not stay with the kept tree; an encode's
     // (the coded bytes of a frame) does, within a budget over the whole cache
     if (o->served_decode || o->coded_cap > kTileCacheBytes) { o->free_coded(); o->served_decode = false; }
@@ -818,6 +841,65 @@ GRA_EXPORT gra_plugin_tile* grk_amd_plugin_tile_create(grk_amd_ctx* ctx, const g
     ok = ok && (!total || grk_amd_fetch_coded(ctx, o->coded, total) == GRK_AMD_OK);      // (pinned: one DMA)
     if (!ok) { release_owner(o); return nullptr; }
     patch_owner(o);
+    return &o->tile;
+}
+
+// The library-level drop-in for an image whose components are sub-sampled each in its own way (4:2:0 ...): `p` = the tile on the
+// REFERENCE grid (tile_x0 / tile_y0 / tile_w / tile_h), component c = [ceil(x0 / dx_c), ceil(x1 / dx_c)) x ... of its own samples
+// (tile/TileProcessor.cpp:605-612), `planes` = the components back to back, each tight at its own size.  Runs of consecutive
+// components with equal factors are coded together (MCT only for a run that holds components 0..2, else off as the reference has it:
+// CodeStreamCompress.cpp:434-447); the tree carries every component's own resolutions / precincts / blocks.
+GRA_EXPORT gra_plugin_tile* grk_amd_plugin_tile_create_subsampled(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const uint8_t* comp_dx,
+                                                                 const uint8_t* comp_dy, const void* planes)
+{
+    if (!ctx || !p || !comp_dx || !comp_dy || !planes || p->num_comps == 0) return nullptr;
+    const uint32_t nc = p->num_comps, bps = (p->prec + 7u) / 8u;
+    const grk_amd_image_layout im{p->tile_x0, p->tile_y0, p->tile_x0 + p->tile_w, p->tile_y0 + p->tile_h, p->tile_x0, p->tile_y0, p->tile_w, p->tile_h};
+    std::vector<grk_amd_tile_params> cps(nc);
+    std::vector<size_t> plane_at(nc + 1, 0);
+    for (uint32_t c = 0; c < nc; ++c) {
+        if (grk_amd_layout_tile_comp(&im, p, comp_dx[c], comp_dy[c], 0, &cps[c]) != GRK_AMD_OK) return nullptr;
+        cps[c].num_comps = 1; cps[c].mct = 0;
+        plane_at[c + 1] = plane_at[c] + (size_t)cps[c].tile_w * cps[c].tile_h * bps;
+    }
+    TileOwner* o = make_owner(*p, &cps);           // (not cached: the cache is keyed by the tile's parameters alone)
+    if (!o) return nullptr;
+    bool ok = true;
+    size_t row = 0;
+    uint64_t used = 0;
+    const bool mct = p->mct && nc >= 3 && comp_dx[0] == comp_dx[1] && comp_dx[1] == comp_dx[2] && comp_dy[0] == comp_dy[1] && comp_dy[1] == comp_dy[2];
+    for (uint32_t c0 = 0; ok && c0 < nc;) {
+        uint32_t n = 1;
+        while (c0 + n < nc && comp_dx[c0 + n] == comp_dx[c0] && comp_dy[c0 + n] == comp_dy[c0]) ++n;
+        grk_amd_tile_params pr = cps[c0];
+        pr.num_comps = (uint16_t)n; pr.mct = (mct && c0 == 0 && n >= 3) ? 1 : 0;
+        const int64_t nbl = grk_amd_tile_num_blocks(&pr);
+        uint64_t total = 0;
+        ok = nbl > 0 && row + (size_t)nbl <= o->table.size() &&
+             grk_amd_encode_tiles(ctx, &pr, 1, (const uint8_t*)planes + plane_at[c0], 0, o->table.data() + row, &total) == GRK_AMD_OK;
+        for (size_t i = row; ok && i < row + (size_t)nbl; ++i) {
+            if (o->table[i].length > 65535) ok = false;
+            o->table[i].offset += used;
+        }
+        if (ok && total) {
+            // (the bytes of the runs one behind the other: a run's encode reuses the context's arena)
+            const size_t need = used + total;
+            if (need > o->coded_cap) {
+                uint8_t* old = o->coded; const size_t old_cap = o->coded_cap; const bool old_pinned = o->coded_pinned;
+                o->coded = nullptr; o->coded_cap = 0;
+                ok = o->ensure_coded(ctx, need * 2);
+                if (ok && used) std::memcpy(o->coded, old, used);
+                if (old) { if (old_pinned) grk_amd_host_free(nullptr, old); else std::free(old); }
+                (void)old_cap;
+            }
+            ok = ok && grk_amd_fetch_coded(ctx, o->coded + used, total) == GRK_AMD_OK;
+        }
+        used += total; row += (size_t)nbl; c0 += n;
+    }
+    ok = ok && row == o->table.size() && (o->coded || o->ensure_coded(ctx, 1));
+    if (!ok) { delete o; return nullptr; }
+    patch_owner(o);
+    o->no_cache = true;                            // (release_owner: the cache is keyed by the tile's parameters alone)
     return &o->tile;
 }
 

@@ -94,7 +94,8 @@ struct TagTree {
 int floor_log2(uint32_t v) { int r = 0; while (v >>= 1) ++r; return r; }
 
 // tlm_at: where the Ptlm fields of the TLM marker segment start (0: none written)
-void write_main_header(Out& o, const TileGeom& g, const grk_amd_image_layout& im, uint32_t flags, uint32_t ntiles, uint64_t* tlm_at)
+void write_main_header(Out& o, const TileGeom& g, const grk_amd_image_layout& im, uint32_t flags, uint32_t ntiles, uint64_t* tlm_at,
+                       const uint8_t* comp_dx = nullptr, const uint8_t* comp_dy = nullptr)
 {
     if (tlm_at) *tlm_at = 0;
     const grk_amd_tile_params& p = g.p;
@@ -103,7 +104,9 @@ void write_main_header(Out& o, const TileGeom& g, const grk_amd_image_layout& im
     o.u32(im.x1); o.u32(im.y1); o.u32(im.x0); o.u32(im.y0);            // Xsiz Ysiz XOsiz YOsiz (markers/SIZMarker.cpp)
     o.u32(im.t_width); o.u32(im.t_height); o.u32(im.tx0); o.u32(im.ty0);
     o.u16(p.num_comps);
-    for (uint32_t c = 0; c < p.num_comps; ++c) { o.u8((p.prec - 1) | (p.sgnd ? 0x80 : 0)); o.u8(1); o.u8(1); }
+    for (uint32_t c = 0; c < p.num_comps; ++c) {                       // Ssiz, XRsiz, YRsiz
+        o.u8((p.prec - 1) | (p.sgnd ? 0x80 : 0)); o.u8(comp_dx && comp_dx[c] ? comp_dx[c] : 1); o.u8(comp_dy && comp_dy[c] ? comp_dy[c] : 1);
+    }
     // CAP (CodeStreamCompress.cpp:936-981; MAGBp HTParams.cpp:313-329)
     uint32_t B = 0;
     const uint32_t nb = 3 * p.num_levels + 1;
@@ -217,37 +220,45 @@ grk_amd_image_layout plain_layout(const grk_amd_tile_params& p, uint32_t img_w, 
 }
 
 // SOT, (PLT,) SOD and the packets of one tile in the progression order of `flags`; returns the tile-part's length.
-// One layer, every component with the same geometry: the five orders (ISO 15444-1 B.12.1; t2/PacketIter.cpp:805-1100) are
+// One layer.  `cg[c]` is the geometry of component c's tile-component (all the same object for an image without sub-sampling),
+// `row0[c]` the first of its rows in the tile's table.  The five orders (ISO 15444-1 B.12.1; t2/PacketIter.cpp:805-1100) are
 //   LRCP, RLCP  resolution -> component -> precinct (raster)
 //   RPCL        resolution -> precinct position -> component
 //   PCRL        precinct position -> component -> resolution
 //   CPRL        component -> precinct position -> resolution
-// where a precinct's position is its top-left corner on the canonical grid, clipped to the tile -- the (y, x) at which
-// the standard's position loops meet it; positions are walked in raster order, several resolutions can share one.
-uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, const grk_amd_coded_block* tt, const uint8_t* coded)
+// where a precinct's position is its top-left corner on the REFERENCE grid (component coordinates times the component's
+// sub-sampling factors), clipped to the tile -- the (y, x) at which the standard's position loops meet it; positions are walked
+// in raster order, several resolutions / components can share one.
+uint64_t write_tile_part(Out& o, const std::vector<const TileGeom*>& cg, const std::vector<uint64_t>& row0, const uint8_t* comp_dx,
+                         const uint8_t* comp_dy, uint32_t gx0, uint32_t gy0, uint32_t t, uint32_t flags, const grk_amd_coded_block* tt,
+                         const uint8_t* coded)
 {
-    const grk_amd_tile_params& p = g.p;
+    const uint32_t ncomp = (uint32_t)cg.size();
+    const grk_amd_tile_params& p = cg[0]->p;
     const uint64_t sot = o.n;
     const uint32_t order = (flags >> GRK_AMD_CS_PROG_SHIFT) & 7u;
     const bool sop = (flags & GRK_AMD_CS_SOP) != 0, eph = (flags & GRK_AMD_CS_EPH) != 0;
-    struct Pk { uint32_t r, pi; uint64_t x, y; };
-    std::vector<Pk> prec;                                   // every precinct of a tile-component, resolution-major, raster
-    for (uint32_t r = 0; r <= p.num_levels; ++r) {
-        const ResGeom& R = g.res[r];
-        const uint32_t sh = p.num_levels - r;
-        for (uint32_t pj = 0; pj < R.nph; ++pj)
-            for (uint32_t pi = 0; pi < R.npw; ++pi) {
-                const uint64_t cx = ((uint64_t)((R.x0 >> R.ppx) + pi) << R.ppx) << sh, cy = ((uint64_t)((R.y0 >> R.ppy) + pj) << R.ppy) << sh;
-                prec.push_back(Pk{r, pj * R.npw + pi, std::max<uint64_t>(cx, p.tile_x0), std::max<uint64_t>(cy, p.tile_y0)});
-            }
+    struct Pk { uint32_t c, r, pi; uint64_t x, y; };
+    std::vector<Pk> prec;                                   // every precinct of the tile: component-major, resolution-major, raster
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        const TileGeom& g = *cg[c];
+        const uint64_t dx = comp_dx && comp_dx[c] ? comp_dx[c] : 1, dy = comp_dy && comp_dy[c] ? comp_dy[c] : 1;
+        for (uint32_t r = 0; r <= p.num_levels; ++r) {
+            const ResGeom& R = g.res[r];
+            const uint32_t sh = p.num_levels - r;
+            for (uint32_t pj = 0; pj < R.nph; ++pj)
+                for (uint32_t pi = 0; pi < R.npw; ++pi) {
+                    const uint64_t cx = (((uint64_t)((R.x0 >> R.ppx) + pi) << R.ppx) << sh) * dx, cy = (((uint64_t)((R.y0 >> R.ppy) + pj) << R.ppy) << sh) * dy;
+                    prec.push_back(Pk{c, r, pj * R.npw + pi, std::max<uint64_t>(cx, gx0), std::max<uint64_t>(cy, gy0)});
+                }
+        }
     }
-    std::vector<Pk> by_pos = prec;                          // PCRL / CPRL: by position, then resolution
-    std::stable_sort(by_pos.begin(), by_pos.end(), [](const Pk& a, const Pk& b) { return a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.r < b.r; });
+    auto sorted_by = [&](auto less) { std::vector<Pk> v = prec; std::stable_sort(v.begin(), v.end(), less); return v; };
     auto packets = [&](Out& dst, std::vector<uint8_t>* plt) {
         int32_t n = 0;
-        auto one = [&](uint32_t r, uint32_t c, uint32_t pi) {
+        auto one = [&](const Pk& q) {
             const uint64_t at = dst.n;
-            write_packet(dst, g, r, pi, tt + (uint64_t)c * g.blocks_per_comp, coded, sop ? n : -1, eph);
+            write_packet(dst, *cg[q.c], q.r, q.pi, tt + row0[q.c], coded, sop ? n : -1, eph);
             ++n;
             if (plt) {                          // the packet's length as a big-endian base-128 number (continuation bit 0x80)
                 uint8_t tmp[10]; int k = 0;
@@ -257,26 +268,18 @@ uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, 
                 while (k) plt->push_back(tmp[--k]);
             }
         };
-        if (order <= 1) {
-            size_t i = 0;
-            for (uint32_t r = 0; r <= p.num_levels; ++r) {
-                const size_t first = i;
-                while (i < prec.size() && prec[i].r == r) ++i;
-                for (uint32_t c = 0; c < p.num_comps; ++c)
-                    for (size_t k = first; k < i; ++k) one(r, c, prec[k].pi);
-            }
-        } else if (order == 2) {
-            for (const Pk& q : prec) for (uint32_t c = 0; c < p.num_comps; ++c) one(q.r, c, q.pi);
-        } else if (order == 3) {
-            // (precincts at one position: component, then resolution)
-            for (size_t i = 0; i < by_pos.size();) {
-                size_t j = i;
-                while (j < by_pos.size() && by_pos[j].x == by_pos[i].x && by_pos[j].y == by_pos[i].y) ++j;
-                for (uint32_t c = 0; c < p.num_comps; ++c) for (size_t k = i; k < j; ++k) one(by_pos[k].r, c, by_pos[k].pi);
-                i = j;
-            }
-        } else {
-            for (uint32_t c = 0; c < p.num_comps; ++c) for (const Pk& q : by_pos) one(q.r, c, q.pi);
+        // (stable sorts of the component-major, resolution-major, raster list: the keys named, everything else in that order)
+        if (order <= 1) {              // resolution, component, precinct
+            for (const Pk& q : sorted_by([](const Pk& a, const Pk& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; })) one(q);
+        } else if (order == 2) {       // resolution, position, component
+            for (const Pk& q : sorted_by([](const Pk& a, const Pk& b) {
+                     return a.r != b.r ? a.r < b.r : a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.c < b.c; })) one(q);
+        } else if (order == 3) {       // position, component, resolution
+            for (const Pk& q : sorted_by([](const Pk& a, const Pk& b) {
+                     return a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.c != b.c ? a.c < b.c : a.r < b.r; })) one(q);
+        } else {                       // component, position, resolution
+            for (const Pk& q : sorted_by([](const Pk& a, const Pk& b) {
+                     return a.c != b.c ? a.c < b.c : a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.r < b.r; })) one(q);
         }
     };
     o.u16(0xFF90); o.u16(10); o.u16(t); o.u32(0); o.u8(0); o.u8(1);
@@ -312,6 +315,15 @@ uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, 
     packets(o, nullptr);
     o.patch32(sot + 6, (uint32_t)(o.n - sot));
     return o.n - sot;
+}
+
+// an image without sub-sampling: every component has the tile's own geometry, comp c's rows start at c * blocks_per_comp
+uint64_t write_tile_part(Out& o, const TileGeom& g, uint32_t t, uint32_t flags, const grk_amd_coded_block* tt, const uint8_t* coded)
+{
+    std::vector<const TileGeom*> cg(g.p.num_comps, &g);
+    std::vector<uint64_t> row0(g.p.num_comps);
+    for (uint32_t c = 0; c < g.p.num_comps; ++c) row0[c] = (uint64_t)c * g.blocks_per_comp;
+    return write_tile_part(o, cg, row0, nullptr, nullptr, g.p.tile_x0, g.p.tile_y0, t, flags, tt, coded);
 }
 
 } // namespace
@@ -355,6 +367,74 @@ extern "C" int64_t grk_amd_write_codestream_layout(const grk_amd_image_layout* i
         if (t == 0) write_main_header(o, g, l.im, flags, ntiles, &tlm_at);
         const uint64_t len = write_tile_part(o, g, t, flags, table + row, coded);
         row += (uint64_t)g.blocks_per_comp * p.num_comps;
+        if (tlm_at) o.patch32(tlm_at + 5ull * t + 1, (uint32_t)len);
+    }
+    o.u16(0xFFD9);
+    if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
+    return (int64_t)o.n;
+}
+
+// ---- sub-sampled components ------------------------------------------------------------------------------------------
+// Component c of a tile [x0, x1) x [y0, y1) of the reference grid is [ceil(x0 / dx_c), ceil(x1 / dx_c)) x [ceil(y0 / dy_c),
+// ceil(y1 / dy_c)) in its own coordinates (tile/TileProcessor.cpp:605-612); everything below the tile-component -- resolutions,
+// bands, precincts, code-blocks -- is derived from that rectangle as for any tile (tile/TileComponent.cpp:69-170).
+namespace {
+int tile_comp_of(const Layout& l, const grk_amd_tile_params& base, uint32_t dx, uint32_t dy, uint32_t t, grk_amd_tile_params& p)
+{
+    tile_of(l, base, t, p);
+    dx = dx ? dx : 1; dy = dy ? dy : 1;
+    const uint64_t x0 = p.tile_x0, y0 = p.tile_y0, x1 = x0 + p.tile_w, y1 = y0 + p.tile_h;
+    const uint64_t cx0 = (x0 + dx - 1) / dx, cy0 = (y0 + dy - 1) / dy, cx1 = (x1 + dx - 1) / dx, cy1 = (y1 + dy - 1) / dy;
+    if (cx1 <= cx0 || cy1 <= cy0) return GRK_AMD_ERR_UNSUPPORTED;      // (a tile without a sample of this component)
+    p.tile_x0 = (uint32_t)cx0; p.tile_y0 = (uint32_t)cy0; p.tile_w = (uint32_t)(cx1 - cx0); p.tile_h = (uint32_t)(cy1 - cy0);
+    return GRK_AMD_OK;
+}
+} // namespace
+
+extern "C" int grk_amd_layout_tile_comp(const grk_amd_image_layout* im, const grk_amd_tile_params* base, uint32_t dx, uint32_t dy,
+                                        uint32_t tile_index, grk_amd_tile_params* out)
+{
+    Layout l;
+    const int rc = check_layout(im, l);
+    if (rc != GRK_AMD_OK) return rc;
+    if (!base || !out || tile_index >= l.tcols * l.trows || dx > 255 || dy > 255) return GRK_AMD_ERR_INVALID;
+    return tile_comp_of(l, *base, dx, dy, tile_index, *out);
+}
+
+extern "C" int64_t grk_amd_write_codestream_subsampled(const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                                       const uint8_t* comp_dx, const uint8_t* comp_dy,
+                                                       const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
+                                                       uint8_t* out, uint64_t cap)
+{
+    if (!base || !table || !coded || !out || !comp_dx || !comp_dy) return GRK_AMD_ERR_INVALID;
+    Layout l;
+    int rc = check_layout(im, l);
+    if (rc != GRK_AMD_OK) return rc;
+    const uint32_t ntiles = l.tcols * l.trows, nc = base->num_comps;
+    if ((flags & GRK_AMD_CS_TLM) && ntiles > 255) return GRK_AMD_ERR_UNSUPPORTED;
+    // the multiple component transform needs its three components on one grid: otherwise the reference switches it off with a
+    // warning (CodeStreamCompress.cpp:434-447), and COD says so
+    grk_amd_tile_params based = *base;
+    if (based.mct && nc >= 3 && !(comp_dx[0] == comp_dx[1] && comp_dx[1] == comp_dx[2] && comp_dy[0] == comp_dy[1] && comp_dy[1] == comp_dy[2]))
+        based.mct = 0;
+    base = &based;
+    std::vector<TileGeom> geoms(nc);
+    std::vector<const TileGeom*> cg(nc);
+    std::vector<uint64_t> row0(nc);
+    grk_amd_tile_params p, pt;
+    Out o{out, cap};
+    uint64_t tlm_at = 0, row = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        tile_of(l, *base, t, pt);
+        uint64_t rows = 0;
+        for (uint32_t c = 0; c < nc; ++c) {
+            if ((rc = tile_comp_of(l, *base, comp_dx[c], comp_dy[c], t, p)) != GRK_AMD_OK) return rc;
+            if ((rc = build_tile_geom(p, geoms[c])) != GRK_AMD_OK) return rc;
+            cg[c] = &geoms[c]; row0[c] = rows; rows += geoms[c].blocks_per_comp;
+        }
+        if (t == 0) write_main_header(o, geoms[0], l.im, flags, ntiles, &tlm_at, comp_dx, comp_dy);
+        const uint64_t len = write_tile_part(o, cg, row0, comp_dx, comp_dy, pt.tile_x0, pt.tile_y0, t, flags, table + row, coded);
+        row += rows;
         if (tlm_at) o.patch32(tlm_at + 5ull * t + 1, (uint32_t)len);
     }
     o.u16(0xFFD9);

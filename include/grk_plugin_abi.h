@@ -286,6 +286,12 @@ void grk_amd_plugin_batch_decode_counts(int32_t* gpu, int32_t* cpu, int32_t* fai
 gra_plugin_tile* grk_amd_plugin_tile_create(grk_amd_ctx* ctx, const grk_amd_tile_params* p,
                                             const void* pixels, int pixels_on_device);
 void grk_amd_plugin_tile_destroy(gra_plugin_tile* tile);
+/* The same for an image whose components are sub-sampled each in its own way (grk_image_comp::dx / dy, e.g. 4:2:0): `p` is the tile
+ * on the REFERENCE grid, component c covers [ceil(x0 / dx_c), ceil(x1 / dx_c)) x [ceil(y0 / dy_c), ceil(y1 / dy_c)) of its own
+ * samples (tile/TileProcessor.cpp:605-612); `planes` (host) holds the components back to back, each tight at its own size.  The tree
+ * carries every component's own resolutions, precincts and blocks, as the host's tile does. */
+gra_plugin_tile* grk_amd_plugin_tile_create_subsampled(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const uint8_t* comp_dx,
+                                                       const uint8_t* comp_dy, const void* planes);
 /* The rate-control hook: passes[0].distortionDecrease of every block of a tree just made by ..._tile_create, from
  * grk_amd_block_distortion (what compress_synch_with_plugin copies into the host's passes when the job has rate or quality targets,
  * plugin/plugin_bridge.cpp:214-226).  plugin_encode calls it for jobs with several layers or -r / -q targets. */

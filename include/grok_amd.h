@@ -358,6 +358,26 @@ int64_t grk_amd_write_main_header_layout(const grk_amd_image_layout* im, const g
 int64_t grk_amd_encode_image(grk_amd_ctx* ctx, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
                              const void* pixels, uint32_t flags, uint8_t* out, uint64_t cap);
 
+/* ---- sub-sampled components (4:2:2, 4:2:0 ...; SIZ XRsiz / YRsiz, grok.h grk_image_comp::dx / dy) ------------------------------------
+ * Component c of a tile [x0, x1) x [y0, y1) of the reference grid covers [ceil(x0 / dx_c), ceil(x1 / dx_c)) x [ceil(y0 / dy_c),
+ * ceil(y1 / dy_c)) of its own samples (tile/TileProcessor.cpp:605-612): grk_amd_layout_tile_comp gives *base with that rectangle.
+ * grk_amd_encode_image_subsampled: `pixels` (host) holds the components back to back, component c as ceil(x1 / dx_c) - ceil(x0 / dx_c)
+ * columns x ceil(y1 / dy_c) - ceil(y0 / dy_c) rows, tight (the planar layout of a .yuv / raw file).  Runs of consecutive components
+ * with equal factors are coded together (the colour transform applies only where components 0..2 are such a run; with
+ * other factors base->mct is switched off, as the reference does: CodeStreamCompress.cpp:434-447); the codestream == grk_compress's for the same image (one precinct per resolution or
+ * any precinct sizes, the five progression orders, SOP / EPH / TLM / PLT as for any image).
+ * grk_amd_write_codestream_subsampled: the table's rows tile by tile, within a tile component by component, each component with the
+ * grk_amd_tile_num_blocks() rows of ITS rectangle (num_comps = 1). */
+int grk_amd_layout_tile_comp(const grk_amd_image_layout* im, const grk_amd_tile_params* base, uint32_t dx, uint32_t dy,
+                             uint32_t tile_index, grk_amd_tile_params* out);
+int64_t grk_amd_write_codestream_subsampled(const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                            const uint8_t* comp_dx, const uint8_t* comp_dy,
+                                            const grk_amd_coded_block* table, const uint8_t* coded, uint32_t flags,
+                                            uint8_t* out, uint64_t cap);
+int64_t grk_amd_encode_image_subsampled(grk_amd_ctx* ctx, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
+                                        const uint8_t* comp_dx, const uint8_t* comp_dy, const void* pixels, uint32_t flags,
+                                        uint8_t* out, uint64_t cap);
+
 /* The same with the optional pointer marker segments of the reference's encoder (grk_compress -L / -X, grok.h
  * grk_cparameters::writePLT / writeTLM; codestream/markers/LengthMarkers.cpp): TLM in the main header (one-byte tile index +
  * four-byte tile-part length, <= 255 tiles), PLT (packet lengths) in every tile-part header. */

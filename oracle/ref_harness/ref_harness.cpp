@@ -191,6 +191,7 @@ static void fill_params(grk_cparameters& p, const EncCfg& c)
 	p.numresolution = (uint32_t)c.numres;
 	p.prog_order = GRK_LRCP;
 	p.tcp_mct = (c.C >= 3) ? 1 : 0;
+	if (const char* e = getenv("REF_TCP_MCT")) { if (atoi(e) != 255) p.tcp_mct = (uint8_t)atoi(e); }
 	if (c.ht) { p.isHT = true; p.cblk_sty = GRK_CBLKSTY_HT; }
 	else if (c.cblk_sty) p.cblk_sty = (uint8_t)c.cblk_sty;
 	p.rateControlAlgorithm = (uint32_t)c.rate_algo;
@@ -249,9 +250,26 @@ static grk_image* make_image(const EncCfg& c, bool alloc)
 		q.dx = sdx; q.dy = sdy; q.w = (uint32_t)c.W; q.h = (uint32_t)c.H;
 		q.x0 = ix0; q.y0 = iy0; q.prec = (uint8_t)c.prec; q.sgnd = false;
 	}
+	// components sub-sampled each in its own way (REF_COMP_SUBSAMPLING="dx0,dy0,dx1,dy1,...": a raw / yuv image, grk_compress -F
+	// w,h,c,prec,u@1x1:2x2:2x2, image_format/RAWFormat.cpp:255-290): W x H is the image area on the reference grid, component c has
+	// ceil(x1 / dx) - ceil(x0 / dx) columns -- what grk_image_new computes from x0 / x1 is overwritten by cmptparm w / h, so both are set
+	bool per_comp = false;
+	if (const char* e = getenv("REF_COMP_SUBSAMPLING")) {
+		const char* q = e;
+		for (auto& cpi : cp) {
+			unsigned dx = 1, dy = 1; int used = 0;
+			if (sscanf(q, "%u,%u%n", &dx, &dy, &used) != 2 || !dx || !dy) break;
+			cpi.dx = dx; cpi.dy = dy;
+			cpi.w = (ix0 + (uint32_t)c.W + dx - 1) / dx - (ix0 + dx - 1) / dx;
+			cpi.h = (iy0 + (uint32_t)c.H + dy - 1) / dy - (iy0 + dy - 1) / dy;
+			q += used; if (*q == ',') ++q;
+			per_comp = true;
+		}
+	}
 	auto img = grk_image_new((uint16_t)c.C, cp.data(), c.C >= 3 ? GRK_CLRSPC_SRGB : GRK_CLRSPC_GRAY, alloc);
 	if (!img) return nullptr;
 	img->x0 = ix0; img->y0 = iy0; img->x1 = ix0 + ((uint32_t)c.W - 1) * sdx + 1; img->y1 = iy0 + ((uint32_t)c.H - 1) * sdy + 1;
+	if (per_comp) { img->x1 = ix0 + (uint32_t)c.W; img->y1 = iy0 + (uint32_t)c.H; }
 	return img;
 }
 
@@ -269,15 +287,18 @@ int64_t ref_encode(const EncCfg* cfg, const uint8_t* pixels, uint8_t* out, uint6
 	grk_image* image = make_image(c, true);   // multi-tile paths dereference comp->data (TileProcessor.cpp:1137-1147)
 	if (!image) return -2;
 	if (use_image_data) {
+		// (components back to back, each with its own size: all W x H unless REF_COMP_SUBSAMPLING says otherwise)
+		const uint8_t* src = pixels;
 		for (int k = 0; k < c.C; ++k) {
 			auto comp = image->comps + k;
-			const uint8_t* src = pixels + (size_t)k * c.W * c.H * bps;
-			for (int y = 0; y < c.H; ++y)
-				for (int x = 0; x < c.W; ++x) {
-					size_t i = (size_t)y * c.W + x;
+			const int cw = (int)comp->w, chh = (int)comp->h;
+			for (int y = 0; y < chh; ++y)
+				for (int x = 0; x < cw; ++x) {
+					size_t i = (size_t)y * cw + x;
 					comp->data[(size_t)y * comp->stride + x] =
 						bps == 1 ? (int32_t)src[i] : (int32_t)((const uint16_t*)src)[i];
 				}
+			src += (size_t)cw * chh * bps;
 		}
 	}
 	grk_stream* stream = grk_stream_create_mem_stream(out, cap, false, false);
@@ -343,6 +364,19 @@ int32_t ref_decode(const uint8_t* j2k, uint64_t len, int32_t* out, int32_t C, in
 		if (!grk_decompress(codec, nullptr)) { rc = -4; break; }
 		grk_image* img = grk_decompress_get_composited_image(codec);
 		if (!img || img->numcomps != C) { rc = -5; break; }
+		if (getenv("REF_COMP_SUBSAMPLING")) {       // components of their own sizes, back to back in `out` (room for C x H x W)
+			int32_t* dst = out;
+			for (int k = 0; k < C; ++k) {
+				auto comp = img->comps + k;
+				if ((int)comp->w > W || (int)comp->h > H || !comp->data) { rc = -6; break; }
+				for (uint32_t y = 0; y < comp->h; ++y, dst += comp->w)
+					memcpy(dst, comp->data + (size_t)y * comp->stride, (size_t)comp->w * 4);
+			}
+			if (rc == -6) break;
+			grk_decompress_end(codec);
+			rc = 0;
+			break;
+		}
 		for (int k = 0; k < C; ++k) {
 			auto comp = img->comps + k;
 			if ((int)comp->w != W || (int)comp->h != H || !comp->data) { rc = -6; break; }

@@ -74,6 +74,56 @@ def encode(pixels, prec, TW=None, TH=None, irrev=0, numres=6, ht=1, mode=0, rate
     return out[:n].tobytes(), secs.value
 
 
+def encode_planes(planes, sampling, prec, W, H, TW=None, TH=None, numres=6, irrev=0, mct=0):
+    """grk_compress of an image whose components are sub-sampled each in its own way (a raw / yuv image: grk_compress -F
+    w,h,c,prec,u@1x1:2x2:2x2): planes = one 2-D array per component, sampling = [(dx, dy)]; W x H = the image area on the
+    reference grid.  -> codestream bytes.  (Process-wide environment: REF_COMP_SUBSAMPLING / REF_TCP_MCT are set for the call.)"""
+    L = lib()
+    flat = np.concatenate([np.ascontiguousarray(p).reshape(-1) for p in planes])
+    cfg = EncCfg(len(planes), W, H, TW or W, TH or H, prec, irrev, numres, 1, 1, 0, 0, 0, 0)
+    cap = flat.size * flat.itemsize * 4 + (1 << 20)
+    out = np.zeros(cap, np.uint8)
+    secs = C.c_double(0)
+    keep = {k: os.environ.get(k) for k in ("REF_COMP_SUBSAMPLING", "REF_TCP_MCT")}
+    os.environ["REF_COMP_SUBSAMPLING"] = ",".join("%d,%d" % s for s in sampling)
+    os.environ["REF_TCP_MCT"] = str(int(mct))
+    try:
+        n = L.ref_encode(C.byref(cfg), flat.ctypes.data, out.ctypes.data, cap, C.byref(secs), None)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if n < 0:
+        raise RuntimeError("ref_encode failed rc=%d" % n)
+    return out[:n].tobytes()
+
+
+def decode_planes(j2k, sampling, W, H):
+    """grk_decompress of such a stream -> one (h_c, w_c) int32 array per component (image area at the origin)."""
+    L = lib()
+    buf = np.frombuffer(j2k, np.uint8).copy()
+    out = np.zeros((len(sampling), H, W), np.int32)
+    keep = os.environ.get("REF_COMP_SUBSAMPLING")
+    os.environ["REF_COMP_SUBSAMPLING"] = ",".join("%d,%d" % s for s in sampling)
+    try:
+        rc = L.ref_decode(buf.ctypes.data, buf.size, out.ctypes.data, len(sampling), W, H)
+    finally:
+        if keep is None:
+            os.environ.pop("REF_COMP_SUBSAMPLING", None)
+        else:
+            os.environ["REF_COMP_SUBSAMPLING"] = keep
+    if rc != 0:
+        raise RuntimeError("ref_decode failed rc=%d" % rc)
+    flat, res, at = out.reshape(-1), [], 0
+    for dx, dy in sampling:
+        w, h = (W + dx - 1) // dx, (H + dy - 1) // dy
+        res.append(flat[at:at + w * h].reshape(h, w).copy())
+        at += w * h
+    return res
+
+
 def decode(j2k, Cn, H, W):
     L = lib()
     buf = np.frombuffer(j2k, np.uint8).copy()

@@ -1,0 +1,96 @@
+"""-m gpu: images with sub-sampled components (4:2:2, 4:2:0, ...; VERDICT r5 missing 2) through grk_amd_encode_image_subsampled
+== the file grk_compress writes for the same planes (SIZ XRsiz / YRsiz, per-component tile-components
+ceil(tile / dx), tile/TileProcessor.cpp:605-612), and the reference decoder returns the planes."""
+import os
+
+import numpy as np
+import pytest
+
+import grok_amd as G
+import gpuutil as U
+import refharness as R
+import synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not shipped")]
+
+
+def _planes(W, H, sampling, prec, seed=0):
+    out = []
+    for c, (dx, dy) in enumerate(sampling):
+        w, h = (W + dx - 1) // dx, (H + dy - 1) // dy
+        out.append(synth.g2(1, h, w, prec, seed=100 + 7 * c + seed)[0])
+    return out
+
+
+CASES = [
+    # W, H, sampling, prec, levels, tile, mct, env
+    (256, 192, [(1, 1), (2, 2), (2, 2)], 8, 4, None, 0, {}),                        # 4:2:0
+    (300, 200, [(1, 1), (2, 1), (2, 1)], 8, 5, None, 0, {}),                        # 4:2:2
+    (257, 131, [(1, 1), (2, 2), (2, 2)], 8, 3, None, 1, {}),                        # MCT asked for: switched off, as the reference does
+    (320, 256, [(1, 1), (2, 2), (2, 2)], 8, 4, (128, 128), 0, {}),                  # several tiles
+    (200, 150, [(1, 1), (2, 2), (2, 2), (1, 1)], 8, 3, None, 0, {}),                # 4:2:0 + alpha
+    (320, 240, [(1, 1), (2, 2), (2, 2)], 12, 4, (160, 120), 0, {"REF_PROG_ORDER": "2", "REF_WRITE_TLM": "1", "REF_WRITE_PLT": "1"}),
+    (256, 256, [(2, 2), (2, 2), (2, 2)], 8, 4, None, 1, {}),                        # all alike: one run, MCT stays
+    (384, 256, [(1, 1), (2, 2), (2, 2)], 8, 4, None, 0, {"REF_PROG_ORDER": "3", "REF_CSTY": "6"}),
+    (384, 256, [(1, 1), (2, 2), (2, 2)], 8, 4, (192, 128), 0, {"REF_PROG_ORDER": "4", "REF_PRECINCTS": "128,128,64,64"}),
+]
+
+
+@pytest.mark.parametrize("W,H,sampling,prec,L,tile,mct,env", CASES)
+def test_subsampled_image_equals_grk_compress(W, H, sampling, prec, L, tile, mct, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    planes = _planes(W, H, sampling, prec)
+    TW, TH = tile or (W, H)
+    want = R.encode_planes(planes, sampling, prec, W, H, TW=TW, TH=TH, numres=L + 1, mct=mct)
+    flags = (G.CS_TLM if env.get("REF_WRITE_TLM") else 0) | (G.CS_PLT if env.get("REF_WRITE_PLT") else 0)
+    csty = int(env.get("REF_CSTY", "0"))
+    flags |= (G.CS_SOP if csty & 2 else 0) | (G.CS_EPH if csty & 4 else 0) | G.CS_PROG(int(env.get("REF_PROG_ORDER", "0")))
+    prec_list = None
+    if env.get("REF_PRECINCTS"):
+        v = [int(x) for x in env["REF_PRECINCTS"].split(",")]
+        sizes = list(zip(v[0::2], v[1::2]))
+        prec_list = []
+        for r in range(L + 1):                    # from the highest resolution down, the last one halved beyond the list
+            q = L - r
+            pw, ph = sizes[q] if q < len(sizes) else (sizes[-1][0] >> (q - len(sizes) + 1), sizes[-1][1] >> (q - len(sizes) + 1))
+            prec_list.append((max(1, int(pw).bit_length() - 1), max(1, int(ph).bit_length() - 1)))
+    base = G.TileParams.make(1, 1, len(sampling), prec, L, mct=bool(mct), precincts=prec_list)
+    layout = G.ImageLayout.make(W, H, TW, TH)
+    got = U.ctx().encode_image_subsampled(layout, base, sampling, planes, flags)
+    assert len(got) == len(want) and got == want
+    back = R.decode_planes(got, sampling, W, H)
+    for a, b in zip(back, planes):
+        assert np.array_equal(a, b.astype(np.int32))
+
+
+@pytest.mark.parametrize("W,H,sampling,prec,L", [(256, 192, [(1, 1), (2, 2), (2, 2)], 8, 4), (300, 200, [(1, 1), (2, 1), (2, 1)], 8, 5),
+                                                  (200, 150, [(1, 1), (2, 2), (2, 2), (1, 1)], 12, 3)])
+def test_subsampled_tile_tree_through_grk_compress_with_plugin(W, H, sampling, prec, L, monkeypatch):
+    """The library-level drop-in for such an image: grk_amd_plugin_tile_create_subsampled builds the tile tree with every
+    component's own resolutions / precincts / blocks, the host (grk_compress_with_plugin, its own Tier-2 and headers) writes the
+    file -- == its pure-CPU encode."""
+    import ctypes as C
+    planes = _planes(W, H, sampling, prec, seed=3)
+    want = R.encode_planes(planes, sampling, prec, W, H, numres=L + 1, mct=0)
+    Lp = C.CDLL(os.path.join(os.path.dirname(G.lib_path()), "libgrokj2k_plugin.so"))
+    Lp.grk_amd_plugin_tile_create_subsampled.restype = C.c_void_p
+    Lp.grk_amd_plugin_tile_create_subsampled.argtypes = [C.c_void_p, C.POINTER(G.TileParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    Lp.grk_amd_plugin_tile_destroy.argtypes = [C.c_void_p]
+    p = G.TileParams.make(W, H, len(sampling), prec, L, mct=False)
+    dx = (C.c_uint8 * len(sampling))(*[a for a, _ in sampling])
+    dy = (C.c_uint8 * len(sampling))(*[b for _, b in sampling])
+    flat = np.concatenate([pl.reshape(-1) for pl in planes])
+    tile = Lp.grk_amd_plugin_tile_create_subsampled(U.ctx()._h, C.byref(p), dx, dy, flat.ctypes.data)
+    assert tile
+    monkeypatch.setenv("REF_COMP_SUBSAMPLING", ",".join("%d,%d" % s for s in sampling))
+    monkeypatch.setenv("REF_TCP_MCT", "0")
+    try:
+        Lr = R.lib()
+        cfg = R.EncCfg(len(sampling), W, H, W, H, prec, 0, L + 1, 1, 1, 1, 0, 0, 0)
+        out = np.zeros(flat.size * 4 + (1 << 20), np.uint8)
+        secs = C.c_double(0)
+        n = Lr.ref_encode(C.byref(cfg), flat.ctypes.data, out.ctypes.data, out.size, C.byref(secs), tile)
+    finally:
+        Lp.grk_amd_plugin_tile_destroy(tile)
+    assert n > 0 and out[:n].tobytes() == want
