@@ -543,7 +543,10 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
         const uint64_t strips = (a.cw + a.px + dwt_level_strip_cols(a) - 1) / dwt_level_strip_cols(a);
         // workgroups along z: planes, or for the fused level 0 tiles (x components when there is no MCT triple)
         const uint32_t zslots = (l == 0 && d_pixels) ? ntiles * ((g.p.mct && g.p.num_comps >= 3) ? 1u : g.p.num_comps) : nplanes;
-        static const uint32_t kMinWgs = getenv("GRK_AMD_DWT_MIN_WGS") ? (uint32_t)std::max(1, atoi(getenv("GRK_AMD_DWT_MIN_WGS"))) : 2048u;
+        // (... for the packed 5/3 kernel; the 32-bit kernels -- 448-column strips, twice the workgroups per row -- are better off with
+        //  the finer cut: cfg3's 9/7 family 0.361 ms at 4096, 0.394 at 2048)
+        static const int kMinWgsEnv = getenv("GRK_AMD_DWT_MIN_WGS") ? std::max(1, atoi(getenv("GRK_AMD_DWT_MIN_WGS"))) : 0;
+        const uint32_t kMinWgs = kMinWgsEnv ? (uint32_t)kMinWgsEnv : (a.pk ? 2048u : 4096u);
         while (seg > 8 && strips * ((sh + seg - 1) / seg) * zslots < kMinWgs) seg >>= 1;
         a.seg_pairs = seg;
         if (a.cw == 0 || a.ch == 0) {
@@ -1548,6 +1551,17 @@ int grk_amd_fetch_coded(grk_amd_ctx* c, uint8_t* dst, uint64_t nbytes)
     { const int jr = join_side(c); if (jr) return jr; }
     { const int rc = copy_d2h(c, dst, c->arena.p, nbytes); if (rc) return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    return GRK_AMD_OK;
+}
+
+int grk_amd_fetch_coded_async(grk_amd_ctx* c, uint8_t* dst, uint64_t nbytes)
+{
+    if (!c || !dst) return GRK_AMD_ERR_INVALID;
+    if (nbytes > c->arena.cap) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    if (!host_is_pinned(dst)) return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_fetch_coded_async needs pinned memory (grk_amd_host_alloc)");
+    { const int jr = join_side(c); if (jr) return jr; }
+    if (nbytes) HIP_TRY(c, hipMemcpyAsync(dst, c->arena.p, nbytes, hipMemcpyDeviceToHost, c->stream), "download");
     return GRK_AMD_OK;
 }
 

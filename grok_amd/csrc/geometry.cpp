@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
 
 namespace grk_amd {
 
@@ -61,7 +64,30 @@ static void make_qcd(const grk_amd_tile_params& p, uint16_t* w)
     }
 }
 
+static int build_tile_geom_uncached(const grk_amd_tile_params& p, TileGeom& g);
+
+// The geometry of a tile is asked for again and again with the same parameters -- per tile when an image is laid out, per call of
+// the codestream writer, twice by a caller that sizes before it writes -- and enumerating the 49 152 code-blocks of an 8K tile takes
+// 1.4 ms of host time: the last few are kept (a copy is ~0.05 ms).
 int build_tile_geom(const grk_amd_tile_params& p, TileGeom& g)
+{
+    static std::mutex mu;
+    static std::vector<std::shared_ptr<const TileGeom>> cache;             // most recent last
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = cache.size(); i-- > 0;)
+            if (std::memcmp(&cache[i]->p, &p, sizeof p) == 0) { g = *cache[i]; return GRK_AMD_OK; }
+    }
+    const int rc = build_tile_geom_uncached(p, g);
+    if (rc != GRK_AMD_OK) return rc;
+    auto keep = std::make_shared<const TileGeom>(g);
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() >= 8) cache.erase(cache.begin());
+    cache.push_back(std::move(keep));
+    return GRK_AMD_OK;
+}
+
+static int build_tile_geom_uncached(const grk_amd_tile_params& p, TileGeom& g)
 {
     if (p.tile_w == 0 || p.tile_h == 0 || p.num_comps == 0 || p.num_comps > 4) return GRK_AMD_ERR_INVALID;
     if (p.prec == 0 || p.prec > 16) return GRK_AMD_ERR_UNSUPPORTED;

@@ -60,6 +60,10 @@ inline bool on_even_grid(const TileGeom& g)
     return true;
 }
 
+// t2_writer.cpp: a tile-part as literal bytes + a segment list (grk_amd_plan_tile_part, include/grok_amd.h); returns its length
+int64_t plan_tile_part(const grk_amd_tile_params& p, uint32_t tile_index, uint32_t flags, const grk_amd_coded_block* tile_table,
+                       std::vector<uint8_t>& lit, std::vector<grk_amd_tp_segment>& segs);
+
 inline uint32_t ceil_div_pow2(uint32_t v, uint32_t n) { return (uint32_t)(((uint64_t)v + (1ull << n) - 1) >> n); }
 
 } // namespace grk_amd

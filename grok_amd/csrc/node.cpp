@@ -80,6 +80,9 @@ bool pin_grow(grk_amd_ctx* ctx, uint8_t*& p, size_t& cap, size_t n, size_t keep)
 struct TileJob {               // what the workers leave per tile
     std::vector<grk_amd_coded_block> rows;     // offsets into the coded bytes on the host (the owning worker's, or the writer's)
     uint64_t part_len = 0;                     // the tile-part's size
+    bool planned = false;                      // ... its plan was made by the tile's worker (beside the download of its bytes)
+    std::vector<uint8_t> lit;                  // its plan (plan_tile_part): marker segments + packet headers ...
+    std::vector<grk_amd_tp_segment> segs;      // ... and the segments it is made of
 };
 
 // fn(t) for t in [0, n) on up to `threads` host threads; the first error wins
@@ -355,13 +358,25 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
                 } else {
                     // (the worker's groups one after the other: Tier-2 runs over all of them once every worker is done)
                     if (!pin_grow(w.ctx, w.pin_coded, w.pin_coded_cap, coded_used + total + 16, coded_used)) { rc = GRK_AMD_ERR_NOMEM; break; }
-                    rc = grk_amd_fetch_coded(w.ctx, w.pin_coded + coded_used, total);
+                    // (queued, not waited for: Tier-2 of these tiles needs their table only and runs below while the bytes cross the link)
+                    rc = grk_amd_fetch_coded_async(w.ctx, w.pin_coded + coded_used, total);
                     if (rc) break;
                 }
                 for (size_t i = 0; i < mine.size(); ++i) {
                     TileJob& j = jobs[mine[i]];
                     j.rows.assign(table.begin() + i * bpt, table.begin() + (i + 1) * bpt);
                     for (auto& row : j.rows) row.offset += coded_used;
+                }
+                if (!gather) {
+                    for (size_t i = 0; i < mine.size() && rc == GRK_AMD_OK; ++i) {
+                        TileJob& j = jobs[mine[i]];
+                        const int64_t need = plan_tile_part(tp[mine[i]], mine[i], cs_flags, j.rows.data(), j.lit, j.segs);
+                        if (need < 0) rc = (int)need; else { j.part_len = (uint64_t)need; j.planned = true; }
+                    }
+                    // the bytes are in the pinned buffer before the next group's encode writes the arena again
+                    const int sr = grk_amd_synchronize(w.ctx);
+                    if (rc == GRK_AMD_OK) rc = sr;
+                    if (rc) break;
                 }
                 coded_used += total;
             }
@@ -397,12 +412,15 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
     } else {
         for (uint32_t t = 0; t < ntiles; ++t) src[t] = nd->w[t % R].pin_coded;
     }
-    // Tier-2 and the codestream, tiles on several host threads: the tile-parts' sizes (a dry run of the packet writer), the main
-    // header (TLM from the sizes) -- which fixes every tile-part's place --, then each tile-part written where it belongs: every
-    // coded byte is copied once, and not by one thread (a frame of BASELINE configs[3] is ~400 MB of codestream).
+    // Tier-2 and the codestream.  Tier-2 ONCE per tile, as a plan (plan_tile_part: the marker segments and packet headers as literal
+    // bytes + the list of segments the tile-part is made of; ~1 ms for the 49 152 blocks of an 8K tile), tiles on several host
+    // threads; the plans give the tile-parts' sizes, those the main header (TLM) and every tile-part's place; then the segments --
+    // ~100 MB of coded bytes per 8K frame -- are copied to where they belong by all the threads, whatever the number of tiles (r05
+    // ran Tier-2 twice, once to size and once to write, and one tile's bytes were one thread's work: 12.8 ms per 8K frame as one tile).
     const uint32_t host_threads = std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency() / 4u));
     int rc = parallel_tiles(ntiles, host_threads, [&](uint32_t t) -> int {
-        const int64_t need = grk_amd_write_tile_part(&tp[t], t, cs_flags, jobs[t].rows.data(), src[t], nullptr, 0);
+        if (jobs[t].planned) return GRK_AMD_OK;
+        const int64_t need = plan_tile_part(tp[t], t, cs_flags, jobs[t].rows.data(), jobs[t].lit, jobs[t].segs);
         if (need < 0) return (int)need;
         jobs[t].part_len = (uint64_t)need;
         return GRK_AMD_OK;
@@ -415,11 +433,38 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
     std::vector<uint64_t> at(ntiles + 1, (uint64_t)hdr);
     for (uint32_t t = 0; t < ntiles; ++t) at[t + 1] = at[t] + jobs[t].part_len;
     if (at[ntiles] + 2 > cap) return GRK_AMD_ERR_OVERFLOW;
-    rc = parallel_tiles(ntiles, host_threads, [&](uint32_t t) -> int {
-        const int64_t got = grk_amd_write_tile_part(&tp[t], t, cs_flags, jobs[t].rows.data(), src[t], out + at[t], jobs[t].part_len);
-        return got == (int64_t)jobs[t].part_len ? GRK_AMD_OK : got < 0 ? (int)got : GRK_AMD_ERR_INVALID;
-    });
-    if (rc) return rc;
+    {
+        // pieces of ~2 MB of output: (tile, first segment, segment count), handed out by a counter
+        struct Piece { uint32_t t; size_t s0, s1; };
+        std::vector<Piece> pieces;
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const auto& sg = jobs[t].segs;
+            size_t s0 = 0; uint64_t bytes = 0;
+            for (size_t i = 0; i < sg.size(); ++i) {
+                bytes += sg[i].len;
+                if (bytes >= (2u << 20) || i + 1 == sg.size()) { pieces.push_back(Piece{t, s0, i + 1}); s0 = i + 1; bytes = 0; }
+            }
+        }
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= pieces.size()) break;
+                const Piece& pc = pieces[k];
+                const TileJob& j = jobs[pc.t];
+                uint8_t* const dst = out + at[pc.t];
+                for (size_t i = pc.s0; i < pc.s1; ++i) {
+                    const grk_amd_tp_segment& sgm = j.segs[i];
+                    std::memcpy(dst + sgm.dst, (sgm.kind ? src[pc.t] : j.lit.data()) + sgm.src, sgm.len);
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        const uint32_t nthr = (uint32_t)std::min<size_t>(host_threads, pieces.size());
+        for (uint32_t i = 1; i < nthr; ++i) pool.emplace_back(work);
+        work();
+        for (auto& th2 : pool) th2.join();
+    }
     uint64_t end = at[ntiles];
     out[end++] = 0xFF; out[end++] = 0xD9;
     return (int64_t)end;

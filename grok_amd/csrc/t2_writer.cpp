@@ -21,75 +21,96 @@ namespace {
 
 using namespace grk_amd;
 
-struct Out {          // p == nullptr: only counts (ovf stays false)
+// p == nullptr: only counts (ovf stays false).  PLAN mode (lit != nullptr): nothing is copied -- what the writer writes itself (marker
+// segments, packet headers) collects in `lit`, and the output is described as a list of segments, each either a run of those
+// literal bytes or a code-block's bytes in the coded buffer (grk_amd_plan_tile_part: the caller places them, on whatever
+// threads or device it likes, once it knows where the tile-part goes).
+struct Out {
     uint8_t* p; uint64_t cap; uint64_t n = 0; bool ovf = false;
-    void u8(uint32_t v) { if (p) { if (n < cap) p[n] = (uint8_t)v; else ovf = true; } ++n; }
+    std::vector<uint8_t>* lit = nullptr; std::vector<grk_amd_tp_segment>* segs = nullptr;
+    void u8(uint32_t v)
+    {
+        if (lit) {
+            if (segs->empty() || segs->back().kind != 0 || segs->back().dst + segs->back().len != n)
+                segs->push_back(grk_amd_tp_segment{n, (uint64_t)lit->size(), 0u, 0u});
+            lit->push_back((uint8_t)v); segs->back().len++;
+        } else if (p) { if (n < cap) p[n] = (uint8_t)v; else ovf = true; }
+        ++n;
+    }
     void u16(uint32_t v) { u8(v >> 8); u8(v & 0xFF); }
     void u32(uint32_t v) { u16(v >> 16); u16(v & 0xFFFF); }
-    void bytes(const uint8_t* s, uint64_t len)
+    void bytes(const uint8_t* s, uint64_t len)               // bytes of the writer's own
     {
+        if (lit) { for (uint64_t i = 0; i < len; ++i) u8(s[i]); return; }
         if (p) { if (n + len <= cap) std::memcpy(p + n, s, len); else ovf = true; }
         n += len;
     }
-    void patch32(uint64_t at, uint32_t v)
+    void body(const uint8_t* coded, uint64_t off, uint64_t len)   // a code-block's bytes
     {
-        if (p && at + 4 <= cap) { p[at] = (uint8_t)(v >> 24); p[at + 1] = (uint8_t)(v >> 16); p[at + 2] = (uint8_t)(v >> 8); p[at + 3] = (uint8_t)v; }
+        if (lit) { if (len) segs->push_back(grk_amd_tp_segment{n, off, (uint32_t)len, 1u}); n += len; return; }
+        if (p) { if (n + len <= cap) std::memcpy(p + n, coded + off, len); else ovf = true; }
+        n += len;
+    }
+    // (a patch lies in the SOT marker segment or the TLM: literal bytes written in one run -- `lit_at` = where that run began in lit,
+    //  `run_dst` = its first byte's place in the output)
+    void patch32(uint64_t at, uint32_t v, uint64_t lit_at = 0, uint64_t run_dst = 0)
+    {
+        uint8_t* q = nullptr;
+        if (lit) { const uint64_t i = lit_at + (at - run_dst); if (i + 4 <= lit->size()) q = lit->data() + i; }
+        else if (p && at + 4 <= cap) q = p + at;
+        if (q) { q[0] = (uint8_t)(v >> 24); q[1] = (uint8_t)(v >> 16); q[2] = (uint8_t)(v >> 8); q[3] = (uint8_t)v; }
     }
 };
 
-// MSB-first packet-header bit writer: a byte following 0xFF carries 7 bits (BitIO.cpp:46-175)
+// MSB-first packet-header bit writer: a byte following 0xFF carries 7 bits (BitIO.cpp:46-175).  Bits collect in a 64-bit
+// register and leave a byte at a time; BitIO's own form (one call per bit, the byte written when the NEXT bit arrives) gives the same
+// bytes: a full byte is the same byte whenever it is written, and its flush -- the byte in work as it is, then an empty byte if that
+// one was 0xFF -- is flush() below.
 struct HeaderBits {
-    Out& o; uint8_t buf = 0; int ct = 8;
+    Out& o; uint64_t acc = 0; int n = 0; uint32_t last = 0;
     explicit HeaderBits(Out& out) : o(out) {}
-    void byteout() { o.u8(buf); ct = (buf == 0xFF) ? 7 : 8; buf = 0; }
-    void bit(uint32_t b) { if (ct == 0) byteout(); --ct; buf = (uint8_t)(buf | (b << ct)); }
-    void put(uint32_t v, int n) { for (int i = n - 1; i >= 0; --i) bit((v >> i) & 1); }
-    void comma(int n) { while (--n >= 0) bit(1); bit(0); }
-    void flush() { byteout(); if (ct == 7) byteout(); }
+    void drain()
+    {
+        for (;;) {
+            const int take = last == 0xFF ? 7 : 8;
+            if (n < take) break;
+            last = (uint32_t)(acc >> (n - take)) & ((1u << take) - 1u);
+            o.u8(last);
+            n -= take;
+        }
+    }
+    void put(uint32_t v, int k) { acc = (acc << k) | v; n += k; drain(); }      // k <= 32 bits of v, MSB first
+    void bit(uint32_t b) { put(b & 1u, 1); }
+    void ones(int k) { put((uint32_t)((1ull << k) - 1ull), k); }                  // k <= 32
+    void zeros(int k) { while (k > 0) { const int t = k > 32 ? 32 : k; put(0, t); k -= t; } }
+    void comma(int k) { while (k > 31) { ones(31); k -= 31; } put(((1u << k) - 1u) << 1, k + 1); }   // k ones, then a zero
+    void flush()
+    {
+        if (n) { const int take = last == 0xFF ? 7 : 8; last = (uint32_t)(acc & ((1ull << n) - 1ull)) << (take - n); o.u8(last); n = 0; }
+        else if (last == 0xFF) { o.u8(0); last = 0; }
+    }
 };
 
-// Tag tree over a gw x gh leaf grid (ISO 15444-1 B.10.2), quad-tree reduced level by level.
-struct TagTree {
-    struct Node { int32_t value, low; bool known; };
-    std::vector<std::vector<Node>> lvl;
-    std::vector<uint32_t> lw, lh;
-    void init(uint32_t gw, uint32_t gh)
-    {
-        lvl.clear(); lw.clear(); lh.clear();
-        uint32_t w = gw, h = gh;
-        for (;;) {
-            lw.push_back(w); lh.push_back(h);
-            lvl.emplace_back((size_t)w * h, Node{0x7FFFFFFF, 0, false});
-            if (w * h <= 1) break;
-            w = (w + 1) >> 1; h = (h + 1) >> 1;
-        }
-    }
-    void set(uint32_t x, uint32_t y, int32_t v)
-    {
-        for (size_t l = 0; l < lvl.size(); ++l) {
-            Node& nd = lvl[l][(size_t)(y >> l) * lw[l] + (x >> l)];
-            if (nd.value <= v) break;
-            nd.value = v;
-        }
-    }
-    void encode(HeaderBits& hb, uint32_t x, uint32_t y, int32_t threshold)
-    {
-        int32_t low = 0;
-        for (int l = (int)lvl.size() - 1; l >= 0; --l) {
-            Node& nd = lvl[l][(size_t)(y >> l) * lw[l] + (x >> l)];
-            if (low > nd.low) nd.low = low; else low = nd.low;
-            while (low < threshold) {
-                if (low >= nd.value) {
-                    if (!nd.known) { hb.bit(1); nd.known = true; }
-                    break;
-                }
-                hb.bit(0);
-                ++low;
-            }
-            nd.low = low;
-        }
-    }
-};
+// Tag trees (ISO 15444-1 B.10.2; t1/TagTree.cpp:170-218) as this writer meets them.  A packet of the single layer includes every
+// code-block, and every block of a band has the same number of missing bit-planes (numbps = 1 is signalled for an HT block,
+// T1HT.cpp:123: Kmax - 1 of them): BOTH trees of a band's precinct -- inclusion, all leaves 0 against threshold 1; zero bit-planes,
+// all leaves v -- are uniform.  Coding leaf (x, y) then emits, from the root down, one '1' for every node on its path that no
+// earlier leaf (raster order) has passed -- the nodes (x >> l, y >> l) with the low l bits of x and y zero: 1 + min(ctz x, ctz y)
+// of them, at most the tree's height -- and, for the zero-bit-plane tree's root alone, v '0's in front of its '1'.  (The general
+// procedure -- per node a lower bound raised bit by bit to the threshold -- reduces to exactly this when no node's value is
+// below its parent's.)
+inline int tag_tree_height(uint32_t gw, uint32_t gh)
+{
+    int h = 1;
+    while ((uint64_t)gw * gh > 1) { gw = (gw + 1) >> 1; gh = (gh + 1) >> 1; ++h; }
+    return h;
+}
+inline int new_nodes(uint32_t x, uint32_t y, int height)
+{
+    const uint32_t m = x | y;
+    const int z = m ? __builtin_ctz(m) : 31;
+    return z + 1 < height ? z + 1 : height;
+}
 
 int floor_log2(uint32_t v) { int r = 0; while (v >>= 1) ++r; return r; }
 
@@ -158,24 +179,23 @@ void write_packet(Out& o, const TileGeom& g, uint32_t r, uint32_t pi, const grk_
     if (sop >= 0) { o.u16(0xFF91); o.u16(4); o.u16((uint32_t)sop & 0xFFFFu); }
     HeaderBits hb(o);
     hb.bit(1);
-    TagTree incl, zbp;
     for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
         const BandGeom& B = R.band[bi];
         const BandGeom::Prec& P = B.prec[pi];
         if (!P.gw || !P.gh) continue;
-        incl.init(P.gw, P.gh); zbp.init(P.gw, P.gh);
+        const int height = tag_tree_height(P.gw, P.gh);
+        const grk_amd_coded_block* cb = comp_table + P.first_block;
         for (uint32_t y = 0; y < P.gh; ++y)
-            for (uint32_t x = 0; x < P.gw; ++x) { incl.set(x, y, 0); zbp.set(x, y, (int32_t)B.kmax - 1); }
-        for (uint32_t y = 0; y < P.gh; ++y)
-            for (uint32_t x = 0; x < P.gw; ++x) {
-                const grk_amd_coded_block& cb = comp_table[P.first_block + y * P.gw + x];
-                incl.encode(hb, x, y, 1);
-                zbp.encode(hb, x, y, 0x7FFFFFFF);
-                hb.bit(0);                                            // one coding pass
-                const uint32_t len = cb.length;
+            for (uint32_t x = 0; x < P.gw; ++x, ++cb) {
+                const int nn = new_nodes(x, y, height);
+                hb.ones(nn);                                          // inclusion: the path's new nodes
+                if (!(x | y)) hb.zeros((int)B.kmax - 1);              // zero bit-planes: the root's value ...
+                hb.ones(nn);                                          // ... and the path's new nodes
+                const uint32_t len = cb->length;
                 int inc = floor_log2(len) + 1 - 3;
                 if (inc < 0) inc = 0;
-                hb.comma(inc);
+                hb.put(0, 1);                                         // one coding pass
+                hb.comma(inc);                                        // Lblock raised from 3 to what the length needs
                 hb.put(len, 3 + inc);
             }
     }
@@ -185,7 +205,7 @@ void write_packet(Out& o, const TileGeom& g, uint32_t r, uint32_t pi, const grk_
         const BandGeom::Prec& P = R.band[bi].prec[pi];
         for (uint32_t k = 0; k < P.gw * P.gh; ++k) {
             const grk_amd_coded_block& cb = comp_table[P.first_block + k];
-            o.bytes(coded + cb.offset, cb.length);
+            o.body(coded, cb.offset, cb.length);
         }
     }
 }
@@ -235,7 +255,7 @@ uint64_t write_tile_part(Out& o, const std::vector<const TileGeom*>& cg, const s
 {
     const uint32_t ncomp = (uint32_t)cg.size();
     const grk_amd_tile_params& p = cg[0]->p;
-    const uint64_t sot = o.n;
+    const uint64_t sot = o.n, sot_lit = o.lit ? o.lit->size() : 0;
     const uint32_t order = (flags >> GRK_AMD_CS_PROG_SHIFT) & 7u;
     const bool sop = (flags & GRK_AMD_CS_SOP) != 0, eph = (flags & GRK_AMD_CS_EPH) != 0;
     struct Pk { uint32_t c, r, pi; uint64_t x, y; };
@@ -313,7 +333,7 @@ uint64_t write_tile_part(Out& o, const std::vector<const TileGeom*>& cg, const s
     }
     o.u16(0xFF93);
     packets(o, nullptr);
-    o.patch32(sot + 6, (uint32_t)(o.n - sot));
+    o.patch32(sot + 6, (uint32_t)(o.n - sot), sot_lit, sot);
     return o.n - sot;
 }
 
@@ -511,6 +531,42 @@ extern "C" int64_t grk_amd_write_tile_part(const grk_amd_tile_params* p, uint32_
     Out o{out, cap};
     write_tile_part(o, g, tile_index, flags, tile_table, coded);
     if (o.ovf) return GRK_AMD_ERR_OVERFLOW;
+    return (int64_t)o.n;
+}
+
+namespace grk_amd {
+int64_t plan_tile_part(const grk_amd_tile_params& p, uint32_t tile_index, uint32_t flags, const grk_amd_coded_block* tile_table,
+                       std::vector<uint8_t>& lit, std::vector<grk_amd_tp_segment>& segs)
+{
+    TileGeom g;
+    const int rc = build_tile_geom(p, g);
+    if (rc != GRK_AMD_OK) return rc;
+    lit.clear(); segs.clear();
+    lit.reserve((size_t)g.blocks_per_comp * p.num_comps * 5 + 256);
+    segs.reserve((size_t)g.blocks_per_comp * p.num_comps + 64);
+    Out o{nullptr, 0};
+    o.lit = &lit; o.segs = &segs;
+    write_tile_part(o, g, tile_index, flags, tile_table, nullptr);
+    return (int64_t)o.n;
+}
+} // namespace grk_amd
+
+extern "C" int64_t grk_amd_plan_tile_part(const grk_amd_tile_params* p, uint32_t tile_index, uint32_t flags,
+                                          const grk_amd_coded_block* tile_table, uint8_t* literal, uint64_t literal_cap, uint64_t* literal_len,
+                                          grk_amd_tp_segment* segments, uint64_t segment_cap, uint64_t* num_segments)
+{
+    if (!p || !tile_table || !literal_len || !num_segments) return GRK_AMD_ERR_INVALID;
+    std::vector<uint8_t> lit;
+    std::vector<grk_amd_tp_segment> segs;
+    const int64_t total = grk_amd::plan_tile_part(*p, tile_index, flags, tile_table, lit, segs);
+    if (total < 0) return total;
+    struct { uint64_t n; } o{(uint64_t)total};
+    *literal_len = lit.size(); *num_segments = segs.size();
+    if (literal && segments) {
+        if (lit.size() > literal_cap || segs.size() > segment_cap) return GRK_AMD_ERR_OVERFLOW;
+        std::memcpy(literal, lit.data(), lit.size());
+        std::memcpy(segments, segs.data(), segs.size() * sizeof(grk_amd_tp_segment));
+    }
     return (int64_t)o.n;
 }
 

@@ -159,6 +159,9 @@ int grk_amd_fetch_table(grk_amd_ctx* ctx, grk_amd_coded_block* table, uint64_t* 
 int grk_amd_block_distortion(grk_amd_ctx* ctx, double* distortion, uint64_t capacity);
 /* copy coded bytes [0,total) of the arena to host memory */
 int grk_amd_fetch_coded(grk_amd_ctx* ctx, uint8_t* dst, uint64_t nbytes);
+/* The same without waiting: `dst` must be pinned (grk_amd_host_alloc); the copy is queued on the context's stream and complete after
+ * grk_amd_synchronize -- a host that runs Tier-2 over the table (grk_amd_plan_tile_part) while the bytes cross the link. */
+int grk_amd_fetch_coded_async(grk_amd_ctx* ctx, uint8_t* dst, uint64_t nbytes);
 /* device pointers for zero-copy consumers (RCCL gather of tile parts, tests) */
 void* grk_amd_coded_device_ptr(grk_amd_ctx* ctx);
 void* grk_amd_plane_device_ptr(grk_amd_ctx* ctx, int which /*0: ingest planes, 1: Mallat planes*/);
@@ -328,6 +331,17 @@ double grk_amd_kernel_ms(grk_amd_ctx* ctx, int which, uint32_t* launches);
 int64_t grk_amd_write_codestream(const grk_amd_tile_params* p, uint32_t img_w, uint32_t img_h,
                                  const grk_amd_coded_block* table, const uint8_t* coded,
                                  uint8_t* out, uint64_t cap);
+
+/* A tile-part as a PLAN instead of bytes: what the writer writes itself (SOT .. SOD, packet headers, SOP / EPH) in `literal`, and the
+ * tile-part as a list of segments in output order -- kind 0: `len` bytes of `literal` from `src`; kind 1: a code-block's bytes, `len`
+ * bytes of the coded buffer from `src` (the table row's offset) -- each with its place `dst` in the tile-part.  Tier-2 is O(#blocks) of
+ * host work (~1 ms for the 49 152 blocks of an 8K tile); moving the ~100 MB of coded bytes is then the caller's to spread over host
+ * threads or to do on the device (grk_amd_assemble_device), once, into the tile-part's final place.  Returns the tile-part's length;
+ * with literal / segments NULL only the sizes (*literal_len, *num_segments). */
+typedef struct grk_amd_tp_segment { uint64_t dst, src; uint32_t len, kind; } grk_amd_tp_segment;
+int64_t grk_amd_plan_tile_part(const grk_amd_tile_params* p, uint32_t tile_index, uint32_t flags,
+                               const grk_amd_coded_block* tile_table, uint8_t* literal, uint64_t literal_cap, uint64_t* literal_len,
+                               grk_amd_tp_segment* segments, uint64_t segment_cap, uint64_t* num_segments);
 
 /* ---- images of any tile layout (tiles / images off the origin, ragged edge tiles) ----------------------------------
  * What SIZ says about the image (ISO 15444-1 B.2, B.3; grok.h grk_image x0..y1, grk_cparameters tx0 ty0 t_width t_height):

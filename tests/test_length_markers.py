@@ -147,3 +147,41 @@ def test_plt_longer_than_one_marker_segment_is_split(monkeypatch):
     # the same packets as without PLT
     assert got[at + 2:sot + psot] == plain[plain.index(b"\xff\x93") + 2:-2]
     assert np.array_equal(R.decode(got, 3, H, W), px.astype(np.int32))
+
+
+def test_tile_part_plan_materialises_to_the_written_tile_part():
+    """grk_amd_plan_tile_part: the literal bytes + segment list of a tile-part, placed, are the bytes grk_amd_write_tile_part writes
+    (every flag combination that changes the tile-part: PLT, SOP, EPH, the progression orders, precincts)."""
+    import ctypes as C
+    import oracle as O
+    rng = np.random.default_rng(11)
+    L = G.lib()
+    L.grk_amd_plan_tile_part.restype = C.c_int64
+    L.grk_amd_plan_tile_part.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    SEG = np.dtype([("dst", "<u8"), ("src", "<u8"), ("len", "<u4"), ("kind", "<u4")])
+    for W, H, Cn, Lv, flags, precincts in ((256, 192, 3, 3, 0, None), (300, 200, 1, 4, G.CS_PLT | G.CS_SOP | G.CS_EPH | G.CS_PROG(2), None),
+                                           (256, 256, 3, 3, G.CS_PROG(4) | G.CS_PLT, [(5, 5)] * 4), (64, 64, 3, 0, G.CS_PROG(3), None)):
+        p = G.TileParams.make(W, H, Cn, 8, Lv, precincts=precincts)
+        nb = L.grk_amd_tile_num_blocks(C.byref(p))
+        t = np.zeros(nb, G.capi.CODED_DTYPE)
+        t["length"] = rng.integers(0, 3000, nb)
+        order = rng.permutation(nb)                       # (blocks anywhere in the coded buffer)
+        offs = np.zeros(nb, np.int64)
+        offs[order] = np.concatenate([[0], np.cumsum(t["length"][order].astype(np.int64))[:-1]])
+        t["offset"] = offs
+        coded = rng.integers(0, 256, int(t["length"].astype(np.int64).sum()) + 1, dtype=np.uint8)
+        want = G.write_tile_part(p, 3, t, coded, flags=flags)
+        nlit, nseg = C.c_uint64(0), C.c_uint64(0)
+        total = L.grk_amd_plan_tile_part(C.byref(p), 3, flags, t.ctypes.data, None, 0, C.byref(nlit), None, 0, C.byref(nseg))
+        assert total == len(want)
+        lit = np.zeros(nlit.value, np.uint8)
+        segs = np.zeros(nseg.value, SEG)
+        assert L.grk_amd_plan_tile_part(C.byref(p), 3, flags, t.ctypes.data, lit.ctypes.data, lit.size, C.byref(nlit),
+                                        segs.ctypes.data, segs.size, C.byref(nseg)) == total
+        out = np.zeros(total, np.uint8)
+        covered = 0
+        for s in segs:
+            src = coded if s["kind"] else lit
+            out[int(s["dst"]):int(s["dst"]) + int(s["len"])] = src[int(s["src"]):int(s["src"]) + int(s["len"])]
+            covered += int(s["len"])
+        assert covered == total and out.tobytes() == want
