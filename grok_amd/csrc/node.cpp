@@ -367,17 +367,19 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
                     j.rows.assign(table.begin() + i * bpt, table.begin() + (i + 1) * bpt);
                     for (auto& row : j.rows) row.offset += coded_used;
                 }
+                // Tier-2 of these tiles here, on the worker's thread, while their bytes travel (over PCIe to the pinned buffer, or
+                // device to device to the frame's writer): a plan needs the table only
+                for (size_t i = 0; i < mine.size() && rc == GRK_AMD_OK; ++i) {
+                    TileJob& j = jobs[mine[i]];
+                    const int64_t need = plan_tile_part(tp[mine[i]], mine[i], cs_flags, j.rows.data(), j.lit, j.segs);
+                    if (need < 0) rc = (int)need; else { j.part_len = (uint64_t)need; j.planned = true; }
+                }
                 if (!gather) {
-                    for (size_t i = 0; i < mine.size() && rc == GRK_AMD_OK; ++i) {
-                        TileJob& j = jobs[mine[i]];
-                        const int64_t need = plan_tile_part(tp[mine[i]], mine[i], cs_flags, j.rows.data(), j.lit, j.segs);
-                        if (need < 0) rc = (int)need; else { j.part_len = (uint64_t)need; j.planned = true; }
-                    }
                     // the bytes are in the pinned buffer before the next group's encode writes the arena again
                     const int sr = grk_amd_synchronize(w.ctx);
                     if (rc == GRK_AMD_OK) rc = sr;
-                    if (rc) break;
                 }
+                if (rc) break;
                 coded_used += total;
             }
             if (gather && (hipSetDevice(w.device) != hipSuccess || hipStreamSynchronize(w.copy) != hipSuccess)) {      // the last groups' bytes
