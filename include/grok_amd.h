@@ -103,6 +103,9 @@ typedef struct grk_amd_coded_block {
 int  grk_amd_create(int device_id, int verbose, grk_amd_ctx** out);
 void grk_amd_destroy(grk_amd_ctx* ctx);
 const char* grk_amd_version(void);
+/* sha1 over the sources (grok_amd/csrc, include) the library was built from, as __graft_entry__.source_stamp() computes it for a
+ * tree: the test suite compares the two, so that a stale prebuilt library cannot pass for the tree it travels with */
+const char* grk_amd_source_stamp(void);
 const char* grk_amd_last_error(grk_amd_ctx* ctx);
 /* use an externally owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own */
 int  grk_amd_set_stream(grk_amd_ctx* ctx, void* hip_stream);

@@ -42,3 +42,24 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _library_matches_the_tree():
+    """On the GPU box the product libraries are prebuilt artefacts shipped beside the sources: refuse to vouch for a tree with
+    libraries that were made of other sources (the CPU suite checks the same in tests/test_capi_host.py)."""
+    if not _gpu_available():
+        yield
+        return
+    import ctypes as C
+    import importlib.util
+    import grok_amd as G
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    L = G.lib()
+    L.grk_amd_source_stamp.restype = C.c_char_p
+    got, want = L.grk_amd_source_stamp().decode(), ge.source_stamp()
+    if got != want:
+        pytest.exit("grok_amd/lib/libgrok_amd.so was built from other sources (%s) than this tree's (%s): run python __graft_entry__.py" % (got[:12], want[:12]), returncode=3)
+    yield

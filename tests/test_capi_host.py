@@ -147,3 +147,16 @@ def test_native_rccl_host_compiles_and_fails_loudly_without_a_gpu(tmp_path):
         assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
     else:
         assert r.returncode == 3 and "no device" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_loaded_library_was_built_from_this_tree():
+    """The shared libraries are prebuilt, git-ignored artefacts that travel to the GPU box as they are: the
+    library says which sources it was made of, and that has to be the tree the tests run from."""
+    import ctypes as C
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    L = G.lib()
+    L.grk_amd_source_stamp.restype = C.c_char_p
+    assert L.grk_amd_source_stamp().decode() == ge.source_stamp(), "grok_amd/lib/libgrok_amd.so is stale: run python __graft_entry__.py"
