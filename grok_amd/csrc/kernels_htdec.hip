@@ -476,7 +476,17 @@ __global__ __launch_bounds__(64) void ht_dec_ms_kernel(HtDecArgs a, uint32_t raw
     const uint32_t mm = in.missing_msbs;
     const uint32_t p = 30u - mm;
     const bool refined = ht_block_refined(a, blk, mm);
-    const uint16_t* qi = reinterpret_cast<const uint16_t*>(a.quads) + (size_t)blk * kQuadWords;     // K5a's 16 bits per quad
+    // K5a's 16 bits per quad: the block's 2 KB in LDS first (two 16-byte loads per lane, all in flight at once) -- fetched row by row,
+    // one row ahead, every row of the dependent chain waited for an L2 round trip
+    __shared__ __attribute__((aligned(16))) uint16_t qi[kQuadWords];
+    {
+        const uint4* const src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.quads) + (size_t)blk * kQuadWords);
+        const uint32_t n16 = (QH * kQuadStride * 2u + 15u) / 16u;            // 16-byte pieces that hold rows 0 .. QH - 1
+        uint4* const dq = reinterpret_cast<uint4*>(qi);
+        if ((uint32_t)lane < n16) dq[lane] = src[lane];
+        if ((uint32_t)lane + 64u < n16) dq[lane + 64] = src[lane + 64];
+    }
+    __syncthreads();
     const uint32_t q = x >> 1, right = x & 1u;
     uint32_t Eprev = 0;                                   // exponent of this column's bottom sample, row above
     uint32_t bitpos = 0;
