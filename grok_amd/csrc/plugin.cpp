@@ -694,14 +694,21 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
         (h.irreversible && (h.cblk_sty & 0x40u)) || (h.cblk_sty & 0x05u) || h.numresolutions == 0)
         return clean(-1);
     const gra_image_comp& c0 = img->comps[0];
+    // Components: one precision and signedness; sub-sampled components (SIZ XRsiz / YRsiz) as they come -- all alike (every
+    // component then is the same w x h rectangle at ceil(offset / d): one geometry) or each in its own way (4:2:0 ...: every
+    // component its own tile-component, the tree built per component, runs of equal factors decoded together)
+    bool alike = true;
     for (uint16_t k = 0; k < img->numcomps; ++k) {
         const gra_image_comp& ck = img->comps[k];
-        if (ck.dx != 1 || ck.dy != 1 || ck.w != c0.w || ck.h != c0.h || ck.prec != c0.prec || ck.sgnd != c0.sgnd || ck.prec > 16)
+        if (ck.dx < 1 || ck.dy < 1 || ck.dx > 255 || ck.dy > 255 || ck.w == 0 || ck.h == 0 || ck.prec != c0.prec || ck.sgnd != c0.sgnd || ck.prec > 16)
             return clean(-1);
+        alike = alike && ck.dx == c0.dx && ck.dy == c0.dy && ck.w == c0.w && ck.h == c0.h && ck.x0 == c0.x0 && ck.y0 == c0.y0;
     }
+    if (!alike && img->numcomps > 4) return clean(-1);
     grk_amd_tile_params tp{};
-    tp.tile_w = img->x1 - img->x0; tp.tile_h = img->y1 - img->y0; tp.num_comps = img->numcomps;
-    tp.tile_x0 = img->x0; tp.tile_y0 = img->y0;
+    // alike: the tile IS the component rectangle; else: the tile on the reference grid, the components derived from it
+    tp.tile_w = alike ? c0.w : img->x1 - img->x0; tp.tile_h = alike ? c0.h : img->y1 - img->y0; tp.num_comps = img->numcomps;
+    tp.tile_x0 = alike ? c0.x0 : img->x0; tp.tile_y0 = alike ? c0.y0 : img->y0;
     tp.prec = c0.prec; tp.sgnd = c0.sgnd; tp.irreversible = h.irreversible ? 1 : 0; tp.mct = h.mct ? 1 : 0;
     tp.num_levels = (uint8_t)(h.numresolutions - 1);
     uint32_t ew = 0, eh = 0;
@@ -719,10 +726,33 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
     }
     tp.reserved[0] = (h.cblk_sty & 0x40u) ? 0 : 1;         // HT bit clear: classic Part-1 blocks
     tp.reserved[1] = h.cblk_sty & 0x3Fu;
-    const int64_t nb = grk_amd_tile_num_blocks(&tp);
-    if (nb <= 0) return clean(-1);
-    std::vector<grk_amd_block> layout((size_t)nb);
-    if (grk_amd_tile_layout(&tp, layout.data(), (uint64_t)nb, nullptr) != nb) return clean(-1);
+    std::vector<grk_amd_tile_params> cps;                 // !alike: every component's rectangle (num_comps = 1)
+    uint8_t cdx[4] = {1, 1, 1, 1}, cdy[4] = {1, 1, 1, 1};
+    std::vector<grk_amd_block> layout;
+    int64_t nb = 0;
+    if (alike) {
+        nb = grk_amd_tile_num_blocks(&tp);
+        if (nb <= 0) return clean(-1);
+        layout.resize((size_t)nb);
+        if (grk_amd_tile_layout(&tp, layout.data(), (uint64_t)nb, nullptr) != nb) return clean(-1);
+    } else {
+        if (tp.mct) return clean(-1);                     // (a colour transform across component sizes: no encoder writes that)
+        const grk_amd_image_layout iml{tp.tile_x0, tp.tile_y0, tp.tile_x0 + tp.tile_w, tp.tile_y0 + tp.tile_h, tp.tile_x0, tp.tile_y0, tp.tile_w, tp.tile_h};
+        cps.resize(tp.num_comps);
+        for (uint32_t c = 0; c < tp.num_comps; ++c) {
+            const gra_image_comp& ck = img->comps[c];
+            cdx[c] = (uint8_t)ck.dx; cdy[c] = (uint8_t)ck.dy;
+            if (grk_amd_layout_tile_comp(&iml, &tp, ck.dx, ck.dy, 0, &cps[c]) != GRK_AMD_OK) return clean(-1);
+            cps[c].num_comps = 1; cps[c].mct = 0;
+            if (cps[c].tile_w != ck.w || cps[c].tile_h != ck.h) return clean(-1);      // (the host's component is not the rectangle SIZ implies)
+            const int64_t nbc = grk_amd_tile_num_blocks(&cps[c]);
+            if (nbc <= 0) return clean(-1);
+            const size_t at = layout.size();
+            layout.resize(at + (size_t)nbc);
+            if (grk_amd_tile_layout(&cps[c], layout.data() + at, (uint64_t)nbc, nullptr) != nbc) return clean(-1);
+            nb += nbc;
+        }
+    }
     // a tree whose blocks own buffers the host can copy into: nominal block area x 4 bytes, as the host allocates
     // for its own code-blocks (t1/T1Structs.cpp:292-307)
     // The host copies getSegBuffersLen() bytes into a block's buffer without asking how large it is
@@ -748,8 +778,8 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
             band_numbps.push_back((uint8_t)v);
         }
     }
-    TileOwner* const owner = acquire_owner(tp);
-    if (owner) owner->served_decode = true;
+    TileOwner* const owner = alike ? acquire_owner(tp) : make_owner(tp, &cps);
+    if (owner) { owner->served_decode = true; owner->no_cache = !alike; }
     if (!owner || !owner->ensure_coded(g_ctx, cap + sh.file_size + 64)) { release_owner(owner); return clean(-1); }
     std::memset(owner->coded, 0, cap + sh.file_size + 64);
     owner->table = slots;
@@ -771,13 +801,20 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
         for (size_t i = 0; i < (size_t)nb; ++i)
             if (bl[i].compressedDataLength > slot_cap[i]) return done(-1);       // overran its slot: the CPU decoder takes it
     }
-    const size_t bps = (tp.prec + 7u) / 8u, npx = (size_t)tp.tile_w * tp.tile_h;
-    std::vector<uint8_t> px(npx * tp.num_comps * bps);
-    if (grk_amd_plugin_tile_decode_qcd(g_ctx, &tp, tree, band_numbps.empty() ? nullptr : band_numbps.data(),
-                                       (uint32_t)band_numbps.size(), px.data(), 0) != GRK_AMD_OK) return done(-1);
+    const size_t bps = (tp.prec + 7u) / 8u;
+    std::vector<size_t> plane_at(tp.num_comps + 1u, 0);
+    for (uint32_t c = 0; c < tp.num_comps; ++c)
+        plane_at[c + 1] = plane_at[c] + (alike ? (size_t)tp.tile_w * tp.tile_h : (size_t)cps[c].tile_w * cps[c].tile_h) * bps;
+    std::vector<uint8_t> px(plane_at[tp.num_comps]);
+    const int drc = alike ? grk_amd_plugin_tile_decode_qcd(g_ctx, &tp, tree, band_numbps.empty() ? nullptr : band_numbps.data(),
+                                                           (uint32_t)band_numbps.size(), px.data(), 0)
+                          : grk_amd_plugin_tile_decode_subsampled(g_ctx, &tp, cdx, cdy, tree, band_numbps.empty() ? nullptr : band_numbps.data(),
+                                                                  (uint32_t)band_numbps.size(), px.data());
+    if (drc != GRK_AMD_OK) return done(-1);
     img = info.image ? info.image : img;
     for (uint16_t k = 0; k < img->numcomps; ++k) {
         gra_image_comp& ck = img->comps[k];
+        const uint32_t pw = alike ? tp.tile_w : cps[k].tile_w;
         if (!ck.data) {                                   // the host skipped post-T1, so nothing was allocated
             ck.stride = (ck.w + 31u) & ~31u;
             void* mem = nullptr;
@@ -786,7 +823,7 @@ int32_t decompress_file(void* params, DecodeUserCallback cb, const char* in_path
         }
         for (uint32_t y = 0; y < ck.h; ++y) {
             int32_t* dst = ck.data + (size_t)y * ck.stride;
-            const uint8_t* src = px.data() + ((size_t)k * npx + (size_t)y * tp.tile_w) * bps;
+            const uint8_t* src = px.data() + plane_at[k] + (size_t)y * pw * bps;
             for (uint32_t x = 0; x < ck.w; ++x) {
                 if (bps == 1) dst[x] = tp.sgnd ? (int32_t)(int8_t)src[x] : (int32_t)src[x];
                 else { uint16_t v; std::memcpy(&v, src + 2 * x, 2); dst[x] = tp.sgnd ? (int32_t)(int16_t)v : (int32_t)v; }
@@ -925,22 +962,62 @@ GRA_EXPORT int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_p
     return grk_amd_plugin_tile_decode_qcd(ctx, p, tile, nullptr, 0, pixels, pixels_on_device);
 }
 
+// components [comp0, comp0 + p->num_comps) of the tree, which all have p's geometry (the whole tree: comp0 = 0)
+static int decode_tree_comps(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile, uint32_t comp0,
+                             const uint8_t* band_numbps, uint32_t nbands, void* pixels, int pixels_on_device);
+
 GRA_EXPORT int grk_amd_plugin_tile_decode_qcd(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
                                               const uint8_t* band_numbps, uint32_t nbands, void* pixels, int pixels_on_device)
 {
     if (!ctx || !p || !tile || !pixels) return GRK_AMD_ERR_INVALID;
+    if (tile->numComponents != p->num_comps) return GRK_AMD_ERR_INVALID;
+    return decode_tree_comps(ctx, p, tile, 0, band_numbps, nbands, pixels, pixels_on_device);
+}
+
+// The decode counterpart of grk_amd_plugin_tile_create_subsampled: `p` = the tile on the reference grid, component c of the tree has
+// the geometry of [ceil(x0 / dx_c), ceil(x1 / dx_c)) x ...; `planes` receives the components back to back, each tight at its own size.
+// Runs of components with equal factors are decoded together (the inverse colour transform only for a run that holds components
+// 0..2 of a stream that signals it -- an encoder cannot have applied it across sizes).
+GRA_EXPORT int grk_amd_plugin_tile_decode_subsampled(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const uint8_t* comp_dx,
+                                                     const uint8_t* comp_dy, const gra_plugin_tile* tile, const uint8_t* band_numbps,
+                                                     uint32_t nbands, void* planes)
+{
+    if (!ctx || !p || !comp_dx || !comp_dy || !tile || !planes || tile->numComponents != p->num_comps) return GRK_AMD_ERR_INVALID;
+    const uint32_t nc = p->num_comps, bps = (p->prec + 7u) / 8u;
+    const grk_amd_image_layout im{p->tile_x0, p->tile_y0, p->tile_x0 + p->tile_w, p->tile_y0 + p->tile_h, p->tile_x0, p->tile_y0, p->tile_w, p->tile_h};
+    size_t at = 0;
+    for (uint32_t c0 = 0; c0 < nc;) {
+        uint32_t n = 1;
+        while (c0 + n < nc && comp_dx[c0 + n] == comp_dx[c0] && comp_dy[c0 + n] == comp_dy[c0]) ++n;
+        grk_amd_tile_params pr;
+        int rc = grk_amd_layout_tile_comp(&im, p, comp_dx[c0], comp_dy[c0], 0, &pr);
+        if (rc) return rc;
+        pr.num_comps = (uint16_t)n;
+        pr.mct = (p->mct && c0 == 0 && n >= 3) ? 1 : 0;
+        if (p->mct && c0 == 0 && n < 3 && nc >= 3) return GRK_AMD_ERR_UNSUPPORTED;     // (a colour transform across sizes: no encoder writes that)
+        rc = decode_tree_comps(ctx, &pr, tile, c0, band_numbps, nbands, (uint8_t*)planes + at, 0);
+        if (rc) return rc;
+        at += (size_t)pr.tile_w * pr.tile_h * n * bps;
+        c0 += n;
+    }
+    return GRK_AMD_OK;
+}
+
+static int decode_tree_comps(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile, uint32_t comp0,
+                             const uint8_t* band_numbps, uint32_t nbands, void* pixels, int pixels_on_device)
+{
     if (band_numbps && nbands != 3u * p->num_levels + 1u) return GRK_AMD_ERR_INVALID;
     const int64_t nb = grk_amd_tile_num_blocks(p);
     if (nb <= 0) return (int)(nb ? nb : GRK_AMD_ERR_UNSUPPORTED);
     std::vector<grk_amd_block> layout((size_t)nb);
     if (grk_amd_tile_layout(p, layout.data(), (uint64_t)nb, nullptr) != nb) return GRK_AMD_ERR_INVALID;
-    if (tile->numComponents != p->num_comps) return GRK_AMD_ERR_INVALID;
+    if (comp0 + p->num_comps > tile->numComponents) return GRK_AMD_ERR_INVALID;
     // walk the tree in the enumeration order both sides share: comp -> resolution -> band -> precinct -> block
     std::vector<grk_amd_coded_block> table((size_t)nb);
     std::vector<uint8_t> coded;
     std::vector<float> steps;            // irreversible: the bands' step sizes; the host's synch stores half (plugin_bridge.cpp:40)
     size_t i = 0;
-    for (uint32_t c = 0; c < tile->numComponents; ++c) {
+    for (uint32_t c = comp0; c < comp0 + p->num_comps; ++c) {
         const gra_plugin_tile_component* tc = tile->tileComponents[c];
         for (uint32_t r = 0; r < tc->numResolutions; ++r) {
             const gra_plugin_resolution* res = tc->resolutions[r];

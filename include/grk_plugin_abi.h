@@ -314,6 +314,12 @@ int grk_amd_plugin_tile_decode(grk_amd_ctx* ctx, const grk_amd_tile_params* p, c
 int grk_amd_plugin_tile_decode_qcd(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const gra_plugin_tile* tile,
                                    const uint8_t* band_numbps, uint32_t nbands, void* pixels, int pixels_on_device);
 
+/* ... and for a tree whose components are sub-sampled each in its own way (the decode counterpart of
+ * grk_amd_plugin_tile_create_subsampled): `p` = the tile on the reference grid, `planes` (host) receives the components back to back,
+ * each tight at its own size. */
+int grk_amd_plugin_tile_decode_subsampled(grk_amd_ctx* ctx, const grk_amd_tile_params* p, const uint8_t* comp_dx, const uint8_t* comp_dy,
+                                          const gra_plugin_tile* tile, const uint8_t* band_numbps, uint32_t nbands, void* planes);
+
 #ifdef __cplusplus
 }
 #endif

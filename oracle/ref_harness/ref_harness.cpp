@@ -637,6 +637,15 @@ static int32_t host_decompress_callback(grk_plugin_decompress_callback_info* inf
 			return 0;
 		}
 		if (img->numcomps != g_dcb_C) return 1;
+		if (getenv("REF_COMP_SUBSAMPLING")) {      // components of their own sizes, back to back (room for C x H x W)
+			int32_t* dst = g_dcb_out;
+			for (int k = 0; k < g_dcb_C; ++k) {
+				auto comp = img->comps + k;
+				if ((int)comp->w > g_dcb_W || (int)comp->h > g_dcb_H || !comp->data) return 1;
+				for (uint32_t y = 0; y < comp->h; ++y, dst += comp->w) memcpy(dst, comp->data + (size_t)y * comp->stride, (size_t)comp->w * 4);
+			}
+			return 0;
+		}
 		for (int k = 0; k < g_dcb_C; ++k) {
 			auto comp = img->comps + k;
 			if ((int)comp->w != g_dcb_W || (int)comp->h != g_dcb_H || !comp->data) return 1;

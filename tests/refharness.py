@@ -294,6 +294,28 @@ def plugin_decompress(j2k, Cn, H, W, as_file=True):
     return (out if rc == 0 else int(rc)), [int(v) for v in stages]
 
 
+def plugin_decompress_planes(j2k, sampling, W, H):
+    """plugin_decompress for a stream whose components are sub-sampled each in its own way -> ([(h_c, w_c) int32], stages) or
+    (refusal code, stages)."""
+    keep = os.environ.get("REF_COMP_SUBSAMPLING")
+    os.environ["REF_COMP_SUBSAMPLING"] = ",".join("%d,%d" % s for s in sampling)
+    try:
+        out, stages = plugin_decompress(j2k, len(sampling), H, W)
+    finally:
+        if keep is None:
+            os.environ.pop("REF_COMP_SUBSAMPLING", None)
+        else:
+            os.environ["REF_COMP_SUBSAMPLING"] = keep
+    if isinstance(out, int):
+        return out, stages
+    flat, res, at = out.reshape(-1), [], 0
+    for dx, dy in sampling:
+        w, h = (W + dx - 1) // dx, (H + dy - 1) // dy
+        res.append(flat[at:at + w * h].reshape(h, w).copy())
+        at += w * h
+    return res, stages
+
+
 def plugin_batch_decompress(in_dir, out_dir, timeout_s=60):
     L = lib()
     L.ref_plugin_batch_decompress.restype = C.c_int32

@@ -94,3 +94,48 @@ def test_subsampled_tile_tree_through_grk_compress_with_plugin(W, H, sampling, p
     finally:
         Lp.grk_amd_plugin_tile_destroy(tile)
     assert n > 0 and out[:n].tobytes() == want
+
+
+@pytest.mark.parametrize("W,H,sampling,prec,L,ht,irrev", [(256, 192, [(1, 1), (2, 2), (2, 2)], 8, 4, 1, 0), (300, 200, [(1, 1), (2, 1), (2, 1)], 8, 3, 1, 0),
+                                                          (200, 150, [(1, 1), (2, 2), (2, 2), (1, 1)], 12, 3, 1, 0),
+                                                          (256, 192, [(1, 1), (2, 2), (2, 2)], 8, 4, 0, 0), (320, 200, [(1, 1), (2, 2), (2, 2)], 10, 3, 0, 1)])
+def test_subsampled_stream_through_the_decode_protocol(W, H, sampling, prec, L, ht, irrev, monkeypatch):
+    """grk_plugin_decompress of a stream with sub-sampled components (HT and classic blocks, lossless and 9/7): the host runs Tier-2
+    into a tile tree that carries every component's own geometry, the GPU decodes the runs of equal factors, the planes ==
+    grk_decompress's on the CPU (== the source when lossless)."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    planes = _planes(W, H, sampling, prec, seed=9)
+    monkeypatch.setenv("REF_COMP_SUBSAMPLING", ",".join("%d,%d" % s for s in sampling))
+    monkeypatch.setenv("REF_TCP_MCT", "0")
+    import ctypes as C
+    Lr = R.lib()
+    flat = np.concatenate([pl.reshape(-1) for pl in planes])
+    cfg = R.EncCfg(len(sampling), W, H, W, H, prec, irrev, L + 1, ht, 1, 0, 0, 0, 0)
+    out = np.zeros(flat.size * flat.itemsize * 4 + (1 << 20), np.uint8)
+    secs = C.c_double(0)
+    n = Lr.ref_encode(C.byref(cfg), flat.ctypes.data, out.ctypes.data, out.size, C.byref(secs), None)
+    assert n > 0
+    cs = out[:n].tobytes()
+    want = R.decode_planes(cs, sampling, W, H)
+    got, stages = R.plugin_decompress_planes(cs, sampling, W, H)
+    assert not isinstance(got, int), "plugin refused: %s (stages %s)" % (got, stages)
+    for a, b, src in zip(got, want, planes):
+        assert np.array_equal(a, b)
+        if not irrev:
+            assert np.array_equal(a, src.astype(np.int32))
+
+
+@pytest.mark.parametrize("sub", [(2, 2), (2, 1), (3, 2)])
+def test_uniformly_subsampled_stream_through_the_decode_protocol(sub, monkeypatch):
+    """... and grk_compress -s dx,dy streams (every component sub-sampled alike): one geometry, the component rectangle."""
+    assert R.plugin_load() == 1
+    assert R.plugin_init(0) == 1
+    monkeypatch.setenv("REF_SUBSAMPLING", "%d,%d" % sub)
+    for Cn, H, W, prec in ((3, 191, 255, 8), (1, 80, 300, 12)):
+        px = synth.g2(Cn, H, W, prec)
+        TW, TH = (W - 1) * sub[0] + 1, (H - 1) * sub[1] + 1
+        cs, _ = R.encode(px, prec, TW=TW, TH=TH, numres=5, mode=1)
+        got, stages = R.plugin_decompress(cs, Cn, H, W)
+        assert not isinstance(got, int), "plugin refused: %s (stages %s)" % (got, stages)
+        assert np.array_equal(got, px.astype(np.int32))
