@@ -814,14 +814,32 @@ def start_gather_watchdog(timeout, out, emit, rc):
     return dog
 
 
+_JSON_FD = None          # the process's original stdout, when fd 1 has been pointed at stderr (_own_stdout)
+
+
+def _own_stdout():
+    """RCCL writes a version banner to stdout through C stdio when its first communicator is made: from here on everything that goes
+    to fd 1 lands on stderr, and the JSON line alone is written to the original stdout (_emit) -- ONE line, as the contract says."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
 def _emit(o):
-    # RCCL writes a version banner to stdout through C stdio: flush that first so that the JSON line is the LAST line on stdout
     try:
         C.CDLL(None).fflush(None)
     except Exception:
         pass
     if o is not None:
-        print(json.dumps(o), flush=True)
+        line = json.dumps(o) + "\n"
+        if _JSON_FD is None:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stdout.flush()
+            os.write(_JSON_FD, line.encode())
 
 
 def dry_run(world, rank, args):
@@ -916,6 +934,7 @@ def main():
     # GROK_AMD_FORCE_DIST=1 exercises the exchange step on a 1-GPU box (world_size 1 over RCCL)
     use_dist = world > 1 or os.environ.get("GROK_AMD_FORCE_DIST") == "1"
     if use_dist:
+        _own_stdout()
         # RCCL's footprint, bounded unless the caller says otherwise: a gather is a point-to-point transfer over ONE xGMI link pair, depth
         # of them run side by side on communicators of their own next to a coder that wants every CU -- a channel is a workgroup
         # that holds a CU, and the default (up to 32 per communicator) is sized for ring collectives over all links at once

@@ -33,6 +33,9 @@ CASES = [
     (256, 256, [(2, 2), (2, 2), (2, 2)], 8, 4, None, 1, {}),                        # all alike: one run, MCT stays
     (384, 256, [(1, 1), (2, 2), (2, 2)], 8, 4, None, 0, {"REF_PROG_ORDER": "3", "REF_CSTY": "6"}),
     (384, 256, [(1, 1), (2, 2), (2, 2)], 8, 4, (192, 128), 0, {"REF_PROG_ORDER": "4", "REF_PRECINCTS": "128,128,64,64"}),
+    (256, 192, [(1, 1), (2, 2), (2, 2)], 16, 3, None, 0, {}),                       # 16-bit samples
+    (1920, 1080, [(1, 1), (2, 2), (2, 2)], 8, 5, None, 0, {}),                      # a 1080p 4:2:0 frame
+    (259, 131, [(1, 1), (4, 1), (1, 4)], 8, 2, (100, 70), 0, {}),                   # odd factors, ragged tiles
 ]
 
 
