@@ -34,6 +34,7 @@
 // the order of WaveletFwd.cpp:143-160; scaling low*invK, high*K as in :46, :203-213.
 #include "kernels.h"
 #include "pk16.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace grk_amd {
@@ -177,7 +178,11 @@ __device__ __forceinline__ void color_fwd_px(int32_t& c0, int32_t& c1, int32_t& 
 //   (saves 8 of the 8 + b_in + 4 bytes per sample that K1 + level 0 move separately).
 // H16 (reversible only): the planes this level reads (PX = 0) and writes hold int16 coefficients -- half the bytes
 //   of the int32 working type; the caller guarantees the range (context.hip: planes16_ok).
-template <bool F97, int NC, int PX, bool H16 = false>
+// GEN = false: the instance for levels the launcher knows to be even (on the origin, even width >= 4, even height >= 16), whose
+//   every strip takes a FAST path -- without the general path in the kernel the three-component 9/7 level 0 needs 83 registers
+//   instead of 124 (the 5/3 one 84 instead of 99): five waves per SIMD, and room on a SIMD whose other waves are the block
+//   coder's ROOM instance (kernels_ht.hip) -- the pairing that cfg3's pipeline lacked.
+template <bool F97, int NC, int PX, bool H16 = false, bool GEN = true>
 __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
 {
     static_assert(!(F97 && H16), "16-bit planes are for the reversible transform");
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     const bool interior = c_first >= 0 && (uint32_t)c_first + kCols <= cw && (bx + 1) * kOutPairs <= dw;
     if (even && interior) strip(std::true_type{}, std::false_type{});
     else if (even) strip(std::true_type{}, std::true_type{});
-    else strip(std::false_type{}, std::false_type{});
+    else if constexpr (GEN) strip(std::false_type{}, std::false_type{});
 }
 
 // ---- the 5/3 level on packed int16 pairs, four columns per lane ------------------------------------------------------
@@ -739,7 +744,11 @@ hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint
         DwtLevelArgs a = a0;
         a.comp0 = comp0; a.zdiv = zdiv; a.ncomp = ncomp;
         dim3 grid((a.cw + a.px + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, ntiles * zdiv);
-#define GRK_L0(F97, NC, PX) hipLaunchKernelGGL((dwt_level_kernel<F97, NC, PX>), grid, block, 0, s, a)
+        // (what the kernel calls `even`: every strip of the level takes a FAST path)
+        static const bool only_fast_ok = !(getenv("GRK_AMD_DWT_FAST_ONLY") && atoi(getenv("GRK_AMD_DWT_FAST_ONLY")) == 0);   // (=0: A/B runs)
+        const bool all_fast = only_fast_ok && (a.px | a.py) == 0 && (a.cw & 1u) == 0 && a.cw >= 4 && a.ch >= 16 && (a.ch & 1u) == 0;
+#define GRK_L0(F97, NC, PX) do { if (all_fast) hipLaunchKernelGGL((dwt_level_kernel<F97, NC, PX, false, false>), grid, block, 0, s, a); \
+                                 else hipLaunchKernelGGL((dwt_level_kernel<F97, NC, PX>), grid, block, 0, s, a); } while (0)
         const int px = a.px_bytes == 1 ? 1 : 2;
         if (a.irreversible) {
             if (nc == 3) { if (px == 1) GRK_L0(true, 3, 1); else GRK_L0(true, 3, 2); }

@@ -1532,6 +1532,8 @@ hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hip
         // (the packed 8-bit kernel first: its place in the code object does not move when the others change)
         if (a.h16 && !a.irreversible && a.room) hipLaunchKernelGGL((ht_encode_kernel<false, true, true>), dim3(grid), dim3(64), shmem, s, b, L, k);
         else if (a.h16 && !a.irreversible)      hipLaunchKernelGGL((ht_encode_kernel<false, true, false>), dim3(grid), dim3(64), shmem, s, b, L, k);
+        // (r06: a ROOM instance of the 32-bit kernels was measured beside the level-0 DWT that now fits the registers it would leave
+        //  -- kernels_dwt.hip GEN = false, 83 / 84 registers --: cfg3's step 0.640 / 0.647 without, 0.642 / 0.645 with: not kept)
         else if (a.irreversible)                hipLaunchKernelGGL((ht_encode_kernel<true, false, false>), dim3(grid), dim3(64), shmem, s, b, L, k);
         else                                    hipLaunchKernelGGL((ht_encode_kernel<false, false, false>), dim3(grid), dim3(64), shmem, s, b, L, k);
         // the blocks that outgrew the capped buffers: a small fixed grid walks the list (with nothing on it -- natural
