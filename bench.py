@@ -447,7 +447,7 @@ def cfg5_sequence_child(fcs, fref, S, device):
     ctx = G.Context(device)
     ctx.set_decode_qcd([(e << 11) | m for e, m in info["qcd"]])
     d_c = torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(dev)
-    res = cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, (2, 3, 6))
+    res = cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, (2, 4, 8))
     res["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
     print(json.dumps(res))
 
@@ -551,11 +551,11 @@ def extra_workloads(ctx, dev, stream, steps, cfg5, cpu_md5s=None):
             ctx.enable_timing(False)
             # a SEQUENCE of such frames through the one context, several in flight (grk_amd_set_decode_pipelining): the later frames'
             # lane waves and long chains run beside the first's -- chain-bound kernels leave most of the machine's issue slots free.
-            # Two and six in flight here, on the HIP runtime's default 4 hardware queues and beside every other stream this process
+            # Two, four and eight in flight here (r06: a frame's block decoding is ONE launch on one stream), on the HIP runtime's default 4 hardware queues and beside every other stream this process
             # has made (streams that share a queue run in turn); the same in a child process of this one started with
             # GPU_MAX_HW_QUEUES=8 -- process-wide, read at the runtime's start, and a setting the encode-over-RCCL path does not
             # like, so it is the host's to make (profiles/r04_hw_queues.txt)
-            seq5 = cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, (2, 6))
+            seq5 = cfg5_sequence(ctx, dev, p5, table, d_c, ref5, S, (2, 4, 8))
             seq5["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")
             try:
                 import subprocess

@@ -937,6 +937,13 @@ int run_t1_decode(grk_amd_ctx* c, uint32_t ntiles, grk_amd_ctx::DecUpload* up, c
         la.mallat = a.mallat; la.stride = a.stride; la.pitch = a.pitch; la.irreversible = a.irreversible;
         la.pass_sync = c->t1_pass_sync ? 1 : 0;
         a.list = d_lane + 2 * nblocks; a.count = n_tail;
+        // one launch, one stream (r06): the long chains are the launch's first workgroups, the lane waves follow; a decode SEQUENCE then
+        // needs one hardware queue per frame in flight instead of two (GRK_AMD_T1_FUSED=0: two launches on two streams, as r04-r05)
+        static const bool fused_t1 = !(getenv("GRK_AMD_T1_FUSED") && atoi(getenv("GRK_AMD_T1_FUSED")) == 0);
+        if (fused_t1 && n_tail) {
+            HIP_TRY(c, launch_t1_fused(a, la, c->stream), "launch Part-1 decode (both decoders)");
+            return GRK_AMD_OK;
+        }
         if (c->overlap && c->side) {
             // the long chains on the call's stream, the lanes beside them on the side stream
             if (!c->ev_dec_front) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_dec_front, hipEventDisableTiming), "create event");

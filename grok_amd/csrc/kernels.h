@@ -172,6 +172,8 @@ struct T1LaneArgs {
 };
 constexpr uint32_t kT1NoBlock = 0xFFFFFFFFu;   // list entry of a lane without a block
 hipError_t launch_t1_lanes(const T1LaneArgs& a, hipStream_t s);       // t1_lanes_kernel, then t1_recon_kernel
+// both decoders in ONE launch (the blocks of d.list first, then the lane waves), then t1_recon_kernel: a frame's block decoding on one stream
+hipError_t launch_t1_fused(const T1DecArgs& d, const T1LaneArgs& a, hipStream_t s);
 
 // ---- K6: one inverse DWT level, horizontal + vertical fused (kernels_idwt.hip) ------------------
 struct IdwtLevelArgs {

@@ -393,15 +393,17 @@ __device__ __forceinline__ void dense_run_half(DenseRun& r, uint32_t tabv, uint3
 
 constexpr uint32_t kNarrowPlanes = 14;
 
+// (the kernel's body as a device function: kernels_t1lanes.hip includes this file -- GRK_T1_FUSED_INCLUDE -- and runs it as the first
+//  workgroups of ONE launch that also holds the lane decoder's waves: a frame's block decoding on one stream)
 template <bool IRREV>
-__global__ void t1_dec_kernel(T1DecArgs a)
+__device__ __forceinline__ void t1_dec_block(const T1DecArgs& a, const uint32_t bidx)
 {
     __shared__ uint64_t bm_l[4][66];
     const uint32_t tabv0 = threadIdx.x < 47 ? g_mq_table[threadIdx.x] : 0u;       // Table C.2 across the lanes
     // all 64 lanes run the same (uniform) program -- lane-resident tables need every lane's registers to stay live
     // through the compiler's copies -- and only lane 0 performs the side effects
     const bool writer = threadIdx.x == 0;
-    const uint32_t blk = a.list ? a.list[blockIdx.x] : blockIdx.x;
+    const uint32_t blk = a.list ? a.list[bidx] : bidx;
     if (blk >= a.nblocks) return;
     // beside the lane decoder this kernel holds the frame's longest chains: its waves win the issue arbitration of their SIMDs
     if (a.list) __builtin_amdgcn_s_setprio(3);
@@ -700,8 +702,14 @@ __global__ void t1_dec_kernel(T1DecArgs a)
     }
 }
 
+#ifndef GRK_T1_FUSED_INCLUDE
+template <bool IRREV>
+__global__ void t1_dec_kernel(T1DecArgs a) { t1_dec_block<IRREV>(a, blockIdx.x); }
+#endif
+
 } // namespace
 
+#ifndef GRK_T1_FUSED_INCLUDE
 hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s)
 {
     const uint32_t n = a.list ? a.count : a.nblocks;
@@ -710,5 +718,6 @@ hipError_t launch_t1_decode(const T1DecArgs& a, hipStream_t s)
     else hipLaunchKernelGGL(t1_dec_kernel<false>, dim3(n), dim3(64), 0, s, a);
     return hipGetLastError();
 }
+#endif
 
 } // namespace grk_amd

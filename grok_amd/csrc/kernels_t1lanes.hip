@@ -13,6 +13,10 @@
 #include "kernels.h"
 #include "t1_lanes.h"
 #include <type_traits>
+// the wave-per-block decoder's body (t1_dec_block) for the fused launch below
+#define GRK_T1_FUSED_INCLUDE
+#include "kernels_t1dec.hip"
+#undef GRK_T1_FUSED_INCLUDE
 
 #ifndef T1L_ROUND_STEPS
 #define T1L_ROUND_STEPS 6        // steps between two stripe hand-overs (4, 6 or 8: fewer hand-over passes, lanes wait longer for theirs)
@@ -30,10 +34,10 @@ struct LaneTables {
     uint16_t sc[256];
     constexpr LaneTables() : mq{}, zc{}, sc{}
     {
-        for (uint32_t e = 0; e < 94; ++e) mq[e] = mq_entry(e);
+        for (uint32_t e = 0; e < 94; ++e) mq[e] = t1l::mq_entry(e);
         for (int o = 0; o < 4; ++o)
-            for (uint32_t i = 0; i < 512; ++i) zc[o][i] = (uint16_t)(zc_context9(o, i) * 256u);
-        for (uint32_t i = 0; i < 256; ++i) sc[i] = (uint16_t)sign_context(i);
+            for (uint32_t i = 0; i < 512; ++i) zc[o][i] = (uint16_t)(t1l::zc_context9(o, i) * 256u);
+        for (uint32_t i = 0; i < 256; ++i) sc[i] = (uint16_t)t1l::sign_context(i);
     }
 };
 static_assert(sizeof(LaneTables) == kLdsBytes - kCtxBytes, "the tables follow the context rows in LDS");
@@ -44,7 +48,7 @@ __device__ const LaneTables g_lane_tables{};
 // (188 vector registers, two waves per SIMD.  A version with packed lane state -- 124 / 154 registers -- was measured and lost
 //  15 % to the extra instructions: profiles/r04_hw_queues.txt; the limit of a decode sequence was the hardware queues.)
 template <bool SYNC>
-__global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
+__device__ __forceinline__ void t1_lanes_wave(const T1LaneArgs& a, const uint32_t wave)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds32[kLdsBytes / 4];
     uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds32);
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
 #pragma unroll
     for (uint32_t cx = 0; cx < 19; ++cx) lds32[cx * 64 + lane] = mq_entry(cx == 18 ? 46u : cx == 17 ? 3u : cx == 0 ? 4u : 0u);
     Lane L;
-    const uint32_t idx = blockIdx.x * 64u + lane;
+    const uint32_t idx = wave * 64u + lane;
     const uint32_t blk = idx < a.count ? a.list[idx] : kT1NoBlock;
     if (blk != kT1NoBlock) {
         const HtDecBlock in = a.table[blk];
@@ -118,6 +122,19 @@ __global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a)
     }
 }
 
+template <bool SYNC>
+__global__ __launch_bounds__(64) void t1_lanes_kernel(T1LaneArgs a) { t1_lanes_wave<SYNC>(a, blockIdx.x); }
+
+// ONE launch for a frame's block decoding (r06): workgroups [0, d.count) are the wave-per-block decoder's blocks -- the long chains, so
+// they start first --, the rest the lane decoder's waves.  Two launches on two streams (r04-r05) cost a frame in a decode SEQUENCE two of
+// the runtime's four hardware queues per priority level; streams that share a queue run their kernels in turn.
+template <bool IRREV, bool SYNC>
+__global__ __launch_bounds__(64) void t1_fused_kernel(T1DecArgs d, T1LaneArgs l)
+{
+    if (blockIdx.x < d.count) t1_dec_block<IRREV>(d, blockIdx.x);
+    else t1_lanes_wave<SYNC>(l, blockIdx.x - d.count);
+}
+
 // One wave per block.  Lane y first loads ROW y of every bitmap the block left (coalesced 512-byte loads, all in flight at once:
 // the sign rows and, per bit-plane, the significance rows at the end of the plane and the mag-ref bits); then the wave goes through
 // the rows, lane x taking bit x of each row's words as they are broadcast from lane y (v_readlane) -- no memory access on the chain.
@@ -173,6 +190,22 @@ __global__ __launch_bounds__(64) void t1_recon_kernel(T1LaneArgs a)
 }
 
 } // namespace
+
+hipError_t launch_t1_fused(const T1DecArgs& d, const T1LaneArgs& a, hipStream_t s)
+{
+    if (!a.count || !d.count || !d.list) return hipErrorInvalidValue;
+    const uint32_t grid = d.count + (a.count + 63u) / 64u;
+    if (d.irreversible) {
+        if (a.pass_sync) hipLaunchKernelGGL((t1_fused_kernel<true, true>), dim3(grid), dim3(64), 0, s, d, a);
+        else hipLaunchKernelGGL((t1_fused_kernel<true, false>), dim3(grid), dim3(64), 0, s, d, a);
+    } else {
+        if (a.pass_sync) hipLaunchKernelGGL((t1_fused_kernel<false, true>), dim3(grid), dim3(64), 0, s, d, a);
+        else hipLaunchKernelGGL((t1_fused_kernel<false, false>), dim3(grid), dim3(64), 0, s, d, a);
+    }
+    if (a.irreversible) hipLaunchKernelGGL(t1_recon_kernel<true>, dim3(a.count), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_recon_kernel<false>, dim3(a.count), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_t1_lanes(const T1LaneArgs& a, hipStream_t s)
 {
