@@ -716,6 +716,26 @@ def node_native(dev, tile, prec, levels, d_px, cpu_file_md5=None):
                         import hashlib
                         row["file_equals_cpu_encode"] = bool(row.get("file_equals_cpu_encode", True) and hashlib.md5(cs).hexdigest() == cpu_file_md5)
             row["codestream_bytes"] = int(len(cs))
+            # the same frame into a PINNED output buffer (grk_amd_host_alloc): the assembled tile-parts cross the link straight to
+            # their places in the file, no host copy at all
+            try:
+                pin_ctx = G.Context(d)
+                pin = pin_ctx.host_array(out_buf.size)
+            except Exception:  # noqa: BLE001
+                pin = None
+            if pin is not None:
+                def once_pin():
+                    return node.encode_image_device(layout, base, d_px.data_ptr(), d_px.numel(), d, 0, out=pin)
+                cs = once_pin()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    cs = once_pin()
+                row["parallel_writers_device_pixels_pinned_out_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+                if T == W and cpu_file_md5:
+                    import hashlib
+                    row["file_equals_cpu_encode"] = bool(row.get("file_equals_cpu_encode", True) and hashlib.md5(cs).hexdigest() == cpu_file_md5)
+                del pin, pin_ctx
+            row["tier2"] = "host plan (GRK_AMD_NODE_T2=host)" if os.environ.get("GRK_AMD_NODE_T2") == "host" else "device (grk_amd_assemble_device)"
             res[name] = row
             node.close()
         except Exception as e:  # noqa: BLE001

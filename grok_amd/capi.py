@@ -395,6 +395,29 @@ class Context:
             self._check(self._L.grk_amd_fetch_coded(self._h, coded.ctypes.data, nbytes), "fetch_coded")
         return coded
 
+    def assemble_device(self, params, tile_index, flags=0, dst_offset=0):
+        """Tier-2 on the device for the latest encode_tiles call (grk_amd_assemble_device) -> (bytes assembled, [tile-part lengths])."""
+        idx = np.ascontiguousarray(np.asarray(tile_index, np.uint32))
+        lens = np.zeros(idx.size, np.uint32)
+        self._L.grk_amd_assemble_device.restype = C.c_int64
+        self._L.grk_amd_assemble_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        n = self._L.grk_amd_assemble_device(self._h, C.addressof(params), idx.size, idx.ctypes.data, flags, dst_offset, lens.ctypes.data)
+        if n < 0:
+            raise RuntimeError("assemble_device failed: %d (%s)" % (n, self._L.grk_amd_last_error(self._h).decode()))
+        return int(n), lens
+
+    def fetch_assembled(self, offset, nbytes):
+        out = np.empty(nbytes, np.uint8)
+        self._L.grk_amd_fetch_assembled.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        if nbytes:
+            self._check(self._L.grk_amd_fetch_assembled(self._h, offset, nbytes, out.ctypes.data), "fetch_assembled")
+        return out
+
+    def assembled_device_ptr(self):
+        self._L.grk_amd_assembled_device_ptr.restype = C.c_void_p
+        self._L.grk_amd_assembled_device_ptr.argtypes = [C.c_void_p]
+        return self._L.grk_amd_assembled_device_ptr(self._h)
+
     def coded_device_ptr(self):
         return self._L.grk_amd_coded_device_ptr(self._h)
 

@@ -141,6 +141,15 @@ struct grk_amd_ctx {
     bool planes16 = true;                                   // int16 planes between K2 and K3 where the range allows (GRK_AMD_PLANES16=0: never)
     DevBuf ht_sel;
     DevBuf energy;                   // grk_amd_block_distortion: sum of q^2 per block
+    // Tier-2 on the device (grk_amd_assemble_device): the packets of the geometry in the order last asked for, scratch, and the
+    // finished tile-parts
+    struct T2State {
+        bool valid = false; grk_amd_tile_params p{}; uint32_t order = 0;
+        T2Plan plan; uint32_t max_blocks = 0;
+        DevBuf packets, pob;
+    } t2;
+    DevBuf t2_u, t2_h, t2_rel, t2_pkhdr, t2_pkbody, t2_pkdst, t2_lit, t2_litat, t2_litdst, t2_out;
+    uint64_t t2_out_used = 0;
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
     uint32_t last_ntiles = 0;
@@ -1160,6 +1169,9 @@ void grk_amd_destroy(grk_amd_ctx* c)
         for (DevBuf* b : {&as->p1, &as->arena, &as->lengths, &as->offsets, &as->flag, &as->ovf, &as->llA, &as->llB}) b->release();
     }
     c->ovf.release();
+    for (DevBuf* b : {&c->t2.packets, &c->t2.pob, &c->t2_u, &c->t2_h, &c->t2_rel, &c->t2_pkhdr, &c->t2_pkbody, &c->t2_pkdst, &c->t2_lit,
+                      &c->t2_litat, &c->t2_litdst, &c->t2_out})
+        b->release();
     if (c->ev_level0) (void)hipEventDestroy(c->ev_level0);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     for (DevBuf* b : {&c->dec_seg_dev}) b->release();
@@ -1636,6 +1648,135 @@ int grk_amd_block_distortion(grk_amd_ctx* c, double* out, uint64_t cap)
         const double w = w1 * w2 * (double)b.stepsize;
         out[i] = w * w * (double)e[i];
     }
+    return GRK_AMD_OK;
+}
+
+// ---- Tier-2 on the device ----------------------------------------------------------------------------------------------------
+// The finished tile-parts of the LATEST grk_amd_encode_tiles call, made where the coded bytes are: KT1 writes every packet's header
+// (kernels_t2.hip), the packets' lengths come to the host -- a few bytes per packet, the one round trip -- which frames the
+// tile-parts (SOT, PLT, SOD: t2_device_frame) and says where every packet goes, KT2 gathers headers, code-block bytes and frames
+// into the context's output buffer at `dst_offset` (what lies below it is kept: a caller with several batches appends).
+int64_t grk_amd_assemble_device(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const uint32_t* tile_index, uint32_t flags,
+                                uint64_t dst_offset, uint32_t* part_bytes)
+{
+    if (!c || !p || !ntiles || !tile_index) return GRK_AMD_ERR_INVALID;
+    if (!c->have_geom || !same_params(c->gp, *p) || ntiles != c->last_ntiles || !c->last_nblocks)
+        return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_assemble_device assembles the grk_amd_encode_tiles call before it: same tiles, same parameters");
+    if (dst_offset > c->t2_out_used) return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_assemble_device: dst_offset lies behind what has been assembled");
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    { const int jr = join_side(c); if (jr) return jr; }
+    const TileGeom& g = c->geom;
+    const uint32_t order = (flags >> GRK_AMD_CS_PROG_SHIFT) & 7u;
+    auto& T = c->t2;
+    if (!T.valid || !same_params(T.p, *p) || T.order != order) {
+        T.valid = false;
+        const int rc = t2_device_plan(g, flags, T.plan);
+        if (rc) return fail(c, rc, "tile layout beyond the device writer's tables");
+        T.max_blocks = 0;
+        for (const T2Packet& k : T.plan.packets) T.max_blocks = std::max(T.max_blocks, k.nblocks);
+        // (the tables of the plan before may still be read by a gather that is queued: the stream is drained first)
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+        HIP_TRY(c, T.packets.ensure(T.plan.packets.size() * sizeof(T2Packet)), "alloc packet table");
+        HIP_TRY(c, T.pob.ensure(T.plan.packet_of_block.size() * 4), "alloc packet-of-block table");
+        HIP_TRY(c, hipMemcpyAsync(T.packets.p, T.plan.packets.data(), T.plan.packets.size() * sizeof(T2Packet), hipMemcpyHostToDevice, c->stream), "upload");
+        HIP_TRY(c, hipMemcpyAsync(T.pob.p, T.plan.packet_of_block.data(), T.plan.packet_of_block.size() * 4, hipMemcpyHostToDevice, c->stream), "upload");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+        T.p = *p; T.order = order; T.valid = true;
+    }
+    const size_t npk = T.plan.packets.size();
+    const uint32_t bpt = (uint32_t)(c->last_nblocks / ntiles);
+    const size_t nq = npk * ntiles;
+    HIP_TRY(c, c->t2_u.ensure((size_t)T.plan.u_words * 4 * ntiles + 16), "alloc header bits");
+    HIP_TRY(c, c->t2_h.ensure((size_t)T.plan.h_bytes * ntiles + 16), "alloc headers");
+    HIP_TRY(c, c->t2_rel.ensure(c->last_nblocks * 4), "alloc block places");
+    HIP_TRY(c, c->t2_pkhdr.ensure(nq * 4), "alloc packet lengths");
+    HIP_TRY(c, c->t2_pkbody.ensure(nq * 8), "alloc packet lengths");
+    HIP_TRY(c, hipMemsetAsync(c->t2_u.p, 0, (size_t)T.plan.u_words * 4 * ntiles, c->stream), "clear header bits");
+    T2HeaderArgs ha{};
+    ha.packets = (const T2Packet*)T.packets.p; ha.npackets = (uint32_t)npk;
+    ha.lengths = (const uint32_t*)c->lengths.p; ha.bpt = bpt; ha.ntiles = ntiles;
+    ha.ubits = (uint32_t*)c->t2_u.p; ha.u_words = T.plan.u_words;
+    ha.hdr = (uint8_t*)c->t2_h.p; ha.h_bytes = T.plan.h_bytes;
+    ha.rel = (uint32_t*)c->t2_rel.p; ha.pk_hdr = (uint32_t*)c->t2_pkhdr.p; ha.pk_body = (uint64_t*)c->t2_pkbody.p;
+    ha.status = (unsigned int*)c->flag.p;
+    HIP_TRY(c, launch_t2_header(ha, T.max_blocks, c->stream), "launch Tier-2 headers");
+    std::vector<uint32_t> hdr_len(nq);
+    std::vector<uint64_t> body_len(nq), pk_dst(nq), lit_dst(ntiles);
+    std::vector<uint32_t> lit_at(ntiles + 1, 0);
+    uint64_t flagwords[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(flagwords, c->flag.p, 16, hipMemcpyDeviceToHost, c->stream), "fetch flag");
+    HIP_TRY(c, hipMemcpyAsync(hdr_len.data(), c->t2_pkhdr.p, nq * 4, hipMemcpyDeviceToHost, c->stream), "fetch packet lengths");
+    HIP_TRY(c, hipMemcpyAsync(body_len.data(), c->t2_pkbody.p, nq * 8, hipMemcpyDeviceToHost, c->stream), "fetch packet lengths");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    if (flagwords[0] & 1u) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
+    if (flagwords[0] & 2u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "coefficient magnitude exceeds Kmax+1 bits");
+    if (flagwords[0] & 4u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "a code-block longer than the device writer takes");
+    // the frames and everybody's place
+    std::vector<uint8_t> lit;
+    uint64_t at = dst_offset;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        lit_at[t] = (uint32_t)lit.size();
+        lit_dst[t] = at;
+        const uint64_t len = t2_device_frame(flags, tile_index[t], hdr_len.data() + t * npk, body_len.data() + t * npk, npk, lit, pk_dst.data() + t * npk);
+        if (!len) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "tile-part beyond 4 GB or packet lengths beyond what PLT can carry");
+        for (size_t i = 0; i < npk; ++i) pk_dst[t * npk + i] += at;
+        if (part_bytes) part_bytes[t] = (uint32_t)len;
+        at += len;
+    }
+    lit_at[ntiles] = (uint32_t)lit.size();
+    if (c->t2_out.cap < at) {
+        // (grown with what lies below dst_offset kept)
+        DevBuf bigger;
+        HIP_TRY(c, bigger.ensure(at + (at >> 2)), "alloc tile-parts");
+        if (dst_offset) HIP_TRY(c, hipMemcpyAsync(bigger.p, c->t2_out.p, dst_offset, hipMemcpyDeviceToDevice, c->stream), "keep tile-parts");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+        c->t2_out.release();
+        c->t2_out = bigger;
+    }
+    HIP_TRY(c, c->t2_pkdst.ensure(nq * 8), "alloc packet places");
+    HIP_TRY(c, c->t2_lit.ensure(lit.size() + 16), "alloc frames");
+    HIP_TRY(c, c->t2_litat.ensure((ntiles + 1) * 4), "alloc frames");
+    HIP_TRY(c, c->t2_litdst.ensure((size_t)ntiles * 8), "alloc frames");
+    HIP_TRY(c, hipMemcpyAsync(c->t2_pkdst.p, pk_dst.data(), nq * 8, hipMemcpyHostToDevice, c->stream), "upload");
+    HIP_TRY(c, hipMemcpyAsync(c->t2_lit.p, lit.data(), lit.size(), hipMemcpyHostToDevice, c->stream), "upload");
+    HIP_TRY(c, hipMemcpyAsync(c->t2_litat.p, lit_at.data(), (ntiles + 1) * 4, hipMemcpyHostToDevice, c->stream), "upload");
+    HIP_TRY(c, hipMemcpyAsync(c->t2_litdst.p, lit_dst.data(), (size_t)ntiles * 8, hipMemcpyHostToDevice, c->stream), "upload");
+    T2GatherArgs ga{};
+    ga.packets = (const T2Packet*)T.packets.p; ga.npackets = (uint32_t)npk; ga.packet_of_block = (const uint32_t*)T.pob.p;
+    ga.lengths = (const uint32_t*)c->lengths.p; ga.offsets = (const uint64_t*)c->offsets.p; ga.arena = (const uint8_t*)c->arena.p;
+    ga.bpt = bpt; ga.ntiles = ntiles;
+    ga.hdr = (const uint8_t*)c->t2_h.p; ga.h_bytes = T.plan.h_bytes;
+    ga.rel = (const uint32_t*)c->t2_rel.p; ga.pk_hdr = (const uint32_t*)c->t2_pkhdr.p; ga.pk_dst = (const uint64_t*)c->t2_pkdst.p;
+    ga.lit = (const uint8_t*)c->t2_lit.p; ga.lit_at = (const uint32_t*)c->t2_litat.p; ga.lit_dst = (const uint64_t*)c->t2_litdst.p;
+    ga.out = (uint8_t*)c->t2_out.p;
+    ga.sop = (flags & GRK_AMD_CS_SOP) ? 6u : 0u; ga.eph = (flags & GRK_AMD_CS_EPH) ? 2u : 0u;
+    HIP_TRY(c, launch_t2_gather(ga, c->stream), "launch Tier-2 gather");
+    // (the uploads above read pageable vectors of this frame: the runtime has staged them by the time the calls return)
+    c->t2_out_used = at;
+    return (int64_t)(at - dst_offset);
+}
+
+void* grk_amd_assembled_device_ptr(grk_amd_ctx* c) { return c ? c->t2_out.p : nullptr; }
+
+// bytes [offset, offset + nbytes) of the assembled tile-parts to host memory: pinned memory in one DMA, pageable memory through the
+// context's pinned chunks on several copy threads (copy_d2h); complete on return
+int grk_amd_fetch_assembled(grk_amd_ctx* c, uint64_t offset, uint64_t nbytes, uint8_t* dst)
+{
+    if (!c || !dst || offset + nbytes > c->t2_out_used) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    if (!nbytes) return GRK_AMD_OK;
+    { const int rc = copy_d2h(c, dst, (const uint8_t*)c->t2_out.p + offset, nbytes); if (rc) return rc; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    return GRK_AMD_OK;
+}
+
+// the same queued on the context's stream, for pinned memory only; complete after grk_amd_synchronize
+int grk_amd_fetch_assembled_async(grk_amd_ctx* c, uint64_t offset, uint64_t nbytes, uint8_t* dst)
+{
+    if (!c || !dst || offset + nbytes > c->t2_out_used) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    if (!host_is_pinned(dst)) return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_fetch_assembled_async needs pinned memory (grk_amd_host_alloc)");
+    if (nbytes) HIP_TRY(c, hipMemcpyAsync(dst, (const uint8_t*)c->t2_out.p + offset, nbytes, hipMemcpyDeviceToHost, c->stream), "download");
     return GRK_AMD_OK;
 }
 

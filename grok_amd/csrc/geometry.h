@@ -64,6 +64,29 @@ inline bool on_even_grid(const TileGeom& g)
 int64_t plan_tile_part(const grk_amd_tile_params& p, uint32_t tile_index, uint32_t flags, const grk_amd_coded_block* tile_table,
                        std::vector<uint8_t>& lit, std::vector<grk_amd_tp_segment>& segs);
 
+// ---- Tier-2 on the device (kernels_t2.hip; the host's share in t2_writer.cpp) -----------------------------------------------------
+// One packet of a tile in progression order, as the header kernel meets it: up to three bands' code-block grids (rows of the
+// tile's table, raster order within a band), each with the height of its tag trees and its Kmax, and where the packet's raw header
+// bits and stuffed header bytes go in the tile's scratch areas (bounds that hold for any block lengths below 2^29).
+struct T2Packet {
+    uint32_t row0;                    // first row of the packet's component in the tile's table
+    uint32_t nbands, nblocks;
+    uint32_t first_block[3], gw[3], gh[3], kmax[3], height[3];
+    uint32_t u_at, u_words;           // raw header bits: 32-bit words of the tile's scratch
+    uint32_t h_at;                    // stuffed header: bytes of the tile's header scratch
+};
+struct T2Plan {
+    std::vector<T2Packet> packets;
+    std::vector<uint32_t> packet_of_block;        // [rows of a tile]
+    uint32_t u_words = 0, h_bytes = 0;            // scratch per tile
+};
+constexpr uint32_t kT2MaxLenBits = 29;            // block lengths the device writer takes (a coded block is a few KB)
+int t2_device_plan(const TileGeom& g, uint32_t flags, T2Plan& out);
+// The frame of one tile-part once the packets' header and body lengths are known: SOT, (PLT,) SOD appended to `lit`, every packet's
+// place relative to the tile-part's start in pk_at[]; returns the tile-part's length (0: PLT does not fit the syntax).
+uint64_t t2_device_frame(uint32_t flags, uint32_t tile_index, const uint32_t* hdr_len, const uint64_t* body_len, size_t npk,
+                         std::vector<uint8_t>& lit, uint64_t* pk_at);
+
 inline uint32_t ceil_div_pow2(uint32_t v, uint32_t n) { return (uint32_t)(((uint64_t)v + (1ull << n) - 1) >> n); }
 
 } // namespace grk_amd

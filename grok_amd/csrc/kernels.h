@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <hip/hip_runtime.h>
+#include "geometry.h"
 
 namespace grk_amd {
 
@@ -216,5 +217,32 @@ struct EgressArgs {
     int      mct, irreversible;
 };
 hipError_t launch_egress(const EgressArgs& a, hipStream_t s);
+
+// ---- KT1 / KT2: Tier-2 on the device (kernels_t2.hip) -------------------------------------------------------------------------
+struct T2HeaderArgs {
+    const T2Packet* packets; uint32_t npackets;      // a tile's packets in progression order (geometry.h)
+    const uint32_t* lengths;                         // the call's table: [tile][row]
+    uint32_t bpt, ntiles;                            // rows per tile
+    uint32_t* ubits; uint32_t u_words;               // raw header bits, per tile, ZEROED by the caller
+    uint8_t*  hdr;   uint32_t h_bytes;               // stuffed headers, per tile
+    uint32_t* rel;                                   // [tile][row]: the block's offset in its packet's body
+    uint32_t* pk_hdr; uint64_t* pk_body;             // [tile][packet]: header / body bytes
+    unsigned int* status;                            // bit 2: a block length the writer does not take (>= 2^kT2MaxLenBits)
+};
+hipError_t launch_t2_header(const T2HeaderArgs& a, uint32_t max_blocks_per_packet, hipStream_t s);
+struct T2GatherArgs {
+    const T2Packet* packets; uint32_t npackets;
+    const uint32_t* packet_of_block;                 // [row]
+    const uint32_t* lengths; const uint64_t* offsets; const uint8_t* arena;
+    uint32_t bpt, ntiles;
+    const uint8_t* hdr; uint32_t h_bytes;
+    const uint32_t* rel; const uint32_t* pk_hdr;
+    const uint64_t* pk_dst;                          // [tile][packet]: where the packet starts in `out`
+    const uint8_t* lit; const uint32_t* lit_at;      // the tile-parts' frames (SOT .. SOD): tile t's bytes are lit[lit_at[t] .. lit_at[t + 1])
+    const uint64_t* lit_dst;                         // ... and go to out + lit_dst[t]
+    uint8_t* out;
+    uint32_t sop, eph;                               // 6 / 2 when the markers are written, else 0
+};
+hipError_t launch_t2_gather(const T2GatherArgs& a, hipStream_t s);
 
 } // namespace grk_amd

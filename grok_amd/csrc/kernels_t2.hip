@@ -1,0 +1,253 @@
+// grok_amd/csrc/kernels_t2.hip -- Tier-2 on the device: packet headers and the assembly of finished tile-parts in HBM.
+//
+// Replaces, for the single-layer HTJ2K packets this encoder makes, T2Compress::compressPacket (t2/T2Compress.cpp:123-333: the
+// header's inclusion / zero-bit-plane tag trees t1/TagTree.cpp:170-218, the pass count and Lblock / length coding), the header's
+// bit stuffing (t1/BitIO.cpp:46-175) and the copy of the code-blocks' bytes behind it (T2Compress.cpp:300-333); the frame of a
+// tile-part (SOT markers/SOTMarker.cpp:41-72, PLT markers/LengthMarkers.cpp:313-374, SOD) stays with the host, which needs the
+// packets' lengths for it (t2_device_frame, t2_writer.cpp).  The host writer (t2_writer.cpp) is the oracle of this file's tests.
+//
+// KT1 t2_header_kernel: one workgroup per (packet, tile).
+//   1. Every code-block's share of the header is a bit string that depends on its place in the band's grid and on its length
+//      alone (t2_writer.cpp, "tag trees as this writer meets them": both trees are uniform): `nn` ones, (root: Kmax - 1 zeros,) `nn`
+//      ones, the pass bit 0, Lblock's comma code, the length.  A workgroup-wide prefix sum over (bits, bytes) gives every block its
+//      bit position in the RAW header and its byte offset in the packet's body; the bits are OR-ed into zeroed scratch words.
+//   2. Stuffing -- a byte that follows 0xFF carries seven bits -- makes every byte's position depend on the bytes before it:
+//      from a byte start p the next one is p + 8, or p + 15 behind an 0xFF (the 0xFF and the 7-bit byte as one step).  The chain is
+//      cut into chunks of 256 raw bits; a chain enters a chunk at one of 15 offsets, and per (chunk, entry offset) a lane walks
+//      the chunk's <= 32 steps: exit offset + bytes produced.  Sixteen chunks make a super-chunk with a table of the same kind,
+//      one lane walks the super-chunks, then the chunks of every super-chunk and the steps of every chunk are walked again from
+//      their now known entry, the last walk writing the bytes.  The raw bits pass through LDS in windows of 16 KB.
+// KT2 t2_gather_kernel: one wavefront per item -- a code-block's bytes, a packet's header (+ SOP / EPH), a tile-part's frame -- copies
+//   it to its place in the output: 16-byte stores on the destination's alignment, unaligned 16-byte loads.
+#include "kernels.h"
+
+namespace grk_amd {
+namespace {
+
+constexpr uint32_t kChunkBits = 256;                              // raw bits per chunk
+constexpr uint32_t kSup = 16;                                     // chunks per super-chunk
+constexpr uint32_t kWinWords = 4096;                              // raw words per LDS window
+constexpr uint32_t kWinBits = kWinWords * 32;
+constexpr uint32_t kWinChunks = kWinBits / kChunkBits;            // 512
+constexpr uint32_t kWinSups = kWinChunks / kSup;                  // 32
+constexpr uint64_t kByteMask = (1ull << 40) - 1;                  // the scan's packing: bits << 40 | bytes
+
+__device__ __forceinline__ void put_bits(uint32_t* u, uint32_t pos, uint64_t v, uint32_t n)     // n <= 64 bits of v, MSB first, at bit `pos`
+{
+    if (!n) return;
+    const uint64_t a = v << (64 - n);                             // left-aligned
+    const uint32_t o = pos & 31u;
+    uint32_t* w = u + (pos >> 5);
+    const uint32_t w0 = (uint32_t)(a >> 32) >> o, w1 = (uint32_t)(a >> o), w2 = o ? (uint32_t)(a << (32 - o)) : 0u;
+    if (w0) atomicOr(w, w0);
+    if (w1) atomicOr(w + 1, w1);
+    if (w2) atomicOr(w + 2, w2);
+}
+
+// one step of the chain at raw bit p of the window in LDS: the byte there, whether it is 0xFF, and the seven bits behind it
+__device__ __forceinline__ uint32_t window16(const uint32_t* win, uint32_t p)
+{
+    const uint64_t v = ((uint64_t)win[p >> 5] << 32) | win[(p >> 5) + 1];
+    return (uint32_t)(v >> (48 - (p & 31u))) & 0xFFFFu;
+}
+
+struct __attribute__((aligned(1))) U128 { uint32_t x, y, z, w; };
+__device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint64_t n, uint32_t lane)
+{
+    const uint64_t head = min(n, (uint64_t)((0 - (uintptr_t)d) & 15u));
+    if (lane < head) d[lane] = s[lane];
+    d += head; s += head; n -= head;
+    const uint64_t nv = n >> 4;
+    for (uint64_t i = lane; i < nv; i += 64) {
+        U128 v;
+        __builtin_memcpy(&v, s + 16 * i, 16);
+        *reinterpret_cast<uint4*>(d + 16 * i) = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    const uint64_t t0 = nv << 4;
+    if (t0 + lane < n) d[t0 + lane] = s[t0 + lane];
+}
+
+} // namespace
+
+__global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
+{
+    __shared__ uint32_t win[kWinWords + 2];
+    __shared__ uint16_t chunk_tab[kWinChunks * 16];               // [chunk][entry]: exit offset << 12 | bytes
+    __shared__ uint32_t sup_tab[kWinSups * 16];                   // [super-chunk][entry]: exit offset << 16 | bytes
+    __shared__ uint32_t chunk_in[kWinChunks];                     // entry offset << 28 | first output byte (relative to the window's)
+    __shared__ uint32_t sup_in[kWinSups + 1];
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint32_t carry_state[2];                           // between windows: entry offset, bytes so far
+
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nthr >> 6;
+    const uint32_t pk = blockIdx.x, tile = blockIdx.y;
+    const T2Packet& P = a.packets[pk];
+    uint32_t* const u = a.ubits + (size_t)tile * a.u_words + P.u_at;
+    const size_t row_base = (size_t)tile * a.bpt + P.row0;
+    const uint32_t n0 = P.nbands > 0 ? P.gw[0] * P.gh[0] : 0u, n1 = P.nbands > 1 ? P.gw[1] * P.gh[1] : 0u;
+
+    // ---- 1. the blocks' bit strings at their places in the raw header ------------------------------------------------------
+    uint64_t carry = 1ull << 40;                                  // the packet's first bit: "not empty"
+    if (tid == 0) atomicOr(u, 0x80000000u);
+    bool bad = false;
+    for (uint32_t base = 0; base < P.nblocks; base += nthr) {
+        const uint32_t j = base + tid;
+        const bool valid = j < P.nblocks;
+        uint32_t b = 0, k = 0, len = 0, nn = 0, inc = 0, nbits = 0;
+        size_t row = 0;
+        if (valid) {
+            b = (j >= n0) + (j >= n0 + n1);
+            k = j - (b == 0 ? 0u : b == 1 ? n0 : n0 + n1);
+            const uint32_t x = k % P.gw[b], y = k / P.gw[b], m = x | y;
+            row = row_base + P.first_block[b] + k;
+            len = a.lengths[row];
+            if (len >> kT2MaxLenBits) { bad = true; len = 0; }
+            nn = m ? min((uint32_t)__builtin_ctz(m) + 1u, P.height[b]) : P.height[b];
+            const int fl = len ? 31 - __builtin_clz(len) : 0;
+            inc = fl + 1 > 3 ? (uint32_t)(fl + 1 - 3) : 0u;
+            nbits = 2 * nn + (k == 0 ? P.kmax[b] - 1u : 0u) + 1 + (inc + 1) + (3 + inc);
+        }
+        const uint64_t v = ((uint64_t)nbits << 40) | len;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += o;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry, total = 0;
+        for (uint32_t w = 0; w < nwaves; ++w) { const uint64_t s = wave_sum[w]; if (w < wave) before += s; total += s; }
+        __syncthreads();
+        if (valid) {
+            const uint64_t excl = before + incl - v;
+            uint32_t pos = (uint32_t)(excl >> 40);
+            a.rel[row] = (uint32_t)(excl & kByteMask);
+            put_bits(u, pos, (1ull << nn) - 1ull, nn);
+            pos += nn + (k == 0 ? P.kmax[b] - 1u : 0u);
+            // `nn` ones and the pass bit 0 | Lblock: `inc` ones and a zero | the length in 3 + inc bits
+            const uint64_t tail = ((((((1ull << nn) - 1ull) << 1) << (inc + 1)) | (((1ull << inc) - 1ull) << 1)) << (3 + inc)) | len;
+            put_bits(u, pos, tail, nn + 1 + inc + 1 + 3 + inc);
+        }
+        carry += total;
+    }
+    if (bad) atomicOr(a.status, 4u);
+    const uint32_t nbits_total = (uint32_t)(carry >> 40);
+    const uint32_t nwords = (nbits_total + 31u) >> 5;
+    __threadfence();
+    __syncthreads();
+
+    // ---- 2. stuffing, window by window --------------------------------------------------------------------------------------
+    uint8_t* const hdr = a.hdr + (size_t)tile * a.h_bytes + P.h_at;
+    if (tid == 0) { carry_state[0] = 0; carry_state[1] = 0; }
+    for (uint32_t w0 = 0; w0 * 32u < nbits_total; w0 += kWinWords) {
+        __syncthreads();
+        for (uint32_t i = tid; i < kWinWords + 2; i += nthr)
+            win[i] = w0 + i < nwords ? __hip_atomic_load(u + w0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t lim = min(nbits_total - w0 * 32u, kWinBits);          // raw bits of this window
+        const uint32_t nch = (lim + kChunkBits - 1) / kChunkBits, nsup = (nch + kSup - 1) / kSup;
+        __syncthreads();
+        // per (chunk, entry offset): where the chain leaves the chunk and how many bytes it makes on the way
+        for (uint32_t job = tid; job < nch * 16u; job += nthr) {
+            const uint32_t c = job >> 4, e = job & 15u;
+            if (e == 15u) continue;
+            const uint32_t end = min((c + 1) * kChunkBits, lim);
+            uint32_t p = c * kChunkBits + e, cnt = 0;
+            while (p < end) {
+                const uint32_t ff = (window16(win, p) >> 8) == 0xFFu;
+                p += 8u + 7u * ff; cnt += 1u + ff;
+            }
+            chunk_tab[job] = (uint16_t)((min(p - min(p, (c + 1) * kChunkBits), 14u) << 12) | cnt);
+        }
+        __syncthreads();
+        for (uint32_t job = tid; job < nsup * 16u; job += nthr) {
+            const uint32_t s = job >> 4;
+            uint32_t e = job & 15u, cnt = 0;
+            if (e == 15u) continue;
+            for (uint32_t c = s * kSup; c < min((s + 1) * kSup, nch); ++c) { const uint32_t t = chunk_tab[c * 16u + e]; e = t >> 12; cnt += t & 0xFFFu; }
+            sup_tab[job] = (e << 16) | cnt;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t e = carry_state[0], at = 0;
+            for (uint32_t s = 0; s < nsup; ++s) { sup_in[s] = (e << 28) | at; const uint32_t t = sup_tab[s * 16u + e]; e = t >> 16; at += t & 0xFFFFu; }
+            sup_in[nsup] = (e << 28) | at;
+        }
+        __syncthreads();
+        if (tid < nsup) {
+            uint32_t e = sup_in[tid] >> 28, at = sup_in[tid] & 0x0FFFFFFFu;
+            for (uint32_t c = tid * kSup; c < min((tid + 1) * kSup, nch); ++c) { chunk_in[c] = (e << 28) | at; const uint32_t t = chunk_tab[c * 16u + e]; e = t >> 12; at += t & 0xFFFu; }
+        }
+        __syncthreads();
+        const uint32_t out0 = carry_state[1];
+        for (uint32_t c = tid; c < nch; c += nthr) {
+            const uint32_t end = min((c + 1) * kChunkBits, lim);
+            uint32_t p = c * kChunkBits + (chunk_in[c] >> 28);
+            uint8_t* o = hdr + out0 + (chunk_in[c] & 0x0FFFFFFFu);
+            while (p < end) {
+                const uint32_t t = window16(win, p), byte = t >> 8, ff = byte == 0xFFu;
+                *o++ = (uint8_t)byte;
+                if (ff) *o++ = (uint8_t)((t >> 1) & 0x7Fu);
+                p += 8u + 7u * ff;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // (a window that is not the last is full: its exit offset is the next one's entry)
+            carry_state[0] = sup_in[nsup] >> 28;
+            carry_state[1] = out0 + (sup_in[nsup] & 0x0FFFFFFFu);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.pk_hdr[(size_t)tile * a.npackets + pk] = carry_state[1];
+        a.pk_body[(size_t)tile * a.npackets + pk] = carry & kByteMask;
+    }
+}
+
+__global__ __launch_bounds__(256) void t2_gather_kernel(T2GatherArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t nblk = (uint64_t)a.ntiles * a.bpt, npk = (uint64_t)a.ntiles * a.npackets;
+    if (item < nblk) {
+        const uint64_t tile = item / a.bpt;
+        const uint32_t row = (uint32_t)(item - tile * a.bpt);
+        const uint64_t q = tile * a.npackets + a.packet_of_block[row];
+        wave_copy(a.out + a.pk_dst[q] + a.sop + a.pk_hdr[q] + a.eph + a.rel[item], a.arena + a.offsets[item], a.lengths[item], lane);
+    } else if (item < nblk + npk) {
+        const uint64_t q = item - nblk;
+        const uint64_t tile = q / a.npackets;
+        const uint32_t pk = (uint32_t)(q - tile * a.npackets);
+        uint8_t* d = a.out + a.pk_dst[q];
+        const uint32_t n = a.pk_hdr[q];
+        if (a.sop) {                    // SOP marker segment: Lsop 4, Nsop = the packet's number in the tile modulo 65536 (T2Compress.cpp:149-164)
+            if (lane < 6) d[lane] = lane == 0 ? 0xFF : lane == 1 ? 0x91 : lane == 2 ? 0 : lane == 3 ? 4 : lane == 4 ? (uint8_t)(pk >> 8) : (uint8_t)pk;
+            d += 6;
+        }
+        wave_copy(d, a.hdr + tile * a.h_bytes + a.packets[pk].h_at, n, lane);
+        if (a.eph && lane < 2) d[n + lane] = lane ? 0x92 : 0xFF;
+    } else if (item < nblk + npk + a.ntiles) {
+        const uint64_t t = item - nblk - npk;
+        wave_copy(a.out + a.lit_dst[t], a.lit + a.lit_at[t], a.lit_at[t + 1] - a.lit_at[t], lane);
+    }
+}
+
+hipError_t launch_t2_header(const T2HeaderArgs& a, uint32_t max_blocks_per_packet, hipStream_t s)
+{
+    if (!a.npackets || !a.ntiles) return hipSuccess;
+    // (a packet of a few blocks -- small precincts, low resolutions -- does not need sixteen waves' barriers)
+    const uint32_t threads = max_blocks_per_packet > 1024 ? 1024u : max_blocks_per_packet > 128 ? 256u : 64u;
+    hipLaunchKernelGGL(t2_header_kernel, dim3(a.npackets, a.ntiles), dim3(threads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_t2_gather(const T2GatherArgs& a, hipStream_t s)
+{
+    const uint64_t items = (uint64_t)a.ntiles * a.bpt + (uint64_t)a.ntiles * a.npackets + a.ntiles;
+    if (!items) return hipSuccess;
+    hipLaunchKernelGGL(t2_gather_kernel, dim3((uint32_t)((items + 3) / 4)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace grk_amd

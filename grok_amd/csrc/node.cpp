@@ -4,9 +4,10 @@
 // The reference's analogue is its tile-level task pool (codestream/CodeStreamCompress.cpp:535-603: tiles are independent
 // tasks, their tile-parts are written in index order); SURVEY.md §8(e): the path shards by tile with no data-path collective,
 // the one real exchange is making one file of the devices' tile-parts.  Two forms of that exchange (grk_amd_node_encode_image):
-//   * parallel writers (default): every worker brings its own coded bytes to the host over its own PCIe link, runs Tier-2 for
-//     its own tiles (grk_amd_write_tile_part) -- R host threads write tile-parts at once -- and the caller's thread puts the main
-//     header (TLM from the sizes) and the tile-parts together;
+//   * parallel writers (default): every worker makes its tiles' finished tile-parts in its own HBM (Tier-2 on the device:
+//     grk_amd_assemble_device, kernels_t2.hip) and brings them to the host over its own PCIe link; the caller's thread writes the main
+//     header (TLM from the sizes) and says where they go.  GRK_AMD_NODE_T2=host: the r06 route -- loose coded bytes to the host, Tier-2
+//     there as a plan (grk_amd_plan_tile_part) on the workers' threads, 49 152 segments per 8K frame placed by the host's threads;
 //   * gather (GRK_AMD_NODE_GATHER): every worker copies its coded bytes device-to-device (hipMemcpyPeer: xGMI between two
 //     GPUs) into the frame's WRITER device, which rotates with the frame number so that consecutive frames spread over all
 //     GPUs' links; the writer brings everything to the host in one piece and runs Tier-2 for all tiles -- north_star's
@@ -17,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -83,6 +85,7 @@ struct TileJob {               // what the workers leave per tile
     bool planned = false;                      // ... its plan was made by the tile's worker (beside the download of its bytes)
     std::vector<uint8_t> lit;                  // its plan (plan_tile_part): marker segments + packet headers ...
     std::vector<grk_amd_tp_segment> segs;      // ... and the segments it is made of
+    uint64_t dev_at = 0;                       // Tier-2 on the device: where the finished tile-part lies in its worker's assembled bytes
 };
 
 // fn(t) for t in [0, n) on up to `threads` host threads; the first error wins
@@ -104,6 +107,20 @@ template <class F> int parallel_tiles(uint32_t n, uint32_t threads, F fn)
     work();
     for (auto& t : th) t.join();
     return rc.load();
+}
+
+bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Tier-2 where the coded bytes are (grk_amd_assemble_device) unless GRK_AMD_NODE_T2=host asks for the host writer's plan
+bool device_t2()
+{
+    const char* e = std::getenv("GRK_AMD_NODE_T2");                  // (read per image: the tests take both routes in one process)
+    return !(e && std::strcmp(e, "host") == 0);
 }
 
 } // namespace
@@ -259,6 +276,11 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
             ww.gather_cap = gather_at[R];
         }
     }
+    // Parallel writers, Tier-2 on the device (the default): a worker's encode is followed by grk_amd_assemble_device -- packet headers
+    // and the gather of the code-blocks' bytes into finished tile-parts in its HBM --, no table and no loose coded bytes come to the
+    // host; the tile-parts are brought to their places in the file once the main header's length is known.
+    const bool dev_t2 = !gather && device_t2();
+    std::vector<uint64_t> asm_used(R, 0);
     std::vector<int> rcs(R, GRK_AMD_OK);
     std::vector<std::thread> th;
     for (uint32_t r = 0; r < R; ++r)
@@ -324,7 +346,7 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
                     enc_px = w.dev_px;
                 }
                 const uint64_t bpt = (uint64_t)geoms[k].blocks_per_comp * nc;
-                std::vector<grk_amd_coded_block> table(bpt * mine.size());
+                std::vector<grk_amd_coded_block> table(dev_t2 ? 0 : bpt * mine.size());
                 uint64_t total = 0;
                 // (the buffer set this encode takes was used kRing + 1 encodes ago: its bytes must have left by now; without the
                 //  rotation -- no DWT level, overlap switched off -- every encode writes the one arena: wait for the last copy)
@@ -332,6 +354,17 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
                 if (gather && !ring && ngroup && hipStreamSynchronize(w.copy) != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
                 if (gather && ring && ngroup > (size_t)kRing) {
                     if (hipEventSynchronize(w.copied[(ngroup - 1 - kRing) % w.copied.size()]) != hipSuccess) { (void)hipGetLastError(); rc = GRK_AMD_ERR_NO_DEVICE; break; }
+                }
+                if (dev_t2) {
+                    rc = grk_amd_encode_tiles(w.ctx, &p, (uint32_t)mine.size(), enc_px, pixels_device >= 0, nullptr, nullptr);
+                    if (rc) break;
+                    std::vector<uint32_t> lens(mine.size());
+                    const int64_t n = grk_amd_assemble_device(w.ctx, &p, (uint32_t)mine.size(), mine.data(), cs_flags, asm_used[r], lens.data());
+                    if (n < 0) { rc = (int)n; break; }
+                    uint64_t at = asm_used[r];
+                    for (size_t i = 0; i < mine.size(); ++i) { TileJob& j = jobs[mine[i]]; j.part_len = lens[i]; j.dev_at = at; at += lens[i]; }
+                    asm_used[r] += (uint64_t)n;
+                    continue;
                 }
                 rc = grk_amd_encode_tiles(w.ctx, &p, (uint32_t)mine.size(), enc_px, pixels_device >= 0, table.data(), &total);
                 if (rc) break;
@@ -393,6 +426,61 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
     for (uint32_t r = 0; r < R; ++r)
         if (rcs[r]) { nd->err = std::string("worker ") + std::to_string(r) + ": " + grk_amd_last_error(nd->w[r].ctx); return rcs[r]; }
 
+    if (dev_t2) {
+        std::vector<uint32_t> sizes(ntiles);
+        for (uint32_t t = 0; t < ntiles; ++t) sizes[t] = (uint32_t)jobs[t].part_len;
+        const int64_t hdr = grk_amd_write_main_header_layout(im, base, cs_flags, sizes.data(), out, cap);
+        if (hdr < 0) return hdr;
+        std::vector<uint64_t> at(ntiles + 1, (uint64_t)hdr);
+        for (uint32_t t = 0; t < ntiles; ++t) at[t + 1] = at[t] + jobs[t].part_len;
+        if (at[ntiles] + 2 > cap) return GRK_AMD_ERR_OVERFLOW;
+        int rc = GRK_AMD_OK;
+        if (R == 1 && geoms.size() == 1) {
+            // one worker, one batch: its assembled bytes ARE the file behind the main header -- one DMA into pinned memory, pinned
+            // chunks on several copy threads into pageable memory
+            rc = grk_amd_fetch_assembled(nd->w[0].ctx, 0, asm_used[0], out + hdr);
+        } else if (is_pinned(out)) {
+            for (uint32_t t = 0; t < ntiles && rc == GRK_AMD_OK; ++t)
+                rc = grk_amd_fetch_assembled_async(nd->w[t % R].ctx, jobs[t].dev_at, jobs[t].part_len, out + at[t]);
+            for (uint32_t r = 0; r < R; ++r) { const int sr = grk_amd_synchronize(nd->w[r].ctx); if (rc == GRK_AMD_OK) rc = sr; }
+        } else {
+            // every worker's assembled bytes over its own link into its pinned buffer, then the tile-parts -- whole, not 49 152
+            // code-blocks each -- to their places on the host's threads
+            for (uint32_t r = 0; r < R && rc == GRK_AMD_OK; ++r) {
+                auto& w = nd->w[r];
+                if (!pin_ensure(w.ctx, w.pin_coded, w.pin_coded_cap, asm_used[r] + 16)) { rc = GRK_AMD_ERR_NOMEM; break; }
+                rc = grk_amd_fetch_assembled_async(w.ctx, 0, asm_used[r], w.pin_coded);
+            }
+            for (uint32_t r = 0; r < R; ++r) { const int sr = grk_amd_synchronize(nd->w[r].ctx); if (rc == GRK_AMD_OK) rc = sr; }
+            if (rc == GRK_AMD_OK) {
+                struct Piece { uint32_t t; uint64_t o, n; };
+                std::vector<Piece> pieces;
+                for (uint32_t t = 0; t < ntiles; ++t)
+                    for (uint64_t o = 0; o < jobs[t].part_len; o += 2u << 20) pieces.push_back(Piece{t, o, std::min<uint64_t>(2u << 20, jobs[t].part_len - o)});
+                std::atomic<size_t> next{0};
+                auto work = [&]() {
+                    for (;;) {
+                        const size_t k = next.fetch_add(1);
+                        if (k >= pieces.size()) break;
+                        const Piece& pc = pieces[k];
+                        std::memcpy(out + at[pc.t] + pc.o, nd->w[pc.t % R].pin_coded + jobs[pc.t].dev_at + pc.o, pc.n);
+                    }
+                };
+                const uint32_t nthr = (uint32_t)std::min<size_t>(std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency() / 4u)), pieces.size());
+                std::vector<std::thread> pool;
+                for (uint32_t i = 1; i < nthr; ++i) pool.emplace_back(work);
+                work();
+                for (auto& th2 : pool) th2.join();
+            }
+        }
+        if (rc) {
+            for (uint32_t r = 0; r < R; ++r) if (*grk_amd_last_error(nd->w[r].ctx)) { nd->err = std::string("worker ") + std::to_string(r) + ": " + grk_amd_last_error(nd->w[r].ctx); break; }
+            return rc;
+        }
+        uint64_t end = at[ntiles];
+        out[end++] = 0xFF; out[end++] = 0xD9;
+        return (int64_t)end;
+    }
     // Where every tile's coded bytes are on the host: with parallel writers in its own worker's pinned buffer (fetched over
     // that worker's PCIe link), in the gather form in the writer's (one piece per worker, brought over by the writer's device).
     std::vector<const uint8_t*> src(ntiles, nullptr);

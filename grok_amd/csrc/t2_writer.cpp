@@ -249,16 +249,12 @@ grk_amd_image_layout plain_layout(const grk_amd_tile_params& p, uint32_t img_w, 
 // where a precinct's position is its top-left corner on the REFERENCE grid (component coordinates times the component's
 // sub-sampling factors), clipped to the tile -- the (y, x) at which the standard's position loops meet it; positions are walked
 // in raster order, several resolutions / components can share one.
-uint64_t write_tile_part(Out& o, const std::vector<const TileGeom*>& cg, const std::vector<uint64_t>& row0, const uint8_t* comp_dx,
-                         const uint8_t* comp_dy, uint32_t gx0, uint32_t gy0, uint32_t t, uint32_t flags, const grk_amd_coded_block* tt,
-                         const uint8_t* coded)
+struct Pk { uint32_t c, r, pi; uint64_t x, y; };
+std::vector<Pk> packet_order(const std::vector<const TileGeom*>& cg, const uint8_t* comp_dx, const uint8_t* comp_dy, uint32_t gx0, uint32_t gy0,
+                             uint32_t order)
 {
     const uint32_t ncomp = (uint32_t)cg.size();
     const grk_amd_tile_params& p = cg[0]->p;
-    const uint64_t sot = o.n, sot_lit = o.lit ? o.lit->size() : 0;
-    const uint32_t order = (flags >> GRK_AMD_CS_PROG_SHIFT) & 7u;
-    const bool sop = (flags & GRK_AMD_CS_SOP) != 0, eph = (flags & GRK_AMD_CS_EPH) != 0;
-    struct Pk { uint32_t c, r, pi; uint64_t x, y; };
     std::vector<Pk> prec;                                   // every precinct of the tile: component-major, resolution-major, raster
     for (uint32_t c = 0; c < ncomp; ++c) {
         const TileGeom& g = *cg[c];
@@ -273,63 +269,80 @@ uint64_t write_tile_part(Out& o, const std::vector<const TileGeom*>& cg, const s
                 }
         }
     }
-    auto sorted_by = [&](auto less) { std::vector<Pk> v = prec; std::stable_sort(v.begin(), v.end(), less); return v; };
+    // (stable sorts of the component-major, resolution-major, raster list: the keys named, everything else in that order)
+    if (order <= 1)                // resolution, component, precinct
+        std::stable_sort(prec.begin(), prec.end(), [](const Pk& a, const Pk& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
+    else if (order == 2)           // resolution, position, component
+        std::stable_sort(prec.begin(), prec.end(), [](const Pk& a, const Pk& b) {
+            return a.r != b.r ? a.r < b.r : a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.c < b.c; });
+    else if (order == 3)           // position, component, resolution
+        std::stable_sort(prec.begin(), prec.end(), [](const Pk& a, const Pk& b) {
+            return a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.c != b.c ? a.c < b.c : a.r < b.r; });
+    else                           // component, position, resolution
+        std::stable_sort(prec.begin(), prec.end(), [](const Pk& a, const Pk& b) {
+            return a.c != b.c ? a.c < b.c : a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.r < b.r; });
+    return prec;
+}
+
+// a packet's length as the PLT marker segment carries it: a big-endian base-128 number (continuation bit 0x80)
+void plt_length(std::vector<uint8_t>& body, uint64_t v)
+{
+    uint8_t tmp[10]; int k = 0;
+    tmp[k++] = (uint8_t)(v & 0x7F);
+    while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
+    while (k) body.push_back(tmp[--k]);
+}
+
+// PLT (markers/LengthMarkers.cpp:313-374, written in front of SOD: TileProcessor.cpp:719-726): Zplt 0, then every packet's length.
+// Marker segments of at most 65535 bytes (Lplt is 16 bits: Lplt, Zplt and 65532 bytes of lengths), Zplt = 0, 1, ...;
+// a packet's length (1-5 bytes, the last one without the continuation bit) is never split over two segments.
+// 18 packets of a 6-resolution RGB tile need < 100 bytes; small precincts multiply that: the reference starts another
+// segment near 64 KiB as well (LengthMarkers.cpp:313-331 -- its continuation segments lack the Zplt byte, a defect
+// this writer does not copy: T.800 A.7.3).
+void write_plt(Out& o, const std::vector<uint8_t>& body)
+{
+    size_t at = 0;
+    uint32_t z = 0;
+    do {
+        size_t end = at, next = at;
+        while (next < body.size()) {
+            size_t e = next;
+            while (body[e] & 0x80) ++e;                        // one length: bytes with the continuation bit, then one without
+            ++e;
+            if (e - at > 65532) break;
+            end = next = e;
+        }
+        if (z > 255) { o.ovf = true; break; }                  // (Zplt is one byte: > 16 MB of packet lengths in one tile-part does not fit the syntax)
+        o.u16(0xFF58); o.u16((uint32_t)(3 + (end - at))); o.u8((uint8_t)z++);
+        o.bytes(body.data() + at, end - at);
+        at = end;
+    } while (at < body.size());
+}
+
+uint64_t write_tile_part(Out& o, const std::vector<const TileGeom*>& cg, const std::vector<uint64_t>& row0, const uint8_t* comp_dx,
+                         const uint8_t* comp_dy, uint32_t gx0, uint32_t gy0, uint32_t t, uint32_t flags, const grk_amd_coded_block* tt,
+                         const uint8_t* coded)
+{
+    const uint64_t sot = o.n, sot_lit = o.lit ? o.lit->size() : 0;
+    const uint32_t order = (flags >> GRK_AMD_CS_PROG_SHIFT) & 7u;
+    const bool sop = (flags & GRK_AMD_CS_SOP) != 0, eph = (flags & GRK_AMD_CS_EPH) != 0;
+    const std::vector<Pk> seq = packet_order(cg, comp_dx, comp_dy, gx0, gy0, order);
     auto packets = [&](Out& dst, std::vector<uint8_t>* plt) {
         int32_t n = 0;
-        auto one = [&](const Pk& q) {
+        for (const Pk& q : seq) {
             const uint64_t at = dst.n;
             write_packet(dst, *cg[q.c], q.r, q.pi, tt + row0[q.c], coded, sop ? n : -1, eph);
             ++n;
-            if (plt) {                          // the packet's length as a big-endian base-128 number (continuation bit 0x80)
-                uint8_t tmp[10]; int k = 0;
-                uint64_t v = dst.n - at;
-                tmp[k++] = (uint8_t)(v & 0x7F);
-                while (v >>= 7) tmp[k++] = (uint8_t)((v & 0x7F) | 0x80);
-                while (k) plt->push_back(tmp[--k]);
-            }
-        };
-        // (stable sorts of the component-major, resolution-major, raster list: the keys named, everything else in that order)
-        if (order <= 1) {              // resolution, component, precinct
-            for (const Pk& q : sorted_by([](const Pk& a, const Pk& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; })) one(q);
-        } else if (order == 2) {       // resolution, position, component
-            for (const Pk& q : sorted_by([](const Pk& a, const Pk& b) {
-                     return a.r != b.r ? a.r < b.r : a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.c < b.c; })) one(q);
-        } else if (order == 3) {       // position, component, resolution
-            for (const Pk& q : sorted_by([](const Pk& a, const Pk& b) {
-                     return a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.c != b.c ? a.c < b.c : a.r < b.r; })) one(q);
-        } else {                       // component, position, resolution
-            for (const Pk& q : sorted_by([](const Pk& a, const Pk& b) {
-                     return a.c != b.c ? a.c < b.c : a.y != b.y ? a.y < b.y : a.x != b.x ? a.x < b.x : a.r < b.r; })) one(q);
+            if (plt) plt_length(*plt, dst.n - at);
         }
     };
     o.u16(0xFF90); o.u16(10); o.u16(t); o.u32(0); o.u8(0); o.u8(1);
     if (flags & GRK_AMD_CS_PLT) {
-        // PLT (markers/LengthMarkers.cpp:313-374, written in front of SOD: TileProcessor.cpp:719-726): Zplt 0, then every
-        // packet's length.  The packets are sized with a counting pass.
+        // the packets are sized with a counting pass
         std::vector<uint8_t> body;
         Out cnt{nullptr, 0};
         packets(cnt, &body);
-        // Marker segments of at most 65535 bytes (Lplt is 16 bits: Lplt, Zplt and 65532 bytes of lengths), Zplt = 0, 1, ...;
-        // a packet's length (1-5 bytes, the last one without the continuation bit) is never split over two segments.
-        // 18 packets of a 6-resolution RGB tile need < 100 bytes; small precincts multiply that: the reference starts another
-        // segment near 64 KiB as well (LengthMarkers.cpp:313-331 -- its continuation segments lack the Zplt byte, a defect
-        // this writer does not copy: T.800 A.7.3).
-        size_t at = 0;
-        uint32_t z = 0;
-        do {
-            size_t end = at, next = at;
-            while (next < body.size()) {
-                size_t e = next;
-                while (body[e] & 0x80) ++e;                        // one length: bytes with the continuation bit, then one without
-                ++e;
-                if (e - at > 65532) break;
-                end = next = e;
-            }
-            if (z > 255) { o.ovf = true; break; }                  // (Zplt is one byte: > 16 MB of packet lengths in one tile-part does not fit the syntax)
-            o.u16(0xFF58); o.u16((uint32_t)(3 + (end - at))); o.u8((uint8_t)z++);
-            o.bytes(body.data() + at, end - at);
-            at = end;
-        } while (at < body.size());
+        write_plt(o, body);
     }
     o.u16(0xFF93);
     packets(o, nullptr);
@@ -548,6 +561,72 @@ int64_t plan_tile_part(const grk_amd_tile_params& p, uint32_t tile_index, uint32
     o.lit = &lit; o.segs = &segs;
     write_tile_part(o, g, tile_index, flags, tile_table, nullptr);
     return (int64_t)o.n;
+}
+} // namespace grk_amd
+
+namespace grk_amd {
+// What the header kernel needs to know about a tile's packets (no sub-sampling: every component has the tile's geometry).
+int t2_device_plan(const TileGeom& g, uint32_t flags, T2Plan& out)
+{
+    const grk_amd_tile_params& p = g.p;
+    std::vector<const TileGeom*> cg(p.num_comps, &g);
+    const std::vector<Pk> seq = packet_order(cg, nullptr, nullptr, p.tile_x0, p.tile_y0, (flags >> GRK_AMD_CS_PROG_SHIFT) & 7u);
+    out.packets.clear();
+    out.packet_of_block.assign((size_t)g.blocks_per_comp * p.num_comps, 0xFFFFFFFFu);
+    uint64_t u = 0, h = 0;
+    for (const Pk& q : seq) {
+        const ResGeom& R = g.res[q.r];
+        T2Packet k{};
+        k.row0 = q.c * g.blocks_per_comp;
+        uint64_t bits = 1;
+        for (uint32_t bi = 0; bi < R.num_bands; ++bi) {
+            const BandGeom& B = R.band[bi];
+            const BandGeom::Prec& P = B.prec[q.pi];
+            if (!P.gw || !P.gh) continue;
+            const uint32_t b = k.nbands++;
+            k.first_block[b] = P.first_block; k.gw[b] = P.gw; k.gh[b] = P.gh; k.kmax[b] = B.kmax;
+            k.height[b] = (uint32_t)tag_tree_height(P.gw, P.gh);
+            const uint64_t n = (uint64_t)P.gw * P.gh;
+            for (uint64_t i = 0; i < n; ++i) out.packet_of_block[k.row0 + P.first_block + i] = (uint32_t)out.packets.size();
+            k.nblocks += (uint32_t)n;
+            // per block: two paths of at most `height` nodes, the pass bit, Lblock's comma code and the length
+            bits += n * (2ull * k.height[b] + 1 + (kT2MaxLenBits - 3 + 1) + kT2MaxLenBits) + B.kmax;
+        }
+        if (bits > 0x7FFFFFFFull) return GRK_AMD_ERR_UNSUPPORTED;
+        k.u_at = (uint32_t)u; k.u_words = (uint32_t)((bits + 31) / 32 + 2);
+        k.h_at = (uint32_t)h;
+        u += (k.u_words + 31u) & ~31ull;                         // (packets start on 128-byte lines)
+        h += ((bits + 6) / 7 + 2 + 15) & ~15ull;                 // a stuffed byte carries at least 7 bits
+        if (u > 0x3FFFFFFFull || h > 0xFFFFFFFFull) return GRK_AMD_ERR_UNSUPPORTED;
+        out.packets.push_back(k);
+    }
+    for (uint32_t v : out.packet_of_block) if (v == 0xFFFFFFFFu) return GRK_AMD_ERR_INVALID;     // (every block lies in one precinct)
+    out.u_words = (uint32_t)u; out.h_bytes = (uint32_t)h;
+    return GRK_AMD_OK;
+}
+
+uint64_t t2_device_frame(uint32_t flags, uint32_t tile_index, const uint32_t* hdr_len, const uint64_t* body_len, size_t npk,
+                         std::vector<uint8_t>& lit, uint64_t* pk_at)
+{
+    const uint64_t extra = ((flags & GRK_AMD_CS_SOP) ? 6u : 0u) + ((flags & GRK_AMD_CS_EPH) ? 2u : 0u);
+    std::vector<uint8_t> mine;
+    std::vector<grk_amd_tp_segment> segs;
+    Out o{nullptr, 0};
+    o.lit = &mine; o.segs = &segs;
+    o.u16(0xFF90); o.u16(10); o.u16(tile_index); o.u32(0); o.u8(0); o.u8(1);
+    if (flags & GRK_AMD_CS_PLT) {
+        std::vector<uint8_t> body;
+        for (size_t i = 0; i < npk; ++i) plt_length(body, extra + hdr_len[i] + body_len[i]);
+        write_plt(o, body);
+        if (o.ovf) return 0;
+    }
+    o.u16(0xFF93);
+    uint64_t at = o.n;
+    for (size_t i = 0; i < npk; ++i) { pk_at[i] = at; at += extra + hdr_len[i] + body_len[i]; }
+    if (at > 0xFFFFFFFFull) return 0;
+    o.patch32(6, (uint32_t)at, 0, 0);
+    lit.insert(lit.end(), mine.begin(), mine.end());
+    return at;
 }
 } // namespace grk_amd
 

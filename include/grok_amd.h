@@ -346,6 +346,23 @@ int64_t grk_amd_plan_tile_part(const grk_amd_tile_params* p, uint32_t tile_index
                                const grk_amd_coded_block* tile_table, uint8_t* literal, uint64_t literal_cap, uint64_t* literal_len,
                                grk_amd_tp_segment* segments, uint64_t segment_cap, uint64_t* num_segments);
 
+/* Tier-2 on the device (replaces T2Compress::compressPacket t2/T2Compress.cpp:123-333, the tag trees t1/TagTree.cpp:170-218 and the
+ * header's bit stuffing t1/BitIO.cpp:46-175 for this encoder's single-layer HT packets; SOT / PLT / SOD as markers/SOTMarker.cpp:41-72,
+ * markers/LengthMarkers.cpp:313-374): the finished tile-parts of the LATEST grk_amd_encode_tiles call (num_tiles tiles of *p; no
+ * table needs to be fetched for it), tile i numbered tile_index[i], in call order back to back in a device buffer of the context's,
+ * starting at dst_offset (0, or the end of what earlier calls assembled: batches of several geometries append).  flags: GRK_AMD_CS_PLT /
+ * SOP / EPH / PROG as grk_amd_write_tile_part, whose bytes these are.  part_bytes[i] (optional) = tile-part i's length (what TLM and
+ * the caller's placement need).  Returns the bytes assembled by this call, or < 0.  One host round trip of a few bytes per packet;
+ * the ~100 MB of an 8K frame's code-blocks are moved once, on the device, to where the file has them. */
+int64_t grk_amd_assemble_device(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles, const uint32_t* tile_index,
+                                uint32_t flags, uint64_t dst_offset, uint32_t* part_bytes);
+void* grk_amd_assembled_device_ptr(grk_amd_ctx* ctx);
+/* bytes [offset, offset + nbytes) of the assembled tile-parts to host memory (pinned: one DMA; pageable: through pinned chunks on
+ * several copy threads); complete on return */
+int grk_amd_fetch_assembled(grk_amd_ctx* ctx, uint64_t offset, uint64_t nbytes, uint8_t* dst);
+/* the same queued on the context's stream (dst pinned: grk_amd_host_alloc); complete after grk_amd_synchronize */
+int grk_amd_fetch_assembled_async(grk_amd_ctx* ctx, uint64_t offset, uint64_t nbytes, uint8_t* dst);
+
 /* ---- images of any tile layout (tiles / images off the origin, ragged edge tiles) ----------------------------------
  * What SIZ says about the image (ISO 15444-1 B.2, B.3; grok.h grk_image x0..y1, grk_cparameters tx0 ty0 t_width t_height):
  * the image area [x0, x1) x [y0, y1) on the canonical grid and the tile grid anchored at (tx0, ty0) <= (x0, y0).  Tile t

@@ -121,3 +121,32 @@ def test_native_rccl_host_one_rank(tmp_path):
     exe = _build_rccl_host_example(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ranks 1" in r.stdout and "identical" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+@pytest.mark.parametrize("pinned_out", [False, True])
+def test_node_tier2_on_the_device_and_on_the_host_make_one_file(monkeypatch, devices, pinned_out):
+    """Parallel writers make their tile-parts on the device by default (grk_amd_assemble_device); GRK_AMD_NODE_T2=host takes the
+    host writer's plan instead.  Same file either way and == the single-context image, for one and for nine geometry groups, one and
+    three workers, the output in pageable memory (staged through the workers' pinned buffers, or the copy threads for one worker
+    and one group) and in pinned memory (every tile-part's DMA straight to its place)."""
+    cases = [((640, 512, 256, 256, 4, (0, 0)), G.CS_TLM | G.CS_PLT | G.CS_PROG(2)),          # one to four groups, markers, RPCL
+             ((1000, 900, 384, 320, 3, (100, 60)), G.CS_SOP | G.CS_EPH),                     # nine groups
+             ((512, 512, 512, 512, 5, (0, 0)), 0)]                                           # one tile: the contiguous route
+    c = U.ctx()
+    for (W, H, TW, TH, L, off), flags in cases:
+        px = synth.g2(3, H, W, 8, seed=W)
+        layout = G.ImageLayout.make(W, H, TW, TH, offset=off)
+        base = G.TileParams.make(1, 1, 3, 8, L)
+        want = c.encode_image(layout, base, px, flags)
+        out = c.host_array(px.size * 2 + (1 << 20)) if pinned_out else None
+        d_px = U.to_dev(px.reshape(-1).view(np.uint8))
+        for route in ("device", "host"):
+            monkeypatch.setenv("GRK_AMD_NODE_T2", route)
+            node = G.Node(devices)
+            try:
+                for _ in range(2):
+                    assert bytes(node.encode_image(layout, base, px, flags, out=out)) == want, route
+                assert bytes(node.encode_image_device(layout, base, d_px.data_ptr(), d_px.numel(), 0, flags, out=out)) == want, route
+            finally:
+                node.close()

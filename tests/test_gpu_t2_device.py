@@ -1,0 +1,114 @@
+"""-m gpu: Tier-2 on the device (grk_amd_assemble_device, kernels_t2.hip) against the host writer (grk_amd_write_tile_part,
+t2_writer.cpp -- itself pinned on grk_compress's files by test_length_markers / test_gpu_precincts): the tile-parts the device
+assembles are the host writer's bytes, for every progression order, with SOP / EPH / PLT, precincts down to a handful of blocks,
+tiles off the grid, batches of several tiles, appended batches, deep content (long headers with many 0xFF) and empty blocks."""
+import numpy as np
+import pytest
+
+import grok_amd as G
+import gpuutil as U
+import synth
+from test_precincts_cpu import exps_from_sizes
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_parts(p, indices, table, coded, flags):
+    bpt = len(table) // len(indices)
+    return [G.write_tile_part(p, int(t), table[i * bpt:(i + 1) * bpt], coded, flags) for i, t in enumerate(indices)]
+
+
+def _check(p, px, indices, flags, ntiles=1):
+    c = U.ctx()
+    table, coded = c.encode_host(p, px, ntiles=ntiles)
+    n, lens = c.assemble_device(p, indices, flags)
+    want = _host_parts(p, indices, table, coded, flags)
+    assert [int(v) for v in lens] == [len(w) for w in want]
+    got = bytes(c.fetch_assembled(0, n))
+    assert n == sum(len(w) for w in want)
+    at = 0
+    for i, w in enumerate(want):
+        if got[at:at + len(w)] != w:
+            g = np.frombuffer(got[at:at + len(w)], np.uint8)
+            first = int(np.nonzero(g != np.frombuffer(w, np.uint8))[0][0])
+            raise AssertionError("tile-part %d differs from byte %d of %d" % (i, first, len(w)))
+        at += len(w)
+    return want
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("extra", [0, G.CS_PLT, G.CS_SOP | G.CS_EPH, G.CS_PLT | G.CS_SOP | G.CS_EPH])
+def test_orders_and_markers(order, extra):
+    px = synth.g2(3, 192, 256, 8, seed=order + extra)
+    p = G.TileParams.make(256, 192, 3, 8, 4, precincts=exps_from_sizes([(128, 128), (64, 64)], 4))
+    _check(p, px, [5], G.CS_PROG(order) | extra)
+
+
+@pytest.mark.parametrize("C,W,H,prec,L,org,sizes,irrev", [
+    (3, 1024, 768, 8, 5, (0, 0), None, False),               # one precinct per resolution: 768 blocks in the largest packet
+    (1, 300, 210, 12, 3, (0, 0), [(64, 32), (32, 64)], False),
+    (3, 257, 129, 8, 5, (33, 95), [(128, 64), (64, 64), (16, 16)], False),      # off the grid, blocks of 16 x 16 and smaller
+    (3, 96, 80, 8, 3, (0, 0), [(16, 16)], False),
+    (3, 640, 512, 16, 5, (0, 0), None, True),                # 16-bit ICT + 9/7: long blocks, long Lblock codes
+    (1, 64, 64, 8, 0, (0, 0), None, False),                  # no DWT level: one packet of one block
+    (3, 33, 17, 8, 2, (7, 3), None, False),
+])
+def test_geometries(C, W, H, prec, L, org, sizes, irrev):
+    px = synth.g2(C, H, W, prec, seed=W + L)
+    prc = exps_from_sizes(sizes, L) if sizes else None
+    p = G.TileParams.make(W, H, C, prec, L, origin=org, precincts=prc, irreversible=irrev)
+    _check(p, px, [0], G.CS_PLT)
+
+
+def test_headers_longer_than_one_window_and_than_one_workgroup_pass():
+    """2048 x 2048 x 3, 5 levels: the top resolution's packets hold 3 072 blocks each -- three passes of a 1 024-lane workgroup over the
+    blocks, a raw header of ~90 000 bits; with 16 x 16 code-blocks 12 288 blocks per packet: several 16 KB windows of raw bits, the
+    chain's state carried from window to window."""
+    px = synth.g2(3, 2048, 2048, 8, seed=11)
+    p = G.TileParams.make(2048, 2048, 3, 8, 5)
+    _check(p, px, [0], 0)
+    p = G.TileParams.make(2048, 2048, 3, 8, 5, cblk=(4, 4))
+    _check(p, px, [0], G.CS_SOP)
+
+
+def test_flat_and_empty_blocks():
+    """A flat frame: every block of the detail bands is empty (length 0: Lblock stays 3, three zero bits of length), and the headers are
+    runs of ones -- 0xFF after 0xFF, the densest stuffing there is."""
+    px = np.full((3, 512, 512), 128, np.uint8)
+    p = G.TileParams.make(512, 512, 3, 8, 5)
+    _check(p, px, [0], G.CS_PLT | G.CS_EPH)
+    px = np.zeros((1, 256, 256), np.uint8)
+    p = G.TileParams.make(256, 256, 1, 8, 3, cblk=(3, 3))
+    _check(p, px, [9], 0)
+
+
+def test_batches_of_tiles_and_appended_batches():
+    c = U.ctx()
+    px = synth.g2(3, 4 * 128, 160, 8, seed=4).reshape(4, 3, 128, 160)          # four tiles of 160 x 128
+    p = G.TileParams.make(160, 128, 3, 8, 3)
+    flags = G.CS_PLT | G.CS_PROG(2)
+    want = _check(p, px, [3, 0, 65534, 7], flags, ntiles=4)
+    # a second batch of another geometry appended behind the first: what lay below dst_offset is kept
+    n0 = sum(len(w) for w in want)
+    px2 = synth.g2(1, 2 * 96, 96, 12, seed=5).reshape(2, 1, 96, 96)
+    p2 = G.TileParams.make(96, 96, 1, 12, 2)
+    table2, coded2 = c.encode_host(p2, px2, ntiles=2)
+    n1, lens2 = c.assemble_device(p2, [1, 2], flags, dst_offset=n0)
+    want2 = _host_parts(p2, [1, 2], table2, coded2, flags)
+    assert n1 == sum(len(w) for w in want2)
+    assert bytes(c.fetch_assembled(0, n0 + n1)) == b"".join(want) + b"".join(want2)
+
+
+def test_refuses_what_it_cannot_assemble():
+    c = U.ctx()
+    px = synth.g2(1, 64, 64, 8, seed=1)
+    p = G.TileParams.make(64, 64, 1, 8, 2)
+    c.encode_host(p, px)
+    q = G.TileParams.make(64, 64, 1, 8, 3)
+    with pytest.raises(RuntimeError):
+        c.assemble_device(q, [0])                       # not the call before it
+    with pytest.raises(RuntimeError):
+        c.assemble_device(p, [0, 1])                    # not its number of tiles
+    n, _ = c.assemble_device(p, [0])
+    with pytest.raises(RuntimeError):
+        c.assemble_device(p, [0], dst_offset=n + 1)     # a hole in the output
