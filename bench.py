@@ -996,7 +996,7 @@ def main():
     # one encode up front: buffers exist
     ctx.encode_tiles(params, ntiles, d_px.data_ptr(), True, fetch=False)
     _, total0 = ctx.fetch_table(nblocks)
-    comm = torch.cuda.Stream(device=dev, priority=D.comm_priority()) if use_dist else None
+    comm = D.independent_stream(ctx, dev) if use_dist else None
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -1048,7 +1048,7 @@ def main():
 
         ctx.set_pipelining(False if args.no_overlap else (depth + lag if exchange == "gather" else True))
         if exchange == "gather":
-            pipe[0] = D.FramePipeline(dev, (stream, comm), depth=1 if args.no_overlap else depth, lag=1 if args.no_overlap else lag)
+            pipe[0] = D.FramePipeline(dev, (stream, comm), depth=1 if args.no_overlap else depth, lag=1 if args.no_overlap else lag, ctx=ctx)
         for f in range(warmup):
             one(f)
         flush()

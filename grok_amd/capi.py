@@ -486,6 +486,23 @@ class Context:
         self._check(self._L.grk_amd_block_distortion(self._h, out.ctypes.data, int(nblocks)), "block_distortion")
         return out
 
+    def probe_streams(self):
+        """The context's stream probe now (grk_amd_probe_streams); returns the side streams replaced so far (-1: probe off)."""
+        self._check(self._L.grk_amd_probe_streams(self._h), "probe_streams")
+        return int(self._L.grk_amd_stream_probe_result(self._h))
+
+    def internal_stream(self, which):
+        self._L.grk_amd_internal_stream.restype = C.c_void_p
+        self._L.grk_amd_internal_stream.argtypes = [C.c_void_p, C.c_int]
+        return self._L.grk_amd_internal_stream(self._h, which)
+
+    def streams_side_by_side(self, a, b):
+        self._L.grk_amd_streams_side_by_side.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        r = self._L.grk_amd_streams_side_by_side(self._h, a, b)
+        if r < 0:
+            raise RuntimeError("streams_side_by_side failed: %d" % r)
+        return bool(r)
+
     def set_pixel_hold(self, on):
         """True: the caller keeps a call's device pixels untouched until stream_wait_pixels / synchronize (include/grok_amd.h)."""
         if hasattr(self._L, "grk_amd_set_pixel_hold"):

@@ -176,6 +176,13 @@ struct grk_amd_ctx {
     // (grk_amd_set_pixel_hold(ctx, 1): the caller keeps a call's pixels untouched until grk_amd_stream_wait_pixels / a synchronisation;
     //  the wait -- two queue hand-overs between consecutive small frames, 0.038 -> 0.057 ms per 512^2 call -- is then left out)
     hipEvent_t ev_px = nullptr; bool want_px_event = false; bool px_hold = false; bool px_event_valid = false;
+    // The encoder's three streams have to DISPATCH side by side.  Hardware queues are served by a few dispatch pipes; two queues on one
+    // pipe take turns while one of them has a large grid in flight, and which queue a stream gets depends on how many streams the process
+    // made before (profiles/r06_hw_queues.txt: 0.37 -> 0.55 ms per 8K frame with 4, 5 or 8 earlier streams).  Before the first
+    // overlapped encode on a given main stream the three are probed pairwise (a grid that stays in dispatch for ~150 us on one, a
+    // one-workgroup kernel on the other) and a side stream that has to wait is replaced (GRK_AMD_STREAM_PROBE=0: never)
+    int stream_probe = 1; hipStream_t probed_main = nullptr; int side_priority = 0;
+    int probe_replaced = 0;           // side streams replaced by the probe so far (grk_amd_stream_probe_result)
     int k3_room = 3;                  // pipelined encodes: K3 launches that leave registers for the next frame's level 0 -- bit 0 the top class, bit 1 the rest (GRK_AMD_K3_ROOM)
     // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
     // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; 2: lanes wherever they can be used; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
@@ -480,6 +487,89 @@ int run_ingest(grk_amd_ctx* c, uint32_t ntiles, const void* d_pixels, void* d_pl
 HtArgs make_ht_args(grk_amd_ctx* c, uint32_t ntiles, const void* d_mallat, int* rc, bool h16 = false);
 
 // everything that reads or overwrites the results of the latest encode on the main stream comes after its side streams
+// ---- stream probe -----------------------------------------------------------------------------------------------------------------
+// 16 384 workgroups that hold 40 KB of LDS (four to a CU) for ~10 us each: ~160 us during which the grid is still being dispatched
+__global__ __launch_bounds__(64) void probe_spin_kernel(unsigned int ticks, unsigned int* sink)
+{
+    extern __shared__ unsigned int pad[];              // 40 KB asked for at the launch
+    pad[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (sink && pad[threadIdx.x] == 0xFFFFFFFFu) *sink = 1;
+}
+__global__ void probe_tick_kernel(unsigned int* sink) { if (sink && threadIdx.x == 1024) *sink = 1; }
+
+// does a kernel launched on `b` while a large grid of `a` is in dispatch run at once?  (both streams idle on entry and on return)
+int streams_side_by_side(grk_amd_ctx* c, hipStream_t a, hipStream_t b, bool* yes)
+{
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&ea);
+    if (e == hipSuccess) e = hipEventCreate(&eb);
+    if (e == hipSuccess) e = hipEventRecord(e0, a);
+    if (e == hipSuccess) { hipLaunchKernelGGL(probe_spin_kernel, dim3(16384), dim3(64), 40960, a, 1000u, (unsigned int*)nullptr); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipEventRecord(ea, a);
+    // (the small kernel is launched once the grid has started: e0 has passed)
+    if (e == hipSuccess) { while ((e = hipEventQuery(e0)) == hipErrorNotReady) {} }
+    if (e == hipSuccess) { hipLaunchKernelGGL(probe_tick_kernel, dim3(1), dim3(64), 0, b, (unsigned int*)nullptr); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipEventRecord(eb, b);
+    if (e == hipSuccess) e = hipStreamSynchronize(a);
+    if (e == hipSuccess) e = hipStreamSynchronize(b);
+    float ta = 0, tb = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ta, e0, ea);
+    if (e == hipSuccess) e = hipEventElapsedTime(&tb, e0, eb);
+    if (e0) (void)hipEventDestroy(e0);
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    if (e != hipSuccess) return fail(c, GRK_AMD_ERR_NO_DEVICE, "stream probe", e);
+    *yes = tb < 0.6f * ta;
+    if (c->verbose) fprintf(stderr, "[grok_amd] stream probe: grid %.3f ms, small kernel done after %.3f ms -> %s\n", ta, tb, *yes ? "side by side" : "in turn");
+    return GRK_AMD_OK;
+}
+
+int probe_streams(grk_amd_ctx* c)
+{
+    if (!c->stream_probe || c->probed_main == c->stream || !c->side) return GRK_AMD_OK;
+    c->probed_main = c->stream;
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    HIP_TRY(c, hipStreamSynchronize(c->side), "sync");
+    if (c->side2) HIP_TRY(c, hipStreamSynchronize(c->side2), "sync");
+    c->side_pending = false;
+    // (the kernels' first launch loads their code: not to be measured)
+    hipLaunchKernelGGL(probe_spin_kernel, dim3(256), dim3(64), 40960, c->stream, 10u, (unsigned int*)nullptr);
+    hipLaunchKernelGGL(probe_tick_kernel, dim3(1), dim3(64), 0, c->stream, (unsigned int*)nullptr);
+    HIP_TRY(c, hipGetLastError(), "stream probe");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    std::vector<hipStream_t> rejects;                  // kept alive until the end: a stream made now gets another queue than these
+    auto good = [&](hipStream_t cand, hipStream_t other, bool* ok) -> int {
+        bool y = false;
+        int rc = streams_side_by_side(c, c->stream, cand, &y); if (rc) return rc;
+        if (y) { rc = streams_side_by_side(c, cand, c->stream, &y); if (rc) return rc; }
+        if (y && other) { rc = streams_side_by_side(c, other, cand, &y); if (rc) return rc; }
+        if (y && other) { rc = streams_side_by_side(c, cand, other, &y); if (rc) return rc; }
+        *ok = y;
+        return GRK_AMD_OK;
+    };
+    int rc = GRK_AMD_OK;
+    for (int which = 0; which < 2 && rc == GRK_AMD_OK; ++which) {
+        hipStream_t& mine = which ? c->side2 : c->side;
+        if (!mine) continue;
+        hipStream_t other = which ? c->side : nullptr;
+        bool ok = false;
+        rc = good(mine, other, &ok);
+        for (int tries = 0; rc == GRK_AMD_OK && !ok && tries < 8; ++tries) {
+            hipStream_t cand = nullptr;
+            if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, c->side_priority) != hipSuccess) { (void)hipGetLastError(); break; }
+            rc = good(cand, other, &ok);
+            if (rc == GRK_AMD_OK && ok) { rejects.push_back(mine); mine = cand; ++c->probe_replaced; }
+            else rejects.push_back(cand);
+        }
+        // (none found: the stream stays as it was)
+    }
+    for (hipStream_t r : rejects) (void)hipStreamDestroy(r);
+    return rc;
+}
+
 int join_side(grk_amd_ctx* c)
 {
     if (!c->side_pending) return GRK_AMD_OK;
@@ -1126,6 +1216,8 @@ int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** o
         if (const char* er = getenv("GRK_AMD_T1_TAIL_RATIO")) c->t1_tail_ratio = (float)atof(er);
         if (const char* es = getenv("GRK_AMD_T1_TAIL_SHARE")) c->t1_tail_share = (float)atof(es);
         if (const char* ey = getenv("GRK_AMD_T1_SYNC")) c->t1_pass_sync = atoi(ey) != 0;
+        if (const char* ep = getenv("GRK_AMD_STREAM_PROBE")) c->stream_probe = atoi(ep);
+        c->side_priority = least;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess ||
@@ -1780,6 +1872,38 @@ int grk_amd_fetch_assembled_async(grk_amd_ctx* c, uint64_t offset, uint64_t nbyt
     return GRK_AMD_OK;
 }
 
+// The probe for a host's own streams (an exchange's stream that waits for the encoder's results holds its dispatch pipe while it waits:
+// it must not share the main stream's): 1 when kernels of `a` and `b` are dispatched side by side, in both directions; 0 when one
+// waits for the other's grid.  Both streams are synchronised.
+int grk_amd_streams_side_by_side(grk_amd_ctx* c, void* a, void* b)
+{
+    if (!c || !a || !b || a == b) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)a), "sync");
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)b), "sync");
+    hipLaunchKernelGGL(probe_spin_kernel, dim3(256), dim3(64), 40960, (hipStream_t)a, 10u, (unsigned int*)nullptr);
+    hipLaunchKernelGGL(probe_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)a, (unsigned int*)nullptr);
+    HIP_TRY(c, hipGetLastError(), "stream probe");
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)a), "sync");
+    bool y = false;
+    int rc = streams_side_by_side(c, (hipStream_t)a, (hipStream_t)b, &y); if (rc) return rc;
+    if (y) { rc = streams_side_by_side(c, (hipStream_t)b, (hipStream_t)a, &y); if (rc) return rc; }
+    return y ? 1 : 0;
+}
+// the context's streams as they are now: 0 the main stream (grk_amd_set_stream's, or its own), 1 / 2 the side streams
+void* grk_amd_internal_stream(grk_amd_ctx* c, int which) { return !c ? nullptr : which == 0 ? (void*)c->stream : which == 1 ? (void*)c->side : which == 2 ? (void*)c->side2 : nullptr; }
+// the context's own probe now (it runs by itself before the first pipelined encode on a main stream)
+int grk_amd_probe_streams(grk_amd_ctx* c)
+{
+    if (!c) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    { const int jr = join_side(c); if (jr) return jr; }
+    return probe_streams(c);
+}
+
+// side streams the probe has replaced so far (-1: the probe is switched off)
+int grk_amd_stream_probe_result(grk_amd_ctx* c) { return !c ? GRK_AMD_ERR_INVALID : c->stream_probe ? c->probe_replaced : -1; }
+
 void* grk_amd_coded_device_ptr(grk_amd_ctx* c) { return c ? c->arena.p : nullptr; }
 void* grk_amd_table_device_ptr(grk_amd_ctx* c, int which)
 {
@@ -1828,6 +1952,7 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     {
         ScopedTimer t(c, 3);
         const bool ov = c->overlap && g.p.num_levels >= 1 && c->side != nullptr;
+        if (ov && c->pipelining && c->seq_index < 0) { rc = probe_streams(c); if (rc) return rc; }
         // (device-resident pixels only: the staging buffer of host pixels is filled on the main stream, which must then carry level 0)
         // (... and the fused level 0: the stand-alone ingest writes planes that are not part of a buffer set)
         const bool fs = ov && c->pipelining && c->side2 != nullptr && on_device && fused &&

@@ -116,6 +116,27 @@ def comm_priority():
     return int(os.environ.get("GROK_AMD_COMM_PRIORITY", "0"))
 
 
+def independent_stream(ctx, device, priority=None, tries=8):
+    """A stream for work that WAITS for the encoder (the counts exchange, a gather): one whose kernels are dispatched side by side with
+    the context's three streams (Context.streams_side_by_side) -- a stream with a wait at its head holds its dispatch pipe, and when
+    that is the main stream's pipe the encode pipeline loses a third (profiles/r06_hw_queues.txt).  The hardware queue a stream gets
+    depends on the streams made before it: candidates are made until one passes (the others are dropped afterwards); with
+    GRK_AMD_STREAM_PROBE=0, or when none passes, the first one."""
+    pr = comm_priority() if priority is None else priority
+    first = torch.cuda.Stream(device=device, priority=pr)
+    if os.environ.get("GRK_AMD_STREAM_PROBE", "1") == "0":
+        return first
+    ctx.probe_streams()
+    mine = [ctx.internal_stream(i) for i in range(3)]
+    cands = [first]
+    for _ in range(tries):
+        c = cands[-1]
+        if all(m is None or ctx.streams_side_by_side(m, c.cuda_stream) for m in mine):
+            return c
+        cands.append(torch.cuda.Stream(device=device, priority=pr))
+    return first
+
+
 def comm_options():
     """Process-group options: RCCL's OWN streams -- the ones the transfers run on -- at high priority (GROK_AMD_RCCL_PRIORITY=0:
     the backend's default).  The HIP runtime keeps a pool of (by default 4) hardware queues per priority LEVEL, and kernels of
@@ -158,7 +179,7 @@ class FramePipeline:
     bytes used in their coded arena), straight out of the encoder's own device word -- no kernel, no allocation, no host
     synchronisation on the submitting side."""
 
-    def __init__(self, device, streams=None, depth=1, lag=1):
+    def __init__(self, device, streams=None, depth=1, lag=1, ctx=None):
         self.dev = device
         self.streams = streams
         self.depth = max(1, int(depth))
@@ -188,7 +209,8 @@ class FramePipeline:
             # (main + two side streams), and every further stream shares a queue with one of them (measured at world 1, 8K frames:
             # counts-only exchange 0.425 ms per frame; gather depth 4 with the counts on a stream of their own 0.504, with the
             # counts on slot 0's stream 0.453, everything on one stream 0.448).  The counts therefore ride on slot 0's stream.
-            self.gstreams = [streams[1]] + [torch.cuda.Stream(device=device, priority=comm_priority()) for _ in range(self.depth - 1)]
+            self.gstreams = [streams[1]] + [(independent_stream(ctx, device) if ctx is not None else torch.cuda.Stream(device=device, priority=comm_priority()))
+                                            for _ in range(self.depth - 1)]
             self.ctrl_stream = streams[1]
         else:
             self.gstreams = [None] * self.depth

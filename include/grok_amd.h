@@ -150,6 +150,19 @@ int grk_amd_encode_tiles(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_
  * passed grk_amd_stream_wait_pixels (or grk_amd_synchronize returned); the wait is then left out.  A ring of input buffers with
  * one grk_amd_stream_wait_pixels before a buffer is refilled is the intended use. */
 int grk_amd_set_pixel_hold(grk_amd_ctx* ctx, int on);
+/* Pipelined encodes run on three streams (the caller's + two of the context's) whose kernels have to be DISPATCHED side by side; whether
+ * they can depends on the hardware queues the runtime gave them, i.e. on the streams the process made before (profiles/r06_hw_queues.txt).
+ * Before the first pipelined encode on a given main stream the context probes its streams pairwise (~2 ms, the main stream is
+ * synchronised once) and replaces a side stream that has to take turns (GRK_AMD_STREAM_PROBE=0: never).  Returns the number of side
+ * streams replaced so far, -1 with the probe off. */
+int grk_amd_stream_probe_result(grk_amd_ctx* ctx);
+/* the same probe at once (e.g. before a host vets its own streams against the context's) */
+int grk_amd_probe_streams(grk_amd_ctx* ctx);
+/* ... and for a host's own streams: 1 when kernels of HIP streams a and b are dispatched side by side (both directions), 0 when one waits
+ * for the other's grid.  A stream that WAITS for the encoder's results (an exchange's) should pass this against grk_amd_internal_stream(ctx,
+ * 0 / 1 / 2) -- the main stream and the two side streams as they are now. */
+int grk_amd_streams_side_by_side(grk_amd_ctx* ctx, void* a, void* b);
+void* grk_amd_internal_stream(grk_amd_ctx* ctx, int which);
 /* Makes `hip_stream` wait until the LATEST grk_amd_encode_tiles call has read its device pixels (not for its results). */
 int grk_amd_stream_wait_pixels(grk_amd_ctx* ctx, void* hip_stream);
 int grk_amd_fetch_table(grk_amd_ctx* ctx, grk_amd_coded_block* table, uint64_t* total_bytes);
