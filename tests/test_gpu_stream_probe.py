@@ -27,7 +27,8 @@ def _frames(ctx, p, d_px, n, nblocks):
 def test_results_do_not_depend_on_the_probe(monkeypatch):
     px = synth.g2(3, 512, 768, 8, seed=2)
     p = G.TileParams.make(768, 512, 3, 8, 4)
-    nb = G.lib().grk_amd_tile_num_blocks(p)
+    import ctypes as C
+    nb = G.lib().grk_amd_tile_num_blocks(C.byref(p))
     d_px = U.to_dev(px.reshape(-1).view(np.uint8))
     extra = [torch.cuda.Stream() for _ in range(5)]               # (another count of earlier streams than the other tests')
     for s in extra:
