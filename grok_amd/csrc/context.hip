@@ -1952,7 +1952,10 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
     {
         ScopedTimer t(c, 3);
         const bool ov = c->overlap && g.p.num_levels >= 1 && c->side != nullptr;
-        if (ov && c->pipelining && c->seq_index < 0) { rc = probe_streams(c); if (rc) return rc; }
+        if (ov && c->pipelining && c->seq_index < 0 && probe_streams(c) != GRK_AMD_OK) {
+            // (the probe is a convenience: when it cannot run, the streams stay as they are and it is not tried again)
+            c->stream_probe = 0; (void)hipGetLastError();
+        }
         // (device-resident pixels only: the staging buffer of host pixels is filled on the main stream, which must then carry level 0)
         // (... and the fused level 0: the stand-alone ingest writes planes that are not part of a buffer set)
         const bool fs = ov && c->pipelining && c->side2 != nullptr && on_device && fused &&

@@ -126,14 +126,17 @@ def independent_stream(ctx, device, priority=None, tries=8):
     first = torch.cuda.Stream(device=device, priority=pr)
     if os.environ.get("GRK_AMD_STREAM_PROBE", "1") == "0":
         return first
-    ctx.probe_streams()
-    mine = [ctx.internal_stream(i) for i in range(3)]
-    cands = [first]
-    for _ in range(tries):
-        c = cands[-1]
-        if all(m is None or ctx.streams_side_by_side(m, c.cuda_stream) for m in mine):
-            return c
-        cands.append(torch.cuda.Stream(device=device, priority=pr))
+    try:
+        ctx.probe_streams()
+        mine = [ctx.internal_stream(i) for i in range(3)]
+        cands = [first]
+        for _ in range(tries):
+            c = cands[-1]
+            if all(m is None or ctx.streams_side_by_side(m, c.cuda_stream) for m in mine):
+                return c
+            cands.append(torch.cuda.Stream(device=device, priority=pr))
+    except Exception:  # noqa: BLE001  (the probe is a convenience: without it the first stream, as before r06)
+        pass
     return first
 
 
