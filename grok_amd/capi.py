@@ -406,6 +406,17 @@ class Context:
             raise RuntimeError("assemble_device failed: %d (%s)" % (n, self._L.grk_amd_last_error(self._h).decode()))
         return int(n), lens
 
+    def assemble_device_async(self, params, tile_index, flags, stream_ptr):
+        """grk_amd_assemble_device_async: Tier-2 of the latest encode queued on `stream_ptr`; results stay on the device."""
+        idx = np.ascontiguousarray(np.asarray(tile_index, np.uint32))
+        self._L.grk_amd_assemble_device_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        self._check(self._L.grk_amd_assemble_device_async(self._h, C.addressof(params), idx.size, idx.ctypes.data, flags, stream_ptr), "assemble_device_async")
+
+    def assembled_table_ptr(self, which):
+        self._L.grk_amd_assembled_table_ptr.restype = C.c_void_p
+        self._L.grk_amd_assembled_table_ptr.argtypes = [C.c_void_p, C.c_int]
+        return self._L.grk_amd_assembled_table_ptr(self._h, which)
+
     def fetch_assembled(self, offset, nbytes):
         out = np.empty(nbytes, np.uint8)
         self._L.grk_amd_fetch_assembled.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]

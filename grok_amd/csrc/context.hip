@@ -148,8 +148,14 @@ struct grk_amd_ctx {
         T2Plan plan; uint32_t max_blocks = 0;
         DevBuf packets, pob;
     } t2;
-    DevBuf t2_u, t2_h, t2_rel, t2_pkhdr, t2_pkbody, t2_pkdst, t2_lit, t2_litat, t2_litdst, t2_out;
-    uint64_t t2_out_used = 0;
+    DevBuf t2_u, t2_h, t2_rel, t2_pkhdr, t2_pkbody, t2_pkdst, t2_lit, t2_litlen, t2_index;      // scratch: ONE stream at a time uses it
+    // the finished tile-parts, their places and lengths ([tile]: uint64 / uint32) and {bytes assembled by the call, end of the output};
+    // the asynchronous form rotates as many of these as the encoder rotates buffer sets, so that a frame's tile-parts stay where they
+    // are while an exchange sends them
+    struct T2Out { DevBuf out, tile_dst, part_len, total; };
+    T2Out t2_outs[kMaxAltSets + 1];
+    int t2_cur = 0;
+    uint64_t t2_out_used = 0;        // (the synchronous form) bytes of t2_outs[t2_cur].out that hold tile-parts
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
     uint32_t last_ntiles = 0;
@@ -1262,8 +1268,9 @@ void grk_amd_destroy(grk_amd_ctx* c)
     }
     c->ovf.release();
     for (DevBuf* b : {&c->t2.packets, &c->t2.pob, &c->t2_u, &c->t2_h, &c->t2_rel, &c->t2_pkhdr, &c->t2_pkbody, &c->t2_pkdst, &c->t2_lit,
-                      &c->t2_litat, &c->t2_litdst, &c->t2_out})
+                      &c->t2_litlen, &c->t2_index})
         b->release();
+    for (auto& o : c->t2_outs) for (DevBuf* b : {&o.out, &o.tile_dst, &o.part_len, &o.total}) b->release();
     if (c->ev_level0) (void)hipEventDestroy(c->ev_level0);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     for (DevBuf* b : {&c->dec_seg_dev}) b->release();
@@ -1744,19 +1751,15 @@ int grk_amd_block_distortion(grk_amd_ctx* c, double* out, uint64_t cap)
 }
 
 // ---- Tier-2 on the device ----------------------------------------------------------------------------------------------------
-// The finished tile-parts of the LATEST grk_amd_encode_tiles call, made where the coded bytes are: KT1 writes every packet's header
-// (kernels_t2.hip), the packets' lengths come to the host -- a few bytes per packet, the one round trip -- which frames the
-// tile-parts (SOT, PLT, SOD: t2_device_frame) and says where every packet goes, KT2 gathers headers, code-block bytes and frames
-// into the context's output buffer at `dst_offset` (what lies below it is kept: a caller with several batches appends).
-int64_t grk_amd_assemble_device(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const uint32_t* tile_index, uint32_t flags,
-                                uint64_t dst_offset, uint32_t* part_bytes)
+// The finished tile-parts of the LATEST grk_amd_encode_tiles call, made where the coded bytes are (kernels_t2.hip): KT1 writes every
+// packet's header, KT1b frames the tile-parts (SOT, PLT, SOD) and says where every packet goes, KT2 gathers headers, code-block bytes
+// and frames into the output.  Nothing has to come to the host in between.
+namespace {
+// the kernels queued on `st`, which must already be ordered behind the encode's results; `o` takes the tile-parts from dst_offset on
+// (what lies below is kept when the buffer has to grow).  The scratch is the context's: one stream at a time.
+int assemble_enqueue(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const uint32_t* tile_index, uint32_t flags,
+                     uint64_t dst_offset, hipStream_t st, grk_amd_ctx::T2Out& o)
 {
-    if (!c || !p || !ntiles || !tile_index) return GRK_AMD_ERR_INVALID;
-    if (!c->have_geom || !same_params(c->gp, *p) || ntiles != c->last_ntiles || !c->last_nblocks)
-        return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_assemble_device assembles the grk_amd_encode_tiles call before it: same tiles, same parameters");
-    if (dst_offset > c->t2_out_used) return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_assemble_device: dst_offset lies behind what has been assembled");
-    HIP_TRY(c, hipSetDevice(c->device), "set device");
-    { const int jr = join_side(c); if (jr) return jr; }
     const TileGeom& g = c->geom;
     const uint32_t order = (flags >> GRK_AMD_CS_PROG_SHIFT) & 7u;
     auto& T = c->t2;
@@ -1766,24 +1769,55 @@ int64_t grk_amd_assemble_device(grk_amd_ctx* c, const grk_amd_tile_params* p, ui
         if (rc) return fail(c, rc, "tile layout beyond the device writer's tables");
         T.max_blocks = 0;
         for (const T2Packet& k : T.plan.packets) T.max_blocks = std::max(T.max_blocks, k.nblocks);
-        // (the tables of the plan before may still be read by a gather that is queued: the stream is drained first)
+        // (the tables of the plan before may still be read by a gather that is queued: drained first)
+        HIP_TRY(c, hipStreamSynchronize(st), "sync");
         HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
         HIP_TRY(c, T.packets.ensure(T.plan.packets.size() * sizeof(T2Packet)), "alloc packet table");
         HIP_TRY(c, T.pob.ensure(T.plan.packet_of_block.size() * 4), "alloc packet-of-block table");
-        HIP_TRY(c, hipMemcpyAsync(T.packets.p, T.plan.packets.data(), T.plan.packets.size() * sizeof(T2Packet), hipMemcpyHostToDevice, c->stream), "upload");
-        HIP_TRY(c, hipMemcpyAsync(T.pob.p, T.plan.packet_of_block.data(), T.plan.packet_of_block.size() * 4, hipMemcpyHostToDevice, c->stream), "upload");
-        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+        HIP_TRY(c, hipMemcpyAsync(T.packets.p, T.plan.packets.data(), T.plan.packets.size() * sizeof(T2Packet), hipMemcpyHostToDevice, st), "upload");
+        HIP_TRY(c, hipMemcpyAsync(T.pob.p, T.plan.packet_of_block.data(), T.plan.packet_of_block.size() * 4, hipMemcpyHostToDevice, st), "upload");
+        HIP_TRY(c, hipStreamSynchronize(st), "sync");
         T.p = *p; T.order = order; T.valid = true;
     }
     const size_t npk = T.plan.packets.size();
     const uint32_t bpt = (uint32_t)(c->last_nblocks / ntiles);
     const size_t nq = npk * ntiles;
-    HIP_TRY(c, c->t2_u.ensure((size_t)T.plan.u_words * 4 * ntiles + 16), "alloc header bits");
-    HIP_TRY(c, c->t2_h.ensure((size_t)T.plan.h_bytes * ntiles + 16), "alloc headers");
-    HIP_TRY(c, c->t2_rel.ensure(c->last_nblocks * 4), "alloc block places");
-    HIP_TRY(c, c->t2_pkhdr.ensure(nq * 4), "alloc packet lengths");
-    HIP_TRY(c, c->t2_pkbody.ensure(nq * 8), "alloc packet lengths");
-    HIP_TRY(c, hipMemsetAsync(c->t2_u.p, 0, (size_t)T.plan.u_words * 4 * ntiles, c->stream), "clear header bits");
+    // a frame: SOT 12, SOD 2, PLT: at most 6 bytes per packet and 5 per marker segment of 65 532
+    const uint32_t lit_stride = (uint32_t)((14 + 6 * npk + 5 * (6 * npk / 65000 + 2) + 15) & ~(size_t)15);
+    // what the call can write at most: every byte of the arena, every header, every frame
+    const uint64_t bound = (uint64_t)c->arena.cap + (uint64_t)ntiles * (T.plan.h_bytes + lit_stride + 8ull * npk);
+    auto need = [&](DevBuf& b, size_t n, const char* what) -> int {
+        if (n <= b.cap) return GRK_AMD_OK;
+        // (a scratch buffer about to be replaced may be in use by kernels queued earlier on the stream)
+        HIP_TRY(c, hipStreamSynchronize(st), "sync");
+        HIP_TRY(c, b.ensure(n), what);
+        return GRK_AMD_OK;
+    };
+    int rc;
+    if ((rc = need(c->t2_u, (size_t)T.plan.u_words * 4 * ntiles + 16, "alloc header bits"))) return rc;
+    if ((rc = need(c->t2_h, (size_t)T.plan.h_bytes * ntiles + 16, "alloc headers"))) return rc;
+    if ((rc = need(c->t2_rel, c->last_nblocks * 4, "alloc block places"))) return rc;
+    if ((rc = need(c->t2_pkhdr, nq * 4, "alloc packet lengths"))) return rc;
+    if ((rc = need(c->t2_pkbody, nq * 8, "alloc packet lengths"))) return rc;
+    if ((rc = need(c->t2_pkdst, nq * 8, "alloc packet places"))) return rc;
+    if ((rc = need(c->t2_lit, (size_t)lit_stride * ntiles, "alloc frames"))) return rc;
+    if ((rc = need(c->t2_litlen, (size_t)ntiles * 4, "alloc frames"))) return rc;
+    if ((rc = need(c->t2_index, (size_t)ntiles * 4, "alloc tile numbers"))) return rc;
+    if ((rc = need(o.tile_dst, (size_t)ntiles * 8, "alloc tile-part places"))) return rc;
+    if ((rc = need(o.part_len, (size_t)ntiles * 4, "alloc tile-part lengths"))) return rc;
+    if ((rc = need(o.total, 16, "alloc tile-part total"))) return rc;
+    if (o.out.cap < dst_offset + bound) {
+        DevBuf bigger;
+        HIP_TRY(c, hipStreamSynchronize(st), "sync");
+        HIP_TRY(c, bigger.ensure(dst_offset + bound), "alloc tile-parts");
+        if (dst_offset) HIP_TRY(c, hipMemcpyAsync(bigger.p, o.out.p, dst_offset, hipMemcpyDeviceToDevice, st), "keep tile-parts");
+        HIP_TRY(c, hipStreamSynchronize(st), "sync");
+        o.out.release();
+        o.out = bigger;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->t2_u.p, 0, (size_t)T.plan.u_words * 4 * ntiles, st), "clear header bits");
+    // (the tile numbers: pageable memory of the caller's -- the runtime has staged them when the call returns)
+    HIP_TRY(c, hipMemcpyAsync(c->t2_index.p, tile_index, (size_t)ntiles * 4, hipMemcpyHostToDevice, st), "upload");
     T2HeaderArgs ha{};
     ha.packets = (const T2Packet*)T.packets.p; ha.npackets = (uint32_t)npk;
     ha.lengths = (const uint32_t*)c->lengths.p; ha.bpt = bpt; ha.ntiles = ntiles;
@@ -1791,64 +1825,89 @@ int64_t grk_amd_assemble_device(grk_amd_ctx* c, const grk_amd_tile_params* p, ui
     ha.hdr = (uint8_t*)c->t2_h.p; ha.h_bytes = T.plan.h_bytes;
     ha.rel = (uint32_t*)c->t2_rel.p; ha.pk_hdr = (uint32_t*)c->t2_pkhdr.p; ha.pk_body = (uint64_t*)c->t2_pkbody.p;
     ha.status = (unsigned int*)c->flag.p;
-    HIP_TRY(c, launch_t2_header(ha, T.max_blocks, c->stream), "launch Tier-2 headers");
-    std::vector<uint32_t> hdr_len(nq);
-    std::vector<uint64_t> body_len(nq), pk_dst(nq), lit_dst(ntiles);
-    std::vector<uint32_t> lit_at(ntiles + 1, 0);
-    uint64_t flagwords[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(flagwords, c->flag.p, 16, hipMemcpyDeviceToHost, c->stream), "fetch flag");
-    HIP_TRY(c, hipMemcpyAsync(hdr_len.data(), c->t2_pkhdr.p, nq * 4, hipMemcpyDeviceToHost, c->stream), "fetch packet lengths");
-    HIP_TRY(c, hipMemcpyAsync(body_len.data(), c->t2_pkbody.p, nq * 8, hipMemcpyDeviceToHost, c->stream), "fetch packet lengths");
-    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
-    if (flagwords[0] & 1u) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
-    if (flagwords[0] & 2u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "coefficient magnitude exceeds Kmax+1 bits");
-    if (flagwords[0] & 4u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "a code-block longer than the device writer takes");
-    // the frames and everybody's place
-    std::vector<uint8_t> lit;
-    uint64_t at = dst_offset;
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        lit_at[t] = (uint32_t)lit.size();
-        lit_dst[t] = at;
-        const uint64_t len = t2_device_frame(flags, tile_index[t], hdr_len.data() + t * npk, body_len.data() + t * npk, npk, lit, pk_dst.data() + t * npk);
-        if (!len) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "tile-part beyond 4 GB or packet lengths beyond what PLT can carry");
-        for (size_t i = 0; i < npk; ++i) pk_dst[t * npk + i] += at;
-        if (part_bytes) part_bytes[t] = (uint32_t)len;
-        at += len;
-    }
-    lit_at[ntiles] = (uint32_t)lit.size();
-    if (c->t2_out.cap < at) {
-        // (grown with what lies below dst_offset kept)
-        DevBuf bigger;
-        HIP_TRY(c, bigger.ensure(at + (at >> 2)), "alloc tile-parts");
-        if (dst_offset) HIP_TRY(c, hipMemcpyAsync(bigger.p, c->t2_out.p, dst_offset, hipMemcpyDeviceToDevice, c->stream), "keep tile-parts");
-        HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
-        c->t2_out.release();
-        c->t2_out = bigger;
-    }
-    HIP_TRY(c, c->t2_pkdst.ensure(nq * 8), "alloc packet places");
-    HIP_TRY(c, c->t2_lit.ensure(lit.size() + 16), "alloc frames");
-    HIP_TRY(c, c->t2_litat.ensure((ntiles + 1) * 4), "alloc frames");
-    HIP_TRY(c, c->t2_litdst.ensure((size_t)ntiles * 8), "alloc frames");
-    HIP_TRY(c, hipMemcpyAsync(c->t2_pkdst.p, pk_dst.data(), nq * 8, hipMemcpyHostToDevice, c->stream), "upload");
-    HIP_TRY(c, hipMemcpyAsync(c->t2_lit.p, lit.data(), lit.size(), hipMemcpyHostToDevice, c->stream), "upload");
-    HIP_TRY(c, hipMemcpyAsync(c->t2_litat.p, lit_at.data(), (ntiles + 1) * 4, hipMemcpyHostToDevice, c->stream), "upload");
-    HIP_TRY(c, hipMemcpyAsync(c->t2_litdst.p, lit_dst.data(), (size_t)ntiles * 8, hipMemcpyHostToDevice, c->stream), "upload");
+    HIP_TRY(c, launch_t2_header(ha, T.max_blocks, st), "launch Tier-2 headers");
+    const uint32_t sop = (flags & GRK_AMD_CS_SOP) ? 6u : 0u, eph = (flags & GRK_AMD_CS_EPH) ? 2u : 0u;
+    T2FrameArgs fa{};
+    fa.npackets = (uint32_t)npk; fa.ntiles = ntiles; fa.pk_hdr = ha.pk_hdr; fa.pk_body = ha.pk_body;
+    fa.tile_index = (const uint32_t*)c->t2_index.p; fa.extra = sop + eph; fa.plt = (flags & GRK_AMD_CS_PLT) ? 1u : 0u;
+    fa.dst_offset = dst_offset;
+    fa.lit = (uint8_t*)c->t2_lit.p; fa.lit_stride = lit_stride; fa.lit_len = (uint32_t*)c->t2_litlen.p;
+    fa.pk_dst = (uint64_t*)c->t2_pkdst.p;
+    fa.part_len = (uint32_t*)o.part_len.p; fa.tile_dst = (unsigned long long*)o.tile_dst.p; fa.total = (unsigned long long*)o.total.p;
+    fa.status = (unsigned int*)c->flag.p;
+    HIP_TRY(c, launch_t2_frame(fa, st), "launch Tier-2 frames");
     T2GatherArgs ga{};
     ga.packets = (const T2Packet*)T.packets.p; ga.npackets = (uint32_t)npk; ga.packet_of_block = (const uint32_t*)T.pob.p;
     ga.lengths = (const uint32_t*)c->lengths.p; ga.offsets = (const uint64_t*)c->offsets.p; ga.arena = (const uint8_t*)c->arena.p;
     ga.bpt = bpt; ga.ntiles = ntiles;
     ga.hdr = (const uint8_t*)c->t2_h.p; ga.h_bytes = T.plan.h_bytes;
     ga.rel = (const uint32_t*)c->t2_rel.p; ga.pk_hdr = (const uint32_t*)c->t2_pkhdr.p; ga.pk_dst = (const uint64_t*)c->t2_pkdst.p;
-    ga.lit = (const uint8_t*)c->t2_lit.p; ga.lit_at = (const uint32_t*)c->t2_litat.p; ga.lit_dst = (const uint64_t*)c->t2_litdst.p;
-    ga.out = (uint8_t*)c->t2_out.p;
-    ga.sop = (flags & GRK_AMD_CS_SOP) ? 6u : 0u; ga.eph = (flags & GRK_AMD_CS_EPH) ? 2u : 0u;
-    HIP_TRY(c, launch_t2_gather(ga, c->stream), "launch Tier-2 gather");
-    // (the uploads above read pageable vectors of this frame: the runtime has staged them by the time the calls return)
-    c->t2_out_used = at;
-    return (int64_t)(at - dst_offset);
+    ga.lit = (const uint8_t*)c->t2_lit.p; ga.lit_stride = lit_stride; ga.lit_len = (const uint32_t*)c->t2_litlen.p;
+    ga.tile_dst = (const unsigned long long*)o.tile_dst.p;
+    ga.out = (uint8_t*)o.out.p;
+    ga.sop = sop; ga.eph = eph;
+    HIP_TRY(c, launch_t2_gather(ga, st), "launch Tier-2 gather");
+    return GRK_AMD_OK;
 }
 
-void* grk_amd_assembled_device_ptr(grk_amd_ctx* c) { return c ? c->t2_out.p : nullptr; }
+int assemble_check(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const uint32_t* tile_index)
+{
+    if (!c || !p || !ntiles || !tile_index) return GRK_AMD_ERR_INVALID;
+    if (!c->have_geom || !same_params(c->gp, *p) || ntiles != c->last_ntiles || !c->last_nblocks)
+        return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_assemble_device assembles the grk_amd_encode_tiles call before it: same tiles, same parameters");
+    return GRK_AMD_OK;
+}
+} // namespace
+
+int64_t grk_amd_assemble_device(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const uint32_t* tile_index, uint32_t flags,
+                                uint64_t dst_offset, uint32_t* part_bytes)
+{
+    { const int rc = assemble_check(c, p, ntiles, tile_index); if (rc) return rc; }
+    if (dst_offset > c->t2_out_used) return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_assemble_device: dst_offset lies behind what has been assembled");
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    { const int jr = join_side(c); if (jr) return jr; }
+    auto& o = c->t2_outs[c->t2_cur];
+    { const int rc = assemble_enqueue(c, p, ntiles, tile_index, flags, dst_offset, c->stream, o); if (rc) return rc; }
+    uint64_t flagwords[2] = {0, 0}, total[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(flagwords, c->flag.p, 16, hipMemcpyDeviceToHost, c->stream), "fetch flag");
+    HIP_TRY(c, hipMemcpyAsync(total, o.total.p, 16, hipMemcpyDeviceToHost, c->stream), "fetch total");
+    if (part_bytes) HIP_TRY(c, hipMemcpyAsync(part_bytes, o.part_len.p, (size_t)ntiles * 4, hipMemcpyDeviceToHost, c->stream), "fetch tile-part lengths");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    if (flagwords[0] & 1u) return fail(c, GRK_AMD_ERR_OVERFLOW, "coded arena overflow");
+    if (flagwords[0] & 2u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "coefficient magnitude exceeds Kmax+1 bits");
+    if (flagwords[0] & 4u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "a code-block longer than the device writer takes");
+    if (flagwords[0] & 8u) return fail(c, GRK_AMD_ERR_UNSUPPORTED, "tile-part beyond 4 GB or packet lengths beyond what PLT can carry");
+    c->t2_out_used = total[1];
+    return (int64_t)total[0];
+}
+
+// The same without the host: queued on `hip_stream` (made to wait for the encode's results first, as grk_amd_stream_wait_results does),
+// nothing is waited for.  Pipelined encodes rotate as many outputs as buffer sets: a frame's tile-parts, their places / lengths and the
+// total (grk_amd_assembled_device_ptr, grk_amd_assembled_table_ptr) stay untouched until that many further calls -- time for an
+// exchange to send them.  Every asynchronous call of a context has to use the SAME stream (the scratch is shared, stream order keeps
+// the calls apart); errors (bits 0-3 of the encode's status word) are the consumer's to find: the bytes will not parse.
+int grk_amd_assemble_device_async(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t ntiles, const uint32_t* tile_index, uint32_t flags,
+                                  void* hip_stream)
+{
+    { const int rc = assemble_check(c, p, ntiles, tile_index); if (rc) return rc; }
+    if (!hip_stream) return GRK_AMD_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device), "set device");
+    { const int rc = grk_amd_stream_wait_results(c, hip_stream); if (rc) return rc; }
+    const int nsets = c->pipelining ? std::max(1, std::min(c->pipe_depth, grk_amd_ctx::kMaxAltSets + 1)) : 1;
+    c->t2_cur = (c->t2_cur + 1) % nsets;
+    c->t2_out_used = 0;
+    return assemble_enqueue(c, p, ntiles, tile_index, flags, 0, (hipStream_t)hip_stream, c->t2_outs[c->t2_cur]);
+}
+
+void* grk_amd_assembled_device_ptr(grk_amd_ctx* c) { return c ? c->t2_outs[c->t2_cur].out.p : nullptr; }
+// of the latest assemble call -- 0: uint64[tiles] where each tile-part starts, 1: uint32[tiles] its length, 2: uint64[2] {bytes the call
+// assembled, end of the output}
+void* grk_amd_assembled_table_ptr(grk_amd_ctx* c, int which)
+{
+    if (!c) return nullptr;
+    auto& o = c->t2_outs[c->t2_cur];
+    return which == 0 ? o.tile_dst.p : which == 1 ? o.part_len.p : which == 2 ? o.total.p : nullptr;
+}
 
 // bytes [offset, offset + nbytes) of the assembled tile-parts to host memory: pinned memory in one DMA, pageable memory through the
 // context's pinned chunks on several copy threads (copy_d2h); complete on return
@@ -1857,7 +1916,7 @@ int grk_amd_fetch_assembled(grk_amd_ctx* c, uint64_t offset, uint64_t nbytes, ui
     if (!c || !dst || offset + nbytes > c->t2_out_used) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     if (!nbytes) return GRK_AMD_OK;
-    { const int rc = copy_d2h(c, dst, (const uint8_t*)c->t2_out.p + offset, nbytes); if (rc) return rc; }
+    { const int rc = copy_d2h(c, dst, (const uint8_t*)c->t2_outs[c->t2_cur].out.p + offset, nbytes); if (rc) return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     return GRK_AMD_OK;
 }
@@ -1868,7 +1927,7 @@ int grk_amd_fetch_assembled_async(grk_amd_ctx* c, uint64_t offset, uint64_t nbyt
     if (!c || !dst || offset + nbytes > c->t2_out_used) return GRK_AMD_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     if (!host_is_pinned(dst)) return fail(c, GRK_AMD_ERR_INVALID, "grk_amd_fetch_assembled_async needs pinned memory (grk_amd_host_alloc)");
-    if (nbytes) HIP_TRY(c, hipMemcpyAsync(dst, (const uint8_t*)c->t2_out.p + offset, nbytes, hipMemcpyDeviceToHost, c->stream), "download");
+    if (nbytes) HIP_TRY(c, hipMemcpyAsync(dst, (const uint8_t*)c->t2_outs[c->t2_cur].out.p + offset, nbytes, hipMemcpyDeviceToHost, c->stream), "download");
     return GRK_AMD_OK;
 }
 

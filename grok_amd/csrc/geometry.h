@@ -82,11 +82,6 @@ struct T2Plan {
 };
 constexpr uint32_t kT2MaxLenBits = 29;            // block lengths the device writer takes (a coded block is a few KB)
 int t2_device_plan(const TileGeom& g, uint32_t flags, T2Plan& out);
-// The frame of one tile-part once the packets' header and body lengths are known: SOT, (PLT,) SOD appended to `lit`, every packet's
-// place relative to the tile-part's start in pk_at[]; returns the tile-part's length (0: PLT does not fit the syntax).
-uint64_t t2_device_frame(uint32_t flags, uint32_t tile_index, const uint32_t* hdr_len, const uint64_t* body_len, size_t npk,
-                         std::vector<uint8_t>& lit, uint64_t* pk_at);
-
 inline uint32_t ceil_div_pow2(uint32_t v, uint32_t n) { return (uint32_t)(((uint64_t)v + (1ull << n) - 1) >> n); }
 
 } // namespace grk_amd

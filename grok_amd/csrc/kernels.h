@@ -230,6 +230,21 @@ struct T2HeaderArgs {
     unsigned int* status;                            // bit 2: a block length the writer does not take (>= 2^kT2MaxLenBits)
 };
 hipError_t launch_t2_header(const T2HeaderArgs& a, uint32_t max_blocks_per_packet, hipStream_t s);
+struct T2FrameArgs {
+    uint32_t npackets, ntiles;
+    const uint32_t* pk_hdr; const uint64_t* pk_body;
+    const uint32_t* tile_index;                      // [tile]: Isot
+    uint32_t extra;                                  // bytes per packet beside header and body (SOP 6, EPH 2)
+    uint32_t plt;
+    uint64_t dst_offset;                             // where the call's first tile-part goes in the output
+    uint8_t* lit; uint32_t lit_stride;               // the frames, lit_stride bytes apart
+    uint32_t* lit_len;                               // [tile]
+    uint64_t* pk_dst;                                // [tile][packet]
+    uint32_t* part_len; unsigned long long* tile_dst;   // [tile]: the tile-part's length and place (what a host or an exchange reads)
+    unsigned long long* total;                       // [0] bytes assembled by this call, [1] the end of the output
+    unsigned int* status;                            // bit 3: a tile-part beyond 4 GB / PLT beyond 256 marker segments
+};
+hipError_t launch_t2_frame(const T2FrameArgs& a, hipStream_t s);
 struct T2GatherArgs {
     const T2Packet* packets; uint32_t npackets;
     const uint32_t* packet_of_block;                 // [row]
@@ -238,8 +253,8 @@ struct T2GatherArgs {
     const uint8_t* hdr; uint32_t h_bytes;
     const uint32_t* rel; const uint32_t* pk_hdr;
     const uint64_t* pk_dst;                          // [tile][packet]: where the packet starts in `out`
-    const uint8_t* lit; const uint32_t* lit_at;      // the tile-parts' frames (SOT .. SOD): tile t's bytes are lit[lit_at[t] .. lit_at[t + 1])
-    const uint64_t* lit_dst;                         // ... and go to out + lit_dst[t]
+    const uint8_t* lit; uint32_t lit_stride; const uint32_t* lit_len;    // the tile-parts' frames (SOT .. SOD) as KT1b left them ...
+    const unsigned long long* tile_dst;              // ... and where the tile-parts start in `out`
     uint8_t* out;
     uint32_t sop, eph;                               // 6 / 2 when the markers are written, else 0
 };

@@ -2,9 +2,9 @@
 //
 // Replaces, for the single-layer HTJ2K packets this encoder makes, T2Compress::compressPacket (t2/T2Compress.cpp:123-333: the
 // header's inclusion / zero-bit-plane tag trees t1/TagTree.cpp:170-218, the pass count and Lblock / length coding), the header's
-// bit stuffing (t1/BitIO.cpp:46-175) and the copy of the code-blocks' bytes behind it (T2Compress.cpp:300-333); the frame of a
-// tile-part (SOT markers/SOTMarker.cpp:41-72, PLT markers/LengthMarkers.cpp:313-374, SOD) stays with the host, which needs the
-// packets' lengths for it (t2_device_frame, t2_writer.cpp).  The host writer (t2_writer.cpp) is the oracle of this file's tests.
+// bit stuffing (t1/BitIO.cpp:46-175), the copy of the code-blocks' bytes behind it (T2Compress.cpp:300-333) and the frame of a
+// tile-part (SOT markers/SOTMarker.cpp:41-72, PLT markers/LengthMarkers.cpp:313-374, SOD).  The host writer (t2_writer.cpp) is the
+// oracle of this file's tests.
 //
 // KT1 t2_header_kernel: one workgroup per (packet, tile).
 //   1. Every code-block's share of the header is a bit string that depends on its place in the band's grid and on its length
@@ -17,6 +17,10 @@
 //      the chunk's <= 32 steps: exit offset + bytes produced.  Sixteen chunks make a super-chunk with a table of the same kind,
 //      one lane walks the super-chunks, then the chunks of every super-chunk and the steps of every chunk are walked again from
 //      their now known entry, the last walk writing the bytes.  The raw bits pass through LDS in windows of 16 KB.
+// KT1b t2_frame_kernel: one lane per tile -- the tile-part's frame (SOT with Psot, the PLT marker segments with every packet's length as
+//   a base-128 number, at most 65 532 bytes of them per segment, SOD; markers/SOTMarker.cpp:41-72, markers/LengthMarkers.cpp:313-374,
+//   TileProcessor.cpp:719-734), the tile-part's length, and -- after a prefix sum over the call's tiles -- where every frame and every
+//   packet goes.  Nothing comes to the host: an exchange can send the finished tile-parts with their sizes straight from the device.
 // KT2 t2_gather_kernel: one wavefront per item -- a code-block's bytes, a packet's header (+ SOP / EPH), a tile-part's frame -- copies
 //   it to its place in the output: 16-byte stores on the destination's alignment, unaligned 16-byte loads.
 #include "kernels.h"
@@ -205,6 +209,63 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void t2_frame_kernel(T2FrameArgs a)
+{
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t t = tid; t < a.ntiles; t += blockDim.x) {
+        uint8_t* const f = a.lit + (size_t)t * a.lit_stride;
+        const uint32_t* const hl = a.pk_hdr + (size_t)t * a.npackets;
+        const uint64_t* const bl = a.pk_body + (size_t)t * a.npackets;
+        const uint32_t isot = a.tile_index[t];
+        uint32_t pos = 0;
+        f[pos++] = 0xFF; f[pos++] = 0x90; f[pos++] = 0; f[pos++] = 10; f[pos++] = (uint8_t)(isot >> 8); f[pos++] = (uint8_t)isot;
+        pos += 4;                                                   // Psot: below
+        f[pos++] = 0; f[pos++] = 1;                                 // TPsot, TNsot
+        uint64_t sum = 0;
+        if (a.plt) {
+            uint32_t seg = pos, z = 0, fill = 0;                    // the open marker segment, its Zplt, its bytes of lengths
+            f[pos++] = 0xFF; f[pos++] = 0x58; pos += 2; f[pos++] = 0;
+            for (uint32_t i = 0; i < a.npackets; ++i) {
+                const uint64_t v = (uint64_t)a.extra + hl[i] + bl[i];
+                sum += v;
+                uint32_t k = 1;
+                for (uint64_t w = v >> 7; w; w >>= 7) ++k;
+                if (fill + k > 65532u) {                            // a length is never split over two segments
+                    f[seg + 2] = (uint8_t)((3 + fill) >> 8); f[seg + 3] = (uint8_t)(3 + fill);
+                    if (++z > 255u) atomicOr(a.status, 8u);         // (Zplt is one byte)
+                    seg = pos; fill = 0;
+                    f[pos++] = 0xFF; f[pos++] = 0x58; pos += 2; f[pos++] = (uint8_t)z;
+                }
+                for (uint32_t j = k; j-- > 0;) f[pos++] = (uint8_t)(((v >> (7 * j)) & 0x7Fu) | (j ? 0x80u : 0u));
+                fill += k;
+            }
+            f[seg + 2] = (uint8_t)((3 + fill) >> 8); f[seg + 3] = (uint8_t)(3 + fill);
+        } else {
+            for (uint32_t i = 0; i < a.npackets; ++i) sum += (uint64_t)a.extra + hl[i] + bl[i];
+        }
+        f[pos++] = 0xFF; f[pos++] = 0x93;
+        const uint64_t len = pos + sum;
+        if (len >> 32) atomicOr(a.status, 8u);                      // (Psot is 32 bits)
+        f[6] = (uint8_t)(len >> 24); f[7] = (uint8_t)(len >> 16); f[8] = (uint8_t)(len >> 8); f[9] = (uint8_t)len;
+        a.lit_len[t] = pos;
+        a.part_len[t] = (uint32_t)len;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t at = a.dst_offset;
+        for (uint32_t t = 0; t < a.ntiles; ++t) { a.tile_dst[t] = at; at += a.part_len[t]; }
+        a.total[0] = at - a.dst_offset; a.total[1] = at;
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < a.ntiles; t += blockDim.x) {
+        uint64_t at = a.tile_dst[t] + a.lit_len[t];
+        const uint32_t* const hl = a.pk_hdr + (size_t)t * a.npackets;
+        const uint64_t* const bl = a.pk_body + (size_t)t * a.npackets;
+        uint64_t* const dst = a.pk_dst + (size_t)t * a.npackets;
+        for (uint32_t i = 0; i < a.npackets; ++i) { dst[i] = at; at += (uint64_t)a.extra + hl[i] + bl[i]; }
+    }
+}
+
 __global__ __launch_bounds__(256) void t2_gather_kernel(T2GatherArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -229,7 +290,7 @@ __global__ __launch_bounds__(256) void t2_gather_kernel(T2GatherArgs a)
         if (a.eph && lane < 2) d[n + lane] = lane ? 0x92 : 0xFF;
     } else if (item < nblk + npk + a.ntiles) {
         const uint64_t t = item - nblk - npk;
-        wave_copy(a.out + a.lit_dst[t], a.lit + a.lit_at[t], a.lit_at[t + 1] - a.lit_at[t], lane);
+        wave_copy(a.out + a.tile_dst[t], a.lit + t * a.lit_stride, a.lit_len[t], lane);
     }
 }
 
@@ -239,6 +300,13 @@ hipError_t launch_t2_header(const T2HeaderArgs& a, uint32_t max_blocks_per_packe
     // (a packet of a few blocks -- small precincts, low resolutions -- does not need sixteen waves' barriers)
     const uint32_t threads = max_blocks_per_packet > 1024 ? 1024u : max_blocks_per_packet > 128 ? 256u : 64u;
     hipLaunchKernelGGL(t2_header_kernel, dim3(a.npackets, a.ntiles), dim3(threads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_t2_frame(const T2FrameArgs& a, hipStream_t s)
+{
+    if (!a.ntiles) return hipSuccess;
+    hipLaunchKernelGGL(t2_frame_kernel, dim3(1), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -605,29 +605,6 @@ int t2_device_plan(const TileGeom& g, uint32_t flags, T2Plan& out)
     return GRK_AMD_OK;
 }
 
-uint64_t t2_device_frame(uint32_t flags, uint32_t tile_index, const uint32_t* hdr_len, const uint64_t* body_len, size_t npk,
-                         std::vector<uint8_t>& lit, uint64_t* pk_at)
-{
-    const uint64_t extra = ((flags & GRK_AMD_CS_SOP) ? 6u : 0u) + ((flags & GRK_AMD_CS_EPH) ? 2u : 0u);
-    std::vector<uint8_t> mine;
-    std::vector<grk_amd_tp_segment> segs;
-    Out o{nullptr, 0};
-    o.lit = &mine; o.segs = &segs;
-    o.u16(0xFF90); o.u16(10); o.u16(tile_index); o.u32(0); o.u8(0); o.u8(1);
-    if (flags & GRK_AMD_CS_PLT) {
-        std::vector<uint8_t> body;
-        for (size_t i = 0; i < npk; ++i) plt_length(body, extra + hdr_len[i] + body_len[i]);
-        write_plt(o, body);
-        if (o.ovf) return 0;
-    }
-    o.u16(0xFF93);
-    uint64_t at = o.n;
-    for (size_t i = 0; i < npk; ++i) { pk_at[i] = at; at += extra + hdr_len[i] + body_len[i]; }
-    if (at > 0xFFFFFFFFull) return 0;
-    o.patch32(6, (uint32_t)at, 0, 0);
-    lit.insert(lit.end(), mine.begin(), mine.end());
-    return at;
-}
 } // namespace grk_amd
 
 extern "C" int64_t grk_amd_plan_tile_part(const grk_amd_tile_params* p, uint32_t tile_index, uint32_t flags,

@@ -365,11 +365,20 @@ int64_t grk_amd_plan_tile_part(const grk_amd_tile_params* p, uint32_t tile_index
  * table needs to be fetched for it), tile i numbered tile_index[i], in call order back to back in a device buffer of the context's,
  * starting at dst_offset (0, or the end of what earlier calls assembled: batches of several geometries append).  flags: GRK_AMD_CS_PLT /
  * SOP / EPH / PROG as grk_amd_write_tile_part, whose bytes these are.  part_bytes[i] (optional) = tile-part i's length (what TLM and
- * the caller's placement need).  Returns the bytes assembled by this call, or < 0.  One host round trip of a few bytes per packet;
- * the ~100 MB of an 8K frame's code-blocks are moved once, on the device, to where the file has them. */
+ * the caller's placement need).  Returns the bytes assembled by this call, or < 0.  Three kernels (packet headers; the tile-parts' frames
+ * and everybody's place; the gather) and one wait for the sizes; the ~100 MB of an 8K frame's code-blocks are moved once, on the device,
+ * to where the file has them. */
 int64_t grk_amd_assemble_device(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles, const uint32_t* tile_index,
                                 uint32_t flags, uint64_t dst_offset, uint32_t* part_bytes);
 void* grk_amd_assembled_device_ptr(grk_amd_ctx* ctx);
+/* The same without the host: queued on `hip_stream`, which is first made to wait for the encode's results (grk_amd_stream_wait_results);
+ * nothing is waited for, nothing comes to the host.  The tile-parts (grk_amd_assembled_device_ptr), their places and lengths and the total
+ * (grk_amd_assembled_table_ptr -- 0: uint64[tiles] offsets, 1: uint32[tiles] lengths, 2: uint64[2] {bytes assembled, end}) stay where they are
+ * for as many further calls as the encoder rotates buffer sets (grk_amd_set_pipelining): what an exchange needs to send FINISHED tile-parts
+ * from device memory ("gather of coded tile-parts over xGMI").  Every asynchronous call of a context uses the same stream. */
+int grk_amd_assemble_device_async(grk_amd_ctx* ctx, const grk_amd_tile_params* p, uint32_t num_tiles, const uint32_t* tile_index,
+                                  uint32_t flags, void* hip_stream);
+void* grk_amd_assembled_table_ptr(grk_amd_ctx* ctx, int which);
 /* bytes [offset, offset + nbytes) of the assembled tile-parts to host memory (pinned: one DMA; pageable: through pinned chunks on
  * several copy threads); complete on return */
 int grk_amd_fetch_assembled(grk_amd_ctx* ctx, uint64_t offset, uint64_t nbytes, uint8_t* dst);

@@ -48,3 +48,13 @@ def upload_planes(planes, params):
 
 def split_blocks(table, coded):
     return [bytes(coded[int(o):int(o) + int(l)]) for o, l in zip(table["offset"], table["length"])]
+
+
+def from_dev_ptr(ptr, nbytes):
+    """nbytes at a raw device pointer (context-owned memory) as a numpy uint8 array; everything queued so far is waited for."""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    torch.cuda.synchronize()
+    return torch.as_tensor(h, device="cuda").cpu().numpy().copy()

@@ -112,3 +112,51 @@ def test_refuses_what_it_cannot_assemble():
     n, _ = c.assemble_device(p, [0])
     with pytest.raises(RuntimeError):
         c.assemble_device(p, [0], dst_offset=n + 1)     # a hole in the output
+
+
+def test_plt_of_many_packets_splits_into_marker_segments_on_the_device():
+    """16 x 16 precincts of a 2048 x 1024 x 3 tile: ~30 000 packets, each length one to two bytes in PLT -- a handful of marker segments
+    (the host's write_plt and the device's frame kernel have to agree on where they split)."""
+    px = synth.g2(3, 1024, 2048, 8, seed=21)
+    p = G.TileParams.make(2048, 1024, 3, 8, 3, precincts=exps_from_sizes([(16, 16)], 3))
+    want = _check(p, px, [2], G.CS_PLT | G.CS_SOP | G.CS_PROG(3))
+    assert want[0].count(b"\xff\x58") >= 2
+
+
+def test_asynchronous_form_on_a_stream_of_the_callers_with_pipelined_encodes():
+    """grk_amd_assemble_device_async: nothing waited for, results read from the device tables; frames alternate between two inputs while
+    the encoder rotates three buffer sets -- every frame's tile-parts are still intact two frames later."""
+    import torch
+    c = G.Context(0)
+    try:
+        p = G.TileParams.make(320, 256, 3, 8, 4)
+        flags = G.CS_PLT | G.CS_EPH
+        idx = [4, 9, 1]
+        frames = [synth.g2(3, 3 * 256, 320, 8, seed=s).reshape(3, 3, 256, 320) for s in (1, 2)]
+        want = []
+        for px in frames:
+            table, coded = c.encode_host(p, px, ntiles=3)
+            want.append(b"".join(_host_parts(p, idx, table, coded, flags)))
+        d_px = [U.to_dev(px.reshape(-1).view(np.uint8)) for px in frames]
+        st, t2 = torch.cuda.Stream(), torch.cuda.Stream()
+        c.set_stream(st.cuda_stream)
+        c.set_pipelining(2)
+        held = []
+        for f in range(6):
+            with torch.cuda.stream(st):
+                c.encode_tiles(p, 3, d_px[f & 1].data_ptr(), True, fetch=False)
+            c.assemble_device_async(p, idx, flags, t2.cuda_stream)
+            held.append((f, c.assembled_device_ptr(), c.assembled_table_ptr(0), c.assembled_table_ptr(1), c.assembled_table_ptr(2)))
+            if len(held) == 3:                      # frame f - 2: its output set is reused by the NEXT call, not before
+                g, out, dst, ln, tot = held.pop(0)
+                t2.synchronize()
+                total = U.from_dev_ptr(tot, 16).view(np.uint64)
+                assert int(total[0]) == len(want[g & 1])
+                lens = U.from_dev_ptr(ln, 12).view(np.uint32)
+                offs = U.from_dev_ptr(dst, 24).view(np.uint64)
+                assert [int(v) for v in offs] == [0, int(lens[0]), int(lens[0]) + int(lens[1])]
+                assert bytes(U.from_dev_ptr(out, int(total[0]))) == want[g & 1], "frame %d" % g
+        c.set_pipelining(False)
+        c.synchronize()
+    finally:
+        c.close()
