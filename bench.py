@@ -1033,6 +1033,15 @@ def main():
                     ctx.stream_wait_results(comm.cuda_stream)
                     with torch.cuda.stream(comm):
                         dist.all_gather_into_tensor(cbuf[f & 1], used)      # 8 bytes per rank, out of the encoder's own word
+                elif exchange == "parts":
+                    # Tier-2 on the device, queued on the exchange's stream behind the frame's results: what travels is the rank's FINISHED
+                    # tile-parts -- one table row (place, length) per tile-part instead of one per code-block
+                    ctx.assemble_device_async(prm, list(range(rank, world * nt, world)), 0, comm.cuda_stream)
+                    pipe[0].submit(f, _as_tensor(ctx.assembled_table_ptr(2), 1, dev, "<i8"), _as_tensor(ctx.assembled_table_ptr(0), nt, dev, "<i8"),
+                                   _as_tensor(ctx.assembled_table_ptr(1), nt, dev, "<i4"), _as_tensor(ctx.assembled_device_ptr(), arena_cap, dev),
+                                   wait_results=None)
+                    if args.no_overlap:
+                        pipe[0].flush()
                 else:
                     offs = _as_tensor(ctx.table_device_ptr(0), nblk, dev, "<i8")
                     lens = _as_tensor(ctx.table_device_ptr(1), nblk, dev, "<i4")
@@ -1046,8 +1055,8 @@ def main():
                 return pipe[0].flush()
             return None, None
 
-        ctx.set_pipelining(False if args.no_overlap else (depth + lag if exchange == "gather" else True))
-        if exchange == "gather":
+        ctx.set_pipelining(False if args.no_overlap else (depth + lag if exchange in ("gather", "parts") else True))
+        if exchange in ("gather", "parts"):
             pipe[0] = D.FramePipeline(dev, (stream, comm), depth=1 if args.no_overlap else depth, lag=1 if args.no_overlap else lag, ctx=ctx)
         for f in range(warmup):
             one(f)
@@ -1067,14 +1076,40 @@ def main():
             secs = float(t.item())
         return secs, parts, root
 
+    gather_md5 = [None]
+
     def assembled_bytes(prm, nt, nblk, img_w, img_h, parts, root):
         """The frame the last gather delivered really is a codestream: Tier-2 + headers over it on its writer."""
         n = torch.zeros(1, dtype=torch.int64, device=dev)
         if parts is not None and rank == root:
             ft, fc = D.merge_tile_parts(D.parts_to_numpy(parts), world * nt, nblk // nt)
-            n[0] = len(G.write_codestream(prm, img_w, img_h, ft, fc)) if nt == 1 or img_w else int(ft["length"].sum())
+            if nt == 1 or img_w:
+                import hashlib
+                cs_g = G.write_codestream(prm, img_w, img_h, ft, fc)
+                n[0] = len(cs_g)
+                gather_md5[0] = hashlib.md5(cs_g).hexdigest()
+            else:
+                n[0] = int(ft["length"].sum())
         dist.all_reduce(n, op=dist.ReduceOp.MAX)
         return int(n.item())
+
+    def assembled_file(prm, nt, img_w, img_h, parts, root):
+        """The "parts" exchange's last frame on its writer: main header + the ranks' finished tile-parts in tile order + EOC.
+        Returns (length, md5) -- (sum of the tile-parts' lengths, None) for a layout the header writer is not asked for here."""
+        import hashlib
+        n = torch.zeros(1, dtype=torch.int64, device=dev)
+        md5 = None
+        if parts is not None and rank == root:
+            ft, fc = D.merge_tile_parts(D.parts_to_numpy(parts), world * nt, 1)
+            body = b"".join(bytes(fc[int(r["offset"]):int(r["offset"]) + int(r["length"])]) for r in ft)
+            if nt == 1 or img_w:
+                cs = G.write_main_header(prm, img_w, img_h, 0, None) + body + b"\xff\xd9"
+                n[0] = len(cs)
+                md5 = hashlib.md5(cs).hexdigest()
+            else:
+                n[0] = len(body)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        return int(n.item()), md5
 
     pipelined = not args.no_overlap
     # N > 1: the counts exchange first -- no data-path transfer, nothing that can stall --; the gather regions run LAST (below),
@@ -1488,8 +1523,26 @@ def main():
             d_t, parts4, root4 = run_frames(p4, nt4, d4, nb4, "gather", st4, gw)
             g4 = {"ms_per_step": round(d_t / st4 * 1e3, 4), "Mpixels_s": round(16384.0 * 16384.0 * st4 / d_t / 1e6, 1),
                   "assembled_block_bytes": assembled_bytes(p4, nt4, nb4, 0, 0, parts4, root4)}
+        # ---- ... and the exchange of FINISHED tile-parts: Tier-2 runs on every rank's device inside the timed region (grk_amd_assemble_device_async
+        # on the exchange's stream), the writer receives tile-parts it only has to put behind the main header.  More work per frame than
+        # the gather of loose blocks (whose Tier-2, on the writer's host, is NOT in that form's timed region): reported, never the headline
+        parts_fig = None
+        try:
+            dtp, parts_p, root_p = run_frames(params, ntiles, rot, nblocks, "parts", args.steps, gw, gather_depth=args.gather_depth)
+            plen, pmd5 = assembled_file(params, ntiles, W * world if ntiles == 1 else 0, H, parts_p, root_p)
+            parts_fig = {"ms_per_step": round(dtp / args.steps * 1e3, 4), "Mpixels_s": round(pixels_per_step * world * args.steps / dtp / 1e6, 1),
+                         "codestream_bytes": plen, "equals_gather_form_length": bool(plen == cs_len), "gather_depth": args.gather_depth,
+                         "what": "Tier-2 on each rank's device inside the timed region; finished tile-parts (one table row each) to the frame's writer"}
+            if world == 1 and pmd5 is not None and gather_md5[0] is not None:      # (one process: the same frame's two files side by side)
+                parts_fig["file_equals_gather_form_file"] = bool(pmd5 == gather_md5[0])
+                ref = (out or {}).get("cpu_baseline") or {}
+                if ref.get("file_md5"):
+                    parts_fig["file_equals_cpu_encode"] = bool(ref["file_md5"] == pmd5)
+        except Exception as e:  # noqa: BLE001
+            parts_fig = {"error": str(e)}
         dog.cancel()
         if out is not None:
+            out["exchange"]["parts"] = parts_fig
             rep["gather"] = g8
             out["exchange"]["gather"] = g8
             if g4 is not None:
