@@ -189,7 +189,7 @@ extern "C" grk_amd_ctx* grk_amd_node_ctx(grk_amd_node* nd, uint32_t i) { return 
 extern "C" const char* grk_amd_node_last_error(grk_amd_node* nd) { return nd ? nd->err.c_str() : "null node"; }
 
 static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
-                                 const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap);
+                                 const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap, bool host_t2);
 
 static int64_t node_encode_locked(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
                                   const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap)
@@ -197,7 +197,12 @@ static int64_t node_encode_locked(grk_amd_node* nd, const grk_amd_image_layout* 
     if (!nd) return GRK_AMD_ERR_INVALID;
     std::lock_guard<std::mutex> lk(nd->mu);
     nd->err.clear();
-    const int64_t rc = node_encode_image(nd, im, base, pixels, pixels_device, flags, out, cap);
+    int64_t rc = node_encode_image(nd, im, base, pixels, pixels_device, flags, out, cap, false);
+    // (a layout beyond the device writer's tables -- header bits of one packet past 2^31, a code-block of 512 MB: the host writer takes it)
+    if (rc == GRK_AMD_ERR_UNSUPPORTED && !(flags & GRK_AMD_NODE_GATHER) && device_t2()) {
+        nd->err.clear();
+        rc = node_encode_image(nd, im, base, pixels, pixels_device, flags, out, cap, true);
+    }
     if (rc < 0 && nd->err.empty()) {
         nd->err = rc == GRK_AMD_ERR_INVALID ? "invalid argument" : rc == GRK_AMD_ERR_UNSUPPORTED ? "unsupported layout (TLM with more than 255 tiles?)"
                 : rc == GRK_AMD_ERR_NOMEM ? "out of (pinned or device) memory" : rc == GRK_AMD_ERR_NO_DEVICE ? "a HIP call failed (device lost or peer copy refused)"
@@ -228,7 +233,7 @@ extern "C" int64_t grk_amd_node_encode_image_device(grk_amd_node* nd, const grk_
 }
 
 static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* im, const grk_amd_tile_params* base,
-                                 const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap)
+                                 const void* pixels, int pixels_device, uint32_t flags, uint8_t* out, uint64_t cap, bool host_t2)
 {
     if (nd->w.empty() || !im || !base || !pixels || !out) return GRK_AMD_ERR_INVALID;
     const int64_t nt = grk_amd_layout_num_tiles(im);
@@ -279,7 +284,7 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
     // Parallel writers, Tier-2 on the device (the default): a worker's encode is followed by grk_amd_assemble_device -- packet headers
     // and the gather of the code-blocks' bytes into finished tile-parts in its HBM --, no table and no loose coded bytes come to the
     // host; the tile-parts are brought to their places in the file once the main header's length is known.
-    const bool dev_t2 = !gather && device_t2();
+    const bool dev_t2 = !gather && !host_t2 && device_t2();
     std::vector<uint64_t> asm_used(R, 0);
     std::vector<int> rcs(R, GRK_AMD_OK);
     std::vector<std::thread> th;
