@@ -189,6 +189,8 @@ struct grk_amd_ctx {
     // one-workgroup kernel on the other) and a side stream that has to wait is replaced (GRK_AMD_STREAM_PROBE=0: never)
     int stream_probe = 1; hipStream_t probed_main = nullptr; int side_priority = 0;
     int probe_replaced = 0;           // side streams replaced by the probe so far (grk_amd_stream_probe_result)
+    bool probe_warm = false;          // the probe's kernels have been launched once (their first launch loads their code: not to be measured)
+    bool seq_vetted = false;          // (a sequence's internal context) its streams have been vetted against its neighbours' (vet_sequence_streams)
     int k3_room = 3;                  // pipelined encodes: K3 launches that leave registers for the next frame's level 0 -- bit 0 the top class, bit 1 the rest (GRK_AMD_K3_ROOM)
     // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
     // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; 2: lanes wherever they can be used; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
@@ -533,6 +535,45 @@ int streams_side_by_side(grk_amd_ctx* c, hipStream_t a, hipStream_t b, bool* yes
     return GRK_AMD_OK;
 }
 
+int probe_warmup(grk_amd_ctx* c, hipStream_t st)
+{
+    if (c->probe_warm) return GRK_AMD_OK;
+    hipLaunchKernelGGL(probe_spin_kernel, dim3(256), dim3(64), 40960, st, 10u, (unsigned int*)nullptr);
+    hipLaunchKernelGGL(probe_tick_kernel, dim3(1), dim3(64), 0, st, (unsigned int*)nullptr);
+    HIP_TRY(c, hipGetLastError(), "stream probe");
+    HIP_TRY(c, hipStreamSynchronize(st), "sync");
+    c->probe_warm = true;
+    return GRK_AMD_OK;
+}
+
+// *cur, or a stream made now with *cur's priority, whose kernels are dispatched side by side with every stream of `against` (both
+// directions); *cur is replaced (and destroyed) when a better one is found within eight tries, else kept.  All streams idle on entry.
+int vetted_stream(grk_amd_ctx* c, hipStream_t* cur, const std::vector<hipStream_t>& against, int* replaced)
+{
+    int rc = probe_warmup(c, *cur); if (rc) return rc;
+    int prio = 0;
+    if (hipStreamGetPriority(*cur, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    std::vector<hipStream_t> rejects;
+    hipStream_t cand = *cur;
+    for (int tries = 0; tries < 9; ++tries) {
+        bool ok = true;
+        for (hipStream_t a : against) {
+            if (!a || a == cand) continue;
+            rc = streams_side_by_side(c, a, cand, &ok);
+            if (rc == GRK_AMD_OK && ok) rc = streams_side_by_side(c, cand, a, &ok);
+            if (rc || !ok) break;
+        }
+        if (rc) break;
+        if (ok) { if (cand != *cur) { rejects.push_back(*cur); *cur = cand; if (replaced) ++*replaced; } cand = nullptr; break; }
+        if (cand != *cur) rejects.push_back(cand);
+        cand = nullptr;
+        if (tries == 8 || hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); cand = nullptr; break; }
+    }
+    if (cand && cand != *cur) rejects.push_back(cand);
+    for (hipStream_t r : rejects) (void)hipStreamDestroy(r);
+    return rc;
+}
+
 int probe_streams(grk_amd_ctx* c)
 {
     if (!c->stream_probe || c->probed_main == c->stream || !c->side) return GRK_AMD_OK;
@@ -541,11 +582,7 @@ int probe_streams(grk_amd_ctx* c)
     HIP_TRY(c, hipStreamSynchronize(c->side), "sync");
     if (c->side2) HIP_TRY(c, hipStreamSynchronize(c->side2), "sync");
     c->side_pending = false;
-    // (the kernels' first launch loads their code: not to be measured)
-    hipLaunchKernelGGL(probe_spin_kernel, dim3(256), dim3(64), 40960, c->stream, 10u, (unsigned int*)nullptr);
-    hipLaunchKernelGGL(probe_tick_kernel, dim3(1), dim3(64), 0, c->stream, (unsigned int*)nullptr);
-    HIP_TRY(c, hipGetLastError(), "stream probe");
-    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    { const int wr = probe_warmup(c, c->stream); if (wr) return wr; }
     std::vector<hipStream_t> rejects;                  // kept alive until the end: a stream made now gets another queue than these
     auto good = [&](hipStream_t cand, hipStream_t other, bool* ok) -> int {
         bool y = false;
@@ -1396,6 +1433,10 @@ static int decode_impl(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t nt
     const grk_amd_coded_block* table_in = table;
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     int rc = join_side(c); if (rc) return rc;        // (the Mallat planes and the status word are shared with the encoder)
+    // (the block decoders of the top resolution run on the side stream beside the rest: the two have to be dispatched side by side)
+    if (c->overlap && c->side && c->seq_index < 0 && c->stream_probe && c->probed_main != c->stream && probe_streams(c) != GRK_AMD_OK) {
+        c->stream_probe = 0; (void)hipGetLastError();
+    }
     rc = ensure_geom(c, p); if (rc) return rc;
     const TileGeom& g = c->geom;
     const uint32_t nplanes = ntiles * g.p.num_comps;
@@ -1505,7 +1546,7 @@ int sequence_streams(grk_amd_ctx* k, bool part1)
     if (e != hipSuccess) { if (ns) (void)hipStreamDestroy(ns); return fail(k, GRK_AMD_ERR_NO_DEVICE, "streams of a decode sequence", e); }
     (void)hipStreamDestroy(k->stream); k->stream = ns;
     if (k->side) { (void)hipStreamDestroy(k->side); k->side = nside; }
-    k->seq_flavour = flavour;
+    k->seq_flavour = flavour; k->seq_vetted = false;
     return GRK_AMD_OK;
 }
 } // namespace
@@ -1529,6 +1570,29 @@ int grk_amd_decode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             k->overlap = c->overlap && k->side != nullptr; k->t1_lanes = c->t1_lanes; k->t1_tail_ratio = c->t1_tail_ratio;
             HIP_TRY(c, hipSetDevice(c->device), "set device");
             { const int sr = sequence_streams(k, p && p->reserved[0] != 0); if (sr) { c->err = k->err; return sr; } }
+            // The contexts' streams, vetted in the contexts' order: a context's two streams against each other and against the (up to
+            // three) streams accepted just before -- four dispatch pipes: two frames in flight can have a pipe per stream (HT frames:
+            // 0.66 instead of 0.75-0.81 ms per frame when the runtime's choice collides, tools/hwq_alias_dec.py), more cannot
+            if (c->stream_probe && !k->seq_vetted) {
+                int vr = grk_amd_synchronize(k);
+                const int nk = (int)c->dec_kids.size();
+                for (int which = 0; which < 2 && vr == GRK_AMD_OK; ++which) {
+                    hipStream_t* st = which ? &k->side : &k->stream;
+                    if (!*st) continue;
+                    // (the streams as they are NOW: a context that changed its kind of frames has re-made its own)
+                    std::vector<hipStream_t> against;
+                    if (which) against.push_back(k->stream);
+                    for (int back = 1; back < nk && against.size() < 3; ++back) {
+                        grk_amd_ctx* o = c->dec_kids[(size_t)((k->seq_index - back + nk) % nk)];
+                        if (!o->seq_vetted) continue;
+                        if (o->side && against.size() < 3) against.push_back(o->side);
+                        if (against.size() < 3) against.push_back(o->stream);
+                    }
+                    vr = vetted_stream(k, st, against, &c->probe_replaced);
+                }
+                if (vr) { c->stream_probe = 0; (void)hipGetLastError(); }
+                k->seq_vetted = true;
+            }
             // ... behind whatever the caller queued on this context's stream (its uploads of the coded bytes)
             HIP_TRY(c, hipEventRecord(c->ev_seq, c->stream), "record the caller's stream");
             HIP_TRY(c, hipStreamWaitEvent(k->stream, c->ev_seq, 0), "order the frame behind the caller's stream");
@@ -1940,10 +2004,7 @@ int grk_amd_streams_side_by_side(grk_amd_ctx* c, void* a, void* b)
     HIP_TRY(c, hipSetDevice(c->device), "set device");
     HIP_TRY(c, hipStreamSynchronize((hipStream_t)a), "sync");
     HIP_TRY(c, hipStreamSynchronize((hipStream_t)b), "sync");
-    hipLaunchKernelGGL(probe_spin_kernel, dim3(256), dim3(64), 40960, (hipStream_t)a, 10u, (unsigned int*)nullptr);
-    hipLaunchKernelGGL(probe_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)a, (unsigned int*)nullptr);
-    HIP_TRY(c, hipGetLastError(), "stream probe");
-    HIP_TRY(c, hipStreamSynchronize((hipStream_t)a), "sync");
+    { const int wr = probe_warmup(c, (hipStream_t)a); if (wr) return wr; }
     bool y = false;
     int rc = streams_side_by_side(c, (hipStream_t)a, (hipStream_t)b, &y); if (rc) return rc;
     if (y) { rc = streams_side_by_side(c, (hipStream_t)b, (hipStream_t)a, &y); if (rc) return rc; }
