@@ -30,10 +30,8 @@ namespace {
 
 constexpr uint32_t kChunkBits = 256;                              // raw bits per chunk
 constexpr uint32_t kSup = 16;                                     // chunks per super-chunk
-constexpr uint32_t kWinWords = 4096;                              // raw words per LDS window
-constexpr uint32_t kWinBits = kWinWords * 32;
-constexpr uint32_t kWinChunks = kWinBits / kChunkBits;            // 512
-constexpr uint32_t kWinSups = kWinChunks / kSup;                  // 32
+// raw words per LDS window: 4096 (16 KB; 512 chunks, 32 super-chunks) for the instance of large packets, 512 for the others -- a
+// workgroup of a small packet does not claim 37 KB of LDS
 constexpr uint64_t kByteMask = (1ull << 40) - 1;                  // the scan's packing: bits << 40 | bytes
 
 __device__ __forceinline__ void put_bits(uint32_t* u, uint32_t pos, uint64_t v, uint32_t n)     // n <= 64 bits of v, MSB first, at bit `pos`
@@ -43,17 +41,36 @@ __device__ __forceinline__ void put_bits(uint32_t* u, uint32_t pos, uint64_t v, 
     const uint32_t o = pos & 31u;
     uint32_t* w = u + (pos >> 5);
     const uint32_t w0 = (uint32_t)(a >> 32) >> o, w1 = (uint32_t)(a >> o), w2 = o ? (uint32_t)(a << (32 - o)) : 0u;
-    if (w0) atomicOr(w, w0);
-    if (w1) atomicOr(w + 1, w1);
-    if (w2) atomicOr(w + 2, w2);
+    // (workgroup scope: a packet's raw bits are written and read by ONE workgroup, and stay in its XCD's L2)
+    if (w0) __hip_atomic_fetch_or(w, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (w1) __hip_atomic_fetch_or(w + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (w2) __hip_atomic_fetch_or(w + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// one step of the chain at raw bit p of the window in LDS: the byte there, whether it is 0xFF, and the seven bits behind it
-__device__ __forceinline__ uint32_t window16(const uint32_t* win, uint32_t p)
-{
-    const uint64_t v = ((uint64_t)win[p >> 5] << 32) | win[(p >> 5) + 1];
-    return (uint32_t)(v >> (48 - (p & 31u))) & 0xFFFFu;
-}
+// The chain's steps over the window in LDS, through a 64-bit register that is refilled a word at a time (one LDS read per ~3 steps).
+// A step takes 24 bits at the position: an 0xFF and the seven bits behind it (15 raw bits, two bytes out); else, when the next byte
+// starts inside the chunk and is no 0xFF either, two bytes (16 bits); else one (8).
+struct ChainWalk {
+    const uint32_t* win; uint64_t buf; uint32_t wi, off;
+    __device__ __forceinline__ void start(const uint32_t* w, uint32_t p)
+    {
+        win = w; wi = p >> 5; off = p & 31u;
+        buf = ((uint64_t)w[wi] << 32) | w[wi + 1];
+    }
+    // -> raw bits consumed; b0 / b1: the bytes made (b1 only when two: the return value is 15 or 16)
+    __device__ __forceinline__ uint32_t step(uint32_t p, uint32_t end, uint32_t& b0, uint32_t& b1)
+    {
+        if (off >= 32u) { buf = (buf << 32) | win[wi + 2]; ++wi; off -= 32u; }
+        const uint32_t t = (uint32_t)(buf >> (40u - off)) & 0xFFFFFFu;
+        b0 = t >> 16;
+        const uint32_t n1 = (t >> 8) & 0xFFu;
+        const bool ff = b0 == 0xFFu, two = !ff && n1 != 0xFFu && p + 8u < end;
+        b1 = ff ? (t >> 9) & 0x7Fu : n1;
+        const uint32_t adv = ff ? 15u : two ? 16u : 8u;
+        off += adv;
+        return adv;
+    }
+};
 
 struct __attribute__((aligned(1))) U128 { uint32_t x, y, z, w; };
 __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint64_t n, uint32_t lane)
@@ -73,8 +90,10 @@ __device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint64_t
 
 } // namespace
 
+template <uint32_t kWinWords>
 __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
 {
+    constexpr uint32_t kWinBits = kWinWords * 32, kWinChunks = kWinBits / kChunkBits, kWinSups = kWinChunks / kSup;
     __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint16_t chunk_tab[kWinChunks * 16];               // [chunk][entry]: exit offset << 12 | bytes
     __shared__ uint32_t sup_tab[kWinSups * 16];                   // [super-chunk][entry]: exit offset << 16 | bytes
@@ -85,31 +104,38 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
 
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nthr >> 6;
     const uint32_t pk = blockIdx.x, tile = blockIdx.y;
-    const T2Packet& P = a.packets[pk];
-    uint32_t* const u = a.ubits + (size_t)tile * a.u_words + P.u_at;
-    const size_t row_base = (size_t)tile * a.bpt + P.row0;
-    const uint32_t n0 = P.nbands > 0 ? P.gw[0] * P.gh[0] : 0u, n1 = P.nbands > 1 ? P.gw[1] * P.gh[1] : 0u;
+    // (the packet's descriptor once, into scalar registers: indexed by a lane's band it would be a load per use)
+    const T2Packet* const Pp = a.packets + pk;
+    struct { uint32_t nblocks, h_at; } P = {Pp->nblocks, Pp->h_at};
+    const uint32_t nbands = Pp->nbands;
+    const uint32_t gw0 = Pp->gw[0], gw1 = Pp->gw[1], gw2 = Pp->gw[2], fb0 = Pp->first_block[0], fb1 = Pp->first_block[1], fb2 = Pp->first_block[2];
+    const uint32_t ht0 = Pp->height[0], ht1 = Pp->height[1], ht2 = Pp->height[2], km0 = Pp->kmax[0], km1 = Pp->kmax[1], km2 = Pp->kmax[2];
+    uint32_t* const u = a.ubits + (size_t)tile * a.u_words + Pp->u_at;
+    const size_t row_base = (size_t)tile * a.bpt + Pp->row0;
+    const uint32_t n0 = nbands > 0 ? gw0 * Pp->gh[0] : 0u, n1 = nbands > 1 ? gw1 * Pp->gh[1] : 0u;
 
     // ---- 1. the blocks' bit strings at their places in the raw header ------------------------------------------------------
     uint64_t carry = 1ull << 40;                                  // the packet's first bit: "not empty"
-    if (tid == 0) atomicOr(u, 0x80000000u);
+    if (tid == 0) __hip_atomic_fetch_or(u, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     bool bad = false;
     for (uint32_t base = 0; base < P.nblocks; base += nthr) {
         const uint32_t j = base + tid;
         const bool valid = j < P.nblocks;
-        uint32_t b = 0, k = 0, len = 0, nn = 0, inc = 0, nbits = 0;
+        uint32_t b = 0, k = 0, len = 0, nn = 0, inc = 0, nbits = 0, zeros = 0;
         size_t row = 0;
         if (valid) {
             b = (j >= n0) + (j >= n0 + n1);
             k = j - (b == 0 ? 0u : b == 1 ? n0 : n0 + n1);
-            const uint32_t x = k % P.gw[b], y = k / P.gw[b], m = x | y;
-            row = row_base + P.first_block[b] + k;
+            const uint32_t gw = b == 0 ? gw0 : b == 1 ? gw1 : gw2, height = b == 0 ? ht0 : b == 1 ? ht1 : ht2;
+            const uint32_t x = k % gw, y = k / gw, m = x | y;
+            row = row_base + (b == 0 ? fb0 : b == 1 ? fb1 : fb2) + k;
             len = a.lengths[row];
             if (len >> kT2MaxLenBits) { bad = true; len = 0; }
-            nn = m ? min((uint32_t)__builtin_ctz(m) + 1u, P.height[b]) : P.height[b];
+            nn = m ? min((uint32_t)__builtin_ctz(m) + 1u, height) : height;
             const int fl = len ? 31 - __builtin_clz(len) : 0;
             inc = fl + 1 > 3 ? (uint32_t)(fl + 1 - 3) : 0u;
-            nbits = 2 * nn + (k == 0 ? P.kmax[b] - 1u : 0u) + 1 + (inc + 1) + (3 + inc);
+            zeros = k == 0 ? (b == 0 ? km0 : b == 1 ? km1 : km2) - 1u : 0u;      // the zero-bit-plane tree's root: Kmax - 1
+            nbits = 2 * nn + zeros + 1 + (inc + 1) + (3 + inc);
         }
         const uint64_t v = ((uint64_t)nbits << 40) | len;
         uint64_t incl = v;
@@ -128,7 +154,7 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
             uint32_t pos = (uint32_t)(excl >> 40);
             a.rel[row] = (uint32_t)(excl & kByteMask);
             put_bits(u, pos, (1ull << nn) - 1ull, nn);
-            pos += nn + (k == 0 ? P.kmax[b] - 1u : 0u);
+            pos += nn + zeros;
             // `nn` ones and the pass bit 0 | Lblock: `inc` ones and a zero | the length in 3 + inc bits
             const uint64_t tail = ((((((1ull << nn) - 1ull) << 1) << (inc + 1)) | (((1ull << inc) - 1ull) << 1)) << (3 + inc)) | len;
             put_bits(u, pos, tail, nn + 1 + inc + 1 + 3 + inc);
@@ -138,8 +164,11 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
     if (bad) atomicOr(a.status, 4u);
     const uint32_t nbits_total = (uint32_t)(carry >> 40);
     const uint32_t nwords = (nbits_total + 31u) >> 5;
-    __threadfence();
+    // the raw bits are complete before anybody reads them back.  A WORKGROUP-scope fence: an agent-scope one (__threadfence) writes the
+    // XCD's L2 back on this machine -- 1 152 workgroups of a 64-tile call spent 70 of their 94 us in it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // ---- 2. stuffing, window by window --------------------------------------------------------------------------------------
     uint8_t* const hdr = a.hdr + (size_t)tile * a.h_bytes + P.h_at;
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
     for (uint32_t w0 = 0; w0 * 32u < nbits_total; w0 += kWinWords) {
         __syncthreads();
         for (uint32_t i = tid; i < kWinWords + 2; i += nthr)
-            win[i] = w0 + i < nwords ? __hip_atomic_load(u + w0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            win[i] = w0 + i < nwords ? __hip_atomic_load(u + w0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         const uint32_t lim = min(nbits_total - w0 * 32u, kWinBits);          // raw bits of this window
         const uint32_t nch = (lim + kChunkBits - 1) / kChunkBits, nsup = (nch + kSup - 1) / kSup;
         __syncthreads();
@@ -156,10 +185,12 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
             const uint32_t c = job >> 4, e = job & 15u;
             if (e == 15u) continue;
             const uint32_t end = min((c + 1) * kChunkBits, lim);
-            uint32_t p = c * kChunkBits + e, cnt = 0;
+            uint32_t p = c * kChunkBits + e, cnt = 0, b0, b1;
+            ChainWalk cw;
+            cw.start(win, p);
             while (p < end) {
-                const uint32_t ff = (window16(win, p) >> 8) == 0xFFu;
-                p += 8u + 7u * ff; cnt += 1u + ff;
+                const uint32_t adv = cw.step(p, end, b0, b1);
+                p += adv; cnt += 1u + (adv > 8u);
             }
             chunk_tab[job] = (uint16_t)((min(p - min(p, (c + 1) * kChunkBits), 14u) << 12) | cnt);
         }
@@ -186,13 +217,15 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
         const uint32_t out0 = carry_state[1];
         for (uint32_t c = tid; c < nch; c += nthr) {
             const uint32_t end = min((c + 1) * kChunkBits, lim);
-            uint32_t p = c * kChunkBits + (chunk_in[c] >> 28);
+            uint32_t p = c * kChunkBits + (chunk_in[c] >> 28), b0, b1;
             uint8_t* o = hdr + out0 + (chunk_in[c] & 0x0FFFFFFFu);
+            ChainWalk cw;
+            cw.start(win, p);
             while (p < end) {
-                const uint32_t t = window16(win, p), byte = t >> 8, ff = byte == 0xFFu;
-                *o++ = (uint8_t)byte;
-                if (ff) *o++ = (uint8_t)((t >> 1) & 0x7Fu);
-                p += 8u + 7u * ff;
+                const uint32_t adv = cw.step(p, end, b0, b1);
+                *o++ = (uint8_t)b0;
+                if (adv > 8u) *o++ = (uint8_t)b1;
+                p += adv;
             }
         }
         __syncthreads();
@@ -299,7 +332,8 @@ hipError_t launch_t2_header(const T2HeaderArgs& a, uint32_t max_blocks_per_packe
     if (!a.npackets || !a.ntiles) return hipSuccess;
     // (a packet of a few blocks -- small precincts, low resolutions -- does not need sixteen waves' barriers)
     const uint32_t threads = max_blocks_per_packet > 1024 ? 1024u : max_blocks_per_packet > 128 ? 256u : 64u;
-    hipLaunchKernelGGL(t2_header_kernel, dim3(a.npackets, a.ntiles), dim3(threads), 0, s, a);
+    if (threads == 1024u) hipLaunchKernelGGL(t2_header_kernel<4096>, dim3(a.npackets, a.ntiles), dim3(threads), 0, s, a);
+    else hipLaunchKernelGGL(t2_header_kernel<512>, dim3(a.npackets, a.ntiles), dim3(threads), 0, s, a);
     return hipGetLastError();
 }
 

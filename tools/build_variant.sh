@@ -6,5 +6,5 @@ n=$1; shift
 mkdir -p $R/build/abl/$n
 cd $R/grok_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable "$@" -shared -o $R/build/abl/$n/libgrok_amd.so \
-  context.hip kernels_ingest.hip kernels_dwt.hip kernels_ht.hip kernels_htdec.hip kernels_t1dec.hip kernels_t1lanes.hip kernels_idwt.hip node.cpp geometry.cpp t2_writer.cpp image.cpp
+  context.hip kernels_ingest.hip kernels_dwt.hip kernels_ht.hip kernels_htdec.hip kernels_t1dec.hip kernels_t1lanes.hip kernels_t2.hip kernels_idwt.hip ../../build/source_stamp.cpp node.cpp geometry.cpp t2_writer.cpp image.cpp
 echo built $R/build/abl/$n/libgrok_amd.so
