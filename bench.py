@@ -6,13 +6,14 @@ One "step" = one pass of the hot path (ingest+DC+RCT -> 5-level 5/3 DWT -> HT cl
 64x64 code-blocks -> compaction) over one 8192x8192x3 8-bit tile whose pixels are already
 resident in HBM.  With N ranks (torchrun, one process per GPU) the job is a sequence of (N*8192)x8192
 frames cut into N tiles of 8192x8192: tile t is encoded on rank t (tiles are independent, SURVEY.md
-§8e: no data-path collective) and every frame ends with an exchange over RCCL/xGMI.  TWO forms are timed
-and both are in the line (top-level `exchange`): "gather" -- the ranks' coded tile-parts (exact sizes) to
-the frame's writer rank, which rotates with the frame number, `--gather-depth` frames' gathers in flight
-at once on communicators of their own (grok_amd.dist.FramePipeline) -- and "counts" -- only the byte
-counts travel, every rank writes its own tile-parts (parallel writers).  `value` is the GATHER figure
-(what BASELINE's north_star words) when that region completed, the counts figure otherwise;
-`config.headline_exchange` says which.  Per-GPU work is fixed => weak scaling.  "multi_gpu" also carries
+§8e: no data-path collective) and every frame ends with an exchange over RCCL/xGMI.  THREE forms are timed
+and all are in the line (top-level `exchange`): "gather" -- the ranks' coded blocks + block tables (exact
+sizes) to the frame's writer rank, which rotates with the frame number, `--gather-depth` frames' gathers in
+flight at once on communicators of their own (grok_amd.dist.FramePipeline); "counts" -- only the byte
+counts travel, every rank writes its own tile-parts (parallel writers); "parts" -- every rank runs Tier-2
+on its device inside the timed region (grk_amd_assemble_device_async) and its FINISHED tile-parts travel.
+`value` is the faster of gather / counts unless `--exchange` names one (`config.headline_exchange` says
+which); "parts" is reported, never the headline.  Per-GPU work is fixed => weak scaling.  "multi_gpu" also carries
 the BASELINE configs[3] shape -- 16384x16384 as 256 tiles of 1024x1024 split over the ranks, strong
 scaling.  `python bench.py --gpus N` starts its N ranks itself (launch_ranks).
 
