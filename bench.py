@@ -818,7 +818,7 @@ def launch_ranks(n, dry_run):
     return subprocess.call(cmd, env=env)
 
 
-def start_gather_watchdog(timeout, out, emit, rc):
+def start_gather_watchdog(timeout, out, emit, rc, key="gather"):
     """The gather regions run LAST and under this timer: if a transfer never completes, rank 0 still prints the line -- with the
     counts figures it already holds and exchange.gather = {"error": ...} -- and every rank leaves with exit code `rc`
     (--gather-timeout-rc, default 0: the line carries the failure; non-zero for callers that want the process status to say it)."""
@@ -826,7 +826,7 @@ def start_gather_watchdog(timeout, out, emit, rc):
 
     def bail():
         if out is not None:
-            out.setdefault("exchange", {})["gather"] = {"error": "the gather regions did not complete within %.0f s" % timeout}
+            out.setdefault("exchange", {})[key] = {"error": "the %s regions did not complete within %.0f s" % (key, timeout)}
             emit(out)
         os._exit(rc)
     dog = threading.Timer(timeout, bail)
@@ -1524,6 +1524,28 @@ def main():
             d_t, parts4, root4 = run_frames(p4, nt4, d4, nb4, "gather", st4, gw)
             g4 = {"ms_per_step": round(d_t / st4 * 1e3, 4), "Mpixels_s": round(16384.0 * 16384.0 * st4 / d_t / 1e6, 1),
                   "assembled_block_bytes": assembled_bytes(p4, nt4, nb4, 0, 0, parts4, root4)}
+        if out is not None:
+            rep["gather"] = g8
+            out["exchange"]["gather"] = g8
+            if g4 is not None:
+                multi_gpu["cfg4_strong"]["gather"] = g4
+            # the headline: the faster of the two complete exchanges unless the caller named one; both stay in `exchange`
+            counts_v = (rep.get("counts") or {}).get("Mpixels_s") or 0.0
+            gbest = g8
+            if args.exchange == "best":            # ... at the depth that did best (every depth's figure is a complete gather)
+                dbest = max(by_depth, key=lambda k: by_depth[k]["Mpixels_s"])
+                gbest = dict(by_depth[dbest], gather_depth=int(dbest))
+            take_gather = args.exchange == "gather" or (args.exchange == "best" and gbest["Mpixels_s"] > counts_v)
+            out["config"]["headline_exchange_rule"] = args.exchange
+            if take_gather:
+                out["value"] = gbest["Mpixels_s"]
+                out["ms_per_step"] = gbest["ms_per_step"]
+                out["config"]["headline_exchange"] = "gather (depth %d)" % gbest["gather_depth"]
+                out["config"]["assembled_codestream_bytes"] = cs_len
+        # (the line already carries the gather figures and the headline: a rank that fails or stalls below costs it `exchange.parts` only --
+        #  a watchdog of its own)
+        dog.cancel()
+        dog = start_gather_watchdog(args.gather_timeout, out, emit, args.gather_timeout_rc, key="parts")
         # ---- ... and the exchange of FINISHED tile-parts: Tier-2 runs on every rank's device inside the timed region (grk_amd_assemble_device_async
         # on the exchange's stream), the writer receives tile-parts it only has to put behind the main header.  More work per frame than
         # the gather of loose blocks (whose Tier-2, on the writer's host, is NOT in that form's timed region): reported, never the headline
@@ -1544,23 +1566,6 @@ def main():
         dog.cancel()
         if out is not None:
             out["exchange"]["parts"] = parts_fig
-            rep["gather"] = g8
-            out["exchange"]["gather"] = g8
-            if g4 is not None:
-                multi_gpu["cfg4_strong"]["gather"] = g4
-            # the headline: the faster of the two complete exchanges unless the caller named one; both stay in `exchange`
-            counts_v = (rep.get("counts") or {}).get("Mpixels_s") or 0.0
-            gbest = g8
-            if args.exchange == "best":            # ... at the depth that did best (every depth's figure is a complete gather)
-                dbest = max(by_depth, key=lambda k: by_depth[k]["Mpixels_s"])
-                gbest = dict(by_depth[dbest], gather_depth=int(dbest))
-            take_gather = args.exchange == "gather" or (args.exchange == "best" and gbest["Mpixels_s"] > counts_v)
-            out["config"]["headline_exchange_rule"] = args.exchange
-            if take_gather:
-                out["value"] = gbest["Mpixels_s"]
-                out["ms_per_step"] = gbest["ms_per_step"]
-                out["config"]["headline_exchange"] = "gather (depth %d)" % gbest["gather_depth"]
-                out["config"]["assembled_codestream_bytes"] = cs_len
         dist.barrier()
         dist.destroy_process_group()
     emit(out)
