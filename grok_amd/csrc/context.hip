@@ -191,6 +191,8 @@ struct grk_amd_ctx {
     int probe_replaced = 0;           // side streams replaced by the probe so far (grk_amd_stream_probe_result)
     bool probe_warm = false;          // the probe's kernels have been launched once (their first launch loads their code: not to be measured)
     bool seq_vetted = false;          // (a sequence's internal context) its streams have been vetted against its neighbours' (vet_sequence_streams)
+    unsigned long long* pend_alloc = nullptr; uint32_t pend_alloc_units = 0;   // K3's allocator reset handed to the fused level 0 (run_dwt)
+    bool alloc_in_level0 = true;      // GRK_AMD_ALLOC_IN_LEVEL0=0: a launch of its own, as before r06
     int k3_room = 3;                  // pipelined encodes: K3 launches that leave registers for the next frame's level 0 -- bit 0 the top class, bit 1 the rest (GRK_AMD_K3_ROOM)
     // Part-1 decode: blocks of the default style go 64 to a wave (K8L, kernels_t1lanes.hip) unless much longer than the rest
     // (GRK_AMD_T1_LANES=0: every block its own wave, K8 as in r01-r03; 2: lanes wherever they can be used; GRK_AMD_T1_TAIL_RATIO: see run_t1_decode)
@@ -696,6 +698,7 @@ int run_dwt(grk_amd_ctx* c, uint32_t nplanes, void* d_in, void* d_out, const voi
             // nothing to transform, and nothing deeper either
         } else if (l == 0 && d_pixels) {
             a.pixels = d_pixels; a.px_bytes = (g.p.prec + 7) / 8;
+            a.alloc_reset = c->pend_alloc; a.alloc_chunk_units = c->pend_alloc_units; c->pend_alloc = nullptr;
             a.dc = g.p.sgnd ? 0 : (1 << (g.p.prec - 1));
             a.sext = g.p.sgnd ? (1 << (8 * a.px_bytes - 1)) : 0;
             HIP_TRY(c, launch_dwt_level0_fused(a, ntiles, g.p.num_comps, g.p.mct, c->stream), "launch fused dwt level 0");
@@ -1260,6 +1263,7 @@ int create_context(int device_id, int verbose, bool decode_only, grk_amd_ctx** o
         if (const char* es = getenv("GRK_AMD_T1_TAIL_SHARE")) c->t1_tail_share = (float)atof(es);
         if (const char* ey = getenv("GRK_AMD_T1_SYNC")) c->t1_pass_sync = atoi(ey) != 0;
         if (const char* ep = getenv("GRK_AMD_STREAM_PROBE")) c->stream_probe = atoi(ep);
+        if (const char* ea = getenv("GRK_AMD_ALLOC_IN_LEVEL0")) c->alloc_in_level0 = atoi(ea) != 0;
         c->side_priority = least;
         const char* e = getenv("GRK_AMD_OVERLAP");
         c->overlap = e ? atoi(e) != 0 : GRK_AMD_OVERLAP_DEFAULT;
@@ -2140,7 +2144,9 @@ int grk_amd_encode_tiles(grk_amd_ctx* c, const grk_amd_tile_params* p, uint32_t 
             int rc2 = GRK_AMD_OK;
             const HtArgs h = make_ht_args(c, ntiles, c->p1.p, &rc2, h16);
             if (rc2) return rc2;
-            HIP_TRY(c, launch_ht_alloc_init(h, c->stream), "reset arena allocator");
+            // (with the fused level 0 its first workgroup does it: one launch less on the main stream's chain)
+            if (fused && c->alloc_in_level0) { c->pend_alloc = h.alloc; c->pend_alloc_units = h.chunk_units; }
+            else HIP_TRY(c, launch_ht_alloc_init(h, c->stream), "reset arena allocator");
         }
         if (fused) {
             rc = run_dwt(c, nplanes, nullptr, c->p1.p, d_px, ntiles, ov, h16); if (rc) return rc;

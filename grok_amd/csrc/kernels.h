@@ -38,6 +38,9 @@ struct DwtLevelArgs {
     int32_t  sext;        // signed samples: sign bit of the stored word (see IngestArgs), else 0
     uint32_t ncomp;       // components per tile
     uint32_t comp0, zdiv; // set by the launcher: first component of a z slot, z slots per tile
+    // level 0 fused with K1 in a pipelined encode also resets K3's arena allocator (its first workgroup; kernels_ht.hip ht_alloc_reset):
+    // one launch less on the chain that bounds frames of 4096 x 4096 and below
+    unsigned long long* alloc_reset; uint32_t alloc_chunk_units;
     int      h16;         // reversible, 8-bit pixels: every plane (in, ll, mallat) holds int16 instead of int32
     int      xcd;         // XCD-aware workgroup order (kernels_dwt.hip)
     int      pk;          // h16 and every intermediate of this level within 16 bits: arithmetic on packed int16 pairs
@@ -94,6 +97,16 @@ constexpr uint32_t kHtAllocRegions = GRK_HT_ALLOC_REGIONS;           // region w
 constexpr uint32_t kHtAllocChunk = 64u << 10;      // bytes a region takes from the shared cursor at a time (> twice the largest block)
 constexpr uint32_t kHtAllocChunkSmall = 32u << 10; // ... in a job of few blocks (the slack of half-used chunks counts there)
 constexpr size_t   kHtAllocBytes = 256u * (1u + kHtAllocRegions);   // 32 status / cursor / class words, then one 256-byte line per region word
+
+// the allocator's initial state, written by `nthreads` lanes of one workgroup (ht_alloc_init_kernel; the fused level 0 of a pipelined
+// encode): [0] status flags, [1] cursor (bytes), [2 + class] blocks handed to the fallback launch = 0; every region word "chunk full"
+// so that the first allocation refills -- the start field holds a value no real chunk has, otherwise waves waiting for the refill
+// could not tell the first chunk (start 0) from this state
+__device__ __forceinline__ void ht_alloc_reset(unsigned long long* flagbuf, uint32_t chunk_units, uint32_t t, uint32_t nthreads)
+{
+    if (t < 32) flagbuf[t] = 0;
+    for (uint32_t r = t; r < kHtAllocRegions; r += nthreads) flagbuf[32 * (1 + r)] = (0xFFFFFFFFFFull << 24) | chunk_units;
+}
 hipError_t launch_ht_encode(const HtArgs& a, hipStream_t s);          // allocator reset + every class
 hipError_t launch_ht_alloc_init(const HtArgs& a, hipStream_t s);
 hipError_t launch_ht_classes(const HtArgs& a, uint32_t first, uint32_t last, hipStream_t s);   // classes [first, last)

@@ -201,6 +201,7 @@ __global__ __launch_bounds__(kThreads) void dwt_level_kernel(DwtLevelArgs a)
     // it also reads -- run on OTHER XCDs and those lines are fetched once per XCD.  xcd != 0: XCD k (= dispatch id mod 8)
     // takes a contiguous run of the linear (strip fastest) order instead, so that neighbours share an L2.
     uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if constexpr (PX != 0) { if (a.alloc_reset && (bx | by | bz) == 0) ht_alloc_reset(a.alloc_reset, a.alloc_chunk_units, threadIdx.x, blockDim.x); }
     if (a.xcd) {
         const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
         const uint32_t id = bx + gx * (by + gy * bz);
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(NT) void dwt53_pk_kernel(DwtLevelArgs a)
 
     const uint32_t t = threadIdx.x;
     uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if constexpr (PX != 0) { if (a.alloc_reset && (bx | by | bz) == 0) ht_alloc_reset(a.alloc_reset, a.alloc_chunk_units, threadIdx.x, blockDim.x); }
     if (a.xcd) {                                           // XCD k takes a contiguous run of the strip-fastest order (see above)
         const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
         const uint32_t id = bx + gx * (by + gy * bz);
@@ -743,6 +745,7 @@ hipError_t launch_dwt_level0_fused(const DwtLevelArgs& a0, uint32_t ntiles, uint
     auto go = [&](uint32_t comp0, uint32_t zdiv, int nc) {
         DwtLevelArgs a = a0;
         a.comp0 = comp0; a.zdiv = zdiv; a.ncomp = ncomp;
+        if (comp0 != 0) a.alloc_reset = nullptr;             // (the first launch resets the allocator)
         dim3 grid((a.cw + a.px + kOutCols - 1) / kOutCols, (sh + a.seg_pairs - 1) / a.seg_pairs, ntiles * zdiv);
         // (what the kernel calls `even`: every strip of the level takes a FAST path)
         static const bool only_fast_ok = !(getenv("GRK_AMD_DWT_FAST_ONLY") && atoi(getenv("GRK_AMD_DWT_FAST_ONLY")) == 0);   // (=0: A/B runs)

@@ -425,15 +425,10 @@ __device__ __forceinline__ uint32_t quad_swap(uint32_t v)          // value of l
 // a chunk; only a chunk refill (every ~30 blocks) touches the shared cursor.  The arena stays one
 // compact extent [0, *cursor) with at most a block-sized gap at chunk ends.
 // Region word: bits 63..24 = chunk start / 16, bits 23..0 = 16-byte units used in the chunk.
-constexpr uint32_t kAllocRegions = kHtAllocRegions;
 
 __global__ void ht_alloc_init_kernel(unsigned long long* flagbuf, uint32_t chunk_units)
 {
-    const uint32_t t = threadIdx.x;
-    if (t < 32) flagbuf[t] = 0;                                 // [0] status flags, [1] cursor (bytes), [2 + class] blocks handed to the fallback launch
-    // "chunk full" so that the first allocation refills; the start field holds a value no real chunk
-    // has, otherwise waves waiting for the refill could not tell the first chunk (start 0) from this state
-    for (uint32_t r = t; r < kAllocRegions; r += blockDim.x) flagbuf[32 * (1 + r)] = (0xFFFFFFFFFFull << 24) | chunk_units;
+    ht_alloc_reset(flagbuf, chunk_units, threadIdx.x, blockDim.x);
 }
 
 __device__ __forceinline__ unsigned long long arena_alloc(unsigned long long* flagbuf, uint32_t region, uint32_t bytes, uint32_t kChunkUnits)
