@@ -10,6 +10,7 @@ for S in (2048, 4096, 8192):
     d = torch.from_numpy(px.reshape(-1)).cuda()
     ctx = G.Context(0)
     ctx.set_stream(stream.cuda_stream)
+    ctx.set_pixel_hold(os.environ.get("SF_HOLD", "0") == "1")
     ctx.set_pipelining(2)
     for _ in range(30):
         ctx.encode_tiles(p, 1, d.data_ptr(), True, fetch=False)
