@@ -188,6 +188,7 @@ struct grk_amd_ctx {
     // overlapped encode on a given main stream the three are probed pairwise (a grid that stays in dispatch for ~150 us on one, a
     // one-workgroup kernel on the other) and a side stream that has to wait is replaced (GRK_AMD_STREAM_PROBE=0: never)
     int stream_probe = 1; hipStream_t probed_main = nullptr; int side_priority = 0;
+    hipStream_t probed_before[4] = {};   // main streams probed earlier: a host that alternates between a few streams is not probed at every switch
     int probe_replaced = 0;           // side streams replaced by the probe so far (grk_amd_stream_probe_result)
     bool probe_warm = false;          // the probe's kernels have been launched once (their first launch loads their code: not to be measured)
     bool seq_vetted = false;          // (a sequence's internal context) its streams have been vetted against its neighbours' (vet_sequence_streams)
@@ -580,6 +581,9 @@ int probe_streams(grk_amd_ctx* c)
 {
     if (!c->stream_probe || c->probed_main == c->stream || !c->side) return GRK_AMD_OK;
     c->probed_main = c->stream;
+    for (hipStream_t seen : c->probed_before) if (seen == c->stream) return GRK_AMD_OK;
+    for (int i = 3; i > 0; --i) c->probed_before[i] = c->probed_before[i - 1];
+    c->probed_before[0] = c->stream;
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     HIP_TRY(c, hipStreamSynchronize(c->side), "sync");
     if (c->side2) HIP_TRY(c, hipStreamSynchronize(c->side2), "sync");
