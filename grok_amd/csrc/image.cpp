@@ -10,6 +10,7 @@
 // tile-parts are written in tile order (codestream/CodeStreamCompress.cpp:535-603).
 #include "../../include/grok_amd.h"
 #include "geometry.h"
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -46,6 +47,58 @@ extern "C" int64_t grk_amd_encode_image(grk_amd_ctx* ctx, const grk_amd_image_la
         for (; k < geoms.size(); ++k) if (same_geometry(geoms[k], g)) break;
         if (k == geoms.size()) { geoms.push_back(std::move(g)); groups.emplace_back(); }
         groups[k].push_back(t);
+    }
+    // Tier-2 on the device (grk_amd_assemble_device; GRK_AMD_IMAGE_T2=host: the host writer below, which is also where a layout beyond
+    // the device writer's tables goes): every group's finished tile-parts appended in the context's output buffer, then -- their sizes
+    // known -- the main header and each tile-part fetched to its place
+    const char* const et2 = std::getenv("GRK_AMD_IMAGE_T2");
+    if (!(et2 && std::strcmp(et2, "host") == 0)) {
+        std::vector<uint32_t> part_len(ntiles, 0);
+        std::vector<uint64_t> dev_at(ntiles, 0);
+        std::vector<uint8_t> staging;
+        uint64_t used = 0;
+        int64_t rc = GRK_AMD_OK;
+        for (size_t k = 0; k < groups.size() && rc >= 0; ++k) {
+            const auto& G = groups[k];
+            const grk_amd_tile_params& p = tp[G[0]];
+            const size_t tile_bytes = (size_t)p.tile_w * p.tile_h * nc * bps;
+            staging.resize(tile_bytes * G.size());
+            for (size_t i = 0; i < G.size(); ++i) {
+                const grk_amd_tile_params& q = tp[G[i]];
+                const size_t ox = q.tile_x0 - im->x0, oy = q.tile_y0 - im->y0;
+                for (uint32_t c = 0; c < nc; ++c)
+                    for (uint32_t y = 0; y < q.tile_h; ++y)
+                        std::memcpy(&staging[i * tile_bytes + ((size_t)c * q.tile_h + y) * q.tile_w * bps],
+                                    (const uint8_t*)pixels + (((size_t)c * H + oy + y) * W + ox) * bps, (size_t)q.tile_w * bps);
+            }
+            rc = grk_amd_encode_tiles(ctx, &p, (uint32_t)G.size(), staging.data(), 0, nullptr, nullptr);
+            if (rc < 0) return rc;
+            std::vector<uint32_t> lens(G.size());
+            rc = grk_amd_assemble_device(ctx, &p, (uint32_t)G.size(), G.data(), flags, used, lens.data());
+            if (rc < 0) break;
+            for (size_t i = 0; i < G.size(); ++i) { part_len[G[i]] = lens[i]; dev_at[G[i]] = used; used += lens[i]; }
+        }
+        if (rc >= 0) {
+            if ((flags & GRK_AMD_CS_TLM) && ntiles > 255) return GRK_AMD_ERR_UNSUPPORTED;
+            const int64_t hdr = grk_amd_write_main_header_layout(im, base, flags, part_len.data(), out, cap);
+            if (hdr < 0) return hdr;
+            uint64_t at = (uint64_t)hdr;
+            for (uint32_t t = 0; t < ntiles; ++t) at += part_len[t];
+            if (at + 2 > cap) return GRK_AMD_ERR_OVERFLOW;
+            at = (uint64_t)hdr;
+            for (uint32_t t = 0; t < ntiles; ++t) {
+                // (tile-parts that lie one behind the other on the device as in the file go in one piece)
+                uint32_t t1 = t;
+                uint64_t n = part_len[t];
+                while (t1 + 1 < ntiles && dev_at[t1 + 1] == dev_at[t] + n) { n += part_len[t1 + 1]; ++t1; }
+                const int fr = grk_amd_fetch_assembled(ctx, dev_at[t], n, out + at);
+                if (fr) return fr;
+                at += n; t = t1;
+            }
+            out[at++] = 0xFF; out[at++] = 0xD9;
+            return (int64_t)at;
+        }
+        if (rc != GRK_AMD_ERR_UNSUPPORTED) return rc;
     }
     // per tile: its rows and where its group's coded bytes start in `coded`
     std::vector<std::vector<grk_amd_coded_block>> rows(ntiles);

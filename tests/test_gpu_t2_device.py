@@ -160,3 +160,17 @@ def test_asynchronous_form_on_a_stream_of_the_callers_with_pipelined_encodes():
         c.synchronize()
     finally:
         c.close()
+
+
+def test_encode_image_takes_the_device_route_and_the_host_writer_agrees(monkeypatch):
+    """grk_amd_encode_image assembles on the device by default; GRK_AMD_IMAGE_T2=host is the host writer: the same file, for an offset
+    tiling with nine geometry groups, markers and a position-major progression order."""
+    c = U.ctx()
+    W, H, TW, TH, L = 1000, 900, 384, 320, 3
+    px = synth.g2(3, H, W, 8, seed=31)
+    layout = G.ImageLayout.make(W, H, TW, TH, offset=(100, 60))
+    base = G.TileParams.make(1, 1, 3, 8, L, precincts=exps_from_sizes([(64, 64)], L))
+    flags = G.CS_TLM | G.CS_PLT | G.CS_SOP | G.CS_PROG(3)
+    dev = c.encode_image(layout, base, px, flags)
+    monkeypatch.setenv("GRK_AMD_IMAGE_T2", "host")
+    assert c.encode_image(layout, base, px, flags) == dev
