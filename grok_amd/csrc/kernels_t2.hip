@@ -14,7 +14,7 @@
 //   2. Stuffing -- a byte that follows 0xFF carries seven bits -- makes every byte's position depend on the bytes before it:
 //      from a byte start p the next one is p + 8, or p + 15 behind an 0xFF (the 0xFF and the 7-bit byte as one step).  The chain is
 //      cut into chunks of 256 raw bits; a chain enters a chunk at one of 15 offsets, and per (chunk, entry offset) a lane walks
-//      the chunk's <= 32 steps: exit offset + bytes produced.  Sixteen chunks make a super-chunk with a table of the same kind,
+//      the chunk -- from 0xFF candidate to 0xFF candidate of its phase (a mask per chunk and phase) --: exit offset + bytes produced.  Sixteen chunks make a super-chunk with a table of the same kind,
 //      one lane walks the super-chunks, then the chunks of every super-chunk and the steps of every chunk are walked again from
 //      their now known entry, the last walk writing the bytes.  The raw bits pass through LDS in windows of 16 KB.
 // KT1b t2_frame_kernel: one lane per tile -- the tile-part's frame (SOT with Psot, the PLT marker segments with every packet's length as
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
     __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint16_t chunk_tab[kWinChunks * 16];               // [chunk][entry]: exit offset << 12 | bytes
     __shared__ uint32_t sup_tab[kWinSups * 16];                   // [super-chunk][entry]: exit offset << 16 | bytes
+    __shared__ uint32_t ev_mask[kWinChunks * 8];                  // [chunk][phase]: bit k = the byte at chunk bit 8 k + phase is 0xFF (eight ones there)
     __shared__ uint32_t chunk_in[kWinChunks];                     // entry offset << 28 | first output byte (relative to the window's)
     __shared__ uint32_t sup_in[kWinSups + 1];
     __shared__ uint64_t wave_sum[16];
@@ -180,19 +181,45 @@ __global__ __launch_bounds__(1024) void t2_header_kernel(T2HeaderArgs a)
         const uint32_t lim = min(nbits_total - w0 * 32u, kWinBits);          // raw bits of this window
         const uint32_t nch = (lim + kChunkBits - 1) / kChunkBits, nsup = (nch + kSup - 1) / kSup;
         __syncthreads();
+        // Where the 0xFF bytes COULD be: for every raw word the bit positions at which eight ones start (three shift-and steps over
+        // the word and its successor), sorted by phase -- position modulo 8 -- into a 32-bit mask per (chunk, phase).  A chain that
+        // enters a chunk in phase f meets byte starts 8 k + f only, until an 0xFF moves it to phase f - 1: it steps from 0xFF to 0xFF.
+        for (uint32_t i = tid; i < nch * 8u; i += nthr) ev_mask[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < nch * 8u; i += nthr) {                  // word i of the window = word j of chunk c
+            const uint64_t x = ((uint64_t)win[i] << 32) | win[i + 1];
+            uint64_t y = x & (x << 1); y &= y << 2; y &= y << 4;           // bit q: x's bits q .. q - 7 are ones
+            const uint32_t e8 = (uint32_t)(y >> 32);                       // bit 31 - o: eight ones from bit o of the word on
+            if (e8) {
+                const uint32_t c = i >> 3, j = i & 7u;
+#pragma unroll
+                for (uint32_t f = 0; f < 8; ++f) {
+                    const uint32_t v = (e8 >> (7u - f)) & 0x01010101u;     // the word's four byte starts of phase f: bits 24, 16, 8, 0
+                    const uint32_t nib = ((v >> 24) & 1u) | ((v >> 15) & 2u) | ((v >> 6) & 4u) | ((v << 3) & 8u);
+                    if (nib) atomicOr(&ev_mask[c * 8u + f], nib << (4u * j));
+                }
+            }
+        }
+        __syncthreads();
         // per (chunk, entry offset): where the chain leaves the chunk and how many bytes it makes on the way
         for (uint32_t job = tid; job < nch * 16u; job += nthr) {
             const uint32_t c = job >> 4, e = job & 15u;
             if (e == 15u) continue;
-            const uint32_t end = min((c + 1) * kChunkBits, lim);
-            uint32_t p = c * kChunkBits + e, cnt = 0, b0, b1;
-            ChainWalk cw;
-            cw.start(win, p);
-            while (p < end) {
-                const uint32_t adv = cw.step(p, end, b0, b1);
-                p += adv; cnt += 1u + (adv > 8u);
+            const uint32_t limc = min(kChunkBits, lim - c * kChunkBits);       // raw bits of this chunk
+            uint32_t f = e & 7u, k = e >> 3, cnt = 0;
+            for (;;) {
+                const uint32_t ns = limc > f ? (limc - f + 7u) >> 3 : 0u;      // byte starts of phase f inside the chunk
+                if (k >= ns) break;
+                const uint32_t m = ev_mask[c * 8u + f] >> k;
+                if (!m) { cnt += ns - k; k = ns; break; }
+                const uint32_t j = (uint32_t)__builtin_ctz(m);                  // j plain bytes, then the 0xFF and its 7-bit byte: 15 raw bits
+                cnt += j + 2u;
+                k += j + (f ? 2u : 1u);
+                f = (f + 7u) & 7u;
             }
-            chunk_tab[job] = (uint16_t)((min(p - min(p, (c + 1) * kChunkBits), 14u) << 12) | cnt);
+            // (a full chunk is left at bit 8 k + f >= 256: offset 0 .. 14 into the next one; the last chunk's exit is not used)
+            const uint32_t p = 8u * k + f;
+            chunk_tab[job] = (uint16_t)((min(p - min(p, kChunkBits), 14u) << 12) | cnt);
         }
         __syncthreads();
         for (uint32_t job = tid; job < nsup * 16u; job += nthr) {
