@@ -321,7 +321,11 @@ static int64_t node_encode_image(grk_amd_node* nd, const grk_amd_image_layout* i
                 const grk_amd_tile_params& p = tp[mine[0]];
                 const size_t tile_bytes = (size_t)p.tile_w * p.tile_h * nc * bps;
                 const void* enc_px = nullptr;
-                if (pixels_device < 0) {
+                if (pixels_device < 0 && mine.size() == 1 && p.tile_w == W && p.tile_h == H) {
+                    // (the tile IS the image: uploaded from where it lies -- grk_amd_encode_tiles moves pageable memory through pinned chunks
+                    //  with the copies and the DMAs overlapped, pinned memory in one DMA -- instead of being staged whole first)
+                    enc_px = pixels;
+                } else if (pixels_device < 0) {
                     if (!pin_ensure(w.ctx, w.pin_px, w.pin_px_cap, tile_bytes * mine.size())) { rc = GRK_AMD_ERR_NOMEM; break; }
                     // the tiles' rows out of the caller's image into pinned memory; several threads when it is much, each taking
                     // its share of the rows of every tile component (one tile of 8192 x 8192 x 3 is 200 MB for one worker)
