@@ -174,3 +174,17 @@ def test_encode_image_takes_the_device_route_and_the_host_writer_agrees(monkeypa
     dev = c.encode_image(layout, base, px, flags)
     monkeypatch.setenv("GRK_AMD_IMAGE_T2", "host")
     assert c.encode_image(layout, base, px, flags) == dev
+
+
+@pytest.mark.parametrize("C,W,H,prec,L,org,cblk", [
+    (1, 1, 1, 8, 1, (0, 0), (6, 6)),          # one sample: resolutions without a band, packets that are just the "not empty" bit
+    (3, 5, 3, 8, 3, (0, 0), (6, 6)),          # more levels than the tile has rows to halve
+    (4, 130, 70, 8, 2, (3, 1), (5, 4)),       # four components (no MCT for the fourth), 32 x 16 blocks, an odd origin
+    (2, 64, 64, 12, 5, (0, 0), (2, 2)),       # 4 x 4 code-blocks: 256 blocks per band at the top, headers of a few bits each
+    (1, 2048, 8, 8, 1, (0, 0), (6, 2)),       # 64 x 4 blocks
+])
+def test_degenerate_geometries(C, W, H, prec, L, org, cblk):
+    px = synth.g2(C, H, W, prec, seed=W * 7 + H)
+    p = G.TileParams.make(W, H, C, prec, L, origin=org, cblk=cblk)
+    for flags in (0, G.CS_PLT | G.CS_SOP | G.CS_EPH | G.CS_PROG(4)):
+        _check(p, px, [1], flags)
