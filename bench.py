@@ -735,6 +735,32 @@ def node_native(dev, tile, prec, levels, d_px, cpu_file_md5=None):
                 if T == W and cpu_file_md5:
                     import hashlib
                     row["file_equals_cpu_encode"] = bool(row.get("file_equals_cpu_encode", True) and hashlib.md5(cs).hexdigest() == cpu_file_md5)
+                # ... and as a SEQUENCE: three node objects on this GPU, a host thread each (ctypes releases the GIL): one frame's D2H runs
+                # beside the others' encode + Tier-2 -- the route's throughput form (tools/node_two_in_flight.py)
+                if T == W:
+                    try:
+                        import threading
+                        extra = [G.Node(devices) for _ in range(2)]
+                        nodes3 = [node] + extra
+                        pins = [pin] + [pin_ctx.host_array(out_buf.size) for _ in range(2)]
+
+                        def run3(i, n):
+                            for _ in range(n):
+                                nodes3[i].encode_image_device(layout, base, d_px.data_ptr(), d_px.numel(), d, 0, out=pins[i])
+                        for i in range(3):
+                            run3(i, 1)
+                        th3 = [threading.Thread(target=run3, args=(i, 6)) for i in range(3)]
+                        t0 = time.perf_counter()
+                        for t3 in th3:
+                            t3.start()
+                        for t3 in th3:
+                            t3.join()
+                        row["three_nodes_in_flight_pinned_out_ms_per_frame"] = round((time.perf_counter() - t0) / 18 * 1e3, 2)
+                        for n3 in extra:
+                            n3.close()
+                        del pins
+                    except Exception as e:  # noqa: BLE001
+                        row["three_nodes_in_flight_pinned_out_ms_per_frame"] = {"error": str(e)}
                 del pin, pin_ctx
             row["tier2"] = "host plan (GRK_AMD_NODE_T2=host)" if os.environ.get("GRK_AMD_NODE_T2") == "host" else "device (grk_amd_assemble_device)"
             res[name] = row
